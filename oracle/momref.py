@@ -1,0 +1,853 @@
+"""
+oracle/momref.py -- TEST INFRASTRUCTURE ONLY (numpy twin of the CPU oracle).
+
+A CPU restatement, in plain numpy, of the reference's (vSmartMOM.jl) elastic
+Matrix-Operator hot path: streams -> Z moments -> layer optics -> per layer
+{elemental, doubling, interaction} -> Lambertian surface -> post-processing.
+Every function cites the reference file:line it follows (paths relative to the
+reference's root).  Nothing in the product path (radiativetransfer.jl_amd/,
+csrc/) may import this file; only tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py do, and only as the checker.
+
+Pinned against the reference's own known-answer tests (test/test_CoreRT.jl:3-83:
+6SV1 and Natraj tables, committed as data under tests/golden/) by
+tests/test_oracle_reference_tables.py.  Per-op values are NOT pinned by anything in
+the reference (no live Julia here) -- see DESIGN.md "oracle pinning".
+
+Layout used inside this twin: batched matrices are numpy arrays M[n, i, j]
+(spectral index first, then row, column); sources are J[n, i].  `to_abi`/`from_abi`
+convert to the reference's column-major [i, j, n] memory order that the C-ABI uses.
+
+All the reference's index quirks are reproduced when
+`strict_reference_indexing=True` (the default).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# layout helpers
+# --------------------------------------------------------------------------------------
+
+def to_abi(M: np.ndarray) -> np.ndarray:
+    """M[n,i,j] -> flat buffer in Julia column-major [i,j,n] order (i fastest)."""
+    if M.ndim == 3:
+        return np.ascontiguousarray(np.transpose(M, (0, 2, 1))).reshape(-1)
+    if M.ndim == 2:  # J[n,i] -> [i,1,n]
+        return np.ascontiguousarray(M).reshape(-1)
+    raise ValueError("bad rank")
+
+
+def from_abi(buf: np.ndarray, N: int, S: int, vec: bool = False) -> np.ndarray:
+    buf = np.asarray(buf)
+    if vec:
+        return buf.reshape(S, N).copy()
+    return np.transpose(buf.reshape(S, N, N), (0, 2, 1)).copy()
+
+
+# --------------------------------------------------------------------------------------
+# polarization types  (src/Scattering/types.jl:82-123)
+# --------------------------------------------------------------------------------------
+
+@dataclass
+class PolType:
+    n: int
+    D: np.ndarray
+    I0: np.ndarray
+
+
+def Stokes_I():
+    return PolType(1, np.array([1.0]), np.array([1.0]))
+
+
+def Stokes_IQU():
+    return PolType(3, np.array([1.0, 1.0, -1.0]), np.array([1.0, 0.0, 0.0]))
+
+
+def Stokes_IQUV():
+    return PolType(4, np.array([1.0, 1.0, -1.0, -1.0]), np.array([1.0, 0.0, 0.0, 0.0]))
+
+
+def pol_from_n(n: int) -> PolType:
+    return {1: Stokes_I, 3: Stokes_IQU, 4: Stokes_IQUV}[n]()
+
+
+# --------------------------------------------------------------------------------------
+# quadrature (third-party FastGaussQuadrature.jl is not vendored in the reference; the
+# published Gauss-Legendre / Gauss-Radau rules are restated via scipy's Jacobi roots)
+# --------------------------------------------------------------------------------------
+
+def gausslegendre(n: int):
+    x, w = np.polynomial.legendre.leggauss(n)
+    return x, w
+
+
+def gaussradau(n: int):
+    """n-point Gauss-Radau rule on [-1,1] with the fixed node at x=-1 (first node),
+    as FastGaussQuadrature.gaussradau returns it (call site rt_set_streams.jl:115)."""
+    from scipy.special import roots_jacobi
+
+    if n == 1:
+        return np.array([-1.0]), np.array([2.0])
+    xi, vi = roots_jacobi(n - 1, 0.0, 1.0)  # weight (1+x)
+    x = np.concatenate([[-1.0], xi])
+    w = np.concatenate([[2.0 / n ** 2], vi / (1.0 + xi)])
+    return x, w
+
+
+def _unique_keep_order(a: Sequence[float]) -> np.ndarray:
+    """Julia `unique`: first occurrences, original order (exact float comparison)."""
+    seen = set()
+    out = []
+    for v in a:
+        fv = float(v)
+        if fv not in seen:
+            seen.add(fv)
+            out.append(fv)
+    return np.array(out, dtype=np.float64)
+
+
+def cosd(x):
+    """Julia cosd: exact at multiples of 90 deg; otherwise cos(deg2rad(x))."""
+    x = np.asarray(x, dtype=np.float64)
+    out = np.cos(np.deg2rad(x))
+    xm = np.mod(np.abs(x), 360.0)
+    out = np.where((xm == 90.0) | (xm == 270.0), 0.0, out)
+    out = np.where(xm == 0.0, 1.0, out)
+    out = np.where(xm == 180.0, -1.0, out)
+    return out
+
+
+def sind(x):
+    x = np.asarray(x, dtype=np.float64)
+    out = np.sin(np.deg2rad(x))
+    xm = np.mod(x, 360.0)
+    out = np.where((xm == 0.0) | (xm == 180.0), 0.0, out)
+    out = np.where(xm == 90.0, 1.0, out)
+    out = np.where(xm == 270.0, -1.0, out)
+    return out
+
+
+def nearest_point(arr, f) -> int:
+    """rt_helper_functions.jl:60 -- 0-based index of first minimum of |arr-f|."""
+    return int(np.argmin(np.abs(np.asarray(arr) - f)))
+
+
+@dataclass
+class QuadPoints:
+    """types.jl:456-473.  imu0 / imu0Nstart are 1-BASED as in the reference."""
+    mu0: float
+    imu0: int
+    imu0Nstart: int
+    qp_mu: np.ndarray
+    wt_mu: np.ndarray
+    qp_muN: np.ndarray
+    wt_muN: np.ndarray
+    Nquad: int
+
+
+def _finish_streams(qp_mu, wt_mu, mu0, n):
+    imu0 = nearest_point(qp_mu, mu0) + 1
+    qp_muN = np.repeat(qp_mu, n)
+    wt_muN = np.repeat(wt_mu, n)
+    i_start = n * (imu0 - 1) + 1
+    return QuadPoints(float(mu0), imu0, i_start, qp_mu, wt_mu, qp_muN, wt_muN, len(qp_mu))
+
+
+def rt_set_streams(quadtype: str, Ltrunc: int, sza: float, vza: Sequence[float], nStokes: int) -> QuadPoints:
+    """rt_set_streams.jl:24-50 (GaussQuadHemisphere), :63-87 (GaussQuadFullSphere),
+    :101-170 (RadauQuad)."""
+    vza = np.asarray(vza, dtype=np.float64)
+    Nquad = (Ltrunc + 1) // 2
+    mu0 = float(cosd(sza))
+    if quadtype == "GaussQuadHemisphere":
+        xi, w = gausslegendre(Nquad)  # gauleg(Nquad,0,1): mie_helper_functions.jl:177-182
+        qp = 0.5 * xi + 0.5
+        wt = w * 0.5
+        qp_mu = _unique_keep_order(list(qp) + list(cosd(vza)) + [mu0])
+        wt_mu = np.concatenate([wt, np.zeros(len(qp_mu) - len(wt))])
+        return _finish_streams(qp_mu, wt_mu, mu0, nStokes)
+    if quadtype == "GaussQuadFullSphere":
+        xi, w = gausslegendre(2 * Nquad)
+        qp_mu = _unique_keep_order(list(xi[Nquad:]) + list(cosd(vza)) + [mu0])
+        wt_mu = np.concatenate([w[Nquad:], np.zeros(len(qp_mu) - Nquad)])
+        return _finish_streams(qp_mu, wt_mu, mu0, nStokes)
+    if quadtype == "RadauQuad":
+        tq, tw = gaussradau(Nquad)
+        q0 = -tq[::-1]
+        w0 = tw[::-1]
+        if mu0 in q0:
+            qp = (1.0 + q0) / 2.0
+            wt = w0.copy()
+        else:
+            qp = np.zeros(2 * Nquad)
+            wt = np.zeros(2 * Nquad)
+            for i in range(Nquad):
+                qp[i] = (mu0 + mu0 * q0[i]) / 2
+                wt[i] = mu0 * w0[i] / 2
+                qp[Nquad + i] = ((1 + mu0) + (1 - mu0) * q0[i]) / 2
+                wt[Nquad + i] = (1 - mu0) * w0[i] / 2
+        qp_mu = _unique_keep_order(list(qp) + list(cosd(vza)))
+        wt_mu = np.concatenate([wt, np.zeros(len(qp_mu) - len(wt))])
+        return _finish_streams(qp_mu, wt_mu, mu0, nStokes)
+    raise ValueError(quadtype)
+
+
+# --------------------------------------------------------------------------------------
+# Greek coefficients, generalized spherical functions, Z moments
+# --------------------------------------------------------------------------------------
+
+@dataclass
+class GreekCoefs:
+    """src/Scattering/types.jl:198-211"""
+    alpha: np.ndarray
+    beta: np.ndarray
+    gamma: np.ndarray
+    delta: np.ndarray
+    epsilon: np.ndarray
+    zeta: np.ndarray
+
+
+def get_greek_rayleigh(depol: float) -> GreekCoefs:
+    """mie_helper_functions.jl:237-251"""
+    dpl_p = (1 - depol) / (1 + depol / 2)
+    dpl_r = (1 - 2 * depol) / (1 - depol)
+    a = np.array([0.0, 0.0, 3 * dpl_p])
+    b = np.array([1.0, 0.0, 0.5 * dpl_p])
+    g = np.array([0.0, 0.0, dpl_p * math.sqrt(1.5)])
+    d = np.array([0.0, dpl_p * dpl_r * 1.5, 0.0])
+    e = np.zeros(3)
+    z = np.zeros(3)
+    return GreekCoefs(a, b, g, d, e, z)
+
+
+def compute_associated_legendre_PRT(mu: np.ndarray, Lmax: int):
+    """legendre_functions.jl:17-178.  Returns P,R,T of shape [len(mu),Lmax,Lmax]
+    (index [imu, l, m], 0-based l and m), T already sign-flipped as the reference
+    returns `-T`."""
+    mu = np.asarray(mu, dtype=np.float64)
+    n = len(mu)
+    P = np.zeros((n, Lmax, Lmax))
+    R = np.zeros((n, Lmax, Lmax))
+    T = np.zeros((n, Lmax, Lmax))
+    smu = np.sqrt(1.0 - mu ** 2)
+    cmu = mu
+    for m in range(Lmax):
+        for l in range(m, Lmax):
+            if m == 0:
+                if l == 0:
+                    P[:, l, m] = 1
+                elif l == 1:
+                    P[:, l, m] = cmu
+                elif l == 2:
+                    P[:, l, m] = 0.5 * (3.0 * cmu * cmu - 1.0)
+                    R[:, l, m] = 0.5 * math.sqrt(1.5) * smu * smu
+                else:
+                    P[:, l, m] = (P[:, l - 1, m] * (2 * l - 1) * cmu - P[:, l - 2, m] * (l - 1)) / l
+                    Y = math.sqrt((l + 1) * (l - 3))
+                    X = math.sqrt(l * l - 4)
+                    R[:, l, m] = (R[:, l - 1, m] * (2 * l - 1) * cmu - R[:, l - 2, m] * Y) / X
+            elif m == 1:
+                if l == 1:
+                    P[:, l, m] = math.sqrt(0.5) * smu
+                elif l == 2:
+                    m1 = math.sqrt(1 / 6)
+                    cA = 3 * cmu * smu
+                    cB = math.sqrt(1.5) * smu
+                    P[:, l, m] = m1 * cA
+                    R[:, l, m] = -m1 * cmu * cB
+                    T[:, l, m] = m1 * cB
+                else:
+                    m1 = math.sqrt((l - 1) / (l + 1))
+                    m2 = m1 * math.sqrt((l - 2) / l)
+                    Y = l - 1 + m
+                    X = l - m
+                    P[:, l, m] = (m1 * P[:, l - 1, m] * (2 * l - 1) * cmu - m2 * P[:, l - 2, m] * Y) / X
+                    Z = (2 * m * (2 * l - 1)) / (l * (l - 1))
+                    Y = ((l + m - 1) / (l - 1)) * math.sqrt((l - 3) * (l + 1))
+                    X = ((l - m) / l) * math.sqrt(l * l - 4)
+                    R[:, l, m] = (m1 * R[:, l - 1, m] * (2 * l - 1) * cmu - m2 * R[:, l - 2, m] * Y
+                                  + m1 * T[:, l - 1, m] * Z) / X
+                    T[:, l, m] = (m1 * T[:, l - 1, m] * (2 * l - 1) * cmu - m2 * T[:, l - 2, m] * Y
+                                  + m1 * R[:, l - 1, m] * Z) / X
+            else:
+                if l == m:
+                    fact1 = np.ones(n)
+                    fact2 = np.ones(n)
+                    sfull = smu
+                    shalf = sfull / 2
+                    for i in range(1, m + 1):
+                        fact1 = fact1 * ((2 * i - 1) * sfull) / math.sqrt(i * (i + m))
+                        if i > 2:
+                            fact2 = fact2 * shalf * math.sqrt((m + i) / (i - 2))
+                        else:
+                            fact2 = fact2 * shalf
+                    big = smu > 1e-8
+                    safe = np.where(big, smu, 1.0)
+                    Aii = np.where(big, fact2 * (1.0 + cmu * cmu) / (safe * safe), 0.5 if m == 2 else 0.0)
+                    Aij = np.where(big, fact2 * (2 * cmu) / (safe * safe), 0.5 if m == 2 else 0.0)
+                    P[:, l, m] = fact1
+                    R[:, l, m] = Aii
+                    T[:, l, m] = -Aij
+                elif l == m + 1:
+                    m1 = math.sqrt(1 / (l + m))
+                    X = l - m
+                    P[:, l, m] = (m1 * P[:, l - 1, m] * (2 * l - 1) * cmu) / X
+                    Z = (2 * m * (2 * l - 1)) / (l * (l - 1))
+                    X = ((l - m) / l) * math.sqrt(l * l - 4)
+                    R[:, l, m] = (m1 * R[:, l - 1, m] * (2 * l - 1) * cmu + m1 * T[:, l - 1, m] * Z) / X
+                    T[:, l, m] = (m1 * T[:, l - 1, m] * (2 * l - 1) * cmu + m1 * R[:, l - 1, m] * Z) / X
+                else:
+                    m1 = math.sqrt((l - m) / (l + m))
+                    m2 = m1 * math.sqrt((l - m - 1) / (l + m - 1))
+                    Y = l - 1 + m
+                    X = l - m
+                    P[:, l, m] = (m1 * P[:, l - 1, m] * (2 * l - 1) * cmu - m2 * P[:, l - 2, m] * Y) / X
+                    Z = (2 * m * (2 * l - 1)) / (l * (l - 1))
+                    Y = ((l + m - 1) / (l - 1)) * math.sqrt((l - 3) * (l + 1))
+                    X = ((l - m) / l) * math.sqrt(l * l - 4)
+                    R[:, l, m] = (m1 * R[:, l - 1, m] * (2 * l - 1) * cmu - m2 * R[:, l - 2, m] * Y
+                                  + m1 * T[:, l - 1, m] * Z) / X
+                    T[:, l, m] = (m1 * T[:, l - 1, m] * (2 * l - 1) * cmu - m2 * T[:, l - 2, m] * Y
+                                  + m1 * R[:, l - 1, m] * Z) / X
+    return P, R, -T
+
+
+def _Pi_matrices(n: int, P, R, T, l: int, m: int) -> np.ndarray:
+    """construct_Π_matrix, mie_helper_functions.jl:287-323 (sign_change=false branch);
+    l, m are 0-based array indices here.  Returns [nmu, n, n]."""
+    nmu = P.shape[0]
+    Pi = np.zeros((nmu, n, n))
+    Pi[:, 0, 0] = P[:, l, m]
+    if n >= 3:
+        Pi[:, 1, 1] = R[:, l, m]
+        Pi[:, 1, 2] = -T[:, l, m]
+        Pi[:, 2, 1] = -T[:, l, m]
+        Pi[:, 2, 2] = R[:, l, m]
+    if n == 4:
+        Pi[:, 3, 3] = P[:, l, m]
+    return Pi
+
+
+def _B_matrix(n: int, g: GreekCoefs, l: int) -> np.ndarray:
+    """construct_B_matrix, mie_helper_functions.jl:334-348 (l 0-based index)."""
+    if n == 1:
+        return np.array([[g.beta[l]]])
+    if n == 3:
+        return np.array([[g.beta[l], g.gamma[l], 0], [g.gamma[l], g.alpha[l], 0], [0, 0, g.zeta[l]]])
+    return np.array([[g.beta[l], g.gamma[l], 0, 0], [g.gamma[l], g.alpha[l], 0, 0],
+                     [0, 0, g.zeta[l], g.epsilon[l]], [0, 0, -g.epsilon[l], g.delta[l]]])
+
+
+def compute_Z_moments(nStokes: int, mu: np.ndarray, greek: GreekCoefs, m: int):
+    """Scattering/compute_Z_matrices.jl:5-84.  Returns Z++ and Z-+ as [N,N] (row i, col j)."""
+    mu = np.asarray(mu, dtype=np.float64)
+    assert np.all((0 < mu) & (mu <= 1)), "all mu within compute_Z_moments have to be in ]0,1]"
+    n = len(mu)
+    fact = 0.5 if m == 0 else 1.0
+    l_max = len(greek.beta)
+    P, R, T = compute_associated_legendre_PRT(mu, l_max)
+    Pm, Rm, Tm = compute_associated_legendre_PRT(-mu, l_max)
+    B = nStokes
+    App = np.zeros((B, B, n, n))
+    Amp = np.zeros((B, B, n, n))
+    for l in range(m, l_max):  # reference: l = m+1 : l_max in 1-based
+        Bl = _B_matrix(B, greek, l)
+        Pi = _Pi_matrices(B, P, R, T, l, m)
+        Pim = _Pi_matrices(B, Pm, Rm, Tm, l, m)
+        left = np.einsum("iab,bc->iac", Pi, Bl)  # Pi[i]*B
+        App += np.einsum("iac,jcd->adij", left, Pi)
+        Amp += np.einsum("iac,jcd->adij", left, Pim)
+    N = B * n
+    Zpp = np.zeros((N, N))
+    Zmp = np.zeros((N, N))
+    for i in range(B):
+        for j in range(B):
+            sgn = 1.0
+            if (i <= 1 and j >= 2) or (i >= 2 and j <= 1):
+                sgn = -1.0
+            Zpp[i::B, j::B] = 2 * fact * App[i, j]
+            Zmp[i::B, j::B] = sgn * 2 * fact * Amp[i, j]
+    return Zpp, Zmp
+
+
+# --------------------------------------------------------------------------------------
+# layer optics  (LayerOpticalProperties/compEffectiveLayerProperties.jl, types.jl:632-678)
+# --------------------------------------------------------------------------------------
+
+@dataclass
+class AerosolOptics:
+    greek: GreekCoefs
+    omega: float  # ω̃
+    ft: float = 0.0  # fᵗ
+
+
+@dataclass
+class Scene:
+    """Inputs of the hot path = outputs of the reference's model_from_parameters()
+    (model_from_parameters.jl:12-194) restricted to one concatenated band."""
+    pol: PolType
+    quad: QuadPoints
+    max_m: int
+    tau_rayl: np.ndarray  # [S, Nz]
+    tau_abs: np.ndarray  # [S, Nz]
+    greek_rayleigh: GreekCoefs
+    tau_aer: np.ndarray = field(default_factory=lambda: np.zeros((0, 0)))  # [nAer, Nz]
+    aerosols: List[AerosolOptics] = field(default_factory=list)
+    varpi_cabannes: float = 1.0
+    albedo: float = 0.0
+    vza: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    vaz: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    strict_reference_indexing: bool = True
+
+    @property
+    def S(self):
+        return self.tau_rayl.shape[0]
+
+    @property
+    def Nz(self):
+        return self.tau_rayl.shape[1]
+
+    @property
+    def N(self):
+        return len(self.quad.qp_muN)
+
+
+@dataclass
+class LayerOptics:
+    """CoreScatteringOpticalProperties (types.jl:605-614) for one layer: tau[S], varpi[S],
+    Z as basis [K,N,N] + weights [K,S] (the reference stores the mixed N x N x S array;
+    `Zfull()` rebuilds it with the same chained arithmetic as types.jl:632-661)."""
+    tau: np.ndarray
+    varpi: np.ndarray
+    Zpp_basis: np.ndarray
+    Zmp_basis: np.ndarray
+    zweights: np.ndarray  # [K,S]
+
+    def Zfull(self):
+        Zpp = np.einsum("ks,kij->sij", self.zweights, self.Zpp_basis)
+        Zmp = np.einsum("ks,kij->sij", self.zweights, self.Zmp_basis)
+        return Zpp, Zmp
+
+
+def construct_core_optical_properties(scene: Scene, m: int) -> List[LayerOptics]:
+    """constructCoreOpticalProperties (compEffectiveLayerProperties.jl:1-78) with the
+    `+` algebra of types.jl:632-678 and createAero (:80-85).
+
+    The reference materialises Z[:,:,n] = wx[n]*Zx + wy[n]*Zy per pair, chained over
+    aerosols; here the chain is carried on the K weights (w_k[n]) instead -- identical
+    up to re-association of two multiplications (<= 1 ulp per term)."""
+    S, Nz = scene.tau_rayl.shape
+    nS = scene.pol.n
+    mu = scene.quad.qp_mu
+    Zr_pp, Zr_mp = compute_Z_moments(nS, mu, scene.greek_rayleigh, m)
+    Zb_pp = [Zr_pp]
+    Zb_mp = [Zr_mp]
+    for a in scene.aerosols:
+        zp, zm = compute_Z_moments(nS, mu, a.greek, m)
+        Zb_pp.append(zp)
+        Zb_mp.append(zm)
+    Zb_pp = np.array(Zb_pp)
+    Zb_mp = np.array(Zb_mp)
+    K = len(Zb_pp)
+    out = []
+    for iz in range(Nz):
+        tau = scene.tau_rayl[:, iz].astype(np.float64).copy()
+        varpi = np.full(S, scene.varpi_cabannes, dtype=np.float64)
+        wts = np.zeros((K, S))
+        wts[0] = 1.0
+        only = 0  # index of the single basis in use while Z is still unmixed
+        mixed = False
+        for ia, a in enumerate(scene.aerosols):
+            tau_y = (1 - a.ft * a.omega) * scene.tau_aer[ia, iz]
+            varpi_y = (1 - a.ft) * a.omega / (1 - a.ft * a.omega)
+            tau_new = tau + tau_y
+            wx = tau * varpi
+            wy = np.full(S, tau_y * varpi_y)
+            w = wx + wy
+            varpi_new = w / tau_new
+            if np.all(wx == 0.0):  # types.jl:650
+                wts[:] = 0.0
+                wts[ia + 1] = 1.0
+            elif np.all(wy == 0.0):  # types.jl:651
+                pass
+            else:
+                fx = wx / w
+                fy = wy / w
+                wts *= fx[None, :]
+                wts[ia + 1] = fy
+            tau, varpi = tau_new, varpi_new
+        # + CoreAbsorptionOpticalProperties (types.jl:672-678)
+        tau_new = tau + scene.tau_abs[:, iz]
+        wx = tau * varpi
+        varpi = wx / tau_new
+        tau = tau_new
+        out.append(LayerOptics(tau, varpi, Zb_pp, Zb_mp, wts))
+    return out
+
+
+def get_scattering_interface(prev: Optional[int], scatter: bool, iz: int) -> int:
+    """rt_helper_functions.jl:8-27.  Codes: 0='00', 1='01', 2='10', 3='11'. iz 1-based."""
+    if iz == 1:
+        return 3 if scatter else 0
+    if prev == 0:
+        return 0 if not scatter else 1
+    return 2 if not scatter else 3
+
+
+def extract_effective_props(layers: List[LayerOptics]):
+    """extractEffectiveProps, compEffectiveLayerProperties.jl:88-111."""
+    S = len(layers[0].tau)
+    Nz = len(layers)
+    tau_sum = np.zeros((S, Nz + 1))
+    ifaces = []
+    iface = 0  # ScatteringInterface_00()
+    eps = np.finfo(np.float64).eps
+    for iz in range(Nz):
+        scatter = bool(np.max(layers[iz].tau * layers[iz].varpi) > 2 * eps)
+        iface = get_scattering_interface(iface, scatter, iz + 1)
+        ifaces.append(iface)
+        tau_sum[:, iz + 1] = tau_sum[:, iz] + 1.0 * layers[iz].tau
+    return ifaces, tau_sum
+
+
+def doubling_number(dtau_max: float, tau_end: float):
+    """rt_helper_functions.jl:31-57"""
+    if tau_end <= dtau_max:
+        return tau_end, 0
+    q1 = math.log10(2.0)
+    q2 = math.log10(dtau_max)
+    q3 = math.log10(tau_end)
+    tlimit = (q3 - q2) / q1
+    nlimit = math.floor(tlimit)
+    diff = tlimit - nlimit
+    if diff < np.finfo(np.float64).eps:
+        return dtau_max, int(nlimit)
+    nd = int(nlimit) + 1
+    return 10.0 ** (q3 - q1 * nd), nd
+
+
+def get_dtau_ndoubl(tau: np.ndarray, varpi: np.ndarray, qp_mu: np.ndarray):
+    """rt_kernel.jl:238-246 -- maxima over the WHOLE spectral axis."""
+    mx = float(np.max(tau * varpi))
+    dtau_max = min(mx, 0.001 * float(np.min(qp_mu)))
+    _, nd = doubling_number(dtau_max, mx)
+    dtau = tau / 2 ** nd
+    return dtau, nd
+
+
+# --------------------------------------------------------------------------------------
+# added / composite layers
+# --------------------------------------------------------------------------------------
+
+@dataclass
+class AddedLayer:
+    """types.jl:123-142"""
+    r_pm: np.ndarray  # r⁺⁻
+    r_mp: np.ndarray  # r⁻⁺
+    t_mm: np.ndarray  # t⁻⁻
+    t_pp: np.ndarray  # t⁺⁺
+    j0p: np.ndarray
+    j0m: np.ndarray
+
+
+@dataclass
+class CompositeLayer:
+    """types.jl:105-121"""
+    R_mp: np.ndarray
+    R_pm: np.ndarray
+    T_pp: np.ndarray
+    T_mm: np.ndarray
+    J0p: np.ndarray
+    J0m: np.ndarray
+
+
+def make_added_layer(N, S):
+    z = lambda: np.zeros((S, N, N))
+    return AddedLayer(z(), z(), z(), z(), np.zeros((S, N)), np.zeros((S, N)))
+
+
+def make_composite_layer(N, S):
+    z = lambda: np.zeros((S, N, N))
+    return CompositeLayer(z(), z(), z(), z(), np.zeros((S, N)), np.zeros((S, N)))
+
+
+def stokes_comp(idx0: np.ndarray, n: int, strict: bool) -> np.ndarray:
+    """Stokes-component label used by the D-sign kernels.  strict (reference, Q1):
+    mod(i_1based, n) -> 1,2,..,n-1,0.  non-strict: 1..n."""
+    if strict:
+        return np.mod(idx0 + 1, n)
+    return np.mod(idx0, n) + 1
+
+
+def elemental(pol: PolType, quad: QuadPoints, tau_sum: np.ndarray, dtau: np.ndarray, varpi: np.ndarray,
+              Zpp: np.ndarray, Zmp: np.ndarray, m: int, nd: int, added: AddedLayer, strict: bool = True):
+    """elemental! (elemental.jl:109-162) with kernels get_elem_rt! (:164-207),
+    get_elem_rt_SFI! (:209-253), apply_D_elemental! (:255-274).
+    Zpp/Zmp: [N,N] or [S,N,N].  Writes into `added` in place."""
+    mu = quad.qp_muN
+    N = len(mu)
+    S = len(dtau)
+    wct02 = 0.5 if m == 0 else 0.25
+    wct = quad.wt_muN / 2 if m == 0 else quad.wt_muN / 4
+    if Zpp.ndim == 2:
+        Zpp = Zpp[None]
+        Zmp = Zmp[None]
+    mui = mu[:, None]
+    muj = mu[None, :]
+    d = dtau[:, None, None]
+    w3 = varpi[:, None, None]
+    wj = wct[None, None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = w3 * Zmp * (muj / (mui + muj))[None] * wj * (1 - np.exp(-d * ((1 / mui) + (1 / muj))[None]))
+        ei = np.exp(-d / mui[None])
+        ej = np.exp(-d / muj[None])
+        t_off = w3 * Zpp * (muj / (mui - muj))[None] * wj * (ei - ej)
+    eye = np.eye(N, dtype=bool)
+    # diagonal formula uses wct[i] and Z[i,i]
+    t_diag = ei * (1 + w3 * Zpp * (d / mui[None]) * wct[None, :, None])
+    same_mu = (mui == muj)
+    t = np.where(same_mu[None], np.where(eye[None], t_diag, 0.0), t_off)
+    zero_w = ~(wct > 1e-8)  # columns with zero weight (Q4)
+    r = np.where(zero_w[None, None, :], 0.0, r)
+    t = np.where(zero_w[None, None, :], np.where(eye[None], ei * np.ones((1, N, N)), 0.0), t)
+    added.r_mp[:] = r
+    added.t_pp[:] = t
+
+    # SFI
+    n = pol.n
+    i_start = n * (quad.imu0 - 1)  # 0-based
+    i_end = n * quad.imu0  # exclusive
+    I0 = pol.I0
+    Zpp_I0 = np.einsum("sik,k->si", Zpp[:, :, i_start:i_end], I0)
+    Zmp_I0 = np.einsum("sik,k->si", Zmp[:, :, i_start:i_end], I0)
+    Zpp_I0 = np.broadcast_to(Zpp_I0, (S, N))
+    Zmp_I0 = np.broadcast_to(Zmp_I0, (S, N))
+    mu_s = mu[i_start]
+    d2 = dtau[:, None]
+    w2 = varpi[:, None]
+    idx = np.arange(N)
+    insun = (idx >= i_start) & (idx < i_end)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        jp_in = wct02 * w2 * Zpp_I0 * (d2 / mu[None]) * np.exp(-d2 / mu[None])
+        jp_out = wct02 * w2 * Zpp_I0 * (mu_s / (mu - mu_s))[None] * (np.exp(-d2 / mu[None]) - np.exp(-d2 / mu_s))
+        jp = np.where(insun[None], jp_in, jp_out)
+        jm = wct02 * w2 * Zmp_I0 * (mu_s / (mu + mu_s))[None] * (1 - np.exp(-d2 * ((1 / mu) + (1 / mu_s))[None]))
+    att = np.exp(-tau_sum / mu_s)[:, None]
+    jp = jp * att
+    jm = jm * att
+    if nd >= 1:
+        Dfull = np.tile(pol.D, N // n)
+        jm = Dfull[None] * jm
+    added.j0p[:] = jp
+    added.j0m[:] = jm
+
+    # apply_D_elemental!
+    comp = stokes_comp(idx, n, strict)
+    if nd < 1:
+        ii = comp[:, None]
+        jj = comp[None, :]
+        same = ((ii <= 2) & (jj <= 2)) | ((ii > 2) & (jj > 2))
+        sgn = np.where(same, 1.0, -1.0)[None]
+        added.r_pm[:] = sgn * added.r_mp
+        added.t_mm[:] = sgn * added.t_pp
+    else:
+        neg = comp > 2
+        added.r_mp[:, neg, :] = -added.r_mp[:, neg, :]
+    # apply_D_matrix_elemental_SFI! is a no-op for every nd (Q3, elemental.jl:296-307)
+
+
+def batch_inv(A: np.ndarray) -> np.ndarray:
+    """batch_inv! CPU method (gpu_batched.jl:78-82): A[:,:,i]\\I via LU, partial pivoting."""
+    return np.linalg.inv(A)
+
+
+def doubling(pol: PolType, expk: np.ndarray, nd: int, added: AddedLayer, strict: bool = True,
+             snapshots: Optional[list] = None):
+    """doubling_helper! (doubling.jl:13-79) + apply_D! (:93-110) + apply_D_SFI! (:112-118).
+    expk is updated in place like the reference's `expk .= expk.^2`."""
+    if nd == 0:
+        return
+    r = added.r_mp
+    t = added.t_pp
+    jp = added.j0p
+    jm = added.j0m
+    N = r.shape[1]
+    I = np.eye(N)[None]
+    for _ in range(nd):
+        gp = batch_inv(I - r @ r)
+        ttgp = t @ gp
+        j1p = jp * expk[:, None]
+        j1m = jm * expk[:, None]
+        jm_new = jm + np.einsum("sij,sj->si", ttgp, j1m + np.einsum("sij,sj->si", r, jp))
+        jp_new = j1p + np.einsum("sij,sj->si", ttgp, jp + np.einsum("sij,sj->si", r, j1m))
+        jm[:] = jm_new
+        jp[:] = jp_new
+        expk[:] = expk ** 2
+        r_new = r + (ttgp @ r) @ t
+        t_new = ttgp @ t
+        r[:] = r_new
+        t[:] = t_new
+        if snapshots is not None:
+            snapshots.append((r.copy(), t.copy(), jp.copy(), jm.copy()))
+    n = pol.n
+    if n == 1:
+        added.r_pm[:] = r
+        added.t_mm[:] = t
+        return
+    comp = stokes_comp(np.arange(N), n, strict)
+    neg = comp > 2
+    r[:, neg, :] = -r[:, neg, :]
+    ii = comp[:, None]
+    jj = comp[None, :]
+    same = ((ii <= 2) & (jj <= 2)) | ((ii > 2) & (jj > 2))
+    sgn = np.where(same, 1.0, -1.0)[None]
+    added.r_pm[:] = sgn * r
+    added.t_mm[:] = sgn * t
+    jm[:, neg] = -jm[:, neg]
+
+
+def _mv(A, x):
+    return np.einsum("sij,sj->si", A, x)
+
+
+def interaction(iface: int, comp: CompositeLayer, added: AddedLayer):
+    """interaction_helper! for the four interfaces (interaction.jl:8-22, 27-43, 49-64,
+    69-117), dispatcher interaction_inelastic.jl:474-484.  iface: 0='00',1='01',2='10',3='11'."""
+    r_pm, r_mp, t_mm, t_pp, j0p, j0m = added.r_pm, added.r_mp, added.t_mm, added.t_pp, added.j0p, added.j0m
+    c = comp
+    if iface == 0:
+        J0p = j0p + _mv(t_pp, c.J0p)
+        J0m = c.J0m + _mv(c.T_mm, j0m)
+        c.J0p[:] = J0p
+        c.J0m[:] = J0m
+        c.T_mm[:] = t_mm @ c.T_mm
+        c.T_pp[:] = t_pp @ c.T_pp
+    elif iface == 1:
+        J0m = c.J0m + _mv(c.T_mm, _mv(r_mp, c.J0p) + j0m)
+        c.J0m[:] = J0m
+        c.J0p[:] = j0p + _mv(t_pp, c.J0p)
+        c.R_mp[:] = (c.T_mm @ r_mp) @ c.T_pp
+        c.R_pm[:] = r_pm
+        c.T_pp[:] = t_pp @ c.T_pp
+        c.T_mm[:] = c.T_mm @ t_mm
+    elif iface == 2:
+        c.J0p[:] = j0p + _mv(t_pp, c.J0p + _mv(c.R_pm, j0m))
+        c.J0m[:] = c.J0m + _mv(c.T_mm, j0m)
+        c.T_pp[:] = t_pp @ c.T_pp
+        c.T_mm[:] = c.T_mm @ t_mm
+        c.R_pm[:] = (t_pp @ c.R_pm) @ t_mm
+    elif iface == 3:
+        N = r_mp.shape[1]
+        I = np.eye(N)[None]
+        tmp_inv = batch_inv(I - r_mp @ c.R_pm)
+        T01_inv = c.T_mm @ tmp_inv
+        c.J0m[:] = c.J0m + _mv(T01_inv, _mv(r_mp, c.J0p) + j0m)
+        c.R_mp[:] = c.R_mp + (T01_inv @ r_mp) @ c.T_pp
+        c.T_mm[:] = T01_inv @ t_mm
+        tmp_inv = batch_inv(I - c.R_pm @ r_mp)
+        T21_inv = t_pp @ tmp_inv
+        c.J0p[:] = j0p + _mv(T21_inv, c.J0p + _mv(c.R_pm, j0m))
+        c.T_pp[:] = T21_inv @ c.T_pp
+        c.R_pm[:] = r_pm + (T21_inv @ c.R_pm) @ t_mm
+    else:
+        raise ValueError(iface)
+
+
+def create_surface_layer_lambertian(albedo: float, added: AddedLayer, m: int, pol: PolType, quad: QuadPoints,
+                                    tau_sum: np.ndarray):
+    """create_surface_layer!(::LambertianSurfaceScalar) lambertian_surface.jl:20-75."""
+    N = len(quad.qp_muN)
+    n = pol.n
+    Nquad = N // n
+    if m == 0:
+        rho = 2 * albedo
+        blk = np.zeros((n, n))
+        blk[0, 0] = rho
+        R_surf = np.tile(blk, (Nquad, Nquad))
+        I0N = np.zeros(N)
+        I0N[quad.imu0Nstart - 1: n * quad.imu0] = pol.I0
+        att = np.exp(-tau_sum / quad.mu0)
+        added.j0p[:] = I0N[None, :] * att[:, None]
+        added.j0m[:] = (quad.mu0 * (R_surf @ I0N))[None, :] * att[:, None]
+        R_surf = R_surf @ np.diag(quad.qp_muN * quad.wt_muN)
+        added.r_mp[:] = R_surf[None]
+        added.r_pm[:] = 0
+        added.t_pp[:] = np.eye(N)[None]
+        added.t_mm[:] = np.eye(N)[None]
+    else:
+        added.r_mp[:] = 0
+        added.t_pp[:] = np.eye(N)[None]
+        added.t_mm[:] = np.eye(N)[None]
+        added.j0p[:] = 0
+        added.j0m[:] = 0
+
+
+def postprocessing_vza(pol: PolType, comp: CompositeLayer, vza, qp_mu, m: int, vaz, weight: float,
+                       R_SFI: np.ndarray, T_SFI: np.ndarray):
+    """postprocessing_vza!(::noRS) postprocessing_vza.jl:9-60 (SFI branch).
+    R_SFI/T_SFI: [nVza, nStokes, S]."""
+    n = pol.n
+    for i in range(len(vza)):
+        imu = nearest_point(qp_mu, float(cosd(vza[i])))
+        istart = imu * n
+        cs = np.array([float(cosd(m * vaz[i])), float(cosd(m * vaz[i])), float(sind(m * vaz[i])),
+                       float(sind(m * vaz[i]))])[:n]
+        bigCS = weight * cs
+        R_SFI[i] += (bigCS[None, :] * comp.J0m[:, istart:istart + n]).T
+        T_SFI[i] += (bigCS[None, :] * comp.J0p[:, istart:istart + n]).T
+
+
+def rt_kernel(pol, quad, added, comp, lay: LayerOptics, iface, tau_sum, m, iz, strict=True, hook=None):
+    """rt_kernel!(::noRS) rt_kernel.jl:173-235.  iz is 1-based."""
+    dtau, nd = get_dtau_ndoubl(lay.tau, lay.varpi, quad.qp_mu)
+    expk = np.exp(-dtau / quad.mu0)
+    Zpp, Zmp = lay.Zfull()
+    elemental(pol, quad, tau_sum, dtau, lay.varpi, Zpp, Zmp, m, nd, added, strict)
+    if hook:
+        hook("elemental", m, iz, added, comp)
+    doubling(pol, expk, nd, added, strict)
+    if hook:
+        hook("doubling", m, iz, added, comp)
+    if iz == 1:
+        comp.T_pp[:] = added.t_pp
+        comp.T_mm[:] = added.t_mm
+        comp.R_mp[:] = added.r_mp
+        comp.R_pm[:] = added.r_pm
+        comp.J0p[:] = added.j0p
+        comp.J0m[:] = added.j0m
+    else:
+        interaction(iface, comp, added)
+    if hook:
+        hook("interaction", m, iz, added, comp)
+    return nd
+
+
+def rt_run(scene: Scene, hook=None):
+    """rt_run(::noRS, model, iBand) rt_run.jl:41-230, SFI=true; returns (R_SFI, T_SFI)
+    each [nVza, nStokes, S]."""
+    pol, quad = scene.pol, scene.quad
+    S, Nz, N = scene.S, scene.Nz, scene.N
+    nV = len(scene.vza)
+    R_SFI = np.zeros((nV, pol.n, S))
+    T_SFI = np.zeros((nV, pol.n, S))
+    added = make_added_layer(N, S)
+    surf = make_added_layer(N, S)
+    comp = make_composite_layer(N, S)
+    strict = scene.strict_reference_indexing
+    for m in range(scene.max_m):
+        weight = 0.5 if m == 0 else 1.0
+        layers = construct_core_optical_properties(scene, m)
+        ifaces, tau_sum_all = extract_effective_props(layers)
+        for iz in range(Nz):
+            rt_kernel(pol, quad, added, comp, layers[iz], ifaces[iz], tau_sum_all[:, iz], m, iz + 1, strict, hook)
+        create_surface_layer_lambertian(scene.albedo, surf, m, pol, quad, tau_sum_all[:, -1])
+        interaction(ifaces[-1], comp, surf)  # Q6: last layer's interface code
+        if hook:
+            hook("surface", m, Nz + 1, surf, comp)
+        postprocessing_vza(pol, comp, scene.vza, quad.qp_mu, m, scene.vaz, weight, R_SFI, T_SFI)
+    return R_SFI, T_SFI
