@@ -1,0 +1,168 @@
+/*
+ * momcore.h -- C ABI of libmomcore.so, the MI355X (gfx950) Matrix-Operator RT core.
+ *
+ * Drop-in boundary for ONE path of vSmartMOM.jl (RadiativeTransfer/RadiativeTransfer.jl):
+ * the CoreRT layer-adding loop  elemental! -> doubling! -> interaction!  inside rt_run,
+ * the Lambertian surface + post-processing that close it, and the Absorption Voigt
+ * line-shape kernel.  Every entry point names the reference interface it replaces
+ * (file:line relative to the reference root).  A Julia maintainer binds these with
+ * `ccall((:mom_xxx, libmomcore), Cint, (...), ...)` -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - all functions return int status: MOM_OK (0) or a negative MOM_E* code; the text of
+ *     the last error is available from mom_last_error().
+ *   - arrays use the reference's memory order: Julia column-major [i, j, n] with the
+ *     spectral index n slowest (batch stride N*N); sources are [i, 1, n]; optical depth
+ *     tables are [nSpec, Nz] (model_from_parameters.jl:48); outputs are
+ *     [nVza, nStokes, nSpec] (rt_run.jl:89-90).
+ *   - indices passed as `*_1based` are Julia indices.
+ *   - host pointers are borrowed for the duration of the call only.  All device memory is
+ *     owned by the handle.  One handle <-> one GPU <-> one HIP stream; a handle is not
+ *     thread-safe, distinct handles are independent.
+ *   - double precision (Float64) only in this round; `dtype` is reserved (0 = f64).
+ */
+#ifndef MOMCORE_H
+#define MOMCORE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mom_handle mom_t;
+
+enum {
+  MOM_OK = 0,
+  MOM_EINVAL = -1,   /* bad argument */
+  MOM_EHIP = -2,     /* HIP runtime error (no device, launch failure, OOM ...) */
+  MOM_ESTATE = -3,   /* call sequence error (e.g. streams not set) */
+  MOM_ESINGULAR = -4 /* an (I - R r) operator was numerically singular (zero pivot) */
+};
+
+/* which-codes for mom_upload / mom_download (AddedLayer / CompositeLayer fields,
+ * types.jl:105-142).  Matrices are N*N*S doubles, sources N*S doubles.
+ * The surface layer (rt_run.jl:111-112 `added_layer_surface`) is a second AddedLayer. */
+enum {
+  MOM_ADDED_R_PM = 0, MOM_ADDED_R_MP = 1, MOM_ADDED_T_MM = 2, MOM_ADDED_T_PP = 3,
+  MOM_ADDED_J0P = 4, MOM_ADDED_J0M = 5,
+  MOM_COMP_R_MP = 6, MOM_COMP_R_PM = 7, MOM_COMP_T_PP = 8, MOM_COMP_T_MM = 9,
+  MOM_COMP_J0P = 10, MOM_COMP_J0M = 11,
+  MOM_SURF_R_PM = 12, MOM_SURF_R_MP = 13, MOM_SURF_T_MM = 14, MOM_SURF_T_PP = 15,
+  MOM_SURF_J0P = 16, MOM_SURF_J0M = 17
+};
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+
+/* Allocates the layer state of rt_run.jl:109-115 (make_added_layer x2, make_composite_layer;
+ * rt_helper_functions.jl:105-121,152-159) on GPU `device` for operators of edge
+ * N = nStokes*Nquad and S spectral points, for up to `max_m` Fourier moments processed
+ * as one batch (the moments of rt_run.jl:125 are independent).  */
+int mom_create(mom_t **out, int device, int N, int nStokes, int S, int max_m, int dtype);
+int mom_destroy(mom_t *h);
+const char *mom_last_error(const mom_t *h);
+/* library-level error text for failures that happen before a handle exists */
+const char *mom_last_global_error(void);
+/* blocks until everything queued on the handle's stream has finished */
+int mom_sync(mom_t *h);
+
+/* QuadPoints (types.jl:456-473) + polarization type (Scattering/types.jl:82-123).
+ * qp_muN/wt_muN: N values (already repeated per Stokes component); imu0_1based = iμ₀;
+ * mu0 = quad_points.μ₀; I0, D: nStokes values.  strict_reference_indexing != 0 keeps the
+ * reference's 1-based `mod(i, nStokes)` Stokes-component rule of elemental.jl:259-269,
+ * doubling.jl:95-117; 0 uses the zero-based component. */
+int mom_set_streams(mom_t *h, const double *qp_muN, const double *wt_muN, int N, int imu0_1based, double mu0,
+                    const double *I0, const double *D, int strict_reference_indexing);
+
+/* ---- operator-level API: one call per reference operator (used for parity tests and for
+ *      a Julia shim that overloads the operators one by one) ------------------------------ */
+
+/* elemental!(pol_type, SFI, τ_sum, dτ, computed_layer_properties, m, ndoubl, scatter, quad_points,
+ *            added_layer, architecture)  -- elemental.jl:109-162 (+ kernels :164-285).
+ * tau_sum, dtau, varpi: S values; Zpp/Zmp: N*N*z_batch with z_batch = 1 or S
+ * (expandOpticalProperties, compEffectiveLayerProperties.jl:124-135).  Fills the added layer. */
+int mom_elemental(mom_t *h, int m, int ndoubl, const double *tau_sum, const double *dtau, const double *varpi,
+                  const double *Zpp, const double *Zmp, int z_batch);
+
+/* doubling!(pol_type, SFI, expk, ndoubl, added_layer, I_static, architecture) -- doubling.jl:81-91
+ * (helper :13-79).  expk: S values, updated in place like the reference's `expk .= expk.^2`. */
+int mom_doubling(mom_t *h, int ndoubl, double *expk);
+
+/* interaction!(RS_type::noRS, scattering_interface, SFI, composite_layer, added_layer, I_static)
+ * -- interaction_inelastic.jl:474-484 -> interaction.jl:8-117.
+ * iface: 0 = ScatteringInterface_00, 1 = _01, 2 = _10, 3 = _11.
+ * with_surface_layer != 0 uses added_layer_surface instead of added_layer (rt_run.jl:179-185). */
+int mom_interaction(mom_t *h, int iface, int with_surface_layer);
+
+/* rt_kernel.jl:227-230: composite <- added (first layer, iz == 1) */
+int mom_copy_added_to_composite(mom_t *h);
+
+/* create_surface_layer!(::LambertianSurfaceScalar, added_layer_surface, SFI, m, pol_type, quad_points,
+ *                       τ_sum, architecture) -- lambertian_surface.jl:20-75.  tau_tot: S values. */
+int mom_surface_lambertian(mom_t *h, int m, double albedo, const double *tau_tot);
+
+/* batch_inv!(X, A) -- gpu_batched.jl:36-87;  X, A: n*n*batch doubles (host). */
+int mom_batch_inv(mom_t *h, int n, int batch, const double *A, double *X);
+/* A ⊠ B = batched_mul(A, B) -- gpu_batched.jl:90-97. */
+int mom_batched_mul(mom_t *h, int n, int batch, const double *A, const double *B, double *C);
+
+/* Array(composite_layer.J₀⁻) etc. (postprocessing_vza.jl:17-20) / test access.
+ * Operator-level state lives in moment slot 0 of the handle. */
+int mom_upload(mom_t *h, int which, const double *src);
+int mom_download(mom_t *h, int which, double *dst);
+
+/* ---- scene-level API: inputs resident in HBM, fused per-layer kernels -------------------
+ *
+ * mom_scene_set uploads everything rt_run's loops (rt_run.jl:125-215) consume, prepared by
+ * the host exactly as the reference's host code does (constructCoreOpticalProperties /
+ * extractEffectiveProps / get_dtau_ndoubl):
+ *   tau, varpi  [S, Nz]         layer optical depth and single-scattering albedo
+ *   zw          [K, S, Nz]      weights of the K phase-matrix bases (Rayleigh + aerosols):
+ *                               Z[:,:,n] = sum_k zw[k,n,z] * Zbasis_k  (types.jl:656-661)
+ *   Zpp, Zmp    [N, N, K, M]    compute_Z_moments per basis and Fourier moment
+ *   ndoubl      [Nz]            doubling_number per layer (GLOBAL over the spectral axis,
+ *                               rt_kernel.jl:238-246 -- compute before sharding)
+ *   iface       [Nz]            scattering-interface codes (rt_helper_functions.jl:8-27)
+ *   tau_sum     [S, Nz+1]       cumulative optical depth (compEffectiveLayerProperties.jl:108)
+ *   albedo                      LambertianSurfaceScalar
+ *   node_1based [nVza]          nearest stream per view (postprocessing_vza.jl:28)
+ *   cos_mphi, sin_mphi [nVza, M] cosd(m*vaz), sind(m*vaz) (postprocessing_vza.jl:32)
+ */
+int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
+                  const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface, const double *tau_sum,
+                  double albedo, int nVza, const int *node_1based, const double *cos_mphi, const double *sin_mphi);
+
+/* The whole of rt_run.jl:125-215 for the resident scene: all Fourier moments, all layers,
+ * surface, post-processing.  Asynchronous on the handle's stream; results stay on the GPU. */
+int mom_rt_run(mom_t *h);
+
+/* R_SFI, T_SFI [nVza, nStokes, S] to host (synchronises). */
+int mom_get_RT(mom_t *h, double *R_SFI, double *T_SFI);
+/* Same, into caller-owned DEVICE buffers (e.g. the send buffer of an RCCL all-gather). */
+int mom_get_RT_device(mom_t *h, void *dR_SFI, void *dT_SFI);
+
+/* Per-stage GPU time of the last mom_rt_run in milliseconds (hipEvent based):
+ * ms[0] = layer kernels, ms[1] = surface, ms[2] = post-processing, ms[3] = total;
+ * kernel_launches = number of layer-kernel launches.  Synchronises. */
+int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
+
+/* Tuning / test knob: 0 = automatic (default), 1 = force the pivoted Gauss-Jordan inverse,
+ * 2 = force the generic (global-memory) kernels even when the LDS-resident ones apply. */
+int mom_set_option(mom_t *h, int option, int value);
+enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1 };
+
+/* ---- Voigt line-by-line cross section --------------------------------------------------
+ * compute_absorption_cross_section(model::HitranModel, grid, p, T)
+ * (compute_absorption_cross_section.jl:19-130) with Voigt broadening and the
+ * HumlicekWeidemann32SDErrorFunction (complex_error_functions.jl:226-234).  The host passes
+ * the per-line prefactors of :79-107: nu = pressure-shifted centre, gamma_d, y, S =
+ * temperature-corrected strength, and the 1-based inclusive grid window of each line.
+ * sigma[nGrid] (host) receives sum over lines in line order.  `device` as in mom_create. */
+int mom_voigt_xsec(int device, int nLines, const double *nu, const double *gamma_d, const double *y,
+                   const double *S, const int *ind_start_1based, const int *ind_stop_1based, int nGrid,
+                   const double *grid, double *sigma);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOMCORE_H */

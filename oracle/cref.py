@@ -1,0 +1,177 @@
+"""
+oracle/cref.py -- TEST INFRASTRUCTURE ONLY: ctypes binding of oracle/libmomref.so (the
+C restatement, momref.c) plus `pack_scene`, which turns a numpy-twin `Scene` into the flat
+host-prepared arrays both the C oracle and the HIP library's C-ABI consume.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from . import momref as mr
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+
+
+def build(force: bool = False) -> Path:
+    so = _HERE / "libmomref.so"
+    src = _HERE / "momref.c"
+    if force or (not so.exists()) or so.stat().st_mtime < src.stat().st_mtime:
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", str(src), "-o", str(so), "-lm"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(str(build()))
+        _LIB.ora_w_hw32sd_re.restype = C.c_double
+        _LIB.ora_w_hw32sd_re.argtypes = [C.c_double, C.c_double]
+    return _LIB
+
+
+def dp(a):
+    return a.ctypes.data_as(c_dp)
+
+
+def ip(a):
+    return a.ctypes.data_as(c_ip)
+
+
+class OraScene(C.Structure):
+    _fields_ = [("N", C.c_int), ("nS", C.c_int), ("S", C.c_int), ("Nz", C.c_int), ("K", C.c_int), ("M", C.c_int),
+                ("imu0", C.c_int), ("strict", C.c_int), ("mu0", C.c_double),
+                ("mu", c_dp), ("wt", c_dp), ("I0", c_dp), ("D", c_dp),
+                ("tau", c_dp), ("varpi", c_dp), ("zw", c_dp), ("Zpp", c_dp), ("Zmp", c_dp),
+                ("nd", c_ip), ("iface", c_ip), ("tau_sum", c_dp), ("albedo", C.c_double),
+                ("nVza", C.c_int), ("node", c_ip), ("cos_mphi", c_dp), ("sin_mphi", c_dp)]
+
+
+class Packed:
+    """Flat, host-prepared inputs of the hot path (what the reference's Julia host code
+    hands to rt_kernel!/interaction!/postprocessing_vza!), in ABI memory order."""
+
+    def __init__(self, scene: mr.Scene):
+        pol, quad = scene.pol, scene.quad
+        self.N, self.nS, self.S, self.Nz, self.M = scene.N, pol.n, scene.S, scene.Nz, scene.max_m
+        self.imu0, self.mu0 = quad.imu0, quad.mu0
+        self.strict = 1 if scene.strict_reference_indexing else 0
+        self.mu = np.ascontiguousarray(quad.qp_muN, dtype=np.float64)
+        self.wt = np.ascontiguousarray(quad.wt_muN, dtype=np.float64)
+        self.I0 = np.ascontiguousarray(pol.I0, dtype=np.float64)
+        self.D = np.ascontiguousarray(pol.D, dtype=np.float64)
+        S, Nz, N = self.S, self.Nz, self.N
+        Zpp_all, Zmp_all = [], []
+        for m in range(self.M):
+            layers = mr.construct_core_optical_properties(scene, m)
+            Zpp_all.append(layers[0].Zpp_basis)
+            Zmp_all.append(layers[0].Zmp_basis)
+        self.K = layers[0].Zpp_basis.shape[0]
+        K = self.K
+        # [N,N,K,M] column-major: element (i,j,k,m) at i + N*(j + N*(k + K*m))
+        self.Zpp = np.ascontiguousarray(np.transpose(np.array(Zpp_all), (0, 1, 3, 2))).reshape(-1)  # [m,k,j,i]
+        self.Zmp = np.ascontiguousarray(np.transpose(np.array(Zmp_all), (0, 1, 3, 2))).reshape(-1)
+        self.tau = np.ascontiguousarray(np.array([l.tau for l in layers])).reshape(-1)  # [z][n]
+        self.varpi = np.ascontiguousarray(np.array([l.varpi for l in layers])).reshape(-1)
+        # zw[k + K*(n + S*z)] -> array [z][n][k]
+        self.zw = np.ascontiguousarray(np.array([l.zweights.T for l in layers])).reshape(-1)
+        ifaces, tau_sum = mr.extract_effective_props(layers)
+        self.iface = np.array(ifaces, dtype=np.int32)
+        self.tau_sum = np.ascontiguousarray(tau_sum.T).reshape(-1)  # [z][n]
+        self.nd = np.array([mr.get_dtau_ndoubl(l.tau, l.varpi, quad.qp_mu)[1] for l in layers], dtype=np.int32)
+        self.albedo = float(scene.albedo)
+        self.nVza = len(scene.vza)
+        self.node = np.array([mr.nearest_point(quad.qp_mu, float(mr.cosd(v))) + 1 for v in scene.vza], dtype=np.int32)
+        self.vaz = np.asarray(scene.vaz, dtype=np.float64)
+        cm = np.array([[float(mr.cosd(m * a)) for a in scene.vaz] for m in range(self.M)])
+        sm = np.array([[float(mr.sind(m * a)) for a in scene.vaz] for m in range(self.M)])
+        self.cos_mphi = np.ascontiguousarray(cm).reshape(-1)  # [m][v]
+        self.sin_mphi = np.ascontiguousarray(sm).reshape(-1)
+
+    def c_struct(self) -> OraScene:
+        s = OraScene()
+        s.N, s.nS, s.S, s.Nz, s.K, s.M = self.N, self.nS, self.S, self.Nz, self.K, self.M
+        s.imu0, s.strict, s.mu0 = self.imu0, self.strict, self.mu0
+        s.mu, s.wt, s.I0, s.D = dp(self.mu), dp(self.wt), dp(self.I0), dp(self.D)
+        s.tau, s.varpi, s.zw = dp(self.tau), dp(self.varpi), dp(self.zw)
+        s.Zpp, s.Zmp = dp(self.Zpp), dp(self.Zmp)
+        s.nd, s.iface, s.tau_sum = ip(self.nd), ip(self.iface), dp(self.tau_sum)
+        s.albedo, s.nVza, s.node = self.albedo, self.nVza, ip(self.node)
+        s.cos_mphi, s.sin_mphi = dp(self.cos_mphi), dp(self.sin_mphi)
+        return s
+
+
+def pack_scene(scene: mr.Scene) -> Packed:
+    return Packed(scene)
+
+
+def rt_run(p: Packed, pts=None, nthreads: int = 0):
+    """Full elastic run on the C oracle.  Returns R_SFI, T_SFI as [nVza, nStokes, S]."""
+    if nthreads <= 0:
+        nthreads = os.cpu_count() or 1
+    R = np.zeros(p.nVza * p.nS * p.S)
+    T = np.zeros(p.nVza * p.nS * p.S)
+    st = p.c_struct()
+    if pts is None:
+        info = lib().ora_rt_run(C.byref(st), None, 0, nthreads, dp(R), dp(T))
+    else:
+        pts = np.ascontiguousarray(pts, dtype=np.int32)
+        info = lib().ora_rt_run(C.byref(st), ip(pts), len(pts), nthreads, dp(R), dp(T))
+    shp = (p.S, p.nS, p.nVza)
+    return np.transpose(R.reshape(shp), (2, 1, 0)).copy(), np.transpose(T.reshape(shp), (2, 1, 0)).copy(), info
+
+
+# ---- op-level wrappers on ABI-ordered flat arrays -----------------------------------------
+
+def elemental(p: Packed, m, nd, tau_sum, dtau, varpi, Zpp, Zmp, z_batch, S):
+    N = p.N
+    out = [np.zeros(N * N * S) for _ in range(4)] + [np.zeros(N * S) for _ in range(2)]
+    lib().ora_elemental(N, p.nS, S, m, nd, p.imu0, dp(p.mu), dp(p.wt), dp(p.I0), dp(p.D), p.strict,
+                        dp(tau_sum), dp(dtau), dp(varpi), dp(Zpp), dp(Zmp), z_batch, *[dp(o) for o in out])
+    return out  # r_pm, r_mp, t_mm, t_pp, j0p, j0m
+
+
+def doubling(p: Packed, nd, expk, added, S):
+    return lib().ora_doubling(p.N, p.nS, S, nd, p.strict, dp(expk), *[dp(a) for a in added])
+
+
+def interaction(N, S, iface, comp, added):
+    """comp: [R_mp, R_pm, T_pp, T_mm, J0p, J0m]; added: [r_pm, r_mp, t_mm, t_pp, j0p, j0m]"""
+    return lib().ora_interaction(N, S, iface, *[dp(a) for a in comp], *[dp(a) for a in added])
+
+
+def surface_lambertian(p: Packed, m, tau_tot, S):
+    N = p.N
+    out = [np.zeros(N * N * S) for _ in range(4)] + [np.zeros(N * S) for _ in range(2)]
+    lib().ora_surface_lambertian(N, p.nS, S, m, p.imu0, C.c_double(p.mu0), dp(p.mu), dp(p.wt), dp(p.I0),
+                                 C.c_double(p.albedo), dp(tau_tot), *[dp(o) for o in out])
+    return out
+
+
+def batch_inv(N, S, A):
+    X = np.zeros_like(A)
+    info = lib().ora_batch_inv(N, S, dp(A), dp(X))
+    return X, info
+
+
+def batched_mul(N, S, A, B):
+    Cm = np.zeros_like(A)
+    lib().ora_batched_mul(N, S, dp(A), dp(B), dp(Cm))
+    return Cm
+
+
+def voigt_xsec(nu, gamma_d, y, Sline, ind_start, ind_stop, grid):
+    sigma = np.zeros(len(grid))
+    ind_start = np.ascontiguousarray(ind_start, dtype=np.int32)
+    ind_stop = np.ascontiguousarray(ind_stop, dtype=np.int32)
+    lib().ora_voigt_xsec(len(nu), dp(nu), dp(gamma_d), dp(y), dp(Sline), ip(ind_start), ip(ind_stop), len(grid),
+                         dp(np.ascontiguousarray(grid, dtype=np.float64)), dp(sigma))
+    return sigma

@@ -1,0 +1,7 @@
+"""MI355X-native Matrix-Operator RT core (drop-in for vSmartMOM.jl's CoreRT hot path).
+
+The directory name contains a dot, so import it through the root-level shim:
+    import rtamd            # -> this package, registered as module "rtamd"
+"""
+from . import _lib  # noqa: F401
+from ._lib import Handle, MomError, voigt_xsec, load  # noqa: F401

@@ -1,0 +1,229 @@
+"""ctypes binding of libmomcore.so (include/momcore.h).
+
+There is no CPU fallback: if the HIP library is missing or a call fails, a `MomError` is
+raised.  The library is built in-tree (radiativetransfer.jl_amd/libmomcore.so) by
+`make -C radiativetransfer.jl_amd/csrc` or `__graft_entry__.build()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libmomcore.so"
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+c_h = C.c_void_p
+
+MOM_OK, MOM_EINVAL, MOM_EHIP, MOM_ESTATE, MOM_ESINGULAR = 0, -1, -2, -3, -4
+_CODES = {MOM_EINVAL: "MOM_EINVAL", MOM_EHIP: "MOM_EHIP", MOM_ESTATE: "MOM_ESTATE", MOM_ESINGULAR: "MOM_ESINGULAR"}
+
+# which-codes of mom_upload / mom_download
+ADDED = dict(r_pm=0, r_mp=1, t_mm=2, t_pp=3, j0p=4, j0m=5)
+COMP = dict(R_mp=6, R_pm=7, T_pp=8, T_mm=9, J0p=10, J0m=11)
+SURF = dict(r_pm=12, r_mp=13, t_mm=14, t_pp=15, j0p=16, j0m=17)
+
+MOM_OPT_INVERSE, MOM_OPT_FORCE_GENERIC = 0, 1
+
+
+class MomError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{_CODES.get(code, code)}: {msg}")
+        self.code = code
+
+
+# every symbol include/momcore.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "mom_create": (C.c_int, [C.POINTER(c_h), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mom_destroy": (C.c_int, [c_h]),
+    "mom_last_error": (C.c_char_p, [c_h]),
+    "mom_last_global_error": (C.c_char_p, []),
+    "mom_sync": (C.c_int, [c_h]),
+    "mom_set_streams": (C.c_int, [c_h, c_dp, c_dp, C.c_int, C.c_int, C.c_double, c_dp, c_dp, C.c_int]),
+    "mom_elemental": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int]),
+    "mom_doubling": (C.c_int, [c_h, C.c_int, c_dp]),
+    "mom_interaction": (C.c_int, [c_h, C.c_int, C.c_int]),
+    "mom_copy_added_to_composite": (C.c_int, [c_h]),
+    "mom_surface_lambertian": (C.c_int, [c_h, C.c_int, C.c_double, c_dp]),
+    "mom_batch_inv": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp]),
+    "mom_batched_mul": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp, c_dp]),
+    "mom_upload": (C.c_int, [c_h, C.c_int, c_dp]),
+    "mom_download": (C.c_int, [c_h, C.c_int, c_dp]),
+    "mom_scene_set": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip, c_dp,
+                                C.c_double, C.c_int, c_ip, c_dp, c_dp]),
+    "mom_rt_run": (C.c_int, [c_h]),
+    "mom_get_RT": (C.c_int, [c_h, c_dp, c_dp]),
+    "mom_get_RT_device": (C.c_int, [c_h, C.c_void_p, C.c_void_p]),
+    "mom_timers": (C.c_int, [c_h, c_dp, C.c_int, c_ip]),
+    "mom_set_option": (C.c_int, [c_h, C.c_int, C.c_int]),
+    "mom_voigt_xsec": (C.c_int, [C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip, C.c_int, c_dp, c_dp]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libmomcore.so and bind every declared symbol.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise MomError(MOM_EHIP, f"{LIB_PATH} not found - build it with `make -C {PKG_DIR / 'csrc'}` "
+                                 "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def dp(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_dp)
+
+
+def ip(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_ip)
+
+
+class Handle:
+    """RAII wrapper of mom_t*.  One handle <-> one GPU <-> one stream."""
+
+    def __init__(self, N: int, nStokes: int, S: int, max_m: int = 1, device: int = 0):
+        self.lib = load()
+        self.N, self.nS, self.S, self.M = int(N), int(nStokes), int(S), int(max_m)
+        self._h = c_h()
+        rc = self.lib.mom_create(C.byref(self._h), device, self.N, self.nS, self.S, self.M, 0)
+        if rc != MOM_OK:
+            msg = self.lib.mom_last_global_error().decode()
+            if self._h:
+                self.lib.mom_destroy(self._h)
+                self._h = c_h()
+            raise MomError(rc, msg)
+
+    def check(self, rc):
+        if rc != MOM_OK:
+            raise MomError(rc, self.lib.mom_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.mom_destroy(self._h)
+            self._h = c_h()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- thin 1:1 wrappers ---------------------------------------------------------------
+    def set_option(self, option, value):
+        self.check(self.lib.mom_set_option(self._h, option, value))
+
+    def sync(self):
+        self.check(self.lib.mom_sync(self._h))
+
+    def set_streams(self, qp_muN, wt_muN, imu0_1based, mu0, I0, D, strict=True):
+        qp, wt, I0, D = f64(qp_muN), f64(wt_muN), f64(I0), f64(D)
+        self.check(self.lib.mom_set_streams(self._h, dp(qp), dp(wt), len(qp), int(imu0_1based), float(mu0), dp(I0),
+                                            dp(D), 1 if strict else 0))
+
+    def elemental(self, m, nd, tau_sum, dtau, varpi, Zpp, Zmp, z_batch):
+        a = [f64(x) for x in (tau_sum, dtau, varpi, Zpp, Zmp)]
+        self.check(self.lib.mom_elemental(self._h, int(m), int(nd), *[dp(x) for x in a], int(z_batch)))
+
+    def doubling(self, nd, expk):
+        e = f64(expk).copy()
+        self.check(self.lib.mom_doubling(self._h, int(nd), dp(e)))
+        return e
+
+    def interaction(self, iface, with_surface_layer=False):
+        self.check(self.lib.mom_interaction(self._h, int(iface), 1 if with_surface_layer else 0))
+
+    def copy_added_to_composite(self):
+        self.check(self.lib.mom_copy_added_to_composite(self._h))
+
+    def surface_lambertian(self, m, albedo, tau_tot):
+        t = f64(tau_tot)
+        self.check(self.lib.mom_surface_lambertian(self._h, int(m), float(albedo), dp(t)))
+
+    def upload(self, which, src):
+        s = f64(src).reshape(-1)
+        self.check(self.lib.mom_upload(self._h, int(which), dp(s)))
+
+    def download(self, which):
+        k = which % 6
+        out = np.empty((self.N * self.N if k < 4 else self.N) * self.S)
+        self.check(self.lib.mom_download(self._h, int(which), dp(out)))
+        return out
+
+    def batch_inv(self, n, batch, A):
+        A = f64(A).reshape(-1)
+        X = np.empty_like(A)
+        self.check(self.lib.mom_batch_inv(self._h, n, batch, dp(A), dp(X)))
+        return X
+
+    def batched_mul(self, n, batch, A, B):
+        A, B = f64(A).reshape(-1), f64(B).reshape(-1)
+        Cm = np.empty_like(A)
+        self.check(self.lib.mom_batched_mul(self._h, n, batch, dp(A), dp(B), dp(Cm)))
+        return Cm
+
+    def scene_set(self, Nz, K, M, tau, varpi, zw, Zpp, Zmp, nd, iface, tau_sum, albedo, node, cos_mphi, sin_mphi):
+        d = [f64(x).reshape(-1) for x in (tau, varpi, zw, Zpp, Zmp)]
+        nd, iface, node = i32(nd), i32(iface), i32(node)
+        ts, cm, sm = f64(tau_sum).reshape(-1), f64(cos_mphi).reshape(-1), f64(sin_mphi).reshape(-1)
+        self.nVza = len(node)
+        self.check(self.lib.mom_scene_set(self._h, int(Nz), int(K), int(M), *[dp(x) for x in d], ip(nd), ip(iface),
+                                          dp(ts), float(albedo), len(node), ip(node), dp(cm), dp(sm)))
+
+    def rt_run(self):
+        self.check(self.lib.mom_rt_run(self._h))
+
+    def get_RT(self):
+        """R_SFI, T_SFI as numpy [nVza, nStokes, S] (reference layout, rt_run.jl:89-90)."""
+        n = self.nVza * self.nS * self.S
+        R, T = np.empty(n), np.empty(n)
+        self.check(self.lib.mom_get_RT(self._h, dp(R), dp(T)))
+        shp = (self.S, self.nS, self.nVza)
+        return np.transpose(R.reshape(shp), (2, 1, 0)).copy(), np.transpose(T.reshape(shp), (2, 1, 0)).copy()
+
+    def get_RT_device(self, dR_ptr: int, dT_ptr: int):
+        self.check(self.lib.mom_get_RT_device(self._h, C.c_void_p(dR_ptr), C.c_void_p(dT_ptr)))
+
+    def timers(self):
+        ms = np.zeros(4)
+        nl = C.c_int(0)
+        self.check(self.lib.mom_timers(self._h, dp(ms), 4, C.byref(nl)))
+        return dict(layers_ms=ms[0], surface_ms=ms[1], postprocess_ms=ms[2], total_ms=ms[3], layer_launches=nl.value)
+
+
+def voigt_xsec(nu, gamma_d, y, S, ind_start, ind_stop, grid, device: int = 0):
+    lib = load()
+    a = [f64(x) for x in (nu, gamma_d, y, S)]
+    i0, i1, g = i32(ind_start), i32(ind_stop), f64(grid)
+    sigma = np.empty(len(g))
+    rc = lib.mom_voigt_xsec(device, len(a[0]), *[dp(x) for x in a], ip(i0), ip(i1), len(g), dp(g), dp(sigma))
+    if rc != MOM_OK:
+        raise MomError(rc, "mom_voigt_xsec failed")
+    return sigma

@@ -1,0 +1,455 @@
+// mom_kernels.hpp -- the per-layer Matrix-Operator kernels (elemental -> doubling ->
+// interaction), written against the workgroup primitives of mom_device.hpp.
+//
+// Reference semantics restated here (file:line relative to the reference root, src/CoreRT):
+//   elemental!        CoreKernel/elemental.jl:109-162, kernels :164-285
+//   doubling_helper!  CoreKernel/doubling.jl:13-79, apply_D! :93-118
+//   interaction_helper! CoreKernel/interaction.jl:8-22 (00) :27-43 (01) :49-64 (10) :69-117 (11)
+//   create_surface_layer!(::LambertianSurfaceScalar) Surfaces/lambertian_surface.jl:20-75
+//   postprocessing_vza! tools/postprocessing_vza.jl:9-60
+//
+// Sign bookkeeping: with sg[i] = -1 where the (reference-indexed) Stokes component of row i
+// is "> 2" and +1 elsewhere, the reference's D kernels amount to
+//   r-+ rows scaled by sg (elemental when nd>=1, and again after doubling), j0- scaled by sg
+//   after doubling, and  r+- = diag(sg) r-+ diag(sg),  t-- = diag(sg) t++ diag(sg)  always.
+// So r+- and t-- are never materialised in the fused path: they are operand functors.
+#pragma once
+#include "mom_device.hpp"
+
+namespace mom {
+
+struct DevStreams {
+  const double *mu;  // [N] qp_μN
+  const double *wt;  // [N] wt_μN
+  const double *sg;  // [N] +-1 (see above)
+  double I0[4];
+  double D[4];
+  int N, nS, imu0;  // imu0: 1-based stream index of the sun
+  double mu0;
+};
+
+// workgroup context: where this workgroup's matrices and vectors live
+struct Ctx {
+  int N, ld, ldv;
+  double *r, *t, *P, *Q, *X;  // N x N buffers (X: spare, generic mode only)
+  double *jp, *jm, *j1p, *j1m, *v1, *v2, *Jp, *Jm, *prow, *pcol, *rowk, *ei, *mu, *wt, *sg, *part;
+  int *ipiv, *sh, *bad;
+};
+
+__host__ __device__ inline int ld_for(int N) { return (N & 1) ? N + 1 : N + 2; }
+__host__ __device__ inline int ldv_for(int N) { return (N + 1) & ~1; }
+constexpr int kNumVec = 15 + 2 * kWaves;  // vectors carved from LDS (part = 2*kWaves vectors)
+__host__ __device__ inline size_t lds_bytes(int N, bool lds_mats) {
+  size_t b = (size_t)kNumVec * ldv_for(N) * sizeof(double) + (size_t)(ldv_for(N) + 4) * sizeof(int);
+  if (lds_mats) b += (size_t)4 * N * ld_for(N) * sizeof(double);
+  return b;
+}
+
+template <bool LDSM>
+__device__ __forceinline__ void make_ctx(Ctx &c, int N, double *smem, double *gscratch) {
+  c.N = N;
+  c.ld = ld_for(N);
+  c.ldv = ldv_for(N);
+  double *p = smem;
+  if (LDSM) {
+    const size_t msz = (size_t)N * c.ld;
+    c.r = p; c.t = p + msz; c.P = p + 2 * msz; c.Q = p + 3 * msz; c.X = nullptr;
+    p += 4 * msz;
+  } else {
+    const size_t msz = (size_t)N * c.ld;
+    c.r = gscratch; c.t = gscratch + msz; c.P = gscratch + 2 * msz; c.Q = gscratch + 3 * msz; c.X = gscratch + 4 * msz;
+  }
+  const int lv = c.ldv;
+  c.jp = p; c.jm = p + lv; c.j1p = p + 2 * lv; c.j1m = p + 3 * lv; c.v1 = p + 4 * lv; c.v2 = p + 5 * lv;
+  c.Jp = p + 6 * lv; c.Jm = p + 7 * lv; c.prow = p + 8 * lv; c.pcol = p + 9 * lv; c.rowk = p + 10 * lv;
+  c.ei = p + 11 * lv; c.mu = p + 12 * lv; c.wt = p + 13 * lv; c.sg = p + 14 * lv; c.part = p + 15 * lv;
+  int *ip = reinterpret_cast<int *>(p + (size_t)kNumVec * lv);
+  c.ipiv = ip; c.sh = ip + lv; c.bad = ip + lv + 1;
+}
+
+// element functor of a column-major buffer with leading dimension ld, zero outside [0,N)^2
+struct El {
+  const double *p; int ld, N;
+  __device__ __forceinline__ double operator()(int i, int j) const { return (i < N && j < N) ? p[i + j * ld] : 0.0; }
+};
+// diag(sg) * buf * diag(sg)
+struct ElSig {
+  const double *p; const double *sg; int ld, N;
+  __device__ __forceinline__ double operator()(int i, int j) const {
+    return (i < N && j < N) ? sg[i] * sg[j] * p[i + j * ld] : 0.0;
+  }
+};
+struct ElZero { __device__ __forceinline__ double operator()(int, int) const { return 0.0; } };
+struct ElEye {
+  int N;
+  __device__ __forceinline__ double operator()(int i, int j) const { return (i == j && i < N) ? 1.0 : 0.0; }
+};
+
+// y = M x (+ nothing); all threads; ends with barrier
+template <class FM>
+__device__ __forceinline__ void wg_matvec(const Ctx &c, FM M, const double *x, double *y) {
+  const int N = c.N, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int chunk = (N + kWaves - 1) / kWaves;
+  const int k0 = wave * chunk, k1 = min(N, k0 + chunk);
+  for (int i = lane; i < N; i += 64) {
+    double s = 0.0;
+    for (int k = k0; k < k1; ++k) s += M(i, k) * x[k];
+    c.part[wave * c.ldv + i] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += kThreads) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) s += c.part[w * c.ldv + i];
+    y[i] = s;
+  }
+  __syncthreads();
+}
+
+// dst = dst * B  (dst is the A operand); LDS mode: true in place; generic: via spare + swap
+template <bool LDSM, class FB>
+__device__ __forceinline__ void gemm_inplace_A(Ctx &c, double *&dst, FB B) {
+  const int N = c.N, ld = c.ld;
+  if (LDSM) {
+    double *d = dst;
+    wg_gemm<true>(N, El{d, ld, N}, B, [=](int i, int j, double v) { d[i + j * ld] = v; });
+  } else {
+    double *d = dst, *s = c.X;
+    wg_gemm<false>(N, El{d, ld, N}, B, [=](int i, int j, double v) { s[i + j * ld] = v; });
+    c.X = d;
+    dst = s;
+  }
+  __syncthreads();
+}
+// dst = A * dst  (dst is the B operand)
+template <bool LDSM, class FA>
+__device__ __forceinline__ void gemm_inplace_B(Ctx &c, FA A, double *&dst) {
+  const int N = c.N, ld = c.ld;
+  if (LDSM) {
+    double *d = dst;
+    wg_gemm<true>(N, A, El{d, ld, N}, [=](int i, int j, double v) { d[i + j * ld] = v; });
+  } else {
+    double *d = dst, *s = c.X;
+    wg_gemm<false>(N, A, El{d, ld, N}, [=](int i, int j, double v) { s[i + j * ld] = v; });
+    c.X = d;
+    dst = s;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
+// stream constants -> LDS
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_streams(const Ctx &c, const DevStreams &q) {
+  for (int i = threadIdx.x; i < c.N; i += kThreads) {
+    c.mu[i] = q.mu[i];
+    c.wt[i] = q.wt[i];
+    c.sg[i] = q.sg[i];
+  }
+  if (threadIdx.x == 0) *c.bad = 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// elemental! into c.r (r-+), c.t (t++), c.jp, c.jm.  Zpp(i,j), Zmp(i,j): phase-matrix
+// element functors for this spectral point.  Needs load_streams + barrier before.
+// Ends with a barrier.
+// ---------------------------------------------------------------------------------------
+template <class FZP, class FZM>
+__device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &q, int m, int nd, double tau_sum,
+                                                double dtau, double varpi, FZP Zpp, FZM Zmp) {
+  const int N = c.N, ld = c.ld, n = q.nS;
+  const double wdiv = (m == 0) ? 2.0 : 4.0;
+  const double wct02 = (m == 0) ? 0.5 : 0.25;
+  for (int i = threadIdx.x; i < N; i += kThreads) c.ei[i] = exp(-dtau / c.mu[i]);
+  __syncthreads();
+  for (int e = threadIdx.x; e < N * N; e += kThreads) {
+    const int j = e / N, i = e - j * N;
+    const double mui = c.mu[i], muj = c.mu[j];
+    const double wj = c.wt[j] / wdiv;
+    double rr, tt;
+    if (wj > 1.e-8) {
+      rr = varpi * Zmp(i, j) * (muj / (mui + muj)) * wj * (1 - exp(-dtau * ((1 / mui) + (1 / muj))));
+      if (mui == muj) {
+        if (i == j) {
+          const double wi = c.wt[i] / wdiv;
+          tt = c.ei[i] * (1 + varpi * Zpp(i, i) * (dtau / mui) * wi);
+        } else {
+          tt = 0.0;
+        }
+      } else {
+        tt = varpi * Zpp(i, j) * (muj / (mui - muj)) * wj * (c.ei[i] - c.ei[j]);
+      }
+    } else {
+      rr = 0.0;
+      tt = (i == j) ? c.ei[i] : 0.0;
+    }
+    if (nd >= 1) rr *= c.sg[i];  // apply_D_elemental!, elemental.jl:265-269
+    c.r[i + j * ld] = rr;
+    c.t[i + j * ld] = tt;
+  }
+  const int i_start = n * (q.imu0 - 1), i_end = n * q.imu0;
+  const double mus = c.mu[i_start];
+  const double att = exp(-tau_sum / mus);
+  for (int i = threadIdx.x; i < N; i += kThreads) {
+    double zp = 0.0, zm = 0.0;
+    for (int ii = i_start; ii < i_end; ++ii) {
+      zp += Zpp(i, ii) * q.I0[ii - i_start];
+      zm += Zmp(i, ii) * q.I0[ii - i_start];
+    }
+    const double mui = c.mu[i];
+    double jp, jm;
+    if (i >= i_start && i < i_end)
+      jp = wct02 * varpi * zp * (dtau / mui) * c.ei[i];
+    else
+      jp = wct02 * varpi * zp * (mus / (mui - mus)) * (c.ei[i] - c.ei[i_start]);
+    jm = wct02 * varpi * zm * (mus / (mui + mus)) * (1 - exp(-dtau * ((1 / mui) + (1 / mus))));
+    jp *= att;
+    jm *= att;
+    if (nd >= 1) jm = q.D[i % n] * jm;  // elemental.jl:249-251
+    c.jp[i] = jp;
+    c.jm[i] = jm;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
+// doubling_helper!: nd doublings of (r, t, jp, jm) held in the context, then the D signs.
+// expk: this point's exp(-dtau/mu0) (returned squared nd times).  Ends with a barrier.
+// ---------------------------------------------------------------------------------------
+template <bool LDSM>
+__device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
+  const int N = c.N, ld = c.ld;
+  if (nd == 0) return expk;
+  for (int it = 0; it < nd; ++it) {
+    double *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
+    // P = I - r r                                         (doubling.jl:44)
+    wg_gemm<false>(N, El{r, ld, N}, El{r, ld, N},
+                   [=](int i, int j, double v) { P[i + j * ld] = ((i == j) ? 1.0 : 0.0) - v; });
+    __syncthreads();
+    wg_inverse(N, P, ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);  // :47
+    // Q = t P   (tt⁺⁺_gp_refl)                              (:48)
+    wg_gemm<false>(N, El{t, ld, N}, El{P, ld, N}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+    // j1± = j0± expk                                       (:51,:54)
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+      c.j1p[i] = c.jp[i] * expk;
+      c.j1m[i] = c.jm[i] * expk;
+    }
+    __syncthreads();
+    // v1 = r j0+ ; v2 = r j1-
+    wg_matvec2(N, c.ldv, El{r, ld, N}, c.jp, c.j1m, c.v1, c.v2, c.part);
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+      c.v1[i] = c.j1m[i] + c.v1[i];  // j1- + r j0+
+      c.v2[i] = c.jp[i] + c.v2[i];   // j0+ (old) + r j1-
+    }
+    __syncthreads();
+    wg_matvec2(N, c.ldv, El{Q, ld, N}, c.v1, c.v2, c.v1, c.v2, c.part);
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+      c.jm[i] = c.jm[i] + c.v1[i];   // :57
+      c.jp[i] = c.j1p[i] + c.v2[i];  // :60
+    }
+    expk = expk * expk;  // :61
+    // P = Q r
+    wg_gemm<false>(N, El{Q, ld, N}, El{r, ld, N}, [=](int i, int j, double v) { P[i + j * ld] = v; });
+    __syncthreads();
+    // r = r + P t (:64) ; t = Q t (:67)
+    if (LDSM) {
+      wg_gemm2<true>(N, El{P, ld, N}, El{Q, ld, N}, El{t, ld, N},
+                     [=](int i, int j, double v) { r[i + j * ld] = r[i + j * ld] + v; },
+                     [=](int i, int j, double v) { t[i + j * ld] = v; });
+    } else {
+      double *X = c.X;
+      wg_gemm2<false>(N, El{P, ld, N}, El{Q, ld, N}, El{t, ld, N},
+                      [=](int i, int j, double v) { r[i + j * ld] = r[i + j * ld] + v; },
+                      [=](int i, int j, double v) { X[i + j * ld] = v; });
+      c.X = t;
+      c.t = X;
+    }
+    __syncthreads();
+  }
+  // apply_D! (doubling.jl:93-110) and apply_D_SFI! (:112-118): r-+ rows and j0- scaled by sg
+  {
+    double *r = c.r;
+    for (int e = threadIdx.x; e < N * N; e += kThreads) {
+      const int j = e / N, i = e - j * N;
+      r[i + j * ld] *= c.sg[i];
+    }
+    for (int i = threadIdx.x; i < N; i += kThreads) c.jm[i] *= c.sg[i];
+  }
+  __syncthreads();
+  return expk;
+}
+
+// composite-layer pointers of one spectral point (column-major, ld = N)
+struct CompPtrs {
+  double *R_mp, *R_pm, *T_pp, *T_mm, *J0p, *J0m;
+};
+
+// ---------------------------------------------------------------------------------------
+// interaction_helper!: composite (global) <- composite (+) added.  Added r-+ in c.r, t++ in
+// c.t, j0+ in c.jp, j0- in c.jm; added r+- and t-- as element functors.  Ends with barrier.
+// ---------------------------------------------------------------------------------------
+template <bool LDSM, class FRPM, class FTMM>
+__device__ __forceinline__ void interaction_core(Ctx &c, int iface, const CompPtrs &g, FRPM rpm, FTMM tmm) {
+  const int N = c.N, ld = c.ld;
+  double *r = c.r, *t = c.t;
+  // composite sources -> LDS
+  for (int i = threadIdx.x; i < N; i += kThreads) {
+    c.Jp[i] = g.J0p[i];
+    c.Jm[i] = g.J0m[i];
+  }
+  __syncthreads();
+  if (iface == 0) {
+    // J0+ = j0+ + t++ J0+ ; J0- = J0- + T-- j0-            (interaction.jl:16-17)
+    wg_matvec(c, El{t, ld, N}, c.Jp, c.v1);
+    wg_matvec(c, El{g.T_mm, N, N}, c.jm, c.v2);
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+      c.Jp[i] = c.jp[i] + c.v1[i];
+      c.Jm[i] = c.Jm[i] + c.v2[i];
+    }
+    // T-- = t-- T-- ; T++ = t++ T++                          (:20-21)
+    wg_copy_mat(N, g.T_mm, N, c.P, ld);
+    wg_copy_mat(N, g.T_pp, N, c.Q, ld);
+    __syncthreads();
+    double *Tmm = g.T_mm, *Tpp = g.T_pp;
+    wg_gemm<false>(N, tmm, El{c.P, ld, N}, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
+    wg_gemm<false>(N, El{t, ld, N}, El{c.Q, ld, N}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
+  } else if (iface == 1) {
+    wg_copy_mat(N, g.T_mm, N, c.P, ld);  // P = T--
+    // J0- = J0- + T-- (r-+ J0+ + j0-) ; J0+ = j0+ + t++ J0+  (:36-37)
+    wg_matvec(c, El{r, ld, N}, c.Jp, c.v1);
+    for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
+    __syncthreads();
+    wg_matvec(c, El{c.P, ld, N}, c.v1, c.v2);
+    wg_matvec(c, El{t, ld, N}, c.Jp, c.v1);
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+      c.Jm[i] = c.Jm[i] + c.v2[i];
+      c.Jp[i] = c.jp[i] + c.v1[i];
+    }
+    // R-+ = (T-- r-+) T++ ; R+- = r+- ; T++ = t++ T++ ; T-- = T-- t--   (:40-43)
+    double *Q = c.Q, *P = c.P;
+    wg_gemm<false>(N, El{P, ld, N}, El{r, ld, N}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+    __syncthreads();
+    double *Rmp = g.R_mp, *Rpm = g.R_pm, *Tpp = g.T_pp, *Tmm = g.T_mm;
+    wg_gemm<false>(N, El{Q, ld, N}, El{g.T_pp, N, N}, [=](int i, int j, double v) { Rmp[i + j * N] = v; });
+    __syncthreads();
+    wg_copy_mat(N, g.T_pp, N, Q, ld);
+    __syncthreads();
+    wg_gemm<false>(N, El{t, ld, N}, El{Q, ld, N}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
+    wg_gemm<false>(N, El{P, ld, N}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
+    for (int e = threadIdx.x; e < N * N; e += kThreads) {
+      const int j = e / N, i = e - j * N;
+      Rpm[i + j * N] = rpm(i, j);
+    }
+  } else if (iface == 2) {
+    double *P = c.P, *Q = c.Q;
+    wg_copy_mat(N, g.R_pm, N, P, ld);  // P = R+-
+    wg_copy_mat(N, g.T_mm, N, Q, ld);  // Q = T--
+    __syncthreads();
+    // J0+ = j0+ + t++ (J0+ + R+- j0-) ; J0- = J0- + T-- j0-   (:58-59)
+    wg_matvec(c, El{P, ld, N}, c.jm, c.v1);
+    for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.Jp[i] + c.v1[i];
+    __syncthreads();
+    wg_matvec(c, El{t, ld, N}, c.v1, c.v2);
+    wg_matvec(c, El{Q, ld, N}, c.jm, c.v1);
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+      c.Jp[i] = c.jp[i] + c.v2[i];
+      c.Jm[i] = c.Jm[i] + c.v1[i];
+    }
+    // T++ = t++ T++ ; T-- = T-- t-- ; R+- = (t++ R+-) t--       (:62-64)
+    double *Tpp = g.T_pp, *Tmm = g.T_mm, *Rpm = g.R_pm;
+    wg_gemm<false>(N, El{Q, ld, N}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
+    __syncthreads();
+    wg_copy_mat(N, g.T_pp, N, Q, ld);
+    __syncthreads();
+    wg_gemm<false>(N, El{t, ld, N}, El{Q, ld, N}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
+    __syncthreads();
+    wg_gemm<false>(N, El{t, ld, N}, El{P, ld, N}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+    __syncthreads();
+    wg_gemm<false>(N, El{Q, ld, N}, tmm, [=](int i, int j, double v) { Rpm[i + j * N] = v; });
+  } else {
+    // ---- ScatteringInterface_11 (interaction.jl:69-117)
+    wg_copy_mat(N, g.R_pm, N, c.P, ld);  // P = R+-
+    __syncthreads();
+    {
+      double *P = c.P, *Q = c.Q;
+      // Q = I - r-+ R+-                                        (:81)
+      wg_gemm<false>(N, El{r, ld, N}, El{P, ld, N},
+                     [=](int i, int j, double v) { Q[i + j * ld] = ((i == j) ? 1.0 : 0.0) - v; });
+      __syncthreads();
+    }
+    wg_inverse(N, c.Q, ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);  // :83
+    wg_copy_mat(N, g.T_mm, N, c.P, ld);                                     // P = T--
+    __syncthreads();
+    gemm_inplace_A<LDSM>(c, c.P, El{c.Q, ld, N});  // P = T01_inv = T-- inv   (:87)
+    // J0- = J0- + T01 (r-+ J0+ + j0-)                          (:90)
+    wg_matvec(c, El{r, ld, N}, c.Jp, c.v1);
+    for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
+    __syncthreads();
+    wg_matvec(c, El{c.P, ld, N}, c.v1, c.v2);
+    for (int i = threadIdx.x; i < N; i += kThreads) c.Jm[i] = c.Jm[i] + c.v2[i];
+    {
+      double *P = c.P, *Q = c.Q, *Tmm = g.T_mm, *Rmp = g.R_mp;
+      // T-- = T01 t--                                           (:96)
+      wg_gemm<false>(N, El{P, ld, N}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
+      // Q = T01 r-+
+      wg_gemm<false>(N, El{P, ld, N}, El{r, ld, N}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+      __syncthreads();
+      wg_copy_mat(N, g.T_pp, N, P, ld);  // P = T++ (old)
+      __syncthreads();
+      // R-+ = R-+ + (T01 r-+) T++                              (:93)
+      wg_gemm<false>(N, El{Q, ld, N}, El{P, ld, N},
+                     [=](int i, int j, double v) { Rmp[i + j * N] = Rmp[i + j * N] + v; });
+      __syncthreads();
+      wg_copy_mat(N, g.R_pm, N, Q, ld);  // Q = R+- (old)
+      __syncthreads();
+      // P = I - R+- r-+                                        (:104)
+      wg_gemm<false>(N, El{Q, ld, N}, El{r, ld, N},
+                     [=](int i, int j, double v) { P[i + j * ld] = ((i == j) ? 1.0 : 0.0) - v; });
+      __syncthreads();
+    }
+    wg_inverse(N, c.P, ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);  // :105
+    gemm_inplace_B<LDSM>(c, El{t, ld, N}, c.P);  // P = T21_inv = t++ inv     (:107)
+    // J0+ = j0+ + T21 (J0+ + R+- j0-)                          (:110)
+    wg_matvec(c, El{c.Q, ld, N}, c.jm, c.v1);
+    for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.Jp[i] + c.v1[i];
+    __syncthreads();
+    wg_matvec(c, El{c.P, ld, N}, c.v1, c.v2);
+    for (int i = threadIdx.x; i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.v2[i];
+    gemm_inplace_B<LDSM>(c, El{c.P, ld, N}, c.Q);  // Q = T21 R+-
+    {
+      double *P = c.P, *Q = c.Q, *Rpm = g.R_pm, *Tpp = g.T_pp;
+      // R+- = r+- + (T21 R+-) t--                              (:116)
+      wg_gemm<false>(N, El{Q, ld, N}, tmm, [=](int i, int j, double v) { Rpm[i + j * N] = rpm(i, j) + v; });
+      __syncthreads();
+      wg_copy_mat(N, g.T_pp, N, Q, ld);  // Q = T++ (old)
+      __syncthreads();
+      // T++ = T21 T++                                          (:113)
+      wg_gemm<false>(N, El{P, ld, N}, El{Q, ld, N}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += kThreads) {
+    g.J0p[i] = c.Jp[i];
+    g.J0m[i] = c.Jm[i];
+  }
+  __syncthreads();
+}
+
+// composite <- added (rt_kernel.jl:227-230) from the context
+__device__ __forceinline__ void store_added_as_composite(const Ctx &c, const CompPtrs &g) {
+  const int N = c.N, ld = c.ld;
+  for (int e = threadIdx.x; e < N * N; e += kThreads) {
+    const int j = e / N, i = e - j * N;
+    const double rv = c.r[i + j * ld], tv = c.t[i + j * ld], s = c.sg[i] * c.sg[j];
+    g.R_mp[e] = rv;
+    g.R_pm[e] = s * rv;
+    g.T_pp[e] = tv;
+    g.T_mm[e] = s * tv;
+  }
+  for (int i = threadIdx.x; i < N; i += kThreads) {
+    g.J0p[i] = c.jp[i];
+    g.J0m[i] = c.jm[i];
+  }
+}
+
+}  // namespace mom

@@ -1,0 +1,789 @@
+// momcore.hip -- __global__ kernels and the C ABI (include/momcore.h) of libmomcore.so.
+// gfx950 (MI355X) only.  See DESIGN.md for the data layout and the kernel inventory.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "momcore.h"
+#include "mom_kernels.hpp"
+
+using namespace mom;
+
+// =========================================================================================
+// kernels
+// =========================================================================================
+
+struct LayerArgs {
+  DevStreams q;
+  int S, M, K;
+  int nd, iface, first;
+  const double *tau, *varpi, *zw, *tau_sum;  // slices of layer z: tau[n], varpi[n], zw[k + K*n], tau_sum[n]
+  const double *Zpp, *Zmp;                   // [N,N,K,M]
+  double *comp[6];                           // R_mp, R_pm, T_pp, T_mm [N,N,S,M]; J0p, J0m [N,S,M]
+  double *scratch;                           // generic mode: per-workgroup slabs
+  int *info;
+};
+
+struct ZMix {
+  const double *base;  // Z[:,:,0,m]
+  const double *w;     // K weights of this point
+  int K, N;
+  __device__ __forceinline__ double operator()(int i, int j) const {
+    double acc = 0.0;
+    const size_t NN = (size_t)N * N;
+    for (int k = 0; k < K; ++k) acc += w[k] * base[i + (size_t)j * N + NN * k];
+    return acc;
+  }
+};
+
+__device__ __forceinline__ CompPtrs comp_ptrs(double *const comp[6], int N, size_t pt) {
+  const size_t NN = (size_t)N * N;
+  CompPtrs g;
+  g.R_mp = comp[0] + NN * pt;
+  g.R_pm = comp[1] + NN * pt;
+  g.T_pp = comp[2] + NN * pt;
+  g.T_mm = comp[3] + NN * pt;
+  g.J0p = comp[4] + (size_t)N * pt;
+  g.J0m = comp[5] + (size_t)N * pt;
+  return g;
+}
+
+extern __shared__ double mom_smem[];
+
+// One launch per atmospheric layer: every (spectral point, Fourier moment) pair runs
+// elemental -> nd doublings -> interaction with its composite state (rt_kernel!,
+// rt_kernel.jl:173-235) inside one workgroup; the added layer never touches HBM.
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads) k_layer(LayerArgs a) {
+  const int N = a.q.N;
+  const size_t total = (size_t)a.S * a.M;
+  Ctx c;
+  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
+  load_streams(c, a.q);
+  __syncthreads();
+  for (size_t pt = blockIdx.x; pt < total; pt += gridDim.x) {
+    const int n = (int)(pt % a.S), m = (int)(pt / a.S);
+    const double tau = a.tau[n], varpi = a.varpi[n];
+    const double dtau = ldexp(tau, -a.nd);       // τ ./ 2^ndoubl   (rt_kernel.jl:244)
+    double expk = exp(-dtau / a.q.mu0);          // init_layer      (rt_kernel.jl:273)
+    const size_t NN = (size_t)N * N;
+    ZMix zpp{a.Zpp + NN * a.K * m, a.zw + (size_t)a.K * n, a.K, N};
+    ZMix zmp{a.Zmp + NN * a.K * m, a.zw + (size_t)a.K * n, a.K, N};
+    elemental_build(c, a.q, m, a.nd, a.tau_sum[n], dtau, varpi, zpp, zmp);
+    expk = doubling_run<LDSM>(c, a.nd, expk);
+    CompPtrs g = comp_ptrs(a.comp, N, pt);
+    if (a.first) {
+      store_added_as_composite(c, g);
+      __syncthreads();
+    } else {
+      interaction_core<LDSM>(c, a.iface, g, ElSig{c.r, c.sg, c.ld, N}, ElSig{c.t, c.sg, c.ld, N});
+    }
+  }
+  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
+}
+
+struct SurfArgs {
+  DevStreams q;
+  int S, iface;
+  double albedo;
+  const double *tau_tot;  // [S]
+  double *comp[6];        // moment-0 slices
+  double *scratch;
+  int *info;
+};
+
+// Lambertian surface as an added layer (m = 0) + the closing interaction (rt_run.jl:169-185).
+// For m > 0 the surface layer is r = 0, t = I, j = 0 and the interaction is the identity on
+// every quantity post-processing reads, so no launch is made for those moments.
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads) k_surface(SurfArgs a) {
+  const int N = a.q.N, n = a.q.nS;
+  Ctx c;
+  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
+  load_streams(c, a.q);
+  __syncthreads();
+  const int ld = c.ld;
+  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
+    const double rho = 2 * a.albedo;                       // lambertian_surface.jl:37
+    const double att = exp(-a.tau_tot[pt] / a.q.mu0);
+    const int i_start = n * (a.q.imu0 - 1), i_end = n * a.q.imu0;
+    for (int e = threadIdx.x; e < N * N; e += kThreads) {
+      const int j = e / N, i = e - j * N;
+      c.r[i + j * ld] = ((i % n == 0) && (j % n == 0)) ? rho * (c.mu[j] * c.wt[j]) : 0.0;  // :41-43,:58
+      c.t[i + j * ld] = (i == j) ? 1.0 : 0.0;
+    }
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+      const bool in_sun = (i >= i_start) && (i < i_end);
+      c.jp[i] = (in_sun ? a.q.I0[i - i_start] : 0.0) * att;                 // :55
+      c.jm[i] = (i % n == 0) ? (a.q.mu0 * (rho * a.q.I0[0])) * att : 0.0;  // :56
+    }
+    __syncthreads();
+    CompPtrs g = comp_ptrs(a.comp, N, pt);
+    interaction_core<LDSM>(c, a.iface, g, ElZero{}, ElEye{N});
+  }
+  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
+}
+
+// postprocessing_vza! (postprocessing_vza.jl:9-60, SFI branch), all moments in m order.
+__global__ void k_postprocess(int N, int nS, int S, int M, int nVza, const int *node, const double *cos_mphi,
+                              const double *sin_mphi, const double *J0p, const double *J0m, double *R, double *T) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)nVza * nS * S;
+  if (idx >= total) return;
+  const int v = (int)(idx % nVza);
+  const int k = (int)((idx / nVza) % nS);
+  const size_t s = idx / ((size_t)nVza * nS);
+  const int row = (node[v] - 1) * nS + k;
+  double r = 0.0, t = 0.0;
+  for (int m = 0; m < M; ++m) {
+    const double weight = (m == 0) ? 0.5 : 1.0;
+    const double cs = weight * ((k < 2) ? cos_mphi[v + (size_t)nVza * m] : sin_mphi[v + (size_t)nVza * m]);
+    const size_t o = row + (size_t)N * (s + (size_t)S * m);
+    r += cs * J0m[o];
+    t += cs * J0p[o];
+  }
+  R[idx] = r;
+  T[idx] = t;
+}
+
+// ---------------------------------------------------------------- operator-level kernels
+
+struct OpArgs {
+  DevStreams q;
+  int S, m, nd, iface, z_batch;
+  const double *tau_sum, *dtau, *varpi, *Zpp, *Zmp;
+  double *expk;
+  double *added[6];  // r_pm, r_mp, t_mm, t_pp, j0p, j0m
+  double *comp[6];
+  double *scratch;
+  int *info;
+};
+
+__device__ __forceinline__ void store_added(const Ctx &c, double *const added[6], size_t pt, bool with_mirror) {
+  const int N = c.N, ld = c.ld;
+  const size_t NN = (size_t)N * N;
+  for (int e = threadIdx.x; e < N * N; e += kThreads) {
+    const int j = e / N, i = e - j * N;
+    const double rv = c.r[i + j * ld], tv = c.t[i + j * ld];
+    added[1][NN * pt + e] = rv;
+    added[3][NN * pt + e] = tv;
+    if (with_mirror) {
+      const double s = c.sg[i] * c.sg[j];
+      added[0][NN * pt + e] = s * rv;
+      added[2][NN * pt + e] = s * tv;
+    }
+  }
+  for (int i = threadIdx.x; i < N; i += kThreads) {
+    added[4][(size_t)N * pt + i] = c.jp[i];
+    added[5][(size_t)N * pt + i] = c.jm[i];
+  }
+}
+
+__device__ __forceinline__ void load_added(const Ctx &c, double *const added[6], size_t pt) {
+  const int N = c.N, ld = c.ld;
+  const size_t NN = (size_t)N * N;
+  for (int e = threadIdx.x; e < N * N; e += kThreads) {
+    const int j = e / N, i = e - j * N;
+    c.r[i + j * ld] = added[1][NN * pt + e];
+    c.t[i + j * ld] = added[3][NN * pt + e];
+  }
+  for (int i = threadIdx.x; i < N; i += kThreads) {
+    c.jp[i] = added[4][(size_t)N * pt + i];
+    c.jm[i] = added[5][(size_t)N * pt + i];
+  }
+}
+
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads) k_op_elemental(OpArgs a) {
+  const int N = a.q.N;
+  Ctx c;
+  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
+  load_streams(c, a.q);
+  __syncthreads();
+  const size_t NN = (size_t)N * N;
+  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
+    const size_t zo = a.z_batch > 1 ? NN * pt : 0;
+    El zpp{a.Zpp + zo, N, N}, zmp{a.Zmp + zo, N, N};
+    elemental_build(c, a.q, a.m, a.nd, a.tau_sum[pt], a.dtau[pt], a.varpi[pt], zpp, zmp);
+    // the reference leaves r+-/t-- untouched when nd >= 1 (elemental.jl:255-274)
+    store_added(c, a.added, pt, a.nd < 1);
+    __syncthreads();
+  }
+}
+
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads) k_op_doubling(OpArgs a) {
+  const int N = a.q.N;
+  Ctx c;
+  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
+  load_streams(c, a.q);
+  __syncthreads();
+  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
+    load_added(c, a.added, pt);
+    __syncthreads();
+    const double e = doubling_run<LDSM>(c, a.nd, a.expk[pt]);
+    if (threadIdx.x == 0) a.expk[pt] = e;
+    store_added(c, a.added, pt, true);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
+}
+
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads) k_op_interaction(OpArgs a) {
+  const int N = a.q.N;
+  Ctx c;
+  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
+  load_streams(c, a.q);
+  __syncthreads();
+  const size_t NN = (size_t)N * N;
+  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
+    load_added(c, a.added, pt);
+    __syncthreads();
+    CompPtrs g = comp_ptrs(a.comp, N, pt);
+    interaction_core<LDSM>(c, a.iface, g, El{a.added[0] + NN * pt, N, N}, El{a.added[2] + NN * pt, N, N});
+  }
+  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
+}
+
+// surface layer arrays for the operator-level API (lambertian_surface.jl:20-75)
+__global__ void k_op_surface_fill(DevStreams q, int S, int m, double albedo, const double *tau_tot, double *r_pm,
+                                  double *r_mp, double *t_mm, double *t_pp, double *j0p, double *j0m) {
+  const int N = q.N, n = q.nS;
+  const size_t NN = (size_t)N * N;
+  const size_t pt = blockIdx.x;
+  const double rho = 2 * albedo;
+  const double att = exp(-tau_tot[pt] / q.mu0);
+  const int i_start = n * (q.imu0 - 1), i_end = n * q.imu0;
+  for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+    const int j = e / N, i = e - j * N;
+    r_mp[NN * pt + e] = (m == 0 && (i % n == 0) && (j % n == 0)) ? rho * (q.mu[j] * q.wt[j]) : 0.0;
+    if (m == 0) r_pm[NN * pt + e] = 0.0;  // not reset for m > 0 (:68-73)
+    t_pp[NN * pt + e] = (i == j) ? 1.0 : 0.0;
+    t_mm[NN * pt + e] = (i == j) ? 1.0 : 0.0;
+  }
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const bool in_sun = (i >= i_start) && (i < i_end);
+    j0p[(size_t)N * pt + i] = (m == 0) ? (in_sun ? q.I0[i - i_start] : 0.0) * att : 0.0;
+    j0m[(size_t)N * pt + i] = (m == 0 && (i % n == 0)) ? (q.mu0 * (rho * q.I0[0])) * att : 0.0;
+  }
+}
+
+struct BlasArgs {
+  int N, S;
+  const double *A, *B;
+  double *C;
+  double *scratch;
+  int *info;
+};
+
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads) k_batch_inv(BlasArgs a) {
+  const int N = a.N;
+  Ctx c;
+  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
+  if (threadIdx.x == 0) *c.bad = 0;
+  __syncthreads();
+  const size_t NN = (size_t)N * N;
+  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
+    wg_copy_mat(N, a.A + NN * pt, N, c.P, c.ld);
+    __syncthreads();
+    wg_inverse(N, c.P, c.ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);
+    wg_copy_mat(N, c.P, c.ld, a.C + NN * pt, N);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
+}
+
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads) k_batched_mul(BlasArgs a) {
+  const int N = a.N;
+  Ctx c;
+  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
+  const size_t NN = (size_t)N * N;
+  const int ld = c.ld;
+  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
+    wg_copy_mat(N, a.A + NN * pt, N, c.P, ld);
+    wg_copy_mat(N, a.B + NN * pt, N, c.Q, ld);
+    __syncthreads();
+    double *C = a.C + NN * pt;
+    wg_gemm<false>(N, El{c.P, ld, N}, El{c.Q, ld, N}, [=](int i, int j, double v) { C[i + (size_t)j * N] = v; });
+    __syncthreads();
+  }
+}
+
+// =========================================================================================
+// host side
+// =========================================================================================
+
+static thread_local std::string g_err;
+
+struct mom_handle {
+  int device = 0, N = 0, nS = 0, S = 0, M = 0;
+  bool lds_mode = true;
+  int opt_inverse = 0, opt_force_generic = 0;
+  hipStream_t stream = nullptr;
+  double *d_mu = nullptr, *d_wt = nullptr, *d_sg = nullptr;
+  DevStreams q{};
+  bool streams_set = false;
+  double *added[6] = {}, *surf[6] = {}, *comp[6] = {};
+  double *d_vec[4] = {};  // S-length temporaries (tau_sum, dtau, varpi, expk)
+  double *d_Zop[2] = {};
+  size_t Zop_cap = 0;
+  // scene
+  int Nz = 0, K = 0, nVza = 0, scene_M = 0;
+  double *d_tau = nullptr, *d_varpi = nullptr, *d_zw = nullptr, *d_Zpp = nullptr, *d_Zmp = nullptr,
+         *d_tau_sum = nullptr, *d_cos = nullptr, *d_sin = nullptr, *d_R = nullptr, *d_T = nullptr;
+  int *d_node = nullptr;
+  std::vector<int> nd, iface;
+  double albedo = 0.0;
+  bool scene_set = false;
+  double *d_scratch = nullptr;
+  int G = 0;  // workgroups in generic mode
+  int *d_info = nullptr;
+  hipEvent_t ev[4] = {};
+  int launches = 0;
+  std::string err;
+};
+
+#define HIPCHK(h, call)                                                                            \
+  do {                                                                                             \
+    hipError_t e__ = (call);                                                                       \
+    if (e__ != hipSuccess) {                                                                       \
+      char buf__[512];                                                                             \
+      snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      if (h) (h)->err = buf__;                                                                     \
+      g_err = buf__;                                                                               \
+      return MOM_EHIP;                                                                             \
+    }                                                                                              \
+  } while (0)
+
+static int fail(mom_t *h, int code, const char *msg) {
+  if (h) h->err = msg;
+  g_err = msg;
+  return code;
+}
+
+template <class T>
+static hipError_t dmalloc(T **p, size_t count) {
+  return hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
+}
+
+static size_t smem_bytes(const mom_t *h) { return lds_bytes(h->N, h->lds_mode); }
+
+template <class K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes);
+}
+
+extern "C" const char *mom_last_global_error(void) { return g_err.c_str(); }
+extern "C" const char *mom_last_error(const mom_t *h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+extern "C" int mom_create(mom_t **out, int device, int N, int nStokes, int S, int max_m, int dtype) {
+  if (!out || N <= 0 || S <= 0 || max_m <= 0 || nStokes <= 0 || nStokes > 4 || N % nStokes != 0)
+    return fail(nullptr, MOM_EINVAL, "mom_create: bad argument");
+  if (dtype != 0) return fail(nullptr, MOM_EINVAL, "mom_create: only dtype 0 (Float64) is implemented");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return fail(nullptr, MOM_EHIP, "mom_create: no HIP device available");
+  if (device < 0 || device >= ndev) return fail(nullptr, MOM_EINVAL, "mom_create: device index out of range");
+  mom_t *h = new mom_t();
+  h->device = device; h->N = N; h->nS = nStokes; h->S = S; h->M = max_m;
+  h->lds_mode = (N <= 64);
+  *out = h;
+  HIPCHK(h, hipSetDevice(device));
+  HIPCHK(h, hipStreamCreate(&h->stream));
+  const size_t NN = (size_t)N * N;
+  HIPCHK(h, dmalloc(&h->d_mu, N));
+  HIPCHK(h, dmalloc(&h->d_wt, N));
+  HIPCHK(h, dmalloc(&h->d_sg, N));
+  for (int k = 0; k < 6; ++k) {
+    const size_t per = (k < 4) ? NN : (size_t)N;
+    HIPCHK(h, dmalloc(&h->added[k], per * S));
+    HIPCHK(h, dmalloc(&h->surf[k], per * S));
+    HIPCHK(h, dmalloc(&h->comp[k], per * S * max_m));
+    HIPCHK(h, hipMemsetAsync(h->added[k], 0, per * S * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->surf[k], 0, per * S * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->comp[k], 0, per * S * max_m * sizeof(double), h->stream));
+  }
+  for (int k = 0; k < 4; ++k) HIPCHK(h, dmalloc(&h->d_vec[k], S));
+  HIPCHK(h, dmalloc(&h->d_info, 1));
+  HIPCHK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+  h->G = 1024;
+  HIPCHK(h, dmalloc(&h->d_scratch, (size_t)h->G * 5 * N * ld_for(N)));
+  for (int k = 0; k < 4; ++k) HIPCHK(h, hipEventCreate(&h->ev[k]));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_destroy(mom_t *h) {
+  if (!h) return MOM_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  auto fr = [](void *p) { if (p) (void)hipFree(p); };
+  fr(h->d_mu); fr(h->d_wt); fr(h->d_sg);
+  for (int k = 0; k < 6; ++k) { fr(h->added[k]); fr(h->surf[k]); fr(h->comp[k]); }
+  for (int k = 0; k < 4; ++k) fr(h->d_vec[k]);
+  fr(h->d_Zop[0]); fr(h->d_Zop[1]);
+  fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
+  fr(h->d_R); fr(h->d_T); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
+  for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return MOM_OK;
+}
+
+extern "C" int mom_sync(mom_t *h) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_set_option(mom_t *h, int option, int value) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (option == MOM_OPT_INVERSE) h->opt_inverse = value;
+  else if (option == MOM_OPT_FORCE_GENERIC) {
+    h->opt_force_generic = value;
+    h->lds_mode = (h->N <= 64) && !value;
+  } else return fail(h, MOM_EINVAL, "mom_set_option: unknown option");
+  return MOM_OK;
+}
+
+extern "C" int mom_set_streams(mom_t *h, const double *qp_muN, const double *wt_muN, int N, int imu0_1based, double mu0,
+                               const double *I0, const double *D, int strict) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (N != h->N || !qp_muN || !wt_muN || !I0 || !D || imu0_1based < 1 || imu0_1based * h->nS > N)
+    return fail(h, MOM_EINVAL, "mom_set_streams: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<double> sg(N);
+  for (int i = 0; i < N; ++i) {
+    const int comp = strict ? ((i + 1) % h->nS) : (i % h->nS) + 1;
+    sg[i] = (comp > 2) ? -1.0 : 1.0;
+  }
+  HIPCHK(h, hipMemcpyAsync(h->d_mu, qp_muN, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_wt, wt_muN, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_sg, sg.data(), N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  DevStreams &q = h->q;
+  q.mu = h->d_mu; q.wt = h->d_wt; q.sg = h->d_sg;
+  for (int k = 0; k < 4; ++k) { q.I0[k] = (k < h->nS) ? I0[k] : 0.0; q.D[k] = (k < h->nS) ? D[k] : 1.0; }
+  q.N = N; q.nS = h->nS; q.imu0 = imu0_1based; q.mu0 = mu0;
+  h->streams_set = true;
+  return MOM_OK;
+}
+
+static int grid_for(const mom_t *h, size_t total) {
+  if (h->lds_mode) return (int)total;
+  return (int)std::min<size_t>(total, (size_t)h->G);
+}
+
+static int check_info(mom_t *h) {
+  int info = 0;
+  HIPCHK(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (info) {
+    HIPCHK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    char buf[128];
+    snprintf(buf, sizeof buf, "zero pivot at elimination step %d while inverting (I - R r)", info);
+    return fail(h, MOM_ESINGULAR, buf);
+  }
+  return MOM_OK;
+}
+
+#define LAUNCH(h, KERN, grid, args)                                                       \
+  do {                                                                                    \
+    const size_t sm__ = smem_bytes(h);                                                    \
+    if ((h)->lds_mode) {                                                                  \
+      HIPCHK(h, allow_lds(KERN<true>, sm__));                                             \
+      hipLaunchKernelGGL(KERN<true>, dim3(grid), dim3(kThreads), sm__, (h)->stream, args); \
+    } else {                                                                              \
+      HIPCHK(h, allow_lds(KERN<false>, sm__));                                            \
+      hipLaunchKernelGGL(KERN<false>, dim3(grid), dim3(kThreads), sm__, (h)->stream, args); \
+    }                                                                                     \
+    HIPCHK(h, hipGetLastError());                                                         \
+  } while (0)
+
+extern "C" int mom_elemental(mom_t *h, int m, int ndoubl, const double *tau_sum, const double *dtau, const double *varpi,
+                             const double *Zpp, const double *Zmp, int z_batch) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_elemental: call mom_set_streams first");
+  if (!tau_sum || !dtau || !varpi || !Zpp || !Zmp || (z_batch != 1 && z_batch != h->S) || m < 0 || ndoubl < 0)
+    return fail(h, MOM_EINVAL, "mom_elemental: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t NN = (size_t)h->N * h->N, zc = NN * z_batch;
+  if (zc > h->Zop_cap) {
+    if (h->d_Zop[0]) { (void)hipFree(h->d_Zop[0]); (void)hipFree(h->d_Zop[1]); }
+    HIPCHK(h, dmalloc(&h->d_Zop[0], zc));
+    HIPCHK(h, dmalloc(&h->d_Zop[1], zc));
+    h->Zop_cap = zc;
+  }
+  const size_t sb = (size_t)h->S * sizeof(double);
+  HIPCHK(h, hipMemcpyAsync(h->d_vec[0], tau_sum, sb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_vec[1], dtau, sb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_vec[2], varpi, sb, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_Zop[0], Zpp, zc * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->d_Zop[1], Zmp, zc * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  OpArgs a{};
+  a.q = h->q; a.S = h->S; a.m = m; a.nd = ndoubl; a.z_batch = z_batch;
+  a.tau_sum = h->d_vec[0]; a.dtau = h->d_vec[1]; a.varpi = h->d_vec[2]; a.Zpp = h->d_Zop[0]; a.Zmp = h->d_Zop[1];
+  for (int k = 0; k < 6; ++k) a.added[k] = h->added[k];
+  a.scratch = h->d_scratch; a.info = h->d_info;
+  LAUNCH(h, k_op_elemental, grid_for(h, h->S), a);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_doubling(mom_t *h, int ndoubl, double *expk) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_doubling: call mom_set_streams first");
+  if (!expk || ndoubl < 0) return fail(h, MOM_EINVAL, "mom_doubling: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t sb = (size_t)h->S * sizeof(double);
+  HIPCHK(h, hipMemcpyAsync(h->d_vec[3], expk, sb, hipMemcpyHostToDevice, h->stream));
+  OpArgs a{};
+  a.q = h->q; a.S = h->S; a.nd = ndoubl; a.expk = h->d_vec[3];
+  for (int k = 0; k < 6; ++k) a.added[k] = h->added[k];
+  a.scratch = h->d_scratch; a.info = h->d_info;
+  if (ndoubl > 0) LAUNCH(h, k_op_doubling, grid_for(h, h->S), a);  // doubling.jl:28 returns early for 0
+  HIPCHK(h, hipMemcpyAsync(expk, h->d_vec[3], sb, hipMemcpyDeviceToHost, h->stream));
+  return check_info(h);
+}
+
+extern "C" int mom_interaction(mom_t *h, int iface, int with_surface_layer) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_interaction: call mom_set_streams first");
+  if (iface < 0 || iface > 3) return fail(h, MOM_EINVAL, "mom_interaction: iface must be 0..3");
+  HIPCHK(h, hipSetDevice(h->device));
+  OpArgs a{};
+  a.q = h->q; a.S = h->S; a.iface = iface;
+  for (int k = 0; k < 6; ++k) { a.added[k] = with_surface_layer ? h->surf[k] : h->added[k]; a.comp[k] = h->comp[k]; }
+  a.scratch = h->d_scratch; a.info = h->d_info;
+  LAUNCH(h, k_op_interaction, grid_for(h, h->S), a);
+  return check_info(h);
+}
+
+extern "C" int mom_copy_added_to_composite(mom_t *h) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t NN = (size_t)h->N * h->N;
+  // composite order: R_mp, R_pm, T_pp, T_mm, J0p, J0m ; added order: r_pm, r_mp, t_mm, t_pp, j0p, j0m
+  const int src[6] = {1, 0, 3, 2, 4, 5};
+  for (int k = 0; k < 6; ++k) {
+    const size_t bytes = ((k < 4) ? NN : (size_t)h->N) * h->S * sizeof(double);
+    HIPCHK(h, hipMemcpyAsync(h->comp[k], h->added[src[k]], bytes, hipMemcpyDeviceToDevice, h->stream));
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_surface_lambertian(mom_t *h, int m, double albedo, const double *tau_tot) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_surface_lambertian: call mom_set_streams first");
+  if (!tau_tot || m < 0) return fail(h, MOM_EINVAL, "mom_surface_lambertian: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(h->d_vec[0], tau_tot, (size_t)h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_op_surface_fill, dim3(h->S), dim3(256), 0, h->stream, h->q, h->S, m, albedo, h->d_vec[0],
+                     h->surf[0], h->surf[1], h->surf[2], h->surf[3], h->surf[4], h->surf[5]);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+static double *which_ptr(mom_t *h, int which, size_t *count) {
+  const size_t NN = (size_t)h->N * h->N;
+  if (which < 0 || which > 17) return nullptr;
+  const int grp = which / 6, k = which % 6;
+  *count = ((k < 4) ? NN : (size_t)h->N) * h->S;
+  return grp == 0 ? h->added[k] : (grp == 1 ? h->comp[k] : h->surf[k]);
+}
+
+extern "C" int mom_upload(mom_t *h, int which, const double *src) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  size_t count = 0;
+  double *p = which_ptr(h, which, &count);
+  if (!p || !src) return fail(h, MOM_EINVAL, "mom_upload: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(p, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_download(mom_t *h, int which, double *dst) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  size_t count = 0;
+  double *p = which_ptr(h, which, &count);
+  if (!p || !dst) return fail(h, MOM_EINVAL, "mom_download: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(dst, p, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+static int blas_common(mom_t *h, int n, int batch, const double *A, const double *B, double *C, bool inv) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (n <= 0 || batch <= 0 || !A || !C || (!inv && !B)) return fail(h, MOM_EINVAL, "batched op: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t cnt = (size_t)n * n * batch;
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr, *scr = nullptr;
+  HIPCHK(h, dmalloc(&dA, cnt));
+  HIPCHK(h, dmalloc(&dC, cnt));
+  HIPCHK(h, hipMemcpyAsync(dA, A, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (!inv) {
+    HIPCHK(h, dmalloc(&dB, cnt));
+    HIPCHK(h, hipMemcpyAsync(dB, B, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  const bool lds = n <= 64 && !h->opt_force_generic;
+  const int grid = lds ? batch : std::min(batch, 1024);
+  if (!lds) HIPCHK(h, dmalloc(&scr, (size_t)grid * 5 * n * ld_for(n)));
+  BlasArgs a{n, batch, dA, dB, dC, scr, h->d_info};
+  const size_t sm = lds_bytes(n, lds);
+  if (inv) {
+    if (lds) { HIPCHK(h, allow_lds(k_batch_inv<true>, sm)); hipLaunchKernelGGL(k_batch_inv<true>, dim3(grid), dim3(kThreads), sm, h->stream, a); }
+    else { HIPCHK(h, allow_lds(k_batch_inv<false>, sm)); hipLaunchKernelGGL(k_batch_inv<false>, dim3(grid), dim3(kThreads), sm, h->stream, a); }
+  } else {
+    if (lds) { HIPCHK(h, allow_lds(k_batched_mul<true>, sm)); hipLaunchKernelGGL(k_batched_mul<true>, dim3(grid), dim3(kThreads), sm, h->stream, a); }
+    else { HIPCHK(h, allow_lds(k_batched_mul<false>, sm)); hipLaunchKernelGGL(k_batched_mul<false>, dim3(grid), dim3(kThreads), sm, h->stream, a); }
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(C, dC, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  (void)hipFree(dA); (void)hipFree(dC);
+  if (dB) (void)hipFree(dB);
+  if (scr) (void)hipFree(scr);
+  return inv ? check_info(h) : MOM_OK;
+}
+
+extern "C" int mom_batch_inv(mom_t *h, int n, int batch, const double *A, double *X) {
+  return blas_common(h, n, batch, A, nullptr, X, true);
+}
+extern "C" int mom_batched_mul(mom_t *h, int n, int batch, const double *A, const double *B, double *C) {
+  return blas_common(h, n, batch, A, B, C, false);
+}
+
+// ---------------------------------------------------------------- scene-level
+
+template <class T>
+static int upload_new(mom_t *h, T **dst, const T *src, size_t count) {
+  if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+  HIPCHK(h, dmalloc(dst, count));
+  HIPCHK(h, hipMemcpyAsync(*dst, src, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
+                             const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface,
+                             const double *tau_sum, double albedo, int nVza, const int *node_1based,
+                             const double *cos_mphi, const double *sin_mphi) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_scene_set: call mom_set_streams first");
+  if (Nz <= 0 || K <= 0 || M <= 0 || M > h->M || nVza <= 0 || !tau || !varpi || !zw || !Zpp || !Zmp || !ndoubl ||
+      !iface || !tau_sum || !node_1based || !cos_mphi || !sin_mphi)
+    return fail(h, MOM_EINVAL, "mom_scene_set: bad argument");
+  for (int z = 0; z < Nz; ++z)
+    if (ndoubl[z] < 0 || ndoubl[z] > 60 || iface[z] < 0 || iface[z] > 3)
+      return fail(h, MOM_EINVAL, "mom_scene_set: ndoubl/iface out of range");
+  for (int v = 0; v < nVza; ++v)
+    if (node_1based[v] < 1 || node_1based[v] * h->nS > h->N) return fail(h, MOM_EINVAL, "mom_scene_set: bad view node");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t S = h->S, NN = (size_t)h->N * h->N;
+  int rc;
+  if ((rc = upload_new(h, &h->d_tau, tau, S * Nz))) return rc;
+  if ((rc = upload_new(h, &h->d_varpi, varpi, S * Nz))) return rc;
+  if ((rc = upload_new(h, &h->d_zw, zw, (size_t)K * S * Nz))) return rc;
+  if ((rc = upload_new(h, &h->d_Zpp, Zpp, NN * K * M))) return rc;
+  if ((rc = upload_new(h, &h->d_Zmp, Zmp, NN * K * M))) return rc;
+  if ((rc = upload_new(h, &h->d_tau_sum, tau_sum, S * (Nz + 1)))) return rc;
+  if ((rc = upload_new(h, &h->d_node, node_1based, (size_t)nVza))) return rc;
+  if ((rc = upload_new(h, &h->d_cos, cos_mphi, (size_t)nVza * M))) return rc;
+  if ((rc = upload_new(h, &h->d_sin, sin_mphi, (size_t)nVza * M))) return rc;
+  if (h->d_R) { (void)hipFree(h->d_R); (void)hipFree(h->d_T); h->d_R = h->d_T = nullptr; }
+  HIPCHK(h, dmalloc(&h->d_R, (size_t)nVza * h->nS * S));
+  HIPCHK(h, dmalloc(&h->d_T, (size_t)nVza * h->nS * S));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->Nz = Nz; h->K = K; h->scene_M = M; h->nVza = nVza; h->albedo = albedo;
+  h->nd.assign(ndoubl, ndoubl + Nz);
+  h->iface.assign(iface, iface + Nz);
+  h->scene_set = true;
+  return MOM_OK;
+}
+
+extern "C" int mom_rt_run(mom_t *h) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_rt_run: call mom_scene_set first");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t S = h->S;
+  const int M = h->scene_M;
+  h->launches = 0;
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  for (int z = 0; z < h->Nz; ++z) {
+    LayerArgs a{};
+    a.q = h->q; a.S = h->S; a.M = M; a.K = h->K;
+    a.nd = h->nd[z]; a.iface = h->iface[z]; a.first = (z == 0);
+    a.tau = h->d_tau + S * z; a.varpi = h->d_varpi + S * z; a.zw = h->d_zw + (size_t)h->K * S * z;
+    a.tau_sum = h->d_tau_sum + S * z;
+    a.Zpp = h->d_Zpp; a.Zmp = h->d_Zmp;
+    for (int k = 0; k < 6; ++k) a.comp[k] = h->comp[k];
+    a.scratch = h->d_scratch; a.info = h->d_info;
+    LAUNCH(h, k_layer, grid_for(h, S * M), a);
+    h->launches++;
+  }
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  {
+    SurfArgs a{};
+    a.q = h->q; a.S = h->S; a.iface = h->iface[h->Nz - 1];  // Q6: last layer's interface code (rt_run.jl:181)
+    a.albedo = h->albedo; a.tau_tot = h->d_tau_sum + S * h->Nz;
+    for (int k = 0; k < 6; ++k) a.comp[k] = h->comp[k];
+    a.scratch = h->d_scratch; a.info = h->d_info;
+    LAUNCH(h, k_surface, grid_for(h, S), a);
+  }
+  HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+  {
+    const size_t total = (size_t)h->nVza * h->nS * S;
+    hipLaunchKernelGGL(k_postprocess, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->N, h->nS, h->S,
+                       M, h->nVza, h->d_node, h->d_cos, h->d_sin, h->comp[4], h->comp[5], h->d_R, h->d_T);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_get_RT(mom_t *h, double *R_SFI, double *T_SFI) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->scene_set || !R_SFI || !T_SFI) return fail(h, MOM_ESTATE, "mom_get_RT: no scene / null output");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->nVza * h->nS * h->S * sizeof(double);
+  HIPCHK(h, hipMemcpyAsync(R_SFI, h->d_R, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(T_SFI, h->d_T, bytes, hipMemcpyDeviceToHost, h->stream));
+  return check_info(h);
+}
+
+extern "C" int mom_get_RT_device(mom_t *h, void *dR, void *dT) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->scene_set || !dR || !dT) return fail(h, MOM_ESTATE, "mom_get_RT_device: no scene / null output");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->nVza * h->nS * h->S * sizeof(double);
+  HIPCHK(h, hipMemcpyAsync(dR, h->d_R, bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dT, h->d_T, bytes, hipMemcpyDeviceToDevice, h->stream));
+  return check_info(h);
+}
+
+extern "C" int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!ms || n < 4) return fail(h, MOM_EINVAL, "mom_timers: need room for 4 values");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventSynchronize(h->ev[3]));
+  float t01, t12, t23, t03;
+  HIPCHK(h, hipEventElapsedTime(&t01, h->ev[0], h->ev[1]));
+  HIPCHK(h, hipEventElapsedTime(&t12, h->ev[1], h->ev[2]));
+  HIPCHK(h, hipEventElapsedTime(&t23, h->ev[2], h->ev[3]));
+  HIPCHK(h, hipEventElapsedTime(&t03, h->ev[0], h->ev[3]));
+  ms[0] = t01; ms[1] = t12; ms[2] = t23; ms[3] = t03;
+  if (kernel_launches) *kernel_launches = h->launches;
+  return MOM_OK;
+}
