@@ -1,12 +1,15 @@
 // mom_device.hpp -- workgroup-level building blocks of the MI355X Matrix-Operator core.
 //
-// Execution model: ONE WORKGROUP (4 wavefronts of 64 lanes) owns ONE spectral point of ONE
-// Fourier moment.  Its N x N operators (N = nStokes*Nquad) live in LDS (N <= 64, "LDS mode")
-// or in a per-workgroup global scratch slab (N > 64, "generic mode"); all dense products run
-// on the FP64 matrix cores (v_mfma_f64_16x16x4_f64, 16x16 output tile per wave, K step 4);
-// (I - R r)^-1 is a pivoted Gauss-Jordan inverse held in the same memory (later rounds:
-// blocked).  Matrices are column-major with leading dimension ld (ld % 32 in {2,30} keeps the
-// MFMA B-operand reads bank-conflict free and the A-operand reads 2-way).
+// Execution model: ONE WORKGROUP (kWaves wavefronts of 64 lanes) owns ONE spectral point of
+// ONE Fourier moment.  Its N x N operators (N = nStokes*Nquad) live in LDS (N <= 64, "LDS
+// mode") or in a per-workgroup global scratch slab (N > 64, "generic mode").  All dense
+// products run on the FP64 matrix cores (v_mfma_f64_16x16x4_f64: 16x16 output tile per wave,
+// K step 4, 64 cycles per instruction per SIMD -> 77 TFLOP/s measured on MI355X).
+//
+// Buffers are column-major with leading dimension ld = Np + 2 and Np = 16*ceil(N/16) columns;
+// rows/columns >= N are ZERO and stay zero (every store is guarded), so the MFMA operand loads
+// need no bounds checks.  ld % 32 in {2, 18} keeps the B-operand ds_read_b64 conflict-free
+// and the A-operand reads 2-way.
 //
 // MFMA f64 16x16x4 operand maps (cdna_hip_programming.md section 3): lane l holds
 //   A[row = l & 15][k = l >> 4],  B[k = l >> 4][col = l & 15],
@@ -18,15 +21,69 @@ namespace mom {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 256;
-constexpr int kWaves = 4;
-constexpr int kTJ = 4;  // column tiles processed together by one wave (shares the A operand)
+#ifndef MOM_WAVES
+#define MOM_WAVES 4
+#endif
+constexpr int kWaves = MOM_WAVES;
+constexpr int kThreads = 64 * kWaves;
+constexpr int kTJ = 16 / kWaves;  // column tiles per work item: 4 waves x 4 tiles or 8 x 2 cover N <= 64
+
+// e -> (i = e % N, j = e / N) without an integer division (valid for e*N < 2^32)
+struct FastDiv {
+  unsigned magic;
+  int N;
+  __device__ __forceinline__ void init(int n) { N = n; magic = (unsigned)((0x100000000ull + (unsigned)n - 1u) / (unsigned)n); }
+  __device__ __forceinline__ void split(int e, int &i, int &j) const {
+    j = (int)__umulhi((unsigned)e, magic);
+    i = e - j * N;
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// one K chunk: C k-steps, operands loaded first (all loads in flight), then C*kTJ MFMAs
+// ---------------------------------------------------------------------------------------
+template <int C, class FA, class FB>
+__device__ __forceinline__ void kchunk(int ks0, int row, int lq, int col0, FA A, FB B, d4 (&acc)[kTJ]) {
+  double a[C], b[C][kTJ];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = 4 * (ks0 + c) + lq;
+    a[c] = A(row, k);
+#pragma unroll
+    for (int t = 0; t < kTJ; ++t) b[c][t] = B(k, col0 + 16 * t);
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int t = 0; t < kTJ; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c], b[c][t], acc[t], 0, 0, 0);
+}
+
+template <int C, class FA1, class FA2, class FB>
+__device__ __forceinline__ void kchunk2(int ks0, int row, int lq, int col0, FA1 A1, FA2 A2, FB B, d4 (&acc1)[kTJ],
+                                        d4 (&acc2)[kTJ]) {
+  double a1[C], a2[C], b[C][kTJ];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int k = 4 * (ks0 + c) + lq;
+    a1[c] = A1(row, k);
+    a2[c] = A2(row, k);
+#pragma unroll
+    for (int t = 0; t < kTJ; ++t) b[c][t] = B(k, col0 + 16 * t);
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int t = 0; t < kTJ; ++t) {
+      acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[c], b[c][t], acc1[t], 0, 0, 0);
+      acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[c], b[c][t], acc2[t], 0, 0, 0);
+    }
+}
 
 // ---------------------------------------------------------------------------------------
 // C(i,j) <- epi(i, j, sum_k A(i,k) B(k,j)) for an N x N product.
-// A(i,k), B(k,j): element functors (any memory space; must return 0 outside [0,N)).
-// SYNC: all waves finish reading their operands before any wave stores (allows the output
-// to alias an operand).  Requires at most one work item per wave, i.e. N <= 64.
+// A(i,k), B(k,j): element functors valid (and zero) on the whole padded index range.
+// SYNC: all waves finish reading their operands before any wave stores (the output may
+// alias an operand).  Requires at most one work item per wave, i.e. N <= 64.
 // ---------------------------------------------------------------------------------------
 template <bool SYNC, class FA, class FB, class FE>
 __device__ __forceinline__ void wg_gemm(int N, FA A, FB B, FE epi) {
@@ -43,17 +100,13 @@ __device__ __forceinline__ void wg_gemm(int N, FA A, FB B, FE epi) {
 #pragma unroll
     for (int t = 0; t < kTJ; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
     if (have) {
-      const int row = 16 * ti + lr;
-#pragma unroll 4
-      for (int ks = 0; ks < ksteps; ++ks) {
-        const int k = 4 * ks + lq;
-        const double a = A(row, k);
-#pragma unroll
-        for (int t = 0; t < kTJ; ++t) {
-          const double b = B(k, 16 * (cg * kTJ + t) + lr);
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-        }
-      }
+      const int row = 16 * ti + lr, col0 = 16 * cg * kTJ + lr;
+      int ks = 0;
+      for (; ks + 4 <= ksteps; ks += 4) kchunk<4>(ks, row, lq, col0, A, B, acc);
+      const int rem = ksteps - ks;
+      if (rem == 3) kchunk<3>(ks, row, lq, col0, A, B, acc);
+      else if (rem == 2) kchunk<2>(ks, row, lq, col0, A, B, acc);
+      else if (rem == 1) kchunk<1>(ks, row, lq, col0, A, B, acc);
     }
     if (SYNC) __syncthreads();
     if (have) {
@@ -70,7 +123,7 @@ __device__ __forceinline__ void wg_gemm(int N, FA A, FB B, FE epi) {
   }
 }
 
-// Two products sharing the B operand: C1 = A1*B, C2 = A2*B (e.g. r += (A r) t and t = A t).
+// Two products sharing the B operand: C1 = A1*B, C2 = A2*B (r += (A r) t and t = A t).
 template <bool SYNC, class FA1, class FA2, class FB, class FE1, class FE2>
 __device__ __forceinline__ void wg_gemm2(int N, FA1 A1, FA2 A2, FB B, FE1 epi1, FE2 epi2) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -86,19 +139,10 @@ __device__ __forceinline__ void wg_gemm2(int N, FA1 A1, FA2 A2, FB B, FE1 epi1, 
 #pragma unroll
     for (int t = 0; t < kTJ; ++t) { acc1[t] = (d4){0.0, 0.0, 0.0, 0.0}; acc2[t] = (d4){0.0, 0.0, 0.0, 0.0}; }
     if (have) {
-      const int row = 16 * ti + lr;
-#pragma unroll 2
-      for (int ks = 0; ks < ksteps; ++ks) {
-        const int k = 4 * ks + lq;
-        const double a1 = A1(row, k);
-        const double a2 = A2(row, k);
-#pragma unroll
-        for (int t = 0; t < kTJ; ++t) {
-          const double b = B(k, 16 * (cg * kTJ + t) + lr);
-          acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc1[t], 0, 0, 0);
-          acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, acc2[t], 0, 0, 0);
-        }
-      }
+      const int row = 16 * ti + lr, col0 = 16 * cg * kTJ + lr;
+      int ks = 0;
+      for (; ks + 2 <= ksteps; ks += 2) kchunk2<2>(ks, row, lq, col0, A1, A2, B, acc1, acc2);
+      if (ks < ksteps) kchunk2<1>(ks, row, lq, col0, A1, A2, B, acc1, acc2);
     }
     if (SYNC) __syncthreads();
     if (have) {
@@ -117,7 +161,7 @@ __device__ __forceinline__ void wg_gemm2(int N, FA1 A1, FA2 A2, FB B, FE1 epi1, 
 
 // ---------------------------------------------------------------------------------------
 // y1 = M x1, y2 = M x2 (one pass over M).  M(i,k) functor; x1,x2,y1,y2 in LDS; part: LDS
-// scratch of 8*ldv doubles.  All threads must call.  y may alias x.
+// scratch of 2*kWaves*ldv doubles.  All threads must call.  y may alias x.
 // ---------------------------------------------------------------------------------------
 template <class FM>
 __device__ __forceinline__ void wg_matvec2(int N, int ldv, FM M, const double *x1, const double *x2, double *y1,
@@ -127,6 +171,7 @@ __device__ __forceinline__ void wg_matvec2(int N, int ldv, FM M, const double *x
   const int k0 = wave * chunk, k1 = min(N, k0 + chunk);
   for (int i = lane; i < N; i += 64) {
     double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
     for (int k = k0; k < k1; ++k) {
       const double m = M(i, k);
       s1 += m * x1[k];
@@ -146,6 +191,18 @@ __device__ __forceinline__ void wg_matvec2(int N, int ldv, FM M, const double *x
   __syncthreads();
 }
 
+// max over the wave (all lanes get it)
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------
 // In-place inverse of the N x N matrix a (column-major, ld) by Gauss-Jordan elimination
 // with partial (row) pivoting -- the arithmetic counterpart of the reference's batch_inv!
@@ -153,28 +210,28 @@ __device__ __forceinline__ void wg_matvec2(int N, int ldv, FM M, const double *x
 // (>= N), sh: LDS int.  *bad (LDS int) is set nonzero if a zero pivot was met.
 // All threads must call; ends with a barrier.  3 barriers per elimination step.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void wg_inverse(int N, double *a, int ld, double *prow, double *pcol, double *rowk,
-                                           int *ipiv, int *sh, int *bad) {
+__device__ __forceinline__ void wg_inverse(int N, const FastDiv &fd, double *a, int ld, double *prow, double *pcol,
+                                           double *rowk, int *ipiv, int *sh, int *bad) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NN = N * N;
   for (int k = 0; k < N; ++k) {
     // (1) pivot search on column k, rows k..N-1 (first maximum, like idamax)
     if (wave == 0) {
       double best = -1.0;
-      int bi = k;
+      int bi = N;
       for (int i = k + lane; i < N; i += 64) {
         const double v = fabs(a[i + k * ld]);
         if (v > best) { best = v; bi = i; }
       }
+      const double wm = wave_max(best);
+      // lowest row index attaining the maximum
+      int cand = (best == wm) ? bi : N;
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(best, off);
-        const int oi = __shfl_xor(bi, off);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-      }
+      for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off));
       if (lane == 0) {
-        sh[0] = bi;
-        ipiv[k] = bi;
-        if (!(best > 0.0)) *bad = k + 1;
+        sh[0] = cand;
+        ipiv[k] = cand;
+        if (!(wm > 0.0)) *bad = k + 1;
       }
     }
     __syncthreads();
@@ -193,17 +250,34 @@ __device__ __forceinline__ void wg_inverse(int N, double *a, int ld, double *pro
     __syncthreads();
     // (3) rank-1 update of every row but k (row p takes the old row k: the interchange);
     //     row k <- scaled pivot row
-    for (int e = tid; e < N * N; e += kThreads) {
-      const int j = e / N, i = e - j * N;
-      double v;
-      if (i == k) {
-        v = prow[j];
-      } else {
-        const double f = pcol[i];
-        const double aij = (i == p) ? rowk[j] : a[i + j * ld];
-        v = (j == k) ? (-f * d) : (aij - f * prow[j]);
+    for (int e0 = tid; e0 < NN; e0 += 4 * kThreads) {
+      double av[4], fv[4], pv[4];
+      int ii[4], jj[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * kThreads;
+        if (e < NN) {
+          fd.split(e, ii[u], jj[u]);
+          av[u] = a[ii[u] + jj[u] * ld];
+          fv[u] = pcol[ii[u]];
+          pv[u] = prow[jj[u]];
+        }
       }
-      a[i + j * ld] = v;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * kThreads;
+        if (e < NN) {
+          const int i = ii[u], j = jj[u];
+          double v;
+          if (i == k) {
+            v = pv[u];
+          } else {
+            const double aij = (i == p) ? rowk[j] : av[u];
+            v = (j == k) ? (-fv[u] * d) : (aij - fv[u] * pv[u]);
+          }
+          a[i + j * ld] = v;
+        }
+      }
     }
     __syncthreads();
   }
@@ -222,12 +296,26 @@ __device__ __forceinline__ void wg_inverse(int N, double *a, int ld, double *pro
   __syncthreads();
 }
 
-// copy N x N column-major block src(ld_s) -> dst(ld_d), all threads
-__device__ __forceinline__ void wg_copy_mat(int N, const double *__restrict__ src, int ld_s, double *__restrict__ dst,
-                                            int ld_d) {
-  for (int e = threadIdx.x; e < N * N; e += kThreads) {
-    const int j = e / N, i = e - j * N;
-    dst[i + j * ld_d] = src[i + j * ld_s];
+// copy an N x N column-major block src(ld_s) -> dst(ld_d), all threads; loads batched by 4
+__device__ __forceinline__ void wg_copy_mat(int N, const FastDiv &fd, const double *__restrict__ src, int ld_s,
+                                            double *__restrict__ dst, int ld_d) {
+  const int NN = N * N;
+  for (int e0 = threadIdx.x; e0 < NN; e0 += 4 * kThreads) {
+    double v[4];
+    int o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * kThreads;
+      if (e < NN) {
+        int i, j;
+        fd.split(e, i, j);
+        v[u] = src[i + j * ld_s];
+        o[u] = i + j * ld_d;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (e0 + u * kThreads < NN) dst[o[u]] = v[u];
   }
 }
 

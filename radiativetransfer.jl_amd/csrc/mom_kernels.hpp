@@ -13,6 +13,13 @@
 //   r-+ rows scaled by sg (elemental when nd>=1, and again after doubling), j0- scaled by sg
 //   after doubling, and  r+- = diag(sg) r-+ diag(sg),  t-- = diag(sg) t++ diag(sg)  always.
 // So r+- and t-- are never materialised in the fused path: they are operand functors.
+//
+// T (I - B)^-1 (the reference forms inv(I - B) by LU, gpu_batched.jl:36-87, then multiplies):
+//   with beta = ||B||_F < 1/2 and p the smallest integer with beta^p / (1 - beta) <= 2^-56, the
+//   truncated Neumann series sum_{k<p} B^k differs from (I - B)^-1 by at most 2^-56 in every
+//   element (||B^k||_F <= beta^k) -- below FP64 rounding of the O(1) result -- and needs only
+//   MFMA products: Horner (p <= 4) or repeated squaring (p <= 32).  Otherwise: Gauss-Jordan
+//   with partial pivoting.  MOM_OPT_INVERSE = 1 forces the pivoted path.
 #pragma once
 #include "mom_device.hpp"
 
@@ -25,38 +32,45 @@ struct DevStreams {
   double I0[4];
   double D[4];
   int N, nS, imu0;  // imu0: 1-based stream index of the sun
+  int inv_mode;     // 0 auto, 1 force pivoted Gauss-Jordan
   double mu0;
 };
 
 // workgroup context: where this workgroup's matrices and vectors live
 struct Ctx {
-  int N, ld, ldv;
-  double *r, *t, *P, *Q, *X;  // N x N buffers (X: spare, generic mode only)
+  int N, Np, ld, ldv;
+  FastDiv fd;
+  double *r, *t, *P, *Q, *X;  // padded N x N buffers (X: spare, generic mode only)
   double *jp, *jm, *j1p, *j1m, *v1, *v2, *Jp, *Jm, *prow, *pcol, *rowk, *ei, *mu, *wt, *sg, *part;
   int *ipiv, *sh, *bad;
+  int inv_mode;
 };
 
-__host__ __device__ inline int ld_for(int N) { return (N & 1) ? N + 1 : N + 2; }
-__host__ __device__ inline int ldv_for(int N) { return (N + 1) & ~1; }
+__host__ __device__ inline int np_for(int N) { return 16 * ((N + 15) / 16); }
+__host__ __device__ inline int ld_for(int N) { return np_for(N) + 2; }
+__host__ __device__ inline size_t mat_elems(int N) { return (size_t)ld_for(N) * np_for(N); }
 constexpr int kNumVec = 15 + 2 * kWaves;  // vectors carved from LDS (part = 2*kWaves vectors)
+constexpr int kGenericBufs = 5;
 __host__ __device__ inline size_t lds_bytes(int N, bool lds_mats) {
-  size_t b = (size_t)kNumVec * ldv_for(N) * sizeof(double) + (size_t)(ldv_for(N) + 4) * sizeof(int);
-  if (lds_mats) b += (size_t)4 * N * ld_for(N) * sizeof(double);
+  size_t b = (size_t)kNumVec * np_for(N) * sizeof(double) + (size_t)(np_for(N) + 4) * sizeof(int);
+  if (lds_mats) b += 4 * mat_elems(N) * sizeof(double);
   return b;
 }
 
 template <bool LDSM>
-__device__ __forceinline__ void make_ctx(Ctx &c, int N, double *smem, double *gscratch) {
+__device__ __forceinline__ void make_ctx(Ctx &c, int N, int inv_mode, double *smem, double *gscratch) {
   c.N = N;
+  c.Np = np_for(N);
   c.ld = ld_for(N);
-  c.ldv = ldv_for(N);
+  c.ldv = c.Np;
+  c.fd.init(N);
+  c.inv_mode = inv_mode;
+  const size_t msz = mat_elems(N);
   double *p = smem;
   if (LDSM) {
-    const size_t msz = (size_t)N * c.ld;
     c.r = p; c.t = p + msz; c.P = p + 2 * msz; c.Q = p + 3 * msz; c.X = nullptr;
     p += 4 * msz;
   } else {
-    const size_t msz = (size_t)N * c.ld;
     c.r = gscratch; c.t = gscratch + msz; c.P = gscratch + 2 * msz; c.Q = gscratch + 3 * msz; c.X = gscratch + 4 * msz;
   }
   const int lv = c.ldv;
@@ -67,17 +81,41 @@ __device__ __forceinline__ void make_ctx(Ctx &c, int N, double *smem, double *gs
   c.ipiv = ip; c.sh = ip + lv; c.bad = ip + lv + 1;
 }
 
-// element functor of a column-major buffer with leading dimension ld, zero outside [0,N)^2
+// zero the padding (rows/cols >= N) of the LDS matrix buffers; vectors fully
+template <bool LDSM>
+__device__ __forceinline__ void zero_padding(const Ctx &c) {
+  const int N = c.N, Np = c.Np, ld = c.ld;
+  if (LDSM) {
+    const int padr = ld - N;
+    for (int e = threadIdx.x; e < padr * Np; e += kThreads) {
+      const int j = e / padr, i = N + (e - j * padr);
+      const int o = i + j * ld;
+      c.r[o] = 0.0; c.t[o] = 0.0; c.P[o] = 0.0; c.Q[o] = 0.0;
+    }
+    const int padc = Np - N;
+    for (int e = threadIdx.x; e < padc * N; e += kThreads) {
+      const int jj = e / N, i = e - jj * N;
+      const int o = i + (N + jj) * ld;
+      c.r[o] = 0.0; c.t[o] = 0.0; c.P[o] = 0.0; c.Q[o] = 0.0;
+    }
+  }
+  for (int e = threadIdx.x; e < kNumVec * c.ldv; e += kThreads) c.jp[e] = 0.0;
+}
+
+// element functor of a PADDED buffer (no bounds checks)
+struct ElP {
+  const double *p; int ld;
+  __device__ __forceinline__ double operator()(int i, int j) const { return p[i + j * ld]; }
+};
+// diag(sg) * padded buf * diag(sg)   (sg padded with anything finite)
+struct ElSigP {
+  const double *p; const double *sg; int ld;
+  __device__ __forceinline__ double operator()(int i, int j) const { return sg[i] * sg[j] * p[i + j * ld]; }
+};
+// element functor of an unpadded (global) array with bounds checks
 struct El {
   const double *p; int ld, N;
   __device__ __forceinline__ double operator()(int i, int j) const { return (i < N && j < N) ? p[i + j * ld] : 0.0; }
-};
-// diag(sg) * buf * diag(sg)
-struct ElSig {
-  const double *p; const double *sg; int ld, N;
-  __device__ __forceinline__ double operator()(int i, int j) const {
-    return (i < N && j < N) ? sg[i] * sg[j] * p[i + j * ld] : 0.0;
-  }
 };
 struct ElZero { __device__ __forceinline__ double operator()(int, int) const { return 0.0; } };
 struct ElEye {
@@ -85,7 +123,7 @@ struct ElEye {
   __device__ __forceinline__ double operator()(int i, int j) const { return (i == j && i < N) ? 1.0 : 0.0; }
 };
 
-// y = M x (+ nothing); all threads; ends with barrier
+// y = M x ; all threads; ends with barrier
 template <class FM>
 __device__ __forceinline__ void wg_matvec(const Ctx &c, FM M, const double *x, double *y) {
   const int N = c.N, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -93,6 +131,7 @@ __device__ __forceinline__ void wg_matvec(const Ctx &c, FM M, const double *x, d
   const int k0 = wave * chunk, k1 = min(N, k0 + chunk);
   for (int i = lane; i < N; i += 64) {
     double s = 0.0;
+#pragma unroll 4
     for (int k = k0; k < k1; ++k) s += M(i, k) * x[k];
     c.part[wave * c.ldv + i] = s;
   }
@@ -106,31 +145,17 @@ __device__ __forceinline__ void wg_matvec(const Ctx &c, FM M, const double *x, d
   __syncthreads();
 }
 
-// dst = dst * B  (dst is the A operand); LDS mode: true in place; generic: via spare + swap
-template <bool LDSM, class FB>
-__device__ __forceinline__ void gemm_inplace_A(Ctx &c, double *&dst, FB B) {
+// dst(i,j) <- f(i, j, sum_k A(i,k) B(k,j), dst_old(i,j)); dst may be an operand of A/B.
+// LDS mode: true in place (SYNC); generic mode: written to the spare buffer, then swapped.
+template <bool LDSM, class FA, class FB, class FV>
+__device__ __forceinline__ void gemm_to(Ctx &c, double *&dst, FA A, FB B, FV f) {
   const int N = c.N, ld = c.ld;
+  double *d = dst;
   if (LDSM) {
-    double *d = dst;
-    wg_gemm<true>(N, El{d, ld, N}, B, [=](int i, int j, double v) { d[i + j * ld] = v; });
+    wg_gemm<true>(N, A, B, [=](int i, int j, double v) { d[i + j * ld] = f(i, j, v, d[i + j * ld]); });
   } else {
-    double *d = dst, *s = c.X;
-    wg_gemm<false>(N, El{d, ld, N}, B, [=](int i, int j, double v) { s[i + j * ld] = v; });
-    c.X = d;
-    dst = s;
-  }
-  __syncthreads();
-}
-// dst = A * dst  (dst is the B operand)
-template <bool LDSM, class FA>
-__device__ __forceinline__ void gemm_inplace_B(Ctx &c, FA A, double *&dst) {
-  const int N = c.N, ld = c.ld;
-  if (LDSM) {
-    double *d = dst;
-    wg_gemm<true>(N, A, El{d, ld, N}, [=](int i, int j, double v) { d[i + j * ld] = v; });
-  } else {
-    double *d = dst, *s = c.X;
-    wg_gemm<false>(N, A, El{d, ld, N}, [=](int i, int j, double v) { s[i + j * ld] = v; });
+    double *s = c.X;
+    wg_gemm<false>(N, A, B, [=](int i, int j, double v) { s[i + j * ld] = f(i, j, v, d[i + j * ld]); });
     c.X = d;
     dst = s;
   }
@@ -138,21 +163,104 @@ __device__ __forceinline__ void gemm_inplace_B(Ctx &c, FA A, double *&dst) {
 }
 
 // ---------------------------------------------------------------------------------------
-// stream constants -> LDS
+// Ob <- T (I - B)^-1 with B in Bb (destroyed).  T: element functor usable as MFMA A operand.
+// See the header comment for the series bound.  Ends with a barrier.
+// ---------------------------------------------------------------------------------------
+template <bool LDSM, class FT>
+__device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob) {
+  const int N = c.N, ld = c.ld, NN = N * N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int p = 1000;
+  if (c.inv_mode != 1) {
+    double s = 0.0;
+    for (int e = threadIdx.x; e < NN; e += kThreads) {
+      int i, j;
+      c.fd.split(e, i, j);
+      const double v = Bb[i + j * ld];
+      s += v * v;
+    }
+    s = wave_sum(s);
+    if (lane == 0) c.part[wave] = s;
+    __syncthreads();
+    double b2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) b2 += c.part[w];
+    __syncthreads();
+    const double beta = sqrt(b2);
+    if (beta == 0.0) p = 1;
+    else if (beta < 0.5) p = (int)ceil(log(1.3877787807814457e-17 * (1.0 - beta)) / log(beta));
+    if (p < 1) p = 1;
+  }
+  if (p <= 4) {
+    // Horner: A_1 = T, A_{k+1} = T + A_k B
+    double *o = Ob;
+    if (p == 1) {
+      for (int e = threadIdx.x; e < NN; e += kThreads) {
+        int i, j;
+        c.fd.split(e, i, j);
+        o[i + j * ld] = T(i, j);
+      }
+      __syncthreads();
+    } else {
+      wg_gemm<false>(N, T, ElP{Bb, ld}, [=](int i, int j, double v) { o[i + j * ld] = T(i, j) + v; });
+      __syncthreads();
+      for (int k = 3; k <= p; ++k)
+        gemm_to<LDSM>(c, Ob, ElP{Ob, ld}, ElP{Bb, ld}, [=](int i, int j, double v, double) { return T(i, j) + v; });
+    }
+  } else if (p <= 32) {
+    // G = (I + B)(I + B^2)(I + B^4)... ; Ob <- T G
+    {
+      double *o = Ob, *b = Bb;
+      for (int e = threadIdx.x; e < NN; e += kThreads) {
+        int i, j;
+        c.fd.split(e, i, j);
+        o[i + j * ld] = ((i == j) ? 1.0 : 0.0) + b[i + j * ld];
+      }
+      __syncthreads();
+    }
+    for (int terms = 2; terms < p; terms *= 2) {
+      gemm_to<LDSM>(c, Bb, ElP{Bb, ld}, ElP{Bb, ld}, [=](int, int, double v, double) { return v; });
+      gemm_to<LDSM>(c, Ob, ElP{Ob, ld}, ElP{Bb, ld}, [=](int, int, double v, double old) { return old + v; });
+    }
+    gemm_to<LDSM>(c, Ob, T, ElP{Ob, ld}, [=](int, int, double v, double) { return v; });
+  } else {
+    double *b = Bb, *o = Ob;
+    for (int e = threadIdx.x; e < NN; e += kThreads) {
+      int i, j;
+      c.fd.split(e, i, j);
+      b[i + j * ld] = ((i == j) ? 1.0 : 0.0) - b[i + j * ld];
+    }
+    __syncthreads();
+    wg_inverse(N, c.fd, b, ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);
+    wg_gemm<false>(N, T, ElP{b, ld}, [=](int i, int j, double v) { o[i + j * ld] = v; });
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// stream constants -> LDS (call after zero_padding + barrier; needs a barrier after)
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_streams(const Ctx &c, const DevStreams &q) {
-  for (int i = threadIdx.x; i < c.N; i += kThreads) {
-    c.mu[i] = q.mu[i];
-    c.wt[i] = q.wt[i];
-    c.sg[i] = q.sg[i];
+  for (int i = threadIdx.x; i < c.Np; i += kThreads) {
+    c.mu[i] = (i < c.N) ? q.mu[i] : 1.0;
+    c.wt[i] = (i < c.N) ? q.wt[i] : 0.0;
+    c.sg[i] = (i < c.N) ? q.sg[i] : 1.0;
   }
   if (threadIdx.x == 0) *c.bad = 0;
 }
 
+template <bool LDSM>
+__device__ __forceinline__ void wg_prologue(Ctx &c, const DevStreams &q, double *smem, double *gscratch) {
+  make_ctx<LDSM>(c, q.N, q.inv_mode, smem, gscratch);
+  zero_padding<LDSM>(c);
+  __syncthreads();
+  load_streams(c, q);
+  __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------
 // elemental! into c.r (r-+), c.t (t++), c.jp, c.jm.  Zpp(i,j), Zmp(i,j): phase-matrix
-// element functors for this spectral point.  Needs load_streams + barrier before.
-// Ends with a barrier.
+// element functors for this spectral point.  Ends with a barrier.
 // ---------------------------------------------------------------------------------------
 template <class FZP, class FZM>
 __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &q, int m, int nd, double tau_sum,
@@ -163,7 +271,8 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   for (int i = threadIdx.x; i < N; i += kThreads) c.ei[i] = exp(-dtau / c.mu[i]);
   __syncthreads();
   for (int e = threadIdx.x; e < N * N; e += kThreads) {
-    const int j = e / N, i = e - j * N;
+    int i, j;
+    c.fd.split(e, i, j);
     const double mui = c.mu[i], muj = c.mu[j];
     const double wj = c.wt[j] / wdiv;
     double rr, tt;
@@ -221,14 +330,14 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
   const int N = c.N, ld = c.ld;
   if (nd == 0) return expk;
   for (int it = 0; it < nd; ++it) {
+    {
+      double *r = c.r, *P = c.P;
+      // P = r r ; Q = t (I - r r)^-1  (tt⁺⁺_gp_refl)           (doubling.jl:44-48)
+      wg_gemm<false>(N, ElP{r, ld}, ElP{r, ld}, [=](int i, int j, double v) { P[i + j * ld] = v; });
+      __syncthreads();
+    }
+    times_inv<LDSM>(c, ElP{c.t, ld}, c.P, c.Q);
     double *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
-    // P = I - r r                                         (doubling.jl:44)
-    wg_gemm<false>(N, El{r, ld, N}, El{r, ld, N},
-                   [=](int i, int j, double v) { P[i + j * ld] = ((i == j) ? 1.0 : 0.0) - v; });
-    __syncthreads();
-    wg_inverse(N, P, ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);  // :47
-    // Q = t P   (tt⁺⁺_gp_refl)                              (:48)
-    wg_gemm<false>(N, El{t, ld, N}, El{P, ld, N}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
     // j1± = j0± expk                                       (:51,:54)
     for (int i = threadIdx.x; i < N; i += kThreads) {
       c.j1p[i] = c.jp[i] * expk;
@@ -236,29 +345,29 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
     }
     __syncthreads();
     // v1 = r j0+ ; v2 = r j1-
-    wg_matvec2(N, c.ldv, El{r, ld, N}, c.jp, c.j1m, c.v1, c.v2, c.part);
+    wg_matvec2(N, c.ldv, ElP{r, ld}, c.jp, c.j1m, c.v1, c.v2, c.part);
     for (int i = threadIdx.x; i < N; i += kThreads) {
       c.v1[i] = c.j1m[i] + c.v1[i];  // j1- + r j0+
       c.v2[i] = c.jp[i] + c.v2[i];   // j0+ (old) + r j1-
     }
     __syncthreads();
-    wg_matvec2(N, c.ldv, El{Q, ld, N}, c.v1, c.v2, c.v1, c.v2, c.part);
+    wg_matvec2(N, c.ldv, ElP{Q, ld}, c.v1, c.v2, c.v1, c.v2, c.part);
     for (int i = threadIdx.x; i < N; i += kThreads) {
       c.jm[i] = c.jm[i] + c.v1[i];   // :57
       c.jp[i] = c.j1p[i] + c.v2[i];  // :60
     }
     expk = expk * expk;  // :61
     // P = Q r
-    wg_gemm<false>(N, El{Q, ld, N}, El{r, ld, N}, [=](int i, int j, double v) { P[i + j * ld] = v; });
+    wg_gemm<false>(N, ElP{Q, ld}, ElP{r, ld}, [=](int i, int j, double v) { P[i + j * ld] = v; });
     __syncthreads();
     // r = r + P t (:64) ; t = Q t (:67)
     if (LDSM) {
-      wg_gemm2<true>(N, El{P, ld, N}, El{Q, ld, N}, El{t, ld, N},
+      wg_gemm2<true>(N, ElP{P, ld}, ElP{Q, ld}, ElP{t, ld},
                      [=](int i, int j, double v) { r[i + j * ld] = r[i + j * ld] + v; },
                      [=](int i, int j, double v) { t[i + j * ld] = v; });
     } else {
       double *X = c.X;
-      wg_gemm2<false>(N, El{P, ld, N}, El{Q, ld, N}, El{t, ld, N},
+      wg_gemm2<false>(N, ElP{P, ld}, ElP{Q, ld}, ElP{t, ld},
                       [=](int i, int j, double v) { r[i + j * ld] = r[i + j * ld] + v; },
                       [=](int i, int j, double v) { X[i + j * ld] = v; });
       c.X = t;
@@ -270,7 +379,8 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
   {
     double *r = c.r;
     for (int e = threadIdx.x; e < N * N; e += kThreads) {
-      const int j = e / N, i = e - j * N;
+      int i, j;
+      c.fd.split(e, i, j);
       r[i + j * ld] *= c.sg[i];
     }
     for (int i = threadIdx.x; i < N; i += kThreads) c.jm[i] *= c.sg[i];
@@ -300,131 +410,130 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface, const CompPt
   __syncthreads();
   if (iface == 0) {
     // J0+ = j0+ + t++ J0+ ; J0- = J0- + T-- j0-            (interaction.jl:16-17)
-    wg_matvec(c, El{t, ld, N}, c.Jp, c.v1);
+    wg_matvec(c, ElP{t, ld}, c.Jp, c.v1);
     wg_matvec(c, El{g.T_mm, N, N}, c.jm, c.v2);
     for (int i = threadIdx.x; i < N; i += kThreads) {
       c.Jp[i] = c.jp[i] + c.v1[i];
       c.Jm[i] = c.Jm[i] + c.v2[i];
     }
     // T-- = t-- T-- ; T++ = t++ T++                          (:20-21)
-    wg_copy_mat(N, g.T_mm, N, c.P, ld);
-    wg_copy_mat(N, g.T_pp, N, c.Q, ld);
+    wg_copy_mat(N, c.fd, g.T_mm, N, c.P, ld);
+    wg_copy_mat(N, c.fd, g.T_pp, N, c.Q, ld);
     __syncthreads();
     double *Tmm = g.T_mm, *Tpp = g.T_pp;
-    wg_gemm<false>(N, tmm, El{c.P, ld, N}, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
-    wg_gemm<false>(N, El{t, ld, N}, El{c.Q, ld, N}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
+    wg_gemm<false>(N, tmm, ElP{c.P, ld}, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
+    wg_gemm<false>(N, ElP{t, ld}, ElP{c.Q, ld}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
   } else if (iface == 1) {
-    wg_copy_mat(N, g.T_mm, N, c.P, ld);  // P = T--
+    wg_copy_mat(N, c.fd, g.T_mm, N, c.P, ld);  // P = T--
     // J0- = J0- + T-- (r-+ J0+ + j0-) ; J0+ = j0+ + t++ J0+  (:36-37)
-    wg_matvec(c, El{r, ld, N}, c.Jp, c.v1);
+    wg_matvec(c, ElP{r, ld}, c.Jp, c.v1);
     for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
     __syncthreads();
-    wg_matvec(c, El{c.P, ld, N}, c.v1, c.v2);
-    wg_matvec(c, El{t, ld, N}, c.Jp, c.v1);
+    wg_matvec(c, ElP{c.P, ld}, c.v1, c.v2);
+    wg_matvec(c, ElP{t, ld}, c.Jp, c.v1);
     for (int i = threadIdx.x; i < N; i += kThreads) {
       c.Jm[i] = c.Jm[i] + c.v2[i];
       c.Jp[i] = c.jp[i] + c.v1[i];
     }
     // R-+ = (T-- r-+) T++ ; R+- = r+- ; T++ = t++ T++ ; T-- = T-- t--   (:40-43)
     double *Q = c.Q, *P = c.P;
-    wg_gemm<false>(N, El{P, ld, N}, El{r, ld, N}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+    wg_gemm<false>(N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
     __syncthreads();
     double *Rmp = g.R_mp, *Rpm = g.R_pm, *Tpp = g.T_pp, *Tmm = g.T_mm;
-    wg_gemm<false>(N, El{Q, ld, N}, El{g.T_pp, N, N}, [=](int i, int j, double v) { Rmp[i + j * N] = v; });
+    wg_gemm<false>(N, ElP{Q, ld}, El{g.T_pp, N, N}, [=](int i, int j, double v) { Rmp[i + j * N] = v; });
     __syncthreads();
-    wg_copy_mat(N, g.T_pp, N, Q, ld);
+    wg_copy_mat(N, c.fd, g.T_pp, N, Q, ld);
     __syncthreads();
-    wg_gemm<false>(N, El{t, ld, N}, El{Q, ld, N}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
-    wg_gemm<false>(N, El{P, ld, N}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
+    wg_gemm<false>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
+    wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
     for (int e = threadIdx.x; e < N * N; e += kThreads) {
-      const int j = e / N, i = e - j * N;
+      int i, j;
+      c.fd.split(e, i, j);
       Rpm[i + j * N] = rpm(i, j);
     }
   } else if (iface == 2) {
     double *P = c.P, *Q = c.Q;
-    wg_copy_mat(N, g.R_pm, N, P, ld);  // P = R+-
-    wg_copy_mat(N, g.T_mm, N, Q, ld);  // Q = T--
+    wg_copy_mat(N, c.fd, g.R_pm, N, P, ld);  // P = R+-
+    wg_copy_mat(N, c.fd, g.T_mm, N, Q, ld);  // Q = T--
     __syncthreads();
     // J0+ = j0+ + t++ (J0+ + R+- j0-) ; J0- = J0- + T-- j0-   (:58-59)
-    wg_matvec(c, El{P, ld, N}, c.jm, c.v1);
+    wg_matvec(c, ElP{P, ld}, c.jm, c.v1);
     for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.Jp[i] + c.v1[i];
     __syncthreads();
-    wg_matvec(c, El{t, ld, N}, c.v1, c.v2);
-    wg_matvec(c, El{Q, ld, N}, c.jm, c.v1);
+    wg_matvec(c, ElP{t, ld}, c.v1, c.v2);
+    wg_matvec(c, ElP{Q, ld}, c.jm, c.v1);
     for (int i = threadIdx.x; i < N; i += kThreads) {
       c.Jp[i] = c.jp[i] + c.v2[i];
       c.Jm[i] = c.Jm[i] + c.v1[i];
     }
     // T++ = t++ T++ ; T-- = T-- t-- ; R+- = (t++ R+-) t--       (:62-64)
     double *Tpp = g.T_pp, *Tmm = g.T_mm, *Rpm = g.R_pm;
-    wg_gemm<false>(N, El{Q, ld, N}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
+    wg_gemm<false>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
     __syncthreads();
-    wg_copy_mat(N, g.T_pp, N, Q, ld);
+    wg_copy_mat(N, c.fd, g.T_pp, N, Q, ld);
     __syncthreads();
-    wg_gemm<false>(N, El{t, ld, N}, El{Q, ld, N}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
+    wg_gemm<false>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
     __syncthreads();
-    wg_gemm<false>(N, El{t, ld, N}, El{P, ld, N}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+    wg_gemm<false>(N, ElP{t, ld}, ElP{P, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
     __syncthreads();
-    wg_gemm<false>(N, El{Q, ld, N}, tmm, [=](int i, int j, double v) { Rpm[i + j * N] = v; });
+    wg_gemm<false>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * N] = v; });
   } else {
     // ---- ScatteringInterface_11 (interaction.jl:69-117)
-    wg_copy_mat(N, g.R_pm, N, c.P, ld);  // P = R+-
+    wg_copy_mat(N, c.fd, g.R_pm, N, c.P, ld);  // P = R+-
     __syncthreads();
     {
       double *P = c.P, *Q = c.Q;
-      // Q = I - r-+ R+-                                        (:81)
-      wg_gemm<false>(N, El{r, ld, N}, El{P, ld, N},
-                     [=](int i, int j, double v) { Q[i + j * ld] = ((i == j) ? 1.0 : 0.0) - v; });
+      // Q = r-+ R+-  ;  P = T01 = T-- (I - r-+ R+-)^-1            (:81-87)
+      wg_gemm<false>(N, ElP{r, ld}, ElP{P, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
       __syncthreads();
     }
-    wg_inverse(N, c.Q, ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);  // :83
-    wg_copy_mat(N, g.T_mm, N, c.P, ld);                                     // P = T--
-    __syncthreads();
-    gemm_inplace_A<LDSM>(c, c.P, El{c.Q, ld, N});  // P = T01_inv = T-- inv   (:87)
+    times_inv<LDSM>(c, El{g.T_mm, N, N}, c.Q, c.P);
     // J0- = J0- + T01 (r-+ J0+ + j0-)                          (:90)
-    wg_matvec(c, El{r, ld, N}, c.Jp, c.v1);
+    wg_matvec(c, ElP{r, ld}, c.Jp, c.v1);
     for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
     __syncthreads();
-    wg_matvec(c, El{c.P, ld, N}, c.v1, c.v2);
+    wg_matvec(c, ElP{c.P, ld}, c.v1, c.v2);
     for (int i = threadIdx.x; i < N; i += kThreads) c.Jm[i] = c.Jm[i] + c.v2[i];
     {
       double *P = c.P, *Q = c.Q, *Tmm = g.T_mm, *Rmp = g.R_mp;
       // T-- = T01 t--                                           (:96)
-      wg_gemm<false>(N, El{P, ld, N}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
+      wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
       // Q = T01 r-+
-      wg_gemm<false>(N, El{P, ld, N}, El{r, ld, N}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+      wg_gemm<false>(N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
       __syncthreads();
-      wg_copy_mat(N, g.T_pp, N, P, ld);  // P = T++ (old)
+      wg_copy_mat(N, c.fd, g.T_pp, N, P, ld);  // P = T++ (old)
       __syncthreads();
       // R-+ = R-+ + (T01 r-+) T++                              (:93)
-      wg_gemm<false>(N, El{Q, ld, N}, El{P, ld, N},
-                     [=](int i, int j, double v) { Rmp[i + j * N] = Rmp[i + j * N] + v; });
+      wg_gemm<false>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Rmp[i + j * N] = Rmp[i + j * N] + v; });
       __syncthreads();
-      wg_copy_mat(N, g.R_pm, N, Q, ld);  // Q = R+- (old)
-      __syncthreads();
-      // P = I - R+- r-+                                        (:104)
-      wg_gemm<false>(N, El{Q, ld, N}, El{r, ld, N},
-                     [=](int i, int j, double v) { P[i + j * ld] = ((i == j) ? 1.0 : 0.0) - v; });
+      wg_copy_mat(N, c.fd, g.R_pm, N, Q, ld);  // Q = R+- (old)
       __syncthreads();
     }
-    wg_inverse(N, c.P, ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);  // :105
-    gemm_inplace_B<LDSM>(c, El{t, ld, N}, c.P);  // P = T21_inv = t++ inv     (:107)
+    // w = J0+ + R+- j0-  (kept in j1p; j1p/j1m are free outside doubling)
+    wg_matvec(c, ElP{c.Q, ld}, c.jm, c.v1);
+    for (int i = threadIdx.x; i < N; i += kThreads) c.j1p[i] = c.Jp[i] + c.v1[i];
+    {
+      double *P = c.P, *Q = c.Q;
+      // P = R+- r-+ ; Q = T21 = t++ (I - R+- r-+)^-1            (:104-107)
+      wg_gemm<false>(N, ElP{Q, ld}, ElP{r, ld}, [=](int i, int j, double v) { P[i + j * ld] = v; });
+      __syncthreads();
+    }
+    times_inv<LDSM>(c, ElP{t, ld}, c.P, c.Q);
     // J0+ = j0+ + T21 (J0+ + R+- j0-)                          (:110)
-    wg_matvec(c, El{c.Q, ld, N}, c.jm, c.v1);
-    for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.Jp[i] + c.v1[i];
-    __syncthreads();
-    wg_matvec(c, El{c.P, ld, N}, c.v1, c.v2);
+    wg_matvec(c, ElP{c.Q, ld}, c.j1p, c.v2);
     for (int i = threadIdx.x; i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.v2[i];
-    gemm_inplace_B<LDSM>(c, El{c.P, ld, N}, c.Q);  // Q = T21 R+-
+    wg_copy_mat(N, c.fd, g.R_pm, N, c.P, ld);  // P = R+- (old)
+    __syncthreads();
+    gemm_to<LDSM>(c, c.P, ElP{c.Q, ld}, ElP{c.P, ld}, [=](int, int, double v, double) { return v; });  // P = T21 R+-
     {
       double *P = c.P, *Q = c.Q, *Rpm = g.R_pm, *Tpp = g.T_pp;
       // R+- = r+- + (T21 R+-) t--                              (:116)
-      wg_gemm<false>(N, El{Q, ld, N}, tmm, [=](int i, int j, double v) { Rpm[i + j * N] = rpm(i, j) + v; });
+      wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * N] = rpm(i, j) + v; });
       __syncthreads();
-      wg_copy_mat(N, g.T_pp, N, Q, ld);  // Q = T++ (old)
+      wg_copy_mat(N, c.fd, g.T_pp, N, P, ld);  // P = T++ (old)
       __syncthreads();
       // T++ = T21 T++                                          (:113)
-      wg_gemm<false>(N, El{P, ld, N}, El{Q, ld, N}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
+      wg_gemm<false>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
     }
   }
   __syncthreads();
@@ -439,7 +548,8 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface, const CompPt
 __device__ __forceinline__ void store_added_as_composite(const Ctx &c, const CompPtrs &g) {
   const int N = c.N, ld = c.ld;
   for (int e = threadIdx.x; e < N * N; e += kThreads) {
-    const int j = e / N, i = e - j * N;
+    int i, j;
+    c.fd.split(e, i, j);
     const double rv = c.r[i + j * ld], tv = c.t[i + j * ld], s = c.sg[i] * c.sg[j];
     g.R_mp[e] = rv;
     g.R_pm[e] = s * rv;

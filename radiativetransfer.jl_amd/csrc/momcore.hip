@@ -62,9 +62,7 @@ __global__ void __launch_bounds__(kThreads) k_layer(LayerArgs a) {
   const int N = a.q.N;
   const size_t total = (size_t)a.S * a.M;
   Ctx c;
-  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
-  load_streams(c, a.q);
-  __syncthreads();
+  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
   for (size_t pt = blockIdx.x; pt < total; pt += gridDim.x) {
     const int n = (int)(pt % a.S), m = (int)(pt / a.S);
     const double tau = a.tau[n], varpi = a.varpi[n];
@@ -80,7 +78,7 @@ __global__ void __launch_bounds__(kThreads) k_layer(LayerArgs a) {
       store_added_as_composite(c, g);
       __syncthreads();
     } else {
-      interaction_core<LDSM>(c, a.iface, g, ElSig{c.r, c.sg, c.ld, N}, ElSig{c.t, c.sg, c.ld, N});
+      interaction_core<LDSM>(c, a.iface, g, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
     }
   }
   if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
@@ -103,16 +101,15 @@ template <bool LDSM>
 __global__ void __launch_bounds__(kThreads) k_surface(SurfArgs a) {
   const int N = a.q.N, n = a.q.nS;
   Ctx c;
-  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
-  load_streams(c, a.q);
-  __syncthreads();
+  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
   const int ld = c.ld;
   for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
     const double rho = 2 * a.albedo;                       // lambertian_surface.jl:37
     const double att = exp(-a.tau_tot[pt] / a.q.mu0);
     const int i_start = n * (a.q.imu0 - 1), i_end = n * a.q.imu0;
     for (int e = threadIdx.x; e < N * N; e += kThreads) {
-      const int j = e / N, i = e - j * N;
+      int i, j;
+      c.fd.split(e, i, j);
       c.r[i + j * ld] = ((i % n == 0) && (j % n == 0)) ? rho * (c.mu[j] * c.wt[j]) : 0.0;  // :41-43,:58
       c.t[i + j * ld] = (i == j) ? 1.0 : 0.0;
     }
@@ -167,7 +164,8 @@ __device__ __forceinline__ void store_added(const Ctx &c, double *const added[6]
   const int N = c.N, ld = c.ld;
   const size_t NN = (size_t)N * N;
   for (int e = threadIdx.x; e < N * N; e += kThreads) {
-    const int j = e / N, i = e - j * N;
+    int i, j;
+    c.fd.split(e, i, j);
     const double rv = c.r[i + j * ld], tv = c.t[i + j * ld];
     added[1][NN * pt + e] = rv;
     added[3][NN * pt + e] = tv;
@@ -187,7 +185,8 @@ __device__ __forceinline__ void load_added(const Ctx &c, double *const added[6],
   const int N = c.N, ld = c.ld;
   const size_t NN = (size_t)N * N;
   for (int e = threadIdx.x; e < N * N; e += kThreads) {
-    const int j = e / N, i = e - j * N;
+    int i, j;
+    c.fd.split(e, i, j);
     c.r[i + j * ld] = added[1][NN * pt + e];
     c.t[i + j * ld] = added[3][NN * pt + e];
   }
@@ -201,9 +200,7 @@ template <bool LDSM>
 __global__ void __launch_bounds__(kThreads) k_op_elemental(OpArgs a) {
   const int N = a.q.N;
   Ctx c;
-  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
-  load_streams(c, a.q);
-  __syncthreads();
+  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
   const size_t NN = (size_t)N * N;
   for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
     const size_t zo = a.z_batch > 1 ? NN * pt : 0;
@@ -219,9 +216,7 @@ template <bool LDSM>
 __global__ void __launch_bounds__(kThreads) k_op_doubling(OpArgs a) {
   const int N = a.q.N;
   Ctx c;
-  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
-  load_streams(c, a.q);
-  __syncthreads();
+  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
   for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
     load_added(c, a.added, pt);
     __syncthreads();
@@ -237,9 +232,7 @@ template <bool LDSM>
 __global__ void __launch_bounds__(kThreads) k_op_interaction(OpArgs a) {
   const int N = a.q.N;
   Ctx c;
-  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
-  load_streams(c, a.q);
-  __syncthreads();
+  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
   const size_t NN = (size_t)N * N;
   for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
     load_added(c, a.added, pt);
@@ -285,15 +278,16 @@ template <bool LDSM>
 __global__ void __launch_bounds__(kThreads) k_batch_inv(BlasArgs a) {
   const int N = a.N;
   Ctx c;
-  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
+  make_ctx<LDSM>(c, N, 1, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
+  zero_padding<LDSM>(c);
   if (threadIdx.x == 0) *c.bad = 0;
   __syncthreads();
   const size_t NN = (size_t)N * N;
   for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
-    wg_copy_mat(N, a.A + NN * pt, N, c.P, c.ld);
+    wg_copy_mat(N, c.fd, a.A + NN * pt, N, c.P, c.ld);
     __syncthreads();
-    wg_inverse(N, c.P, c.ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);
-    wg_copy_mat(N, c.P, c.ld, a.C + NN * pt, N);
+    wg_inverse(N, c.fd, c.P, c.ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);
+    wg_copy_mat(N, c.fd, c.P, c.ld, a.C + NN * pt, N);
     __syncthreads();
   }
   if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
@@ -303,15 +297,17 @@ template <bool LDSM>
 __global__ void __launch_bounds__(kThreads) k_batched_mul(BlasArgs a) {
   const int N = a.N;
   Ctx c;
-  make_ctx<LDSM>(c, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * 5 * N * ld_for(N));
+  make_ctx<LDSM>(c, N, 1, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
+  zero_padding<LDSM>(c);
+  __syncthreads();
   const size_t NN = (size_t)N * N;
   const int ld = c.ld;
   for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
-    wg_copy_mat(N, a.A + NN * pt, N, c.P, ld);
-    wg_copy_mat(N, a.B + NN * pt, N, c.Q, ld);
+    wg_copy_mat(N, c.fd, a.A + NN * pt, N, c.P, ld);
+    wg_copy_mat(N, c.fd, a.B + NN * pt, N, c.Q, ld);
     __syncthreads();
     double *C = a.C + NN * pt;
-    wg_gemm<false>(N, El{c.P, ld, N}, El{c.Q, ld, N}, [=](int i, int j, double v) { C[i + (size_t)j * N] = v; });
+    wg_gemm<false>(N, ElP{c.P, ld}, ElP{c.Q, ld}, [=](int i, int j, double v) { C[i + (size_t)j * N] = v; });
     __syncthreads();
   }
 }
@@ -415,7 +411,8 @@ extern "C" int mom_create(mom_t **out, int device, int N, int nStokes, int S, in
   HIPCHK(h, dmalloc(&h->d_info, 1));
   HIPCHK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
   h->G = 1024;
-  HIPCHK(h, dmalloc(&h->d_scratch, (size_t)h->G * 5 * N * ld_for(N)));
+  HIPCHK(h, dmalloc(&h->d_scratch, (size_t)h->G * kGenericBufs * mat_elems(N)));
+  HIPCHK(h, hipMemsetAsync(h->d_scratch, 0, (size_t)h->G * kGenericBufs * mat_elems(N) * sizeof(double), h->stream));
   for (int k = 0; k < 4; ++k) HIPCHK(h, hipEventCreate(&h->ev[k]));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
@@ -447,7 +444,7 @@ extern "C" int mom_sync(mom_t *h) {
 
 extern "C" int mom_set_option(mom_t *h, int option, int value) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  if (option == MOM_OPT_INVERSE) h->opt_inverse = value;
+  if (option == MOM_OPT_INVERSE) { h->opt_inverse = value; h->q.inv_mode = value; }
   else if (option == MOM_OPT_FORCE_GENERIC) {
     h->opt_force_generic = value;
     h->lds_mode = (h->N <= 64) && !value;
@@ -473,7 +470,7 @@ extern "C" int mom_set_streams(mom_t *h, const double *qp_muN, const double *wt_
   DevStreams &q = h->q;
   q.mu = h->d_mu; q.wt = h->d_wt; q.sg = h->d_sg;
   for (int k = 0; k < 4; ++k) { q.I0[k] = (k < h->nS) ? I0[k] : 0.0; q.D[k] = (k < h->nS) ? D[k] : 1.0; }
-  q.N = N; q.nS = h->nS; q.imu0 = imu0_1based; q.mu0 = mu0;
+  q.N = N; q.nS = h->nS; q.imu0 = imu0_1based; q.mu0 = mu0; q.inv_mode = h->opt_inverse;
   h->streams_set = true;
   return MOM_OK;
 }
@@ -640,7 +637,10 @@ static int blas_common(mom_t *h, int n, int batch, const double *A, const double
   }
   const bool lds = n <= 64 && !h->opt_force_generic;
   const int grid = lds ? batch : std::min(batch, 1024);
-  if (!lds) HIPCHK(h, dmalloc(&scr, (size_t)grid * 5 * n * ld_for(n)));
+  if (!lds) {
+    HIPCHK(h, dmalloc(&scr, (size_t)grid * kGenericBufs * mat_elems(n)));
+    HIPCHK(h, hipMemsetAsync(scr, 0, (size_t)grid * kGenericBufs * mat_elems(n) * sizeof(double), h->stream));
+  }
   BlasArgs a{n, batch, dA, dB, dC, scr, h->d_info};
   const size_t sm = lds_bytes(n, lds);
   if (inv) {
