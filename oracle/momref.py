@@ -851,3 +851,52 @@ def rt_run(scene: Scene, hook=None):
             hook("surface", m, Nz + 1, surf, comp)
         postprocessing_vza(pol, comp, scene.vza, quad.qp_mu, m, scene.vaz, weight, R_SFI, T_SFI)
     return R_SFI, T_SFI
+
+
+# --------------------------------------------------------------------------------------
+# Voigt line shape (src/Absorption)
+# --------------------------------------------------------------------------------------
+
+_W32A = np.array([
+    2.5722534081245696e+00, 2.2635372999002676e+00, 1.8256696296324824e+00, 1.3455441692345453e+00,
+    9.0192548936480144e-01, 5.4601397206393498e-01, 2.9544451071508926e-01, 1.4060716226893769e-01,
+    5.7304403529837900e-02, 1.9006155784845689e-02, 4.5195411053501429e-03, 3.9259136070122748e-04,
+    -2.4532980269928922e-04, -1.3075449254548613e-04, -2.1409619200870880e-05, 6.8210319440412389e-06,
+    4.4015317319048931e-06, 4.2558331390536872e-07, -4.1840763666294341e-07, -1.4813078891201116e-07,
+    2.2930439569075392e-08, 2.3797557105844622e-08, 8.1248960947953431e-10, -3.2080150458594088e-09,
+    -5.2310170266050247e-10, 4.1537465934749353e-10, 1.1658312885903929e-10, -5.5441820344468828e-11,
+    -2.1542618451370239e-11, 8.0314997274316680e-12, 3.7424975634801558e-12, -1.3031797863050087e-12])
+
+
+def w_hw32sd(z: np.ndarray) -> np.ndarray:
+    """w(::HumlicekWeidemann32SDErrorFunction, z) complex_error_functions.jl:226-234:
+    humlicek2 (:24-30) where |x|+y >= 8, weideman32a (:170-190) elsewhere."""
+    z = np.asarray(z, dtype=np.complex128)
+    far = np.abs(z.real) + z.imag >= 8
+    t = z.imag - 1j * z.real
+    u = t * t
+    w_far = (t * (1.410474 + u * (1 / math.sqrt(math.pi)))) / (3 / 4 + (u * (3 + u)))
+    L = math.sqrt(32 / math.sqrt(2))
+    iz = 1j * z.real - z.imag
+    rec = 1 / (L - iz)
+    Z = (L + iz) * rec
+    poly = np.full(z.shape, _W32A[31], dtype=np.complex128)
+    for k in range(30, -1, -1):
+        poly = _W32A[k] + poly * Z
+    w_near = (1 / math.sqrt(math.pi) + 2 * poly * rec) * rec
+    return np.where(far, w_far, w_near)
+
+
+def voigt_xsec(nu, gamma_d, y, S, ind_start, ind_stop, grid) -> np.ndarray:
+    """line_shape!(::Voigt) (compute_absorption_cross_section.jl:179-183) summed over lines in
+    line order over each line's 1-based inclusive window (:106-122)."""
+    grid = np.asarray(grid, dtype=np.float64)
+    out = np.zeros(grid.size)
+    cS, cL = 0.469718639319144059835, 0.8325546111577
+    for j in range(len(nu)):
+        a, b = int(ind_start[j]) - 1, int(ind_stop[j])
+        if b <= a:
+            continue
+        zz = cL / gamma_d[j] * (grid[a:b] - nu[j]) + 1j * y[j]
+        out[a:b] += S[j] * cS / gamma_d[j] * w_hw32sd(zz).real
+    return out

@@ -1,0 +1,602 @@
+"""Host-side mirror of the reference's CoreRT interface for the elastic path.
+
+The reference (vSmartMOM.jl) keeps this logic in Julia; no Julia toolchain exists in this
+image, so the same interface is restated in Python above the C ABI (include/momcore.h):
+same names, argument meaning and error behaviour, so that tests read like the reference's
+own (test/test_CoreRT.jl).  Everything numerical on the hot path -- elemental, doubling,
+interaction, surface, post-processing -- runs in libmomcore.so on the GPU; this module only
+prepares the inputs the reference's host code prepares (streams, phase-matrix Fourier
+moments, layer optics, doubling numbers, interface codes) and replays rt_run's loops.
+
+Reference files followed (relative to the reference root):
+  src/CoreRT/rt_run.jl:41-230                       rt_run
+  src/CoreRT/tools/rt_set_streams.jl:24-170         rt_set_streams
+  src/CoreRT/tools/rt_helper_functions.jl:8-57      interface state machine, doubling_number
+  src/CoreRT/CoreKernel/rt_kernel.jl:238-275        get_dtau_ndoubl / init_layer
+  src/CoreRT/LayerOpticalProperties/compEffectiveLayerProperties.jl:1-135, types.jl:632-678
+  src/Scattering/compute_Z_matrices.jl:5-84, legendre_functions.jl:17-178,
+  src/Scattering/mie_helper_functions.jl:237-251,287-348
+  src/Architectures.jl:20-55                        architecture dispatch seam
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+EPS = float(np.finfo(np.float64).eps)
+
+# ------------------------------------------------------------------------------------------
+# Architectures (src/Architectures.jl:20-55): CPU()/GPU() exist in the reference; MI355X is
+# the architecture this package adds.  There is deliberately no CPU execution path here.
+# ------------------------------------------------------------------------------------------
+
+
+class AbstractArchitecture:
+    pass
+
+
+@dataclass(frozen=True)
+class MI355X(AbstractArchitecture):
+    device: int = 0
+
+
+def default_architecture() -> MI355X:
+    return MI355X(0)
+
+
+# ------------------------------------------------------------------------------------------
+# Polarization types (src/Scattering/types.jl:82-123)
+# ------------------------------------------------------------------------------------------
+
+
+@dataclass(frozen=True)
+class PolarizationType:
+    n: int
+    D: tuple
+    I0: tuple
+
+
+def Stokes_I():
+    return PolarizationType(1, (1.0,), (1.0,))
+
+
+def Stokes_IQU():
+    return PolarizationType(3, (1.0, 1.0, -1.0), (1.0, 0.0, 0.0))
+
+
+def Stokes_IQUV():
+    return PolarizationType(4, (1.0, 1.0, -1.0, -1.0), (1.0, 0.0, 0.0, 0.0))
+
+
+# ------------------------------------------------------------------------------------------
+# trig in degrees, exact at the quadrant points like Julia's cosd/sind
+# ------------------------------------------------------------------------------------------
+
+
+def cosd(x: float) -> float:
+    r = math.fmod(abs(float(x)), 360.0)
+    if r in (90.0, 270.0):
+        return 0.0
+    if r == 0.0:
+        return 1.0
+    if r == 180.0:
+        return -1.0
+    return math.cos(math.radians(float(x)))
+
+
+def sind(x: float) -> float:
+    r = math.fmod(float(x), 360.0)
+    if r < 0:
+        r += 360.0
+    if r in (0.0, 180.0):
+        return 0.0
+    if r == 90.0:
+        return 1.0
+    if r == 270.0:
+        return -1.0
+    return math.sin(math.radians(float(x)))
+
+
+# ------------------------------------------------------------------------------------------
+# Quadrature streams
+# ------------------------------------------------------------------------------------------
+
+
+@dataclass
+class QuadPoints:
+    """types.jl:456-473; iμ₀ and iμ₀Nstart are 1-based like the reference."""
+    μ0: float
+    iμ0: int
+    iμ0Nstart: int
+    qp_μ: np.ndarray
+    wt_μ: np.ndarray
+    qp_μN: np.ndarray
+    wt_μN: np.ndarray
+    Nquad: int
+
+
+def _julia_unique(values: Sequence[float]) -> np.ndarray:
+    out: List[float] = []
+    for v in values:
+        if float(v) not in out:
+            out.append(float(v))
+    return np.asarray(out, dtype=np.float64)
+
+
+def _gauss_radau(n: int):
+    """n-point Gauss-Radau rule on [-1, 1], fixed node -1 first (what
+    FastGaussQuadrature.gaussradau returns at rt_set_streams.jl:115)."""
+    from scipy.special import roots_jacobi
+
+    if n == 1:
+        return np.array([-1.0]), np.array([2.0])
+    x, v = roots_jacobi(n - 1, 0.0, 1.0)
+    return np.concatenate(([-1.0], x)), np.concatenate(([2.0 / (n * n)], v / (1.0 + x)))
+
+
+def rt_set_streams(quadrature_type: str, Ltrunc: int, sza: float, vza: Sequence[float],
+                   pol_type: PolarizationType) -> QuadPoints:
+    """rt_set_streams(::GaussQuadHemisphere | ::GaussQuadFullSphere | ::RadauQuad, ...)."""
+    Nq = (Ltrunc + 1) // 2
+    μ0 = cosd(sza)
+    cams = [cosd(v) for v in vza]
+    if quadrature_type == "GaussQuadHemisphere":
+        x, w = np.polynomial.legendre.leggauss(Nq)
+        nodes, weights = 0.5 * x + 0.5, 0.5 * w
+        qp = _julia_unique(list(nodes) + cams + [μ0])
+    elif quadrature_type == "GaussQuadFullSphere":
+        x, w = np.polynomial.legendre.leggauss(2 * Nq)
+        nodes, weights = x[Nq:], w[Nq:]
+        qp = _julia_unique(list(nodes) + cams + [μ0])
+    elif quadrature_type == "RadauQuad":
+        tx, tw = _gauss_radau(Nq)
+        x0, w0 = -tx[::-1], tw[::-1]
+        if μ0 in x0:
+            nodes, weights = (1.0 + x0) / 2.0, w0.copy()
+        else:
+            nodes = np.concatenate([(μ0 + μ0 * x0) / 2.0, ((1.0 + μ0) + (1.0 - μ0) * x0) / 2.0])
+            weights = np.concatenate([μ0 * w0 / 2.0, (1.0 - μ0) * w0 / 2.0])
+        qp = _julia_unique(list(nodes) + cams)
+    else:
+        raise ValueError(f"unknown quadrature type {quadrature_type!r}")
+    wt = np.concatenate([weights, np.zeros(len(qp) - len(weights))])
+    iμ0 = int(np.argmin(np.abs(qp - μ0))) + 1
+    n = pol_type.n
+    return QuadPoints(μ0, iμ0, n * (iμ0 - 1) + 1, qp, wt, np.repeat(qp, n), np.repeat(wt, n), len(qp))
+
+
+# ------------------------------------------------------------------------------------------
+# Greek coefficients and phase-matrix Fourier moments
+# ------------------------------------------------------------------------------------------
+
+
+@dataclass
+class GreekCoefs:
+    """src/Scattering/types.jl:198-211"""
+    α: np.ndarray
+    β: np.ndarray
+    γ: np.ndarray
+    δ: np.ndarray
+    ϵ: np.ndarray
+    ζ: np.ndarray
+
+
+def get_greek_rayleigh(depol: float) -> GreekCoefs:
+    """mie_helper_functions.jl:237-251"""
+    p = (1 - depol) / (1 + depol / 2)
+    r = (1 - 2 * depol) / (1 - depol)
+    z3 = np.zeros(3)
+    return GreekCoefs(α=np.array([0.0, 0.0, 3 * p]), β=np.array([1.0, 0.0, 0.5 * p]),
+                      γ=np.array([0.0, 0.0, p * math.sqrt(1.5)]), δ=np.array([0.0, p * r * 1.5, 0.0]),
+                      ϵ=z3.copy(), ζ=z3.copy())
+
+
+def _prt_for_moment(μ: np.ndarray, lmax: int, m: int):
+    """Generalised spherical functions P, R, T for ONE Fourier index m and l = m..lmax-1 at the
+    nodes μ (legendre_functions.jl:17-178, normalisation built in).  Returns arrays [lmax, nμ]
+    (rows l < m are zero) with T sign-flipped as the reference returns it."""
+    μ = np.asarray(μ, dtype=np.float64)
+    s = np.sqrt(1.0 - μ * μ)
+    P = np.zeros((lmax, μ.size))
+    R = np.zeros_like(P)
+    T = np.zeros_like(P)
+    for l in range(m, lmax):
+        if m == 0:
+            if l == 0:
+                P[l] = 1.0
+            elif l == 1:
+                P[l] = μ
+            elif l == 2:
+                P[l] = 0.5 * (3.0 * μ * μ - 1.0)
+                R[l] = 0.5 * math.sqrt(1.5) * s * s
+            else:
+                P[l] = (P[l - 1] * (2 * l - 1) * μ - P[l - 2] * (l - 1)) / l
+                R[l] = (R[l - 1] * (2 * l - 1) * μ - R[l - 2] * math.sqrt((l + 1) * (l - 3))) / math.sqrt(l * l - 4)
+            continue
+        if m == 1 and l == 1:
+            P[l] = math.sqrt(0.5) * s
+            continue
+        if m == 1 and l == 2:
+            c = math.sqrt(1 / 6)
+            P[l] = c * (3 * μ * s)
+            R[l] = -c * μ * (math.sqrt(1.5) * s)
+            T[l] = c * (math.sqrt(1.5) * s)
+            continue
+        if l == m:  # m >= 2 seed (eq. 36, 37)
+            f1 = np.ones_like(μ)
+            f2 = np.ones_like(μ)
+            for i in range(1, m + 1):
+                f1 = f1 * ((2 * i - 1) * s) / math.sqrt(i * (i + m))
+                f2 = f2 * (s / 2) * (math.sqrt((m + i) / (i - 2)) if i > 2 else 1.0)
+            ok = s > 1e-8
+            ss = np.where(ok, s * s, 1.0)
+            edge = 0.5 if m == 2 else 0.0
+            P[l] = f1
+            R[l] = np.where(ok, f2 * (1.0 + μ * μ) / ss, edge)
+            T[l] = -np.where(ok, f2 * (2 * μ) / ss, edge)
+            continue
+        # three-term recurrences (eq. 34-35, 38)
+        if l == m + 1 and m >= 2:
+            m1, m2 = math.sqrt(1 / (l + m)), 0.0
+        elif m == 1:
+            m1 = math.sqrt((l - 1) / (l + 1))
+            m2 = m1 * math.sqrt((l - 2) / l)
+        else:
+            m1 = math.sqrt((l - m) / (l + m))
+            m2 = m1 * math.sqrt((l - m - 1) / (l + m - 1))
+        Zc = (2 * m * (2 * l - 1)) / (l * (l - 1))
+        Yp, Xp = (l - 1 + m), (l - m)
+        Yr = ((l + m - 1) / (l - 1)) * math.sqrt((l - 3) * (l + 1))
+        Xr = ((l - m) / l) * math.sqrt(l * l - 4)
+        Pm2 = P[l - 2] if l - 2 >= 0 else 0.0
+        P[l] = (m1 * P[l - 1] * (2 * l - 1) * μ - m2 * Pm2 * Yp) / Xp
+        R[l] = (m1 * R[l - 1] * (2 * l - 1) * μ - m2 * R[l - 2] * Yr + m1 * T[l - 1] * Zc) / Xr
+        T[l] = (m1 * T[l - 1] * (2 * l - 1) * μ - m2 * T[l - 2] * Yr + m1 * R[l - 1] * Zc) / Xr
+    return P, R, -T
+
+
+def compute_Z_moments(pol_type: PolarizationType, μ: np.ndarray, greek: GreekCoefs, m: int):
+    """Scattering.compute_Z_moments (compute_Z_matrices.jl:5-84): Z⁺⁺, Z⁻⁺ of shape [N, N]
+    (N = n*len(μ); row = outgoing, column = incoming) for Fourier moment m."""
+    μ = np.asarray(μ, dtype=np.float64)
+    if not np.all((0 < μ) & (μ <= 1)):
+        raise AssertionError("all μ's within compute_Z_moments have to be ∈ ]0,1]")
+    n, nμ, lmax = pol_type.n, μ.size, len(greek.β)
+    fact = 0.5 if m == 0 else 1.0
+    Pp, Rp, Tp = _prt_for_moment(μ, lmax, m)
+    Pn, Rn, Tn = _prt_for_moment(-μ, lmax, m)
+
+    def pi_stack(P, R, T):  # [lmax, nμ, n, n]  (construct_Π_matrix, mie_helper_functions.jl:287-323)
+        Π = np.zeros((lmax, nμ, n, n))
+        Π[:, :, 0, 0] = P
+        if n >= 3:
+            Π[:, :, 1, 1] = R
+            Π[:, :, 2, 2] = R
+            Π[:, :, 1, 2] = -T
+            Π[:, :, 2, 1] = -T
+        if n == 4:
+            Π[:, :, 3, 3] = P
+        return Π
+
+    B = np.zeros((lmax, n, n))  # construct_B_matrix (:334-348)
+    B[:, 0, 0] = greek.β
+    if n >= 3:
+        B[:, 0, 1] = greek.γ
+        B[:, 1, 0] = greek.γ
+        B[:, 1, 1] = greek.α
+        B[:, 2, 2] = greek.ζ
+    if n == 4:
+        B[:, 2, 3] = greek.ϵ
+        B[:, 3, 2] = -greek.ϵ
+        B[:, 3, 3] = greek.δ
+    Πp, Πn = pi_stack(Pp, Rp, Tp), pi_stack(Pn, Rn, Tn)
+    App = np.zeros((nμ, nμ, n, n))
+    Amp = np.zeros((nμ, nμ, n, n))
+    for l in range(m, lmax):  # sequential over l like the reference's accumulation
+        left = Πp[l] @ B[l]  # [nμ, n, n]
+        App += np.einsum("iab,jbc->ijac", left, Πp[l])
+        Amp += np.einsum("iab,jbc->ijac", left, Πn[l])
+    sign = np.ones((n, n))
+    if n >= 3:
+        sign[:2, 2:] = -1.0
+        sign[2:, :2] = -1.0
+    N = n * nμ
+    Zpp = (2 * fact * App).transpose(0, 2, 1, 3).reshape(N, N)
+    Zmp = (2 * fact * Amp * sign).transpose(0, 2, 1, 3).reshape(N, N)
+    return Zpp, Zmp
+
+
+# ------------------------------------------------------------------------------------------
+# model containers
+# ------------------------------------------------------------------------------------------
+
+
+@dataclass
+class AerosolOptics:
+    """The fields of the reference's AerosolOptics that the RT core consumes."""
+    greek_coefs: GreekCoefs
+    ω̃: float
+    fᵗ: float = 0.0
+
+
+@dataclass
+class vSmartMOM_Parameters:
+    """Subset of types.jl:394-446 consumed by the elastic hot path."""
+    polarization_type: PolarizationType
+    quadrature_type: str
+    max_m: int
+    l_trunc: int
+    depol: float
+    sza: float
+    vza: np.ndarray
+    vaz: np.ndarray
+    brdf_albedo: float = 0.0  # LambertianSurfaceScalar(albedo)
+    architecture: AbstractArchitecture = field(default_factory=default_architecture)
+    strict_reference_indexing: bool = True
+
+
+@dataclass
+class vSmartMOM_Model:
+    """types.jl:476-520, restricted to one concatenated band: τ arrays are [nSpec, Nz]."""
+    params: vSmartMOM_Parameters
+    quad_points: QuadPoints
+    greek_rayleigh: GreekCoefs
+    τ_rayl: np.ndarray
+    τ_abs: np.ndarray
+    τ_aer: np.ndarray  # [nAer, Nz]
+    aerosol_optics: List[AerosolOptics]
+    ϖ_Cabannes: float = 1.0
+
+
+def model_from_parameters(params: vSmartMOM_Parameters, τ_rayl, τ_abs, τ_aer=None,
+                          aerosol_optics: Optional[List[AerosolOptics]] = None) -> vSmartMOM_Model:
+    """model_from_parameters(params) (model_from_parameters.jl:12-194) for callers that bring
+    their own optical-depth tables (the reference computes them from profiles/HITRAN/Mie, which
+    stays host-side Julia and is outside this package's scope)."""
+    qp = rt_set_streams(params.quadrature_type, params.l_trunc, params.sza, params.vza, params.polarization_type)
+    τ_rayl = np.asarray(τ_rayl, dtype=np.float64)
+    τ_abs = np.asarray(τ_abs, dtype=np.float64)
+    if τ_rayl.shape != τ_abs.shape or τ_rayl.ndim != 2:
+        raise ValueError("τ_rayl and τ_abs must both be [nSpec, Nz]")
+    aerosol_optics = list(aerosol_optics or [])
+    τ_aer = np.zeros((0, τ_rayl.shape[1])) if τ_aer is None else np.asarray(τ_aer, dtype=np.float64)
+    if τ_aer.shape != (len(aerosol_optics), τ_rayl.shape[1]):
+        raise ValueError("τ_aer must be [nAer, Nz]")
+    return vSmartMOM_Model(params, qp, get_greek_rayleigh(params.depol), τ_rayl, τ_abs, τ_aer, aerosol_optics)
+
+
+# ------------------------------------------------------------------------------------------
+# layer optics, doubling numbers, interface codes
+# ------------------------------------------------------------------------------------------
+
+
+def doubling_number(dτ_max: float, τ_end: float):
+    """rt_helper_functions.jl:31-57 (log10 arithmetic and the eps test kept verbatim)."""
+    if τ_end <= dτ_max:
+        return τ_end, 0
+    q1, q2, q3 = math.log10(2.0), math.log10(dτ_max), math.log10(τ_end)
+    tlimit = (q3 - q2) / q1
+    nlimit = math.floor(tlimit)
+    if tlimit - nlimit < EPS:
+        return dτ_max, int(nlimit)
+    nd = int(nlimit) + 1
+    return 10.0 ** (q3 - q1 * nd), nd
+
+
+def get_dtau_ndoubl(τ: np.ndarray, ϖ: np.ndarray, qp_μ: np.ndarray):
+    """rt_kernel.jl:238-246: both maxima run over the WHOLE spectral axis."""
+    mx = float(np.max(τ * ϖ))
+    _, nd = doubling_number(min(mx, 0.001 * float(np.min(qp_μ))), mx)
+    return τ / 2 ** nd, nd
+
+
+@dataclass
+class LayerInputs:
+    """What constructCoreOpticalProperties + extractEffectiveProps + get_dtau_ndoubl deliver
+    for all layers, in the native form of the C ABI (basis + weights instead of N×N×nSpec)."""
+    τ: np.ndarray  # [S, Nz]
+    ϖ: np.ndarray  # [S, Nz]
+    zw: np.ndarray  # [K, S, Nz]
+    ndoubl: np.ndarray  # [Nz] int32
+    iface: np.ndarray  # [Nz] int32, 0..3 = ScatteringInterface_00/01/10/11
+    τ_sum: np.ndarray  # [S, Nz+1]
+
+
+def construct_layer_inputs(model: vSmartMOM_Model) -> LayerInputs:
+    """constructCoreOpticalProperties (compEffectiveLayerProperties.jl:1-78) with the `+` of
+    types.jl:632-678, createAero (:80-85), extractEffectiveProps (:88-111) and
+    get_scattering_interface (rt_helper_functions.jl:8-27).  None of it depends on m."""
+    S, Nz = model.τ_rayl.shape
+    K = 1 + len(model.aerosol_optics)
+    τ = np.empty((S, Nz))
+    ϖ = np.empty((S, Nz))
+    zw = np.zeros((K, S, Nz))
+    for z in range(Nz):
+        τz = model.τ_rayl[:, z].copy()
+        ϖz = np.full(S, float(model.ϖ_Cabannes))
+        w = np.zeros((K, S))
+        w[0] = 1.0
+        for a, aer in enumerate(model.aerosol_optics, start=1):
+            τy = (1 - aer.fᵗ * aer.ω̃) * model.τ_aer[a - 1, z]
+            ϖy = (1 - aer.fᵗ) * aer.ω̃ / (1 - aer.fᵗ * aer.ω̃)
+            wx, wy = τz * ϖz, np.full(S, τy * ϖy)
+            tot = wx + wy
+            τn = τz + τy
+            ϖn = tot / τn
+            if np.all(wx == 0.0):
+                w[:] = 0.0
+                w[a] = 1.0
+            elif not np.all(wy == 0.0):
+                w *= (wx / tot)[None, :]
+                w[a] = wy / tot
+            τz, ϖz = τn, ϖn
+        τn = τz + model.τ_abs[:, z]
+        ϖz = (τz * ϖz) / τn
+        τ[:, z], ϖ[:, z], zw[:, :, z] = τn, ϖz, w
+    iface = np.zeros(Nz, dtype=np.int32)
+    nd = np.zeros(Nz, dtype=np.int32)
+    τ_sum = np.zeros((S, Nz + 1))
+    prev = 0
+    for z in range(Nz):
+        scatter = bool(np.max(τ[:, z] * ϖ[:, z]) > 2 * EPS)
+        if z == 0:
+            prev = 3 if scatter else 0
+        elif prev == 0:
+            prev = 1 if scatter else 0
+        else:
+            prev = 3 if scatter else 2
+        iface[z] = prev
+        τ_sum[:, z + 1] = τ_sum[:, z] + 1.0 * τ[:, z]
+        nd[z] = get_dtau_ndoubl(τ[:, z], ϖ[:, z], model.quad_points.qp_μ)[1]
+    return LayerInputs(τ, ϖ, zw, nd, iface, τ_sum)
+
+
+def z_bases(model: vSmartMOM_Model):
+    """Z⁺⁺/Z⁻⁺ bases [M, K, N, N] (k = 0 Rayleigh, then aerosols) for m = 0..max_m-1."""
+    pol, μ = model.params.polarization_type, model.quad_points.qp_μ
+    greeks = [model.greek_rayleigh] + [a.greek_coefs for a in model.aerosol_optics]
+    Zpp = np.array([[compute_Z_moments(pol, μ, g, m)[0] for g in greeks] for m in range(model.params.max_m)])
+    Zmp = np.array([[compute_Z_moments(pol, μ, g, m)[1] for g in greeks] for m in range(model.params.max_m)])
+    return Zpp, Zmp
+
+
+def _abi_mats(Z: np.ndarray) -> np.ndarray:
+    """[..., i, j] -> flat buffer with i fastest (Julia column-major per matrix)."""
+    return np.ascontiguousarray(np.swapaxes(Z, -1, -2)).reshape(-1)
+
+
+def view_nodes(model: vSmartMOM_Model) -> np.ndarray:
+    """postprocessing_vza.jl:28: nearest quadrature node (1-based) per viewing zenith angle."""
+    qp = model.quad_points.qp_μ
+    return np.array([int(np.argmin(np.abs(qp - cosd(v)))) + 1 for v in model.params.vza], dtype=np.int32)
+
+
+# ------------------------------------------------------------------------------------------
+# rt_run
+# ------------------------------------------------------------------------------------------
+
+
+@dataclass
+class SceneInputs:
+    """Everything mom_scene_set consumes, already in ABI memory order."""
+    N: int
+    nStokes: int
+    S: int
+    Nz: int
+    K: int
+    M: int
+    tau: np.ndarray
+    varpi: np.ndarray
+    zw: np.ndarray
+    Zpp: np.ndarray
+    Zmp: np.ndarray
+    ndoubl: np.ndarray
+    iface: np.ndarray
+    tau_sum: np.ndarray
+    albedo: float
+    node: np.ndarray
+    cos_mphi: np.ndarray
+    sin_mphi: np.ndarray
+
+    def spectral_slice(self, lo: int, hi: int) -> "SceneInputs":
+        """Shard [lo, hi) of the spectral axis.  ndoubl / iface stay the GLOBAL ones
+        (rt_kernel.jl:241-242 takes maxima over the whole axis): SURVEY section 8e."""
+        S, Nz, K = self.S, self.Nz, self.K
+        sl = slice(lo, hi)
+        return SceneInputs(self.N, self.nStokes, hi - lo, Nz, K, self.M,
+                           np.ascontiguousarray(self.tau.reshape(Nz, S)[:, sl]).reshape(-1),
+                           np.ascontiguousarray(self.varpi.reshape(Nz, S)[:, sl]).reshape(-1),
+                           np.ascontiguousarray(self.zw.reshape(Nz, S, K)[:, sl, :]).reshape(-1),
+                           self.Zpp, self.Zmp, self.ndoubl, self.iface,
+                           np.ascontiguousarray(self.tau_sum.reshape(Nz + 1, S)[:, sl]).reshape(-1),
+                           self.albedo, self.node, self.cos_mphi, self.sin_mphi)
+
+
+def prepare_scene(model: vSmartMOM_Model) -> SceneInputs:
+    """Host preparation of rt_run.jl:43-138 for every Fourier moment at once."""
+    p, qp = model.params, model.quad_points
+    L = construct_layer_inputs(model)
+    Zpp, Zmp = z_bases(model)
+    M = p.max_m
+    S, Nz = L.τ.shape
+    cm = np.array([[cosd(m * a) for a in p.vaz] for m in range(M)])
+    sm = np.array([[sind(m * a) for a in p.vaz] for m in range(M)])
+    return SceneInputs(
+        N=len(qp.qp_μN), nStokes=p.polarization_type.n, S=S, Nz=Nz, K=L.zw.shape[0], M=M,
+        tau=np.ascontiguousarray(L.τ.T).reshape(-1), varpi=np.ascontiguousarray(L.ϖ.T).reshape(-1),
+        zw=np.ascontiguousarray(L.zw.transpose(2, 1, 0)).reshape(-1),  # [z][n][k]
+        Zpp=_abi_mats(Zpp), Zmp=_abi_mats(Zmp), ndoubl=L.ndoubl, iface=L.iface,
+        tau_sum=np.ascontiguousarray(L.τ_sum.T).reshape(-1), albedo=float(p.brdf_albedo), node=view_nodes(model),
+        cos_mphi=cm.reshape(-1), sin_mphi=sm.reshape(-1))
+
+
+def make_handle(model: vSmartMOM_Model, S: Optional[int] = None) -> _lib.Handle:
+    p, qp = model.params, model.quad_points
+    if not isinstance(p.architecture, MI355X):
+        raise TypeError("this package only executes on Architectures.MI355X (no CPU path)")
+    h = _lib.Handle(len(qp.qp_μN), p.polarization_type.n, S if S is not None else model.τ_rayl.shape[0], p.max_m,
+                    device=p.architecture.device)
+    h.set_streams(qp.qp_μN, qp.wt_μN, qp.iμ0, qp.μ0, p.polarization_type.I0, p.polarization_type.D,
+                  p.strict_reference_indexing)
+    return h
+
+
+def run_scene(h: _lib.Handle, sc: SceneInputs):
+    h.scene_set(sc.Nz, sc.K, sc.M, sc.tau, sc.varpi, sc.zw, sc.Zpp, sc.Zmp, sc.ndoubl, sc.iface, sc.tau_sum,
+                sc.albedo, sc.node, sc.cos_mphi, sc.sin_mphi)
+    h.rt_run()
+    return h.get_RT()
+
+
+def rt_run(model: vSmartMOM_Model, i_band: int = 1):
+    """rt_run(model; i_band) (rt_run.jl:19-21 -> :41-230), SFI = true, noRS.
+    Returns (R_SFI, T_SFI), each [nVza, nStokes, nSpec] like rt_run.jl:226 (the RAMI extras
+    hdr/bhr of the reference's 7-tuple are outside this round's scope)."""
+    sc = prepare_scene(model)
+    with make_handle(model) as h:
+        return run_scene(h, sc)
+
+
+def rt_run_operators(model: vSmartMOM_Model):
+    """The same run replayed operator by operator through the op-level ABI, exactly in the
+    order of rt_run.jl:125-215 / rt_kernel.jl:173-235 (what a Julia shim overloading
+    elemental!/doubling!/interaction! one by one would execute)."""
+    p, qp = model.params, model.quad_points
+    pol = p.polarization_type
+    L = construct_layer_inputs(model)
+    Zpp, Zmp = z_bases(model)
+    S, Nz = L.τ.shape
+    nV = len(p.vza)
+    R = np.zeros((nV, pol.n, S))
+    T = np.zeros((nV, pol.n, S))
+    nodes = view_nodes(model)
+    with make_handle(model) as h:
+        for m in range(p.max_m):
+            weight = 0.5 if m == 0 else 1.0
+            for z in range(Nz):
+                dτ, nd = get_dtau_ndoubl(L.τ[:, z], L.ϖ[:, z], qp.qp_μ)
+                expk = np.exp(-dτ / qp.μ0)
+                Zp = np.einsum("ks,kij->sij", L.zw[:, :, z], Zpp[m])
+                Zm = np.einsum("ks,kij->sij", L.zw[:, :, z], Zmp[m])
+                h.elemental(m, nd, L.τ_sum[:, z], dτ, L.ϖ[:, z], _abi_mats(Zp), _abi_mats(Zm), S)
+                h.doubling(nd, expk)
+                if z == 0:
+                    h.copy_added_to_composite()
+                else:
+                    h.interaction(int(L.iface[z]))
+            h.surface_lambertian(m, p.brdf_albedo, L.τ_sum[:, -1])
+            h.interaction(int(L.iface[-1]), with_surface_layer=True)
+            J0p = h.download(_lib.COMP["J0p"]).reshape(S, -1)
+            J0m = h.download(_lib.COMP["J0m"]).reshape(S, -1)
+            for i in range(nV):
+                ist = (nodes[i] - 1) * pol.n
+                c, s_ = cosd(m * p.vaz[i]), sind(m * p.vaz[i])
+                cs = weight * np.array([c, c, s_, s_])[: pol.n]
+                R[i] += (cs[None, :] * J0m[:, ist:ist + pol.n]).T
+                T[i] += (cs[None, :] * J0p[:, ist:ist + pol.n]).T
+    return R, T

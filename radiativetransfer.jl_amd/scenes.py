@@ -1,0 +1,113 @@
+"""Seeded synthetic scenes for benchmarks and parity tests (no external data): SURVEY.md
+section 8d / BASELINE.json `configs`.  They stand in for what the reference's
+model_from_parameters() derives from YAML + HITRAN + Mie, with the same shapes:
+
+  C1  scalar I, 4 streams, 10 layers, S = 100                  ("default_parameters-like" plumbing)
+  C2  O2 A-band, IQU, 20 streams (N = 60), 40 layers, S = 10 000   <- headline metric
+  C3  3-band OCO-2-like, S = 29 944, sharded over the GPUs of a node
+  C4  aerosol + cloud, IQUV, 64 streams (N = 256)
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import corert as rt
+
+
+def hg_like_greek(g: float, lmax: int) -> rt.GreekCoefs:
+    """Henyey-Greenstein-like expansion: β_l = (2l+1) g^l, polarised terms scaled from it."""
+    l = np.arange(lmax, dtype=np.float64)
+    β = (2 * l + 1) * g ** l
+    hi = (l >= 2).astype(np.float64)
+    return rt.GreekCoefs(α=0.9 * β * hi, β=β, γ=0.08 * β * hi * g, δ=0.8 * β, ϵ=0.02 * β * hi * g, ζ=0.9 * β * hi)
+
+
+def pressure_grid(Nz: int) -> np.ndarray:
+    """Nz layers between log-spaced half levels 0.1 ... 1000 hPa (TOA first)."""
+    return np.exp(np.linspace(math.log(0.1), math.log(1000.0), Nz + 1))
+
+
+def rayleigh_tau(ν: np.ndarray, p_half: np.ndarray, depol: float) -> np.ndarray:
+    """getRayleighLayerOptProp (atmo_prof.jl:210-224) with vcd ∝ Δp.  ν in cm⁻¹ -> [S, Nz]."""
+    λ = 1.0e4 / ν  # μm
+    tau = 0.00864 * (p_half[-1] / 1013.25) * λ ** (-(3.916 + 0.074 * λ + 0.05 / λ))
+    tau = tau * (6.0 + 3.0 * depol) / (6.0 - 7.0 * depol)
+    dp = np.diff(p_half)
+    return tau[:, None] * (dp / dp.sum())[None, :]
+
+
+def aerosol_profile(total: float, p0: float, σp: float, p_half: np.ndarray) -> np.ndarray:
+    """Gaussian-in-pressure aerosol optical depth per layer (like getAerosolLayerOptProp)."""
+    pc = 0.5 * (p_half[1:] + p_half[:-1])
+    w = np.exp(-0.5 * ((pc - p0) / σp) ** 2) * np.diff(p_half)
+    return total * w / w.sum()
+
+
+def lognormal_absorption(S: int, p_half: np.ndarray, seed: int) -> np.ndarray:
+    """Line-like gas absorption: column optical depth log-uniform-ish over 1e-3 ... 50 along the
+    spectral axis (smooth random walk + spikes), split over layers ∝ Δp·p (pressure broadening)."""
+    rng = np.random.default_rng(seed)
+    x = np.cumsum(rng.normal(0.0, 0.35, S))
+    x = (x - x.min()) / max(x.max() - x.min(), 1e-300)
+    col = 10.0 ** (-3.0 + x * (math.log10(50.0) + 3.0))
+    pc = 0.5 * (p_half[1:] + p_half[:-1])
+    w = np.diff(p_half) * pc
+    return col[:, None] * (w / w.sum())[None, :]
+
+
+def make_scene(nStokes: int, l_trunc: int, Nz: int, S: int, ν_lo: float = 12903.0, ν_hi: float = 13245.0,
+               sza: float = 60.0, vza=(0.0, 30.0, 60.0), vaz=(0.0, 45.0, 120.0), aerosol_total: float = 0.2,
+               aerosol_p0: float = 800.0, aerosol_σp: float = 50.0, g: float = 0.7, albedo: float = 0.2,
+               depol: float = 0.03, max_m: int = 3, seed: int = 1234, absorption: bool = True,
+               architecture=None) -> rt.vSmartMOM_Model:
+    pol = {1: rt.Stokes_I, 3: rt.Stokes_IQU, 4: rt.Stokes_IQUV}[nStokes]()
+    params = rt.vSmartMOM_Parameters(
+        polarization_type=pol, quadrature_type="GaussQuadHemisphere", max_m=max_m, l_trunc=l_trunc, depol=depol,
+        sza=sza, vza=np.asarray(vza, dtype=np.float64), vaz=np.asarray(vaz, dtype=np.float64), brdf_albedo=albedo,
+        architecture=architecture or rt.default_architecture())
+    p_half = pressure_grid(Nz)
+    ν = np.linspace(ν_lo, ν_hi, S)
+    τ_rayl = rayleigh_tau(ν, p_half, depol)
+    τ_abs = lognormal_absorption(S, p_half, seed) if absorption else np.zeros((S, Nz))
+    aer, τ_aer = [], None
+    if aerosol_total > 0:
+        aer = [rt.AerosolOptics(hg_like_greek(g, l_trunc), 0.95, 0.0)]
+        τ_aer = aerosol_profile(aerosol_total, aerosol_p0, aerosol_σp, p_half)[None, :]
+    return rt.model_from_parameters(params, τ_rayl, τ_abs, τ_aer, aer)
+
+
+def scene_C1(S: int = 100, **kw):
+    """scalar I, Nquad_eff = 4 (2 Gauss nodes + μ=1 + μ₀), 10 layers."""
+    return make_scene(1, 3, 10, S, vza=(0.0,), vaz=(0.0,), **kw)
+
+
+def scene_C2(S: int = 10_000, Nz: int = 40, **kw):
+    """O2 A-band IQU: 17 Gauss nodes + {1, cos30°, cos60°=μ₀} = 20 streams, N = 60."""
+    return make_scene(3, 33, Nz, S, **kw)
+
+
+def scene_C3(S: int = 29_944, Nz: int = 40, **kw):
+    """three concatenated bands (13 672 + 6 402 + 9 870 points) on one spectral axis."""
+    m = make_scene(3, 33, Nz, S, **kw)
+    n1, n2 = 13_672 * S // 29_944, 6_402 * S // 29_944
+    ν = np.concatenate([np.linspace(12903.0, 13245.0, n1), np.linspace(6170.0, 6290.0, n2),
+                        np.linspace(4800.0, 4900.0, S - n1 - n2)])
+    m.τ_rayl[:] = rayleigh_tau(ν, pressure_grid(Nz), m.params.depol)
+    return m
+
+
+def scene_C4(S: int = 2_000, Nz: int = 40, **kw):
+    """aerosol + cloud, IQUV, 61 Gauss nodes + 3 = 64 streams, N = 256."""
+    kw.setdefault("aerosol_total", 5.0)
+    kw.setdefault("aerosol_p0", 700.0)
+    return make_scene(4, 121, Nz, S, **kw)
+
+
+def work_model_flops(N: int, ndoubl, M: int) -> float:
+    """ALGORITHMIC flop per spectral point: the reference's op list, GEMM =
+    2N³, inverse = 2N³, matvec = 2N², regardless of how the kernels restructure it."""
+    Nz = len(ndoubl)
+    per_m = float(np.sum(ndoubl)) * (12 * N ** 3 + 8 * N ** 2) + Nz * (24 * N ** 3 + 8 * N ** 2)
+    return M * per_m + M * Nz * N * N * (3 + 12)

@@ -1,0 +1,60 @@
+"""Shared test helpers: model <-> oracle scene conversion and the parity tolerances."""
+import numpy as np
+
+from oracle import momref as mr
+
+# Parity bar of BASELINE.json north_star: Stokes I/Q/U within 1e-10 relative.  "Relative" is
+# taken against the intensity |I| of the same view and spectral point (Q and U cross zero), plus an
+# absolute floor of 1e-14 of the unit incoming solar flux for points whose reference value is itself
+# rounding noise (deep absorption, tau ~ 17+: the reference's own I comes out as -2.6e-16 there).
+RTOL_STOKES = 1e-10
+ATOL_STOKES = 1e-14
+# per-operator bar: 1e-12 of the operator's largest element
+RTOL_OP = 1e-12
+
+
+def assert_stokes_close(X, Xref, rtol=RTOL_STOKES, atol=ATOL_STOKES, what=""):
+    X, Xref = np.asarray(X), np.asarray(Xref)
+    assert X.shape == Xref.shape, (X.shape, Xref.shape)
+    assert np.all(np.isfinite(X)), f"{what}: non-finite values"
+    scale = np.abs(Xref[:, 0:1, :])
+    err = np.abs(X - Xref)
+    bad = err > rtol * scale + atol
+    if np.any(bad):
+        idx = np.unravel_index(np.argmax(err / (rtol * scale + atol)), err.shape)
+        raise AssertionError(f"{what}: |Δ|={err[idx]:.3e} at {idx}, ref={Xref[idx]:.6e}, I_ref={scale[idx[0],0,idx[2]]:.3e}")
+    return float(np.max(err / np.maximum(scale, atol / rtol)))
+
+
+def assert_op_close(X, Xref, rtol=RTOL_OP, what=""):
+    X, Xref = np.asarray(X).reshape(-1), np.asarray(Xref).reshape(-1)
+    assert X.shape == Xref.shape
+    assert np.all(np.isfinite(X)), f"{what}: non-finite values"
+    scale = max(float(np.max(np.abs(Xref))), 1e-300)
+    err = float(np.max(np.abs(X - Xref))) / scale
+    assert err <= rtol, f"{what}: max |Δ|/max|ref| = {err:.3e} > {rtol:.1e}"
+    return err
+
+
+def oracle_scene(model) -> mr.Scene:
+    """vSmartMOM_Model (product host types) -> numpy-twin Scene (oracle types).  The oracle
+    recomputes streams, Z moments and layer optics with ITS OWN code from the same physical inputs."""
+    p = model.params
+    n = p.polarization_type.n
+    quad = mr.rt_set_streams(p.quadrature_type, p.l_trunc, p.sza, p.vza, n)
+    aer = [mr.AerosolOptics(mr.GreekCoefs(a.greek_coefs.α, a.greek_coefs.β, a.greek_coefs.γ, a.greek_coefs.δ,
+                                          a.greek_coefs.ϵ, a.greek_coefs.ζ), a.ω̃, a.fᵗ) for a in model.aerosol_optics]
+    return mr.Scene(pol=mr.pol_from_n(n), quad=quad, max_m=p.max_m, tau_rayl=model.τ_rayl, tau_abs=model.τ_abs,
+                    greek_rayleigh=mr.get_greek_rayleigh(p.depol), tau_aer=model.τ_aer, aerosols=aer,
+                    varpi_cabannes=model.ϖ_Cabannes, albedo=p.brdf_albedo, vza=np.asarray(p.vza, float),
+                    vaz=np.asarray(p.vaz, float), strict_reference_indexing=p.strict_reference_indexing)
+
+
+def one_layer_rayleigh(rt, sza, vza, vaz, tau, rho, pol=None, quad="RadauQuad", l_trunc=20, max_m=3):
+    """The set-up of test/test_CoreRT.jl: one Rayleigh layer with τ_rayl forced to `tau`
+    (test_CoreRT.jl:21,:63), no absorption, Lambertian albedo rho, depol 0."""
+    pol = pol or rt.Stokes_IQUV()
+    params = rt.vSmartMOM_Parameters(polarization_type=pol, quadrature_type=quad, max_m=max_m, l_trunc=l_trunc,
+                                     depol=0.0, sza=sza, vza=np.asarray(vza, float), vaz=np.asarray(vaz, float),
+                                     brdf_albedo=rho)
+    return rt.model_from_parameters(params, np.full((1, 1), tau), np.zeros((1, 1)))

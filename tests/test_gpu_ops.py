@@ -1,0 +1,174 @@
+"""Operator-level parity on the GPU, through the C ABI: each reference operator
+(elemental!, doubling!, interaction!, create_surface_layer!, batch_inv!, ⊠) against the C oracle on
+the same seeded inputs.  Shapes follow the reference's own GPU-vs-CPU scripts (test/gpu_tests/*.jl)."""
+import numpy as np
+import pytest
+
+import helpers
+from oracle import momref as mr
+
+pytestmark = pytest.mark.gpu
+
+
+def _streams(rt, nS, Nquad=6, sza=50.0):
+    pol = {1: rt.Stokes_I, 3: rt.Stokes_IQU, 4: rt.Stokes_IQUV}[nS]()
+    q = rt.rt_set_streams("GaussQuadHemisphere", 2 * (Nquad - 3) - 1 if Nquad > 3 else 1, sza, [0.0, 30.0], pol)
+    return pol, q
+
+
+def _handle(rtamd, pol, q, S, strict=True, generic=False, force_gj=False):
+    h = rtamd.Handle(len(q.qp_μN), pol.n, S, 1)
+    if generic:
+        h.set_option(rtamd._lib.MOM_OPT_FORCE_GENERIC, 1)
+    if force_gj:
+        h.set_option(rtamd._lib.MOM_OPT_INVERSE, 1)
+    h.set_streams(q.qp_μN, q.wt_μN, q.iμ0, q.μ0, pol.I0, pol.D, strict)
+    return h
+
+
+class _P:  # what oracle.cref op wrappers need
+    def __init__(self, pol, q, strict=True):
+        self.N, self.nS, self.imu0, self.mu0 = len(q.qp_μN), pol.n, q.iμ0, q.μ0
+        self.mu, self.wt = np.ascontiguousarray(q.qp_μN), np.ascontiguousarray(q.wt_μN)
+        self.I0, self.D, self.strict, self.albedo = np.array(pol.I0), np.array(pol.D), int(strict), 0.3
+
+
+NAMES = ["r_pm", "r_mp", "t_mm", "t_pp", "j0p", "j0m"]
+
+
+@pytest.mark.parametrize("nS", [1, 3, 4])
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nd", [0, 1, 6])
+def test_elemental_and_doubling(rtamd, cref, nS, strict, nd):
+    """elemental_test.jl (n=40 there) + D_matrix_test.jl (nStokes 1..4) + gpu_cpu_tests.jl doubling."""
+    rt = rtamd.corert
+    pol, q = _streams(rt, nS, Nquad=8)
+    N, S = len(q.qp_μN), 37
+    rng = np.random.default_rng(nS * 10 + nd)
+    g = rtamd.scenes.hg_like_greek(0.6, 9)
+    Zpp, Zmp = rt.compute_Z_moments(pol, q.qp_μ, g, 1)
+    zb = 1 if nd == 1 else S  # both the shared and the per-point Z form
+    Zp = np.repeat(Zpp[None], zb, 0) * (1 + 0.1 * rng.random((zb, 1, 1)))
+    Zm = np.repeat(Zmp[None], zb, 0) * (1 + 0.1 * rng.random((zb, 1, 1)))
+    dtau = 10.0 ** rng.uniform(-7, -3, S)
+    varpi = rng.uniform(0.0, 1.0, S)
+    tau_sum = rng.uniform(0.0, 3.0, S)
+    p = _P(pol, q, strict)
+    ref = cref.elemental(p, 1, nd, tau_sum, dtau, varpi, mr.to_abi(Zp), mr.to_abi(Zm), zb, S)
+    with _handle(rtamd, pol, q, S, strict) as h:
+        h.elemental(1, nd, tau_sum, dtau, varpi, mr.to_abi(Zp), mr.to_abi(Zm), zb)
+        for k, nm in enumerate(NAMES):
+            if nd >= 1 and nm in ("r_pm", "t_mm"):
+                continue
+            helpers.assert_op_close(h.download(k), ref[k], what=f"elemental {nm}")
+        expk = np.exp(-dtau / q.μ0)
+        e_ref = expk.copy()
+        assert cref.doubling(p, nd, e_ref, ref, S) == 0
+        e_gpu = h.doubling(nd, expk)
+        np.testing.assert_allclose(e_gpu, e_ref, rtol=1e-15)
+        for k, nm in enumerate(NAMES):
+            if nd == 0 and False:
+                continue
+            helpers.assert_op_close(h.download(k), ref[k], rtol=1e-11, what=f"doubling {nm}")
+
+
+@pytest.mark.parametrize("mode", ["lds", "lds_gj", "generic", "generic_gj"])
+def test_doubling_thick_layer_all_inverse_paths(rtamd, cref, mode):
+    """Strongly reflecting layer: r large enough that the Neumann bound does not apply -> pivoted
+    Gauss-Jordan; thin steps take the series path.  All four code paths must agree with the oracle."""
+    rt = rtamd.corert
+    pol, q = _streams(rt, 3, Nquad=9)
+    N, S, nd = len(q.qp_μN), 19, 14
+    rng = np.random.default_rng(4)
+    Zpp, Zmp = rt.compute_Z_moments(pol, q.qp_μ, rtamd.scenes.hg_like_greek(0.75, 11), 0)
+    dtau = np.full(S, 2e-4) * rng.uniform(0.5, 1.0, S)  # final tau ~ 3: conservative cloud
+    varpi = np.full(S, 0.999999)
+    p = _P(pol, q)
+    ref = cref.elemental(p, 0, nd, np.zeros(S), dtau, varpi, mr.to_abi(Zpp[None]), mr.to_abi(Zmp[None]), 1, S)
+    e_ref = np.exp(-dtau / q.μ0)
+    assert cref.doubling(p, nd, e_ref, ref, S) == 0
+    with _handle(rtamd, pol, q, S, generic="generic" in mode, force_gj="gj" in mode) as h:
+        h.elemental(0, nd, np.zeros(S), dtau, varpi, mr.to_abi(Zpp[None]), mr.to_abi(Zmp[None]), 1)
+        h.doubling(nd, np.exp(-dtau / q.μ0))
+        for k, nm in enumerate(NAMES):
+            helpers.assert_op_close(h.download(k), ref[k], rtol=1e-10, what=f"{mode} {nm}")
+        assert np.abs(ref[1]).max() > 0.05  # the layer really is reflective
+
+
+@pytest.mark.parametrize("iface", [0, 1, 2, 3])
+@pytest.mark.parametrize("N,S,generic", [(16, 100, False), (16, 100, True), (32, 40, False), (72, 3, False)])
+def test_interaction(rtamd, cref, iface, N, S, generic):
+    """gpu_batched_interaction2.jl: n=16, nSpec=100, Float64, random operators."""
+    rt = rtamd.corert
+    rng = np.random.default_rng(iface + N)
+    mk = lambda s: rng.random((S, N, N)) * s / N
+    added = [mk(0.6), mk(0.6), mk(0.9) + 0.3 * np.eye(N), mk(0.9) + 0.3 * np.eye(N), rng.random((S, N)), rng.random((S, N))]
+    comp = [mk(0.6), mk(0.6), mk(0.9), mk(0.9), rng.random((S, N)), rng.random((S, N))]
+    c_add = [mr.to_abi(x).copy() for x in added]
+    c_comp = [mr.to_abi(x).copy() for x in comp]
+    pol = rt.Stokes_I()
+    mu = np.linspace(0.1, 1.0, N)
+    h = rtamd.Handle(N, 1, S, 1)
+    if generic:
+        h.set_option(rtamd._lib.MOM_OPT_FORCE_GENERIC, 1)
+    h.set_streams(mu, np.full(N, 1.0 / N), 1, mu[0], pol.I0, pol.D, True)
+    for k in range(6):
+        h.upload(k, c_add[k])
+        h.upload(6 + k, c_comp[k])
+    h.interaction(iface)
+    assert cref.interaction(N, S, iface, c_comp, c_add) == 0
+    for k, nm in enumerate(["R_mp", "R_pm", "T_pp", "T_mm", "J0p", "J0m"]):
+        helpers.assert_op_close(h.download(6 + k), c_comp[k], rtol=1e-11, what=f"iface {iface} {nm}")
+    h.close()
+
+
+@pytest.mark.parametrize("nS", [1, 3, 4])
+def test_surface_lambertian(rtamd, cref, nS):
+    rt = rtamd.corert
+    pol, q = _streams(rt, nS, Nquad=7)
+    S = 11
+    p = _P(pol, q)
+    tau_tot = np.random.default_rng(1).uniform(0.1, 4.0, S)
+    with _handle(rtamd, pol, q, S) as h:
+        for m in (0, 1):
+            ref = cref.surface_lambertian(p, m, tau_tot, S)
+            h.surface_lambertian(m, p.albedo, tau_tot)
+            for k, nm in enumerate(NAMES):
+                helpers.assert_op_close(h.download(12 + k), ref[k] if (m == 0 or nm != "r_pm") else ref[k] * 0,
+                                        rtol=1e-14, what=f"surface m={m} {nm}")
+
+
+@pytest.mark.parametrize("n,batch", [(32, 1000), (60, 64), (7, 33), (100, 5)])
+def test_batch_inv_and_mul(rtamd, cref, n, batch):
+    """matrix_inv_test.jl: n=32, batch 10 000 (reduced)."""
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(batch, n, n)) + 3 * np.eye(n)
+    B = rng.normal(size=(batch, n, n))
+    with rtamd.Handle(4, 1, 1, 1) as h:
+        X = h.batch_inv(n, batch, mr.to_abi(A))
+        Xr, info = cref.batch_inv(n, batch, mr.to_abi(A))
+        assert info == 0
+        helpers.assert_op_close(X, Xr, rtol=1e-11, what="batch_inv")
+        Cg = h.batched_mul(n, batch, mr.to_abi(A), mr.to_abi(B))
+        helpers.assert_op_close(Cg, cref.batched_mul(n, batch, mr.to_abi(A), mr.to_abi(B)), rtol=1e-13, what="⊠")
+
+
+def test_singular_operator_is_reported(rtamd):
+    """The reference ignores cuBLAS `info` (gpu_batched.jl:65-70); here a zero pivot surfaces as MOM_ESINGULAR."""
+    n, batch = 12, 4
+    A = np.random.default_rng(0).normal(size=(batch, n, n))
+    A[2, :, 5] = 0.0
+    with rtamd.Handle(4, 1, 1, 1) as h:
+        with pytest.raises(rtamd.MomError) as e:
+            h.batch_inv(n, batch, mr.to_abi(A))
+        assert e.value.code == rtamd._lib.MOM_ESINGULAR
+        h.batch_inv(n, batch, mr.to_abi(A + 5 * np.eye(n)))  # the handle stays usable
+
+
+def test_call_sequence_errors(rtamd):
+    with rtamd.Handle(12, 3, 4, 1) as h:
+        with pytest.raises(rtamd.MomError) as e:
+            h.interaction(3)
+        assert e.value.code == rtamd._lib.MOM_ESTATE
+        with pytest.raises(rtamd.MomError):
+            h.rt_run()

@@ -1,0 +1,174 @@
+"""Scene-level parity on the GPU through the C ABI: mom_rt_run (fused per-layer kernels) and the
+operator-by-operator replay against the C oracle, the golden vectors and the reference's tables."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import momref as mr
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def _oracle(cref, model, pts=None):
+    p = cref.pack_scene(helpers.oracle_scene(model))
+    R, T, info = cref.rt_run(p, pts=pts)
+    assert info == 0
+    return R, T
+
+
+def _gpu(rtamd, model, generic=False, force_gj=False):
+    sc = rtamd.prepare_scene(model)
+    with rtamd.corert.make_handle(model) as h:
+        if generic:
+            h.set_option(rtamd._lib.MOM_OPT_FORCE_GENERIC, 1)
+        if force_gj:
+            h.set_option(rtamd._lib.MOM_OPT_INVERSE, 1)
+        return rtamd.corert.run_scene(h, sc)
+
+
+@pytest.mark.parametrize("nS,lt", [(1, 3), (3, 9), (4, 7), (3, 33)])
+@pytest.mark.parametrize("mode", ["lds", "generic", "gj"])
+def test_rt_run_parity(rtamd, cref, nS, lt, mode):
+    m = rtamd.scenes.make_scene(nS, lt, 6, 24, seed=nS + lt)
+    R, T = _gpu(rtamd, m, generic=mode == "generic", force_gj=mode == "gj")
+    Rr, Tr = _oracle(cref, m)
+    helpers.assert_stokes_close(R, Rr, what=f"R {mode}")
+    helpers.assert_stokes_close(T, Tr, what=f"T {mode}")
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_rt_run_iquv_indexing_switch(rtamd, cref, strict):
+    m = rtamd.scenes.make_scene(4, 9, 4, 8, seed=9, vaz=(90.0, 10.0, 170.0))
+    m.params.strict_reference_indexing = strict
+    R, T = _gpu(rtamd, m)
+    Rr, Tr = _oracle(cref, m)
+    helpers.assert_stokes_close(R, Rr, what="R")
+    helpers.assert_stokes_close(T, Tr, what="T")
+
+
+def test_operator_replay_equals_fused(rtamd, cref):
+    """rt_run replayed op by op (elemental!/doubling!/interaction! like a Julia shim would) gives the
+    fused kernels' result to rounding, and both match the oracle."""
+    m = rtamd.scenes.make_scene(3, 9, 5, 12, seed=21)
+    R1, T1 = rtamd.rt_run(m)
+    R2, T2 = rtamd.rt_run_operators(m)
+    Rr, Tr = _oracle(cref, m)
+    helpers.assert_stokes_close(R1, Rr, what="fused R")
+    helpers.assert_stokes_close(R2, Rr, what="replay R")
+    helpers.assert_stokes_close(T2, Tr, what="replay T")
+    helpers.assert_stokes_close(R1, R2, rtol=1e-11, what="fused vs replay")
+
+
+def test_all_interface_cases_and_zero_doublings(rtamd, cref):
+    """Non-scattering layers drive the interface state machine through 00, 01, 10, 11
+    (rt_helper_functions.jl:8-27) and ndoubl = 0 (doubling.jl:28)."""
+    m = rtamd.scenes.make_scene(3, 7, 5, 10, aerosol_total=0.0, seed=2)
+    for z in (0, 1, 3):
+        m.τ_rayl[:, z] = 0.0
+    sc = rtamd.prepare_scene(m)
+    assert list(sc.iface) == [0, 0, 1, 2, 3] and sc.ndoubl[0] == 0
+    for generic in (False, True):
+        R, T = _gpu(rtamd, m, generic=generic)
+        Rr, Tr = _oracle(cref, m)
+        helpers.assert_stokes_close(R, Rr, what="R")
+        helpers.assert_stokes_close(T, Tr, what="T")
+    # surface after a non-scattering last layer: interface code 10 is used for the surface (Q6)
+    m2 = rtamd.scenes.make_scene(1, 5, 3, 6, aerosol_total=0.0, seed=3)
+    m2.τ_rayl[:, 2] = 0.0
+    assert list(rtamd.prepare_scene(m2).iface) == [3, 3, 2]
+    helpers.assert_stokes_close(_gpu(rtamd, m2)[0], _oracle(cref, m2)[0], what="R iface10 surface")
+
+
+def test_golden_small_iqu(rtamd):
+    g = np.load(GOLD / "small_iqu.npz")
+    m = rtamd.scenes.make_scene(3, 3, 3, 4, vza=(0.0,), vaz=(35.0,), seed=7, aerosol_total=0.3, aerosol_p0=500.0,
+                                aerosol_σp=300.0)
+    R, T = rtamd.rt_run(m)
+    helpers.assert_stokes_close(R, g["R"], what="R vs golden")
+    helpers.assert_stokes_close(T, g["T"], what="T vs golden")
+    # per-operator golden: doubling iterations 1 and 2 of the thickest layer
+    z = int(g["dbl_layer"]) - 1
+    sc = rtamd.prepare_scene(m)
+    S, N, Nz = sc.S, sc.N, sc.Nz
+    nd = int(sc.ndoubl[z])
+    dtau = sc.tau.reshape(Nz, S)[z] / 2 ** nd
+    L = rtamd.corert.construct_layer_inputs(m)
+    Zpp, Zmp = rtamd.corert.z_bases(m)
+    Zp = np.einsum("ks,kij->sij", L.zw[:, :, z], Zpp[0])
+    Zm = np.einsum("ks,kij->sij", L.zw[:, :, z], Zmp[0])
+    with rtamd.corert.make_handle(m) as h:
+        for it in (1, 2):
+            h.elemental(0, nd, sc.tau_sum.reshape(Nz + 1, S)[z], dtau, sc.varpi.reshape(Nz, S)[z], mr.to_abi(Zp),
+                        mr.to_abi(Zm), S)
+            h.doubling(it, np.exp(-dtau / m.quad_points.μ0))
+            # undo the D signs the operator applies after its last iteration (identity for strict IQU)
+            helpers.assert_op_close(h.download(3), mr.to_abi(g[f"dbl_iter{it}_z{z + 1}_t_pp"]), rtol=1e-12, what="t_pp")
+            helpers.assert_op_close(h.download(1), mr.to_abi(g[f"dbl_iter{it}_z{z + 1}_r_mp"]), rtol=1e-12, what="r_mp")
+            helpers.assert_op_close(h.download(4), mr.to_abi(g[f"dbl_iter{it}_z{z + 1}_j0p"]), rtol=1e-12, what="j0p")
+
+
+def test_natraj_on_gpu(rtamd):
+    """test/test_CoreRT.jl:40-83 end to end on the GPU (N = 136 -> generic kernels, ndoubl = 18):
+    the reference's thresholds against the Natraj tables, and 1e-10 against the oracle's stored output."""
+    import test_oracle_reference_tables as t
+    g = np.load(GOLD / "natraj.npz")
+    rt = rtamd.corert
+    m = helpers.one_layer_rayleigh(rt, float(np.degrees(np.arccos(0.2))), g["vza"], g["vaz"], 0.5, 0.0)
+    sc = rtamd.prepare_scene(m)
+    assert sc.N == 136 and list(sc.ndoubl) == [18]
+    np.testing.assert_allclose(sc.Zmp, g["Zmp"], rtol=0, atol=1e-13)
+    R, T = rtamd.rt_run(m)
+    helpers.assert_stokes_close(R, g["R"], what="Natraj R vs oracle")
+    eI, eQ, eU = t.natraj_errors(R)
+    assert eI < 0.002 and eQ < 0.008 and eU < 0.008
+
+
+@pytest.mark.parametrize("case", [0, 1, 5])
+def test_6sv1_on_gpu(rtamd, case):
+    """test/test_CoreRT.jl:3-38 on the GPU: R/μ₀ within 0.006 of the 6SV1 tables."""
+    G = json.loads((GOLD / "reference_tables.json").read_text())
+    c = G["sixsv_cases"][case]
+    Rt = np.array(G["sixsv_R"][case])
+    vza1 = np.array(G["sixsv_vza"])
+    for si, sza in enumerate(c["sza"]):
+        m = helpers.one_layer_rayleigh(rtamd.corert, sza, np.tile(vza1, 3), np.repeat(np.array(c["az"], float), 16),
+                                       c["tau"], c["rho"])
+        R, _ = rtamd.rt_run(m)
+        Rm = (R[:, 0, 0] / m.quad_points.μ0).reshape(3, 16)
+        assert np.max(np.abs(Rt[si] - Rm) / Rt[si]) < 0.006
+
+
+def test_sharded_equals_unsharded_bitwise(rtamd):
+    """an N-way split of the spectral axis with GLOBAL ndoubl/iface reproduces the
+    1-way result bit for bit (the multi-GPU correctness argument, exercised on one device)."""
+    m = rtamd.scenes.make_scene(3, 9, 5, 30, seed=8)
+    sc = rtamd.prepare_scene(m)
+    R, T = rtamd.rt_run(m)
+    parts = []
+    for lo, hi in ((0, 11), (11, 19), (19, 30)):
+        with rtamd.corert.make_handle(m, S=hi - lo) as h:
+            parts.append(rtamd.corert.run_scene(h, sc.spectral_slice(lo, hi)))
+    assert np.array_equal(np.concatenate([p[0] for p in parts], axis=2), R)
+    assert np.array_equal(np.concatenate([p[1] for p in parts], axis=2), T)
+
+
+def test_full_size_c2_properties(rtamd, cref):
+    """BASELINE config C2 at full size (N=60, 40 layers, S=10 000): finite, reproducible run to run,
+    and equal to the oracle on a seeded sample of spectral points (the oracle needs ~0.5 s per point)."""
+    m = rtamd.scenes.scene_C2()
+    sc = rtamd.prepare_scene(m)
+    assert (sc.N, sc.Nz, sc.S, sc.M) == (60, 40, 10_000, 3)
+    with rtamd.corert.make_handle(m) as h:
+        R, T = rtamd.corert.run_scene(h, sc)
+        h.rt_run()
+        R2, _ = h.get_RT()
+    assert np.all(np.isfinite(R)) and np.all(np.isfinite(T)) and np.array_equal(R, R2)
+    assert np.all(R[:, 0, :] > 0)
+    pts = np.random.default_rng(0).choice(sc.S, 12, replace=False).astype(np.int32)
+    Rr, Tr = _oracle(cref, m, pts=pts)
+    helpers.assert_stokes_close(R[:, :, pts], Rr[:, :, pts], what="C2 sample R")
+    helpers.assert_stokes_close(T[:, :, pts], Tr[:, :, pts], what="C2 sample T")

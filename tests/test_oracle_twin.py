@@ -1,0 +1,125 @@
+"""C oracle (oracle/momref.c) against its numpy twin (oracle/momref.py) and the golden vectors."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import momref as mr
+
+GOLD = Path(__file__).parent / "golden"
+
+
+def _model(rtamd, nS, **kw):
+    kw.setdefault("seed", 3)
+    return rtamd.scenes.make_scene(nS, 5, 3, 6, **kw)
+
+
+@pytest.mark.parametrize("nS", [1, 3, 4])
+@pytest.mark.parametrize("strict", [True, False])
+def test_full_run_c_vs_numpy(cref, rtamd, nS, strict):
+    m = _model(rtamd, nS)
+    m.params.strict_reference_indexing = strict
+    sc = helpers.oracle_scene(m)
+    R, T = mr.rt_run(sc)
+    Rc, Tc, info = cref.rt_run(cref.pack_scene(sc))
+    assert info == 0
+    helpers.assert_stokes_close(Rc, R, rtol=1e-11, what="R")
+    helpers.assert_stokes_close(Tc, T, rtol=1e-11, what="T")
+
+
+def test_strict_indexing_matters_for_iqu(cref, rtamd):
+    """for Stokes_IQU the reference's 1-based mod() never applies the D similarity."""
+    m = _model(rtamd, 3, vaz=(90.0, 90.0, 90.0))
+    a = cref.rt_run(cref.pack_scene(helpers.oracle_scene(m)))[0]
+    m.params.strict_reference_indexing = False
+    b = cref.rt_run(cref.pack_scene(helpers.oracle_scene(m)))[0]
+    assert np.max(np.abs(a[:, 2] - b[:, 2])) > 1e-6  # U differs
+
+
+def test_golden_small_iqu(cref, rtamd):
+    g = np.load(GOLD / "small_iqu.npz")
+    m = rtamd.scenes.make_scene(3, 3, 3, 4, vza=(0.0,), vaz=(35.0,), seed=7, aerosol_total=0.3, aerosol_p0=500.0,
+                                aerosol_σp=300.0)
+    sc = helpers.oracle_scene(m)
+    p = cref.pack_scene(sc)
+    assert np.array_equal(p.nd, g["nd"]) and np.array_equal(p.iface, g["iface"])
+    np.testing.assert_allclose(p.Zpp, g["Zpp"], rtol=0, atol=1e-13)
+    R, T, _ = cref.rt_run(p)
+    helpers.assert_stokes_close(R, g["R"], rtol=1e-11, what="R vs golden")
+    helpers.assert_stokes_close(T, g["T"], rtol=1e-11, what="T vs golden")
+    # per-operator snapshots: elemental + doubling of every layer for m = 0
+    S, N = sc.S, sc.N
+    for z in range(sc.Nz):
+        nd = int(p.nd[z])
+        tau = p.tau.reshape(sc.Nz, S)[z]
+        dtau = tau / 2 ** nd
+        varpi = p.varpi.reshape(sc.Nz, S)[z]
+        ts = p.tau_sum.reshape(sc.Nz + 1, S)[z]
+        lay = mr.construct_core_optical_properties(sc, 0)[z]
+        Zpp, Zmp = lay.Zfull()
+        out = cref.elemental(p, 0, nd, ts, dtau, varpi, mr.to_abi(Zpp), mr.to_abi(Zmp), S, S)
+        names = ["r_pm", "r_mp", "t_mm", "t_pp", "j0p", "j0m"]
+        for nm, arr in zip(names, out):
+            if nd >= 1 and nm in ("r_pm", "t_mm"):
+                continue  # left untouched by the reference when nd >= 1
+            ref = g[f"elemental_m0_z{z + 1}_{nm}"]
+            helpers.assert_op_close(arr, mr.to_abi(ref), what=f"elemental z{z + 1} {nm}")
+        expk = np.exp(-dtau / sc.quad.mu0)
+        cref.doubling(p, nd, expk, out, S)
+        for nm, arr in zip(names, out):
+            ref = g[f"doubling_m0_z{z + 1}_{nm}"]
+            helpers.assert_op_close(arr, mr.to_abi(ref), rtol=1e-11, what=f"doubling z{z + 1} {nm}")
+
+
+@pytest.mark.parametrize("iface", [0, 1, 2, 3])
+def test_interaction_c_vs_numpy(cref, iface):
+    rng = np.random.default_rng(iface)
+    N, S = 9, 5
+    mk = lambda s: rng.random((S, N, N)) * s / N
+    added = mr.AddedLayer(mk(0.5), mk(0.5), mk(0.9) + np.eye(N) * 0.3, mk(0.9) + np.eye(N) * 0.3, rng.random((S, N)),
+                          rng.random((S, N)))
+    comp = mr.CompositeLayer(mk(0.5), mk(0.5), mk(0.9), mk(0.9), rng.random((S, N)), rng.random((S, N)))
+    c_comp = [mr.to_abi(x).copy() for x in (comp.R_mp, comp.R_pm, comp.T_pp, comp.T_mm, comp.J0p, comp.J0m)]
+    c_add = [mr.to_abi(x).copy() for x in (added.r_pm, added.r_mp, added.t_mm, added.t_pp, added.j0p, added.j0m)]
+    mr.interaction(iface, comp, added)
+    assert cref.interaction(N, S, iface, c_comp, c_add) == 0
+    for arr, ref in zip(c_comp, (comp.R_mp, comp.R_pm, comp.T_pp, comp.T_mm, comp.J0p, comp.J0m)):
+        helpers.assert_op_close(arr, mr.to_abi(ref), what=f"iface {iface}")
+
+
+def test_batch_inv_and_mul(cref):
+    rng = np.random.default_rng(0)
+    N, S = 17, 6
+    A = rng.normal(size=(S, N, N))
+    B = rng.normal(size=(S, N, N))
+    X, info = cref.batch_inv(N, S, mr.to_abi(A))
+    assert info == 0
+    helpers.assert_op_close(X, mr.to_abi(np.linalg.inv(A)), rtol=1e-10)
+    helpers.assert_op_close(cref.batched_mul(N, S, mr.to_abi(A), mr.to_abi(B)), mr.to_abi(A @ B), rtol=1e-13)
+    Z = A.copy()
+    Z[2, :, 3] = 0.0  # singular: zero column
+    assert cref.batch_inv(N, S, mr.to_abi(Z))[1] != 0
+
+
+def test_cef_against_scipy_and_golden(cref):
+    from scipy.special import wofz
+    g = np.load(GOLD / "cef.npz")
+    X, Y = np.meshgrid(g["x"], g["y"], indexing="ij")
+    w = mr.w_hw32sd(X + 1j * Y)
+    np.testing.assert_allclose(w.real, g["w_re"], rtol=1e-14, atol=0)
+    ex = wofz(X + 1j * Y)
+    assert np.max(np.abs(w.real - ex.real) / np.abs(ex)) < 1e-4  # the approximation's own error, not parity
+    wc = np.array([[cref.lib().ora_w_hw32sd_re(float(a), float(b)) for b in g["y"]] for a in g["x"]])
+    np.testing.assert_allclose(wc, g["w_re"], rtol=2e-13, atol=2e-16)  # |w| <= 1; Re w cancels to 1e-5 in places
+
+
+def test_voigt_c_vs_numpy_and_golden(cref):
+    g = np.load(GOLD / "voigt_co2.npz")
+    for tag in ("a", "b"):
+        args = [g[f"{k}_{tag}"] for k in ("nu", "gamma_d", "y", "S", "ind_start", "ind_stop")]
+        sig_np = mr.voigt_xsec(*args, g["grid"])
+        sig_c = cref.voigt_xsec(*args, g["grid"])
+        scale = g[f"sigma_{tag}"].max()
+        assert np.max(np.abs(sig_np - g[f"sigma_{tag}"])) <= 1e-14 * scale
+        assert np.max(np.abs(sig_c - g[f"sigma_{tag}"])) <= 1e-12 * scale
