@@ -1,0 +1,44 @@
+"""Spectral sharding over the GPUs of one node.
+
+Every spectral point is independent in the elastic path, so the concatenated spectral axis is cut
+into contiguous slices, one per rank (one process per GPU).  The only quantities that couple points
+-- ndoubl and the scattering-interface codes, which the reference derives from maxima over the
+WHOLE axis (rt_kernel.jl:241-242, compEffectiveLayerProperties.jl:104) -- are computed by
+prepare_scene() on the global axis before slicing, so an N-way run reproduces the 1-way run bit
+for bit.  The single collective is an all-gather of the R/T spectra (RCCL over xGMI when the
+process group backend is "nccl"; gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Callable, Tuple
+
+import numpy as np
+
+
+def shard_bounds(S: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous slice [lo, hi) of rank `rank`: ceil(S/world) points each, the tail may be short or empty."""
+    per = -(-S // world)
+    lo = min(S, rank * per)
+    return lo, min(S, lo + per)
+
+
+def rt_run_sharded(scene, run_local: Callable, dist, device=None):
+    """Run `run_local(shard) -> (R, T)` ([nVza, nStokes, S_loc] numpy) on this rank's slice and
+    all-gather the spectra.  `dist` is torch.distributed (initialised).  Returns the full
+    (R, T) [nVza, nStokes, S] on every rank."""
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = -(-scene.S // world)
+    lo, hi = shard_bounds(scene.S, world, rank)
+    nV, nS = len(scene.node), scene.nStokes
+    buf = torch.zeros((2, per, nS, nV), dtype=torch.float64, device=device)  # padded to `per` points
+    if hi > lo:
+        R, T = run_local(scene.spectral_slice(lo, hi))
+        buf[0, : hi - lo] = torch.from_numpy(np.ascontiguousarray(R.transpose(2, 1, 0))).to(buf.device)
+        buf[1, : hi - lo] = torch.from_numpy(np.ascontiguousarray(T.transpose(2, 1, 0))).to(buf.device)
+    out = torch.empty(world * buf.numel(), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, buf.reshape(-1))  # one collective: R and T together
+    out = out.cpu().numpy().reshape((world,) + tuple(buf.shape))  # [world, 2, per, nS, nV]
+    full = out.transpose(1, 0, 2, 3, 4).reshape(2, world * per, nS, nV)[:, : scene.S]
+    return full[0].transpose(2, 1, 0).copy(), full[1].transpose(2, 1, 0).copy()
