@@ -22,7 +22,7 @@ namespace mom {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 #ifndef MOM_WAVES
-#define MOM_WAVES 4
+#define MOM_WAVES 8
 #endif
 constexpr int kWaves = MOM_WAVES;
 constexpr int kThreads = 64 * kWaves;
