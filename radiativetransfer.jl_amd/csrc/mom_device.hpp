@@ -86,7 +86,7 @@ __device__ __forceinline__ void kchunk2(int ks0, int row, int lq, int col0, FA1 
 // alias an operand).  Requires at most one work item per wave, i.e. N <= 64.
 // ---------------------------------------------------------------------------------------
 template <bool SYNC, class FA, class FB, class FE>
-__device__ __forceinline__ void wg_gemm(int N, FA A, FB B, FE epi) {
+__device__ __forceinline__ void wg_gemm_nc(int N, int NC, FA A, FB B, FE epi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int Tn = (N + 15) >> 4;
@@ -116,11 +116,18 @@ __device__ __forceinline__ void wg_gemm(int N, FA A, FB B, FE epi) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rw = 16 * ti + lq + 4 * r;
-          if (rw < N && col < N) epi(rw, col, acc[t][r]);
+          if (rw < N && col < NC) epi(rw, col, acc[t][r]);
         }
       }
     }
   }
+}
+
+// NC = N: the plain N x N product.  NC in (N, Np]: columns N..NC-1 of the B operand (kept in the
+// buffer's padding) ride along: vectors get multiplied by A for free in the last column tile.
+template <bool SYNC, class FA, class FB, class FE>
+__device__ __forceinline__ void wg_gemm(int N, FA A, FB B, FE epi) {
+  wg_gemm_nc<SYNC>(N, N, A, B, epi);
 }
 
 // Two products sharing the B operand: C1 = A1*B, C2 = A2*B (r += (A r) t and t = A t).

@@ -23,7 +23,25 @@
 #pragma once
 #include "mom_device.hpp"
 
+// diagnostic builds (scratch/phase_stamp.hip) define MOM_STAMP(id) to accumulate s_memtime deltas;
+// in the product build it expands to nothing.
+#ifndef MOM_STAMP
+#define MOM_STAMP(id)
+#endif
+
 namespace mom {
+
+// beta^2 thresholds: kNeumannThr2[p-1] = largest ||B||_F^2 for which p series terms suffice
+// (beta^p / (1 - beta) <= 2^-56), p = 1..32.
+__device__ const double kNeumannThr2[32] = {
+    1.92592994438723585e-34, 1.38777877561156685e-17, 5.77492213356056750e-12, 3.72517661162420568e-09,
+    1.80656771560518035e-07, 2.40186660760962690e-06, 1.52417448931310540e-05, 6.09157135028591602e-05,
+    1.78874927371965362e-04, 4.23309807394842467e-04, 8.56292603484697687e-04, 1.53988783074545245e-03,
+    2.52966413875025916e-03, 3.87056942792606993e-03, 5.59509450064154569e-03, 7.72318484591632843e-03,
+    1.02632763666295982e-02, 1.32139270473634555e-02, 1.65656642989196294e-02, 2.03028052759899880e-02,
+    2.44051136922726897e-02, 2.88492300492497432e-02, 3.36098586497813809e-02, 3.86607216385354419e-02,
+    4.39753040322414940e-02, 4.95274191527264318e-02, 5.52916244610413068e-02, 6.12435157546498479e-02,
+    6.73599244364155580e-02, 7.36190389296255826e-02, 8.00004677634075928e-02, 8.64852586225294262e-02};
 
 struct DevStreams {
   const double *mu;  // [N] qp_μN
@@ -41,7 +59,7 @@ struct Ctx {
   int N, Np, ld, ldv;
   FastDiv fd;
   double *r, *t, *P, *Q, *X;  // padded N x N buffers (X: spare, generic mode only)
-  double *jp, *jm, *j1p, *j1m, *v1, *v2, *Jp, *Jm, *prow, *pcol, *rowk, *ei, *mu, *wt, *sg, *part;
+  double *jp, *jm, *j1p, *j1m, *v1, *v2, *Jp, *Jm, *prow, *pcol, *rowk, *ei, *mu, *wt, *sg, *part, *thr;
   int *ipiv, *sh, *bad;
   int inv_mode;
 };
@@ -52,7 +70,7 @@ __host__ __device__ inline size_t mat_elems(int N) { return (size_t)ld_for(N) * 
 constexpr int kNumVec = 15 + 2 * kWaves;  // vectors carved from LDS (part = 2*kWaves vectors)
 constexpr int kGenericBufs = 5;
 __host__ __device__ inline size_t lds_bytes(int N, bool lds_mats) {
-  size_t b = (size_t)kNumVec * np_for(N) * sizeof(double) + (size_t)(np_for(N) + 4) * sizeof(int);
+  size_t b = (size_t)(kNumVec * np_for(N) + 32) * sizeof(double) + (size_t)(np_for(N) + 4) * sizeof(int);
   if (lds_mats) b += 4 * mat_elems(N) * sizeof(double);
   return b;
 }
@@ -77,7 +95,8 @@ __device__ __forceinline__ void make_ctx(Ctx &c, int N, int inv_mode, double *sm
   c.jp = p; c.jm = p + lv; c.j1p = p + 2 * lv; c.j1m = p + 3 * lv; c.v1 = p + 4 * lv; c.v2 = p + 5 * lv;
   c.Jp = p + 6 * lv; c.Jm = p + 7 * lv; c.prow = p + 8 * lv; c.pcol = p + 9 * lv; c.rowk = p + 10 * lv;
   c.ei = p + 11 * lv; c.mu = p + 12 * lv; c.wt = p + 13 * lv; c.sg = p + 14 * lv; c.part = p + 15 * lv;
-  int *ip = reinterpret_cast<int *>(p + (size_t)kNumVec * lv);
+  c.thr = p + (size_t)kNumVec * lv;
+  int *ip = reinterpret_cast<int *>(c.thr + 32);
   c.ipiv = ip; c.sh = ip + lv; c.bad = ip + lv + 1;
 }
 
@@ -100,6 +119,7 @@ __device__ __forceinline__ void zero_padding(const Ctx &c) {
     }
   }
   for (int e = threadIdx.x; e < kNumVec * c.ldv; e += kThreads) c.jp[e] = 0.0;
+  if (threadIdx.x < 32) c.thr[threadIdx.x] = kNeumannThr2[threadIdx.x];
 }
 
 // element functor of a PADDED buffer (no bounds checks)
@@ -162,35 +182,41 @@ __device__ __forceinline__ void gemm_to(Ctx &c, double *&dst, FA A, FB B, FV f) 
   __syncthreads();
 }
 
+// smallest p in 1..32 with beta2 <= thr[p-1] (thr: the table above, copied to LDS by the prologue),
+// 1000 if none (or NaN): binary search, 5 dependent LDS reads.
+__device__ __forceinline__ int neumann_terms(const double *thr, double beta2) {
+  if (!(beta2 <= thr[31])) return 1000;
+  int lo = 0, hi = 31;  // invariant: beta2 <= thr[hi]
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int mid = (lo + hi) >> 1;
+    if (beta2 <= thr[mid]) hi = mid; else lo = mid + 1;
+  }
+  return hi + 1;
+}
+
+// lane-partial sum of squares -> part[wave] (call before the barrier that follows the GEMM);
+// read back with wg_sumsq_get after that barrier.
+__device__ __forceinline__ void wg_sumsq_put(const Ctx &c, double ss) {
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) c.part[threadIdx.x >> 6] = ss;
+}
+__device__ __forceinline__ double wg_sumsq_get(const Ctx &c) {
+  double b2 = 0.0;
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) b2 += c.part[w];
+  return b2;
+}
+
 // ---------------------------------------------------------------------------------------
-// Ob <- T (I - B)^-1 with B in Bb (destroyed).  T: element functor usable as MFMA A operand.
-// See the header comment for the series bound.  Ends with a barrier.
+// Ob <- T (I - B)^-1 with B in Bb (destroyed) and beta2 = ||B||_F^2.  T: element functor usable
+// as MFMA A operand.  See the header comment for the series bound.  Ends with a barrier.
 // ---------------------------------------------------------------------------------------
 template <bool LDSM, class FT>
-__device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob) {
+__device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob, double beta2) {
   const int N = c.N, ld = c.ld, NN = N * N;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int p = 1000;
-  if (c.inv_mode != 1) {
-    double s = 0.0;
-    for (int e = threadIdx.x; e < NN; e += kThreads) {
-      int i, j;
-      c.fd.split(e, i, j);
-      const double v = Bb[i + j * ld];
-      s += v * v;
-    }
-    s = wave_sum(s);
-    if (lane == 0) c.part[wave] = s;
-    __syncthreads();
-    double b2 = 0.0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) b2 += c.part[w];
-    __syncthreads();
-    const double beta = sqrt(b2);
-    if (beta == 0.0) p = 1;
-    else if (beta < 0.5) p = (int)ceil(log(1.3877787807814457e-17 * (1.0 - beta)) / log(beta));
-    if (p < 1) p = 1;
-  }
+  const int p = (c.inv_mode == 1) ? 1000 : neumann_terms(c.thr, beta2);
+  MOM_STAMP(6);
   if (p <= 4) {
     // Horner: A_1 = T, A_{k+1} = T + A_k B
     double *o = Ob;
@@ -329,37 +355,81 @@ template <bool LDSM>
 __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
   const int N = c.N, ld = c.ld;
   if (nd == 0) return expk;
+  // "ride": the source vectors travel as columns N, N+1 of the B operand r (buffer padding), so
+  // r j and Q (..) come out of the MFMA products for free.  Needs two spare columns in the last
+  // column tile and no K padding (N % 4 == 0); otherwise: separate mat-vec passes.
+  const bool ride = (N % 4 == 0) && (c.Np - N >= 2);
+  if (ride) {
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+      c.r[i + N * ld] = c.jp[i];
+      c.r[i + (N + 1) * ld] = c.jm[i];
+    }
+    __syncthreads();
+  }
   for (int it = 0; it < nd; ++it) {
     {
       double *r = c.r, *P = c.P;
-      // P = r r ; Q = t (I - r r)^-1  (tt⁺⁺_gp_refl)           (doubling.jl:44-48)
-      wg_gemm<false>(N, ElP{r, ld}, ElP{r, ld}, [=](int i, int j, double v) { P[i + j * ld] = v; });
+      double ss = 0.0;
+      MOM_STAMP(0);
+      // P = r r (+ r j0+, r j0- riding) ; Q = t (I - r r)^-1  (tt⁺⁺_gp_refl)   (doubling.jl:44-48)
+      wg_gemm_nc<false>(N, ride ? N + 2 : N, ElP{r, ld}, ElP{r, ld}, [=, &ss](int i, int j, double v) {
+        P[i + j * ld] = v;
+        if (j < N) ss += v * v;
+      });
+      wg_sumsq_put(c, ss);
       __syncthreads();
+      MOM_STAMP(1);
     }
-    times_inv<LDSM>(c, ElP{c.t, ld}, c.P, c.Q);
+    const double beta2 = wg_sumsq_get(c);
+    if (ride) {
+      // w1 = j1- + r j0+ ; w2 = j0+ + r j1-   with j1± = j0± expk   (:51-60)
+      double *r = c.r, *P = c.P;
+      for (int i = threadIdx.x; i < N; i += kThreads) {
+        const double rjp = P[i + N * ld], rjm = P[i + (N + 1) * ld];
+        r[i + N * ld] = c.jm[i] * expk + rjp;
+        r[i + (N + 1) * ld] = c.jp[i] + expk * rjm;
+      }
+    }
+    times_inv<LDSM>(c, ElP{c.t, ld}, c.P, c.Q, beta2);
+    MOM_STAMP(2);
     double *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
-    // j1± = j0± expk                                       (:51,:54)
-    for (int i = threadIdx.x; i < N; i += kThreads) {
-      c.j1p[i] = c.jp[i] * expk;
-      c.j1m[i] = c.jm[i] * expk;
+    if (!ride) {
+      // j1± = j0± expk                                       (:51,:54)
+      for (int i = threadIdx.x; i < N; i += kThreads) {
+        c.j1p[i] = c.jp[i] * expk;
+        c.j1m[i] = c.jm[i] * expk;
+      }
+      __syncthreads();
+      // v1 = r j0+ ; v2 = r j1-
+      wg_matvec2(N, c.ldv, ElP{r, ld}, c.jp, c.j1m, c.v1, c.v2, c.part);
+      for (int i = threadIdx.x; i < N; i += kThreads) {
+        c.v1[i] = c.j1m[i] + c.v1[i];  // j1- + r j0+
+        c.v2[i] = c.jp[i] + c.v2[i];   // j0+ (old) + r j1-
+      }
+      __syncthreads();
+      wg_matvec2(N, c.ldv, ElP{Q, ld}, c.v1, c.v2, c.v1, c.v2, c.part);
+      for (int i = threadIdx.x; i < N; i += kThreads) {
+        c.jm[i] = c.jm[i] + c.v1[i];   // :57
+        c.jp[i] = c.j1p[i] + c.v2[i];  // :60
+      }
     }
+    MOM_STAMP(3);
+    // P = Q r  (+ Q w1, Q w2 riding)
+    wg_gemm_nc<false>(N, ride ? N + 2 : N, ElP{Q, ld}, ElP{r, ld}, [=](int i, int j, double v) { P[i + j * ld] = v; });
     __syncthreads();
-    // v1 = r j0+ ; v2 = r j1-
-    wg_matvec2(N, c.ldv, ElP{r, ld}, c.jp, c.j1m, c.v1, c.v2, c.part);
-    for (int i = threadIdx.x; i < N; i += kThreads) {
-      c.v1[i] = c.j1m[i] + c.v1[i];  // j1- + r j0+
-      c.v2[i] = c.jp[i] + c.v2[i];   // j0+ (old) + r j1-
-    }
-    __syncthreads();
-    wg_matvec2(N, c.ldv, ElP{Q, ld}, c.v1, c.v2, c.v1, c.v2, c.part);
-    for (int i = threadIdx.x; i < N; i += kThreads) {
-      c.jm[i] = c.jm[i] + c.v1[i];   // :57
-      c.jp[i] = c.j1p[i] + c.v2[i];  // :60
+    MOM_STAMP(4);
+    if (ride) {
+      // j0- += Q w1 (:57) ; j0+ = j1+ + Q w2 (:60); refresh the riding columns for the next step
+      for (int i = threadIdx.x; i < N; i += kThreads) {
+        const double jm = c.jm[i] + P[i + N * ld];
+        const double jp = c.jp[i] * expk + P[i + (N + 1) * ld];
+        c.jm[i] = jm;
+        c.jp[i] = jp;
+        r[i + N * ld] = jp;
+        r[i + (N + 1) * ld] = jm;
+      }
     }
     expk = expk * expk;  // :61
-    // P = Q r
-    wg_gemm<false>(N, ElP{Q, ld}, ElP{r, ld}, [=](int i, int j, double v) { P[i + j * ld] = v; });
-    __syncthreads();
     // r = r + P t (:64) ; t = Q t (:67)
     if (LDSM) {
       wg_gemm2<true>(N, ElP{P, ld}, ElP{Q, ld}, ElP{t, ld},
@@ -374,6 +444,7 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
       c.t = X;
     }
     __syncthreads();
+    MOM_STAMP(5);
   }
   // apply_D! (doubling.jl:93-110) and apply_D_SFI! (:112-118): r-+ rows and j0- scaled by sg
   {
@@ -383,7 +454,10 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
       c.fd.split(e, i, j);
       r[i + j * ld] *= c.sg[i];
     }
-    for (int i = threadIdx.x; i < N; i += kThreads) c.jm[i] *= c.sg[i];
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+      c.jm[i] *= c.sg[i];
+      if (ride) { r[i + N * ld] = 0.0; r[i + (N + 1) * ld] = 0.0; c.P[i + N * ld] = 0.0; c.P[i + (N + 1) * ld] = 0.0; }
+    }
   }
   __syncthreads();
   return expk;
@@ -479,64 +553,132 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface, const CompPt
     wg_gemm<false>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * N] = v; });
   } else {
     // ---- ScatteringInterface_11 (interaction.jl:69-117)
+    // The four mat-vec products ride as column N of the B operands when the buffers have a spare
+    // column in the last tile and no K padding (see doubling_run).
+    const bool ride = (N % 4 == 0) && (c.Np - N >= 1);
+    MOM_STAMP(10);
     wg_copy_mat(N, c.fd, g.R_pm, N, c.P, ld);  // P = R+-
+    if (ride)
+      for (int i = threadIdx.x; i < N; i += kThreads) c.P[i + N * ld] = c.Jp[i];
     __syncthreads();
+    MOM_STAMP(11);
+    double beta2;
     {
       double *P = c.P, *Q = c.Q;
-      // Q = r-+ R+-  ;  P = T01 = T-- (I - r-+ R+-)^-1            (:81-87)
-      wg_gemm<false>(N, ElP{r, ld}, ElP{P, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+      double ss = 0.0;
+      // Q = r-+ R+- (+ r-+ J0+) ;  P = T01 = T-- (I - r-+ R+-)^-1            (:81-87)
+      wg_gemm_nc<false>(N, ride ? N + 1 : N, ElP{r, ld}, ElP{P, ld}, [=, &ss](int i, int j, double v) {
+        Q[i + j * ld] = v;
+        if (j < N) ss += v * v;
+      });
+      wg_sumsq_put(c, ss);
       __syncthreads();
+      beta2 = wg_sumsq_get(c);
+      if (ride)  // v1 = r-+ J0+ + j0-  -> column N of r (B operand of T01 r-+ below)
+        for (int i = threadIdx.x; i < N; i += kThreads) r[i + N * ld] = Q[i + N * ld] + c.jm[i];
     }
-    times_inv<LDSM>(c, El{g.T_mm, N, N}, c.Q, c.P);
-    // J0- = J0- + T01 (r-+ J0+ + j0-)                          (:90)
-    wg_matvec(c, ElP{r, ld}, c.Jp, c.v1);
-    for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
-    __syncthreads();
-    wg_matvec(c, ElP{c.P, ld}, c.v1, c.v2);
-    for (int i = threadIdx.x; i < N; i += kThreads) c.Jm[i] = c.Jm[i] + c.v2[i];
+    MOM_STAMP(12);
+    times_inv<LDSM>(c, El{g.T_mm, N, N}, c.Q, c.P, beta2);
+    MOM_STAMP(13);
+    if (!ride) {
+      // J0- = J0- + T01 (r-+ J0+ + j0-)                          (:90)
+      wg_matvec(c, ElP{r, ld}, c.Jp, c.v1);
+      for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
+      __syncthreads();
+      wg_matvec(c, ElP{c.P, ld}, c.v1, c.v2);
+      for (int i = threadIdx.x; i < N; i += kThreads) c.Jm[i] = c.Jm[i] + c.v2[i];
+    }
+    MOM_STAMP(14);
     {
       double *P = c.P, *Q = c.Q, *Tmm = g.T_mm, *Rmp = g.R_mp;
       // T-- = T01 t--                                           (:96)
       wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
-      // Q = T01 r-+
-      wg_gemm<false>(N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+      // Q = T01 r-+ (+ T01 v1)
+      wg_gemm_nc<false>(N, ride ? N + 1 : N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
       __syncthreads();
+      MOM_STAMP(15);
+      if (ride)  // J0- = J0- + T01 v1 (:90); next rider: j0- for R+- j0-
+        for (int i = threadIdx.x; i < N; i += kThreads) {
+          c.Jm[i] = c.Jm[i] + Q[i + N * ld];
+          r[i + N * ld] = c.jm[i];
+        }
       wg_copy_mat(N, c.fd, g.T_pp, N, P, ld);  // P = T++ (old)
       __syncthreads();
+      MOM_STAMP(16);
       // R-+ = R-+ + (T01 r-+) T++                              (:93)
       wg_gemm<false>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Rmp[i + j * N] = Rmp[i + j * N] + v; });
       __syncthreads();
+      MOM_STAMP(17);
       wg_copy_mat(N, c.fd, g.R_pm, N, Q, ld);  // Q = R+- (old)
       __syncthreads();
+      MOM_STAMP(18);
     }
-    // w = J0+ + R+- j0-  (kept in j1p; j1p/j1m are free outside doubling)
-    wg_matvec(c, ElP{c.Q, ld}, c.jm, c.v1);
-    for (int i = threadIdx.x; i < N; i += kThreads) c.j1p[i] = c.Jp[i] + c.v1[i];
+    if (!ride) {
+      // w = J0+ + R+- j0-  (kept in j1p; j1p/j1m are free outside doubling)
+      wg_matvec(c, ElP{c.Q, ld}, c.jm, c.v1);
+      for (int i = threadIdx.x; i < N; i += kThreads) c.j1p[i] = c.Jp[i] + c.v1[i];
+    }
     {
       double *P = c.P, *Q = c.Q;
-      // P = R+- r-+ ; Q = T21 = t++ (I - R+- r-+)^-1            (:104-107)
-      wg_gemm<false>(N, ElP{Q, ld}, ElP{r, ld}, [=](int i, int j, double v) { P[i + j * ld] = v; });
+      double ss = 0.0;
+      // P = R+- r-+ (+ R+- j0-) ; Q = T21 = t++ (I - R+- r-+)^-1            (:104-107)
+      wg_gemm_nc<false>(N, ride ? N + 1 : N, ElP{Q, ld}, ElP{r, ld}, [=, &ss](int i, int j, double v) {
+        P[i + j * ld] = v;
+        if (j < N) ss += v * v;
+      });
+      wg_sumsq_put(c, ss);
+      __syncthreads();
+      beta2 = wg_sumsq_get(c);
+      if (ride)
+        for (int i = threadIdx.x; i < N; i += kThreads) c.j1p[i] = c.Jp[i] + P[i + N * ld];
+    }
+    MOM_STAMP(19);
+    times_inv<LDSM>(c, ElP{t, ld}, c.P, c.Q, beta2);
+    MOM_STAMP(20);
+    if (!ride) {
+      // J0+ = j0+ + T21 (J0+ + R+- j0-)                          (:110)
+      wg_matvec(c, ElP{c.Q, ld}, c.j1p, c.v2);
+      for (int i = threadIdx.x; i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.v2[i];
+    }
+    MOM_STAMP(21);
+    wg_copy_mat(N, c.fd, g.R_pm, N, c.P, ld);  // P = R+- (old)
+    if (ride)
+      for (int i = threadIdx.x; i < N; i += kThreads) c.P[i + N * ld] = c.j1p[i];
+    __syncthreads();
+    MOM_STAMP(22);
+    {
+      // P = T21 R+- (+ T21 w)
+      double *d = c.P, *Qb = c.Q;
+      if (LDSM) {
+        wg_gemm_nc<true>(N, ride ? N + 1 : N, ElP{Qb, ld}, ElP{d, ld}, [=](int i, int j, double v) { d[i + j * ld] = v; });
+      } else {
+        double *sp = c.X;
+        wg_gemm_nc<false>(N, ride ? N + 1 : N, ElP{Qb, ld}, ElP{d, ld}, [=](int i, int j, double v) { sp[i + j * ld] = v; });
+        c.X = d;
+        c.P = sp;
+      }
       __syncthreads();
     }
-    times_inv<LDSM>(c, ElP{t, ld}, c.P, c.Q);
-    // J0+ = j0+ + T21 (J0+ + R+- j0-)                          (:110)
-    wg_matvec(c, ElP{c.Q, ld}, c.j1p, c.v2);
-    for (int i = threadIdx.x; i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.v2[i];
-    wg_copy_mat(N, c.fd, g.R_pm, N, c.P, ld);  // P = R+- (old)
-    __syncthreads();
-    gemm_to<LDSM>(c, c.P, ElP{c.Q, ld}, ElP{c.P, ld}, [=](int, int, double v, double) { return v; });  // P = T21 R+-
+    MOM_STAMP(23);
+    if (ride)  // J0+ = j0+ + T21 w (:110)
+      for (int i = threadIdx.x; i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.P[i + N * ld];
     {
       double *P = c.P, *Q = c.Q, *Rpm = g.R_pm, *Tpp = g.T_pp;
       // R+- = r+- + (T21 R+-) t--                              (:116)
       wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * N] = rpm(i, j) + v; });
       __syncthreads();
+      MOM_STAMP(24);
+      if (ride)
+        for (int i = threadIdx.x; i < N; i += kThreads) { P[i + N * ld] = 0.0; r[i + N * ld] = 0.0; Q[i + N * ld] = 0.0; }
       wg_copy_mat(N, c.fd, g.T_pp, N, P, ld);  // P = T++ (old)
       __syncthreads();
+      MOM_STAMP(25);
       // T++ = T21 T++                                          (:113)
       wg_gemm<false>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
     }
   }
   __syncthreads();
+  MOM_STAMP(26);
   for (int i = threadIdx.x; i < N; i += kThreads) {
     g.J0p[i] = c.Jp[i];
     g.J0m[i] = c.Jm[i];
