@@ -40,53 +40,88 @@ struct FastDiv {
 };
 
 // ---------------------------------------------------------------------------------------
-// one K chunk: C k-steps, operands loaded first (all loads in flight), then C*kTJ MFMAs
+// Work item of one wave: NA products sharing the B operand over a 16 x (16*kTJ) output strip.
+// Two K schedules:
+//  * straight (57 <= N <= 64, i.e. 15 or 16 MFMA k-steps, LDS operands): branch-free, fully
+//    unrolled stream, so the LDS reads run ahead of the MFMAs (one exposed LDS latency per product
+//    instead of one per chunk) -- measured 2.16 us vs 2.82 us per 60x60 product;
+//  * chunked: 4 k-steps of loads, then their MFMAs (any N; generic mode).
 // ---------------------------------------------------------------------------------------
-template <int C, class FA, class FB>
-__device__ __forceinline__ void kchunk(int ks0, int row, int lq, int col0, FA A, FB B, d4 (&acc)[kTJ]) {
-  double a[C], b[C][kTJ];
+// A-operand bundles: NA functors behind one interface (u selects the product)
+template <class FA>
+struct One {
+  FA a;
+  __device__ __forceinline__ double operator()(int, int i, int k) const { return a(i, k); }
+  template <int LD> __device__ __forceinline__ double at(int, int i, int k) const { return a.template at<LD>(i, k); }
+  __device__ __forceinline__ void launder() { a.launder(); }
+};
+template <class FA1, class FA2>
+struct Two {
+  FA1 a1;
+  FA2 a2;
+  __device__ __forceinline__ double operator()(int u, int i, int k) const { return u == 0 ? a1(i, k) : a2(i, k); }
+  template <int LD> __device__ __forceinline__ double at(int u, int i, int k) const {
+    return u == 0 ? a1.template at<LD>(i, k) : a2.template at<LD>(i, k);
+  }
+  __device__ __forceinline__ void launder() { a1.launder(); a2.launder(); }
+};
+
+// branch-free, fully unrolled item with a COMPILE-TIME leading dimension: every LDS read is
+// base + immediate offset, and the (laundered) bases cannot be hoisted out of the caller's loops,
+// so neither address arithmetic nor long live ranges cost registers.
+template <int NA, int KS, int LD, class FAs, class FB>
+__device__ __forceinline__ void item_straight(int row, int lq, int col0, FAs A, FB B, d4 (&acc)[NA][kTJ]) {
+  // launder the lane coordinates (NOT the pointers: an asm operand would turn the LDS pointers
+  // into generic ones and the reads into flat loads)
+  asm volatile("" : "+v"(row), "+v"(lq), "+v"(col0));
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k = 4 * ks + lq;
+    double a[NA], b[kTJ];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) a[u] = A.template at<LD>(u, row, k);
+#pragma unroll
+    for (int t = 0; t < kTJ; ++t) b[t] = B.template at<LD>(k, col0 + 16 * t);
+#pragma unroll
+    for (int t = 0; t < kTJ; ++t)
+#pragma unroll
+      for (int u = 0; u < NA; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[t], acc[u][t], 0, 0, 0);
+  }
+}
+
+template <int NA, int C, class FAs, class FB>
+__device__ __forceinline__ void kchunk(int ks0, int row, int lq, int col0, const FAs &A, FB B, d4 (&acc)[NA][kTJ]) {
+  double a[NA][C], b[C][kTJ];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const int k = 4 * (ks0 + c) + lq;
-    a[c] = A(row, k);
+#pragma unroll
+    for (int u = 0; u < NA; ++u) a[u][c] = A(u, row, k);
 #pragma unroll
     for (int t = 0; t < kTJ; ++t) b[c][t] = B(k, col0 + 16 * t);
   }
 #pragma unroll
   for (int c = 0; c < C; ++c)
 #pragma unroll
-    for (int t = 0; t < kTJ; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c], b[c][t], acc[t], 0, 0, 0);
-}
-
-template <int C, class FA1, class FA2, class FB>
-__device__ __forceinline__ void kchunk2(int ks0, int row, int lq, int col0, FA1 A1, FA2 A2, FB B, d4 (&acc1)[kTJ],
-                                        d4 (&acc2)[kTJ]) {
-  double a1[C], a2[C], b[C][kTJ];
+    for (int t = 0; t < kTJ; ++t)
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const int k = 4 * (ks0 + c) + lq;
-    a1[c] = A1(row, k);
-    a2[c] = A2(row, k);
-#pragma unroll
-    for (int t = 0; t < kTJ; ++t) b[c][t] = B(k, col0 + 16 * t);
-  }
-#pragma unroll
-  for (int c = 0; c < C; ++c)
-#pragma unroll
-    for (int t = 0; t < kTJ; ++t) {
-      acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[c], b[c][t], acc1[t], 0, 0, 0);
-      acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[c], b[c][t], acc2[t], 0, 0, 0);
-    }
+      for (int u = 0; u < NA; ++u)
+        acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][c], b[c][t], acc[u][t], 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------
-// C(i,j) <- epi(i, j, sum_k A(i,k) B(k,j)) for an N x N product.
-// A(i,k), B(k,j): element functors valid (and zero) on the whole padded index range.
-// SYNC: all waves finish reading their operands before any wave stores (the output may
-// alias an operand).  Requires at most one work item per wave, i.e. N <= 64.
+// C_u(i,j) <- epi(u, i, j, sum_k A(u,i,k) B(k,j)), u < NA, for i < N, j < NC.
+// A(u,i,k), B(k,j): element functors valid on the whole padded index range (zero where the K
+// range is padded).  NC = N: plain products; NC in (N, Np]: columns N..NC-1 of the B operand
+// (kept in the buffer's padding) ride along -- vectors get multiplied by A for free.
+// SYNC: all waves finish reading their operands before any wave stores (an output may alias an
+// operand).  Requires at most one work item per wave, i.e. N <= 64.
 // ---------------------------------------------------------------------------------------
-template <bool SYNC, class FA, class FB, class FE>
-__device__ __forceinline__ void wg_gemm_nc(int N, int NC, FA A, FB B, FE epi) {
+// operand functors that read LDS with cheap addressing opt in to the fast16 schedule
+template <class F> struct lds_operand { static constexpr bool value = false; };
+
+template <int NA, bool SYNC, bool FAST, class FAs, class FB, class FE>
+__device__ __forceinline__ void wg_gemm_n(int N, int NC, FAs A, FB B, FE epi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 15, lq = lane >> 4;
   const int Tn = (N + 15) >> 4;
@@ -96,17 +131,26 @@ __device__ __forceinline__ void wg_gemm_nc(int N, int NC, FA A, FB B, FE epi) {
   for (int item = wave; item < (SYNC ? kWaves : items); item += kWaves) {
     const bool have = item < items;
     const int ti = item % Tn, cg = item / Tn;
-    d4 acc[kTJ];
+    d4 acc[NA][kTJ];
 #pragma unroll
-    for (int t = 0; t < kTJ; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int u = 0; u < NA; ++u)
+#pragma unroll
+      for (int t = 0; t < kTJ; ++t) acc[u][t] = (d4){0.0, 0.0, 0.0, 0.0};
     if (have) {
       const int row = 16 * ti + lr, col0 = 16 * cg * kTJ + lr;
-      int ks = 0;
-      for (; ks + 4 <= ksteps; ks += 4) kchunk<4>(ks, row, lq, col0, A, B, acc);
-      const int rem = ksteps - ks;
-      if (rem == 3) kchunk<3>(ks, row, lq, col0, A, B, acc);
-      else if (rem == 2) kchunk<2>(ks, row, lq, col0, A, B, acc);
-      else if (rem == 1) kchunk<1>(ks, row, lq, col0, A, B, acc);
+      bool done = false;
+      if constexpr (FAST) {
+        if (ksteps == 15) { item_straight<NA, 15, 66>(row, lq, col0, A, B, acc); done = true; }
+        else if (ksteps == 16) { item_straight<NA, 16, 66>(row, lq, col0, A, B, acc); done = true; }
+      }
+      if (!done) {
+        int ks = 0;
+        for (; ks + 4 <= ksteps; ks += 4) kchunk<NA, 4>(ks, row, lq, col0, A, B, acc);
+        const int rem = ksteps - ks;
+        if (rem == 3) kchunk<NA, 3>(ks, row, lq, col0, A, B, acc);
+        else if (rem == 2) kchunk<NA, 2>(ks, row, lq, col0, A, B, acc);
+        else if (rem == 1) kchunk<NA, 1>(ks, row, lq, col0, A, B, acc);
+      }
     }
     if (SYNC) __syncthreads();
     if (have) {
@@ -116,54 +160,31 @@ __device__ __forceinline__ void wg_gemm_nc(int N, int NC, FA A, FB B, FE epi) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rw = 16 * ti + lq + 4 * r;
-          if (rw < N && col < NC) epi(rw, col, acc[t][r]);
+          if (rw < N && col < NC) {
+#pragma unroll
+            for (int u = 0; u < NA; ++u) epi(u, rw, col, acc[u][t][r]);
+          }
         }
       }
     }
   }
 }
 
-// NC = N: the plain N x N product.  NC in (N, Np]: columns N..NC-1 of the B operand (kept in the
-// buffer's padding) ride along: vectors get multiplied by A for free in the last column tile.
+template <bool SYNC, class FA, class FB, class FE>
+__device__ __forceinline__ void wg_gemm_nc(int N, int NC, FA A, FB B, FE epi) {
+  wg_gemm_n<1, SYNC, lds_operand<FA>::value && lds_operand<FB>::value>(
+      N, NC, One<FA>{A}, B, [=](int, int i, int j, double v) { epi(i, j, v); });
+}
 template <bool SYNC, class FA, class FB, class FE>
 __device__ __forceinline__ void wg_gemm(int N, FA A, FB B, FE epi) {
   wg_gemm_nc<SYNC>(N, N, A, B, epi);
 }
-
 // Two products sharing the B operand: C1 = A1*B, C2 = A2*B (r += (A r) t and t = A t).
 template <bool SYNC, class FA1, class FA2, class FB, class FE1, class FE2>
 __device__ __forceinline__ void wg_gemm2(int N, FA1 A1, FA2 A2, FB B, FE1 epi1, FE2 epi2) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int Tn = (N + 15) >> 4;
-  const int Cg = (Tn + kTJ - 1) / kTJ;
-  const int items = Tn * Cg;
-  const int ksteps = (N + 3) >> 2;
-  for (int item = wave; item < (SYNC ? kWaves : items); item += kWaves) {
-    const bool have = item < items;
-    const int ti = item % Tn, cg = item / Tn;
-    d4 acc1[kTJ], acc2[kTJ];
-#pragma unroll
-    for (int t = 0; t < kTJ; ++t) { acc1[t] = (d4){0.0, 0.0, 0.0, 0.0}; acc2[t] = (d4){0.0, 0.0, 0.0, 0.0}; }
-    if (have) {
-      const int row = 16 * ti + lr, col0 = 16 * cg * kTJ + lr;
-      int ks = 0;
-      for (; ks + 2 <= ksteps; ks += 2) kchunk2<2>(ks, row, lq, col0, A1, A2, B, acc1, acc2);
-      if (ks < ksteps) kchunk2<1>(ks, row, lq, col0, A1, A2, B, acc1, acc2);
-    }
-    if (SYNC) __syncthreads();
-    if (have) {
-#pragma unroll
-      for (int t = 0; t < kTJ; ++t) {
-        const int col = 16 * (cg * kTJ + t) + lr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rw = 16 * ti + lq + 4 * r;
-          if (rw < N && col < N) { epi1(rw, col, acc1[t][r]); epi2(rw, col, acc2[t][r]); }
-        }
-      }
-    }
-  }
+  wg_gemm_n<2, SYNC, lds_operand<FA1>::value && lds_operand<FA2>::value && lds_operand<FB>::value>(
+      N, N, Two<FA1, FA2>{A1, A2}, B,
+      [=](int u, int i, int j, double v) { if (u == 0) epi1(i, j, v); else epi2(i, j, v); });
 }
 
 // ---------------------------------------------------------------------------------------

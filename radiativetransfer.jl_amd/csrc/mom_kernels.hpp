@@ -126,12 +126,18 @@ __device__ __forceinline__ void zero_padding(const Ctx &c) {
 struct ElP {
   const double *p; int ld;
   __device__ __forceinline__ double operator()(int i, int j) const { return p[i + j * ld]; }
+  template <int LD> __device__ __forceinline__ double at(int i, int j) const { return p[i + j * LD]; }
+  __device__ __forceinline__ void launder() { asm volatile("" : "+v"(p)); }
 };
 // diag(sg) * padded buf * diag(sg)   (sg padded with anything finite)
 struct ElSigP {
   const double *p; const double *sg; int ld;
   __device__ __forceinline__ double operator()(int i, int j) const { return sg[i] * sg[j] * p[i + j * ld]; }
+  template <int LD> __device__ __forceinline__ double at(int i, int j) const { return sg[i] * sg[j] * p[i + j * LD]; }
+  __device__ __forceinline__ void launder() { asm volatile("" : "+v"(p), "+v"(sg)); }
 };
+template <> struct lds_operand<ElP> { static constexpr bool value = true; };
+template <> struct lds_operand<ElSigP> { static constexpr bool value = true; };
 // element functor of an unpadded (global) array with bounds checks
 struct El {
   const double *p; int ld, N;
