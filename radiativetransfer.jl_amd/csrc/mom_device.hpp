@@ -34,7 +34,7 @@ struct FastDiv {
   int N;
   __device__ __forceinline__ void init(int n) { N = n; magic = (unsigned)((0x100000000ull + (unsigned)n - 1u) / (unsigned)n); }
   __device__ __forceinline__ void split(int e, int &i, int &j) const {
-    j = (int)__umulhi((unsigned)e, magic);
+    j = (N == 1) ? e : (int)__umulhi((unsigned)e, magic);  // n = 1: the magic number does not fit 32 bits
     i = e - j * N;
   }
 };

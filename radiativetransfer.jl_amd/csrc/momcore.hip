@@ -9,6 +9,28 @@
 #include <vector>
 
 #include "momcore.h"
+
+#ifdef MOM_DIAG_STAMPS
+// diagnostic build only (make EXTRA=-DMOM_DIAG_STAMPS): s_memtime deltas of workgroup 0, thread 0,
+// accumulated per code section; read back with mom_diag_read().  Never part of the shipped library.
+__device__ unsigned long long mom_diag_acc[64];
+__device__ unsigned long long mom_diag_last;
+__device__ __forceinline__ unsigned long long mom_diag_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define MOM_STAMP(id)                                                    \
+  do {                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1)) {              \
+      unsigned long long n__ = mom_diag_now();                           \
+      mom_diag_acc[id] += n__ - mom_diag_last;                           \
+      mom_diag_last = n__;                                               \
+    }                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+  } while (0)
+#endif
 #include "mom_kernels.hpp"
 
 using namespace mom;
@@ -62,7 +84,11 @@ __global__ void __launch_bounds__(kThreads) k_layer(LayerArgs a) {
   const int N = a.q.N;
   const size_t total = (size_t)a.S * a.M;
   Ctx c;
+#ifdef MOM_DIAG_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1)) mom_diag_last = mom_diag_now();
+#endif
   wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
+  MOM_STAMP(40);
   for (size_t pt = blockIdx.x; pt < total; pt += gridDim.x) {
     const int n = (int)(pt % a.S), m = (int)(pt / a.S);
     const double tau = a.tau[n], varpi = a.varpi[n];
@@ -72,11 +98,14 @@ __global__ void __launch_bounds__(kThreads) k_layer(LayerArgs a) {
     ZMix zpp{a.Zpp + NN * a.K * m, a.zw + (size_t)a.K * n, a.K, N};
     ZMix zmp{a.Zmp + NN * a.K * m, a.zw + (size_t)a.K * n, a.K, N};
     elemental_build(c, a.q, m, a.nd, a.tau_sum[n], dtau, varpi, zpp, zmp);
+    MOM_STAMP(41);
     expk = doubling_run<LDSM>(c, a.nd, expk);
+    MOM_STAMP(30);
     CompPtrs g = comp_ptrs(a.comp, N, pt);
     if (a.first) {
       store_added_as_composite(c, g);
       __syncthreads();
+      MOM_STAMP(42);
     } else {
       interaction_core<LDSM>(c, a.iface, g, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
     }
@@ -471,6 +500,9 @@ extern "C" int mom_set_streams(mom_t *h, const double *qp_muN, const double *wt_
   q.mu = h->d_mu; q.wt = h->d_wt; q.sg = h->d_sg;
   for (int k = 0; k < 4; ++k) { q.I0[k] = (k < h->nS) ? I0[k] : 0.0; q.D[k] = (k < h->nS) ? D[k] : 1.0; }
   q.N = N; q.nS = h->nS; q.imu0 = imu0_1based; q.mu0 = mu0; q.inv_mode = h->opt_inverse;
+  q.regular = 1;
+  for (int i = 0; i < N; ++i)
+    if (qp_muN[i] != qp_muN[(i / h->nS) * h->nS]) q.regular = 0;
   h->streams_set = true;
   return MOM_OK;
 }
@@ -772,6 +804,17 @@ extern "C" int mom_get_RT_device(mom_t *h, void *dR, void *dT) {
   HIPCHK(h, hipMemcpyAsync(dT, h->d_T, bytes, hipMemcpyDeviceToDevice, h->stream));
   return check_info(h);
 }
+
+#ifdef MOM_DIAG_STAMPS
+extern "C" int mom_diag_read(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mom_diag_acc), 64 * sizeof(unsigned long long)) != hipSuccess) return MOM_EHIP;
+  if (reset) {
+    unsigned long long z[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mom_diag_acc), z, sizeof z) != hipSuccess) return MOM_EHIP;
+  }
+  return MOM_OK;
+}
+#endif
 
 extern "C" int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
