@@ -324,6 +324,90 @@ __device__ __forceinline__ void wg_inverse(int N, const FastDiv &fd, double *a, 
   __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------
+// Register-resident Gauss-Jordan inverse for N <= 64 (one matrix row per lane).
+// Wave w holds columns [CW*w, CW*w + CW) of the matrix, lane = row: CW = 64/kWaves registers per
+// lane.  Partial pivoting is IMPLICIT: the pivot of step k is the largest |a[i][k]| among the rows
+// not yet used as pivots; rows are never moved, the permutation is undone when the result is
+// written back (inv(A)[k][p_j] = S[p_k][j]).  Per elimination step: one wave-level max + ballot in
+// the wave that owns column k, ONE workgroup barrier (pivot column / index / reciprocal travel
+// through double-buffered LDS slots), CW readlane broadcasts of the pivot row and CW FMAs per lane.
+// a: column-major buffer (ld) holding the matrix on entry and the inverse on exit.
+// pcol: LDS, >= 2*64 doubles; shd: LDS, >= 4 doubles; ipiv: LDS ints >= 64; bad: LDS int.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, l);
+  hi = __builtin_amdgcn_readlane(hi, l);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void wg_inverse_reg(int N, double *a, int ld, double *pcol, double *shd, int *ipiv,
+                                               int *bad) {
+  constexpr int CW = 64 / kWaves;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double v[CW];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    const int col = CW * wave + c;
+    v[c] = (lane < N && col < N) ? a[lane + col * ld] : 0.0;
+  }
+  bool used = false;
+  int myk = 0;
+  const int npanel = (N + CW - 1) / CW;
+  for (int kp = 0; kp < npanel; ++kp) {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int k = CW * kp + c;
+      if (k < N) {  // wave-uniform
+        const int slot = k & 1;
+        if (wave == kp) {
+          // pivot = first row whose |a| has the largest HIGH WORD (sign/exponent/20 mantissa bits):
+          // within 2^-20 of the true maximum, which is all partial pivoting needs, and a 32-bit
+          // integer wave reduction instead of a 64-bit one
+          const int ah = (!used && lane < N) ? __double2hiint(fabs(v[c])) : -1;
+          int mh = ah;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) mh = max(mh, __shfl_xor(mh, off));
+          unsigned long long mk = __ballot(ah == mh);
+          int p = __ffsll((long long)mk) - 1;
+          const double m = fabs(readlane_f64(v[c], p));
+          const double piv = readlane_f64(v[c], p);
+          const double d = 1.0 / piv;
+          pcol[slot * 64 + lane] = v[c];
+          if (lane == 0) {
+            shd[2 * slot] = d;
+            shd[2 * slot + 1] = (double)p;
+            ipiv[k] = p;
+            if (!(m > 0.0)) *bad = k + 1;
+          }
+        }
+        __syncthreads();
+        const double d = shd[2 * slot];
+        const int p = __builtin_amdgcn_readfirstlane((int)shd[2 * slot + 1]);
+        const double f = pcol[slot * 64 + lane];
+        const bool isp = (lane == p);
+#pragma unroll
+        for (int cc = 0; cc < CW; ++cc) {
+          const double prow = readlane_f64(v[cc], p) * d;
+          v[cc] = isp ? prow : (v[cc] - f * prow);
+        }
+        if (wave == kp) v[c] = isp ? d : (-f * d);
+        if (isp) { used = true; myk = k; }
+      }
+    }
+  }
+  __syncthreads();  // ipiv complete; everyone is done reading the matrix buffer's old contents
+  if (lane < N) {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int col = CW * wave + c;
+      if (col < N) a[myk + ipiv[col] * ld] = v[c];
+    }
+  }
+  __syncthreads();
+}
+
 // copy an N x N column-major block src(ld_s) -> dst(ld_d), all threads; loads batched by 4
 __device__ __forceinline__ void wg_copy_mat(int N, const FastDiv &fd, const double *__restrict__ src, int ld_s,
                                             double *__restrict__ dst, int ld_d) {

@@ -281,7 +281,8 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob
       b[i + j * ld] = ((i == j) ? 1.0 : 0.0) - b[i + j * ld];
     }
     __syncthreads();
-    wg_inverse(N, c.fd, b, ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);
+    if (N <= 64) wg_inverse_reg(N, b, ld, c.part, c.prow, c.ipiv, c.bad);  // part: >= 128 doubles (2*kWaves*ldv)
+    else wg_inverse(N, c.fd, b, ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);
     wg_gemm<false>(N, T, ElP{b, ld}, [=](int i, int j, double v) { o[i + j * ld] = v; });
     __syncthreads();
   }

@@ -315,7 +315,8 @@ __global__ void __launch_bounds__(kThreads) k_batch_inv(BlasArgs a) {
   for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
     wg_copy_mat(N, c.fd, a.A + NN * pt, N, c.P, c.ld);
     __syncthreads();
-    wg_inverse(N, c.fd, c.P, c.ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);
+    if (N <= 64) wg_inverse_reg(N, c.P, c.ld, c.part, c.prow, c.ipiv, c.bad);
+    else wg_inverse(N, c.fd, c.P, c.ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);
     wg_copy_mat(N, c.fd, c.P, c.ld, a.C + NN * pt, N);
     __syncthreads();
   }
