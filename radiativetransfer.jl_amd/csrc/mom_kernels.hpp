@@ -553,8 +553,12 @@ struct CompPtrs {
 // interaction_helper!: composite (global) <- composite (+) added.  Added r-+ in c.r, t++ in
 // c.t, j0+ in c.jp, j0- in c.jm; added r+- and t-- as element functors.  Ends with barrier.
 // ---------------------------------------------------------------------------------------
-template <bool LDSM, class FRPM, class FTMM>
-__device__ __forceinline__ void interaction_core(Ctx &c, int iface, const CompPtrs &g, FRPM rpm, FTMM tmm) {
+// IFACE: compile-time interface code 0..3 (the code of the other three cases is not generated: the
+// per-layer kernels are launched with the layer's code as a template argument, which keeps the
+// instruction footprint of the common 11 case small), or -1 to select at run time.
+template <bool LDSM, int IFACE, class FRPM, class FTMM>
+__device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const CompPtrs &g, FRPM rpm, FTMM tmm) {
+  const int iface = (IFACE >= 0) ? IFACE : iface_rt;
   const int N = c.N, ld = c.ld;
   double *r = c.r, *t = c.t;
   // composite sources -> LDS
@@ -563,7 +567,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface, const CompPt
     c.Jm[i] = g.J0m[i];
   }
   __syncthreads();
-  if (iface == 0) {
+  if ((IFACE < 0 || IFACE == 0) && iface == 0) {
     // J0+ = j0+ + t++ J0+ ; J0- = J0- + T-- j0-            (interaction.jl:16-17)
     wg_matvec(c, ElP{t, ld}, c.Jp, c.v1);
     wg_matvec(c, El{g.T_mm, N, N}, c.jm, c.v2);
@@ -578,7 +582,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface, const CompPt
     double *Tmm = g.T_mm, *Tpp = g.T_pp;
     wg_gemm<false>(N, tmm, ElP{c.P, ld}, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
     wg_gemm<false>(N, ElP{t, ld}, ElP{c.Q, ld}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
-  } else if (iface == 1) {
+  } else if ((IFACE < 0 || IFACE == 1) && iface == 1) {
     wg_copy_mat(N, c.fd, g.T_mm, N, c.P, ld);  // P = T--
     // J0- = J0- + T-- (r-+ J0+ + j0-) ; J0+ = j0+ + t++ J0+  (:36-37)
     wg_matvec(c, ElP{r, ld}, c.Jp, c.v1);
@@ -606,7 +610,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface, const CompPt
       c.fd.split(e, i, j);
       Rpm[i + j * N] = rpm(i, j);
     }
-  } else if (iface == 2) {
+  } else if ((IFACE < 0 || IFACE == 2) && iface == 2) {
     double *P = c.P, *Q = c.Q;
     wg_copy_mat(N, c.fd, g.R_pm, N, P, ld);  // P = R+-
     wg_copy_mat(N, c.fd, g.T_mm, N, Q, ld);  // Q = T--
@@ -632,7 +636,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface, const CompPt
     wg_gemm<false>(N, ElP{t, ld}, ElP{P, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
     __syncthreads();
     wg_gemm<false>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * N] = v; });
-  } else {
+  } else if ((IFACE < 0 || IFACE == 3) && iface == 3) {
     // ---- ScatteringInterface_11 (interaction.jl:69-117)
     // The four mat-vec products ride as column N of the B operands when the buffers have a spare
     // column in the last tile and no K padding (see doubling_run).

@@ -79,7 +79,7 @@ extern __shared__ double mom_smem[];
 // One launch per atmospheric layer: every (spectral point, Fourier moment) pair runs
 // elemental -> nd doublings -> interaction with its composite state (rt_kernel!,
 // rt_kernel.jl:173-235) inside one workgroup; the added layer never touches HBM.
-template <bool LDSM>
+template <bool LDSM, int IFACE>
 __global__ void __launch_bounds__(kThreads) k_layer(LayerArgs a) {
   const int N = a.q.N;
   const size_t total = (size_t)a.S * a.M;
@@ -97,8 +97,15 @@ __global__ void __launch_bounds__(kThreads) k_layer(LayerArgs a) {
     const size_t NN = (size_t)N * N;
     ZMix zpp{a.Zpp + NN * a.K * m, a.zw + (size_t)a.K * n, a.K, N};
     ZMix zmp{a.Zmp + NN * a.K * m, a.zw + (size_t)a.K * n, a.K, N};
+#ifdef MOM_DIAG_STAMPS
+    MOM_STAMP(43);
+#endif
     elemental_build(c, a.q, m, a.nd, a.tau_sum[n], dtau, varpi, zpp, zmp);
     MOM_STAMP(41);
+#ifdef MOM_DIAG_TWICE
+    elemental_build(c, a.q, m, a.nd, a.tau_sum[n], dtau, varpi, zpp, zmp);
+    MOM_STAMP(44);
+#endif
     expk = doubling_run<LDSM>(c, a.nd, expk);
     MOM_STAMP(30);
     CompPtrs g = comp_ptrs(a.comp, N, pt);
@@ -107,7 +114,7 @@ __global__ void __launch_bounds__(kThreads) k_layer(LayerArgs a) {
       __syncthreads();
       MOM_STAMP(42);
     } else {
-      interaction_core<LDSM>(c, a.iface, g, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
+      interaction_core<LDSM, IFACE>(c, a.iface, g, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
     }
   }
   if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
@@ -149,7 +156,7 @@ __global__ void __launch_bounds__(kThreads) k_surface(SurfArgs a) {
     }
     __syncthreads();
     CompPtrs g = comp_ptrs(a.comp, N, pt);
-    interaction_core<LDSM>(c, a.iface, g, ElZero{}, ElEye{N});
+    interaction_core<LDSM, -1>(c, a.iface, g, ElZero{}, ElEye{N});
   }
   if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
 }
@@ -267,7 +274,7 @@ __global__ void __launch_bounds__(kThreads) k_op_interaction(OpArgs a) {
     load_added(c, a.added, pt);
     __syncthreads();
     CompPtrs g = comp_ptrs(a.comp, N, pt);
-    interaction_core<LDSM>(c, a.iface, g, El{a.added[0] + NN * pt, N, N}, El{a.added[2] + NN * pt, N, N});
+    interaction_core<LDSM, -1>(c, a.iface, g, El{a.added[0] + NN * pt, N, N}, El{a.added[2] + NN * pt, N, N});
   }
   if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
 }
@@ -512,6 +519,13 @@ static int grid_for(const mom_t *h, size_t total) {
   if (h->lds_mode) return (int)total;
   return (int)std::min<size_t>(total, (size_t)h->G);
 }
+// layer kernels: with enough spectral points to fill the chip several times over, one workgroup
+// walks the M Fourier moments of its point (pt = n, n + S, ...): the 2nd and 3rd pass run with the
+// instruction cache and the phase-matrix bases warm.
+static int grid_for_layers(const mom_t *h, size_t S, int M) {
+  if (!h->lds_mode) return (int)std::min<size_t>(S * M, (size_t)h->G);
+  return (int)((S >= 2048) ? S : S * M);
+}
 
 static int check_info(mom_t *h) {
   int info = 0;
@@ -537,6 +551,19 @@ static int check_info(mom_t *h) {
       hipLaunchKernelGGL(KERN<false>, dim3(grid), dim3(kThreads), sm__, (h)->stream, args); \
     }                                                                                     \
     HIPCHK(h, hipGetLastError());                                                         \
+  } while (0)
+
+#define LAUNCH2(h, KERN, TARG, grid, args)                                                        \
+  do {                                                                                            \
+    const size_t sm__ = smem_bytes(h);                                                            \
+    if ((h)->lds_mode) {                                                                          \
+      HIPCHK(h, allow_lds(KERN<true, TARG>, sm__));                                               \
+      hipLaunchKernelGGL((KERN<true, TARG>), dim3(grid), dim3(kThreads), sm__, (h)->stream, args); \
+    } else {                                                                                      \
+      HIPCHK(h, allow_lds(KERN<false, TARG>, sm__));                                              \
+      hipLaunchKernelGGL((KERN<false, TARG>), dim3(grid), dim3(kThreads), sm__, (h)->stream, args); \
+    }                                                                                             \
+    HIPCHK(h, hipGetLastError());                                                                 \
   } while (0)
 
 extern "C" int mom_elemental(mom_t *h, int m, int ndoubl, const double *tau_sum, const double *dtau, const double *varpi,
@@ -763,7 +790,12 @@ extern "C" int mom_rt_run(mom_t *h) {
     a.Zpp = h->d_Zpp; a.Zmp = h->d_Zmp;
     for (int k = 0; k < 6; ++k) a.comp[k] = h->comp[k];
     a.scratch = h->d_scratch; a.info = h->d_info;
-    LAUNCH(h, k_layer, grid_for(h, S * M), a);
+    switch (a.iface) {  // the interface code is a template argument: see interaction_core
+      case 0: LAUNCH2(h, k_layer, 0, grid_for_layers(h, S, M), a); break;
+      case 1: LAUNCH2(h, k_layer, 1, grid_for_layers(h, S, M), a); break;
+      case 2: LAUNCH2(h, k_layer, 2, grid_for_layers(h, S, M), a); break;
+      default: LAUNCH2(h, k_layer, 3, grid_for_layers(h, S, M), a); break;
+    }
     h->launches++;
   }
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
