@@ -162,6 +162,9 @@ int mom_voigt_xsec(int device, int nLines, const double *nu, const double *gamma
                    const double *S, const int *ind_start_1based, const int *ind_stop_1based, int nGrid,
                    const double *grid, double *sigma);
 
+/* GPU time (HIP events around the kernel, ms) of the last mom_voigt_xsec call of the calling thread. */
+double mom_voigt_last_kernel_ms(void);
+
 #ifdef __cplusplus
 }
 #endif

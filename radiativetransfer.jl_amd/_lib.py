@@ -60,6 +60,7 @@ SIGNATURES = {
     "mom_timers": (C.c_int, [c_h, c_dp, C.c_int, c_ip]),
     "mom_set_option": (C.c_int, [c_h, C.c_int, C.c_int]),
     "mom_voigt_xsec": (C.c_int, [C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip, C.c_int, c_dp, c_dp]),
+    "mom_voigt_last_kernel_ms": (C.c_double, []),
 }
 
 _lib = None
@@ -227,3 +228,7 @@ def voigt_xsec(nu, gamma_d, y, S, ind_start, ind_stop, grid, device: int = 0):
     if rc != MOM_OK:
         raise MomError(rc, "mom_voigt_xsec failed")
     return sigma
+
+
+def voigt_last_kernel_ms() -> float:
+    return float(load().mom_voigt_last_kernel_ms())

@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__re
 }
 
 thread_local std::string v_err;
+thread_local double v_last_ms = 0.0;
 
 }  // namespace
 
@@ -147,12 +148,28 @@ extern "C" int mom_voigt_xsec(int device, int nLines, const double *nu, const do
   VCHK(hipMalloc((void **)&d[4], (size_t)nGrid * sizeof(double)));
   VCHK(hipMalloc((void **)&d[5], (size_t)nGrid * sizeof(double)));
   VCHK(hipMemcpy(d[4], grid, (size_t)nGrid * sizeof(double), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_voigt, dim3((nGrid + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, nLines, d[0], d[1], d[2], d[3],
-                     di[0], di[1], nGrid, d[4], d[5]);
-  VCHK(hipGetLastError());
+  {
+    hipEvent_t e0, e1;
+    VCHK(hipEventCreate(&e0));
+    VCHK(hipEventCreate(&e1));
+    VCHK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_voigt, dim3((nGrid + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, nLines, d[0], d[1], d[2], d[3],
+                       di[0], di[1], nGrid, d[4], d[5]);
+    VCHK(hipGetLastError());
+    VCHK(hipEventRecord(e1, 0));
+    VCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    VCHK(hipEventElapsedTime(&ms, e0, e1));
+    v_last_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
   VCHK(hipMemcpy(sigma, d[5], (size_t)nGrid * sizeof(double), hipMemcpyDeviceToHost));
 done:
   for (int k = 0; k < 6; ++k) if (d[k]) (void)hipFree(d[k]);
   for (int k = 0; k < 2; ++k) if (di[k]) (void)hipFree(di[k]);
   return rc;
 }
+
+// GPU time of the k_voigt launch of the last mom_voigt_xsec call on this thread (HIP events), ms.
+extern "C" double mom_voigt_last_kernel_ms(void) { return v_last_ms; }

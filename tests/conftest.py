@@ -23,5 +23,8 @@ def cref():
 
 @pytest.fixture(scope="session")
 def rtamd():
+    import subprocess
     import rtamd as pkg
+    if not pkg._lib.LIB_PATH.exists():  # normally built in-tree by __graft_entry__.build(); hipcc is in the image
+        subprocess.check_call(["make", "-C", str(ROOT / "radiativetransfer.jl_amd" / "csrc")])
     return pkg
