@@ -138,6 +138,11 @@ int mom_rt_run(mom_t *h);
 
 /* R_SFI, T_SFI [nVza, nStokes, S] to host (synchronises). */
 int mom_get_RT(mom_t *h, double *R_SFI, double *T_SFI);
+/* The RAMI extras of rt_run's return tuple (rt_run.jl:226): hdr [nVza, nStokes, S] from
+ * interaction_hdrf! (CoreKernel/interaction_hdrf.jl:9-45) + postprocessing_vza_hdrf!
+ * (postprocessing_vza.jl:63-93), and the up-/down-welling flux sums bhr_uw, bhr_dw [nStokes, S]
+ * (the reference returns their first rows). */
+int mom_get_hdr(mom_t *h, double *hdr, double *bhr_uw, double *bhr_dw);
 /* Same, into caller-owned DEVICE buffers (e.g. the send buffer of an RCCL all-gather). */
 int mom_get_RT_device(mom_t *h, void *dR_SFI, void *dT_SFI);
 

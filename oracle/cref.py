@@ -129,6 +129,24 @@ def rt_run(p: Packed, pts=None, nthreads: int = 0):
     return np.transpose(R.reshape(shp), (2, 1, 0)).copy(), np.transpose(T.reshape(shp), (2, 1, 0)).copy(), info
 
 
+def rt_run_full(p: Packed, pts=None, nthreads: int = 0):
+    """Like rt_run plus the RAMI extras: returns R, T, hdr [nVza,nStokes,S], bhr_uw, bhr_dw [nStokes,S], info."""
+    if nthreads <= 0:
+        nthreads = os.cpu_count() or 1
+    n = p.nVza * p.nS * p.S
+    R, T, H = np.zeros(n), np.zeros(n), np.zeros(n)
+    up, dw = np.zeros(p.nS * p.S), np.zeros(p.nS * p.S)
+    st = p.c_struct()
+    if pts is None:
+        info = lib().ora_rt_run_full(C.byref(st), None, 0, nthreads, dp(R), dp(T), dp(H), dp(up), dp(dw))
+    else:
+        pts = np.ascontiguousarray(pts, dtype=np.int32)
+        info = lib().ora_rt_run_full(C.byref(st), ip(pts), len(pts), nthreads, dp(R), dp(T), dp(H), dp(up), dp(dw))
+    shp = (p.S, p.nS, p.nVza)
+    tr = lambda a: np.transpose(a.reshape(shp), (2, 1, 0)).copy()
+    return tr(R), tr(T), tr(H), up.reshape(p.S, p.nS).T.copy(), dw.reshape(p.S, p.nS).T.copy(), info
+
+
 # ---- op-level wrappers on ABI-ordered flat arrays -----------------------------------------
 
 def elemental(p: Packed, m, nd, tau_sum, dtau, varpi, Zpp, Zmp, z_batch, S):

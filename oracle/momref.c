@@ -462,7 +462,16 @@ typedef struct {
 /* R_SFI,T_SFI: [nVza,nStokes,S] column-major, zero-initialised by the caller.
  * pts: optional list of spectral indices to process (npts entries) or NULL for all.
  * Returns first nonzero LU info. */
+int ora_rt_run_full(const ora_scene *sc, const int *pts, int npts, int nthreads, double *R_SFI, double *T_SFI,
+                    double *hdr, double *bhr_uw, double *bhr_dw);
 int ora_rt_run(const ora_scene *sc, const int *pts, int npts, int nthreads, double *R_SFI, double *T_SFI) {
+  return ora_rt_run_full(sc, pts, npts, nthreads, R_SFI, T_SFI, 0, 0, 0);
+}
+
+/* hdr [nVza,nStokes,S], bhr_uw/bhr_dw [nStokes,S]: interaction_hdrf! (interaction_hdrf.jl:9-45) and
+ * postprocessing_vza_hdrf! (postprocessing_vza.jl:63-93); may be NULL. */
+int ora_rt_run_full(const ora_scene *sc, const int *pts, int npts, int nthreads, double *R_SFI, double *T_SFI,
+                    double *hdr, double *bhr_uw, double *bhr_dw) {
   const int N = sc->N, n = sc->nS, S = sc->S, Nz = sc->Nz, K = sc->K, M = sc->M;
   const size_t NN = (size_t)N * N;
   ora_streams q = {N, n, sc->imu0, sc->mu, sc->wt, sc->I0, sc->D, sc->strict, sc->mu0};
@@ -524,7 +533,22 @@ int ora_rt_run(const ora_scene *sc, const int *pts, int npts, int nthreads, doub
 #pragma omp atomic write
           info = e3;
         }
-        /* postprocessing_vza! postprocessing_vza.jl:9-60 (SFI branch) */
+        /* interaction_hdrf!: hdr_J0- = r-+_surf J0+ + j0-_surf (work[0..N)) */
+        double *hdrJ = work;
+        if (hdr) {
+          gemv(N, a_rmp, c_J0p, hdrJ);
+          for (int i = 0; i < N; ++i) hdrJ[i] += a_j0m[i];
+          if (m == 0) {
+            const int i0 = n * (sc->imu0 - 1);
+            for (int k = 0; k < n; ++k) {
+              double up = 0.0, dw = 0.0;
+              for (int j = k; j < N; j += n) { up += hdrJ[j] * sc->wt[j] * sc->mu[j]; dw += c_J0p[j] * sc->wt[j] * sc->mu[j]; }
+              bhr_uw[k + (size_t)n * s] = up;
+              bhr_dw[k + (size_t)n * s] = dw + a_j0p[i0] * sc->mu[i0];
+            }
+          }
+        }
+        /* postprocessing_vza! postprocessing_vza.jl:9-60 (SFI branch) and _hdrf! :63-93 */
         for (int v = 0; v < sc->nVza; ++v) {
           const int istart = (sc->node[v] - 1) * n;
           const double c = sc->cos_mphi[v + (size_t)sc->nVza * m], sn = sc->sin_mphi[v + (size_t)sc->nVza * m];
@@ -533,6 +557,7 @@ int ora_rt_run(const ora_scene *sc, const int *pts, int npts, int nthreads, doub
             const size_t o = v + (size_t)sc->nVza * (k + (size_t)n * s);
             R_SFI[o] += cs * c_J0m[istart + k];
             T_SFI[o] += cs * c_J0p[istart + k];
+            if (hdr) hdr[o] += cs * hdrJ[istart + k];
           }
         }
       }

@@ -827,6 +827,50 @@ def rt_kernel(pol, quad, added, comp, lay: LayerOptics, iface, tau_sum, m, iz, s
     return nd
 
 
+def interaction_hdrf(surf: AddedLayer, comp: CompositeLayer, m: int, pol: PolType, quad: QuadPoints, bhr_uw, bhr_dw):
+    """interaction_hdrf! (CoreKernel/interaction_hdrf.jl:9-45): hemispherical-directional source
+    hdr_J0- = r-+_surf J0+ + j0-_surf and, for m = 0, the up/down-welling flux sums of the BHR."""
+    n = pol.n
+    hdr_J0m = _mv(surf.r_mp, comp.J0p) + surf.j0m
+    if m == 0:
+        wq = quad.wt_muN * quad.qp_muN
+        i0 = quad.imu0Nstart - 1
+        for i in range(n):
+            bhr_uw[i, :] = (hdr_J0m[:, i::n] * wq[None, i::n]).sum(axis=1)
+            bhr_dw[i, :] = (comp.J0p[:, i::n] * wq[None, i::n]).sum(axis=1) + surf.j0p[:, i0] * quad.qp_muN[i0]
+    return hdr_J0m
+
+
+def rt_run_full(scene: Scene, hook=None):
+    """rt_run.jl:41-230 with the RAMI extras: (R_SFI, T_SFI, hdr, bhr_uw, bhr_dw); hdr is
+    [nVza, nStokes, S] (postprocessing_vza_hdrf!, postprocessing_vza.jl:63-93), bhr_* [nStokes, S]."""
+    pol, quad = scene.pol, scene.quad
+    S, Nz, N = scene.S, scene.Nz, scene.N
+    nV = len(scene.vza)
+    R_SFI = np.zeros((nV, pol.n, S))
+    T_SFI = np.zeros((nV, pol.n, S))
+    hdr = np.zeros((nV, pol.n, S))
+    bhr_uw = np.zeros((pol.n, S))
+    bhr_dw = np.zeros((pol.n, S))
+    added = make_added_layer(N, S)
+    surf = make_added_layer(N, S)
+    comp = make_composite_layer(N, S)
+    strict = scene.strict_reference_indexing
+    for m in range(scene.max_m):
+        weight = 0.5 if m == 0 else 1.0
+        layers = construct_core_optical_properties(scene, m)
+        ifaces, tau_sum_all = extract_effective_props(layers)
+        for iz in range(Nz):
+            rt_kernel(pol, quad, added, comp, layers[iz], ifaces[iz], tau_sum_all[:, iz], m, iz + 1, strict, hook)
+        create_surface_layer_lambertian(scene.albedo, surf, m, pol, quad, tau_sum_all[:, -1])
+        interaction(ifaces[-1], comp, surf)
+        hdr_J0m = interaction_hdrf(surf, comp, m, pol, quad, bhr_uw, bhr_dw)
+        postprocessing_vza(pol, comp, scene.vza, quad.qp_mu, m, scene.vaz, weight, R_SFI, T_SFI)
+        dummy = CompositeLayer(None, None, None, None, np.zeros_like(hdr_J0m), hdr_J0m)
+        postprocessing_vza(pol, dummy, scene.vza, quad.qp_mu, m, scene.vaz, weight, hdr, np.zeros_like(hdr))
+    return R_SFI, T_SFI, hdr, bhr_uw, bhr_dw
+
+
 def rt_run(scene: Scene, hook=None):
     """rt_run(::noRS, model, iBand) rt_run.jl:41-230, SFI=true; returns (R_SFI, T_SFI)
     each [nVza, nStokes, S]."""

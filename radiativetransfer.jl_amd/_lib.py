@@ -56,6 +56,7 @@ SIGNATURES = {
                                 C.c_double, C.c_int, c_ip, c_dp, c_dp]),
     "mom_rt_run": (C.c_int, [c_h]),
     "mom_get_RT": (C.c_int, [c_h, c_dp, c_dp]),
+    "mom_get_hdr": (C.c_int, [c_h, c_dp, c_dp, c_dp]),
     "mom_get_RT_device": (C.c_int, [c_h, C.c_void_p, C.c_void_p]),
     "mom_timers": (C.c_int, [c_h, c_dp, C.c_int, c_ip]),
     "mom_set_option": (C.c_int, [c_h, C.c_int, C.c_int]),
@@ -208,6 +209,14 @@ class Handle:
         self.check(self.lib.mom_get_RT(self._h, dp(R), dp(T)))
         shp = (self.S, self.nS, self.nVza)
         return np.transpose(R.reshape(shp), (2, 1, 0)).copy(), np.transpose(T.reshape(shp), (2, 1, 0)).copy()
+
+    def get_hdr(self):
+        """hdr [nVza, nStokes, S], bhr_uw, bhr_dw [nStokes, S]."""
+        n = self.nVza * self.nS * self.S
+        H, up, dw = np.empty(n), np.empty(self.nS * self.S), np.empty(self.nS * self.S)
+        self.check(self.lib.mom_get_hdr(self._h, dp(H), dp(up), dp(dw)))
+        return (np.transpose(H.reshape(self.S, self.nS, self.nVza), (2, 1, 0)).copy(),
+                up.reshape(self.S, self.nS).T.copy(), dw.reshape(self.S, self.nS).T.copy())
 
     def get_RT_device(self, dR_ptr: int, dT_ptr: int):
         self.check(self.lib.mom_get_RT_device(self._h, C.c_void_p(dR_ptr), C.c_void_p(dT_ptr)))

@@ -554,12 +554,15 @@ def run_scene(h: _lib.Handle, sc: SceneInputs):
 
 
 def rt_run(model: vSmartMOM_Model, i_band: int = 1):
-    """rt_run(model; i_band) (rt_run.jl:19-21 -> :41-230), SFI = true, noRS.
-    Returns (R_SFI, T_SFI), each [nVza, nStokes, nSpec] like rt_run.jl:226 (the RAMI extras
-    hdr/bhr of the reference's 7-tuple are outside this round's scope)."""
+    """rt_run(model; i_band) (rt_run.jl:19-21 -> :41-230), SFI = true, noRS.  Returns the
+    reference's 7-tuple (rt_run.jl:226):
+        (R_SFI, T_SFI, ieR_SFI, ieT_SFI, hdr, bhr_uw[1,:], bhr_dw[1,:])
+    R/T/hdr are [nVza, nStokes, nSpec]; the inelastic terms are zero for noRS."""
     sc = prepare_scene(model)
     with make_handle(model) as h:
-        return run_scene(h, sc)
+        R, T = run_scene(h, sc)
+        hdr, up, dw = h.get_hdr()
+    return R, T, np.zeros_like(R), np.zeros_like(T), hdr, up[0], dw[0]
 
 
 def rt_run_operators(model: vSmartMOM_Model):

@@ -126,6 +126,8 @@ struct SurfArgs {
   double albedo;
   const double *tau_tot;  // [S]
   double *comp[6];        // moment-0 slices
+  double *hdrJ;           // [N,S]   hdr_J0- of interaction_hdrf! (m = 0)
+  double *bhr_uw, *bhr_dw;  // [nStokes,S]
   double *scratch;
   int *info;
 };
@@ -157,13 +159,34 @@ __global__ void __launch_bounds__(kThreads) k_surface(SurfArgs a) {
     __syncthreads();
     CompPtrs g = comp_ptrs(a.comp, N, pt);
     interaction_core<LDSM, -1>(c, a.iface, g, ElZero{}, ElEye{N});
+    // interaction_hdrf! (CoreKernel/interaction_hdrf.jl:9-45): hdr_J0- = r-+_surf J0+ + j0-_surf with the
+    // composite J0+ AFTER the surface interaction (still in c.Jp), then the m = 0 flux sums of the BHR
+    wg_matvec(c, ElP{c.r, ld}, c.Jp, c.v1);
+    for (int i = threadIdx.x; i < N; i += kThreads) {
+      const double hj = c.v1[i] + c.jm[i];
+      c.v1[i] = hj;
+      a.hdrJ[(size_t)N * pt + i] = hj;
+    }
+    __syncthreads();
+    if (threadIdx.x < n) {
+      const int k = threadIdx.x;
+      double up = 0.0, dw = 0.0;
+      for (int j = k; j < N; j += n) {
+        up += c.v1[j] * c.wt[j] * c.mu[j];
+        dw += c.Jp[j] * c.wt[j] * c.mu[j];
+      }
+      a.bhr_uw[k + (size_t)n * pt] = up;
+      a.bhr_dw[k + (size_t)n * pt] = dw + c.jp[i_start] * c.mu[i_start];
+    }
+    __syncthreads();
   }
   if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
 }
 
 // postprocessing_vza! (postprocessing_vza.jl:9-60, SFI branch), all moments in m order.
 __global__ void k_postprocess(int N, int nS, int S, int M, int nVza, const int *node, const double *cos_mphi,
-                              const double *sin_mphi, const double *J0p, const double *J0m, double *R, double *T) {
+                              const double *sin_mphi, const double *J0p, const double *J0m, const double *hdrJ,
+                              double *R, double *T, double *hdr) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)nVza * nS * S;
   if (idx >= total) return;
@@ -181,6 +204,8 @@ __global__ void k_postprocess(int N, int nS, int S, int M, int nVza, const int *
   }
   R[idx] = r;
   T[idx] = t;
+  // postprocessing_vza_hdrf! (postprocessing_vza.jl:63-93): only m = 0 contributes for a Lambertian surface
+  hdr[idx] = 0.5 * ((k < 2) ? cos_mphi[v] : sin_mphi[v]) * hdrJ[row + (size_t)N * s];
 }
 
 // ---------------------------------------------------------------- operator-level kernels
@@ -370,7 +395,8 @@ struct mom_handle {
   // scene
   int Nz = 0, K = 0, nVza = 0, scene_M = 0;
   double *d_tau = nullptr, *d_varpi = nullptr, *d_zw = nullptr, *d_Zpp = nullptr, *d_Zmp = nullptr,
-         *d_tau_sum = nullptr, *d_cos = nullptr, *d_sin = nullptr, *d_R = nullptr, *d_T = nullptr;
+         *d_tau_sum = nullptr, *d_cos = nullptr, *d_sin = nullptr, *d_R = nullptr, *d_T = nullptr, *d_hdr = nullptr,
+         *d_hdrJ = nullptr, *d_bhr_uw = nullptr, *d_bhr_dw = nullptr;
   int *d_node = nullptr;
   std::vector<int> nd, iface;
   double albedo = 0.0;
@@ -465,7 +491,7 @@ extern "C" int mom_destroy(mom_t *h) {
   for (int k = 0; k < 4; ++k) fr(h->d_vec[k]);
   fr(h->d_Zop[0]); fr(h->d_Zop[1]);
   fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
-  fr(h->d_R); fr(h->d_T); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
+  fr(h->d_R); fr(h->d_T); fr(h->d_hdr); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
   for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -762,9 +788,15 @@ extern "C" int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, 
   if ((rc = upload_new(h, &h->d_node, node_1based, (size_t)nVza))) return rc;
   if ((rc = upload_new(h, &h->d_cos, cos_mphi, (size_t)nVza * M))) return rc;
   if ((rc = upload_new(h, &h->d_sin, sin_mphi, (size_t)nVza * M))) return rc;
-  if (h->d_R) { (void)hipFree(h->d_R); (void)hipFree(h->d_T); h->d_R = h->d_T = nullptr; }
+  if (h->d_R) { (void)hipFree(h->d_R); (void)hipFree(h->d_T); (void)hipFree(h->d_hdr); h->d_R = h->d_T = h->d_hdr = nullptr; }
   HIPCHK(h, dmalloc(&h->d_R, (size_t)nVza * h->nS * S));
   HIPCHK(h, dmalloc(&h->d_T, (size_t)nVza * h->nS * S));
+  HIPCHK(h, dmalloc(&h->d_hdr, (size_t)nVza * h->nS * S));
+  if (!h->d_hdrJ) {
+    HIPCHK(h, dmalloc(&h->d_hdrJ, (size_t)h->N * S));
+    HIPCHK(h, dmalloc(&h->d_bhr_uw, (size_t)h->nS * S));
+    HIPCHK(h, dmalloc(&h->d_bhr_dw, (size_t)h->nS * S));
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->Nz = Nz; h->K = K; h->scene_M = M; h->nVza = nVza; h->albedo = albedo;
   h->nd.assign(ndoubl, ndoubl + Nz);
@@ -804,6 +836,7 @@ extern "C" int mom_rt_run(mom_t *h) {
     a.q = h->q; a.S = h->S; a.iface = h->iface[h->Nz - 1];  // Q6: last layer's interface code (rt_run.jl:181)
     a.albedo = h->albedo; a.tau_tot = h->d_tau_sum + S * h->Nz;
     for (int k = 0; k < 6; ++k) a.comp[k] = h->comp[k];
+    a.hdrJ = h->d_hdrJ; a.bhr_uw = h->d_bhr_uw; a.bhr_dw = h->d_bhr_dw;
     a.scratch = h->d_scratch; a.info = h->d_info;
     LAUNCH(h, k_surface, grid_for(h, S), a);
   }
@@ -811,7 +844,8 @@ extern "C" int mom_rt_run(mom_t *h) {
   {
     const size_t total = (size_t)h->nVza * h->nS * S;
     hipLaunchKernelGGL(k_postprocess, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->N, h->nS, h->S,
-                       M, h->nVza, h->d_node, h->d_cos, h->d_sin, h->comp[4], h->comp[5], h->d_R, h->d_T);
+                       M, h->nVza, h->d_node, h->d_cos, h->d_sin, h->comp[4], h->comp[5], h->d_hdrJ, h->d_R, h->d_T,
+                       h->d_hdr);
     HIPCHK(h, hipGetLastError());
   }
   HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
@@ -825,6 +859,16 @@ extern "C" int mom_get_RT(mom_t *h, double *R_SFI, double *T_SFI) {
   const size_t bytes = (size_t)h->nVza * h->nS * h->S * sizeof(double);
   HIPCHK(h, hipMemcpyAsync(R_SFI, h->d_R, bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(T_SFI, h->d_T, bytes, hipMemcpyDeviceToHost, h->stream));
+  return check_info(h);
+}
+
+extern "C" int mom_get_hdr(mom_t *h, double *hdr, double *bhr_uw, double *bhr_dw) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->scene_set || !hdr || !bhr_uw || !bhr_dw) return fail(h, MOM_ESTATE, "mom_get_hdr: no scene / null output");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(hdr, h->d_hdr, (size_t)h->nVza * h->nS * h->S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(bhr_uw, h->d_bhr_uw, (size_t)h->nS * h->S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(bhr_dw, h->d_bhr_dw, (size_t)h->nS * h->S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   return check_info(h);
 }
 

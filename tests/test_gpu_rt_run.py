@@ -54,7 +54,7 @@ def test_operator_replay_equals_fused(rtamd, cref):
     """rt_run replayed op by op (elemental!/doubling!/interaction! like a Julia shim would) gives the
     fused kernels' result to rounding, and both match the oracle."""
     m = rtamd.scenes.make_scene(3, 9, 5, 12, seed=21)
-    R1, T1 = rtamd.rt_run(m)
+    R1, T1 = rtamd.rt_run(m)[:2]
     R2, T2 = rtamd.rt_run_operators(m)
     Rr, Tr = _oracle(cref, m)
     helpers.assert_stokes_close(R1, Rr, what="fused R")
@@ -87,7 +87,7 @@ def test_golden_small_iqu(rtamd):
     g = np.load(GOLD / "small_iqu.npz")
     m = rtamd.scenes.make_scene(3, 3, 3, 4, vza=(0.0,), vaz=(35.0,), seed=7, aerosol_total=0.3, aerosol_p0=500.0,
                                 aerosol_σp=300.0)
-    R, T = rtamd.rt_run(m)
+    R, T = rtamd.rt_run(m)[:2]
     helpers.assert_stokes_close(R, g["R"], what="R vs golden")
     helpers.assert_stokes_close(T, g["T"], what="T vs golden")
     # per-operator golden: doubling iterations 1 and 2 of the thickest layer
@@ -121,7 +121,7 @@ def test_natraj_on_gpu(rtamd):
     sc = rtamd.prepare_scene(m)
     assert sc.N == 136 and list(sc.ndoubl) == [18]
     np.testing.assert_allclose(sc.Zmp, g["Zmp"], rtol=0, atol=1e-13)
-    R, T = rtamd.rt_run(m)
+    R, T = rtamd.rt_run(m)[:2]
     helpers.assert_stokes_close(R, g["R"], what="Natraj R vs oracle")
     eI, eQ, eU = t.natraj_errors(R)
     assert eI < 0.002 and eQ < 0.008 and eU < 0.008
@@ -137,7 +137,7 @@ def test_6sv1_on_gpu(rtamd, case):
     for si, sza in enumerate(c["sza"]):
         m = helpers.one_layer_rayleigh(rtamd.corert, sza, np.tile(vza1, 3), np.repeat(np.array(c["az"], float), 16),
                                        c["tau"], c["rho"])
-        R, _ = rtamd.rt_run(m)
+        R = rtamd.rt_run(m)[0]
         Rm = (R[:, 0, 0] / m.quad_points.μ0).reshape(3, 16)
         assert np.max(np.abs(Rt[si] - Rm) / Rt[si]) < 0.006
 
@@ -147,7 +147,7 @@ def test_sharded_equals_unsharded_bitwise(rtamd):
     1-way result bit for bit (the multi-GPU correctness argument, exercised on one device)."""
     m = rtamd.scenes.make_scene(3, 9, 5, 30, seed=8)
     sc = rtamd.prepare_scene(m)
-    R, T = rtamd.rt_run(m)
+    R, T = rtamd.rt_run(m)[:2]
     parts = []
     for lo, hi in ((0, 11), (11, 19), (19, 30)):
         with rtamd.corert.make_handle(m, S=hi - lo) as h:
@@ -172,3 +172,26 @@ def test_full_size_c2_properties(rtamd, cref):
     Rr, Tr = _oracle(cref, m, pts=pts)
     helpers.assert_stokes_close(R[:, :, pts], Rr[:, :, pts], what="C2 sample R")
     helpers.assert_stokes_close(T[:, :, pts], Tr[:, :, pts], what="C2 sample T")
+
+
+@pytest.mark.parametrize("nS,lt,mode", [(1, 5, "lds"), (3, 9, "lds"), (4, 7, "generic")])
+def test_hdrf_bhr_extras(rtamd, cref, nS, lt, mode):
+    """The RAMI extras of rt_run's 7-tuple (rt_run.jl:226): hdr, bhr_uw[1,:], bhr_dw[1,:]
+    (interaction_hdrf.jl:9-45, postprocessing_vza.jl:63-93)."""
+    m = rtamd.scenes.make_scene(nS, lt, 4, 10, seed=31, albedo=0.35)
+    p = cref.pack_scene(helpers.oracle_scene(m))
+    Rr, Tr, Hr, upr, dwr, info = cref.rt_run_full(p)
+    assert info == 0
+    sc = rtamd.prepare_scene(m)
+    with rtamd.corert.make_handle(m) as h:
+        if mode == "generic":
+            h.set_option(rtamd._lib.MOM_OPT_FORCE_GENERIC, 1)
+        R, T = rtamd.corert.run_scene(h, sc)
+        H, up, dw = h.get_hdr()
+    helpers.assert_stokes_close(R, Rr, what="R")
+    helpers.assert_stokes_close(H, Hr, what="hdr")
+    np.testing.assert_allclose(up, upr, rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(dw, dwr, rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(up[0] / dw[0], 0.35, rtol=1e-12)  # Lambertian: BHR = albedo
+    out = rtamd.rt_run(m)
+    assert len(out) == 7 and np.array_equal(out[4], H) and np.array_equal(out[5], up[0]) and not out[2].any()
