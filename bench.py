@@ -135,7 +135,7 @@ def main():
                        "sharding": f"spectral axis, {world} x {S_loc} points, RCCL all_gather of R/T" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "k_layer<true>", "avg_launch_ms": tm["layers_ms"] / tm["layer_launches"],
+                         "kernel": "k_layer<true, 3>", "avg_launch_ms": tm["layers_ms"] / tm["layer_launches"],
                          "launches_per_step": tm["layer_launches"],
                          "algorithmic_flop_per_avg_launch": f_layers * S_loc / tm["layer_launches"]},
             "stages_ms": {k: tm[k] for k in ("layers_ms", "surface_ms", "postprocess_ms", "total_ms")},

@@ -24,7 +24,7 @@ for tag in ("fetch", "write", "mfma"):
             for cn, v in d.items():
                 summ.setdefault(k, {})[cn] = {"launches": len(v), "mean": sum(v) / len(v)}
 (out / f"{rnd}_pmc_summary.json").write_text(json.dumps(summ, indent=1))
-kl = summ.get("k_layer<true>", {})
+kl = next((v for k, v in summ.items() if k.startswith("k_layer<true")), {})
 if "FETCH_SIZE" in kl and "WRITE_SIZE" in kl:
     rd_raw, wr = kl["FETCH_SIZE"]["mean"] * 1024, kl["WRITE_SIZE"]["mean"] * 1024
     (out / "traffic.json").write_text(json.dumps({
