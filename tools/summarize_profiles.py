@@ -11,11 +11,14 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = ROOT / "profiles"; out.mkdir(exist_ok=True)
-st = glob.glob(str(ROOT / "gpurun_out" / f"{rnd}_stats" / "*" / "*kernel_stats.csv"))
-if st: shutil.copy(st[0], out / f"{rnd}_kernel_stats.csv")
+import os
+st = sorted(glob.glob(str(ROOT / "gpurun_out" / f"{rnd}_stats" / "*" / "*kernel_stats.csv")), key=os.path.getmtime)
+if st: shutil.copy(st[-1], out / f"{rnd}_kernel_stats.csv")
 summ = {}
 for tag in ("fetch", "write", "mfma"):
-    for f in glob.glob(str(ROOT / "gpurun_out" / f"{rnd}_{tag}" / "*" / "*counter_collection.csv")):
+    import os
+    files = sorted(glob.glob(str(ROOT / "gpurun_out" / f"{rnd}_{tag}" / "*" / "*counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:  # newest collection only
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"].split("(")[0].replace("void ", "")
