@@ -127,6 +127,15 @@ int mom_download(mom_t *h, int which, double *dst);
  *   albedo                      LambertianSurfaceScalar
  *   node_1based [nVza]          nearest stream per view (postprocessing_vza.jl:28)
  *   cos_mphi, sin_mphi [nVza, M] cosd(m*vaz), sind(m*vaz) (postprocessing_vza.jl:32)
+ *
+ * m = 0 reduction.  For Fourier moment 0 the generalized spherical function T_l^0 vanishes, so every
+ * phase-matrix basis from compute_Z_moments couples (I,Q) only with (I,Q) and (U,V) only with (U,V)
+ * (compute_Z_matrices.jl:36-57 with legendre_functions.jl:38-58).  With an unpolarised source
+ * (I0 = [1,0,0(,0)]) and a Lambertian surface the (U,V) block then has no source: it never reaches
+ * R_SFI/T_SFI/hdr (its azimuthal weight sin(0) is 0 as well), and the (I,Q) block evolves exactly as in
+ * the full problem (the cross products are exact zeros).  mom_scene_set verifies these conditions on the
+ * uploaded arrays (bitwise zeros) and, if they hold, runs moment 0 on operators of edge 2*Nquad; the
+ * outputs are unchanged.  MOM_OPT_M0_REDUCTION = 0 disables it.
  */
 int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
                   const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface, const double *tau_sum,
@@ -151,10 +160,13 @@ int mom_get_RT_device(mom_t *h, void *dR_SFI, void *dT_SFI);
  * kernel_launches = number of layer-kernel launches.  Synchronises. */
 int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
 
-/* Tuning / test knob: 0 = automatic (default), 1 = force the pivoted Gauss-Jordan inverse,
- * 2 = force the generic (global-memory) kernels even when the LDS-resident ones apply. */
+/* Tuning / test knobs (call before mom_scene_set):
+ *   MOM_OPT_INVERSE       0 = automatic (default), 1 = force the pivoted Gauss-Jordan inverse
+ *   MOM_OPT_FORCE_GENERIC 1 = use the generic (global-memory) kernels even when the LDS-resident ones apply
+ *   MOM_OPT_M0_REDUCTION  1 (default) = run Fourier moment 0 on the (I,Q) sub-problem when the scene allows
+ *                         it (see mom_scene_set), 0 = always the full nStokes problem */
 int mom_set_option(mom_t *h, int option, int value);
-enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1 };
+enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1, MOM_OPT_M0_REDUCTION = 2 };
 
 /* ---- Voigt line-by-line cross section --------------------------------------------------
  * compute_absorption_cross_section(model::HitranModel, grid, p, T)

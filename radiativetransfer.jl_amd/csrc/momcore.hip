@@ -41,11 +41,12 @@ using namespace mom;
 
 struct LayerArgs {
   DevStreams q;
-  int S, M, K;
+  int S, M, K;      // M: number of moments in THIS launch; m_first: Fourier index of the first of them
+  int m_first;
   int nd, iface, first;
   const double *tau, *varpi, *zw, *tau_sum;  // slices of layer z: tau[n], varpi[n], zw[k + K*n], tau_sum[n]
-  const double *Zpp, *Zmp;                   // [N,N,K,M]
-  double *comp[6];                           // R_mp, R_pm, T_pp, T_mm [N,N,S,M]; J0p, J0m [N,S,M]
+  const double *Zpp, *Zmp;                   // [N,N,K,M] starting at moment m_first
+  double *comp[6];                           // R_mp, R_pm, T_pp, T_mm [N,N,S,M]; J0p, J0m [N,S,M], from m_first
   double *scratch;                           // generic mode: per-workgroup slabs
   int *info;
 };
@@ -90,13 +91,13 @@ __global__ void __launch_bounds__(kThreads) k_layer(LayerArgs a) {
   wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
   MOM_STAMP(40);
   for (size_t pt = blockIdx.x; pt < total; pt += gridDim.x) {
-    const int n = (int)(pt % a.S), m = (int)(pt / a.S);
+    const int n = (int)(pt % a.S), mrel = (int)(pt / a.S), m = a.m_first + mrel;
     const double tau = a.tau[n], varpi = a.varpi[n];
     const double dtau = ldexp(tau, -a.nd);       // τ ./ 2^ndoubl   (rt_kernel.jl:244)
     double expk = exp(-dtau / a.q.mu0);          // init_layer      (rt_kernel.jl:273)
     const size_t NN = (size_t)N * N;
-    ZMix zpp{a.Zpp + NN * a.K * m, a.zw + (size_t)a.K * n, a.K, N};
-    ZMix zmp{a.Zmp + NN * a.K * m, a.zw + (size_t)a.K * n, a.K, N};
+    ZMix zpp{a.Zpp + NN * a.K * mrel, a.zw + (size_t)a.K * n, a.K, N};
+    ZMix zmp{a.Zmp + NN * a.K * mrel, a.zw + (size_t)a.K * n, a.K, N};
 #ifdef MOM_DIAG_STAMPS
     MOM_STAMP(43);
 #endif
@@ -127,7 +128,8 @@ struct SurfArgs {
   const double *tau_tot;  // [S]
   double *comp[6];        // moment-0 slices
   double *hdrJ;           // [N,S]   hdr_J0- of interaction_hdrf! (m = 0)
-  double *bhr_uw, *bhr_dw;  // [nStokes,S]
+  double *bhr_uw, *bhr_dw;  // [nS_out,S] (nS_out = the caller's nStokes; rows >= q.nS stay zero)
+  int nS_out;
   double *scratch;
   int *info;
 };
@@ -168,44 +170,63 @@ __global__ void __launch_bounds__(kThreads) k_surface(SurfArgs a) {
       a.hdrJ[(size_t)N * pt + i] = hj;
     }
     __syncthreads();
-    if (threadIdx.x < n) {
+    if (threadIdx.x < a.nS_out) {
       const int k = threadIdx.x;
       double up = 0.0, dw = 0.0;
-      for (int j = k; j < N; j += n) {
-        up += c.v1[j] * c.wt[j] * c.mu[j];
-        dw += c.Jp[j] * c.wt[j] * c.mu[j];
-      }
-      a.bhr_uw[k + (size_t)n * pt] = up;
-      a.bhr_dw[k + (size_t)n * pt] = dw + c.jp[i_start] * c.mu[i_start];
+      if (k < n)  // components beyond the reduced problem's (I,Q) have exactly zero sums for m = 0
+        for (int j = k; j < N; j += n) {
+          up += c.v1[j] * c.wt[j] * c.mu[j];
+          dw += c.Jp[j] * c.wt[j] * c.mu[j];
+        }
+      a.bhr_uw[k + (size_t)a.nS_out * pt] = up;
+      a.bhr_dw[k + (size_t)a.nS_out * pt] = dw + c.jp[i_start] * c.mu[i_start];
     }
     __syncthreads();
   }
   if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
 }
 
-// postprocessing_vza! (postprocessing_vza.jl:9-60, SFI branch), all moments in m order.
-__global__ void k_postprocess(int N, int nS, int S, int M, int nVza, const int *node, const double *cos_mphi,
-                              const double *sin_mphi, const double *J0p, const double *J0m, const double *hdrJ,
-                              double *R, double *T, double *hdr) {
+// postprocessing_vza! (postprocessing_vza.jl:9-60, SFI branch) and postprocessing_vza_hdrf! (:63-93), all
+// moments in m order.  With the m = 0 reduction (see mom_scene_set) the m = 0 sources live in their own
+// arrays with N0 = nS0 * Nquad rows; Stokes components >= nS0 get no m = 0 contribution (it is exactly 0).
+struct PostArgs {
+  int N, nS, S, M, nVza, red0, N0, nS0;
+  const int *node;
+  const double *cos_mphi, *sin_mphi;
+  const double *J0p, *J0m;    // [N,S,M] (moment 0 slice unused when red0)
+  const double *J0p0, *J0m0;  // [N0,S] when red0
+  const double *hdrJ;         // [N,S] or [N0,S] when red0
+  double *R, *T, *hdr;
+};
+__global__ void k_postprocess(PostArgs a) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)nVza * nS * S;
+  const size_t total = (size_t)a.nVza * a.nS * a.S;
   if (idx >= total) return;
-  const int v = (int)(idx % nVza);
-  const int k = (int)((idx / nVza) % nS);
-  const size_t s = idx / ((size_t)nVza * nS);
-  const int row = (node[v] - 1) * nS + k;
-  double r = 0.0, t = 0.0;
-  for (int m = 0; m < M; ++m) {
+  const int v = (int)(idx % a.nVza);
+  const int k = (int)((idx / a.nVza) % a.nS);
+  const size_t s = idx / ((size_t)a.nVza * a.nS);
+  const int row = (a.node[v] - 1) * a.nS + k;
+  double r = 0.0, t = 0.0, h = 0.0;
+  for (int m = 0; m < a.M; ++m) {
     const double weight = (m == 0) ? 0.5 : 1.0;
-    const double cs = weight * ((k < 2) ? cos_mphi[v + (size_t)nVza * m] : sin_mphi[v + (size_t)nVza * m]);
-    const size_t o = row + (size_t)N * (s + (size_t)S * m);
-    r += cs * J0m[o];
-    t += cs * J0p[o];
+    const double cs = weight * ((k < 2) ? a.cos_mphi[v + (size_t)a.nVza * m] : a.sin_mphi[v + (size_t)a.nVza * m]);
+    if (m == 0 && a.red0) {
+      if (k < a.nS0) {
+        const size_t o = (size_t)(a.node[v] - 1) * a.nS0 + k + (size_t)a.N0 * s;
+        r += cs * a.J0m0[o];
+        t += cs * a.J0p0[o];
+        h = cs * a.hdrJ[o];
+      }
+    } else {
+      const size_t o = row + (size_t)a.N * (s + (size_t)a.S * m);
+      r += cs * a.J0m[o];
+      t += cs * a.J0p[o];
+      if (m == 0) h = cs * a.hdrJ[row + (size_t)a.N * s];
+    }
   }
-  R[idx] = r;
-  T[idx] = t;
-  // postprocessing_vza_hdrf! (postprocessing_vza.jl:63-93): only m = 0 contributes for a Lambertian surface
-  hdr[idx] = 0.5 * ((k < 2) ? cos_mphi[v] : sin_mphi[v]) * hdrJ[row + (size_t)N * s];
+  a.R[idx] = r;
+  a.T[idx] = t;
+  a.hdr[idx] = h;  // only m = 0 contributes for a Lambertian surface (r-+ = 0, j0- = 0 for m > 0)
 }
 
 // ---------------------------------------------------------------- operator-level kernels
@@ -388,6 +409,8 @@ struct mom_handle {
   double *d_mu = nullptr, *d_wt = nullptr, *d_sg = nullptr;
   DevStreams q{};
   bool streams_set = false;
+  std::vector<double> h_mu, h_wt;
+  int strict = 1;
   double *added[6] = {}, *surf[6] = {}, *comp[6] = {};
   double *d_vec[4] = {};  // S-length temporaries (tau_sum, dtau, varpi, expk)
   double *d_Zop[2] = {};
@@ -401,6 +424,14 @@ struct mom_handle {
   std::vector<int> nd, iface;
   double albedo = 0.0;
   bool scene_set = false;
+  // m = 0 reduction (see mom_scene_set)
+  int opt_m0 = 1;
+  bool red0 = false;
+  int N0 = 0, nS0 = 0;
+  DevStreams q0{};
+  double *d_mu0 = nullptr, *d_wt0 = nullptr, *d_sg0 = nullptr, *d_Zpp0 = nullptr, *d_Zmp0 = nullptr, *d_hdrJ0 = nullptr,
+         *d_scratch0 = nullptr;
+  double *comp0[6] = {};
   double *d_scratch = nullptr;
   int G = 0;  // workgroups in generic mode
   int *d_info = nullptr;
@@ -491,6 +522,8 @@ extern "C" int mom_destroy(mom_t *h) {
   for (int k = 0; k < 4; ++k) fr(h->d_vec[k]);
   fr(h->d_Zop[0]); fr(h->d_Zop[1]);
   fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
+  fr(h->d_mu0); fr(h->d_wt0); fr(h->d_sg0); fr(h->d_Zpp0); fr(h->d_Zmp0); fr(h->d_hdrJ0); fr(h->d_scratch0);
+  for (int k = 0; k < 6; ++k) fr(h->comp0[k]);
   fr(h->d_R); fr(h->d_T); fr(h->d_hdr); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
   for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -508,6 +541,7 @@ extern "C" int mom_sync(mom_t *h) {
 extern "C" int mom_set_option(mom_t *h, int option, int value) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   if (option == MOM_OPT_INVERSE) { h->opt_inverse = value; h->q.inv_mode = value; }
+  else if (option == MOM_OPT_M0_REDUCTION) h->opt_m0 = value;
   else if (option == MOM_OPT_FORCE_GENERIC) {
     h->opt_force_generic = value;
     h->lds_mode = (h->N <= 64) && !value;
@@ -521,6 +555,9 @@ extern "C" int mom_set_streams(mom_t *h, const double *qp_muN, const double *wt_
   if (N != h->N || !qp_muN || !wt_muN || !I0 || !D || imu0_1based < 1 || imu0_1based * h->nS > N)
     return fail(h, MOM_EINVAL, "mom_set_streams: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
+  h->h_mu.assign(qp_muN, qp_muN + N);
+  h->h_wt.assign(wt_muN, wt_muN + N);
+  h->strict = strict;
   std::vector<double> sg(N);
   for (int i = 0; i < N; ++i) {
     const int comp = strict ? ((i + 1) % h->nS) : (i % h->nS) + 1;
@@ -797,6 +834,58 @@ extern "C" int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, 
     HIPCHK(h, dmalloc(&h->d_bhr_uw, (size_t)h->nS * S));
     HIPCHK(h, dmalloc(&h->d_bhr_dw, (size_t)h->nS * S));
   }
+  // ---- m = 0 reduction (include/momcore.h): conditions checked on the data, bitwise
+  {
+    const int N = h->N, nS = h->nS, Nq = N / nS;
+    bool ok = h->opt_m0 && nS >= 3 && h->q.regular;
+    for (int k = 2; k < nS && ok; ++k) ok = (h->q.I0[k] == 0.0);
+    for (int kb = 0; kb < K && ok; ++kb)
+      for (int j = 0; j < N && ok; ++j)
+        for (int i = 0; i < N; ++i) {
+          if (((i % nS) < 2) == ((j % nS) < 2)) continue;
+          const size_t o = i + (size_t)N * (j + (size_t)N * kb);  // moment 0 block
+          if (Zpp[o] != 0.0 || Zmp[o] != 0.0) { ok = false; break; }
+        }
+    auto fr = [](double *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    fr(h->d_mu0); fr(h->d_wt0); fr(h->d_sg0); fr(h->d_Zpp0); fr(h->d_Zmp0); fr(h->d_hdrJ0); fr(h->d_scratch0);
+    for (int k = 0; k < 6; ++k) fr(h->comp0[k]);
+    h->red0 = ok;
+    if (ok) {
+      const int nS0 = 2, N0 = nS0 * Nq;
+      h->N0 = N0; h->nS0 = nS0;
+      std::vector<double> mu0v(N0), wt0v(N0), sg0v(N0, 1.0), zp((size_t)N0 * N0 * K), zm((size_t)N0 * N0 * K);
+      auto full = [&](int i0) { return (i0 / nS0) * nS + (i0 % nS0); };
+      for (int i = 0; i < N0; ++i) { mu0v[i] = h->h_mu[full(i)]; wt0v[i] = h->h_wt[full(i)]; }
+      for (int kb = 0; kb < K; ++kb)
+        for (int j = 0; j < N0; ++j)
+          for (int i = 0; i < N0; ++i) {
+            const size_t src = full(i) + (size_t)N * (full(j) + (size_t)N * kb);
+            zp[i + (size_t)N0 * (j + (size_t)N0 * kb)] = Zpp[src];
+            zm[i + (size_t)N0 * (j + (size_t)N0 * kb)] = Zmp[src];
+          }
+      if ((rc = upload_new(h, &h->d_mu0, mu0v.data(), (size_t)N0))) return rc;
+      if ((rc = upload_new(h, &h->d_wt0, wt0v.data(), (size_t)N0))) return rc;
+      if ((rc = upload_new(h, &h->d_sg0, sg0v.data(), (size_t)N0))) return rc;
+      if ((rc = upload_new(h, &h->d_Zpp0, zp.data(), zp.size()))) return rc;
+      if ((rc = upload_new(h, &h->d_Zmp0, zm.data(), zm.size()))) return rc;
+      for (int k = 0; k < 6; ++k) {
+        const size_t cnt = ((k < 4) ? (size_t)N0 * N0 : (size_t)N0) * S;
+        HIPCHK(h, dmalloc(&h->comp0[k], cnt));
+        HIPCHK(h, hipMemsetAsync(h->comp0[k], 0, cnt * sizeof(double), h->stream));
+      }
+      HIPCHK(h, dmalloc(&h->d_hdrJ0, (size_t)N0 * S));
+      const size_t scr = (size_t)h->G * kGenericBufs * mat_elems(N0);
+      HIPCHK(h, dmalloc(&h->d_scratch0, scr));
+      HIPCHK(h, hipMemsetAsync(h->d_scratch0, 0, scr * sizeof(double), h->stream));
+      HIPCHK(h, hipMemsetAsync(h->d_bhr_uw, 0, (size_t)h->nS * S * sizeof(double), h->stream));
+      HIPCHK(h, hipMemsetAsync(h->d_bhr_dw, 0, (size_t)h->nS * S * sizeof(double), h->stream));
+      DevStreams &q0 = h->q0;
+      q0 = h->q;
+      q0.mu = h->d_mu0; q0.wt = h->d_wt0; q0.sg = h->d_sg0;
+      q0.N = N0; q0.nS = nS0;
+      for (int k = nS0; k < 4; ++k) { q0.I0[k] = 0.0; q0.D[k] = 1.0; }
+    }
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->Nz = Nz; h->K = K; h->scene_M = M; h->nVza = nVza; h->albedo = albedo;
   h->nd.assign(ndoubl, ndoubl + Nz);
@@ -812,40 +901,86 @@ extern "C" int mom_rt_run(mom_t *h) {
   const size_t S = h->S;
   const int M = h->scene_M;
   h->launches = 0;
-  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  for (int z = 0; z < h->Nz; ++z) {
+  const size_t NN = (size_t)h->N * h->N;
+  // one k_layer launch over `Mcount` moments starting at `m_first` with stream set `q` (full or reduced)
+  auto launch_layer = [&](int z, const DevStreams &q, int m_first, int Mcount, const double *Zpp, const double *Zmp,
+                          double *const comp[6], double *scratch) -> int {
     LayerArgs a{};
-    a.q = h->q; a.S = h->S; a.M = M; a.K = h->K;
+    a.q = q; a.S = h->S; a.M = Mcount; a.K = h->K; a.m_first = m_first;
     a.nd = h->nd[z]; a.iface = h->iface[z]; a.first = (z == 0);
     a.tau = h->d_tau + S * z; a.varpi = h->d_varpi + S * z; a.zw = h->d_zw + (size_t)h->K * S * z;
     a.tau_sum = h->d_tau_sum + S * z;
-    a.Zpp = h->d_Zpp; a.Zmp = h->d_Zmp;
-    for (int k = 0; k < 6; ++k) a.comp[k] = h->comp[k];
-    a.scratch = h->d_scratch; a.info = h->d_info;
+    a.Zpp = Zpp; a.Zmp = Zmp;
+    for (int k = 0; k < 6; ++k) a.comp[k] = comp[k];
+    a.scratch = scratch; a.info = h->d_info;
+    const bool lds = (q.N <= 64) && !h->opt_force_generic;
+    const size_t sm = lds_bytes(q.N, lds);
+    const int grid = lds ? (int)((S >= 2048) ? S : S * Mcount) : (int)std::min<size_t>(S * Mcount, (size_t)h->G);
+#define MOM_LAUNCH_LAYER(IF)                                                                            \
+  if (lds) {                                                                                            \
+    HIPCHK(h, allow_lds(k_layer<true, IF>, sm));                                                        \
+    hipLaunchKernelGGL((k_layer<true, IF>), dim3(grid), dim3(kThreads), sm, h->stream, a);               \
+  } else {                                                                                              \
+    HIPCHK(h, allow_lds(k_layer<false, IF>, sm));                                                       \
+    hipLaunchKernelGGL((k_layer<false, IF>), dim3(grid), dim3(kThreads), sm, h->stream, a);              \
+  }
     switch (a.iface) {  // the interface code is a template argument: see interaction_core
-      case 0: LAUNCH2(h, k_layer, 0, grid_for_layers(h, S, M), a); break;
-      case 1: LAUNCH2(h, k_layer, 1, grid_for_layers(h, S, M), a); break;
-      case 2: LAUNCH2(h, k_layer, 2, grid_for_layers(h, S, M), a); break;
-      default: LAUNCH2(h, k_layer, 3, grid_for_layers(h, S, M), a); break;
+      case 0: MOM_LAUNCH_LAYER(0) break;
+      case 1: MOM_LAUNCH_LAYER(1) break;
+      case 2: MOM_LAUNCH_LAYER(2) break;
+      default: MOM_LAUNCH_LAYER(3) break;
     }
+#undef MOM_LAUNCH_LAYER
+    HIPCHK(h, hipGetLastError());
     h->launches++;
+    return MOM_OK;
+  };
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  for (int z = 0; z < h->Nz; ++z) {
+    int rc;
+    if (h->red0) {
+      if (M > 1) {  // moments 1..M-1 on the full problem
+        double *comp1[6];
+        for (int k = 0; k < 6; ++k) comp1[k] = h->comp[k] + ((k < 4) ? NN : (size_t)h->N) * S;
+        if ((rc = launch_layer(z, h->q, 1, M - 1, h->d_Zpp + NN * h->K, h->d_Zmp + NN * h->K, comp1, h->d_scratch))) return rc;
+      }
+      if ((rc = launch_layer(z, h->q0, 0, 1, h->d_Zpp0, h->d_Zmp0, h->comp0, h->d_scratch0))) return rc;
+    } else {
+      if ((rc = launch_layer(z, h->q, 0, M, h->d_Zpp, h->d_Zmp, h->comp, h->d_scratch))) return rc;
+    }
   }
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   {
     SurfArgs a{};
-    a.q = h->q; a.S = h->S; a.iface = h->iface[h->Nz - 1];  // Q6: last layer's interface code (rt_run.jl:181)
+    const DevStreams &q = h->red0 ? h->q0 : h->q;
+    a.q = q; a.S = h->S; a.iface = h->iface[h->Nz - 1];  // Q6: last layer's interface code (rt_run.jl:181)
     a.albedo = h->albedo; a.tau_tot = h->d_tau_sum + S * h->Nz;
-    for (int k = 0; k < 6; ++k) a.comp[k] = h->comp[k];
-    a.hdrJ = h->d_hdrJ; a.bhr_uw = h->d_bhr_uw; a.bhr_dw = h->d_bhr_dw;
-    a.scratch = h->d_scratch; a.info = h->d_info;
-    LAUNCH(h, k_surface, grid_for(h, S), a);
+    for (int k = 0; k < 6; ++k) a.comp[k] = h->red0 ? h->comp0[k] : h->comp[k];
+    a.hdrJ = h->red0 ? h->d_hdrJ0 : h->d_hdrJ; a.bhr_uw = h->d_bhr_uw; a.bhr_dw = h->d_bhr_dw; a.nS_out = h->nS;
+    a.scratch = h->red0 ? h->d_scratch0 : h->d_scratch; a.info = h->d_info;
+    const bool lds = (q.N <= 64) && !h->opt_force_generic;
+    const size_t sm = lds_bytes(q.N, lds);
+    const int grid = lds ? (int)S : (int)std::min<size_t>(S, (size_t)h->G);
+    if (lds) {
+      HIPCHK(h, allow_lds(k_surface<true>, sm));
+      hipLaunchKernelGGL(k_surface<true>, dim3(grid), dim3(kThreads), sm, h->stream, a);
+    } else {
+      HIPCHK(h, allow_lds(k_surface<false>, sm));
+      hipLaunchKernelGGL(k_surface<false>, dim3(grid), dim3(kThreads), sm, h->stream, a);
+    }
+    HIPCHK(h, hipGetLastError());
   }
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
   {
     const size_t total = (size_t)h->nVza * h->nS * S;
-    hipLaunchKernelGGL(k_postprocess, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->N, h->nS, h->S,
-                       M, h->nVza, h->d_node, h->d_cos, h->d_sin, h->comp[4], h->comp[5], h->d_hdrJ, h->d_R, h->d_T,
-                       h->d_hdr);
+    PostArgs pa{};
+    pa.N = h->N; pa.nS = h->nS; pa.S = h->S; pa.M = M; pa.nVza = h->nVza; pa.red0 = h->red0 ? 1 : 0;
+    pa.N0 = h->N0; pa.nS0 = h->nS0;
+    pa.node = h->d_node; pa.cos_mphi = h->d_cos; pa.sin_mphi = h->d_sin;
+    pa.J0p = h->comp[4]; pa.J0m = h->comp[5]; pa.J0p0 = h->comp0[4]; pa.J0m0 = h->comp0[5];
+    pa.hdrJ = h->red0 ? h->d_hdrJ0 : h->d_hdrJ;
+    pa.R = h->d_R; pa.T = h->d_T; pa.hdr = h->d_hdr;
+    hipLaunchKernelGGL(k_postprocess, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, pa);
     HIPCHK(h, hipGetLastError());
   }
   HIPCHK(h, hipEventRecord(h->ev[3], h->stream));

@@ -195,3 +195,41 @@ def test_hdrf_bhr_extras(rtamd, cref, nS, lt, mode):
     np.testing.assert_allclose(up[0] / dw[0], 0.35, rtol=1e-12)  # Lambertian: BHR = albedo
     out = rtamd.rt_run(m)
     assert len(out) == 7 and np.array_equal(out[4], H) and np.array_equal(out[5], up[0]) and not out[2].any()
+
+
+@pytest.mark.parametrize("nS,lt,generic", [(3, 9, False), (4, 9, False), (3, 33, False), (4, 7, True)])
+def test_m0_reduction_matches_full_problem(rtamd, cref, nS, lt, generic):
+    """Fourier moment 0 on the (I,Q) sub-problem (include/momcore.h, mom_scene_set) gives the outputs of
+    the full nStokes problem: both against the oracle (which always solves the full problem) and against
+    each other."""
+    m = rtamd.scenes.make_scene(nS, lt, 5, 12, seed=17, vaz=(10.0, 95.0, 170.0))
+    sc = rtamd.prepare_scene(m)
+    Rr, Tr, Hr, upr, dwr, _ = cref.rt_run_full(cref.pack_scene(helpers.oracle_scene(m)))
+    res = {}
+    for red in (1, 0):
+        with rtamd.corert.make_handle(m) as h:
+            h.set_option(rtamd._lib.MOM_OPT_M0_REDUCTION, red)
+            if generic:
+                h.set_option(rtamd._lib.MOM_OPT_FORCE_GENERIC, 1)
+            R, T = rtamd.corert.run_scene(h, sc)
+            res[red] = (R, T) + h.get_hdr()
+        helpers.assert_stokes_close(R, Rr, what=f"R red={red}")
+        helpers.assert_stokes_close(T, Tr, what=f"T red={red}")
+        helpers.assert_stokes_close(res[red][2], Hr, what=f"hdr red={red}")
+        np.testing.assert_allclose(res[red][4], dwr, rtol=1e-10, atol=1e-300)
+    helpers.assert_stokes_close(res[1][0], res[0][0], rtol=1e-11, what="reduced vs full R")
+    helpers.assert_stokes_close(res[1][1], res[0][1], rtol=1e-11, what="reduced vs full T")
+
+
+def test_m0_reduction_refused_for_polarised_source(rtamd, cref):
+    """A source with a U component couples the (U,V) block to the outputs for m = 0: the library must
+    detect it (I0[2] != 0) and keep the full problem."""
+    rt = rtamd.corert
+    m = rtamd.scenes.make_scene(3, 7, 3, 6, seed=5, vaz=(30.0, 60.0, 140.0))
+    m.params.polarization_type = rt.PolarizationType(3, (1.0, 1.0, -1.0), (1.0, 0.0, 0.2))
+    sc_o = helpers.oracle_scene(m)
+    sc_o.pol.I0 = np.array([1.0, 0.0, 0.2])
+    Rr, Tr, _ = cref.rt_run(cref.pack_scene(sc_o))
+    R, T = rtamd.rt_run(m)[:2]
+    helpers.assert_stokes_close(R, Rr, what="R polarised source")
+    assert np.abs(Rr[:, 2]).max() > 1e-4  # U really is fed by the source
