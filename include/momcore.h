@@ -164,9 +164,11 @@ int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
  *   MOM_OPT_INVERSE       0 = automatic (default), 1 = force the pivoted Gauss-Jordan inverse
  *   MOM_OPT_FORCE_GENERIC 1 = use the generic (global-memory) kernels even when the LDS-resident ones apply
  *   MOM_OPT_M0_REDUCTION  1 (default) = run Fourier moment 0 on the (I,Q) sub-problem when the scene allows
- *                         it (see mom_scene_set), 0 = always the full nStokes problem */
+ *                         it (see mom_scene_set), 0 = always the full nStokes problem
+ *   MOM_OPT_SMALL_WG      1 (default) = operators small enough for two LDS images per CU run in 4-wave
+ *                         workgroups, two per CU; 0 = always 8-wave workgroups */
 int mom_set_option(mom_t *h, int option, int value);
-enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1, MOM_OPT_M0_REDUCTION = 2 };
+enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1, MOM_OPT_M0_REDUCTION = 2, MOM_OPT_SMALL_WG = 3 };
 
 /* ---- Voigt line-by-line cross section --------------------------------------------------
  * compute_absorption_cross_section(model::HitranModel, grid, p, T)

@@ -17,7 +17,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-namespace mom {
+#include <type_traits>
+
+// The whole device library is compiled once per workgroup shape: MOM_WAVES wavefronts per workgroup inside
+// namespace MOM_NS (momcore.hip: 8 waves, namespace mom; momcore_w4.hip: 4 waves, namespace mom4).
+#ifndef MOM_NS
+#define MOM_NS mom
+#endif
+
+namespace MOM_NS {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -26,7 +34,11 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int kWaves = MOM_WAVES;
 constexpr int kThreads = 64 * kWaves;
-constexpr int kTJ = 16 / kWaves;  // column tiles per work item: 4 waves x 4 tiles or 8 x 2 cover N <= 64
+#ifdef MOM_TJ
+constexpr int kTJ = MOM_TJ;  // 4-wave build: 3 tiles per item (operators up to 48 x 48: one item per wave)
+#else
+constexpr int kTJ = 16 / kWaves;  // column tiles per work item: 8 waves x 2 tiles cover N <= 64
+#endif
 
 // e -> (i = e % N, j = e / N) without an integer division (valid for e*N < 2^32)
 struct FastDiv {
@@ -89,8 +101,11 @@ __device__ __forceinline__ void item_straight(int row, int lq, int col0, FAs A, 
   }
 }
 
-template <int NA, int C, class FAs, class FB>
-__device__ __forceinline__ void kchunk(int ks0, int row, int lq, int col0, const FAs &A, FB B, d4 (&acc)[NA][kTJ]) {
+// nt: number of column tiles of this item that lie inside the padded matrix (wave-uniform); tiles beyond it
+// are neither loaded nor multiplied
+template <int NA, int C, bool PRED, class FAs, class FB>
+__device__ __forceinline__ void kchunk(int ks0, int row, int lq, int col0, int nt, const FAs &A, FB B,
+                                       d4 (&acc)[NA][kTJ]) {
   double a[NA][C], b[C][kTJ];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
@@ -98,15 +113,18 @@ __device__ __forceinline__ void kchunk(int ks0, int row, int lq, int col0, const
 #pragma unroll
     for (int u = 0; u < NA; ++u) a[u][c] = A(u, row, k);
 #pragma unroll
-    for (int t = 0; t < kTJ; ++t) b[c][t] = B(k, col0 + 16 * t);
+    for (int t = 0; t < kTJ; ++t)
+      if (!PRED || t < nt) b[c][t] = B(k, col0 + 16 * t);
   }
 #pragma unroll
-  for (int c = 0; c < C; ++c)
+  for (int t = 0; t < kTJ; ++t)
+    if (!PRED || t < nt) {
 #pragma unroll
-    for (int t = 0; t < kTJ; ++t)
+      for (int c = 0; c < C; ++c)
 #pragma unroll
-      for (int u = 0; u < NA; ++u)
-        acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][c], b[c][t], acc[u][t], 0, 0, 0);
+        for (int u = 0; u < NA; ++u)
+          acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][c], b[c][t], acc[u][t], 0, 0, 0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -139,17 +157,33 @@ __device__ __forceinline__ void wg_gemm_n(int N, int NC, FAs A, FB B, FE epi) {
     if (have) {
       const int row = 16 * ti + lr, col0 = 16 * cg * kTJ + lr;
       bool done = false;
+#ifndef MOM_NO_STRAIGHT
       if constexpr (FAST) {
         if (ksteps == 15) { item_straight<NA, 15, 66>(row, lq, col0, A, B, acc); done = true; }
         else if (ksteps == 16) { item_straight<NA, 16, 66>(row, lq, col0, A, B, acc); done = true; }
       }
+#endif
       if (!done) {
-        int ks = 0;
-        for (; ks + 4 <= ksteps; ks += 4) kchunk<NA, 4>(ks, row, lq, col0, A, B, acc);
-        const int rem = ksteps - ks;
-        if (rem == 3) kchunk<NA, 3>(ks, row, lq, col0, A, B, acc);
-        else if (rem == 2) kchunk<NA, 2>(ks, row, lq, col0, A, B, acc);
-        else if (rem == 1) kchunk<NA, 1>(ks, row, lq, col0, A, B, acc);
+        const int nt = min(kTJ, Tn - cg * kTJ);
+        constexpr int CH = (NA * kTJ > 4) ? 2 : 4;  // k-steps per chunk, bounded by the register budget
+        auto run = [&](auto pred) {
+          constexpr bool PR = decltype(pred)::value;
+          int ks = 0;
+          for (; ks + 4 <= ksteps; ks += 4) {
+            if constexpr (CH == 4) {
+              kchunk<NA, 4, PR>(ks, row, lq, col0, nt, A, B, acc);
+            } else {
+              kchunk<NA, 2, PR>(ks, row, lq, col0, nt, A, B, acc);
+              kchunk<NA, 2, PR>(ks + 2, row, lq, col0, nt, A, B, acc);
+            }
+          }
+          const int rem = ksteps - ks;
+          if (rem == 3) kchunk<NA, 3, PR>(ks, row, lq, col0, nt, A, B, acc);
+          else if (rem == 2) kchunk<NA, 2, PR>(ks, row, lq, col0, nt, A, B, acc);
+          else if (rem == 1) kchunk<NA, 1, PR>(ks, row, lq, col0, nt, A, B, acc);
+        };
+        if (nt == kTJ) run(std::false_type{});  // all column tiles of the item exist: no predicates
+        else run(std::true_type{});
       }
     }
     if (SYNC) __syncthreads();
@@ -431,4 +465,4 @@ __device__ __forceinline__ void wg_copy_mat(int N, const FastDiv &fd, const doub
   }
 }
 
-}  // namespace mom
+}  // namespace MOM_NS

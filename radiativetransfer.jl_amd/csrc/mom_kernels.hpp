@@ -29,7 +29,7 @@
 #define MOM_STAMP(id)
 #endif
 
-namespace mom {
+namespace MOM_NS {
 
 // beta^2 thresholds: kNeumannThr2[p-1] = largest ||B||_F^2 for which p series terms suffice
 // (beta^p / (1 - beta) <= 2^-56), p = 1..32.
@@ -57,7 +57,7 @@ struct DevStreams {
 
 // workgroup context: where this workgroup's matrices and vectors live
 struct Ctx {
-  int N, Np, ld, ldv;
+  int N, Np, nc, ld, ldv;  // nc: stored columns per buffer (cols_for)
   FastDiv fd;
   double *r, *t, *P, *Q, *X;  // padded N x N buffers (X: spare, generic mode only)
   double *jp, *jm, *j1p, *j1m, *v1, *v2, *Jp, *Jm, *prow, *pcol, *rowk, *ei, *mu, *wt, *sg, *part, *thr;
@@ -67,7 +67,14 @@ struct Ctx {
 
 __host__ __device__ inline int np_for(int N) { return 16 * ((N + 15) / 16); }
 __host__ __device__ inline int ld_for(int N) { return np_for(N) + 2; }
-__host__ __device__ inline size_t mat_elems(int N) { return (size_t)ld_for(N) * np_for(N); }
+// columns actually stored per buffer: the K padding (up to the next multiple of 4) and the two riding
+// columns N, N+1; MFMA B-operand reads of the remaining columns of the last tile (< Np) run past the buffer
+// into whatever follows (finite or not, they only feed output columns that are never stored).
+__host__ __device__ inline int cols_for(int N) {
+  const int need = ((N + 3) / 4) * 4 > N + 2 ? ((N + 3) / 4) * 4 : N + 2;
+  return need < np_for(N) ? need : np_for(N);
+}
+__host__ __device__ inline size_t mat_elems(int N) { return (size_t)ld_for(N) * cols_for(N); }
 constexpr int kNumVec = 15 + 2 * kWaves;  // vectors carved from LDS (part = 2*kWaves vectors)
 constexpr int kGenericBufs = 5;
 __host__ __device__ inline size_t lds_bytes(int N, bool lds_mats) {
@@ -80,6 +87,7 @@ template <bool LDSM>
 __device__ __forceinline__ void make_ctx(Ctx &c, int N, int inv_mode, double *smem, double *gscratch) {
   c.N = N;
   c.Np = np_for(N);
+  c.nc = cols_for(N);
   c.ld = ld_for(N);
   c.ldv = c.Np;
   c.fd.init(N);
@@ -104,7 +112,7 @@ __device__ __forceinline__ void make_ctx(Ctx &c, int N, int inv_mode, double *sm
 // zero the padding (rows/cols >= N) of the LDS matrix buffers; vectors fully
 template <bool LDSM>
 __device__ __forceinline__ void zero_padding(const Ctx &c) {
-  const int N = c.N, Np = c.Np, ld = c.ld;
+  const int N = c.N, Np = c.nc, ld = c.ld;
   // the padding is only ever read as a K index when N is not a multiple of the MFMA K step (4);
   // otherwise padded rows/columns only feed output rows/columns that are never stored
   if (LDSM && (N % 4 != 0)) {
@@ -126,7 +134,7 @@ __device__ __forceinline__ void zero_padding(const Ctx &c) {
 
 // restore the zero padding of one buffer after it was used as scratch (only matters if N % 4 != 0)
 __device__ __forceinline__ void rezero_padding(const Ctx &c, double *buf) {
-  const int N = c.N, Np = c.Np, ld = c.ld;
+  const int N = c.N, Np = c.nc, ld = c.ld;
   if (N % 4 == 0) return;
   const int padr = ld - N;
   for (int e = threadIdx.x; e < padr * Np; e += kThreads) {
@@ -439,7 +447,7 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
   // "ride": the source vectors travel as columns N, N+1 of the B operand r (buffer padding), so
   // r j and Q (..) come out of the MFMA products for free.  Needs two spare columns in the last
   // column tile and no K padding (N % 4 == 0); otherwise: separate mat-vec passes.
-  const bool ride = (N % 4 == 0) && (c.Np - N >= 2);
+  const bool ride = (N % 4 == 0) && (c.nc - N >= 2);
   if (ride) {
     for (int i = threadIdx.x; i < N; i += kThreads) {
       c.r[i + N * ld] = c.jp[i];
@@ -640,7 +648,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     // ---- ScatteringInterface_11 (interaction.jl:69-117)
     // The four mat-vec products ride as column N of the B operands when the buffers have a spare
     // column in the last tile and no K padding (see doubling_run).
-    const bool ride = (N % 4 == 0) && (c.Np - N >= 1);
+    const bool ride = (N % 4 == 0) && (c.nc - N >= 1);
     MOM_STAMP(10);
     wg_copy_mat(N, c.fd, g.R_pm, N, c.P, ld);  // P = R+-
     if (ride)
@@ -789,4 +797,4 @@ __device__ __forceinline__ void store_added_as_composite(const Ctx &c, const Com
   }
 }
 
-}  // namespace mom
+}  // namespace MOM_NS

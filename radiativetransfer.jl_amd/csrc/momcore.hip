@@ -31,160 +31,13 @@ __device__ __forceinline__ unsigned long long mom_diag_now() {
     __builtin_amdgcn_sched_barrier(0);                                   \
   } while (0)
 #endif
-#include "mom_kernels.hpp"
+#include "mom_entry.hpp"
 
 using namespace mom;
 
 // =========================================================================================
 // kernels
 // =========================================================================================
-
-struct LayerArgs {
-  DevStreams q;
-  int S, M, K;      // M: number of moments in THIS launch; m_first: Fourier index of the first of them
-  int m_first;
-  int nd, iface, first;
-  const double *tau, *varpi, *zw, *tau_sum;  // slices of layer z: tau[n], varpi[n], zw[k + K*n], tau_sum[n]
-  const double *Zpp, *Zmp;                   // [N,N,K,M] starting at moment m_first
-  double *comp[6];                           // R_mp, R_pm, T_pp, T_mm [N,N,S,M]; J0p, J0m [N,S,M], from m_first
-  double *scratch;                           // generic mode: per-workgroup slabs
-  int *info;
-};
-
-struct ZMix {
-  const double *base;  // Z[:,:,0,m]
-  const double *w;     // K weights of this point
-  int K, N;
-  __device__ __forceinline__ double operator()(int i, int j) const {
-    double acc = 0.0;
-    const size_t NN = (size_t)N * N;
-    for (int k = 0; k < K; ++k) acc += w[k] * base[i + (size_t)j * N + NN * k];
-    return acc;
-  }
-};
-
-__device__ __forceinline__ CompPtrs comp_ptrs(double *const comp[6], int N, size_t pt) {
-  const size_t NN = (size_t)N * N;
-  CompPtrs g;
-  g.R_mp = comp[0] + NN * pt;
-  g.R_pm = comp[1] + NN * pt;
-  g.T_pp = comp[2] + NN * pt;
-  g.T_mm = comp[3] + NN * pt;
-  g.J0p = comp[4] + (size_t)N * pt;
-  g.J0m = comp[5] + (size_t)N * pt;
-  return g;
-}
-
-extern __shared__ double mom_smem[];
-
-// One launch per atmospheric layer: every (spectral point, Fourier moment) pair runs
-// elemental -> nd doublings -> interaction with its composite state (rt_kernel!,
-// rt_kernel.jl:173-235) inside one workgroup; the added layer never touches HBM.
-template <bool LDSM, int IFACE>
-__global__ void __launch_bounds__(kThreads) k_layer(LayerArgs a) {
-  const int N = a.q.N;
-  const size_t total = (size_t)a.S * a.M;
-  Ctx c;
-#ifdef MOM_DIAG_STAMPS
-  if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1)) mom_diag_last = mom_diag_now();
-#endif
-  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
-  MOM_STAMP(40);
-  for (size_t pt = blockIdx.x; pt < total; pt += gridDim.x) {
-    const int n = (int)(pt % a.S), mrel = (int)(pt / a.S), m = a.m_first + mrel;
-    const double tau = a.tau[n], varpi = a.varpi[n];
-    const double dtau = ldexp(tau, -a.nd);       // τ ./ 2^ndoubl   (rt_kernel.jl:244)
-    double expk = exp(-dtau / a.q.mu0);          // init_layer      (rt_kernel.jl:273)
-    const size_t NN = (size_t)N * N;
-    ZMix zpp{a.Zpp + NN * a.K * mrel, a.zw + (size_t)a.K * n, a.K, N};
-    ZMix zmp{a.Zmp + NN * a.K * mrel, a.zw + (size_t)a.K * n, a.K, N};
-#ifdef MOM_DIAG_STAMPS
-    MOM_STAMP(43);
-#endif
-    elemental_build(c, a.q, m, a.nd, a.tau_sum[n], dtau, varpi, zpp, zmp);
-    MOM_STAMP(41);
-#ifdef MOM_DIAG_TWICE
-    elemental_build(c, a.q, m, a.nd, a.tau_sum[n], dtau, varpi, zpp, zmp);
-    MOM_STAMP(44);
-#endif
-    expk = doubling_run<LDSM>(c, a.nd, expk);
-    MOM_STAMP(30);
-    CompPtrs g = comp_ptrs(a.comp, N, pt);
-    if (a.first) {
-      store_added_as_composite(c, g);
-      __syncthreads();
-      MOM_STAMP(42);
-    } else {
-      interaction_core<LDSM, IFACE>(c, a.iface, g, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
-    }
-  }
-  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
-}
-
-struct SurfArgs {
-  DevStreams q;
-  int S, iface;
-  double albedo;
-  const double *tau_tot;  // [S]
-  double *comp[6];        // moment-0 slices
-  double *hdrJ;           // [N,S]   hdr_J0- of interaction_hdrf! (m = 0)
-  double *bhr_uw, *bhr_dw;  // [nS_out,S] (nS_out = the caller's nStokes; rows >= q.nS stay zero)
-  int nS_out;
-  double *scratch;
-  int *info;
-};
-
-// Lambertian surface as an added layer (m = 0) + the closing interaction (rt_run.jl:169-185).
-// For m > 0 the surface layer is r = 0, t = I, j = 0 and the interaction is the identity on
-// every quantity post-processing reads, so no launch is made for those moments.
-template <bool LDSM>
-__global__ void __launch_bounds__(kThreads) k_surface(SurfArgs a) {
-  const int N = a.q.N, n = a.q.nS;
-  Ctx c;
-  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
-  const int ld = c.ld;
-  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
-    const double rho = 2 * a.albedo;                       // lambertian_surface.jl:37
-    const double att = exp(-a.tau_tot[pt] / a.q.mu0);
-    const int i_start = n * (a.q.imu0 - 1), i_end = n * a.q.imu0;
-    for (int e = threadIdx.x; e < N * N; e += kThreads) {
-      int i, j;
-      c.fd.split(e, i, j);
-      c.r[i + j * ld] = ((i % n == 0) && (j % n == 0)) ? rho * (c.mu[j] * c.wt[j]) : 0.0;  // :41-43,:58
-      c.t[i + j * ld] = (i == j) ? 1.0 : 0.0;
-    }
-    for (int i = threadIdx.x; i < N; i += kThreads) {
-      const bool in_sun = (i >= i_start) && (i < i_end);
-      c.jp[i] = (in_sun ? a.q.I0[i - i_start] : 0.0) * att;                 // :55
-      c.jm[i] = (i % n == 0) ? (a.q.mu0 * (rho * a.q.I0[0])) * att : 0.0;  // :56
-    }
-    __syncthreads();
-    CompPtrs g = comp_ptrs(a.comp, N, pt);
-    interaction_core<LDSM, -1>(c, a.iface, g, ElZero{}, ElEye{N});
-    // interaction_hdrf! (CoreKernel/interaction_hdrf.jl:9-45): hdr_J0- = r-+_surf J0+ + j0-_surf with the
-    // composite J0+ AFTER the surface interaction (still in c.Jp), then the m = 0 flux sums of the BHR
-    wg_matvec(c, ElP{c.r, ld}, c.Jp, c.v1);
-    for (int i = threadIdx.x; i < N; i += kThreads) {
-      const double hj = c.v1[i] + c.jm[i];
-      c.v1[i] = hj;
-      a.hdrJ[(size_t)N * pt + i] = hj;
-    }
-    __syncthreads();
-    if (threadIdx.x < a.nS_out) {
-      const int k = threadIdx.x;
-      double up = 0.0, dw = 0.0;
-      if (k < n)  // components beyond the reduced problem's (I,Q) have exactly zero sums for m = 0
-        for (int j = k; j < N; j += n) {
-          up += c.v1[j] * c.wt[j] * c.mu[j];
-          dw += c.Jp[j] * c.wt[j] * c.mu[j];
-        }
-      a.bhr_uw[k + (size_t)a.nS_out * pt] = up;
-      a.bhr_dw[k + (size_t)a.nS_out * pt] = dw + c.jp[i_start] * c.mu[i_start];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
-}
 
 // postprocessing_vza! (postprocessing_vza.jl:9-60, SFI branch) and postprocessing_vza_hdrf! (:63-93), all
 // moments in m order.  With the m = 0 reduction (see mom_scene_set) the m = 0 sources live in their own
@@ -399,6 +252,13 @@ __global__ void __launch_bounds__(kThreads) k_batched_mul(BlasArgs a) {
 // host side
 // =========================================================================================
 
+// momcore_w4.hip: the same kernels built for 4-wave workgroups (2 workgroups per CU when the operators are
+// small enough for two LDS images: the m = 0 (I,Q) sub-problem of N = 60 is N0 = 40 -> 77 KB).
+size_t mom4_lds_bytes(int N, bool lds_mats);
+hipError_t mom4_launch_layer(const void *layer_args, int iface, bool lds, int grid, size_t smem, hipStream_t st);
+hipError_t mom4_launch_surface(const void *surf_args, bool lds, int grid, size_t smem, hipStream_t st);
+int mom4_generic_bufs_elems(int N);
+
 static thread_local std::string g_err;
 
 struct mom_handle {
@@ -426,6 +286,7 @@ struct mom_handle {
   bool scene_set = false;
   // m = 0 reduction (see mom_scene_set)
   int opt_m0 = 1;
+  int opt_w4 = 1;
   bool red0 = false;
   int N0 = 0, nS0 = 0;
   DevStreams q0{};
@@ -505,8 +366,9 @@ extern "C" int mom_create(mom_t **out, int device, int N, int nStokes, int S, in
   HIPCHK(h, dmalloc(&h->d_info, 1));
   HIPCHK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
   h->G = 1024;
-  HIPCHK(h, dmalloc(&h->d_scratch, (size_t)h->G * kGenericBufs * mat_elems(N)));
-  HIPCHK(h, hipMemsetAsync(h->d_scratch, 0, (size_t)h->G * kGenericBufs * mat_elems(N) * sizeof(double), h->stream));
+  // + one padded matrix of slack: B-operand reads of the last column tile run past the stored columns
+  HIPCHK(h, dmalloc(&h->d_scratch, (size_t)h->G * kGenericBufs * mat_elems(N) + (size_t)ld_for(N) * np_for(N)));
+  HIPCHK(h, hipMemsetAsync(h->d_scratch, 0, ((size_t)h->G * kGenericBufs * mat_elems(N) + (size_t)ld_for(N) * np_for(N)) * sizeof(double), h->stream));
   for (int k = 0; k < 4; ++k) HIPCHK(h, hipEventCreate(&h->ev[k]));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
@@ -542,6 +404,7 @@ extern "C" int mom_set_option(mom_t *h, int option, int value) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   if (option == MOM_OPT_INVERSE) { h->opt_inverse = value; h->q.inv_mode = value; }
   else if (option == MOM_OPT_M0_REDUCTION) h->opt_m0 = value;
+  else if (option == MOM_OPT_SMALL_WG) h->opt_w4 = value;
   else if (option == MOM_OPT_FORCE_GENERIC) {
     h->opt_force_generic = value;
     h->lds_mode = (h->N <= 64) && !value;
@@ -761,8 +624,9 @@ static int blas_common(mom_t *h, int n, int batch, const double *A, const double
   const bool lds = n <= 64 && !h->opt_force_generic;
   const int grid = lds ? batch : std::min(batch, 1024);
   if (!lds) {
-    HIPCHK(h, dmalloc(&scr, (size_t)grid * kGenericBufs * mat_elems(n)));
-    HIPCHK(h, hipMemsetAsync(scr, 0, (size_t)grid * kGenericBufs * mat_elems(n) * sizeof(double), h->stream));
+    const size_t scn = (size_t)grid * kGenericBufs * mat_elems(n) + (size_t)ld_for(n) * np_for(n);
+    HIPCHK(h, dmalloc(&scr, scn));
+    HIPCHK(h, hipMemsetAsync(scr, 0, scn * sizeof(double), h->stream));
   }
   BlasArgs a{n, batch, dA, dB, dC, scr, h->d_info};
   const size_t sm = lds_bytes(n, lds);
@@ -874,7 +738,7 @@ extern "C" int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, 
         HIPCHK(h, hipMemsetAsync(h->comp0[k], 0, cnt * sizeof(double), h->stream));
       }
       HIPCHK(h, dmalloc(&h->d_hdrJ0, (size_t)N0 * S));
-      const size_t scr = (size_t)h->G * kGenericBufs * mat_elems(N0);
+      const size_t scr = (size_t)h->G * kGenericBufs * mat_elems(N0) + (size_t)ld_for(N0) * np_for(N0);
       HIPCHK(h, dmalloc(&h->d_scratch0, scr));
       HIPCHK(h, hipMemsetAsync(h->d_scratch0, 0, scr * sizeof(double), h->stream));
       HIPCHK(h, hipMemsetAsync(h->d_bhr_uw, 0, (size_t)h->nS * S * sizeof(double), h->stream));
@@ -914,6 +778,13 @@ extern "C" int mom_rt_run(mom_t *h) {
     for (int k = 0; k < 6; ++k) a.comp[k] = comp[k];
     a.scratch = scratch; a.info = h->d_info;
     const bool lds = (q.N <= 64) && !h->opt_force_generic;
+    // small operators: 4-wave workgroups, two per CU (momcore_w4.hip), when two LDS images fit
+    if (lds && h->opt_w4 && np_for(q.N) <= 48 && 2 * mom4_lds_bytes(q.N, true) + 2048 <= 160 * 1024) {
+      const int grid4 = (int)((S >= 2048) ? S : S * Mcount);
+      HIPCHK(h, mom4_launch_layer(&a, a.iface, true, grid4, mom4_lds_bytes(q.N, true), h->stream));
+      h->launches++;
+      return MOM_OK;
+    }
     const size_t sm = lds_bytes(q.N, lds);
     const int grid = lds ? (int)((S >= 2048) ? S : S * Mcount) : (int)std::min<size_t>(S * Mcount, (size_t)h->G);
 #define MOM_LAUNCH_LAYER(IF)                                                                            \
@@ -961,7 +832,9 @@ extern "C" int mom_rt_run(mom_t *h) {
     const bool lds = (q.N <= 64) && !h->opt_force_generic;
     const size_t sm = lds_bytes(q.N, lds);
     const int grid = lds ? (int)S : (int)std::min<size_t>(S, (size_t)h->G);
-    if (lds) {
+    if (lds && h->opt_w4 && np_for(q.N) <= 48 && 2 * mom4_lds_bytes(q.N, true) + 2048 <= 160 * 1024) {
+      HIPCHK(h, mom4_launch_surface(&a, true, (int)S, mom4_lds_bytes(q.N, true), h->stream));
+    } else if (lds) {
       HIPCHK(h, allow_lds(k_surface<true>, sm));
       hipLaunchKernelGGL(k_surface<true>, dim3(grid), dim3(kThreads), sm, h->stream, a);
     } else {
