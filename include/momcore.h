@@ -157,7 +157,9 @@ int mom_get_RT_device(mom_t *h, void *dR_SFI, void *dT_SFI);
 
 /* Per-stage GPU time of the last mom_rt_run in milliseconds (hipEvent based):
  * ms[0] = layer kernels, ms[1] = surface, ms[2] = post-processing, ms[3] = total;
- * kernel_launches = number of layer-kernel launches.  Synchronises. */
+ * with n >= 8 also ms[4] = sum over the full-problem layer launches (k_layer of namespace mom, or the
+ * only layer kernel when the m = 0 reduction is off), ms[5] = sum over the reduced m = 0 launches,
+ * ms[6], ms[7] = their launch counts.  kernel_launches = number of layer-kernel launches.  Synchronises. */
 int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
 
 /* Tuning / test knobs (call before mom_scene_set):

@@ -222,10 +222,11 @@ class Handle:
         self.check(self.lib.mom_get_RT_device(self._h, C.c_void_p(dR_ptr), C.c_void_p(dT_ptr)))
 
     def timers(self):
-        ms = np.zeros(4)
+        ms = np.zeros(8)
         nl = C.c_int(0)
-        self.check(self.lib.mom_timers(self._h, dp(ms), 4, C.byref(nl)))
-        return dict(layers_ms=ms[0], surface_ms=ms[1], postprocess_ms=ms[2], total_ms=ms[3], layer_launches=nl.value)
+        self.check(self.lib.mom_timers(self._h, dp(ms), 8, C.byref(nl)))
+        return dict(layers_ms=ms[0], surface_ms=ms[1], postprocess_ms=ms[2], total_ms=ms[3], layer_launches=nl.value,
+                    full_layers_ms=ms[4], reduced_layers_ms=ms[5], full_launches=int(ms[6]), reduced_launches=int(ms[7]))
 
 
 def voigt_xsec(nu, gamma_d, y, S, ind_start, ind_stop, grid, device: int = 0):

@@ -297,7 +297,8 @@ struct mom_handle {
   int G = 0;  // workgroups in generic mode
   int *d_info = nullptr;
   hipEvent_t ev[4] = {};
-  int launches = 0;
+  std::vector<hipEvent_t> ev_full, ev_red;  // start/stop pairs around each full-problem / reduced layer launch
+  int launches = 0, launches_full = 0, launches_red = 0;
   std::string err;
 };
 
@@ -388,6 +389,8 @@ extern "C" int mom_destroy(mom_t *h) {
   for (int k = 0; k < 6; ++k) fr(h->comp0[k]);
   fr(h->d_R); fr(h->d_T); fr(h->d_hdr); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
   for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+  for (auto e : h->ev_full) (void)hipEventDestroy(e);
+  for (auto e : h->ev_red) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return MOM_OK;
@@ -764,7 +767,9 @@ extern "C" int mom_rt_run(mom_t *h) {
   HIPCHK(h, hipSetDevice(h->device));
   const size_t S = h->S;
   const int M = h->scene_M;
-  h->launches = 0;
+  h->launches = 0; h->launches_full = 0; h->launches_red = 0;
+  while (h->ev_full.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_full.push_back(e); }
+  while (h->ev_red.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_red.push_back(e); }
   const size_t NN = (size_t)h->N * h->N;
   // one k_layer launch over `Mcount` moments starting at `m_first` with stream set `q` (full or reduced)
   auto launch_layer = [&](int z, const DevStreams &q, int m_first, int Mcount, const double *Zpp, const double *Zmp,
@@ -813,11 +818,20 @@ extern "C" int mom_rt_run(mom_t *h) {
       if (M > 1) {  // moments 1..M-1 on the full problem
         double *comp1[6];
         for (int k = 0; k < 6; ++k) comp1[k] = h->comp[k] + ((k < 4) ? NN : (size_t)h->N) * S;
+        HIPCHK(h, hipEventRecord(h->ev_full[2 * z], h->stream));
         if ((rc = launch_layer(z, h->q, 1, M - 1, h->d_Zpp + NN * h->K, h->d_Zmp + NN * h->K, comp1, h->d_scratch))) return rc;
+        HIPCHK(h, hipEventRecord(h->ev_full[2 * z + 1], h->stream));
+        h->launches_full++;
       }
+      HIPCHK(h, hipEventRecord(h->ev_red[2 * z], h->stream));
       if ((rc = launch_layer(z, h->q0, 0, 1, h->d_Zpp0, h->d_Zmp0, h->comp0, h->d_scratch0))) return rc;
+      HIPCHK(h, hipEventRecord(h->ev_red[2 * z + 1], h->stream));
+      h->launches_red++;
     } else {
+      HIPCHK(h, hipEventRecord(h->ev_full[2 * z], h->stream));
       if ((rc = launch_layer(z, h->q, 0, M, h->d_Zpp, h->d_Zmp, h->comp, h->d_scratch))) return rc;
+      HIPCHK(h, hipEventRecord(h->ev_full[2 * z + 1], h->stream));
+      h->launches_full++;
     }
   }
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
@@ -912,6 +926,13 @@ extern "C" int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches) {
   HIPCHK(h, hipEventElapsedTime(&t23, h->ev[2], h->ev[3]));
   HIPCHK(h, hipEventElapsedTime(&t03, h->ev[0], h->ev[3]));
   ms[0] = t01; ms[1] = t12; ms[2] = t23; ms[3] = t03;
+  if (n >= 8) {  // per-kernel sums: full-problem layer launches, reduced (m = 0) layer launches
+    double full = 0.0, red = 0.0;
+    float t;
+    for (int z = 0; z < h->launches_full; ++z) { HIPCHK(h, hipEventElapsedTime(&t, h->ev_full[2 * z], h->ev_full[2 * z + 1])); full += t; }
+    for (int z = 0; z < h->launches_red; ++z) { HIPCHK(h, hipEventElapsedTime(&t, h->ev_red[2 * z], h->ev_red[2 * z + 1])); red += t; }
+    ms[4] = full; ms[5] = red; ms[6] = h->launches_full; ms[7] = h->launches_red;
+  }
   if (kernel_launches) *kernel_launches = h->launches;
   return MOM_OK;
 }

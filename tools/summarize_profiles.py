@@ -27,13 +27,13 @@ for tag in ("fetch", "write", "mfma"):
             for cn, v in d.items():
                 summ.setdefault(k, {})[cn] = {"launches": len(v), "mean": sum(v) / len(v)}
 (out / f"{rnd}_pmc_summary.json").write_text(json.dumps(summ, indent=1))
-kl = next((v for k, v in summ.items() if k.startswith("k_layer<true")), {})
+kl = next((v for k, v in summ.items() if k.startswith("mom::k_layer<true") or k.startswith("k_layer<true")), {})
 if "FETCH_SIZE" in kl and "WRITE_SIZE" in kl:
     rd_raw, wr = kl["FETCH_SIZE"]["mean"] * 1024, kl["WRITE_SIZE"]["mean"] * 1024
     (out / "traffic.json").write_text(json.dumps({
         "round": rnd, "k_layer_hbm_bytes_per_launch": 2 * rd_raw + wr, "fetch_bytes_raw": rd_raw,
         "fetch_bytes_corrected_x2": 2 * rd_raw, "write_bytes": wr,
-        "note": "mean over the 40 layer launches of one bench step (S=10000, M=3); FETCH_SIZE doubled per MI355X_MICROARCH.md"}, indent=1))
+        "note": "mean over the 40 launches of mom::k_layer<true, 3> in one bench step (S=10000, moments 1-2); FETCH_SIZE doubled per MI355X_MICROARCH.md"}, indent=1))
 for f in ("bench.json", "bench_under_rocprof.json"):
     p = ROOT / "gpurun_out" / f"{rnd}_{f}"
     if p.exists(): shutil.copy(p, out / f"{rnd}_{f}")
