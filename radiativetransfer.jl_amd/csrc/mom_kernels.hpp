@@ -240,6 +240,15 @@ __device__ __forceinline__ double wg_sumsq_get(const Ctx &c) {
   return b2;
 }
 
+// composite-layer pointers of one spectral point (column-major, ld = N)
+struct CompPtrs {
+  double *R_mp, *R_pm, *T_pp, *T_mm, *J0p, *J0m;
+};
+
+}  // namespace MOM_NS
+#include "mom_strip.hpp"
+namespace MOM_NS {
+
 // ---------------------------------------------------------------------------------------
 // Ob <- T (I - B)^-1 with B in Bb (destroyed) and beta2 = ||B||_F^2.  T: element functor usable
 // as MFMA A operand.  See the header comment for the series bound.  Ends with a barrier.
@@ -470,6 +479,19 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
       MOM_STAMP(1);
     }
     const double beta2 = wg_sumsq_get(c);
+    if constexpr (LDSM && kWaves == 8) {
+      // strip-chained step (mom_strip.hpp): the series, A r, (A r) t and A t in one barrier-free MFMA stream
+      if (ride && c.inv_mode == 0 && N >= 52 && N <= 60) {
+        const int p = neumann_terms(c.thr, beta2);
+        if (p <= kStripMaxP) {
+          if (N == 60) doubling_step_strip<15>(c, p, expk);
+          else if (N == 56) doubling_step_strip<14>(c, p, expk);
+          else doubling_step_strip<13>(c, p, expk);
+          expk = expk * expk;
+          continue;
+        }
+      }
+    }
     if (ride) {
       // w1 = j1- + r j0+ ; w2 = j0+ + r j1-   with j1± = j0± expk   (:51-60)
       double *r = c.r, *P = c.P;
@@ -552,11 +574,6 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
   return expk;
 }
 
-// composite-layer pointers of one spectral point (column-major, ld = N)
-struct CompPtrs {
-  double *R_mp, *R_pm, *T_pp, *T_mm, *J0p, *J0m;
-};
-
 // ---------------------------------------------------------------------------------------
 // interaction_helper!: composite (global) <- composite (+) added.  Added r-+ in c.r, t++ in
 // c.t, j0+ in c.jp, j0- in c.jm; added r+- and t-- as element functors.  Ends with barrier.
@@ -569,6 +586,15 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
   const int iface = (IFACE >= 0) ? IFACE : iface_rt;
   const int N = c.N, ld = c.ld;
   double *r = c.r, *t = c.t;
+  if constexpr (LDSM && kWaves == 8 && std::is_same<FRPM, ElSigP>::value && std::is_same<FTMM, ElSigP>::value) {
+    // ScatteringInterface_11 with r+- = D r-+ D, t-- = D t++ D of the layer held in c.r, c.t: two strip chains
+    if ((IFACE < 0 || IFACE == 3) && iface == 3 && c.inv_mode == 0 && N % 4 == 0 && N >= 52 && N <= 60 &&
+        rpm.p == c.r && tmm.p == c.t) {
+      const bool done = (N == 60) ? interaction_strip<15>(c, g)
+                        : (N == 56) ? interaction_strip<14>(c, g) : interaction_strip<13>(c, g);
+      if (done) return;
+    }
+  }
   // composite sources -> LDS
   for (int i = threadIdx.x; i < N; i += kThreads) {
     c.Jp[i] = g.J0p[i];

@@ -1,0 +1,305 @@
+// mom_strip.hpp -- strip-chained products: the barrier-free inner chains of doubling and interaction.
+// (Included from the middle of mom_kernels.hpp; 8-wave LDS-mode build, N in {52, 56, 60}.)
+//
+// The C/D layout of v_mfma_f64_16x16x4_f64 (lane l, register r: row (l>>4)+4r, column l&15) is exactly the
+// B-operand layout of the same 16x16 block for its four k-steps (k = (l>>4)+4s, column l&15).  So a wave
+// that owns a full 64-row x 16-column strip of a matrix X in accumulator registers can multiply it from
+// the LEFT, X' = M^T X, again and again without X ever leaving its registers: no LDS round trip, no
+// barrier, and column strips never interact.  Every product of the algorithm is a right-multiplication
+// chain on a running quantity (A <- t + A B, then A r, (A r) t, A t; T01 <- T-- + T01 B, T01 t--, ...), so
+// the chains run on the TRANSPOSED quantities: a strip holds X^T[:, c0..c0+15] = rows c0.. of X, and the
+// left multiplier M^T is read from the LDS buffer of M with the conflict-free pattern M[k + row*ld].
+//
+// Rows >= N of a strip (60..63 at N = 60) never enter a contraction (K = N exactly, N % 4 == 0).  They
+// carry the source vectors: column N (N+1) of a multiplier's LDS buffer is row N (N+1) of M^T, so the
+// product's row N is v^T X = (X^T... ) i.e. the mat-vec products of doubling.jl:51-60 / interaction.jl:90,110
+// come out of the same MFMA stream ("riding rows", the transposed twin of the riding columns).
+#pragma once
+
+namespace MOM_NS {
+
+constexpr int kStripLD = 66;   // ld_for(N) for 48 < N <= 64
+constexpr int kStripMaxP = 6;  // series terms up to which the Horner chain beats squaring through LDS
+
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// acc[rt] += sum_k M[k + row*LD] B[k][col], row = 16 rt + (l & 15): left-multiplication of the strip B by M^T
+template <int KS>
+__device__ __forceinline__ void strip_mul(const double *M, int lr, int lq, const d4 (&B)[4], d4 (&acc)[4]) {
+  asm volatile("" : "+v"(lr), "+v"(lq));  // keep the address arithmetic inside (see item_straight)
+  const double *base = M + lq + lr * kStripLD;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    double a[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) a[rt] = base[4 * ks + 16 * rt * kStripLD];
+    const double b = B[ks >> 2][ks & 3];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = mfma_f64(a[rt], b, acc[rt]);
+  }
+}
+
+// two strips through the same multiplier: acc1 += M^T B1, acc2 += M^T B2 (A fragments loaded once)
+template <int KS>
+__device__ __forceinline__ void strip_mul2(const double *M, int lr, int lq, const d4 (&B1)[4], d4 (&acc1)[4],
+                                           const d4 (&B2)[4], d4 (&acc2)[4]) {
+  asm volatile("" : "+v"(lr), "+v"(lq));
+  const double *base = M + lq + lr * kStripLD;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    double a[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) a[rt] = base[4 * ks + 16 * rt * kStripLD];
+    const double b1 = B1[ks >> 2][ks & 3], b2 = B2[ks >> 2][ks & 3];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      acc1[rt] = mfma_f64(a[rt], b1, acc1[rt]);
+      acc2[rt] = mfma_f64(a[rt], b2, acc2[rt]);
+    }
+  }
+}
+
+__device__ __forceinline__ void strip_zero(d4 (&W)[4]) {
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) W[rt] = (d4){0.0, 0.0, 0.0, 0.0};
+}
+__device__ __forceinline__ void strip_copy(d4 (&D)[4], const d4 (&S)[4]) {
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) D[rt] = S[rt];
+}
+
+// W[row][col] = X[col][row] for X column-major with leading dimension ld (LDS buffer: ld = kStripLD; global
+// composite block: ld = N); rows >= N read as zero.  col = c0 + lr may run past N - 1 (garbage columns, never
+// stored; an LDS buffer has ld >= 64 rows, a global block is guarded with colok).
+template <int KS>
+__device__ __forceinline__ void strip_load_lds(const double *X, int lr, int lq, int c0, d4 (&W)[4]) {
+  const double *base = X + c0 + lr + lq * kStripLD;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS) ? base[(16 * rt + 4 * r) * kStripLD] : 0.0;
+}
+template <int KS>
+__device__ __forceinline__ void strip_store_lds(double *X, int lr, int lq, int c0, bool colok, const d4 (&W)[4]) {
+  double *base = X + c0 + lr + lq * kStripLD;
+  if (colok) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * rt + r < KS) base[(16 * rt + 4 * r) * kStripLD] = W[rt][r];
+  }
+}
+template <int KS>
+__device__ __forceinline__ void strip_load_glb(const double *__restrict__ X, int lr, int lq, int c0, bool colok,
+                                               d4 (&W)[4]) {
+  constexpr int N = 4 * KS;
+  const double *base = X + c0 + lr + lq * N;
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS && colok) ? base[(16 * rt + 4 * r) * N] : 0.0;
+}
+template <int KS>
+__device__ __forceinline__ void strip_store_glb(double *__restrict__ X, int lr, int lq, int c0, bool colok,
+                                                const d4 (&W)[4]) {
+  constexpr int N = 4 * KS;
+  double *base = X + c0 + lr + lq * N;
+  if (colok) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * rt + r < KS) base[(16 * rt + 4 * r) * N] = W[rt][r];
+  }
+}
+
+// bit 4 rt + r of the mask: sg[row] < 0 for row = 16 rt + 4 r + lq (this lane's 16 strip rows)
+__device__ __forceinline__ unsigned strip_sign_mask(const double *sg, int lq, int N) {
+  unsigned m = 0;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const int row = 4 * b + lq;
+    if (row < N && sg[row] < 0.0) m |= 1u << b;
+  }
+  return m;
+}
+// W <- diag(sg) W  (row signs)
+__device__ __forceinline__ void strip_flip(d4 (&W)[4], unsigned mask) {
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double v = W[rt][r];
+      W[rt][r] = ((mask >> (4 * rt + r)) & 1u) ? -v : v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// One doubling step (doubling.jl:44-67) given P = r r (+ riding columns r j0+, r j0-) and p series terms.
+// Waves 0..3 own the four column strips; waves 4..7 only keep the barriers.  In: c.r, c.t, c.P, c.jp, c.jm;
+// out: c.r, c.t, c.jp, c.jm and the riding columns N, N+1 of c.r (= new j0+, j0-) for the next step.
+// ---------------------------------------------------------------------------------------
+template <int KS>
+__device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, double expk) {
+  constexpr int N = 4 * KS, LD = kStripLD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+  const int c0 = 16 * (wave & 3);
+  const bool colok = c0 + lr < N;
+  double *r = c.r, *t = c.t;
+  const double *P = c.P;
+  d4 Rn[4], Tn[4];
+  double aw = 0.0;
+  if (wave < 4) {
+    // riding rows of the multiplier r^T: w1 = j1- + r j0+, w2 = j0+ + r j1-  (doubling.jl:51-60); every strip wave
+    // writes the same values, so each reads back its own writes in order
+    if (lane < N) {
+      r[lane + N * LD] = c.jm[lane] * expk + P[lane + N * LD];
+      r[lane + (N + 1) * LD] = c.jp[lane] + expk * P[lane + (N + 1) * LD];
+    }
+    d4 T0[4], Y[4];
+    strip_load_lds<KS>(t, lr, lq, c0, T0);
+    strip_copy(Y, T0);
+    // Y = A^T = (t (I - r r)^-1)^T by Horner: Y <- t^T + (r r)^T Y
+#pragma nounroll
+    for (int k = 1; k < p; ++k) {
+      d4 acc[4];
+      strip_copy(acc, T0);
+      strip_mul<KS>(P, lr, lq, Y, acc);
+      strip_copy(Y, acc);
+    }
+    d4 Zt[4];
+    strip_zero(Zt);
+    strip_mul<KS>(r, lr, lq, Y, Zt);  // (A r)^T ; rows N, N+1: (A w1)^T, (A w2)^T
+    strip_load_lds<KS>(r, lr, lq, c0, Rn);
+    strip_zero(Tn);
+    strip_mul2<KS>(t, lr, lq, Zt, Rn, Y, Tn);  // r^T + t^T (A r)^T ; t^T A^T      (:64, :67)
+    aw = Zt[KS >> 2][KS & 3];  // lanes lq == 0: (A w1)[col] ; lq == 1: (A w2)[col]
+  }
+  __syncthreads();
+  if (wave < 4) {
+    strip_store_lds<KS>(r, lr, lq, c0, colok, Rn);
+    strip_store_lds<KS>(t, lr, lq, c0, colok, Tn);
+    const int col = c0 + lr;
+    if (colok && lq == 0) {  // j0- += A w1 (:57)
+      const double jm = c.jm[col] + aw;
+      c.jm[col] = jm;
+      r[col + (N + 1) * LD] = jm;
+    }
+    if (colok && lq == 1) {  // j0+ = j1+ + A w2 (:60)
+      const double jp = c.jp[col] * expk + aw;
+      c.jp[col] = jp;
+      r[col + N * LD] = jp;
+    }
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
+// ScatteringInterface_11 (interaction.jl:69-117) as two concurrent strip chains.  Waves 0..3: the T01 chain
+// (T--, R-+, J0-); waves 4..7: the T21 chain (T++, R+-, J0+).  B = r-+ R+- is formed once through LDS (exact
+// Frobenius norm for the series length); the second inverse is expressed through the first,
+//   T21 R+- = t++ R+- (I - B)^-1 =: X,   T21 = t++ + X r-+        (push-through identity),
+// so both chains iterate with the same multiplier B^T.  Added layer in c.r (r-+), c.t (t++), c.jp, c.jm with
+// r+- = D r-+ D, t-- = D t++ D.  Returns false (nothing stored yet) if the series is too long: the caller
+// then runs the general path.  Ends with a barrier.
+// ---------------------------------------------------------------------------------------
+template <int KS>
+__device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
+  constexpr int N = 4 * KS, LD = kStripLD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+  const int grp = wave >> 2, c0 = 16 * (wave & 3), col = c0 + lr;
+  const bool colok = col < N;
+  double *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
+  // P = R+-, Q = T++ ; riding rows: column N of Q = J0+, column N of r = j0-
+  wg_copy_mat(N, c.fd, g.R_pm, N, P, LD);
+  wg_copy_mat(N, c.fd, g.T_pp, N, Q, LD);
+  for (int i = threadIdx.x; i < N; i += kThreads) {
+    Q[i + N * LD] = g.J0p[i];
+    r[i + N * LD] = c.jm[i];
+  }
+  d4 T0[4];  // chain 1: T--^T strip ; chain 2: W0 = R+-^T t++^T
+  if (grp == 0) strip_load_glb<KS>(g.T_mm, lr, lq, c0, colok, T0);
+  __syncthreads();
+  if (grp == 1) {
+    d4 tT[4];
+    strip_load_lds<KS>(t, lr, lq, c0, tT);
+    strip_zero(T0);
+    strip_mul<KS>(P, lr, lq, tT, T0);
+  }
+  {
+    // B = r-+ R+- over R+- in place (tiles held in registers across the barrier), ||B||_F^2
+    double ss = 0.0;
+    wg_gemm_nc<true>(N, N, ElP{r, LD}, ElP{P, LD}, [=, &ss](int i, int j, double v) {
+      P[i + j * LD] = v;
+      ss += v * v;
+    });
+    wg_sumsq_put(c, ss);
+  }
+  __syncthreads();
+  const double beta2 = wg_sumsq_get(c);
+  const int p = neumann_terms(c.thr, beta2);
+  if (p > kStripMaxP) return false;
+  const unsigned mask = strip_sign_mask(c.sg, lq, N);
+  d4 Y[4];
+  strip_copy(Y, T0);
+#pragma nounroll
+  for (int k = 1; k < p; ++k) {  // Y <- T0 + B^T Y : T01^T (chain 1), X^T (chain 2)
+    d4 acc[4];
+    strip_copy(acc, T0);
+    strip_mul<KS>(P, lr, lq, Y, acc);
+    strip_copy(Y, acc);
+  }
+  if (grp == 0) {
+    d4 Radd[4];
+    strip_load_glb<KS>(g.R_mp, lr, lq, c0, colok, Radd);
+    const double j0m = (colok && lq == 0) ? g.J0m[col] : 0.0;
+    // T-- = T01 t--  ->  (t--)^T T01^T = D t^T D Y                                   (:96)
+    {
+      d4 Yf[4], o[4];
+      strip_copy(Yf, Y);
+      strip_flip(Yf, mask);
+      strip_zero(o);
+      strip_mul<KS>(t, lr, lq, Yf, o);
+      strip_flip(o, mask);
+      strip_store_glb<KS>(g.T_mm, lr, lq, c0, colok, o);
+    }
+    // V = (T01 r-+)^T = r-+^T Y ; row N: (T01 j0-)^T
+    d4 V[4];
+    strip_zero(V);
+    strip_mul<KS>(r, lr, lq, Y, V);
+    // R-+ = R-+ + (T01 r-+) T++  ->  R-+^T + T++^T V ; row N: (T01 r-+ J0+)^T        (:93)
+    strip_mul<KS>(Q, lr, lq, V, Radd);
+    strip_store_glb<KS>(g.R_mp, lr, lq, c0, colok, Radd);
+    // J0- = J0- + T01 (r-+ J0+ + j0-)                                                (:90)
+    if (colok && lq == 0) g.J0m[col] = j0m + (Radd[KS >> 2][KS & 3] + V[KS >> 2][KS & 3]);
+  } else {
+    // T21^T = t++^T + r-+^T X^T ; row N: (X j0-)^T = (T21 R+- j0-)^T
+    d4 T21[4];
+    strip_load_lds<KS>(t, lr, lq, c0, T21);
+    strip_mul<KS>(r, lr, lq, Y, T21);
+    // T++ = T21 T++  ->  T++^T T21^T ; row N: (T21 J0+)^T                            (:113)
+    d4 o[4];
+    strip_zero(o);
+    strip_mul<KS>(Q, lr, lq, T21, o);
+    strip_store_glb<KS>(g.T_pp, lr, lq, c0, colok, o);
+    // J0+ = j0+ + T21 (J0+ + R+- j0-)                                                (:110)
+    if (colok && lq == 0) g.J0p[col] = c.jp[col] + (o[KS >> 2][KS & 3] + T21[KS >> 2][KS & 3]);
+    // R+- = r+- + X t--  ->  r+-^T + D t^T D X^T = D (D r+-^T + t^T D X^T), D r+-^T[row][col] = sg[col] r-+[col][row]   (:116)
+    d4 acc[4];
+    strip_load_lds<KS>(r, lr, lq, c0, acc);
+    const double sc = colok ? c.sg[col] : 1.0;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = acc[rt] * sc;
+    strip_flip(Y, mask);
+    strip_mul<KS>(t, lr, lq, Y, acc);
+    strip_flip(acc, mask);
+    strip_store_glb<KS>(g.R_pm, lr, lq, c0, colok, acc);
+  }
+  __syncthreads();
+  return true;
+}
+
+}  // namespace MOM_NS
