@@ -163,7 +163,8 @@ int mom_get_RT_device(mom_t *h, void *dR_SFI, void *dT_SFI);
 int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
 
 /* Tuning / test knobs (call before mom_scene_set):
- *   MOM_OPT_INVERSE       0 = automatic (default), 1 = force the pivoted Gauss-Jordan inverse
+ *   MOM_OPT_INVERSE       0 = automatic (default), 1 = force the pivoted Gauss-Jordan inverse, 2 = automatic
+ *                         without the strip-chained kernels' register-resident chains (A/B testing)
  *   MOM_OPT_FORCE_GENERIC 1 = use the generic (global-memory) kernels even when the LDS-resident ones apply
  *   MOM_OPT_M0_REDUCTION  1 (default) = run Fourier moment 0 on the (I,Q) sub-problem when the scene allows
  *                         it (see mom_scene_set), 0 = always the full nStokes problem

@@ -47,7 +47,8 @@ extern __shared__ double mom_smem[];
 // One launch per atmospheric layer: every (spectral point, Fourier moment) pair runs
 // elemental -> nd doublings -> interaction with its composite state (rt_kernel!,
 // rt_kernel.jl:173-235) inside one workgroup; the added layer never touches HBM.
-template <bool LDSM, int IFACE>
+// KS > 0: N = 4 KS exactly and the strip-chained paths of mom_strip.hpp are compiled in (8-wave LDS build only)
+template <bool LDSM, int IFACE, int KS = 0>
 __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
   const int N = a.q.N;
   const size_t total = (size_t)a.S * a.M;
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
     elemental_build(c, a.q, m, a.nd, a.tau_sum[n], dtau, varpi, zpp, zmp);
     MOM_STAMP(44);
 #endif
-    expk = doubling_run<LDSM>(c, a.nd, expk);
+    expk = doubling_run<LDSM, KS>(c, a.nd, expk);
     MOM_STAMP(30);
     CompPtrs g = comp_ptrs(a.comp, N, pt);
     if (a.first) {
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
       __syncthreads();
       MOM_STAMP(42);
     } else {
-      interaction_core<LDSM, IFACE>(c, a.iface, g, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
+      interaction_core<LDSM, IFACE, KS>(c, a.iface, g, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
     }
   }
   if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);

@@ -352,14 +352,18 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
     c.v1[i] = c.wt[i] / wdiv;   // wct
     c.v2[i] = dtau / c.mu[i];
   }
-  for (int e = threadIdx.x; e < Nq * Nq; e += kThreads) {
-    int iq, jq;
-    fq.split(e, iq, jq);
-    const double mui = c.mu[iq * ns], muj = c.mu[jq * ns];
-    E[e] = 1 - exp(-dtau * ((1 / mui) + (1 / muj)));
-    F1[e] = muj / (mui + muj);
-    F2[e] = muj / (mui - muj);
-  }
+  // the tables pay (and fit the buffer) when several Stokes components share a stream; scalar problems with
+  // large N evaluate the same expressions per element instead
+  const bool tab = 3 * Nq * Nq <= (int)mat_elems(N);
+  if (tab)
+    for (int e = threadIdx.x; e < Nq * Nq; e += kThreads) {
+      int iq, jq;
+      fq.split(e, iq, jq);
+      const double mui = c.mu[iq * ns], muj = c.mu[jq * ns];
+      E[e] = 1 - exp(-dtau * ((1 / mui) + (1 / muj)));
+      F1[e] = muj / (mui + muj);
+      F2[e] = muj / (mui - muj);
+    }
   __syncthreads();
   const int i_start = n * (q.imu0 - 1), i_end = n * q.imu0;
   double *ZS = c.P;  // mixed Z++ / Z-+ of the sun-block columns, [N x nS] each (P is free here)
@@ -390,9 +394,11 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
         fs.split(i, dummy, iq);
         fs.split(j, dummy, jq);
         const int pq = iq + jq * Nq;
+        const double Epq = tab ? E[pq] : 1 - exp(-dtau * ((1 / mui) + (1 / muj)));
+        const double F1pq = tab ? F1[pq] : muj / (mui + muj);
         double rr, tt;
         if (wj > 1.e-8) {
-          rr = varpi * zm[u] * F1[pq] * wj * E[pq];
+          rr = varpi * zm[u] * F1pq * wj * Epq;
           if (mui == muj) {
             if (i == j) {
               tt = c.ei[i] * (1 + varpi * zp[u] * c.v2[i] * c.v1[i]);
@@ -400,7 +406,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
               tt = 0.0;
             }
           } else {
-            tt = varpi * zp[u] * F2[pq] * wj * (c.ei[i] - c.ei[j]);
+            tt = varpi * zp[u] * (tab ? F2[pq] : muj / (mui - muj)) * wj * (c.ei[i] - c.ei[j]);
           }
         } else {
           rr = 0.0;
@@ -430,7 +436,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
       jp = wct02 * varpi * zp * (dtau / mui) * c.ei[i];
     else
       jp = wct02 * varpi * zp * (mus / (mui - mus)) * (c.ei[i] - c.ei[i_start]);
-    jm = wct02 * varpi * zm * (mus / (mui + mus)) * E[iq + sq * Nq];
+    jm = wct02 * varpi * zm * (mus / (mui + mus)) * (tab ? E[iq + sq * Nq] : 1 - exp(-dtau * ((1 / mui) + (1 / mus))));
     jp *= att;
     jm *= att;
     if (nd >= 1) jm = q.D[i % n] * jm;  // elemental.jl:249-251
@@ -449,7 +455,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
 // doubling_helper!: nd doublings of (r, t, jp, jm) held in the context, then the D signs.
 // expk: this point's exp(-dtau/mu0) (returned squared nd times).  Ends with a barrier.
 // ---------------------------------------------------------------------------------------
-template <bool LDSM>
+template <bool LDSM, int KS = 0>
 __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
   const int N = c.N, ld = c.ld;
   if (nd == 0) return expk;
@@ -479,14 +485,12 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
       MOM_STAMP(1);
     }
     const double beta2 = wg_sumsq_get(c);
-    if constexpr (LDSM && kWaves == 8) {
+    if constexpr (LDSM && KS > 0) {
       // strip-chained step (mom_strip.hpp): the series, A r, (A r) t and A t in one barrier-free MFMA stream
-      if (ride && c.inv_mode == 0 && N >= 52 && N <= 60) {
+      if (ride && c.inv_mode == 0 && N == 4 * KS) {
         const int p = neumann_terms(c.thr, beta2);
         if (p <= kStripMaxP) {
-          if (N == 60) doubling_step_strip<15>(c, p, expk);
-          else if (N == 56) doubling_step_strip<14>(c, p, expk);
-          else doubling_step_strip<13>(c, p, expk);
+          doubling_step_strip<KS>(c, p, expk);
           expk = expk * expk;
           continue;
         }
@@ -581,18 +585,15 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
 // IFACE: compile-time interface code 0..3 (the code of the other three cases is not generated: the
 // per-layer kernels are launched with the layer's code as a template argument, which keeps the
 // instruction footprint of the common 11 case small), or -1 to select at run time.
-template <bool LDSM, int IFACE, class FRPM, class FTMM>
+template <bool LDSM, int IFACE, int KS = 0, class FRPM, class FTMM>
 __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const CompPtrs &g, FRPM rpm, FTMM tmm) {
   const int iface = (IFACE >= 0) ? IFACE : iface_rt;
   const int N = c.N, ld = c.ld;
   double *r = c.r, *t = c.t;
-  if constexpr (LDSM && kWaves == 8 && std::is_same<FRPM, ElSigP>::value && std::is_same<FTMM, ElSigP>::value) {
+  if constexpr (LDSM && KS > 0 && std::is_same<FRPM, ElSigP>::value && std::is_same<FTMM, ElSigP>::value) {
     // ScatteringInterface_11 with r+- = D r-+ D, t-- = D t++ D of the layer held in c.r, c.t: two strip chains
-    if ((IFACE < 0 || IFACE == 3) && iface == 3 && c.inv_mode == 0 && N % 4 == 0 && N >= 52 && N <= 60 &&
-        rpm.p == c.r && tmm.p == c.t) {
-      const bool done = (N == 60) ? interaction_strip<15>(c, g)
-                        : (N == 56) ? interaction_strip<14>(c, g) : interaction_strip<13>(c, g);
-      if (done) return;
+    if ((IFACE < 0 || IFACE == 3) && iface == 3 && c.inv_mode == 0 && N == 4 * KS && rpm.p == c.r && tmm.p == c.t) {
+      if (interaction_strip<KS>(c, g)) return;
     }
   }
   // composite sources -> LDS

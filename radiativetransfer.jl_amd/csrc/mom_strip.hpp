@@ -1,25 +1,37 @@
 // mom_strip.hpp -- strip-chained products: the barrier-free inner chains of doubling and interaction.
-// (Included from the middle of mom_kernels.hpp; 8-wave LDS-mode build, N in {52, 56, 60}.)
+// (Included from the middle of mom_kernels.hpp; LDS mode, N = 4 KS with two spare columns in the last tile.)
 //
 // The C/D layout of v_mfma_f64_16x16x4_f64 (lane l, register r: row (l>>4)+4r, column l&15) is exactly the
 // B-operand layout of the same 16x16 block for its four k-steps (k = (l>>4)+4s, column l&15).  So a wave
-// that owns a full 64-row x 16-column strip of a matrix X in accumulator registers can multiply it from
+// that owns a full Np-row x 16-column strip of a matrix X in accumulator registers can multiply it from
 // the LEFT, X' = M^T X, again and again without X ever leaving its registers: no LDS round trip, no
 // barrier, and column strips never interact.  Every product of the algorithm is a right-multiplication
 // chain on a running quantity (A <- t + A B, then A r, (A r) t, A t; T01 <- T-- + T01 B, T01 t--, ...), so
 // the chains run on the TRANSPOSED quantities: a strip holds X^T[:, c0..c0+15] = rows c0.. of X, and the
 // left multiplier M^T is read from the LDS buffer of M with the conflict-free pattern M[k + row*ld].
 //
-// Rows >= N of a strip (60..63 at N = 60) never enter a contraction (K = N exactly, N % 4 == 0).  They
-// carry the source vectors: column N (N+1) of a multiplier's LDS buffer is row N (N+1) of M^T, so the
-// product's row N is v^T X = (X^T... ) i.e. the mat-vec products of doubling.jl:51-60 / interaction.jl:90,110
-// come out of the same MFMA stream ("riding rows", the transposed twin of the riding columns).
+// Rows >= N of a strip never enter a contraction (K = N exactly, N % 4 == 0).  They carry the source
+// vectors: column N (N+1) of a multiplier's LDS buffer is row N (N+1) of M^T, so row N of the product is
+// v^T X, i.e. the mat-vec products of doubling.jl:51-60 / interaction.jl:90,110 come out of the same MFMA
+// stream ("riding rows", the transposed twin of the riding columns of doubling_run).
+//
+// Geometry per KS = N/4: NT = ceil(N/16) row tiles = column strips, LD = 16 NT + 2 (= ld_for(N)).  Strip s is
+// owned by wave s of a group of four waves; the 8-wave build has two groups (two chains run concurrently in
+// the interaction), the 4-wave build one (two workgroups per CU provide the overlap instead).
 #pragma once
 
 namespace MOM_NS {
 
-constexpr int kStripLD = 66;   // ld_for(N) for 48 < N <= 64
 constexpr int kStripMaxP = 6;  // series terms up to which the Horner chain beats squaring through LDS
+constexpr int kStripGroups = kWaves / 4;
+
+template <int KS>
+struct StripGeom {
+  static constexpr int N = 4 * KS;
+  static constexpr int NT = (N + 15) / 16;
+  static constexpr int LD = 16 * NT + 2;
+  static constexpr int RT = KS >> 2, RR = KS & 3;  // tile / register of rows N (lanes lq == 0) and N+1 (lq == 1)
+};
 
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
@@ -27,96 +39,105 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
 
 // acc[rt] += sum_k M[k + row*LD] B[k][col], row = 16 rt + (l & 15): left-multiplication of the strip B by M^T
 template <int KS>
-__device__ __forceinline__ void strip_mul(const double *M, int lr, int lq, const d4 (&B)[4], d4 (&acc)[4]) {
+__device__ __forceinline__ void strip_mul(const double *M, int lr, int lq, const d4 (&B)[StripGeom<KS>::NT],
+                                          d4 (&acc)[StripGeom<KS>::NT]) {
+  constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
   asm volatile("" : "+v"(lr), "+v"(lq));  // keep the address arithmetic inside (see item_straight)
-  const double *base = M + lq + lr * kStripLD;
+  const double *base = M + lq + lr * LD;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    double a[4];
+    double a[NT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) a[rt] = base[4 * ks + 16 * rt * kStripLD];
+    for (int rt = 0; rt < NT; ++rt) a[rt] = base[4 * ks + 16 * rt * LD];
     const double b = B[ks >> 2][ks & 3];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[rt] = mfma_f64(a[rt], b, acc[rt]);
+    for (int rt = 0; rt < NT; ++rt) acc[rt] = mfma_f64(a[rt], b, acc[rt]);
   }
 }
 
 // two strips through the same multiplier: acc1 += M^T B1, acc2 += M^T B2 (A fragments loaded once)
 template <int KS>
-__device__ __forceinline__ void strip_mul2(const double *M, int lr, int lq, const d4 (&B1)[4], d4 (&acc1)[4],
-                                           const d4 (&B2)[4], d4 (&acc2)[4]) {
+__device__ __forceinline__ void strip_mul2(const double *M, int lr, int lq, const d4 (&B1)[StripGeom<KS>::NT],
+                                           d4 (&acc1)[StripGeom<KS>::NT], const d4 (&B2)[StripGeom<KS>::NT],
+                                           d4 (&acc2)[StripGeom<KS>::NT]) {
+  constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
   asm volatile("" : "+v"(lr), "+v"(lq));
-  const double *base = M + lq + lr * kStripLD;
+  const double *base = M + lq + lr * LD;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    double a[4];
+    double a[NT];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) a[rt] = base[4 * ks + 16 * rt * kStripLD];
+    for (int rt = 0; rt < NT; ++rt) a[rt] = base[4 * ks + 16 * rt * LD];
     const double b1 = B1[ks >> 2][ks & 3], b2 = B2[ks >> 2][ks & 3];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < NT; ++rt) {
       acc1[rt] = mfma_f64(a[rt], b1, acc1[rt]);
       acc2[rt] = mfma_f64(a[rt], b2, acc2[rt]);
     }
   }
 }
 
-__device__ __forceinline__ void strip_zero(d4 (&W)[4]) {
+template <int NT>
+__device__ __forceinline__ void strip_zero(d4 (&W)[NT]) {
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) W[rt] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int rt = 0; rt < NT; ++rt) W[rt] = (d4){0.0, 0.0, 0.0, 0.0};
 }
-__device__ __forceinline__ void strip_copy(d4 (&D)[4], const d4 (&S)[4]) {
+template <int NT>
+__device__ __forceinline__ void strip_copy(d4 (&D)[NT], const d4 (&S)[NT]) {
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) D[rt] = S[rt];
+  for (int rt = 0; rt < NT; ++rt) D[rt] = S[rt];
 }
 
-// W[row][col] = X[col][row] for X column-major with leading dimension ld (LDS buffer: ld = kStripLD; global
-// composite block: ld = N); rows >= N read as zero.  col = c0 + lr may run past N - 1 (garbage columns, never
-// stored; an LDS buffer has ld >= 64 rows, a global block is guarded with colok).
+// W[row][col] = X[col][row] for X column-major (LDS buffer: leading dimension LD; global composite block:
+// N); rows >= N read as zero.  col = c0 + lr may run past N - 1 (garbage columns, never stored; an LDS
+// buffer has LD > 16 NT - 1 rows, a global block is guarded with colok).
 template <int KS>
-__device__ __forceinline__ void strip_load_lds(const double *X, int lr, int lq, int c0, d4 (&W)[4]) {
-  const double *base = X + c0 + lr + lq * kStripLD;
+__device__ __forceinline__ void strip_load_lds(const double *X, int lr, int lq, int c0, d4 (&W)[StripGeom<KS>::NT]) {
+  constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
+  const double *base = X + c0 + lr + lq * LD;
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
+  for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS) ? base[(16 * rt + 4 * r) * kStripLD] : 0.0;
+    for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS) ? base[(16 * rt + 4 * r) * LD] : 0.0;
 }
 template <int KS>
-__device__ __forceinline__ void strip_store_lds(double *X, int lr, int lq, int c0, bool colok, const d4 (&W)[4]) {
-  double *base = X + c0 + lr + lq * kStripLD;
+__device__ __forceinline__ void strip_store_lds(double *X, int lr, int lq, int c0, bool colok,
+                                                const d4 (&W)[StripGeom<KS>::NT]) {
+  constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
+  double *base = X + c0 + lr + lq * LD;
   if (colok) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (4 * rt + r < KS) base[(16 * rt + 4 * r) * kStripLD] = W[rt][r];
+        if (4 * rt + r < KS) base[(16 * rt + 4 * r) * LD] = W[rt][r];
   }
 }
 template <int KS>
 __device__ __forceinline__ void strip_load_glb(const double *__restrict__ X, int lr, int lq, int c0, bool colok,
-                                               d4 (&W)[4]) {
-  constexpr int N = 4 * KS;
+                                               d4 (&W)[StripGeom<KS>::NT]) {
+  constexpr int NT = StripGeom<KS>::NT, N = 4 * KS;
   const double *base = X + c0 + lr + lq * N;
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
+  for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS && colok) ? base[(16 * rt + 4 * r) * N] : 0.0;
 }
 template <int KS>
 __device__ __forceinline__ void strip_store_glb(double *__restrict__ X, int lr, int lq, int c0, bool colok,
-                                                const d4 (&W)[4]) {
-  constexpr int N = 4 * KS;
+                                                const d4 (&W)[StripGeom<KS>::NT]) {
+  constexpr int NT = StripGeom<KS>::NT, N = 4 * KS;
   double *base = X + c0 + lr + lq * N;
   if (colok) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (4 * rt + r < KS) base[(16 * rt + 4 * r) * N] = W[rt][r];
   }
 }
 
-// bit 4 rt + r of the mask: sg[row] < 0 for row = 16 rt + 4 r + lq (this lane's 16 strip rows)
+// bit 4 rt + r of the mask: sg[row] < 0 for row = 16 rt + 4 r + lq (this lane's strip rows)
 __device__ __forceinline__ unsigned strip_sign_mask(const double *sg, int lq, int N) {
   unsigned m = 0;
 #pragma unroll
@@ -127,9 +148,10 @@ __device__ __forceinline__ unsigned strip_sign_mask(const double *sg, int lq, in
   return m;
 }
 // W <- diag(sg) W  (row signs)
-__device__ __forceinline__ void strip_flip(d4 (&W)[4], unsigned mask) {
+template <int NT>
+__device__ __forceinline__ void strip_flip(d4 (&W)[NT], unsigned mask) {
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt)
+  for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const double v = W[rt][r];
@@ -139,47 +161,48 @@ __device__ __forceinline__ void strip_flip(d4 (&W)[4], unsigned mask) {
 
 // ---------------------------------------------------------------------------------------
 // One doubling step (doubling.jl:44-67) given P = r r (+ riding columns r j0+, r j0-) and p series terms.
-// Waves 0..3 own the four column strips; waves 4..7 only keep the barriers.  In: c.r, c.t, c.P, c.jp, c.jm;
-// out: c.r, c.t, c.jp, c.jm and the riding columns N, N+1 of c.r (= new j0+, j0-) for the next step.
+// The waves of group 0 own the column strips; the others only keep the barriers.  In: c.r, c.t, c.P, c.jp,
+// c.jm; out: c.r, c.t, c.jp, c.jm and the riding columns N, N+1 of c.r (= new j0+, j0-) for the next step.
 // ---------------------------------------------------------------------------------------
 template <int KS>
 __device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, double expk) {
-  constexpr int N = 4 * KS, LD = kStripLD;
+  using G = StripGeom<KS>;
+  constexpr int N = G::N, NT = G::NT, LD = G::LD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
   const int c0 = 16 * (wave & 3);
-  const bool colok = c0 + lr < N;
+  const bool active = (wave >> 2) == 0 && (wave & 3) < NT, colok = c0 + lr < N;
   double *r = c.r, *t = c.t;
   const double *P = c.P;
-  d4 Rn[4], Tn[4];
+  d4 Rn[NT], Tn[NT];
   double aw = 0.0;
-  if (wave < 4) {
+  if (active) {
     // riding rows of the multiplier r^T: w1 = j1- + r j0+, w2 = j0+ + r j1-  (doubling.jl:51-60); every strip wave
     // writes the same values, so each reads back its own writes in order
     if (lane < N) {
       r[lane + N * LD] = c.jm[lane] * expk + P[lane + N * LD];
       r[lane + (N + 1) * LD] = c.jp[lane] + expk * P[lane + (N + 1) * LD];
     }
-    d4 T0[4], Y[4];
+    d4 T0[NT], Y[NT];
     strip_load_lds<KS>(t, lr, lq, c0, T0);
     strip_copy(Y, T0);
     // Y = A^T = (t (I - r r)^-1)^T by Horner: Y <- t^T + (r r)^T Y
 #pragma nounroll
     for (int k = 1; k < p; ++k) {
-      d4 acc[4];
+      d4 acc[NT];
       strip_copy(acc, T0);
       strip_mul<KS>(P, lr, lq, Y, acc);
       strip_copy(Y, acc);
     }
-    d4 Zt[4];
+    d4 Zt[NT];
     strip_zero(Zt);
     strip_mul<KS>(r, lr, lq, Y, Zt);  // (A r)^T ; rows N, N+1: (A w1)^T, (A w2)^T
     strip_load_lds<KS>(r, lr, lq, c0, Rn);
     strip_zero(Tn);
     strip_mul2<KS>(t, lr, lq, Zt, Rn, Y, Tn);  // r^T + t^T (A r)^T ; t^T A^T      (:64, :67)
-    aw = Zt[KS >> 2][KS & 3];  // lanes lq == 0: (A w1)[col] ; lq == 1: (A w2)[col]
+    aw = Zt[G::RT][G::RR];  // lanes lq == 0: (A w1)[col] ; lq == 1: (A w2)[col]
   }
   __syncthreads();
-  if (wave < 4) {
+  if (active) {
     strip_store_lds<KS>(r, lr, lq, c0, colok, Rn);
     strip_store_lds<KS>(t, lr, lq, c0, colok, Tn);
     const int col = c0 + lr;
@@ -198,9 +221,10 @@ __device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, double 
 }
 
 // ---------------------------------------------------------------------------------------
-// ScatteringInterface_11 (interaction.jl:69-117) as two concurrent strip chains.  Waves 0..3: the T01 chain
-// (T--, R-+, J0-); waves 4..7: the T21 chain (T++, R+-, J0+).  B = r-+ R+- is formed once through LDS (exact
-// Frobenius norm for the series length); the second inverse is expressed through the first,
+// ScatteringInterface_11 (interaction.jl:69-117) as two strip chains: chain 1 = T01 (T--, R-+, J0-), chain 2 =
+// T21 (T++, R+-, J0+).  8-wave build: waves 0..3 run chain 1 while waves 4..7 run chain 2; 4-wave build: the
+// strip waves run one after the other.  B = r-+ R+- is formed once through LDS (exact Frobenius norm for the
+// series length); the second inverse is expressed through the first,
 //   T21 R+- = t++ R+- (I - B)^-1 =: X,   T21 = t++ + X r-+        (push-through identity),
 // so both chains iterate with the same multiplier B^T.  Added layer in c.r (r-+), c.t (t++), c.jp, c.jm with
 // r+- = D r-+ D, t-- = D t++ D.  Returns false (nothing stored yet) if the series is too long: the caller
@@ -208,10 +232,12 @@ __device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, double 
 // ---------------------------------------------------------------------------------------
 template <int KS>
 __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
-  constexpr int N = 4 * KS, LD = kStripLD;
+  using G = StripGeom<KS>;
+  constexpr int N = G::N, NT = G::NT, LD = G::LD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
   const int grp = wave >> 2, c0 = 16 * (wave & 3), col = c0 + lr;
-  const bool colok = col < N;
+  const bool strip = (wave & 3) < NT, colok = col < N;
+  const bool do1 = strip && grp == 0, do2 = strip && grp == kStripGroups - 1;
   double *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
   // P = R+-, Q = T++ ; riding rows: column N of Q = J0+, column N of r = j0-
   wg_copy_mat(N, c.fd, g.R_pm, N, P, LD);
@@ -220,14 +246,14 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
     Q[i + N * LD] = g.J0p[i];
     r[i + N * LD] = c.jm[i];
   }
-  d4 T0[4];  // chain 1: T--^T strip ; chain 2: W0 = R+-^T t++^T
-  if (grp == 0) strip_load_glb<KS>(g.T_mm, lr, lq, c0, colok, T0);
+  d4 T1[NT], W0[NT];  // chain 1: T--^T strip ; chain 2: W0 = R+-^T t++^T
+  if (do1) strip_load_glb<KS>(g.T_mm, lr, lq, c0, colok, T1);
   __syncthreads();
-  if (grp == 1) {
-    d4 tT[4];
+  if (do2) {
+    d4 tT[NT];
     strip_load_lds<KS>(t, lr, lq, c0, tT);
-    strip_zero(T0);
-    strip_mul<KS>(P, lr, lq, tT, T0);
+    strip_zero(W0);
+    strip_mul<KS>(P, lr, lq, tT, W0);
   }
   {
     // B = r-+ R+- over R+- in place (tiles held in registers across the barrier), ||B||_F^2
@@ -243,22 +269,22 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
   const int p = neumann_terms(c.thr, beta2);
   if (p > kStripMaxP) return false;
   const unsigned mask = strip_sign_mask(c.sg, lq, N);
-  d4 Y[4];
-  strip_copy(Y, T0);
+  if (do1) {
+    d4 Y[NT];
+    strip_copy(Y, T1);
 #pragma nounroll
-  for (int k = 1; k < p; ++k) {  // Y <- T0 + B^T Y : T01^T (chain 1), X^T (chain 2)
-    d4 acc[4];
-    strip_copy(acc, T0);
-    strip_mul<KS>(P, lr, lq, Y, acc);
-    strip_copy(Y, acc);
-  }
-  if (grp == 0) {
-    d4 Radd[4];
+    for (int k = 1; k < p; ++k) {  // Y <- T--^T + B^T Y : T01^T
+      d4 acc[NT];
+      strip_copy(acc, T1);
+      strip_mul<KS>(P, lr, lq, Y, acc);
+      strip_copy(Y, acc);
+    }
+    d4 Radd[NT];
     strip_load_glb<KS>(g.R_mp, lr, lq, c0, colok, Radd);
     const double j0m = (colok && lq == 0) ? g.J0m[col] : 0.0;
     // T-- = T01 t--  ->  (t--)^T T01^T = D t^T D Y                                   (:96)
     {
-      d4 Yf[4], o[4];
+      d4 Yf[NT], o[NT];
       strip_copy(Yf, Y);
       strip_flip(Yf, mask);
       strip_zero(o);
@@ -267,32 +293,42 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
       strip_store_glb<KS>(g.T_mm, lr, lq, c0, colok, o);
     }
     // V = (T01 r-+)^T = r-+^T Y ; row N: (T01 j0-)^T
-    d4 V[4];
+    d4 V[NT];
     strip_zero(V);
     strip_mul<KS>(r, lr, lq, Y, V);
     // R-+ = R-+ + (T01 r-+) T++  ->  R-+^T + T++^T V ; row N: (T01 r-+ J0+)^T        (:93)
     strip_mul<KS>(Q, lr, lq, V, Radd);
     strip_store_glb<KS>(g.R_mp, lr, lq, c0, colok, Radd);
     // J0- = J0- + T01 (r-+ J0+ + j0-)                                                (:90)
-    if (colok && lq == 0) g.J0m[col] = j0m + (Radd[KS >> 2][KS & 3] + V[KS >> 2][KS & 3]);
-  } else {
+    if (colok && lq == 0) g.J0m[col] = j0m + (Radd[G::RT][G::RR] + V[G::RT][G::RR]);
+  }
+  if (do2) {
+    d4 Y[NT];
+    strip_copy(Y, W0);
+#pragma nounroll
+    for (int k = 1; k < p; ++k) {  // Y <- W0 + B^T Y : X^T
+      d4 acc[NT];
+      strip_copy(acc, W0);
+      strip_mul<KS>(P, lr, lq, Y, acc);
+      strip_copy(Y, acc);
+    }
     // T21^T = t++^T + r-+^T X^T ; row N: (X j0-)^T = (T21 R+- j0-)^T
-    d4 T21[4];
+    d4 T21[NT];
     strip_load_lds<KS>(t, lr, lq, c0, T21);
     strip_mul<KS>(r, lr, lq, Y, T21);
     // T++ = T21 T++  ->  T++^T T21^T ; row N: (T21 J0+)^T                            (:113)
-    d4 o[4];
+    d4 o[NT];
     strip_zero(o);
     strip_mul<KS>(Q, lr, lq, T21, o);
     strip_store_glb<KS>(g.T_pp, lr, lq, c0, colok, o);
     // J0+ = j0+ + T21 (J0+ + R+- j0-)                                                (:110)
-    if (colok && lq == 0) g.J0p[col] = c.jp[col] + (o[KS >> 2][KS & 3] + T21[KS >> 2][KS & 3]);
+    if (colok && lq == 0) g.J0p[col] = c.jp[col] + (o[G::RT][G::RR] + T21[G::RT][G::RR]);
     // R+- = r+- + X t--  ->  r+-^T + D t^T D X^T = D (D r+-^T + t^T D X^T), D r+-^T[row][col] = sg[col] r-+[col][row]   (:116)
-    d4 acc[4];
+    d4 acc[NT];
     strip_load_lds<KS>(r, lr, lq, c0, acc);
     const double sc = colok ? c.sg[col] : 1.0;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[rt] = acc[rt] * sc;
+    for (int rt = 0; rt < NT; ++rt) acc[rt] = acc[rt] * sc;
     strip_flip(Y, mask);
     strip_mul<KS>(t, lr, lq, Y, acc);
     strip_flip(acc, mask);

@@ -256,6 +256,13 @@ __global__ void __launch_bounds__(kThreads) k_batched_mul(BlasArgs a) {
 // small enough for two LDS images: the m = 0 (I,Q) sub-problem of N = 60 is N0 = 40 -> 77 KB).
 size_t mom4_lds_bytes(int N, bool lds_mats);
 hipError_t mom4_launch_layer(const void *layer_args, int iface, bool lds, int grid, size_t smem, hipStream_t st);
+// momcore_strip.hip, one object per operator size N = 4 KS
+hipError_t mom_strip9_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
+hipError_t mom_strip10_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
+hipError_t mom_strip11_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
+hipError_t mom_strip13_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
+hipError_t mom_strip14_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
+hipError_t mom_strip15_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom4_launch_surface(const void *surf_args, bool lds, int grid, size_t smem, hipStream_t st);
 int mom4_generic_bufs_elems(int N);
 
@@ -295,6 +302,7 @@ struct mom_handle {
   double *comp0[6] = {};
   double *d_scratch = nullptr;
   int G = 0;  // workgroups in generic mode
+  int num_cu = 256;
   int *d_info = nullptr;
   hipEvent_t ev[4] = {};
   std::vector<hipEvent_t> ev_full, ev_red;  // start/stop pairs around each full-problem / reduced layer launch
@@ -367,6 +375,11 @@ extern "C" int mom_create(mom_t **out, int device, int N, int nStokes, int S, in
   HIPCHK(h, dmalloc(&h->d_info, 1));
   HIPCHK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
   h->G = 1024;
+  {
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, device));
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
   // + one padded matrix of slack: B-operand reads of the last column tile run past the stored columns
   HIPCHK(h, dmalloc(&h->d_scratch, (size_t)h->G * kGenericBufs * mat_elems(N) + (size_t)ld_for(N) * np_for(N)));
   HIPCHK(h, hipMemsetAsync(h->d_scratch, 0, ((size_t)h->G * kGenericBufs * mat_elems(N) + (size_t)ld_for(N) * np_for(N)) * sizeof(double), h->stream));
@@ -786,11 +799,25 @@ extern "C" int mom_rt_run(mom_t *h) {
     // small operators: 4-wave workgroups, two per CU (momcore_w4.hip), when two LDS images fit
     if (lds && h->opt_w4 && np_for(q.N) <= 48 && 2 * mom4_lds_bytes(q.N, true) + 2048 <= 160 * 1024) {
       const int grid4 = (int)((S >= 2048) ? S : S * Mcount);
+      if (q.N == 36 || q.N == 40 || q.N == 44) {  // strip-chained kernels of the 4-wave build (momcore_strip.hip)
+        HIPCHK(h, (q.N == 40 ? mom_strip10_launch_layer : q.N == 36 ? mom_strip9_launch_layer : mom_strip11_launch_layer)(
+                      &a, a.iface, grid4, mom4_lds_bytes(q.N, true), h->stream));
+        h->launches++;
+        return MOM_OK;
+      }
       HIPCHK(h, mom4_launch_layer(&a, a.iface, true, grid4, mom4_lds_bytes(q.N, true), h->stream));
       h->launches++;
       return MOM_OK;
     }
     const size_t sm = lds_bytes(q.N, lds);
+    if (lds && (q.N == 52 || q.N == 56 || q.N == 60)) {  // strip-chained kernels (momcore_strip.hip), one image per N
+      // persistent workgroups, one per CU (only one 135 KB LDS image fits a CU): the prologue is paid once
+      const int grid = (int)std::min<size_t>(S * Mcount, (size_t)h->num_cu);
+      HIPCHK(h, (q.N == 60 ? mom_strip15_launch_layer : q.N == 56 ? mom_strip14_launch_layer : mom_strip13_launch_layer)(
+                    &a, a.iface, grid, sm, h->stream));
+      h->launches++;
+      return MOM_OK;
+    }
     const int grid = lds ? (int)((S >= 2048) ? S : S * Mcount) : (int)std::min<size_t>(S * Mcount, (size_t)h->G);
 #define MOM_LAUNCH_LAYER(IF)                                                                            \
   if (lds) {                                                                                            \

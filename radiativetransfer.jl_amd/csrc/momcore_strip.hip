@@ -1,0 +1,35 @@
+// momcore_strip.hip -- k_layer with the strip-chained doubling / interaction paths (mom_strip.hpp) for ONE
+// operator size N = 4 * MOM_STRIP_KS, compiled once per size so that each kernel image carries a single
+// unrolled variant (Makefile: KS = 13, 14, 15, i.e. N = 52, 56, 60, in the 8-wave build, namespace mom;
+// KS = 9, 10, 11, i.e. N = 36, 40, 44, in the 4-wave build, namespace mom4, two workgroups per CU).
+#ifndef MOM_STRIP_KS
+#error "compile with -DMOM_STRIP_KS=<N/4>"
+#endif
+#include <hip/hip_runtime.h>
+
+#include "mom_entry.hpp"
+
+using namespace MOM_NS;
+
+#define MOM_CAT2(a, b) a##b
+#define MOM_CAT(a, b) MOM_CAT2(a, b)
+
+// host entry used by momcore.hip: mom_strip<KS>_launch_layer(args, iface, grid, smem, stream)
+hipError_t MOM_CAT(MOM_CAT(mom_strip, MOM_STRIP_KS), _launch_layer)(const void *layer_args, int iface, int grid, size_t smem,
+                                                                     hipStream_t st) {
+  const LayerArgs a = *reinterpret_cast<const LayerArgs *>(layer_args);
+  hipError_t e = hipSuccess;
+#define STRIP_LAUNCH(IF)                                                                                            \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_layer<true, IF, MOM_STRIP_KS>),                     \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) != hipSuccess)               \
+    return e;                                                                                                       \
+  hipLaunchKernelGGL((k_layer<true, IF, MOM_STRIP_KS>), dim3(grid), dim3(kThreads), smem, st, a);
+  switch (iface) {
+    case 0: STRIP_LAUNCH(0) break;
+    case 1: STRIP_LAUNCH(1) break;
+    case 2: STRIP_LAUNCH(2) break;
+    default: STRIP_LAUNCH(3) break;
+  }
+#undef STRIP_LAUNCH
+  return hipGetLastError();
+}

@@ -20,13 +20,15 @@ def _oracle(cref, model, pts=None):
     return R, T
 
 
-def _gpu(rtamd, model, generic=False, force_gj=False):
+def _gpu(rtamd, model, generic=False, force_gj=False, inverse=None):
     sc = rtamd.prepare_scene(model)
     with rtamd.corert.make_handle(model) as h:
         if generic:
             h.set_option(rtamd._lib.MOM_OPT_FORCE_GENERIC, 1)
         if force_gj:
             h.set_option(rtamd._lib.MOM_OPT_INVERSE, 1)
+        if inverse is not None:
+            h.set_option(rtamd._lib.MOM_OPT_INVERSE, inverse)
         return rtamd.corert.run_scene(h, sc)
 
 
@@ -38,6 +40,32 @@ def test_rt_run_parity(rtamd, cref, nS, lt, mode):
     Rr, Tr = _oracle(cref, m)
     helpers.assert_stokes_close(R, Rr, what=f"R {mode}")
     helpers.assert_stokes_close(T, Tr, what=f"T {mode}")
+
+
+# operator sizes with strip-chained kernels (mom_strip.hpp): N = 52, 56, 60 in the 8-wave build (IQUV with 13, 14,
+# 15 streams; scalar with 60), N = 36, 40, 44 in the 4-wave build (scalar scenes; the m = 0 (I,Q) sub-problems of
+# IQU scenes with 18, 20, 22 streams -- their full problems have N = 54 (plain LDS path), 60, 66 (generic path))
+@pytest.mark.parametrize("nS,lt", [(4, 19), (4, 21), (4, 23), (1, 113), (1, 65), (1, 73), (1, 81), (3, 29), (3, 37)])
+def test_rt_run_parity_strip_sizes(rtamd, cref, nS, lt):
+    m = rtamd.scenes.make_scene(nS, lt, 5, 10, seed=3 * nS + lt, aerosol_total=0.6)
+    R, T = _gpu(rtamd, m)
+    Rr, Tr = _oracle(cref, m)
+    helpers.assert_stokes_close(R, Rr, what="R strip")
+    helpers.assert_stokes_close(T, Tr, what="T strip")
+    R2, T2 = _gpu(rtamd, m, inverse=2)  # same kernels with the strip chains switched off
+    helpers.assert_stokes_close(R2, Rr, what="R no strip")
+    helpers.assert_stokes_close(R, R2, what="strip vs plain R")
+    helpers.assert_stokes_close(T, T2, what="strip vs plain T")
+
+
+def test_strip_chains_thick_layers_fall_back(rtamd, cref):
+    """optically thick scattering layers: the series length exceeds the strip chains' limit for part of the
+    doubling steps and interactions, which must then take the general path inside the same kernels"""
+    m = rtamd.scenes.make_scene(3, 33, 4, 8, seed=77, aerosol_total=2.0, aerosol_p0=600.0, aerosol_σp=200.0, absorption=False)
+    R, T = _gpu(rtamd, m)
+    Rr, Tr = _oracle(cref, m)
+    helpers.assert_stokes_close(R, Rr, what="R thick")
+    helpers.assert_stokes_close(T, Tr, what="T thick")
 
 
 @pytest.mark.parametrize("strict", [True, False])
