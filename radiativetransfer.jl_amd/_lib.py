@@ -7,12 +7,14 @@ raised.  The library is built in-tree (radiativetransfer.jl_amd/libmomcore.so) b
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libmomcore.so"
+# MOM_LIBRARY: another build of the same HIP library (kernel A/B experiments); never a CPU substitute
+LIB_PATH = Path(os.environ["MOM_LIBRARY"]) if os.environ.get("MOM_LIBRARY") else PKG_DIR / "libmomcore.so"
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)

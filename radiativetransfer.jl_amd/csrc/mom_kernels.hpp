@@ -471,7 +471,14 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
     __syncthreads();
   }
   for (int it = 0; it < nd; ++it) {
-    {
+    bool strip_ok = false;
+    if constexpr (LDSM && KS > 0) strip_ok = ride && c.inv_mode == 0 && N == 4 * KS;
+    // r r on strips where the general product has no straight-line schedule (4-wave build); the 8-wave build's
+    // 8 x 2-tile product is faster than 4 strip waves
+    if (strip_ok && kWaves == 4) {
+      if constexpr (LDSM && KS > 0) doubling_rr_strip<KS>(c);
+      __syncthreads();
+    } else {
       double *r = c.r, *P = c.P;
       double ss = 0.0;
       MOM_STAMP(0);
@@ -487,7 +494,7 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
     const double beta2 = wg_sumsq_get(c);
     if constexpr (LDSM && KS > 0) {
       // strip-chained step (mom_strip.hpp): the series, A r, (A r) t and A t in one barrier-free MFMA stream
-      if (ride && c.inv_mode == 0 && N == 4 * KS) {
+      if (strip_ok) {
         const int p = neumann_terms(c.thr, beta2);
         if (p <= kStripMaxP) {
           doubling_step_strip<KS>(c, p, expk);

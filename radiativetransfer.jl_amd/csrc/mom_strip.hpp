@@ -22,7 +22,10 @@
 
 namespace MOM_NS {
 
-constexpr int kStripMaxP = 6;  // series terms up to which the Horner chain beats squaring through LDS
+#ifndef MOM_STRIP_MAXP
+#define MOM_STRIP_MAXP 12
+#endif
+constexpr int kStripMaxP = MOM_STRIP_MAXP;  // series terms up to which the Horner chain beats squaring through LDS
 constexpr int kStripGroups = kWaves / 4;
 
 template <int KS>
@@ -157,6 +160,38 @@ __device__ __forceinline__ void strip_flip(d4 (&W)[NT], unsigned mask) {
       const double v = W[rt][r];
       W[rt][r] = ((mask >> (4 * rt + r)) & 1u) ? -v : v;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// P = r r with the riding columns N, N+1 = r j0+, r j0- (columns N, N+1 of c.r hold j0+, j0-), and the
+// wave-partial ||r r||_F^2 for wg_sumsq_get: the strip form of the first product of a doubling step.
+// (P^T strip = r^T (r^T strip); the stored layout is the one the general path produces.)  Needs a barrier after.
+// ---------------------------------------------------------------------------------------
+template <int KS>
+__device__ __forceinline__ void doubling_rr_strip(const Ctx &c) {
+  using G = StripGeom<KS>;
+  constexpr int N = G::N, NT = G::NT, LD = G::LD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+  const int c0 = 16 * (wave & 3), col = c0 + lr;
+  const bool active = (wave >> 2) == 0 && (wave & 3) < NT, colok = col < N;
+  double ss = 0.0;
+  if (active) {
+    d4 W[NT], B[NT];
+    strip_load_lds<KS>(c.r, lr, lq, c0, W);
+    strip_zero(B);
+    strip_mul<KS>(c.r, lr, lq, W, B);
+    strip_store_lds<KS>(c.P, lr, lq, c0, colok, B);
+    if (colok) {
+      if (lq == 0) c.P[col + N * LD] = B[G::RT][G::RR];        // (r j0+)[col]
+      if (lq == 1) c.P[col + (N + 1) * LD] = B[G::RT][G::RR];  // (r j0-)[col]
+#pragma unroll
+      for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * rt + r < KS) ss += B[rt][r] * B[rt][r];
+    }
+  }
+  wg_sumsq_put(c, ss);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -800,8 +800,9 @@ extern "C" int mom_rt_run(mom_t *h) {
     if (lds && h->opt_w4 && np_for(q.N) <= 48 && 2 * mom4_lds_bytes(q.N, true) + 2048 <= 160 * 1024) {
       const int grid4 = (int)((S >= 2048) ? S : S * Mcount);
       if (q.N == 36 || q.N == 40 || q.N == 44) {  // strip-chained kernels of the 4-wave build (momcore_strip.hip)
+        const int gridp = (int)std::min<size_t>(S * Mcount, (size_t)2 * h->num_cu);  // persistent, two per CU
         HIPCHK(h, (q.N == 40 ? mom_strip10_launch_layer : q.N == 36 ? mom_strip9_launch_layer : mom_strip11_launch_layer)(
-                      &a, a.iface, grid4, mom4_lds_bytes(q.N, true), h->stream));
+                      &a, a.iface, gridp, mom4_lds_bytes(q.N, true), h->stream));
         h->launches++;
         return MOM_OK;
       }
