@@ -40,6 +40,18 @@ constexpr int kTJ = MOM_TJ;  // 4-wave build: 3 tiles per item (operators up to 
 constexpr int kTJ = 16 / kWaves;  // column tiles per work item: 8 waves x 2 tiles cover N <= 64
 #endif
 
+// Thread coordinates through an opaque asm: the address arithmetic derived from them is recomputed where it is
+// used (a few integer ops) instead of being hoisted out of the per-unit loop of the fused kernels, kept live
+// across its thousands of instructions and spilled -- a scratch reload costs an `s_waitcnt vmcnt(0)`, i.e. it
+// also waits for every global store in flight.
+__device__ __forceinline__ int wg_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+__device__ __forceinline__ int wg_lane() { return wg_tid() & 63; }
+__device__ __forceinline__ int wg_wave() { return __builtin_amdgcn_readfirstlane(wg_tid() >> 6); }
+
 // e -> (i = e % N, j = e / N) without an integer division (valid for e*N < 2^32)
 struct FastDiv {
   unsigned magic;
@@ -140,7 +152,7 @@ template <class F> struct lds_operand { static constexpr bool value = false; };
 
 template <int NA, bool SYNC, bool FAST, class FAs, class FB, class FE>
 __device__ __forceinline__ void wg_gemm_n(int N, int NC, FAs A, FB B, FE epi) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = wg_lane(), wave = wg_wave();
   const int lr = lane & 15, lq = lane >> 4;
   const int Tn = (N + 15) >> 4;
   const int Cg = (Tn + kTJ - 1) / kTJ;
@@ -228,7 +240,7 @@ __device__ __forceinline__ void wg_gemm2(int N, FA1 A1, FA2 A2, FB B, FE1 epi1, 
 template <class FM>
 __device__ __forceinline__ void wg_matvec2(int N, int ldv, FM M, const double *x1, const double *x2, double *y1,
                                            double *y2, double *part) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = wg_lane(), wave = wg_wave();
   const int chunk = (N + kWaves - 1) / kWaves;
   const int k0 = wave * chunk, k1 = min(N, k0 + chunk);
   for (int i = lane; i < N; i += 64) {
@@ -243,7 +255,7 @@ __device__ __forceinline__ void wg_matvec2(int N, int ldv, FM M, const double *x
     part[(kWaves + wave) * ldv + i] = s2;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < N; i += kThreads) {
+  for (int i = wg_tid(); i < N; i += kThreads) {
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) { s1 += part[w * ldv + i]; s2 += part[(kWaves + w) * ldv + i]; }
@@ -274,7 +286,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void wg_inverse(int N, const FastDiv &fd, double *a, int ld, double *prow, double *pcol,
                                            double *rowk, int *ipiv, int *sh, int *bad) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = wg_tid(), lane = tid & 63, wave = tid >> 6;
   const int NN = N * N;
   for (int k = 0; k < N; ++k) {
     // (1) pivot search on column k, rows k..N-1 (first maximum, like idamax)
@@ -379,7 +391,7 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 __device__ __forceinline__ void wg_inverse_reg(int N, double *a, int ld, double *pcol, double *shd, int *ipiv,
                                                int *bad) {
   constexpr int CW = 64 / kWaves;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = wg_lane(), wave = wg_wave();
   double v[CW];
 #pragma unroll
   for (int c = 0; c < CW; ++c) {
@@ -446,7 +458,7 @@ __device__ __forceinline__ void wg_inverse_reg(int N, double *a, int ld, double 
 __device__ __forceinline__ void wg_copy_mat(int N, const FastDiv &fd, const double *__restrict__ src, int ld_s,
                                             double *__restrict__ dst, int ld_d) {
   const int NN = N * N;
-  for (int e0 = threadIdx.x; e0 < NN; e0 += 4 * kThreads) {
+  for (int e0 = wg_tid(); e0 < NN; e0 += 4 * kThreads) {
     double v[4];
     int o[4];
 #pragma unroll

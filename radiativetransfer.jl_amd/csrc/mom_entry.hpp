@@ -50,11 +50,13 @@ extern __shared__ double mom_smem[];
 // KS > 0: N = 4 KS exactly and the strip-chained paths of mom_strip.hpp are compiled in (8-wave LDS build only)
 template <bool LDSM, int IFACE, int KS = 0>
 __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
+  if (KS > 0) a.q.N = 4 * KS;  // the host launches this instantiation only for that size: every dimension folds
   const int N = a.q.N;
   const size_t total = (size_t)a.S * a.M;
   Ctx c;
 #ifdef MOM_DIAG_STAMPS
-  if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1)) mom_diag_last = mom_diag_now();
+  if (wg_tid() == 0 && blockIdx.x == (gridDim.x >> 1)) mom_diag_last = mom_diag_now();
+  if (wg_tid() == 256 && blockIdx.x == (gridDim.x >> 1)) mom_diag_last4 = mom_diag_now();
 #endif
   wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
   MOM_STAMP(40);
@@ -84,9 +86,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
       MOM_STAMP(42);
     } else {
       interaction_core<LDSM, IFACE, KS>(c, a.iface, g, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
+      MOM_STAMP(45);
     }
   }
-  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
+  if (wg_tid() == 0 && *c.bad) atomicMax(a.info, *c.bad);
 }
 
 struct SurfArgs {
@@ -115,13 +118,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_surface(SurfArgs a) {
     const double rho = 2 * a.albedo;                       // lambertian_surface.jl:37
     const double att = exp(-a.tau_tot[pt] / a.q.mu0);
     const int i_start = n * (a.q.imu0 - 1), i_end = n * a.q.imu0;
-    for (int e = threadIdx.x; e < N * N; e += kThreads) {
+    for (int e = wg_tid(); e < N * N; e += kThreads) {
       int i, j;
       c.fd.split(e, i, j);
       c.r[i + j * ld] = ((i % n == 0) && (j % n == 0)) ? rho * (c.mu[j] * c.wt[j]) : 0.0;  // :41-43,:58
       c.t[i + j * ld] = (i == j) ? 1.0 : 0.0;
     }
-    for (int i = threadIdx.x; i < N; i += kThreads) {
+    for (int i = wg_tid(); i < N; i += kThreads) {
       const bool in_sun = (i >= i_start) && (i < i_end);
       c.jp[i] = (in_sun ? a.q.I0[i - i_start] : 0.0) * att;                 // :55
       c.jm[i] = (i % n == 0) ? (a.q.mu0 * (rho * a.q.I0[0])) * att : 0.0;  // :56
@@ -132,14 +135,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_surface(SurfArgs a) {
     // interaction_hdrf! (CoreKernel/interaction_hdrf.jl:9-45): hdr_J0- = r-+_surf J0+ + j0-_surf with the
     // composite J0+ AFTER the surface interaction (still in c.Jp), then the m = 0 flux sums of the BHR
     wg_matvec(c, ElP{c.r, ld}, c.Jp, c.v1);
-    for (int i = threadIdx.x; i < N; i += kThreads) {
+    for (int i = wg_tid(); i < N; i += kThreads) {
       const double hj = c.v1[i] + c.jm[i];
       c.v1[i] = hj;
       a.hdrJ[(size_t)N * pt + i] = hj;
     }
     __syncthreads();
-    if (threadIdx.x < a.nS_out) {
-      const int k = threadIdx.x;
+    if (wg_tid() < a.nS_out) {
+      const int k = wg_tid();
       double up = 0.0, dw = 0.0;
       if (k < n)  // components beyond the reduced problem's (I,Q) have exactly zero sums for m = 0
         for (int j = k; j < N; j += n) {
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_surface(SurfArgs a) {
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
+  if (wg_tid() == 0 && *c.bad) atomicMax(a.info, *c.bad);
 }
 
 }  // namespace MOM_NS

@@ -28,6 +28,9 @@
 #ifndef MOM_STAMP
 #define MOM_STAMP(id)
 #endif
+#ifndef MOM_STAMP4
+#define MOM_STAMP4(id)
+#endif
 
 namespace MOM_NS {
 
@@ -117,19 +120,19 @@ __device__ __forceinline__ void zero_padding(const Ctx &c) {
   // otherwise padded rows/columns only feed output rows/columns that are never stored
   if (LDSM && (N % 4 != 0)) {
     const int padr = ld - N;
-    for (int e = threadIdx.x; e < padr * Np; e += kThreads) {
+    for (int e = wg_tid(); e < padr * Np; e += kThreads) {
       const int j = e / padr, i = N + (e - j * padr);
       const int o = i + j * ld;
       c.r[o] = 0.0; c.t[o] = 0.0; c.P[o] = 0.0; c.Q[o] = 0.0;
     }
     const int padc = Np - N;
-    for (int e = threadIdx.x; e < padc * N; e += kThreads) {
+    for (int e = wg_tid(); e < padc * N; e += kThreads) {
       const int jj = e / N, i = e - jj * N;
       const int o = i + (N + jj) * ld;
       c.r[o] = 0.0; c.t[o] = 0.0; c.P[o] = 0.0; c.Q[o] = 0.0;
     }
   }
-  if (threadIdx.x < 32) c.thr[threadIdx.x] = kNeumannThr2[threadIdx.x];
+  if (wg_tid() < 32) c.thr[wg_tid()] = kNeumannThr2[wg_tid()];
 }
 
 // restore the zero padding of one buffer after it was used as scratch (only matters if N % 4 != 0)
@@ -137,12 +140,12 @@ __device__ __forceinline__ void rezero_padding(const Ctx &c, double *buf) {
   const int N = c.N, Np = c.nc, ld = c.ld;
   if (N % 4 == 0) return;
   const int padr = ld - N;
-  for (int e = threadIdx.x; e < padr * Np; e += kThreads) {
+  for (int e = wg_tid(); e < padr * Np; e += kThreads) {
     const int j = e / padr, i = N + (e - j * padr);
     buf[i + j * ld] = 0.0;
   }
   const int padc = Np - N;
-  for (int e = threadIdx.x; e < padc * N; e += kThreads) {
+  for (int e = wg_tid(); e < padc * N; e += kThreads) {
     const int jj = e / N, i = e - jj * N;
     buf[i + (N + jj) * ld] = 0.0;
   }
@@ -178,7 +181,7 @@ struct ElEye {
 // y = M x ; all threads; ends with barrier
 template <class FM>
 __device__ __forceinline__ void wg_matvec(const Ctx &c, FM M, const double *x, double *y) {
-  const int N = c.N, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int N = c.N, lane = wg_lane(), wave = wg_wave();
   const int chunk = (N + kWaves - 1) / kWaves;
   const int k0 = wave * chunk, k1 = min(N, k0 + chunk);
   for (int i = lane; i < N; i += 64) {
@@ -188,7 +191,7 @@ __device__ __forceinline__ void wg_matvec(const Ctx &c, FM M, const double *x, d
     c.part[wave * c.ldv + i] = s;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < N; i += kThreads) {
+  for (int i = wg_tid(); i < N; i += kThreads) {
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) s += c.part[w * c.ldv + i];
@@ -227,11 +230,22 @@ __device__ __forceinline__ int neumann_terms(const double *thr, double beta2) {
   return hi + 1;
 }
 
+// the same for p <= 12 without memory: thresholds as immediates (the strip chains' range); 1000 beyond or NaN
+__device__ __forceinline__ int neumann_terms_12(double beta2) {
+  if (!(beta2 <= 1.53988783074545245e-03)) return 1000;
+  int p = 1;
+  p += beta2 > 1.92592994438723585e-34; p += beta2 > 1.38777877561156685e-17; p += beta2 > 5.77492213356056750e-12;
+  p += beta2 > 3.72517661162420568e-09; p += beta2 > 1.80656771560518035e-07; p += beta2 > 2.40186660760962690e-06;
+  p += beta2 > 1.52417448931310540e-05; p += beta2 > 6.09157135028591602e-05; p += beta2 > 1.78874927371965362e-04;
+  p += beta2 > 4.23309807394842467e-04; p += beta2 > 8.56292603484697687e-04;
+  return p;
+}
+
 // lane-partial sum of squares -> part[wave] (call before the barrier that follows the GEMM);
 // read back with wg_sumsq_get after that barrier.
 __device__ __forceinline__ void wg_sumsq_put(const Ctx &c, double ss) {
   ss = wave_sum(ss);
-  if ((threadIdx.x & 63) == 0) c.part[threadIdx.x >> 6] = ss;
+  if (wg_lane() == 0) c.part[wg_wave()] = ss;
 }
 __device__ __forceinline__ double wg_sumsq_get(const Ctx &c) {
   double b2 = 0.0;
@@ -262,7 +276,7 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob
     // Horner: A_1 = T, A_{k+1} = T + A_k B
     double *o = Ob;
     if (p == 1) {
-      for (int e = threadIdx.x; e < NN; e += kThreads) {
+      for (int e = wg_tid(); e < NN; e += kThreads) {
         int i, j;
         c.fd.split(e, i, j);
         o[i + j * ld] = T(i, j);
@@ -278,7 +292,7 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob
     // G = (I + B)(I + B^2)(I + B^4)... ; Ob <- T G
     {
       double *o = Ob, *b = Bb;
-      for (int e = threadIdx.x; e < NN; e += kThreads) {
+      for (int e = wg_tid(); e < NN; e += kThreads) {
         int i, j;
         c.fd.split(e, i, j);
         o[i + j * ld] = ((i == j) ? 1.0 : 0.0) + b[i + j * ld];
@@ -292,7 +306,7 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob
     gemm_to<LDSM>(c, Ob, T, ElP{Ob, ld}, [=](int, int, double v, double) { return v; });
   } else {
     double *b = Bb, *o = Ob;
-    for (int e = threadIdx.x; e < NN; e += kThreads) {
+    for (int e = wg_tid(); e < NN; e += kThreads) {
       int i, j;
       c.fd.split(e, i, j);
       b[i + j * ld] = ((i == j) ? 1.0 : 0.0) - b[i + j * ld];
@@ -309,12 +323,12 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob
 // stream constants -> LDS (call after zero_padding + barrier; needs a barrier after)
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_streams(const Ctx &c, const DevStreams &q) {
-  for (int i = threadIdx.x; i < c.Np; i += kThreads) {
+  for (int i = wg_tid(); i < c.Np; i += kThreads) {
     c.mu[i] = (i < c.N) ? q.mu[i] : 1.0;
     c.wt[i] = (i < c.N) ? q.wt[i] : 0.0;
     c.sg[i] = (i < c.N) ? q.sg[i] : 1.0;
   }
-  if (threadIdx.x == 0) *c.bad = 0;
+  if (wg_tid() == 0) *c.bad = 0;
 }
 
 template <bool LDSM>
@@ -347,7 +361,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   fq.init(Nq);
   // per stream pair (iq, jq): E = 1 - exp(..), F1 = mu_j/(mu_i+mu_j), F2 = mu_j/(mu_i-mu_j); the Q buffer is free here
   double *E = c.Q, *F1 = c.Q + Nq * Nq, *F2 = c.Q + 2 * Nq * Nq;
-  for (int i = threadIdx.x; i < N; i += kThreads) {
+  for (int i = wg_tid(); i < N; i += kThreads) {
     c.ei[i] = exp(-dtau / c.mu[i]);
     c.v1[i] = c.wt[i] / wdiv;   // wct
     c.v2[i] = dtau / c.mu[i];
@@ -356,7 +370,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   // large N evaluate the same expressions per element instead
   const bool tab = 3 * Nq * Nq <= (int)mat_elems(N);
   if (tab)
-    for (int e = threadIdx.x; e < Nq * Nq; e += kThreads) {
+    for (int e = wg_tid(); e < Nq * Nq; e += kThreads) {
       int iq, jq;
       fq.split(e, iq, jq);
       const double mui = c.mu[iq * ns], muj = c.mu[jq * ns];
@@ -367,7 +381,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   __syncthreads();
   const int i_start = n * (q.imu0 - 1), i_end = n * q.imu0;
   double *ZS = c.P;  // mixed Z++ / Z-+ of the sun-block columns, [N x nS] each (P is free here)
-  for (int e0 = threadIdx.x; e0 < N * N; e0 += 8 * kThreads) {
+  for (int e0 = wg_tid(); e0 < N * N; e0 += 8 * kThreads) {
     double zp[8], zm[8];
     int ii[8], jj[8];
 #pragma unroll
@@ -421,7 +435,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   __syncthreads();
   const double mus = c.mu[i_start];
   const double att = exp(-tau_sum / mus);
-  for (int i = threadIdx.x; i < N; i += kThreads) {
+  for (int i = wg_tid(); i < N; i += kThreads) {
     double zp = 0.0, zm = 0.0;
     for (int k = 0; k < n; ++k) {
       zp += ZS[i + k * N] * q.I0[k];
@@ -464,7 +478,7 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
   // column tile and no K padding (N % 4 == 0); otherwise: separate mat-vec passes.
   const bool ride = (N % 4 == 0) && (c.nc - N >= 2);
   if (ride) {
-    for (int i = threadIdx.x; i < N; i += kThreads) {
+    for (int i = wg_tid(); i < N; i += kThreads) {
       c.r[i + N * ld] = c.jp[i];
       c.r[i + (N + 1) * ld] = c.jm[i];
     }
@@ -491,11 +505,12 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
       __syncthreads();
       MOM_STAMP(1);
     }
+    MOM_STAMP(70);
     const double beta2 = wg_sumsq_get(c);
     if constexpr (LDSM && KS > 0) {
       // strip-chained step (mom_strip.hpp): the series, A r, (A r) t and A t in one barrier-free MFMA stream
       if (strip_ok) {
-        const int p = neumann_terms(c.thr, beta2);
+        const int p = neumann_terms_12(beta2);
         if (p <= kStripMaxP) {
           doubling_step_strip<KS>(c, p, expk);
           expk = expk * expk;
@@ -506,7 +521,7 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
     if (ride) {
       // w1 = j1- + r j0+ ; w2 = j0+ + r j1-   with j1± = j0± expk   (:51-60)
       double *r = c.r, *P = c.P;
-      for (int i = threadIdx.x; i < N; i += kThreads) {
+      for (int i = wg_tid(); i < N; i += kThreads) {
         const double rjp = P[i + N * ld], rjm = P[i + (N + 1) * ld];
         r[i + N * ld] = c.jm[i] * expk + rjp;
         r[i + (N + 1) * ld] = c.jp[i] + expk * rjm;
@@ -517,20 +532,20 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
     double *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
     if (!ride) {
       // j1± = j0± expk                                       (:51,:54)
-      for (int i = threadIdx.x; i < N; i += kThreads) {
+      for (int i = wg_tid(); i < N; i += kThreads) {
         c.j1p[i] = c.jp[i] * expk;
         c.j1m[i] = c.jm[i] * expk;
       }
       __syncthreads();
       // v1 = r j0+ ; v2 = r j1-
       wg_matvec2(N, c.ldv, ElP{r, ld}, c.jp, c.j1m, c.v1, c.v2, c.part);
-      for (int i = threadIdx.x; i < N; i += kThreads) {
+      for (int i = wg_tid(); i < N; i += kThreads) {
         c.v1[i] = c.j1m[i] + c.v1[i];  // j1- + r j0+
         c.v2[i] = c.jp[i] + c.v2[i];   // j0+ (old) + r j1-
       }
       __syncthreads();
       wg_matvec2(N, c.ldv, ElP{Q, ld}, c.v1, c.v2, c.v1, c.v2, c.part);
-      for (int i = threadIdx.x; i < N; i += kThreads) {
+      for (int i = wg_tid(); i < N; i += kThreads) {
         c.jm[i] = c.jm[i] + c.v1[i];   // :57
         c.jp[i] = c.j1p[i] + c.v2[i];  // :60
       }
@@ -542,7 +557,7 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
     MOM_STAMP(4);
     if (ride) {
       // j0- += Q w1 (:57) ; j0+ = j1+ + Q w2 (:60); refresh the riding columns for the next step
-      for (int i = threadIdx.x; i < N; i += kThreads) {
+      for (int i = wg_tid(); i < N; i += kThreads) {
         const double jm = c.jm[i] + P[i + N * ld];
         const double jp = c.jp[i] * expk + P[i + (N + 1) * ld];
         c.jm[i] = jm;
@@ -571,12 +586,12 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
   // apply_D! (doubling.jl:93-110) and apply_D_SFI! (:112-118): r-+ rows and j0- scaled by sg
   {
     double *r = c.r;
-    for (int e = threadIdx.x; e < N * N; e += kThreads) {
+    for (int e = wg_tid(); e < N * N; e += kThreads) {
       int i, j;
       c.fd.split(e, i, j);
       r[i + j * ld] *= c.sg[i];
     }
-    for (int i = threadIdx.x; i < N; i += kThreads) {
+    for (int i = wg_tid(); i < N; i += kThreads) {
       c.jm[i] *= c.sg[i];
       if (ride) { r[i + N * ld] = 0.0; r[i + (N + 1) * ld] = 0.0; c.P[i + N * ld] = 0.0; c.P[i + (N + 1) * ld] = 0.0; }
     }
@@ -604,7 +619,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     }
   }
   // composite sources -> LDS
-  for (int i = threadIdx.x; i < N; i += kThreads) {
+  for (int i = wg_tid(); i < N; i += kThreads) {
     c.Jp[i] = g.J0p[i];
     c.Jm[i] = g.J0m[i];
   }
@@ -613,7 +628,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     // J0+ = j0+ + t++ J0+ ; J0- = J0- + T-- j0-            (interaction.jl:16-17)
     wg_matvec(c, ElP{t, ld}, c.Jp, c.v1);
     wg_matvec(c, El{g.T_mm, N, N}, c.jm, c.v2);
-    for (int i = threadIdx.x; i < N; i += kThreads) {
+    for (int i = wg_tid(); i < N; i += kThreads) {
       c.Jp[i] = c.jp[i] + c.v1[i];
       c.Jm[i] = c.Jm[i] + c.v2[i];
     }
@@ -628,11 +643,11 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     wg_copy_mat(N, c.fd, g.T_mm, N, c.P, ld);  // P = T--
     // J0- = J0- + T-- (r-+ J0+ + j0-) ; J0+ = j0+ + t++ J0+  (:36-37)
     wg_matvec(c, ElP{r, ld}, c.Jp, c.v1);
-    for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
+    for (int i = wg_tid(); i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
     __syncthreads();
     wg_matvec(c, ElP{c.P, ld}, c.v1, c.v2);
     wg_matvec(c, ElP{t, ld}, c.Jp, c.v1);
-    for (int i = threadIdx.x; i < N; i += kThreads) {
+    for (int i = wg_tid(); i < N; i += kThreads) {
       c.Jm[i] = c.Jm[i] + c.v2[i];
       c.Jp[i] = c.jp[i] + c.v1[i];
     }
@@ -647,7 +662,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     __syncthreads();
     wg_gemm<false>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
     wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
-    for (int e = threadIdx.x; e < N * N; e += kThreads) {
+    for (int e = wg_tid(); e < N * N; e += kThreads) {
       int i, j;
       c.fd.split(e, i, j);
       Rpm[i + j * N] = rpm(i, j);
@@ -659,11 +674,11 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     __syncthreads();
     // J0+ = j0+ + t++ (J0+ + R+- j0-) ; J0- = J0- + T-- j0-   (:58-59)
     wg_matvec(c, ElP{P, ld}, c.jm, c.v1);
-    for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.Jp[i] + c.v1[i];
+    for (int i = wg_tid(); i < N; i += kThreads) c.v1[i] = c.Jp[i] + c.v1[i];
     __syncthreads();
     wg_matvec(c, ElP{t, ld}, c.v1, c.v2);
     wg_matvec(c, ElP{Q, ld}, c.jm, c.v1);
-    for (int i = threadIdx.x; i < N; i += kThreads) {
+    for (int i = wg_tid(); i < N; i += kThreads) {
       c.Jp[i] = c.jp[i] + c.v2[i];
       c.Jm[i] = c.Jm[i] + c.v1[i];
     }
@@ -686,7 +701,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     MOM_STAMP(10);
     wg_copy_mat(N, c.fd, g.R_pm, N, c.P, ld);  // P = R+-
     if (ride)
-      for (int i = threadIdx.x; i < N; i += kThreads) c.P[i + N * ld] = c.Jp[i];
+      for (int i = wg_tid(); i < N; i += kThreads) c.P[i + N * ld] = c.Jp[i];
     __syncthreads();
     MOM_STAMP(11);
     double beta2;
@@ -702,7 +717,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       __syncthreads();
       beta2 = wg_sumsq_get(c);
       if (ride)  // v1 = r-+ J0+ + j0-  -> column N of r (B operand of T01 r-+ below)
-        for (int i = threadIdx.x; i < N; i += kThreads) r[i + N * ld] = Q[i + N * ld] + c.jm[i];
+        for (int i = wg_tid(); i < N; i += kThreads) r[i + N * ld] = Q[i + N * ld] + c.jm[i];
     }
     MOM_STAMP(12);
     times_inv<LDSM>(c, El{g.T_mm, N, N}, c.Q, c.P, beta2);
@@ -710,10 +725,10 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     if (!ride) {
       // J0- = J0- + T01 (r-+ J0+ + j0-)                          (:90)
       wg_matvec(c, ElP{r, ld}, c.Jp, c.v1);
-      for (int i = threadIdx.x; i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
+      for (int i = wg_tid(); i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
       __syncthreads();
       wg_matvec(c, ElP{c.P, ld}, c.v1, c.v2);
-      for (int i = threadIdx.x; i < N; i += kThreads) c.Jm[i] = c.Jm[i] + c.v2[i];
+      for (int i = wg_tid(); i < N; i += kThreads) c.Jm[i] = c.Jm[i] + c.v2[i];
     }
     MOM_STAMP(14);
     {
@@ -725,7 +740,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       __syncthreads();
       MOM_STAMP(15);
       if (ride)  // J0- = J0- + T01 v1 (:90); next rider: j0- for R+- j0-
-        for (int i = threadIdx.x; i < N; i += kThreads) {
+        for (int i = wg_tid(); i < N; i += kThreads) {
           c.Jm[i] = c.Jm[i] + Q[i + N * ld];
           r[i + N * ld] = c.jm[i];
         }
@@ -743,7 +758,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     if (!ride) {
       // w = J0+ + R+- j0-  (kept in j1p; j1p/j1m are free outside doubling)
       wg_matvec(c, ElP{c.Q, ld}, c.jm, c.v1);
-      for (int i = threadIdx.x; i < N; i += kThreads) c.j1p[i] = c.Jp[i] + c.v1[i];
+      for (int i = wg_tid(); i < N; i += kThreads) c.j1p[i] = c.Jp[i] + c.v1[i];
     }
     {
       double *P = c.P, *Q = c.Q;
@@ -757,7 +772,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       __syncthreads();
       beta2 = wg_sumsq_get(c);
       if (ride)
-        for (int i = threadIdx.x; i < N; i += kThreads) c.j1p[i] = c.Jp[i] + P[i + N * ld];
+        for (int i = wg_tid(); i < N; i += kThreads) c.j1p[i] = c.Jp[i] + P[i + N * ld];
     }
     MOM_STAMP(19);
     times_inv<LDSM>(c, ElP{t, ld}, c.P, c.Q, beta2);
@@ -765,12 +780,12 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     if (!ride) {
       // J0+ = j0+ + T21 (J0+ + R+- j0-)                          (:110)
       wg_matvec(c, ElP{c.Q, ld}, c.j1p, c.v2);
-      for (int i = threadIdx.x; i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.v2[i];
+      for (int i = wg_tid(); i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.v2[i];
     }
     MOM_STAMP(21);
     wg_copy_mat(N, c.fd, g.R_pm, N, c.P, ld);  // P = R+- (old)
     if (ride)
-      for (int i = threadIdx.x; i < N; i += kThreads) c.P[i + N * ld] = c.j1p[i];
+      for (int i = wg_tid(); i < N; i += kThreads) c.P[i + N * ld] = c.j1p[i];
     __syncthreads();
     MOM_STAMP(22);
     {
@@ -788,7 +803,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     }
     MOM_STAMP(23);
     if (ride)  // J0+ = j0+ + T21 w (:110)
-      for (int i = threadIdx.x; i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.P[i + N * ld];
+      for (int i = wg_tid(); i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.P[i + N * ld];
     {
       double *P = c.P, *Q = c.Q, *Rpm = g.R_pm, *Tpp = g.T_pp;
       // R+- = r+- + (T21 R+-) t--                              (:116)
@@ -796,7 +811,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       __syncthreads();
       MOM_STAMP(24);
       if (ride)
-        for (int i = threadIdx.x; i < N; i += kThreads) { P[i + N * ld] = 0.0; r[i + N * ld] = 0.0; Q[i + N * ld] = 0.0; }
+        for (int i = wg_tid(); i < N; i += kThreads) { P[i + N * ld] = 0.0; r[i + N * ld] = 0.0; Q[i + N * ld] = 0.0; }
       wg_copy_mat(N, c.fd, g.T_pp, N, P, ld);  // P = T++ (old)
       __syncthreads();
       MOM_STAMP(25);
@@ -806,7 +821,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
   }
   __syncthreads();
   MOM_STAMP(26);
-  for (int i = threadIdx.x; i < N; i += kThreads) {
+  for (int i = wg_tid(); i < N; i += kThreads) {
     g.J0p[i] = c.Jp[i];
     g.J0m[i] = c.Jm[i];
   }
@@ -816,7 +831,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
 // composite <- added (rt_kernel.jl:227-230) from the context
 __device__ __forceinline__ void store_added_as_composite(const Ctx &c, const CompPtrs &g) {
   const int N = c.N, ld = c.ld;
-  for (int e = threadIdx.x; e < N * N; e += kThreads) {
+  for (int e = wg_tid(); e < N * N; e += kThreads) {
     int i, j;
     c.fd.split(e, i, j);
     const double rv = c.r[i + j * ld], tv = c.t[i + j * ld], s = c.sg[i] * c.sg[j];
@@ -825,7 +840,7 @@ __device__ __forceinline__ void store_added_as_composite(const Ctx &c, const Com
     g.T_pp[e] = tv;
     g.T_mm[e] = s * tv;
   }
-  for (int i = threadIdx.x; i < N; i += kThreads) {
+  for (int i = wg_tid(); i < N; i += kThreads) {
     g.J0p[i] = c.jp[i];
     g.J0m[i] = c.jm[i];
   }

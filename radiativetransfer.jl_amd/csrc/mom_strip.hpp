@@ -25,6 +25,7 @@ namespace MOM_NS {
 #ifndef MOM_STRIP_MAXP
 #define MOM_STRIP_MAXP 12
 #endif
+static_assert(MOM_STRIP_MAXP <= 12, "neumann_terms_12 covers p <= 12");
 constexpr int kStripMaxP = MOM_STRIP_MAXP;  // series terms up to which the Horner chain beats squaring through LDS
 constexpr int kStripGroups = kWaves / 4;
 
@@ -96,6 +97,7 @@ __device__ __forceinline__ void strip_copy(d4 (&D)[NT], const d4 (&S)[NT]) {
 // buffer has LD > 16 NT - 1 rows, a global block is guarded with colok).
 template <int KS>
 __device__ __forceinline__ void strip_load_lds(const double *X, int lr, int lq, int c0, d4 (&W)[StripGeom<KS>::NT]) {
+  asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
   const double *base = X + c0 + lr + lq * LD;
 #pragma unroll
@@ -106,6 +108,7 @@ __device__ __forceinline__ void strip_load_lds(const double *X, int lr, int lq, 
 template <int KS>
 __device__ __forceinline__ void strip_store_lds(double *X, int lr, int lq, int c0, bool colok,
                                                 const d4 (&W)[StripGeom<KS>::NT]) {
+  asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
   double *base = X + c0 + lr + lq * LD;
   if (colok) {
@@ -119,6 +122,7 @@ __device__ __forceinline__ void strip_store_lds(double *X, int lr, int lq, int c
 template <int KS>
 __device__ __forceinline__ void strip_load_glb(const double *__restrict__ X, int lr, int lq, int c0, bool colok,
                                                d4 (&W)[StripGeom<KS>::NT]) {
+  asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, N = 4 * KS;
   const double *base = X + c0 + lr + lq * N;
 #pragma unroll
@@ -129,6 +133,7 @@ __device__ __forceinline__ void strip_load_glb(const double *__restrict__ X, int
 template <int KS>
 __device__ __forceinline__ void strip_store_glb(double *__restrict__ X, int lr, int lq, int c0, bool colok,
                                                 const d4 (&W)[StripGeom<KS>::NT]) {
+  asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, N = 4 * KS;
   double *base = X + c0 + lr + lq * N;
   if (colok) {
@@ -171,7 +176,7 @@ template <int KS>
 __device__ __forceinline__ void doubling_rr_strip(const Ctx &c) {
   using G = StripGeom<KS>;
   constexpr int N = G::N, NT = G::NT, LD = G::LD;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+  const int lane = wg_lane(), wave = wg_wave(), lr = lane & 15, lq = lane >> 4;
   const int c0 = 16 * (wave & 3), col = c0 + lr;
   const bool active = (wave >> 2) == 0 && (wave & 3) < NT, colok = col < N;
   double ss = 0.0;
@@ -203,7 +208,7 @@ template <int KS>
 __device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, double expk) {
   using G = StripGeom<KS>;
   constexpr int N = G::N, NT = G::NT, LD = G::LD;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+  const int lane = wg_lane(), wave = wg_wave(), lr = lane & 15, lq = lane >> 4;
   const int c0 = 16 * (wave & 3);
   const bool active = (wave >> 2) == 0 && (wave & 3) < NT, colok = c0 + lr < N;
   double *r = c.r, *t = c.t;
@@ -236,7 +241,9 @@ __device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, double 
     strip_mul2<KS>(t, lr, lq, Zt, Rn, Y, Tn);  // r^T + t^T (A r)^T ; t^T A^T      (:64, :67)
     aw = Zt[G::RT][G::RR];  // lanes lq == 0: (A w1)[col] ; lq == 1: (A w2)[col]
   }
+  MOM_STAMP(71);
   __syncthreads();
+  MOM_STAMP(72);
   if (active) {
     strip_store_lds<KS>(r, lr, lq, c0, colok, Rn);
     strip_store_lds<KS>(t, lr, lq, c0, colok, Tn);
@@ -253,6 +260,7 @@ __device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, double 
     }
   }
   __syncthreads();
+  MOM_STAMP(73);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -269,27 +277,54 @@ template <int KS>
 __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
   using G = StripGeom<KS>;
   constexpr int N = G::N, NT = G::NT, LD = G::LD;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lq = lane >> 4;
+  const int lane = wg_lane(), wave = wg_wave(), lr = lane & 15, lq = lane >> 4;
   const int grp = wave >> 2, c0 = 16 * (wave & 3), col = c0 + lr;
   const bool strip = (wave & 3) < NT, colok = col < N;
   const bool do1 = strip && grp == 0, do2 = strip && grp == kStripGroups - 1;
   double *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
-  // P = R+-, Q = T++ ; riding rows: column N of Q = J0+, column N of r = j0-
-  wg_copy_mat(N, c.fd, g.R_pm, N, P, LD);
-  wg_copy_mat(N, c.fd, g.T_pp, N, Q, LD);
-  for (int i = threadIdx.x; i < N; i += kThreads) {
+  d4 T1[NT], W0[NT];  // chain 1: T--^T strip ; chain 2: W0 = R+-^T t++^T
+  if (do1) strip_load_glb<KS>(g.T_mm, lr, lq, c0, colok, T1);
+  // P = R+-, Q = T++ ; riding rows: column N of Q = J0+, column N of r = j0-.  All global loads of both blocks are
+  // issued before the first LDS store: one exposed HBM latency instead of one per batch.
+  {
+    constexpr int NN = N * N, U = 8;
+    for (int e0 = wg_tid(); e0 < NN; e0 += U * kThreads) {
+      double vr[U], vt[U];
+      int o[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * kThreads;
+        if (e < NN) {
+          int i, j;
+          c.fd.split(e, i, j);
+          vr[u] = g.R_pm[e];
+          vt[u] = g.T_pp[e];
+          o[u] = i + j * LD;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (e0 + u * kThreads < NN) {
+          P[o[u]] = vr[u];
+          Q[o[u]] = vt[u];
+        }
+    }
+  }
+  for (int i = wg_tid(); i < N; i += kThreads) {
     Q[i + N * LD] = g.J0p[i];
     r[i + N * LD] = c.jm[i];
   }
-  d4 T1[NT], W0[NT];  // chain 1: T--^T strip ; chain 2: W0 = R+-^T t++^T
-  if (do1) strip_load_glb<KS>(g.T_mm, lr, lq, c0, colok, T1);
+  MOM_STAMP(50);
   __syncthreads();
+  MOM_STAMP(51);
+  MOM_STAMP4(91);
   if (do2) {
     d4 tT[NT];
     strip_load_lds<KS>(t, lr, lq, c0, tT);
     strip_zero(W0);
     strip_mul<KS>(P, lr, lq, tT, W0);
   }
+  MOM_STAMP4(92);
   {
     // B = r-+ R+- over R+- in place (tiles held in registers across the barrier), ||B||_F^2
     double ss = 0.0;
@@ -299,9 +334,12 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
     });
     wg_sumsq_put(c, ss);
   }
+  MOM_STAMP(52);
   __syncthreads();
+  MOM_STAMP(53);
+  MOM_STAMP4(93);
   const double beta2 = wg_sumsq_get(c);
-  const int p = neumann_terms(c.thr, beta2);
+  const int p = neumann_terms_12(beta2);
   if (p > kStripMaxP) return false;
   const unsigned mask = strip_sign_mask(c.sg, lq, N);
   if (do1) {
@@ -314,6 +352,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
       strip_mul<KS>(P, lr, lq, Y, acc);
       strip_copy(Y, acc);
     }
+    MOM_STAMP(54);
     d4 Radd[NT];
     strip_load_glb<KS>(g.R_mp, lr, lq, c0, colok, Radd);
     const double j0m = (colok && lq == 0) ? g.J0m[col] : 0.0;
@@ -336,6 +375,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
     strip_store_glb<KS>(g.R_mp, lr, lq, c0, colok, Radd);
     // J0- = J0- + T01 (r-+ J0+ + j0-)                                                (:90)
     if (colok && lq == 0) g.J0m[col] = j0m + (Radd[G::RT][G::RR] + V[G::RT][G::RR]);
+    MOM_STAMP(55);
   }
   if (do2) {
     d4 Y[NT];
@@ -347,6 +387,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
       strip_mul<KS>(P, lr, lq, Y, acc);
       strip_copy(Y, acc);
     }
+    MOM_STAMP4(94);
     // T21^T = t++^T + r-+^T X^T ; row N: (X j0-)^T = (T21 R+- j0-)^T
     d4 T21[NT];
     strip_load_lds<KS>(t, lr, lq, c0, T21);
@@ -368,8 +409,11 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
     strip_mul<KS>(t, lr, lq, Y, acc);
     strip_flip(acc, mask);
     strip_store_glb<KS>(g.R_pm, lr, lq, c0, colok, acc);
+    MOM_STAMP4(95);
   }
   __syncthreads();
+  MOM_STAMP(56);
+  MOM_STAMP4(96);
   return true;
 }
 

@@ -10,27 +10,7 @@
 
 #include "momcore.h"
 
-#ifdef MOM_DIAG_STAMPS
-// diagnostic build only (make EXTRA=-DMOM_DIAG_STAMPS): s_memtime deltas of workgroup 0, thread 0,
-// accumulated per code section; read back with mom_diag_read().  Never part of the shipped library.
-__device__ unsigned long long mom_diag_acc[64];
-__device__ unsigned long long mom_diag_last;
-__device__ __forceinline__ unsigned long long mom_diag_now() {
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  return t;
-}
-#define MOM_STAMP(id)                                                    \
-  do {                                                                   \
-    __builtin_amdgcn_sched_barrier(0);                                   \
-    if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1)) {              \
-      unsigned long long n__ = mom_diag_now();                           \
-      mom_diag_acc[id] += n__ - mom_diag_last;                           \
-      mom_diag_last = n__;                                               \
-    }                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                   \
-  } while (0)
-#endif
+#include "mom_diag.hpp"
 #include "mom_entry.hpp"
 
 using namespace mom;
@@ -934,9 +914,9 @@ extern "C" int mom_get_RT_device(mom_t *h, void *dR, void *dT) {
 
 #ifdef MOM_DIAG_STAMPS
 extern "C" int mom_diag_read(unsigned long long *out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mom_diag_acc), 64 * sizeof(unsigned long long)) != hipSuccess) return MOM_EHIP;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mom_diag_acc), 128 * sizeof(unsigned long long)) != hipSuccess) return MOM_EHIP;
   if (reset) {
-    unsigned long long z[64] = {0};
+    unsigned long long z[128] = {0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(mom_diag_acc), z, sizeof z) != hipSuccess) return MOM_EHIP;
   }
   return MOM_OK;

@@ -7,6 +7,7 @@
 #endif
 #include <hip/hip_runtime.h>
 
+#include "mom_diag.hpp"
 #include "mom_entry.hpp"
 
 using namespace MOM_NS;
@@ -33,3 +34,14 @@ hipError_t MOM_CAT(MOM_CAT(mom_strip, MOM_STRIP_KS), _launch_layer)(const void *
 #undef STRIP_LAUNCH
   return hipGetLastError();
 }
+
+#ifdef MOM_DIAG_STAMPS
+extern "C" int MOM_CAT(mom_diag_read_strip, MOM_STRIP_KS)(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mom_diag_acc), 128 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[128] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mom_diag_acc), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
