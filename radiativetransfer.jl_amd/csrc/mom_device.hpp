@@ -40,6 +40,14 @@ constexpr int kTJ = MOM_TJ;  // 4-wave build: 3 tiles per item (operators up to 
 constexpr int kTJ = 16 / kWaves;  // column tiles per work item: 8 waves x 2 tiles cover N <= 64
 #endif
 
+// Global-memory pointers with their address space spelled out.  Pointers that reach a kernel inside an argument
+// struct are generic to the compiler: it would emit FLAT loads/stores, which count on BOTH memory counters, so
+// every LDS wait behind a composite store in flight would also wait for that store.  Through these types the
+// accesses become global_load / global_store (vmcnt only).
+typedef __attribute__((address_space(1))) double gdouble;
+__device__ __forceinline__ gdouble *as_global(double *p) { return (gdouble *)p; }
+__device__ __forceinline__ const gdouble *as_global(const double *p) { return (const gdouble *)p; }
+
 // Thread coordinates through an opaque asm: the address arithmetic derived from them is recomputed where it is
 // used (a few integer ops) instead of being hoisted out of the per-unit loop of the fused kernels, kept live
 // across its thousands of instructions and spilled -- a scratch reload costs an `s_waitcnt vmcnt(0)`, i.e. it
@@ -455,8 +463,8 @@ __device__ __forceinline__ void wg_inverse_reg(int N, double *a, int ld, double 
 }
 
 // copy an N x N column-major block src(ld_s) -> dst(ld_d), all threads; loads batched by 4
-__device__ __forceinline__ void wg_copy_mat(int N, const FastDiv &fd, const double *__restrict__ src, int ld_s,
-                                            double *__restrict__ dst, int ld_d) {
+template <class PS, class PD>  // pointer types: LDS/generic double* or global gdouble*
+__device__ __forceinline__ void wg_copy_mat(int N, const FastDiv &fd, PS src, int ld_s, PD dst, int ld_d) {
   const int NN = N * N;
   for (int e0 = wg_tid(); e0 < NN; e0 += 4 * kThreads) {
     double v[4];

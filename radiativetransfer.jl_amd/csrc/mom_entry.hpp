@@ -19,8 +19,8 @@ struct LayerArgs {
 };
 
 struct ZMix {
-  const double *base;  // Z[:,:,0,m]
-  const double *w;     // K weights of this point
+  const gdouble *base;  // Z[:,:,0,m]
+  const gdouble *w;     // K weights of this point
   int K, N;
   __device__ __forceinline__ double operator()(int i, int j) const {
     double acc = 0.0;
@@ -33,12 +33,12 @@ struct ZMix {
 __device__ __forceinline__ CompPtrs comp_ptrs(double *const comp[6], int N, size_t pt) {
   const size_t NN = (size_t)N * N;
   CompPtrs g;
-  g.R_mp = comp[0] + NN * pt;
-  g.R_pm = comp[1] + NN * pt;
-  g.T_pp = comp[2] + NN * pt;
-  g.T_mm = comp[3] + NN * pt;
-  g.J0p = comp[4] + (size_t)N * pt;
-  g.J0m = comp[5] + (size_t)N * pt;
+  g.R_mp = as_global(comp[0]) + NN * pt;
+  g.R_pm = as_global(comp[1]) + NN * pt;
+  g.T_pp = as_global(comp[2]) + NN * pt;
+  g.T_mm = as_global(comp[3]) + NN * pt;
+  g.J0p = as_global(comp[4]) + (size_t)N * pt;
+  g.J0m = as_global(comp[5]) + (size_t)N * pt;
   return g;
 }
 
@@ -62,19 +62,19 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
   MOM_STAMP(40);
   for (size_t pt = blockIdx.x; pt < total; pt += gridDim.x) {
     const int n = (int)(pt % a.S), mrel = (int)(pt / a.S), m = a.m_first + mrel;
-    const double tau = a.tau[n], varpi = a.varpi[n];
+    const double tau = as_global(a.tau)[n], varpi = as_global(a.varpi)[n];
     const double dtau = ldexp(tau, -a.nd);       // τ ./ 2^ndoubl   (rt_kernel.jl:244)
     double expk = exp(-dtau / a.q.mu0);          // init_layer      (rt_kernel.jl:273)
     const size_t NN = (size_t)N * N;
-    ZMix zpp{a.Zpp + NN * a.K * mrel, a.zw + (size_t)a.K * n, a.K, N};
-    ZMix zmp{a.Zmp + NN * a.K * mrel, a.zw + (size_t)a.K * n, a.K, N};
+    ZMix zpp{as_global(a.Zpp) + NN * a.K * mrel, as_global(a.zw) + (size_t)a.K * n, a.K, N};
+    ZMix zmp{as_global(a.Zmp) + NN * a.K * mrel, as_global(a.zw) + (size_t)a.K * n, a.K, N};
 #ifdef MOM_DIAG_STAMPS
     MOM_STAMP(43);
 #endif
-    elemental_build(c, a.q, m, a.nd, a.tau_sum[n], dtau, varpi, zpp, zmp);
+    elemental_build(c, a.q, m, a.nd, as_global(a.tau_sum)[n], dtau, varpi, zpp, zmp);
     MOM_STAMP(41);
 #ifdef MOM_DIAG_TWICE
-    elemental_build(c, a.q, m, a.nd, a.tau_sum[n], dtau, varpi, zpp, zmp);
+    elemental_build(c, a.q, m, a.nd, as_global(a.tau_sum)[n], dtau, varpi, zpp, zmp);
     MOM_STAMP(44);
 #endif
     expk = doubling_run<LDSM, KS>(c, a.nd, expk);

@@ -169,7 +169,7 @@ template <> struct lds_operand<ElP> { static constexpr bool value = true; };
 template <> struct lds_operand<ElSigP> { static constexpr bool value = true; };
 // element functor of an unpadded (global) array with bounds checks
 struct El {
-  const double *p; int ld, N;
+  const gdouble *p; int ld, N;
   __device__ __forceinline__ double operator()(int i, int j) const { return (i < N && j < N) ? p[i + j * ld] : 0.0; }
 };
 struct ElZero { __device__ __forceinline__ double operator()(int, int) const { return 0.0; } };
@@ -256,7 +256,7 @@ __device__ __forceinline__ double wg_sumsq_get(const Ctx &c) {
 
 // composite-layer pointers of one spectral point (column-major, ld = N)
 struct CompPtrs {
-  double *R_mp, *R_pm, *T_pp, *T_mm, *J0p, *J0m;
+  gdouble *R_mp, *R_pm, *T_pp, *T_mm, *J0p, *J0m;
 };
 
 }  // namespace MOM_NS
@@ -379,6 +379,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
       F2[e] = muj / (mui - muj);
     }
   __syncthreads();
+  MOM_STAMP(46);
   const int i_start = n * (q.imu0 - 1), i_end = n * q.imu0;
   double *ZS = c.P;  // mixed Z++ / Z-+ of the sun-block columns, [N x nS] each (P is free here)
   for (int e0 = wg_tid(); e0 < N * N; e0 += 8 * kThreads) {
@@ -433,6 +434,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
     }
   }
   __syncthreads();
+  MOM_STAMP(47);
   const double mus = c.mu[i_start];
   const double att = exp(-tau_sum / mus);
   for (int i = wg_tid(); i < N; i += kThreads) {
@@ -458,6 +460,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
     c.jm[i] = jm;
   }
   __syncthreads();
+  MOM_STAMP(48);
   if (N % 4 != 0) {  // P and Q served as table space: their K padding must read as zero again
     rezero_padding(c, c.P);
     rezero_padding(c, c.Q);
@@ -636,7 +639,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     wg_copy_mat(N, c.fd, g.T_mm, N, c.P, ld);
     wg_copy_mat(N, c.fd, g.T_pp, N, c.Q, ld);
     __syncthreads();
-    double *Tmm = g.T_mm, *Tpp = g.T_pp;
+    gdouble *Tmm = g.T_mm, *Tpp = g.T_pp;
     wg_gemm<false>(N, tmm, ElP{c.P, ld}, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
     wg_gemm<false>(N, ElP{t, ld}, ElP{c.Q, ld}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
   } else if ((IFACE < 0 || IFACE == 1) && iface == 1) {
@@ -655,7 +658,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     double *Q = c.Q, *P = c.P;
     wg_gemm<false>(N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
     __syncthreads();
-    double *Rmp = g.R_mp, *Rpm = g.R_pm, *Tpp = g.T_pp, *Tmm = g.T_mm;
+    gdouble *Rmp = g.R_mp, *Rpm = g.R_pm, *Tpp = g.T_pp, *Tmm = g.T_mm;
     wg_gemm<false>(N, ElP{Q, ld}, El{g.T_pp, N, N}, [=](int i, int j, double v) { Rmp[i + j * N] = v; });
     __syncthreads();
     wg_copy_mat(N, c.fd, g.T_pp, N, Q, ld);
@@ -683,7 +686,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       c.Jm[i] = c.Jm[i] + c.v1[i];
     }
     // T++ = t++ T++ ; T-- = T-- t-- ; R+- = (t++ R+-) t--       (:62-64)
-    double *Tpp = g.T_pp, *Tmm = g.T_mm, *Rpm = g.R_pm;
+    gdouble *Tpp = g.T_pp, *Tmm = g.T_mm, *Rpm = g.R_pm;
     wg_gemm<false>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
     __syncthreads();
     wg_copy_mat(N, c.fd, g.T_pp, N, Q, ld);
@@ -732,7 +735,8 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     }
     MOM_STAMP(14);
     {
-      double *P = c.P, *Q = c.Q, *Tmm = g.T_mm, *Rmp = g.R_mp;
+      double *P = c.P, *Q = c.Q;
+      gdouble *Tmm = g.T_mm, *Rmp = g.R_mp;
       // T-- = T01 t--                                           (:96)
       wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
       // Q = T01 r-+ (+ T01 v1)
@@ -805,7 +809,8 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     if (ride)  // J0+ = j0+ + T21 w (:110)
       for (int i = wg_tid(); i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.P[i + N * ld];
     {
-      double *P = c.P, *Q = c.Q, *Rpm = g.R_pm, *Tpp = g.T_pp;
+      double *P = c.P, *Q = c.Q;
+      gdouble *Rpm = g.R_pm, *Tpp = g.T_pp;
       // R+- = r+- + (T21 R+-) t--                              (:116)
       wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * N] = rpm(i, j) + v; });
       __syncthreads();

@@ -120,22 +120,22 @@ __device__ __forceinline__ void strip_store_lds(double *X, int lr, int lq, int c
   }
 }
 template <int KS>
-__device__ __forceinline__ void strip_load_glb(const double *__restrict__ X, int lr, int lq, int c0, bool colok,
+__device__ __forceinline__ void strip_load_glb(const gdouble *__restrict__ X, int lr, int lq, int c0, bool colok,
                                                d4 (&W)[StripGeom<KS>::NT]) {
   asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, N = 4 * KS;
-  const double *base = X + c0 + lr + lq * N;
+  const gdouble *base = X + c0 + lr + lq * N;
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS && colok) ? base[(16 * rt + 4 * r) * N] : 0.0;
 }
 template <int KS>
-__device__ __forceinline__ void strip_store_glb(double *__restrict__ X, int lr, int lq, int c0, bool colok,
+__device__ __forceinline__ void strip_store_glb(gdouble *__restrict__ X, int lr, int lq, int c0, bool colok,
                                                 const d4 (&W)[StripGeom<KS>::NT]) {
   asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, N = 4 * KS;
-  double *base = X + c0 + lr + lq * N;
+  gdouble *base = X + c0 + lr + lq * N;
   if (colok) {
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt)

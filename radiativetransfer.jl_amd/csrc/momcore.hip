@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(kThreads) k_op_elemental(OpArgs a) {
   const size_t NN = (size_t)N * N;
   for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
     const size_t zo = a.z_batch > 1 ? NN * pt : 0;
-    El zpp{a.Zpp + zo, N, N}, zmp{a.Zmp + zo, N, N};
+    El zpp{as_global(a.Zpp) + zo, N, N}, zmp{as_global(a.Zmp) + zo, N, N};
     elemental_build(c, a.q, a.m, a.nd, a.tau_sum[pt], a.dtau[pt], a.varpi[pt], zpp, zmp);
     // the reference leaves r+-/t-- untouched when nd >= 1 (elemental.jl:255-274)
     store_added(c, a.added, pt, a.nd < 1);
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(kThreads) k_op_interaction(OpArgs a) {
     load_added(c, a.added, pt);
     __syncthreads();
     CompPtrs g = comp_ptrs(a.comp, N, pt);
-    interaction_core<LDSM, -1>(c, a.iface, g, El{a.added[0] + NN * pt, N, N}, El{a.added[2] + NN * pt, N, N});
+    interaction_core<LDSM, -1>(c, a.iface, g, El{as_global(a.added[0]) + NN * pt, N, N}, El{as_global(a.added[2]) + NN * pt, N, N});
   }
   if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
 }
