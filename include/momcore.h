@@ -169,9 +169,12 @@ int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
  *   MOM_OPT_M0_REDUCTION  1 (default) = run Fourier moment 0 on the (I,Q) sub-problem when the scene allows
  *                         it (see mom_scene_set), 0 = always the full nStokes problem
  *   MOM_OPT_SMALL_WG      1 (default) = operators small enough for two LDS images per CU run in 4-wave
- *                         workgroups, two per CU; 0 = always 8-wave workgroups */
+ *                         workgroups, two per CU; 0 = always 8-wave workgroups
+ *   MOM_OPT_STAGGER       1 (default) = the persistent one-per-CU workgroups of the strip-chained kernels start
+ *                         with offsets spread over one unit time, so that the CUs' composite loads/stores do
+ *                         not all fall into the same microseconds; 0 = all start together */
 int mom_set_option(mom_t *h, int option, int value);
-enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1, MOM_OPT_M0_REDUCTION = 2, MOM_OPT_SMALL_WG = 3 };
+enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1, MOM_OPT_M0_REDUCTION = 2, MOM_OPT_SMALL_WG = 3, MOM_OPT_STAGGER = 4 };
 
 /* ---- Voigt line-by-line cross section --------------------------------------------------
  * compute_absorption_cross_section(model::HitranModel, grid, p, T)

@@ -11,6 +11,7 @@ struct LayerArgs {
   int S, M, K;      // M: number of moments in THIS launch; m_first: Fourier index of the first of them
   int m_first;
   int nd, iface, first;
+  int stagger;      // start offset step between CUs in 100 MHz ticks (persistent strip kernels), 0 = none
   const double *tau, *varpi, *zw, *tau_sum;  // slices of layer z: tau[n], varpi[n], zw[k + K*n], tau_sum[n]
   const double *Zpp, *Zmp;                   // [N,N,K,M] starting at moment m_first
   double *comp[6];                           // R_mp, R_pm, T_pp, T_mm [N,N,S,M]; J0p, J0m [N,S,M], from m_first
@@ -22,12 +23,10 @@ struct ZMix {
   const gdouble *base;  // Z[:,:,0,m]
   const gdouble *w;     // K weights of this point
   int K, N;
-  __device__ __forceinline__ double operator()(int i, int j) const {
-    double acc = 0.0;
-    const size_t NN = (size_t)N * N;
-    for (int k = 0; k < K; ++k) acc += w[k] * base[i + (size_t)j * N + NN * k];
-    return acc;
-  }
+  // Z(i,j) = sum_k w[k] Z_k(i,j), accumulated in k order (elemental_build walks the terms)
+  __device__ __forceinline__ int terms() const { return K; }
+  __device__ __forceinline__ double weight(int k) const { return w[k]; }
+  __device__ __forceinline__ double basis(int k, int i, int j) const { return base[i + (size_t)j * N + (size_t)N * N * k]; }
 };
 
 __device__ __forceinline__ CompPtrs comp_ptrs(double *const comp[6], int N, size_t pt) {
@@ -60,6 +59,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
 #endif
   wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
   MOM_STAMP(40);
+  if (KS > 0 && kWaves == 8 && a.stagger > 0) {
+    // persistent workgroups run identical units in lockstep, so every CU would store (and load) its composite
+    // blocks in the same microseconds and wait for the whole burst to drain; a start offset per CU (32 phases
+    // spread over about one unit time, chosen by the host) spreads that traffic over the unit period
+    const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)((blockIdx.x >> 3) & 31) * a.stagger;
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
   for (size_t pt = blockIdx.x; pt < total; pt += gridDim.x) {
     const int n = (int)(pt % a.S), mrel = (int)(pt / a.S), m = a.m_first + mrel;
     const double tau = as_global(a.tau)[n], varpi = as_global(a.varpi)[n];

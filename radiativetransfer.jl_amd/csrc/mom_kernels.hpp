@@ -171,6 +171,10 @@ template <> struct lds_operand<ElSigP> { static constexpr bool value = true; };
 struct El {
   const gdouble *p; int ld, N;
   __device__ __forceinline__ double operator()(int i, int j) const { return (i < N && j < N) ? p[i + j * ld] : 0.0; }
+  // as a phase-matrix source of elemental_build: one term of weight 1
+  __device__ __forceinline__ int terms() const { return 1; }
+  __device__ __forceinline__ double weight(int) const { return 1.0; }
+  __device__ __forceinline__ double basis(int, int i, int j) const { return p[i + j * ld]; }
 };
 struct ElZero { __device__ __forceinline__ double operator()(int, int) const { return 0.0; } };
 struct ElEye {
@@ -386,14 +390,26 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
     double zp[8], zm[8];
     int ii[8], jj[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {  // phase-matrix loads of 8 elements in flight together
+    for (int u = 0; u < 8; ++u) {
       const int e = e0 + u * kThreads;
-      if (e < N * N) {
-        c.fd.split(e, ii[u], jj[u]);
-        zp[u] = Zpp(ii[u], jj[u]);
-        zm[u] = Zmp(ii[u], jj[u]);
+      zp[u] = 0.0;
+      zm[u] = 0.0;
+      if (e < N * N) c.fd.split(e, ii[u], jj[u]);
+    }
+    // Z = sum_k w_k Z_k: the (run-time) sum over scatterer types is the OUTER loop, so the 16 basis loads of a
+    // term are in flight together -- one memory round trip per term instead of one per element and term
+    for (int k = 0; k < Zpp.terms(); ++k) {
+      const double wp = Zpp.weight(k), wm = Zmp.weight(k);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * kThreads;
+        if (e < N * N) {
+          zp[u] += wp * Zpp.basis(k, ii[u], jj[u]);
+          zm[u] += wm * Zmp.basis(k, ii[u], jj[u]);
+        }
       }
     }
+    MOM_STAMP(49);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = e0 + u * kThreads;
@@ -432,6 +448,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
         c.t[i + j * ld] = tt;
       }
     }
+    MOM_STAMP(57);
   }
   __syncthreads();
   MOM_STAMP(47);

@@ -274,6 +274,7 @@ struct mom_handle {
   // m = 0 reduction (see mom_scene_set)
   int opt_m0 = 1;
   int opt_w4 = 1;
+  int opt_stagger = 1;
   bool red0 = false;
   int N0 = 0, nS0 = 0;
   DevStreams q0{};
@@ -401,6 +402,7 @@ extern "C" int mom_set_option(mom_t *h, int option, int value) {
   if (option == MOM_OPT_INVERSE) { h->opt_inverse = value; h->q.inv_mode = value; }
   else if (option == MOM_OPT_M0_REDUCTION) h->opt_m0 = value;
   else if (option == MOM_OPT_SMALL_WG) h->opt_w4 = value;
+  else if (option == MOM_OPT_STAGGER) h->opt_stagger = value;
   else if (option == MOM_OPT_FORCE_GENERIC) {
     h->opt_force_generic = value;
     h->lds_mode = (h->N <= 64) && !value;
@@ -792,7 +794,12 @@ extern "C" int mom_rt_run(mom_t *h) {
     }
     const size_t sm = lds_bytes(q.N, lds);
     if (lds && (q.N == 52 || q.N == 56 || q.N == 60)) {  // strip-chained kernels (momcore_strip.hip), one image per N
-      // persistent workgroups, one per CU (only one 135 KB LDS image fits a CU): the prologue is paid once
+      // persistent workgroups, one per CU (only one 135 KB LDS image fits a CU): the prologue is paid once;
+      // their start is staggered over about one unit time (~ (44 + 17 nd) us at N = 60)
+      if (S * Mcount >= 8 * (size_t)h->num_cu && h->opt_stagger) {
+        const double f = (double)q.N / 60.0, unit_us = f * f * f * (44.0 + 17.0 * a.nd);
+        a.stagger = (int)(unit_us * 100.0 / 32.0);
+      }
       const int grid = (int)std::min<size_t>(S * Mcount, (size_t)h->num_cu);
       HIPCHK(h, (q.N == 60 ? mom_strip15_launch_layer : q.N == 56 ? mom_strip14_launch_layer : mom_strip13_launch_layer)(
                     &a, a.iface, grid, sm, h->stream));
