@@ -398,14 +398,35 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
     }
     // Z = sum_k w_k Z_k: the (run-time) sum over scatterer types is the OUTER loop, so the 16 basis loads of a
     // term are in flight together -- one memory round trip per term instead of one per element and term
-    for (int k = 0; k < Zpp.terms(); ++k) {
-      const double wp = Zpp.weight(k), wm = Zmp.weight(k);
+    if (Zpp.terms() == 2) {  // Rayleigh + one aerosol type: all 32 loads of both terms in one round trip
+      const double wp0 = Zpp.weight(0), wm0 = Zmp.weight(0), wp1 = Zpp.weight(1), wm1 = Zmp.weight(1);
+      double bp0[8], bm0[8], bp1[8], bm1[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + u * kThreads;
-        if (e < N * N) {
-          zp[u] += wp * Zpp.basis(k, ii[u], jj[u]);
-          zm[u] += wm * Zmp.basis(k, ii[u], jj[u]);
+      for (int u = 0; u < 8; ++u)
+        if (e0 + u * kThreads < N * N) {
+          bp0[u] = Zpp.basis(0, ii[u], jj[u]);
+          bm0[u] = Zmp.basis(0, ii[u], jj[u]);
+          bp1[u] = Zpp.basis(1, ii[u], jj[u]);
+          bm1[u] = Zmp.basis(1, ii[u], jj[u]);
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + u * kThreads < N * N) {
+          zp[u] += wp0 * bp0[u];
+          zm[u] += wm0 * bm0[u];
+          zp[u] += wp1 * bp1[u];
+          zm[u] += wm1 * bm1[u];
+        }
+    } else {
+      for (int k = 0; k < Zpp.terms(); ++k) {
+        const double wp = Zpp.weight(k), wm = Zmp.weight(k);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * kThreads;
+          if (e < N * N) {
+            zp[u] += wp * Zpp.basis(k, ii[u], jj[u]);
+            zm[u] += wm * Zmp.basis(k, ii[u], jj[u]);
+          }
         }
       }
     }
@@ -857,10 +878,10 @@ __device__ __forceinline__ void store_added_as_composite(const Ctx &c, const Com
     int i, j;
     c.fd.split(e, i, j);
     const double rv = c.r[i + j * ld], tv = c.t[i + j * ld], s = c.sg[i] * c.sg[j];
-    g.R_mp[e] = rv;
-    g.R_pm[e] = s * rv;
-    g.T_pp[e] = tv;
-    g.T_mm[e] = s * tv;
+    __builtin_nontemporal_store(rv, g.R_mp + e);  // streaming: see MOM_NT_STORE in mom_strip.hpp
+    __builtin_nontemporal_store(s * rv, g.R_pm + e);
+    __builtin_nontemporal_store(tv, g.T_pp + e);
+    __builtin_nontemporal_store(s * tv, g.T_mm + e);
   }
   for (int i = wg_tid(); i < N; i += kThreads) {
     g.J0p[i] = c.jp[i];

@@ -29,6 +29,16 @@ static_assert(MOM_STRIP_MAXP <= 12, "neumann_terms_12 covers p <= 12");
 constexpr int kStripMaxP = MOM_STRIP_MAXP;  // series terms up to which the Horner chain beats squaring through LDS
 constexpr int kStripGroups = kWaves / 4;
 
+// composite blocks are touched once per launch: streaming (non-temporal) accesses keep them from evicting the
+// phase-matrix bases, which every unit re-reads, from L2
+#ifndef MOM_NO_NT
+#define MOM_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define MOM_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define MOM_NT_LOAD(p) (*(p))
+#define MOM_NT_STORE(v, p) (*(p) = (v))
+#endif
+
 template <int KS>
 struct StripGeom {
   static constexpr int N = 4 * KS;
@@ -128,7 +138,7 @@ __device__ __forceinline__ void strip_load_glb(const gdouble *__restrict__ X, in
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS && colok) ? base[(16 * rt + 4 * r) * N] : 0.0;
+    for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS && colok) ? MOM_NT_LOAD(base + (16 * rt + 4 * r) * N) : 0.0;
 }
 template <int KS>
 __device__ __forceinline__ void strip_store_glb(gdouble *__restrict__ X, int lr, int lq, int c0, bool colok,
@@ -141,7 +151,7 @@ __device__ __forceinline__ void strip_store_glb(gdouble *__restrict__ X, int lr,
     for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (4 * rt + r < KS) base[(16 * rt + 4 * r) * N] = W[rt][r];
+        if (4 * rt + r < KS) MOM_NT_STORE(W[rt][r], base + (16 * rt + 4 * r) * N);
   }
 }
 
@@ -297,8 +307,8 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
         if (e < NN) {
           int i, j;
           c.fd.split(e, i, j);
-          vr[u] = g.R_pm[e];
-          vt[u] = g.T_pp[e];
+          vr[u] = MOM_NT_LOAD(g.R_pm + e);
+          vt[u] = MOM_NT_LOAD(g.T_pp + e);
           o[u] = i + j * LD;
         }
       }
