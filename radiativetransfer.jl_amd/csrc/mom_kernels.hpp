@@ -365,6 +365,24 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   fq.init(Nq);
   // per stream pair (iq, jq): E = 1 - exp(..), F1 = mu_j/(mu_i+mu_j), F2 = mu_j/(mu_i-mu_j); the Q buffer is free here
   double *E = c.Q, *F1 = c.Q + Nq * Nq, *F2 = c.Q + 2 * Nq * Nq;
+  // two-term phase matrices (Rayleigh + one aerosol type): the 32 basis loads of this thread's first 8 elements go
+  // out before the tables are built and are consumed after them
+  const int e_first = wg_tid();
+  const bool pre = Zpp.terms() == 2;
+  double bp0[8], bm0[8], bp1[8], bm1[8];
+  int ii[8], jj[8];
+  auto issue_z2 = [&](int e0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + u * kThreads < N * N) {
+        c.fd.split(e0 + u * kThreads, ii[u], jj[u]);
+        bp0[u] = Zpp.basis(0, ii[u], jj[u]);
+        bm0[u] = Zmp.basis(0, ii[u], jj[u]);
+        bp1[u] = Zpp.basis(1, ii[u], jj[u]);
+        bm1[u] = Zmp.basis(1, ii[u], jj[u]);
+      }
+  };
+  if (pre) issue_z2(e_first);
   for (int i = wg_tid(); i < N; i += kThreads) {
     c.ei[i] = exp(-dtau / c.mu[i]);
     c.v1[i] = c.wt[i] / wdiv;   // wct
@@ -386,29 +404,17 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   MOM_STAMP(46);
   const int i_start = n * (q.imu0 - 1), i_end = n * q.imu0;
   double *ZS = c.P;  // mixed Z++ / Z-+ of the sun-block columns, [N x nS] each (P is free here)
-  for (int e0 = wg_tid(); e0 < N * N; e0 += 8 * kThreads) {
+  for (int e0 = e_first; e0 < N * N; e0 += 8 * kThreads) {
     double zp[8], zm[8];
-    int ii[8], jj[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u * kThreads;
       zp[u] = 0.0;
       zm[u] = 0.0;
-      if (e < N * N) c.fd.split(e, ii[u], jj[u]);
     }
-    // Z = sum_k w_k Z_k: the (run-time) sum over scatterer types is the OUTER loop, so the 16 basis loads of a
-    // term are in flight together -- one memory round trip per term instead of one per element and term
-    if (Zpp.terms() == 2) {  // Rayleigh + one aerosol type: all 32 loads of both terms in one round trip
+    // Z = sum_k w_k Z_k, accumulated in k order
+    if (pre) {
+      if (e0 != e_first) issue_z2(e0);
       const double wp0 = Zpp.weight(0), wm0 = Zmp.weight(0), wp1 = Zpp.weight(1), wm1 = Zmp.weight(1);
-      double bp0[8], bm0[8], bp1[8], bm1[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (e0 + u * kThreads < N * N) {
-          bp0[u] = Zpp.basis(0, ii[u], jj[u]);
-          bm0[u] = Zmp.basis(0, ii[u], jj[u]);
-          bp1[u] = Zpp.basis(1, ii[u], jj[u]);
-          bm1[u] = Zmp.basis(1, ii[u], jj[u]);
-        }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
         if (e0 + u * kThreads < N * N) {
@@ -418,6 +424,10 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
           zm[u] += wm1 * bm1[u];
         }
     } else {
+      // the (run-time) sum over scatterer types is the OUTER loop: the 16 basis loads of a term are in flight together
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + u * kThreads < N * N) c.fd.split(e0 + u * kThreads, ii[u], jj[u]);
       for (int k = 0; k < Zpp.terms(); ++k) {
         const double wp = Zpp.weight(k), wm = Zmp.weight(k);
 #pragma unroll
