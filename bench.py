@@ -120,7 +120,7 @@ def main():
         # interaction runs in k_surface): GEMM = 2N^3, inverse = 2N^3, matvec = 2N^2 -- the reference's op list
         # on the FULL N x N operators, whatever the kernels do internally (Neumann series, m = 0 sub-problem)
         f_pm = (nd.sum() * (12 * N ** 3 + 8 * N ** 2) + (scene.Nz - 1) * (24 * N ** 3 + 8 * N ** 2) + scene.Nz * N * N * 15)
-        # dominant kernel = the full-problem layer kernel mom::k_layer<true, 3>; it handles moments 1..M-1 when
+        # dominant kernel = the full-problem layer kernel mom::k_layer<true, 3, 15> (strip-chained, N = 60); it handles moments 1..M-1 when
         # moment 0 runs as the (I,Q) sub-problem in mom4::k_layer (reduced_launches > 0), else all M moments
         m_dom = (M - 1) if tm["reduced_launches"] > 0 else M
         flop_dom = f_pm * m_dom * S_loc
@@ -140,7 +140,7 @@ def main():
                        "sharding": f"spectral axis, {world} x {S_loc} points, RCCL all_gather of R/T" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "mom::k_layer<true, 3>", "avg_launch_ms": tm["full_layers_ms"] / max(tm["full_launches"], 1),
+                         "kernel": "mom::k_layer<true, 3, 15>", "avg_launch_ms": tm["full_layers_ms"] / max(tm["full_launches"], 1),
                          "launches_per_step": tm["full_launches"], "moments_per_launch": m_dom,
                          "algorithmic_flop_per_avg_launch": flop_dom / max(tm["full_launches"], 1),
                          "all_layer_kernels_achieved": whole, "all_layer_kernels_frac": whole / PEAK_FP64_MFMA_TFLOPS},

@@ -328,6 +328,23 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
   __syncthreads();
   MOM_STAMP(51);
   MOM_STAMP4(91);
+  // B = r-+ R+- on strips (B^T strip = R+-^T (r-+^T strip)) by the chain-1 waves while the chain-2 waves form W0;
+  // both read R+- in P, which B then replaces (after the barrier), with ||B||_F^2 for the series length
+  d4 Bs[NT];
+  double ss = 0.0;
+  if (do1) {
+    d4 rT[NT];
+    strip_load_lds<KS>(r, lr, lq, c0, rT);
+    strip_zero(Bs);
+    strip_mul<KS>(P, lr, lq, rT, Bs);
+    if (colok) {
+#pragma unroll
+      for (int rt = 0; rt < NT; ++rt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          if (4 * rt + rr < KS) ss += Bs[rt][rr] * Bs[rt][rr];
+    }
+  }
   if (do2) {
     d4 tT[NT];
     strip_load_lds<KS>(t, lr, lq, c0, tT);
@@ -335,16 +352,10 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
     strip_mul<KS>(P, lr, lq, tT, W0);
   }
   MOM_STAMP4(92);
-  {
-    // B = r-+ R+- over R+- in place (tiles held in registers across the barrier), ||B||_F^2
-    double ss = 0.0;
-    wg_gemm_nc<true>(N, N, ElP{r, LD}, ElP{P, LD}, [=, &ss](int i, int j, double v) {
-      P[i + j * LD] = v;
-      ss += v * v;
-    });
-    wg_sumsq_put(c, ss);
-  }
   MOM_STAMP(52);
+  __syncthreads();
+  if (do1) strip_store_lds<KS>(P, lr, lq, c0, colok, Bs);
+  wg_sumsq_put(c, ss);
   __syncthreads();
   MOM_STAMP(53);
   MOM_STAMP4(93);

@@ -33,7 +33,7 @@ if "FETCH_SIZE" in kl and "WRITE_SIZE" in kl:
     (out / "traffic.json").write_text(json.dumps({
         "round": rnd, "k_layer_hbm_bytes_per_launch": 2 * rd_raw + wr, "fetch_bytes_raw": rd_raw,
         "fetch_bytes_corrected_x2": 2 * rd_raw, "write_bytes": wr,
-        "note": "mean over the 40 launches of mom::k_layer<true, 3> in one bench step (S=10000, moments 1-2); FETCH_SIZE doubled per MI355X_MICROARCH.md"}, indent=1))
+        "note": "mean over the 40 launches of mom::k_layer<true, 3, 15> in one bench step (S=10000, moments 1-2); FETCH_SIZE doubled per MI355X_MICROARCH.md"}, indent=1))
 for f in ("bench.json", "bench_under_rocprof.json"):
     p = ROOT / "gpurun_out" / f"{rnd}_{f}"
     if p.exists(): shutil.copy(p, out / f"{rnd}_{f}")
