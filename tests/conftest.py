@@ -26,5 +26,5 @@ def rtamd():
     import subprocess
     import rtamd as pkg
     if not pkg._lib.LIB_PATH.exists():  # normally built in-tree by __graft_entry__.build(); hipcc is in the image
-        subprocess.check_call(["make", "-C", str(ROOT / "radiativetransfer.jl_amd" / "csrc")])
+        subprocess.check_call(["make", "-C", str(ROOT / "radiativetransfer.jl_amd" / "csrc"), "-j8"])
     return pkg

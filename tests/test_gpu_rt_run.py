@@ -68,6 +68,26 @@ def test_strip_chains_thick_layers_fall_back(rtamd, cref):
     helpers.assert_stokes_close(T, Tr, what="T thick")
 
 
+def test_launch_shape_options_do_not_change_results(rtamd, cref):
+    """MOM_OPT_STAGGER only delays workgroup starts and MOM_OPT_SMALL_WG only picks the workgroup shape: the
+    staggered run is bitwise the default run, the 8-wave run of the m = 0 sub-problem agrees to rounding."""
+    m = rtamd.scenes.make_scene(3, 33, 6, 2400, seed=8)   # N = 60, enough units for the persistent grid to stagger
+    sc = rtamd.prepare_scene(m)
+    out = {}
+    for key, opt, val in (("default", None, None), ("nostagger", rtamd._lib.MOM_OPT_STAGGER, 0),
+                          ("wg8", rtamd._lib.MOM_OPT_SMALL_WG, 0)):
+        with rtamd.corert.make_handle(m) as h:
+            if opt is not None:
+                h.set_option(opt, val)
+            out[key] = rtamd.corert.run_scene(h, sc)
+    np.testing.assert_array_equal(out["default"][0], out["nostagger"][0])
+    np.testing.assert_array_equal(out["default"][1], out["nostagger"][1])
+    helpers.assert_stokes_close(out["wg8"][0], out["default"][0], rtol=1e-11, what="8-wave vs 4-wave m = 0")
+    pts = np.arange(0, 2400, 300)
+    Rr, Tr = _oracle(cref, m, pts=pts)
+    helpers.assert_stokes_close(out["default"][0][:, :, pts], Rr[:, :, pts], what="R")
+
+
 @pytest.mark.parametrize("strict", [True, False])
 def test_rt_run_iquv_indexing_switch(rtamd, cref, strict):
     m = rtamd.scenes.make_scene(4, 9, 4, 8, seed=9, vaz=(90.0, 10.0, 170.0))
