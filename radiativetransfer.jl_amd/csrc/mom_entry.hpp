@@ -29,15 +29,17 @@ struct ZMix {
   __device__ __forceinline__ double basis(int k, int i, int j) const { return base[i + (size_t)j * N + (size_t)N * N * k]; }
 };
 
-__device__ __forceinline__ CompPtrs comp_ptrs(double *const comp[6], int N, size_t pt) {
-  const size_t NN = (size_t)N * N;
+// pitch: row pitch of the matrix blocks (N for the operator-level arrays, comp_pitch(N) for the scene-level state)
+__device__ __forceinline__ CompPtrs comp_ptrs(double *const comp[6], int N, int pitch, size_t pt) {
+  const size_t blk = (size_t)pitch * N;
   CompPtrs g;
-  g.R_mp = as_global(comp[0]) + NN * pt;
-  g.R_pm = as_global(comp[1]) + NN * pt;
-  g.T_pp = as_global(comp[2]) + NN * pt;
-  g.T_mm = as_global(comp[3]) + NN * pt;
+  g.R_mp = as_global(comp[0]) + blk * pt;
+  g.R_pm = as_global(comp[1]) + blk * pt;
+  g.T_pp = as_global(comp[2]) + blk * pt;
+  g.T_mm = as_global(comp[3]) + blk * pt;
   g.J0p = as_global(comp[4]) + (size_t)N * pt;
   g.J0m = as_global(comp[5]) + (size_t)N * pt;
+  g.ld = pitch;
   return g;
 }
 
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
 #endif
     expk = doubling_run<LDSM, KS>(c, a.nd, expk);
     MOM_STAMP(30);
-    CompPtrs g = comp_ptrs(a.comp, N, pt);
+    CompPtrs g = comp_ptrs(a.comp, N, comp_pitch(N), pt);
     if (a.first) {
       store_added_as_composite(c, g);
       __syncthreads();
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_surface(SurfArgs a) {
       c.jm[i] = (i % n == 0) ? (a.q.mu0 * (rho * a.q.I0[0])) * att : 0.0;  // :56
     }
     __syncthreads();
-    CompPtrs g = comp_ptrs(a.comp, N, pt);
+    CompPtrs g = comp_ptrs(a.comp, N, comp_pitch(N), pt);
     interaction_core<LDSM, -1>(c, a.iface, g, ElZero{}, ElEye{N});
     // interaction_hdrf! (CoreKernel/interaction_hdrf.jl:9-45): hdr_J0- = r-+_surf J0+ + j0-_surf with the
     // composite J0+ AFTER the surface interaction (still in c.Jp), then the m = 0 flux sums of the BHR

@@ -261,7 +261,13 @@ __device__ __forceinline__ double wg_sumsq_get(const Ctx &c) {
 // composite-layer pointers of one spectral point (column-major, ld = N)
 struct CompPtrs {
   gdouble *R_mp, *R_pm, *T_pp, *T_mm, *J0p, *J0m;
+  int ld;  // row pitch of the four matrix blocks (column-major, N columns): N in the operator-level arrays,
+           // comp_pitch(N) in the scene-level composite state
 };
+// The scene-level composite blocks use a row pitch of a whole number of 128-byte lines: the strip chains store
+// 16-double (128-byte) column segments straight from the accumulators, and with the natural pitch N three
+// quarters of them would straddle two cache lines (partial-line HBM writes).
+__host__ __device__ inline int comp_pitch(int N) { return 16 * ((N + 15) / 16); }
 
 }  // namespace MOM_NS
 #include "mom_strip.hpp"
@@ -661,7 +667,7 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
 template <bool LDSM, int IFACE, int KS = 0, class FRPM, class FTMM>
 __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const CompPtrs &g, FRPM rpm, FTMM tmm) {
   const int iface = (IFACE >= 0) ? IFACE : iface_rt;
-  const int N = c.N, ld = c.ld;
+  const int N = c.N, ld = c.ld, cl = g.ld;
   double *r = c.r, *t = c.t;
   if constexpr (LDSM && KS > 0 && std::is_same<FRPM, ElSigP>::value && std::is_same<FTMM, ElSigP>::value) {
     // ScatteringInterface_11 with r+- = D r-+ D, t-- = D t++ D of the layer held in c.r, c.t: two strip chains
@@ -678,20 +684,20 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
   if ((IFACE < 0 || IFACE == 0) && iface == 0) {
     // J0+ = j0+ + t++ J0+ ; J0- = J0- + T-- j0-            (interaction.jl:16-17)
     wg_matvec(c, ElP{t, ld}, c.Jp, c.v1);
-    wg_matvec(c, El{g.T_mm, N, N}, c.jm, c.v2);
+    wg_matvec(c, El{g.T_mm, cl, N}, c.jm, c.v2);
     for (int i = wg_tid(); i < N; i += kThreads) {
       c.Jp[i] = c.jp[i] + c.v1[i];
       c.Jm[i] = c.Jm[i] + c.v2[i];
     }
     // T-- = t-- T-- ; T++ = t++ T++                          (:20-21)
-    wg_copy_mat(N, c.fd, g.T_mm, N, c.P, ld);
-    wg_copy_mat(N, c.fd, g.T_pp, N, c.Q, ld);
+    wg_copy_mat(N, c.fd, g.T_mm, cl, c.P, ld);
+    wg_copy_mat(N, c.fd, g.T_pp, cl, c.Q, ld);
     __syncthreads();
     gdouble *Tmm = g.T_mm, *Tpp = g.T_pp;
-    wg_gemm<false>(N, tmm, ElP{c.P, ld}, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
-    wg_gemm<false>(N, ElP{t, ld}, ElP{c.Q, ld}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
+    wg_gemm<false>(N, tmm, ElP{c.P, ld}, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
+    wg_gemm<false>(N, ElP{t, ld}, ElP{c.Q, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
   } else if ((IFACE < 0 || IFACE == 1) && iface == 1) {
-    wg_copy_mat(N, c.fd, g.T_mm, N, c.P, ld);  // P = T--
+    wg_copy_mat(N, c.fd, g.T_mm, cl, c.P, ld);  // P = T--
     // J0- = J0- + T-- (r-+ J0+ + j0-) ; J0+ = j0+ + t++ J0+  (:36-37)
     wg_matvec(c, ElP{r, ld}, c.Jp, c.v1);
     for (int i = wg_tid(); i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
@@ -707,21 +713,21 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     wg_gemm<false>(N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
     __syncthreads();
     gdouble *Rmp = g.R_mp, *Rpm = g.R_pm, *Tpp = g.T_pp, *Tmm = g.T_mm;
-    wg_gemm<false>(N, ElP{Q, ld}, El{g.T_pp, N, N}, [=](int i, int j, double v) { Rmp[i + j * N] = v; });
+    wg_gemm<false>(N, ElP{Q, ld}, El{g.T_pp, cl, N}, [=](int i, int j, double v) { Rmp[i + j * cl] = v; });
     __syncthreads();
-    wg_copy_mat(N, c.fd, g.T_pp, N, Q, ld);
+    wg_copy_mat(N, c.fd, g.T_pp, cl, Q, ld);
     __syncthreads();
-    wg_gemm<false>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
-    wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
+    wg_gemm<false>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
+    wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
     for (int e = wg_tid(); e < N * N; e += kThreads) {
       int i, j;
       c.fd.split(e, i, j);
-      Rpm[i + j * N] = rpm(i, j);
+      Rpm[i + j * cl] = rpm(i, j);
     }
   } else if ((IFACE < 0 || IFACE == 2) && iface == 2) {
     double *P = c.P, *Q = c.Q;
-    wg_copy_mat(N, c.fd, g.R_pm, N, P, ld);  // P = R+-
-    wg_copy_mat(N, c.fd, g.T_mm, N, Q, ld);  // Q = T--
+    wg_copy_mat(N, c.fd, g.R_pm, cl, P, ld);  // P = R+-
+    wg_copy_mat(N, c.fd, g.T_mm, cl, Q, ld);  // Q = T--
     __syncthreads();
     // J0+ = j0+ + t++ (J0+ + R+- j0-) ; J0- = J0- + T-- j0-   (:58-59)
     wg_matvec(c, ElP{P, ld}, c.jm, c.v1);
@@ -735,22 +741,22 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     }
     // T++ = t++ T++ ; T-- = T-- t-- ; R+- = (t++ R+-) t--       (:62-64)
     gdouble *Tpp = g.T_pp, *Tmm = g.T_mm, *Rpm = g.R_pm;
-    wg_gemm<false>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
+    wg_gemm<false>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
     __syncthreads();
-    wg_copy_mat(N, c.fd, g.T_pp, N, Q, ld);
+    wg_copy_mat(N, c.fd, g.T_pp, cl, Q, ld);
     __syncthreads();
-    wg_gemm<false>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
+    wg_gemm<false>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
     __syncthreads();
     wg_gemm<false>(N, ElP{t, ld}, ElP{P, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
     __syncthreads();
-    wg_gemm<false>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * N] = v; });
+    wg_gemm<false>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * cl] = v; });
   } else if ((IFACE < 0 || IFACE == 3) && iface == 3) {
     // ---- ScatteringInterface_11 (interaction.jl:69-117)
     // The four mat-vec products ride as column N of the B operands when the buffers have a spare
     // column in the last tile and no K padding (see doubling_run).
     const bool ride = (N % 4 == 0) && (c.nc - N >= 1);
     MOM_STAMP(10);
-    wg_copy_mat(N, c.fd, g.R_pm, N, c.P, ld);  // P = R+-
+    wg_copy_mat(N, c.fd, g.R_pm, cl, c.P, ld);  // P = R+-
     if (ride)
       for (int i = wg_tid(); i < N; i += kThreads) c.P[i + N * ld] = c.Jp[i];
     __syncthreads();
@@ -771,7 +777,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
         for (int i = wg_tid(); i < N; i += kThreads) r[i + N * ld] = Q[i + N * ld] + c.jm[i];
     }
     MOM_STAMP(12);
-    times_inv<LDSM>(c, El{g.T_mm, N, N}, c.Q, c.P, beta2);
+    times_inv<LDSM>(c, El{g.T_mm, cl, N}, c.Q, c.P, beta2);
     MOM_STAMP(13);
     if (!ride) {
       // J0- = J0- + T01 (r-+ J0+ + j0-)                          (:90)
@@ -786,7 +792,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       double *P = c.P, *Q = c.Q;
       gdouble *Tmm = g.T_mm, *Rmp = g.R_mp;
       // T-- = T01 t--                                           (:96)
-      wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * N] = v; });
+      wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
       // Q = T01 r-+ (+ T01 v1)
       wg_gemm_nc<false>(N, ride ? N + 1 : N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
       __syncthreads();
@@ -796,14 +802,14 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
           c.Jm[i] = c.Jm[i] + Q[i + N * ld];
           r[i + N * ld] = c.jm[i];
         }
-      wg_copy_mat(N, c.fd, g.T_pp, N, P, ld);  // P = T++ (old)
+      wg_copy_mat(N, c.fd, g.T_pp, cl, P, ld);  // P = T++ (old)
       __syncthreads();
       MOM_STAMP(16);
       // R-+ = R-+ + (T01 r-+) T++                              (:93)
-      wg_gemm<false>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Rmp[i + j * N] = Rmp[i + j * N] + v; });
+      wg_gemm<false>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Rmp[i + j * cl] = Rmp[i + j * cl] + v; });
       __syncthreads();
       MOM_STAMP(17);
-      wg_copy_mat(N, c.fd, g.R_pm, N, Q, ld);  // Q = R+- (old)
+      wg_copy_mat(N, c.fd, g.R_pm, cl, Q, ld);  // Q = R+- (old)
       __syncthreads();
       MOM_STAMP(18);
     }
@@ -835,7 +841,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       for (int i = wg_tid(); i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.v2[i];
     }
     MOM_STAMP(21);
-    wg_copy_mat(N, c.fd, g.R_pm, N, c.P, ld);  // P = R+- (old)
+    wg_copy_mat(N, c.fd, g.R_pm, cl, c.P, ld);  // P = R+- (old)
     if (ride)
       for (int i = wg_tid(); i < N; i += kThreads) c.P[i + N * ld] = c.j1p[i];
     __syncthreads();
@@ -860,16 +866,16 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       double *P = c.P, *Q = c.Q;
       gdouble *Rpm = g.R_pm, *Tpp = g.T_pp;
       // R+- = r+- + (T21 R+-) t--                              (:116)
-      wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * N] = rpm(i, j) + v; });
+      wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * cl] = rpm(i, j) + v; });
       __syncthreads();
       MOM_STAMP(24);
       if (ride)
         for (int i = wg_tid(); i < N; i += kThreads) { P[i + N * ld] = 0.0; r[i + N * ld] = 0.0; Q[i + N * ld] = 0.0; }
-      wg_copy_mat(N, c.fd, g.T_pp, N, P, ld);  // P = T++ (old)
+      wg_copy_mat(N, c.fd, g.T_pp, cl, P, ld);  // P = T++ (old)
       __syncthreads();
       MOM_STAMP(25);
       // T++ = T21 T++                                          (:113)
-      wg_gemm<false>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Tpp[i + j * N] = v; });
+      wg_gemm<false>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
     }
   }
   __syncthreads();
@@ -888,10 +894,11 @@ __device__ __forceinline__ void store_added_as_composite(const Ctx &c, const Com
     int i, j;
     c.fd.split(e, i, j);
     const double rv = c.r[i + j * ld], tv = c.t[i + j * ld], s = c.sg[i] * c.sg[j];
-    __builtin_nontemporal_store(rv, g.R_mp + e);  // streaming: see MOM_NT_STORE in mom_strip.hpp
-    __builtin_nontemporal_store(s * rv, g.R_pm + e);
-    __builtin_nontemporal_store(tv, g.T_pp + e);
-    __builtin_nontemporal_store(s * tv, g.T_mm + e);
+    const int o = i + j * g.ld;
+    __builtin_nontemporal_store(rv, g.R_mp + o);  // streaming: see MOM_NT_STORE in mom_strip.hpp
+    __builtin_nontemporal_store(s * rv, g.R_pm + o);
+    __builtin_nontemporal_store(tv, g.T_pp + o);
+    __builtin_nontemporal_store(s * tv, g.T_mm + o);
   }
   for (int i = wg_tid(); i < N; i += kThreads) {
     g.J0p[i] = c.jp[i];

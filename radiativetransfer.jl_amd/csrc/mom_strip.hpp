@@ -44,6 +44,7 @@ struct StripGeom {
   static constexpr int N = 4 * KS;
   static constexpr int NT = (N + 15) / 16;
   static constexpr int LD = 16 * NT + 2;
+  static constexpr int CP = 16 * NT;               // row pitch of the scene-level composite blocks (comp_pitch)
   static constexpr int RT = KS >> 2, RR = KS & 3;  // tile / register of rows N (lanes lq == 0) and N+1 (lq == 1)
 };
 
@@ -133,25 +134,25 @@ template <int KS>
 __device__ __forceinline__ void strip_load_glb(const gdouble *__restrict__ X, int lr, int lq, int c0, bool colok,
                                                d4 (&W)[StripGeom<KS>::NT]) {
   asm volatile("" : "+v"(lr), "+v"(lq));
-  constexpr int NT = StripGeom<KS>::NT, N = 4 * KS;
-  const gdouble *base = X + c0 + lr + lq * N;
+  constexpr int NT = StripGeom<KS>::NT, CP = StripGeom<KS>::CP;
+  const gdouble *base = X + c0 + lr + lq * CP;
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS && colok) ? MOM_NT_LOAD(base + (16 * rt + 4 * r) * N) : 0.0;
+    for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS && colok) ? MOM_NT_LOAD(base + (16 * rt + 4 * r) * CP) : 0.0;
 }
 template <int KS>
 __device__ __forceinline__ void strip_store_glb(gdouble *__restrict__ X, int lr, int lq, int c0, bool colok,
                                                 const d4 (&W)[StripGeom<KS>::NT]) {
   asm volatile("" : "+v"(lr), "+v"(lq));
-  constexpr int NT = StripGeom<KS>::NT, N = 4 * KS;
-  gdouble *base = X + c0 + lr + lq * N;
+  constexpr int NT = StripGeom<KS>::NT, CP = StripGeom<KS>::CP;
+  gdouble *base = X + c0 + lr + lq * CP;
   if (colok) {
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (4 * rt + r < KS) MOM_NT_STORE(W[rt][r], base + (16 * rt + 4 * r) * N);
+        if (4 * rt + r < KS) MOM_NT_STORE(W[rt][r], base + (16 * rt + 4 * r) * CP);
   }
 }
 
@@ -307,8 +308,8 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
         if (e < NN) {
           int i, j;
           c.fd.split(e, i, j);
-          vr[u] = MOM_NT_LOAD(g.R_pm + e);
-          vt[u] = MOM_NT_LOAD(g.T_pp + e);
+          vr[u] = MOM_NT_LOAD(g.R_pm + i + j * G::CP);
+          vt[u] = MOM_NT_LOAD(g.T_pp + i + j * G::CP);
           o[u] = i + j * LD;
         }
       }

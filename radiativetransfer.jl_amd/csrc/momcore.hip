@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(kThreads) k_op_interaction(OpArgs a) {
   for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
     load_added(c, a.added, pt);
     __syncthreads();
-    CompPtrs g = comp_ptrs(a.comp, N, pt);
+    CompPtrs g = comp_ptrs(a.comp, N, N, pt);  // operator-level arrays: natural pitch
     interaction_core<LDSM, -1>(c, a.iface, g, El{as_global(a.added[0]) + NN * pt, N, N}, El{as_global(a.added[2]) + NN * pt, N, N});
   }
   if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
@@ -347,10 +347,12 @@ extern "C" int mom_create(mom_t **out, int device, int N, int nStokes, int S, in
     const size_t per = (k < 4) ? NN : (size_t)N;
     HIPCHK(h, dmalloc(&h->added[k], per * S));
     HIPCHK(h, dmalloc(&h->surf[k], per * S));
-    HIPCHK(h, dmalloc(&h->comp[k], per * S * max_m));
+    // composite blocks: room for the scene-level row pitch (comp_pitch); the operator-level API uses the natural one
+    const size_t perc = (k < 4) ? (size_t)comp_pitch(N) * N : (size_t)N;
+    HIPCHK(h, dmalloc(&h->comp[k], perc * S * max_m));
     HIPCHK(h, hipMemsetAsync(h->added[k], 0, per * S * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(h->surf[k], 0, per * S * sizeof(double), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->comp[k], 0, per * S * max_m * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->comp[k], 0, perc * S * max_m * sizeof(double), h->stream));
   }
   for (int k = 0; k < 4; ++k) HIPCHK(h, dmalloc(&h->d_vec[k], S));
   HIPCHK(h, dmalloc(&h->d_info, 1));
@@ -731,7 +733,7 @@ extern "C" int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, 
       if ((rc = upload_new(h, &h->d_Zpp0, zp.data(), zp.size()))) return rc;
       if ((rc = upload_new(h, &h->d_Zmp0, zm.data(), zm.size()))) return rc;
       for (int k = 0; k < 6; ++k) {
-        const size_t cnt = ((k < 4) ? (size_t)N0 * N0 : (size_t)N0) * S;
+        const size_t cnt = ((k < 4) ? (size_t)comp_pitch(N0) * N0 : (size_t)N0) * S;
         HIPCHK(h, dmalloc(&h->comp0[k], cnt));
         HIPCHK(h, hipMemsetAsync(h->comp0[k], 0, cnt * sizeof(double), h->stream));
       }
@@ -832,7 +834,7 @@ extern "C" int mom_rt_run(mom_t *h) {
     if (h->red0) {
       if (M > 1) {  // moments 1..M-1 on the full problem
         double *comp1[6];
-        for (int k = 0; k < 6; ++k) comp1[k] = h->comp[k] + ((k < 4) ? NN : (size_t)h->N) * S;
+        for (int k = 0; k < 6; ++k) comp1[k] = h->comp[k] + ((k < 4) ? (size_t)comp_pitch(h->N) * h->N : (size_t)h->N) * S;
         HIPCHK(h, hipEventRecord(h->ev_full[2 * z], h->stream));
         if ((rc = launch_layer(z, h->q, 1, M - 1, h->d_Zpp + NN * h->K, h->d_Zmp + NN * h->K, comp1, h->d_scratch))) return rc;
         HIPCHK(h, hipEventRecord(h->ev_full[2 * z + 1], h->stream));
