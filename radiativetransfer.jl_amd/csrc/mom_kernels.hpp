@@ -373,22 +373,46 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   double *E = c.Q, *F1 = c.Q + Nq * Nq, *F2 = c.Q + 2 * Nq * Nq;
   // two-term phase matrices (Rayleigh + one aerosol type): the 32 basis loads of this thread's first 8 elements go
   // out before the tables are built and are consumed after them
-  const int e_first = wg_tid();
+  // Element enumeration: lane = row (in blocks of 64), wave = column (strided by kWaves).  A thread's elements share
+  // the row, so its per-row constants are loaded once, and everything per column is wave-uniform; the phase-matrix
+  // loads stay coalesced (consecutive lanes = consecutive rows of one column).  Slot s -> (row block, column slot).
+  // (4-wave build: the operators there have N <= 48, most lanes of a row block would idle -- plain linear order.)
+  constexpr bool kRowLanes = kWaves >= 8;
+  const int lane_e = wg_lane(), wave_e = wg_wave(), tid_e = wg_tid();
+  const int CS = (N + kWaves - 1) / kWaves;
+  const int slots = kRowLanes ? ((N + 63) >> 6) * CS : (N * N + kThreads - 1) / kThreads;
   const bool pre = Zpp.terms() == 2;
   double bp0[8], bm0[8], bp1[8], bm1[8];
   int ii[8], jj[8];
-  auto issue_z2 = [&](int e0) {
+  bool ok[8];
+  auto coords = [&](int s0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int s = s0 + u;
+      if constexpr (kRowLanes) {
+        const int rb = s / CS;
+        ii[u] = lane_e + 64 * rb;
+        jj[u] = wave_e + kWaves * (s - rb * CS);
+        ok[u] = s < slots && ii[u] < N && jj[u] < N;
+      } else {
+        const int e = tid_e + s * kThreads;
+        ok[u] = e < N * N;
+        c.fd.split(ok[u] ? e : 0, ii[u], jj[u]);
+      }
+    }
+  };
+  auto issue_z2 = [&](int s0) {
+    coords(s0);
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-      if (e0 + u * kThreads < N * N) {
-        c.fd.split(e0 + u * kThreads, ii[u], jj[u]);
+      if (ok[u]) {
         bp0[u] = Zpp.basis(0, ii[u], jj[u]);
         bm0[u] = Zmp.basis(0, ii[u], jj[u]);
         bp1[u] = Zpp.basis(1, ii[u], jj[u]);
         bm1[u] = Zmp.basis(1, ii[u], jj[u]);
       }
   };
-  if (pre) issue_z2(e_first);
+  if (pre) issue_z2(0);
   for (int i = wg_tid(); i < N; i += kThreads) {
     c.ei[i] = exp(-dtau / c.mu[i]);
     c.v1[i] = c.wt[i] / wdiv;   // wct
@@ -410,7 +434,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   MOM_STAMP(46);
   const int i_start = n * (q.imu0 - 1), i_end = n * q.imu0;
   double *ZS = c.P;  // mixed Z++ / Z-+ of the sun-block columns, [N x nS] each (P is free here)
-  for (int e0 = e_first; e0 < N * N; e0 += 8 * kThreads) {
+  for (int s0 = 0; s0 < slots; s0 += 8) {
     double zp[8], zm[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -419,11 +443,11 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
     }
     // Z = sum_k w_k Z_k, accumulated in k order
     if (pre) {
-      if (e0 != e_first) issue_z2(e0);
+      if (s0 != 0) issue_z2(s0);
       const double wp0 = Zpp.weight(0), wm0 = Zmp.weight(0), wp1 = Zpp.weight(1), wm1 = Zmp.weight(1);
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (e0 + u * kThreads < N * N) {
+        if (ok[u]) {
           zp[u] += wp0 * bp0[u];
           zm[u] += wm0 * bm0[u];
           zp[u] += wp1 * bp1[u];
@@ -431,15 +455,12 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
         }
     } else {
       // the (run-time) sum over scatterer types is the OUTER loop: the 16 basis loads of a term are in flight together
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (e0 + u * kThreads < N * N) c.fd.split(e0 + u * kThreads, ii[u], jj[u]);
+      coords(s0);
       for (int k = 0; k < Zpp.terms(); ++k) {
         const double wp = Zpp.weight(k), wm = Zmp.weight(k);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int e = e0 + u * kThreads;
-          if (e < N * N) {
+          if (ok[u]) {
             zp[u] += wp * Zpp.basis(k, ii[u], jj[u]);
             zm[u] += wm * Zmp.basis(k, ii[u], jj[u]);
           }
@@ -449,8 +470,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
     MOM_STAMP(49);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int e = e0 + u * kThreads;
-      if (e < N * N) {
+      if (ok[u]) {
         const int i = ii[u], j = jj[u];
         if (j >= i_start && j < i_end) {
           ZS[i + (j - i_start) * N] = zp[u];
