@@ -468,43 +468,59 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
       }
     }
     MOM_STAMP(49);
+    // the table / no-table choice is hoisted out of the element loop (as a compile-time flag of the body), so the
+    // table path carries neither the exponential nor the divisions of the other one
+    auto element_math = [&](auto tabc) {
+      constexpr bool TAB = decltype(tabc)::value;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (ok[u]) {
-        const int i = ii[u], j = jj[u];
-        if (j >= i_start && j < i_end) {
-          ZS[i + (j - i_start) * N] = zp[u];
-          ZS[i + (n + j - i_start) * N] = zm[u];
-        }
-        const double mui = c.mu[i], muj = c.mu[j];
-        const double wj = c.v1[j];
-        int iq, jq, dummy;
-        fs.split(i, dummy, iq);
-        fs.split(j, dummy, jq);
-        const int pq = iq + jq * Nq;
-        const double Epq = tab ? E[pq] : 1 - exp(-dtau * ((1 / mui) + (1 / muj)));
-        const double F1pq = tab ? F1[pq] : muj / (mui + muj);
-        double rr, tt;
-        if (wj > 1.e-8) {
-          rr = varpi * zm[u] * F1pq * wj * Epq;
-          if (mui == muj) {
-            if (i == j) {
-              tt = c.ei[i] * (1 + varpi * zp[u] * c.v2[i] * c.v1[i]);
+      for (int u = 0; u < 8; ++u) {
+        if (ok[u]) {
+          const int i = ii[u], j = jj[u];
+          if (j >= i_start && j < i_end) {
+            ZS[i + (j - i_start) * N] = zp[u];
+            ZS[i + (n + j - i_start) * N] = zm[u];
+          }
+          const double mui = c.mu[i], muj = c.mu[j];
+          const double wj = c.v1[j];
+          int iq, jq, dummy;
+          fs.split(i, dummy, iq);
+          fs.split(j, dummy, jq);
+          const int pq = iq + jq * Nq;
+          double rr, tt;
+          if (wj > 1.e-8) {
+            double Epq, F1pq;
+            if constexpr (TAB) {
+              Epq = E[pq];
+              F1pq = F1[pq];
             } else {
-              tt = 0.0;
+              Epq = 1 - exp(-dtau * ((1 / mui) + (1 / muj)));
+              F1pq = muj / (mui + muj);
+            }
+            rr = varpi * zm[u] * F1pq * wj * Epq;
+            if (mui == muj) {
+              if (i == j) {
+                tt = c.ei[i] * (1 + varpi * zp[u] * c.v2[i] * c.v1[i]);
+              } else {
+                tt = 0.0;
+              }
+            } else {
+              double F2pq;
+              if constexpr (TAB) F2pq = F2[pq];
+              else F2pq = muj / (mui - muj);
+              tt = varpi * zp[u] * F2pq * wj * (c.ei[i] - c.ei[j]);
             }
           } else {
-            tt = varpi * zp[u] * (tab ? F2[pq] : muj / (mui - muj)) * wj * (c.ei[i] - c.ei[j]);
+            rr = 0.0;
+            tt = (i == j) ? c.ei[i] : 0.0;
           }
-        } else {
-          rr = 0.0;
-          tt = (i == j) ? c.ei[i] : 0.0;
+          if (nd >= 1) rr *= c.sg[i];  // apply_D_elemental!, elemental.jl:265-269
+          c.r[i + j * ld] = rr;
+          c.t[i + j * ld] = tt;
         }
-        if (nd >= 1) rr *= c.sg[i];  // apply_D_elemental!, elemental.jl:265-269
-        c.r[i + j * ld] = rr;
-        c.t[i + j * ld] = tt;
       }
-    }
+    };
+    if (tab) element_math(std::true_type{});
+    else element_math(std::false_type{});
     MOM_STAMP(57);
   }
   __syncthreads();
