@@ -50,7 +50,9 @@ __device__ __forceinline__ double w_hw32sd_re(double x, double y) {
     const cplx up3 = {3.0 + u.re, u.im};
     cplx den = cmul(u, up3);
     den.re += 0.75;
-    return cdiv(num, den).re;
+    // only the real part of num/den is needed: one division (|den| ~ |t|^4 >= 4e3 here and < 1e30 for any
+    // line/grid distance in cm^-1 units, so the squares neither overflow nor underflow)
+    return (num.re * den.re + num.im * den.im) / (den.re * den.re + den.im * den.im);
   }
   const double L = 4.756828460010884;  // sqrt(32/sqrt(2))
   const cplx lpiz = {L - y, x}, lmiz = {L + y, -x};
@@ -74,9 +76,11 @@ __global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__re
                                                   const double *__restrict__ S, const int *__restrict__ i0,
                                                   const int *__restrict__ i1, int nGrid,
                                                   const double *__restrict__ grid, double *__restrict__ sigma) {
-  __shared__ int cand[kBlock];
+  // per-line constants of the candidates, staged once per workgroup: centre, S c/gamma_d, c'/gamma_d, y and the
+  // 0-based window -- the two divisions by gamma_d are per LINE here, not per evaluation (same expressions, same values)
+  __shared__ double c_nu[kBlock], c_a[kBlock], c_b[kBlock], c_y[kBlock];
+  __shared__ int c_lo[kBlock], c_hi[kBlock];
   __shared__ int wcount[kBlock / 64];
-  __shared__ int ncand;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g0 = blockIdx.x * kBlock;             // 0-based first grid index of this block
   const int g1 = min(nGrid, g0 + kBlock) - 1;     // last
@@ -87,22 +91,31 @@ __global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__re
   for (int base = 0; base < nLines; base += kBlock) {
     const int j = base + tid;
     bool hit = false;
-    if (j < nLines) hit = (i0[j] - 1 <= g1) && (i1[j] - 1 >= g0);
+    int lo = 0, hi = -1;
+    if (j < nLines) {
+      lo = i0[j] - 1;
+      hi = i1[j] - 1;
+      hit = (lo <= g1) && (hi >= g0);
+    }
     const unsigned long long mask = __ballot(hit);
     if (lane == 0) wcount[wave] = __popcll(mask);
     __syncthreads();
     int off = 0;
     for (int w = 0; w < wave; ++w) off += wcount[w];
-    if (hit) cand[off + __popcll(mask & ((1ull << lane) - 1ull))] = j;
-    if (tid == 0) ncand = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    if (hit) {  // ordered compaction: candidates keep the line order (the reference's accumulation order)
+      const int pos = off + __popcll(mask & ((1ull << lane) - 1ull));
+      const double gd = gamma_d[j];
+      c_nu[pos] = nu[j];
+      c_a[pos] = S[j] * cSqrtLn2divSqrtPi / gd;
+      c_b[pos] = cSqrtLn2 / gd;
+      c_y[pos] = y[j];
+      c_lo[pos] = lo;
+      c_hi[pos] = hi;
+    }
+    const int nc = wcount[0] + wcount[1] + wcount[2] + wcount[3];
     __syncthreads();
-    const int nc = ncand;
     for (int c = 0; c < nc; ++c) {
-      const int l = cand[c];
-      if (gi < nGrid && gi >= i0[l] - 1 && gi <= i1[l] - 1) {
-        const double gd = gamma_d[l];
-        acc += S[l] * cSqrtLn2divSqrtPi / gd * w_hw32sd_re(cSqrtLn2 / gd * (gx - nu[l]), y[l]);
-      }
+      if (gi >= c_lo[c] && gi <= c_hi[c] && gi < nGrid) acc += c_a[c] * w_hw32sd_re(c_b[c] * (gx - c_nu[c]), c_y[c]);
     }
     __syncthreads();
   }
