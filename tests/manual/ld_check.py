@@ -1,8 +1,8 @@
 """Extended-precision (x87 80-bit) replay of doubling/interaction on the numpy twin, to tell which of
 {oracle LU float64, GPU series, GPU strip chains, GPU Gauss-Jordan} is closest to the exact result."""
 import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
 import rtamd, helpers
 from oracle import momref as mr
