@@ -28,6 +28,9 @@ namespace MOM_NS {
 static_assert(MOM_STRIP_MAXP <= 12, "neumann_terms_12 covers p <= 12");
 constexpr int kStripMaxP = MOM_STRIP_MAXP;  // series terms up to which the Horner chain beats squaring through LDS
 constexpr int kStripGroups = kWaves / 4;
+// k-steps whose A fragments the scheduler may have in flight at once (a scheduling barrier every kStripChunk steps):
+// without it it hoists most of a product's 60 LDS reads to the front, 120 VGPRs that the fused kernel does not have
+constexpr int kStripChunk = 4;
 
 // composite blocks are touched once per launch: streaming (non-temporal) accesses keep them from evicting the
 // phase-matrix bases, which every unit re-reads, from L2
@@ -67,6 +70,7 @@ __device__ __forceinline__ void strip_mul(const double *M, int lr, int lq, const
     const double b = B[ks >> 2][ks & 3];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) acc[rt] = mfma_f64(a[rt], b, acc[rt]);
+    if ((ks + 1) % kStripChunk == 0) __builtin_amdgcn_sched_barrier(0);  // cap the A fragments in flight
   }
 }
 
@@ -89,6 +93,7 @@ __device__ __forceinline__ void strip_mul2(const double *M, int lr, int lq, cons
       acc1[rt] = mfma_f64(a[rt], b1, acc1[rt]);
       acc2[rt] = mfma_f64(a[rt], b2, acc2[rt]);
     }
+    if ((ks + 1) % kStripChunk == 0) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
