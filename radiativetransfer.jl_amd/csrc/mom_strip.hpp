@@ -252,10 +252,13 @@ __device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, double 
     d4 Zt[NT];
     strip_zero(Zt);
     strip_mul<KS>(r, lr, lq, Y, Zt);  // (A r)^T ; rows N, N+1: (A w1)^T, (A w2)^T
-    strip_load_lds<KS>(r, lr, lq, c0, Rn);
-    strip_zero(Tn);
-    strip_mul2<KS>(t, lr, lq, Zt, Rn, Y, Tn);  // r^T + t^T (A r)^T ; t^T A^T      (:64, :67)
     aw = Zt[G::RT][G::RR];  // lanes lq == 0: (A w1)[col] ; lq == 1: (A w2)[col]
+    // two single-strip products rather than one pass over t with shared A fragments (strip_mul2): the double product
+    // needs 32 more live VGPRs, which the fused kernel pays for with spills inside the chain
+    strip_load_lds<KS>(r, lr, lq, c0, Rn);
+    strip_mul<KS>(t, lr, lq, Zt, Rn);  // r^T + t^T (A r)^T      (:64)
+    strip_zero(Tn);
+    strip_mul<KS>(t, lr, lq, Y, Tn);   // t^T A^T                (:67)
   }
   MOM_STAMP(71);
   __syncthreads();
