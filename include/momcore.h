@@ -107,7 +107,11 @@ int mom_batch_inv(mom_t *h, int n, int batch, const double *A, double *X);
 int mom_batched_mul(mom_t *h, int n, int batch, const double *A, const double *B, double *C);
 
 /* Array(composite_layer.J₀⁻) etc. (postprocessing_vza.jl:17-20) / test access.
- * Operator-level state lives in moment slot 0 of the handle. */
+ * Operator-level state lives in moment slot 0 of the handle.  The composite MATRIX codes (R⁻⁺, R⁺⁻, T⁺⁺, T⁻⁻)
+ * refer to the operator-level path ([N,N,nSpec], as written by mom_interaction / mom_copy_added_to_composite /
+ * mom_upload): mom_rt_run keeps its composite blocks in the same allocation with an internal row pitch
+ * (whole cache lines), so reading them back after a scene-level run is not meaningful; the source vectors
+ * J₀⁺, J₀⁻ and everything mom_get_RT / mom_get_hdr return are unaffected. */
 int mom_upload(mom_t *h, int which, const double *src);
 int mom_download(mom_t *h, int which, double *dst);
 
