@@ -131,6 +131,20 @@ def test_all_interface_cases_and_zero_doublings(rtamd, cref):
     helpers.assert_stokes_close(_gpu(rtamd, m2)[0], _oracle(cref, m2)[0], what="R iface10 surface")
 
 
+def test_interface_cases_in_strip_kernels(rtamd, cref):
+    """The same interface state machine at N = 60 and N0 = 40: the strip-chained kernel images (8-wave and, for the
+    m = 0 sub-problem, 4-wave) contain the general code of the 00 / 01 / 10 cases with the pitched composite blocks."""
+    m = rtamd.scenes.make_scene(3, 33, 5, 10, aerosol_total=0.0, seed=4)
+    for z in (0, 1, 3):
+        m.τ_rayl[:, z] = 0.0
+    sc = rtamd.prepare_scene(m)
+    assert sc.N == 60 and list(sc.iface) == [0, 0, 1, 2, 3]
+    R, T = _gpu(rtamd, m)
+    Rr, Tr = _oracle(cref, m)
+    helpers.assert_stokes_close(R, Rr, what="R")
+    helpers.assert_stokes_close(T, Tr, what="T")
+
+
 def test_golden_small_iqu(rtamd):
     g = np.load(GOLD / "small_iqu.npz")
     m = rtamd.scenes.make_scene(3, 3, 3, 4, vza=(0.0,), vaz=(35.0,), seed=7, aerosol_total=0.3, aerosol_p0=500.0,
