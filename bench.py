@@ -5,16 +5,27 @@ Workload (BASELINE.json configs[1], "C2"): O2 A-band, Stokes IQU, 20 quadrature 
 (N = 60), 40 layers, 3 Fourier moments, 10 000 spectral points per GPU, Float64, seeded synthetic
 scene (radiativetransfer.jl_amd/scenes.py).  One "step" = the whole of rt_run.jl:125-215 for the
 resident scene: every layer's elemental -> doubling -> interaction, the surface, post-processing,
-and (N > 1) the RCCL all-gather of the R/T spectra.  Inputs are in HBM before the timed region.
+and (N > 1) the ONE RCCL all-gather of the R/T spectra.  Inputs are in HBM before the timed region.
 
-  python bench.py [--gpus N --steps K --warmup W]        (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W]
 
-Prints ONE JSON line on rank 0 (contract in the task description).  Weak scaling: every rank owns
-10 000 points of a global axis of N x 10 000; ndoubl / interface codes are computed on the global axis.
+N > 1: one process per GPU.  The driver's launcher (`python -m torch.distributed.run ... bench.py --gpus N`)
+sets WORLD_SIZE/RANK/LOCAL_RANK; started WITHOUT it, `--gpus N` spawns that launcher as a child process before
+anything touches a GPU and exits with its code.  Collective back ends (`--backend`):
+  rccl   (default) mom_comm_init + mom_allgather_RT_device: RCCL through the C ABI on the library's own stream;
+         torch.distributed (gloo) is only the control plane (id exchange, barrier, max over ranks)
+  torch  torch.distributed all_gather_into_tensor on the "nccl" (= RCCL) process group
+  gloo   host all-gather over gloo; with --share-device every rank uses GPU 0 (the 1-GPU test box)
+
+Other workloads (`--workload`): C1 (scalar, N = 4: HBM-bound wave-per-point kernel), C4 (IQUV, 64 streams,
+N = 256).  Prints ONE JSON line on rank 0 (contract in the task description).  Weak scaling: every rank owns
+`--points` spectral points of a global axis of N x points; ndoubl / interface codes are computed on the global axis.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -24,28 +35,54 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-S_PER_GPU = 10_000
 PEAK_FP64_MFMA_TFLOPS = 78.6  # AMD MI355X FP64 matrix spec; v_mfma_f64_16x16x4 issue-rate microbenchmark: 77.5
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+DEFAULT_POINTS = {"C2": 10_000, "C1": 200_000, "C4": 2_000}
 
 
-def cpu_baseline(model, budget_s=12.0):
+def cpu_baseline(model, workload, budget_s=12.0):
     """The C oracle (oracle/momref.c, kind "port": the reference is Julia and cannot run here) on all
     host cores over a bounded seeded sample of the same scene's spectral points."""
     sys.path.insert(0, str(ROOT / "tests"))
     import helpers
     from oracle import cref
+    import rtamd
     cores = os.cpu_count() or 1
-    p = cref.pack_scene(helpers.oracle_scene(model))
+    sc = helpers.oracle_scene(model)
+    p = cref.pack_scene(sc)
     rng = np.random.default_rng(0)
-    done, t_used, batch = 0, 0.0, cores
+    done, t_used, batch = 0, 0.0, cores * (64 if workload == "C1" else 1)
     while t_used < budget_s and done < p.S:
-        pts = rng.choice(p.S, batch, replace=False).astype(np.int32)
+        pts = rng.choice(p.S, min(batch, p.S), replace=False).astype(np.int32)
         t0 = time.perf_counter()
         cref.rt_run(p, pts=pts, nthreads=cores)
         t_used += time.perf_counter() - t0
-        done += batch
+        done += len(pts)
+    flop_pt = rtamd.scenes.work_model_flops(p.N, p.nd, p.M)
+    gfs_core = done * flop_pt / t_used / cores / 1e9
     return {"value": done / t_used, "unit": "spectral points/s", "cores": cores, "kind": "port",
-            "sample": f"{done} seeded random spectral points of the same C2 scene, {t_used:.1f} s, OpenMP over points"}
+            "gflops_per_core": gfs_core,
+            "sample": f"{done} seeded random spectral points of the same {workload} scene, {t_used:.1f} s, OpenMP over points, "
+                      f"blocked AVX2 GEMM: {gfs_core:.2f} algorithmic GFLOP/s per core"}
+
+
+def voigt_leg():
+    """Second kernel of the north star, reported as `extra.voigt` with its own roofline."""
+    import bench_voigt
+    return bench_voigt.run(repeats=5)
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the driver's launcher as a CHILD (this process has not
+    touched the GPU and never will) and pass its exit code on."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -53,44 +90,77 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--points", type=int, default=S_PER_GPU, help="spectral points per GPU")
+    ap.add_argument("--workload", choices=["C2", "C1", "C4"], default="C2")
+    ap.add_argument("--points", type=int, default=0, help="spectral points per GPU (default: the workload's size)")
+    ap.add_argument("--backend", choices=["rccl", "torch", "gloo"], default="rccl")
+    ap.add_argument("--share-device", action="store_true", help="all ranks on GPU 0 (needs --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-voigt", action="store_true")
     a = ap.parse_args()
-
-    import torch
-    import rtamd
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if a.share_device and a.backend != "gloo":
+        ap.error("--share-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); refusing to report a wrong n_gpus",
+              file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import rtamd
+
+    dev_index = 0 if (a.share_device or world == 1) else local
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
+    collective = "none"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # "nccl" is RCCL on ROCm
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+        if a.backend == "torch":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+            collective = "torch.distributed all_gather_into_tensor (RCCL)"
+        else:
+            dist.init_process_group("gloo")
+            collective = "mom_allgather_RT_device (RCCL through the C ABI)" if a.backend == "rccl" else "gloo host all_gather"
 
-    S_loc, S_tot = a.points, a.points * world
-    model = rtamd.scenes.scene_C2(S=S_tot, architecture=rtamd.MI355X(dev.index))
+    S_loc = a.points or DEFAULT_POINTS[a.workload]
+    S_tot = S_loc * world
+    scene_fn = {"C2": rtamd.scenes.scene_C2, "C1": rtamd.scenes.scene_C1, "C4": rtamd.scenes.scene_C4}[a.workload]
+    model = scene_fn(S=S_tot, architecture=rtamd.MI355X(dev.index))
     scene = rtamd.prepare_scene(model)          # global axis: ndoubl / iface are global
     shard = scene.spectral_slice(rank * S_loc, (rank + 1) * S_loc) if world > 1 else scene
     h = rtamd.corert.make_handle(model, S=S_loc)
     h.scene_set(shard.Nz, shard.K, shard.M, shard.tau, shard.varpi, shard.zw, shard.Zpp, shard.Zmp, shard.ndoubl,
                 shard.iface, shard.tau_sum, shard.albedo, shard.node, shard.cos_mphi, shard.sin_mphi)
     nout = len(shard.node) * shard.nStokes * S_loc
-    R = torch.empty(nout, dtype=torch.float64, device=dev)
-    T = torch.empty(nout, dtype=torch.float64, device=dev)
-    Rg = torch.empty(nout * world, dtype=torch.float64, device=dev) if world > 1 else None
-    Tg = torch.empty(nout * world, dtype=torch.float64, device=dev) if world > 1 else None
+    RT = torch.empty(2 * nout, dtype=torch.float64, device=dev)           # local R || T
+    G = torch.empty(2 * nout * world, dtype=torch.float64, device=dev) if world > 1 else None
+    Gh = torch.empty(2 * nout * world, dtype=torch.float64) if (world > 1 and a.backend == "gloo") else None
+    if world > 1 and a.backend == "rccl":
+        ident = [rtamd._lib.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        h.comm_init(rank, world, ident[0])
 
     def step():
         h.rt_run()
-        h.get_RT_device(R.data_ptr(), T.data_ptr())  # synchronises the library's stream
-        if world > 1:
-            dist.all_gather_into_tensor(Rg, R)
-            dist.all_gather_into_tensor(Tg, T)
+        if world == 1:
+            h.get_RT_device(RT.data_ptr(), RT.data_ptr() + 8 * nout)      # asynchronous, library stream
+        elif a.backend == "rccl":
+            h.allgather_RT_device(G.data_ptr())                           # ONE collective, library stream
+        elif a.backend == "torch":
+            h.get_RT_device(RT.data_ptr(), RT.data_ptr() + 8 * nout)
+            h.sync()
+            dist.all_gather_into_tensor(G, RT)                            # ONE collective: R and T packed
+        else:
+            h.get_RT_device(RT.data_ptr(), RT.data_ptr() + 8 * nout)
+            h.sync()
+            dist.all_gather_into_tensor(Gh, RT.cpu())
 
     def fence():
         h.sync()
@@ -107,10 +177,16 @@ def main():
         step()
     fence()
     el = time.perf_counter() - t0
+    h.check_async()  # deferred singular-operator report of the asynchronous steps
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=dev if a.backend == "torch" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+        # the gathered block of this rank must be its own spectra, and every block finite
+        R_loc, T_loc = h.get_RT()
+        mine = np.concatenate([np.transpose(R_loc, (2, 1, 0)).reshape(-1), np.transpose(T_loc, (2, 1, 0)).reshape(-1)])
+        got = (Gh if a.backend == "gloo" else G.cpu()).numpy().reshape(world, 2 * nout)
+        assert np.array_equal(got[rank], mine) and np.all(np.isfinite(got)), "all-gather returned wrong data"
     tm = h.timers()  # of the last step, HIP events on the library's stream
 
     if rank == 0:
@@ -120,35 +196,60 @@ def main():
         # interaction runs in k_surface): GEMM = 2N^3, inverse = 2N^3, matvec = 2N^2 -- the reference's op list
         # on the FULL N x N operators, whatever the kernels do internally (Neumann series, m = 0 sub-problem)
         f_pm = (nd.sum() * (12 * N ** 3 + 8 * N ** 2) + (scene.Nz - 1) * (24 * N ** 3 + 8 * N ** 2) + scene.Nz * N * N * 15)
-        # dominant kernel = the full-problem layer kernel mom::k_layer<true, 3, 15> (strip-chained, N = 60); it handles moments 1..M-1 when
-        # moment 0 runs as the (I,Q) sub-problem in mom4::k_layer (reduced_launches > 0), else all M moments
+        # dominant kernel = the full-problem layer kernel; it handles moments 1..M-1 when moment 0 runs as the (I,Q)
+        # sub-problem (reduced_launches > 0), else all M moments
         m_dom = (M - 1) if tm["reduced_launches"] > 0 else M
         flop_dom = f_pm * m_dom * S_loc
-        achieved = flop_dom / (tm["full_layers_ms"] * 1e-3) / 1e12
         whole = f_pm * M * S_loc / (tm["layers_ms"] * 1e-3) / 1e12
-        traffic = None
+        prof = {}
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
-            traffic = json.loads(tf.read_text()).get("k_layer_hbm_bytes_per_launch")
+            prof = json.loads(tf.read_text()).get(a.workload, {})
+        if a.workload == "C1":
+            # HBM-bound regime: algorithmic bytes per point = inputs 2 Nz 8 (tau, varpi) + K Nz 8 (weights)
+            # + Nz 8 (tau_sum) + outputs 2 nVza nStokes 8; the composite state never leaves the chip
+            bytes_pt = (3 + scene.K) * scene.Nz * 8 + 2 * len(scene.node) * scene.nStokes * 8
+            ach = bytes_pt * S_loc / (tm["layers_ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                    "traffic": prof.get("hbm_bytes_per_launch"), "kernel": "momsm::k_sweep",
+                    "avg_launch_ms": tm["layers_ms"] / max(tm["layer_launches"], 1),
+                    "algorithmic_bytes_per_point": bytes_pt,
+                    "algorithmic_tflops": f_pm * M * S_loc / (tm["layers_ms"] * 1e-3) / 1e12}
+        else:
+            achieved = flop_dom / (tm["full_layers_ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": prof.get("hbm_bytes_per_launch"),
+                    "kernel": prof.get("kernel", "full-problem layer kernel"),
+                    "avg_launch_ms": tm["full_layers_ms"] / max(tm["full_launches"], 1),
+                    "launches_per_step": tm["full_launches"], "moments_per_launch": m_dom,
+                    "algorithmic_flop_per_avg_launch": flop_dom / max(tm["full_launches"], 1),
+                    "all_layer_kernels_achieved": whole, "all_layer_kernels_frac": whole / PEAK_FP64_MFMA_TFLOPS,
+                    # `achieved` counts the reference's op list (full 2N^3 inverses); the hardware-side figure is the
+                    # MFMA-busy share of SIMD cycles from the PMC pass (profiles/), not recomputed here
+                    "hw_mfma_busy_frac": prof.get("mfma_busy_frac")}
         out = {
             "metric": "spectral points/sec (whole node), O2-A band IQU scene", "value": S_tot / (el / a.steps),
             "unit": "spectral points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"C2 O2-A IQU: N=60 (20 streams x 3 Stokes), Nz=40, M=3, S={S_loc}/GPU, "
-                                   f"sum(ndoubl)={int(nd.sum())}, Lambertian surface, 3 VZA",
-                       "sharding": f"spectral axis, {world} x {S_loc} points, RCCL all_gather of R/T" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                         "kernel": "mom::k_layer<true, 3, 15>", "avg_launch_ms": tm["full_layers_ms"] / max(tm["full_launches"], 1),
-                         "launches_per_step": tm["full_launches"], "moments_per_launch": m_dom,
-                         "algorithmic_flop_per_avg_launch": flop_dom / max(tm["full_launches"], 1),
-                         "all_layer_kernels_achieved": whole, "all_layer_kernels_frac": whole / PEAK_FP64_MFMA_TFLOPS},
+            "config": {"workload": f"{a.workload}: N={N} ({N // scene.nStokes} streams x {scene.nStokes} Stokes), Nz={scene.Nz}, "
+                                   f"M={M}, S={S_loc}/GPU, sum(ndoubl)={int(nd.sum())}, Lambertian surface, {len(scene.node)} VZA",
+                       "sharding": f"spectral axis, {world} x {S_loc} points, one all-gather of R||T" if world > 1 else "none",
+                       "collective": collective,
+                       "devices": "all ranks on GPU 0 (--share-device)" if a.share_device else "one GPU per rank"},
+            "roofline": roof,
             "stages_ms": {k: tm[k] for k in ("layers_ms", "full_layers_ms", "reduced_layers_ms", "surface_ms",
                                              "postprocess_ms", "total_ms")},
         }
+        if a.workload != "C2":
+            out["metric"] = f"spectral points/sec (whole node), {a.workload} scene"
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model)
+            out["cpu_baseline"] = cpu_baseline(model, a.workload)
+        if world == 1 and not a.no_voigt and a.workload == "C2":
+            try:
+                out["extra"] = {"voigt": voigt_leg()}
+            except Exception as e:  # the headline number must not depend on the second kernel's leg
+                out["extra"] = {"voigt": {"error": repr(e)}}
         print(json.dumps(out), flush=True)
     h.close()
     if world > 1:

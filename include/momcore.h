@@ -19,7 +19,7 @@
  *   - host pointers are borrowed for the duration of the call only.  All device memory is
  *     owned by the handle.  One handle <-> one GPU <-> one HIP stream; a handle is not
  *     thread-safe, distinct handles are independent.
- *   - double precision (Float64) only in this round; `dtype` is reserved (0 = f64).
+ *   - `dtype` of mom_create: 0 = Float64 (the reference's default float_type).
  */
 #ifndef MOMCORE_H
 #define MOMCORE_H
@@ -65,6 +65,8 @@ const char *mom_last_error(const mom_t *h);
 const char *mom_last_global_error(void);
 /* blocks until everything queued on the handle's stream has finished */
 int mom_sync(mom_t *h);
+/* mom_sync + the deferred error report of the asynchronous calls (MOM_ESINGULAR if a kernel met a zero pivot) */
+int mom_check(mom_t *h);
 
 /* QuadPoints (types.jl:456-473) + polarization type (Scattering/types.jl:82-123).
  * qp_muN/wt_muN: N values (already repeated per Stokes component); imu0_1based = iμ₀;
@@ -107,13 +109,22 @@ int mom_batch_inv(mom_t *h, int n, int batch, const double *A, double *X);
 int mom_batched_mul(mom_t *h, int n, int batch, const double *A, const double *B, double *C);
 
 /* Array(composite_layer.J₀⁻) etc. (postprocessing_vza.jl:17-20) / test access.
- * Operator-level state lives in moment slot 0 of the handle.  The composite MATRIX codes (R⁻⁺, R⁺⁻, T⁺⁺, T⁻⁻)
- * refer to the operator-level path ([N,N,nSpec], as written by mom_interaction / mom_copy_added_to_composite /
- * mom_upload): mom_rt_run keeps its composite blocks in the same allocation with an internal row pitch
- * (whole cache lines), so reading them back after a scene-level run is not meaningful; the source vectors
- * J₀⁺, J₀⁻ and everything mom_get_RT / mom_get_hdr return are unaffected. */
+ * Operator-level state lives in moment slot 0 of the handle; the added and surface layers are allocated on the
+ * first operator-level call.  After a scene-level mom_rt_run the composite codes return Fourier moment 0 of that
+ * run in the same [N,N,nSpec] / [N,nSpec] layout (the internal row pitch is removed), or MOM_ESTATE when moment 0
+ * ran on the (I,Q) sub-problem (MOM_OPT_M0_REDUCTION); mom_interaction / mom_postprocess refuse to continue from
+ * scene-level state (MOM_ESTATE) until mom_copy_added_to_composite or a composite mom_upload restarts the
+ * operator-level sequence. */
 int mom_upload(mom_t *h, int which, const double *src);
 int mom_download(mom_t *h, int which, double *dst);
+
+/* postprocessing_vza!(RS_type::noRS, iμ₀, pol_type, composite_layer, vza, qp_μ, m, vaz, μ₀, weight, nSpec, SFI, R, R_SFI,
+ * T, T_SFI, ieR_SFI, ieT_SFI) -- postprocessing_vza.jl:9-60, SFI branch, for ONE Fourier moment m of the
+ * operator-level composite layer: R_SFI[i,:,s] += bigCS * J₀⁻[rows(i),1,s], T_SFI likewise with J₀⁺ (:48-49);
+ * node_1based[i] = nearest_point(qp_μ, cosd(vza[i])) (:28), vaz_deg in degrees, weight = 0.5 for m = 0 else 1
+ * (rt_run.jl:128).  R_SFI, T_SFI: [nVza, nStokes, nSpec] host arrays, accumulated in place like the reference. */
+int mom_postprocess(mom_t *h, int m, int nVza, const int *node_1based, const double *vaz_deg, double weight,
+                    double *R_SFI, double *T_SFI);
 
 /* ---- scene-level API: inputs resident in HBM, fused per-layer kernels -------------------
  *
@@ -156,8 +167,29 @@ int mom_get_RT(mom_t *h, double *R_SFI, double *T_SFI);
  * (postprocessing_vza.jl:63-93), and the up-/down-welling flux sums bhr_uw, bhr_dw [nStokes, S]
  * (the reference returns their first rows). */
 int mom_get_hdr(mom_t *h, double *hdr, double *bhr_uw, double *bhr_dw);
-/* Same, into caller-owned DEVICE buffers (e.g. the send buffer of an RCCL all-gather). */
+/* Same, into caller-owned DEVICE buffers (asynchronous on the handle's stream; errors surface at the next
+ * synchronising call). */
 int mom_get_RT_device(mom_t *h, void *dR_SFI, void *dT_SFI);
+
+/* ---- multi-GPU: one process per GPU, spectral shards, ONE RCCL all-gather ----------
+ * The reference has no multi-GPU path; a sharded host (Julia Distributed/MPI.jl ranks, or this repository's
+ * bench.py) gives every rank a contiguous slice of the spectral axis with the GLOBAL ndoubl / interface codes
+ * (rt_kernel.jl:241-242 takes maxima over the whole axis) and gathers the spectra once at the end.
+ *   mom_comm_unique_id   rank 0 obtains the RCCL id (MOM_COMM_ID_BYTES bytes) and hands it to the other ranks
+ *                        by whatever means the host has (MPI_Bcast, a TCP store, a file)
+ *   mom_comm_init        ncclCommInitRank on the handle's GPU; librccl.so.1 is loaded on first use
+ *   mom_allgather        count doubles per rank, device pointers, asynchronous on the handle's stream
+ *   mom_allgather_RT_device  the handle's R_SFI || T_SFI block (2*nVza*nStokes*S_loc doubles) of every rank into
+ *                        d_global [nranks][2][nVza*nStokes*S_loc]; asynchronous
+ *   mom_allgather_RT     the same into host arrays R_SFI, T_SFI [nVza, nStokes, nranks*S_loc] (rank-major
+ *                        spectral axis: every rank must run the same S_loc, pad the tail); synchronises */
+enum { MOM_COMM_ID_BYTES = 128 };
+int mom_comm_unique_id(void *id_out, size_t bytes);
+int mom_comm_init(mom_t *h, int rank, int nranks, const void *nccl_id);
+int mom_comm_destroy(mom_t *h);
+int mom_allgather(mom_t *h, const void *d_local, void *d_global, size_t count);
+int mom_allgather_RT_device(mom_t *h, void *d_global);
+int mom_allgather_RT(mom_t *h, double *R_SFI_global, double *T_SFI_global);
 
 /* Per-stage GPU time of the last mom_rt_run in milliseconds (hipEvent based):
  * ms[0] = layer kernels, ms[1] = surface, ms[2] = post-processing, ms[3] = total;

@@ -24,8 +24,9 @@ c_ip = C.POINTER(C.c_int)
 def build(force: bool = False) -> Path:
     so = _HERE / "libmomref.so"
     src = _HERE / "momref.c"
-    if force or (not so.exists()) or so.stat().st_mtime < src.stat().st_mtime:
-        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", str(src), "-o", str(so), "-lm"])
+    mk = _HERE / "Makefile"
+    if force or (not so.exists()) or so.stat().st_mtime < max(src.stat().st_mtime, mk.stat().st_mtime):
+        subprocess.check_call(["make", "-C", str(_HERE), "-B" if force else "-s"])
     return so
 
 

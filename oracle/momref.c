@@ -16,7 +16,7 @@
  * slowest, batch stride N*N), sources [i,1,n].  Each function cites the reference
  * file:line it follows (paths relative to the reference root, src/CoreRT/...).
  *
- * Build: gcc -O2 -fopenmp -fPIC -shared oracle/momref.c -o oracle/libmomref.so -lm
+ * Build: gcc -O3 -mavx2 -mfma -fopenmp -fPIC -shared oracle/momref.c -o oracle/libmomref.so -lm  (oracle/Makefile)
  */
 #include <math.h>
 #include <stdlib.h>
@@ -27,9 +27,62 @@
 
 /* ---------------------------------------------------------------- dense helpers */
 
-/* C = A*B, column-major N x N.  (`⊠` = NNlib.batched_mul, gpu_batched.jl:90-97) */
+/* C = A*B, column-major N x N.  (`⊠` = NNlib.batched_mul, gpu_batched.jl:90-97)
+ * Register-blocked micro-kernel (12 x 4 block of C in 12 AVX2 accumulators, k innermost and sequential, so every
+ * element is the same left-to-right sum over k as the textbook triple loop; only the FMA contraction differs): the
+ * CPU baseline of bench.py should not be an un-blocked loop. */
+typedef double v4d __attribute__((vector_size(32), aligned(8)));
+static inline v4d ld4(const double *p) { return *(const v4d *)p; }
+static inline void st4(double *p, v4d v) { *(v4d *)p = v; }
 static void gemm(int N, const double *A, const double *B, double *C) {
-  for (int j = 0; j < N; ++j) {
+  int j = 0;
+  for (; j + 4 <= N; j += 4) {
+    const double *b0 = B + (size_t)j * N, *b1 = b0 + N, *b2 = b1 + N, *b3 = b2 + N;
+    int i = 0;
+    for (; i + 12 <= N; i += 12) {
+      v4d c00 = {0, 0, 0, 0}, c10 = c00, c20 = c00, c01 = c00, c11 = c00, c21 = c00, c02 = c00, c12 = c00, c22 = c00,
+          c03 = c00, c13 = c00, c23 = c00;
+      const double *a = A + i;
+      for (int k = 0; k < N; ++k, a += N) {
+        const v4d a0 = ld4(a), a1 = ld4(a + 4), a2 = ld4(a + 8);
+        v4d b = {b0[k], b0[k], b0[k], b0[k]};
+        c00 += a0 * b; c10 += a1 * b; c20 += a2 * b;
+        b = (v4d){b1[k], b1[k], b1[k], b1[k]};
+        c01 += a0 * b; c11 += a1 * b; c21 += a2 * b;
+        b = (v4d){b2[k], b2[k], b2[k], b2[k]};
+        c02 += a0 * b; c12 += a1 * b; c22 += a2 * b;
+        b = (v4d){b3[k], b3[k], b3[k], b3[k]};
+        c03 += a0 * b; c13 += a1 * b; c23 += a2 * b;
+      }
+      double *c = C + IDX(i, j, N);
+      st4(c, c00); st4(c + 4, c10); st4(c + 8, c20); c += N;
+      st4(c, c01); st4(c + 4, c11); st4(c + 8, c21); c += N;
+      st4(c, c02); st4(c + 4, c12); st4(c + 8, c22); c += N;
+      st4(c, c03); st4(c + 4, c13); st4(c + 8, c23);
+    }
+    for (; i + 4 <= N; i += 4) {
+      v4d c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+      const double *a = A + i;
+      for (int k = 0; k < N; ++k, a += N) {
+        const v4d a0 = ld4(a);
+        c0 += a0 * (v4d){b0[k], b0[k], b0[k], b0[k]};
+        c1 += a0 * (v4d){b1[k], b1[k], b1[k], b1[k]};
+        c2 += a0 * (v4d){b2[k], b2[k], b2[k], b2[k]};
+        c3 += a0 * (v4d){b3[k], b3[k], b3[k], b3[k]};
+      }
+      double *c = C + IDX(i, j, N);
+      st4(c, c0); st4(c + N, c1); st4(c + 2 * (size_t)N, c2); st4(c + 3 * (size_t)N, c3);
+    }
+    for (; i < N; ++i) {
+      double c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+      for (int k = 0; k < N; ++k) {
+        const double a = A[IDX(i, k, N)];
+        c0 += a * b0[k]; c1 += a * b1[k]; c2 += a * b2[k]; c3 += a * b3[k];
+      }
+      C[IDX(i, j, N)] = c0; C[IDX(i, j + 1, N)] = c1; C[IDX(i, j + 2, N)] = c2; C[IDX(i, j + 3, N)] = c3;
+    }
+  }
+  for (; j < N; ++j) {
     double *c = C + (size_t)j * N;
     for (int i = 0; i < N; ++i) c[i] = 0.0;
     for (int k = 0; k < N; ++k) {

@@ -44,6 +44,7 @@ SIGNATURES = {
     "mom_last_error": (C.c_char_p, [c_h]),
     "mom_last_global_error": (C.c_char_p, []),
     "mom_sync": (C.c_int, [c_h]),
+    "mom_check": (C.c_int, [c_h]),
     "mom_set_streams": (C.c_int, [c_h, c_dp, c_dp, C.c_int, C.c_int, C.c_double, c_dp, c_dp, C.c_int]),
     "mom_elemental": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int]),
     "mom_doubling": (C.c_int, [c_h, C.c_int, c_dp]),
@@ -60,6 +61,13 @@ SIGNATURES = {
     "mom_get_RT": (C.c_int, [c_h, c_dp, c_dp]),
     "mom_get_hdr": (C.c_int, [c_h, c_dp, c_dp, c_dp]),
     "mom_get_RT_device": (C.c_int, [c_h, C.c_void_p, C.c_void_p]),
+    "mom_postprocess": (C.c_int, [c_h, C.c_int, C.c_int, c_ip, c_dp, C.c_double, c_dp, c_dp]),
+    "mom_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "mom_comm_init": (C.c_int, [c_h, C.c_int, C.c_int, C.c_void_p]),
+    "mom_comm_destroy": (C.c_int, [c_h]),
+    "mom_allgather": (C.c_int, [c_h, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mom_allgather_RT_device": (C.c_int, [c_h, C.c_void_p]),
+    "mom_allgather_RT": (C.c_int, [c_h, c_dp, c_dp]),
     "mom_timers": (C.c_int, [c_h, c_dp, C.c_int, c_ip]),
     "mom_set_option": (C.c_int, [c_h, C.c_int, C.c_int]),
     "mom_voigt_xsec": (C.c_int, [C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip, C.c_int, c_dp, c_dp]),
@@ -147,6 +155,9 @@ class Handle:
     def sync(self):
         self.check(self.lib.mom_sync(self._h))
 
+    def check_async(self):
+        self.check(self.lib.mom_check(self._h))
+
     def set_streams(self, qp_muN, wt_muN, imu0_1based, mu0, I0, D, strict=True):
         qp, wt, I0, D = f64(qp_muN), f64(wt_muN), f64(I0), f64(D)
         self.check(self.lib.mom_set_streams(self._h, dp(qp), dp(wt), len(qp), int(imu0_1based), float(mu0), dp(I0),
@@ -223,12 +234,50 @@ class Handle:
     def get_RT_device(self, dR_ptr: int, dT_ptr: int):
         self.check(self.lib.mom_get_RT_device(self._h, C.c_void_p(dR_ptr), C.c_void_p(dT_ptr)))
 
+    def postprocess(self, m, node_1based, vaz_deg, weight, R_SFI, T_SFI):
+        """In-place accumulation into R_SFI/T_SFI given as ABI-ordered flat arrays [nVza, nStokes, S] (v fastest)."""
+        node, vaz = i32(node_1based), f64(vaz_deg)
+        self.check(self.lib.mom_postprocess(self._h, int(m), len(node), ip(node), dp(vaz), float(weight), dp(R_SFI),
+                                            dp(T_SFI)))
+
+    # -- multi-GPU (RCCL behind the C ABI) -------------------------------------------------
+    def comm_init(self, rank: int, nranks: int, nccl_id: bytes):
+        buf = C.create_string_buffer(bytes(nccl_id), COMM_ID_BYTES)
+        self.check(self.lib.mom_comm_init(self._h, int(rank), int(nranks), C.cast(buf, C.c_void_p)))
+        self.comm_size = int(nranks)
+
+    def comm_destroy(self):
+        self.check(self.lib.mom_comm_destroy(self._h))
+
+    def allgather_RT_device(self, d_global_ptr: int):
+        self.check(self.lib.mom_allgather_RT_device(self._h, C.c_void_p(d_global_ptr)))
+
+    def allgather_RT(self):
+        """R_SFI, T_SFI [nVza, nStokes, nranks*S_loc] on every rank (one RCCL all-gather)."""
+        n = self.nVza * self.nS * self.S * self.comm_size
+        R, T = np.empty(n), np.empty(n)
+        self.check(self.lib.mom_allgather_RT(self._h, dp(R), dp(T)))
+        shp = (self.S * self.comm_size, self.nS, self.nVza)
+        return np.transpose(R.reshape(shp), (2, 1, 0)).copy(), np.transpose(T.reshape(shp), (2, 1, 0)).copy()
+
     def timers(self):
         ms = np.zeros(8)
         nl = C.c_int(0)
         self.check(self.lib.mom_timers(self._h, dp(ms), 8, C.byref(nl)))
         return dict(layers_ms=ms[0], surface_ms=ms[1], postprocess_ms=ms[2], total_ms=ms[3], layer_launches=nl.value,
                     full_layers_ms=ms[4], reduced_layers_ms=ms[5], full_launches=int(ms[6]), reduced_launches=int(ms[7]))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """RCCL unique id (rank 0 calls this and distributes the bytes)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().mom_comm_unique_id(C.cast(buf, C.c_void_p), COMM_ID_BYTES)
+    if rc != MOM_OK:
+        raise MomError(rc, load().mom_last_global_error().decode())
+    return buf.raw
 
 
 def voigt_xsec(nu, gamma_d, y, S, ind_start, ind_stop, grid, device: int = 0):

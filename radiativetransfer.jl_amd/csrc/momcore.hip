@@ -5,13 +5,17 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
+
+#include <rccl/rccl.h>  // types and enums only: the library itself is dlopen'ed by mom_comm_init
 
 #include "momcore.h"
 
 #include "mom_diag.hpp"
 #include "mom_entry.hpp"
+#include "mom_host.hpp"
 
 using namespace mom;
 
@@ -247,6 +251,8 @@ hipError_t mom4_launch_surface(const void *surf_args, bool lds, int grid, size_t
 int mom4_generic_bufs_elems(int N);
 
 static thread_local std::string g_err;
+static int check_info(mom_t *h);
+static void (*g_rccl_destroy)(void *) = nullptr;  // set once RCCL is loaded (mom_comm_init)
 
 struct mom_handle {
   int device = 0, N = 0, nS = 0, S = 0, M = 0;
@@ -259,6 +265,15 @@ struct mom_handle {
   std::vector<double> h_mu, h_wt;
   int strict = 1;
   double *added[6] = {}, *surf[6] = {}, *comp[6] = {};
+  bool op_layers = false;     // added / surface layers of the operator-level API: allocated on first use
+  bool comp_pitched = false;  // composite matrix blocks hold scene-level (row-pitched) state
+  double *d_post[2] = {};     // operator-level mom_postprocess: gathered J0-/J0+ rows [nVza*nS*S] x 2
+  size_t post_cap = 0;
+  // RCCL communicator (mom_comm_init); the library is dlopen'ed on first use
+  void *comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
+  double *d_gather = nullptr;
+  size_t gather_cap = 0;
   double *d_vec[4] = {};  // S-length temporaries (tau_sum, dtau, varpi, expk)
   double *d_Zop[2] = {};
   size_t Zop_cap = 0;
@@ -318,12 +333,37 @@ static size_t smem_bytes(const mom_t *h) { return lds_bytes(h->N, h->lds_mode); 
 
 template <class K>
 static hipError_t allow_lds(K kernel, size_t bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)bytes);
+  return mom_allow_lds(reinterpret_cast<const void *>(kernel), bytes);
 }
 
 extern "C" const char *mom_last_global_error(void) { return g_err.c_str(); }
 extern "C" const char *mom_last_error(const mom_t *h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+// added layer + surface layer of the operator-level API (rt_run.jl:109-112), on first use
+static int ensure_op_layers(mom_t *h) {
+  if (h->op_layers) return MOM_OK;
+  const size_t NN = (size_t)h->N * h->N;
+  for (int k = 0; k < 6; ++k) {
+    const size_t per = ((k < 4) ? NN : (size_t)h->N) * h->S;
+    HIPCHK(h, dmalloc(&h->added[k], per));
+    HIPCHK(h, dmalloc(&h->surf[k], per));
+    HIPCHK(h, hipMemsetAsync(h->added[k], 0, per * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->surf[k], 0, per * sizeof(double), h->stream));
+  }
+  h->op_layers = true;
+  return MOM_OK;
+}
+// the operator-level API keeps the composite matrices in the natural [N,N,S] layout; after a scene-level run the
+// allocation holds row-pitched blocks, which the operator kernels must not be fed
+static int op_composite_ready(mom_t *h, const char *who) {
+  if (h->comp_pitched) {
+    char buf[192];
+    snprintf(buf, sizeof buf, "%s: the composite layer holds scene-level (mom_rt_run) state; start the operator-level "
+             "sequence with mom_copy_added_to_composite or mom_upload", who);
+    return fail(h, MOM_ESTATE, buf);
+  }
+  return MOM_OK;
+}
 
 extern "C" int mom_create(mom_t **out, int device, int N, int nStokes, int S, int max_m, int dtype) {
   if (!out || N <= 0 || S <= 0 || max_m <= 0 || nStokes <= 0 || nStokes > 4 || N % nStokes != 0)
@@ -343,15 +383,13 @@ extern "C" int mom_create(mom_t **out, int device, int N, int nStokes, int S, in
   HIPCHK(h, dmalloc(&h->d_mu, N));
   HIPCHK(h, dmalloc(&h->d_wt, N));
   HIPCHK(h, dmalloc(&h->d_sg, N));
+  (void)NN;
   for (int k = 0; k < 6; ++k) {
-    const size_t per = (k < 4) ? NN : (size_t)N;
-    HIPCHK(h, dmalloc(&h->added[k], per * S));
-    HIPCHK(h, dmalloc(&h->surf[k], per * S));
-    // composite blocks: room for the scene-level row pitch (comp_pitch); the operator-level API uses the natural one
+    // composite blocks: room for the scene-level row pitch (comp_pitch); the operator-level API uses the natural one.
+    // The added / surface layers of the operator-level API (12 N^2 S doubles) are allocated on its first use
+    // (ensure_op_layers): the scene-level path keeps the added layer in LDS and never needs them.
     const size_t perc = (k < 4) ? (size_t)comp_pitch(N) * N : (size_t)N;
     HIPCHK(h, dmalloc(&h->comp[k], perc * S * max_m));
-    HIPCHK(h, hipMemsetAsync(h->added[k], 0, per * S * sizeof(double), h->stream));
-    HIPCHK(h, hipMemsetAsync(h->surf[k], 0, per * S * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(h->comp[k], 0, perc * S * max_m * sizeof(double), h->stream));
   }
   for (int k = 0; k < 4; ++k) HIPCHK(h, dmalloc(&h->d_vec[k], S));
@@ -375,6 +413,7 @@ extern "C" int mom_destroy(mom_t *h) {
   if (!h) return MOM_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->comm && g_rccl_destroy) g_rccl_destroy(h->comm);
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(h->d_mu); fr(h->d_wt); fr(h->d_sg);
   for (int k = 0; k < 6; ++k) { fr(h->added[k]); fr(h->surf[k]); fr(h->comp[k]); }
@@ -383,7 +422,7 @@ extern "C" int mom_destroy(mom_t *h) {
   fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
   fr(h->d_mu0); fr(h->d_wt0); fr(h->d_sg0); fr(h->d_Zpp0); fr(h->d_Zmp0); fr(h->d_hdrJ0); fr(h->d_scratch0);
   for (int k = 0; k < 6; ++k) fr(h->comp0[k]);
-  fr(h->d_R); fr(h->d_T); fr(h->d_hdr); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
+  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
   for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (auto e : h->ev_full) (void)hipEventDestroy(e);
   for (auto e : h->ev_red) (void)hipEventDestroy(e);
@@ -399,9 +438,15 @@ extern "C" int mom_sync(mom_t *h) {
   return MOM_OK;
 }
 
+extern "C" int mom_check(mom_t *h) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  HIPCHK(h, hipSetDevice(h->device));
+  return check_info(h);
+}
+
 extern "C" int mom_set_option(mom_t *h, int option, int value) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  if (option == MOM_OPT_INVERSE) { h->opt_inverse = value; h->q.inv_mode = value; }
+  if (option == MOM_OPT_INVERSE) { h->opt_inverse = value; h->q.inv_mode = value; h->q0.inv_mode = value; }
   else if (option == MOM_OPT_M0_REDUCTION) h->opt_m0 = value;
   else if (option == MOM_OPT_SMALL_WG) h->opt_w4 = value;
   else if (option == MOM_OPT_STAGGER) h->opt_stagger = value;
@@ -438,6 +483,7 @@ extern "C" int mom_set_streams(mom_t *h, const double *qp_muN, const double *wt_
   for (int i = 0; i < N; ++i)
     if (qp_muN[i] != qp_muN[(i / h->nS) * h->nS]) q.regular = 0;
   h->streams_set = true;
+  h->scene_set = false;  // the reduced (I,Q) stream set of a resident scene was derived from the old streams
   return MOM_OK;
 }
 
@@ -445,14 +491,6 @@ static int grid_for(const mom_t *h, size_t total) {
   if (h->lds_mode) return (int)total;
   return (int)std::min<size_t>(total, (size_t)h->G);
 }
-// layer kernels: with enough spectral points to fill the chip several times over, one workgroup
-// walks the M Fourier moments of its point (pt = n, n + S, ...): the 2nd and 3rd pass run with the
-// instruction cache and the phase-matrix bases warm.
-static int grid_for_layers(const mom_t *h, size_t S, int M) {
-  if (!h->lds_mode) return (int)std::min<size_t>(S * M, (size_t)h->G);
-  return (int)((S >= 2048) ? S : S * M);
-}
-
 static int check_info(mom_t *h) {
   int info = 0;
   HIPCHK(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -499,6 +537,7 @@ extern "C" int mom_elemental(mom_t *h, int m, int ndoubl, const double *tau_sum,
   if (!tau_sum || !dtau || !varpi || !Zpp || !Zmp || (z_batch != 1 && z_batch != h->S) || m < 0 || ndoubl < 0)
     return fail(h, MOM_EINVAL, "mom_elemental: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
+  { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
   const size_t NN = (size_t)h->N * h->N, zc = NN * z_batch;
   if (zc > h->Zop_cap) {
     if (h->d_Zop[0]) { (void)hipFree(h->d_Zop[0]); (void)hipFree(h->d_Zop[1]); }
@@ -527,6 +566,7 @@ extern "C" int mom_doubling(mom_t *h, int ndoubl, double *expk) {
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_doubling: call mom_set_streams first");
   if (!expk || ndoubl < 0) return fail(h, MOM_EINVAL, "mom_doubling: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
+  { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
   const size_t sb = (size_t)h->S * sizeof(double);
   HIPCHK(h, hipMemcpyAsync(h->d_vec[3], expk, sb, hipMemcpyHostToDevice, h->stream));
   OpArgs a{};
@@ -543,6 +583,7 @@ extern "C" int mom_interaction(mom_t *h, int iface, int with_surface_layer) {
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_interaction: call mom_set_streams first");
   if (iface < 0 || iface > 3) return fail(h, MOM_EINVAL, "mom_interaction: iface must be 0..3");
   HIPCHK(h, hipSetDevice(h->device));
+  { int rc_ = ensure_op_layers(h); if (rc_) return rc_; if ((rc_ = op_composite_ready(h, "mom_interaction"))) return rc_; }
   OpArgs a{};
   a.q = h->q; a.S = h->S; a.iface = iface;
   for (int k = 0; k < 6; ++k) { a.added[k] = with_surface_layer ? h->surf[k] : h->added[k]; a.comp[k] = h->comp[k]; }
@@ -554,6 +595,8 @@ extern "C" int mom_interaction(mom_t *h, int iface, int with_surface_layer) {
 extern "C" int mom_copy_added_to_composite(mom_t *h) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   HIPCHK(h, hipSetDevice(h->device));
+  { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
+  h->comp_pitched = false;
   const size_t NN = (size_t)h->N * h->N;
   // composite order: R_mp, R_pm, T_pp, T_mm, J0p, J0m ; added order: r_pm, r_mp, t_mm, t_pp, j0p, j0m
   const int src[6] = {1, 0, 3, 2, 4, 5};
@@ -570,6 +613,7 @@ extern "C" int mom_surface_lambertian(mom_t *h, int m, double albedo, const doub
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_surface_lambertian: call mom_set_streams first");
   if (!tau_tot || m < 0) return fail(h, MOM_EINVAL, "mom_surface_lambertian: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
+  { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
   HIPCHK(h, hipMemcpyAsync(h->d_vec[0], tau_tot, (size_t)h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_op_surface_fill, dim3(h->S), dim3(256), 0, h->stream, h->q, h->S, m, albedo, h->d_vec[0],
                      h->surf[0], h->surf[1], h->surf[2], h->surf[3], h->surf[4], h->surf[5]);
@@ -588,10 +632,12 @@ static double *which_ptr(mom_t *h, int which, size_t *count) {
 
 extern "C" int mom_upload(mom_t *h, int which, const double *src) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (which < 0 || which > 17 || !src) return fail(h, MOM_EINVAL, "mom_upload: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (which / 6 != 1) { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
+  else h->comp_pitched = false;  // the caller (re)starts an operator-level sequence: natural [N,N,S] layout
   size_t count = 0;
   double *p = which_ptr(h, which, &count);
-  if (!p || !src) return fail(h, MOM_EINVAL, "mom_upload: bad argument");
-  HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(p, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
@@ -599,10 +645,24 @@ extern "C" int mom_upload(mom_t *h, int which, const double *src) {
 
 extern "C" int mom_download(mom_t *h, int which, double *dst) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (which < 0 || which > 17 || !dst) return fail(h, MOM_EINVAL, "mom_download: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (which / 6 != 1) { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
   size_t count = 0;
   double *p = which_ptr(h, which, &count);
-  if (!p || !dst) return fail(h, MOM_EINVAL, "mom_download: bad argument");
-  HIPCHK(h, hipSetDevice(h->device));
+  if (which / 6 == 1 && h->comp_pitched) {
+    // after mom_rt_run: moment slot 0 of the scene-level state.  With the m = 0 reduction that moment lives in the
+    // (I,Q) sub-problem's own arrays, which have no [N,N,S] image
+    if (h->red0)
+      return fail(h, MOM_ESTATE, "mom_download: Fourier moment 0 ran on the (I,Q) sub-problem; set "
+                                 "MOM_OPT_M0_REDUCTION = 0 before mom_scene_set to read the composite layer back");
+    if (which % 6 < 4) {  // de-pitch: columns of N doubles at a pitch of comp_pitch(N)
+      HIPCHK(h, hipMemcpy2DAsync(dst, (size_t)h->N * sizeof(double), p, (size_t)comp_pitch(h->N) * sizeof(double),
+                                 (size_t)h->N * sizeof(double), (size_t)h->N * h->S, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      return MOM_OK;
+    }
+  }
   HIPCHK(h, hipMemcpyAsync(dst, p, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
@@ -689,9 +749,10 @@ extern "C" int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, 
   if ((rc = upload_new(h, &h->d_node, node_1based, (size_t)nVza))) return rc;
   if ((rc = upload_new(h, &h->d_cos, cos_mphi, (size_t)nVza * M))) return rc;
   if ((rc = upload_new(h, &h->d_sin, sin_mphi, (size_t)nVza * M))) return rc;
-  if (h->d_R) { (void)hipFree(h->d_R); (void)hipFree(h->d_T); (void)hipFree(h->d_hdr); h->d_R = h->d_T = h->d_hdr = nullptr; }
-  HIPCHK(h, dmalloc(&h->d_R, (size_t)nVza * h->nS * S));
-  HIPCHK(h, dmalloc(&h->d_T, (size_t)nVza * h->nS * S));
+  if (h->d_R) { (void)hipFree(h->d_R); (void)hipFree(h->d_hdr); h->d_R = h->d_T = h->d_hdr = nullptr; }
+  // R_SFI || T_SFI in ONE buffer: it is the send buffer of the all-gather (mom_allgather_RT) as it stands
+  HIPCHK(h, dmalloc(&h->d_R, 2 * (size_t)nVza * h->nS * S));
+  h->d_T = h->d_R + (size_t)nVza * h->nS * S;
   HIPCHK(h, dmalloc(&h->d_hdr, (size_t)nVza * h->nS * S));
   if (!h->d_hdrJ) {
     HIPCHK(h, dmalloc(&h->d_hdrJ, (size_t)h->N * S));
@@ -765,6 +826,7 @@ extern "C" int mom_rt_run(mom_t *h) {
   const size_t S = h->S;
   const int M = h->scene_M;
   h->launches = 0; h->launches_full = 0; h->launches_red = 0;
+  h->comp_pitched = true;
   while (h->ev_full.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_full.push_back(e); }
   while (h->ev_red.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_red.push_back(e); }
   const size_t NN = (size_t)h->N * h->N;
@@ -918,6 +980,187 @@ extern "C" int mom_get_RT_device(mom_t *h, void *dR, void *dT) {
   const size_t bytes = (size_t)h->nVza * h->nS * h->S * sizeof(double);
   HIPCHK(h, hipMemcpyAsync(dR, h->d_R, bytes, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(dT, h->d_T, bytes, hipMemcpyDeviceToDevice, h->stream));
+  return MOM_OK;  // asynchronous: a singular-operator report surfaces at mom_get_RT / mom_check
+}
+
+// ---------------------------------------------------------------- operator-level post-processing
+
+// postprocessing_vza!(RS_type::noRS, iμ₀, pol_type, composite_layer, vza, qp_μ, m, vaz, μ₀, weight, nSpec, SFI, R, R_SFI,
+// T, T_SFI, ...) -- postprocessing_vza.jl:9-60 for ONE Fourier moment on the operator-level composite layer: gathers
+// the nVza view rows of J0-/J0+ on the GPU (the reference copies the whole composite layer to the host, :17-20)
+__global__ void k_op_postprocess(int N, int nS, int S, int nVza, const int *node, const double *cs_k, const double *J0p,
+                                 const double *J0m, double *outR, double *outT) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)nVza * nS * S;
+  if (idx >= total) return;
+  const int v = (int)(idx % nVza);
+  const int k = (int)((idx / nVza) % nS);
+  const size_t s = idx / ((size_t)nVza * nS);
+  const size_t o = (size_t)(node[v] - 1) * nS + k + (size_t)N * s;
+  const double cs = cs_k[v + (size_t)nVza * k];
+  outR[idx] = cs * J0m[o];
+  outT[idx] = cs * J0p[o];
+}
+
+extern "C" int mom_postprocess(mom_t *h, int m, int nVza, const int *node_1based, const double *vaz_deg, double weight,
+                               double *R_SFI, double *T_SFI) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (m < 0 || nVza <= 0 || !node_1based || !vaz_deg || !R_SFI || !T_SFI)
+    return fail(h, MOM_EINVAL, "mom_postprocess: bad argument");
+  for (int v = 0; v < nVza; ++v)
+    if (node_1based[v] < 1 || node_1based[v] * h->nS > h->N) return fail(h, MOM_EINVAL, "mom_postprocess: bad view node");
+  HIPCHK(h, hipSetDevice(h->device));
+  { const int rc_ = op_composite_ready(h, "mom_postprocess"); if (rc_) return rc_; }
+  const size_t total = (size_t)nVza * h->nS * h->S;
+  if (total > h->post_cap) {
+    if (h->d_post[0]) (void)hipFree(h->d_post[0]);
+    h->d_post[0] = nullptr; h->post_cap = 0;
+    HIPCHK(h, dmalloc(&h->d_post[0], 2 * total));
+    h->post_cap = total;
+  }
+  h->d_post[1] = h->d_post[0] + total;
+  // bigCS = weight * Diagonal([cos(m φ), cos(m φ), sin(m φ), sin(m φ)][1:n])   (postprocessing_vza.jl:32-33), cosd/sind
+  // exact at the quadrant angles like Julia's
+  auto cosd = [](double x) { double r = std::fmod(std::fabs(x), 360.0); if (r == 90.0 || r == 270.0) return 0.0; if (r == 0.0) return 1.0;
+                             if (r == 180.0) return -1.0; return std::cos(x * (M_PI / 180.0)); };
+  auto sind = [](double x) { double r = std::fmod(x, 360.0); if (r < 0) r += 360.0; if (r == 0.0 || r == 180.0) return 0.0;
+                             if (r == 90.0) return 1.0; if (r == 270.0) return -1.0; return std::sin(x * (M_PI / 180.0)); };
+  std::vector<double> cs((size_t)nVza * h->nS);
+  for (int k = 0; k < h->nS; ++k)
+    for (int v = 0; v < nVza; ++v) cs[v + (size_t)nVza * k] = weight * ((k < 2) ? cosd(m * vaz_deg[v]) : sind(m * vaz_deg[v]));
+  int *d_node = nullptr;
+  double *d_cs = nullptr;
+  HIPCHK(h, dmalloc(&d_node, (size_t)nVza));
+  HIPCHK(h, dmalloc(&d_cs, cs.size()));
+  HIPCHK(h, hipMemcpyAsync(d_node, node_1based, (size_t)nVza * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_op_postprocess, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->N, h->nS, h->S, nVza,
+                     d_node, d_cs, h->comp[4], h->comp[5], h->d_post[0], h->d_post[1]);
+  HIPCHK(h, hipGetLastError());
+  std::vector<double> hr(total), ht(total);
+  HIPCHK(h, hipMemcpyAsync(hr.data(), h->d_post[0], total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(ht.data(), h->d_post[1], total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  (void)hipFree(d_node); (void)hipFree(d_cs);
+  for (size_t i = 0; i < total; ++i) { R_SFI[i] += hr[i]; T_SFI[i] += ht[i]; }  // `+=` like :48-49
+  return MOM_OK;
+}
+
+// ---------------------------------------------------------------- multi-GPU: RCCL behind the C ABI
+
+namespace {
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+// librccl.so.1 is loaded on first use (the soname a host process such as PyTorch-ROCm may already have mapped: one
+// copy per process); libmomcore.so itself stays loadable on machines without RCCL
+int rccl_load(mom_t *h) {
+  if (g_rccl.lib) return MOM_OK;
+  void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return fail(h, MOM_EHIP, "mom_comm: cannot load librccl.so.1 (RCCL)");
+  Rccl r;
+  r.lib = lib;
+  *(void **)(&r.GetUniqueId) = dlsym(lib, "ncclGetUniqueId");
+  *(void **)(&r.CommInitRank) = dlsym(lib, "ncclCommInitRank");
+  *(void **)(&r.CommDestroy) = dlsym(lib, "ncclCommDestroy");
+  *(void **)(&r.AllGather) = dlsym(lib, "ncclAllGather");
+  *(void **)(&r.GetErrorString) = dlsym(lib, "ncclGetErrorString");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+    return fail(h, MOM_EHIP, "mom_comm: librccl.so.1 lacks a required symbol");
+  g_rccl = r;
+  g_rccl_destroy = [](void *c) { (void)g_rccl.CommDestroy((ncclComm_t)c); };
+  return MOM_OK;
+}
+int rccl_fail(mom_t *h, const char *what, ncclResult_t r) {
+  char buf[256];
+  snprintf(buf, sizeof buf, "%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+  return fail(h, MOM_EHIP, buf);
+}
+}  // namespace
+
+extern "C" int mom_comm_unique_id(void *id_out, size_t bytes) {
+  if (!id_out || bytes < sizeof(ncclUniqueId)) return fail(nullptr, MOM_EINVAL, "mom_comm_unique_id: need MOM_COMM_ID_BYTES bytes");
+  const int rc = rccl_load(nullptr);
+  if (rc) return rc;
+  ncclUniqueId id;
+  const ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) return rccl_fail(nullptr, "ncclGetUniqueId", r);
+  memcpy(id_out, &id, sizeof id);
+  return MOM_OK;
+}
+
+extern "C" int mom_comm_init(mom_t *h, int rank, int nranks, const void *nccl_id) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (nranks < 1 || rank < 0 || rank >= nranks || !nccl_id) return fail(h, MOM_EINVAL, "mom_comm_init: bad argument");
+  if (h->comm) return fail(h, MOM_ESTATE, "mom_comm_init: communicator already initialised");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int rc = rccl_load(h);
+  if (rc) return rc;
+  ncclUniqueId id;
+  memcpy(&id, nccl_id, sizeof id);
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = g_rccl.CommInitRank(&comm, nranks, id, rank);
+  if (r != ncclSuccess) return rccl_fail(h, "ncclCommInitRank", r);
+  h->comm = comm; h->comm_rank = rank; h->comm_size = nranks;
+  return MOM_OK;
+}
+
+extern "C" int mom_comm_destroy(mom_t *h) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (h->comm) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    (void)g_rccl.CommDestroy((ncclComm_t)h->comm);
+    h->comm = nullptr; h->comm_size = 1; h->comm_rank = 0;
+  }
+  return MOM_OK;
+}
+
+extern "C" int mom_allgather(mom_t *h, const void *d_local, void *d_global, size_t count) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->comm) return fail(h, MOM_ESTATE, "mom_allgather: call mom_comm_init first");
+  if (!d_local || !d_global) return fail(h, MOM_EINVAL, "mom_allgather: null buffer");
+  HIPCHK(h, hipSetDevice(h->device));
+  const ncclResult_t r = g_rccl.AllGather(d_local, d_global, count, ncclDouble, (ncclComm_t)h->comm, h->stream);
+  if (r != ncclSuccess) return rccl_fail(h, "ncclAllGather", r);
+  return MOM_OK;
+}
+
+// The ONE collective of a sharded run: every rank contributes its R_SFI || T_SFI block (already contiguous in the
+// handle, 2 * nVza * nStokes * S_loc doubles) and receives [nranks][2][nVza*nStokes*S_loc]
+extern "C" int mom_allgather_RT_device(mom_t *h, void *d_global) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->scene_set || !d_global) return fail(h, MOM_ESTATE, "mom_allgather_RT_device: no scene / null output");
+  return mom_allgather(h, h->d_R, d_global, 2 * (size_t)h->nVza * h->nS * h->S);
+}
+
+extern "C" int mom_allgather_RT(mom_t *h, double *R_SFI_global, double *T_SFI_global) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->scene_set || !R_SFI_global || !T_SFI_global) return fail(h, MOM_ESTATE, "mom_allgather_RT: no scene / null output");
+  if (!h->comm) return fail(h, MOM_ESTATE, "mom_allgather_RT: call mom_comm_init first");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t nout = (size_t)h->nVza * h->nS * h->S, need = 2 * nout * h->comm_size;
+  if (need > h->gather_cap) {
+    if (h->d_gather) (void)hipFree(h->d_gather);
+    h->d_gather = nullptr; h->gather_cap = 0;
+    HIPCHK(h, dmalloc(&h->d_gather, need));
+    h->gather_cap = need;
+  }
+  int rc = mom_allgather_RT_device(h, h->d_gather);
+  if (rc) return rc;
+  // [rank][R|T][nVza, nStokes, S_loc] -> R_SFI, T_SFI [nVza, nStokes, nranks * S_loc] (rank-major spectral axis)
+  for (int r = 0; r < h->comm_size; ++r) {
+    HIPCHK(h, hipMemcpyAsync(R_SFI_global + nout * r, h->d_gather + 2 * nout * r, nout * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(T_SFI_global + nout * r, h->d_gather + 2 * nout * r + nout, nout * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
   return check_info(h);
 }
 

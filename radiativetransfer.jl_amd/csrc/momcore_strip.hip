@@ -9,6 +9,7 @@
 
 #include "mom_diag.hpp"
 #include "mom_entry.hpp"
+#include "mom_host.hpp"
 
 using namespace MOM_NS;
 
@@ -21,8 +22,7 @@ hipError_t MOM_CAT(MOM_CAT(mom_strip, MOM_STRIP_KS), _launch_layer)(const void *
   const LayerArgs a = *reinterpret_cast<const LayerArgs *>(layer_args);
   hipError_t e = hipSuccess;
 #define STRIP_LAUNCH(IF)                                                                                            \
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_layer<true, IF, MOM_STRIP_KS>),                     \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)) != hipSuccess)               \
+  if ((e = mom_allow_lds(reinterpret_cast<const void *>(k_layer<true, IF, MOM_STRIP_KS>), smem)) != hipSuccess)     \
     return e;                                                                                                       \
   hipLaunchKernelGGL((k_layer<true, IF, MOM_STRIP_KS>), dim3(grid), dim3(kThreads), smem, st, a);
   switch (iface) {

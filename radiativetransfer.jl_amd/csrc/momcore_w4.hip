@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mom_entry.hpp"
+#include "mom_host.hpp"
 
 using namespace mom4;
 
@@ -17,7 +18,7 @@ int mom4_generic_bufs_elems(int N) { return (int)(kGenericBufs * mat_elems(N)); 
 
 template <class K>
 static hipError_t allow(K kernel, size_t bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return mom_allow_lds(reinterpret_cast<const void *>(kernel), bytes);
 }
 
 hipError_t mom4_launch_layer(const void *layer_args, int iface, bool lds, int grid, size_t smem, hipStream_t st) {
