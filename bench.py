@@ -41,13 +41,13 @@ DEFAULT_POINTS = {"C2": 10_000, "C1": 200_000, "C4": 2_000}
 
 
 def cpu_baseline(model, workload, budget_s=12.0):
-    """The C oracle (oracle/momref.c, kind "port": the reference is Julia and cannot run here) on all
-    host cores over a bounded seeded sample of the same scene's spectral points."""
+    """The C oracle (oracle/momref.c, kind "port": the reference is Julia and cannot run here) on all the
+    host cores this process may use over a bounded seeded sample of the same scene's spectral points."""
     sys.path.insert(0, str(ROOT / "tests"))
     import helpers
     from oracle import cref
     import rtamd
-    cores = os.cpu_count() or 1
+    cores = cref.effective_cores()  # affinity mask and cgroup CPU quota, not the machine's logical CPU count
     sc = helpers.oracle_scene(model)
     p = cref.pack_scene(sc)
     rng = np.random.default_rng(0)

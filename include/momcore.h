@@ -156,6 +156,39 @@ int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, const doubl
                   const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface, const double *tau_sum,
                   double albedo, int nVza, const int *node_1based, const double *cos_mphi, const double *sin_mphi);
 
+/* ---- device-side layer optics: tau_abs never visits the host -----------------------
+ *
+ * mom_absorption_begin   τ_abs = zeros(nSpec, Nz) resident in HBM (model_from_parameters.jl:48) + the spectral grid
+ *                        [nSpec] the line shapes are evaluated on (NULL keeps a previously uploaded grid)
+ * mom_voigt_tau_abs      compute_absorption_profile! for ONE layer (atmo_prof.jl:427-449):
+ *                          τ_abs[:, iz] += absorption_cross_section(model, grid, p[iz], T[iz]) * vcd_dry[iz] * vmr
+ *                        with the Voigt/HW32SD line shape; the host passes the per-line prefactors like for
+ *                        mom_voigt_xsec and factor = vcd_dry[iz] * vmr; σ is accumulated straight into the resident
+ *                        table by the line-shape kernel (no σ round trip, no allocation in steady state)
+ * mom_absorption_set     uploads a host τ_abs [nSpec, Nz] instead (ABSCO/LUT or synthetic tables)
+ * mom_absorption_get     test access
+ * mom_scene_set_optics   mom_scene_set with the layer optics assembled ON THE DEVICE from their ingredients:
+ *                        constructCoreOpticalProperties (compEffectiveLayerProperties.jl:1-78) = Rayleigh
+ *                        (tau_rayl [nSpec, Nz], ϖ = varpi_rayl = ϖ_Cabannes) `+` each aerosol type (createAero :80-85:
+ *                        tau_aer [nAer, Nz], omega_aer, ft_aer [nAer]; types.jl:632-661) `+` the resident gas
+ *                        absorption (:672-678), τ_sum (:108), then ndoubl (rt_kernel.jl:238-246) and the
+ *                        interface codes (rt_helper_functions.jl:8-27) from per-layer maxima of τϖ -- reduced over all
+ *                        ranks first when a communicator is initialised (mom_comm_init), so a sharded run uses the
+ *                        GLOBAL doubling numbers.  Zpp/Zmp: [N, N, 1 + nAer, M].  Results are bitwise those of the
+ *                        host route (mom_scene_set fed by the reference's host algebra).
+ * mom_scene_get_layers   ndoubl / iface [Nz] and (optionally, NULL to skip) τ, ϖ [nSpec,Nz], zw [K,nSpec,Nz],
+ *                        τ_sum [nSpec,Nz+1] of the resident scene */
+int mom_absorption_begin(mom_t *h, int Nz, const double *grid);
+int mom_voigt_tau_abs(mom_t *h, int iz_1based, int nLines, const double *nu, const double *gamma_d, const double *y,
+                      const double *S, const int *ind_start_1based, const int *ind_stop_1based, double factor);
+int mom_absorption_set(mom_t *h, int Nz, const double *tau_abs);
+int mom_absorption_get(mom_t *h, double *tau_abs);
+int mom_scene_set_optics(mom_t *h, int Nz, int nAer, int M, const double *tau_rayl, double varpi_rayl,
+                         const double *tau_aer, const double *omega_aer, const double *ft_aer, const double *Zpp,
+                         const double *Zmp, double albedo, int nVza, const int *node_1based, const double *cos_mphi,
+                         const double *sin_mphi);
+int mom_scene_get_layers(mom_t *h, int *ndoubl, int *iface, double *tau, double *varpi, double *zw, double *tau_sum);
+
 /* The whole of rt_run.jl:125-215 for the resident scene: all Fourier moments, all layers,
  * surface, post-processing.  Asynchronous on the handle's stream; results stay on the GPU. */
 int mom_rt_run(mom_t *h);
@@ -218,7 +251,8 @@ enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1, MOM_OPT_M0_REDUCTION = 2,
  * HumlicekWeidemann32SDErrorFunction (complex_error_functions.jl:226-234).  The host passes
  * the per-line prefactors of :79-107: nu = pressure-shifted centre, gamma_d, y, S =
  * temperature-corrected strength, and the 1-based inclusive grid window of each line.
- * sigma[nGrid] (host) receives sum over lines in line order.  `device` as in mom_create. */
+ * sigma[nGrid] (host) receives sum over lines in line order.  `device` as in mom_create.
+ * Error text: mom_last_global_error(). */
 int mom_voigt_xsec(int device, int nLines, const double *nu, const double *gamma_d, const double *y,
                    const double *S, const int *ind_start_1based, const int *ind_stop_1based, int nGrid,
                    const double *grid, double *sigma);

@@ -34,9 +34,23 @@ def lib():
     global _LIB
     if _LIB is None:
         _LIB = C.CDLL(str(build()))
+        _LIB.omp_set_num_threads(effective_cores())  # libgomp's default would be the machine's logical CPU count
         _LIB.ora_w_hw32sd_re.restype = C.c_double
         _LIB.ora_w_hw32sd_re.argtypes = [C.c_double, C.c_double]
     return _LIB
+
+
+def effective_cores() -> int:
+    """CPUs this process may actually use: the affinity mask and the cgroup CPU quota (the GPU boxes show 256 logical
+    CPUs but run the container under a 16-CPU quota: 256 OpenMP threads there only fight over 16 CPUs' time)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def dp(a):
@@ -117,7 +131,7 @@ def pack_scene(scene: mr.Scene) -> Packed:
 def rt_run(p: Packed, pts=None, nthreads: int = 0):
     """Full elastic run on the C oracle.  Returns R_SFI, T_SFI as [nVza, nStokes, S]."""
     if nthreads <= 0:
-        nthreads = os.cpu_count() or 1
+        nthreads = effective_cores()
     R = np.zeros(p.nVza * p.nS * p.S)
     T = np.zeros(p.nVza * p.nS * p.S)
     st = p.c_struct()
@@ -133,7 +147,7 @@ def rt_run(p: Packed, pts=None, nthreads: int = 0):
 def rt_run_full(p: Packed, pts=None, nthreads: int = 0):
     """Like rt_run plus the RAMI extras: returns R, T, hdr [nVza,nStokes,S], bhr_uw, bhr_dw [nStokes,S], info."""
     if nthreads <= 0:
-        nthreads = os.cpu_count() or 1
+        nthreads = effective_cores()
     n = p.nVza * p.nS * p.S
     R, T, H = np.zeros(n), np.zeros(n), np.zeros(n)
     up, dw = np.zeros(p.nS * p.S), np.zeros(p.nS * p.S)

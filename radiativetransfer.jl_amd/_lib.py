@@ -57,6 +57,13 @@ SIGNATURES = {
     "mom_download": (C.c_int, [c_h, C.c_int, c_dp]),
     "mom_scene_set": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip, c_dp,
                                 C.c_double, C.c_int, c_ip, c_dp, c_dp]),
+    "mom_absorption_begin": (C.c_int, [c_h, C.c_int, c_dp]),
+    "mom_voigt_tau_abs": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip, C.c_double]),
+    "mom_absorption_set": (C.c_int, [c_h, C.c_int, c_dp]),
+    "mom_absorption_get": (C.c_int, [c_h, c_dp]),
+    "mom_scene_set_optics": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_dp, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp,
+                                       C.c_double, C.c_int, c_ip, c_dp, c_dp]),
+    "mom_scene_get_layers": (C.c_int, [c_h, c_ip, c_ip, c_dp, c_dp, c_dp, c_dp]),
     "mom_rt_run": (C.c_int, [c_h]),
     "mom_get_RT": (C.c_int, [c_h, c_dp, c_dp]),
     "mom_get_hdr": (C.c_int, [c_h, c_dp, c_dp, c_dp]),
@@ -212,6 +219,53 @@ class Handle:
         self.check(self.lib.mom_scene_set(self._h, int(Nz), int(K), int(M), *[dp(x) for x in d], ip(nd), ip(iface),
                                           dp(ts), float(albedo), len(node), ip(node), dp(cm), dp(sm)))
 
+    # -- device-side layer optics --------------------------------------------------------------
+    def absorption_begin(self, Nz, grid=None):
+        g = f64(grid) if grid is not None else None
+        assert g is None or g.size == self.S
+        self._absNz = int(Nz)
+        self.check(self.lib.mom_absorption_begin(self._h, int(Nz), dp(g) if g is not None else None))
+
+    def absorption_set(self, tau_abs):
+        """tau_abs: [S, Nz] numpy (reference layout)."""
+        t = np.ascontiguousarray(np.asarray(tau_abs, dtype=np.float64).T).reshape(-1)  # column-major [S, Nz]
+        self._absNz = int(np.asarray(tau_abs).shape[1])
+        self.check(self.lib.mom_absorption_set(self._h, self._absNz, dp(t)))
+
+    def absorption_get(self):
+        out = np.empty(self.S * self._absNz)
+        self.check(self.lib.mom_absorption_get(self._h, dp(out)))
+        return out.reshape(self._absNz, self.S).T.copy()
+
+    def voigt_tau_abs(self, iz_1based, nu, gamma_d, y, S, ind_start, ind_stop, factor):
+        a = [f64(x) for x in (nu, gamma_d, y, S)]
+        i0, i1 = i32(ind_start), i32(ind_stop)
+        self.check(self.lib.mom_voigt_tau_abs(self._h, int(iz_1based), len(a[0]), *[dp(x) for x in a], ip(i0), ip(i1),
+                                              float(factor)))
+
+    def scene_set_optics(self, Nz, M, tau_rayl, varpi_rayl, tau_aer, omega_aer, ft_aer, Zpp, Zmp, albedo, node, cos_mphi,
+                         sin_mphi):
+        """tau_rayl [S, Nz], tau_aer [nAer, Nz] numpy (reference layouts); Zpp/Zmp already in ABI order."""
+        tr = np.ascontiguousarray(np.asarray(tau_rayl, dtype=np.float64).T).reshape(-1)
+        ta = np.asarray(tau_aer, dtype=np.float64)
+        nAer = ta.shape[0] if ta.size else 0
+        taf = np.ascontiguousarray(ta.T).reshape(-1) if nAer else np.zeros(1)  # [nAer, Nz] column-major
+        om, ft = (f64(omega_aer), f64(ft_aer)) if nAer else (np.zeros(1), np.zeros(1))
+        zp, zm = f64(Zpp).reshape(-1), f64(Zmp).reshape(-1)
+        node = i32(node)
+        cm, sm = f64(cos_mphi).reshape(-1), f64(sin_mphi).reshape(-1)
+        self.nVza = len(node)
+        self._Nz, self._K = int(Nz), 1 + nAer
+        self.check(self.lib.mom_scene_set_optics(self._h, int(Nz), nAer, int(M), dp(tr), float(varpi_rayl), dp(taf), dp(om),
+                                                 dp(ft), dp(zp), dp(zm), float(albedo), len(node), ip(node), dp(cm), dp(sm)))
+
+    def scene_get_layers(self, Nz, K, arrays=True):
+        nd, iface = np.zeros(Nz, dtype=np.int32), np.zeros(Nz, dtype=np.int32)
+        S = self.S
+        bufs = [np.empty(S * Nz), np.empty(S * Nz), np.empty(K * S * Nz), np.empty(S * (Nz + 1))] if arrays else [None] * 4
+        self.check(self.lib.mom_scene_get_layers(self._h, ip(nd), ip(iface), *[dp(b) if b is not None else None for b in bufs]))
+        return (nd, iface) + tuple(bufs)
+
     def rt_run(self):
         self.check(self.lib.mom_rt_run(self._h))
 
@@ -287,7 +341,7 @@ def voigt_xsec(nu, gamma_d, y, S, ind_start, ind_stop, grid, device: int = 0):
     sigma = np.empty(len(g))
     rc = lib.mom_voigt_xsec(device, len(a[0]), *[dp(x) for x in a], ip(i0), ip(i1), len(g), dp(g), dp(sigma))
     if rc != MOM_OK:
-        raise MomError(rc, "mom_voigt_xsec failed")
+        raise MomError(rc, lib.mom_last_global_error().decode())
     return sigma
 
 

@@ -27,7 +27,9 @@ t_ref = 296.0
 
 @dataclass
 class HitranTable:
-    """The columns of read_hitran's table (read_hitran.jl:14-68) that the line shape needs."""
+    """The columns of read_hitran's table (read_hitran.jl:14-68, types.jl:24-61) that the line shape needs."""
+    mol: np.ndarray      # HITRAN molecule id per line
+    iso: np.ndarray      # HITRAN isotopologue id per line
     νᵢ: np.ndarray
     Sᵢ: np.ndarray
     γ_air: np.ndarray
@@ -35,7 +37,6 @@ class HitranTable:
     E_lower: np.ndarray  # E″ ; -1 means "no temperature correction"
     n_air: np.ndarray
     δ_air: np.ndarray
-    mol_weight: np.ndarray  # g/mol per line (mol_weight(mol, iso), constants/mol_weights.jl)
 
 
 _HITRAN_FIELDS = [("mol", 2, int), ("iso", 1, int), ("νᵢ", 12, float), ("Sᵢ", 10, float), ("Aᵢ", 10, float),
@@ -74,9 +75,111 @@ def read_hitran(filepath, mol: int = -1, iso: int = -1, ν_min: float = 0.0, ν_
     return {k: (np.array(v) if not isinstance(v[0], str) else v) for k, v in cols.items()}
 
 
+def hitran_table(cols: dict) -> HitranTable:
+    """read_hitran's column dict -> HitranTable (make_hitran_model's input, make_model_helpers.jl)."""
+    f = lambda k: np.asarray(cols[k], dtype=np.float64)
+    return HitranTable(mol=np.asarray(cols["mol"], dtype=np.int64), iso=np.asarray(cols["iso"], dtype=np.int64),
+                       νᵢ=f("νᵢ"), Sᵢ=f("Sᵢ"), γ_air=f("γ_air"), γ_self=f("γ_self"), E_lower=f("E_lower"),
+                       n_air=f("n_air"), δ_air=f("δ_air"))
+
+
+# ------------------------------------------------------------------------------------------
+# TIPS-2017 partition sums and isotopologue weights (constants/TIPS_2017.jl, mol_weights.jl).
+# The tables are the reference's NetCDF files, extracted for HITRAN molecules 1-7 by
+# tools/extract_tips.py into data/tips_2017_subset.npz (Float32 like the originals).
+# ------------------------------------------------------------------------------------------
+
+_TIPS = None
+
+
+def _tips():
+    global _TIPS
+    if _TIPS is None:
+        f = _lib.PKG_DIR / "data" / "tips_2017_subset.npz"
+        if not f.exists():
+            raise FileNotFoundError(f"{f} missing: run /opt/conda/bin/python3.9 tools/extract_tips.py")
+        _TIPS = dict(np.load(f))
+    return _TIPS
+
+
+def mol_weight(mol: int, iso: int) -> np.float32:
+    """mol_weight(mol, iso) (mol_weights.jl:23): Float32 g/mol; raises like check_exists for unfilled pairs."""
+    t = _tips()
+    mols = list(t["molecules"])
+    if int(mol) not in mols or not (1 <= int(iso) <= t["mol_weight"].shape[1]):
+        raise KeyError(f"No matching (mol, iso) pair ({mol}, {iso}) in the extracted tables (tools/extract_tips.py)")
+    w = t["mol_weight"][mols.index(int(mol)), int(iso) - 1]
+    if w == -1:
+        raise KeyError("No matching (mol, iso) pair")
+    return np.float32(w)
+
+
+def get_TT(mol: int, iso: int) -> np.ndarray:
+    return _tips()[f"T_{int(mol)}_{int(iso)}"]
+
+
+def get_TQ(mol: int, iso: int) -> np.ndarray:
+    return _tips()[f"Q_{int(mol)}_{int(iso)}"]
+
+
+class CubicSpline:
+    """DataInterpolations.CubicSpline(u, t) as `qoft!` uses it (compute_absorption_cross_section.jl:208-210; compat
+    DataInterpolations 4, third-party, restated from its published source): second derivatives z from the
+    tridiagonal system with rows [2(h_i + h_{i+1})] and right-hand side 0 at BOTH ends (first row 2 h_1 z_1 + h_1 z_2 = 0,
+    not z_1 = 0), all in the element type of the data -- Float32 for the TIPS tables -- and a Float64 evaluation."""
+
+    def __init__(self, u: np.ndarray, t: np.ndarray):
+        FT = np.result_type(u.dtype, t.dtype).type
+        u, t = u.astype(FT), t.astype(FT)
+        n = len(t) - 1
+        h = np.concatenate(([FT(0)], (t[1:] - t[:-1]).astype(FT), [FT(0)])).astype(FT)
+        dl = h[1:n + 1].copy()
+        dg = (FT(2) * (h[0:n + 1] + h[1:n + 2])).astype(FT)
+        du = h[1:n + 1].copy()
+        d = np.zeros(n + 1, dtype=FT)
+        for i in range(1, n):
+            d[i] = FT(6) * (u[i + 1] - u[i]) / h[i + 1] - FT(6) * (u[i] - u[i - 1]) / h[i]
+        # LU of the (diagonally dominant: no interchange) tridiagonal matrix and the two substitutions, in FT
+        for i in range(n):
+            f = FT(dl[i] / dg[i])
+            dg[i + 1] = FT(dg[i + 1] - f * du[i])
+            d[i + 1] = FT(d[i + 1] - f * d[i])
+        z = np.zeros(n + 1, dtype=FT)
+        z[n] = FT(d[n] / dg[n])
+        for i in range(n - 1, -1, -1):
+            z[i] = FT((d[i] - du[i] * z[i + 1]) / dg[i])
+        self.u, self.t, self.h, self.z = u, t, h[:n + 1], z
+
+    def __call__(self, x: float) -> float:
+        t, u, h, z = self.t, self.u, self.h, self.z
+        i = int(np.searchsorted(t, x, side="right")) - 1        # searchsortedlast
+        i = max(0, min(i, len(t) - 2))
+        x = np.float64(x)
+        I = z[i] * (t[i + 1] - x) ** 3 / (6 * h[i + 1]) + z[i + 1] * (x - t[i]) ** 3 / (6 * h[i + 1])
+        C = (u[i + 1] / h[i + 1] - z[i + 1] * h[i + 1] / 6) * (x - t[i])
+        D = (u[i] / h[i + 1] - z[i] * h[i + 1] / 6) * (t[i + 1] - x)
+        return float(I + C + D)
+
+
+_SPLINES = {}
+
+
+def qoft(mol: int, iso: int, T: float, T_ref: float = t_ref) -> float:
+    """qoft!(M, I, T, T_ref, result) (compute_absorption_cross_section.jl:197-214): Q(T_ref)/Q(T) from the
+    TIPS-2017 table of the isotopologue by cubic-spline interpolation."""
+    key = (int(mol), int(iso))
+    if key not in _SPLINES:
+        TT, TQ = get_TT(*key), get_TQ(*key)
+        _SPLINES[key] = (CubicSpline(TQ, TT), float(TT.min()), float(TT.max()))
+    sp, Tmin, Tmax = _SPLINES[key]
+    if not (Tmin < T < Tmax):
+        raise AssertionError(f"TIPS2017: T ({T}) must be between {Tmin} K and {Tmax} K.")
+    return sp(T_ref) / sp(T)
+
+
 def linear_rotor_qratio(T: float) -> float:
-    """Q(T_ref)/Q(T) for a rigid linear rotor (stand-in for the TIPS-2017 spline of qoft!,
-    compute_absorption_cross_section.jl:197-214, whose NetCDF tables are not shipped here)."""
+    """Q(T_ref)/Q(T) of a rigid linear rotor -- NOT what the reference uses (that is `qoft`); kept only as an
+    explicit `qratio=` choice for synthetic line lists of molecules outside the extracted tables."""
     return t_ref / T
 
 
@@ -93,20 +196,32 @@ class LinePrefactors:
 def line_prefactors(h: HitranTable, grid: np.ndarray, pressure: float, temperature: float, vmr: float = 0.0,
                     wing_cutoff: float = 40.0, qratio: Optional[Callable[[float], float]] = None) -> LinePrefactors:
     """compute_absorption_cross_section.jl:54-107: selection of lines inside the padded grid,
-    pressure shift, Lorentz and Doppler half widths, y, temperature-corrected strength and the
-    index window each line touches (linear interpolation of grid -> index, clamped, rounded
-    half-to-even like Julia's `round`)."""
+    pressure shift, Lorentz and Doppler half widths (Float32 square root of the Float32 isotopologue weight, as
+    `sqrt(mol_weight(mol, iso))` evaluates), y, the TIPS-2017 temperature correction of the strength (`qoft!`) and the
+    index window each line touches (linear interpolation of grid -> index, clamped, rounded half-to-even like
+    Julia's `round`).  `qratio` overrides the partition-sum ratio (a callable of T); default = the reference's qoft."""
     grid = np.asarray(grid, dtype=np.float64)
-    qratio = qratio or linear_rotor_qratio
+    temperature = float(temperature)
     keep = (grid.min() - wing_cutoff < h.νᵢ) & (h.νᵢ < grid.max() + wing_cutoff)
     ν0, S0 = h.νᵢ[keep], h.Sᵢ[keep]
+    mol, iso = h.mol[keep], h.iso[keep]
     ν = ν0 + pressure / p_ref * h.δ_air[keep]
     γ_l = (h.γ_air[keep] * (1 - vmr) * pressure / p_ref + h.γ_self[keep] * vmr * pressure / p_ref) * \
           (t_ref / temperature) ** h.n_air[keep]
-    γ_d = (cSqrt2Ln2 / cc_) * np.sqrt(cBolts_ / cMassMol) * np.sqrt(temperature) * ν0 / np.sqrt(h.mol_weight[keep])
-    y = np.sqrt(cLn2) * γ_l / γ_d
+    pairs = sorted(set(zip(mol.tolist(), iso.tolist())))
+    sqw = np.empty(ν0.size)
+    rate = np.empty(ν0.size)
     E = h.E_lower[keep]
-    corr = qratio(temperature) * np.exp(c2 * E * (1 / t_ref - 1 / temperature)) * \
+    for (M, I) in pairs:
+        sel = (mol == M) & (iso == I)
+        sqw[sel] = np.float64(np.sqrt(mol_weight(M, I)))  # Float32 sqrt, then promoted
+        if np.any(E[sel] != -1):
+            rate[sel] = qratio(temperature) if qratio is not None else qoft(M, I, temperature, t_ref)
+        else:
+            rate[sel] = 1.0
+    γ_d = ((cSqrt2Ln2 / cc_) * np.sqrt(cBolts_ / cMassMol) * np.sqrt(temperature) * ν0 / sqw)
+    y = np.sqrt(cLn2) * γ_l / γ_d
+    corr = rate * np.exp(c2 * E * (1 / t_ref - 1 / temperature)) * \
            (1 - np.exp(-c2 * ν0 / temperature)) / (1 - np.exp(-c2 * ν0 / t_ref))
     S = np.where(E != -1, S0 * corr, S0)
     idx = np.arange(1, grid.size + 1, dtype=np.float64)
@@ -129,10 +244,30 @@ def compute_absorption_cross_section(h: HitranTable, grid, pressure: float, temp
                            device=device)
 
 
+def compute_absorption_profile(h, table: HitranTable, grid, p_full, T, vcd_dry, vmr, wing_cutoff: float = 40.0,
+                               model_vmr: float = 0.0, qratio=None, begin: bool = True):
+    """compute_absorption_profile!(τ_abs, absorption_model, grid, vmr, profile) (atmo_prof.jl:427-449) on the handle's
+    resident τ_abs table: per layer the host builds the line prefactors (O(nLines)), the GPU adds
+    σ(ν; p[iz], T[iz]) * vcd_dry[iz] * vmr[iz] into τ_abs[:, iz] (mom_voigt_tau_abs).  `vmr` scalar or per layer (the
+    profile's mixing ratio); `model_vmr` is HitranModel.vmr, the self-broadening fraction of the line shape.
+    begin=False adds another absorber to the same table (the reference's `+=` over molecules)."""
+    p_full, T, vcd_dry = (np.asarray(x, dtype=np.float64) for x in (p_full, T, vcd_dry))
+    Nz = p_full.size
+    assert T.size == Nz and vcd_dry.size == Nz
+    vmr_arr = np.full(Nz, float(vmr)) if np.ndim(vmr) == 0 else np.asarray(vmr, dtype=np.float64)
+    assert vmr_arr.size == Nz, "Length of VMR array has to match profile size or be uniform"
+    if begin:
+        h.absorption_begin(Nz, grid)
+    for iz in range(Nz):
+        pf = line_prefactors(table, grid, p_full[iz], T[iz], vmr=model_vmr, wing_cutoff=wing_cutoff, qratio=qratio)
+        h.voigt_tau_abs(iz + 1, pf.ν, pf.γ_d, pf.y, pf.S, pf.ind_start, pf.ind_stop, vcd_dry[iz] * vmr_arr[iz])
+
+
 def synthetic_o2a_lines(n_lines: int = 300, ν_lo: float = 12903.0, ν_hi: float = 13245.0, seed: int = 1234) -> HitranTable:
     """Seeded O2-A-like line list of SURVEY section 8d."""
     rng = np.random.default_rng(seed)
     ν = np.sort(rng.uniform(ν_lo, ν_hi, n_lines))
-    return HitranTable(νᵢ=ν, Sᵢ=10.0 ** rng.uniform(-27, -23, n_lines), γ_air=rng.uniform(0.03, 0.06, n_lines),
-                       γ_self=rng.uniform(0.03, 0.06, n_lines), E_lower=rng.uniform(0.0, 2000.0, n_lines),
-                       n_air=np.full(n_lines, 0.7), δ_air=np.full(n_lines, -0.005), mol_weight=np.full(n_lines, 31.98983))
+    return HitranTable(mol=np.full(n_lines, 7), iso=np.full(n_lines, 1), νᵢ=ν, Sᵢ=10.0 ** rng.uniform(-27, -23, n_lines),
+                       γ_air=rng.uniform(0.03, 0.06, n_lines), γ_self=rng.uniform(0.03, 0.06, n_lines),
+                       E_lower=rng.uniform(0.0, 2000.0, n_lines), n_air=np.full(n_lines, 0.7),
+                       δ_air=np.full(n_lines, -0.005))

@@ -553,6 +553,25 @@ def run_scene(h: _lib.Handle, sc: SceneInputs):
     return h.get_RT()
 
 
+def run_scene_device_optics(h: _lib.Handle, model: vSmartMOM_Model, upload_tau_abs: bool = True):
+    """The same run with the layer optics assembled on the GPU (mom_scene_set_optics): the host hands over the
+    INGREDIENTS (τ_rayl, aerosol columns, Z bases) and the gas absorption is the handle's resident τ_abs table --
+    uploaded here from model.τ_abs, or (upload_tau_abs=False) already accumulated by mom_voigt_tau_abs."""
+    p, qp = model.params, model.quad_points
+    Zpp, Zmp = z_bases(model)
+    M = p.max_m
+    S, Nz = model.τ_rayl.shape
+    if upload_tau_abs:
+        h.absorption_set(model.τ_abs)
+    cm = np.array([[cosd(m * a) for a in p.vaz] for m in range(M)])
+    sm = np.array([[sind(m * a) for a in p.vaz] for m in range(M)])
+    h.scene_set_optics(Nz, M, model.τ_rayl, model.ϖ_Cabannes, model.τ_aer, [a.ω̃ for a in model.aerosol_optics],
+                       [a.fᵗ for a in model.aerosol_optics], _abi_mats(Zpp), _abi_mats(Zmp), float(p.brdf_albedo),
+                       view_nodes(model), cm.reshape(-1), sm.reshape(-1))
+    h.rt_run()
+    return h.get_RT()
+
+
 def rt_run(model: vSmartMOM_Model, i_band: int = 1):
     """rt_run(model; i_band) (rt_run.jl:19-21 -> :41-230), SFI = true, noRS.  Returns the
     reference's 7-tuple (rt_run.jl:226):
@@ -575,8 +594,8 @@ def rt_run_operators(model: vSmartMOM_Model):
     Zpp, Zmp = z_bases(model)
     S, Nz = L.τ.shape
     nV = len(p.vza)
-    R = np.zeros((nV, pol.n, S))
-    T = np.zeros((nV, pol.n, S))
+    R = np.zeros(nV * pol.n * S)  # ABI order [nVza, nStokes, nSpec], v fastest
+    T = np.zeros(nV * pol.n * S)
     nodes = view_nodes(model)
     with make_handle(model) as h:
         for m in range(p.max_m):
@@ -594,12 +613,6 @@ def rt_run_operators(model: vSmartMOM_Model):
                     h.interaction(int(L.iface[z]))
             h.surface_lambertian(m, p.brdf_albedo, L.τ_sum[:, -1])
             h.interaction(int(L.iface[-1]), with_surface_layer=True)
-            J0p = h.download(_lib.COMP["J0p"]).reshape(S, -1)
-            J0m = h.download(_lib.COMP["J0m"]).reshape(S, -1)
-            for i in range(nV):
-                ist = (nodes[i] - 1) * pol.n
-                c, s_ = cosd(m * p.vaz[i]), sind(m * p.vaz[i])
-                cs = weight * np.array([c, c, s_, s_])[: pol.n]
-                R[i] += (cs[None, :] * J0m[:, ist:ist + pol.n]).T
-                T[i] += (cs[None, :] * J0p[:, ist:ist + pol.n]).T
-    return R, T
+            h.postprocess(m, nodes, p.vaz, weight, R, T)  # postprocessing_vza! (R_SFI += ..., T_SFI += ...)
+    shp = (S, pol.n, nV)
+    return np.transpose(R.reshape(shp), (2, 1, 0)).copy(), np.transpose(T.reshape(shp), (2, 1, 0)).copy()

@@ -274,6 +274,12 @@ struct mom_handle {
   int comm_rank = 0, comm_size = 1;
   double *d_gather = nullptr;
   size_t gather_cap = 0;
+  // device-side layer optics (mom_absorption_* / mom_voigt_tau_abs / mom_scene_set_optics)
+  double *d_tau_abs = nullptr, *d_grid = nullptr, *d_lines = nullptr, *d_tau_rayl = nullptr, *d_layer_max = nullptr,
+         *d_aer = nullptr;
+  int *d_aer_mode = nullptr;
+  int abs_Nz = 0;
+  size_t lines_cap = 0;
   double *d_vec[4] = {};  // S-length temporaries (tau_sum, dtau, varpi, expk)
   double *d_Zop[2] = {};
   size_t Zop_cap = 0;
@@ -336,6 +342,7 @@ static hipError_t allow_lds(K kernel, size_t bytes) {
   return mom_allow_lds(reinterpret_cast<const void *>(kernel), bytes);
 }
 
+void mom_set_global_error(const char *msg) { g_err = msg ? msg : ""; }
 extern "C" const char *mom_last_global_error(void) { return g_err.c_str(); }
 extern "C" const char *mom_last_error(const mom_t *h) { return h ? h->err.c_str() : g_err.c_str(); }
 
@@ -422,7 +429,8 @@ extern "C" int mom_destroy(mom_t *h) {
   fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
   fr(h->d_mu0); fr(h->d_wt0); fr(h->d_sg0); fr(h->d_Zpp0); fr(h->d_Zmp0); fr(h->d_hdrJ0); fr(h->d_scratch0);
   for (int k = 0; k < 6; ++k) fr(h->comp0[k]);
-  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
+  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_tau_rayl);
+  fr(h->d_layer_max); fr(h->d_aer); if (h->d_aer_mode) (void)hipFree(h->d_aer_mode); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
   for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (auto e : h->ev_full) (void)hipEventDestroy(e);
   for (auto e : h->ev_red) (void)hipEventDestroy(e);
@@ -723,6 +731,11 @@ static int upload_new(mom_t *h, T **dst, const T *src, size_t count) {
   return MOM_OK;
 }
 
+// everything of a scene that does not depend on how the layer optics reach the device: phase-matrix bases, view
+// geometry, output buffers, the m = 0 reduction
+static int scene_common(mom_t *h, int Nz, int K, int M, const double *Zpp, const double *Zmp, double albedo, int nVza,
+                        const int *node_1based, const double *cos_mphi, const double *sin_mphi);
+
 extern "C" int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
                              const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface,
                              const double *tau_sum, double albedo, int nVza, const int *node_1based,
@@ -735,17 +748,29 @@ extern "C" int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, 
   for (int z = 0; z < Nz; ++z)
     if (ndoubl[z] < 0 || ndoubl[z] > 60 || iface[z] < 0 || iface[z] > 3)
       return fail(h, MOM_EINVAL, "mom_scene_set: ndoubl/iface out of range");
-  for (int v = 0; v < nVza; ++v)
-    if (node_1based[v] < 1 || node_1based[v] * h->nS > h->N) return fail(h, MOM_EINVAL, "mom_scene_set: bad view node");
   HIPCHK(h, hipSetDevice(h->device));
-  const size_t S = h->S, NN = (size_t)h->N * h->N;
+  const size_t S = h->S;
+  h->scene_set = false;
   int rc;
   if ((rc = upload_new(h, &h->d_tau, tau, S * Nz))) return rc;
   if ((rc = upload_new(h, &h->d_varpi, varpi, S * Nz))) return rc;
   if ((rc = upload_new(h, &h->d_zw, zw, (size_t)K * S * Nz))) return rc;
+  if ((rc = upload_new(h, &h->d_tau_sum, tau_sum, S * (Nz + 1)))) return rc;
+  if ((rc = scene_common(h, Nz, K, M, Zpp, Zmp, albedo, nVza, node_1based, cos_mphi, sin_mphi))) return rc;
+  h->nd.assign(ndoubl, ndoubl + Nz);
+  h->iface.assign(iface, iface + Nz);
+  h->scene_set = true;
+  return MOM_OK;
+}
+
+static int scene_common(mom_t *h, int Nz, int K, int M, const double *Zpp, const double *Zmp, double albedo, int nVza,
+                        const int *node_1based, const double *cos_mphi, const double *sin_mphi) {
+  for (int v = 0; v < nVza; ++v)
+    if (node_1based[v] < 1 || node_1based[v] * h->nS > h->N) return fail(h, MOM_EINVAL, "mom_scene_set: bad view node");
+  const size_t S = h->S, NN = (size_t)h->N * h->N;
+  int rc;
   if ((rc = upload_new(h, &h->d_Zpp, Zpp, NN * K * M))) return rc;
   if ((rc = upload_new(h, &h->d_Zmp, Zmp, NN * K * M))) return rc;
-  if ((rc = upload_new(h, &h->d_tau_sum, tau_sum, S * (Nz + 1)))) return rc;
   if ((rc = upload_new(h, &h->d_node, node_1based, (size_t)nVza))) return rc;
   if ((rc = upload_new(h, &h->d_cos, cos_mphi, (size_t)nVza * M))) return rc;
   if ((rc = upload_new(h, &h->d_sin, sin_mphi, (size_t)nVza * M))) return rc;
@@ -813,9 +838,6 @@ extern "C" int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, 
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->Nz = Nz; h->K = K; h->scene_M = M; h->nVza = nVza; h->albedo = albedo;
-  h->nd.assign(ndoubl, ndoubl + Nz);
-  h->iface.assign(iface, iface + Nz);
-  h->scene_set = true;
   return MOM_OK;
 }
 
@@ -1055,6 +1077,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -1072,8 +1095,9 @@ int rccl_load(mom_t *h) {
   *(void **)(&r.CommInitRank) = dlsym(lib, "ncclCommInitRank");
   *(void **)(&r.CommDestroy) = dlsym(lib, "ncclCommDestroy");
   *(void **)(&r.AllGather) = dlsym(lib, "ncclAllGather");
+  *(void **)(&r.AllReduce) = dlsym(lib, "ncclAllReduce");
   *(void **)(&r.GetErrorString) = dlsym(lib, "ncclGetErrorString");
-  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString)
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.AllReduce || !r.GetErrorString)
     return fail(h, MOM_EHIP, "mom_comm: librccl.so.1 lacks a required symbol");
   g_rccl = r;
   g_rccl_destroy = [](void *c) { (void)g_rccl.CommDestroy((ncclComm_t)c); };
@@ -1104,6 +1128,9 @@ extern "C" int mom_comm_init(mom_t *h, int rank, int nranks, const void *nccl_id
   HIPCHK(h, hipSetDevice(h->device));
   const int rc = rccl_load(h);
   if (rc) return rc;
+  // RCCL checks hipGetLastError() after its own launches: a stale (non-sticky) error code left behind by an earlier,
+  // already reported failure in this process would be taken for its own
+  (void)hipGetLastError();
   ncclUniqueId id;
   memcpy(&id, nccl_id, sizeof id);
   ncclComm_t comm = nullptr;
@@ -1162,6 +1189,247 @@ extern "C" int mom_allgather_RT(mom_t *h, double *R_SFI_global, double *T_SFI_gl
     HIPCHK(h, hipMemcpyAsync(T_SFI_global + nout * r, h->d_gather + 2 * nout * r + nout, nout * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   }
   return check_info(h);
+}
+
+// ---------------------------------------------------------------- device-side layer optics
+
+extern "C" int mom_absorption_begin(mom_t *h, int Nz, const double *grid) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (Nz <= 0) return fail(h, MOM_EINVAL, "mom_absorption_begin: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t S = h->S;
+  if (h->d_tau_abs) { (void)hipFree(h->d_tau_abs); h->d_tau_abs = nullptr; }
+  HIPCHK(h, dmalloc(&h->d_tau_abs, S * Nz));
+  HIPCHK(h, hipMemsetAsync(h->d_tau_abs, 0, S * Nz * sizeof(double), h->stream));  // τ_abs = zeros (model_from_parameters.jl:48)
+  h->abs_Nz = Nz;
+  if (grid) {
+    int rc = upload_new(h, &h->d_grid, grid, S);
+    if (rc) return rc;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_absorption_set(mom_t *h, int Nz, const double *tau_abs) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (Nz <= 0 || !tau_abs) return fail(h, MOM_EINVAL, "mom_absorption_set: bad argument");
+  int rc = mom_absorption_begin(h, Nz, nullptr);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->d_tau_abs, tau_abs, (size_t)h->S * Nz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_absorption_get(mom_t *h, double *tau_abs) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->d_tau_abs || !tau_abs) return fail(h, MOM_ESTATE, "mom_absorption_get: no resident tau_abs table / null output");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(tau_abs, h->d_tau_abs, (size_t)h->S * h->abs_Nz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_voigt_tau_abs(mom_t *h, int iz_1based, int nLines, const double *nu, const double *gamma_d, const double *y,
+                                 const double *S, const int *ind_start_1based, const int *ind_stop_1based, double factor) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->d_tau_abs || !h->d_grid) return fail(h, MOM_ESTATE, "mom_voigt_tau_abs: call mom_absorption_begin with the spectral grid first");
+  if (iz_1based < 1 || iz_1based > h->abs_Nz || nLines < 0 ||
+      (nLines > 0 && (!nu || !gamma_d || !y || !S || !ind_start_1based || !ind_stop_1based)))
+    return fail(h, MOM_EINVAL, "mom_voigt_tau_abs: bad argument");
+  for (int j = 0; j < nLines; ++j)
+    if (ind_start_1based[j] < 1 || ind_stop_1based[j] > h->S) {
+      char buf[160];
+      snprintf(buf, sizeof buf, "mom_voigt_tau_abs: line %d: window [%d, %d] outside the grid 1..%d", j + 1, ind_start_1based[j],
+               ind_stop_1based[j], h->S);
+      return fail(h, MOM_EINVAL, buf);
+    }
+  if (nLines == 0) return MOM_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t lb = (size_t)nLines;
+  if (lb > h->lines_cap) {  // 4 double + 2 int arrays per line, grown geometrically: no allocation in steady state
+    if (h->d_lines) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_lines); h->d_lines = nullptr; h->lines_cap = 0; }
+    const size_t cap = std::max<size_t>(lb, 1024) * 2;
+    HIPCHK(h, dmalloc(&h->d_lines, 5 * cap));
+    h->lines_cap = cap;
+  }
+  const size_t cap = h->lines_cap;
+  double *dl = h->d_lines;
+  int *dw = reinterpret_cast<int *>(dl + 4 * cap);
+  const double *src[4] = {nu, gamma_d, y, S};
+  // the host arrays are borrowed for the call only: the copies must have left them before we return
+  for (int k = 0; k < 4; ++k) HIPCHK(h, hipMemcpyAsync(dl + k * cap, src[k], lb * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dw, ind_start_1based, lb * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dw + cap, ind_stop_1based, lb * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, mom_voigt_launch(h->stream, nLines, dl, dl + cap, dl + 2 * cap, dl + 3 * cap, dw, dw + cap, h->S, h->d_grid,
+                             h->d_tau_abs + (size_t)h->S * (iz_1based - 1), factor, 1));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+// constructCoreOpticalProperties (compEffectiveLayerProperties.jl:1-78) with the `+` of types.jl:632-678, createAero
+// (:80-85), the gas term (:672-678) and the cumulative τ_sum of extractEffectiveProps (:108), one thread per spectral
+// point walking the layers; per-layer max(τ ϖ) for get_dtau_ndoubl / `scatter` by atomic max on the bit pattern
+// (non-negative doubles order like their unsigned bit patterns).  Contraction off: the same IEEE operations as the
+// host (numpy / Julia) path, so both routes give bitwise equal τ, ϖ, weights.
+struct OpticsArgs {
+  int S, Nz, nAer;
+  double varpi_rayl;
+  const double *tau_rayl, *tau_abs;  // [S,Nz]
+  const double *aer;                 // [2,nAer,Nz]: τ_y, w_y = τ_y ϖ_y per aerosol type and layer (spectrally flat)
+  const int *aer_mode;               // [nAer,Nz]: 0 = Rayleigh side all zero, 1 = mix, 2 = aerosol side all zero
+  double *tau, *varpi, *zw, *tau_sum, *layer_max;
+};
+#pragma clang fp contract(off)
+__global__ void k_optics(OpticsArgs a) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int K = 1 + a.nAer;
+  double tsum = 0.0;
+  const bool live = n < a.S;
+  if (live) a.tau_sum[n] = 0.0;
+  for (int z = 0; z < a.Nz; ++z) {
+    double tw = 0.0;
+    if (live) {
+      const size_t o = n + (size_t)a.S * z;
+      double tau = a.tau_rayl[o], varpi = a.varpi_rayl;
+      double w[8];
+      w[0] = 1.0;
+      for (int k = 1; k < K; ++k) w[k] = 0.0;
+      for (int x = 0; x < a.nAer; ++x) {
+        const double ty = a.aer[x + (size_t)a.nAer * z], wy = a.aer[a.nAer * a.Nz + x + (size_t)a.nAer * z];
+        const int mode = a.aer_mode[x + (size_t)a.nAer * z];
+        const double wx = tau * varpi, tot = wx + wy, tn = tau + ty;
+        if (mode == 0) {
+          for (int k = 0; k < K; ++k) w[k] = 0.0;
+          w[x + 1] = 1.0;
+        } else if (mode == 1) {
+          const double fx = wx / tot;
+          for (int k = 0; k < K; ++k) w[k] *= fx;
+          w[x + 1] = wy / tot;
+        }
+        varpi = tot / tn;
+        tau = tn;
+      }
+      const double tn = tau + a.tau_abs[o];
+      varpi = (tau * varpi) / tn;
+      tau = tn;
+      a.tau[o] = tau;
+      a.varpi[o] = varpi;
+      for (int k = 0; k < K; ++k) a.zw[k + (size_t)K * o] = w[k];
+      tsum = tsum + 1.0 * tau;
+      a.tau_sum[o + a.S] = tsum;
+      tw = tau * varpi;
+    }
+    // NaN (0/0 in an empty layer) must not win silently: fmax drops it like Julia's maximum would propagate it --
+    // the host path would fail on such a scene as well; keep it visible as +inf
+    if (tw != tw) tw = __longlong_as_double(0x7ff0000000000000ll);
+    double m = tw;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.0)
+      atomicMax(reinterpret_cast<unsigned long long *>(a.layer_max + z), (unsigned long long)__double_as_longlong(m));
+  }
+}
+
+// doubling_number (rt_helper_functions.jl:31-57): log10 arithmetic and the eps test as in the reference
+static int doubling_number_host(double dtau_max, double tau_end) {
+  if (tau_end <= dtau_max) return 0;
+  const double q1 = std::log10(2.0), q2 = std::log10(dtau_max), q3 = std::log10(tau_end);
+  const double tlimit = (q3 - q2) / q1, nlimit = std::floor(tlimit);
+  if (tlimit - nlimit < 2.220446049250313e-16) return (int)nlimit;
+  return (int)nlimit + 1;
+}
+
+extern "C" int mom_scene_set_optics(mom_t *h, int Nz, int nAer, int M, const double *tau_rayl, double varpi_rayl,
+                                    const double *tau_aer, const double *omega_aer, const double *ft_aer,
+                                    const double *Zpp, const double *Zmp, double albedo, int nVza, const int *node_1based,
+                                    const double *cos_mphi, const double *sin_mphi) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_scene_set_optics: call mom_set_streams first");
+  if (Nz <= 0 || nAer < 0 || nAer > 7 || M <= 0 || M > h->M || nVza <= 0 || !tau_rayl || !Zpp || !Zmp || !node_1based ||
+      !cos_mphi || !sin_mphi || (nAer > 0 && (!tau_aer || !omega_aer || !ft_aer)))
+    return fail(h, MOM_EINVAL, "mom_scene_set_optics: bad argument");
+  if (!h->d_tau_abs || h->abs_Nz != Nz)
+    return fail(h, MOM_ESTATE, "mom_scene_set_optics: no resident tau_abs table of this Nz (mom_absorption_begin / _set)");
+  HIPCHK(h, hipSetDevice(h->device));
+  h->scene_set = false;
+  const size_t S = h->S;
+  const int K = 1 + nAer;
+  int rc;
+  if ((rc = upload_new(h, &h->d_tau_rayl, tau_rayl, S * Nz))) return rc;
+  // createAero (compEffectiveLayerProperties.jl:80-85): τ' = (1 - fᵗ ω̃) τ_aer, ϖ' = (1 - fᵗ) ω̃ / (1 - fᵗ ω̃); the
+  // all-zero tests of types.jl:641-661 are decided here on the host (they are properties of whole spectral columns)
+  std::vector<double> aer((size_t)2 * std::max(nAer, 1) * Nz, 0.0);
+  std::vector<int> mode((size_t)std::max(nAer, 1) * Nz, 2);
+  for (int z = 0; z < Nz; ++z) {
+    bool x_zero = true;  // all(τ ϖ == 0) of the accumulated left operand
+    if (varpi_rayl != 0.0)
+      for (size_t n = 0; n < S; ++n)
+        if (tau_rayl[n + S * z] != 0.0) { x_zero = false; break; }
+    for (int x = 0; x < nAer; ++x) {
+      const double ty = (1 - ft_aer[x] * omega_aer[x]) * tau_aer[x + (size_t)nAer * z];
+      const double vy = (1 - ft_aer[x]) * omega_aer[x] / (1 - ft_aer[x] * omega_aer[x]);
+      const double wy = ty * vy;
+      aer[x + (size_t)nAer * z] = ty;
+      aer[(size_t)nAer * Nz + x + (size_t)nAer * z] = wy;
+      mode[x + (size_t)nAer * z] = x_zero ? 0 : (wy != 0.0 ? 1 : 2);
+      x_zero = x_zero && (wy == 0.0);
+    }
+  }
+  if ((rc = upload_new(h, &h->d_aer, aer.data(), aer.size()))) return rc;
+  if ((rc = upload_new(h, &h->d_aer_mode, mode.data(), mode.size()))) return rc;
+  auto renew = [&](double **p, size_t cnt) -> hipError_t { if (*p) { (void)hipFree(*p); *p = nullptr; } return dmalloc(p, cnt); };
+  HIPCHK(h, renew(&h->d_tau, S * Nz));
+  HIPCHK(h, renew(&h->d_varpi, S * Nz));
+  HIPCHK(h, renew(&h->d_zw, (size_t)K * S * Nz));
+  HIPCHK(h, renew(&h->d_tau_sum, S * (Nz + 1)));
+  HIPCHK(h, renew(&h->d_layer_max, (size_t)Nz));
+  HIPCHK(h, hipMemsetAsync(h->d_layer_max, 0, (size_t)Nz * sizeof(double), h->stream));
+  OpticsArgs a{};
+  a.S = h->S; a.Nz = Nz; a.nAer = nAer; a.varpi_rayl = varpi_rayl;
+  a.tau_rayl = h->d_tau_rayl; a.tau_abs = h->d_tau_abs; a.aer = h->d_aer; a.aer_mode = h->d_aer_mode;
+  a.tau = h->d_tau; a.varpi = h->d_varpi; a.zw = h->d_zw; a.tau_sum = h->d_tau_sum; a.layer_max = h->d_layer_max;
+  hipLaunchKernelGGL(k_optics, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, h->stream, a);
+  HIPCHK(h, hipGetLastError());
+  // get_dtau_ndoubl takes maximum(τ .* ϖ) over the WHOLE spectral axis (rt_kernel.jl:241-242): across the ranks of a
+  // sharded run the per-layer maxima are combined first (one tiny all-reduce at set-up time, not in the sweep)
+  if (h->comm) {
+    const ncclResult_t r = g_rccl.AllReduce(h->d_layer_max, h->d_layer_max, (size_t)Nz, ncclDouble, ncclMax, (ncclComm_t)h->comm, h->stream);
+    if (r != ncclSuccess) return rccl_fail(h, "ncclAllReduce", r);
+  }
+  std::vector<double> mx((size_t)Nz);
+  HIPCHK(h, hipMemcpyAsync(mx.data(), h->d_layer_max, (size_t)Nz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  double mu_min = h->h_mu[0];
+  for (double v : h->h_mu) mu_min = std::min(mu_min, v);
+  h->nd.assign((size_t)Nz, 0);
+  h->iface.assign((size_t)Nz, 0);
+  int prev = 0;
+  for (int z = 0; z < Nz; ++z) {
+    if (!std::isfinite(mx[z])) return fail(h, MOM_EINVAL, "mom_scene_set_optics: a layer has non-finite τ ϖ (empty layer: τ = 0?)");
+    h->nd[z] = doubling_number_host(std::min(mx[z], 0.001 * mu_min), mx[z]);
+    if (h->nd[z] > 60) return fail(h, MOM_EINVAL, "mom_scene_set_optics: ndoubl out of range");
+    const bool scatter = mx[z] > 2 * 2.220446049250313e-16;  // compEffectiveLayerProperties.jl:104
+    prev = (z == 0) ? (scatter ? 3 : 0) : (prev == 0 ? (scatter ? 1 : 0) : (scatter ? 3 : 2));  // rt_helper_functions.jl:8-27
+    h->iface[z] = prev;
+  }
+  if ((rc = scene_common(h, Nz, K, M, Zpp, Zmp, albedo, nVza, node_1based, cos_mphi, sin_mphi))) return rc;
+  h->scene_set = true;
+  return MOM_OK;
+}
+
+extern "C" int mom_scene_get_layers(mom_t *h, int *ndoubl, int *iface, double *tau, double *varpi, double *zw, double *tau_sum) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_scene_get_layers: no scene");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t S = h->S, Nz = h->Nz;
+  if (ndoubl) std::copy(h->nd.begin(), h->nd.end(), ndoubl);
+  if (iface) std::copy(h->iface.begin(), h->iface.end(), iface);
+  if (tau) HIPCHK(h, hipMemcpyAsync(tau, h->d_tau, S * Nz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (varpi) HIPCHK(h, hipMemcpyAsync(varpi, h->d_varpi, S * Nz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (zw) HIPCHK(h, hipMemcpyAsync(zw, h->d_zw, (size_t)h->K * S * Nz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (tau_sum) HIPCHK(h, hipMemcpyAsync(tau_sum, h->d_tau_sum, S * (Nz + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
 }
 
 #ifdef MOM_DIAG_STAMPS

@@ -11,9 +11,11 @@
 // FP64 VALU-bound (about 300 flop per (line, grid point) evaluation), negligible HBM bytes.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <string>
 
 #include "momcore.h"
+#include "mom_host.hpp"
 
 namespace {
 
@@ -75,7 +77,8 @@ __global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__re
                                                   const double *__restrict__ gamma_d, const double *__restrict__ y,
                                                   const double *__restrict__ S, const int *__restrict__ i0,
                                                   const int *__restrict__ i1, int nGrid,
-                                                  const double *__restrict__ grid, double *__restrict__ sigma) {
+                                                  const double *__restrict__ grid, double *__restrict__ sigma,
+                                                  double factor, int accumulate) {
   // per-line constants of the candidates, staged once per workgroup: centre, S c/gamma_d, c'/gamma_d, y and the
   // 0-based window -- the two divisions by gamma_d are per LINE here, not per evaluation (same expressions, same values)
   __shared__ double c_nu[kBlock], c_a[kBlock], c_b[kBlock], c_y[kBlock];
@@ -119,68 +122,94 @@ __global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__re
     }
     __syncthreads();
   }
-  if (gi < nGrid) sigma[gi] = acc;
+  // accumulate: tau_abs[:, iz] += sigma * (vcd_dry[iz] * vmr)  (atmo_prof.jl:446), fused into the line-shape kernel
+  // (separately rounded product and sum, like the host expression: no FMA contraction)
+  if (gi < nGrid) sigma[gi] = accumulate ? __dadd_rn(sigma[gi], __dmul_rn(acc, factor)) : acc;
 }
 
-thread_local std::string v_err;
 thread_local double v_last_ms = 0.0;
 
 }  // namespace
 
-#define VCHK(call)                                                        \
-  do {                                                                    \
-    hipError_t e__ = (call);                                              \
-    if (e__ != hipSuccess) { v_err = hipGetErrorString(e__); rc = MOM_EHIP; goto done; } \
+// one launch for all lines on `st` (device pointers); used by mom_voigt_xsec below and by the handle-level
+// mom_voigt_tau_abs (momcore.hip), which accumulates straight into the resident tau_abs table
+hipError_t mom_voigt_launch(hipStream_t st, int nLines, const double *nu, const double *gamma_d, const double *y,
+                            const double *S, const int *i0, const int *i1, int nGrid, const double *grid, double *out,
+                            double factor, int accumulate) {
+  hipLaunchKernelGGL(k_voigt, dim3((nGrid + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nLines, nu, gamma_d, y, S, i0, i1,
+                     nGrid, grid, out, factor, accumulate);
+  return hipGetLastError();
+}
+
+#define VCHK(call)                                                                                     \
+  do {                                                                                                 \
+    hipError_t e__ = (call);                                                                           \
+    if (e__ != hipSuccess) {                                                                           \
+      char buf__[384];                                                                                 \
+      snprintf(buf__, sizeof buf__, "mom_voigt_xsec: %s failed: %s", #call, hipGetErrorString(e__));   \
+      mom_set_global_error(buf__);                                                                     \
+      rc = MOM_EHIP;                                                                                   \
+      goto done;                                                                                       \
+    }                                                                                                  \
   } while (0)
 
 extern "C" int mom_voigt_xsec(int device, int nLines, const double *nu, const double *gamma_d, const double *y,
                               const double *S, const int *ind_start, const int *ind_stop, int nGrid, const double *grid,
                               double *sigma) {
-  if (nLines < 0 || nGrid <= 0 || !grid || !sigma || (nLines > 0 && (!nu || !gamma_d || !y || !S || !ind_start || !ind_stop)))
+  if (nLines < 0 || nGrid <= 0 || !grid || !sigma || (nLines > 0 && (!nu || !gamma_d || !y || !S || !ind_start || !ind_stop))) {
+    mom_set_global_error("mom_voigt_xsec: bad argument (null pointer or non-positive size)");
     return MOM_EINVAL;
+  }
   for (int j = 0; j < nLines; ++j)
-    if (ind_start[j] < 1 || ind_stop[j] > nGrid) return MOM_EINVAL;  // empty windows (start > stop) are allowed
+    if (ind_start[j] < 1 || ind_stop[j] > nGrid) {  // empty windows (start > stop) are allowed
+      char buf[160];
+      snprintf(buf, sizeof buf, "mom_voigt_xsec: line %d: window [%d, %d] outside the grid 1..%d", j + 1, ind_start[j], ind_stop[j], nGrid);
+      mom_set_global_error(buf);
+      return MOM_EINVAL;
+    }
   int rc = MOM_OK;
-  double *d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  int *di[2] = {nullptr, nullptr};
-  const double *hsrc[4] = {nu, gamma_d, y, S};
+  // one device allocation (lines | windows | grid | sigma) and one pinned-free staging copy per array on a private
+  // stream; callers that evaluate many layers should use the handle-level mom_voigt_tau_abs, which keeps all of
+  // this resident
   const size_t lb = (size_t)(nLines > 0 ? nLines : 1);
+  const size_t bytes = (4 * lb + 2 * (size_t)nGrid) * sizeof(double) + 2 * lb * sizeof(int);
+  char *base = nullptr;
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return MOM_EHIP;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { mom_set_global_error("mom_voigt_xsec: no HIP device available"); return MOM_EHIP; }
+  if (device < 0 || device >= ndev) { mom_set_global_error("mom_voigt_xsec: device index out of range"); return MOM_EINVAL; }
   VCHK(hipSetDevice(device));
-  for (int k = 0; k < 4; ++k) {
-    VCHK(hipMalloc((void **)&d[k], lb * sizeof(double)));
-    if (nLines) VCHK(hipMemcpy(d[k], hsrc[k], (size_t)nLines * sizeof(double), hipMemcpyHostToDevice));
-  }
-  VCHK(hipMalloc((void **)&di[0], lb * sizeof(int)));
-  VCHK(hipMalloc((void **)&di[1], lb * sizeof(int)));
-  if (nLines) {
-    VCHK(hipMemcpy(di[0], ind_start, (size_t)nLines * sizeof(int), hipMemcpyHostToDevice));
-    VCHK(hipMemcpy(di[1], ind_stop, (size_t)nLines * sizeof(int), hipMemcpyHostToDevice));
-  }
-  VCHK(hipMalloc((void **)&d[4], (size_t)nGrid * sizeof(double)));
-  VCHK(hipMalloc((void **)&d[5], (size_t)nGrid * sizeof(double)));
-  VCHK(hipMemcpy(d[4], grid, (size_t)nGrid * sizeof(double), hipMemcpyHostToDevice));
+  VCHK(hipStreamCreate(&st));
+  VCHK(hipMalloc((void **)&base, bytes));
   {
-    hipEvent_t e0, e1;
+    double *d_line = (double *)base, *d_grid = d_line + 4 * lb, *d_sig = d_grid + nGrid;
+    int *d_win = (int *)(d_sig + nGrid);
+    const double *hsrc[4] = {nu, gamma_d, y, S};
+    for (int k = 0; k < 4; ++k)
+      if (nLines) VCHK(hipMemcpyAsync(d_line + k * lb, hsrc[k], (size_t)nLines * sizeof(double), hipMemcpyHostToDevice, st));
+    if (nLines) {
+      VCHK(hipMemcpyAsync(d_win, ind_start, (size_t)nLines * sizeof(int), hipMemcpyHostToDevice, st));
+      VCHK(hipMemcpyAsync(d_win + lb, ind_stop, (size_t)nLines * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    VCHK(hipMemcpyAsync(d_grid, grid, (size_t)nGrid * sizeof(double), hipMemcpyHostToDevice, st));
     VCHK(hipEventCreate(&e0));
     VCHK(hipEventCreate(&e1));
-    VCHK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_voigt, dim3((nGrid + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, nLines, d[0], d[1], d[2], d[3],
-                       di[0], di[1], nGrid, d[4], d[5]);
-    VCHK(hipGetLastError());
-    VCHK(hipEventRecord(e1, 0));
-    VCHK(hipEventSynchronize(e1));
+    VCHK(hipEventRecord(e0, st));
+    VCHK(mom_voigt_launch(st, nLines, d_line, d_line + lb, d_line + 2 * lb, d_line + 3 * lb, d_win, d_win + lb, nGrid, d_grid,
+                          d_sig, 1.0, 0));
+    VCHK(hipEventRecord(e1, st));
+    VCHK(hipMemcpyAsync(sigma, d_sig, (size_t)nGrid * sizeof(double), hipMemcpyDeviceToHost, st));
+    VCHK(hipStreamSynchronize(st));
     float ms = 0.f;
     VCHK(hipEventElapsedTime(&ms, e0, e1));
     v_last_ms = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
   }
-  VCHK(hipMemcpy(sigma, d[5], (size_t)nGrid * sizeof(double), hipMemcpyDeviceToHost));
 done:
-  for (int k = 0; k < 6; ++k) if (d[k]) (void)hipFree(d[k]);
-  for (int k = 0; k < 2; ++k) if (di[k]) (void)hipFree(di[k]);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (base) (void)hipFree(base);
+  if (st) (void)hipStreamDestroy(st);
   return rc;
 }
 

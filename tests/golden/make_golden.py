@@ -85,21 +85,23 @@ def cef():
 
 
 def voigt_co2():
-    ab = rtamd.absorption
-    ht = ab.read_hitran(OUT / "testCO2.data")
-    n = len(ht["mol"])
-    tab = ab.HitranTable(νᵢ=ht["νᵢ"], Sᵢ=ht["Sᵢ"], γ_air=ht["γ_air"], γ_self=ht["γ_self"], E_lower=ht["E_lower"],
-                         n_air=ht["n_air"], δ_air=ht["δ_air"], mol_weight=np.full(n, 43.98983))
+    """Inputs: the reference's 16-line HITRAN fixture (test/test_profiles/testCO2.data).  Expected values come from
+    the ORACLE side only (oracle/absref.py host restatement + oracle/momref.py line shape): per-line parameters with
+    the TIPS-2017 correction, and the Voigt cross section on a 0.01 cm^-1 grid at two (p, T)."""
+    from oracle import absref
+    ht = rtamd.absorption.read_hitran(OUT / "testCO2.data")
     grid = np.arange(5990.0, 6400.0, 0.01)
     out = {"grid": grid}
     for tag, (p, T) in {"a": (1013.25, 296.0), "b": (250.0, 220.0)}.items():
-        pf = ab.line_prefactors(tab, grid, p, T, vmr=0.0, wing_cutoff=40.0)
-        out[f"sigma_{tag}"] = mr.voigt_xsec(pf.ν, pf.γ_d, pf.y, pf.S, pf.ind_start, pf.ind_stop, grid)
-        for k in ("ν", "γ_d", "y", "S", "ind_start", "ind_stop"):
-            out[f"{k}_{tag}".replace("ν", "nu").replace("γ", "gamma")] = getattr(pf, k)
+        nu, gd, y, S, i0, i1 = absref.line_parameters(ht, grid, p, T, 0.0, 40.0)
+        out[f"sigma_{tag}"] = mr.voigt_xsec(nu, gd, y, S, i0, i1, grid)
+        for k, v in (("nu", nu), ("gamma_d", gd), ("y", y), ("S", S), ("ind_start", i0), ("ind_stop", i1)):
+            out[f"{k}_{tag}"] = v
         out[f"pT_{tag}"] = np.array([p, T])
+    out["qoft_cases"] = np.array([(M, I, T, absref.qoft(M, I, T)) for (M, I, T) in
+                                  [(2, 1, 220.0), (2, 2, 250.0), (7, 1, 250.0), (7, 1, 1000.0), (1, 1, 310.5), (6, 1, 180.0), (5, 1, 77.0)]])
     np.savez_compressed(OUT / "voigt_co2.npz", **out)
-    print("voigt_co2: lines", n, "max sigma", out["sigma_a"].max())
+    print("voigt_co2: lines", len(out["nu_a"]), "max sigma", out["sigma_a"].max())
 
 
 if __name__ == "__main__":

@@ -1,0 +1,68 @@
+"""The N > 1 path with the REAL HIP kernels on a one-GPU box: two processes share GPU 0, each runs its spectral
+shard through libmomcore.so, the spectra are gathered over gloo (RCCL refuses two ranks on one device) -- and the
+result is bitwise the one-rank run.  Also bench.py's own launcher logic (--gpus 2 must start two ranks itself)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _worker(rank, world, port, S, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    import rtamd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = rtamd.scenes.make_scene(3, 33, 5, S, seed=13)     # N = 60: the strip-chained kernels + m = 0 sub-problem
+    scene = rtamd.prepare_scene(model)
+
+    def run_local(shard):
+        with rtamd.corert.make_handle(model, S=shard.S) as h:  # GPU 0 for every rank
+            return rtamd.corert.run_scene(h, shard)
+
+    R, T = rtamd.sharding.rt_run_sharded(scene, run_local, dist)
+    if rank == 0:
+        q.put((R, T))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S", [40, 33])  # even split and a ragged tail
+def test_two_ranks_on_one_gpu_match_single_rank_bitwise(rtamd, S):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, S, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    R, T = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model = rtamd.scenes.make_scene(3, 33, 5, S, seed=13)
+    R1, T1 = rtamd.rt_run(model)[:2]
+    assert np.array_equal(R, R1) and np.array_equal(T, T1)
+
+
+def test_bench_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) must start two ranks and report n_gpus = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device",
+                          "--points", "1024", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-voigt"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["config"]["sharding"].startswith("spectral axis, 2 x 1024")
+    assert j["value"] > 0 and j["scaling"] == "weak"

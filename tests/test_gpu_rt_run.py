@@ -189,7 +189,7 @@ def test_natraj_on_gpu(rtamd):
     assert eI < 0.002 and eQ < 0.008 and eU < 0.008
 
 
-@pytest.mark.parametrize("case", [0, 1, 5])
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
 def test_6sv1_on_gpu(rtamd, case):
     """test/test_CoreRT.jl:3-38 on the GPU: R/μ₀ within 0.006 of the 6SV1 tables."""
     G = json.loads((GOLD / "reference_tables.json").read_text())
@@ -216,24 +216,6 @@ def test_sharded_equals_unsharded_bitwise(rtamd):
             parts.append(rtamd.corert.run_scene(h, sc.spectral_slice(lo, hi)))
     assert np.array_equal(np.concatenate([p[0] for p in parts], axis=2), R)
     assert np.array_equal(np.concatenate([p[1] for p in parts], axis=2), T)
-
-
-def test_full_size_c2_properties(rtamd, cref):
-    """BASELINE config C2 at full size (N=60, 40 layers, S=10 000): finite, reproducible run to run,
-    and equal to the oracle on a seeded sample of spectral points (the oracle needs ~0.5 s per point)."""
-    m = rtamd.scenes.scene_C2()
-    sc = rtamd.prepare_scene(m)
-    assert (sc.N, sc.Nz, sc.S, sc.M) == (60, 40, 10_000, 3)
-    with rtamd.corert.make_handle(m) as h:
-        R, T = rtamd.corert.run_scene(h, sc)
-        h.rt_run()
-        R2, _ = h.get_RT()
-    assert np.all(np.isfinite(R)) and np.all(np.isfinite(T)) and np.array_equal(R, R2)
-    assert np.all(R[:, 0, :] > 0)
-    pts = np.random.default_rng(0).choice(sc.S, 12, replace=False).astype(np.int32)
-    Rr, Tr = _oracle(cref, m, pts=pts)
-    helpers.assert_stokes_close(R[:, :, pts], Rr[:, :, pts], what="C2 sample R")
-    helpers.assert_stokes_close(T[:, :, pts], Tr[:, :, pts], what="C2 sample T")
 
 
 @pytest.mark.parametrize("nS,lt,mode", [(1, 5, "lds"), (3, 9, "lds"), (4, 7, "generic")])
@@ -298,3 +280,107 @@ def test_m0_reduction_refused_for_polarised_source(rtamd, cref):
     R, T = rtamd.rt_run(m)[:2]
     helpers.assert_stokes_close(R, Rr, what="R polarised source")
     assert np.abs(Rr[:, 2]).max() > 1e-4  # U really is fed by the source
+
+
+def test_operator_level_state_rules(rtamd, cref):
+    """mom_download of the composite layer after a scene-level run returns Fourier moment 0 without the internal row
+    pitch (N = 24: pitch 32), or MOM_ESTATE when moment 0 ran on the (I,Q) sub-problem; the operator-level calls
+    refuse to continue from scene-level state; the inverse option reaches the reduced problem's stream set."""
+    L = rtamd._lib
+    m = rtamd.scenes.make_scene(3, 9, 3, 6, seed=12)
+    sc = rtamd.prepare_scene(m)
+    N, S = sc.N, sc.S
+    assert N == 24
+    # operator-level replay of moment 0 -> composite R-+ and J0-
+    qp, p = m.quad_points, m.params
+    Lin = rtamd.corert.construct_layer_inputs(m)
+    Zpp, Zmp = rtamd.corert.z_bases(m)
+    with rtamd.corert.make_handle(m) as h:
+        for z in range(sc.Nz):
+            dtau, nd = rtamd.corert.get_dtau_ndoubl(Lin.τ[:, z], Lin.ϖ[:, z], qp.qp_μ)
+            Zp = np.einsum("ks,kij->sij", Lin.zw[:, :, z], Zpp[0])
+            Zm = np.einsum("ks,kij->sij", Lin.zw[:, :, z], Zmp[0])
+            h.elemental(0, nd, Lin.τ_sum[:, z], dtau, Lin.ϖ[:, z], rtamd.corert._abi_mats(Zp), rtamd.corert._abi_mats(Zm), S)
+            h.doubling(nd, np.exp(-dtau / qp.μ0))
+            if z == 0:
+                h.copy_added_to_composite()
+            else:
+                h.interaction(int(Lin.iface[z]))
+        h.surface_lambertian(0, p.brdf_albedo, Lin.τ_sum[:, -1])
+        h.interaction(int(Lin.iface[-1]), with_surface_layer=True)
+        R_op, J_op = h.download(L.COMP["R_mp"]), h.download(L.COMP["J0m"])
+    with rtamd.corert.make_handle(m) as h:
+        h.set_option(L.MOM_OPT_M0_REDUCTION, 0)
+        rtamd.corert.run_scene(h, sc)
+        helpers.assert_op_close(h.download(L.COMP["R_mp"]), R_op, rtol=1e-11, what="de-pitched R-+ after mom_rt_run")
+        helpers.assert_op_close(h.download(L.COMP["J0m"]), J_op, rtol=1e-11, what="J0- after mom_rt_run")
+        with pytest.raises(rtamd.MomError) as e:
+            h.interaction(3)
+        assert e.value.code == L.MOM_ESTATE
+    with rtamd.corert.make_handle(m) as h:
+        Rd, _ = rtamd.corert.run_scene(h, sc)  # default: m = 0 on the (I,Q) sub-problem
+        with pytest.raises(rtamd.MomError) as e:
+            h.download(L.COMP["R_mp"])
+        assert e.value.code == L.MOM_ESTATE and "sub-problem" in str(e.value)
+        # forcing the pivoted inverse AFTER mom_scene_set must reach the reduced problem too (ADVICE r1)
+        h.set_option(L.MOM_OPT_INVERSE, 1)
+        h.rt_run()
+        Rg, _ = h.get_RT()
+    assert not np.array_equal(Rg, Rd)  # a different inverse: equal only to rounding
+    helpers.assert_stokes_close(Rg, Rd, rtol=1e-11, what="Gauss-Jordan vs series after scene_set")
+
+
+def test_rccl_allgather_single_rank(rtamd):
+    """mom_comm_unique_id / mom_comm_init / mom_allgather_RT with a world of one rank: the RCCL path behind the C
+    ABI executes on the GPU and returns this rank's spectra (the N > 1 layout is rank-major, tests/test_gpu_multirank.py)."""
+    m = rtamd.scenes.make_scene(3, 9, 4, 20, seed=5)
+    sc = rtamd.prepare_scene(m)
+    with rtamd.corert.make_handle(m) as h:
+        R, T = rtamd.corert.run_scene(h, sc)
+        h.comm_init(0, 1, rtamd._lib.comm_unique_id())
+        Rg, Tg = h.allgather_RT()
+        h.comm_destroy()
+    assert np.array_equal(Rg, R) and np.array_equal(Tg, T)
+
+
+@pytest.mark.parametrize("nS,lt,aer", [(3, 9, 0.2), (1, 5, 0.0), (4, 7, 0.4), (3, 33, 0.2)])
+def test_device_side_optics_bitwise_equals_host_route(rtamd, cref, nS, lt, aer):
+    """mom_scene_set_optics assembles tau, varpi, Z weights, tau_sum, ndoubl and the interface codes on the
+    GPU from tau_rayl / aerosol columns / the resident tau_abs table; every array and the resulting spectra are
+    bitwise those of the host route (reference algebra in corert.construct_layer_inputs + mom_scene_set)."""
+    m = rtamd.scenes.make_scene(nS, lt, 6, 40, seed=3 + nS, aerosol_total=aer)
+    if aer == 0.0:
+        m.τ_rayl[:, 1] = 0.0     # a non-scattering layer drives the interface state machine
+    sc = rtamd.prepare_scene(m)
+    with rtamd.corert.make_handle(m) as h:
+        R0, T0 = rtamd.corert.run_scene(h, sc)
+    with rtamd.corert.make_handle(m) as h:
+        R1, T1 = rtamd.corert.run_scene_device_optics(h, m)
+        nd, iface, tau, varpi, zw, tau_sum = h.scene_get_layers(sc.Nz, sc.K)
+    assert np.array_equal(nd, sc.ndoubl) and np.array_equal(iface, sc.iface)
+    assert np.array_equal(tau, sc.tau) and np.array_equal(varpi, sc.varpi)
+    assert np.array_equal(zw, sc.zw) and np.array_equal(tau_sum, sc.tau_sum)
+    assert np.array_equal(R1, R0) and np.array_equal(T1, T0)
+    Rr, Tr, info = cref.rt_run(cref.pack_scene(helpers.oracle_scene(m)))
+    helpers.assert_stokes_close(R1, Rr, what="device optics R vs oracle")
+
+
+def test_voigt_to_spectrum_without_host_tau(rtamd):
+    """Line list -> tau_abs (mom_voigt_tau_abs) -> layer optics (mom_scene_set_optics) -> spectrum, with tau_abs
+    resident on the GPU throughout; equals the route that downloads tau_abs and feeds it through the host algebra."""
+    ab = rtamd.absorption
+    m = rtamd.scenes.make_scene(3, 9, 5, 600, seed=11, absorption=False)
+    S, Nz = m.τ_rayl.shape
+    grid = np.linspace(12903.0, 13245.0, S)
+    lines = ab.synthetic_o2a_lines(200, seed=3)
+    ph = rtamd.scenes.pressure_grid(Nz)
+    p_full = 0.5 * (ph[1:] + ph[:-1]); T = np.linspace(215.0, 288.0, Nz); vcd = np.diff(ph) * 2.1e22
+    with rtamd.corert.make_handle(m) as h:
+        ab.compute_absorption_profile(h, lines, grid, p_full, T, vcd, 0.2095, model_vmr=0.2095)
+        tau_abs = h.absorption_get()
+        R1, T1 = rtamd.corert.run_scene_device_optics(h, m, upload_tau_abs=False)
+    assert tau_abs.max() > 0.05
+    m.τ_abs[:] = tau_abs
+    R0, T0 = rtamd.rt_run(m)[:2]
+    assert np.array_equal(R1, R0) and np.array_equal(T1, T0)
+    assert np.ptp(R1[0, 0]) > 1e-3 * R1[0, 0].max()    # the lines are in the spectrum

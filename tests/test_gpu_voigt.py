@@ -44,3 +44,54 @@ def test_edge_cases(rtamd, cref):
     assert rtamd.voigt_xsec(one(5.0), one(1e-2), one(1.0), one(1e-20), [1], [1], one(5.0))[0] > 0
     with pytest.raises(rtamd.MomError):
         rtamd.voigt_xsec(nu, gd, y, S, [0, 1, 1], [1, 1, 1], grid)  # window outside the grid
+
+
+def test_product_host_path_end_to_end_vs_golden(rtamd):
+    """compute_absorption_cross_section (product host code: read_hitran -> TIPS qoft -> prefactors -> GPU kernel) on
+    the reference's HITRAN fixture against the ORACLE-side golden spectrum (tests/golden/make_golden.py: oracle/absref.py
+    + oracle/momref.py): nothing is shared between the two routes but the input file and the TIPS data table."""
+    ab = rtamd.absorption
+    g = np.load(GOLD / "voigt_co2.npz")
+    tab = ab.hitran_table(ab.read_hitran(GOLD / "testCO2.data"))
+    for tag in ("a", "b"):
+        p, T = g[f"pT_{tag}"]
+        sig = ab.compute_absorption_cross_section(tab, g["grid"], float(p), float(T), vmr=0.0, wing_cutoff=40.0)
+        ref = g[f"sigma_{tag}"]
+        assert np.max(np.abs(sig - ref)) <= 1e-9 * ref.max()  # Float32 spline set-up differs by ~3e-11 between the routes
+
+
+def test_error_text_reaches_the_caller(rtamd):
+    grid = np.linspace(100.0, 101.0, 50)
+    one = lambda v: np.array([v])
+    with pytest.raises(rtamd.MomError) as e:
+        rtamd.voigt_xsec(one(100.5), one(1e-3), one(0.5), one(1e-20), [0], [10], grid)
+    assert "window [0, 10] outside the grid 1..50" in str(e.value)
+    with pytest.raises(rtamd.MomError) as e:
+        rtamd.voigt_xsec(one(100.5), one(1e-3), one(0.5), one(1e-20), [1], [10], grid, device=99)
+    assert "device index out of range" in str(e.value)
+
+
+def test_voigt_tau_abs_accumulates_into_resident_table(rtamd):
+    """compute_absorption_profile! (atmo_prof.jl:427-449) on the handle: tau_abs[:, iz] += sigma * vcd_dry[iz] * vmr with
+    sigma never leaving the GPU, two absorbers into the same table; bitwise the host accumulation of mom_voigt_xsec
+    spectra (same kernel, separately rounded product and sum)."""
+    ab = rtamd.absorption
+    S, Nz = 3000, 4
+    grid = np.linspace(12950.0, 13150.0, S)
+    o2, co2ish = ab.synthetic_o2a_lines(120, seed=5), ab.synthetic_o2a_lines(40, seed=6)
+    p_full = np.array([50.0, 300.0, 700.0, 980.0]); T = np.array([220.0, 235.0, 270.0, 290.0])
+    vcd = np.array([2.0e23, 1.1e24, 2.5e24, 1.9e24])
+    expect = np.zeros((S, Nz))
+    for tab, vmr, mv in ((o2, 0.21, 0.21), (co2ish, np.array([4e-4, 4.1e-4, 4.2e-4, 4.3e-4]), 0.0)):
+        for iz in range(Nz):
+            v = vmr if np.ndim(vmr) == 0 else vmr[iz]
+            sig = ab.compute_absorption_cross_section(tab, grid, p_full[iz], T[iz], vmr=mv)
+            expect[:, iz] += sig * (vcd[iz] * v)
+    with rtamd.Handle(4, 1, S, 1) as h:
+        ab.compute_absorption_profile(h, o2, grid, p_full, T, vcd, 0.21, model_vmr=0.21)
+        ab.compute_absorption_profile(h, co2ish, grid, p_full, T, vcd, np.array([4e-4, 4.1e-4, 4.2e-4, 4.3e-4]), begin=False)
+        got = h.absorption_get()
+        with pytest.raises(rtamd.MomError) as e:
+            h.voigt_tau_abs(5, [1.0], [1.0], [1.0], [1.0], [1], [1], 1.0)   # layer out of range
+        assert e.value.code == rtamd._lib.MOM_EINVAL
+    assert expect.max() > 1e-3 and np.array_equal(got, expect)

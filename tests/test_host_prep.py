@@ -94,9 +94,9 @@ def test_read_hitran_reference_cases(rtamd):
 def test_line_windows(rtamd):
     ab = rtamd.absorption
     grid = np.arange(6000.0, 6010.0, 0.01)
-    tab = ab.HitranTable(νᵢ=np.array([5990.0, 6005.0, 6049.9, 6060.0]), Sᵢ=np.full(4, 1e-25), γ_air=np.full(4, 0.05),
-                         γ_self=np.full(4, 0.05), E_lower=np.array([100.0, -1.0, 10.0, 5.0]), n_air=np.full(4, 0.7),
-                         δ_air=np.zeros(4), mol_weight=np.full(4, 44.0))
+    tab = ab.HitranTable(mol=np.full(4, 2), iso=np.full(4, 1), νᵢ=np.array([5990.0, 6005.0, 6049.9, 6060.0]),
+                         Sᵢ=np.full(4, 1e-25), γ_air=np.full(4, 0.05), γ_self=np.full(4, 0.05),
+                         E_lower=np.array([100.0, -1.0, 10.0, 5.0]), n_air=np.full(4, 0.7), δ_air=np.zeros(4))
     pf = ab.line_prefactors(tab, grid, 500.0, 250.0, wing_cutoff=40.0)
     assert len(pf.ν) == 3  # the 6060 line lies outside grid_max + wing (strict <, :76)
     assert list(pf.ind_start) == [1, 1, 991] and list(pf.ind_stop) == [1000, 1000, 1000]
