@@ -111,24 +111,59 @@ def _unique_keep_order(a: Sequence[float]) -> np.ndarray:
     return np.array(out, dtype=np.float64)
 
 
+def _deg2rad_dd(x):
+    """Julia's deg2rad_ext (base/special/trig.jl): x * m, m = Float64(pi/180), as an unevaluated sum hi + lo."""
+    m, mh, ml = 0.017453292519943295, 0.01745329238474369, 1.3519960527851425e-10
+    u = 134217729.0 * x
+    xh = u - (u - x)
+    xl = x - xh
+    hi = m * x
+    lo = xh * ml + (xl * mh + ((xh * mh - hi) + xl * ml))
+    return hi, lo
+
+
+def _ksin(deg):
+    """sin_kernel(::DoubleFloat64) = fdlibm __kernel_sin(x, y, 1) on the double-double radians of |deg| <= 45."""
+    x, y = _deg2rad_dd(deg)
+    z = x * x
+    v = z * x
+    r = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (
+        -2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))
+    return x - ((z * (0.5 * y - v * r) - y) - v * -1.66666666666666324348e-01)
+
+
+def _kcos(deg):
+    """cos_kernel(::DoubleFloat64) = fdlibm __kernel_cos(x, y)."""
+    x, y = _deg2rad_dd(deg)
+    z = x * x
+    w = z * z
+    r = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05)) + \
+        w * w * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))
+    hz = 0.5 * z
+    w = 1.0 - hz
+    return w + (((1.0 - w) - hz) + (z * r - x * y))
+
+
 def cosd(x):
-    """Julia cosd: exact at multiples of 90 deg; otherwise cos(deg2rad(x))."""
+    """Julia cosd (base/special/trig.jl): reduction in degrees, kernels on a double-double argument; exact at the
+    multiples of 30 and 90 degrees (cosd(60) == 0.5)."""
     x = np.asarray(x, dtype=np.float64)
-    out = np.cos(np.deg2rad(x))
-    xm = np.mod(np.abs(x), 360.0)
-    out = np.where((xm == 90.0) | (xm == 270.0), 0.0, out)
-    out = np.where(xm == 0.0, 1.0, out)
-    out = np.where(xm == 180.0, -1.0, out)
+    rx = np.abs(np.fmod(x, 360.0))
+    with np.errstate(all="ignore"):
+        out = np.select([rx <= 45.0, rx < 135.0, rx <= 225.0, rx < 315.0],
+                        [_kcos(rx), _ksin(90.0 - rx), -_kcos(180.0 - rx), _ksin(rx - 270.0)], _kcos(360.0 - rx))
     return out
 
 
 def sind(x):
     x = np.asarray(x, dtype=np.float64)
-    out = np.sin(np.deg2rad(x))
-    xm = np.mod(x, 360.0)
-    out = np.where((xm == 0.0) | (xm == 180.0), 0.0, out)
-    out = np.where(xm == 90.0, 1.0, out)
-    out = np.where(xm == 270.0, -1.0, out)
+    rx = np.fmod(x, 360.0)
+    arx = np.abs(rx)
+    sg = np.copysign(1.0, rx)
+    with np.errstate(all="ignore"):
+        out = np.select([rx == 0.0, arx < 45.0, arx <= 135.0, arx == 180.0, arx < 225.0, arx <= 315.0],
+                        [rx, _ksin(rx), np.copysign(_kcos(90.0 - arx), rx), np.copysign(0.0, rx), _ksin((180.0 - arx) * sg),
+                         -np.copysign(_kcos(270.0 - arx), rx)], _ksin(rx - np.copysign(360.0, rx)))
     return out
 
 

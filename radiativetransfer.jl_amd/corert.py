@@ -74,32 +74,81 @@ def Stokes_IQUV():
 
 
 # ------------------------------------------------------------------------------------------
-# trig in degrees, exact at the quadrant points like Julia's cosd/sind
+# trig in degrees like Julia's sind/cosd (base/special/trig.jl): the argument is reduced in DEGREES
+# (exact) to [-45, 45], converted to radians in double-double (deg2rad_ext) and fed to the sine or
+# cosine kernel with its low word -- so cosd(60) == 0.5 and sind(30) == 0.5 EXACTLY, not
+# 0.5000000000000001.  This matters beyond an ulp: rt_set_streams removes duplicate nodes with
+# `unique`, and a Gauss node at 0.5 next to mu0 = cosd(60) must collapse into one stream
+# (near-duplicate nodes make t++ depend on the rounding of exp).
 # ------------------------------------------------------------------------------------------
+
+def _deg2rad_ext(x: float):
+    """deg2rad_ext (Julia base/special/trig.jl): x * (pi/180 as a double) as an exact double-double (Dekker split)."""
+    m, m_hi, m_lo = 0.017453292519943295, 0.01745329238474369, 1.3519960527851425e-10
+    u = 134217729.0 * x  # 0x1p27 + 1
+    x_hi = u - (u - x)
+    x_lo = x - x_hi
+    y_hi = m * x
+    y_lo = x_hi * m_lo + (x_lo * m_hi + ((x_hi * m_hi - y_hi) + x_lo * m_lo))
+    return y_hi, y_lo
+
+
+# fdlibm's __kernel_sin / __kernel_cos on a (hi, lo) argument, |hi| <= pi/4 -- the kernels Julia's sin_kernel /
+# cos_kernel(::DoubleFloat64) evaluate
+_S = (-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+      2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10)
+_C = (4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+      -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11)
+
+
+def _sin_k(deg: float) -> float:  # |deg| <= 45
+    x, y = _deg2rad_ext(deg)
+    z = x * x
+    v = z * x
+    r = _S[1] + z * (_S[2] + z * (_S[3] + z * (_S[4] + z * _S[5])))
+    return x - ((z * (0.5 * y - v * r) - y) - v * _S[0])
+
+
+def _cos_k(deg: float) -> float:  # |deg| <= 45
+    x, y = _deg2rad_ext(deg)
+    z = x * x
+    w = z * z
+    r = z * (_C[0] + z * (_C[1] + z * _C[2])) + w * w * (_C[3] + z * (_C[4] + z * _C[5]))
+    hz = 0.5 * z
+    w = 1.0 - hz
+    return w + (((1.0 - w) - hz) + (z * r - x * y))
 
 
 def cosd(x: float) -> float:
-    r = math.fmod(abs(float(x)), 360.0)
-    if r in (90.0, 270.0):
-        return 0.0
-    if r == 0.0:
-        return 1.0
-    if r == 180.0:
-        return -1.0
-    return math.cos(math.radians(float(x)))
+    rx = abs(math.fmod(float(x), 360.0))
+    if rx <= 45.0:
+        return _cos_k(rx)
+    if rx < 135.0:
+        return _sin_k(90.0 - rx)
+    if rx <= 225.0:
+        return -_cos_k(180.0 - rx)
+    if rx < 315.0:
+        return _sin_k(rx - 270.0)
+    return _cos_k(360.0 - rx)
 
 
 def sind(x: float) -> float:
-    r = math.fmod(float(x), 360.0)
-    if r < 0:
-        r += 360.0
-    if r in (0.0, 180.0):
-        return 0.0
-    if r == 90.0:
-        return 1.0
-    if r == 270.0:
-        return -1.0
-    return math.sin(math.radians(float(x)))
+    rx = math.fmod(float(x), 360.0)
+    arx = abs(rx)
+    sg = math.copysign(1.0, rx)
+    if rx == 0.0:
+        return rx
+    if arx < 45.0:
+        return _sin_k(rx)
+    if arx <= 135.0:
+        return math.copysign(_cos_k(90.0 - arx), rx)
+    if arx == 180.0:
+        return math.copysign(0.0, rx)
+    if arx < 225.0:
+        return _sin_k((180.0 - arx) * sg)
+    if arx <= 315.0:
+        return -math.copysign(_cos_k(270.0 - arx), rx)
+    return _sin_k(rx - math.copysign(360.0, rx))
 
 
 # ------------------------------------------------------------------------------------------

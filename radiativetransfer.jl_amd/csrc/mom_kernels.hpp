@@ -35,9 +35,12 @@
 namespace MOM_NS {
 
 // beta^2 thresholds: kNeumannThr2[p-1] = largest ||B||_F^2 for which p series terms suffice
-// (beta^p / (1 - beta) <= 2^-56), p = 1..32.
+// (beta^p / (1 - beta) <= 2^-56), p = 1..32 -- except that the first-order term B is always kept (p >= 2 unless
+// B = 0): the bound is ABSOLUTE, i.e. against the O(1) diagonal, while the off-diagonal (diffuse) elements of t++ are
+// themselves only of order rho = sqrt(beta) in a doubling step; dropping B there would cost them a relative rho (up to
+// 4e-9), whereas the tail after B is of relative size rho^3 <= 2e-13.
 __device__ const double kNeumannThr2[32] = {
-    1.92592994438723585e-34, 1.38777877561156685e-17, 5.77492213356056750e-12, 3.72517661162420568e-09,
+    0.0 /* p = 1 only for B = 0 */, 1.38777877561156685e-17, 5.77492213356056750e-12, 3.72517661162420568e-09,
     1.80656771560518035e-07, 2.40186660760962690e-06, 1.52417448931310540e-05, 6.09157135028591602e-05,
     1.78874927371965362e-04, 4.23309807394842467e-04, 8.56292603484697687e-04, 1.53988783074545245e-03,
     2.52966413875025916e-03, 3.87056942792606993e-03, 5.59509450064154569e-03, 7.72318484591632843e-03,
@@ -238,7 +241,7 @@ __device__ __forceinline__ int neumann_terms(const double *thr, double beta2) {
 __device__ __forceinline__ int neumann_terms_12(double beta2) {
   if (!(beta2 <= 1.53988783074545245e-03)) return 1000;
   int p = 1;
-  p += beta2 > 1.92592994438723585e-34; p += beta2 > 1.38777877561156685e-17; p += beta2 > 5.77492213356056750e-12;
+  p += beta2 > 0.0; p += beta2 > 1.38777877561156685e-17; p += beta2 > 5.77492213356056750e-12;
   p += beta2 > 3.72517661162420568e-09; p += beta2 > 1.80656771560518035e-07; p += beta2 > 2.40186660760962690e-06;
   p += beta2 > 1.52417448931310540e-05; p += beta2 > 6.09157135028591602e-05; p += beta2 > 1.78874927371965362e-04;
   p += beta2 > 4.23309807394842467e-04; p += beta2 > 8.56292603484697687e-04;

@@ -1007,6 +1007,54 @@ extern "C" int mom_get_RT_device(mom_t *h, void *dR, void *dT) {
 
 // ---------------------------------------------------------------- operator-level post-processing
 
+// cosd / sind as Julia evaluates them (base/special/trig.jl): reduction in degrees, double-double radians
+// (deg2rad_ext), fdlibm kernels with the low word -- exact at the multiples of 30 and 90 degrees
+#pragma clang fp contract(off)
+static void mom_deg2rad_ext(double x, double &hi, double &lo) {
+  const double m = 0.017453292519943295, m_hi = 0.01745329238474369, m_lo = 1.3519960527851425e-10;
+  const volatile double u = 134217729.0 * x;
+  const volatile double t = u - x;
+  const double x_hi = u - t, x_lo = x - x_hi;
+  hi = m * x;
+  lo = x_hi * m_lo + (x_lo * m_hi + ((x_hi * m_hi - hi) + x_lo * m_lo));
+}
+static double mom_ksin(double deg) {
+  double x, y;
+  mom_deg2rad_ext(deg, x, y);
+  const double z = x * x, v = z * x;
+  const double r = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  return x - ((z * (0.5 * y - v * r) - y) - v * -1.66666666666666324348e-01);
+}
+static double mom_kcos(double deg) {
+  double x, y;
+  mom_deg2rad_ext(deg, x, y);
+  const double z = x * x;
+  double w = z * z;
+  const double r = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * 2.48015872894767294178e-05)) +
+                   w * w * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11));
+  const double hz = 0.5 * z;
+  w = 1.0 - hz;
+  return w + (((1.0 - w) - hz) + (z * r - x * y));
+}
+static double mom_cosd(double x) {
+  const double rx = std::fabs(std::fmod(x, 360.0));
+  if (rx <= 45.0) return mom_kcos(rx);
+  if (rx < 135.0) return mom_ksin(90.0 - rx);
+  if (rx <= 225.0) return -mom_kcos(180.0 - rx);
+  if (rx < 315.0) return mom_ksin(rx - 270.0);
+  return mom_kcos(360.0 - rx);
+}
+static double mom_sind(double x) {
+  const double rx = std::fmod(x, 360.0), arx = std::fabs(rx);
+  if (rx == 0.0) return rx;
+  if (arx < 45.0) return mom_ksin(rx);
+  if (arx <= 135.0) return std::copysign(mom_kcos(90.0 - arx), rx);
+  if (arx == 180.0) return std::copysign(0.0, rx);
+  if (arx < 225.0) return mom_ksin((180.0 - arx) * std::copysign(1.0, rx));
+  if (arx <= 315.0) return -std::copysign(mom_kcos(270.0 - arx), rx);
+  return mom_ksin(rx - std::copysign(360.0, rx));
+}
+
 // postprocessing_vza!(RS_type::noRS, iμ₀, pol_type, composite_layer, vza, qp_μ, m, vaz, μ₀, weight, nSpec, SFI, R, R_SFI,
 // T, T_SFI, ...) -- postprocessing_vza.jl:9-60 for ONE Fourier moment on the operator-level composite layer: gathers
 // the nVza view rows of J0-/J0+ on the GPU (the reference copies the whole composite layer to the host, :17-20)
@@ -1041,12 +1089,9 @@ extern "C" int mom_postprocess(mom_t *h, int m, int nVza, const int *node_1based
     h->post_cap = total;
   }
   h->d_post[1] = h->d_post[0] + total;
-  // bigCS = weight * Diagonal([cos(m φ), cos(m φ), sin(m φ), sin(m φ)][1:n])   (postprocessing_vza.jl:32-33), cosd/sind
-  // exact at the quadrant angles like Julia's
-  auto cosd = [](double x) { double r = std::fmod(std::fabs(x), 360.0); if (r == 90.0 || r == 270.0) return 0.0; if (r == 0.0) return 1.0;
-                             if (r == 180.0) return -1.0; return std::cos(x * (M_PI / 180.0)); };
-  auto sind = [](double x) { double r = std::fmod(x, 360.0); if (r < 0) r += 360.0; if (r == 0.0 || r == 180.0) return 0.0;
-                             if (r == 90.0) return 1.0; if (r == 270.0) return -1.0; return std::sin(x * (M_PI / 180.0)); };
+  // bigCS = weight * Diagonal([cos(m φ), cos(m φ), sin(m φ), sin(m φ)][1:n])   (postprocessing_vza.jl:32-33)
+  auto cosd = [](double x) { return mom_cosd(x); };
+  auto sind = [](double x) { return mom_sind(x); };
   std::vector<double> cs((size_t)nVza * h->nS);
   for (int k = 0; k < h->nS; ++k)
     for (int v = 0; v < nVza; ++v) cs[v + (size_t)nVza * k] = weight * ((k < 2) ? cosd(m * vaz_deg[v]) : sind(m * vaz_deg[v]));
@@ -1085,9 +1130,24 @@ Rccl g_rccl;
 // copy per process); libmomcore.so itself stays loadable on machines without RCCL
 int rccl_load(mom_t *h) {
   if (g_rccl.lib) return MOM_OK;
-  void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  // RCCL must sit on the SAME HIP runtime instance as this library.  A host process may hold two (PyTorch-ROCm wheels
+  // bundle libamdhip64.so + librccl.so next to /opt/rocm's, and which one libmomcore.so was bound to depends on the
+  // import order), so the copy next to the runtime that resolves OUR hip* symbols is taken first
+  void *lib = nullptr;
+  Dl_info info;
+  if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos) {
+      dir.resize(slash);
+      for (const char *name : {"/librccl.so.1", "/librccl.so"}) {
+        lib = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+      }
+    }
+  }
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
   if (!lib) return fail(h, MOM_EHIP, "mom_comm: cannot load librccl.so.1 (RCCL)");
   Rccl r;
   r.lib = lib;

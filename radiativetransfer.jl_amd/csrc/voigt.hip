@@ -124,7 +124,11 @@ __global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__re
   }
   // accumulate: tau_abs[:, iz] += sigma * (vcd_dry[iz] * vmr)  (atmo_prof.jl:446), fused into the line-shape kernel
   // (separately rounded product and sum, like the host expression: no FMA contraction)
-  if (gi < nGrid) sigma[gi] = accumulate ? __dadd_rn(sigma[gi], __dmul_rn(acc, factor)) : acc;
+  if (gi < nGrid) {
+#pragma clang fp contract(off)
+    const double scaled = acc * factor;
+    sigma[gi] = accumulate ? sigma[gi] + scaled : acc;
+  }
 }
 
 thread_local double v_last_ms = 0.0;

@@ -10,6 +10,7 @@ model_from_parameters() derives from YAML + HITRAN + Mie, with the same shapes:
 from __future__ import annotations
 
 import math
+from typing import Optional
 
 import numpy as np
 
@@ -58,11 +59,16 @@ def lognormal_absorption(S: int, p_half: np.ndarray, seed: int) -> np.ndarray:
 
 
 def make_scene(nStokes: int, l_trunc: int, Nz: int, S: int, ν_lo: float = 12903.0, ν_hi: float = 13245.0,
-               sza: float = 60.0, vza=(0.0, 30.0, 60.0), vaz=(0.0, 45.0, 120.0), aerosol_total: float = 0.2,
+               sza: Optional[float] = None, vza=(0.0, 30.0, 60.0), vaz=(0.0, 45.0, 120.0), aerosol_total: float = 0.2,
                aerosol_p0: float = 800.0, aerosol_σp: float = 50.0, g: float = 0.7, albedo: float = 0.2,
                depol: float = 0.03, max_m: int = 3, seed: int = 1234, absorption: bool = True,
                architecture=None) -> rt.vSmartMOM_Model:
     pol = {1: rt.Stokes_I, 3: rt.Stokes_IQU, 4: rt.Stokes_IQUV}[nStokes]()
+    if sza is None:
+        # Sun at 60 deg -- unless the Gauss rule itself has a node at cosd(60) = 0.5 (odd number of nodes on [0, 1]):
+        # then mu0 would merge with that node under rt_set_streams' `unique`; 50 deg keeps the Sun a zero-weight stream
+        # of its own, so every scene has (l_trunc + 1) // 2 + 3 streams for the default three view angles
+        sza = 50.0 if ((l_trunc + 1) // 2) % 2 == 1 else 60.0
     params = rt.vSmartMOM_Parameters(
         polarization_type=pol, quadrature_type="GaussQuadHemisphere", max_m=max_m, l_trunc=l_trunc, depol=depol,
         sza=sza, vza=np.asarray(vza, dtype=np.float64), vaz=np.asarray(vaz, dtype=np.float64), brdf_albedo=albedo,
@@ -84,7 +90,8 @@ def scene_C1(S: int = 100, **kw):
 
 
 def scene_C2(S: int = 10_000, Nz: int = 40, **kw):
-    """O2 A-band IQU: 17 Gauss nodes + {1, cos30°, cos60°=μ₀} = 20 streams, N = 60."""
+    """O2 A-band IQU: 17 Gauss nodes (one of them at 0.5 = cos 60°, the third view angle) + {1, cos 30°} + μ₀ = cos 50°
+    = 20 streams, N = 60."""
     return make_scene(3, 33, Nz, S, **kw)
 
 
@@ -99,7 +106,7 @@ def scene_C3(S: int = 29_944, Nz: int = 40, **kw):
 
 
 def scene_C4(S: int = 2_000, Nz: int = 40, **kw):
-    """aerosol + cloud, IQUV, 61 Gauss nodes + 3 = 64 streams, N = 256."""
+    """aerosol + cloud, IQUV, 61 Gauss nodes (incl. 0.5 = cos 60°) + {1, cos 30°, μ₀ = cos 50°} = 64 streams, N = 256."""
     kw.setdefault("aerosol_total", 5.0)
     kw.setdefault("aerosol_p0", 700.0)
     return make_scene(4, 121, Nz, S, **kw)

@@ -50,12 +50,16 @@ def test_rt_run_parity_strip_sizes(rtamd, cref, nS, lt):
     m = rtamd.scenes.make_scene(nS, lt, 5, 10, seed=3 * nS + lt, aerosol_total=0.6)
     R, T = _gpu(rtamd, m)
     Rr, Tr = _oracle(cref, m)
-    helpers.assert_stokes_close(R, Rr, what="R strip")
-    helpers.assert_stokes_close(T, Tr, what="T strip")
+    tol = helpers.stokes_rtol(rtamd.prepare_scene(m).ndoubl)  # aerosol tau 0.6: up to 21 doublings
+    helpers.assert_stokes_close(R, Rr, rtol=tol, what="R strip")
+    helpers.assert_stokes_close(T, Tr, rtol=tol, what="T strip")
     R2, T2 = _gpu(rtamd, m, inverse=2)  # same kernels with the strip chains switched off
-    helpers.assert_stokes_close(R2, Rr, what="R no strip")
-    helpers.assert_stokes_close(R, R2, what="strip vs plain R")
-    helpers.assert_stokes_close(T, T2, what="strip vs plain T")
+    helpers.assert_stokes_close(R2, Rr, rtol=tol, what="R no strip")
+    helpers.assert_stokes_close(R, R2, rtol=tol, what="strip vs plain R")
+    helpers.assert_stokes_close(T, T2, rtol=tol, what="strip vs plain T")
+    R3, T3 = _gpu(rtamd, m, force_gj=True)  # pivoted Gauss-Jordan on I - B like the oracle's LU: same rounding pattern
+    helpers.assert_stokes_close(R3, Rr, rtol=1e-11, what="R gauss-jordan")
+    helpers.assert_stokes_close(T3, Tr, rtol=1e-11, what="T gauss-jordan")
 
 
 def test_strip_chains_thick_layers_fall_back(rtamd, cref):
@@ -64,8 +68,9 @@ def test_strip_chains_thick_layers_fall_back(rtamd, cref):
     m = rtamd.scenes.make_scene(3, 33, 4, 8, seed=77, aerosol_total=2.0, aerosol_p0=600.0, aerosol_σp=200.0, absorption=False)
     R, T = _gpu(rtamd, m)
     Rr, Tr = _oracle(cref, m)
-    helpers.assert_stokes_close(R, Rr, what="R thick")
-    helpers.assert_stokes_close(T, Tr, what="T thick")
+    tol = helpers.stokes_rtol(rtamd.prepare_scene(m).ndoubl)
+    helpers.assert_stokes_close(R, Rr, rtol=tol, what="R thick")
+    helpers.assert_stokes_close(T, Tr, rtol=tol, what="T thick")
 
 
 def test_launch_shape_options_do_not_change_results(rtamd, cref):
