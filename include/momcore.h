@@ -241,9 +241,13 @@ int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
  *                         workgroups, two per CU; 0 = always 8-wave workgroups
  *   MOM_OPT_STAGGER       1 (default) = the persistent one-per-CU workgroups of the strip-chained kernels start
  *                         with offsets spread over one unit time, so that the CUs' composite loads/stores do
- *                         not all fall into the same microseconds; 0 = all start together */
+ *                         not all fall into the same microseconds; 0 = all start together
+ *   MOM_OPT_SMALL_N       1 (default) = operators of edge N <= 4 (with at most 4 view angles and 4 phase-matrix bases)
+ *                         run the lane-per-spectral-point sweep kernel: the whole of mom_rt_run in one launch, all
+ *                         operators in registers (csrc/mom_small.hip); 0 = the general workgroup-per-point kernels */
 int mom_set_option(mom_t *h, int option, int value);
-enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1, MOM_OPT_M0_REDUCTION = 2, MOM_OPT_SMALL_WG = 3, MOM_OPT_STAGGER = 4 };
+enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1, MOM_OPT_M0_REDUCTION = 2, MOM_OPT_SMALL_WG = 3, MOM_OPT_STAGGER = 4,
+       MOM_OPT_SMALL_N = 5 };
 
 /* ---- Voigt line-by-line cross section --------------------------------------------------
  * compute_absorption_cross_section(model::HitranModel, grid, p, T)

@@ -249,6 +249,8 @@ hipError_t mom_strip14_launch_layer(const void *layer_args, int iface, int grid,
 hipError_t mom_strip15_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom4_launch_surface(const void *surf_args, bool lds, int grid, size_t smem, hipStream_t st);
 int mom4_generic_bufs_elems(int N);
+// mom_small.hip: N <= 4, one spectral point per lane, the whole sweep in one launch
+hipError_t momsm_launch_sweep(const void *args, int N, hipStream_t st);
 
 static thread_local std::string g_err;
 static int check_info(mom_t *h);
@@ -296,6 +298,9 @@ struct mom_handle {
   int opt_m0 = 1;
   int opt_w4 = 1;
   int opt_stagger = 1;
+  int opt_small = 1;       // N <= 4: lane-per-point sweep kernel (mom_small.hip)
+  double *d_smtab = nullptr;  // F1 | F2 | SI tables [3][N,N]
+  int *d_ndif = nullptr;      // ndoubl | iface [2][Nz]
   bool red0 = false;
   int N0 = 0, nS0 = 0;
   DevStreams q0{};
@@ -429,7 +434,7 @@ extern "C" int mom_destroy(mom_t *h) {
   fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
   fr(h->d_mu0); fr(h->d_wt0); fr(h->d_sg0); fr(h->d_Zpp0); fr(h->d_Zmp0); fr(h->d_hdrJ0); fr(h->d_scratch0);
   for (int k = 0; k < 6; ++k) fr(h->comp0[k]);
-  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_tau_rayl);
+  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_smtab); if (h->d_ndif) (void)hipFree(h->d_ndif); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_tau_rayl);
   fr(h->d_layer_max); fr(h->d_aer); if (h->d_aer_mode) (void)hipFree(h->d_aer_mode); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
   for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (auto e : h->ev_full) (void)hipEventDestroy(e);
@@ -458,6 +463,7 @@ extern "C" int mom_set_option(mom_t *h, int option, int value) {
   else if (option == MOM_OPT_M0_REDUCTION) h->opt_m0 = value;
   else if (option == MOM_OPT_SMALL_WG) h->opt_w4 = value;
   else if (option == MOM_OPT_STAGGER) h->opt_stagger = value;
+  else if (option == MOM_OPT_SMALL_N) h->opt_small = value;
   else if (option == MOM_OPT_FORCE_GENERIC) {
     h->opt_force_generic = value;
     h->lds_mode = (h->N <= 64) && !value;
@@ -787,7 +793,7 @@ static int scene_common(mom_t *h, int Nz, int K, int M, const double *Zpp, const
   // ---- m = 0 reduction (include/momcore.h): conditions checked on the data, bitwise
   {
     const int N = h->N, nS = h->nS, Nq = N / nS;
-    bool ok = h->opt_m0 && nS >= 3 && h->q.regular;
+    bool ok = h->opt_m0 && nS >= 3 && h->q.regular && !(N <= 4 && h->opt_small && nVza <= 4);
     for (int k = 2; k < nS && ok; ++k) ok = (h->q.I0[k] == 0.0);
     for (int kb = 0; kb < K && ok; ++kb)
       for (int j = 0; j < N && ok; ++j)
@@ -841,6 +847,66 @@ static int scene_common(mom_t *h, int Nz, int K, int M, const double *Zpp, const
   return MOM_OK;
 }
 
+// The argument block of momsm::k_sweep (mom_small.hip), layout-identical plain data
+struct SmallSweepArgs {
+  int S, M, K, Nz, nVza, nS, imu0, pad;
+  double mu0, albedo;
+  double I0[4], D[4];
+  const double *mu, *wt, *sg, *F1, *F2, *SI, *Zpp, *Zmp;
+  const int *nd, *iface, *node;
+  const double *cos_mphi, *sin_mphi;
+  const double *tau, *varpi, *zw, *tau_sum;
+  double *R, *T, *hdr, *bhr_uw, *bhr_dw;
+  int *info;
+};
+
+// N <= 4: one spectral point per lane, all moments / layers / surface / post-processing in ONE launch
+static int rt_run_small(mom_t *h) {
+  const int N = h->N, Nz = h->Nz;
+  if (!h->d_smtab) HIPCHK(h, dmalloc(&h->d_smtab, 3 * 16));
+  {  // mu_j/(mu_i + mu_j), mu_j/(mu_i - mu_j), (1/mu_i) + (1/mu_j): the expressions of elemental.jl:176-186, evaluated once
+    double tab[48] = {0};
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < N; ++i) {
+        const double mui = h->h_mu[i], muj = h->h_mu[j];
+        tab[i + N * j] = muj / (mui + muj);
+        tab[16 + i + N * j] = muj / (mui - muj);
+        tab[32 + i + N * j] = (1 / mui) + (1 / muj);
+      }
+    HIPCHK(h, hipMemcpyAsync(h->d_smtab, tab, sizeof tab, hipMemcpyHostToDevice, h->stream));
+  }
+  {
+    if (h->d_ndif) { (void)hipFree(h->d_ndif); h->d_ndif = nullptr; }
+    HIPCHK(h, dmalloc(&h->d_ndif, 2 * (size_t)Nz));
+    std::vector<int> v(h->nd);
+    v.insert(v.end(), h->iface.begin(), h->iface.end());
+    HIPCHK(h, hipMemcpyAsync(h->d_ndif, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // the host vectors above go out of scope
+  }
+  SmallSweepArgs a{};
+  a.S = h->S; a.M = h->scene_M; a.K = h->K; a.Nz = Nz; a.nVza = h->nVza; a.nS = h->nS; a.imu0 = h->q.imu0;
+  a.mu0 = h->q.mu0; a.albedo = h->albedo;
+  for (int k = 0; k < 4; ++k) { a.I0[k] = h->q.I0[k]; a.D[k] = h->q.D[k]; }
+  a.mu = h->d_mu; a.wt = h->d_wt; a.sg = h->d_sg;
+  a.F1 = h->d_smtab; a.F2 = h->d_smtab + 16; a.SI = h->d_smtab + 32;
+  a.Zpp = h->d_Zpp; a.Zmp = h->d_Zmp;
+  a.nd = h->d_ndif; a.iface = h->d_ndif + Nz; a.node = h->d_node; a.cos_mphi = h->d_cos; a.sin_mphi = h->d_sin;
+  a.tau = h->d_tau; a.varpi = h->d_varpi; a.zw = h->d_zw; a.tau_sum = h->d_tau_sum;
+  a.R = h->d_R; a.T = h->d_T; a.hdr = h->d_hdr; a.bhr_uw = h->d_bhr_uw; a.bhr_dw = h->d_bhr_dw;
+  a.info = h->d_info;
+  if (h->K > 4) return fail(h, MOM_EINVAL, "mom_rt_run: the N <= 4 sweep kernel handles at most 4 phase-matrix bases");
+  while (h->ev_full.size() < 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_full.push_back(e); }
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_full[0], h->stream));
+  HIPCHK(h, momsm_launch_sweep(&a, N, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_full[1], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+  h->launches = 1; h->launches_full = 1; h->launches_red = 0;
+  return MOM_OK;
+}
+
 extern "C" int mom_rt_run(mom_t *h) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_rt_run: call mom_scene_set first");
@@ -849,6 +915,7 @@ extern "C" int mom_rt_run(mom_t *h) {
   const int M = h->scene_M;
   h->launches = 0; h->launches_full = 0; h->launches_red = 0;
   h->comp_pitched = true;
+  if (h->N <= 4 && h->opt_small && h->nVza <= 4) return rt_run_small(h);
   while (h->ev_full.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_full.push_back(e); }
   while (h->ev_red.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_red.push_back(e); }
   const size_t NN = (size_t)h->N * h->N;

@@ -35,6 +35,39 @@ def test_config_C1_default_scalar(rtamd, cref):
     helpers.assert_stokes_close(T, Tr, what="C1 T")
 
 
+@pytest.mark.parametrize("lt,vza,kw", [(3, (0.0,), {}), (3, (0.0,), dict(aerosol_total=0.0, zero_layers=(0, 1, 3))),
+                                       (1, (0.0,), dict(albedo=0.35)), (1, (50.0,), {}), (3, (60.0,), dict(aerosol_total=1.5))])
+def test_small_operator_sweep_kernel(rtamd, cref, lt, vza, kw):
+    """N <= 4 (mom_small.hip: one spectral point per lane, the whole sweep in one launch) against the oracle AND against
+    the general workgroup-per-point kernels (MOM_OPT_SMALL_N = 0): spectra, hdr and the BHR fluxes; includes all four
+    interface cases with zero doublings, N = 2, 3, 4 and a thick aerosol layer."""
+    kw = dict(kw)
+    zero = kw.pop("zero_layers", ())
+    m = rtamd.scenes.make_scene(1, lt, 6, 200, seed=5 + lt, vza=vza, vaz=(30.0,) * len(vza), **kw)
+    for z in zero:
+        m.τ_rayl[:, z] = 0.0
+    sc = rtamd.prepare_scene(m)
+    assert sc.N <= 4
+    p = cref.pack_scene(helpers.oracle_scene(m))
+    Rr, Tr, Hr, upr, dwr, info = cref.rt_run_full(p)
+    assert info == 0
+    out = {}
+    for small in (1, 0):
+        with rtamd.corert.make_handle(m) as h:
+            h.set_option(rtamd._lib.MOM_OPT_SMALL_N, small)
+            R, T = rtamd.corert.run_scene(h, sc)
+            out[small] = (R, T) + h.get_hdr() + (h.timers()["layer_launches"],)
+    assert out[1][5] == 1 and out[0][5] > 1           # one launch vs one per layer
+    tol = helpers.stokes_rtol(sc.ndoubl)
+    for small in (1, 0):
+        R, T, H, up, dw, _ = out[small]
+        helpers.assert_stokes_close(R, Rr, rtol=tol, what=f"R small={small}")
+        helpers.assert_stokes_close(T, Tr, rtol=tol, what=f"T small={small}")
+        helpers.assert_stokes_close(H, Hr, rtol=tol, what=f"hdr small={small}")
+        np.testing.assert_allclose(up, upr, rtol=max(tol, 1e-10), atol=1e-300)
+        np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=1e-300)
+
+
 def test_config_C2_full_size_stratified(rtamd, cref):
     """configs[1] at full size (N = 60, 40 layers, S = 10 000): finite, reproducible run to run, and equal to the
     oracle on 256 points stratified over absorption depth."""
