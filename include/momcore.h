@@ -189,6 +189,19 @@ int mom_scene_set_optics(mom_t *h, int Nz, int nAer, int M, const double *tau_ra
                          const double *sin_mphi);
 int mom_scene_get_layers(mom_t *h, int *ndoubl, int *iface, double *tau, double *varpi, double *zw, double *tau_sum);
 
+/* Surface type of the resident scene (call after mom_scene_set / mom_scene_set_optics, which select
+ * LambertianSurfaceScalar(albedo)):
+ *   kind 0  LambertianSurfaceScalar (lambertian_surface.jl:20-75), the `albedo` of mom_scene_set
+ *   kind 1  any BRDF surface handled by create_surface_layer!(brdf::AbstractSurfaceType, ...) (rpv_surface.jl:20-66:
+ *           rpvSurfaceScalar, RossLiSurfaceScalar, ...): Rsurf [N, N, M] = the matrices the host obtains from
+ *           reflectance(brdf, pol_type, qp_μ, m) (rpv_surface.jl:104-134), times 2 for m = 0 (:39-43).  The library
+ *           forms j₀⁺, j₀⁻ = μ₀ (R_surf I₀) e^{-τ/μ₀}, r⁻⁺ = R_surf Diagonal(qp_μN .* wt_μN) (:48-62) and interacts
+ *           the surface with the composite layer for EVERY Fourier moment; hdr accumulates over all moments.
+ *   kind 2  LambertianSurfaceLegendre (lambertian_surface.jl:77-138): albedo_spec [nSpec] = P * legendre_coeff
+ *           evaluated by the host (:90-96); reproduces that method's j₀⁺ = 0 (:112) and its t = 0 for m > 0 (:131-132).
+ * Unused pointers may be NULL. */
+int mom_scene_set_surface(mom_t *h, int kind, int M, const double *Rsurf, const double *albedo_spec);
+
 /* The whole of rt_run.jl:125-215 for the resident scene: all Fourier moments, all layers,
  * surface, post-processing.  Asynchronous on the handle's stream; results stay on the GPU. */
 int mom_rt_run(mom_t *h);

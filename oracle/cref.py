@@ -67,7 +67,8 @@ class OraScene(C.Structure):
                 ("mu", c_dp), ("wt", c_dp), ("I0", c_dp), ("D", c_dp),
                 ("tau", c_dp), ("varpi", c_dp), ("zw", c_dp), ("Zpp", c_dp), ("Zmp", c_dp),
                 ("nd", c_ip), ("iface", c_ip), ("tau_sum", c_dp), ("albedo", C.c_double),
-                ("nVza", C.c_int), ("node", c_ip), ("cos_mphi", c_dp), ("sin_mphi", c_dp)]
+                ("nVza", C.c_int), ("node", c_ip), ("cos_mphi", c_dp), ("sin_mphi", c_dp),
+                ("surf_kind", C.c_int), ("Rsurf", c_dp), ("albedo_spec", c_dp)]
 
 
 class Packed:
@@ -103,6 +104,10 @@ class Packed:
         self.tau_sum = np.ascontiguousarray(tau_sum.T).reshape(-1)  # [z][n]
         self.nd = np.array([mr.get_dtau_ndoubl(l.tau, l.varpi, quad.qp_mu)[1] for l in layers], dtype=np.int32)
         self.albedo = float(scene.albedo)
+        # surface type (Scene.brdf: None = LambertianSurfaceScalar(albedo)); the oracle's own reflectance code
+        self.surf_kind, self.Rsurf, self.albedo_spec = mr.surface_inputs(scene)
+        if self.Rsurf is not None:  # [M,N,N] -> [N,N,M] column-major
+            self.Rsurf = np.ascontiguousarray(np.transpose(self.Rsurf, (0, 2, 1))).reshape(-1)
         self.nVza = len(scene.vza)
         self.node = np.array([mr.nearest_point(quad.qp_mu, float(mr.cosd(v))) + 1 for v in scene.vza], dtype=np.int32)
         self.vaz = np.asarray(scene.vaz, dtype=np.float64)
@@ -121,6 +126,9 @@ class Packed:
         s.nd, s.iface, s.tau_sum = ip(self.nd), ip(self.iface), dp(self.tau_sum)
         s.albedo, s.nVza, s.node = self.albedo, self.nVza, ip(self.node)
         s.cos_mphi, s.sin_mphi = dp(self.cos_mphi), dp(self.sin_mphi)
+        s.surf_kind = self.surf_kind
+        s.Rsurf = dp(self.Rsurf) if self.Rsurf is not None else None
+        s.albedo_spec = dp(self.albedo_spec) if self.albedo_spec is not None else None
         return s
 
 

@@ -389,6 +389,47 @@ static void surface_lambertian_pt(const ora_streams *q, int m, double albedo, do
   }
 }
 
+/* create_surface_layer!(brdf::AbstractSurfaceType, ...) rpv_surface.jl:20-66 for ONE Fourier moment:
+ * Rs = rho_m [N,N] column-major (reflectance(brdf, pol_type, qp_mu, m), x2 for m = 0, computed by the host),
+ * j0+ = I0N e^{-tau/mu0}, j0- = mu0 (Rs I0N) e^{-tau/mu0}, r-+ = Rs Diagonal(mu .* wt), r+- = 0, t = I. */
+static void surface_brdf_pt(const ora_streams *q, const double *Rs, double tau_tot, double *r_pm, double *r_mp,
+                            double *t_mm, double *t_pp, double *j0p, double *j0m) {
+  const int N = q->N, n = q->nS;
+  const size_t NN = (size_t)N * N;
+  const int i0 = n * (q->imu0 - 1);
+  const double att = exp(-tau_tot / q->mu0);
+  for (size_t x = 0; x < NN; ++x) { t_pp[x] = 0; t_mm[x] = 0; r_pm[x] = 0; }
+  for (int i = 0; i < N; ++i) { t_pp[IDX(i, i, N)] = 1.0; t_mm[IDX(i, i, N)] = 1.0; }
+  for (int i = 0; i < N; ++i) {
+    const int in_sun = (i >= i0) && (i < n * q->imu0);
+    j0p[i] = (in_sun ? q->I0[i - i0] : 0.0) * att;
+    double rI = 0.0;
+    for (int k = 0; k < n; ++k) rI += Rs[IDX(i, i0 + k, N)] * q->I0[k];
+    j0m[i] = (q->mu0 * rI) * att;
+  }
+  for (int j = 0; j < N; ++j)
+    for (int i = 0; i < N; ++i) r_mp[IDX(i, j, N)] = Rs[IDX(i, j, N)] * (q->mu[j] * q->wt[j]);
+}
+
+/* create_surface_layer!(::LambertianSurfaceLegendre) lambertian_surface.jl:77-138: albedo = P * legendre_coeff per
+ * spectral point (host); m = 0: j0+ = 0 (:112), j0- = mu0 (R_surf I0N) (rho e^{-tau/mu0}) (:114); m > 0: everything 0
+ * INCLUDING t++ and t-- (:127-134). */
+static void surface_legendre_pt(const ora_streams *q, int m, double albedo, double tau_tot, double *r_pm, double *r_mp,
+                                double *t_mm, double *t_pp, double *j0p, double *j0m) {
+  const int N = q->N, n = q->nS;
+  const size_t NN = (size_t)N * N;
+  for (size_t x = 0; x < NN; ++x) { t_pp[x] = 0; t_mm[x] = 0; r_mp[x] = 0; }
+  for (int i = 0; i < N; ++i) { j0p[i] = 0; j0m[i] = 0; }
+  if (m != 0) return; /* r+- is not touched for m > 0 (it still holds the m = 0 zeros) */
+  const double rho = 2 * albedo, att = exp(-tau_tot / q->mu0);
+  for (size_t x = 0; x < NN; ++x) r_pm[x] = 0;
+  for (int i = 0; i < N; ++i) { t_pp[IDX(i, i, N)] = 1.0; t_mm[IDX(i, i, N)] = 1.0; }
+  for (int i = 0; i < N; ++i) j0m[i] = (i % n == 0) ? (q->mu0 * q->I0[0]) * (rho * att) : 0.0;
+  for (int j = 0; j < N; ++j)
+    for (int i = 0; i < N; ++i)
+      r_mp[IDX(i, j, N)] = ((i % n == 0) && (j % n == 0)) ? rho * (q->mu[j] * q->wt[j]) : 0.0;
+}
+
 /* ---------------------------------------------------------------- batched op-level API */
 
 void ora_elemental(int N, int nS, int S, int m, int nd, int imu0, const double *mu, const double *wt,
@@ -510,6 +551,9 @@ typedef struct {
   const int *node;        /* [nVza] 1-based stream index nearest to vza  */
   const double *cos_mphi; /* [nVza,M] cosd(m*vaz): cos_mphi[v + nVza*m]  */
   const double *sin_mphi; /* [nVza,M]                                    */
+  int surf_kind;          /* 0 LambertianSurfaceScalar(albedo), 1 BRDF matrices, 2 LambertianSurfaceLegendre */
+  const double *Rsurf;    /* kind 1: [N,N,M] rho_m, x2 for m = 0 included  */
+  const double *albedo_spec; /* kind 2: [S]                                */
 } ora_scene;
 
 /* R_SFI,T_SFI: [nVza,nStokes,S] column-major, zero-initialised by the caller.
@@ -578,8 +622,14 @@ int ora_rt_run_full(const ora_scene *sc, const int *pts, int npts, int nthreads,
           }
         }
         /* surface: rt_run.jl:169-185 (interface code of the LAST layer, Q6) */
-        surface_lambertian_pt(&q, m, sc->albedo, sc->tau_sum[s + (size_t)S * Nz], s_rpm, a_rmp, a_tmm, a_tpp, a_j0p,
-                              a_j0m);
+        if (sc->surf_kind == 1)
+          surface_brdf_pt(&q, sc->Rsurf + NN * m, sc->tau_sum[s + (size_t)S * Nz], s_rpm, a_rmp, a_tmm, a_tpp, a_j0p, a_j0m);
+        else if (sc->surf_kind == 2)
+          surface_legendre_pt(&q, m, sc->albedo_spec[s], sc->tau_sum[s + (size_t)S * Nz], s_rpm, a_rmp, a_tmm, a_tpp,
+                              a_j0p, a_j0m);
+        else
+          surface_lambertian_pt(&q, m, sc->albedo, sc->tau_sum[s + (size_t)S * Nz], s_rpm, a_rmp, a_tmm, a_tpp, a_j0p,
+                                a_j0m);
         int e3 = interaction_pt(N, sc->iface[Nz - 1], c_Rmp, c_Rpm, c_Tpp, c_Tmm, c_J0p, c_J0m, s_rpm, a_rmp, a_tmm,
                                 a_tpp, a_j0p, a_j0m, work, piv);
         if (e3) {

@@ -438,6 +438,8 @@ class Scene:
     vza: np.ndarray = field(default_factory=lambda: np.zeros(0))
     vaz: np.ndarray = field(default_factory=lambda: np.zeros(0))
     strict_reference_indexing: bool = True
+    brdf: Optional[tuple] = None  # None = LambertianSurfaceScalar(albedo); ("rpv", rho0, rho_c, k, Theta);
+    #                               ("rossli", fvol, fgeo, fiso); ("legendre", c0, c1, ...)
 
     @property
     def S(self):
@@ -822,6 +824,111 @@ def create_surface_layer_lambertian(albedo: float, added: AddedLayer, m: int, po
         added.j0m[:] = 0
 
 
+def brdf_value(brdf: tuple, mu_i: float, mu_r: float, dphi: float) -> float:
+    """reflectance(brdf, n = 1, mu_i, mu_r, dphi): rpv_surface.jl:69-95 (Rahman-Pinty-Verstraete, the signs of the
+    reference's vSmartMOM convention) and rossli_surface.jl:1-56 (Ross-thick + Li-sparse, h/b = 2, b/r = 1)."""
+    if brdf[0] == "rpv":
+        _, rho0, rho_c, k, Theta = brdf
+        ti, tr = math.acos(mu_i), math.acos(mu_r)
+        cosg = -mu_i * mu_r + math.sin(ti) * math.sin(tr) * math.cos(dphi)
+        G = (math.tan(ti) ** 2 + math.tan(tr) ** 2 + 2 * math.tan(ti) * math.tan(tr) * math.cos(dphi)) ** 0.5
+        Mf = (mu_i * mu_r) ** (k - 1) / (mu_i + mu_r) ** (1 - k)
+        th = -Theta
+        F = (1 - th ** 2) / (1 + th ** 2 + 2 * th * cosg) ** 1.5
+        H = 1 + (1 - rho_c) / (1 + G)
+        return rho0 * Mf * F * H
+    if brdf[0] == "rossli":
+        _, fvol, fgeo, fiso = brdf
+        dphi = math.pi - dphi
+        ti, tr = math.acos(mu_i), math.acos(mu_r)
+        clip = lambda v: max(-1.0, min(1.0, v))
+        xi = math.acos(clip(math.cos(ti) * math.cos(tr) + math.sin(ti) * math.sin(tr) * math.cos(dphi)))
+        K_vol = ((math.pi / 2 - xi) * math.cos(xi) + math.sin(xi)) / (math.cos(ti) + math.cos(tr)) - math.pi / 4
+        tip, trp = math.atan(math.tan(ti) * 1.0), math.atan(math.tan(tr) * 1.0)
+        xip = math.acos(clip(math.cos(tip) * math.cos(trp) + math.sin(tip) * math.sin(trp) * math.cos(dphi)))
+        D2 = math.tan(tip) ** 2 + math.tan(trp) ** 2 - 2 * math.tan(tip) * math.tan(trp) * math.cos(dphi)
+        D = math.sqrt(max(D2, 0.0)) if D2 > -1e-300 else float("nan")
+        sec_sum = 1 / math.cos(tip) + 1 / math.cos(trp)
+        ct = 2.0 * math.sqrt(D ** 2 + (math.tan(tip) * math.tan(trp) * math.sin(dphi)) ** 2) / sec_sum
+        t = math.acos(clip(ct))
+        O = (1 / math.pi) * (t - math.sin(t) * math.cos(t)) * sec_sum
+        K_geo = O - sec_sum + 0.5 * (1 + math.cos(xip)) / (math.cos(tip) * math.cos(trp))
+        return fiso * 1.0 + fvol * K_vol + fgeo * K_geo
+    raise ValueError(brdf[0])
+
+
+def brdf_fourier_moment(brdf: tuple, n: int, mu: np.ndarray, m: int, nquad: int = 100) -> np.ndarray:
+    """reflectance(brdf, pol_type, mu, m) (rpv_surface.jl:104-134): (1/pi) sum_q w_q rho(mu_i, mu_j, phi_q) cos(m phi_q)
+    on a 100-point Gauss-Legendre rule over [0, pi], placed on the I component of every stream pair, times 1 (m = 0)
+    or 2 (m > 0)."""
+    x, w = np.polynomial.legendre.leggauss(nquad)
+    phi, w = 0.5 * math.pi * (x + 1.0), 0.5 * math.pi * w
+    nmu = len(mu)
+    R = np.zeros((n * nmu, n * nmu))
+    for i in range(nmu):
+        for j in range(nmu):
+            acc = 0.0
+            for q in range(nquad):
+                acc += w[q] * (brdf_value(brdf, float(mu[i]), float(mu[j]), float(phi[q])) * math.cos(m * phi[q]))
+            R[i * n, j * n] = acc / math.pi
+    return (1.0 if m == 0 else 2.0) * R
+
+
+def surface_inputs(scene: "Scene"):
+    """(kind, Rsurf [M,N,N] | None, albedo_spec [S] | None) of the scene's surface type."""
+    b = scene.brdf
+    if b is None:
+        return 0, None, None
+    if b[0] == "legendre":
+        coef = np.asarray(b[1:], dtype=np.float64)
+        x = np.linspace(-1.0, 1.0, scene.S)
+        P = np.polynomial.legendre.legvander(x, len(coef) - 1)  # P_0 .. P_{n-1}
+        return 2, None, P @ coef
+    Rs = np.array([(2.0 if m == 0 else 1.0) * brdf_fourier_moment(b, scene.pol.n, scene.quad.qp_mu, m)
+                   for m in range(scene.max_m)])
+    return 1, Rs, None
+
+
+def create_surface_layer(scene: "Scene", sinp, added: AddedLayer, m: int, tau_sum: np.ndarray):
+    """Dispatch of create_surface_layer! on the surface type: LambertianSurfaceScalar (lambertian_surface.jl:20-75),
+    LambertianSurfaceLegendre (:77-138), any BRDF type (rpv_surface.jl:20-66)."""
+    pol, quad = scene.pol, scene.quad
+    kind, Rs, alb = sinp
+    if kind == 0:
+        return create_surface_layer_lambertian(scene.albedo, added, m, pol, quad, tau_sum)
+    N, n = len(quad.qp_muN), pol.n
+    I0N = np.zeros(N)
+    I0N[quad.imu0Nstart - 1: n * quad.imu0] = pol.I0
+    att = np.exp(-tau_sum / quad.mu0)
+    if kind == 1:
+        R_surf = Rs[m]
+        added.j0p[:] = I0N[None, :] * att[:, None]
+        added.j0m[:] = (quad.mu0 * (R_surf @ I0N))[None, :] * att[:, None]
+        added.r_mp[:] = (R_surf @ np.diag(quad.qp_muN * quad.wt_muN))[None]
+        added.r_pm[:] = 0
+        added.t_pp[:] = np.eye(N)[None]
+        added.t_mm[:] = np.eye(N)[None]
+        return
+    # LambertianSurfaceLegendre
+    if m == 0:
+        rho = 2 * alb
+        blk = np.zeros((n, n))
+        blk[0, 0] = 1.0
+        R_surf = np.tile(blk, (N // n, N // n))
+        added.j0p[:] = 0
+        added.j0m[:] = (quad.mu0 * (R_surf @ I0N))[None, :] * (rho * att)[:, None]
+        added.r_mp[:] = rho[:, None, None] * (R_surf @ np.diag(quad.qp_muN * quad.wt_muN))[None]
+        added.r_pm[:] = 0
+        added.t_pp[:] = np.eye(N)[None]
+        added.t_mm[:] = np.eye(N)[None]
+    else:
+        added.r_mp[:] = 0
+        added.t_pp[:] = 0
+        added.t_mm[:] = 0
+        added.j0p[:] = 0
+        added.j0m[:] = 0
+
+
 def postprocessing_vza(pol: PolType, comp: CompositeLayer, vza, qp_mu, m: int, vaz, weight: float,
                        R_SFI: np.ndarray, T_SFI: np.ndarray):
     """postprocessing_vza!(::noRS) postprocessing_vza.jl:9-60 (SFI branch).
@@ -891,13 +998,14 @@ def rt_run_full(scene: Scene, hook=None):
     surf = make_added_layer(N, S)
     comp = make_composite_layer(N, S)
     strict = scene.strict_reference_indexing
+    sinp = surface_inputs(scene)
     for m in range(scene.max_m):
         weight = 0.5 if m == 0 else 1.0
         layers = construct_core_optical_properties(scene, m)
         ifaces, tau_sum_all = extract_effective_props(layers)
         for iz in range(Nz):
             rt_kernel(pol, quad, added, comp, layers[iz], ifaces[iz], tau_sum_all[:, iz], m, iz + 1, strict, hook)
-        create_surface_layer_lambertian(scene.albedo, surf, m, pol, quad, tau_sum_all[:, -1])
+        create_surface_layer(scene, sinp, surf, m, tau_sum_all[:, -1])
         interaction(ifaces[-1], comp, surf)
         hdr_J0m = interaction_hdrf(surf, comp, m, pol, quad, bhr_uw, bhr_dw)
         postprocessing_vza(pol, comp, scene.vza, quad.qp_mu, m, scene.vaz, weight, R_SFI, T_SFI)
@@ -918,13 +1026,14 @@ def rt_run(scene: Scene, hook=None):
     surf = make_added_layer(N, S)
     comp = make_composite_layer(N, S)
     strict = scene.strict_reference_indexing
+    sinp = surface_inputs(scene)
     for m in range(scene.max_m):
         weight = 0.5 if m == 0 else 1.0
         layers = construct_core_optical_properties(scene, m)
         ifaces, tau_sum_all = extract_effective_props(layers)
         for iz in range(Nz):
             rt_kernel(pol, quad, added, comp, layers[iz], ifaces[iz], tau_sum_all[:, iz], m, iz + 1, strict, hook)
-        create_surface_layer_lambertian(scene.albedo, surf, m, pol, quad, tau_sum_all[:, -1])
+        create_surface_layer(scene, sinp, surf, m, tau_sum_all[:, -1])
         interaction(ifaces[-1], comp, surf)  # Q6: last layer's interface code
         if hook:
             hook("surface", m, Nz + 1, surf, comp)

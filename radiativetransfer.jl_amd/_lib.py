@@ -64,6 +64,7 @@ SIGNATURES = {
     "mom_scene_set_optics": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_dp, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp,
                                        C.c_double, C.c_int, c_ip, c_dp, c_dp]),
     "mom_scene_get_layers": (C.c_int, [c_h, c_ip, c_ip, c_dp, c_dp, c_dp, c_dp]),
+    "mom_scene_set_surface": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp]),
     "mom_rt_run": (C.c_int, [c_h]),
     "mom_get_RT": (C.c_int, [c_h, c_dp, c_dp]),
     "mom_get_hdr": (C.c_int, [c_h, c_dp, c_dp, c_dp]),
@@ -265,6 +266,13 @@ class Handle:
         bufs = [np.empty(S * Nz), np.empty(S * Nz), np.empty(K * S * Nz), np.empty(S * (Nz + 1))] if arrays else [None] * 4
         self.check(self.lib.mom_scene_get_layers(self._h, ip(nd), ip(iface), *[dp(b) if b is not None else None for b in bufs]))
         return (nd, iface) + tuple(bufs)
+
+    def scene_set_surface(self, kind, M=0, Rsurf=None, albedo_spec=None):
+        """Rsurf: already in ABI order ([N, N, M], i fastest); albedo_spec: [S]."""
+        r = f64(Rsurf).reshape(-1) if Rsurf is not None else None
+        al = f64(albedo_spec).reshape(-1) if albedo_spec is not None else None
+        self.check(self.lib.mom_scene_set_surface(self._h, int(kind), int(M), dp(r) if r is not None else None,
+                                                  dp(al) if al is not None else None))
 
     def rt_run(self):
         self.check(self.lib.mom_rt_run(self._h))

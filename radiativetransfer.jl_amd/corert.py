@@ -361,6 +361,117 @@ def compute_Z_moments(pol_type: PolarizationType, μ: np.ndarray, greek: GreekCo
 
 
 # ------------------------------------------------------------------------------------------
+# Surface types (types.jl:300-344) and their Fourier-moment reflectance matrices
+# ------------------------------------------------------------------------------------------
+
+
+@dataclass(frozen=True)
+class LambertianSurfaceScalar:
+    albedo: float
+
+
+@dataclass(frozen=True)
+class LambertianSurfaceLegendre:
+    """albedo(ν) = Σ legendre_coeff[k] P_k(x), x = linspace(-1, 1, nSpec) (lambertian_surface.jl:90-96)"""
+    legendre_coeff: tuple
+
+
+@dataclass(frozen=True)
+class rpvSurfaceScalar:
+    """Rahman-Pinty-Verstraete (types.jl:320-329)"""
+    ρ0: float
+    ρ_c: float
+    k: float
+    Θ: float
+
+
+@dataclass(frozen=True)
+class RossLiSurfaceScalar:
+    """Ross-thick / Li-sparse kernels (types.jl:331-338)"""
+    fvol: float
+    fgeo: float
+    fiso: float
+
+
+def gauleg(n: int, a: float, b: float):
+    """Gauss-Legendre nodes/weights on [a, b] (CanopyOptics.gauleg as used at rpv_surface.jl:116)."""
+    x, w = np.polynomial.legendre.leggauss(n)
+    return 0.5 * (b - a) * x + 0.5 * (b + a), 0.5 * (b - a) * w
+
+
+def _brdf_scalar(brdf, μi: np.ndarray, μr: np.ndarray, dϕ: float) -> np.ndarray:
+    """reflectance(brdf, n = 1, μᵢ, μᵣ, dϕ) broadcast over μᵢ (rows) x μᵣ (columns)."""
+    if isinstance(brdf, rpvSurfaceScalar):  # rpv_surface.jl:69-95
+        θi, θr = np.arccos(μi), np.arccos(μr)
+        cosg = -μi * μr + np.sin(θi) * np.sin(θr) * math.cos(dϕ)
+        G = (np.tan(θi) ** 2 + np.tan(θr) ** 2 + 2 * np.tan(θi) * np.tan(θr) * math.cos(dϕ)) ** 0.5
+        Mf = (μi * μr) ** (brdf.k - 1) / (μi + μr) ** (1 - brdf.k)
+        θ = -brdf.Θ
+        F = (1 - θ ** 2) / (1 + θ ** 2 + 2 * θ * cosg) ** 1.5
+        H = 1 + (1 - brdf.ρ_c) / (1 + G)
+        return brdf.ρ0 * Mf * F * H
+    if isinstance(brdf, RossLiSurfaceScalar):  # rossli_surface.jl:1-56
+        dϕ = math.pi - dϕ
+        θi, θr = np.arccos(μi), np.arccos(μr)
+        ξ = np.arccos(np.cos(θi) * np.cos(θr) + np.sin(θi) * np.sin(θr) * math.cos(dϕ))
+        K_vol = ((math.pi / 2 - ξ) * np.cos(ξ) + np.sin(ξ)) / (np.cos(θi) + np.cos(θr)) - (math.pi / 4)
+        h_by_b, b_by_r = 2.0, 1.0
+        θip, θrp = np.arctan(np.tan(θi) * b_by_r), np.arctan(np.tan(θr) * b_by_r)
+        ξp = np.arccos(np.cos(θip) * np.cos(θrp) + np.sin(θip) * np.sin(θrp) * math.cos(dϕ))
+        D = np.sqrt(np.tan(θip) ** 2 + np.tan(θrp) ** 2 - 2 * np.tan(θip) * np.tan(θrp) * math.cos(dϕ))
+        sec = lambda a: 1.0 / np.cos(a)
+        ct = h_by_b * np.sqrt(D ** 2 + (np.tan(θip) * np.tan(θrp) * math.sin(dϕ)) ** 2) / (sec(θip) + sec(θrp))
+        ct = np.clip(ct, -1.0, 1.0)
+        t = np.arccos(ct)
+        O = (1 / math.pi) * (t - np.sin(t) * np.cos(t)) * (sec(θip) + sec(θrp))
+        K_geo = O - (sec(θip) + sec(θrp)) + 0.5 * (1 + np.cos(ξp)) * sec(θip) * sec(θrp)
+        return brdf.fiso * 1.0 + brdf.fvol * K_vol + brdf.fgeo * K_geo
+    raise TypeError(f"no reflectance() for {type(brdf).__name__}")
+
+
+def reflectance(brdf, pol_type: PolarizationType, μ: np.ndarray, m: int, nQuad: int = 100) -> np.ndarray:
+    """reflectance(brdf, pol_type, μ, m) (rpv_surface.jl:104-134): Fourier moment m of the BRDF on the quadrature
+    streams, (1/π) ∫₀^π ρ(μᵢ, μⱼ, φ) cos(mφ) dφ by nQuad-point Gauss-Legendre, expanded to the Stokes layout (only the
+    I component is populated by the scalar BRDF types), times 1 (m = 0) or 2 (m > 0)."""
+    μ = np.asarray(μ, dtype=np.float64)
+    n, nμ = pol_type.n, μ.size
+    R = np.zeros((n * nμ, n * nμ))
+    ff = 1.0 if m == 0 else 2.0
+    ϕ, w = gauleg(nQuad, 0.0, math.pi)
+    c = np.zeros((nμ, nμ))
+    for ϕi, wi in zip(ϕ, w):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            c += wi * (_brdf_scalar(brdf, μ[:, None], μ[None, :], float(ϕi)) * math.cos(m * ϕi))
+    R[0::n, 0::n] = c / math.pi
+    return ff * R
+
+
+def compute_legendre_poly(x: np.ndarray, nmax: int) -> np.ndarray:
+    """Scattering.compute_legendre_poly(x, nmax)[1]: P_0 .. P_{nmax-1} at x, shape [len(x), nmax]."""
+    x = np.asarray(x, dtype=np.float64)
+    P = np.zeros((x.size, nmax))
+    P[:, 0] = 1.0
+    if nmax > 1:
+        P[:, 1] = x
+    for l in range(2, nmax):
+        P[:, l] = ((2 * l - 1) * x * P[:, l - 1] - (l - 1) * P[:, l - 2]) / l
+    return P
+
+
+def surface_inputs(brdf, pol_type: PolarizationType, qp_μ: np.ndarray, max_m: int, nSpec: int):
+    """What mom_scene_set_surface needs for a surface type: (kind, Rsurf [M, N, N] or None, albedo_spec [nSpec] or None).
+    create_surface_layer! multiplies the m = 0 BRDF moment by 2 (rpv_surface.jl:39-43)."""
+    if isinstance(brdf, LambertianSurfaceScalar):
+        return 0, None, None
+    if isinstance(brdf, LambertianSurfaceLegendre):
+        x = np.linspace(-1.0, 1.0, nSpec)
+        coef = np.asarray(brdf.legendre_coeff, dtype=np.float64)
+        return 2, None, compute_legendre_poly(x, coef.size) @ coef
+    Rs = np.array([(2.0 if m == 0 else 1.0) * reflectance(brdf, pol_type, qp_μ, m) for m in range(max_m)])
+    return 1, Rs, None
+
+
+# ------------------------------------------------------------------------------------------
 # model containers
 # ------------------------------------------------------------------------------------------
 
@@ -385,6 +496,7 @@ class vSmartMOM_Parameters:
     vza: np.ndarray
     vaz: np.ndarray
     brdf_albedo: float = 0.0  # LambertianSurfaceScalar(albedo)
+    brdf: Optional[object] = None  # any surface type above; None = LambertianSurfaceScalar(brdf_albedo)
     architecture: AbstractArchitecture = field(default_factory=default_architecture)
     strict_reference_indexing: bool = True
 
@@ -551,6 +663,9 @@ class SceneInputs:
     node: np.ndarray
     cos_mphi: np.ndarray
     sin_mphi: np.ndarray
+    surf_kind: int = 0
+    Rsurf: Optional[np.ndarray] = None        # ABI order [N, N, M]
+    albedo_spec: Optional[np.ndarray] = None  # [S]
 
     def spectral_slice(self, lo: int, hi: int) -> "SceneInputs":
         """Shard [lo, hi) of the spectral axis.  ndoubl / iface stay the GLOBAL ones
@@ -563,7 +678,8 @@ class SceneInputs:
                            np.ascontiguousarray(self.zw.reshape(Nz, S, K)[:, sl, :]).reshape(-1),
                            self.Zpp, self.Zmp, self.ndoubl, self.iface,
                            np.ascontiguousarray(self.tau_sum.reshape(Nz + 1, S)[:, sl]).reshape(-1),
-                           self.albedo, self.node, self.cos_mphi, self.sin_mphi)
+                           self.albedo, self.node, self.cos_mphi, self.sin_mphi, self.surf_kind, self.Rsurf,
+                           None if self.albedo_spec is None else np.ascontiguousarray(self.albedo_spec[sl]))
 
 
 def prepare_scene(model: vSmartMOM_Model) -> SceneInputs:
@@ -575,12 +691,16 @@ def prepare_scene(model: vSmartMOM_Model) -> SceneInputs:
     S, Nz = L.τ.shape
     cm = np.array([[cosd(m * a) for a in p.vaz] for m in range(M)])
     sm = np.array([[sind(m * a) for a in p.vaz] for m in range(M)])
+    brdf = p.brdf if p.brdf is not None else LambertianSurfaceScalar(float(p.brdf_albedo))
+    kind, Rs, alb = surface_inputs(brdf, p.polarization_type, qp.qp_μ, M, S)
     return SceneInputs(
+        surf_kind=kind, Rsurf=None if Rs is None else _abi_mats(Rs), albedo_spec=alb,
         N=len(qp.qp_μN), nStokes=p.polarization_type.n, S=S, Nz=Nz, K=L.zw.shape[0], M=M,
         tau=np.ascontiguousarray(L.τ.T).reshape(-1), varpi=np.ascontiguousarray(L.ϖ.T).reshape(-1),
         zw=np.ascontiguousarray(L.zw.transpose(2, 1, 0)).reshape(-1),  # [z][n][k]
         Zpp=_abi_mats(Zpp), Zmp=_abi_mats(Zmp), ndoubl=L.ndoubl, iface=L.iface,
-        tau_sum=np.ascontiguousarray(L.τ_sum.T).reshape(-1), albedo=float(p.brdf_albedo), node=view_nodes(model),
+        tau_sum=np.ascontiguousarray(L.τ_sum.T).reshape(-1),
+        albedo=float(brdf.albedo) if isinstance(brdf, LambertianSurfaceScalar) else 0.0, node=view_nodes(model),
         cos_mphi=cm.reshape(-1), sin_mphi=sm.reshape(-1))
 
 
@@ -598,6 +718,8 @@ def make_handle(model: vSmartMOM_Model, S: Optional[int] = None) -> _lib.Handle:
 def run_scene(h: _lib.Handle, sc: SceneInputs):
     h.scene_set(sc.Nz, sc.K, sc.M, sc.tau, sc.varpi, sc.zw, sc.Zpp, sc.Zmp, sc.ndoubl, sc.iface, sc.tau_sum,
                 sc.albedo, sc.node, sc.cos_mphi, sc.sin_mphi)
+    if sc.surf_kind != 0:
+        h.scene_set_surface(sc.surf_kind, sc.M, sc.Rsurf, sc.albedo_spec)
     h.rt_run()
     return h.get_RT()
 

@@ -29,6 +29,8 @@ namespace MOM_NS {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+extern __shared__ double mom_smem[];  // the workgroup's dynamic LDS image (carved by make_ctx)
+
 #ifndef MOM_WAVES
 #define MOM_WAVES 8
 #endif
@@ -224,18 +226,36 @@ __device__ __forceinline__ void wg_gemm_n(int N, int NC, FAs A, FB B, FE epi) {
   }
 }
 
-template <bool SYNC, class FA, class FB, class FE>
+// Large operators (generic mode, N > 64): operands streamed through LDS in k panels, see wg_gemm_big in mom_kernels.hpp.
+// BIG is true only in the generic-mode (LDSM = false) instantiations, so the LDS-resident kernels carry none of it.
+template <class FA, class FB, class FE>
+__device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi);
+
+template <bool SYNC, bool BIG = false, class FA, class FB, class FE>
 __device__ __forceinline__ void wg_gemm_nc(int N, int NC, FA A, FB B, FE epi) {
+  if constexpr (BIG && !SYNC && kWaves == 8) {
+    if (N > 64 && N <= 256) {
+      wg_gemm_big(N, NC, A, B, epi);
+      return;
+    }
+  }
   wg_gemm_n<1, SYNC, lds_operand<FA>::value && lds_operand<FB>::value>(
       N, NC, One<FA>{A}, B, [=](int, int i, int j, double v) { epi(i, j, v); });
 }
-template <bool SYNC, class FA, class FB, class FE>
+template <bool SYNC, bool BIG = false, class FA, class FB, class FE>
 __device__ __forceinline__ void wg_gemm(int N, FA A, FB B, FE epi) {
-  wg_gemm_nc<SYNC>(N, N, A, B, epi);
+  wg_gemm_nc<SYNC, BIG>(N, N, A, B, epi);
 }
 // Two products sharing the B operand: C1 = A1*B, C2 = A2*B (r += (A r) t and t = A t).
-template <bool SYNC, class FA1, class FA2, class FB, class FE1, class FE2>
+template <bool SYNC, bool BIG = false, class FA1, class FA2, class FB, class FE1, class FE2>
 __device__ __forceinline__ void wg_gemm2(int N, FA1 A1, FA2 A2, FB B, FE1 epi1, FE2 epi2) {
+  if constexpr (BIG && !SYNC && kWaves == 8) {
+    if (N > 64 && N <= 256) {  // two passes over B: the two accumulator sets of the shared-operand form do not fit next to 64 x 64 wave tiles
+      wg_gemm_big(N, N, A1, B, epi1);
+      wg_gemm_big(N, N, A2, B, epi2);
+      return;
+    }
+  }
   wg_gemm_n<2, SYNC, lds_operand<FA1>::value && lds_operand<FA2>::value && lds_operand<FB>::value>(
       N, N, Two<FA1, FA2>{A1, A2}, B,
       [=](int u, int i, int j, double v) { if (u == 0) epi1(i, j, v); else epi2(i, j, v); });

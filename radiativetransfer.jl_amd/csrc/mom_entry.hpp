@@ -43,7 +43,6 @@ __device__ __forceinline__ CompPtrs comp_ptrs(double *const comp[6], int N, int 
   return g;
 }
 
-extern __shared__ double mom_smem[];
 
 // One launch per atmospheric layer: every (spectral point, Fourier moment) pair runs
 // elemental -> nd doublings -> interaction with its composite state (rt_kernel!,
@@ -105,17 +104,23 @@ struct SurfArgs {
   int S, iface;
   double albedo;
   const double *tau_tot;  // [S]
-  double *comp[6];        // moment-0 slices
-  double *hdrJ;           // [N,S]   hdr_J0- of interaction_hdrf! (m = 0)
-  double *bhr_uw, *bhr_dw;  // [nS_out,S] (nS_out = the caller's nStokes; rows >= q.nS stay zero)
+  double *comp[6];        // slices of THIS moment
+  double *hdrJ;           // [N,S]   hdr_J0- of interaction_hdrf! for this moment
+  double *bhr_uw, *bhr_dw;  // [nS_out,S] (nS_out = the caller's nStokes; rows >= q.nS stay zero); written for m = 0
   int nS_out;
   double *scratch;
   int *info;
+  // surface type (include/momcore.h, mom_scene_set_surface): 0 = LambertianSurfaceScalar, 1 = BRDF matrix of this
+  // moment (rpv / Ross-Li ...: create_surface_layer!(::AbstractSurfaceType), rpv_surface.jl:20-66), 2 =
+  // LambertianSurfaceLegendre (spectrally varying albedo, lambertian_surface.jl:77-138)
+  int kind, m;
+  const double *Rsurf;        // kind 1: [N,N] rho_m (column-major), factor 2 for m = 0 included
+  const double *albedo_spec;  // kind 2: [S]
 };
 
-// Lambertian surface as an added layer (m = 0) + the closing interaction (rt_run.jl:169-185).
-// For m > 0 the surface layer is r = 0, t = I, j = 0 and the interaction is the identity on
-// every quantity post-processing reads, so no launch is made for those moments.
+// The surface as an added layer + the closing interaction (rt_run.jl:169-185), then interaction_hdrf!.
+// LambertianSurfaceScalar/Legendre: m = 0 only (for m > 0 the surface layer is r = 0, j = 0 and the interaction is the
+// identity on everything post-processing reads, so no launch is made); BRDF surfaces: one launch per moment.
 template <bool LDSM>
 __global__ void __launch_bounds__(kThreads, 2) k_surface(SurfArgs a) {
   const int N = a.q.N, n = a.q.nS;
@@ -123,19 +128,42 @@ __global__ void __launch_bounds__(kThreads, 2) k_surface(SurfArgs a) {
   wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
   const int ld = c.ld;
   for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
-    const double rho = 2 * a.albedo;                       // lambertian_surface.jl:37
     const double att = exp(-a.tau_tot[pt] / a.q.mu0);
     const int i_start = n * (a.q.imu0 - 1), i_end = n * a.q.imu0;
-    for (int e = wg_tid(); e < N * N; e += kThreads) {
-      int i, j;
-      c.fd.split(e, i, j);
-      c.r[i + j * ld] = ((i % n == 0) && (j % n == 0)) ? rho * (c.mu[j] * c.wt[j]) : 0.0;  // :41-43,:58
-      c.t[i + j * ld] = (i == j) ? 1.0 : 0.0;
-    }
-    for (int i = wg_tid(); i < N; i += kThreads) {
-      const bool in_sun = (i >= i_start) && (i < i_end);
-      c.jp[i] = (in_sun ? a.q.I0[i - i_start] : 0.0) * att;                 // :55
-      c.jm[i] = (i % n == 0) ? (a.q.mu0 * (rho * a.q.I0[0])) * att : 0.0;  // :56
+    if (a.kind == 1) {
+      // R_surf = rho_m ; j0+ = I0 exp(-tau/mu0) at the sun rows ; j0- = mu0 (R_surf I0N) exp(-tau/mu0) ;
+      // r-+ = R_surf Diagonal(qp_muN .* wt_muN)                                   (rpv_surface.jl:48-62)
+      for (int e = wg_tid(); e < N * N; e += kThreads) {
+        int i, j;
+        c.fd.split(e, i, j);
+        c.r[i + j * ld] = a.Rsurf[i + (size_t)N * j] * (c.mu[j] * c.wt[j]);
+        c.t[i + j * ld] = (i == j) ? 1.0 : 0.0;
+      }
+      for (int i = wg_tid(); i < N; i += kThreads) {
+        const bool in_sun = (i >= i_start) && (i < i_end);
+        double rI = 0.0;
+        for (int k = 0; k < n; ++k) rI += a.Rsurf[i + (size_t)N * (i_start + k)] * a.q.I0[k];
+        c.jp[i] = (in_sun ? a.q.I0[i - i_start] : 0.0) * att;
+        c.jm[i] = (a.q.mu0 * rI) * att;
+      }
+    } else {
+      const double rho = 2 * ((a.kind == 2) ? a.albedo_spec[pt] : a.albedo);  // lambertian_surface.jl:37 / :97
+      for (int e = wg_tid(); e < N * N; e += kThreads) {
+        int i, j;
+        c.fd.split(e, i, j);
+        c.r[i + j * ld] = ((i % n == 0) && (j % n == 0)) ? rho * (c.mu[j] * c.wt[j]) : 0.0;  // :41-43,:58
+        c.t[i + j * ld] = (i == j) ? 1.0 : 0.0;
+      }
+      for (int i = wg_tid(); i < N; i += kThreads) {
+        const bool in_sun = (i >= i_start) && (i < i_end);
+        if (a.kind == 2) {
+          c.jp[i] = 0.0;                                                              // :112 (the Legendre type sets j0+ = 0)
+          c.jm[i] = (i % n == 0) ? (a.q.mu0 * a.q.I0[0]) * (rho * att) : 0.0;         // :114
+        } else {
+          c.jp[i] = (in_sun ? a.q.I0[i - i_start] : 0.0) * att;                 // :55
+          c.jm[i] = (i % n == 0) ? (a.q.mu0 * (rho * a.q.I0[0])) * att : 0.0;  // :56
+        }
+      }
     }
     __syncthreads();
     CompPtrs g = comp_ptrs(a.comp, N, comp_pitch(N), pt);
@@ -149,7 +177,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_surface(SurfArgs a) {
       a.hdrJ[(size_t)N * pt + i] = hj;
     }
     __syncthreads();
-    if (wg_tid() < a.nS_out) {
+    if (a.m == 0 && wg_tid() < a.nS_out) {
       const int k = wg_tid();
       double up = 0.0, dw = 0.0;
       if (k < n)  // components beyond the reduced problem's (I,Q) have exactly zero sums for m = 0

@@ -83,9 +83,21 @@ __host__ __device__ inline int cols_for(int N) {
 __host__ __device__ inline size_t mat_elems(int N) { return (size_t)ld_for(N) * cols_for(N); }
 constexpr int kNumVec = 15 + 2 * kWaves;  // vectors carved from LDS (part = 2*kWaves vectors)
 constexpr int kGenericBufs = 5;
+// generic mode, N > 64: LDS staging tiles of wg_gemm_big behind the vectors: A panels [2][kBigKB][kBigLdA] and
+// B panels [2][256][kBigLdB] doubles
+constexpr int kBigKB = 8;      // k extent of a panel (2 MFMA k-steps)
+constexpr int kBigRows = 128;  // rows of the output block of one pass (2 x 4 waves of 64 x 64)
+constexpr int kBigLdA = 144;   // row pitch of an A panel: 128 + 16 (ds_read_b64 of 16 rows x 2 k conflict-free)
+constexpr int kBigLdB = 10;    // k pitch of a B-panel column: 8 + 2
+constexpr int kBigCols = 256;  // largest operator the tiles are sized for
+constexpr int kBigTileDoubles = 2 * kBigKB * kBigLdA + 2 * kBigCols * kBigLdB;
+__host__ __device__ inline size_t vec_area_doubles(int N) {
+  return (size_t)(kNumVec * np_for(N) + 32) + (size_t)((np_for(N) + 4 + 1) / 2);
+}
 __host__ __device__ inline size_t lds_bytes(int N, bool lds_mats) {
-  size_t b = (size_t)(kNumVec * np_for(N) + 32) * sizeof(double) + (size_t)(np_for(N) + 4) * sizeof(int);
+  size_t b = vec_area_doubles(N) * sizeof(double);
   if (lds_mats) b += 4 * mat_elems(N) * sizeof(double);
+  else if (N > 64) b += (size_t)kBigTileDoubles * sizeof(double);
   return b;
 }
 
@@ -217,7 +229,7 @@ __device__ __forceinline__ void gemm_to(Ctx &c, double *&dst, FA A, FB B, FV f) 
     wg_gemm<true>(N, A, B, [=](int i, int j, double v) { d[i + j * ld] = f(i, j, v, d[i + j * ld]); });
   } else {
     double *s = c.X;
-    wg_gemm<false>(N, A, B, [=](int i, int j, double v) { s[i + j * ld] = f(i, j, v, d[i + j * ld]); });
+    wg_gemm<false, !LDSM>(N, A, B, [=](int i, int j, double v) { s[i + j * ld] = f(i, j, v, d[i + j * ld]); });
     c.X = d;
     dst = s;
   }
@@ -272,6 +284,96 @@ struct CompPtrs {
 // quarters of them would straddle two cache lines (partial-line HBM writes).
 __host__ __device__ inline int comp_pitch(int N) { return 16 * ((N + 15) / 16); }
 
+// ---------------------------------------------------------------------------------------
+// C(i,j) <- epi(i, j, sum_k A(i,k) B(k,j)) for 64 < N <= 256 (generic mode): the operands live in global memory
+// (per-workgroup scratch slab or the composite layer); each k panel of 8 is staged once through LDS with coalesced
+// loads and feeds 8 waves x 4 x 4 MFMA tiles (64 x 64 outputs per wave, 128 x 256 per pass), double-buffered: the
+// loads of panel p+1 are in flight while panel p is multiplied, one barrier per panel.  Against the element-functor
+// loop of wg_gemm_n (every MFMA operand a separate 8-byte global load) this reads each operand element once per pass.
+// All threads must call; C must not alias A or B; ends WITHOUT a barrier after the epilogue (callers add theirs).
+// ---------------------------------------------------------------------------------------
+template <class FA, class FB, class FE>
+__device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
+  double *tA = mom_smem + vec_area_doubles(N);
+  double *tB = tA + 2 * kBigKB * kBigLdA;
+  const int tid = wg_tid(), lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int wr = (wave >> 2) & 1, wc = wave & 3;  // 2 x 4 wave grid (8-wave build only, see wg_gemm_nc)
+  const int Np = np_for(N);
+  const int P = (N + kBigKB - 1) / kBigKB;
+  // B panel element of this thread: 8 k x 256 columns = 2048 elements, 4 per thread; A panel: 128 rows x 8 k = 1024, 2 per thread
+  for (int row0 = 0; row0 < N; row0 += kBigRows) {
+    d4 acc[4][4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
+    double ra[2], rb[4];
+    auto fetch = [&](int p) {
+      const int k0 = p * kBigKB;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + kThreads * u, row = e & (kBigRows - 1), kk = e >> 7;
+        const int i = row0 + row, k = k0 + kk;
+        ra[u] = (i < N && k < N) ? A(i, k) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = tid + kThreads * u, kk = e & (kBigKB - 1), col = e >> 3;
+        const int k = k0 + kk;
+        rb[u] = (k < N && col < NC) ? B(k, col) : 0.0;
+      }
+    };
+    auto stash = [&](int stage) {
+      double *sa = tA + stage * kBigKB * kBigLdA, *sb = tB + stage * kBigCols * kBigLdB;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + kThreads * u, row = e & (kBigRows - 1), kk = e >> 7;
+        sa[row + kk * kBigLdA] = ra[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = tid + kThreads * u, kk = e & (kBigKB - 1), col = e >> 3;
+        sb[kk + col * kBigLdB] = rb[u];
+      }
+    };
+    __syncthreads();  // the previous pass (or the caller) is done with the tiles
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int p = 0; p < P; ++p) {
+      if (p + 1 < P) fetch(p + 1);
+      const double *sa = tA + (p & 1) * kBigKB * kBigLdA + 64 * wr + lr + lq * kBigLdA;
+      const double *sb = tB + (p & 1) * kBigCols * kBigLdB + lq + (64 * wc + lr) * kBigLdB;
+#pragma unroll
+      for (int ks = 0; ks < kBigKB / 4; ++ks) {
+        double a[4], b[4];
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) a[ti] = sa[16 * ti + 4 * ks * kBigLdA];
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) b[tj] = sb[4 * ks + 16 * tj * kBigLdB];
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < 4; ++tj)
+            if (64 * wc + 16 * tj < Np) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+      }
+      if (p + 1 < P) stash((p + 1) & 1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 4; ++tj) {
+        const int col = 64 * wc + 16 * tj + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rw = row0 + 64 * wr + 16 * ti + lq + 4 * r;
+          if (rw < N && col < NC) epi(rw, col, acc[ti][tj][r]);
+        }
+      }
+  }
+}
+
 }  // namespace MOM_NS
 #include "mom_strip.hpp"
 namespace MOM_NS {
@@ -296,7 +398,7 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob
       }
       __syncthreads();
     } else {
-      wg_gemm<false>(N, T, ElP{Bb, ld}, [=](int i, int j, double v) { o[i + j * ld] = T(i, j) + v; });
+      wg_gemm<false, !LDSM>(N, T, ElP{Bb, ld}, [=](int i, int j, double v) { o[i + j * ld] = T(i, j) + v; });
       __syncthreads();
       for (int k = 3; k <= p; ++k)
         gemm_to<LDSM>(c, Ob, ElP{Ob, ld}, ElP{Bb, ld}, [=](int i, int j, double v, double) { return T(i, j) + v; });
@@ -327,7 +429,7 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob
     __syncthreads();
     if (N <= 64) wg_inverse_reg(N, b, ld, c.part, c.prow, c.ipiv, c.bad);  // part: >= 128 doubles (2*kWaves*ldv)
     else wg_inverse(N, c.fd, b, ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);
-    wg_gemm<false>(N, T, ElP{b, ld}, [=](int i, int j, double v) { o[i + j * ld] = v; });
+    wg_gemm<false, !LDSM>(N, T, ElP{b, ld}, [=](int i, int j, double v) { o[i + j * ld] = v; });
     __syncthreads();
   }
 }
@@ -593,7 +695,7 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
       double ss = 0.0;
       MOM_STAMP(0);
       // P = r r (+ r j0+, r j0- riding) ; Q = t (I - r r)^-1  (tt⁺⁺_gp_refl)   (doubling.jl:44-48)
-      wg_gemm_nc<false>(N, ride ? N + 2 : N, ElP{r, ld}, ElP{r, ld}, [=, &ss](int i, int j, double v) {
+      wg_gemm_nc<false, !LDSM>(N, ride ? N + 2 : N, ElP{r, ld}, ElP{r, ld}, [=, &ss](int i, int j, double v) {
         P[i + j * ld] = v;
         if (j < N) ss += v * v;
       });
@@ -648,7 +750,7 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
     }
     MOM_STAMP(3);
     // P = Q r  (+ Q w1, Q w2 riding)
-    wg_gemm_nc<false>(N, ride ? N + 2 : N, ElP{Q, ld}, ElP{r, ld}, [=](int i, int j, double v) { P[i + j * ld] = v; });
+    wg_gemm_nc<false, !LDSM>(N, ride ? N + 2 : N, ElP{Q, ld}, ElP{r, ld}, [=](int i, int j, double v) { P[i + j * ld] = v; });
     __syncthreads();
     MOM_STAMP(4);
     if (ride) {
@@ -670,7 +772,7 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
                      [=](int i, int j, double v) { t[i + j * ld] = v; });
     } else {
       double *X = c.X;
-      wg_gemm2<false>(N, ElP{P, ld}, ElP{Q, ld}, ElP{t, ld},
+      wg_gemm2<false, !LDSM>(N, ElP{P, ld}, ElP{Q, ld}, ElP{t, ld},
                       [=](int i, int j, double v) { r[i + j * ld] = r[i + j * ld] + v; },
                       [=](int i, int j, double v) { X[i + j * ld] = v; });
       c.X = t;
@@ -733,8 +835,8 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     wg_copy_mat(N, c.fd, g.T_pp, cl, c.Q, ld);
     __syncthreads();
     gdouble *Tmm = g.T_mm, *Tpp = g.T_pp;
-    wg_gemm<false>(N, tmm, ElP{c.P, ld}, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
-    wg_gemm<false>(N, ElP{t, ld}, ElP{c.Q, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, tmm, ElP{c.P, ld}, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{c.Q, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
   } else if ((IFACE < 0 || IFACE == 1) && iface == 1) {
     wg_copy_mat(N, c.fd, g.T_mm, cl, c.P, ld);  // P = T--
     // J0- = J0- + T-- (r-+ J0+ + j0-) ; J0+ = j0+ + t++ J0+  (:36-37)
@@ -749,15 +851,15 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     }
     // R-+ = (T-- r-+) T++ ; R+- = r+- ; T++ = t++ T++ ; T-- = T-- t--   (:40-43)
     double *Q = c.Q, *P = c.P;
-    wg_gemm<false>(N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
     __syncthreads();
     gdouble *Rmp = g.R_mp, *Rpm = g.R_pm, *Tpp = g.T_pp, *Tmm = g.T_mm;
-    wg_gemm<false>(N, ElP{Q, ld}, El{g.T_pp, cl, N}, [=](int i, int j, double v) { Rmp[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{Q, ld}, El{g.T_pp, cl, N}, [=](int i, int j, double v) { Rmp[i + j * cl] = v; });
     __syncthreads();
     wg_copy_mat(N, c.fd, g.T_pp, cl, Q, ld);
     __syncthreads();
-    wg_gemm<false>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
-    wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
     for (int e = wg_tid(); e < N * N; e += kThreads) {
       int i, j;
       c.fd.split(e, i, j);
@@ -780,15 +882,15 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     }
     // T++ = t++ T++ ; T-- = T-- t-- ; R+- = (t++ R+-) t--       (:62-64)
     gdouble *Tpp = g.T_pp, *Tmm = g.T_mm, *Rpm = g.R_pm;
-    wg_gemm<false>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
     __syncthreads();
     wg_copy_mat(N, c.fd, g.T_pp, cl, Q, ld);
     __syncthreads();
-    wg_gemm<false>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
     __syncthreads();
-    wg_gemm<false>(N, ElP{t, ld}, ElP{P, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{P, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
     __syncthreads();
-    wg_gemm<false>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * cl] = v; });
   } else if ((IFACE < 0 || IFACE == 3) && iface == 3) {
     // ---- ScatteringInterface_11 (interaction.jl:69-117)
     // The four mat-vec products ride as column N of the B operands when the buffers have a spare
@@ -805,7 +907,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       double *P = c.P, *Q = c.Q;
       double ss = 0.0;
       // Q = r-+ R+- (+ r-+ J0+) ;  P = T01 = T-- (I - r-+ R+-)^-1            (:81-87)
-      wg_gemm_nc<false>(N, ride ? N + 1 : N, ElP{r, ld}, ElP{P, ld}, [=, &ss](int i, int j, double v) {
+      wg_gemm_nc<false, !LDSM>(N, ride ? N + 1 : N, ElP{r, ld}, ElP{P, ld}, [=, &ss](int i, int j, double v) {
         Q[i + j * ld] = v;
         if (j < N) ss += v * v;
       });
@@ -831,9 +933,9 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       double *P = c.P, *Q = c.Q;
       gdouble *Tmm = g.T_mm, *Rmp = g.R_mp;
       // T-- = T01 t--                                           (:96)
-      wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
+      wg_gemm<false, !LDSM>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
       // Q = T01 r-+ (+ T01 v1)
-      wg_gemm_nc<false>(N, ride ? N + 1 : N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+      wg_gemm_nc<false, !LDSM>(N, ride ? N + 1 : N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
       __syncthreads();
       MOM_STAMP(15);
       if (ride)  // J0- = J0- + T01 v1 (:90); next rider: j0- for R+- j0-
@@ -845,7 +947,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       __syncthreads();
       MOM_STAMP(16);
       // R-+ = R-+ + (T01 r-+) T++                              (:93)
-      wg_gemm<false>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Rmp[i + j * cl] = Rmp[i + j * cl] + v; });
+      wg_gemm<false, !LDSM>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Rmp[i + j * cl] = Rmp[i + j * cl] + v; });
       __syncthreads();
       MOM_STAMP(17);
       wg_copy_mat(N, c.fd, g.R_pm, cl, Q, ld);  // Q = R+- (old)
@@ -861,7 +963,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       double *P = c.P, *Q = c.Q;
       double ss = 0.0;
       // P = R+- r-+ (+ R+- j0-) ; Q = T21 = t++ (I - R+- r-+)^-1            (:104-107)
-      wg_gemm_nc<false>(N, ride ? N + 1 : N, ElP{Q, ld}, ElP{r, ld}, [=, &ss](int i, int j, double v) {
+      wg_gemm_nc<false, !LDSM>(N, ride ? N + 1 : N, ElP{Q, ld}, ElP{r, ld}, [=, &ss](int i, int j, double v) {
         P[i + j * ld] = v;
         if (j < N) ss += v * v;
       });
@@ -892,7 +994,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
         wg_gemm_nc<true>(N, ride ? N + 1 : N, ElP{Qb, ld}, ElP{d, ld}, [=](int i, int j, double v) { d[i + j * ld] = v; });
       } else {
         double *sp = c.X;
-        wg_gemm_nc<false>(N, ride ? N + 1 : N, ElP{Qb, ld}, ElP{d, ld}, [=](int i, int j, double v) { sp[i + j * ld] = v; });
+        wg_gemm_nc<false, !LDSM>(N, ride ? N + 1 : N, ElP{Qb, ld}, ElP{d, ld}, [=](int i, int j, double v) { sp[i + j * ld] = v; });
         c.X = d;
         c.P = sp;
       }
@@ -905,7 +1007,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       double *P = c.P, *Q = c.Q;
       gdouble *Rpm = g.R_pm, *Tpp = g.T_pp;
       // R+- = r+- + (T21 R+-) t--                              (:116)
-      wg_gemm<false>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * cl] = rpm(i, j) + v; });
+      wg_gemm<false, !LDSM>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * cl] = rpm(i, j) + v; });
       __syncthreads();
       MOM_STAMP(24);
       if (ride)
@@ -914,7 +1016,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       __syncthreads();
       MOM_STAMP(25);
       // T++ = T21 T++                                          (:113)
-      wg_gemm<false>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
+      wg_gemm<false, !LDSM>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
     }
   }
   __syncthreads();

@@ -28,11 +28,14 @@ using namespace mom;
 // arrays with N0 = nS0 * Nquad rows; Stokes components >= nS0 get no m = 0 contribution (it is exactly 0).
 struct PostArgs {
   int N, nS, S, M, nVza, red0, N0, nS0;
+  int hdr_all;   // BRDF surfaces: hdr_J0- exists for every moment (hdrJm), not only m = 0
+  int zeroT_hi;  // LambertianSurfaceLegendre: t++ = t-- = 0 for m > 0 (lambertian_surface.jl:131-132) -> J0+ = 0 there
   const int *node;
   const double *cos_mphi, *sin_mphi;
   const double *J0p, *J0m;    // [N,S,M] (moment 0 slice unused when red0)
   const double *J0p0, *J0m0;  // [N0,S] when red0
-  const double *hdrJ;         // [N,S] or [N0,S] when red0
+  const double *hdrJ;         // m = 0: [N,S] or [N0,S] when red0
+  const double *hdrJm;        // hdr_all: [N,S,M] (slot 0 unused)
   double *R, *T, *hdr;
 };
 __global__ void k_postprocess(PostArgs a) {
@@ -52,18 +55,19 @@ __global__ void k_postprocess(PostArgs a) {
         const size_t o = (size_t)(a.node[v] - 1) * a.nS0 + k + (size_t)a.N0 * s;
         r += cs * a.J0m0[o];
         t += cs * a.J0p0[o];
-        h = cs * a.hdrJ[o];
+        h += cs * a.hdrJ[o];
       }
     } else {
       const size_t o = row + (size_t)a.N * (s + (size_t)a.S * m);
       r += cs * a.J0m[o];
-      t += cs * a.J0p[o];
-      if (m == 0) h = cs * a.hdrJ[row + (size_t)a.N * s];
+      if (!(a.zeroT_hi && m > 0)) t += cs * a.J0p[o];
+      if (m == 0) h += cs * a.hdrJ[row + (size_t)a.N * s];
+      else if (a.hdr_all) h += cs * a.hdrJm[o];
     }
   }
   a.R[idx] = r;
   a.T[idx] = t;
-  a.hdr[idx] = h;  // only m = 0 contributes for a Lambertian surface (r-+ = 0, j0- = 0 for m > 0)
+  a.hdr[idx] = h;  // Lambertian surfaces: only m = 0 contributes (r-+ = 0, j0- = 0 for m > 0)
 }
 
 // ---------------------------------------------------------------- operator-level kernels
@@ -298,6 +302,8 @@ struct mom_handle {
   int opt_m0 = 1;
   int opt_w4 = 1;
   int opt_stagger = 1;
+  int surf_kind = 0;         // 0 Lambertian scalar, 1 BRDF matrices, 2 Lambertian Legendre (mom_scene_set_surface)
+  double *d_Rsurf = nullptr, *d_Rsurf0 = nullptr, *d_albedo_spec = nullptr, *d_hdrJm = nullptr;
   int opt_small = 1;       // N <= 4: lane-per-point sweep kernel (mom_small.hip)
   double *d_smtab = nullptr;  // F1 | F2 | SI tables [3][N,N]
   int *d_ndif = nullptr;      // ndoubl | iface [2][Nz]
@@ -434,7 +440,7 @@ extern "C" int mom_destroy(mom_t *h) {
   fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
   fr(h->d_mu0); fr(h->d_wt0); fr(h->d_sg0); fr(h->d_Zpp0); fr(h->d_Zmp0); fr(h->d_hdrJ0); fr(h->d_scratch0);
   for (int k = 0; k < 6; ++k) fr(h->comp0[k]);
-  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_smtab); if (h->d_ndif) (void)hipFree(h->d_ndif); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_tau_rayl);
+  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_Rsurf); fr(h->d_Rsurf0); fr(h->d_albedo_spec); fr(h->d_hdrJm); fr(h->d_smtab); if (h->d_ndif) (void)hipFree(h->d_ndif); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_tau_rayl);
   fr(h->d_layer_max); fr(h->d_aer); if (h->d_aer_mode) (void)hipFree(h->d_aer_mode); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
   for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (auto e : h->ev_full) (void)hipEventDestroy(e);
@@ -844,6 +850,43 @@ static int scene_common(mom_t *h, int Nz, int K, int M, const double *Zpp, const
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->Nz = Nz; h->K = K; h->scene_M = M; h->nVza = nVza; h->albedo = albedo;
+  h->surf_kind = 0;  // LambertianSurfaceScalar(albedo) until mom_scene_set_surface says otherwise
+  return MOM_OK;
+}
+
+extern "C" int mom_scene_set_surface(mom_t *h, int kind, int M, const double *Rsurf, const double *albedo_spec) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_scene_set_surface: call mom_scene_set first");
+  if (kind < 0 || kind > 2 || (kind == 1 && (!Rsurf || M != h->scene_M)) || (kind == 2 && !albedo_spec))
+    return fail(h, MOM_EINVAL, "mom_scene_set_surface: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int N = h->N, nS = h->nS;
+  const size_t NN = (size_t)N * N, S = h->S;
+  int rc;
+  if (kind == 1) {
+    if ((rc = upload_new(h, &h->d_Rsurf, Rsurf, NN * M))) return rc;
+    if (h->d_hdrJm) { (void)hipFree(h->d_hdrJm); h->d_hdrJm = nullptr; }
+    HIPCHK(h, dmalloc(&h->d_hdrJm, (size_t)N * S * M));
+    if (h->red0) {
+      // moment 0 runs on the (I,Q) sub-problem: its surface matrix must not couple (I,Q) with (U,V) either
+      const int nS0 = h->nS0, N0 = h->N0;
+      std::vector<double> r0((size_t)N0 * N0);
+      for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i) {
+          const bool iq_i = (i % nS) < nS0, iq_j = (j % nS) < nS0;
+          const double v = Rsurf[i + (size_t)N * j];
+          if (iq_i != iq_j && v != 0.0)
+            return fail(h, MOM_EINVAL, "mom_scene_set_surface: the m = 0 BRDF matrix couples (I,Q) with (U,V); set "
+                                       "MOM_OPT_M0_REDUCTION = 0 before mom_scene_set for this surface");
+          if (iq_i && iq_j) r0[(i / nS) * nS0 + (i % nS) + (size_t)N0 * ((j / nS) * nS0 + (j % nS))] = v;
+        }
+      if ((rc = upload_new(h, &h->d_Rsurf0, r0.data(), r0.size()))) return rc;
+    }
+  } else if (kind == 2) {
+    if ((rc = upload_new(h, &h->d_albedo_spec, albedo_spec, S))) return rc;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->surf_kind = kind;
   return MOM_OK;
 }
 
@@ -915,7 +958,7 @@ extern "C" int mom_rt_run(mom_t *h) {
   const int M = h->scene_M;
   h->launches = 0; h->launches_full = 0; h->launches_red = 0;
   h->comp_pitched = true;
-  if (h->N <= 4 && h->opt_small && h->nVza <= 4) return rt_run_small(h);
+  if (h->N <= 4 && h->opt_small && h->nVza <= 4 && h->surf_kind == 0) return rt_run_small(h);
   while (h->ev_full.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_full.push_back(e); }
   while (h->ev_red.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_red.push_back(e); }
   const size_t NN = (size_t)h->N * h->N;
@@ -1003,14 +1046,20 @@ extern "C" int mom_rt_run(mom_t *h) {
     }
   }
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
-  {
+  // surface layer + closing interaction: m = 0 always; every moment for a BRDF surface (kind 1)
+  for (int m = 0; m < ((h->surf_kind == 1) ? M : 1); ++m) {
     SurfArgs a{};
-    const DevStreams &q = h->red0 ? h->q0 : h->q;
+    const bool red = h->red0 && m == 0;
+    const DevStreams &q = red ? h->q0 : h->q;
     a.q = q; a.S = h->S; a.iface = h->iface[h->Nz - 1];  // Q6: last layer's interface code (rt_run.jl:181)
     a.albedo = h->albedo; a.tau_tot = h->d_tau_sum + S * h->Nz;
-    for (int k = 0; k < 6; ++k) a.comp[k] = h->red0 ? h->comp0[k] : h->comp[k];
-    a.hdrJ = h->red0 ? h->d_hdrJ0 : h->d_hdrJ; a.bhr_uw = h->d_bhr_uw; a.bhr_dw = h->d_bhr_dw; a.nS_out = h->nS;
-    a.scratch = h->red0 ? h->d_scratch0 : h->d_scratch; a.info = h->d_info;
+    a.kind = h->surf_kind; a.m = m; a.albedo_spec = h->d_albedo_spec;
+    a.Rsurf = (h->surf_kind == 1) ? (red ? h->d_Rsurf0 : h->d_Rsurf + NN * m) : nullptr;
+    for (int k = 0; k < 6; ++k)
+      a.comp[k] = red ? h->comp0[k] : h->comp[k] + ((k < 4) ? (size_t)comp_pitch(h->N) * h->N : (size_t)h->N) * S * m;
+    a.hdrJ = red ? h->d_hdrJ0 : (m == 0 ? h->d_hdrJ : h->d_hdrJm + (size_t)h->N * S * m);
+    a.bhr_uw = h->d_bhr_uw; a.bhr_dw = h->d_bhr_dw; a.nS_out = h->nS;
+    a.scratch = red ? h->d_scratch0 : h->d_scratch; a.info = h->d_info;
     const bool lds = (q.N <= 64) && !h->opt_force_generic;
     const size_t sm = lds_bytes(q.N, lds);
     const int grid = lds ? (int)S : (int)std::min<size_t>(S, (size_t)h->G);
@@ -1034,6 +1083,7 @@ extern "C" int mom_rt_run(mom_t *h) {
     pa.node = h->d_node; pa.cos_mphi = h->d_cos; pa.sin_mphi = h->d_sin;
     pa.J0p = h->comp[4]; pa.J0m = h->comp[5]; pa.J0p0 = h->comp0[4]; pa.J0m0 = h->comp0[5];
     pa.hdrJ = h->red0 ? h->d_hdrJ0 : h->d_hdrJ;
+    pa.hdr_all = (h->surf_kind == 1) ? 1 : 0; pa.zeroT_hi = (h->surf_kind == 2) ? 1 : 0; pa.hdrJm = h->d_hdrJm;
     pa.R = h->d_R; pa.T = h->d_T; pa.hdr = h->d_hdr;
     hipLaunchKernelGGL(k_postprocess, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, pa);
     HIPCHK(h, hipGetLastError());

@@ -58,7 +58,19 @@ def oracle_scene(model) -> mr.Scene:
     quad = mr.rt_set_streams(p.quadrature_type, p.l_trunc, p.sza, p.vza, n)
     aer = [mr.AerosolOptics(mr.GreekCoefs(a.greek_coefs.α, a.greek_coefs.β, a.greek_coefs.γ, a.greek_coefs.δ,
                                           a.greek_coefs.ϵ, a.greek_coefs.ζ), a.ω̃, a.fᵗ) for a in model.aerosol_optics]
-    return mr.Scene(pol=mr.pol_from_n(n), quad=quad, max_m=p.max_m, tau_rayl=model.τ_rayl, tau_abs=model.τ_abs,
+    b = getattr(p, "brdf", None)
+    brdf = None
+    if b is not None:
+        nm = type(b).__name__
+        if nm == "rpvSurfaceScalar":
+            brdf = ("rpv", b.ρ0, b.ρ_c, b.k, b.Θ)
+        elif nm == "RossLiSurfaceScalar":
+            brdf = ("rossli", b.fvol, b.fgeo, b.fiso)
+        elif nm == "LambertianSurfaceLegendre":
+            brdf = ("legendre",) + tuple(b.legendre_coeff)
+        elif nm == "LambertianSurfaceScalar":
+            p = type(p)(**{**p.__dict__, "brdf_albedo": b.albedo})
+    return mr.Scene(brdf=brdf, pol=mr.pol_from_n(n), quad=quad, max_m=p.max_m, tau_rayl=model.τ_rayl, tau_abs=model.τ_abs,
                     greek_rayleigh=mr.get_greek_rayleigh(p.depol), tau_aer=model.τ_aer, aerosols=aer,
                     varpi_cabannes=model.ϖ_Cabannes, albedo=p.brdf_albedo, vza=np.asarray(p.vza, float),
                     vaz=np.asarray(p.vaz, float), strict_reference_indexing=p.strict_reference_indexing)

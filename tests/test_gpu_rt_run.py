@@ -389,3 +389,38 @@ def test_voigt_to_spectrum_without_host_tau(rtamd):
     R0, T0 = rtamd.rt_run(m)[:2]
     assert np.array_equal(R1, R0) and np.array_equal(T1, T0)
     assert np.ptp(R1[0, 0]) > 1e-3 * R1[0, 0].max()    # the lines are in the spectrum
+
+
+def _surfaces(rt):
+    return {"rpv": rt.rpvSurfaceScalar(0.1, 0.8, 0.7, -0.1), "rossli": rt.RossLiSurfaceScalar(0.1, 0.05, 0.2),
+            "legendre": rt.LambertianSurfaceLegendre((0.2, 0.05, -0.02))}
+
+
+@pytest.mark.parametrize("surf", ["rpv", "rossli", "legendre"])
+@pytest.mark.parametrize("nS,lt,mode", [(3, 9, "lds"), (1, 5, "lds"), (4, 7, "generic"), (3, 33, "lds"), (3, 9, "nored")])
+def test_surface_types(rtamd, cref, surf, nS, lt, mode):
+    """SURVEY 8f-2: non-Lambertian surfaces through mom_scene_set_surface -- create_surface_layer!(brdf::AbstractSurfaceType)
+    (rpv_surface.jl:20-66: RPV and Ross-Li BRDF Fourier moments, a surface interaction for EVERY moment, hdr over all
+    moments) and LambertianSurfaceLegendre (lambertian_surface.jl:77-138, incl. its j0+ = 0 and t = 0 for m > 0) --
+    against the oracle's own surface code; N = 60 exercises the m = 0 (I,Q) sub-problem with the reduced BRDF matrix."""
+    m = rtamd.scenes.make_scene(nS, lt, 4, 12, seed=41, vaz=(10.0, 95.0, 170.0))
+    m.params.brdf = _surfaces(rtamd.corert)[surf]
+    sc = rtamd.prepare_scene(m)
+    Rr, Tr, Hr, upr, dwr, info = cref.rt_run_full(cref.pack_scene(helpers.oracle_scene(m)))
+    assert info == 0
+    with rtamd.corert.make_handle(m) as h:
+        if mode == "generic":
+            h.set_option(rtamd._lib.MOM_OPT_FORCE_GENERIC, 1)
+        if mode == "nored":
+            h.set_option(rtamd._lib.MOM_OPT_M0_REDUCTION, 0)
+        R, T = rtamd.corert.run_scene(h, sc)
+        H, up, dw = h.get_hdr()
+    helpers.assert_stokes_close(R, Rr, what="R")
+    helpers.assert_stokes_close(T, Tr, what="T")
+    helpers.assert_stokes_close(H, Hr, what="hdr")
+    np.testing.assert_allclose(up, upr, rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(dw, dwr, rtol=1e-10, atol=1e-300)
+    # the surface matters: a Lambertian surface of similar brightness gives a different spectrum
+    m.params.brdf = None
+    R0, _ = rtamd.rt_run(m)[:2]
+    assert np.abs(R0 - R).max() > 1e-6

@@ -123,3 +123,31 @@ def test_voigt_c_vs_numpy_and_golden(cref):
         scale = g[f"sigma_{tag}"].max()
         assert np.max(np.abs(sig_np - g[f"sigma_{tag}"])) <= 1e-14 * scale
         assert np.max(np.abs(sig_c - g[f"sigma_{tag}"])) <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("brdf", [("rpv", 0.1, 0.8, 0.7, -0.1), ("rossli", 0.1, 0.05, 0.2), ("legendre", 0.2, 0.05, -0.02)])
+def test_surface_types_twin_vs_c(rtamd, cref, brdf):
+    """The two oracles (numpy twin / C) agree on the non-Lambertian surface layers (rpv_surface.jl:20-66,
+    lambertian_surface.jl:77-138), and the product's host-side BRDF Fourier moments (corert.reflectance, vectorised)
+    agree with the oracle's scalar-loop version."""
+    import helpers
+    from oracle import momref as mr
+    m = rtamd.scenes.make_scene(3, 7, 3, 5, seed=3)
+    so = helpers.oracle_scene(m)
+    so.brdf = brdf
+    p = cref.pack_scene(so)
+    Rr, Tr, Hr, up, dw, info = cref.rt_run_full(p)
+    Rt, Tt, Ht, upt, dwt = mr.rt_run_full(so)
+    assert info == 0
+    helpers.assert_stokes_close(Rt, Rr, rtol=1e-12, what="R")
+    helpers.assert_stokes_close(Tt, Tr, rtol=1e-12, what="T")
+    helpers.assert_stokes_close(Ht, Hr, rtol=1e-12, what="hdr")
+    rt = rtamd.corert
+    prod = {"rpv": lambda b: rt.rpvSurfaceScalar(*b[1:]), "rossli": lambda b: rt.RossLiSurfaceScalar(*b[1:]),
+            "legendre": lambda b: rt.LambertianSurfaceLegendre(tuple(b[1:]))}[brdf[0]](brdf)
+    kind, Rs, alb = rt.surface_inputs(prod, m.params.polarization_type, m.quad_points.qp_μ, m.params.max_m, 5)
+    assert kind == p.surf_kind
+    if Rs is not None:
+        np.testing.assert_allclose(rt._abi_mats(Rs), p.Rsurf, rtol=0, atol=1e-13)
+    if alb is not None:
+        np.testing.assert_allclose(alb, p.albedo_spec, rtol=0, atol=1e-15)
