@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="all ranks on GPU 0 (needs --backend gloo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-voigt", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="ID=VALUE", help="mom_set_option(ID, VALUE) before the scene is set (kernel A/B runs)")
     a = ap.parse_args()
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -136,6 +137,9 @@ def main():
     scene = rtamd.prepare_scene(model)          # global axis: ndoubl / iface are global
     shard = scene.spectral_slice(rank * S_loc, (rank + 1) * S_loc) if world > 1 else scene
     h = rtamd.corert.make_handle(model, S=S_loc)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        h.set_option(int(k), int(v))
     h.scene_set(shard.Nz, shard.K, shard.M, shard.tau, shard.varpi, shard.zw, shard.Zpp, shard.Zmp, shard.ndoubl,
                 shard.iface, shard.tau_sum, shard.albedo, shard.node, shard.cos_mphi, shard.sin_mphi)
     nout = len(shard.node) * shard.nStokes * S_loc

@@ -6,6 +6,7 @@
 
 namespace MOM_NS {
 
+constexpr int kMaxSweepLayers = 96;
 struct LayerArgs {
   DevStreams q;
   int S, M, K;      // M: number of moments in THIS launch; m_first: Fourier index of the first of them
@@ -17,6 +18,12 @@ struct LayerArgs {
   double *comp[6];                           // R_mp, R_pm, T_pp, T_mm [N,N,S,M]; J0p, J0m [N,S,M], from m_first
   double *scratch;                           // generic mode: per-workgroup slabs
   int *info;
+  // sweep mode (Nz_sweep > 0): ONE launch walks all layers of a unit before it moves to the next unit -- the composite
+  // blocks a workgroup stored for layer z are the ones it loads for layer z + 1 (same CU, L2-resident), there is one
+  // tail per sweep instead of one per layer, and no launch gap.  tau/varpi/zw/tau_sum then point at layer 0 and layer z
+  // lies z * S (z * K * S) elements further; nd / iface come from the tables below.
+  int Nz_sweep;
+  signed char nd_z[kMaxSweepLayers], iface_z[kMaxSweepLayers];
 };
 
 struct ZMix {
@@ -67,33 +74,40 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
     const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)((blockIdx.x >> 3) & 31) * a.stagger;
     while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
   }
+  const int nz = a.Nz_sweep > 0 ? a.Nz_sweep : 1;
   for (size_t pt = blockIdx.x; pt < total; pt += gridDim.x) {
     const int n = (int)(pt % a.S), mrel = (int)(pt / a.S), m = a.m_first + mrel;
-    const double tau = as_global(a.tau)[n], varpi = as_global(a.varpi)[n];
-    const double dtau = ldexp(tau, -a.nd);       // τ ./ 2^ndoubl   (rt_kernel.jl:244)
-    double expk = exp(-dtau / a.q.mu0);          // init_layer      (rt_kernel.jl:273)
     const size_t NN = (size_t)N * N;
-    ZMix zpp{as_global(a.Zpp) + NN * a.K * mrel, as_global(a.zw) + (size_t)a.K * n, a.K, N};
-    ZMix zmp{as_global(a.Zmp) + NN * a.K * mrel, as_global(a.zw) + (size_t)a.K * n, a.K, N};
-#ifdef MOM_DIAG_STAMPS
-    MOM_STAMP(43);
-#endif
-    elemental_build(c, a.q, m, a.nd, as_global(a.tau_sum)[n], dtau, varpi, zpp, zmp);
-    MOM_STAMP(41);
-#ifdef MOM_DIAG_TWICE
-    elemental_build(c, a.q, m, a.nd, as_global(a.tau_sum)[n], dtau, varpi, zpp, zmp);
-    MOM_STAMP(44);
-#endif
-    expk = doubling_run<LDSM, KS>(c, a.nd, expk);
-    MOM_STAMP(30);
     CompPtrs g = comp_ptrs(a.comp, N, comp_pitch(N), pt);
-    if (a.first) {
-      store_added_as_composite(c, g);
-      __syncthreads();
-      MOM_STAMP(42);
-    } else {
-      interaction_core<LDSM, IFACE, KS>(c, a.iface, g, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
-      MOM_STAMP(45);
+    for (int z = 0; z < nz; ++z) {
+      const int nd = a.Nz_sweep > 0 ? a.nd_z[z] : a.nd;
+      const int iface = a.Nz_sweep > 0 ? a.iface_z[z] : a.iface;
+      const bool first = a.Nz_sweep > 0 ? (z == 0) : (a.first != 0);
+      const size_t zo = (size_t)a.S * z;
+      const double tau = as_global(a.tau)[n + zo], varpi = as_global(a.varpi)[n + zo];
+      const double dtau = ldexp(tau, -nd);         // τ ./ 2^ndoubl   (rt_kernel.jl:244)
+      double expk = exp(-dtau / a.q.mu0);          // init_layer      (rt_kernel.jl:273)
+      ZMix zpp{as_global(a.Zpp) + NN * a.K * mrel, as_global(a.zw) + (size_t)a.K * (n + zo), a.K, N};
+      ZMix zmp{as_global(a.Zmp) + NN * a.K * mrel, as_global(a.zw) + (size_t)a.K * (n + zo), a.K, N};
+#ifdef MOM_DIAG_STAMPS
+      MOM_STAMP(43);
+#endif
+      elemental_build(c, a.q, m, nd, as_global(a.tau_sum)[n + zo], dtau, varpi, zpp, zmp);
+      MOM_STAMP(41);
+#ifdef MOM_DIAG_TWICE
+      elemental_build(c, a.q, m, nd, as_global(a.tau_sum)[n + zo], dtau, varpi, zpp, zmp);
+      MOM_STAMP(44);
+#endif
+      expk = doubling_run<LDSM, KS>(c, nd, expk);
+      MOM_STAMP(30);
+      if (first) {
+        store_added_as_composite(c, g);
+        __syncthreads();
+        MOM_STAMP(42);
+      } else {
+        interaction_core<LDSM, IFACE, KS>(c, iface, g, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
+        MOM_STAMP(45);
+      }
     }
   }
   if (wg_tid() == 0 && *c.bad) atomicMax(a.info, *c.bad);

@@ -304,6 +304,7 @@ struct mom_handle {
   int opt_stagger = 1;
   int surf_kind = 0;         // 0 Lambertian scalar, 1 BRDF matrices, 2 Lambertian Legendre (mom_scene_set_surface)
   double *d_Rsurf = nullptr, *d_Rsurf0 = nullptr, *d_albedo_spec = nullptr, *d_hdrJm = nullptr;
+  int opt_sweep = 1;       // one launch walks all layers of a unit (LayerArgs::Nz_sweep)
   int opt_small = 1;       // N <= 4: lane-per-point sweep kernel (mom_small.hip)
   double *d_smtab = nullptr;  // F1 | F2 | SI tables [3][N,N]
   int *d_ndif = nullptr;      // ndoubl | iface [2][Nz]
@@ -470,6 +471,7 @@ extern "C" int mom_set_option(mom_t *h, int option, int value) {
   else if (option == MOM_OPT_SMALL_WG) h->opt_w4 = value;
   else if (option == MOM_OPT_STAGGER) h->opt_stagger = value;
   else if (option == MOM_OPT_SMALL_N) h->opt_small = value;
+  else if (option == MOM_OPT_LAYER_SWEEP) h->opt_sweep = value;
   else if (option == MOM_OPT_FORCE_GENERIC) {
     h->opt_force_generic = value;
     h->lds_mode = (h->N <= 64) && !value;
@@ -963,11 +965,25 @@ extern "C" int mom_rt_run(mom_t *h) {
   while (h->ev_red.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_red.push_back(e); }
   const size_t NN = (size_t)h->N * h->N;
   // one k_layer launch over `Mcount` moments starting at `m_first` with stream set `q` (full or reduced)
+  // sweep mode: every layer of a unit inside one launch (z < 0 selects it); needs one interface code for all z >= 1
+  // (the code is a template argument of the kernel images) -- always the case once scattering has set in
+  bool can_sweep = h->opt_sweep && h->Nz <= kMaxSweepLayers && h->Nz > 1;
+  for (int z = 2; z < h->Nz && can_sweep; ++z) can_sweep = (h->iface[z] == h->iface[1]);
+  for (int z = 0; z < h->Nz && can_sweep; ++z) can_sweep = (h->nd[z] <= 127);
   auto launch_layer = [&](int z, const DevStreams &q, int m_first, int Mcount, const double *Zpp, const double *Zmp,
                           double *const comp[6], double *scratch) -> int {
     LayerArgs a{};
     a.q = q; a.S = h->S; a.M = Mcount; a.K = h->K; a.m_first = m_first;
-    a.nd = h->nd[z]; a.iface = h->iface[z]; a.first = (z == 0);
+    const bool sweep = z < 0;
+    if (sweep) {
+      z = 0;
+      a.Nz_sweep = h->Nz;
+      int ndsum = 0;
+      for (int k = 0; k < h->Nz; ++k) { a.nd_z[k] = (signed char)h->nd[k]; a.iface_z[k] = (signed char)h->iface[k]; ndsum += h->nd[k]; }
+      a.nd = ndsum / h->Nz; a.iface = h->iface[1]; a.first = 1;
+    } else {
+      a.nd = h->nd[z]; a.iface = h->iface[z]; a.first = (z == 0);
+    }
     a.tau = h->d_tau + S * z; a.varpi = h->d_varpi + S * z; a.zw = h->d_zw + (size_t)h->K * S * z;
     a.tau_sum = h->d_tau_sum + S * z;
     a.Zpp = Zpp; a.Zmp = Zmp;
@@ -1023,25 +1039,26 @@ extern "C" int mom_rt_run(mom_t *h) {
     return MOM_OK;
   };
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  for (int z = 0; z < h->Nz; ++z) {
+  for (int z = (can_sweep ? -1 : 0); z < (can_sweep ? 0 : h->Nz); ++z) {
     int rc;
+    const int e = can_sweep ? 0 : z;  // event slot
     if (h->red0) {
       if (M > 1) {  // moments 1..M-1 on the full problem
         double *comp1[6];
         for (int k = 0; k < 6; ++k) comp1[k] = h->comp[k] + ((k < 4) ? (size_t)comp_pitch(h->N) * h->N : (size_t)h->N) * S;
-        HIPCHK(h, hipEventRecord(h->ev_full[2 * z], h->stream));
+        HIPCHK(h, hipEventRecord(h->ev_full[2 * e], h->stream));
         if ((rc = launch_layer(z, h->q, 1, M - 1, h->d_Zpp + NN * h->K, h->d_Zmp + NN * h->K, comp1, h->d_scratch))) return rc;
-        HIPCHK(h, hipEventRecord(h->ev_full[2 * z + 1], h->stream));
+        HIPCHK(h, hipEventRecord(h->ev_full[2 * e + 1], h->stream));
         h->launches_full++;
       }
-      HIPCHK(h, hipEventRecord(h->ev_red[2 * z], h->stream));
+      HIPCHK(h, hipEventRecord(h->ev_red[2 * e], h->stream));
       if ((rc = launch_layer(z, h->q0, 0, 1, h->d_Zpp0, h->d_Zmp0, h->comp0, h->d_scratch0))) return rc;
-      HIPCHK(h, hipEventRecord(h->ev_red[2 * z + 1], h->stream));
+      HIPCHK(h, hipEventRecord(h->ev_red[2 * e + 1], h->stream));
       h->launches_red++;
     } else {
-      HIPCHK(h, hipEventRecord(h->ev_full[2 * z], h->stream));
+      HIPCHK(h, hipEventRecord(h->ev_full[2 * e], h->stream));
       if ((rc = launch_layer(z, h->q, 0, M, h->d_Zpp, h->d_Zmp, h->comp, h->d_scratch))) return rc;
-      HIPCHK(h, hipEventRecord(h->ev_full[2 * z + 1], h->stream));
+      HIPCHK(h, hipEventRecord(h->ev_full[2 * e + 1], h->stream));
       h->launches_full++;
     }
   }

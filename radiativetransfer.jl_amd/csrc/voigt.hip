@@ -91,11 +91,33 @@ __global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__re
   const double gx = (gi < nGrid) ? grid[gi] : 0.0;
   const double cSqrtLn2divSqrtPi = 0.469718639319144059835, cSqrtLn2 = 0.8325546111577;
   double acc = 0.0;
-  for (int base = 0; base < nLines; base += kBlock) {
+  // Range [jlo, jhi] of line indices whose window touches this block: one cheap strided pass (two loads and a compare
+  // per line, no barrier) instead of running the ordered compaction below over the whole list -- line lists are
+  // sorted by wavenumber, so the range is tight (an unsorted list still works, it only gets no benefit).  The sum
+  // stays in ascending line order.
+  __shared__ int s_lo, s_hi;
+  if (tid == 0) { s_lo = nLines; s_hi = -1; }
+  __syncthreads();
+  {
+    int mylo = nLines, myhi = -1;
+    for (int j = tid; j < nLines; j += kBlock) {
+      const int lo = i0[j] - 1, hi = i1[j] - 1;
+      if (lo <= g1 && hi >= g0 && hi >= lo) { mylo = min(mylo, j); myhi = max(myhi, j); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      mylo = min(mylo, __shfl_xor(mylo, off));
+      myhi = max(myhi, __shfl_xor(myhi, off));
+    }
+    if (lane == 0) { atomicMin(&s_lo, mylo); atomicMax(&s_hi, myhi); }
+  }
+  __syncthreads();
+  const int jlo = s_lo, jhi = s_hi;
+  for (int base = jlo; base <= jhi; base += kBlock) {
     const int j = base + tid;
     bool hit = false;
     int lo = 0, hi = -1;
-    if (j < nLines) {
+    if (j <= jhi) {
       lo = i0[j] - 1;
       hi = i1[j] - 1;
       hit = (lo <= g1) && (hi >= g0);
