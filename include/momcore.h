@@ -19,7 +19,11 @@
  *   - host pointers are borrowed for the duration of the call only.  All device memory is
  *     owned by the handle.  One handle <-> one GPU <-> one HIP stream; a handle is not
  *     thread-safe, distinct handles are independent.
- *   - `dtype` of mom_create: 0 = Float64 (the reference's default float_type).
+ *   - `dtype` of mom_create: 0 = Float64 (the reference's default float_type), 1 = Float32 (float_type = Float32,
+ *     parameters_from_yaml.jl:160): operators, sources and products in f32 on the GPU.  The ABI keeps Float64 host
+ *     arrays for both (inputs are rounded on upload, outputs widened on download).  A Float32 handle supports the
+ *     scene-level path -- mom_set_streams, mom_scene_set, mom_scene_set_surface, mom_set_option, mom_rt_run,
+ *     mom_get_RT, mom_get_hdr, mom_timers, mom_sync, mom_check -- every other entry point returns MOM_EINVAL on it.
  */
 #ifndef MOMCORE_H
 #define MOMCORE_H

@@ -123,11 +123,12 @@ def ip(a: np.ndarray):
 class Handle:
     """RAII wrapper of mom_t*.  One handle <-> one GPU <-> one stream."""
 
-    def __init__(self, N: int, nStokes: int, S: int, max_m: int = 1, device: int = 0):
+    def __init__(self, N: int, nStokes: int, S: int, max_m: int = 1, device: int = 0, dtype: int = 0):
+        """dtype 0 = Float64 (everything), 1 = Float32 (scene-level path: scene_set / rt_run / get_RT / get_hdr)."""
         self.lib = load()
         self.N, self.nS, self.S, self.M = int(N), int(nStokes), int(S), int(max_m)
         self._h = c_h()
-        rc = self.lib.mom_create(C.byref(self._h), device, self.N, self.nS, self.S, self.M, 0)
+        rc = self.lib.mom_create(C.byref(self._h), device, self.N, self.nS, self.S, self.M, int(dtype))
         if rc != MOM_OK:
             msg = self.lib.mom_last_global_error().decode()
             if self._h:

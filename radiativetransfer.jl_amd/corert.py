@@ -704,12 +704,13 @@ def prepare_scene(model: vSmartMOM_Model) -> SceneInputs:
         cos_mphi=cm.reshape(-1), sin_mphi=sm.reshape(-1))
 
 
-def make_handle(model: vSmartMOM_Model, S: Optional[int] = None) -> _lib.Handle:
+def make_handle(model: vSmartMOM_Model, S: Optional[int] = None, float_type: str = "Float64") -> _lib.Handle:
+    """float_type: the reference's `float_type` (parameters_from_yaml.jl:160): "Float64" or "Float32"."""
     p, qp = model.params, model.quad_points
     if not isinstance(p.architecture, MI355X):
         raise TypeError("this package only executes on Architectures.MI355X (no CPU path)")
     h = _lib.Handle(len(qp.qp_μN), p.polarization_type.n, S if S is not None else model.τ_rayl.shape[0], p.max_m,
-                    device=p.architecture.device)
+                    device=p.architecture.device, dtype={"Float64": 0, "Float32": 1}[float_type])
     h.set_streams(qp.qp_μN, qp.wt_μN, qp.iμ0, qp.μ0, p.polarization_type.I0, p.polarization_type.D,
                   p.strict_reference_indexing)
     return h

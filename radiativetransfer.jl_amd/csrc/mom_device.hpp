@@ -27,9 +27,24 @@
 
 namespace MOM_NS {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
+// The device library is compiled once per scalar type as well: MOM_REAL = double (default; every build but one) or
+// float (momcore_f32.hip, namespace momf: the reference's float_type = Float32, parameters_from_yaml.jl:160).
+#ifndef MOM_REAL
+#define MOM_REAL double
+#endif
+typedef MOM_REAL real;
+typedef real r4 __attribute__((ext_vector_type(4)));
+constexpr bool kF64 = sizeof(real) == 8;
 
-extern __shared__ double mom_smem[];  // the workgroup's dynamic LDS image (carved by make_ctx)
+// one 16 x 16 x 4 MFMA step in the build's scalar type.  C/D layout: f64: row = (lane >> 4) + 4 reg; f32: row =
+// 4 (lane >> 4) + reg (cdna_hip_programming.md section 3); column = lane & 15 in both.
+typedef double mom_d4 __attribute__((ext_vector_type(4)));
+typedef float mom_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mom_d4 mma16(double a, double b, mom_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ mom_f4 mma16(float a, float b, mom_f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int cd_row(int lq, int r) { return kF64 ? lq + 4 * r : 4 * lq + r; }
+
+extern __shared__ real mom_smem[];  // the workgroup's dynamic LDS image (carved by make_ctx)
 
 #ifndef MOM_WAVES
 #define MOM_WAVES 8
@@ -46,9 +61,9 @@ constexpr int kTJ = 16 / kWaves;  // column tiles per work item: 8 waves x 2 til
 // struct are generic to the compiler: it would emit FLAT loads/stores, which count on BOTH memory counters, so
 // every LDS wait behind a composite store in flight would also wait for that store.  Through these types the
 // accesses become global_load / global_store (vmcnt only).
-typedef __attribute__((address_space(1))) double gdouble;
-__device__ __forceinline__ gdouble *as_global(double *p) { return (gdouble *)p; }
-__device__ __forceinline__ const gdouble *as_global(const double *p) { return (const gdouble *)p; }
+typedef __attribute__((address_space(1))) real gdouble;  // (the name predates the float build)
+__device__ __forceinline__ gdouble *as_global(real *p) { return (gdouble *)p; }
+__device__ __forceinline__ const gdouble *as_global(const real *p) { return (const gdouble *)p; }
 
 // Thread coordinates through an opaque asm: the address arithmetic derived from them is recomputed where it is
 // used (a few integer ops) instead of being hoisted out of the per-unit loop of the fused kernels, kept live
@@ -85,16 +100,16 @@ struct FastDiv {
 template <class FA>
 struct One {
   FA a;
-  __device__ __forceinline__ double operator()(int, int i, int k) const { return a(i, k); }
-  template <int LD> __device__ __forceinline__ double at(int, int i, int k) const { return a.template at<LD>(i, k); }
+  __device__ __forceinline__ real operator()(int, int i, int k) const { return a(i, k); }
+  template <int LD> __device__ __forceinline__ real at(int, int i, int k) const { return a.template at<LD>(i, k); }
   __device__ __forceinline__ void launder() { a.launder(); }
 };
 template <class FA1, class FA2>
 struct Two {
   FA1 a1;
   FA2 a2;
-  __device__ __forceinline__ double operator()(int u, int i, int k) const { return u == 0 ? a1(i, k) : a2(i, k); }
-  template <int LD> __device__ __forceinline__ double at(int u, int i, int k) const {
+  __device__ __forceinline__ real operator()(int u, int i, int k) const { return u == 0 ? a1(i, k) : a2(i, k); }
+  template <int LD> __device__ __forceinline__ real at(int u, int i, int k) const {
     return u == 0 ? a1.template at<LD>(i, k) : a2.template at<LD>(i, k);
   }
   __device__ __forceinline__ void launder() { a1.launder(); a2.launder(); }
@@ -104,14 +119,14 @@ struct Two {
 // base + immediate offset, and the (laundered) bases cannot be hoisted out of the caller's loops,
 // so neither address arithmetic nor long live ranges cost registers.
 template <int NA, int KS, int LD, class FAs, class FB>
-__device__ __forceinline__ void item_straight(int row, int lq, int col0, FAs A, FB B, d4 (&acc)[NA][kTJ]) {
+__device__ __forceinline__ void item_straight(int row, int lq, int col0, FAs A, FB B, r4 (&acc)[NA][kTJ]) {
   // launder the lane coordinates (NOT the pointers: an asm operand would turn the LDS pointers
   // into generic ones and the reads into flat loads)
   asm volatile("" : "+v"(row), "+v"(lq), "+v"(col0));
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const int k = 4 * ks + lq;
-    double a[NA], b[kTJ];
+    real a[NA], b[kTJ];
 #pragma unroll
     for (int u = 0; u < NA; ++u) a[u] = A.template at<LD>(u, row, k);
 #pragma unroll
@@ -119,7 +134,7 @@ __device__ __forceinline__ void item_straight(int row, int lq, int col0, FAs A, 
 #pragma unroll
     for (int t = 0; t < kTJ; ++t)
 #pragma unroll
-      for (int u = 0; u < NA; ++u) acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[t], acc[u][t], 0, 0, 0);
+      for (int u = 0; u < NA; ++u) acc[u][t] = mma16(a[u], b[t], acc[u][t]);
   }
 }
 
@@ -127,8 +142,8 @@ __device__ __forceinline__ void item_straight(int row, int lq, int col0, FAs A, 
 // are neither loaded nor multiplied
 template <int NA, int C, bool PRED, class FAs, class FB>
 __device__ __forceinline__ void kchunk(int ks0, int row, int lq, int col0, int nt, const FAs &A, FB B,
-                                       d4 (&acc)[NA][kTJ]) {
-  double a[NA][C], b[C][kTJ];
+                                       r4 (&acc)[NA][kTJ]) {
+  real a[NA][C], b[C][kTJ];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     const int k = 4 * (ks0 + c) + lq;
@@ -145,7 +160,7 @@ __device__ __forceinline__ void kchunk(int ks0, int row, int lq, int col0, int n
       for (int c = 0; c < C; ++c)
 #pragma unroll
         for (int u = 0; u < NA; ++u)
-          acc[u][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][c], b[c][t], acc[u][t], 0, 0, 0);
+          acc[u][t] = mma16(a[u][c], b[c][t], acc[u][t]);
     }
 }
 
@@ -171,11 +186,11 @@ __device__ __forceinline__ void wg_gemm_n(int N, int NC, FAs A, FB B, FE epi) {
   for (int item = wave; item < (SYNC ? kWaves : items); item += kWaves) {
     const bool have = item < items;
     const int ti = item % Tn, cg = item / Tn;
-    d4 acc[NA][kTJ];
+    r4 acc[NA][kTJ];
 #pragma unroll
     for (int u = 0; u < NA; ++u)
 #pragma unroll
-      for (int t = 0; t < kTJ; ++t) acc[u][t] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int t = 0; t < kTJ; ++t) acc[u][t] = (r4){0.0, 0.0, 0.0, 0.0};
     if (have) {
       const int row = 16 * ti + lr, col0 = 16 * cg * kTJ + lr;
       bool done = false;
@@ -215,7 +230,7 @@ __device__ __forceinline__ void wg_gemm_n(int N, int NC, FAs A, FB B, FE epi) {
         const int col = 16 * (cg * kTJ + t) + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int rw = 16 * ti + lq + 4 * r;
+          const int rw = 16 * ti + cd_row(lq, r);
           if (rw < N && col < NC) {
 #pragma unroll
             for (int u = 0; u < NA; ++u) epi(u, rw, col, acc[u][t][r]);
@@ -240,7 +255,7 @@ __device__ __forceinline__ void wg_gemm_nc(int N, int NC, FA A, FB B, FE epi) {
     }
   }
   wg_gemm_n<1, SYNC, lds_operand<FA>::value && lds_operand<FB>::value>(
-      N, NC, One<FA>{A}, B, [=](int, int i, int j, double v) { epi(i, j, v); });
+      N, NC, One<FA>{A}, B, [=](int, int i, int j, real v) { epi(i, j, v); });
 }
 template <bool SYNC, bool BIG = false, class FA, class FB, class FE>
 __device__ __forceinline__ void wg_gemm(int N, FA A, FB B, FE epi) {
@@ -258,7 +273,7 @@ __device__ __forceinline__ void wg_gemm2(int N, FA1 A1, FA2 A2, FB B, FE1 epi1, 
   }
   wg_gemm_n<2, SYNC, lds_operand<FA1>::value && lds_operand<FA2>::value && lds_operand<FB>::value>(
       N, N, Two<FA1, FA2>{A1, A2}, B,
-      [=](int u, int i, int j, double v) { if (u == 0) epi1(i, j, v); else epi2(i, j, v); });
+      [=](int u, int i, int j, real v) { if (u == 0) epi1(i, j, v); else epi2(i, j, v); });
 }
 
 // ---------------------------------------------------------------------------------------
@@ -266,16 +281,16 @@ __device__ __forceinline__ void wg_gemm2(int N, FA1 A1, FA2 A2, FB B, FE1 epi1, 
 // scratch of 2*kWaves*ldv doubles.  All threads must call.  y may alias x.
 // ---------------------------------------------------------------------------------------
 template <class FM>
-__device__ __forceinline__ void wg_matvec2(int N, int ldv, FM M, const double *x1, const double *x2, double *y1,
-                                           double *y2, double *part) {
+__device__ __forceinline__ void wg_matvec2(int N, int ldv, FM M, const real *x1, const real *x2, real *y1,
+                                           real *y2, real *part) {
   const int lane = wg_lane(), wave = wg_wave();
   const int chunk = (N + kWaves - 1) / kWaves;
   const int k0 = wave * chunk, k1 = min(N, k0 + chunk);
   for (int i = lane; i < N; i += 64) {
-    double s1 = 0.0, s2 = 0.0;
+    real s1 = 0.0, s2 = 0.0;
 #pragma unroll 4
     for (int k = k0; k < k1; ++k) {
-      const double m = M(i, k);
+      const real m = M(i, k);
       s1 += m * x1[k];
       s2 += m * x2[k];
     }
@@ -284,7 +299,7 @@ __device__ __forceinline__ void wg_matvec2(int N, int ldv, FM M, const double *x
   }
   __syncthreads();
   for (int i = wg_tid(); i < N; i += kThreads) {
-    double s1 = 0.0, s2 = 0.0;
+    real s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) { s1 += part[w * ldv + i]; s2 += part[(kWaves + w) * ldv + i]; }
     y1[i] = s1;
@@ -294,12 +309,12 @@ __device__ __forceinline__ void wg_matvec2(int N, int ldv, FM M, const double *x
 }
 
 // max over the wave (all lanes get it)
-__device__ __forceinline__ double wave_max(double v) {
+__device__ __forceinline__ real wave_max(real v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
   return v;
 }
-__device__ __forceinline__ double wave_sum(double v) {
+__device__ __forceinline__ real wave_sum(real v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
@@ -312,20 +327,20 @@ __device__ __forceinline__ double wave_sum(double v) {
 // (>= N), sh: LDS int.  *bad (LDS int) is set nonzero if a zero pivot was met.
 // All threads must call; ends with a barrier.  3 barriers per elimination step.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void wg_inverse(int N, const FastDiv &fd, double *a, int ld, double *prow, double *pcol,
-                                           double *rowk, int *ipiv, int *sh, int *bad) {
+__device__ __forceinline__ void wg_inverse(int N, const FastDiv &fd, real *a, int ld, real *prow, real *pcol,
+                                           real *rowk, int *ipiv, int *sh, int *bad) {
   const int tid = wg_tid(), lane = tid & 63, wave = tid >> 6;
   const int NN = N * N;
   for (int k = 0; k < N; ++k) {
     // (1) pivot search on column k, rows k..N-1 (first maximum, like idamax)
     if (wave == 0) {
-      double best = -1.0;
+      real best = -1.0;
       int bi = N;
       for (int i = k + lane; i < N; i += 64) {
-        const double v = fabs(a[i + k * ld]);
+        const real v = fabs(a[i + k * ld]);
         if (v > best) { best = v; bi = i; }
       }
-      const double wm = wave_max(best);
+      const real wm = wave_max(best);
       // lowest row index attaining the maximum
       int cand = (best == wm) ? bi : N;
 #pragma unroll
@@ -338,7 +353,7 @@ __device__ __forceinline__ void wg_inverse(int N, const FastDiv &fd, double *a, 
     }
     __syncthreads();
     const int p = sh[0];
-    const double d = 1.0 / a[p + k * ld];
+    const real d = 1.0 / a[p + k * ld];
     // (2) scaled pivot row -> prow, old row k -> rowk, pivot column (as after the swap) -> pcol
     for (int j = tid; j < 2 * N; j += kThreads) {
       if (j < N) {
@@ -353,7 +368,7 @@ __device__ __forceinline__ void wg_inverse(int N, const FastDiv &fd, double *a, 
     // (3) rank-1 update of every row but k (row p takes the old row k: the interchange);
     //     row k <- scaled pivot row
     for (int e0 = tid; e0 < NN; e0 += 4 * kThreads) {
-      double av[4], fv[4], pv[4];
+      real av[4], fv[4], pv[4];
       int ii[4], jj[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -370,11 +385,11 @@ __device__ __forceinline__ void wg_inverse(int N, const FastDiv &fd, double *a, 
         const int e = e0 + u * kThreads;
         if (e < NN) {
           const int i = ii[u], j = jj[u];
-          double v;
+          real v;
           if (i == k) {
             v = pv[u];
           } else {
-            const double aij = (i == p) ? rowk[j] : av[u];
+            const real aij = (i == p) ? rowk[j] : av[u];
             v = (j == k) ? (-fv[u] * d) : (aij - fv[u] * pv[u]);
           }
           a[i + j * ld] = v;
@@ -388,7 +403,7 @@ __device__ __forceinline__ void wg_inverse(int N, const FastDiv &fd, double *a, 
     const int p = ipiv[k];
     if (p != k) {
       for (int i = tid; i < N; i += kThreads) {
-        const double x = a[i + k * ld], y = a[i + p * ld];
+        const real x = a[i + k * ld], y = a[i + p * ld];
         a[i + k * ld] = y;
         a[i + p * ld] = x;
       }
@@ -405,7 +420,7 @@ __device__ __forceinline__ void wg_inverse(int N, const FastDiv &fd, double *a, 
 // not yet used as pivots; rows are never moved, the permutation is undone when the result is
 // written back (inv(A)[k][p_j] = S[p_k][j]).  Per elimination step: one wave-level max + ballot in
 // the wave that owns column k, ONE workgroup barrier (pivot column / index / reciprocal travel
-// through double-buffered LDS slots), CW readlane broadcasts of the pivot row and CW FMAs per lane.
+// through real-buffered LDS slots), CW readlane broadcasts of the pivot row and CW FMAs per lane.
 // a: column-major buffer (ld) holding the matrix on entry and the inverse on exit.
 // pcol: LDS, >= 2*64 doubles; shd: LDS, >= 4 doubles; ipiv: LDS ints >= 64; bad: LDS int.
 // ---------------------------------------------------------------------------------------
@@ -415,12 +430,18 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   hi = __builtin_amdgcn_readlane(hi, l);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float readlane_f64(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+// sign/exponent/leading mantissa bits of |v| as an ordered integer (the pivot search key of wg_inverse_reg)
+__device__ __forceinline__ int abs_key(double v) { return __double2hiint(fabs(v)); }
+__device__ __forceinline__ int abs_key(float v) { return __float_as_int(fabsf(v)); }
 
-__device__ __forceinline__ void wg_inverse_reg(int N, double *a, int ld, double *pcol, double *shd, int *ipiv,
+__device__ __forceinline__ void wg_inverse_reg(int N, real *a, int ld, real *pcol, real *shd, int *ipiv,
                                                int *bad) {
   constexpr int CW = 64 / kWaves;
   const int lane = wg_lane(), wave = wg_wave();
-  double v[CW];
+  real v[CW];
 #pragma unroll
   for (int c = 0; c < CW; ++c) {
     const int col = CW * wave + c;
@@ -439,31 +460,31 @@ __device__ __forceinline__ void wg_inverse_reg(int N, double *a, int ld, double 
           // pivot = first row whose |a| has the largest HIGH WORD (sign/exponent/20 mantissa bits):
           // within 2^-20 of the true maximum, which is all partial pivoting needs, and a 32-bit
           // integer wave reduction instead of a 64-bit one
-          const int ah = (!used && lane < N) ? __double2hiint(fabs(v[c])) : -1;
+          const int ah = (!used && lane < N) ? abs_key(v[c]) : -1;
           int mh = ah;
 #pragma unroll
           for (int off = 32; off > 0; off >>= 1) mh = max(mh, __shfl_xor(mh, off));
           unsigned long long mk = __ballot(ah == mh);
           int p = __ffsll((long long)mk) - 1;
-          const double m = fabs(readlane_f64(v[c], p));
-          const double piv = readlane_f64(v[c], p);
-          const double d = 1.0 / piv;
+          const real m = fabs(readlane_f64(v[c], p));
+          const real piv = readlane_f64(v[c], p);
+          const real d = 1.0 / piv;
           pcol[slot * 64 + lane] = v[c];
           if (lane == 0) {
             shd[2 * slot] = d;
-            shd[2 * slot + 1] = (double)p;
+            shd[2 * slot + 1] = (real)p;
             ipiv[k] = p;
             if (!(m > 0.0)) *bad = k + 1;
           }
         }
         __syncthreads();
-        const double d = shd[2 * slot];
+        const real d = shd[2 * slot];
         const int p = __builtin_amdgcn_readfirstlane((int)shd[2 * slot + 1]);
-        const double f = pcol[slot * 64 + lane];
+        const real f = pcol[slot * 64 + lane];
         const bool isp = (lane == p);
 #pragma unroll
         for (int cc = 0; cc < CW; ++cc) {
-          const double prow = readlane_f64(v[cc], p) * d;
+          const real prow = readlane_f64(v[cc], p) * d;
           v[cc] = isp ? prow : (v[cc] - f * prow);
         }
         if (wave == kp) v[c] = isp ? d : (-f * d);
@@ -483,11 +504,11 @@ __device__ __forceinline__ void wg_inverse_reg(int N, double *a, int ld, double 
 }
 
 // copy an N x N column-major block src(ld_s) -> dst(ld_d), all threads; loads batched by 4
-template <class PS, class PD>  // pointer types: LDS/generic double* or global gdouble*
+template <class PS, class PD>  // pointer types: LDS/generic real* or global gdouble*
 __device__ __forceinline__ void wg_copy_mat(int N, const FastDiv &fd, PS src, int ld_s, PD dst, int ld_d) {
   const int NN = N * N;
   for (int e0 = wg_tid(); e0 < NN; e0 += 4 * kThreads) {
-    double v[4];
+    real v[4];
     int o[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

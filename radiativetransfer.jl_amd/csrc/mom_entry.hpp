@@ -13,10 +13,10 @@ struct LayerArgs {
   int m_first;
   int nd, iface, first;
   int stagger;      // start offset step between CUs in 100 MHz ticks (persistent strip kernels), 0 = none
-  const double *tau, *varpi, *zw, *tau_sum;  // slices of layer z: tau[n], varpi[n], zw[k + K*n], tau_sum[n]
-  const double *Zpp, *Zmp;                   // [N,N,K,M] starting at moment m_first
-  double *comp[6];                           // R_mp, R_pm, T_pp, T_mm [N,N,S,M]; J0p, J0m [N,S,M], from m_first
-  double *scratch;                           // generic mode: per-workgroup slabs
+  const real *tau, *varpi, *zw, *tau_sum;  // slices of layer z: tau[n], varpi[n], zw[k + K*n], tau_sum[n]
+  const real *Zpp, *Zmp;                   // [N,N,K,M] starting at moment m_first
+  real *comp[6];                           // R_mp, R_pm, T_pp, T_mm [N,N,S,M]; J0p, J0m [N,S,M], from m_first
+  real *scratch;                           // generic mode: per-workgroup slabs
   int *info;
   // sweep mode (Nz_sweep > 0): ONE launch walks all layers of a unit before it moves to the next unit -- the composite
   // blocks a workgroup stored for layer z are the ones it loads for layer z + 1 (same CU, L2-resident), there is one
@@ -32,12 +32,12 @@ struct ZMix {
   int K, N;
   // Z(i,j) = sum_k w[k] Z_k(i,j), accumulated in k order (elemental_build walks the terms)
   __device__ __forceinline__ int terms() const { return K; }
-  __device__ __forceinline__ double weight(int k) const { return w[k]; }
-  __device__ __forceinline__ double basis(int k, int i, int j) const { return base[i + (size_t)j * N + (size_t)N * N * k]; }
+  __device__ __forceinline__ real weight(int k) const { return w[k]; }
+  __device__ __forceinline__ real basis(int k, int i, int j) const { return base[i + (size_t)j * N + (size_t)N * N * k]; }
 };
 
 // pitch: row pitch of the matrix blocks (N for the operator-level arrays, comp_pitch(N) for the scene-level state)
-__device__ __forceinline__ CompPtrs comp_ptrs(double *const comp[6], int N, int pitch, size_t pt) {
+__device__ __forceinline__ CompPtrs comp_ptrs(real *const comp[6], int N, int pitch, size_t pt) {
   const size_t blk = (size_t)pitch * N;
   CompPtrs g;
   g.R_mp = as_global(comp[0]) + blk * pt;
@@ -84,9 +84,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
       const int iface = a.Nz_sweep > 0 ? a.iface_z[z] : a.iface;
       const bool first = a.Nz_sweep > 0 ? (z == 0) : (a.first != 0);
       const size_t zo = (size_t)a.S * z;
-      const double tau = as_global(a.tau)[n + zo], varpi = as_global(a.varpi)[n + zo];
-      const double dtau = ldexp(tau, -nd);         // τ ./ 2^ndoubl   (rt_kernel.jl:244)
-      double expk = exp(-dtau / a.q.mu0);          // init_layer      (rt_kernel.jl:273)
+      const real tau = as_global(a.tau)[n + zo], varpi = as_global(a.varpi)[n + zo];
+      const real dtau = ldexp(tau, -nd);         // τ ./ 2^ndoubl   (rt_kernel.jl:244)
+      real expk = exp(-dtau / a.q.mu0);          // init_layer      (rt_kernel.jl:273)
       ZMix zpp{as_global(a.Zpp) + NN * a.K * mrel, as_global(a.zw) + (size_t)a.K * (n + zo), a.K, N};
       ZMix zmp{as_global(a.Zmp) + NN * a.K * mrel, as_global(a.zw) + (size_t)a.K * (n + zo), a.K, N};
 #ifdef MOM_DIAG_STAMPS
@@ -116,20 +116,20 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
 struct SurfArgs {
   DevStreams q;
   int S, iface;
-  double albedo;
-  const double *tau_tot;  // [S]
-  double *comp[6];        // slices of THIS moment
-  double *hdrJ;           // [N,S]   hdr_J0- of interaction_hdrf! for this moment
-  double *bhr_uw, *bhr_dw;  // [nS_out,S] (nS_out = the caller's nStokes; rows >= q.nS stay zero); written for m = 0
+  real albedo;
+  const real *tau_tot;  // [S]
+  real *comp[6];        // slices of THIS moment
+  real *hdrJ;           // [N,S]   hdr_J0- of interaction_hdrf! for this moment
+  real *bhr_uw, *bhr_dw;  // [nS_out,S] (nS_out = the caller's nStokes; rows >= q.nS stay zero); written for m = 0
   int nS_out;
-  double *scratch;
+  real *scratch;
   int *info;
   // surface type (include/momcore.h, mom_scene_set_surface): 0 = LambertianSurfaceScalar, 1 = BRDF matrix of this
   // moment (rpv / Ross-Li ...: create_surface_layer!(::AbstractSurfaceType), rpv_surface.jl:20-66), 2 =
   // LambertianSurfaceLegendre (spectrally varying albedo, lambertian_surface.jl:77-138)
   int kind, m;
-  const double *Rsurf;        // kind 1: [N,N] rho_m (column-major), factor 2 for m = 0 included
-  const double *albedo_spec;  // kind 2: [S]
+  const real *Rsurf;        // kind 1: [N,N] rho_m (column-major), factor 2 for m = 0 included
+  const real *albedo_spec;  // kind 2: [S]
 };
 
 // The surface as an added layer + the closing interaction (rt_run.jl:169-185), then interaction_hdrf!.
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_surface(SurfArgs a) {
   wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
   const int ld = c.ld;
   for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
-    const double att = exp(-a.tau_tot[pt] / a.q.mu0);
+    const real att = exp(-a.tau_tot[pt] / a.q.mu0);
     const int i_start = n * (a.q.imu0 - 1), i_end = n * a.q.imu0;
     if (a.kind == 1) {
       // R_surf = rho_m ; j0+ = I0 exp(-tau/mu0) at the sun rows ; j0- = mu0 (R_surf I0N) exp(-tau/mu0) ;
@@ -155,13 +155,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_surface(SurfArgs a) {
       }
       for (int i = wg_tid(); i < N; i += kThreads) {
         const bool in_sun = (i >= i_start) && (i < i_end);
-        double rI = 0.0;
+        real rI = 0.0;
         for (int k = 0; k < n; ++k) rI += a.Rsurf[i + (size_t)N * (i_start + k)] * a.q.I0[k];
         c.jp[i] = (in_sun ? a.q.I0[i - i_start] : 0.0) * att;
         c.jm[i] = (a.q.mu0 * rI) * att;
       }
     } else {
-      const double rho = 2 * ((a.kind == 2) ? a.albedo_spec[pt] : a.albedo);  // lambertian_surface.jl:37 / :97
+      const real rho = 2 * ((a.kind == 2) ? a.albedo_spec[pt] : a.albedo);  // lambertian_surface.jl:37 / :97
       for (int e = wg_tid(); e < N * N; e += kThreads) {
         int i, j;
         c.fd.split(e, i, j);
@@ -186,14 +186,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_surface(SurfArgs a) {
     // composite J0+ AFTER the surface interaction (still in c.Jp), then the m = 0 flux sums of the BHR
     wg_matvec(c, ElP{c.r, ld}, c.Jp, c.v1);
     for (int i = wg_tid(); i < N; i += kThreads) {
-      const double hj = c.v1[i] + c.jm[i];
+      const real hj = c.v1[i] + c.jm[i];
       c.v1[i] = hj;
       a.hdrJ[(size_t)N * pt + i] = hj;
     }
     __syncthreads();
     if (a.m == 0 && wg_tid() < a.nS_out) {
       const int k = wg_tid();
-      double up = 0.0, dw = 0.0;
+      real up = 0.0, dw = 0.0;
       if (k < n)  // components beyond the reduced problem's (I,Q) have exactly zero sums for m = 0
         for (int j = k; j < N; j += n) {
           up += c.v1[j] * c.wt[j] * c.mu[j];

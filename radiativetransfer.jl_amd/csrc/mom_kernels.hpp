@@ -39,7 +39,19 @@ namespace MOM_NS {
 // B = 0): the bound is ABSOLUTE, i.e. against the O(1) diagonal, while the off-diagonal (diffuse) elements of t++ are
 // themselves only of order rho = sqrt(beta) in a doubling step; dropping B there would cost them a relative rho (up to
 // 4e-9), whereas the tail after B is of relative size rho^3 <= 2e-13.
-__device__ const double kNeumannThr2[32] = {
+#ifdef MOM_REAL_IS_FLOAT
+// Float32 build: beta^p / (1 - beta) <= 2^-26 (a quarter of the f32 epsilon), first-order term always kept
+__device__ const real kNeumannThr2[32] = {
+    0.000000000e+00f, 1.489934232e-08f, 6.045524421e-06f, 1.213959655e-04f,
+    7.320204349e-04f, 2.419753539e-03f, 5.676200029e-03f, 1.075029447e-02f,
+    1.765854019e-02f, 2.625958398e-02f, 3.632882835e-02f, 4.761229038e-02f,
+    5.985942527e-02f, 7.284045577e-02f, 8.635379794e-02f, 1.002277241e-01f,
+    1.143189633e-01f, 1.285098733e-01f, 1.427051184e-01f, 1.568283537e-01f,
+    1.708191621e-01f, 1.846303449e-01f, 1.982255889e-01f, 2.115774909e-01f,
+    2.246659062e-01f, 2.374765770e-01f, 2.500000000e-01f, 2.622304965e-01f,
+    2.741654486e-01f, 2.858046753e-01f, 2.971499218e-01f, 3.082044441e-01f};
+#else
+__device__ const real kNeumannThr2[32] = {
     0.0 /* p = 1 only for B = 0 */, 1.38777877561156685e-17, 5.77492213356056750e-12, 3.72517661162420568e-09,
     1.80656771560518035e-07, 2.40186660760962690e-06, 1.52417448931310540e-05, 6.09157135028591602e-05,
     1.78874927371965362e-04, 4.23309807394842467e-04, 8.56292603484697687e-04, 1.53988783074545245e-03,
@@ -48,25 +60,26 @@ __device__ const double kNeumannThr2[32] = {
     2.44051136922726897e-02, 2.88492300492497432e-02, 3.36098586497813809e-02, 3.86607216385354419e-02,
     4.39753040322414940e-02, 4.95274191527264318e-02, 5.52916244610413068e-02, 6.12435157546498479e-02,
     6.73599244364155580e-02, 7.36190389296255826e-02, 8.00004677634075928e-02, 8.64852586225294262e-02};
+#endif
 
 struct DevStreams {
-  const double *mu;  // [N] qp_μN
-  const double *wt;  // [N] wt_μN
-  const double *sg;  // [N] +-1 (see above)
-  double I0[4];
-  double D[4];
+  const real *mu;  // [N] qp_μN
+  const real *wt;  // [N] wt_μN
+  const real *sg;  // [N] +-1 (see above)
+  real I0[4];
+  real D[4];
   int N, nS, imu0;  // imu0: 1-based stream index of the sun
   int inv_mode;     // 0 auto, 1 force pivoted Gauss-Jordan
   int regular;      // qp_μN repeats each stream value nS times (always true for the reference's QuadPoints)
-  double mu0;
+  real mu0;
 };
 
 // workgroup context: where this workgroup's matrices and vectors live
 struct Ctx {
   int N, Np, nc, ld, ldv;  // nc: stored columns per buffer (cols_for)
   FastDiv fd;
-  double *r, *t, *P, *Q, *X;  // padded N x N buffers (X: spare, generic mode only)
-  double *jp, *jm, *j1p, *j1m, *v1, *v2, *Jp, *Jm, *prow, *pcol, *rowk, *ei, *mu, *wt, *sg, *part, *thr;
+  real *r, *t, *P, *Q, *X;  // padded N x N buffers (X: spare, generic mode only)
+  real *jp, *jm, *j1p, *j1m, *v1, *v2, *Jp, *Jm, *prow, *pcol, *rowk, *ei, *mu, *wt, *sg, *part, *thr;
   int *ipiv, *sh, *bad;
   int inv_mode;
 };
@@ -95,14 +108,14 @@ __host__ __device__ inline size_t vec_area_doubles(int N) {
   return (size_t)(kNumVec * np_for(N) + 32) + (size_t)((np_for(N) + 4 + 1) / 2);
 }
 __host__ __device__ inline size_t lds_bytes(int N, bool lds_mats) {
-  size_t b = vec_area_doubles(N) * sizeof(double);
-  if (lds_mats) b += 4 * mat_elems(N) * sizeof(double);
-  else if (N > 64) b += (size_t)kBigTileDoubles * sizeof(double);
+  size_t b = vec_area_doubles(N) * sizeof(real);
+  if (lds_mats) b += 4 * mat_elems(N) * sizeof(real);
+  else if (N > 64) b += (size_t)kBigTileDoubles * sizeof(real);
   return b;
 }
 
 template <bool LDSM>
-__device__ __forceinline__ void make_ctx(Ctx &c, int N, int inv_mode, double *smem, double *gscratch) {
+__device__ __forceinline__ void make_ctx(Ctx &c, int N, int inv_mode, real *smem, real *gscratch) {
   c.N = N;
   c.Np = np_for(N);
   c.nc = cols_for(N);
@@ -111,7 +124,7 @@ __device__ __forceinline__ void make_ctx(Ctx &c, int N, int inv_mode, double *sm
   c.fd.init(N);
   c.inv_mode = inv_mode;
   const size_t msz = mat_elems(N);
-  double *p = smem;
+  real *p = smem;
   if (LDSM) {
     c.r = p; c.t = p + msz; c.P = p + 2 * msz; c.Q = p + 3 * msz; c.X = nullptr;
     p += 4 * msz;
@@ -151,7 +164,7 @@ __device__ __forceinline__ void zero_padding(const Ctx &c) {
 }
 
 // restore the zero padding of one buffer after it was used as scratch (only matters if N % 4 != 0)
-__device__ __forceinline__ void rezero_padding(const Ctx &c, double *buf) {
+__device__ __forceinline__ void rezero_padding(const Ctx &c, real *buf) {
   const int N = c.N, Np = c.nc, ld = c.ld;
   if (N % 4 == 0) return;
   const int padr = ld - N;
@@ -168,16 +181,16 @@ __device__ __forceinline__ void rezero_padding(const Ctx &c, double *buf) {
 
 // element functor of a PADDED buffer (no bounds checks)
 struct ElP {
-  const double *p; int ld;
-  __device__ __forceinline__ double operator()(int i, int j) const { return p[i + j * ld]; }
-  template <int LD> __device__ __forceinline__ double at(int i, int j) const { return p[i + j * LD]; }
+  const real *p; int ld;
+  __device__ __forceinline__ real operator()(int i, int j) const { return p[i + j * ld]; }
+  template <int LD> __device__ __forceinline__ real at(int i, int j) const { return p[i + j * LD]; }
   __device__ __forceinline__ void launder() { asm volatile("" : "+v"(p)); }
 };
 // diag(sg) * padded buf * diag(sg)   (sg padded with anything finite)
 struct ElSigP {
-  const double *p; const double *sg; int ld;
-  __device__ __forceinline__ double operator()(int i, int j) const { return sg[i] * sg[j] * p[i + j * ld]; }
-  template <int LD> __device__ __forceinline__ double at(int i, int j) const { return sg[i] * sg[j] * p[i + j * LD]; }
+  const real *p; const real *sg; int ld;
+  __device__ __forceinline__ real operator()(int i, int j) const { return sg[i] * sg[j] * p[i + j * ld]; }
+  template <int LD> __device__ __forceinline__ real at(int i, int j) const { return sg[i] * sg[j] * p[i + j * LD]; }
   __device__ __forceinline__ void launder() { asm volatile("" : "+v"(p), "+v"(sg)); }
 };
 template <> struct lds_operand<ElP> { static constexpr bool value = true; };
@@ -185,33 +198,33 @@ template <> struct lds_operand<ElSigP> { static constexpr bool value = true; };
 // element functor of an unpadded (global) array with bounds checks
 struct El {
   const gdouble *p; int ld, N;
-  __device__ __forceinline__ double operator()(int i, int j) const { return (i < N && j < N) ? p[i + j * ld] : 0.0; }
+  __device__ __forceinline__ real operator()(int i, int j) const { return (i < N && j < N) ? p[i + j * ld] : 0.0; }
   // as a phase-matrix source of elemental_build: one term of weight 1
   __device__ __forceinline__ int terms() const { return 1; }
-  __device__ __forceinline__ double weight(int) const { return 1.0; }
-  __device__ __forceinline__ double basis(int, int i, int j) const { return p[i + j * ld]; }
+  __device__ __forceinline__ real weight(int) const { return 1.0; }
+  __device__ __forceinline__ real basis(int, int i, int j) const { return p[i + j * ld]; }
 };
-struct ElZero { __device__ __forceinline__ double operator()(int, int) const { return 0.0; } };
+struct ElZero { __device__ __forceinline__ real operator()(int, int) const { return 0.0; } };
 struct ElEye {
   int N;
-  __device__ __forceinline__ double operator()(int i, int j) const { return (i == j && i < N) ? 1.0 : 0.0; }
+  __device__ __forceinline__ real operator()(int i, int j) const { return (i == j && i < N) ? 1.0 : 0.0; }
 };
 
 // y = M x ; all threads; ends with barrier
 template <class FM>
-__device__ __forceinline__ void wg_matvec(const Ctx &c, FM M, const double *x, double *y) {
+__device__ __forceinline__ void wg_matvec(const Ctx &c, FM M, const real *x, real *y) {
   const int N = c.N, lane = wg_lane(), wave = wg_wave();
   const int chunk = (N + kWaves - 1) / kWaves;
   const int k0 = wave * chunk, k1 = min(N, k0 + chunk);
   for (int i = lane; i < N; i += 64) {
-    double s = 0.0;
+    real s = 0.0;
 #pragma unroll 4
     for (int k = k0; k < k1; ++k) s += M(i, k) * x[k];
     c.part[wave * c.ldv + i] = s;
   }
   __syncthreads();
   for (int i = wg_tid(); i < N; i += kThreads) {
-    double s = 0.0;
+    real s = 0.0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) s += c.part[w * c.ldv + i];
     y[i] = s;
@@ -222,14 +235,14 @@ __device__ __forceinline__ void wg_matvec(const Ctx &c, FM M, const double *x, d
 // dst(i,j) <- f(i, j, sum_k A(i,k) B(k,j), dst_old(i,j)); dst may be an operand of A/B.
 // LDS mode: true in place (SYNC); generic mode: written to the spare buffer, then swapped.
 template <bool LDSM, class FA, class FB, class FV>
-__device__ __forceinline__ void gemm_to(Ctx &c, double *&dst, FA A, FB B, FV f) {
+__device__ __forceinline__ void gemm_to(Ctx &c, real *&dst, FA A, FB B, FV f) {
   const int N = c.N, ld = c.ld;
-  double *d = dst;
+  real *d = dst;
   if (LDSM) {
-    wg_gemm<true>(N, A, B, [=](int i, int j, double v) { d[i + j * ld] = f(i, j, v, d[i + j * ld]); });
+    wg_gemm<true>(N, A, B, [=](int i, int j, real v) { d[i + j * ld] = f(i, j, v, d[i + j * ld]); });
   } else {
-    double *s = c.X;
-    wg_gemm<false, !LDSM>(N, A, B, [=](int i, int j, double v) { s[i + j * ld] = f(i, j, v, d[i + j * ld]); });
+    real *s = c.X;
+    wg_gemm<false, !LDSM>(N, A, B, [=](int i, int j, real v) { s[i + j * ld] = f(i, j, v, d[i + j * ld]); });
     c.X = d;
     dst = s;
   }
@@ -238,7 +251,7 @@ __device__ __forceinline__ void gemm_to(Ctx &c, double *&dst, FA A, FB B, FV f) 
 
 // smallest p in 1..32 with beta2 <= thr[p-1] (thr: the table above, copied to LDS by the prologue),
 // 1000 if none (or NaN): binary search, 5 dependent LDS reads.
-__device__ __forceinline__ int neumann_terms(const double *thr, double beta2) {
+__device__ __forceinline__ int neumann_terms(const real *thr, real beta2) {
   if (!(beta2 <= thr[31])) return 1000;
   int lo = 0, hi = 31;  // invariant: beta2 <= thr[hi]
 #pragma unroll
@@ -250,7 +263,7 @@ __device__ __forceinline__ int neumann_terms(const double *thr, double beta2) {
 }
 
 // the same for p <= 12 without memory: thresholds as immediates (the strip chains' range); 1000 beyond or NaN
-__device__ __forceinline__ int neumann_terms_12(double beta2) {
+__device__ __forceinline__ int neumann_terms_12(real beta2) {
   if (!(beta2 <= 1.53988783074545245e-03)) return 1000;
   int p = 1;
   p += beta2 > 0.0; p += beta2 > 1.38777877561156685e-17; p += beta2 > 5.77492213356056750e-12;
@@ -262,12 +275,12 @@ __device__ __forceinline__ int neumann_terms_12(double beta2) {
 
 // lane-partial sum of squares -> part[wave] (call before the barrier that follows the GEMM);
 // read back with wg_sumsq_get after that barrier.
-__device__ __forceinline__ void wg_sumsq_put(const Ctx &c, double ss) {
+__device__ __forceinline__ void wg_sumsq_put(const Ctx &c, real ss) {
   ss = wave_sum(ss);
   if (wg_lane() == 0) c.part[wg_wave()] = ss;
 }
-__device__ __forceinline__ double wg_sumsq_get(const Ctx &c) {
-  double b2 = 0.0;
+__device__ __forceinline__ real wg_sumsq_get(const Ctx &c) {
+  real b2 = 0.0;
 #pragma unroll
   for (int w = 0; w < kWaves; ++w) b2 += c.part[w];
   return b2;
@@ -280,34 +293,34 @@ struct CompPtrs {
            // comp_pitch(N) in the scene-level composite state
 };
 // The scene-level composite blocks use a row pitch of a whole number of 128-byte lines: the strip chains store
-// 16-double (128-byte) column segments straight from the accumulators, and with the natural pitch N three
+// 16-real (128-byte) column segments straight from the accumulators, and with the natural pitch N three
 // quarters of them would straddle two cache lines (partial-line HBM writes).
 __host__ __device__ inline int comp_pitch(int N) { return 16 * ((N + 15) / 16); }
 
 // ---------------------------------------------------------------------------------------
 // C(i,j) <- epi(i, j, sum_k A(i,k) B(k,j)) for 64 < N <= 256 (generic mode): the operands live in global memory
 // (per-workgroup scratch slab or the composite layer); each k panel of 8 is staged once through LDS with coalesced
-// loads and feeds 8 waves x 4 x 4 MFMA tiles (64 x 64 outputs per wave, 128 x 256 per pass), double-buffered: the
+// loads and feeds 8 waves x 4 x 4 MFMA tiles (64 x 64 outputs per wave, 128 x 256 per pass), real-buffered: the
 // loads of panel p+1 are in flight while panel p is multiplied, one barrier per panel.  Against the element-functor
 // loop of wg_gemm_n (every MFMA operand a separate 8-byte global load) this reads each operand element once per pass.
 // All threads must call; C must not alias A or B; ends WITHOUT a barrier after the epilogue (callers add theirs).
 // ---------------------------------------------------------------------------------------
 template <class FA, class FB, class FE>
 __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
-  double *tA = mom_smem + vec_area_doubles(N);
-  double *tB = tA + 2 * kBigKB * kBigLdA;
+  real *tA = mom_smem + vec_area_doubles(N);
+  real *tB = tA + 2 * kBigKB * kBigLdA;
   const int tid = wg_tid(), lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
   const int wr = (wave >> 2) & 1, wc = wave & 3;  // 2 x 4 wave grid (8-wave build only, see wg_gemm_nc)
   const int Np = np_for(N);
   const int P = (N + kBigKB - 1) / kBigKB;
   // B panel element of this thread: 8 k x 256 columns = 2048 elements, 4 per thread; A panel: 128 rows x 8 k = 1024, 2 per thread
   for (int row0 = 0; row0 < N; row0 += kBigRows) {
-    d4 acc[4][4];
+    r4 acc[4][4];
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-      for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = (d4){0.0, 0.0, 0.0, 0.0};
-    double ra[2], rb[4];
+      for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = (r4){0.0, 0.0, 0.0, 0.0};
+    real ra[2], rb[4];
     auto fetch = [&](int p) {
       const int k0 = p * kBigKB;
 #pragma unroll
@@ -324,7 +337,7 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
       }
     };
     auto stash = [&](int stage) {
-      double *sa = tA + stage * kBigKB * kBigLdA, *sb = tB + stage * kBigCols * kBigLdB;
+      real *sa = tA + stage * kBigKB * kBigLdA, *sb = tB + stage * kBigCols * kBigLdB;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int e = tid + kThreads * u, row = e & (kBigRows - 1), kk = e >> 7;
@@ -342,11 +355,11 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
     __syncthreads();
     for (int p = 0; p < P; ++p) {
       if (p + 1 < P) fetch(p + 1);
-      const double *sa = tA + (p & 1) * kBigKB * kBigLdA + 64 * wr + lr + lq * kBigLdA;
-      const double *sb = tB + (p & 1) * kBigCols * kBigLdB + lq + (64 * wc + lr) * kBigLdB;
+      const real *sa = tA + (p & 1) * kBigKB * kBigLdA + 64 * wr + lr + lq * kBigLdA;
+      const real *sb = tB + (p & 1) * kBigCols * kBigLdB + lq + (64 * wc + lr) * kBigLdB;
 #pragma unroll
       for (int ks = 0; ks < kBigKB / 4; ++ks) {
-        double a[4], b[4];
+        real a[4], b[4];
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) a[ti] = sa[16 * ti + 4 * ks * kBigLdA];
 #pragma unroll
@@ -355,7 +368,7 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
           for (int tj = 0; tj < 4; ++tj)
-            if (64 * wc + 16 * tj < Np) acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti], b[tj], acc[ti][tj], 0, 0, 0);
+            if (64 * wc + 16 * tj < Np) acc[ti][tj] = mma16(a[ti], b[tj], acc[ti][tj]);
       }
       if (p + 1 < P) stash((p + 1) & 1);
       __syncthreads();
@@ -367,7 +380,7 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
         const int col = 64 * wc + 16 * tj + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int rw = row0 + 64 * wr + 16 * ti + lq + 4 * r;
+          const int rw = row0 + 64 * wr + 16 * ti + cd_row(lq, r);
           if (rw < N && col < NC) epi(rw, col, acc[ti][tj][r]);
         }
       }
@@ -383,13 +396,13 @@ namespace MOM_NS {
 // as MFMA A operand.  See the header comment for the series bound.  Ends with a barrier.
 // ---------------------------------------------------------------------------------------
 template <bool LDSM, class FT>
-__device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob, double beta2) {
+__device__ __forceinline__ void times_inv(Ctx &c, FT T, real *&Bb, real *&Ob, real beta2) {
   const int N = c.N, ld = c.ld, NN = N * N;
   const int p = (c.inv_mode == 1) ? 1000 : neumann_terms(c.thr, beta2);
   MOM_STAMP(6);
   if (p <= 4) {
     // Horner: A_1 = T, A_{k+1} = T + A_k B
-    double *o = Ob;
+    real *o = Ob;
     if (p == 1) {
       for (int e = wg_tid(); e < NN; e += kThreads) {
         int i, j;
@@ -398,15 +411,15 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob
       }
       __syncthreads();
     } else {
-      wg_gemm<false, !LDSM>(N, T, ElP{Bb, ld}, [=](int i, int j, double v) { o[i + j * ld] = T(i, j) + v; });
+      wg_gemm<false, !LDSM>(N, T, ElP{Bb, ld}, [=](int i, int j, real v) { o[i + j * ld] = T(i, j) + v; });
       __syncthreads();
       for (int k = 3; k <= p; ++k)
-        gemm_to<LDSM>(c, Ob, ElP{Ob, ld}, ElP{Bb, ld}, [=](int i, int j, double v, double) { return T(i, j) + v; });
+        gemm_to<LDSM>(c, Ob, ElP{Ob, ld}, ElP{Bb, ld}, [=](int i, int j, real v, real) { return T(i, j) + v; });
     }
   } else if (p <= 32) {
     // G = (I + B)(I + B^2)(I + B^4)... ; Ob <- T G
     {
-      double *o = Ob, *b = Bb;
+      real *o = Ob, *b = Bb;
       for (int e = wg_tid(); e < NN; e += kThreads) {
         int i, j;
         c.fd.split(e, i, j);
@@ -415,12 +428,12 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob
       __syncthreads();
     }
     for (int terms = 2; terms < p; terms *= 2) {
-      gemm_to<LDSM>(c, Bb, ElP{Bb, ld}, ElP{Bb, ld}, [=](int, int, double v, double) { return v; });
-      gemm_to<LDSM>(c, Ob, ElP{Ob, ld}, ElP{Bb, ld}, [=](int, int, double v, double old) { return old + v; });
+      gemm_to<LDSM>(c, Bb, ElP{Bb, ld}, ElP{Bb, ld}, [=](int, int, real v, real) { return v; });
+      gemm_to<LDSM>(c, Ob, ElP{Ob, ld}, ElP{Bb, ld}, [=](int, int, real v, real old) { return old + v; });
     }
-    gemm_to<LDSM>(c, Ob, T, ElP{Ob, ld}, [=](int, int, double v, double) { return v; });
+    gemm_to<LDSM>(c, Ob, T, ElP{Ob, ld}, [=](int, int, real v, real) { return v; });
   } else {
-    double *b = Bb, *o = Ob;
+    real *b = Bb, *o = Ob;
     for (int e = wg_tid(); e < NN; e += kThreads) {
       int i, j;
       c.fd.split(e, i, j);
@@ -429,7 +442,7 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, double *&Bb, double *&Ob
     __syncthreads();
     if (N <= 64) wg_inverse_reg(N, b, ld, c.part, c.prow, c.ipiv, c.bad);  // part: >= 128 doubles (2*kWaves*ldv)
     else wg_inverse(N, c.fd, b, ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);
-    wg_gemm<false, !LDSM>(N, T, ElP{b, ld}, [=](int i, int j, double v) { o[i + j * ld] = v; });
+    wg_gemm<false, !LDSM>(N, T, ElP{b, ld}, [=](int i, int j, real v) { o[i + j * ld] = v; });
     __syncthreads();
   }
 }
@@ -447,7 +460,7 @@ __device__ __forceinline__ void load_streams(const Ctx &c, const DevStreams &q) 
 }
 
 template <bool LDSM>
-__device__ __forceinline__ void wg_prologue(Ctx &c, const DevStreams &q, double *smem, double *gscratch) {
+__device__ __forceinline__ void wg_prologue(Ctx &c, const DevStreams &q, real *smem, real *gscratch) {
   make_ctx<LDSM>(c, q.N, q.inv_mode, smem, gscratch);
   zero_padding<LDSM>(c);
   __syncthreads();
@@ -460,11 +473,11 @@ __device__ __forceinline__ void wg_prologue(Ctx &c, const DevStreams &q, double 
 // element functors for this spectral point.  Ends with a barrier.
 // ---------------------------------------------------------------------------------------
 template <class FZP, class FZM>
-__device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &q, int m, int nd, double tau_sum,
-                                                double dtau, double varpi, FZP Zpp, FZM Zmp) {
+__device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &q, int m, int nd, real tau_sum,
+                                                real dtau, real varpi, FZP Zpp, FZM Zmp) {
   const int N = c.N, ld = c.ld, n = q.nS;
-  const double wdiv = (m == 0) ? 2.0 : 4.0;
-  const double wct02 = (m == 0) ? 0.5 : 0.25;
+  const real wdiv = (m == 0) ? 2.0 : 4.0;
+  const real wct02 = (m == 0) ? 0.5 : 0.25;
   // exp(-dtau/mu_i) per stream and 1 - exp(-dtau (1/mu_i + 1/mu_j)) per PAIR OF STREAMS: the Stokes
   // components of a stream share mu, so the nS^2-fold repeated exponentials of get_elem_rt!
   // (elemental.jl:176) are evaluated once (same expression, same operands: identical values).
@@ -475,7 +488,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   FastDiv fq;
   fq.init(Nq);
   // per stream pair (iq, jq): E = 1 - exp(..), F1 = mu_j/(mu_i+mu_j), F2 = mu_j/(mu_i-mu_j); the Q buffer is free here
-  double *E = c.Q, *F1 = c.Q + Nq * Nq, *F2 = c.Q + 2 * Nq * Nq;
+  real *E = c.Q, *F1 = c.Q + Nq * Nq, *F2 = c.Q + 2 * Nq * Nq;
   // two-term phase matrices (Rayleigh + one aerosol type): the 32 basis loads of this thread's first 8 elements go
   // out before the tables are built and are consumed after them
   // Element enumeration: lane = row (in blocks of 64), wave = column (strided by kWaves).  A thread's elements share
@@ -487,7 +500,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   const int CS = (N + kWaves - 1) / kWaves;
   const int slots = kRowLanes ? ((N + 63) >> 6) * CS : (N * N + kThreads - 1) / kThreads;
   const bool pre = Zpp.terms() == 2;
-  double bp0[8], bm0[8], bp1[8], bm1[8];
+  real bp0[8], bm0[8], bp1[8], bm1[8];
   int ii[8], jj[8];
   bool ok[8];
   auto coords = [&](int s0) {
@@ -530,7 +543,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
     for (int e = wg_tid(); e < Nq * Nq; e += kThreads) {
       int iq, jq;
       fq.split(e, iq, jq);
-      const double mui = c.mu[iq * ns], muj = c.mu[jq * ns];
+      const real mui = c.mu[iq * ns], muj = c.mu[jq * ns];
       E[e] = 1 - exp(-dtau * ((1 / mui) + (1 / muj)));
       F1[e] = muj / (mui + muj);
       F2[e] = muj / (mui - muj);
@@ -538,9 +551,9 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   __syncthreads();
   MOM_STAMP(46);
   const int i_start = n * (q.imu0 - 1), i_end = n * q.imu0;
-  double *ZS = c.P;  // mixed Z++ / Z-+ of the sun-block columns, [N x nS] each (P is free here)
+  real *ZS = c.P;  // mixed Z++ / Z-+ of the sun-block columns, [N x nS] each (P is free here)
   for (int s0 = 0; s0 < slots; s0 += 8) {
-    double zp[8], zm[8];
+    real zp[8], zm[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       zp[u] = 0.0;
@@ -549,7 +562,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
     // Z = sum_k w_k Z_k, accumulated in k order
     if (pre) {
       if (s0 != 0) issue_z2(s0);
-      const double wp0 = Zpp.weight(0), wm0 = Zmp.weight(0), wp1 = Zpp.weight(1), wm1 = Zmp.weight(1);
+      const real wp0 = Zpp.weight(0), wm0 = Zmp.weight(0), wp1 = Zpp.weight(1), wm1 = Zmp.weight(1);
 #pragma unroll
       for (int u = 0; u < 8; ++u)
         if (ok[u]) {
@@ -562,7 +575,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
       // the (run-time) sum over scatterer types is the OUTER loop: the 16 basis loads of a term are in flight together
       coords(s0);
       for (int k = 0; k < Zpp.terms(); ++k) {
-        const double wp = Zpp.weight(k), wm = Zmp.weight(k);
+        const real wp = Zpp.weight(k), wm = Zmp.weight(k);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           if (ok[u]) {
@@ -585,15 +598,15 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
             ZS[i + (j - i_start) * N] = zp[u];
             ZS[i + (n + j - i_start) * N] = zm[u];
           }
-          const double mui = c.mu[i], muj = c.mu[j];
-          const double wj = c.v1[j];
+          const real mui = c.mu[i], muj = c.mu[j];
+          const real wj = c.v1[j];
           int iq, jq, dummy;
           fs.split(i, dummy, iq);
           fs.split(j, dummy, jq);
           const int pq = iq + jq * Nq;
-          double rr, tt;
+          real rr, tt;
           if (wj > 1.e-8) {
-            double Epq, F1pq;
+            real Epq, F1pq;
             if constexpr (TAB) {
               Epq = E[pq];
               F1pq = F1[pq];
@@ -609,7 +622,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
                 tt = 0.0;
               }
             } else {
-              double F2pq;
+              real F2pq;
               if constexpr (TAB) F2pq = F2[pq];
               else F2pq = muj / (mui - muj);
               tt = varpi * zp[u] * F2pq * wj * (c.ei[i] - c.ei[j]);
@@ -630,16 +643,16 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   }
   __syncthreads();
   MOM_STAMP(47);
-  const double mus = c.mu[i_start];
-  const double att = exp(-tau_sum / mus);
+  const real mus = c.mu[i_start];
+  const real att = exp(-tau_sum / mus);
   for (int i = wg_tid(); i < N; i += kThreads) {
-    double zp = 0.0, zm = 0.0;
+    real zp = 0.0, zm = 0.0;
     for (int k = 0; k < n; ++k) {
       zp += ZS[i + k * N] * q.I0[k];
       zm += ZS[i + (n + k) * N] * q.I0[k];
     }
-    const double mui = c.mu[i];
-    double jp, jm;
+    const real mui = c.mu[i];
+    real jp, jm;
     int iq, sq, dummy;
     fs.split(i, dummy, iq);
     fs.split(i_start, dummy, sq);
@@ -668,7 +681,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
 // expk: this point's exp(-dtau/mu0) (returned squared nd times).  Ends with a barrier.
 // ---------------------------------------------------------------------------------------
 template <bool LDSM, int KS = 0>
-__device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
+__device__ __forceinline__ real doubling_run(Ctx &c, int nd, real expk) {
   const int N = c.N, ld = c.ld;
   if (nd == 0) return expk;
   // "ride": the source vectors travel as columns N, N+1 of the B operand r (buffer padding), so
@@ -691,11 +704,11 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
       if constexpr (LDSM && KS > 0) doubling_rr_strip<KS>(c);
       __syncthreads();
     } else {
-      double *r = c.r, *P = c.P;
-      double ss = 0.0;
+      real *r = c.r, *P = c.P;
+      real ss = 0.0;
       MOM_STAMP(0);
       // P = r r (+ r j0+, r j0- riding) ; Q = t (I - r r)^-1  (tt⁺⁺_gp_refl)   (doubling.jl:44-48)
-      wg_gemm_nc<false, !LDSM>(N, ride ? N + 2 : N, ElP{r, ld}, ElP{r, ld}, [=, &ss](int i, int j, double v) {
+      wg_gemm_nc<false, !LDSM>(N, ride ? N + 2 : N, ElP{r, ld}, ElP{r, ld}, [=, &ss](int i, int j, real v) {
         P[i + j * ld] = v;
         if (j < N) ss += v * v;
       });
@@ -704,7 +717,7 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
       MOM_STAMP(1);
     }
     MOM_STAMP(70);
-    const double beta2 = wg_sumsq_get(c);
+    const real beta2 = wg_sumsq_get(c);
     if constexpr (LDSM && KS > 0) {
       // strip-chained step (mom_strip.hpp): the series, A r, (A r) t and A t in one barrier-free MFMA stream
       if (strip_ok) {
@@ -718,16 +731,16 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
     }
     if (ride) {
       // w1 = j1- + r j0+ ; w2 = j0+ + r j1-   with j1± = j0± expk   (:51-60)
-      double *r = c.r, *P = c.P;
+      real *r = c.r, *P = c.P;
       for (int i = wg_tid(); i < N; i += kThreads) {
-        const double rjp = P[i + N * ld], rjm = P[i + (N + 1) * ld];
+        const real rjp = P[i + N * ld], rjm = P[i + (N + 1) * ld];
         r[i + N * ld] = c.jm[i] * expk + rjp;
         r[i + (N + 1) * ld] = c.jp[i] + expk * rjm;
       }
     }
     times_inv<LDSM>(c, ElP{c.t, ld}, c.P, c.Q, beta2);
     MOM_STAMP(2);
-    double *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
+    real *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
     if (!ride) {
       // j1± = j0± expk                                       (:51,:54)
       for (int i = wg_tid(); i < N; i += kThreads) {
@@ -750,14 +763,14 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
     }
     MOM_STAMP(3);
     // P = Q r  (+ Q w1, Q w2 riding)
-    wg_gemm_nc<false, !LDSM>(N, ride ? N + 2 : N, ElP{Q, ld}, ElP{r, ld}, [=](int i, int j, double v) { P[i + j * ld] = v; });
+    wg_gemm_nc<false, !LDSM>(N, ride ? N + 2 : N, ElP{Q, ld}, ElP{r, ld}, [=](int i, int j, real v) { P[i + j * ld] = v; });
     __syncthreads();
     MOM_STAMP(4);
     if (ride) {
       // j0- += Q w1 (:57) ; j0+ = j1+ + Q w2 (:60); refresh the riding columns for the next step
       for (int i = wg_tid(); i < N; i += kThreads) {
-        const double jm = c.jm[i] + P[i + N * ld];
-        const double jp = c.jp[i] * expk + P[i + (N + 1) * ld];
+        const real jm = c.jm[i] + P[i + N * ld];
+        const real jp = c.jp[i] * expk + P[i + (N + 1) * ld];
         c.jm[i] = jm;
         c.jp[i] = jp;
         r[i + N * ld] = jp;
@@ -768,13 +781,13 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
     // r = r + P t (:64) ; t = Q t (:67)
     if (LDSM) {
       wg_gemm2<true>(N, ElP{P, ld}, ElP{Q, ld}, ElP{t, ld},
-                     [=](int i, int j, double v) { r[i + j * ld] = r[i + j * ld] + v; },
-                     [=](int i, int j, double v) { t[i + j * ld] = v; });
+                     [=](int i, int j, real v) { r[i + j * ld] = r[i + j * ld] + v; },
+                     [=](int i, int j, real v) { t[i + j * ld] = v; });
     } else {
-      double *X = c.X;
+      real *X = c.X;
       wg_gemm2<false, !LDSM>(N, ElP{P, ld}, ElP{Q, ld}, ElP{t, ld},
-                      [=](int i, int j, double v) { r[i + j * ld] = r[i + j * ld] + v; },
-                      [=](int i, int j, double v) { X[i + j * ld] = v; });
+                      [=](int i, int j, real v) { r[i + j * ld] = r[i + j * ld] + v; },
+                      [=](int i, int j, real v) { X[i + j * ld] = v; });
       c.X = t;
       c.t = X;
     }
@@ -783,7 +796,7 @@ __device__ __forceinline__ double doubling_run(Ctx &c, int nd, double expk) {
   }
   // apply_D! (doubling.jl:93-110) and apply_D_SFI! (:112-118): r-+ rows and j0- scaled by sg
   {
-    double *r = c.r;
+    real *r = c.r;
     for (int e = wg_tid(); e < N * N; e += kThreads) {
       int i, j;
       c.fd.split(e, i, j);
@@ -809,7 +822,7 @@ template <bool LDSM, int IFACE, int KS = 0, class FRPM, class FTMM>
 __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const CompPtrs &g, FRPM rpm, FTMM tmm) {
   const int iface = (IFACE >= 0) ? IFACE : iface_rt;
   const int N = c.N, ld = c.ld, cl = g.ld;
-  double *r = c.r, *t = c.t;
+  real *r = c.r, *t = c.t;
   if constexpr (LDSM && KS > 0 && std::is_same<FRPM, ElSigP>::value && std::is_same<FTMM, ElSigP>::value) {
     // ScatteringInterface_11 with r+- = D r-+ D, t-- = D t++ D of the layer held in c.r, c.t: two strip chains
     if ((IFACE < 0 || IFACE == 3) && iface == 3 && c.inv_mode == 0 && N == 4 * KS && rpm.p == c.r && tmm.p == c.t) {
@@ -835,8 +848,8 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     wg_copy_mat(N, c.fd, g.T_pp, cl, c.Q, ld);
     __syncthreads();
     gdouble *Tmm = g.T_mm, *Tpp = g.T_pp;
-    wg_gemm<false, !LDSM>(N, tmm, ElP{c.P, ld}, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
-    wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{c.Q, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, tmm, ElP{c.P, ld}, [=](int i, int j, real v) { Tmm[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{c.Q, ld}, [=](int i, int j, real v) { Tpp[i + j * cl] = v; });
   } else if ((IFACE < 0 || IFACE == 1) && iface == 1) {
     wg_copy_mat(N, c.fd, g.T_mm, cl, c.P, ld);  // P = T--
     // J0- = J0- + T-- (r-+ J0+ + j0-) ; J0+ = j0+ + t++ J0+  (:36-37)
@@ -850,23 +863,23 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       c.Jp[i] = c.jp[i] + c.v1[i];
     }
     // R-+ = (T-- r-+) T++ ; R+- = r+- ; T++ = t++ T++ ; T-- = T-- t--   (:40-43)
-    double *Q = c.Q, *P = c.P;
-    wg_gemm<false, !LDSM>(N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+    real *Q = c.Q, *P = c.P;
+    wg_gemm<false, !LDSM>(N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, real v) { Q[i + j * ld] = v; });
     __syncthreads();
     gdouble *Rmp = g.R_mp, *Rpm = g.R_pm, *Tpp = g.T_pp, *Tmm = g.T_mm;
-    wg_gemm<false, !LDSM>(N, ElP{Q, ld}, El{g.T_pp, cl, N}, [=](int i, int j, double v) { Rmp[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{Q, ld}, El{g.T_pp, cl, N}, [=](int i, int j, real v) { Rmp[i + j * cl] = v; });
     __syncthreads();
     wg_copy_mat(N, c.fd, g.T_pp, cl, Q, ld);
     __syncthreads();
-    wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
-    wg_gemm<false, !LDSM>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, real v) { Tpp[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{P, ld}, tmm, [=](int i, int j, real v) { Tmm[i + j * cl] = v; });
     for (int e = wg_tid(); e < N * N; e += kThreads) {
       int i, j;
       c.fd.split(e, i, j);
       Rpm[i + j * cl] = rpm(i, j);
     }
   } else if ((IFACE < 0 || IFACE == 2) && iface == 2) {
-    double *P = c.P, *Q = c.Q;
+    real *P = c.P, *Q = c.Q;
     wg_copy_mat(N, c.fd, g.R_pm, cl, P, ld);  // P = R+-
     wg_copy_mat(N, c.fd, g.T_mm, cl, Q, ld);  // Q = T--
     __syncthreads();
@@ -882,15 +895,15 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     }
     // T++ = t++ T++ ; T-- = T-- t-- ; R+- = (t++ R+-) t--       (:62-64)
     gdouble *Tpp = g.T_pp, *Tmm = g.T_mm, *Rpm = g.R_pm;
-    wg_gemm<false, !LDSM>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{Q, ld}, tmm, [=](int i, int j, real v) { Tmm[i + j * cl] = v; });
     __syncthreads();
     wg_copy_mat(N, c.fd, g.T_pp, cl, Q, ld);
     __syncthreads();
-    wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, real v) { Tpp[i + j * cl] = v; });
     __syncthreads();
-    wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{P, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{P, ld}, [=](int i, int j, real v) { Q[i + j * ld] = v; });
     __syncthreads();
-    wg_gemm<false, !LDSM>(N, ElP{Q, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * cl] = v; });
+    wg_gemm<false, !LDSM>(N, ElP{Q, ld}, tmm, [=](int i, int j, real v) { Rpm[i + j * cl] = v; });
   } else if ((IFACE < 0 || IFACE == 3) && iface == 3) {
     // ---- ScatteringInterface_11 (interaction.jl:69-117)
     // The four mat-vec products ride as column N of the B operands when the buffers have a spare
@@ -902,12 +915,12 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       for (int i = wg_tid(); i < N; i += kThreads) c.P[i + N * ld] = c.Jp[i];
     __syncthreads();
     MOM_STAMP(11);
-    double beta2;
+    real beta2;
     {
-      double *P = c.P, *Q = c.Q;
-      double ss = 0.0;
+      real *P = c.P, *Q = c.Q;
+      real ss = 0.0;
       // Q = r-+ R+- (+ r-+ J0+) ;  P = T01 = T-- (I - r-+ R+-)^-1            (:81-87)
-      wg_gemm_nc<false, !LDSM>(N, ride ? N + 1 : N, ElP{r, ld}, ElP{P, ld}, [=, &ss](int i, int j, double v) {
+      wg_gemm_nc<false, !LDSM>(N, ride ? N + 1 : N, ElP{r, ld}, ElP{P, ld}, [=, &ss](int i, int j, real v) {
         Q[i + j * ld] = v;
         if (j < N) ss += v * v;
       });
@@ -930,12 +943,12 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     }
     MOM_STAMP(14);
     {
-      double *P = c.P, *Q = c.Q;
+      real *P = c.P, *Q = c.Q;
       gdouble *Tmm = g.T_mm, *Rmp = g.R_mp;
       // T-- = T01 t--                                           (:96)
-      wg_gemm<false, !LDSM>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Tmm[i + j * cl] = v; });
+      wg_gemm<false, !LDSM>(N, ElP{P, ld}, tmm, [=](int i, int j, real v) { Tmm[i + j * cl] = v; });
       // Q = T01 r-+ (+ T01 v1)
-      wg_gemm_nc<false, !LDSM>(N, ride ? N + 1 : N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, double v) { Q[i + j * ld] = v; });
+      wg_gemm_nc<false, !LDSM>(N, ride ? N + 1 : N, ElP{P, ld}, ElP{r, ld}, [=](int i, int j, real v) { Q[i + j * ld] = v; });
       __syncthreads();
       MOM_STAMP(15);
       if (ride)  // J0- = J0- + T01 v1 (:90); next rider: j0- for R+- j0-
@@ -947,7 +960,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       __syncthreads();
       MOM_STAMP(16);
       // R-+ = R-+ + (T01 r-+) T++                              (:93)
-      wg_gemm<false, !LDSM>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Rmp[i + j * cl] = Rmp[i + j * cl] + v; });
+      wg_gemm<false, !LDSM>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, real v) { Rmp[i + j * cl] = Rmp[i + j * cl] + v; });
       __syncthreads();
       MOM_STAMP(17);
       wg_copy_mat(N, c.fd, g.R_pm, cl, Q, ld);  // Q = R+- (old)
@@ -960,10 +973,10 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       for (int i = wg_tid(); i < N; i += kThreads) c.j1p[i] = c.Jp[i] + c.v1[i];
     }
     {
-      double *P = c.P, *Q = c.Q;
-      double ss = 0.0;
+      real *P = c.P, *Q = c.Q;
+      real ss = 0.0;
       // P = R+- r-+ (+ R+- j0-) ; Q = T21 = t++ (I - R+- r-+)^-1            (:104-107)
-      wg_gemm_nc<false, !LDSM>(N, ride ? N + 1 : N, ElP{Q, ld}, ElP{r, ld}, [=, &ss](int i, int j, double v) {
+      wg_gemm_nc<false, !LDSM>(N, ride ? N + 1 : N, ElP{Q, ld}, ElP{r, ld}, [=, &ss](int i, int j, real v) {
         P[i + j * ld] = v;
         if (j < N) ss += v * v;
       });
@@ -989,12 +1002,12 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     MOM_STAMP(22);
     {
       // P = T21 R+- (+ T21 w)
-      double *d = c.P, *Qb = c.Q;
+      real *d = c.P, *Qb = c.Q;
       if (LDSM) {
-        wg_gemm_nc<true>(N, ride ? N + 1 : N, ElP{Qb, ld}, ElP{d, ld}, [=](int i, int j, double v) { d[i + j * ld] = v; });
+        wg_gemm_nc<true>(N, ride ? N + 1 : N, ElP{Qb, ld}, ElP{d, ld}, [=](int i, int j, real v) { d[i + j * ld] = v; });
       } else {
-        double *sp = c.X;
-        wg_gemm_nc<false, !LDSM>(N, ride ? N + 1 : N, ElP{Qb, ld}, ElP{d, ld}, [=](int i, int j, double v) { sp[i + j * ld] = v; });
+        real *sp = c.X;
+        wg_gemm_nc<false, !LDSM>(N, ride ? N + 1 : N, ElP{Qb, ld}, ElP{d, ld}, [=](int i, int j, real v) { sp[i + j * ld] = v; });
         c.X = d;
         c.P = sp;
       }
@@ -1004,10 +1017,10 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     if (ride)  // J0+ = j0+ + T21 w (:110)
       for (int i = wg_tid(); i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.P[i + N * ld];
     {
-      double *P = c.P, *Q = c.Q;
+      real *P = c.P, *Q = c.Q;
       gdouble *Rpm = g.R_pm, *Tpp = g.T_pp;
       // R+- = r+- + (T21 R+-) t--                              (:116)
-      wg_gemm<false, !LDSM>(N, ElP{P, ld}, tmm, [=](int i, int j, double v) { Rpm[i + j * cl] = rpm(i, j) + v; });
+      wg_gemm<false, !LDSM>(N, ElP{P, ld}, tmm, [=](int i, int j, real v) { Rpm[i + j * cl] = rpm(i, j) + v; });
       __syncthreads();
       MOM_STAMP(24);
       if (ride)
@@ -1016,7 +1029,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       __syncthreads();
       MOM_STAMP(25);
       // T++ = T21 T++                                          (:113)
-      wg_gemm<false, !LDSM>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, double v) { Tpp[i + j * cl] = v; });
+      wg_gemm<false, !LDSM>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, real v) { Tpp[i + j * cl] = v; });
     }
   }
   __syncthreads();
@@ -1034,7 +1047,7 @@ __device__ __forceinline__ void store_added_as_composite(const Ctx &c, const Com
   for (int e = wg_tid(); e < N * N; e += kThreads) {
     int i, j;
     c.fd.split(e, i, j);
-    const double rv = c.r[i + j * ld], tv = c.t[i + j * ld], s = c.sg[i] * c.sg[j];
+    const real rv = c.r[i + j * ld], tv = c.t[i + j * ld], s = c.sg[i] * c.sg[j];
     const int o = i + j * g.ld;
     __builtin_nontemporal_store(rv, g.R_mp + o);  // streaming: see MOM_NT_STORE in mom_strip.hpp
     __builtin_nontemporal_store(s * rv, g.R_pm + o);

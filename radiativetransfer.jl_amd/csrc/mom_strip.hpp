@@ -51,23 +51,23 @@ struct StripGeom {
   static constexpr int RT = KS >> 2, RR = KS & 3;  // tile / register of rows N (lanes lq == 0) and N+1 (lq == 1)
 };
 
-__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+__device__ __forceinline__ r4 mfma_f64(real a, real b, r4 c) {
+  return mma16(a, b, c);
 }
 
 // acc[rt] += sum_k M[k + row*LD] B[k][col], row = 16 rt + (l & 15): left-multiplication of the strip B by M^T
 template <int KS>
-__device__ __forceinline__ void strip_mul(const double *M, int lr, int lq, const d4 (&B)[StripGeom<KS>::NT],
-                                          d4 (&acc)[StripGeom<KS>::NT]) {
+__device__ __forceinline__ void strip_mul(const real *M, int lr, int lq, const r4 (&B)[StripGeom<KS>::NT],
+                                          r4 (&acc)[StripGeom<KS>::NT]) {
   constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
   asm volatile("" : "+v"(lr), "+v"(lq));  // keep the address arithmetic inside (see item_straight)
-  const double *base = M + lq + lr * LD;
+  const real *base = M + lq + lr * LD;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    double a[NT];
+    real a[NT];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) a[rt] = base[4 * ks + 16 * rt * LD];
-    const double b = B[ks >> 2][ks & 3];
+    const real b = B[ks >> 2][ks & 3];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) acc[rt] = mfma_f64(a[rt], b, acc[rt]);
     if ((ks + 1) % kStripChunk == 0) __builtin_amdgcn_sched_barrier(0);  // cap the A fragments in flight
@@ -76,18 +76,18 @@ __device__ __forceinline__ void strip_mul(const double *M, int lr, int lq, const
 
 // two strips through the same multiplier: acc1 += M^T B1, acc2 += M^T B2 (A fragments loaded once)
 template <int KS>
-__device__ __forceinline__ void strip_mul2(const double *M, int lr, int lq, const d4 (&B1)[StripGeom<KS>::NT],
-                                           d4 (&acc1)[StripGeom<KS>::NT], const d4 (&B2)[StripGeom<KS>::NT],
-                                           d4 (&acc2)[StripGeom<KS>::NT]) {
+__device__ __forceinline__ void strip_mul2(const real *M, int lr, int lq, const r4 (&B1)[StripGeom<KS>::NT],
+                                           r4 (&acc1)[StripGeom<KS>::NT], const r4 (&B2)[StripGeom<KS>::NT],
+                                           r4 (&acc2)[StripGeom<KS>::NT]) {
   constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
   asm volatile("" : "+v"(lr), "+v"(lq));
-  const double *base = M + lq + lr * LD;
+  const real *base = M + lq + lr * LD;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    double a[NT];
+    real a[NT];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) a[rt] = base[4 * ks + 16 * rt * LD];
-    const double b1 = B1[ks >> 2][ks & 3], b2 = B2[ks >> 2][ks & 3];
+    const real b1 = B1[ks >> 2][ks & 3], b2 = B2[ks >> 2][ks & 3];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
       acc1[rt] = mfma_f64(a[rt], b1, acc1[rt]);
@@ -98,12 +98,12 @@ __device__ __forceinline__ void strip_mul2(const double *M, int lr, int lq, cons
 }
 
 template <int NT>
-__device__ __forceinline__ void strip_zero(d4 (&W)[NT]) {
+__device__ __forceinline__ void strip_zero(r4 (&W)[NT]) {
 #pragma unroll
-  for (int rt = 0; rt < NT; ++rt) W[rt] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int rt = 0; rt < NT; ++rt) W[rt] = (r4){0.0, 0.0, 0.0, 0.0};
 }
 template <int NT>
-__device__ __forceinline__ void strip_copy(d4 (&D)[NT], const d4 (&S)[NT]) {
+__device__ __forceinline__ void strip_copy(r4 (&D)[NT], const r4 (&S)[NT]) {
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt) D[rt] = S[rt];
 }
@@ -112,21 +112,21 @@ __device__ __forceinline__ void strip_copy(d4 (&D)[NT], const d4 (&S)[NT]) {
 // N); rows >= N read as zero.  col = c0 + lr may run past N - 1 (garbage columns, never stored; an LDS
 // buffer has LD > 16 NT - 1 rows, a global block is guarded with colok).
 template <int KS>
-__device__ __forceinline__ void strip_load_lds(const double *X, int lr, int lq, int c0, d4 (&W)[StripGeom<KS>::NT]) {
+__device__ __forceinline__ void strip_load_lds(const real *X, int lr, int lq, int c0, r4 (&W)[StripGeom<KS>::NT]) {
   asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
-  const double *base = X + c0 + lr + lq * LD;
+  const real *base = X + c0 + lr + lq * LD;
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS) ? base[(16 * rt + 4 * r) * LD] : 0.0;
 }
 template <int KS>
-__device__ __forceinline__ void strip_store_lds(double *X, int lr, int lq, int c0, bool colok,
-                                                const d4 (&W)[StripGeom<KS>::NT]) {
+__device__ __forceinline__ void strip_store_lds(real *X, int lr, int lq, int c0, bool colok,
+                                                const r4 (&W)[StripGeom<KS>::NT]) {
   asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
-  double *base = X + c0 + lr + lq * LD;
+  real *base = X + c0 + lr + lq * LD;
   if (colok) {
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt)
@@ -137,7 +137,7 @@ __device__ __forceinline__ void strip_store_lds(double *X, int lr, int lq, int c
 }
 template <int KS>
 __device__ __forceinline__ void strip_load_glb(const gdouble *__restrict__ X, int lr, int lq, int c0, bool colok,
-                                               d4 (&W)[StripGeom<KS>::NT]) {
+                                               r4 (&W)[StripGeom<KS>::NT]) {
   asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, CP = StripGeom<KS>::CP;
   const gdouble *base = X + c0 + lr + lq * CP;
@@ -148,7 +148,7 @@ __device__ __forceinline__ void strip_load_glb(const gdouble *__restrict__ X, in
 }
 template <int KS>
 __device__ __forceinline__ void strip_store_glb(gdouble *__restrict__ X, int lr, int lq, int c0, bool colok,
-                                                const d4 (&W)[StripGeom<KS>::NT]) {
+                                                const r4 (&W)[StripGeom<KS>::NT]) {
   asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, CP = StripGeom<KS>::CP;
   gdouble *base = X + c0 + lr + lq * CP;
@@ -162,7 +162,7 @@ __device__ __forceinline__ void strip_store_glb(gdouble *__restrict__ X, int lr,
 }
 
 // bit 4 rt + r of the mask: sg[row] < 0 for row = 16 rt + 4 r + lq (this lane's strip rows)
-__device__ __forceinline__ unsigned strip_sign_mask(const double *sg, int lq, int N) {
+__device__ __forceinline__ unsigned strip_sign_mask(const real *sg, int lq, int N) {
   unsigned m = 0;
 #pragma unroll
   for (int b = 0; b < 16; ++b) {
@@ -173,12 +173,12 @@ __device__ __forceinline__ unsigned strip_sign_mask(const double *sg, int lq, in
 }
 // W <- diag(sg) W  (row signs)
 template <int NT>
-__device__ __forceinline__ void strip_flip(d4 (&W)[NT], unsigned mask) {
+__device__ __forceinline__ void strip_flip(r4 (&W)[NT], unsigned mask) {
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double v = W[rt][r];
+      const real v = W[rt][r];
       W[rt][r] = ((mask >> (4 * rt + r)) & 1u) ? -v : v;
     }
 }
@@ -195,9 +195,9 @@ __device__ __forceinline__ void doubling_rr_strip(const Ctx &c) {
   const int lane = wg_lane(), wave = wg_wave(), lr = lane & 15, lq = lane >> 4;
   const int c0 = 16 * (wave & 3), col = c0 + lr;
   const bool active = (wave >> 2) == 0 && (wave & 3) < NT, colok = col < N;
-  double ss = 0.0;
+  real ss = 0.0;
   if (active) {
-    d4 W[NT], B[NT];
+    r4 W[NT], B[NT];
     strip_load_lds<KS>(c.r, lr, lq, c0, W);
     strip_zero(B);
     strip_mul<KS>(c.r, lr, lq, W, B);
@@ -221,16 +221,16 @@ __device__ __forceinline__ void doubling_rr_strip(const Ctx &c) {
 // c.jm; out: c.r, c.t, c.jp, c.jm and the riding columns N, N+1 of c.r (= new j0+, j0-) for the next step.
 // ---------------------------------------------------------------------------------------
 template <int KS>
-__device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, double expk) {
+__device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, real expk) {
   using G = StripGeom<KS>;
   constexpr int N = G::N, NT = G::NT, LD = G::LD;
   const int lane = wg_lane(), wave = wg_wave(), lr = lane & 15, lq = lane >> 4;
   const int c0 = 16 * (wave & 3);
   const bool active = (wave >> 2) == 0 && (wave & 3) < NT, colok = c0 + lr < N;
-  double *r = c.r, *t = c.t;
-  const double *P = c.P;
-  d4 Rn[NT], Tn[NT];
-  double aw = 0.0;
+  real *r = c.r, *t = c.t;
+  const real *P = c.P;
+  r4 Rn[NT], Tn[NT];
+  real aw = 0.0;
   if (active) {
     // riding rows of the multiplier r^T: w1 = j1- + r j0+, w2 = j0+ + r j1-  (doubling.jl:51-60); every strip wave
     // writes the same values, so each reads back its own writes in order
@@ -238,22 +238,22 @@ __device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, double 
       r[lane + N * LD] = c.jm[lane] * expk + P[lane + N * LD];
       r[lane + (N + 1) * LD] = c.jp[lane] + expk * P[lane + (N + 1) * LD];
     }
-    d4 T0[NT], Y[NT];
+    r4 T0[NT], Y[NT];
     strip_load_lds<KS>(t, lr, lq, c0, T0);
     strip_copy(Y, T0);
     // Y = A^T = (t (I - r r)^-1)^T by Horner: Y <- t^T + (r r)^T Y
 #pragma nounroll
     for (int k = 1; k < p; ++k) {
-      d4 acc[NT];
+      r4 acc[NT];
       strip_copy(acc, T0);
       strip_mul<KS>(P, lr, lq, Y, acc);
       strip_copy(Y, acc);
     }
-    d4 Zt[NT];
+    r4 Zt[NT];
     strip_zero(Zt);
     strip_mul<KS>(r, lr, lq, Y, Zt);  // (A r)^T ; rows N, N+1: (A w1)^T, (A w2)^T
     aw = Zt[G::RT][G::RR];  // lanes lq == 0: (A w1)[col] ; lq == 1: (A w2)[col]
-    // two single-strip products rather than one pass over t with shared A fragments (strip_mul2): the double product
+    // two single-strip products rather than one pass over t with shared A fragments (strip_mul2): the real product
     // needs 32 more live VGPRs, which the fused kernel pays for with spills inside the chain
     strip_load_lds<KS>(r, lr, lq, c0, Rn);
     strip_mul<KS>(t, lr, lq, Zt, Rn);  // r^T + t^T (A r)^T      (:64)
@@ -268,12 +268,12 @@ __device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, double 
     strip_store_lds<KS>(t, lr, lq, c0, colok, Tn);
     const int col = c0 + lr;
     if (colok && lq == 0) {  // j0- += A w1 (:57)
-      const double jm = c.jm[col] + aw;
+      const real jm = c.jm[col] + aw;
       c.jm[col] = jm;
       r[col + (N + 1) * LD] = jm;
     }
     if (colok && lq == 1) {  // j0+ = j1+ + A w2 (:60)
-      const double jp = c.jp[col] * expk + aw;
+      const real jp = c.jp[col] * expk + aw;
       c.jp[col] = jp;
       r[col + N * LD] = jp;
     }
@@ -300,15 +300,15 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
   const int grp = wave >> 2, c0 = 16 * (wave & 3), col = c0 + lr;
   const bool strip = (wave & 3) < NT, colok = col < N;
   const bool do1 = strip && grp == 0, do2 = strip && grp == kStripGroups - 1;
-  double *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
-  d4 T1[NT], W0[NT];  // chain 1: T--^T strip ; chain 2: W0 = R+-^T t++^T
+  real *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
+  r4 T1[NT], W0[NT];  // chain 1: T--^T strip ; chain 2: W0 = R+-^T t++^T
   if (do1) strip_load_glb<KS>(g.T_mm, lr, lq, c0, colok, T1);
   // P = R+-, Q = T++ ; riding rows: column N of Q = J0+, column N of r = j0-.  All global loads of both blocks are
   // issued before the first LDS store: one exposed HBM latency instead of one per batch.
   {
     constexpr int NN = N * N, U = 8;
     for (int e0 = wg_tid(); e0 < NN; e0 += U * kThreads) {
-      double vr[U], vt[U];
+      real vr[U], vt[U];
       int o[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -339,10 +339,10 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
   MOM_STAMP4(91);
   // B = r-+ R+- on strips (B^T strip = R+-^T (r-+^T strip)) by the chain-1 waves while the chain-2 waves form W0;
   // both read R+- in P, which B then replaces (after the barrier), with ||B||_F^2 for the series length
-  d4 Bs[NT];
-  double ss = 0.0;
+  r4 Bs[NT];
+  real ss = 0.0;
   if (do1) {
-    d4 rT[NT];
+    r4 rT[NT];
     strip_load_lds<KS>(r, lr, lq, c0, rT);
     strip_zero(Bs);
     strip_mul<KS>(P, lr, lq, rT, Bs);
@@ -355,7 +355,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
     }
   }
   if (do2) {
-    d4 tT[NT];
+    r4 tT[NT];
     strip_load_lds<KS>(t, lr, lq, c0, tT);
     strip_zero(W0);
     strip_mul<KS>(P, lr, lq, tT, W0);
@@ -368,27 +368,27 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
   __syncthreads();
   MOM_STAMP(53);
   MOM_STAMP4(93);
-  const double beta2 = wg_sumsq_get(c);
+  const real beta2 = wg_sumsq_get(c);
   const int p = neumann_terms_12(beta2);
   if (p > kStripMaxP) return false;
   const unsigned mask = strip_sign_mask(c.sg, lq, N);
   if (do1) {
-    d4 Y[NT];
+    r4 Y[NT];
     strip_copy(Y, T1);
 #pragma nounroll
     for (int k = 1; k < p; ++k) {  // Y <- T--^T + B^T Y : T01^T
-      d4 acc[NT];
+      r4 acc[NT];
       strip_copy(acc, T1);
       strip_mul<KS>(P, lr, lq, Y, acc);
       strip_copy(Y, acc);
     }
     MOM_STAMP(54);
-    d4 Radd[NT];
+    r4 Radd[NT];
     strip_load_glb<KS>(g.R_mp, lr, lq, c0, colok, Radd);
-    const double j0m = (colok && lq == 0) ? g.J0m[col] : 0.0;
+    const real j0m = (colok && lq == 0) ? g.J0m[col] : 0.0;
     // T-- = T01 t--  ->  (t--)^T T01^T = D t^T D Y                                   (:96)
     {
-      d4 Yf[NT], o[NT];
+      r4 Yf[NT], o[NT];
       strip_copy(Yf, Y);
       strip_flip(Yf, mask);
       strip_zero(o);
@@ -397,7 +397,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
       strip_store_glb<KS>(g.T_mm, lr, lq, c0, colok, o);
     }
     // V = (T01 r-+)^T = r-+^T Y ; row N: (T01 j0-)^T
-    d4 V[NT];
+    r4 V[NT];
     strip_zero(V);
     strip_mul<KS>(r, lr, lq, Y, V);
     // R-+ = R-+ + (T01 r-+) T++  ->  R-+^T + T++^T V ; row N: (T01 r-+ J0+)^T        (:93)
@@ -408,31 +408,31 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
     MOM_STAMP(55);
   }
   if (do2) {
-    d4 Y[NT];
+    r4 Y[NT];
     strip_copy(Y, W0);
 #pragma nounroll
     for (int k = 1; k < p; ++k) {  // Y <- W0 + B^T Y : X^T
-      d4 acc[NT];
+      r4 acc[NT];
       strip_copy(acc, W0);
       strip_mul<KS>(P, lr, lq, Y, acc);
       strip_copy(Y, acc);
     }
     MOM_STAMP4(94);
     // T21^T = t++^T + r-+^T X^T ; row N: (X j0-)^T = (T21 R+- j0-)^T
-    d4 T21[NT];
+    r4 T21[NT];
     strip_load_lds<KS>(t, lr, lq, c0, T21);
     strip_mul<KS>(r, lr, lq, Y, T21);
     // T++ = T21 T++  ->  T++^T T21^T ; row N: (T21 J0+)^T                            (:113)
-    d4 o[NT];
+    r4 o[NT];
     strip_zero(o);
     strip_mul<KS>(Q, lr, lq, T21, o);
     strip_store_glb<KS>(g.T_pp, lr, lq, c0, colok, o);
     // J0+ = j0+ + T21 (J0+ + R+- j0-)                                                (:110)
     if (colok && lq == 0) g.J0p[col] = c.jp[col] + (o[G::RT][G::RR] + T21[G::RT][G::RR]);
     // R+- = r+- + X t--  ->  r+-^T + D t^T D X^T = D (D r+-^T + t^T D X^T), D r+-^T[row][col] = sg[col] r-+[col][row]   (:116)
-    d4 acc[NT];
+    r4 acc[NT];
     strip_load_lds<KS>(r, lr, lq, c0, acc);
-    const double sc = colok ? c.sg[col] : 1.0;
+    const real sc = colok ? c.sg[col] : 1.0;
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) acc[rt] = acc[rt] * sc;
     strip_flip(Y, mask);

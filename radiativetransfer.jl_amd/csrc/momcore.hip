@@ -253,6 +253,22 @@ hipError_t mom_strip14_launch_layer(const void *layer_args, int iface, int grid,
 hipError_t mom_strip15_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom4_launch_surface(const void *surf_args, bool lds, int grid, size_t smem, hipStream_t st);
 int mom4_generic_bufs_elems(int N);
+// momcore_f32.hip: the Float32 build of the scene-level path (dtype = 1)
+struct momf_scene;
+int momf_create(momf_scene **out, int device, hipStream_t stream, int N, int nS, int S, int max_m, int *d_info);
+void momf_destroy(momf_scene *s);
+const char *momf_error(const momf_scene *s);
+void momf_set_options(momf_scene *s, int inv_mode, int force_generic, int sweep);
+int momf_set_streams(momf_scene *s, const double *mu, const double *wt, const double *sg, int imu0, double mu0, const double *I0,
+                     const double *D, int regular);
+int momf_scene_set(momf_scene *s, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
+                   const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface, const double *tau_sum,
+                   double albedo, int nVza, const int *node, const double *cos_mphi, const double *sin_mphi);
+int momf_scene_set_surface(momf_scene *s, int kind, int M, const double *Rsurf, const double *albedo_spec);
+int momf_rt_run(momf_scene *s);
+int momf_get_RT(momf_scene *s, double *R, double *T);
+int momf_get_hdr(momf_scene *s, double *hdr, double *up, double *dw);
+int momf_timers(momf_scene *s, double *ms, int *launches);
 // mom_small.hip: N <= 4, one spectral point per lane, the whole sweep in one launch
 hipError_t momsm_launch_sweep(const void *args, int N, hipStream_t st);
 
@@ -262,6 +278,8 @@ static void (*g_rccl_destroy)(void *) = nullptr;  // set once RCCL is loaded (mo
 
 struct mom_handle {
   int device = 0, N = 0, nS = 0, S = 0, M = 0;
+  int dtype = 0;              // 0 = Float64, 1 = Float32 (scene-level path only, momcore_f32.hip)
+  momf_scene *f32 = nullptr;
   bool lds_mode = true;
   int opt_inverse = 0, opt_force_generic = 0;
   hipStream_t stream = nullptr;
@@ -336,6 +354,11 @@ struct mom_handle {
     }                                                                                              \
   } while (0)
 
+#define F64_ONLY(h, name)                                                                                 \
+  if ((h) && (h)->dtype != 0)                                                                             \
+  return fail(h, MOM_EINVAL, name ": not available on a Float32 (dtype = 1) handle (scene-level path only)")
+
+static int fail(mom_t *h, int code, const char *msg);
 static int fail(mom_t *h, int code, const char *msg) {
   if (h) h->err = msg;
   g_err = msg;
@@ -387,13 +410,13 @@ static int op_composite_ready(mom_t *h, const char *who) {
 extern "C" int mom_create(mom_t **out, int device, int N, int nStokes, int S, int max_m, int dtype) {
   if (!out || N <= 0 || S <= 0 || max_m <= 0 || nStokes <= 0 || nStokes > 4 || N % nStokes != 0)
     return fail(nullptr, MOM_EINVAL, "mom_create: bad argument");
-  if (dtype != 0) return fail(nullptr, MOM_EINVAL, "mom_create: only dtype 0 (Float64) is implemented");
+  if (dtype != 0 && dtype != 1) return fail(nullptr, MOM_EINVAL, "mom_create: dtype must be 0 (Float64) or 1 (Float32)");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) return fail(nullptr, MOM_EHIP, "mom_create: no HIP device available");
   if (device < 0 || device >= ndev) return fail(nullptr, MOM_EINVAL, "mom_create: device index out of range");
   mom_t *h = new mom_t();
-  h->device = device; h->N = N; h->nS = nStokes; h->S = S; h->M = max_m;
+  h->device = device; h->N = N; h->nS = nStokes; h->S = S; h->M = max_m; h->dtype = dtype;
   h->lds_mode = (N <= 64);
   *out = h;
   HIPCHK(h, hipSetDevice(device));
@@ -403,7 +426,7 @@ extern "C" int mom_create(mom_t **out, int device, int N, int nStokes, int S, in
   HIPCHK(h, dmalloc(&h->d_wt, N));
   HIPCHK(h, dmalloc(&h->d_sg, N));
   (void)NN;
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < 6 && dtype == 0; ++k) {
     // composite blocks: room for the scene-level row pitch (comp_pitch); the operator-level API uses the natural one.
     // The added / surface layers of the operator-level API (12 N^2 S doubles) are allocated on its first use
     // (ensure_op_layers): the scene-level path keeps the added layer in LDS and never needs them.
@@ -420,6 +443,13 @@ extern "C" int mom_create(mom_t **out, int device, int N, int nStokes, int S, in
     HIPCHK(h, hipGetDeviceProperties(&prop, device));
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
+  if (dtype == 1) {  // Float32: the scene-level state lives in the f32 build's own object
+    for (int k = 0; k < 4; ++k) HIPCHK(h, hipEventCreate(&h->ev[k]));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int rc = momf_create(&h->f32, device, h->stream, N, nStokes, S, max_m, h->d_info);
+    if (rc) return fail(h, rc, momf_error(h->f32));
+    return MOM_OK;
+  }
   // + one padded matrix of slack: B-operand reads of the last column tile run past the stored columns
   HIPCHK(h, dmalloc(&h->d_scratch, (size_t)h->G * kGenericBufs * mat_elems(N) + (size_t)ld_for(N) * np_for(N)));
   HIPCHK(h, hipMemsetAsync(h->d_scratch, 0, ((size_t)h->G * kGenericBufs * mat_elems(N) + (size_t)ld_for(N) * np_for(N)) * sizeof(double), h->stream));
@@ -432,6 +462,7 @@ extern "C" int mom_destroy(mom_t *h) {
   if (!h) return MOM_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->f32) momf_destroy(h->f32);
   if (h->comm && g_rccl_destroy) g_rccl_destroy(h->comm);
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(h->d_mu); fr(h->d_wt); fr(h->d_sg);
@@ -476,6 +507,7 @@ extern "C" int mom_set_option(mom_t *h, int option, int value) {
     h->opt_force_generic = value;
     h->lds_mode = (h->N <= 64) && !value;
   } else return fail(h, MOM_EINVAL, "mom_set_option: unknown option");
+  if (h->f32) momf_set_options(h->f32, h->opt_inverse, h->opt_force_generic, h->opt_sweep);
   return MOM_OK;
 }
 
@@ -504,6 +536,11 @@ extern "C" int mom_set_streams(mom_t *h, const double *qp_muN, const double *wt_
   q.regular = 1;
   for (int i = 0; i < N; ++i)
     if (qp_muN[i] != qp_muN[(i / h->nS) * h->nS]) q.regular = 0;
+  if (h->f32) {
+    momf_set_options(h->f32, h->opt_inverse, h->opt_force_generic, h->opt_sweep);
+    const int rc = momf_set_streams(h->f32, qp_muN, wt_muN, sg.data(), imu0_1based, mu0, I0, D, q.regular);
+    if (rc) return fail(h, rc, momf_error(h->f32));
+  }
   h->streams_set = true;
   h->scene_set = false;  // the reduced (I,Q) stream set of a resident scene was derived from the old streams
   return MOM_OK;
@@ -555,6 +592,7 @@ static int check_info(mom_t *h) {
 extern "C" int mom_elemental(mom_t *h, int m, int ndoubl, const double *tau_sum, const double *dtau, const double *varpi,
                              const double *Zpp, const double *Zmp, int z_batch) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_elemental");
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_elemental: call mom_set_streams first");
   if (!tau_sum || !dtau || !varpi || !Zpp || !Zmp || (z_batch != 1 && z_batch != h->S) || m < 0 || ndoubl < 0)
     return fail(h, MOM_EINVAL, "mom_elemental: bad argument");
@@ -585,6 +623,7 @@ extern "C" int mom_elemental(mom_t *h, int m, int ndoubl, const double *tau_sum,
 
 extern "C" int mom_doubling(mom_t *h, int ndoubl, double *expk) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_doubling");
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_doubling: call mom_set_streams first");
   if (!expk || ndoubl < 0) return fail(h, MOM_EINVAL, "mom_doubling: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
@@ -602,6 +641,7 @@ extern "C" int mom_doubling(mom_t *h, int ndoubl, double *expk) {
 
 extern "C" int mom_interaction(mom_t *h, int iface, int with_surface_layer) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_interaction");
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_interaction: call mom_set_streams first");
   if (iface < 0 || iface > 3) return fail(h, MOM_EINVAL, "mom_interaction: iface must be 0..3");
   HIPCHK(h, hipSetDevice(h->device));
@@ -616,6 +656,7 @@ extern "C" int mom_interaction(mom_t *h, int iface, int with_surface_layer) {
 
 extern "C" int mom_copy_added_to_composite(mom_t *h) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_copy_added_to_composite");
   HIPCHK(h, hipSetDevice(h->device));
   { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
   h->comp_pitched = false;
@@ -632,6 +673,7 @@ extern "C" int mom_copy_added_to_composite(mom_t *h) {
 
 extern "C" int mom_surface_lambertian(mom_t *h, int m, double albedo, const double *tau_tot) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_surface_lambertian");
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_surface_lambertian: call mom_set_streams first");
   if (!tau_tot || m < 0) return fail(h, MOM_EINVAL, "mom_surface_lambertian: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
@@ -654,6 +696,7 @@ static double *which_ptr(mom_t *h, int which, size_t *count) {
 
 extern "C" int mom_upload(mom_t *h, int which, const double *src) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_upload");
   if (which < 0 || which > 17 || !src) return fail(h, MOM_EINVAL, "mom_upload: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   if (which / 6 != 1) { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
@@ -667,6 +710,7 @@ extern "C" int mom_upload(mom_t *h, int which, const double *src) {
 
 extern "C" int mom_download(mom_t *h, int which, double *dst) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_download");
   if (which < 0 || which > 17 || !dst) return fail(h, MOM_EINVAL, "mom_download: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   if (which / 6 != 1) { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
@@ -692,6 +736,7 @@ extern "C" int mom_download(mom_t *h, int which, double *dst) {
 
 static int blas_common(mom_t *h, int n, int batch, const double *A, const double *B, double *C, bool inv) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_batch_inv / mom_batched_mul");
   if (n <= 0 || batch <= 0 || !A || !C || (!inv && !B)) return fail(h, MOM_EINVAL, "batched op: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t cnt = (size_t)n * n * batch;
@@ -766,6 +811,18 @@ extern "C" int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, 
   const size_t S = h->S;
   h->scene_set = false;
   int rc;
+  if (h->f32) {
+    for (int v = 0; v < nVza; ++v)
+      if (node_1based[v] < 1 || node_1based[v] * h->nS > h->N) return fail(h, MOM_EINVAL, "mom_scene_set: bad view node");
+    if ((rc = momf_scene_set(h->f32, Nz, K, M, tau, varpi, zw, Zpp, Zmp, ndoubl, iface, tau_sum, albedo, nVza, node_1based,
+                             cos_mphi, sin_mphi)))
+      return fail(h, rc, momf_error(h->f32));
+    h->Nz = Nz; h->K = K; h->scene_M = M; h->nVza = nVza; h->albedo = albedo; h->surf_kind = 0;
+    h->nd.assign(ndoubl, ndoubl + Nz);
+    h->iface.assign(iface, iface + Nz);
+    h->scene_set = true;
+    return MOM_OK;
+  }
   if ((rc = upload_new(h, &h->d_tau, tau, S * Nz))) return rc;
   if ((rc = upload_new(h, &h->d_varpi, varpi, S * Nz))) return rc;
   if ((rc = upload_new(h, &h->d_zw, zw, (size_t)K * S * Nz))) return rc;
@@ -865,6 +922,11 @@ extern "C" int mom_scene_set_surface(mom_t *h, int kind, int M, const double *Rs
   const int N = h->N, nS = h->nS;
   const size_t NN = (size_t)N * N, S = h->S;
   int rc;
+  if (h->f32) {
+    if ((rc = momf_scene_set_surface(h->f32, kind, M, Rsurf, albedo_spec))) return fail(h, rc, momf_error(h->f32));
+    h->surf_kind = kind;
+    return MOM_OK;
+  }
   if (kind == 1) {
     if ((rc = upload_new(h, &h->d_Rsurf, Rsurf, NN * M))) return rc;
     if (h->d_hdrJm) { (void)hipFree(h->d_hdrJm); h->d_hdrJm = nullptr; }
@@ -956,6 +1018,10 @@ extern "C" int mom_rt_run(mom_t *h) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_rt_run: call mom_scene_set first");
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->f32) {
+    const int rc = momf_rt_run(h->f32);
+    return rc ? fail(h, rc, momf_error(h->f32)) : MOM_OK;
+  }
   const size_t S = h->S;
   const int M = h->scene_M;
   h->launches = 0; h->launches_full = 0; h->launches_red = 0;
@@ -1113,6 +1179,10 @@ extern "C" int mom_get_RT(mom_t *h, double *R_SFI, double *T_SFI) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   if (!h->scene_set || !R_SFI || !T_SFI) return fail(h, MOM_ESTATE, "mom_get_RT: no scene / null output");
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->f32) {
+    const int rc = momf_get_RT(h->f32, R_SFI, T_SFI);
+    return rc ? fail(h, rc, momf_error(h->f32)) : check_info(h);
+  }
   const size_t bytes = (size_t)h->nVza * h->nS * h->S * sizeof(double);
   HIPCHK(h, hipMemcpyAsync(R_SFI, h->d_R, bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(T_SFI, h->d_T, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1123,6 +1193,10 @@ extern "C" int mom_get_hdr(mom_t *h, double *hdr, double *bhr_uw, double *bhr_dw
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   if (!h->scene_set || !hdr || !bhr_uw || !bhr_dw) return fail(h, MOM_ESTATE, "mom_get_hdr: no scene / null output");
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->f32) {
+    const int rc = momf_get_hdr(h->f32, hdr, bhr_uw, bhr_dw);
+    return rc ? fail(h, rc, momf_error(h->f32)) : check_info(h);
+  }
   HIPCHK(h, hipMemcpyAsync(hdr, h->d_hdr, (size_t)h->nVza * h->nS * h->S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(bhr_uw, h->d_bhr_uw, (size_t)h->nS * h->S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(bhr_dw, h->d_bhr_dw, (size_t)h->nS * h->S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1131,6 +1205,7 @@ extern "C" int mom_get_hdr(mom_t *h, double *hdr, double *bhr_uw, double *bhr_dw
 
 extern "C" int mom_get_RT_device(mom_t *h, void *dR, void *dT) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_get_RT_device");
   if (!h->scene_set || !dR || !dT) return fail(h, MOM_ESTATE, "mom_get_RT_device: no scene / null output");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t bytes = (size_t)h->nVza * h->nS * h->S * sizeof(double);
@@ -1209,6 +1284,7 @@ __global__ void k_op_postprocess(int N, int nS, int S, int nVza, const int *node
 extern "C" int mom_postprocess(mom_t *h, int m, int nVza, const int *node_1based, const double *vaz_deg, double weight,
                                double *R_SFI, double *T_SFI) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_postprocess");
   if (m < 0 || nVza <= 0 || !node_1based || !vaz_deg || !R_SFI || !T_SFI)
     return fail(h, MOM_EINVAL, "mom_postprocess: bad argument");
   for (int v = 0; v < nVza; ++v)
@@ -1359,12 +1435,14 @@ extern "C" int mom_allgather(mom_t *h, const void *d_local, void *d_global, size
 // handle, 2 * nVza * nStokes * S_loc doubles) and receives [nranks][2][nVza*nStokes*S_loc]
 extern "C" int mom_allgather_RT_device(mom_t *h, void *d_global) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_allgather_RT_device");
   if (!h->scene_set || !d_global) return fail(h, MOM_ESTATE, "mom_allgather_RT_device: no scene / null output");
   return mom_allgather(h, h->d_R, d_global, 2 * (size_t)h->nVza * h->nS * h->S);
 }
 
 extern "C" int mom_allgather_RT(mom_t *h, double *R_SFI_global, double *T_SFI_global) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_allgather_RT");
   if (!h->scene_set || !R_SFI_global || !T_SFI_global) return fail(h, MOM_ESTATE, "mom_allgather_RT: no scene / null output");
   if (!h->comm) return fail(h, MOM_ESTATE, "mom_allgather_RT: call mom_comm_init first");
   HIPCHK(h, hipSetDevice(h->device));
@@ -1389,6 +1467,7 @@ extern "C" int mom_allgather_RT(mom_t *h, double *R_SFI_global, double *T_SFI_gl
 
 extern "C" int mom_absorption_begin(mom_t *h, int Nz, const double *grid) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_absorption_begin");
   if (Nz <= 0) return fail(h, MOM_EINVAL, "mom_absorption_begin: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t S = h->S;
@@ -1406,6 +1485,7 @@ extern "C" int mom_absorption_begin(mom_t *h, int Nz, const double *grid) {
 
 extern "C" int mom_absorption_set(mom_t *h, int Nz, const double *tau_abs) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_absorption_set");
   if (Nz <= 0 || !tau_abs) return fail(h, MOM_EINVAL, "mom_absorption_set: bad argument");
   int rc = mom_absorption_begin(h, Nz, nullptr);
   if (rc) return rc;
@@ -1416,6 +1496,7 @@ extern "C" int mom_absorption_set(mom_t *h, int Nz, const double *tau_abs) {
 
 extern "C" int mom_absorption_get(mom_t *h, double *tau_abs) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_absorption_get");
   if (!h->d_tau_abs || !tau_abs) return fail(h, MOM_ESTATE, "mom_absorption_get: no resident tau_abs table / null output");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(tau_abs, h->d_tau_abs, (size_t)h->S * h->abs_Nz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1426,6 +1507,7 @@ extern "C" int mom_absorption_get(mom_t *h, double *tau_abs) {
 extern "C" int mom_voigt_tau_abs(mom_t *h, int iz_1based, int nLines, const double *nu, const double *gamma_d, const double *y,
                                  const double *S, const int *ind_start_1based, const int *ind_stop_1based, double factor) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_voigt_tau_abs");
   if (!h->d_tau_abs || !h->d_grid) return fail(h, MOM_ESTATE, "mom_voigt_tau_abs: call mom_absorption_begin with the spectral grid first");
   if (iz_1based < 1 || iz_1based > h->abs_Nz || nLines < 0 ||
       (nLines > 0 && (!nu || !gamma_d || !y || !S || !ind_start_1based || !ind_stop_1based)))
@@ -1538,6 +1620,7 @@ extern "C" int mom_scene_set_optics(mom_t *h, int Nz, int nAer, int M, const dou
                                     const double *Zpp, const double *Zmp, double albedo, int nVza, const int *node_1based,
                                     const double *cos_mphi, const double *sin_mphi) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_scene_set_optics");
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_scene_set_optics: call mom_set_streams first");
   if (Nz <= 0 || nAer < 0 || nAer > 7 || M <= 0 || M > h->M || nVza <= 0 || !tau_rayl || !Zpp || !Zmp || !node_1based ||
       !cos_mphi || !sin_mphi || (nAer > 0 && (!tau_aer || !omega_aer || !ft_aer)))
@@ -1613,6 +1696,7 @@ extern "C" int mom_scene_set_optics(mom_t *h, int Nz, int nAer, int M, const dou
 
 extern "C" int mom_scene_get_layers(mom_t *h, int *ndoubl, int *iface, double *tau, double *varpi, double *zw, double *tau_sum) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_scene_get_layers");
   if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_scene_get_layers: no scene");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t S = h->S, Nz = h->Nz;
@@ -1641,6 +1725,15 @@ extern "C" int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   if (!ms || n < 4) return fail(h, MOM_EINVAL, "mom_timers: need room for 4 values");
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->f32) {
+    for (int k = 0; k < n; ++k) ms[k] = 0.0;
+    int nl = 0;
+    const int rc = momf_timers(h->f32, ms, &nl);
+    if (rc) return fail(h, rc, momf_error(h->f32));
+    if (n >= 8) { ms[4] = ms[0]; ms[6] = nl; }
+    if (kernel_launches) *kernel_launches = nl;
+    return MOM_OK;
+  }
   HIPCHK(h, hipEventSynchronize(h->ev[3]));
   float t01, t12, t23, t03;
   HIPCHK(h, hipEventElapsedTime(&t01, h->ev[0], h->ev[1]));

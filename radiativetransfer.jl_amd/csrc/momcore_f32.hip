@@ -1,0 +1,348 @@
+// momcore_f32.hip -- the Float32 build of the scene-level path (mom_create(..., dtype = 1)).
+//
+// The reference selects its float type with `float_type` (parameters_from_yaml.jl:160; batched ops for Float32 at
+// gpu_batched.jl:45-58, the shapes of its own GPU tests: test/gpu_tests/gpu_batched_interaction.jl, n = 32, S = 20 000,
+// Float32).  The same device templates as the Float64 library are compiled here with MOM_REAL = float in namespace
+// momf: operators and sources in f32, products on v_mfma_f32_16x16x4_f32 (32 cycles per instruction per SIMD: twice
+// the f64 rate), LDS images half the size.  What runs: the fused per-layer kernels of the general path (LDS-resident
+// for N <= 64, generic mode above), layer-sweep mode, the surface layer (all three surface kinds) with HDRF/BHR, and
+// post-processing.  Not built for f32: the strip-chained images, the (I,Q) reduction of moment 0, the lane-per-point
+// kernel and the operator-level API (mom_elemental ... return MOM_EINVAL on a dtype = 1 handle).
+//
+// The C ABI keeps Float64 host arrays for both dtypes (a Float32 Julia host passes Float64.(x) and converts back):
+// inputs are rounded to f32 on upload, outputs widened on download.
+#define MOM_REAL float
+#define MOM_REAL_IS_FLOAT 1
+#define MOM_NS momf
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "momcore.h"
+
+#include "mom_diag.hpp"
+#include "mom_entry.hpp"
+#include "mom_host.hpp"
+
+using namespace momf;
+
+namespace {
+
+struct PostArgsF {
+  int N, nS, S, M, nVza, hdr_all, zeroT_hi;
+  const int *node;
+  const double *cos_mphi, *sin_mphi;
+  const float *J0p, *J0m, *hdrJ0, *hdrJm;
+  float *R, *T, *hdr;
+};
+// postprocessing_vza! / postprocessing_vza_hdrf! (postprocessing_vza.jl:9-93); the azimuthal weights stay Float64
+// like the reference's host-side `bigCS`, the sources are f32
+__global__ void k_postprocess_f32(PostArgsF a) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)a.nVza * a.nS * a.S;
+  if (idx >= total) return;
+  const int v = (int)(idx % a.nVza);
+  const int k = (int)((idx / a.nVza) % a.nS);
+  const size_t s = idx / ((size_t)a.nVza * a.nS);
+  const int row = (a.node[v] - 1) * a.nS + k;
+  float r = 0.f, t = 0.f, h = 0.f;
+  for (int m = 0; m < a.M; ++m) {
+    const double weight = (m == 0) ? 0.5 : 1.0;
+    const float cs = (float)(weight * ((k < 2) ? a.cos_mphi[v + (size_t)a.nVza * m] : a.sin_mphi[v + (size_t)a.nVza * m]));
+    const size_t o = row + (size_t)a.N * (s + (size_t)a.S * m);
+    r += cs * a.J0m[o];
+    if (!(a.zeroT_hi && m > 0)) t += cs * a.J0p[o];
+    if (m == 0) h += cs * a.hdrJ0[row + (size_t)a.N * s];
+    else if (a.hdr_all) h += cs * a.hdrJm[o];
+  }
+  a.R[idx] = r;
+  a.T[idx] = t;
+  a.hdr[idx] = h;
+}
+
+template <class T>
+hipError_t dmallocf(T **p, size_t count) { return hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T)); }
+
+std::vector<float> tof(const double *src, size_t n) {
+  std::vector<float> v(n);
+  for (size_t i = 0; i < n; ++i) v[i] = (float)src[i];
+  return v;
+}
+
+}  // namespace
+
+struct momf_scene {
+  int device = 0, N = 0, nS = 0, S = 0, Mmax = 0;
+  hipStream_t stream = nullptr;
+  DevStreams q{};
+  float *d_mu = nullptr, *d_wt = nullptr, *d_sg = nullptr;
+  float *comp[6] = {};
+  float *d_tau = nullptr, *d_varpi = nullptr, *d_zw = nullptr, *d_tau_sum = nullptr, *d_Zpp = nullptr, *d_Zmp = nullptr;
+  float *d_R = nullptr, *d_T = nullptr, *d_hdr = nullptr, *d_hdrJ = nullptr, *d_hdrJm = nullptr, *d_bhr_uw = nullptr,
+        *d_bhr_dw = nullptr, *d_scratch = nullptr, *d_Rsurf = nullptr, *d_albedo_spec = nullptr;
+  double *d_cos = nullptr, *d_sin = nullptr;
+  int *d_node = nullptr, *d_info = nullptr;
+  int Nz = 0, K = 0, M = 0, nVza = 0, surf_kind = 0, G = 1024;
+  float albedo = 0.f;
+  std::vector<int> nd, iface;
+  std::vector<float> h_mu;
+  bool lds = true, force_generic = false, sweep = true;
+  hipEvent_t ev[4] = {};
+  int launches = 0;
+  std::string err;
+};
+
+#define FCHK(s, call)                                                                                         \
+  do {                                                                                                        \
+    hipError_t e__ = (call);                                                                                  \
+    if (e__ != hipSuccess) {                                                                                  \
+      char b__[384];                                                                                          \
+      snprintf(b__, sizeof b__, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__);  \
+      (s)->err = b__;                                                                                         \
+      return MOM_EHIP;                                                                                        \
+    }                                                                                                         \
+  } while (0)
+
+const char *momf_error(const momf_scene *s) { return s->err.c_str(); }
+
+int momf_create(momf_scene **out, int device, hipStream_t stream, int N, int nS, int S, int max_m, int *d_info) {
+  momf_scene *s = new momf_scene();
+  *out = s;
+  s->device = device; s->N = N; s->nS = nS; s->S = S; s->Mmax = max_m; s->stream = stream; s->d_info = d_info;
+  s->lds = N <= 64;
+  FCHK(s, hipSetDevice(device));
+  FCHK(s, dmallocf(&s->d_mu, N));
+  FCHK(s, dmallocf(&s->d_wt, N));
+  FCHK(s, dmallocf(&s->d_sg, N));
+  for (int k = 0; k < 6; ++k) {
+    const size_t per = (k < 4) ? (size_t)comp_pitch(N) * N : (size_t)N;
+    FCHK(s, dmallocf(&s->comp[k], per * S * max_m));
+    FCHK(s, hipMemsetAsync(s->comp[k], 0, per * S * max_m * sizeof(float), stream));
+  }
+  const size_t scr = (size_t)s->G * kGenericBufs * mat_elems(N) + (size_t)ld_for(N) * np_for(N);
+  FCHK(s, dmallocf(&s->d_scratch, scr));
+  FCHK(s, hipMemsetAsync(s->d_scratch, 0, scr * sizeof(float), stream));
+  for (int k = 0; k < 4; ++k) FCHK(s, hipEventCreate(&s->ev[k]));
+  FCHK(s, hipStreamSynchronize(stream));
+  return MOM_OK;
+}
+
+void momf_destroy(momf_scene *s) {
+  if (!s) return;
+  auto fr = [](void *p) { if (p) (void)hipFree(p); };
+  fr(s->d_mu); fr(s->d_wt); fr(s->d_sg);
+  for (int k = 0; k < 6; ++k) fr(s->comp[k]);
+  fr(s->d_tau); fr(s->d_varpi); fr(s->d_zw); fr(s->d_tau_sum); fr(s->d_Zpp); fr(s->d_Zmp); fr(s->d_R); fr(s->d_hdr);
+  fr(s->d_hdrJ); fr(s->d_hdrJm); fr(s->d_bhr_uw); fr(s->d_bhr_dw); fr(s->d_scratch); fr(s->d_Rsurf); fr(s->d_albedo_spec);
+  fr(s->d_cos); fr(s->d_sin); fr(s->d_node);
+  for (int k = 0; k < 4; ++k) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
+  delete s;
+}
+
+void momf_set_options(momf_scene *s, int inv_mode, int force_generic, int sweep) {
+  s->q.inv_mode = inv_mode;
+  s->force_generic = force_generic != 0;
+  s->lds = (s->N <= 64) && !s->force_generic;
+  s->sweep = sweep != 0;
+}
+
+int momf_set_streams(momf_scene *s, const double *mu, const double *wt, const double *sg, int imu0, double mu0,
+                     const double *I0, const double *D, int regular) {
+  FCHK(s, hipSetDevice(s->device));
+  const int N = s->N;
+  const std::vector<float> fm = tof(mu, N), fw = tof(wt, N), fs = tof(sg, N);
+  s->h_mu = fm;
+  FCHK(s, hipMemcpyAsync(s->d_mu, fm.data(), N * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  FCHK(s, hipMemcpyAsync(s->d_wt, fw.data(), N * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  FCHK(s, hipMemcpyAsync(s->d_sg, fs.data(), N * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  FCHK(s, hipStreamSynchronize(s->stream));
+  DevStreams &q = s->q;
+  const int inv = q.inv_mode;
+  q.mu = s->d_mu; q.wt = s->d_wt; q.sg = s->d_sg;
+  for (int k = 0; k < 4; ++k) { q.I0[k] = (k < s->nS) ? (float)I0[k] : 0.f; q.D[k] = (k < s->nS) ? (float)D[k] : 1.f; }
+  q.N = N; q.nS = s->nS; q.imu0 = imu0; q.mu0 = (float)mu0; q.inv_mode = inv; q.regular = regular;
+  // `regular` was decided on the Float64 streams; two distinct f64 nodes may round to one f32 value, which only makes
+  // more stream pairs take the equal-mu branch of get_elem_rt! -- exactly what a Float32 reference run does
+  return MOM_OK;
+}
+
+template <class T, class U>
+static int upload_f(momf_scene *s, T **dst, const U *src, size_t n) {
+  if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+  FCHK(s, dmallocf(dst, n));
+  std::vector<T> v(n);
+  for (size_t i = 0; i < n; ++i) v[i] = (T)src[i];
+  FCHK(s, hipMemcpyAsync(*dst, v.data(), n * sizeof(T), hipMemcpyHostToDevice, s->stream));
+  FCHK(s, hipStreamSynchronize(s->stream));
+  return MOM_OK;
+}
+
+int momf_scene_set(momf_scene *s, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
+                   const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface, const double *tau_sum,
+                   double albedo, int nVza, const int *node, const double *cos_mphi, const double *sin_mphi) {
+  FCHK(s, hipSetDevice(s->device));
+  const size_t S = s->S, NN = (size_t)s->N * s->N;
+  int rc;
+  if ((rc = upload_f(s, &s->d_tau, tau, S * Nz))) return rc;
+  if ((rc = upload_f(s, &s->d_varpi, varpi, S * Nz))) return rc;
+  if ((rc = upload_f(s, &s->d_zw, zw, (size_t)K * S * Nz))) return rc;
+  if ((rc = upload_f(s, &s->d_tau_sum, tau_sum, S * (Nz + 1)))) return rc;
+  if ((rc = upload_f(s, &s->d_Zpp, Zpp, NN * K * M))) return rc;
+  if ((rc = upload_f(s, &s->d_Zmp, Zmp, NN * K * M))) return rc;
+  if ((rc = upload_f(s, &s->d_node, node, (size_t)nVza))) return rc;
+  if ((rc = upload_f(s, &s->d_cos, cos_mphi, (size_t)nVza * M))) return rc;
+  if ((rc = upload_f(s, &s->d_sin, sin_mphi, (size_t)nVza * M))) return rc;
+  auto renew = [&](float **p, size_t n) -> hipError_t { if (*p) { (void)hipFree(*p); *p = nullptr; } return dmallocf(p, n); };
+  const size_t nout = (size_t)nVza * s->nS * S;
+  FCHK(s, renew(&s->d_R, 2 * nout));
+  s->d_T = s->d_R + nout;
+  FCHK(s, renew(&s->d_hdr, nout));
+  FCHK(s, renew(&s->d_hdrJ, (size_t)s->N * S));
+  FCHK(s, renew(&s->d_bhr_uw, (size_t)s->nS * S));
+  FCHK(s, renew(&s->d_bhr_dw, (size_t)s->nS * S));
+  s->Nz = Nz; s->K = K; s->M = M; s->nVza = nVza; s->albedo = (float)albedo; s->surf_kind = 0;
+  s->nd.assign(ndoubl, ndoubl + Nz);
+  s->iface.assign(iface, iface + Nz);
+  return MOM_OK;
+}
+
+int momf_scene_set_surface(momf_scene *s, int kind, int M, const double *Rsurf, const double *albedo_spec) {
+  FCHK(s, hipSetDevice(s->device));
+  int rc;
+  if (kind == 1) {
+    if ((rc = upload_f(s, &s->d_Rsurf, Rsurf, (size_t)s->N * s->N * M))) return rc;
+    if (s->d_hdrJm) { (void)hipFree(s->d_hdrJm); s->d_hdrJm = nullptr; }
+    FCHK(s, dmallocf(&s->d_hdrJm, (size_t)s->N * s->S * M));
+  } else if (kind == 2) {
+    if ((rc = upload_f(s, &s->d_albedo_spec, albedo_spec, (size_t)s->S))) return rc;
+  }
+  s->surf_kind = kind;
+  return MOM_OK;
+}
+
+template <class K>
+static hipError_t allow(K kernel, size_t bytes) { return mom_allow_lds(reinterpret_cast<const void *>(kernel), bytes); }
+
+int momf_rt_run(momf_scene *s) {
+  FCHK(s, hipSetDevice(s->device));
+  const size_t S = s->S;
+  const int N = s->N, M = s->M, Nz = s->Nz;
+  const bool lds = s->lds;
+  const size_t sm = lds_bytes(N, lds);
+  s->launches = 0;
+  bool can_sweep = s->sweep && Nz <= kMaxSweepLayers && Nz > 1;
+  for (int z = 2; z < Nz && can_sweep; ++z) can_sweep = (s->iface[z] == s->iface[1]);
+  for (int z = 0; z < Nz && can_sweep; ++z) can_sweep = (s->nd[z] <= 127);
+  FCHK(s, hipEventRecord(s->ev[0], s->stream));
+  for (int z = (can_sweep ? -1 : 0); z < (can_sweep ? 0 : Nz); ++z) {
+    LayerArgs a{};
+    a.q = s->q; a.S = s->S; a.M = M; a.K = s->K; a.m_first = 0;
+    int zz = z;
+    if (z < 0) {
+      zz = 0;
+      a.Nz_sweep = Nz;
+      for (int k = 0; k < Nz; ++k) { a.nd_z[k] = (signed char)s->nd[k]; a.iface_z[k] = (signed char)s->iface[k]; }
+      a.nd = s->nd[0]; a.iface = s->iface[1]; a.first = 1;
+    } else {
+      a.nd = s->nd[z]; a.iface = s->iface[z]; a.first = (z == 0);
+    }
+    a.tau = s->d_tau + S * zz; a.varpi = s->d_varpi + S * zz; a.zw = s->d_zw + (size_t)s->K * S * zz;
+    a.tau_sum = s->d_tau_sum + S * zz;
+    a.Zpp = s->d_Zpp; a.Zmp = s->d_Zmp;
+    for (int k = 0; k < 6; ++k) a.comp[k] = s->comp[k];
+    a.scratch = s->d_scratch; a.info = s->d_info;
+    const int grid = lds ? (int)((S >= 2048) ? S : S * M) : (int)std::min<size_t>(S * M, (size_t)s->G);
+#define F32_LAUNCH(IF)                                                                            \
+  if (lds) {                                                                                      \
+    FCHK(s, allow(k_layer<true, IF>, sm));                                                        \
+    hipLaunchKernelGGL((k_layer<true, IF>), dim3(grid), dim3(kThreads), sm, s->stream, a);         \
+  } else {                                                                                        \
+    FCHK(s, allow(k_layer<false, IF>, sm));                                                       \
+    hipLaunchKernelGGL((k_layer<false, IF>), dim3(grid), dim3(kThreads), sm, s->stream, a);        \
+  }
+    switch (a.iface) {
+      case 0: F32_LAUNCH(0) break;
+      case 1: F32_LAUNCH(1) break;
+      case 2: F32_LAUNCH(2) break;
+      default: F32_LAUNCH(3) break;
+    }
+#undef F32_LAUNCH
+    FCHK(s, hipGetLastError());
+    s->launches++;
+  }
+  FCHK(s, hipEventRecord(s->ev[1], s->stream));
+  for (int m = 0; m < ((s->surf_kind == 1) ? M : 1); ++m) {
+    SurfArgs a{};
+    a.q = s->q; a.S = s->S; a.iface = s->iface[Nz - 1];
+    a.albedo = s->albedo; a.tau_tot = s->d_tau_sum + S * Nz;
+    a.kind = s->surf_kind; a.m = m; a.albedo_spec = s->d_albedo_spec;
+    a.Rsurf = (s->surf_kind == 1) ? s->d_Rsurf + (size_t)N * N * m : nullptr;
+    for (int k = 0; k < 6; ++k) a.comp[k] = s->comp[k] + ((k < 4) ? (size_t)comp_pitch(N) * N : (size_t)N) * S * m;
+    a.hdrJ = (m == 0) ? s->d_hdrJ : s->d_hdrJm + (size_t)N * S * m;
+    a.bhr_uw = s->d_bhr_uw; a.bhr_dw = s->d_bhr_dw; a.nS_out = s->nS;
+    a.scratch = s->d_scratch; a.info = s->d_info;
+    const int grid = lds ? (int)S : (int)std::min<size_t>(S, (size_t)s->G);
+    if (lds) {
+      FCHK(s, allow(k_surface<true>, sm));
+      hipLaunchKernelGGL(k_surface<true>, dim3(grid), dim3(kThreads), sm, s->stream, a);
+    } else {
+      FCHK(s, allow(k_surface<false>, sm));
+      hipLaunchKernelGGL(k_surface<false>, dim3(grid), dim3(kThreads), sm, s->stream, a);
+    }
+    FCHK(s, hipGetLastError());
+  }
+  FCHK(s, hipEventRecord(s->ev[2], s->stream));
+  {
+    const size_t total = (size_t)s->nVza * s->nS * S;
+    PostArgsF pa{};
+    pa.N = N; pa.nS = s->nS; pa.S = s->S; pa.M = M; pa.nVza = s->nVza;
+    pa.hdr_all = (s->surf_kind == 1); pa.zeroT_hi = (s->surf_kind == 2);
+    pa.node = s->d_node; pa.cos_mphi = s->d_cos; pa.sin_mphi = s->d_sin;
+    pa.J0p = s->comp[4]; pa.J0m = s->comp[5]; pa.hdrJ0 = s->d_hdrJ; pa.hdrJm = s->d_hdrJm;
+    pa.R = s->d_R; pa.T = s->d_T; pa.hdr = s->d_hdr;
+    hipLaunchKernelGGL(k_postprocess_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s->stream, pa);
+    FCHK(s, hipGetLastError());
+  }
+  FCHK(s, hipEventRecord(s->ev[3], s->stream));
+  return MOM_OK;
+}
+
+static int download_f(momf_scene *s, double *dst, const float *src, size_t n) {
+  std::vector<float> v(n);
+  FCHK(s, hipMemcpyAsync(v.data(), src, n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  FCHK(s, hipStreamSynchronize(s->stream));
+  for (size_t i = 0; i < n; ++i) dst[i] = (double)v[i];
+  return MOM_OK;
+}
+
+int momf_get_RT(momf_scene *s, double *R, double *T) {
+  FCHK(s, hipSetDevice(s->device));
+  const size_t nout = (size_t)s->nVza * s->nS * s->S;
+  int rc = download_f(s, R, s->d_R, nout);
+  if (rc) return rc;
+  return download_f(s, T, s->d_T, nout);
+}
+
+int momf_get_hdr(momf_scene *s, double *hdr, double *up, double *dw) {
+  FCHK(s, hipSetDevice(s->device));
+  int rc = download_f(s, hdr, s->d_hdr, (size_t)s->nVza * s->nS * s->S);
+  if (rc) return rc;
+  if ((rc = download_f(s, up, s->d_bhr_uw, (size_t)s->nS * s->S))) return rc;
+  return download_f(s, dw, s->d_bhr_dw, (size_t)s->nS * s->S);
+}
+
+int momf_timers(momf_scene *s, double *ms, int *launches) {
+  FCHK(s, hipSetDevice(s->device));
+  FCHK(s, hipEventSynchronize(s->ev[3]));
+  float t01, t12, t23, t03;
+  FCHK(s, hipEventElapsedTime(&t01, s->ev[0], s->ev[1]));
+  FCHK(s, hipEventElapsedTime(&t12, s->ev[1], s->ev[2]));
+  FCHK(s, hipEventElapsedTime(&t23, s->ev[2], s->ev[3]));
+  FCHK(s, hipEventElapsedTime(&t03, s->ev[0], s->ev[3]));
+  ms[0] = t01; ms[1] = t12; ms[2] = t23; ms[3] = t03;
+  *launches = s->launches;
+  return MOM_OK;
+}

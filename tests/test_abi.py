@@ -55,7 +55,7 @@ def test_argument_validation(rtamd):
     h = C.c_void_p()
     assert lib.mom_create(C.byref(h), 0, 0, 1, 1, 1, 0) == rtamd._lib.MOM_EINVAL
     assert lib.mom_create(C.byref(h), 0, 10, 3, 1, 1, 0) == rtamd._lib.MOM_EINVAL  # N % nStokes != 0
-    assert lib.mom_create(C.byref(h), 0, 12, 3, 1, 1, 1) == rtamd._lib.MOM_EINVAL  # dtype f32 not implemented
+    assert lib.mom_create(C.byref(h), 0, 12, 3, 1, 1, 2) == rtamd._lib.MOM_EINVAL  # dtype: 0 = Float64, 1 = Float32
     assert b"dtype" in lib.mom_last_global_error()
     assert lib.mom_sync(None) == rtamd._lib.MOM_EINVAL and lib.mom_destroy(None) == 0
     g = np.ones(4)

@@ -424,3 +424,38 @@ def test_surface_types(rtamd, cref, surf, nS, lt, mode):
     m.params.brdf = None
     R0, _ = rtamd.rt_run(m)[:2]
     assert np.abs(R0 - R).max() > 1e-6
+
+
+@pytest.mark.parametrize("nS,lt,kw", [(3, 9, {}), (1, 5, {}), (4, 7, {}), (3, 33, {}), (4, 31, dict(generic=True)), (3, 9, dict(surf="rpv"))])
+def test_float32_scene_level_path(rtamd, cref, nS, lt, kw):
+    """dtype = 1 (the reference's float_type = Float32): the same scene through the f32 build of the fused kernels
+    (v_mfma_f32_16x16x4_f32, operators in f32) against the Float64 oracle.  Tolerance: the elemental layer has
+    dtau <= 1e-3 min(mu) (rt_kernel.jl:241), so its transmission along the most vertical stream, t = exp(-dtau/mu_max)
+    ~ 1 - 1e-3 min(mu)/max(mu), is stored in Float32 with an absolute error of eps32 = 6e-8: a RELATIVE error of
+    eps32 / (1e-3 min(mu)) of that stream's optical depth, which the doublings carry into the layer transmission.
+    rtol = 16 eps32 / (1e-3 min(mu)): 2e-2 for 5 Gauss nodes, 0.2 for the 17 of N = 60 (min(mu) = 0.0046); measured
+    1e-3 ... 8e-3 and 2.5e-2.  Any Float32 run of the reference's algorithm carries this error."""
+    kw = dict(kw)
+    generic = kw.pop("generic", False)
+    surf = kw.pop("surf", None)
+    m = rtamd.scenes.make_scene(nS, lt, 4, 40, seed=23, aerosol_total=0.1)
+    if surf:
+        m.params.brdf = _surfaces(rtamd.corert)[surf]
+    sc = rtamd.prepare_scene(m)
+    Rr, Tr, Hr, upr, dwr, info = cref.rt_run_full(cref.pack_scene(helpers.oracle_scene(m)))
+    with rtamd.corert.make_handle(m, float_type="Float32") as h:
+        if generic:
+            h.set_option(rtamd._lib.MOM_OPT_FORCE_GENERIC, 1)
+        R, T = rtamd.corert.run_scene(h, sc)
+        H, up, dw = h.get_hdr()
+        assert h.timers()["layer_launches"] >= 1
+        with pytest.raises(rtamd.MomError) as e:   # operator-level API: Float64 handles only
+            h.doubling(1, np.ones(sc.S))
+        assert e.value.code == rtamd._lib.MOM_EINVAL and "Float32" in str(e.value)
+    tol = 16 * 6e-8 / (1e-3 * float(m.quad_points.qp_μ.min()))
+    eR = helpers.assert_stokes_close(R, Rr, rtol=tol, atol=1e-6, what="f32 R")
+    eT = helpers.assert_stokes_close(T, Tr, rtol=tol, atol=1e-6, what="f32 T")
+    helpers.assert_stokes_close(H, Hr, rtol=tol, atol=1e-6, what="f32 hdr")
+    np.testing.assert_allclose(up[0], upr[0], rtol=tol)
+    print(f"float32 vs oracle: max |dR|/I = {eR:.2e}, max |dT|/I = {eT:.2e}, nd max {int(sc.ndoubl.max())}")
+    assert not np.array_equal(R, Rr)  # it really is a different precision
