@@ -420,7 +420,7 @@ __device__ __forceinline__ void wg_inverse(int N, const FastDiv &fd, real *a, in
 // not yet used as pivots; rows are never moved, the permutation is undone when the result is
 // written back (inv(A)[k][p_j] = S[p_k][j]).  Per elimination step: one wave-level max + ballot in
 // the wave that owns column k, ONE workgroup barrier (pivot column / index / reciprocal travel
-// through real-buffered LDS slots), CW readlane broadcasts of the pivot row and CW FMAs per lane.
+// through double-buffered LDS slots), CW readlane broadcasts of the pivot row and CW FMAs per lane.
 // a: column-major buffer (ld) holding the matrix on entry and the inverse on exit.
 // pcol: LDS, >= 2*64 doubles; shd: LDS, >= 4 doubles; ipiv: LDS ints >= 64; bad: LDS int.
 // ---------------------------------------------------------------------------------------

@@ -98,10 +98,13 @@ constexpr int kNumVec = 15 + 2 * kWaves;  // vectors carved from LDS (part = 2*k
 constexpr int kGenericBufs = 5;
 // generic mode, N > 64: LDS staging tiles of wg_gemm_big behind the vectors: A panels [2][kBigKB][kBigLdA] and
 // B panels [2][256][kBigLdB] doubles
-constexpr int kBigKB = 8;      // k extent of a panel (2 MFMA k-steps)
+#ifndef MOM_BIG_KB
+#define MOM_BIG_KB 8
+#endif
+constexpr int kBigKB = MOM_BIG_KB;  // k extent of a panel (MOM_BIG_KB / 4 MFMA k-steps between two barriers)
 constexpr int kBigRows = 128;  // rows of the output block of one pass (2 x 4 waves of 64 x 64)
 constexpr int kBigLdA = 144;   // row pitch of an A panel: 128 + 16 (ds_read_b64 of 16 rows x 2 k conflict-free)
-constexpr int kBigLdB = 10;    // k pitch of a B-panel column: 8 + 2
+constexpr int kBigLdB = kBigKB + 2;  // k pitch of a B-panel column (ds_read_b64 of 2 k x 16 columns conflict-free for 10, 14, 18)
 constexpr int kBigCols = 256;  // largest operator the tiles are sized for
 constexpr int kBigTileDoubles = 2 * kBigKB * kBigLdA + 2 * kBigCols * kBigLdB;
 __host__ __device__ inline size_t vec_area_doubles(int N) {
@@ -300,7 +303,7 @@ __host__ __device__ inline int comp_pitch(int N) { return 16 * ((N + 15) / 16); 
 // ---------------------------------------------------------------------------------------
 // C(i,j) <- epi(i, j, sum_k A(i,k) B(k,j)) for 64 < N <= 256 (generic mode): the operands live in global memory
 // (per-workgroup scratch slab or the composite layer); each k panel of 8 is staged once through LDS with coalesced
-// loads and feeds 8 waves x 4 x 4 MFMA tiles (64 x 64 outputs per wave, 128 x 256 per pass), real-buffered: the
+// loads and feeds 8 waves x 4 x 4 MFMA tiles (64 x 64 outputs per wave, 128 x 256 per pass), double-buffered: the
 // loads of panel p+1 are in flight while panel p is multiplied, one barrier per panel.  Against the element-functor
 // loop of wg_gemm_n (every MFMA operand a separate 8-byte global load) this reads each operand element once per pass.
 // All threads must call; C must not alias A or B; ends WITHOUT a barrier after the epilogue (callers add theirs).
@@ -320,41 +323,48 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = (r4){0.0, 0.0, 0.0, 0.0};
-    real ra[2], rb[4];
-    auto fetch = [&](int p) {
+    // two register sets: the loads of panel p + 2 are issued while panel p is multiplied and reach LDS one iteration
+    // later -- two panel times (~8 k cycles) to cover an HBM / Infinity-Cache round trip
+    constexpr int kNA = kBigRows * kBigKB / kThreads, kNB = kBigCols * kBigKB / kThreads;  // elements per thread and panel
+    static_assert(kNA * kThreads == kBigRows * kBigKB && kNB * kThreads == kBigCols * kBigKB, "panel must divide over the threads");
+    real ra[2][kNA], rb[2][kNB];
+    auto fetch = [&](int p, int set) {
       const int k0 = p * kBigKB;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < kNA; ++u) {
         const int e = tid + kThreads * u, row = e & (kBigRows - 1), kk = e >> 7;
         const int i = row0 + row, k = k0 + kk;
-        ra[u] = (i < N && k < N) ? A(i, k) : 0.0;
+        ra[set][u] = (i < N && k < N) ? A(i, k) : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = tid + kThreads * u, kk = e & (kBigKB - 1), col = e >> 3;
+      for (int u = 0; u < kNB; ++u) {
+        const int e = tid + kThreads * u, col = e / kBigKB, kk = e - col * kBigKB;
         const int k = k0 + kk;
-        rb[u] = (k < N && col < NC) ? B(k, col) : 0.0;
+        rb[set][u] = (k < N && col < NC) ? B(k, col) : 0.0;
       }
     };
-    auto stash = [&](int stage) {
+    auto stash = [&](int stage, int set) {
       real *sa = tA + stage * kBigKB * kBigLdA, *sb = tB + stage * kBigCols * kBigLdB;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < kNA; ++u) {
         const int e = tid + kThreads * u, row = e & (kBigRows - 1), kk = e >> 7;
-        sa[row + kk * kBigLdA] = ra[u];
+        sa[row + kk * kBigLdA] = ra[set][u];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = tid + kThreads * u, kk = e & (kBigKB - 1), col = e >> 3;
-        sb[kk + col * kBigLdB] = rb[u];
+      for (int u = 0; u < kNB; ++u) {
+        const int e = tid + kThreads * u, col = e / kBigKB, kk = e - col * kBigKB;
+        sb[kk + col * kBigLdB] = rb[set][u];
       }
     };
     __syncthreads();  // the previous pass (or the caller) is done with the tiles
-    fetch(0);
-    stash(0);
+    fetch(0, 0);
+    if (P > 1) fetch(1, 1);
+    stash(0, 0);
     __syncthreads();
-    for (int p = 0; p < P; ++p) {
-      if (p + 1 < P) fetch(p + 1);
+    // panels are walked two per trip so that the register-set index is a compile-time constant
+    auto panel = [&](int p, auto setc) {
+      constexpr int SET = decltype(setc)::value;  // set holding panel p + 1 (fetched one iteration ago)
+      if (p + 2 < P) fetch(p + 2, 1 - SET);        // -> the set panel p's data came from, free since its stash
       const real *sa = tA + (p & 1) * kBigKB * kBigLdA + 64 * wr + lr + lq * kBigLdA;
       const real *sb = tB + (p & 1) * kBigCols * kBigLdB + lq + (64 * wc + lr) * kBigLdB;
 #pragma unroll
@@ -370,8 +380,12 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
           for (int tj = 0; tj < 4; ++tj)
             if (64 * wc + 16 * tj < Np) acc[ti][tj] = mma16(a[ti], b[tj], acc[ti][tj]);
       }
-      if (p + 1 < P) stash((p + 1) & 1);
+      if (p + 1 < P) stash((p + 1) & 1, SET);
       __syncthreads();
+    };
+    for (int p = 0; p < P; p += 2) {
+      panel(p, std::integral_constant<int, 1>{});
+      if (p + 1 < P) panel(p + 1, std::integral_constant<int, 0>{});
     }
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
