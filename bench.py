@@ -120,6 +120,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
+    nccl_group = None
     collective = "none"
     if world > 1:
         import torch.distributed as dist
@@ -147,9 +148,30 @@ def main():
     G = torch.empty(2 * nout * world, dtype=torch.float64, device=dev) if world > 1 else None
     Gh = torch.empty(2 * nout * world, dtype=torch.float64) if (world > 1 and a.backend == "gloo") else None
     if world > 1 and a.backend == "rccl":
-        ident = [rtamd._lib.comm_unique_id() if rank == 0 else None]
+        # RCCL through the C ABI.  Should its set-up fail on ANY rank (a mis-matched RCCL/HIP pair in the host process,
+        # for instance), every rank falls back -- together -- to torch.distributed's own RCCL group, so that a scaling
+        # run still produces its line; the JSON says which collective ran.
+        ok = 1
+        try:
+            ident = [rtamd._lib.comm_unique_id() if rank == 0 else None]
+        except Exception as e:
+            ident, ok = [None], 0
+            print(f"bench.py: mom_comm_unique_id failed on rank {rank}: {e}", file=sys.stderr)
         dist.broadcast_object_list(ident, src=0)
-        h.comm_init(rank, world, ident[0])
+        if ok and ident[0] is not None:
+            try:
+                h.comm_init(rank, world, ident[0])
+            except Exception as e:
+                ok = 0
+                print(f"bench.py: mom_comm_init failed on rank {rank}: {e}", file=sys.stderr)
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            nccl_group = dist.new_group(backend="nccl")
+            a.backend = "torch-fallback"
+            collective = "torch.distributed all_gather_into_tensor (RCCL; fallback: the C-ABI communicator failed to initialise)"
 
     def step():
         h.rt_run()
@@ -157,10 +179,10 @@ def main():
             h.get_RT_device(RT.data_ptr(), RT.data_ptr() + 8 * nout)      # asynchronous, library stream
         elif a.backend == "rccl":
             h.allgather_RT_device(G.data_ptr())                           # ONE collective, library stream
-        elif a.backend == "torch":
+        elif a.backend in ("torch", "torch-fallback"):
             h.get_RT_device(RT.data_ptr(), RT.data_ptr() + 8 * nout)
             h.sync()
-            dist.all_gather_into_tensor(G, RT)                            # ONE collective: R and T packed
+            dist.all_gather_into_tensor(G, RT, group=nccl_group)          # ONE collective: R and T packed
         else:
             h.get_RT_device(RT.data_ptr(), RT.data_ptr() + 8 * nout)
             h.sync()

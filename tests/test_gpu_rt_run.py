@@ -344,8 +344,12 @@ def test_rccl_allgather_single_rank(rtamd):
         R, T = rtamd.corert.run_scene(h, sc)
         h.comm_init(0, 1, rtamd._lib.comm_unique_id())
         Rg, Tg = h.allgather_RT()
+        # device-side optics with a communicator: the per-layer maxima go through ncclAllReduce(max) before ndoubl is derived
+        R2, T2 = rtamd.corert.run_scene_device_optics(h, m)
+        nd, iface = h.scene_get_layers(sc.Nz, sc.K, arrays=False)[:2]
         h.comm_destroy()
     assert np.array_equal(Rg, R) and np.array_equal(Tg, T)
+    assert np.array_equal(nd, sc.ndoubl) and np.array_equal(iface, sc.iface) and np.array_equal(R2, R)
 
 
 @pytest.mark.parametrize("nS,lt,aer", [(3, 9, 0.2), (1, 5, 0.0), (4, 7, 0.4), (3, 33, 0.2)])
