@@ -271,6 +271,7 @@ int momf_get_hdr(momf_scene *s, double *hdr, double *up, double *dw);
 int momf_timers(momf_scene *s, double *ms, int *launches);
 // mom_small.hip: N <= 4, one spectral point per lane, the whole sweep in one launch
 hipError_t momsm_launch_sweep(const void *args, int N, hipStream_t st);
+hipError_t momw_launch_sweep(const void *args, hipStream_t st);
 
 static thread_local std::string g_err;
 static int check_info(mom_t *h);
@@ -1014,6 +1015,59 @@ static int rt_run_small(mom_t *h) {
   return MOM_OK;
 }
 
+// The argument block of momw::k_wsweep (mom_wave.hip), layout-identical plain data
+struct WaveSweepArgs {
+  int N, S, M, K, Nz, nVza, nS, imu0, inv_mode, pad;
+  double mu0, albedo;
+  double I0[4], D[4];
+  const double *mu, *wt, *sg, *Zpp, *Zmp;
+  const int *nd, *node;
+  const double *cos_mphi, *sin_mphi;
+  const double *tau, *varpi, *zw, *tau_sum;
+  double *R, *T, *hdr, *bhr_uw, *bhr_dw;
+  int *info;
+};
+
+// the wave-per-point kernel covers ScatteringInterface_11 on every layer after the first and at the surface
+static bool wave_sweep_applies(const mom_t *h) {
+  if (!(h->N > 4 && h->N <= 16 && h->opt_small && h->surf_kind == 0 && h->nVza * h->nS <= 64)) return false;
+  for (int z = 1; z < h->Nz; ++z)
+    if (h->iface[z] != 3) return false;
+  return h->iface[h->Nz - 1] == 3;
+}
+
+// 4 < N <= 16: one spectral point per wavefront, operators in MFMA-layout registers, ONE launch
+static int rt_run_wave(mom_t *h) {
+  const int Nz = h->Nz;
+  {
+    if (h->d_ndif) { (void)hipFree(h->d_ndif); h->d_ndif = nullptr; }
+    HIPCHK(h, dmalloc(&h->d_ndif, (size_t)Nz));
+    HIPCHK(h, hipMemcpyAsync(h->d_ndif, h->nd.data(), (size_t)Nz * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  WaveSweepArgs a{};
+  a.N = h->N; a.S = h->S; a.M = h->scene_M; a.K = h->K; a.Nz = Nz; a.nVza = h->nVza; a.nS = h->nS; a.imu0 = h->q.imu0;
+  a.inv_mode = h->opt_inverse;
+  a.mu0 = h->q.mu0; a.albedo = h->albedo;
+  for (int k = 0; k < 4; ++k) { a.I0[k] = h->q.I0[k]; a.D[k] = h->q.D[k]; }
+  a.mu = h->d_mu; a.wt = h->d_wt; a.sg = h->d_sg;
+  a.Zpp = h->d_Zpp; a.Zmp = h->d_Zmp;
+  a.nd = h->d_ndif; a.node = h->d_node; a.cos_mphi = h->d_cos; a.sin_mphi = h->d_sin;
+  a.tau = h->d_tau; a.varpi = h->d_varpi; a.zw = h->d_zw; a.tau_sum = h->d_tau_sum;
+  a.R = h->d_R; a.T = h->d_T; a.hdr = h->d_hdr; a.bhr_uw = h->d_bhr_uw; a.bhr_dw = h->d_bhr_dw;
+  a.info = h->d_info;
+  while (h->ev_full.size() < 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_full.push_back(e); }
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_full[0], h->stream));
+  HIPCHK(h, momw_launch_sweep(&a, h->stream));
+  HIPCHK(h, hipEventRecord(h->ev_full[1], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // h->nd may be rewritten by the next scene_set
+  h->launches = 1; h->launches_full = 1; h->launches_red = 0;
+  return MOM_OK;
+}
+
 extern "C" int mom_rt_run(mom_t *h) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_rt_run: call mom_scene_set first");
@@ -1027,6 +1081,7 @@ extern "C" int mom_rt_run(mom_t *h) {
   h->launches = 0; h->launches_full = 0; h->launches_red = 0;
   h->comp_pitched = true;
   if (h->N <= 4 && h->opt_small && h->nVza <= 4 && h->surf_kind == 0) return rt_run_small(h);
+  if (wave_sweep_applies(h)) return rt_run_wave(h);
   while (h->ev_full.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_full.push_back(e); }
   while (h->ev_red.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_red.push_back(e); }
   const size_t NN = (size_t)h->N * h->N;

@@ -36,14 +36,15 @@ def test_config_C1_default_scalar(rtamd, cref):
 
 
 @pytest.mark.parametrize("lt,vza,kw", [(3, (0.0,), {}), (3, (0.0,), dict(aerosol_total=0.0, zero_layers=(0, 1, 3))),
-                                       (1, (0.0,), dict(albedo=0.35)), (1, (50.0,), {}), (3, (60.0,), dict(aerosol_total=1.5))])
+                                       (1, (0.0,), dict(albedo=0.35)), (1, (50.0,), {}), (3, (60.0,), dict(aerosol_total=1.5)),
+                                       (1, (0.0, 30.0), {}), (1, (0.0, 50.0, 50.0, 0.0), dict(albedo=0.1))])
 def test_small_operator_sweep_kernel(rtamd, cref, lt, vza, kw):
     """N <= 4 (mom_small.hip: one spectral point per lane, the whole sweep in one launch) against the oracle AND against
     the general workgroup-per-point kernels (MOM_OPT_SMALL_N = 0): spectra, hdr and the BHR fluxes; includes all four
     interface cases with zero doublings, N = 2, 3, 4 and a thick aerosol layer."""
     kw = dict(kw)
     zero = kw.pop("zero_layers", ())
-    m = rtamd.scenes.make_scene(1, lt, 6, 200, seed=5 + lt, vza=vza, vaz=(30.0,) * len(vza), **kw)
+    m = rtamd.scenes.make_scene(1, lt, 6, 200, seed=5 + lt, vza=vza, vaz=tuple(30.0 + 40.0 * i for i in range(len(vza))), **kw)
     for z in zero:
         m.τ_rayl[:, z] = 0.0
     sc = rtamd.prepare_scene(m)
@@ -66,6 +67,61 @@ def test_small_operator_sweep_kernel(rtamd, cref, lt, vza, kw):
         helpers.assert_stokes_close(H, Hr, rtol=tol, what=f"hdr small={small}")
         np.testing.assert_allclose(up, upr, rtol=max(tol, 1e-10), atol=1e-300)
         np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=1e-300)
+
+
+@pytest.mark.parametrize("nS,lt,vza,kw", [
+    (1, 9, (0.0, 30.0), {}),                                    # N = 8
+    (1, 21, (0.0, 30.0, 60.0), dict(aerosol_total=1.0)),        # N = 14
+    (3, 3, (0.0,), {}),                                         # N = 12, polarized
+    (3, 5, (20.0,), dict(albedo=0.6)),                          # N = 15
+    (4, 3, (0.0,), {}),                                         # N = 16, IQUV
+    (4, 3, (0.0,), dict(aerosol_total=3.0, albedo=0.05)),       # N = 16, thick aerosol: long series / pivoted inverse
+    (3, 1, (0.0,), {}),                                         # N = 9
+])
+@pytest.mark.parametrize("inverse", [0, 1])
+def test_wave_per_point_sweep_kernel(rtamd, cref, nS, lt, vza, kw, inverse):
+    """4 < N <= 16 (mom_wave.hip: one spectral point per wavefront, operators as MFMA-layout register tiles, the whole
+    sweep in one launch) against the oracle and against the general kernels; inverse = 1 forces the pivoted
+    Gauss-Jordan inverse in place of the series."""
+    m = rtamd.scenes.make_scene(nS, lt, 8, 300, seed=11 + lt + nS, vza=vza,
+                                vaz=tuple(15.0 + 50.0 * i for i in range(len(vza))), **kw)
+    sc = rtamd.prepare_scene(m)
+    assert 4 < sc.N <= 16, sc.N
+    p = cref.pack_scene(helpers.oracle_scene(m))
+    Rr, Tr, Hr, upr, dwr, info = cref.rt_run_full(p)
+    assert info == 0
+    out = {}
+    for small in (1, 0):
+        with rtamd.corert.make_handle(m) as h:
+            h.set_option(rtamd._lib.MOM_OPT_SMALL_N, small)
+            h.set_option(rtamd._lib.MOM_OPT_INVERSE, inverse)
+            R, T = rtamd.corert.run_scene(h, sc)
+            out[small] = (R, T) + h.get_hdr() + (h.timers()["layer_launches"],)
+    assert out[1][5] == 1                            # the whole sweep in ONE launch
+    tol = helpers.stokes_rtol(sc.ndoubl)
+    for small in (1, 0):
+        R, T, H, up, dw, _ = out[small]
+        helpers.assert_stokes_close(R, Rr, rtol=tol, what=f"R small={small}")
+        helpers.assert_stokes_close(T, Tr, rtol=tol, what=f"T small={small}")
+        helpers.assert_stokes_close(H, Hr, rtol=tol, what=f"hdr small={small}")
+        np.testing.assert_allclose(up, upr, rtol=max(tol, 1e-10), atol=1e-300)
+        np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=1e-300)
+
+
+def test_wave_kernel_falls_back_on_other_interfaces(rtamd, cref):
+    """Layers without scattering above the first scattering layer give interface codes other than 11: the wave-per-point
+    kernel does not apply and the general kernels run."""
+    m = rtamd.scenes.make_scene(3, 3, 8, 64, seed=3, vza=(0.0,), vaz=(0.0,), aerosol_total=0.0)
+    for z in (0, 1, 3):
+        m.τ_rayl[:, z] = 0.0
+    sc = rtamd.prepare_scene(m)
+    assert 4 < sc.N <= 16
+    with rtamd.corert.make_handle(m) as h:
+        R, T = rtamd.corert.run_scene(h, sc)
+        assert h.timers()["layer_launches"] > 1
+    Rr, Tr = _oracle(cref, m)
+    helpers.assert_stokes_close(R, Rr, what="R")
+    helpers.assert_stokes_close(T, Tr, what="T")
 
 
 def test_config_C2_full_size_stratified(rtamd, cref):
