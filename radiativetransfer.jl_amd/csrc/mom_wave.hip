@@ -22,19 +22,26 @@
 
 #include "mom_host.hpp"
 
+#ifndef MOMW_OCC
+#define MOMW_OCC 2  // waves per SIMD the kernel is built for
+#endif
+
 namespace momw {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// KS = ceil(N / 4) k-steps: rows >= 4 KS of every tile are zero padding
+template <int KS>
 __device__ __forceinline__ d4 TN(d4 U, d4 V) {  // U^T V
   d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[s], V[s], acc, 0, 0, 0);
+  for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[s], V[s], acc, 0, 0, 0);
   return acc;
 }
+template <int KS>
 __device__ __forceinline__ d4 TNacc(d4 U, d4 V, d4 acc) {  // acc + U^T V
 #pragma unroll
-  for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[s], V[s], acc, 0, 0, 0);
+  for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[s], V[s], acc, 0, 0, 0);
   return acc;
 }
 __device__ __forceinline__ double wave_sum(double v) {
@@ -82,14 +89,30 @@ struct WArgs {
   int *info;
 };
 
-// per-lane constants of the tile layout
+// per-lane constants of the tile layout; the row quantities (row = lq + 4 r) are read from the block's LDS table
+// tab = mu[16] | wt[16] | sg[16] (padding rows: mu = 1, wt = 0, sg = 1) when needed instead of living in 24 VGPRs
 struct Lay {
   int lr, lq, N, nS;
-  bool cok;               // column < N
-  bool rok[4];            // row < N
-  double mur[4], wr[4], sgr[4];  // row quantities (row = lq + 4 r)
-  double muc, wc, sgc;           // column quantities (column = lr)
+  bool cok;                // column < N
+  double muc, wc, sgc;     // column quantities (column = lr)
+  const double *tab;
+  __device__ __forceinline__ bool rok(int r) const { return lq + 4 * r < N; }
+  __device__ __forceinline__ double mur(int r) const { return tab[lq + 4 * r]; }
+  __device__ __forceinline__ double wr(int r) const { return tab[16 + lq + 4 * r]; }
+  __device__ __forceinline__ double sgr(int r) const { return tab[32 + lq + 4 * r]; }
 };
+__device__ __forceinline__ d4 ident(const Lay &L) {
+  d4 I;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) I[r] = (L.lq + 4 * r == L.lr && L.cok) ? 1.0 : 0.0;
+  return I;
+}
+__device__ __forceinline__ d4 scaleD(const Lay &L, d4 X) {  // D X D, D = Diagonal(sg)
+  d4 Y;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Y[r] = (L.sgr(r) * L.sgc) * X[r];
+  return Y;
+}
 
 // (I - B)^-1 for the tile pair (B in c-form Bc, B^T in c-form Bt): Horner G <- I + B G = I + TN(Bt, G); beyond 32
 // terms (or MOM_OPT_INVERSE = 1) Gauss-Jordan with implicit partial pivoting in a row-per-lane layout through the
@@ -145,15 +168,17 @@ __device__ __noinline__ d4 inverse_gj(d4 Bc, d4 Ic, int N, double *lds, int *ipi
   return G;
 }
 
-__device__ __forceinline__ d4 inv_one_minus(const Lay &L, d4 Bc, d4 Bt, d4 Ic, int inv_mode, double *lds, int *ipiv, int &bad) {
+template <int KS>
+__device__ __forceinline__ d4 inv_one_minus(const Lay &L, d4 Bc, d4 Bt, int inv_mode, double *lds, int *ipiv, int &bad) {
   double ss = 0.0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) ss += Bc[r] * Bc[r];
   const double beta2 = wave_sum(ss);
   const int p = (inv_mode == 1) ? 1000 : series_terms(beta2);
+  const d4 Ic = ident(L);
   if (p <= 32) {
     d4 G = Ic;
-    for (int k = 1; k < p; ++k) G = TNacc(Bt, G, Ic);
+    for (int k = 1; k < p; ++k) G = TNacc<KS>(Bt, G, Ic);
     return G;
   }
   int b = 0;
@@ -162,76 +187,84 @@ __device__ __forceinline__ d4 inv_one_minus(const Lay &L, d4 Bc, d4 Bt, d4 Ic, i
   return G;
 }
 
-// ScatteringInterface_11 (interaction.jl:69-117) on tiles.  Added layer: r-+ (rc, rt), t++ (tc, tt), r+- = D r-+ D (rpm_c,
-// rpm_t), t-- = D t++ D (tmm_c), sources jv (column 0 j0+, column 1 j0-).  Composite state kept in exactly the forms the
-// next interaction consumes: R-+ (c), R+- (c and t), T++ (c), T-- (t), Jv (column 0 J0+, column 1 J0-).
+// ScatteringInterface_11 (interaction.jl:69-117) on tiles.  Added layer: r-+ (rc, rt), t++ (tc, tt), sources jv (column 0
+// j0+, column 1 j0-); r+- = D r-+ D and t-- = D t++ D are formed where they are used (SURF: the surface layer has
+// r+- = 0, t = I).  Composite state kept in exactly the forms the next interaction consumes: R-+ (c), R+- (c and t),
+// T++ (c), T-- (t), Jv (column 0 J0+, column 1 J0-).
 struct Comp {
   d4 Rmp_c, Rpm_c, Rpm_t, Tpp_c, Tmm_t, Jv;
 };
-__device__ __forceinline__ void interact11(const Lay &L, Comp &C, d4 rc, d4 rt, d4 tc, d4 tt, d4 rpm_c, d4 rpm_t, d4 tmm_c,
-                                           d4 jv, d4 Ic, int inv_mode, double *lds, int *ipiv, int &bad) {
+template <int KS, bool SURF>
+__device__ __forceinline__ void interact11(const Lay &L, Comp &C, d4 rc, d4 rt, d4 tc, d4 tt, d4 jv, int inv_mode,
+                                           double *lds, int *ipiv, int &bad) {
   // --- T01 = T-- (I - r-+ R+-)^-1                                                   (:81-87)
-  const d4 B1 = TN(rt, C.Rpm_c), B1t = TN(C.Rpm_c, rt);
-  const d4 G1 = inv_one_minus(L, B1, B1t, Ic, inv_mode, lds, ipiv, bad);
-  const d4 T01t = TN(G1, C.Tmm_t);  // (T-- G1)^T = G1^T T--^T
+  const d4 B1 = TN<KS>(rt, C.Rpm_c), B1t = TN<KS>(C.Rpm_c, rt);
+  const d4 G1 = inv_one_minus<KS>(L, B1, B1t, inv_mode, lds, ipiv, bad);
+  const d4 T01t = TN<KS>(G1, C.Tmm_t);  // (T-- G1)^T = G1^T T--^T
   // J0- = J0- + T01 (r-+ J0+ + j0-)                                                  (:90)  [old J0+]
-  const d4 V1 = TN(rt, C.Jv);       // column 0: r-+ J0+
-  const d4 jsw = shfl_xor1(jv);     // column 0: j0-
+  const d4 V1 = TN<KS>(rt, C.Jv);       // column 0: r-+ J0+
+  const d4 jsw = shfl_xor1(jv);         // column 0: j0-
   d4 X1;
 #pragma unroll
   for (int r = 0; r < 4; ++r) X1[r] = (L.lr == 0) ? V1[r] + jsw[r] : 0.0;
-  const d4 TX1 = TN(T01t, X1);      // column 0: T01 (...)
+  const d4 TX1 = TN<KS>(T01t, X1);      // column 0: T01 (...)
   const d4 TX1s = shfl_xor1(TX1);
   // R-+ = R-+ + T01 r-+ T++                                                          (:93)
-  const d4 rT = TN(rt, C.Tpp_c);
-  const d4 Rmp_new = TNacc(T01t, rT, C.Rmp_c);
+  const d4 rT = TN<KS>(rt, C.Tpp_c);
+  C.Rmp_c = TNacc<KS>(T01t, rT, C.Rmp_c);
   // T-- = T01 t--   (kept transposed: t--^T T01^T)                                   (:96)
-  const d4 Tmm_t_new = TN(tmm_c, T01t);
+  C.Tmm_t = SURF ? T01t : TN<KS>(scaleD(L, tc), T01t);
   // --- T21 = t++ (I - R+- r-+)^-1                                                   (:104-107)  [old R+-]
-  const d4 B2 = TN(C.Rpm_t, rc), B2t = TN(rc, C.Rpm_t);
-  const d4 G2 = inv_one_minus(L, B2, B2t, Ic, inv_mode, lds, ipiv, bad);
-  const d4 T21t = TN(G2, tt);
+  const d4 B2 = TN<KS>(C.Rpm_t, rc), B2t = TN<KS>(rc, C.Rpm_t);
+  const d4 G2 = inv_one_minus<KS>(L, B2, B2t, inv_mode, lds, ipiv, bad);
+  const d4 T21t = SURF ? TN<KS>(G2, ident(L)) : TN<KS>(G2, tt);
   // J0+ = j0+ + T21 (J0+ + R+- j0-)                                                  (:110)
-  const d4 V2 = TN(C.Rpm_t, jv);    // column 1: R+- j0-
+  const d4 V2 = TN<KS>(C.Rpm_t, jv);    // column 1: R+- j0-
   const d4 V2s = shfl_xor1(V2);
   d4 X2;
 #pragma unroll
   for (int r = 0; r < 4; ++r) X2[r] = (L.lr == 0) ? C.Jv[r] + V2s[r] : 0.0;
-  const d4 TX2 = TN(T21t, X2);      // column 0: T21 (...)
-  // T++ = T21 T++                                                                    (:113)
-  const d4 Tpp_new = TN(T21t, C.Tpp_c);
-  // R+- = r+- + T21 R+- t--   (both forms)                                           (:116)
-  const d4 Y = TN(C.Rpm_t, tmm_c);
-  const d4 Rpm_c_new = TNacc(T21t, Y, rpm_c);
-  const d4 Rpm_t_new = TNacc(Y, T21t, rpm_t);
+  const d4 TX2 = TN<KS>(T21t, X2);      // column 0: T21 (...)
 #pragma unroll
   for (int r = 0; r < 4; ++r)
     C.Jv[r] = (L.lr == 0) ? jv[r] + TX2[r] : ((L.lr == 1) ? C.Jv[r] + TX1s[r] : 0.0);
-  C.Rmp_c = Rmp_new; C.Tmm_t = Tmm_t_new; C.Tpp_c = Tpp_new; C.Rpm_c = Rpm_c_new; C.Rpm_t = Rpm_t_new;
+  // T++ = T21 T++                                                                    (:113)
+  C.Tpp_c = TN<KS>(T21t, C.Tpp_c);
+  // R+- = r+- + T21 R+- t--   (both forms)                                           (:116)
+  d4 Y, zero = {0.0, 0.0, 0.0, 0.0};
+  if (SURF) {  // t-- = I: Y = R+-
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Y[r] = C.Rpm_c[r];
+  } else {
+    Y = TN<KS>(C.Rpm_t, scaleD(L, tc));
+  }
+  const d4 Rpm_c_new = TNacc<KS>(T21t, Y, SURF ? zero : scaleD(L, rc));
+  const d4 Rpm_t_new = TNacc<KS>(Y, T21t, SURF ? zero : scaleD(L, rt));
+  C.Rpm_c = Rpm_c_new; C.Rpm_t = Rpm_t_new;
 }
 
-__global__ void __launch_bounds__(256, 1) k_wsweep(WArgs a) {
+template <int KS>
+__global__ void __launch_bounds__(256, MOMW_OCC) k_wsweep(WArgs a) {
   __shared__ double s_lds[4][16 * 17 + 48];
   __shared__ int s_piv[4][16];
+  __shared__ double s_tab[48];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 4 + wave;  // spectral point of this wave
-  if (n >= a.S) return;
+  const int N = a.N, nS = a.nS, S = a.S, K = a.K;
+  if (threadIdx.x < 16) {
+    const int i = threadIdx.x;
+    s_tab[i] = i < N ? a.mu[i] : 1.0;
+    s_tab[16 + i] = i < N ? a.wt[i] : 0.0;
+    s_tab[32 + i] = i < N ? a.sg[i] : 1.0;
+  }
+  __syncthreads();
+  if (n >= S) return;
   double *lds = s_lds[wave];
   int *ipiv = s_piv[wave];
-  const int N = a.N, nS = a.nS, S = a.S, K = a.K;
   Lay L;
-  L.lr = lane & 15; L.lq = lane >> 4; L.N = N; L.nS = nS;
+  L.lr = lane & 15; L.lq = lane >> 4; L.N = N; L.nS = nS; L.tab = s_tab;
   L.cok = L.lr < N;
-  L.muc = L.cok ? a.mu[L.lr] : 1.0; L.wc = L.cok ? a.wt[L.lr] : 0.0; L.sgc = L.cok ? a.sg[L.lr] : 1.0;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int i = L.lq + 4 * r;
-    L.rok[r] = i < N;
-    L.mur[r] = L.rok[r] ? a.mu[i] : 1.0; L.wr[r] = L.rok[r] ? a.wt[i] : 0.0; L.sgr[r] = L.rok[r] ? a.sg[i] : 1.0;
-  }
-  d4 Ic;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) Ic[r] = (L.lq + 4 * r == L.lr && L.cok) ? 1.0 : 0.0;
+  L.muc = s_tab[L.lr]; L.wc = s_tab[16 + L.lr]; L.sgc = s_tab[32 + L.lr];
   const int i_start = nS * (a.imu0 - 1), i_end = nS * a.imu0;
   const double mus = a.mu[i_start];
   int bad = 0;
@@ -255,11 +288,13 @@ __global__ void __launch_bounds__(256, 1) k_wsweep(WArgs a) {
       {
         const double wjc = L.wc / wdiv;              // w'_j of the column stream
         const double ec = exp(-dtau / L.muc);        // exp(-dtau / mu_col)
-        double zpI[4] = {0, 0, 0, 0}, zmI[4] = {0, 0, 0, 0};
-#pragma unroll
+        const double att = exp(-tau_sum / mus), es = exp(-dtau / mus);
+        // one row (register) per iteration, NOT unrolled: the live set of one iteration is what the register budget of
+        // two waves per SIMD affords next to the composite tiles
+#pragma unroll 1
         for (int r = 0; r < 4; ++r) {
           const int i = L.lq + 4 * r, j = L.lr;
-          const bool ok = L.rok[r] && L.cok;
+          const bool rok = i < N, ok = rok && L.cok;
           double zpij = 0.0, zmij = 0.0, zpji = 0.0, zmji = 0.0;
           if (ok)
             for (int k = 0; k < K; ++k) {
@@ -268,7 +303,7 @@ __global__ void __launch_bounds__(256, 1) k_wsweep(WArgs a) {
               zpij += w * Zp_m[b + i + N * j]; zmij += w * Zm_m[b + i + N * j];
               zpji += w * Zp_m[b + j + N * i]; zmji += w * Zm_m[b + j + N * i];
             }
-          const double mui = L.mur[r], muj = L.muc, wir = L.wr[r] / wdiv;
+          const double mui = L.mur(r), muj = L.muc, wir = L.wr(r) / wdiv;
           const double er = exp(-dtau / mui);
           const double E = 1 - exp(-dtau * ((1 / mui) + (1 / muj)));  // symmetric in (i, j)
           double rij, tij, rji, tji;
@@ -281,87 +316,75 @@ __global__ void __launch_bounds__(256, 1) k_wsweep(WArgs a) {
             rij = 0.0;
             tij = (i == j) ? er : 0.0;
           }
-          // element (j, i): column stream i; (1/mu_j + 1/mu_i) is the same sum evaluated in the other order: the
-          // reference's expression for element (j, i) is reproduced operand by operand
+          // element (j, i): column stream i (the reference's expression with i and j exchanged)
           if (wir > 1.e-8) {
-            const double Eji = 1 - exp(-dtau * ((1 / muj) + (1 / mui)));
-            rji = varpi * zmji * (mui / (muj + mui)) * wir * Eji;
+            rji = varpi * zmji * (mui / (muj + mui)) * wir * E;
             if (muj == mui) tji = (i == j) ? ec * (1 + varpi * zpji * (dtau / muj) * wjc) : 0.0;
             else tji = varpi * zpji * (mui / (muj - mui)) * wir * (ec - er);
           } else {
             rji = 0.0;
             tji = (i == j) ? ec : 0.0;
           }
-          if (nd >= 1) { rij *= L.sgr[r]; rji *= L.sgc; }  // apply_D_elemental!: rows of r-+ (elemental.jl:265-269)
+          if (nd >= 1) { rij *= L.sgr(r); rji *= L.sgc; }  // apply_D_elemental!: rows of r-+ (elemental.jl:265-269)
           rc[r] = ok ? rij : 0.0; tc[r] = ok ? tij : 0.0;
           rt[r] = ok ? rji : 0.0; tt[r] = ok ? tji : 0.0;
-          // Z I0 over the sun's Stokes block for the source rows (computed by the lanes of columns 0 and 1)
-          if (L.rok[r] && L.lr < 2)
+          // source rows: Z I0 over the sun's Stokes block (lanes of columns 0 and 1)             (elemental.jl:224-251)
+          double jx = 0.0;
+          if (rok && L.lr < 2) {
+            const double *Zs = (L.lr == 0) ? Zp_m : Zm_m;
+            double zI = 0.0;
             for (int ks = 0; ks < nS; ++ks)
-              for (int k = 0; k < K; ++k) {
-                const double w = a.zw[k + (size_t)K * o];
-                const size_t b = (size_t)N * N * k + i + (size_t)N * (i_start + ks);
-                zpI[r] += w * Zp_m[b] * a.I0[ks];
-                zmI[r] += w * Zm_m[b] * a.I0[ks];
-              }
-        }
-        const double att = exp(-tau_sum / mus), es = exp(-dtau / mus);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = L.lq + 4 * r;
-          const double mui = L.mur[r], er = exp(-dtau / mui);
-          double jp, jm;
-          if (i >= i_start && i < i_end) jp = wct02 * varpi * zpI[r] * (dtau / mui) * er;
-          else jp = wct02 * varpi * zpI[r] * (mus / (mui - mus)) * (er - es);
-          jm = wct02 * varpi * zmI[r] * (mus / (mui + mus)) * (1 - exp(-dtau * ((1 / mui) + (1 / mus))));
-          jp *= att;
-          jm *= att;
-          if (nd >= 1) jm = a.D[i % nS] * jm;
-          jv[r] = !L.rok[r] ? 0.0 : (L.lr == 0 ? jp : (L.lr == 1 ? jm : 0.0));
+              for (int k = 0; k < K; ++k)
+                zI += a.zw[k + (size_t)K * o] * Zs[(size_t)N * N * k + i + (size_t)N * (i_start + ks)] * a.I0[ks];
+            if (L.lr == 0) {
+              if (i >= i_start && i < i_end) jx = wct02 * varpi * zI * (dtau / mui) * er;
+              else jx = wct02 * varpi * zI * (mus / (mui - mus)) * (er - es);
+              jx *= att;
+            } else {
+              jx = wct02 * varpi * zI * (mus / (mui + mus)) * (1 - exp(-dtau * ((1 / mui) + (1 / mus))));
+              jx *= att;
+              if (nd >= 1) jx = a.D[i % nS] * jx;
+            }
+          }
+          jv[r] = jx;
         }
       }
       // ------------------------------------------------ doubling_helper! (doubling.jl:43-68)
       // forms: rc, rt, tc, tt; per step B = r r, B^T, G = (I - B)^-1, A^T = G^T t^T, W = r t, then
       // r <- r + A W (c and t), t <- A t (c and t); sources through the vector tile
       for (int it = 0; it < nd; ++it) {
-        const d4 B = TN(rt, rc), Bt = TN(rc, rt);
-        const d4 G = inv_one_minus(L, B, Bt, Ic, a.inv_mode, lds, ipiv, bad);
-        const d4 At = TN(G, tt);
-        const d4 U = TN(rt, jv);          // columns: r j0+ | r j0-
+        const d4 B = TN<KS>(rt, rc), Bt = TN<KS>(rc, rt);
+        const d4 G = inv_one_minus<KS>(L, B, Bt, a.inv_mode, lds, ipiv, bad);
+        const d4 At = TN<KS>(G, tt);
+        const d4 U = TN<KS>(rt, jv);          // columns: r j0+ | r j0-
         const d4 Us = shfl_xor1(U);
         d4 Wv;
 #pragma unroll
         for (int r = 0; r < 4; ++r)       // column 0: w2 = j0+ + r j1-  ; column 1: w1 = j1- + r j0+   (:51-60)
           Wv[r] = (L.lr == 0) ? jv[r] + expk * Us[r] : ((L.lr == 1) ? jv[r] * expk + Us[r] : 0.0);
-        const d4 AW = TN(At, Wv);
+        const d4 AW = TN<KS>(At, Wv);
 #pragma unroll
         for (int r = 0; r < 4; ++r)       // j0+ = j1+ + A w2 (:60) ; j0- = j0- + A w1 (:57)
           jv[r] = (L.lr == 0) ? jv[r] * expk + AW[r] : ((L.lr == 1) ? jv[r] + AW[r] : 0.0);
         expk = expk * expk;               // :61
-        const d4 W = TN(rt, tc);          // r t (old t)
-        const d4 rc_n = TNacc(At, W, rc), rt_n = TNacc(W, At, rt);   // r + A (r t)      (:64)
-        const d4 tc_n = TN(At, tc), tt_n = TN(tc, At);               // A t             (:67)
+        const d4 W = TN<KS>(rt, tc);          // r t (old t)
+        const d4 rc_n = TNacc<KS>(At, W, rc), rt_n = TNacc<KS>(W, At, rt);   // r + A (r t)      (:64)
+        const d4 tc_n = TN<KS>(At, tc), tt_n = TN<KS>(tc, At);               // A t             (:67)
         rc = rc_n; rt = rt_n; tc = tc_n; tt = tt_n;
       }
       if (nd >= 1) {  // apply_D! / apply_D_SFI! (doubling.jl:93-118): rows of r-+ and j0- scaled by sg
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          rc[r] *= L.sgr[r];
+          rc[r] *= L.sgr(r);
           rt[r] *= L.sgc;
-          if (L.lr == 1) jv[r] *= L.sgr[r];
+          if (L.lr == 1) jv[r] *= L.sgr(r);
         }
-      }
-      d4 rpm_c, rpm_t, tmm_c, tmm_t;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double s = L.sgr[r] * L.sgc;
-        rpm_c[r] = s * rc[r]; rpm_t[r] = s * rt[r]; tmm_c[r] = s * tc[r]; tmm_t[r] = s * tt[r];
       }
       // ------------------------------------------------ composite <- added (rt_kernel.jl:227-230) or interaction!
       if (z == 0) {
-        C.Rmp_c = rc; C.Rpm_c = rpm_c; C.Rpm_t = rpm_t; C.Tpp_c = tc; C.Tmm_t = tmm_t; C.Jv = jv;
+        C.Rmp_c = rc; C.Rpm_c = scaleD(L, rc); C.Rpm_t = scaleD(L, rt); C.Tpp_c = tc; C.Tmm_t = scaleD(L, tt); C.Jv = jv;
       } else {
-        interact11(L, C, rc, rt, tc, tt, rpm_c, rpm_t, tmm_c, jv, Ic, a.inv_mode, lds, ipiv, bad);
+        interact11<KS, false>(L, C, rc, rt, tc, tt, jv, a.inv_mode, lds, ipiv, bad);
       }
     }
     // ---------------------------------------------------- Lambertian surface (m = 0) + closing interaction (Q6)
@@ -369,21 +392,21 @@ __global__ void __launch_bounds__(256, 1) k_wsweep(WArgs a) {
     if (m == 0) {
       const double rho = 2 * a.albedo;
       const double att = exp(-a.tau_sum[n + (size_t)S * a.Nz] / a.mu0);
-      d4 rs_c, rs_t, jv, Z0 = {0.0, 0.0, 0.0, 0.0};
+      d4 rs_c, rs_t, jv;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = L.lq + 4 * r, j = L.lr;
-        const bool ok = L.rok[r] && L.cok, ii = (i % nS == 0) && (j % nS == 0);
+        const bool ok = L.rok(r) && L.cok, ii = (i % nS == 0) && (j % nS == 0);
         rs_c[r] = (ok && ii) ? rho * (L.muc * L.wc) : 0.0;         // r-+ = R_surf Diagonal(mu w)  (:41-43,:58)
-        rs_t[r] = (ok && ii) ? rho * (L.mur[r] * L.wr[r]) : 0.0;
+        rs_t[r] = (ok && ii) ? rho * (L.mur(r) * L.wr(r)) : 0.0;
         const bool in_sun = (i >= i_start) && (i < i_end);
         const double jp = (in_sun ? a.I0[i - i_start] : 0.0) * att;                     // :55
         const double jm = (i % nS == 0) ? (a.mu0 * (rho * a.I0[0])) * att : 0.0;       // :56
-        jv[r] = !L.rok[r] ? 0.0 : (L.lr == 0 ? jp : (L.lr == 1 ? jm : 0.0));
+        jv[r] = !L.rok(r) ? 0.0 : (L.lr == 0 ? jp : (L.lr == 1 ? jm : 0.0));
       }
-      interact11(L, C, rs_c, rs_t, Ic, Ic, Z0, Z0, Ic, jv, Ic, a.inv_mode, lds, ipiv, bad);
+      interact11<KS, true>(L, C, rs_c, rs_t, rs_c, rs_c, jv, a.inv_mode, lds, ipiv, bad);  // (t operands unused)
       // interaction_hdrf! (interaction_hdrf.jl:9-45): hdr_J0- = r-+_surf J0+ + j0-_surf  -> column 0
-      const d4 rJ = TN(rs_t, C.Jv);
+      const d4 rJ = TN<KS>(rs_t, C.Jv);
       const d4 jsw = shfl_xor1(jv);
 #pragma unroll
       for (int r = 0; r < 4; ++r) hdrJ[r] = (L.lr == 0) ? rJ[r] + jsw[r] : 0.0;
@@ -393,9 +416,9 @@ __global__ void __launch_bounds__(256, 1) k_wsweep(WArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = L.lq + 4 * r;
-          if (L.lr == 0 && L.rok[r] && (i % nS == k)) {
-            up += hdrJ[r] * L.wr[r] * L.mur[r];
-            dw += C.Jv[r] * L.wr[r] * L.mur[r];
+          if (L.lr == 0 && L.rok(r) && (i % nS == k)) {
+            up += hdrJ[r] * L.wr(r) * L.mur(r);
+            dw += C.Jv[r] * L.wr(r) * L.mur(r);
           }
         }
         up = wave_sum(up);
@@ -440,6 +463,9 @@ __global__ void __launch_bounds__(256, 1) k_wsweep(WArgs a) {
 
 hipError_t momw_launch_sweep(const void *args, hipStream_t st) {
   const momw::WArgs a = *reinterpret_cast<const momw::WArgs *>(args);
-  hipLaunchKernelGGL(momw::k_wsweep, dim3((unsigned)((a.S + 3) / 4)), dim3(256), 0, st, a);
+  const dim3 grid((unsigned)((a.S + 3) / 4)), block(256);
+  if (a.N <= 8) hipLaunchKernelGGL(momw::k_wsweep<2>, grid, block, 0, st, a);
+  else if (a.N <= 12) hipLaunchKernelGGL(momw::k_wsweep<3>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(momw::k_wsweep<4>, grid, block, 0, st, a);
   return hipGetLastError();
 }

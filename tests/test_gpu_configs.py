@@ -71,7 +71,7 @@ def test_small_operator_sweep_kernel(rtamd, cref, lt, vza, kw):
 
 @pytest.mark.parametrize("nS,lt,vza,kw", [
     (1, 9, (0.0, 30.0), {}),                                    # N = 8
-    (1, 21, (0.0, 30.0, 60.0), dict(aerosol_total=1.0)),        # N = 14
+    (1, 21, (0.0, 30.0, 45.0), dict(aerosol_total=0.6)),        # N = 15
     (3, 3, (0.0,), {}),                                         # N = 12, polarized
     (3, 5, (20.0,), dict(albedo=0.6)),                          # N = 15
     (4, 3, (0.0,), {}),                                         # N = 16, IQUV
