@@ -261,14 +261,20 @@ int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
  *                         not all fall into the same microseconds; 0 = all start together
  *   MOM_OPT_SMALL_N       1 (default) = operators of edge N <= 4 (with at most 4 view angles and 4 phase-matrix bases)
  *                         run the lane-per-spectral-point sweep kernel: the whole of mom_rt_run in one launch, all
- *                         operators in registers (csrc/mom_small.hip); 0 = the general workgroup-per-point kernels
+ *                         operators in registers (csrc/mom_small.hip); edges 4 < N <= 16 (Lambertian scalar surface,
+ *                         scattering in every layer after the first) the wave-per-spectral-point sweep kernel
+ *                         (csrc/mom_wave.hip); 0 = the general workgroup-per-point kernels
  *   MOM_OPT_LAYER_SWEEP   1 (default) = one launch per problem size walks ALL layers of a (spectral point, moment)
  *                         unit before the next unit: the composite blocks stay in the storing CU's L2 between layers,
  *                         one tail per sweep instead of one per layer (needs one interface code for all layers >= 2,
- *                         else falls back); 0 = one launch per layer (per-layer timing for profiling) */
+ *                         else falls back); 0 = one launch per layer (per-layer timing for profiling)
+ *   MOM_OPT_STRIP_PAD     1 (default) = an operator edge N (or the m = 0 sub-problem's) without a strip-chained kernel
+ *                         image is padded with up to 4 decoupled dummy stream entries (mu = 1, weight 0, zero
+ *                         phase-matrix rows and columns) when that reaches a size with one (36, 40, 44, 52, 56, 60);
+ *                         results for the real streams are unchanged; 0 = run the edge as given */
 int mom_set_option(mom_t *h, int option, int value);
 enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1, MOM_OPT_M0_REDUCTION = 2, MOM_OPT_SMALL_WG = 3, MOM_OPT_STAGGER = 4,
-       MOM_OPT_SMALL_N = 5, MOM_OPT_LAYER_SWEEP = 6 };
+       MOM_OPT_SMALL_N = 5, MOM_OPT_LAYER_SWEEP = 6, MOM_OPT_STRIP_PAD = 7 };
 
 /* ---- Voigt line-by-line cross section --------------------------------------------------
  * compute_absorption_cross_section(model::HitranModel, grid, p, T)

@@ -29,6 +29,7 @@ COMP = dict(R_mp=6, R_pm=7, T_pp=8, T_mm=9, J0p=10, J0m=11)
 SURF = dict(r_pm=12, r_mp=13, t_mm=14, t_pp=15, j0p=16, j0m=17)
 
 MOM_OPT_INVERSE, MOM_OPT_FORCE_GENERIC, MOM_OPT_M0_REDUCTION, MOM_OPT_SMALL_WG, MOM_OPT_STAGGER, MOM_OPT_SMALL_N, MOM_OPT_LAYER_SWEEP = 0, 1, 2, 3, 4, 5, 6
+MOM_OPT_STRIP_PAD = 7
 
 
 class MomError(RuntimeError):

@@ -314,10 +314,25 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
   real *tB = tA + 2 * kBigKB * kBigLdA;
   const int tid = wg_tid(), lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
   const int wr = (wave >> 2) & 1, wc = wave & 3;  // 2 x 4 wave grid (8-wave build only, see wg_gemm_nc)
-  const int Np = np_for(N);
   const int P = (N + kBigKB - 1) / kBigKB;
-  // B panel element of this thread: 8 k x 256 columns = 2048 elements, 4 per thread; A panel: 128 rows x 8 k = 1024, 2 per thread
-  for (int row0 = 0; row0 < N; row0 += kBigRows) {
+  // Wave tiling fitted to the operator: a wave owns TMr x TNr MFMA tiles (each <= 4), TNr = ceil(column tiles / 4) and
+  // TMr = ceil(row tiles of this pass / 2), the row tiles split evenly over ceil(row tiles / 8) passes.  N = 256 keeps
+  // the 4 x 4 register block of two passes; N = 66 (5 x 5 tiles) runs 3 x 2 per wave instead of one wave carrying 16.
+  const int ntr = (N + 15) >> 4, ntc = (NC + 15) >> 4;
+  const int TNr = (ntc + 3) >> 2;
+  const int npass = (ntr + 7) >> 3;
+  int t0 = 0;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int tcnt = (ntr - t0 + (npass - pass) - 1) / (npass - pass);  // row tiles of this pass
+    const int TMr = (tcnt + 1) >> 1;
+    const int row0 = 16 * t0, rows_pass = 16 * tcnt;
+    t0 += tcnt;
+    bool vr[4], vc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      vr[t] = t < TMr && TMr * wr + t < tcnt;
+      vc[t] = t < TNr && TNr * wc + t < ntc;
+    }
     r4 acc[4][4];
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
@@ -334,7 +349,7 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
       for (int u = 0; u < kNA; ++u) {
         const int e = tid + kThreads * u, row = e & (kBigRows - 1), kk = e >> 7;
         const int i = row0 + row, k = k0 + kk;
-        ra[set][u] = (i < N && k < N) ? A(i, k) : 0.0;
+        ra[set][u] = (row < rows_pass && i < N && k < N) ? A(i, k) : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < kNB; ++u) {
@@ -365,20 +380,20 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
     auto panel = [&](int p, auto setc) {
       constexpr int SET = decltype(setc)::value;  // set holding panel p + 1 (fetched one iteration ago)
       if (p + 2 < P) fetch(p + 2, 1 - SET);        // -> the set panel p's data came from, free since its stash
-      const real *sa = tA + (p & 1) * kBigKB * kBigLdA + 64 * wr + lr + lq * kBigLdA;
-      const real *sb = tB + (p & 1) * kBigCols * kBigLdB + lq + (64 * wc + lr) * kBigLdB;
+      const real *sa = tA + (p & 1) * kBigKB * kBigLdA + 16 * TMr * wr + lr + lq * kBigLdA;
+      const real *sb = tB + (p & 1) * kBigCols * kBigLdB + lq + (16 * TNr * wc + lr) * kBigLdB;
 #pragma unroll
       for (int ks = 0; ks < kBigKB / 4; ++ks) {
         real a[4], b[4];
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) a[ti] = sa[16 * ti + 4 * ks * kBigLdA];
+        for (int ti = 0; ti < 4; ++ti) a[ti] = vr[ti] ? sa[16 * ti + 4 * ks * kBigLdA] : 0.0;
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) b[tj] = sb[4 * ks + 16 * tj * kBigLdB];
+        for (int tj = 0; tj < 4; ++tj) b[tj] = vc[tj] ? sb[4 * ks + 16 * tj * kBigLdB] : 0.0;
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
           for (int tj = 0; tj < 4; ++tj)
-            if (64 * wc + 16 * tj < Np) acc[ti][tj] = mma16(a[ti], b[tj], acc[ti][tj]);
+            if (vr[ti] && vc[tj]) acc[ti][tj] = mma16(a[ti], b[tj], acc[ti][tj]);
       }
       if (p + 1 < P) stash((p + 1) & 1, SET);
       __syncthreads();
@@ -391,10 +406,11 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
       for (int tj = 0; tj < 4; ++tj) {
-        const int col = 64 * wc + 16 * tj + lr;
+        if (!(vr[ti] && vc[tj])) continue;
+        const int col = 16 * (TNr * wc + tj) + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int rw = row0 + 64 * wr + 16 * ti + cd_row(lq, r);
+          const int rw = row0 + 16 * (TMr * wr + ti) + cd_row(lq, r);
           if (rw < N && col < NC) epi(rw, col, acc[ti][tj][r]);
         }
       }

@@ -324,6 +324,9 @@ struct mom_handle {
   int surf_kind = 0;         // 0 Lambertian scalar, 1 BRDF matrices, 2 Lambertian Legendre (mom_scene_set_surface)
   double *d_Rsurf = nullptr, *d_Rsurf0 = nullptr, *d_albedo_spec = nullptr, *d_hdrJm = nullptr;
   int opt_sweep = 1;       // one launch walks all layers of a unit (LayerArgs::Nz_sweep)
+  int opt_pad = 1;         // scene-level path: pad the operator edge to the next strip-chained kernel size (strip_pad)
+  int Nk = 0;              // operator edge the scene-level kernels of the full problem run with (>= N)
+  DevStreams qk{};         // q with N = Nk
   int opt_small = 1;       // N <= 4: lane-per-point sweep kernel (mom_small.hip)
   double *d_smtab = nullptr;  // F1 | F2 | SI tables [3][N,N]
   int *d_ndif = nullptr;      // ndoubl | iface [2][Nz]
@@ -372,6 +375,29 @@ static hipError_t dmalloc(T **p, size_t count) {
 }
 
 static size_t smem_bytes(const mom_t *h) { return lds_bytes(h->N, h->lds_mode); }
+
+// Scene-level path: an operator edge N for which no strip-chained kernel image exists is padded with up to 4 DUMMY
+// STREAM ENTRIES (mu = 1, weight 0, zero rows and columns in every phase-matrix basis and BRDF matrix) when that
+// reaches a size one exists for: most IQU stream counts (N = 3 k is a multiple of 4 only for every fourth k), and
+// N = 32, 48 (measured: N = 48 as 52 runs 1.3x faster than the general path at 48).  A dummy entry is decoupled exactly:
+// its column is zero in r and off-diagonal in t (zero weight, elemental.jl:198-205), its row is zero because its Z row
+// is, so every product, series and pivoted inverse leaves the real rows and columns with the same terms plus exact zeros.
+constexpr int kPadMax = 4;
+static bool strip_size(int N) { return N == 36 || N == 40 || N == 44 || N == 52 || N == 56 || N == 60; }
+static int strip_pad(int N) {
+  if (strip_size(N)) return N;
+  for (int p = N + 1; p <= N + kPadMax; ++p)
+    if (strip_size(p)) return p;
+  return N;
+}
+// [N,N,B] -> [Nk,Nk,B], zero padded
+static std::vector<double> pad_blocks(const double *src, int N, int Nk, size_t B) {
+  std::vector<double> out((size_t)Nk * Nk * B, 0.0);
+  for (size_t b = 0; b < B; ++b)
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < N; ++i) out[i + (size_t)Nk * (j + (size_t)Nk * b)] = src[i + (size_t)N * (j + (size_t)N * b)];
+  return out;
+}
 
 template <class K>
 static hipError_t allow_lds(K kernel, size_t bytes) {
@@ -423,15 +449,16 @@ extern "C" int mom_create(mom_t **out, int device, int N, int nStokes, int S, in
   HIPCHK(h, hipSetDevice(device));
   HIPCHK(h, hipStreamCreate(&h->stream));
   const size_t NN = (size_t)N * N;
-  HIPCHK(h, dmalloc(&h->d_mu, N));
-  HIPCHK(h, dmalloc(&h->d_wt, N));
-  HIPCHK(h, dmalloc(&h->d_sg, N));
+  const int Na = N + kPadMax;  // room for the dummy entries of strip_pad
+  HIPCHK(h, dmalloc(&h->d_mu, Na));
+  HIPCHK(h, dmalloc(&h->d_wt, Na));
+  HIPCHK(h, dmalloc(&h->d_sg, Na));
   (void)NN;
   for (int k = 0; k < 6 && dtype == 0; ++k) {
     // composite blocks: room for the scene-level row pitch (comp_pitch); the operator-level API uses the natural one.
     // The added / surface layers of the operator-level API (12 N^2 S doubles) are allocated on its first use
     // (ensure_op_layers): the scene-level path keeps the added layer in LDS and never needs them.
-    const size_t perc = (k < 4) ? (size_t)comp_pitch(N) * N : (size_t)N;
+    const size_t perc = (k < 4) ? (size_t)comp_pitch(Na) * Na : (size_t)Na;
     HIPCHK(h, dmalloc(&h->comp[k], perc * S * max_m));
     HIPCHK(h, hipMemsetAsync(h->comp[k], 0, perc * S * max_m * sizeof(double), h->stream));
   }
@@ -498,12 +525,13 @@ extern "C" int mom_check(mom_t *h) {
 
 extern "C" int mom_set_option(mom_t *h, int option, int value) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  if (option == MOM_OPT_INVERSE) { h->opt_inverse = value; h->q.inv_mode = value; h->q0.inv_mode = value; }
+  if (option == MOM_OPT_INVERSE) { h->opt_inverse = value; h->q.inv_mode = value; h->qk.inv_mode = value; h->q0.inv_mode = value; }
   else if (option == MOM_OPT_M0_REDUCTION) h->opt_m0 = value;
   else if (option == MOM_OPT_SMALL_WG) h->opt_w4 = value;
   else if (option == MOM_OPT_STAGGER) h->opt_stagger = value;
   else if (option == MOM_OPT_SMALL_N) h->opt_small = value;
   else if (option == MOM_OPT_LAYER_SWEEP) h->opt_sweep = value;
+  else if (option == MOM_OPT_STRIP_PAD) { h->opt_pad = value; h->scene_set = false; }
   else if (option == MOM_OPT_FORCE_GENERIC) {
     h->opt_force_generic = value;
     h->lds_mode = (h->N <= 64) && !value;
@@ -526,10 +554,14 @@ extern "C" int mom_set_streams(mom_t *h, const double *qp_muN, const double *wt_
     const int comp = strict ? ((i + 1) % h->nS) : (i % h->nS) + 1;
     sg[i] = (comp > 2) ? -1.0 : 1.0;
   }
-  HIPCHK(h, hipMemcpyAsync(h->d_mu, qp_muN, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_wt, wt_muN, N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipMemcpyAsync(h->d_sg, sg.data(), N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  {
+    std::vector<double> mu(qp_muN, qp_muN + N), wt(wt_muN, wt_muN + N);
+    mu.resize(N + kPadMax, 1.0); wt.resize(N + kPadMax, 0.0); sg.resize(N + kPadMax, 1.0);  // dummy entries (strip_pad)
+    HIPCHK(h, hipMemcpyAsync(h->d_mu, mu.data(), mu.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_wt, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_sg, sg.data(), sg.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
   DevStreams &q = h->q;
   q.mu = h->d_mu; q.wt = h->d_wt; q.sg = h->d_sg;
   for (int k = 0; k < 4; ++k) { q.I0[k] = (k < h->nS) ? I0[k] : 0.0; q.D[k] = (k < h->nS) ? D[k] : 1.0; }
@@ -723,6 +755,9 @@ extern "C" int mom_download(mom_t *h, int which, double *dst) {
     if (h->red0)
       return fail(h, MOM_ESTATE, "mom_download: Fourier moment 0 ran on the (I,Q) sub-problem; set "
                                  "MOM_OPT_M0_REDUCTION = 0 before mom_scene_set to read the composite layer back");
+    if (h->Nk != h->N)
+      return fail(h, MOM_ESTATE, "mom_download: the scene ran on an operator edge padded to a strip-chained kernel size; "
+                                 "set MOM_OPT_STRIP_PAD = 0 before mom_scene_set to read the composite layer back");
     if (which % 6 < 4) {  // de-pitch: columns of N doubles at a pitch of comp_pitch(N)
       HIPCHK(h, hipMemcpy2DAsync(dst, (size_t)h->N * sizeof(double), p, (size_t)comp_pitch(h->N) * sizeof(double),
                                  (size_t)h->N * sizeof(double), (size_t)h->N * h->S, hipMemcpyDeviceToHost, h->stream));
@@ -841,8 +876,19 @@ static int scene_common(mom_t *h, int Nz, int K, int M, const double *Zpp, const
     if (node_1based[v] < 1 || node_1based[v] * h->nS > h->N) return fail(h, MOM_EINVAL, "mom_scene_set: bad view node");
   const size_t S = h->S, NN = (size_t)h->N * h->N;
   int rc;
-  if ((rc = upload_new(h, &h->d_Zpp, Zpp, NN * K * M))) return rc;
-  if ((rc = upload_new(h, &h->d_Zmp, Zmp, NN * K * M))) return rc;
+  const int Nk = h->opt_pad ? strip_pad(h->N) : h->N;
+  h->Nk = Nk;
+  h->qk = h->q;
+  h->qk.N = Nk;
+  if (Nk == h->N) {
+    if ((rc = upload_new(h, &h->d_Zpp, Zpp, NN * K * M))) return rc;
+    if ((rc = upload_new(h, &h->d_Zmp, Zmp, NN * K * M))) return rc;
+  } else {
+    const std::vector<double> zp = pad_blocks(Zpp, h->N, Nk, (size_t)K * M), zm = pad_blocks(Zmp, h->N, Nk, (size_t)K * M);
+    if ((rc = upload_new(h, &h->d_Zpp, zp.data(), zp.size()))) return rc;
+    if ((rc = upload_new(h, &h->d_Zmp, zm.data(), zm.size()))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // the padded host copies go out of scope
+  }
   if ((rc = upload_new(h, &h->d_node, node_1based, (size_t)nVza))) return rc;
   if ((rc = upload_new(h, &h->d_cos, cos_mphi, (size_t)nVza * M))) return rc;
   if ((rc = upload_new(h, &h->d_sin, sin_mphi, (size_t)nVza * M))) return rc;
@@ -852,7 +898,7 @@ static int scene_common(mom_t *h, int Nz, int K, int M, const double *Zpp, const
   h->d_T = h->d_R + (size_t)nVza * h->nS * S;
   HIPCHK(h, dmalloc(&h->d_hdr, (size_t)nVza * h->nS * S));
   if (!h->d_hdrJ) {
-    HIPCHK(h, dmalloc(&h->d_hdrJ, (size_t)h->N * S));
+    HIPCHK(h, dmalloc(&h->d_hdrJ, (size_t)(h->N + kPadMax) * S));
     HIPCHK(h, dmalloc(&h->d_bhr_uw, (size_t)h->nS * S));
     HIPCHK(h, dmalloc(&h->d_bhr_dw, (size_t)h->nS * S));
   }
@@ -873,14 +919,15 @@ static int scene_common(mom_t *h, int Nz, int K, int M, const double *Zpp, const
     for (int k = 0; k < 6; ++k) fr(h->comp0[k]);
     h->red0 = ok;
     if (ok) {
-      const int nS0 = 2, N0 = nS0 * Nq;
+      // N0r real entries; the kernels run on N0 >= N0r (dummy entries of strip_pad at the end: mu = 1, weight 0, Z = 0)
+      const int nS0 = 2, N0r = nS0 * Nq, N0 = h->opt_pad ? strip_pad(N0r) : N0r;
       h->N0 = N0; h->nS0 = nS0;
-      std::vector<double> mu0v(N0), wt0v(N0), sg0v(N0, 1.0), zp((size_t)N0 * N0 * K), zm((size_t)N0 * N0 * K);
+      std::vector<double> mu0v(N0, 1.0), wt0v(N0, 0.0), sg0v(N0, 1.0), zp((size_t)N0 * N0 * K, 0.0), zm((size_t)N0 * N0 * K, 0.0);
       auto full = [&](int i0) { return (i0 / nS0) * nS + (i0 % nS0); };
-      for (int i = 0; i < N0; ++i) { mu0v[i] = h->h_mu[full(i)]; wt0v[i] = h->h_wt[full(i)]; }
+      for (int i = 0; i < N0r; ++i) { mu0v[i] = h->h_mu[full(i)]; wt0v[i] = h->h_wt[full(i)]; }
       for (int kb = 0; kb < K; ++kb)
-        for (int j = 0; j < N0; ++j)
-          for (int i = 0; i < N0; ++i) {
+        for (int j = 0; j < N0r; ++j)
+          for (int i = 0; i < N0r; ++i) {
             const size_t src = full(i) + (size_t)N * (full(j) + (size_t)N * kb);
             zp[i + (size_t)N0 * (j + (size_t)N0 * kb)] = Zpp[src];
             zm[i + (size_t)N0 * (j + (size_t)N0 * kb)] = Zmp[src];
@@ -929,9 +976,15 @@ extern "C" int mom_scene_set_surface(mom_t *h, int kind, int M, const double *Rs
     return MOM_OK;
   }
   if (kind == 1) {
-    if ((rc = upload_new(h, &h->d_Rsurf, Rsurf, NN * M))) return rc;
+    if (h->Nk == N) {
+      if ((rc = upload_new(h, &h->d_Rsurf, Rsurf, NN * M))) return rc;
+    } else {
+      const std::vector<double> rp = pad_blocks(Rsurf, N, h->Nk, (size_t)M);
+      if ((rc = upload_new(h, &h->d_Rsurf, rp.data(), rp.size()))) return rc;
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     if (h->d_hdrJm) { (void)hipFree(h->d_hdrJm); h->d_hdrJm = nullptr; }
-    HIPCHK(h, dmalloc(&h->d_hdrJm, (size_t)N * S * M));
+    HIPCHK(h, dmalloc(&h->d_hdrJm, (size_t)h->Nk * S * M));
     if (h->red0) {
       // moment 0 runs on the (I,Q) sub-problem: its surface matrix must not couple (I,Q) with (U,V) either
       const int nS0 = h->nS0, N0 = h->N0;
@@ -1084,7 +1137,8 @@ extern "C" int mom_rt_run(mom_t *h) {
   if (wave_sweep_applies(h)) return rt_run_wave(h);
   while (h->ev_full.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_full.push_back(e); }
   while (h->ev_red.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_red.push_back(e); }
-  const size_t NN = (size_t)h->N * h->N;
+  const int Nk = h->Nk;  // kernel-side edge of the full problem (strip_pad)
+  const size_t NN = (size_t)Nk * Nk;
   // one k_layer launch over `Mcount` moments starting at `m_first` with stream set `q` (full or reduced)
   // sweep mode: every layer of a unit inside one launch (z < 0 selects it); needs one interface code for all z >= 1
   // (the code is a template argument of the kernel images) -- always the case once scattering has set in
@@ -1114,9 +1168,9 @@ extern "C" int mom_rt_run(mom_t *h) {
     // small operators: 4-wave workgroups, two per CU (momcore_w4.hip), when two LDS images fit
     if (lds && h->opt_w4 && np_for(q.N) <= 48 && 2 * mom4_lds_bytes(q.N, true) + 2048 <= 160 * 1024) {
       const int grid4 = (int)((S >= 2048) ? S : S * Mcount);
-      if (q.N == 36 || q.N == 40 || q.N == 44) {  // strip-chained kernels of the 4-wave build (momcore_strip.hip)
+      if (q.N == 36 || q.N == 40) {  // strip-chained kernels of the 4-wave build (momcore_strip.hip)
         const int gridp = (int)std::min<size_t>(S * Mcount, (size_t)2 * h->num_cu);  // persistent, two per CU
-        HIPCHK(h, (q.N == 40 ? mom_strip10_launch_layer : q.N == 36 ? mom_strip9_launch_layer : mom_strip11_launch_layer)(
+        HIPCHK(h, (q.N == 40 ? mom_strip10_launch_layer : mom_strip9_launch_layer)(
                       &a, a.iface, gridp, mom4_lds_bytes(q.N, true), h->stream));
         h->launches++;
         return MOM_OK;
@@ -1126,7 +1180,7 @@ extern "C" int mom_rt_run(mom_t *h) {
       return MOM_OK;
     }
     const size_t sm = lds_bytes(q.N, lds);
-    if (lds && (q.N == 52 || q.N == 56 || q.N == 60)) {  // strip-chained kernels (momcore_strip.hip), one image per N
+    if (lds && (q.N == 44 || q.N == 52 || q.N == 56 || q.N == 60)) {  // strip-chained kernels (momcore_strip.hip), one image per N
       // persistent workgroups, one per CU (only one 135 KB LDS image fits a CU): the prologue is paid once;
       // their start is staggered over about one unit time (~ (44 + 17 nd) us at N = 60)
       if (S * Mcount >= 8 * (size_t)h->num_cu && h->opt_stagger) {
@@ -1134,7 +1188,7 @@ extern "C" int mom_rt_run(mom_t *h) {
         a.stagger = (int)(unit_us * 100.0 / 32.0);
       }
       const int grid = (int)std::min<size_t>(S * Mcount, (size_t)h->num_cu);
-      HIPCHK(h, (q.N == 60 ? mom_strip15_launch_layer : q.N == 56 ? mom_strip14_launch_layer : mom_strip13_launch_layer)(
+      HIPCHK(h, (q.N == 60 ? mom_strip15_launch_layer : q.N == 56 ? mom_strip14_launch_layer : q.N == 52 ? mom_strip13_launch_layer : mom_strip11_launch_layer)(
                     &a, a.iface, grid, sm, h->stream));
       h->launches++;
       return MOM_OK;
@@ -1166,9 +1220,9 @@ extern "C" int mom_rt_run(mom_t *h) {
     if (h->red0) {
       if (M > 1) {  // moments 1..M-1 on the full problem
         double *comp1[6];
-        for (int k = 0; k < 6; ++k) comp1[k] = h->comp[k] + ((k < 4) ? (size_t)comp_pitch(h->N) * h->N : (size_t)h->N) * S;
+        for (int k = 0; k < 6; ++k) comp1[k] = h->comp[k] + ((k < 4) ? (size_t)comp_pitch(Nk) * Nk : (size_t)Nk) * S;
         HIPCHK(h, hipEventRecord(h->ev_full[2 * e], h->stream));
-        if ((rc = launch_layer(z, h->q, 1, M - 1, h->d_Zpp + NN * h->K, h->d_Zmp + NN * h->K, comp1, h->d_scratch))) return rc;
+        if ((rc = launch_layer(z, h->qk, 1, M - 1, h->d_Zpp + NN * h->K, h->d_Zmp + NN * h->K, comp1, h->d_scratch))) return rc;
         HIPCHK(h, hipEventRecord(h->ev_full[2 * e + 1], h->stream));
         h->launches_full++;
       }
@@ -1178,7 +1232,7 @@ extern "C" int mom_rt_run(mom_t *h) {
       h->launches_red++;
     } else {
       HIPCHK(h, hipEventRecord(h->ev_full[2 * e], h->stream));
-      if ((rc = launch_layer(z, h->q, 0, M, h->d_Zpp, h->d_Zmp, h->comp, h->d_scratch))) return rc;
+      if ((rc = launch_layer(z, h->qk, 0, M, h->d_Zpp, h->d_Zmp, h->comp, h->d_scratch))) return rc;
       HIPCHK(h, hipEventRecord(h->ev_full[2 * e + 1], h->stream));
       h->launches_full++;
     }
@@ -1188,14 +1242,14 @@ extern "C" int mom_rt_run(mom_t *h) {
   for (int m = 0; m < ((h->surf_kind == 1) ? M : 1); ++m) {
     SurfArgs a{};
     const bool red = h->red0 && m == 0;
-    const DevStreams &q = red ? h->q0 : h->q;
+    const DevStreams &q = red ? h->q0 : h->qk;
     a.q = q; a.S = h->S; a.iface = h->iface[h->Nz - 1];  // Q6: last layer's interface code (rt_run.jl:181)
     a.albedo = h->albedo; a.tau_tot = h->d_tau_sum + S * h->Nz;
     a.kind = h->surf_kind; a.m = m; a.albedo_spec = h->d_albedo_spec;
     a.Rsurf = (h->surf_kind == 1) ? (red ? h->d_Rsurf0 : h->d_Rsurf + NN * m) : nullptr;
     for (int k = 0; k < 6; ++k)
-      a.comp[k] = red ? h->comp0[k] : h->comp[k] + ((k < 4) ? (size_t)comp_pitch(h->N) * h->N : (size_t)h->N) * S * m;
-    a.hdrJ = red ? h->d_hdrJ0 : (m == 0 ? h->d_hdrJ : h->d_hdrJm + (size_t)h->N * S * m);
+      a.comp[k] = red ? h->comp0[k] : h->comp[k] + ((k < 4) ? (size_t)comp_pitch(Nk) * Nk : (size_t)Nk) * S * m;
+    a.hdrJ = red ? h->d_hdrJ0 : (m == 0 ? h->d_hdrJ : h->d_hdrJm + (size_t)Nk * S * m);
     a.bhr_uw = h->d_bhr_uw; a.bhr_dw = h->d_bhr_dw; a.nS_out = h->nS;
     a.scratch = red ? h->d_scratch0 : h->d_scratch; a.info = h->d_info;
     const bool lds = (q.N <= 64) && !h->opt_force_generic;
@@ -1216,7 +1270,7 @@ extern "C" int mom_rt_run(mom_t *h) {
   {
     const size_t total = (size_t)h->nVza * h->nS * S;
     PostArgs pa{};
-    pa.N = h->N; pa.nS = h->nS; pa.S = h->S; pa.M = M; pa.nVza = h->nVza; pa.red0 = h->red0 ? 1 : 0;
+    pa.N = Nk; pa.nS = h->nS; pa.S = h->S; pa.M = M; pa.nVza = h->nVza; pa.red0 = h->red0 ? 1 : 0;
     pa.N0 = h->N0; pa.nS0 = h->nS0;
     pa.node = h->d_node; pa.cos_mphi = h->d_cos; pa.sin_mphi = h->d_sin;
     pa.J0p = h->comp[4]; pa.J0m = h->comp[5]; pa.J0p0 = h->comp0[4]; pa.J0m0 = h->comp0[5];

@@ -62,6 +62,36 @@ def test_rt_run_parity_strip_sizes(rtamd, cref, nS, lt):
     helpers.assert_stokes_close(T3, Tr, rtol=1e-11, what="T gauss-jordan")
 
 
+@pytest.mark.parametrize("nS,lt,N,kw", [(3, 19, 39, {}), (3, 21, 42, {}), (3, 27, 51, {}), (3, 29, 54, {}), (3, 31, 57, {}),
+                                        (1, 69, 38, {}), (1, 91, 49, {}), (3, 25, 48, {}), (4, 9, 32, {}),
+                                        (3, 27, 51, dict(brdf="rpv"))])
+def test_strip_padding_to_kernel_sizes(rtamd, cref, nS, lt, N, kw):
+    """MOM_OPT_STRIP_PAD: operator edges without a strip-chained kernel image (most IQU stream counts, N = 32, 48) run the
+    kernels of the next size that has one, with up to 4 decoupled dummy stream entries; the m = 0 sub-problem pads itself the same way (N0 = 34 -> 36,
+    38 -> 40).  Same results as the unpadded general path and as the oracle."""
+    kw = dict(kw)
+    brdf = kw.pop("brdf", None)
+    m = rtamd.scenes.make_scene(nS, lt, 5, 12, seed=5 * nS + lt, aerosol_total=0.4, **kw)
+    if brdf:
+        m.params.brdf = rtamd.corert.rpvSurfaceScalar(0.12, 0.7, -0.15, 0.9)
+    sc = rtamd.prepare_scene(m)
+    assert sc.N == N
+    out = {}
+    for pad in (1, 0):
+        with rtamd.corert.make_handle(m) as h:
+            h.set_option(rtamd._lib.MOM_OPT_STRIP_PAD, pad)
+            R, T = rtamd.corert.run_scene(h, sc)
+            out[pad] = (R, T) + h.get_hdr()
+    Rr, Tr = _oracle(cref, m)
+    tol = helpers.stokes_rtol(sc.ndoubl)
+    for pad in (1, 0):
+        helpers.assert_stokes_close(out[pad][0], Rr, rtol=tol, what=f"R pad={pad}")
+        helpers.assert_stokes_close(out[pad][1], Tr, rtol=tol, what=f"T pad={pad}")
+    helpers.assert_stokes_close(out[1][2], out[0][2], rtol=tol, what="hdr padded vs unpadded")
+    np.testing.assert_allclose(out[1][3], out[0][3], rtol=max(tol, 1e-10), atol=1e-300)
+    np.testing.assert_allclose(out[1][4], out[0][4], rtol=max(tol, 1e-10), atol=1e-300)
+
+
 def test_strip_chains_thick_layers_fall_back(rtamd, cref):
     """optically thick scattering layers: the series length exceeds the strip chains' limit for part of the
     doubling steps and interactions, which must then take the general path inside the same kernels"""
