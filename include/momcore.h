@@ -210,6 +210,17 @@ int mom_scene_set_surface(mom_t *h, int kind, int M, const double *Rsurf, const 
  * surface, post-processing.  Asynchronous on the handle's stream; results stay on the GPU. */
 int mom_rt_run(mom_t *h);
 
+/* rt_run_test_ms(RS_type::noRS, sensor_levels, model, iBand) (src/CoreRT/rt_run_multisensor.jl:14-191) for the resident
+ * scene: sensors inside the atmosphere.  sensor_levels[ims] = 0 is the TOA/BOA pair (uwJ = R_SFI, dwJ = T_SFI of
+ * mom_rt_run); L in 1..Nz-1 puts the sensor below layer L counted from the top: rt_kernel_multisensor!
+ * (rt_kernel_multisensor.jl:2-113) builds the composite of layers 1..L ("top") and of layers L+1..Nz plus the surface
+ * ("bot"), interlayer_flux_helper! (CoreKernel/interlayer_flux.jl:7-24) solves for the fields at the interface,
+ *   dwJ = (I - topR+- botR-+)^-1 (topJ0+ + topR+- botJ0-),  uwJ = (I - botR-+ topR+-)^-1 (botJ0- + botR-+ topJ0+),
+ * and postprocessing_vza_ms! (tools/postprocessing_vza_ms.jl:9-77) weights them azimuthally.
+ * uwJ, dwJ: host [nVza, nStokes, nSpec, nSensors] (the reference's vector-of-arrays, sensor-major).  Synchronous.
+ * Float64, noRS; the hdr / bhr outputs of mom_get_hdr are not defined after this call. */
+int mom_rt_run_multisensor(mom_t *h, int nSensors, const int *sensor_levels, double *uwJ, double *dwJ);
+
 /* R_SFI, T_SFI [nVza, nStokes, S] to host (synchronises). */
 int mom_get_RT(mom_t *h, double *R_SFI, double *T_SFI);
 /* The RAMI extras of rt_run's return tuple (rt_run.jl:226): hdr [nVza, nStokes, S] from

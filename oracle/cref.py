@@ -170,6 +170,24 @@ def rt_run_full(p: Packed, pts=None, nthreads: int = 0):
     return tr(R), tr(T), tr(H), up.reshape(p.S, p.nS).T.copy(), dw.reshape(p.S, p.nS).T.copy(), info
 
 
+def rt_run_multisensor(p: Packed, sensor_levels, pts=None, nthreads: int = 0):
+    """rt_run_test_ms (rt_run_multisensor.jl): returns uwJ, dwJ [nSensors, nVza, nStokes, S], info."""
+    if nthreads <= 0:
+        nthreads = effective_cores()
+    lv = np.ascontiguousarray(sensor_levels, dtype=np.int32)
+    n = p.nVza * p.nS * p.S * len(lv)
+    uw, dw = np.zeros(n), np.zeros(n)
+    st = p.c_struct()
+    if pts is None:
+        info = lib().ora_rt_run_ms(C.byref(st), None, 0, nthreads, len(lv), ip(lv), dp(uw), dp(dw))
+    else:
+        pts = np.ascontiguousarray(pts, dtype=np.int32)
+        info = lib().ora_rt_run_ms(C.byref(st), ip(pts), len(pts), nthreads, len(lv), ip(lv), dp(uw), dp(dw))
+    shp = (len(lv), p.S, p.nS, p.nVza)
+    tr = lambda a: np.transpose(a.reshape(shp), (0, 3, 2, 1)).copy()
+    return tr(uw), tr(dw), info
+
+
 # ---- op-level wrappers on ABI-ordered flat arrays -----------------------------------------
 
 def elemental(p: Packed, m, nd, tau_sum, dtau, varpi, Zpp, Zmp, z_batch, S):

@@ -670,6 +670,140 @@ int ora_rt_run_full(const ora_scene *sc, const int *pts, int npts, int nthreads,
   return info;
 }
 
+/* rt_run_test_ms(::noRS, sensor_levels, model, iBand) rt_run_multisensor.jl:14-191: rt_kernel_multisensor!(::noRS)
+ * (rt_kernel_multisensor.jl:2-113: which composite -- above (top) or below (bot) sensor ims -- the added layer of iz
+ * joins), the surface interaction with every bottom composite (rt_run_multisensor.jl:150-159), interlayer_flux_helper!
+ * (interlayer_flux.jl:7-24) and postprocessing_vza_ms!(::noRS) (postprocessing_vza_ms.jl:9-77).
+ * levels[ims] in 0..Nz-1: 0 = the TOA/BOA pair, L >= 1 = below layer L (counted from the top).
+ * uwJ, dwJ: [nVza,nStokes,S,nSens] column-major, zero-initialised by the caller. */
+int ora_rt_run_ms(const ora_scene *sc, const int *pts, int npts, int nthreads, int nSens, const int *levels, double *uwJ,
+                  double *dwJ) {
+  const int N = sc->N, n = sc->nS, S = sc->S, Nz = sc->Nz, K = sc->K, M = sc->M;
+  const size_t NN = (size_t)N * N, CS = 4 * NN + 2 * (size_t)N; /* one composite: R-+, R+-, T++, T--, J0+, J0- */
+  ora_streams q = {N, n, sc->imu0, sc->mu, sc->wt, sc->I0, sc->D, sc->strict, sc->mu0};
+  const int count = pts ? npts : S;
+  int info = 0;
+  for (int i = 0; i < nSens; ++i)
+    if (levels[i] < 0 || levels[i] >= Nz) return -1;
+  (void)nthreads;
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+  {
+    double *buf = (double *)malloc((12 * NN + 16 * N + 2 * (size_t)nSens * CS) * sizeof(double));
+    int *piv = (int *)malloc(N * sizeof(int));
+    double *Zp = buf, *Zm = buf + NN;
+    double *a_rpm = buf + 2 * NN, *a_rmp = buf + 3 * NN, *a_tmm = buf + 4 * NN, *a_tpp = buf + 5 * NN;
+    double *work = buf + 6 * NN; /* 4*NN + 4*N */
+    double *vec = buf + 10 * NN + 4 * N;
+    double *a_j0p = vec, *a_j0m = vec + N, *tdw = vec + 2 * N, *tuw = vec + 3 * N;
+    double *s_rpm = buf + 11 * NN + 12 * N;
+    double *comps = buf + 12 * NN + 16 * N; /* [top, bot] x nSens */
+#define MS_COMP(which, ims, k) (comps + ((size_t)(2 * (ims) + (which))) * CS + ((k) < 4 ? (size_t)(k) * NN : 4 * NN + (size_t)((k) - 4) * N))
+#pragma omp for schedule(dynamic, 1)
+    for (int ip = 0; ip < count; ++ip) {
+      const int s = pts ? pts[ip] : ip;
+      for (size_t x = 0; x < NN; ++x) s_rpm[x] = 0.0;
+      for (int m = 0; m < M; ++m) {
+        const double weight = (m == 0) ? 0.5 : 1.0;
+        int e = 0;
+        for (int z = 0; z < Nz; ++z) {
+          const int iz = z + 1;
+          const double tau = sc->tau[s + (size_t)S * z], varpi = sc->varpi[s + (size_t)S * z];
+          const int nd = sc->nd[z];
+          const double dtau = tau / ldexp(1.0, nd);
+          double expk = exp(-dtau / sc->mu0);
+          for (size_t x = 0; x < NN; ++x) { Zp[x] = 0; Zm[x] = 0; }
+          for (int k = 0; k < K; ++k) {
+            const double w = sc->zw[k + (size_t)K * (s + (size_t)S * z)];
+            const double *bp = sc->Zpp + NN * (k + (size_t)K * m), *bm = sc->Zmp + NN * (k + (size_t)K * m);
+            for (size_t x = 0; x < NN; ++x) { Zp[x] += w * bp[x]; Zm[x] += w * bm[x]; }
+          }
+          elemental_pt(&q, m, nd, sc->tau_sum[s + (size_t)S * z], dtau, varpi, Zp, Zm, a_rmp, a_tpp, a_rpm, a_tmm,
+                       a_j0p, a_j0m);
+          int e1 = doubling_pt(&q, nd, &expk, a_rmp, a_tpp, a_rpm, a_tmm, a_j0p, a_j0m, work, piv);
+          if (e1 && !e) e = e1;
+          for (int ims = 0; ims < nSens; ++ims) {
+            const int L = levels[ims];
+            int which, copy; /* which: 0 top, 1 bot */
+            if (iz == 1) { which = (L == 0) ? 1 : 0; copy = 1; }
+            else if (L == 0) { which = 1; copy = 0; }
+            else if (L == iz - 1) { which = 1; copy = 1; }
+            else if (L < iz - 1) { which = 1; copy = 0; }
+            else { which = 0; copy = 0; }
+            double *cR_mp = MS_COMP(which, ims, 0), *cR_pm = MS_COMP(which, ims, 1), *cT_pp = MS_COMP(which, ims, 2),
+                   *cT_mm = MS_COMP(which, ims, 3), *cJ0p = MS_COMP(which, ims, 4), *cJ0m = MS_COMP(which, ims, 5);
+            if (copy) {
+              memcpy(cT_pp, a_tpp, NN * 8); memcpy(cT_mm, a_tmm, NN * 8);
+              memcpy(cR_mp, a_rmp, NN * 8); memcpy(cR_pm, a_rpm, NN * 8);
+              memcpy(cJ0p, a_j0p, N * 8); memcpy(cJ0m, a_j0m, N * 8);
+            } else {
+              int e2 = interaction_pt(N, sc->iface[z], cR_mp, cR_pm, cT_pp, cT_mm, cJ0p, cJ0m, a_rpm, a_rmp, a_tmm, a_tpp,
+                                      a_j0p, a_j0m, work, piv);
+              if (e2 && !e) e = e2;
+            }
+          }
+        }
+        if (sc->surf_kind == 1)
+          surface_brdf_pt(&q, sc->Rsurf + NN * m, sc->tau_sum[s + (size_t)S * Nz], s_rpm, a_rmp, a_tmm, a_tpp, a_j0p, a_j0m);
+        else if (sc->surf_kind == 2)
+          surface_legendre_pt(&q, m, sc->albedo_spec[s], sc->tau_sum[s + (size_t)S * Nz], s_rpm, a_rmp, a_tmm, a_tpp,
+                              a_j0p, a_j0m);
+        else
+          surface_lambertian_pt(&q, m, sc->albedo, sc->tau_sum[s + (size_t)S * Nz], s_rpm, a_rmp, a_tmm, a_tpp, a_j0p,
+                                a_j0m);
+        for (int ims = 0; ims < nSens; ++ims) {
+          int e3 = interaction_pt(N, sc->iface[Nz - 1], MS_COMP(1, ims, 0), MS_COMP(1, ims, 1), MS_COMP(1, ims, 2),
+                                  MS_COMP(1, ims, 3), MS_COMP(1, ims, 4), MS_COMP(1, ims, 5), s_rpm, a_rmp, a_tmm, a_tpp,
+                                  a_j0p, a_j0m, work, piv);
+          if (e3 && !e) e = e3;
+        }
+        for (int ims = 0; ims < nSens; ++ims) {
+          const double *uw, *dw;
+          if (levels[ims] == 0) {
+            uw = MS_COMP(1, ims, 5); dw = MS_COMP(1, ims, 4);
+          } else {
+            /* interlayer_flux.jl:14-23 */
+            const double *tR_pm = MS_COMP(0, ims, 1), *bR_mp = MS_COMP(1, ims, 0), *tJ0p = MS_COMP(0, ims, 4),
+                         *bJ0m = MS_COMP(1, ims, 5);
+            double *W1 = work, *W2 = work + NN, *v1 = work + 4 * NN, *v2 = v1 + N;
+            gemm(N, tR_pm, bR_mp, W1);
+            for (size_t x = 0; x < NN; ++x) W1[x] = -W1[x];
+            for (int i = 0; i < N; ++i) W1[IDX(i, i, N)] += 1.0;
+            int e4 = inv_lu(N, W1, W2, piv); if (e4 && !e) e = e4;
+            gemv(N, tR_pm, bJ0m, v1);
+            for (int i = 0; i < N; ++i) v1[i] = tJ0p[i] + v1[i];
+            gemv(N, W2, v1, tdw);
+            gemm(N, bR_mp, tR_pm, W1);
+            for (size_t x = 0; x < NN; ++x) W1[x] = -W1[x];
+            for (int i = 0; i < N; ++i) W1[IDX(i, i, N)] += 1.0;
+            e4 = inv_lu(N, W1, W2, piv); if (e4 && !e) e = e4;
+            gemv(N, bR_mp, tJ0p, v2);
+            for (int i = 0; i < N; ++i) v2[i] = bJ0m[i] + v2[i];
+            gemv(N, W2, v2, tuw);
+            uw = tuw; dw = tdw;
+          }
+          for (int v = 0; v < sc->nVza; ++v) {
+            const int istart = (sc->node[v] - 1) * n;
+            const double c = sc->cos_mphi[v + (size_t)sc->nVza * m], sn = sc->sin_mphi[v + (size_t)sc->nVza * m];
+            for (int k = 0; k < n; ++k) {
+              const double cs = weight * ((k < 2) ? c : sn);
+              const size_t o = v + (size_t)sc->nVza * (k + (size_t)n * (s + (size_t)S * ims));
+              uwJ[o] += cs * uw[istart + k];
+              dwJ[o] += cs * dw[istart + k];
+            }
+          }
+        }
+        if (e) {
+#pragma omp atomic write
+          info = e;
+        }
+      }
+    }
+#undef MS_COMP
+    free(buf); free(piv);
+  }
+  return info;
+}
+
 /* ---------------------------------------------------------------- Voigt (src/Absorption) */
 
 /* humlicek2: complex_error_functions.jl:24-30; weideman32a: :170-190;

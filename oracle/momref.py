@@ -1041,6 +1041,85 @@ def rt_run(scene: Scene, hook=None):
     return R_SFI, T_SFI
 
 
+def _copy_added(comp: CompositeLayer, added: AddedLayer):
+    comp.T_pp[:] = added.t_pp
+    comp.T_mm[:] = added.t_mm
+    comp.R_mp[:] = added.r_mp
+    comp.R_pm[:] = added.r_pm
+    comp.J0p[:] = added.j0p
+    comp.J0m[:] = added.j0m
+
+
+def interlayer_flux(top: CompositeLayer, bot: CompositeLayer):
+    """interlayer_flux_helper!(::noRS) CoreKernel/interlayer_flux.jl:7-24: the downwelling and upwelling fields at the
+    interface between the composite above (top) and below (bot) a sensor.  Returns (tdwJ, tuwJ) [S, N]."""
+    N = top.R_pm.shape[1]
+    I = np.eye(N)[None]
+    tmpR = batch_inv(I - top.R_pm @ bot.R_mp)
+    tdw = _mv(tmpR, top.J0p + _mv(top.R_pm, bot.J0m))
+    tmpR = batch_inv(I - bot.R_mp @ top.R_pm)
+    tuw = _mv(tmpR, bot.J0m + _mv(bot.R_mp, top.J0p))
+    return tdw, tuw
+
+
+def rt_run_multisensor(scene: Scene, sensor_levels: Sequence[int], hook=None):
+    """rt_run_test_ms(::noRS, sensor_levels, model, iBand) rt_run_multisensor.jl:14-191 with
+    rt_kernel_multisensor!(::noRS) rt_kernel_multisensor.jl:2-113 and postprocessing_vza_ms!(::noRS)
+    tools/postprocessing_vza_ms.jl:9-77.  A sensor at level L >= 1 sits below layer L (counted from the top, L < Nz):
+    its top composite holds layers 1..L, its bottom composite layers L+1..Nz and the surface; level 0 is the TOA/BOA
+    pair (uwJ = J0- at the top, dwJ = J0+ at the bottom of the whole column).  Returns (uwJ, dwJ), each
+    [nSensors, nVza, nStokes, S]."""
+    pol, quad = scene.pol, scene.quad
+    S, Nz, N = scene.S, scene.Nz, scene.N
+    nV, nSens = len(scene.vza), len(sensor_levels)
+    for L in sensor_levels:
+        if not 0 <= L < Nz:
+            raise ValueError("sensor level must be in 0..Nz-1")
+    uwJ = np.zeros((nSens, nV, pol.n, S))
+    dwJ = np.zeros((nSens, nV, pol.n, S))
+    added = make_added_layer(N, S)
+    surf = make_added_layer(N, S)
+    tops = [make_composite_layer(N, S) for _ in sensor_levels]
+    bots = [make_composite_layer(N, S) for _ in sensor_levels]
+    strict = scene.strict_reference_indexing
+    sinp = surface_inputs(scene)
+    for m in range(scene.max_m):
+        weight = 0.5 if m == 0 else 1.0
+        layers = construct_core_optical_properties(scene, m)
+        ifaces, tau_sum_all = extract_effective_props(layers)
+        for iz in range(1, Nz + 1):
+            lay = layers[iz - 1]
+            dtau, nd = get_dtau_ndoubl(lay.tau, lay.varpi, quad.qp_mu)
+            expk = np.exp(-dtau / quad.mu0)
+            Zpp, Zmp = lay.Zfull()
+            elemental(pol, quad, tau_sum_all[:, iz - 1], dtau, lay.varpi, Zpp, Zmp, m, nd, added, strict)
+            doubling(pol, expk, nd, added, strict)
+            for ims, L in enumerate(sensor_levels):           # rt_kernel_multisensor.jl:51-112
+                if iz == 1:
+                    _copy_added(bots[ims] if L == 0 else tops[ims], added)
+                elif L == 0:
+                    interaction(ifaces[iz - 1], bots[ims], added)
+                elif L == iz - 1:
+                    _copy_added(bots[ims], added)
+                elif L < iz - 1:
+                    interaction(ifaces[iz - 1], bots[ims], added)
+                else:
+                    interaction(ifaces[iz - 1], tops[ims], added)
+        create_surface_layer(scene, sinp, surf, m, tau_sum_all[:, -1])
+        for ims in range(nSens):                              # rt_run_multisensor.jl:150-159
+            interaction(ifaces[-1], bots[ims], surf)
+        for ims, L in enumerate(sensor_levels):               # postprocessing_vza_ms.jl:33-53
+            if L == 0:
+                tuw, tdw = bots[ims].J0m, bots[ims].J0p
+            else:
+                tdw, tuw = interlayer_flux(tops[ims], bots[ims])
+            if hook:
+                hook(m, ims, tops[ims], bots[ims], tdw, tuw)
+            dummy = CompositeLayer(None, None, None, None, tdw, tuw)
+            postprocessing_vza(pol, dummy, scene.vza, quad.qp_mu, m, scene.vaz, weight, uwJ[ims], dwJ[ims])
+    return uwJ, dwJ
+
+
 # --------------------------------------------------------------------------------------
 # Voigt line shape (src/Absorption)
 # --------------------------------------------------------------------------------------

@@ -67,6 +67,7 @@ SIGNATURES = {
     "mom_scene_get_layers": (C.c_int, [c_h, c_ip, c_ip, c_dp, c_dp, c_dp, c_dp]),
     "mom_scene_set_surface": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp]),
     "mom_rt_run": (C.c_int, [c_h]),
+    "mom_rt_run_multisensor": (C.c_int, [c_h, C.c_int, c_ip, c_dp, c_dp]),
     "mom_get_RT": (C.c_int, [c_h, c_dp, c_dp]),
     "mom_get_hdr": (C.c_int, [c_h, c_dp, c_dp, c_dp]),
     "mom_get_RT_device": (C.c_int, [c_h, C.c_void_p, C.c_void_p]),
@@ -278,6 +279,17 @@ class Handle:
 
     def rt_run(self):
         self.check(self.lib.mom_rt_run(self._h))
+
+    def rt_run_multisensor(self, sensor_levels):
+        """uwJ, dwJ as numpy [nSensors, nVza, nStokes, S] (the reference's vector of [nVza, nStokes, nSpec] arrays,
+        rt_run_multisensor.jl:52-55)."""
+        lv = np.ascontiguousarray(sensor_levels, dtype=np.int32)
+        n = self.nVza * self.nS * self.S * len(lv)
+        uw, dw = np.empty(n), np.empty(n)
+        self.check(self.lib.mom_rt_run_multisensor(self._h, len(lv), ip(lv), dp(uw), dp(dw)))
+        shp = (len(lv), self.S, self.nS, self.nVza)
+        tr = lambda a: np.transpose(a.reshape(shp), (0, 3, 2, 1)).copy()
+        return tr(uw), tr(dw)
 
     def get_RT(self):
         """R_SFI, T_SFI as numpy [nVza, nStokes, S] (reference layout, rt_run.jl:89-90)."""

@@ -756,6 +756,26 @@ def rt_run(model: vSmartMOM_Model, i_band: int = 1):
     return R, T, np.zeros_like(R), np.zeros_like(T), hdr, up[0], dw[0]
 
 
+def scene_set(h: _lib.Handle, sc: SceneInputs):
+    h.scene_set(sc.Nz, sc.K, sc.M, sc.tau, sc.varpi, sc.zw, sc.Zpp, sc.Zmp, sc.ndoubl, sc.iface, sc.tau_sum,
+                sc.albedo, sc.node, sc.cos_mphi, sc.sin_mphi)
+    if sc.surf_kind != 0:
+        h.scene_set_surface(sc.surf_kind, sc.M, sc.Rsurf, sc.albedo_spec)
+
+
+def rt_run_test_ms(sensor_levels, model: vSmartMOM_Model, i_band: int = 1):
+    """rt_run_test_ms(RS_type::noRS, sensor_levels, model, iBand) (rt_run_multisensor.jl:14-191): sensors inside the
+    atmosphere, labelled from the top (0 = the TOA/BOA pair, L = below layer L), all sharing the view angles.
+    Returns the reference's 4-tuple (uwJ, dwJ, uwieJ, dwieJ): lists over the sensors of [nVza, nStokes, nSpec] arrays;
+    the inelastic terms are zero for noRS."""
+    sc = prepare_scene(model)
+    with make_handle(model) as h:
+        scene_set(h, sc)
+        uw, dw = h.rt_run_multisensor(sensor_levels)
+    z = [np.zeros_like(u) for u in uw]
+    return list(uw), list(dw), z, [x.copy() for x in z]
+
+
 def rt_run_operators(model: vSmartMOM_Model):
     """The same run replayed operator by operator through the op-level ABI, exactly in the
     order of rt_run.jl:125-215 / rt_kernel.jl:173-235 (what a Julia shim overloading

@@ -207,4 +207,62 @@ __global__ void __launch_bounds__(kThreads, 2) k_surface(SurfArgs a) {
   if (wg_tid() == 0 && *c.bad) atomicMax(a.info, *c.bad);
 }
 
+// Fields at a sensor between two composite slabs (interlayer_flux_helper!(::noRS), CoreKernel/interlayer_flux.jl:7-24):
+//   dwJ = (I - topR+- botR-+)^-1 (topJ0+ + topR+- botJ0-)      uwJ = (I - botR-+ topR+-)^-1 (botJ0- + botR-+ topJ0+)
+// per (spectral point, moment) unit; top = the layers above the sensor, bot = the layers below it and the surface.
+struct InterArgs {
+  DevStreams q;
+  int S, M;
+  real *top[6], *bot[6];  // scene-level composite states [.,.,S,M]
+  real *dwJ, *uwJ;        // [N,S,M]
+  real *scratch;
+  int *info;
+};
+
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads, 2) k_interlayer(InterArgs a) {
+  const int N = a.q.N;
+  Ctx c;
+  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
+  const int ld = c.ld;
+  const size_t units = (size_t)a.S * a.M;
+  for (size_t pt = blockIdx.x; pt < units; pt += gridDim.x) {
+    const CompPtrs gt = comp_ptrs(a.top, N, comp_pitch(N), pt), gb = comp_ptrs(a.bot, N, comp_pitch(N), pt);
+    const int cl = gt.ld;
+    wg_copy_mat(N, c.fd, gt.R_pm, cl, c.r, ld);  // r = topR+-
+    wg_copy_mat(N, c.fd, gb.R_mp, cl, c.t, ld);  // t = botR-+
+    for (int i = wg_tid(); i < N; i += kThreads) {
+      c.Jp[i] = gt.J0p[i];
+      c.Jm[i] = gb.J0m[i];
+    }
+    __syncthreads();
+    for (int dir = 0; dir < 2; ++dir) {
+      // dir 0 (down): X = topR+-, Y = botR-+, x = topJ0+, y = botJ0-;  dir 1 (up): the roles exchanged
+      real *X = dir ? c.t : c.r, *Y = dir ? c.r : c.t;
+      const real *x = dir ? c.Jm : c.Jp, *y = dir ? c.Jp : c.Jm;
+      real beta2;
+      {
+        real *Q = c.Q;
+        real ss = 0.0;
+        wg_gemm<false, !LDSM>(N, ElP{X, ld}, ElP{Y, ld}, [=, &ss](int i, int j, real v) {
+          Q[i + j * ld] = v;
+          ss += v * v;
+        });
+        wg_sumsq_put(c, ss);
+        __syncthreads();
+        beta2 = wg_sumsq_get(c);
+      }
+      times_inv<LDSM>(c, ElEye{N}, c.Q, c.P, beta2);  // P = (I - X Y)^-1
+      wg_matvec(c, ElP{X, ld}, y, c.v1);
+      for (int i = wg_tid(); i < N; i += kThreads) c.v1[i] = x[i] + c.v1[i];
+      __syncthreads();
+      wg_matvec(c, ElP{c.P, ld}, c.v1, c.v2);
+      real *out = (dir ? a.uwJ : a.dwJ) + (size_t)N * pt;
+      for (int i = wg_tid(); i < N; i += kThreads) out[i] = c.v2[i];
+      __syncthreads();
+    }
+  }
+  if (wg_tid() == 0 && *c.bad) atomicMax(a.info, *c.bad);
+}
+
 }  // namespace MOM_NS

@@ -324,6 +324,10 @@ struct mom_handle {
   int surf_kind = 0;         // 0 Lambertian scalar, 1 BRDF matrices, 2 Lambertian Legendre (mom_scene_set_surface)
   double *d_Rsurf = nullptr, *d_Rsurf0 = nullptr, *d_albedo_spec = nullptr, *d_hdrJm = nullptr;
   int opt_sweep = 1;       // one launch walks all layers of a unit (LayerArgs::Nz_sweep)
+  double *comp_top[6] = {};  // mom_rt_run_multisensor: composite state of the slab above a sensor
+  double *d_msJ[2] = {};     // interface fields dwJ, uwJ [Nk,S,M]
+  double *d_ms_out = nullptr;  // [2][nVza*nS*S*nSensors]
+  size_t ms_out_cap = 0;
   int opt_pad = 1;         // scene-level path: pad the operator edge to the next strip-chained kernel size (strip_pad)
   int Nk = 0;              // operator edge the scene-level kernels of the full problem run with (>= N)
   DevStreams qk{};         // q with N = Nk
@@ -494,7 +498,8 @@ extern "C" int mom_destroy(mom_t *h) {
   if (h->comm && g_rccl_destroy) g_rccl_destroy(h->comm);
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(h->d_mu); fr(h->d_wt); fr(h->d_sg);
-  for (int k = 0; k < 6; ++k) { fr(h->added[k]); fr(h->surf[k]); fr(h->comp[k]); }
+  for (int k = 0; k < 6; ++k) { fr(h->added[k]); fr(h->surf[k]); fr(h->comp[k]); fr(h->comp_top[k]); }
+  fr(h->d_msJ[0]); fr(h->d_msJ[1]); fr(h->d_ms_out);
   for (int k = 0; k < 4; ++k) fr(h->d_vec[k]);
   fr(h->d_Zop[0]); fr(h->d_Zop[1]);
   fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
@@ -1121,43 +1126,38 @@ static int rt_run_wave(mom_t *h) {
   return MOM_OK;
 }
 
-extern "C" int mom_rt_run(mom_t *h) {
-  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_rt_run: call mom_scene_set first");
-  HIPCHK(h, hipSetDevice(h->device));
-  if (h->f32) {
-    const int rc = momf_rt_run(h->f32);
-    return rc ? fail(h, rc, momf_error(h->f32)) : MOM_OK;
-  }
+// The general path of mom_rt_run for the layers [za, zb) of the column into the composite state `compF` (full problem;
+// the m = 0 sub-problem keeps its own arrays and is used only when allow_red): layer kernels, then (do_surface) the
+// surface layer with its closing interaction, then (do_post) the azimuthal post-processing into d_R / d_T / d_hdr.
+// mom_rt_run: the whole column; mom_rt_run_multisensor: the slabs above and below a sensor.
+static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const compF[6], bool do_surface, bool do_post) {
   const size_t S = h->S;
   const int M = h->scene_M;
-  h->launches = 0; h->launches_full = 0; h->launches_red = 0;
-  h->comp_pitched = true;
-  if (h->N <= 4 && h->opt_small && h->nVza <= 4 && h->surf_kind == 0) return rt_run_small(h);
-  if (wave_sweep_applies(h)) return rt_run_wave(h);
-  while (h->ev_full.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_full.push_back(e); }
-  while (h->ev_red.size() < 2 * (size_t)h->Nz) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_red.push_back(e); }
+  const bool red0 = h->red0 && allow_red;
+  const int nzr = zb - za;
+  while (h->ev_full.size() < 2 * (size_t)h->Nz + 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_full.push_back(e); }
+  while (h->ev_red.size() < 2 * (size_t)h->Nz + 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_red.push_back(e); }
   const int Nk = h->Nk;  // kernel-side edge of the full problem (strip_pad)
   const size_t NN = (size_t)Nk * Nk;
   // one k_layer launch over `Mcount` moments starting at `m_first` with stream set `q` (full or reduced)
   // sweep mode: every layer of a unit inside one launch (z < 0 selects it); needs one interface code for all z >= 1
   // (the code is a template argument of the kernel images) -- always the case once scattering has set in
-  bool can_sweep = h->opt_sweep && h->Nz <= kMaxSweepLayers && h->Nz > 1;
-  for (int z = 2; z < h->Nz && can_sweep; ++z) can_sweep = (h->iface[z] == h->iface[1]);
-  for (int z = 0; z < h->Nz && can_sweep; ++z) can_sweep = (h->nd[z] <= 127);
+  bool can_sweep = h->opt_sweep && nzr <= kMaxSweepLayers && nzr > 1;
+  for (int z = za + 2; z < zb && can_sweep; ++z) can_sweep = (h->iface[z] == h->iface[za + 1]);
+  for (int z = za; z < zb && can_sweep; ++z) can_sweep = (h->nd[z] <= 127);
   auto launch_layer = [&](int z, const DevStreams &q, int m_first, int Mcount, const double *Zpp, const double *Zmp,
                           double *const comp[6], double *scratch) -> int {
     LayerArgs a{};
     a.q = q; a.S = h->S; a.M = Mcount; a.K = h->K; a.m_first = m_first;
     const bool sweep = z < 0;
     if (sweep) {
-      z = 0;
-      a.Nz_sweep = h->Nz;
+      z = za;
+      a.Nz_sweep = nzr;
       int ndsum = 0;
-      for (int k = 0; k < h->Nz; ++k) { a.nd_z[k] = (signed char)h->nd[k]; a.iface_z[k] = (signed char)h->iface[k]; ndsum += h->nd[k]; }
-      a.nd = ndsum / h->Nz; a.iface = h->iface[1]; a.first = 1;
+      for (int k = 0; k < nzr; ++k) { a.nd_z[k] = (signed char)h->nd[za + k]; a.iface_z[k] = (signed char)h->iface[za + k]; ndsum += h->nd[za + k]; }
+      a.nd = ndsum / nzr; a.iface = h->iface[za + 1]; a.first = 1;
     } else {
-      a.nd = h->nd[z]; a.iface = h->iface[z]; a.first = (z == 0);
+      a.nd = h->nd[z]; a.iface = h->iface[z]; a.first = (z == za);
     }
     a.tau = h->d_tau + S * z; a.varpi = h->d_varpi + S * z; a.zw = h->d_zw + (size_t)h->K * S * z;
     a.tau_sum = h->d_tau_sum + S * z;
@@ -1214,13 +1214,13 @@ extern "C" int mom_rt_run(mom_t *h) {
     return MOM_OK;
   };
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
-  for (int z = (can_sweep ? -1 : 0); z < (can_sweep ? 0 : h->Nz); ++z) {
+  for (int z = (can_sweep ? -1 : za); z < (can_sweep ? 0 : zb); ++z) {
     int rc;
-    const int e = can_sweep ? 0 : z;  // event slot
-    if (h->red0) {
+    const int e = can_sweep ? 0 : z - za;  // event slot
+    if (red0) {
       if (M > 1) {  // moments 1..M-1 on the full problem
         double *comp1[6];
-        for (int k = 0; k < 6; ++k) comp1[k] = h->comp[k] + ((k < 4) ? (size_t)comp_pitch(Nk) * Nk : (size_t)Nk) * S;
+        for (int k = 0; k < 6; ++k) comp1[k] = compF[k] + ((k < 4) ? (size_t)comp_pitch(Nk) * Nk : (size_t)Nk) * S;
         HIPCHK(h, hipEventRecord(h->ev_full[2 * e], h->stream));
         if ((rc = launch_layer(z, h->qk, 1, M - 1, h->d_Zpp + NN * h->K, h->d_Zmp + NN * h->K, comp1, h->d_scratch))) return rc;
         HIPCHK(h, hipEventRecord(h->ev_full[2 * e + 1], h->stream));
@@ -1232,23 +1232,23 @@ extern "C" int mom_rt_run(mom_t *h) {
       h->launches_red++;
     } else {
       HIPCHK(h, hipEventRecord(h->ev_full[2 * e], h->stream));
-      if ((rc = launch_layer(z, h->qk, 0, M, h->d_Zpp, h->d_Zmp, h->comp, h->d_scratch))) return rc;
+      if ((rc = launch_layer(z, h->qk, 0, M, h->d_Zpp, h->d_Zmp, compF, h->d_scratch))) return rc;
       HIPCHK(h, hipEventRecord(h->ev_full[2 * e + 1], h->stream));
       h->launches_full++;
     }
   }
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   // surface layer + closing interaction: m = 0 always; every moment for a BRDF surface (kind 1)
-  for (int m = 0; m < ((h->surf_kind == 1) ? M : 1); ++m) {
+  for (int m = 0; do_surface && m < ((h->surf_kind == 1) ? M : 1); ++m) {
     SurfArgs a{};
-    const bool red = h->red0 && m == 0;
+    const bool red = red0 && m == 0;
     const DevStreams &q = red ? h->q0 : h->qk;
     a.q = q; a.S = h->S; a.iface = h->iface[h->Nz - 1];  // Q6: last layer's interface code (rt_run.jl:181)
     a.albedo = h->albedo; a.tau_tot = h->d_tau_sum + S * h->Nz;
     a.kind = h->surf_kind; a.m = m; a.albedo_spec = h->d_albedo_spec;
     a.Rsurf = (h->surf_kind == 1) ? (red ? h->d_Rsurf0 : h->d_Rsurf + NN * m) : nullptr;
     for (int k = 0; k < 6; ++k)
-      a.comp[k] = red ? h->comp0[k] : h->comp[k] + ((k < 4) ? (size_t)comp_pitch(Nk) * Nk : (size_t)Nk) * S * m;
+      a.comp[k] = red ? h->comp0[k] : compF[k] + ((k < 4) ? (size_t)comp_pitch(Nk) * Nk : (size_t)Nk) * S * m;
     a.hdrJ = red ? h->d_hdrJ0 : (m == 0 ? h->d_hdrJ : h->d_hdrJm + (size_t)Nk * S * m);
     a.bhr_uw = h->d_bhr_uw; a.bhr_dw = h->d_bhr_dw; a.nS_out = h->nS;
     a.scratch = red ? h->d_scratch0 : h->d_scratch; a.info = h->d_info;
@@ -1267,14 +1267,14 @@ extern "C" int mom_rt_run(mom_t *h) {
     HIPCHK(h, hipGetLastError());
   }
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
-  {
+  if (do_post) {
     const size_t total = (size_t)h->nVza * h->nS * S;
     PostArgs pa{};
-    pa.N = Nk; pa.nS = h->nS; pa.S = h->S; pa.M = M; pa.nVza = h->nVza; pa.red0 = h->red0 ? 1 : 0;
+    pa.N = Nk; pa.nS = h->nS; pa.S = h->S; pa.M = M; pa.nVza = h->nVza; pa.red0 = red0 ? 1 : 0;
     pa.N0 = h->N0; pa.nS0 = h->nS0;
     pa.node = h->d_node; pa.cos_mphi = h->d_cos; pa.sin_mphi = h->d_sin;
-    pa.J0p = h->comp[4]; pa.J0m = h->comp[5]; pa.J0p0 = h->comp0[4]; pa.J0m0 = h->comp0[5];
-    pa.hdrJ = h->red0 ? h->d_hdrJ0 : h->d_hdrJ;
+    pa.J0p = compF[4]; pa.J0m = compF[5]; pa.J0p0 = h->comp0[4]; pa.J0m0 = h->comp0[5];
+    pa.hdrJ = red0 ? h->d_hdrJ0 : h->d_hdrJ;
     pa.hdr_all = (h->surf_kind == 1) ? 1 : 0; pa.zeroT_hi = (h->surf_kind == 2) ? 1 : 0; pa.hdrJm = h->d_hdrJm;
     pa.R = h->d_R; pa.T = h->d_T; pa.hdr = h->d_hdr;
     hipLaunchKernelGGL(k_postprocess, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, pa);
@@ -1282,6 +1282,94 @@ extern "C" int mom_rt_run(mom_t *h) {
   }
   HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
   return MOM_OK;
+}
+
+extern "C" int mom_rt_run(mom_t *h) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_rt_run: call mom_scene_set first");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->f32) {
+    const int rc = momf_rt_run(h->f32);
+    return rc ? fail(h, rc, momf_error(h->f32)) : MOM_OK;
+  }
+  h->launches = 0; h->launches_full = 0; h->launches_red = 0;
+  h->comp_pitched = true;
+  if (h->N <= 4 && h->opt_small && h->nVza <= 4 && h->surf_kind == 0) return rt_run_small(h);
+  if (wave_sweep_applies(h)) return rt_run_wave(h);
+  return rt_run_core(h, 0, h->Nz, true, h->comp, true, true);
+}
+
+// rt_run_test_ms(::noRS, sensor_levels, model, iBand) (rt_run_multisensor.jl:14-191).  Sensors are processed one after
+// the other with two composite states: the slab above the sensor (layers 1..L) and the slab below it (layers L+1..Nz and
+// the surface), each built by the same fused layer kernels as mom_rt_run (sweep mode, strip chains, padded edges), then
+// k_interlayer and the azimuthal post-processing of the interface fields.  The m = 0 (I,Q) reduction is not used here
+// (the interface fields couple two states of the full problem); level 0 is mom_rt_run itself.
+extern "C" int mom_rt_run_multisensor(mom_t *h, int nSensors, const int *sensor_levels, double *uwJ, double *dwJ) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_rt_run_multisensor");
+  if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_rt_run_multisensor: call mom_scene_set first");
+  if (nSensors <= 0 || !sensor_levels || !uwJ || !dwJ) return fail(h, MOM_EINVAL, "mom_rt_run_multisensor: bad argument");
+  for (int i = 0; i < nSensors; ++i)
+    if (sensor_levels[i] < 0 || sensor_levels[i] >= h->Nz)
+      return fail(h, MOM_EINVAL, "mom_rt_run_multisensor: sensor level must be in 0..Nz-1 (0 = TOA/BOA, L = below layer L)");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t S = h->S;
+  const int M = h->scene_M, Nk = h->Nk;
+  const size_t out1 = (size_t)h->nVza * h->nS * S;
+  h->launches = 0; h->launches_full = 0; h->launches_red = 0;
+  h->comp_pitched = true;
+  if (!h->comp_top[0]) {
+    const int Na = h->N + kPadMax;
+    for (int k = 0; k < 6; ++k) {
+      const size_t perc = (k < 4) ? (size_t)comp_pitch(Na) * Na : (size_t)Na;
+      HIPCHK(h, dmalloc(&h->comp_top[k], perc * S * h->M));
+    }
+    for (int k = 0; k < 2; ++k) HIPCHK(h, dmalloc(&h->d_msJ[k], (size_t)Na * S * h->M));
+  }
+  if (h->ms_out_cap < 2 * out1 * nSensors) {
+    if (h->d_ms_out) { (void)hipFree(h->d_ms_out); h->d_ms_out = nullptr; }
+    HIPCHK(h, dmalloc(&h->d_ms_out, 2 * out1 * nSensors));
+    h->ms_out_cap = 2 * out1 * nSensors;
+  }
+  double *d_uw = h->d_ms_out, *d_dw = h->d_ms_out + out1 * nSensors;
+  for (int ims = 0; ims < nSensors; ++ims) {
+    const int L = sensor_levels[ims];
+    int rc;
+    if (L == 0) {  // the TOA/BOA pair: uwJ = R_SFI, dwJ = T_SFI of the whole column (postprocessing_vza_ms.jl:34-36)
+      if ((rc = rt_run_core(h, 0, h->Nz, false, h->comp, true, true))) return rc;
+    } else {
+      if ((rc = rt_run_core(h, 0, L, false, h->comp_top, false, false))) return rc;
+      if ((rc = rt_run_core(h, L, h->Nz, false, h->comp, true, false))) return rc;
+      InterArgs a{};
+      a.q = h->qk; a.S = h->S; a.M = M;
+      for (int k = 0; k < 6; ++k) { a.top[k] = h->comp_top[k]; a.bot[k] = h->comp[k]; }
+      a.dwJ = h->d_msJ[0]; a.uwJ = h->d_msJ[1]; a.scratch = h->d_scratch; a.info = h->d_info;
+      const bool lds = (Nk <= 64) && !h->opt_force_generic;
+      const size_t sm = lds_bytes(Nk, lds);
+      const size_t units = S * M;
+      if (lds) {
+        HIPCHK(h, allow_lds(k_interlayer<true>, sm));
+        hipLaunchKernelGGL(k_interlayer<true>, dim3((unsigned)units), dim3(kThreads), sm, h->stream, a);
+      } else {
+        HIPCHK(h, allow_lds(k_interlayer<false>, sm));
+        hipLaunchKernelGGL(k_interlayer<false>, dim3((unsigned)std::min<size_t>(units, (size_t)h->G)), dim3(kThreads), sm, h->stream, a);
+      }
+      HIPCHK(h, hipGetLastError());
+      PostArgs pa{};
+      pa.N = Nk; pa.nS = h->nS; pa.S = h->S; pa.M = M; pa.nVza = h->nVza; pa.red0 = 0;
+      pa.node = h->d_node; pa.cos_mphi = h->d_cos; pa.sin_mphi = h->d_sin;
+      pa.J0p = h->d_msJ[0]; pa.J0m = h->d_msJ[1];
+      pa.hdrJ = h->d_hdrJ; pa.hdr_all = 0; pa.zeroT_hi = 0; pa.hdrJm = nullptr;
+      pa.R = h->d_R; pa.T = h->d_T; pa.hdr = h->d_hdr;
+      hipLaunchKernelGGL(k_postprocess, dim3((unsigned)((out1 + 255) / 256)), dim3(256), 0, h->stream, pa);
+      HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipMemcpyAsync(d_uw + out1 * ims, h->d_R, out1 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(d_dw + out1 * ims, h->d_T, out1 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  }
+  HIPCHK(h, hipMemcpyAsync(uwJ, d_uw, out1 * nSensors * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dwJ, d_dw, out1 * nSensors * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return check_info(h);
 }
 
 extern "C" int mom_get_RT(mom_t *h, double *R_SFI, double *T_SFI) {

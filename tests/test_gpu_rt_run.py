@@ -493,3 +493,42 @@ def test_float32_scene_level_path(rtamd, cref, nS, lt, kw):
     np.testing.assert_allclose(up[0], upr[0], rtol=tol)
     print(f"float32 vs oracle: max |dR|/I = {eR:.2e}, max |dT|/I = {eT:.2e}, nd max {int(sc.ndoubl.max())}")
     assert not np.array_equal(R, Rr)  # it really is a different precision
+
+
+@pytest.mark.parametrize("nS,lt,Nz,kw", [(3, 9, 6, {}), (1, 5, 5, {}), (4, 7, 5, dict(generic=True)), (3, 33, 6, {}),
+                                          (3, 27, 5, dict(brdf="rpv")), (3, 9, 5, dict(brdf="legendre")),
+                                          (4, 31, 4, {}), (3, 9, 5, dict(zero=(0, 1)))])
+def test_multisensor_sweep(rtamd, cref, nS, lt, Nz, kw):
+    """rt_run_test_ms (rt_run_multisensor.jl) -- sensors inside the atmosphere through
+    mom_rt_run_multisensor: the slabs above and below each sensor by the fused layer kernels (N = 60 strip chains, N = 51
+    padded to 52, N = 76 generic), k_interlayer (interlayer_flux.jl:7-24) and the azimuthal weighting, against the
+    oracle's rt_kernel_multisensor restatement; includes the level-0 (TOA/BOA) sensor, the lowest interface, BRDF and
+    Legendre surfaces and non-scattering top layers (interface codes 00/01)."""
+    m = rtamd.scenes.make_scene(nS, lt, Nz, 10, seed=17 + lt, aerosol_total=0.0 if "zero" in kw else 0.3,
+                                vaz=(10.0, 95.0, 170.0))
+    if kw.get("brdf"):
+        m.params.brdf = _surfaces(rtamd.corert)[kw["brdf"]]
+    for z in kw.get("zero", ()):
+        m.τ_rayl[:, z] = 0.0
+    sc = rtamd.prepare_scene(m)
+    levels = [0, 1, Nz // 2, Nz - 1]
+    uwr, dwr, info = cref.rt_run_multisensor(cref.pack_scene(helpers.oracle_scene(m)), levels)
+    assert info == 0
+    with rtamd.corert.make_handle(m) as h:
+        if kw.get("generic"):
+            h.set_option(rtamd._lib.MOM_OPT_FORCE_GENERIC, 1)
+        rtamd.corert.scene_set(h, sc)
+        uw, dw = h.rt_run_multisensor(levels)
+        R, T = rtamd.corert.run_scene(h, sc)       # the handle still runs the plain column afterwards
+    tol = helpers.stokes_rtol(sc.ndoubl)
+    for ims in range(len(levels)):
+        helpers.assert_stokes_close(uw[ims], uwr[ims], rtol=tol, what=f"uwJ level {levels[ims]}")
+        helpers.assert_stokes_close(dw[ims], dwr[ims], rtol=tol, what=f"dwJ level {levels[ims]}")
+    helpers.assert_stokes_close(uw[0], R, rtol=tol, what="level 0 vs mom_rt_run R")
+    helpers.assert_stokes_close(dw[0], T, rtol=tol, what="level 0 vs mom_rt_run T")
+    out = rtamd.rt_run_test_ms(levels, m)
+    assert len(out) == 4 and len(out[0]) == len(levels) and np.array_equal(out[0][2], uw[2])
+    with pytest.raises(rtamd.MomError):
+        with rtamd.corert.make_handle(m) as h:
+            rtamd.corert.scene_set(h, sc)
+            h.rt_run_multisensor([Nz])

@@ -151,3 +151,39 @@ def test_surface_types_twin_vs_c(rtamd, cref, brdf):
         np.testing.assert_allclose(rt._abi_mats(Rs), p.Rsurf, rtol=0, atol=1e-13)
     if alb is not None:
         np.testing.assert_allclose(alb, p.albedo_spec, rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("nS,kw", [(1, {}), (3, {}), (4, dict(brdf="rpv")), (3, dict(brdf="legendre"))])
+def test_multisensor_twin_vs_c_and_adding_identities(rtamd, cref, nS, kw):
+    """rt_run_test_ms (rt_run_multisensor.jl:14-191): the C oracle against the numpy twin, and the twin against the
+    standard run through the adding equations themselves -- for a sensor below layer L the TOA field is the top slab's own
+    source plus the interface upwelling transmitted through it, J0-(TOA) = topJ0- + topT-- tuwJ, and the BOA field
+    J0+(BOA) = botJ0+ + botT++ tdwJ (interaction.jl:87-90,107-110 with the inverses of interlayer_flux.jl:14-23)."""
+    m = rtamd.scenes.make_scene(nS, 5, 5, 6, seed=13, aerosol_total=0.4, vaz=(20.0, 70.0, 140.0))
+    if kw.get("brdf") == "rpv":
+        m.params.brdf = rtamd.corert.rpvSurfaceScalar(0.1, 0.8, 0.7, -0.1)
+    elif kw.get("brdf") == "legendre":
+        m.params.brdf = rtamd.corert.LambertianSurfaceLegendre((0.2, 0.05, -0.02))
+    sc = helpers.oracle_scene(m)
+    levels = [0, 1, 3, 4]
+    total = {}
+    mr.rt_run(sc, hook=lambda what, mm, iz, added, comp: total.__setitem__(mm, (comp.J0p.copy(), comp.J0m.copy()))
+              if what == "surface" else None)
+
+    def check(mm, ims, top, bot, tdw, tuw):
+        if levels[ims] == 0:
+            return
+        J0p, J0m = total[mm]
+        np.testing.assert_allclose(top.J0m + mr._mv(top.T_mm, tuw), J0m, rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(bot.J0p + mr._mv(bot.T_pp, tdw), J0p, rtol=1e-9, atol=1e-13)
+
+    uw, dw = mr.rt_run_multisensor(sc, levels, hook=check)
+    R, T = mr.rt_run(sc)
+    np.testing.assert_allclose(uw[0], R, rtol=1e-12, atol=1e-15)   # level 0 = the TOA/BOA pair of rt_run
+    np.testing.assert_allclose(dw[0], T, rtol=1e-12, atol=1e-15)
+    uwc, dwc, info = cref.rt_run_multisensor(cref.pack_scene(sc), levels)
+    assert info == 0
+    for ims in range(len(levels)):
+        helpers.assert_stokes_close(uwc[ims], uw[ims], rtol=1e-10, what=f"uwJ sensor {ims}")
+        helpers.assert_stokes_close(dwc[ims], dw[ims], rtol=1e-10, what=f"dwJ sensor {ims}")
+    assert np.abs(uw[2] - uw[0]).max() > 1e-4   # the sensors see different fields
