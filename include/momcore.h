@@ -111,6 +111,14 @@ int mom_surface_lambertian(mom_t *h, int m, double albedo, const double *tau_tot
 int mom_batch_inv(mom_t *h, int n, int batch, const double *A, double *X);
 /* A ⊠ B = batched_mul(A, B) -- gpu_batched.jl:90-97. */
 int mom_batched_mul(mom_t *h, int n, int batch, const double *A, const double *B, double *C);
+/* The ForwardDiff.Dual methods of the same two operators (gpu_batched.jl:100-150), values and partials as separate
+ * arrays: values [n,n,batch], partials [n,n,batch,P] (one [n,n,batch] block per partial i = ForwardDiff.partials.(A, i)).
+ *   batched_mul:  C = A ⊠ B,   dC_i = A ⊠ dB_i + dA_i ⊠ B            (gpu_batched.jl:100-110)
+ *   batch_inv!:   X = A⁻¹,     dX_i = -A⁻¹ ⊠ dA_i ⊠ A⁻¹              (gpu_batched.jl:129-150)
+ * P = 0 reduces to the plain operators (dA/dB/dC may be NULL then). */
+int mom_batched_mul_dual(mom_t *h, int n, int batch, int P, const double *A, const double *dA, const double *B,
+                         const double *dB, double *C, double *dC);
+int mom_batch_inv_dual(mom_t *h, int n, int batch, int P, const double *A, const double *dA, double *X, double *dX);
 
 /* Array(composite_layer.J₀⁻) etc. (postprocessing_vza.jl:17-20) / test access.
  * Operator-level state lives in moment slot 0 of the handle; the added and surface layers are allocated on the

@@ -703,6 +703,18 @@ def batch_inv(A: np.ndarray) -> np.ndarray:
     return np.linalg.inv(A)
 
 
+def batched_mul_dual(A, dA, B, dB):
+    """batched_mul on ForwardDiff.Dual arrays (gpu_batched.jl:100-110): values [S,N,N], partials [P,S,N,N].
+    C = A B, dC_i = A dB_i + dA_i B."""
+    return A @ B, A[None] @ dB + dA @ B[None]
+
+
+def batch_inv_dual(A, dA):
+    """batch_inv! on ForwardDiff.Dual arrays (gpu_batched.jl:129-150): X = A^-1, dX_i = -A^-1 dA_i A^-1."""
+    X = batch_inv(A)
+    return X, -(X[None] @ dA) @ X[None]
+
+
 def doubling(pol: PolType, expk: np.ndarray, nd: int, added: AddedLayer, strict: bool = True,
              snapshots: Optional[list] = None):
     """doubling_helper! (doubling.jl:13-79) + apply_D! (:93-110) + apply_D_SFI! (:112-118).

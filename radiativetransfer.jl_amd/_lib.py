@@ -54,6 +54,8 @@ SIGNATURES = {
     "mom_surface_lambertian": (C.c_int, [c_h, C.c_int, C.c_double, c_dp]),
     "mom_batch_inv": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp]),
     "mom_batched_mul": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp, c_dp]),
+    "mom_batched_mul_dual": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "mom_batch_inv_dual": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp]),
     "mom_upload": (C.c_int, [c_h, C.c_int, c_dp]),
     "mom_download": (C.c_int, [c_h, C.c_int, c_dp]),
     "mom_scene_set": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip, c_dp,
@@ -214,6 +216,20 @@ class Handle:
         Cm = np.empty_like(A)
         self.check(self.lib.mom_batched_mul(self._h, n, batch, dp(A), dp(B), dp(Cm)))
         return Cm
+
+    def batch_inv_dual(self, n, batch, P, A, dA):
+        """Dual batch_inv! (gpu_batched.jl:129-150): flat ABI arrays, values n*n*batch, partials n*n*batch*P."""
+        A, dA = f64(A).reshape(-1), f64(dA).reshape(-1)
+        X, dX = np.empty_like(A), np.empty_like(dA)
+        self.check(self.lib.mom_batch_inv_dual(self._h, n, batch, P, dp(A), dp(dA), dp(X), dp(dX)))
+        return X, dX
+
+    def batched_mul_dual(self, n, batch, P, A, dA, B, dB):
+        """Dual batched_mul (gpu_batched.jl:100-110)."""
+        A, dA, B, dB = (f64(x).reshape(-1) for x in (A, dA, B, dB))
+        Cm, dC = np.empty_like(A), np.empty_like(dA)
+        self.check(self.lib.mom_batched_mul_dual(self._h, n, batch, P, dp(A), dp(dA), dp(B), dp(dB), dp(Cm), dp(dC)))
+        return Cm, dC
 
     def scene_set(self, Nz, K, M, tau, varpi, zw, Zpp, Zmp, nd, iface, tau_sum, albedo, node, cos_mphi, sin_mphi):
         d = [f64(x).reshape(-1) for x in (tau, varpi, zw, Zpp, Zmp)]

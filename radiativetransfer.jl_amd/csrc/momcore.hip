@@ -236,6 +236,80 @@ __global__ void __launch_bounds__(kThreads) k_batched_mul(BlasArgs a) {
   }
 }
 
+// batched_mul / batch_inv! on ForwardDiff.Dual arrays (gpu_batched.jl:100-150): values [N,N,S] and P partials [N,N,S,P].
+//   mul:  C = A B,      dC_i = A dB_i + dA_i B          inv:  X = A^-1,   dX_i = -X dA_i X
+// One workgroup per batch item keeps the values in LDS (slab) while it walks the partials.
+struct DualArgs {
+  int N, S, P;
+  const double *A, *dA, *B, *dB;
+  double *C, *dC;
+  double *scratch;
+  int *info;
+};
+
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads) k_batched_mul_dual(DualArgs a) {
+  const int N = a.N;
+  Ctx c;
+  make_ctx<LDSM>(c, N, 1, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
+  zero_padding<LDSM>(c);
+  __syncthreads();
+  const size_t NN = (size_t)N * N;
+  const int ld = c.ld;
+  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
+    wg_copy_mat(N, c.fd, a.A + NN * pt, N, c.P, ld);
+    wg_copy_mat(N, c.fd, a.B + NN * pt, N, c.Q, ld);
+    __syncthreads();
+    double *C = a.C + NN * pt;
+    wg_gemm<false, !LDSM>(N, ElP{c.P, ld}, ElP{c.Q, ld}, [=](int i, int j, double v) { C[i + (size_t)j * N] = v; });
+    for (int ip = 0; ip < a.P; ++ip) {
+      const size_t o = NN * (pt + (size_t)a.S * ip);
+      __syncthreads();
+      wg_copy_mat(N, c.fd, a.dB + o, N, c.r, ld);
+      wg_copy_mat(N, c.fd, a.dA + o, N, c.t, ld);
+      __syncthreads();
+      double *dC = a.dC + o;
+      wg_gemm<false, !LDSM>(N, ElP{c.P, ld}, ElP{c.r, ld}, [=](int i, int j, double v) { dC[i + (size_t)j * N] = v; });
+      __syncthreads();
+      wg_gemm<false, !LDSM>(N, ElP{c.t, ld}, ElP{c.Q, ld},
+                            [=](int i, int j, double v) { dC[i + (size_t)j * N] = dC[i + (size_t)j * N] + v; });
+    }
+    __syncthreads();
+  }
+}
+
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads) k_batch_inv_dual(DualArgs a) {
+  const int N = a.N;
+  Ctx c;
+  make_ctx<LDSM>(c, N, 1, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
+  zero_padding<LDSM>(c);
+  if (threadIdx.x == 0) *c.bad = 0;
+  __syncthreads();
+  const size_t NN = (size_t)N * N;
+  const int ld = c.ld;
+  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
+    wg_copy_mat(N, c.fd, a.A + NN * pt, N, c.P, ld);
+    __syncthreads();
+    if (N <= 64) wg_inverse_reg(N, c.P, ld, c.part, c.prow, c.ipiv, c.bad);
+    else wg_inverse(N, c.fd, c.P, ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);
+    wg_copy_mat(N, c.fd, c.P, ld, a.C + NN * pt, N);
+    for (int ip = 0; ip < a.P; ++ip) {
+      const size_t o = NN * (pt + (size_t)a.S * ip);
+      __syncthreads();
+      wg_copy_mat(N, c.fd, a.dA + o, N, c.Q, ld);
+      __syncthreads();
+      double *r = c.r;
+      wg_gemm<false, !LDSM>(N, ElP{c.P, ld}, ElP{c.Q, ld}, [=](int i, int j, double v) { r[i + j * ld] = v; });
+      __syncthreads();
+      double *dX = a.dC + o;
+      wg_gemm<false, !LDSM>(N, ElP{c.r, ld}, ElP{c.P, ld}, [=](int i, int j, double v) { dX[i + (size_t)j * N] = -v; });
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
+}
+
 // =========================================================================================
 // host side
 // =========================================================================================
@@ -819,6 +893,57 @@ extern "C" int mom_batch_inv(mom_t *h, int n, int batch, const double *A, double
 }
 extern "C" int mom_batched_mul(mom_t *h, int n, int batch, const double *A, const double *B, double *C) {
   return blas_common(h, n, batch, A, B, C, false);
+}
+
+static int dual_common(mom_t *h, int n, int batch, int P, const double *A, const double *dA, const double *B,
+                       const double *dB, double *C, double *dC, bool inv) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_batch_inv_dual / mom_batched_mul_dual");
+  if (n <= 0 || batch <= 0 || P < 0 || !A || !C || (P > 0 && (!dA || !dC)) || (!inv && (!B || (P > 0 && !dB))))
+    return fail(h, MOM_EINVAL, "batched dual op: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t cnt = (size_t)n * n * batch, cntP = cnt * P;
+  double *buf = nullptr, *scr = nullptr;
+  // one allocation: A, B, C [cnt] and dA, dB, dC [cntP]
+  HIPCHK(h, dmalloc(&buf, 3 * cnt + 3 * cntP + 1));
+  double *dA_ = buf + 3 * cnt, *dB_ = dA_ + cntP, *dC_ = dB_ + cntP;
+  HIPCHK(h, hipMemcpyAsync(buf, A, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (P) HIPCHK(h, hipMemcpyAsync(dA_, dA, cntP * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (!inv) {
+    HIPCHK(h, hipMemcpyAsync(buf + cnt, B, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (P) HIPCHK(h, hipMemcpyAsync(dB_, dB, cntP * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  const bool lds = n <= 64 && !h->opt_force_generic;
+  const int grid = lds ? batch : std::min(batch, 1024);
+  if (!lds) {
+    const size_t scn = (size_t)grid * kGenericBufs * mat_elems(n) + (size_t)ld_for(n) * np_for(n);
+    HIPCHK(h, dmalloc(&scr, scn));
+    HIPCHK(h, hipMemsetAsync(scr, 0, scn * sizeof(double), h->stream));
+  }
+  DualArgs a{n, batch, P, buf, dA_, buf + cnt, dB_, buf + 2 * cnt, dC_, scr, h->d_info};
+  const size_t sm = lds_bytes(n, lds);
+  if (inv) {
+    if (lds) { HIPCHK(h, allow_lds(k_batch_inv_dual<true>, sm)); hipLaunchKernelGGL(k_batch_inv_dual<true>, dim3(grid), dim3(kThreads), sm, h->stream, a); }
+    else { HIPCHK(h, allow_lds(k_batch_inv_dual<false>, sm)); hipLaunchKernelGGL(k_batch_inv_dual<false>, dim3(grid), dim3(kThreads), sm, h->stream, a); }
+  } else {
+    if (lds) { HIPCHK(h, allow_lds(k_batched_mul_dual<true>, sm)); hipLaunchKernelGGL(k_batched_mul_dual<true>, dim3(grid), dim3(kThreads), sm, h->stream, a); }
+    else { HIPCHK(h, allow_lds(k_batched_mul_dual<false>, sm)); hipLaunchKernelGGL(k_batched_mul_dual<false>, dim3(grid), dim3(kThreads), sm, h->stream, a); }
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(C, buf + 2 * cnt, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (P) HIPCHK(h, hipMemcpyAsync(dC, dC_, cntP * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  (void)hipFree(buf);
+  if (scr) (void)hipFree(scr);
+  return inv ? check_info(h) : MOM_OK;
+}
+
+extern "C" int mom_batch_inv_dual(mom_t *h, int n, int batch, int P, const double *A, const double *dA, double *X, double *dX) {
+  return dual_common(h, n, batch, P, A, dA, nullptr, nullptr, X, dX, true);
+}
+extern "C" int mom_batched_mul_dual(mom_t *h, int n, int batch, int P, const double *A, const double *dA, const double *B,
+                                    const double *dB, double *C, double *dC) {
+  return dual_common(h, n, batch, P, A, dA, B, dB, C, dC, false);
 }
 
 // ---------------------------------------------------------------- scene-level

@@ -153,6 +153,28 @@ def test_batch_inv_and_mul(rtamd, cref, n, batch):
         helpers.assert_op_close(Cg, cref.batched_mul(n, batch, mr.to_abi(A), mr.to_abi(B)), rtol=1e-13, what="⊠")
 
 
+@pytest.mark.parametrize("n,batch,P", [(32, 50, 3), (60, 16, 2), (7, 33, 1), (100, 4, 2), (16, 8, 0)])
+def test_dual_batch_inv_and_mul(rtamd, n, batch, P):
+    """The ForwardDiff.Dual methods of batch_inv! and batched_mul (gpu_batched.jl:100-150) through
+    mom_batch_inv_dual / mom_batched_mul_dual against the numpy restatement (itself pinned by finite differences in
+    tests/test_oracle_twin.py)."""
+    rng = np.random.default_rng(n + P)
+    A = rng.normal(size=(batch, n, n)) + 3 * np.eye(n)
+    B = rng.normal(size=(batch, n, n))
+    dA, dB = rng.normal(size=(P, batch, n, n)), rng.normal(size=(P, batch, n, n))
+    abi = lambda M: mr.to_abi(M.reshape(-1, n, n)) if M.size else np.zeros(0)
+    Cr, dCr = mr.batched_mul_dual(A, dA, B, dB)
+    Xr, dXr = mr.batch_inv_dual(A, dA)
+    with rtamd.Handle(4, 1, 1, 1) as h:
+        Cg, dCg = h.batched_mul_dual(n, batch, P, abi(A), abi(dA), abi(B), abi(dB))
+        Xg, dXg = h.batch_inv_dual(n, batch, P, abi(A), abi(dA))
+    helpers.assert_op_close(Cg, abi(Cr), rtol=1e-13, what="C")
+    helpers.assert_op_close(Xg, abi(Xr), rtol=1e-11, what="X")
+    if P:
+        helpers.assert_op_close(dCg, abi(dCr), rtol=1e-13, what="dC")
+        helpers.assert_op_close(dXg, abi(dXr), rtol=1e-10, what="dX")
+
+
 def test_singular_operator_is_reported(rtamd):
     """The reference ignores cuBLAS `info` (gpu_batched.jl:65-70); here a zero pivot surfaces as MOM_ESINGULAR."""
     n, batch = 12, 4

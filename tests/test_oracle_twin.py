@@ -187,3 +187,23 @@ def test_multisensor_twin_vs_c_and_adding_identities(rtamd, cref, nS, kw):
         helpers.assert_stokes_close(uwc[ims], uw[ims], rtol=1e-10, what=f"uwJ sensor {ims}")
         helpers.assert_stokes_close(dwc[ims], dw[ims], rtol=1e-10, what=f"dwJ sensor {ims}")
     assert np.abs(uw[2] - uw[0]).max() > 1e-4   # the sensors see different fields
+
+
+def test_dual_operators_against_finite_differences():
+    """gpu_batched.jl:100-150: the Dual rules of the two batched operators, pinned by central differences of the plain
+    operators along a random direction."""
+    rng = np.random.default_rng(5)
+    S, N, P = 3, 6, 2
+    A = rng.normal(size=(S, N, N)) + 3 * np.eye(N)
+    B = rng.normal(size=(S, N, N))
+    dA, dB = rng.normal(size=(P, S, N, N)), rng.normal(size=(P, S, N, N))
+    C, dC = mr.batched_mul_dual(A, dA, B, dB)
+    X, dX = mr.batch_inv_dual(A, dA)
+    np.testing.assert_allclose(C, A @ B)
+    np.testing.assert_allclose(X @ A, np.broadcast_to(np.eye(N), A.shape), atol=1e-12)
+    eps = 1e-6
+    for i in range(P):
+        fdC = ((A + eps * dA[i]) @ (B + eps * dB[i]) - (A - eps * dA[i]) @ (B - eps * dB[i])) / (2 * eps)
+        fdX = (mr.batch_inv(A + eps * dA[i]) - mr.batch_inv(A - eps * dA[i])) / (2 * eps)
+        np.testing.assert_allclose(dC[i], fdC, rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(dX[i], fdX, rtol=1e-6, atol=1e-8)
