@@ -1,58 +1,103 @@
-// mom_wave.hip -- operators of edge 4 < N <= 16: ONE SPECTRAL POINT PER WAVEFRONT, all operators in registers, every
-// product on the FP64 matrix cores without touching LDS.
+// mom_wave.hip -- operators of edge 4 < N <= 32: ONE SPECTRAL POINT PER WAVEFRONT, all operators in registers, every
+// product on the FP64 matrix cores, no barrier.
 //
 // A 16 x 16 tile in the C/D layout of v_mfma_f64_16x16x4_f64 (lane l, register r: row (l >> 4) + 4 r, column l & 15) is
 // four doubles per lane.  Feeding two such tiles U, V to the four k-steps of one 16 x 16 x 16 product -- register s of U
 // as the A operand, register s of V as the B operand -- gives
 //        TN(U, V) = U^T V        in the same layout,
 // because the A operand is read as A[row = l & 15][k = l >> 4]: a tile in C-layout IS the A operand of its transpose
-// (mom_strip.hpp uses the B-operand half of this observation).  So a wave that keeps, for every operator X it needs as a
-// LEFT factor, the tile of X^T ("t-form") next to or instead of the tile of X ("c-form"), runs the whole adding
-// algorithm as a sequence of 4-MFMA products on registers: X Y = TN(X_t, Y_c), (X Y)^T = TN(Y_c, X_t).  The elemental
-// layer is evaluated directly in both forms (element (i,j) and (j,i) share their exponentials), the doubling recursion
-// and the interaction are closed under TN with the forms listed at the functions below, source vectors travel as
-// columns 0 (J+) and 1 (J-) of a tile.  No LDS, no barrier: LDS only serves the rare pivoted inverse (series too long)
-// and the final gather of the view rows.  A lane-per-point layout (mom_small.hip) stops at N = 4, the workgroup-per-
-// point kernels (mom_kernels.hpp) use 1/16 ... 1/4 of their tiles and a whole CU per 2 units at these sizes.
+// (mom_strip.hpp uses the B-operand half of this observation).  An operator of edge N <= 16 NT is NT x NT such tiles; a
+// product X Y is TN(X^T, Y), and X^T is one pass of the tiles through a wave-private LDS slice (4 ds_write + 4 ds_read
+// per tile, about a sixth of a product at NT = 2).  So a wave runs the whole adding algorithm -- elemental, doublings,
+// interaction, surface, post-processing, for all Fourier moments and layers of its spectral point -- as a sequence of
+// register products with the reference's own operation count (doubling step: r r, the series, t G, r t, A (r t), A t;
+// interaction: 10 products + 2 inverses), the source vectors travelling as columns 0 (J+) and 1 (J-) of a tile column.
+// LDS only serves the transposes, the rare pivoted inverse (series too long) and the final gather of the view rows.
+// A lane-per-point layout (mom_small.hip) stops at N = 4; the workgroup-per-unit kernels (mom_kernels.hpp) are
+// barrier-bound below N ~ 32 (a 32^3 product is 0.2 us of MFMA per wave) and use a fraction of their tiles.
 //
-// One wave walks all Fourier moments and layers of its spectral point (like momsm::k_sweep), two waves per SIMD.
+// NT = 1 (N <= 16): two waves per SIMD; NT = 2 (N <= 32): one wave per SIMD (about 400 VGPRs).  k-steps are templated
+// on KS = ceil(N / 4): rows >= 4 KS of every tile are zero padding and are skipped.
 // Scope: ScatteringInterface_11 on every layer after the first (the host falls back to the general kernels otherwise),
 // LambertianSurfaceScalar, Float64.  Reference semantics and file:line as in mom_kernels.hpp / mom_small.hip.
 #include <hip/hip_runtime.h>
 
 #include "mom_host.hpp"
 
-#ifndef MOMW_OCC
-#define MOMW_OCC 2  // waves per SIMD the kernel is built for
-#endif
-
 namespace momw {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-// KS = ceil(N / 4) k-steps: rows >= 4 KS of every tile are zero padding
+template <int NT>
+struct Mat {
+  d4 t[NT][NT];  // t[bi][bj]: rows 16 bi .., columns 16 bj ..
+};
+template <int NT>
+struct Vec {
+  d4 t[NT];  // row block bi; column 0 = the "+" vector, column 1 = the "-" vector (lanes l & 15 == 0 / 1)
+};
+
+// k-steps of row block tk
 template <int KS>
-__device__ __forceinline__ d4 TN(d4 U, d4 V) {  // U^T V
-  d4 acc = {0.0, 0.0, 0.0, 0.0};
+__device__ __forceinline__ constexpr int ksteps(int tk) { return (KS - 4 * tk) >= 4 ? 4 : ((KS - 4 * tk) > 0 ? (KS - 4 * tk) : 0); }
+
+template <int NT, int KS>
+__device__ __forceinline__ Mat<NT> TNacc(const Mat<NT> &U, const Mat<NT> &V, Mat<NT> acc) {  // acc + U^T V
 #pragma unroll
-  for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[s], V[s], acc, 0, 0, 0);
+  for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < ksteps<KS>(tk)) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < NT; ++tj)
+            acc.t[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(U.t[tk][ti][s], V.t[tk][tj][s], acc.t[ti][tj], 0, 0, 0);
+      }
   return acc;
 }
-template <int KS>
-__device__ __forceinline__ d4 TNacc(d4 U, d4 V, d4 acc) {  // acc + U^T V
+template <int NT>
+__device__ __forceinline__ Mat<NT> zeros() {
+  Mat<NT> Z;
 #pragma unroll
-  for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(U[s], V[s], acc, 0, 0, 0);
-  return acc;
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) Z.t[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  return Z;
 }
+template <int NT, int KS>
+__device__ __forceinline__ Mat<NT> TN(const Mat<NT> &U, const Mat<NT> &V) {
+  return TNacc<NT, KS>(U, V, zeros<NT>());
+}
+template <int NT, int KS>
+__device__ __forceinline__ Vec<NT> TNv(const Mat<NT> &U, const Vec<NT> &v) {  // U^T v
+  Vec<NT> o;
+#pragma unroll
+  for (int ti = 0; ti < NT; ++ti) o.t[ti] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < ksteps<KS>(tk)) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+          o.t[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(U.t[tk][ti][s], v.t[tk][s], o.t[ti], 0, 0, 0);
+      }
+  return o;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
 }
-__device__ __forceinline__ d4 shfl_xor1(d4 v) {  // exchange columns 0 <-> 1 (2 <-> 3, ...)
-  d4 o;
+template <int NT>
+__device__ __forceinline__ Vec<NT> swap01(const Vec<NT> &v) {  // exchange columns 0 <-> 1
+  Vec<NT> o;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = __shfl_xor(v[r], 1);
+  for (int b = 0; b < NT; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o.t[b][r] = __shfl_xor(v.t[b][r], 1);
   return o;
 }
 
@@ -89,48 +134,105 @@ struct WArgs {
   int *info;
 };
 
-// per-lane constants of the tile layout; the row quantities (row = lq + 4 r) are read from the block's LDS table
-// tab = mu[16] | wt[16] | sg[16] (padding rows: mu = 1, wt = 0, sg = 1) when needed instead of living in 24 VGPRs
+// per-lane coordinates; row / column quantities are read from the block's LDS table tab = mu[32] | wt[32] | sg[32]
+// (padding entries: mu = 1, wt = 0, sg = 1)
 struct Lay {
   int lr, lq, N, nS;
-  bool cok;                // column < N
-  double muc, wc, sgc;     // column quantities (column = lr)
   const double *tab;
-  __device__ __forceinline__ bool rok(int r) const { return lq + 4 * r < N; }
-  __device__ __forceinline__ double mur(int r) const { return tab[lq + 4 * r]; }
-  __device__ __forceinline__ double wr(int r) const { return tab[16 + lq + 4 * r]; }
-  __device__ __forceinline__ double sgr(int r) const { return tab[32 + lq + 4 * r]; }
+  double *xp;  // wave-private LDS slice: transposes / pivoted inverse / output gather
+  int *ipiv;
+  __device__ __forceinline__ int row(int bi, int r) const { return 16 * bi + lq + 4 * r; }
+  __device__ __forceinline__ int col(int bj) const { return 16 * bj + lr; }
+  __device__ __forceinline__ double mu(int i) const { return tab[i]; }
+  __device__ __forceinline__ double wt(int i) const { return tab[32 + i]; }
+  __device__ __forceinline__ double sg(int i) const { return tab[64 + i]; }
 };
-__device__ __forceinline__ d4 ident(const Lay &L) {
-  d4 I;
+
+template <int NT>
+__device__ __forceinline__ Mat<NT> ident(const Lay &L) {
+  Mat<NT> I;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) I[r] = (L.lq + 4 * r == L.lr && L.cok) ? 1.0 : 0.0;
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) I.t[a][b][r] = (a == b && L.lq + 4 * r == L.lr && L.col(b) < L.N) ? 1.0 : 0.0;
   return I;
 }
-__device__ __forceinline__ d4 scaleD(const Lay &L, d4 X) {  // D X D, D = Diagonal(sg)
-  d4 Y;
+template <int NT>
+__device__ __forceinline__ Mat<NT> add(const Mat<NT> &A, const Mat<NT> &B) {
+  Mat<NT> C;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) Y[r] = (L.sgr(r) * L.sgc) * X[r];
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) C.t[a][b] = A.t[a][b] + B.t[a][b];
+  return C;
+}
+template <int NT>
+__device__ __forceinline__ Mat<NT> scaleD(const Lay &L, const Mat<NT> &X) {  // D X D, D = Diagonal(sg)
+  Mat<NT> Y;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Y.t[a][b][r] = (L.sg(L.row(a, r)) * L.sg(L.col(b))) * X.t[a][b][r];
   return Y;
 }
 
-// (I - B)^-1 for the tile pair (B in c-form Bc, B^T in c-form Bt): Horner G <- I + B G = I + TN(Bt, G); beyond 32
-// terms (or MOM_OPT_INVERSE = 1) Gauss-Jordan with implicit partial pivoting in a row-per-lane layout through the
-// wave's LDS slice (the register-resident scheme of wg_inverse_reg, mom_device.hpp, for a single wave).
-__device__ __noinline__ d4 inverse_gj(d4 Bc, d4 Ic, int N, double *lds, int *ipiv, int *bad_out) {
+constexpr int kTileLd = 17;                   // pitch of a 16 x 16 tile in the LDS slice
+constexpr int kTileDoubles = 16 * kTileLd;    // 272
+template <int NT>
+constexpr int slice_doubles() {
+  return (NT * NT * kTileDoubles > (16 * NT) * (16 * NT + 1) ? NT * NT * kTileDoubles : (16 * NT) * (16 * NT + 1)) + 3 * 16 * NT;
+}
+
+// X^T through the wave's LDS slice: tile (a, b) of the result is the transpose of tile (b, a)
+template <int NT>
+__device__ __forceinline__ Mat<NT> transpose(const Lay &L, const Mat<NT> &X) {
+  double *buf = L.xp;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) buf[(a * NT + b) * kTileDoubles + (L.lq + 4 * r) * kTileLd + L.lr] = X.t[a][b][r];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  Mat<NT> Y;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Y.t[a][b][r] = buf[(b * NT + a) * kTileDoubles + L.lr * kTileLd + L.lq + 4 * r];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  return Y;
+}
+
+// (I - B)^-1 by Gauss-Jordan elimination with implicit partial pivoting, one matrix row per lane through the wave's LDS
+// slice (the register-resident scheme of wg_inverse_reg, mom_device.hpp, for a single wave)
+template <int NT>
+__device__ __noinline__ Mat<NT> inverse_gj(Mat<NT> B, int N, double *lds, int *ipiv, int *bad_out) {
+  constexpr int NP = 16 * NT, LDM = NP + 1;
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   int bad = 0;
-  // A = I - B, row-major with pitch 17 in the wave's LDS slice
 #pragma unroll
-  for (int r = 0; r < 4; ++r) lds[(lq + 4 * r) * 17 + lr] = Ic[r] - Bc[r];
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * a + lq + 4 * r, j = 16 * b + lr;
+        lds[i * LDM + j] = ((i == j) ? 1.0 : 0.0) - B.t[a][b][r];
+      }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  double v[16];
+  double v[NP];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) v[c] = (lane < N && c < N) ? lds[lane * 17 + c] : ((lane < 16 && lane == c) ? 1.0 : 0.0);
+  for (int c = 0; c < NP; ++c) v[c] = (lane < N && c < N) ? lds[lane * LDM + c] : ((lane == c) ? 1.0 : 0.0);
   bool used = false;
   int myk = lane;  // rows >= N keep their identity row
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < NP; ++k) {
     if (k < N) {
       const int ah = (!used && lane < N) ? __double2hiint(fabs(v[k])) : -1;
       int mh = ah;
@@ -143,7 +245,7 @@ __device__ __noinline__ d4 inverse_gj(d4 Bc, d4 Ic, int N, double *lds, int *ipi
       const double d = 1.0 / piv, f = v[k];
       const bool isp = (lane == pl);
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
+      for (int c = 0; c < NP; ++c) {
         const double prow = __shfl(v[c], pl) * d;
         v[c] = isp ? prow : (v[c] - f * prow);
       }
@@ -156,115 +258,133 @@ __device__ __noinline__ d4 inverse_gj(d4 Bc, d4 Ic, int N, double *lds, int *ipi
   // inv(A)[k][p_j] = S[p_k][j]: lane (row p_k, pivot of step myk) writes row myk with permuted columns
   if (lane < N) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-      if (c < N) lds[myk * 17 + ipiv[c]] = v[c];
+    for (int c = 0; c < NP; ++c)
+      if (c < N) lds[myk * LDM + ipiv[c]] = v[c];
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  d4 G;
+  Mat<NT> G;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) G[r] = (lq + 4 * r < N && lr < N) ? lds[(lq + 4 * r) * 17 + lr] : 0.0;
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * a + lq + 4 * r, j = 16 * b + lr;
+        G.t[a][b][r] = (i < N && j < N) ? lds[i * LDM + j] : 0.0;
+      }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (bad) *bad_out = bad;
   return G;
 }
 
-template <int KS>
-__device__ __forceinline__ d4 inv_one_minus(const Lay &L, d4 Bc, d4 Bt, int inv_mode, double *lds, int *ipiv, int &bad) {
+// (I - B)^-1: truncated Neumann series by Horner, G <- I + B G = I + TN(B^T, G); beyond 32 terms (or MOM_OPT_INVERSE = 1)
+// the pivoted inverse
+template <int NT, int KS>
+__device__ __forceinline__ Mat<NT> inv_one_minus(const Lay &L, const Mat<NT> &B, int inv_mode, int &bad) {
   double ss = 0.0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) ss += Bc[r] * Bc[r];
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ss += B.t[a][b][r] * B.t[a][b][r];
   const double beta2 = wave_sum(ss);
   const int p = (inv_mode == 1) ? 1000 : series_terms(beta2);
-  const d4 Ic = ident(L);
+  const Mat<NT> I = ident<NT>(L);
   if (p <= 32) {
-    d4 G = Ic;
-    for (int k = 1; k < p; ++k) G = TNacc<KS>(Bt, G, Ic);
+    if (p == 1) return I;
+    Mat<NT> G = add<NT>(I, B);
+    if (p > 2) {
+      const Mat<NT> Bt = transpose<NT>(L, B);
+      for (int k = 2; k < p; ++k) G = TNacc<NT, KS>(Bt, G, I);
+    }
     return G;
   }
   int b = 0;
-  const d4 G = inverse_gj(Bc, Ic, L.N, lds, ipiv, &b);
+  const Mat<NT> G = inverse_gj<NT>(B, L.N, L.xp, L.ipiv, &b);
   if (b && !bad) bad = b;
   return G;
 }
 
-// ScatteringInterface_11 (interaction.jl:69-117) on tiles.  Added layer: r-+ (rc, rt), t++ (tc, tt), sources jv (column 0
-// j0+, column 1 j0-); r+- = D r-+ D and t-- = D t++ D are formed where they are used (SURF: the surface layer has
-// r+- = 0, t = I).  Composite state kept in exactly the forms the next interaction consumes: R-+ (c), R+- (c and t),
-// T++ (c), T-- (t), Jv (column 0 J0+, column 1 J0-).
+// composite state in natural (c-) form; Jv: column 0 J0+, column 1 J0-
+template <int NT>
 struct Comp {
-  d4 Rmp_c, Rpm_c, Rpm_t, Tpp_c, Tmm_t, Jv;
+  Mat<NT> Rmp, Rpm, Tpp, Tmm;
+  Vec<NT> Jv;
 };
-template <int KS, bool SURF>
-__device__ __forceinline__ void interact11(const Lay &L, Comp &C, d4 rc, d4 rt, d4 tc, d4 tt, d4 jv, int inv_mode,
-                                           double *lds, int *ipiv, int &bad) {
+
+// ScatteringInterface_11 (interaction.jl:69-117).  Added layer: r-+ (r), t++ (t), sources jv; r+- = D r-+ D and
+// t-- = D t++ D are formed where they are used (SURF: the surface layer has r+- = 0, t = I).  Returns r^T (the surface
+// caller needs it for interaction_hdrf!).
+template <int NT, int KS, bool SURF>
+__device__ __forceinline__ Mat<NT> interact11(const Lay &L, Comp<NT> &C, const Mat<NT> &r, const Mat<NT> &t, const Vec<NT> &jv,
+                                              int inv_mode, int &bad) {
+  const Mat<NT> rT = transpose<NT>(L, r);
   // --- T01 = T-- (I - r-+ R+-)^-1                                                   (:81-87)
-  const d4 B1 = TN<KS>(rt, C.Rpm_c), B1t = TN<KS>(C.Rpm_c, rt);
-  const d4 G1 = inv_one_minus<KS>(L, B1, B1t, inv_mode, lds, ipiv, bad);
-  const d4 T01t = TN<KS>(G1, C.Tmm_t);  // (T-- G1)^T = G1^T T--^T
+  const Mat<NT> G1 = inv_one_minus<NT, KS>(L, TN<NT, KS>(rT, C.Rpm), inv_mode, bad);
+  const Mat<NT> T01t = TN<NT, KS>(G1, transpose<NT>(L, C.Tmm));  // (T-- G1)^T = G1^T T--^T
   // J0- = J0- + T01 (r-+ J0+ + j0-)                                                  (:90)  [old J0+]
-  const d4 V1 = TN<KS>(rt, C.Jv);       // column 0: r-+ J0+
-  const d4 jsw = shfl_xor1(jv);         // column 0: j0-
-  d4 X1;
+  const Vec<NT> V1 = TNv<NT, KS>(rT, C.Jv);  // column 0: r-+ J0+
+  const Vec<NT> jsw = swap01<NT>(jv);        // column 0: j0-
+  Vec<NT> X1;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) X1[r] = (L.lr == 0) ? V1[r] + jsw[r] : 0.0;
-  const d4 TX1 = TN<KS>(T01t, X1);      // column 0: T01 (...)
-  const d4 TX1s = shfl_xor1(TX1);
+  for (int b = 0; b < NT; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) X1.t[b][q] = (L.lr == 0) ? V1.t[b][q] + jsw.t[b][q] : 0.0;
+  const Vec<NT> TX1s = swap01<NT>(TNv<NT, KS>(T01t, X1));  // column 1: T01 (...)
   // R-+ = R-+ + T01 r-+ T++                                                          (:93)
-  const d4 rT = TN<KS>(rt, C.Tpp_c);
-  C.Rmp_c = TNacc<KS>(T01t, rT, C.Rmp_c);
-  // T-- = T01 t--   (kept transposed: t--^T T01^T)                                   (:96)
-  C.Tmm_t = SURF ? T01t : TN<KS>(scaleD(L, tc), T01t);
+  C.Rmp = TNacc<NT, KS>(T01t, TN<NT, KS>(rT, C.Tpp), C.Rmp);
+  // T-- = T01 t--                                                                    (:96)
+  const Mat<NT> tmm = SURF ? ident<NT>(L) : scaleD<NT>(L, t);
+  C.Tmm = TN<NT, KS>(T01t, tmm);
   // --- T21 = t++ (I - R+- r-+)^-1                                                   (:104-107)  [old R+-]
-  const d4 B2 = TN<KS>(C.Rpm_t, rc), B2t = TN<KS>(rc, C.Rpm_t);
-  const d4 G2 = inv_one_minus<KS>(L, B2, B2t, inv_mode, lds, ipiv, bad);
-  const d4 T21t = SURF ? TN<KS>(G2, ident(L)) : TN<KS>(G2, tt);
+  const Mat<NT> RpmT = transpose<NT>(L, C.Rpm);
+  const Mat<NT> G2 = inv_one_minus<NT, KS>(L, TN<NT, KS>(RpmT, r), inv_mode, bad);
+  const Mat<NT> T21t = TN<NT, KS>(G2, SURF ? ident<NT>(L) : transpose<NT>(L, t));
   // J0+ = j0+ + T21 (J0+ + R+- j0-)                                                  (:110)
-  const d4 V2 = TN<KS>(C.Rpm_t, jv);    // column 1: R+- j0-
-  const d4 V2s = shfl_xor1(V2);
-  d4 X2;
+  const Vec<NT> V2s = swap01<NT>(TNv<NT, KS>(RpmT, jv));  // column 0: R+- j0-
+  Vec<NT> X2;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) X2[r] = (L.lr == 0) ? C.Jv[r] + V2s[r] : 0.0;
-  const d4 TX2 = TN<KS>(T21t, X2);      // column 0: T21 (...)
+  for (int b = 0; b < NT; ++b)
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
-    C.Jv[r] = (L.lr == 0) ? jv[r] + TX2[r] : ((L.lr == 1) ? C.Jv[r] + TX1s[r] : 0.0);
+    for (int q = 0; q < 4; ++q) X2.t[b][q] = (L.lr == 0) ? C.Jv.t[b][q] + V2s.t[b][q] : 0.0;
+  const Vec<NT> TX2 = TNv<NT, KS>(T21t, X2);  // column 0: T21 (...)
+#pragma unroll
+  for (int b = 0; b < NT; ++b)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      C.Jv.t[b][q] = (L.lr == 0) ? jv.t[b][q] + TX2.t[b][q] : ((L.lr == 1) ? C.Jv.t[b][q] + TX1s.t[b][q] : 0.0);
   // T++ = T21 T++                                                                    (:113)
-  C.Tpp_c = TN<KS>(T21t, C.Tpp_c);
-  // R+- = r+- + T21 R+- t--   (both forms)                                           (:116)
-  d4 Y, zero = {0.0, 0.0, 0.0, 0.0};
-  if (SURF) {  // t-- = I: Y = R+-
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Y[r] = C.Rpm_c[r];
-  } else {
-    Y = TN<KS>(C.Rpm_t, scaleD(L, tc));
-  }
-  const d4 Rpm_c_new = TNacc<KS>(T21t, Y, SURF ? zero : scaleD(L, rc));
-  const d4 Rpm_t_new = TNacc<KS>(Y, T21t, SURF ? zero : scaleD(L, rt));
-  C.Rpm_c = Rpm_c_new; C.Rpm_t = Rpm_t_new;
+  C.Tpp = TN<NT, KS>(T21t, C.Tpp);
+  // R+- = r+- + T21 R+- t--                                                          (:116)
+  if (SURF) C.Rpm = TN<NT, KS>(T21t, C.Rpm);
+  else C.Rpm = TNacc<NT, KS>(T21t, TN<NT, KS>(RpmT, tmm), scaleD<NT>(L, r));
+  return rT;
 }
 
-template <int KS>
-__global__ void __launch_bounds__(256, MOMW_OCC) k_wsweep(WArgs a) {
-  __shared__ double s_lds[4][16 * 17 + 48];
-  __shared__ int s_piv[4][16];
-  __shared__ double s_tab[48];
+#ifndef MOMW_OCC1
+#define MOMW_OCC1 2  // waves per SIMD of the NT = 1 images
+#endif
+
+template <int NT, int KS>
+__global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs a) {
+  __shared__ double s_lds[4][slice_doubles<NT>()];
+  __shared__ int s_piv[4][16 * NT];
+  __shared__ double s_tab[96];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 4 + wave;  // spectral point of this wave
   const int N = a.N, nS = a.nS, S = a.S, K = a.K;
-  if (threadIdx.x < 16) {
+  if (threadIdx.x < 32) {
     const int i = threadIdx.x;
     s_tab[i] = i < N ? a.mu[i] : 1.0;
-    s_tab[16 + i] = i < N ? a.wt[i] : 0.0;
-    s_tab[32 + i] = i < N ? a.sg[i] : 1.0;
+    s_tab[32 + i] = i < N ? a.wt[i] : 0.0;
+    s_tab[64 + i] = i < N ? a.sg[i] : 1.0;
   }
   __syncthreads();
   if (n >= S) return;
-  double *lds = s_lds[wave];
-  int *ipiv = s_piv[wave];
   Lay L;
-  L.lr = lane & 15; L.lq = lane >> 4; L.N = N; L.nS = nS; L.tab = s_tab;
-  L.cok = L.lr < N;
-  L.muc = s_tab[L.lr]; L.wc = s_tab[16 + L.lr]; L.sgc = s_tab[32 + L.lr];
+  L.lr = lane & 15; L.lq = lane >> 4; L.N = N; L.nS = nS; L.tab = s_tab; L.xp = s_lds[wave]; L.ipiv = s_piv[wave];
+  double *post = L.xp + slice_doubles<NT>() - 3 * 16 * NT;  // J0+ | J0- | hdr_J0-, 16 NT each
   const int i_start = nS * (a.imu0 - 1), i_end = nS * a.imu0;
   const double mus = a.mu[i_start];
   int bad = 0;
@@ -276,151 +396,162 @@ __global__ void __launch_bounds__(256, MOMW_OCC) k_wsweep(WArgs a) {
   for (int m = 0; m < a.M; ++m) {
     const double wdiv = (m == 0) ? 2.0 : 4.0, wct02 = (m == 0) ? 0.5 : 0.25;
     const double *Zp_m = a.Zpp + (size_t)N * N * K * m, *Zm_m = a.Zmp + (size_t)N * N * K * m;
-    Comp C;
+    Comp<NT> C;
     for (int z = 0; z < a.Nz; ++z) {
       const int nd = a.nd[z];
       const size_t o = n + (size_t)S * z;
       const double tau = a.tau[o], varpi = a.varpi[o], tau_sum = a.tau_sum[o];
       const double dtau = ldexp(tau, -nd);
       double expk = exp(-dtau / a.mu0);
-      // ------------------------------------------------ elemental! in both forms (elemental.jl:164-253)
-      d4 rc, rt, tc, tt, jv;
+      // ------------------------------------------------ elemental! (elemental.jl:164-253)
+      Mat<NT> r, t;
+      Vec<NT> jv;
       {
-        const double wjc = L.wc / wdiv;              // w'_j of the column stream
-        const double ec = exp(-dtau / L.muc);        // exp(-dtau / mu_col)
         const double att = exp(-tau_sum / mus), es = exp(-dtau / mus);
-        // one row (register) per iteration, NOT unrolled: the live set of one iteration is what the register budget of
-        // two waves per SIMD affords next to the composite tiles
+        // one register row (of every tile of a row block) per iteration, NOT unrolled over q: the live set of one
+        // iteration is what the register budget affords next to the composite tiles
+#pragma unroll
+        for (int bi = 0; bi < NT; ++bi) {
 #pragma unroll 1
-        for (int r = 0; r < 4; ++r) {
-          const int i = L.lq + 4 * r, j = L.lr;
-          const bool rok = i < N, ok = rok && L.cok;
-          double zpij = 0.0, zmij = 0.0, zpji = 0.0, zmji = 0.0;
-          if (ok)
-            for (int k = 0; k < K; ++k) {
-              const double w = a.zw[k + (size_t)K * o];
-              const size_t b = (size_t)N * N * k;
-              zpij += w * Zp_m[b + i + N * j]; zmij += w * Zm_m[b + i + N * j];
-              zpji += w * Zp_m[b + j + N * i]; zmji += w * Zm_m[b + j + N * i];
+          for (int q = 0; q < 4; ++q) {
+            const int i = L.row(bi, q);
+            const bool rok = i < N;
+            const double mui = L.mu(i), wir = L.wt(i) / wdiv;
+            const double er = exp(-dtau / mui);
+#pragma unroll
+            for (int bj = 0; bj < NT; ++bj) {
+              const int j = L.col(bj);
+              const bool ok = rok && j < N;
+              const double muj = L.mu(j), wjc = L.wt(j) / wdiv;
+              double zp = 0.0, zm = 0.0;
+              if (ok)
+                for (int k = 0; k < K; ++k) {
+                  const double w = a.zw[k + (size_t)K * o];
+                  const size_t b = (size_t)N * N * k + i + (size_t)N * j;
+                  zp += w * Zp_m[b];
+                  zm += w * Zm_m[b];
+                }
+              double rij, tij;
+              if (wjc > 1.e-8) {
+                rij = varpi * zm * (muj / (mui + muj)) * wjc * (1 - exp(-dtau * ((1 / mui) + (1 / muj))));
+                if (mui == muj) tij = (i == j) ? er * (1 + varpi * zp * (dtau / mui) * wir) : 0.0;
+                else tij = varpi * zp * (muj / (mui - muj)) * wjc * (er - exp(-dtau / muj));
+              } else {
+                rij = 0.0;
+                tij = (i == j) ? er : 0.0;
+              }
+              if (nd >= 1) rij *= L.sg(i);  // apply_D_elemental!: rows of r-+ (elemental.jl:265-269)
+              r.t[bi][bj][q] = ok ? rij : 0.0;
+              t.t[bi][bj][q] = ok ? tij : 0.0;
             }
-          const double mui = L.mur(r), muj = L.muc, wir = L.wr(r) / wdiv;
-          const double er = exp(-dtau / mui);
-          const double E = 1 - exp(-dtau * ((1 / mui) + (1 / muj)));  // symmetric in (i, j)
-          double rij, tij, rji, tji;
-          // element (i, j): column stream j
-          if (wjc > 1.e-8) {
-            rij = varpi * zmij * (muj / (mui + muj)) * wjc * E;
-            if (mui == muj) tij = (i == j) ? er * (1 + varpi * zpij * (dtau / mui) * wir) : 0.0;
-            else tij = varpi * zpij * (muj / (mui - muj)) * wjc * (er - ec);
-          } else {
-            rij = 0.0;
-            tij = (i == j) ? er : 0.0;
-          }
-          // element (j, i): column stream i (the reference's expression with i and j exchanged)
-          if (wir > 1.e-8) {
-            rji = varpi * zmji * (mui / (muj + mui)) * wir * E;
-            if (muj == mui) tji = (i == j) ? ec * (1 + varpi * zpji * (dtau / muj) * wjc) : 0.0;
-            else tji = varpi * zpji * (mui / (muj - mui)) * wir * (ec - er);
-          } else {
-            rji = 0.0;
-            tji = (i == j) ? ec : 0.0;
-          }
-          if (nd >= 1) { rij *= L.sgr(r); rji *= L.sgc; }  // apply_D_elemental!: rows of r-+ (elemental.jl:265-269)
-          rc[r] = ok ? rij : 0.0; tc[r] = ok ? tij : 0.0;
-          rt[r] = ok ? rji : 0.0; tt[r] = ok ? tji : 0.0;
-          // source rows: Z I0 over the sun's Stokes block (lanes of columns 0 and 1)             (elemental.jl:224-251)
-          double jx = 0.0;
-          if (rok && L.lr < 2) {
-            const double *Zs = (L.lr == 0) ? Zp_m : Zm_m;
-            double zI = 0.0;
-            for (int ks = 0; ks < nS; ++ks)
-              for (int k = 0; k < K; ++k)
-                zI += a.zw[k + (size_t)K * o] * Zs[(size_t)N * N * k + i + (size_t)N * (i_start + ks)] * a.I0[ks];
-            if (L.lr == 0) {
-              if (i >= i_start && i < i_end) jx = wct02 * varpi * zI * (dtau / mui) * er;
-              else jx = wct02 * varpi * zI * (mus / (mui - mus)) * (er - es);
-              jx *= att;
-            } else {
-              jx = wct02 * varpi * zI * (mus / (mui + mus)) * (1 - exp(-dtau * ((1 / mui) + (1 / mus))));
-              jx *= att;
-              if (nd >= 1) jx = a.D[i % nS] * jx;
+            // source rows: Z I0 over the sun's Stokes block (lanes of columns 0 and 1)             (elemental.jl:224-251)
+            double jx = 0.0;
+            if (rok && L.lr < 2) {
+              const double *Zs = (L.lr == 0) ? Zp_m : Zm_m;
+              double zI = 0.0;
+              for (int ks = 0; ks < nS; ++ks)
+                for (int k = 0; k < K; ++k)
+                  zI += a.zw[k + (size_t)K * o] * Zs[(size_t)N * N * k + i + (size_t)N * (i_start + ks)] * a.I0[ks];
+              if (L.lr == 0) {
+                if (i >= i_start && i < i_end) jx = wct02 * varpi * zI * (dtau / mui) * er;
+                else jx = wct02 * varpi * zI * (mus / (mui - mus)) * (er - es);
+                jx *= att;
+              } else {
+                jx = wct02 * varpi * zI * (mus / (mui + mus)) * (1 - exp(-dtau * ((1 / mui) + (1 / mus))));
+                jx *= att;
+                if (nd >= 1) jx = a.D[i % nS] * jx;
+              }
             }
+            jv.t[bi][q] = jx;
           }
-          jv[r] = jx;
         }
       }
       // ------------------------------------------------ doubling_helper! (doubling.jl:43-68)
-      // forms: rc, rt, tc, tt; per step B = r r, B^T, G = (I - B)^-1, A^T = G^T t^T, W = r t, then
-      // r <- r + A W (c and t), t <- A t (c and t); sources through the vector tile
       for (int it = 0; it < nd; ++it) {
-        const d4 B = TN<KS>(rt, rc), Bt = TN<KS>(rc, rt);
-        const d4 G = inv_one_minus<KS>(L, B, Bt, a.inv_mode, lds, ipiv, bad);
-        const d4 At = TN<KS>(G, tt);
-        const d4 U = TN<KS>(rt, jv);          // columns: r j0+ | r j0-
-        const d4 Us = shfl_xor1(U);
-        d4 Wv;
+        const Mat<NT> rT = transpose<NT>(L, r);
+        const Mat<NT> G = inv_one_minus<NT, KS>(L, TN<NT, KS>(rT, r), a.inv_mode, bad);  // (I - r r)^-1      (:44-47)
+        const Mat<NT> At = TN<NT, KS>(G, transpose<NT>(L, t));                            // (t G)^T           (:48)
+        const Vec<NT> Us = swap01<NT>(TNv<NT, KS>(rT, jv));  // columns: r j0- | r j0+
+        Vec<NT> Wv;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)       // column 0: w2 = j0+ + r j1-  ; column 1: w1 = j1- + r j0+   (:51-60)
-          Wv[r] = (L.lr == 0) ? jv[r] + expk * Us[r] : ((L.lr == 1) ? jv[r] * expk + Us[r] : 0.0);
-        const d4 AW = TN<KS>(At, Wv);
+        for (int b = 0; b < NT; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)       // j0+ = j1+ + A w2 (:60) ; j0- = j0- + A w1 (:57)
-          jv[r] = (L.lr == 0) ? jv[r] * expk + AW[r] : ((L.lr == 1) ? jv[r] + AW[r] : 0.0);
-        expk = expk * expk;               // :61
-        const d4 W = TN<KS>(rt, tc);          // r t (old t)
-        const d4 rc_n = TNacc<KS>(At, W, rc), rt_n = TNacc<KS>(W, At, rt);   // r + A (r t)      (:64)
-        const d4 tc_n = TN<KS>(At, tc), tt_n = TN<KS>(tc, At);               // A t             (:67)
-        rc = rc_n; rt = rt_n; tc = tc_n; tt = tt_n;
+          for (int q = 0; q < 4; ++q)  // column 0: w2 = j0+ + r j1-  ; column 1: w1 = j1- + r j0+   (:51-60)
+            Wv.t[b][q] = (L.lr == 0) ? jv.t[b][q] + expk * Us.t[b][q] : ((L.lr == 1) ? jv.t[b][q] * expk + Us.t[b][q] : 0.0);
+        const Vec<NT> AW = TNv<NT, KS>(At, Wv);
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)  // j0+ = j1+ + A w2 (:60) ; j0- = j0- + A w1 (:57)
+            jv.t[b][q] = (L.lr == 0) ? jv.t[b][q] * expk + AW.t[b][q] : ((L.lr == 1) ? jv.t[b][q] + AW.t[b][q] : 0.0);
+        expk = expk * expk;                                   // :61
+        r = TNacc<NT, KS>(At, TN<NT, KS>(rT, t), r);          // r + A (r t), old t                 (:64)
+        t = TN<NT, KS>(At, t);                                // A t                               (:67)
       }
       if (nd >= 1) {  // apply_D! / apply_D_SFI! (doubling.jl:93-118): rows of r-+ and j0- scaled by sg
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          rc[r] *= L.sgr(r);
-          rt[r] *= L.sgc;
-          if (L.lr == 1) jv[r] *= L.sgr(r);
-        }
+        for (int bi = 0; bi < NT; ++bi)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const double s = L.sg(L.row(bi, q));
+#pragma unroll
+            for (int bj = 0; bj < NT; ++bj) r.t[bi][bj][q] *= s;
+            if (L.lr == 1) jv.t[bi][q] *= s;
+          }
       }
       // ------------------------------------------------ composite <- added (rt_kernel.jl:227-230) or interaction!
       if (z == 0) {
-        C.Rmp_c = rc; C.Rpm_c = scaleD(L, rc); C.Rpm_t = scaleD(L, rt); C.Tpp_c = tc; C.Tmm_t = scaleD(L, tt); C.Jv = jv;
+        C.Rmp = r; C.Rpm = scaleD<NT>(L, r); C.Tpp = t; C.Tmm = scaleD<NT>(L, t); C.Jv = jv;
       } else {
-        interact11<KS, false>(L, C, rc, rt, tc, tt, jv, a.inv_mode, lds, ipiv, bad);
+        (void)interact11<NT, KS, false>(L, C, r, t, jv, a.inv_mode, bad);
       }
     }
     // ---------------------------------------------------- Lambertian surface (m = 0) + closing interaction (Q6)
-    d4 hdrJ = {0.0, 0.0, 0.0, 0.0};
+    Vec<NT> hdrJ;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) hdrJ.t[b] = (d4){0.0, 0.0, 0.0, 0.0};
     if (m == 0) {
       const double rho = 2 * a.albedo;
       const double att = exp(-a.tau_sum[n + (size_t)S * a.Nz] / a.mu0);
-      d4 rs_c, rs_t, jv;
+      Mat<NT> rs;
+      Vec<NT> jv;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = L.lq + 4 * r, j = L.lr;
-        const bool ok = L.rok(r) && L.cok, ii = (i % nS == 0) && (j % nS == 0);
-        rs_c[r] = (ok && ii) ? rho * (L.muc * L.wc) : 0.0;         // r-+ = R_surf Diagonal(mu w)  (:41-43,:58)
-        rs_t[r] = (ok && ii) ? rho * (L.mur(r) * L.wr(r)) : 0.0;
-        const bool in_sun = (i >= i_start) && (i < i_end);
-        const double jp = (in_sun ? a.I0[i - i_start] : 0.0) * att;                     // :55
-        const double jm = (i % nS == 0) ? (a.mu0 * (rho * a.I0[0])) * att : 0.0;       // :56
-        jv[r] = !L.rok(r) ? 0.0 : (L.lr == 0 ? jp : (L.lr == 1 ? jm : 0.0));
-      }
-      interact11<KS, true>(L, C, rs_c, rs_t, rs_c, rs_c, jv, a.inv_mode, lds, ipiv, bad);  // (t operands unused)
+      for (int bi = 0; bi < NT; ++bi)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = L.row(bi, q);
+#pragma unroll
+          for (int bj = 0; bj < NT; ++bj) {
+            const int j = L.col(bj);
+            const bool ok = i < N && j < N && (i % nS == 0) && (j % nS == 0);
+            rs.t[bi][bj][q] = ok ? rho * (L.mu(j) * L.wt(j)) : 0.0;  // r-+ = R_surf Diagonal(mu w)  (:41-43,:58)
+          }
+          const bool in_sun = (i >= i_start) && (i < i_end);
+          const double jp = (in_sun ? a.I0[i - i_start] : 0.0) * att;                     // :55
+          const double jm = (i % nS == 0) ? (a.mu0 * (rho * a.I0[0])) * att : 0.0;       // :56
+          jv.t[bi][q] = !(i < N) ? 0.0 : (L.lr == 0 ? jp : (L.lr == 1 ? jm : 0.0));
+        }
+      const Mat<NT> rsT = interact11<NT, KS, true>(L, C, rs, rs, jv, a.inv_mode, bad);  // (t operand unused)
       // interaction_hdrf! (interaction_hdrf.jl:9-45): hdr_J0- = r-+_surf J0+ + j0-_surf  -> column 0
-      const d4 rJ = TN<KS>(rs_t, C.Jv);
-      const d4 jsw = shfl_xor1(jv);
+      const Vec<NT> rJ = TNv<NT, KS>(rsT, C.Jv);
+      const Vec<NT> jsw = swap01<NT>(jv);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) hdrJ[r] = (L.lr == 0) ? rJ[r] + jsw[r] : 0.0;
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hdrJ.t[b][q] = (L.lr == 0) ? rJ.t[b][q] + jsw.t[b][q] : 0.0;
       // BHR flux sums over the streams of each Stokes component (column-0 lanes hold hdr_J0- and J0+)
       for (int k = 0; k < nS; ++k) {
         double up = 0.0, dw = 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = L.lq + 4 * r;
-          if (L.lr == 0 && L.rok(r) && (i % nS == k)) {
-            up += hdrJ[r] * L.wr(r) * L.mur(r);
-            dw += C.Jv[r] * L.wr(r) * L.mur(r);
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = L.row(b, q);
+            if (L.lr == 0 && i < N && (i % nS == k)) {
+              up += hdrJ.t[b][q] * L.wt(i) * L.mu(i);
+              dw += C.Jv.t[b][q] * L.wt(i) * L.mu(i);
+            }
           }
-        }
         up = wave_sum(up);
         dw = wave_sum(dw);
         // + j0+_surf[i_start] mu[i_start]: the direct beam (interaction_hdrf.jl:30)
@@ -432,21 +563,22 @@ __global__ void __launch_bounds__(256, MOMW_OCC) k_wsweep(WArgs a) {
       }
     }
     // ---------------------------------------------------- postprocessing_vza! (+ hdrf) through the wave's LDS slice
-    // layout: [0..15] J0+, [16..31] J0-, [32..47] hdr_J0-
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = L.lq + 4 * r;
-      if (L.lr == 0) { lds[i] = C.Jv[r]; lds[32 + i] = hdrJ[r]; }
-      if (L.lr == 1) lds[16 + i] = C.Jv[r];
-    }
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = L.row(b, q);
+        if (L.lr == 0) { post[i] = C.Jv.t[b][q]; post[32 * NT + i] = hdrJ.t[b][q]; }
+        if (L.lr == 1) post[16 * NT + i] = C.Jv.t[b][q];
+      }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (xok) {
       const double weight = (m == 0) ? 0.5 : 1.0;
       const double cs = weight * ((xk < 2) ? a.cos_mphi[xv + a.nVza * m] : a.sin_mphi[xv + a.nVza * m]);
       const int row = (a.node[xv] - 1) * nS + xk;
-      accT += cs * lds[row];
-      accR += cs * lds[16 + row];
-      if (m == 0) accH = cs * lds[32 + row];
+      accT += cs * post[row];
+      accR += cs * post[16 * NT + row];
+      if (m == 0) accH = cs * post[32 * NT + row];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
@@ -464,8 +596,15 @@ __global__ void __launch_bounds__(256, MOMW_OCC) k_wsweep(WArgs a) {
 hipError_t momw_launch_sweep(const void *args, hipStream_t st) {
   const momw::WArgs a = *reinterpret_cast<const momw::WArgs *>(args);
   const dim3 grid((unsigned)((a.S + 3) / 4)), block(256);
-  if (a.N <= 8) hipLaunchKernelGGL(momw::k_wsweep<2>, grid, block, 0, st, a);
-  else if (a.N <= 12) hipLaunchKernelGGL(momw::k_wsweep<3>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(momw::k_wsweep<4>, grid, block, 0, st, a);
+  switch ((a.N + 3) / 4) {
+    case 2: hipLaunchKernelGGL((momw::k_wsweep<1, 2>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((momw::k_wsweep<1, 3>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((momw::k_wsweep<1, 4>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((momw::k_wsweep<2, 5>), grid, block, 0, st, a); break;
+    case 6: hipLaunchKernelGGL((momw::k_wsweep<2, 6>), grid, block, 0, st, a); break;
+    case 7: hipLaunchKernelGGL((momw::k_wsweep<2, 7>), grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL((momw::k_wsweep<2, 8>), grid, block, 0, st, a); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }

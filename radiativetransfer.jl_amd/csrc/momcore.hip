@@ -366,6 +366,7 @@ struct mom_handle {
   double *added[6] = {}, *surf[6] = {}, *comp[6] = {};
   bool op_layers = false;     // added / surface layers of the operator-level API: allocated on first use
   bool comp_pitched = false;  // composite matrix blocks hold scene-level (row-pitched) state
+  bool comp_on_chip = false;  // the last mom_rt_run kept the composite layer in registers (lane / wave kernels)
   double *d_post[2] = {};     // operator-level mom_postprocess: gathered J0-/J0+ rows [nVza*nS*S] x 2
   size_t post_cap = 0;
   // RCCL communicator (mom_comm_init); the library is dlopen'ed on first use
@@ -831,6 +832,9 @@ extern "C" int mom_download(mom_t *h, int which, double *dst) {
   if (which / 6 == 1 && h->comp_pitched) {
     // after mom_rt_run: moment slot 0 of the scene-level state.  With the m = 0 reduction that moment lives in the
     // (I,Q) sub-problem's own arrays, which have no [N,N,S] image
+    if (h->comp_on_chip)
+      return fail(h, MOM_ESTATE, "mom_download: the run kept the composite layer in registers (operator edge <= 32); set "
+                                 "MOM_OPT_SMALL_N = 0 before mom_rt_run to read it back");
     if (h->red0)
       return fail(h, MOM_ESTATE, "mom_download: Fourier moment 0 ran on the (I,Q) sub-problem; set "
                                  "MOM_OPT_M0_REDUCTION = 0 before mom_scene_set to read the composite layer back");
@@ -1006,7 +1010,8 @@ static int scene_common(mom_t *h, int Nz, int K, int M, const double *Zpp, const
     if (node_1based[v] < 1 || node_1based[v] * h->nS > h->N) return fail(h, MOM_EINVAL, "mom_scene_set: bad view node");
   const size_t S = h->S, NN = (size_t)h->N * h->N;
   int rc;
-  const int Nk = h->opt_pad ? strip_pad(h->N) : h->N;
+  // (edges up to 32 belong to the wave-per-point kernel, which takes the operators as they are)
+  const int Nk = (h->opt_pad && !(h->N <= 32 && h->opt_small)) ? strip_pad(h->N) : h->N;
   h->Nk = Nk;
   h->qk = h->q;
   h->qk.N = Nk;
@@ -1035,7 +1040,7 @@ static int scene_common(mom_t *h, int Nz, int K, int M, const double *Zpp, const
   // ---- m = 0 reduction (include/momcore.h): conditions checked on the data, bitwise
   {
     const int N = h->N, nS = h->nS, Nq = N / nS;
-    bool ok = h->opt_m0 && nS >= 3 && h->q.regular && !(N <= 4 && h->opt_small && nVza <= 4);
+    bool ok = h->opt_m0 && nS >= 3 && h->q.regular && !(N <= 4 && h->opt_small && nVza <= 4 && K <= 4);
     for (int k = 2; k < nS && ok; ++k) ok = (h->q.I0[k] == 0.0);
     for (int kb = 0; kb < K && ok; ++kb)
       for (int j = 0; j < N && ok; ++j)
@@ -1213,13 +1218,13 @@ struct WaveSweepArgs {
 
 // the wave-per-point kernel covers ScatteringInterface_11 on every layer after the first and at the surface
 static bool wave_sweep_applies(const mom_t *h) {
-  if (!(h->N > 4 && h->N <= 16 && h->opt_small && h->surf_kind == 0 && h->nVza * h->nS <= 64)) return false;
+  if (!(h->N > 4 && h->N <= 32 && h->opt_small && !h->opt_force_generic && h->surf_kind == 0 && h->nVza * h->nS <= 64)) return false;
   for (int z = 1; z < h->Nz; ++z)
     if (h->iface[z] != 3) return false;
   return h->iface[h->Nz - 1] == 3;
 }
 
-// 4 < N <= 16: one spectral point per wavefront, operators in MFMA-layout registers, ONE launch
+// 4 < N <= 32: one spectral point per wavefront, operators in MFMA-layout registers, ONE launch
 static int rt_run_wave(mom_t *h) {
   const int Nz = h->Nz;
   {
@@ -1419,8 +1424,10 @@ extern "C" int mom_rt_run(mom_t *h) {
   }
   h->launches = 0; h->launches_full = 0; h->launches_red = 0;
   h->comp_pitched = true;
-  if (h->N <= 4 && h->opt_small && h->nVza <= 4 && h->surf_kind == 0) return rt_run_small(h);
+  h->comp_on_chip = true;
+  if (h->N <= 4 && h->opt_small && !h->opt_force_generic && h->nVza <= 4 && h->surf_kind == 0 && h->K <= 4) return rt_run_small(h);
   if (wave_sweep_applies(h)) return rt_run_wave(h);
+  h->comp_on_chip = false;
   return rt_run_core(h, 0, h->Nz, true, h->comp, true, true);
 }
 
@@ -1443,6 +1450,7 @@ extern "C" int mom_rt_run_multisensor(mom_t *h, int nSensors, const int *sensor_
   const size_t out1 = (size_t)h->nVza * h->nS * S;
   h->launches = 0; h->launches_full = 0; h->launches_red = 0;
   h->comp_pitched = true;
+  h->comp_on_chip = false;
   if (!h->comp_top[0]) {
     const int Na = h->N + kPadMax;
     for (int k = 0; k < 6; ++k) {

@@ -77,16 +77,22 @@ def test_small_operator_sweep_kernel(rtamd, cref, lt, vza, kw):
     (4, 3, (0.0,), {}),                                         # N = 16, IQUV
     (4, 3, (0.0,), dict(aerosol_total=3.0, albedo=0.05)),       # N = 16, thick aerosol: long series / pivoted inverse
     (3, 1, (0.0,), {}),                                         # N = 9
+    (1, 27, (0.0, 30.0, 60.0), {}),                             # N = 17: two tiles per edge, one k-step in the second
+    (3, 7, (0.0, 40.0), {}),                                    # N = 21
+    (4, 7, (0.0,), dict(aerosol_total=0.8)),                    # N = 24
+    (1, 51, (0.0, 30.0), {}),                                   # N = 29
+    (3, 13, (0.0, 30.0), dict(albedo=0.5)),                     # N = 30
+    (4, 9, (0.0, 30.0), dict(aerosol_total=2.5)),               # N = 32, thick aerosol
 ])
 @pytest.mark.parametrize("inverse", [0, 1])
 def test_wave_per_point_sweep_kernel(rtamd, cref, nS, lt, vza, kw, inverse):
-    """4 < N <= 16 (mom_wave.hip: one spectral point per wavefront, operators as MFMA-layout register tiles, the whole
-    sweep in one launch) against the oracle and against the general kernels; inverse = 1 forces the pivoted
+    """4 < N <= 32 (mom_wave.hip: one spectral point per wavefront, operators as 1 x 1 or 2 x 2 MFMA-layout register tiles,
+    the whole sweep in one launch) against the oracle and against the general kernels; inverse = 1 forces the pivoted
     Gauss-Jordan inverse in place of the series."""
     m = rtamd.scenes.make_scene(nS, lt, 8, 300, seed=11 + lt + nS, vza=vza,
                                 vaz=tuple(15.0 + 50.0 * i for i in range(len(vza))), **kw)
     sc = rtamd.prepare_scene(m)
-    assert 4 < sc.N <= 16, sc.N
+    assert 4 < sc.N <= 32, sc.N
     p = cref.pack_scene(helpers.oracle_scene(m))
     Rr, Tr, Hr, upr, dwr, info = cref.rt_run_full(p)
     assert info == 0

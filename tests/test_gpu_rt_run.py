@@ -345,7 +345,13 @@ def test_operator_level_state_rules(rtamd, cref):
         h.interaction(int(Lin.iface[-1]), with_surface_layer=True)
         R_op, J_op = h.download(L.COMP["R_mp"]), h.download(L.COMP["J0m"])
     with rtamd.corert.make_handle(m) as h:
+        rtamd.corert.run_scene(h, sc)   # default at N = 24: the wave-per-point kernel, no composite layer in HBM
+        with pytest.raises(rtamd.MomError) as e:
+            h.download(L.COMP["R_mp"])
+        assert e.value.code == L.MOM_ESTATE and "registers" in str(e.value)
+    with rtamd.corert.make_handle(m) as h:
         h.set_option(L.MOM_OPT_M0_REDUCTION, 0)
+        h.set_option(L.MOM_OPT_SMALL_N, 0)
         rtamd.corert.run_scene(h, sc)
         helpers.assert_op_close(h.download(L.COMP["R_mp"]), R_op, rtol=1e-11, what="de-pitched R-+ after mom_rt_run")
         helpers.assert_op_close(h.download(L.COMP["J0m"]), J_op, rtol=1e-11, what="J0- after mom_rt_run")
@@ -353,7 +359,8 @@ def test_operator_level_state_rules(rtamd, cref):
             h.interaction(3)
         assert e.value.code == L.MOM_ESTATE
     with rtamd.corert.make_handle(m) as h:
-        Rd, _ = rtamd.corert.run_scene(h, sc)  # default: m = 0 on the (I,Q) sub-problem
+        h.set_option(L.MOM_OPT_SMALL_N, 0)
+        Rd, _ = rtamd.corert.run_scene(h, sc)  # workgroup kernels: m = 0 on the (I,Q) sub-problem
         with pytest.raises(rtamd.MomError) as e:
             h.download(L.COMP["R_mp"])
         assert e.value.code == L.MOM_ESTATE and "sub-problem" in str(e.value)

@@ -30,8 +30,8 @@ for nS, lt, S in CASES:
         dt = time.time() - t0
     nd = int(sum(sc.ndoubl))
     F = sc.M * (nd * (12 * N**3 + 8 * N**2) + (sc.Nz - 1) * (24 * N**3 + 8 * N**2))
-    pad = next((p for p in (36, 40, 44, 52, 56, 60) if N <= p <= N + 4), None)
-    path = ("lane per point (mom_small)" if N <= 4 else "wave per point (mom_wave)" if N <= 16 else
+    pad = next((p for p in (36, 40, 44, 52, 56, 60) if N <= p <= N + 4), None) if N > 32 else None
+    path = ("lane per point (mom_small)" if N <= 4 else "wave per point (mom_wave)" if N <= 32 else
             f"strip chains{'' if pad == N else f', padded to {pad}'}" if pad else
             "workgroup per unit, LDS operators" if N <= 64 else "workgroup per unit, panel GEMM from the L2 slab")
     print(f"{nS:7d} {N:4d} {S:7d} {dt * 1e3:9.1f} {S / dt:11.0f} {F * S / dt / 1e12:8.2f} {F * S / dt / 78.6e12:12.3f}  {path}", flush=True)
