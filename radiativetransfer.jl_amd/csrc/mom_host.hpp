@@ -24,4 +24,4 @@ void mom_set_global_error(const char *msg);
 // voigt.hip: one launch for all lines (device pointers, stream st); out[g] = acc  or  out[g] += factor * acc
 hipError_t mom_voigt_launch(hipStream_t st, int nLines, const double *nu, const double *gamma_d, const double *y,
                             const double *S, const int *i0, const int *i1, int nGrid, const double *grid, double *out,
-                            double factor, int accumulate);
+                            double factor, int accumulate, int sorted);

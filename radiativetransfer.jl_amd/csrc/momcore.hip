@@ -1850,6 +1850,9 @@ extern "C" int mom_voigt_tau_abs(mom_t *h, int iz_1based, int nLines, const doub
       return fail(h, MOM_EINVAL, buf);
     }
   if (nLines == 0) return MOM_OK;
+  int sorted = 1;
+  for (int j = 1; j < nLines; ++j)
+    if (ind_start_1based[j] < ind_start_1based[j - 1] || ind_stop_1based[j] < ind_stop_1based[j - 1]) { sorted = 0; break; }
   HIPCHK(h, hipSetDevice(h->device));
   const size_t lb = (size_t)nLines;
   if (lb > h->lines_cap) {  // 4 double + 2 int arrays per line, grown geometrically: no allocation in steady state
@@ -1867,7 +1870,7 @@ extern "C" int mom_voigt_tau_abs(mom_t *h, int iz_1based, int nLines, const doub
   HIPCHK(h, hipMemcpyAsync(dw, ind_start_1based, lb * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(dw + cap, ind_stop_1based, lb * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, mom_voigt_launch(h->stream, nLines, dl, dl + cap, dl + 2 * cap, dl + 3 * cap, dw, dw + cap, h->S, h->d_grid,
-                             h->d_tau_abs + (size_t)h->S * (iz_1based - 1), factor, 1));
+                             h->d_tau_abs + (size_t)h->S * (iz_1based - 1), factor, 1, sorted));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
 }

@@ -21,18 +21,6 @@ namespace {
 
 struct cplx { double re, im; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-__device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
-  cplx c;
-  if (fabs(b.re) >= fabs(b.im)) {
-    const double r = b.im / b.re, den = b.re + b.im * r;
-    c.re = (a.re + a.im * r) / den; c.im = (a.im - a.re * r) / den;
-  } else {
-    const double r = b.re / b.im, den = b.re * r + b.im;
-    c.re = (a.re * r + a.im) / den; c.im = (a.im * r - a.re) / den;
-  }
-  return c;
-}
-
 __constant__ double kW32A[32] = {
     2.5722534081245696e+00,  2.2635372999002676e+00,  1.8256696296324824e+00,  1.3455441692345453e+00,
     9.0192548936480144e-01,  5.4601397206393498e-01,  2.9544451071508926e-01,  1.4060716226893769e-01,
@@ -58,7 +46,11 @@ __device__ __forceinline__ double w_hw32sd_re(double x, double y) {
   }
   const double L = 4.756828460010884;  // sqrt(32/sqrt(2))
   const cplx lpiz = {L - y, x}, lmiz = {L + y, -x};
-  const cplx rec = cdiv(cplx{1.0, 0.0}, lmiz);
+  // 1 / (L - i z) = conj / |.|^2: ONE division and no branch (Julia's complex division, complex.jl, is Smith's
+  // branching three-division scheme; |L - i z|^2 lies in [22, 200] here, so the plain form differs from it by rounding
+  // only -- a few 1e-16 relative, inside the 1e-13 parity bar -- and a wave no longer executes both branches)
+  const double inv = 1.0 / (lmiz.re * lmiz.re + lmiz.im * lmiz.im);
+  const cplx rec = {lmiz.re * inv, -lmiz.im * inv};
   const cplx Z = cmul(lpiz, rec);
   cplx p = {kW32A[31], 0.0};
 #pragma unroll
@@ -71,14 +63,17 @@ __device__ __forceinline__ double w_hw32sd_re(double x, double y) {
   return cmul(inner, rec).re;
 }
 
-constexpr int kBlock = 256;
+#ifndef MOM_VOIGT_BLOCK
+#define MOM_VOIGT_BLOCK 256
+#endif
+constexpr int kBlock = MOM_VOIGT_BLOCK;  // grid points per workgroup
 
 __global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__restrict__ nu,
                                                   const double *__restrict__ gamma_d, const double *__restrict__ y,
                                                   const double *__restrict__ S, const int *__restrict__ i0,
                                                   const int *__restrict__ i1, int nGrid,
                                                   const double *__restrict__ grid, double *__restrict__ sigma,
-                                                  double factor, int accumulate) {
+                                                  double factor, int accumulate, int sorted) {
   // per-line constants of the candidates, staged once per workgroup: centre, S c/gamma_d, c'/gamma_d, y and the
   // 0-based window -- the two divisions by gamma_d are per LINE here, not per evaluation (same expressions, same values)
   __shared__ double c_nu[kBlock], c_a[kBlock], c_b[kBlock], c_y[kBlock];
@@ -98,7 +93,17 @@ __global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__re
   __shared__ int s_lo, s_hi;
   if (tid == 0) { s_lo = nLines; s_hi = -1; }
   __syncthreads();
-  {
+  if (sorted) {
+    // window starts and stops both non-decreasing in the line index (the host checked): two binary searches
+    if (tid == 0) {
+      int a = 0, b = nLines;
+      while (a < b) { const int mid = (a + b) >> 1; if (i1[mid] - 1 >= g0) b = mid; else a = mid + 1; }
+      s_lo = a;   // first line whose window ends at or after the block's first point
+      a = 0; b = nLines;
+      while (a < b) { const int mid = (a + b) >> 1; if (i0[mid] - 1 > g1) b = mid; else a = mid + 1; }
+      s_hi = a - 1;  // last line whose window starts at or before the block's last point
+    }
+  } else {
     int mylo = nLines, myhi = -1;
     for (int j = tid; j < nLines; j += kBlock) {
       const int lo = i0[j] - 1, hi = i1[j] - 1;
@@ -137,7 +142,9 @@ __global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__re
       c_lo[pos] = lo;
       c_hi[pos] = hi;
     }
-    const int nc = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    int nc = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) nc += wcount[w];
     __syncthreads();
     for (int c = 0; c < nc; ++c) {
       if (gi >= c_lo[c] && gi <= c_hi[c] && gi < nGrid) acc += c_a[c] * w_hw32sd_re(c_b[c] * (gx - c_nu[c]), c_y[c]);
@@ -161,9 +168,9 @@ thread_local double v_last_ms = 0.0;
 // mom_voigt_tau_abs (momcore.hip), which accumulates straight into the resident tau_abs table
 hipError_t mom_voigt_launch(hipStream_t st, int nLines, const double *nu, const double *gamma_d, const double *y,
                             const double *S, const int *i0, const int *i1, int nGrid, const double *grid, double *out,
-                            double factor, int accumulate) {
+                            double factor, int accumulate, int sorted) {
   hipLaunchKernelGGL(k_voigt, dim3((nGrid + kBlock - 1) / kBlock), dim3(kBlock), 0, st, nLines, nu, gamma_d, y, S, i0, i1,
-                     nGrid, grid, out, factor, accumulate);
+                     nGrid, grid, out, factor, accumulate, sorted);
   return hipGetLastError();
 }
 
@@ -186,6 +193,9 @@ extern "C" int mom_voigt_xsec(int device, int nLines, const double *nu, const do
     mom_set_global_error("mom_voigt_xsec: bad argument (null pointer or non-positive size)");
     return MOM_EINVAL;
   }
+  int sorted = 1;  // window starts and stops non-decreasing: the kernel finds a block's lines by bisection
+  for (int j = 1; j < nLines; ++j)
+    if (ind_start[j] < ind_start[j - 1] || ind_stop[j] < ind_stop[j - 1]) { sorted = 0; break; }
   for (int j = 0; j < nLines; ++j)
     if (ind_start[j] < 1 || ind_stop[j] > nGrid) {  // empty windows (start > stop) are allowed
       char buf[160];
@@ -223,7 +233,7 @@ extern "C" int mom_voigt_xsec(int device, int nLines, const double *nu, const do
     VCHK(hipEventCreate(&e1));
     VCHK(hipEventRecord(e0, st));
     VCHK(mom_voigt_launch(st, nLines, d_line, d_line + lb, d_line + 2 * lb, d_line + 3 * lb, d_win, d_win + lb, nGrid, d_grid,
-                          d_sig, 1.0, 0));
+                          d_sig, 1.0, 0, sorted));
     VCHK(hipEventRecord(e1, st));
     VCHK(hipMemcpyAsync(sigma, d_sig, (size_t)nGrid * sizeof(double), hipMemcpyDeviceToHost, st));
     VCHK(hipStreamSynchronize(st));

@@ -29,6 +29,25 @@ def test_synthetic_o2a_against_oracle(rtamd, cref):
         assert np.all(sig >= 0)
 
 
+def test_line_order_sorted_and_unsorted(rtamd, cref):
+    """Sorted line lists (window starts and stops non-decreasing: a block finds its lines by bisection) and a shuffled
+    list (full scan) give the oracle's sums -- each in its own line order, which is the accumulation order."""
+    ab = rtamd.absorption
+    tab = ab.synthetic_o2a_lines(2000)
+    grid = np.linspace(12903.0, 13245.0, 30_000)
+    pf = ab.line_prefactors(tab, grid, 500.0, 250.0, vmr=0.21, wing_cutoff=3.0)
+    assert np.all(np.diff(pf.ind_start) >= 0) and np.all(np.diff(pf.ind_stop) >= 0)
+    args = [pf.ν, pf.γ_d, pf.y, pf.S, pf.ind_start, pf.ind_stop]
+    ref = cref.voigt_xsec(*args, grid)
+    sig = rtamd.voigt_xsec(*args, grid)
+    assert np.max(np.abs(sig - ref)) <= 1e-13 * ref.max()
+    perm = np.random.default_rng(0).permutation(len(pf.ν))
+    args_p = [np.ascontiguousarray(a[perm]) for a in args]
+    sig_p = rtamd.voigt_xsec(*args_p, grid)
+    assert np.max(np.abs(sig_p - cref.voigt_xsec(*args_p, grid))) <= 1e-13 * ref.max()
+    assert np.max(np.abs(sig_p - sig)) <= 1e-12 * ref.max()
+
+
 def test_edge_cases(rtamd, cref):
     grid = np.linspace(100.0, 101.0, 777)  # not a multiple of the block size
     one = lambda v: np.array([v])
