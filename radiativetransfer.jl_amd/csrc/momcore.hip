@@ -318,6 +318,8 @@ __global__ void __launch_bounds__(kThreads) k_batch_inv_dual(DualArgs a) {
 // small enough for two LDS images: the m = 0 (I,Q) sub-problem of N = 60 is N0 = 40 -> 77 KB).
 size_t mom4_lds_bytes(int N, bool lds_mats);
 hipError_t mom4_launch_layer(const void *layer_args, int iface, bool lds, int grid, size_t smem, hipStream_t st);
+// momcore_gen.hip: the general layer kernels k_layer<LDSM, IFACE> of the 8-wave build
+hipError_t mom_gen_launch_layer(const void *layer_args, int iface, bool lds, int grid, size_t smem, hipStream_t st);
 // momcore_strip.hip, one object per operator size N = 4 KS
 hipError_t mom_strip9_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom_strip10_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
@@ -1324,21 +1326,7 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
       return MOM_OK;
     }
     const int grid = lds ? (int)((S >= 2048) ? S : S * Mcount) : (int)std::min<size_t>(S * Mcount, (size_t)h->G);
-#define MOM_LAUNCH_LAYER(IF)                                                                            \
-  if (lds) {                                                                                            \
-    HIPCHK(h, allow_lds(k_layer<true, IF>, sm));                                                        \
-    hipLaunchKernelGGL((k_layer<true, IF>), dim3(grid), dim3(kThreads), sm, h->stream, a);               \
-  } else {                                                                                              \
-    HIPCHK(h, allow_lds(k_layer<false, IF>, sm));                                                       \
-    hipLaunchKernelGGL((k_layer<false, IF>), dim3(grid), dim3(kThreads), sm, h->stream, a);              \
-  }
-    switch (a.iface) {  // the interface code is a template argument: see interaction_core
-      case 0: MOM_LAUNCH_LAYER(0) break;
-      case 1: MOM_LAUNCH_LAYER(1) break;
-      case 2: MOM_LAUNCH_LAYER(2) break;
-      default: MOM_LAUNCH_LAYER(3) break;
-    }
-#undef MOM_LAUNCH_LAYER
+    HIPCHK(h, mom_gen_launch_layer(&a, a.iface, lds, grid, sm, h->stream));
     HIPCHK(h, hipGetLastError());
     h->launches++;
     return MOM_OK;
