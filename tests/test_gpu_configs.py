@@ -140,8 +140,14 @@ def test_config_C2_full_size_stratified(rtamd, cref):
         R, T = rtamd.corert.run_scene(h, sc)
         h.rt_run()
         R2, _ = h.get_RT()
+        _, up, dw = h.get_hdr()
     assert np.all(np.isfinite(R)) and np.all(np.isfinite(T)) and np.array_equal(R, R2)
     assert np.all(R[:, 0, :] > 0)
+    # size-independent property over ALL 10 000 points: the bihemispherical reflectance of a Lambertian surface is its
+    # albedo -- the upward flux at the surface (interaction_hdrf.jl:9-45, through the whole layer sweep: it contains the
+    # diffuse downward field J0+) over the downward flux, with sum(w mu) = 1/2 exact for the Gauss rule on [0, 1]
+    np.testing.assert_allclose(up[0] / dw[0], m.params.brdf_albedo, rtol=1e-12)
+    assert np.all(dw[0] > 0)
     pts = _stratified(m, 256)
     assert len(pts) >= 250
     Rr, Tr = _oracle(cref, m, pts=pts)
