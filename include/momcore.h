@@ -107,6 +107,19 @@ int mom_copy_added_to_composite(mom_t *h);
  *                       τ_sum, architecture) -- lambertian_surface.jl:20-75.  tau_tot: S values. */
 int mom_surface_lambertian(mom_t *h, int m, double albedo, const double *tau_tot);
 
+/* elemental_inelastic!(RS_type::RRS, pol_type, SFI, τ_sum, dτ_λ, ϖ_λ, Z⁺⁺_λ₁λ₀, Z⁻⁺_λ₁λ₀, m, ndoubl, scatter, quad_points,
+ *                      added_layer, I_static, architecture) -- CoreKernel/elemental_inelastic.jl:23-91: the elemental layer of
+ * the rotational-Raman source operators (get_elem_rt_RRS! :93-160, get_elem_rt_SFI_RRS! :320-382, apply_D_elemental_RRS!
+ * :384-402).  i_l1l0 [nRaman]: grid offsets n₀ - n₁ of the Raman lines (RS_type.i_λ₁λ₀), varpi_l1l0 [nRaman], fscattRayl,
+ * tau_sum, dtau, varpi [nSpec], Z*_l1l0 [N,N].  Outputs (host): ier⁻⁺, iet⁺⁺, ier⁺⁻, iet⁻⁻ [N,N,nSpec,nRaman], ieJ₀⁺, ieJ₀⁻
+ * [N,nSpec,nRaman] (Julia [N,1,nSpec,nRaman]).  For ndoubl >= 1 the reference leaves ier⁺⁻ / iet⁻⁻ untouched (they are
+ * filled after doubling); zeros are returned.  This is the ONLY piece of the RRS path (BASELINE config 5) that is built:
+ * see DESIGN.md section 7 for why doubling_inelastic! / interaction_inelastic! are not. */
+int mom_elemental_inelastic_rrs(mom_t *h, int m, int ndoubl, int nRaman, const int *i_l1l0, const double *varpi_l1l0,
+                                const double *fscattRayl, const double *tau_sum, const double *dtau, const double *varpi,
+                                const double *Zpp_l1l0, const double *Zmp_l1l0, double *ier_mp, double *iet_pp,
+                                double *ier_pm, double *iet_mm, double *ieJ0p, double *ieJ0m);
+
 /* batch_inv!(X, A) -- gpu_batched.jl:36-87;  X, A: n*n*batch doubles (host). */
 int mom_batch_inv(mom_t *h, int n, int batch, const double *A, double *X);
 /* A ⊠ B = batched_mul(A, B) -- gpu_batched.jl:90-97. */

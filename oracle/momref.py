@@ -703,6 +703,67 @@ def batch_inv(A: np.ndarray) -> np.ndarray:
     return np.linalg.inv(A)
 
 
+def elemental_inelastic_rrs(pol: PolType, quad: QuadPoints, i_l1l0, varpi_l1l0, fscatt, tau_sum, dtau, varpi, Zpp, Zmp, m: int,
+                            nd: int, strict: bool = True):
+    """elemental_inelastic!(RS_type::RRS, ...) CoreKernel/elemental_inelastic.jl:23-91 with get_elem_rt_RRS! (:93-160),
+    get_elem_rt_SFI_RRS! (:320-382) and apply_D_elemental_RRS! (:384-402; apply_D_elemental_SFI! :404-412 changes nothing).
+    i_l1l0 [nR]: grid offsets n0 - n1; Zpp/Zmp [N,N]; dtau, varpi, fscatt, tau_sum [S].  Returns ier_mp, iet_pp, ier_pm,
+    iet_mm [nR,S,N,N] and ieJ0p, ieJ0m [nR,S,N] (entries whose n0 is off the grid are zero).  PARITY UNPINNED: the reference
+    holds no known-answer test for its Raman path; pinned here only through the elastic limit (tests/test_oracle_twin.py)."""
+    n, N, S, nR = pol.n, len(quad.qp_muN), len(dtau), len(i_l1l0)
+    mu = np.asarray(quad.qp_muN, dtype=np.float64)
+    wct2 = np.asarray(quad.wt_muN) / (2.0 if m == 0 else 4.0)
+    wct02 = 0.5 if m == 0 else 0.25
+    i_start = n * (quad.imu0 - 1)
+    I0 = np.asarray(pol.I0, dtype=np.float64)
+    ier = np.zeros((nR, S, N, N)); iet = np.zeros((nR, S, N, N))
+    jp = np.zeros((nR, S, N)); jm = np.zeros((nR, S, N))
+    comp = stokes_comp(np.arange(N), n, strict)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for dn in range(nR):
+            for n1 in range(S):
+                n0 = n1 + int(i_l1l0[dn])
+                if not 0 <= n0 < S:
+                    continue
+                d1, d0 = dtau[n1], dtau[n0]
+                pre = varpi_l1l0[dn] * varpi[n0] * fscatt[n0]
+                mi, mj = mu[:, None], mu[None, :]
+                r = fscatt[n0] * varpi_l1l0[dn] * varpi[n0] * Zmp * (1 / ((mi / mj) + (d1 / d0))) * \
+                    (1 - np.exp(-((d1 / mi) + (d0 / mj)))) * wct2[None, :]
+                t_off = pre * Zpp * (1 / ((mi / mj) - (d1 / d0))) * wct2[None, :] * (np.exp(-d1 / mi) - np.exp(-d0 / mj))
+                if abs(d0 - d1) > 1.e-6:
+                    t_dia = pre * np.diag(Zpp) * wct2 * (np.exp(-d0 / mu) - np.exp(-d1 / mu)) / (1 - (d1 / d0))
+                else:
+                    t_dia = pre * np.diag(Zpp) * wct2 * (1 - np.exp(-d0 / mu))
+                eq = mi == mj
+                t = np.where(eq, 0.0, t_off)
+                t[np.arange(N), np.arange(N)] = t_dia
+                live = (wct2 > 1.e-8)[None, :]
+                ier[dn, n1] = np.where(live, r, 0.0)
+                iet[dn, n1] = np.where(live, t, 0.0)
+                zpI = Zpp[:, i_start:i_start + n] @ I0
+                zmI = Zmp[:, i_start:i_start + n] @ I0
+                mus = mu[i_start]
+                sun = (np.arange(N) >= i_start) & (np.arange(N) < i_start + n)
+                if abs(d0 - d1) > 1.e-6:
+                    jp_sun = (np.exp(-d0 / mu) - np.exp(-d1 / mu)) / ((d1 / d0) - 1) * pre * zpI * wct02
+                else:
+                    jp_sun = wct02 * pre * zpI * (1 - np.exp(-d0 / mus))
+                jp_off = wct02 * pre * zpI * (1 / ((mu / mus) - (d1 / d0))) * (np.exp(-d1 / mu) - np.exp(-d0 / mus))
+                att = np.exp(-tau_sum[n0] / mus)
+                jp[dn, n1] = np.where(sun, jp_sun, jp_off) * att
+                jm[dn, n1] = wct02 * pre * zmI * (1 / ((mu / mus) + (d1 / d0))) * (1 - np.exp(-((d1 / mu) + (d0 / mus)))) * att
+    ier_pm = np.zeros_like(ier); iet_mm = np.zeros_like(iet)
+    if nd < 1:
+        same = ((comp[:, None] <= 2) & (comp[None, :] <= 2)) | ((comp[:, None] > 2) & (comp[None, :] > 2))
+        sgn = np.where(same, 1.0, -1.0)
+        ier_pm, iet_mm = sgn * ier, sgn * iet
+    else:
+        ier = np.where((comp > 2)[None, None, :, None], -ier, ier)
+        jm = jm * np.tile(np.asarray(pol.D, dtype=np.float64), N // n)[None, None, :]
+    return ier, iet, ier_pm, iet_mm, jp, jm
+
+
 def batched_mul_dual(A, dA, B, dB):
     """batched_mul on ForwardDiff.Dual arrays (gpu_batched.jl:100-110): values [S,N,N], partials [P,S,N,N].
     C = A B, dC_i = A dB_i + dA_i B."""

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mom_interaction": (C.c_int, [c_h, C.c_int, C.c_int]),
     "mom_copy_added_to_composite": (C.c_int, [c_h]),
     "mom_surface_lambertian": (C.c_int, [c_h, C.c_int, C.c_double, c_dp]),
+    "mom_elemental_inelastic_rrs": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_ip] + [c_dp] * 13),
     "mom_batch_inv": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp]),
     "mom_batched_mul": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp, c_dp]),
     "mom_batched_mul_dual": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
@@ -203,6 +204,18 @@ class Handle:
         k = which % 6
         out = np.empty((self.N * self.N if k < 4 else self.N) * self.S)
         self.check(self.lib.mom_download(self._h, int(which), dp(out)))
+        return out
+
+    def elemental_inelastic_rrs(self, m, ndoubl, i_l1l0, varpi_l1l0, fscatt, tau_sum, dtau, varpi, Zpp, Zmp):
+        """elemental_inelastic!(::RRS) (elemental_inelastic.jl:23-91).  Z*: ABI [N,N] flat; returns the six arrays in ABI
+        order: ier_mp, iet_pp, ier_pm, iet_mm [N,N,S,nRaman] and ieJ0p, ieJ0m [N,S,nRaman] (flat, column-major)."""
+        il = i32(i_l1l0)
+        nR = len(il)
+        v = [f64(x).reshape(-1) for x in (varpi_l1l0, fscatt, tau_sum, dtau, varpi, Zpp, Zmp)]
+        big, vec = self.N * self.N * self.S * nR, self.N * self.S * nR
+        out = [np.empty(big) for _ in range(4)] + [np.empty(vec) for _ in range(2)]
+        self.check(self.lib.mom_elemental_inelastic_rrs(self._h, int(m), int(ndoubl), nR, ip(il), *[dp(x) for x in v],
+                                                        *[dp(x) for x in out]))
         return out
 
     def batch_inv(self, n, batch, A):

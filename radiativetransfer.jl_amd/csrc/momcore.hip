@@ -236,6 +236,94 @@ __global__ void __launch_bounds__(kThreads) k_batched_mul(BlasArgs a) {
   }
 }
 
+// elemental_inelastic!(RS_type::RRS, ...) (CoreKernel/elemental_inelastic.jl:23-91): the single-scattering layer of the
+// rotational-Raman source operators, one thread per element (i, j, n1, dn) of the 4-D arrays -- get_elem_rt_RRS! (:93-160),
+// get_elem_rt_SFI_RRS! (:320-382), apply_D_elemental_RRS! (:384-402; the SFI D kernel :404-412 / :478-490 changes nothing
+// for any ndoubl).  n0 = n1 + i_l1l0[dn] is the incident-wavelength index (0-based here), dtau the elemental optical
+// thickness per spectral point.  Entries whose n0 falls off the grid are written as zeros (the reference leaves the
+// freshly allocated zeros in place).  HBM-write bound: 4 N^2 + 2 N doubles per (n1, dn).
+struct RrsArgs {
+  DevStreams q;
+  int S, nR, m, nd, strict;
+  const int *i_l1l0;                                                     // [nR]
+  const double *varpi_l1l0, *fscatt, *tau_sum, *dtau, *varpi, *Zpp, *Zmp;  // [nR], [S] x4, [N,N] x2
+  double *ier_mp, *iet_pp, *ier_pm, *iet_mm, *ieJ0p, *ieJ0m;              // [N,N,S,nR] x4, [N,S,nR] x2
+};
+
+__global__ void __launch_bounds__(256) k_elemental_rrs(RrsArgs a) {
+#pragma clang fp contract(off)
+  const int N = a.q.N, n = a.q.nS;
+  const size_t NN = (size_t)N * N, total = NN * a.S * a.nR;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int i = (int)(e % N), j = (int)((e / N) % N);
+  const size_t u = e / NN;                       // n1 + S dn
+  const int n1 = (int)(u % a.S), dn = (int)(u / a.S);
+  const int n0 = n1 + a.i_l1l0[dn];
+  const double wdiv = (a.m == 0) ? 2.0 : 4.0, wct02 = (a.m == 0) ? 0.5 : 0.25;
+  const double mui = a.q.mu[i], muj = a.q.mu[j], wj = a.q.wt[j] / wdiv;
+  double r = 0.0, t = 0.0;
+  const bool in = (n0 >= 0) && (n0 < a.S);
+  if (in && wj > 1.e-8) {
+    const double d1 = a.dtau[n1], d0 = a.dtau[n0];
+    const double pre = a.varpi_l1l0[dn] * a.varpi[n0] * a.fscatt[n0];
+    // :118-120
+    r = a.fscatt[n0] * a.varpi_l1l0[dn] * a.varpi[n0] * a.Zmp[i + (size_t)N * j] * (1 / ((mui / muj) + (d1 / d0))) *
+        (1 - exp(-((d1 / mui) + (d0 / muj)))) * wj;
+    if (mui == muj) {
+      if (i == j) {
+        const double wi = a.q.wt[i] / wdiv;
+        if (fabs(d0 - d1) > 1.e-6)   // :130-134
+          t = pre * a.Zpp[i + (size_t)N * i] * wi * (exp(-d0 / mui) - exp(-d1 / mui)) / (1 - (d1 / d0));
+        else                          // :136-138
+          t = pre * a.Zpp[i + (size_t)N * i] * wi * (1 - exp(-d0 / muj));
+      }
+    } else {                          // :147-151
+      t = pre * a.Zpp[i + (size_t)N * j] * (1 / ((mui / muj) - (d1 / d0))) * wj * (exp(-d1 / mui) - exp(-d0 / muj));
+    }
+  }
+  // apply_D_elemental_RRS! (:384-402), component rule of SURVEY Q1
+  const int ci = a.strict ? ((i + 1) % n) : (i % n) + 1, cj = a.strict ? ((j + 1) % n) : (j % n) + 1;
+  if (a.nd < 1) {
+    const double s = (((ci <= 2) && (cj <= 2)) || ((ci > 2) && (cj > 2))) ? 1.0 : -1.0;
+    a.ier_pm[e] = s * r;
+    a.iet_mm[e] = s * t;
+  } else {
+    if (ci > 2) r = -r;
+    a.ier_pm[e] = 0.0;  // left untouched by the reference for ndoubl >= 1 (apply_D_matrix_IE! fills them after doubling)
+    a.iet_mm[e] = 0.0;
+  }
+  a.ier_mp[e] = r;
+  a.iet_pp[e] = t;
+  if (j == 0) {  // source vectors: one thread per (i, n1, dn)                                   (:320-382)
+    const int i_start = n * (a.q.imu0 - 1), i_end = n * a.q.imu0;  // 0-based [i_start, i_end)
+    double jp = 0.0, jm = 0.0;
+    if (in) {
+      const double d1 = a.dtau[n1], d0 = a.dtau[n0], mus = a.q.mu[i_start];
+      double zpI = 0.0, zmI = 0.0;
+      for (int ii = i_start; ii < i_end; ++ii) {
+        zpI += a.Zpp[i + (size_t)N * ii] * a.q.I0[ii - i_start];
+        zmI += a.Zmp[i + (size_t)N * ii] * a.q.I0[ii - i_start];
+      }
+      const double pre = a.varpi_l1l0[dn] * a.varpi[n0] * a.fscatt[n0];
+      if (i >= i_start && i < i_end) {
+        if (fabs(d0 - d1) > 1.e-6) jp = (exp(-d0 / mui) - exp(-d1 / mui)) / ((d1 / d0) - 1) * pre * zpI * wct02;  // :350-353
+        else jp = wct02 * pre * zpI * (1 - exp(-d0 / mus));                                                        // :355-357
+      } else {                                                                                                     // :361-364
+        jp = wct02 * pre * zpI * (1 / ((mui / mus) - (d1 / d0))) * (exp(-d1 / mui) - exp(-d0 / mus));
+      }
+      jm = wct02 * pre * zmI * (1 / ((mui / mus) + (d1 / d0))) * (1 - exp(-((d1 / mui) + (d0 / mus))));            // :368-370
+      const double att = exp(-a.tau_sum[n0] / mus);                                                               // :371-372
+      jp *= att;
+      jm *= att;
+    }
+    if (a.nd >= 1) jm = a.q.D[i % n] * jm;  // :374-376
+    const size_t o = i + (size_t)N * u;
+    a.ieJ0p[o] = jp;
+    a.ieJ0m[o] = jm;
+  }
+}
+
 // batched_mul / batch_inv! on ForwardDiff.Dual arrays (gpu_batched.jl:100-150): values [N,N,S] and P partials [N,N,S,P].
 //   mul:  C = A B,      dC_i = A dB_i + dA_i B          inv:  X = A^-1,   dX_i = -X dA_i X
 // One workgroup per batch item keeps the values in LDS (slab) while it walks the partials.
@@ -899,6 +987,51 @@ extern "C" int mom_batch_inv(mom_t *h, int n, int batch, const double *A, double
 }
 extern "C" int mom_batched_mul(mom_t *h, int n, int batch, const double *A, const double *B, double *C) {
   return blas_common(h, n, batch, A, B, C, false);
+}
+
+extern "C" int mom_elemental_inelastic_rrs(mom_t *h, int m, int ndoubl, int nRaman, const int *i_l1l0, const double *varpi_l1l0,
+                                           const double *fscattRayl, const double *tau_sum, const double *dtau,
+                                           const double *varpi, const double *Zpp_l1l0, const double *Zmp_l1l0,
+                                           double *ier_mp, double *iet_pp, double *ier_pm, double *iet_mm, double *ieJ0p,
+                                           double *ieJ0m) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_elemental_inelastic_rrs");
+  if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_elemental_inelastic_rrs: call mom_set_streams first");
+  if (m < 0 || ndoubl < 0 || nRaman <= 0 || !i_l1l0 || !varpi_l1l0 || !fscattRayl || !tau_sum || !dtau || !varpi ||
+      !Zpp_l1l0 || !Zmp_l1l0 || !ier_mp || !iet_pp || !ier_pm || !iet_mm || !ieJ0p || !ieJ0m)
+    return fail(h, MOM_EINVAL, "mom_elemental_inelastic_rrs: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int N = h->N;
+  const size_t S = h->S, NN = (size_t)N * N, big = NN * S * nRaman, vec = (size_t)N * S * nRaman;
+  double *buf = nullptr;
+  int *dI = nullptr;
+  HIPCHK(h, dmalloc(&buf, 4 * big + 2 * vec + nRaman + 4 * S + 2 * NN));
+  HIPCHK(h, dmalloc(&dI, (size_t)nRaman));
+  double *d_out = buf, *d_vp = buf + 4 * big + 2 * vec, *d_fs = d_vp + nRaman, *d_ts = d_fs + S, *d_dt = d_ts + S,
+         *d_w = d_dt + S, *d_zp = d_w + S, *d_zm = d_zp + NN;
+  HIPCHK(h, hipMemcpyAsync(dI, i_l1l0, nRaman * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_vp, varpi_l1l0, nRaman * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_fs, fscattRayl, S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_ts, tau_sum, S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_dt, dtau, S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_w, varpi, S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_zp, Zpp_l1l0, NN * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(d_zm, Zmp_l1l0, NN * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RrsArgs a{};
+  a.q = h->q; a.S = h->S; a.nR = nRaman; a.m = m; a.nd = ndoubl; a.strict = h->strict;
+  a.i_l1l0 = dI; a.varpi_l1l0 = d_vp; a.fscatt = d_fs; a.tau_sum = d_ts; a.dtau = d_dt; a.varpi = d_w; a.Zpp = d_zp; a.Zmp = d_zm;
+  a.ier_mp = d_out; a.iet_pp = d_out + big; a.ier_pm = d_out + 2 * big; a.iet_mm = d_out + 3 * big;
+  a.ieJ0p = d_out + 4 * big; a.ieJ0m = d_out + 4 * big + vec;
+  hipLaunchKernelGGL(k_elemental_rrs, dim3((unsigned)((big + 255) / 256)), dim3(256), 0, h->stream, a);
+  HIPCHK(h, hipGetLastError());
+  double *dst[6] = {ier_mp, iet_pp, ier_pm, iet_mm, ieJ0p, ieJ0m};
+  for (int k = 0; k < 4; ++k) HIPCHK(h, hipMemcpyAsync(dst[k], d_out + k * big, big * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dst[4], a.ieJ0p, vec * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dst[5], a.ieJ0m, vec * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  (void)hipFree(buf);
+  (void)hipFree(dI);
+  return MOM_OK;
 }
 
 static int dual_common(mom_t *h, int n, int batch, int P, const double *A, const double *dA, const double *B,

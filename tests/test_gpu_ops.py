@@ -175,6 +175,39 @@ def test_dual_batch_inv_and_mul(rtamd, n, batch, P):
         helpers.assert_op_close(dXg, abi(dXr), rtol=1e-10, what="dX")
 
 
+@pytest.mark.parametrize("nS,strict,nd,m", [(1, True, 0, 0), (3, True, 3, 1), (3, False, 0, 2), (4, True, 1, 0), (4, False, 5, 1)])
+def test_elemental_inelastic_rrs(rtamd, nS, strict, nd, m):
+    """elemental_inelastic!(::RRS) (elemental_inelastic.jl:23-91) through mom_elemental_inelastic_rrs against the numpy
+    restatement: Raman offsets of both signs (entries falling off the grid stay zero), equal and unequal elemental
+    optical thicknesses (both branches of the diagonal transmission), ndoubl = 0 (mirror operators by the D rule) and
+    >= 1 (row signs, D on ieJ0-)."""
+    rt = rtamd.corert
+    pol, q = _streams(rt, nS, Nquad=7)
+    N, S = len(q.qp_μN), 23
+    rng = np.random.default_rng(17 * nS + nd)
+    g = rtamd.scenes.hg_like_greek(0.5, 9)
+    Zpp, Zmp = rt.compute_Z_moments(pol, q.qp_μ, g, m)
+    dtau = 10.0 ** rng.uniform(-6, -2, S)
+    dtau[5:9] = dtau[5]                       # equal thicknesses: the |dtau0 - dtau1| <= 1e-6 branch also off n0 == n1
+    varpi, fscatt, tau_sum = rng.uniform(0.1, 1.0, S), rng.uniform(0.5, 1.0, S), rng.uniform(0.0, 2.0, S)
+    i_l, vp = np.array([-4, -1, 0, 2, 7]), rng.uniform(0.001, 0.05, 5)
+    mq = mr.QuadPoints(q.μ0, q.iμ0, pol.n * (q.iμ0 - 1) + 1, np.asarray(q.qp_μ), np.asarray(q.wt_μ), np.asarray(q.qp_μN),
+                       np.asarray(q.wt_μN), len(q.qp_μ))
+    ref = mr.elemental_inelastic_rrs(mr.pol_from_n(nS), mq, i_l, vp, fscatt, tau_sum, dtau, varpi, Zpp, Zmp, m, nd, strict)
+    with _handle(rtamd, pol, q, S, strict) as h:
+        got = h.elemental_inelastic_rrs(m, nd, i_l, vp, fscatt, tau_sum, dtau, varpi, mr.to_abi(Zpp[None]), mr.to_abi(Zmp[None]))
+    names = ["ier_mp", "iet_pp", "ier_pm", "iet_mm", "ieJ0p", "ieJ0m"]
+    for k, nm in enumerate(names):
+        if nd >= 1 and nm in ("ier_pm", "iet_mm"):
+            assert not np.any(got[k])           # untouched by the reference for ndoubl >= 1
+            continue
+        want = mr.to_abi(ref[k].reshape(-1, N, N)) if k < 4 else ref[k].reshape(-1)
+        assert np.any(want)
+        # differences of exponentials over 1 - dtau1/dtau0: one ulp of the device exp vs libm is amplified by the
+        # cancellation (same bar as the elastic per-operator tests: 1e-12 of the operator's largest element, here x10)
+        helpers.assert_op_close(got[k], want, rtol=1e-11, what=nm)
+
+
 def test_singular_operator_is_reported(rtamd):
     """The reference ignores cuBLAS `info` (gpu_batched.jl:65-70); here a zero pivot surfaces as MOM_ESINGULAR."""
     n, batch = 12, 4

@@ -207,3 +207,31 @@ def test_dual_operators_against_finite_differences():
         fdX = (mr.batch_inv(A + eps * dA[i]) - mr.batch_inv(A - eps * dA[i])) / (2 * eps)
         np.testing.assert_allclose(dC[i], fdC, rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(dX[i], fdX, rtol=1e-6, atol=1e-8)
+
+
+def test_rrs_elemental_restatement_elastic_limit(rtamd):
+    """elemental_inelastic.jl:93-160,320-382 restated in oracle/momref.py: with a zero Raman shift, unit Raman albedo and
+    unit Rayleigh fraction the inelastic single-scattering layer is the elastic one (elemental.jl:164-253) wherever the
+    two share an expression -- r-+ everywhere, t++ off the diagonal, j0- everywhere and j0+ off the solar rows.  (The
+    reference has no known-answer test for its Raman path: this limit is the restatement's only pin.)"""
+    rt = rtamd.corert
+    pol = rt.Stokes_IQU()
+    q = rt.rt_set_streams("GaussQuadHemisphere", 7, 50.0, [0.0, 30.0], pol)
+    N, S, m, nd = len(q.qp_μN), 9, 1, 2
+    rng = np.random.default_rng(3)
+    Zpp, Zmp = rt.compute_Z_moments(pol, q.qp_μ, rtamd.scenes.hg_like_greek(0.5, 7), m)
+    dtau, varpi, tau_sum = 10.0 ** rng.uniform(-5, -2, S), rng.uniform(0.1, 1.0, S), rng.uniform(0, 2, S)
+    mq = mr.QuadPoints(q.μ0, q.iμ0, pol.n * (q.iμ0 - 1) + 1, np.asarray(q.qp_μ), np.asarray(q.wt_μ), np.asarray(q.qp_μN),
+                       np.asarray(q.wt_μN), len(q.qp_μ))
+    mp = mr.pol_from_n(3)
+    ier, iet, _, _, jp, jm = mr.elemental_inelastic_rrs(mp, mq, [0], [1.0], np.ones(S), tau_sum, dtau, varpi, Zpp, Zmp, m, nd)
+    added = mr.make_added_layer(N, S)
+    mr.elemental(mp, mq, tau_sum, dtau, varpi, Zpp, Zmp, m, nd, added)
+    np.testing.assert_allclose(ier[0], added.r_mp, rtol=1e-12, atol=1e-300)
+    mu = np.asarray(q.qp_μN)
+    off = mu[:, None] != mu[None, :]
+    np.testing.assert_allclose(iet[0][:, off], added.t_pp[:, off], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(jm[0], added.j0m, rtol=1e-12, atol=1e-300)
+    i0 = pol.n * (q.iμ0 - 1)
+    rows = np.r_[0:i0, i0 + pol.n:N]
+    np.testing.assert_allclose(jp[0][:, rows], added.j0p[:, rows], rtol=1e-9, atol=1e-300)
