@@ -293,8 +293,8 @@ int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
  *                         not all fall into the same microseconds; 0 = all start together
  *   MOM_OPT_SMALL_N       1 (default) = operators of edge N <= 4 (with at most 4 view angles and 4 phase-matrix bases)
  *                         run the lane-per-spectral-point sweep kernel: the whole of mom_rt_run in one launch, all
- *                         operators in registers (csrc/mom_small.hip); edges 4 < N <= 32 (Lambertian scalar surface,
- *                         scattering in every layer after the first) the wave-per-spectral-point sweep kernel
+ *                         operators in registers (csrc/mom_small.hip); edges 4 < N <= 32 (scattering in every layer after the
+ *                         first, at most 256 view x Stokes outputs) the wave-per-spectral-point sweep kernel
  *                         (csrc/mom_wave.hip); 0 = the general workgroup-per-point kernels
  *   MOM_OPT_LAYER_SWEEP   1 (default) = one launch per problem size walks ALL layers of a (spectral point, moment)
  *                         unit before the next unit: the composite blocks stay in the storing CU's L2 between layers,

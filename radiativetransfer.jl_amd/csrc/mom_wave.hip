@@ -19,7 +19,7 @@
 // NT = 1 (N <= 16): two waves per SIMD; NT = 2 (N <= 32): one wave per SIMD (about 400 VGPRs).  k-steps are templated
 // on KS = ceil(N / 4): rows >= 4 KS of every tile are zero padding and are skipped.
 // Scope: ScatteringInterface_11 on every layer after the first (the host falls back to the general kernels otherwise),
-// LambertianSurfaceScalar, Float64.  Reference semantics and file:line as in mom_kernels.hpp / mom_small.hip.
+// all surface kinds of mom_scene_set_surface, up to 256 (view, Stokes) outputs per point, Float64.  Reference semantics and file:line as in mom_kernels.hpp / mom_small.hip.
 #include <hip/hip_runtime.h>
 
 #include "mom_host.hpp"
@@ -132,6 +132,10 @@ struct WArgs {
   const double *tau, *varpi, *zw, *tau_sum;  // [S,Nz], [S,Nz], [K,S,Nz], [S,Nz+1]
   double *R, *T, *hdr, *bhr_uw, *bhr_dw;
   int *info;
+  // surface (mom_scene_set_surface): 0 LambertianSurfaceScalar(albedo), 1 BRDF matrices Rsurf [N,N,M] (every moment),
+  // 2 LambertianSurfaceLegendre (albedo_spec [S]; j0+ = 0, T_SFI from m = 0 only: lambertian_surface.jl:112,131-132)
+  int surf_kind, pad2;
+  const double *Rsurf, *albedo_spec;
 };
 
 // per-lane coordinates; row / column quantities are read from the block's LDS table tab = mu[32] | wt[32] | sg[32]
@@ -389,9 +393,9 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
   const double mus = a.mu[i_start];
   int bad = 0;
   // accumulators of the outputs: lane x < nVza * nS handles (view v = x / nS, component k = x % nS)
-  double accR = 0.0, accT = 0.0, accH = 0.0;
-  const int xv = lane / nS, xk = lane - xv * nS;
-  const bool xok = lane < a.nVza * nS;
+  // outputs: lane x (+ 64 per pass) handles (view v = x / nS, component k = x % nS); the sums over the Fourier moments
+  // are kept in the output arrays themselves (one read-modify-write per moment: no registers held across the sweep)
+  const int nout = a.nVza * nS;
 
   for (int m = 0; m < a.M; ++m) {
     const double wdiv = (m == 0) ? 2.0 : 4.0, wct02 = (m == 0) ? 0.5 : 0.25;
@@ -510,9 +514,10 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
     Vec<NT> hdrJ;
 #pragma unroll
     for (int b = 0; b < NT; ++b) hdrJ.t[b] = (d4){0.0, 0.0, 0.0, 0.0};
-    if (m == 0) {
-      const double rho = 2 * a.albedo;
+    if (m == 0 || a.surf_kind == 1) {
+      const double rho = 2 * ((a.surf_kind == 2) ? a.albedo_spec[n] : a.albedo);  // lambertian_surface.jl:37 / :97
       const double att = exp(-a.tau_sum[n + (size_t)S * a.Nz] / a.mu0);
+      const double *Rs = a.Rsurf + (size_t)N * N * m;  // kind 1: rho_m [N,N] (rpv_surface.jl:39-43)
       Mat<NT> rs;
       Vec<NT> jv;
 #pragma unroll
@@ -523,12 +528,24 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
 #pragma unroll
           for (int bj = 0; bj < NT; ++bj) {
             const int j = L.col(bj);
-            const bool ok = i < N && j < N && (i % nS == 0) && (j % nS == 0);
-            rs.t[bi][bj][q] = ok ? rho * (L.mu(j) * L.wt(j)) : 0.0;  // r-+ = R_surf Diagonal(mu w)  (:41-43,:58)
+            const bool in = i < N && j < N;
+            double v;
+            if (a.surf_kind == 1) v = in ? Rs[i + (size_t)N * j] * (L.mu(j) * L.wt(j)) : 0.0;       // rpv_surface.jl:58-62
+            else v = (in && (i % nS == 0) && (j % nS == 0)) ? rho * (L.mu(j) * L.wt(j)) : 0.0;      // r-+ = R_surf Diagonal(mu w)  (:41-43,:58)
+            rs.t[bi][bj][q] = v;
           }
           const bool in_sun = (i >= i_start) && (i < i_end);
-          const double jp = (in_sun ? a.I0[i - i_start] : 0.0) * att;                     // :55
-          const double jm = (i % nS == 0) ? (a.mu0 * (rho * a.I0[0])) * att : 0.0;       // :56
+          double jp = (in_sun ? a.I0[i - i_start] : 0.0) * att;                           // :55
+          double jm = (i % nS == 0) ? (a.mu0 * (rho * a.I0[0])) * att : 0.0;             // :56
+          if (a.surf_kind == 1 && i < N) {                                                // j0- = mu0 (R_surf I0N) e^(-tau/mu0)  (rpv_surface.jl:48-56)
+            double rI = 0.0;
+            for (int k = 0; k < nS; ++k) rI += Rs[i + (size_t)N * (i_start + k)] * a.I0[k];
+            jm = (a.mu0 * rI) * att;
+          }
+          if (a.surf_kind == 2) {                                                         // lambertian_surface.jl:112-114
+            jp = 0.0;
+            jm = (i % nS == 0) ? (a.mu0 * a.I0[0]) * (rho * att) : 0.0;
+          }
           jv.t[bi][q] = !(i < N) ? 0.0 : (L.lr == 0 ? jp : (L.lr == 1 ? jm : 0.0));
         }
       const Mat<NT> rsT = interact11<NT, KS, true>(L, C, rs, rs, jv, a.inv_mode, bad);  // (t operand unused)
@@ -539,8 +556,8 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
       for (int b = 0; b < NT; ++b)
 #pragma unroll
         for (int q = 0; q < 4; ++q) hdrJ.t[b][q] = (L.lr == 0) ? rJ.t[b][q] + jsw.t[b][q] : 0.0;
-      // BHR flux sums over the streams of each Stokes component (column-0 lanes hold hdr_J0- and J0+)
-      for (int k = 0; k < nS; ++k) {
+      // BHR flux sums over the streams of each Stokes component (column-0 lanes hold hdr_J0- and J0+), m = 0 only
+      for (int k = 0; k < (m == 0 ? nS : 0); ++k) {
         double up = 0.0, dw = 0.0;
 #pragma unroll
         for (int b = 0; b < NT; ++b)
@@ -555,7 +572,7 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
         up = wave_sum(up);
         dw = wave_sum(dw);
         // + j0+_surf[i_start] mu[i_start]: the direct beam (interaction_hdrf.jl:30)
-        const double direct = a.I0[0] * att * mus;
+        const double direct = ((a.surf_kind == 2) ? 0.0 : a.I0[0] * att) * mus;  // j0+_surf[i_start] mu[i_start]
         if (lane == 0) {
           a.bhr_uw[k + (size_t)nS * n] = up;
           a.bhr_dw[k + (size_t)nS * n] = dw + direct;
@@ -572,21 +589,19 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
         if (L.lr == 1) post[16 * NT + i] = C.Jv.t[b][q];
       }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (xok) {
+    for (int x = lane; x < nout; x += 64) {
+      const int xv = x / nS, xk = x - xv * nS;
       const double weight = (m == 0) ? 0.5 : 1.0;
       const double cs = weight * ((xk < 2) ? a.cos_mphi[xv + a.nVza * m] : a.sin_mphi[xv + a.nVza * m]);
       const int row = (a.node[xv] - 1) * nS + xk;
-      accT += cs * post[row];
-      accR += cs * post[16 * NT + row];
-      if (m == 0) accH = cs * post[32 * NT + row];
+      const size_t idx = xv + (size_t)a.nVza * xk + (size_t)nout * n;  // [nVza, nStokes, S]
+      const double tv = (a.surf_kind == 2 && m > 0) ? 0.0 : cs * post[row];  // Legendre surface: t = 0 for m > 0
+      const double hv = (m == 0 || a.surf_kind == 1) ? cs * post[32 * NT + row] : 0.0;  // BRDF surfaces: hdr over all moments
+      a.T[idx] = (m == 0) ? tv : a.T[idx] + tv;
+      a.R[idx] = (m == 0) ? cs * post[16 * NT + row] : a.R[idx] + cs * post[16 * NT + row];
+      a.hdr[idx] = (m == 0) ? hv : a.hdr[idx] + hv;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  }
-  if (xok) {
-    const size_t idx = xv + (size_t)a.nVza * (xk + (size_t)nS * n);
-    a.R[idx] = accR;
-    a.T[idx] = accT;
-    a.hdr[idx] = accH;
   }
   if (bad && lane == 0) atomicMax(a.info, bad);
 }

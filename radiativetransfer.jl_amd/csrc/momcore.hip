@@ -1349,11 +1349,13 @@ struct WaveSweepArgs {
   const double *tau, *varpi, *zw, *tau_sum;
   double *R, *T, *hdr, *bhr_uw, *bhr_dw;
   int *info;
+  int surf_kind, pad2;
+  const double *Rsurf, *albedo_spec;
 };
 
 // the wave-per-point kernel covers ScatteringInterface_11 on every layer after the first and at the surface
 static bool wave_sweep_applies(const mom_t *h) {
-  if (!(h->N > 4 && h->N <= 32 && h->opt_small && !h->opt_force_generic && h->surf_kind == 0 && h->nVza * h->nS <= 64)) return false;
+  if (!(h->N > 4 && h->N <= 32 && h->opt_small && !h->opt_force_generic && h->nVza * h->nS <= 256)) return false;
   for (int z = 1; z < h->Nz; ++z)
     if (h->iface[z] != 3) return false;
   return h->iface[h->Nz - 1] == 3;
@@ -1378,6 +1380,7 @@ static int rt_run_wave(mom_t *h) {
   a.tau = h->d_tau; a.varpi = h->d_varpi; a.zw = h->d_zw; a.tau_sum = h->d_tau_sum;
   a.R = h->d_R; a.T = h->d_T; a.hdr = h->d_hdr; a.bhr_uw = h->d_bhr_uw; a.bhr_dw = h->d_bhr_dw;
   a.info = h->d_info;
+  a.surf_kind = h->surf_kind; a.Rsurf = h->d_Rsurf; a.albedo_spec = h->d_albedo_spec;
   while (h->ev_full.size() < 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_full.push_back(e); }
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   HIPCHK(h, hipEventRecord(h->ev_full[0], h->stream));

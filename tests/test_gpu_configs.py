@@ -114,6 +114,33 @@ def test_wave_per_point_sweep_kernel(rtamd, cref, nS, lt, vza, kw, inverse):
         np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=1e-300)
 
 
+@pytest.mark.parametrize("surf", ["rpv", "rossli", "legendre"])
+@pytest.mark.parametrize("nS,lt", [(3, 3), (4, 7)])
+def test_wave_kernel_surfaces_and_many_views(rtamd, cref, surf, nS, lt):
+    """RAMI-style scenes on the wave-per-point kernel: BRDF surfaces (a surface interaction and hdr for every moment),
+    LambertianSurfaceLegendre (spectral albedo, its j0+ = 0 and T_SFI from m = 0 only) and 30 view directions (90 / 120
+    outputs per point: more than one pass of the wave over the output list), N = 15 (1 x 1 tiles) and N = 28 (2 x 2)."""
+    rt = rtamd.corert
+    vza = (0.0, 40.0) * 15      # two view zenith angles (two extra streams), 30 azimuths
+    m = rtamd.scenes.make_scene(nS, lt, 5, 40, seed=29, vza=vza, vaz=tuple(np.linspace(0.0, 350.0, 30)))
+    m.params.brdf = {"rpv": rt.rpvSurfaceScalar(0.1, 0.8, 0.7, -0.1), "rossli": rt.RossLiSurfaceScalar(0.1, 0.05, 0.2),
+                     "legendre": rt.LambertianSurfaceLegendre((0.2, 0.05, -0.02))}[surf]
+    sc = rtamd.prepare_scene(m)
+    assert 4 < sc.N <= 32 and len(vza) * nS > 64
+    Rr, Tr, Hr, upr, dwr, info = cref.rt_run_full(cref.pack_scene(helpers.oracle_scene(m)))
+    assert info == 0
+    with rt.make_handle(m) as h:
+        R, T = rt.run_scene(h, sc)
+        H, up, dw = h.get_hdr()
+        assert h.timers()["layer_launches"] == 1
+    tol = helpers.stokes_rtol(sc.ndoubl)
+    helpers.assert_stokes_close(R, Rr, rtol=tol, what="R")
+    helpers.assert_stokes_close(T, Tr, rtol=tol, what="T")
+    helpers.assert_stokes_close(H, Hr, rtol=tol, what="hdr")
+    np.testing.assert_allclose(up, upr, rtol=max(tol, 1e-10), atol=1e-300)
+    np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=1e-300)
+
+
 def test_wave_kernel_falls_back_on_other_interfaces(rtamd, cref):
     """Layers without scattering above the first scattering layer give interface codes other than 11: the wave-per-point
     kernel does not apply and the general kernels run."""
