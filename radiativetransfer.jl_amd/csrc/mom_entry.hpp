@@ -82,7 +82,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
     for (int z = 0; z < nz; ++z) {
       const int nd = a.Nz_sweep > 0 ? a.nd_z[z] : a.nd;
       const int iface = a.Nz_sweep > 0 ? a.iface_z[z] : a.iface;
-      const bool first = a.Nz_sweep > 0 ? (z == 0) : (a.first != 0);
+      // first layer of a slab: the added layer becomes the composite (rt_kernel.jl:227-230); a sweep that CONTINUES a
+      // composite already in memory (multi-sensor top slabs, a.first = 0) interacts from its first layer on
+      const bool first = (a.Nz_sweep > 0 ? (z == 0) : true) && (a.first != 0);
       const size_t zo = (size_t)a.S * z;
       const real tau = as_global(a.tau)[n + zo], varpi = as_global(a.varpi)[n + zo];
       const real dtau = ldexp(tau, -nd);         // τ ./ 2^ndoubl   (rt_kernel.jl:244)

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include <rccl/rccl.h>  // types and enums only: the library itself is dlopen'ed by mom_comm_init
@@ -1398,7 +1399,8 @@ static int rt_run_wave(mom_t *h) {
 // the m = 0 sub-problem keeps its own arrays and is used only when allow_red): layer kernels, then (do_surface) the
 // surface layer with its closing interaction, then (do_post) the azimuthal post-processing into d_R / d_T / d_hdr.
 // mom_rt_run: the whole column; mom_rt_run_multisensor: the slabs above and below a sensor.
-static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const compF[6], bool do_surface, bool do_post) {
+static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const compF[6], bool do_surface, bool do_post,
+                       bool cont = false) {
   const size_t S = h->S;
   const int M = h->scene_M;
   const bool red0 = h->red0 && allow_red;
@@ -1410,8 +1412,10 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
   // one k_layer launch over `Mcount` moments starting at `m_first` with stream set `q` (full or reduced)
   // sweep mode: every layer of a unit inside one launch (z < 0 selects it); needs one interface code for all z >= 1
   // (the code is a template argument of the kernel images) -- always the case once scattering has set in
+  // cont: the slab continues the composite state already in compF (its first layer interacts like the others)
   bool can_sweep = h->opt_sweep && nzr <= kMaxSweepLayers && nzr > 1;
   for (int z = za + 2; z < zb && can_sweep; ++z) can_sweep = (h->iface[z] == h->iface[za + 1]);
+  if (cont && can_sweep) can_sweep = (h->iface[za] == h->iface[za + 1]);
   for (int z = za; z < zb && can_sweep; ++z) can_sweep = (h->nd[z] <= 127);
   auto launch_layer = [&](int z, const DevStreams &q, int m_first, int Mcount, const double *Zpp, const double *Zmp,
                           double *const comp[6], double *scratch) -> int {
@@ -1423,9 +1427,9 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
       a.Nz_sweep = nzr;
       int ndsum = 0;
       for (int k = 0; k < nzr; ++k) { a.nd_z[k] = (signed char)h->nd[za + k]; a.iface_z[k] = (signed char)h->iface[za + k]; ndsum += h->nd[za + k]; }
-      a.nd = ndsum / nzr; a.iface = h->iface[za + 1]; a.first = 1;
+      a.nd = ndsum / nzr; a.iface = h->iface[za + 1]; a.first = cont ? 0 : 1;
     } else {
-      a.nd = h->nd[z]; a.iface = h->iface[z]; a.first = (z == za);
+      a.nd = h->nd[z]; a.iface = h->iface[z]; a.first = (z == za) && !cont;
     }
     a.tau = h->d_tau + S * z; a.varpi = h->d_varpi + S * z; a.zw = h->d_zw + (size_t)h->K * S * z;
     a.tau_sum = h->d_tau_sum + S * z;
@@ -1556,7 +1560,7 @@ extern "C" int mom_rt_run(mom_t *h) {
 }
 
 // rt_run_test_ms(::noRS, sensor_levels, model, iBand) (rt_run_multisensor.jl:14-191).  Sensors are processed one after
-// the other with two composite states: the slab above the sensor (layers 1..L) and the slab below it (layers L+1..Nz and
+// the other (in order of depth) with two composite states: the slab above the sensor (layers 1..L) and the slab below it (layers L+1..Nz and
 // the surface), each built by the same fused layer kernels as mom_rt_run (sweep mode, strip chains, padded edges), then
 // k_interlayer and the azimuthal post-processing of the interface fields.  The m = 0 (I,Q) reduction is not used here
 // (the interface fields couple two states of the full problem); level 0 is mom_rt_run itself.
@@ -1589,13 +1593,23 @@ extern "C" int mom_rt_run_multisensor(mom_t *h, int nSensors, const int *sensor_
     h->ms_out_cap = 2 * out1 * nSensors;
   }
   double *d_uw = h->d_ms_out, *d_dw = h->d_ms_out + out1 * nSensors;
-  for (int ims = 0; ims < nSensors; ++ims) {
+  // sensors in order of depth: the slab above sensor k+1 continues the slab above sensor k (layers 1..L are a prefix),
+  // so all top slabs together cost ONE sweep down to the deepest sensor; each bottom slab is its own sweep
+  std::vector<int> order(nSensors);
+  for (int i = 0; i < nSensors; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sensor_levels[x] < sensor_levels[y]; });
+  int top_done = 0;  // layers [0, top_done) are in comp_top
+  for (int io = 0; io < nSensors; ++io) {
+    const int ims = order[io];
     const int L = sensor_levels[ims];
     int rc;
     if (L == 0) {  // the TOA/BOA pair: uwJ = R_SFI, dwJ = T_SFI of the whole column (postprocessing_vza_ms.jl:34-36)
       if ((rc = rt_run_core(h, 0, h->Nz, false, h->comp, true, true))) return rc;
     } else {
-      if ((rc = rt_run_core(h, 0, L, false, h->comp_top, false, false))) return rc;
+      if (L > top_done) {
+        if ((rc = rt_run_core(h, top_done, L, false, h->comp_top, false, false, top_done > 0))) return rc;
+        top_done = L;
+      }
       if ((rc = rt_run_core(h, L, h->Nz, false, h->comp, true, false))) return rc;
       InterArgs a{};
       a.q = h->qk; a.S = h->S; a.M = M;
