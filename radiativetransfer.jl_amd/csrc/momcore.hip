@@ -500,6 +500,7 @@ struct mom_handle {
   int opt_small = 1;       // N <= 4: lane-per-point sweep kernel (mom_small.hip)
   double *d_smtab = nullptr;  // F1 | F2 | SI tables [3][N,N]
   int *d_ndif = nullptr;      // ndoubl | iface [2][Nz]
+  size_t ndif_cap = 0;
   bool red0 = false;
   int N0 = 0, nS0 = 0;
   DevStreams q0{};
@@ -1308,8 +1309,11 @@ static int rt_run_small(mom_t *h) {
     HIPCHK(h, hipMemcpyAsync(h->d_smtab, tab, sizeof tab, hipMemcpyHostToDevice, h->stream));
   }
   {
-    if (h->d_ndif) { (void)hipFree(h->d_ndif); h->d_ndif = nullptr; }
-    HIPCHK(h, dmalloc(&h->d_ndif, 2 * (size_t)Nz));
+    if (h->ndif_cap < 2 * (size_t)Nz) {  // no allocation in steady state
+      if (h->d_ndif) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_ndif); h->d_ndif = nullptr; }
+      HIPCHK(h, dmalloc(&h->d_ndif, 2 * (size_t)Nz));
+      h->ndif_cap = 2 * (size_t)Nz;
+    }
     std::vector<int> v(h->nd);
     v.insert(v.end(), h->iface.begin(), h->iface.end());
     HIPCHK(h, hipMemcpyAsync(h->d_ndif, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -1366,8 +1370,11 @@ static bool wave_sweep_applies(const mom_t *h) {
 static int rt_run_wave(mom_t *h) {
   const int Nz = h->Nz;
   {
-    if (h->d_ndif) { (void)hipFree(h->d_ndif); h->d_ndif = nullptr; }
-    HIPCHK(h, dmalloc(&h->d_ndif, (size_t)Nz));
+    if (h->ndif_cap < 2 * (size_t)Nz) {  // no allocation in steady state
+      if (h->d_ndif) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_ndif); h->d_ndif = nullptr; }
+      HIPCHK(h, dmalloc(&h->d_ndif, 2 * (size_t)Nz));
+      h->ndif_cap = 2 * (size_t)Nz;
+    }
     HIPCHK(h, hipMemcpyAsync(h->d_ndif, h->nd.data(), (size_t)Nz * sizeof(int), hipMemcpyHostToDevice, h->stream));
   }
   WaveSweepArgs a{};
