@@ -23,7 +23,8 @@
  *     parameters_from_yaml.jl:160): operators, sources and products in f32 on the GPU.  The ABI keeps Float64 host
  *     arrays for both (inputs are rounded on upload, outputs widened on download).  A Float32 handle supports the
  *     scene-level path -- mom_set_streams, mom_scene_set, mom_scene_set_surface, mom_set_option, mom_rt_run,
- *     mom_get_RT, mom_get_hdr, mom_timers, mom_sync, mom_check -- every other entry point returns MOM_EINVAL on it.
+ *     mom_get_RT, mom_get_hdr, mom_timers, mom_sync, mom_check -- and the two batched operators mom_batch_inv /
+ *     mom_batched_mul (gpu_batched.jl:45-58); every other entry point returns MOM_EINVAL on it.
  */
 #ifndef MOMCORE_H
 #define MOMCORE_H

@@ -434,6 +434,7 @@ int momf_rt_run(momf_scene *s);
 int momf_get_RT(momf_scene *s, double *R, double *T);
 int momf_get_hdr(momf_scene *s, double *hdr, double *up, double *dw);
 int momf_timers(momf_scene *s, double *ms, int *launches);
+int momf_blas(momf_scene *s, int n, int batch, const double *A, const double *B, double *C, bool inv);
 // mom_small.hip: N <= 4, one spectral point per lane, the whole sweep in one launch
 hipError_t momsm_launch_sweep(const void *args, int N, hipStream_t st);
 hipError_t momw_launch_sweep(const void *args, hipStream_t st);
@@ -947,9 +948,13 @@ extern "C" int mom_download(mom_t *h, int which, double *dst) {
 
 static int blas_common(mom_t *h, int n, int batch, const double *A, const double *B, double *C, bool inv) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_batch_inv / mom_batched_mul");
   if (n <= 0 || batch <= 0 || !A || !C || (!inv && !B)) return fail(h, MOM_EINVAL, "batched op: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->f32) {  // Float32 handle: the f32 build's kernels (gpu_batched.jl:45-58)
+    const int rc = momf_blas(h->f32, n, batch, A, B, C, inv);
+    if (rc) return fail(h, rc, momf_error(h->f32));
+    return inv ? check_info(h) : MOM_OK;
+  }
   const size_t cnt = (size_t)n * n * batch;
   double *dA = nullptr, *dB = nullptr, *dC = nullptr, *scr = nullptr;
   HIPCHK(h, dmalloc(&dA, cnt));

@@ -66,6 +66,54 @@ __global__ void k_postprocess_f32(PostArgsF a) {
 template <class T>
 hipError_t dmallocf(T **p, size_t count) { return hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T)); }
 
+// batch_inv! / batched_mul for Float32 arrays (gpu_batched.jl:45-58, 90-97: cuBLAS Sgetrf/Sgetri, Sgemm)
+struct BlasArgsF {
+  int N, S;
+  const float *A, *B;
+  float *C;
+  float *scratch;
+  int *info;
+};
+
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads) k_batch_inv_f32(BlasArgsF a) {
+  const int N = a.N;
+  Ctx c;
+  make_ctx<LDSM>(c, N, 1, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
+  zero_padding<LDSM>(c);
+  if (threadIdx.x == 0) *c.bad = 0;
+  __syncthreads();
+  const size_t NN = (size_t)N * N;
+  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
+    wg_copy_mat(N, c.fd, a.A + NN * pt, N, c.P, c.ld);
+    __syncthreads();
+    if (N <= 64) wg_inverse_reg(N, c.P, c.ld, c.part, c.prow, c.ipiv, c.bad);
+    else wg_inverse(N, c.fd, c.P, c.ld, c.prow, c.pcol, c.rowk, c.ipiv, c.sh, c.bad);
+    wg_copy_mat(N, c.fd, c.P, c.ld, a.C + NN * pt, N);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
+}
+
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads) k_batched_mul_f32(BlasArgsF a) {
+  const int N = a.N;
+  Ctx c;
+  make_ctx<LDSM>(c, N, 1, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
+  zero_padding<LDSM>(c);
+  __syncthreads();
+  const size_t NN = (size_t)N * N;
+  const int ld = c.ld;
+  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
+    wg_copy_mat(N, c.fd, a.A + NN * pt, N, c.P, ld);
+    wg_copy_mat(N, c.fd, a.B + NN * pt, N, c.Q, ld);
+    __syncthreads();
+    float *C = a.C + NN * pt;
+    wg_gemm<false>(N, ElP{c.P, ld}, ElP{c.Q, ld}, [=](int i, int j, float v) { C[i + (size_t)j * N] = v; });
+    __syncthreads();
+  }
+}
+
 std::vector<float> tof(const double *src, size_t n) {
   std::vector<float> v(n);
   for (size_t i = 0; i < n; ++i) v[i] = (float)src[i];
@@ -345,4 +393,37 @@ int momf_timers(momf_scene *s, double *ms, int *launches) {
   ms[0] = t01; ms[1] = t12; ms[2] = t23; ms[3] = t03;
   *launches = s->launches;
   return MOM_OK;
+}
+
+// batch_inv!(X, A) / A ⊠ B on a Float32 handle: Float64 host arrays at the ABI, f32 on the device
+int momf_blas(momf_scene *s, int n, int batch, const double *A, const double *B, double *C, bool inv) {
+  FCHK(s, hipSetDevice(s->device));
+  const size_t cnt = (size_t)n * n * batch;
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr, *scr = nullptr;
+  int rc;
+  if ((rc = upload_f(s, &dA, A, cnt))) return rc;
+  if (!inv && (rc = upload_f(s, &dB, B, cnt))) return rc;
+  FCHK(s, dmallocf(&dC, cnt));
+  const bool lds = n <= 64 && !s->force_generic;
+  const int grid = lds ? batch : std::min(batch, 1024);
+  if (!lds) {
+    const size_t scn = (size_t)grid * kGenericBufs * mat_elems(n) + (size_t)ld_for(n) * np_for(n);
+    FCHK(s, dmallocf(&scr, scn));
+    FCHK(s, hipMemsetAsync(scr, 0, scn * sizeof(float), s->stream));
+  }
+  BlasArgsF a{n, batch, dA, dB, dC, scr, s->d_info};
+  const size_t sm = lds_bytes(n, lds);
+  if (inv) {
+    if (lds) { FCHK(s, allow(k_batch_inv_f32<true>, sm)); hipLaunchKernelGGL(k_batch_inv_f32<true>, dim3(grid), dim3(kThreads), sm, s->stream, a); }
+    else { FCHK(s, allow(k_batch_inv_f32<false>, sm)); hipLaunchKernelGGL(k_batch_inv_f32<false>, dim3(grid), dim3(kThreads), sm, s->stream, a); }
+  } else {
+    if (lds) { FCHK(s, allow(k_batched_mul_f32<true>, sm)); hipLaunchKernelGGL(k_batched_mul_f32<true>, dim3(grid), dim3(kThreads), sm, s->stream, a); }
+    else { FCHK(s, allow(k_batched_mul_f32<false>, sm)); hipLaunchKernelGGL(k_batched_mul_f32<false>, dim3(grid), dim3(kThreads), sm, s->stream, a); }
+  }
+  FCHK(s, hipGetLastError());
+  rc = download_f(s, C, dC, cnt);
+  (void)hipFree(dA); (void)hipFree(dC);
+  if (dB) (void)hipFree(dB);
+  if (scr) (void)hipFree(scr);
+  return rc;
 }

@@ -208,6 +208,20 @@ def test_elemental_inelastic_rrs(rtamd, nS, strict, nd, m):
         helpers.assert_op_close(got[k], want, rtol=1e-11, what=nm)
 
 
+@pytest.mark.parametrize("n,batch", [(32, 200), (60, 16), (100, 4)])
+def test_batch_inv_and_mul_float32(rtamd, n, batch):
+    """batch_inv! / batched_mul on Float32 arrays (gpu_batched.jl:45-58, 90-97) through a dtype = 1 handle: f32 MFMA
+    products and the pivoted inverse in f32, Float64 host arrays at the ABI."""
+    rng = np.random.default_rng(n)
+    A = (rng.normal(size=(batch, n, n)) + 4 * np.sqrt(n) * np.eye(n)).astype(np.float32).astype(np.float64)
+    B = rng.normal(size=(batch, n, n)).astype(np.float32).astype(np.float64)
+    with rtamd.Handle(4, 1, 1, 1, dtype=1) as h:
+        X = h.batch_inv(n, batch, mr.to_abi(A))
+        Cg = h.batched_mul(n, batch, mr.to_abi(A), mr.to_abi(B))
+    helpers.assert_op_close(X, mr.to_abi(np.linalg.inv(A)), rtol=2e-5, what="batch_inv f32")
+    helpers.assert_op_close(Cg, mr.to_abi(A @ B), rtol=2e-6, what="batched_mul f32")
+
+
 def test_singular_operator_is_reported(rtamd):
     """The reference ignores cuBLAS `info` (gpu_batched.jl:65-70); here a zero pivot surfaces as MOM_ESINGULAR."""
     n, batch = 12, 4
