@@ -17,11 +17,14 @@ CASES = [(1, 3, 200000), (1, 9, 20000), (3, 3, 20000), (4, 3, 20000), (1, 21, 20
          (3, 29, 4096), (4, 21, 4096), (3, 31, 4096), (3, 33, 4096), (4, 23, 4096), (3, 35, 4096), (4, 25, 4096),
          (3, 37, 2048), (3, 49, 2048), (4, 41, 1024), (4, 57, 1024), (4, 65, 512), (4, 85, 512), (4, 121, 256)]
 
+only = {int(x) for x in os.environ.get("MOM_SWEEP_ONLY", "").split(",") if x}  # operator edges to keep (default: all)
 print(f"{'nStokes':>7} {'N':>4} {'S':>7} {'ms':>9} {'points/s':>11} {'TFLOP/s':>8} {'of FP64 peak':>12}  kernel path")
 for nS, lt, S in CASES:
     m = rtamd.scenes.make_scene(nS, lt, 20, S, vza=(0.0, 30.0), vaz=(0.0, 20.0))
     sc = rtamd.prepare_scene(m)
     N = sc.N
+    if only and N not in only:
+        continue
     with rtamd.corert.make_handle(m) as h:
         rtamd.corert.run_scene(h, sc)
         t0 = time.time()
