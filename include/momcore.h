@@ -42,7 +42,8 @@ enum {
   MOM_EINVAL = -1,   /* bad argument */
   MOM_EHIP = -2,     /* HIP runtime error (no device, launch failure, OOM ...) */
   MOM_ESTATE = -3,   /* call sequence error (e.g. streams not set) */
-  MOM_ESINGULAR = -4 /* an (I - R r) operator was numerically singular (zero pivot) */
+  MOM_ESINGULAR = -4, /* an (I - R r) operator was numerically singular (zero pivot) */
+  MOM_EUNSUPPORTED = -5 /* the reference itself raises on this path (RRS strict position), or outside the built scope */
 };
 
 /* which-codes for mom_upload / mom_download (AddedLayer / CompositeLayer fields,
@@ -114,12 +115,66 @@ int mom_surface_lambertian(mom_t *h, int m, double albedo, const double *tau_tot
  * :384-402).  i_l1l0 [nRaman]: grid offsets n₀ - n₁ of the Raman lines (RS_type.i_λ₁λ₀), varpi_l1l0 [nRaman], fscattRayl,
  * tau_sum, dtau, varpi [nSpec], Z*_l1l0 [N,N].  Outputs (host): ier⁻⁺, iet⁺⁺, ier⁺⁻, iet⁻⁻ [N,N,nSpec,nRaman], ieJ₀⁺, ieJ₀⁻
  * [N,nSpec,nRaman] (Julia [N,1,nSpec,nRaman]).  For ndoubl >= 1 the reference leaves ier⁺⁻ / iet⁻⁻ untouched (they are
- * filled after doubling); zeros are returned.  This is the ONLY piece of the RRS path (BASELINE config 5) that is built:
- * see DESIGN.md section 7 for why doubling_inelastic! / interaction_inelastic! are not. */
+ * filled after doubling); zeros are returned.  Stateless form (fresh arrays in, host arrays out); the stateful RRS path
+ * below (mom_rrs_*) keeps the reference's persistent AddedLayerRS instead. */
 int mom_elemental_inelastic_rrs(mom_t *h, int m, int ndoubl, int nRaman, const int *i_l1l0, const double *varpi_l1l0,
                                 const double *fscattRayl, const double *tau_sum, const double *dtau, const double *varpi,
                                 const double *Zpp_l1l0, const double *Zmp_l1l0, double *ier_mp, double *iet_pp,
                                 double *ier_pm, double *iet_mm, double *ieJ0p, double *ieJ0m);
+
+/* ---- rotational-Raman scattering (BASELINE config 5): rt_run(RS_type::RRS, model, iBand) ---------------------------
+ *
+ * The reference's inelastic branch keeps, next to the elastic layers, the 4-D operators ier-+, ier+-, iet++, iet--
+ * [N,N,nSpec,nRaman] and sources ieJ0+-[N,1,nSpec,nRaman] of the added layer and ieR-+, ieR+-, ieT++, ieT--, ieJ0+- of the
+ * composite layer (AddedLayerRS / CompositeLayerRS, src/CoreRT/types.jl:145-205): element [.., n1, dn] takes radiation
+ * from spectral index n0 = n1 + i_l1l0[dn] to n1.  These layers persist over layers and Fourier moments exactly like the
+ * reference's (rt_run.jl:108-116), in the reference's memory order.
+ *
+ *   mom_rrs_set        the fields of the RRS struct (src/Inelastic/types.jl:13-33) the path reads: i_l1l0 [nRaman] (grid
+ *                      offsets n0 - n1, |offset| < nSpec), varpi_l1l0 [nRaman]; allocates the layers (zeros, like
+ *                      make_added_layer(::RRS, ...) rt_helper_functions.jl:127-141).  N <= 32.
+ *                      rrs_strict_reference: the reference's RRS text has defects (DESIGN.md "RRS", D1..D5); != 0 executes
+ *                      it AS WRITTEN with the semantics of a single-threaded Julia run -- and returns MOM_EUNSUPPORTED
+ *                      where the reference raises (interaction_helper! for interfaces 00/01/10, a MethodError) --,
+ *                      0 applies the five documented corrections and nothing else.
+ *   mom_rrs_elemental  rt_kernel!(::RRS) rt_kernel.jl:277-304: elemental_inelastic!(RS_type, pol_type, SFI, tau_sum, dtau, varpi,
+ *                      Z++_l1l0, Z-+_l1l0, m, ndoubl, scatter, quad_points, added_layer, I_static, architecture)
+ *                      (CoreKernel/elemental_inelastic.jl:23-91) followed by elemental!(...) (elemental.jl:109-162) on the
+ *                      persistent added layer.  tau_sum, dtau, varpi, fscattRayl [nSpec]; Z* [N,N] (one phase matrix).
+ *   mom_rrs_doubling   doubling_inelastic!(RS_type, pol_type, SFI, expk, ndoubl, added_layer, I_static, architecture)
+ *                      (CoreKernel/doubling_inelastic.jl:13-134, 263-280); expk [nSpec] updated in place.
+ *   mom_rrs_interaction  interaction!(RS_type::RRS, scattering_interface, SFI, composite_layer, added_layer, I_static)
+ *                      (CoreKernel/interaction_inelastic.jl:464-472 -> :8-340); with_surface_layer != 0 uses added_layer_surface,
+ *                      whose ie* arrays the reference never writes (zeros).
+ *   mom_rrs_copy_added_to_composite   rt_kernel.jl:326-333 (iz == 1), all twelve arrays.
+ *   mom_rrs_surface_lambertian        create_surface_layer!(::LambertianSurfaceScalar) into added_layer_surface.
+ *   mom_rrs_upload / mom_rrs_download  test access; which = MOM_ADDED_* / MOM_COMP_* / MOM_SURF_* for the elastic fields of the RRS
+ *                      layers, MOM_IE_ADDED_* / MOM_IE_COMP_* for the 4-D fields ([N,N,nSpec,nRaman] / [N,nSpec,nRaman]).
+ *   mom_scene_set_rrs  scene-level inputs on top of mom_scene_set: fscattRayl [nSpec, Nz] (fScattRayleigh of
+ *                      constructCoreOpticalProperties, compEffectiveLayerProperties.jl:58, expanded per band), Z*_l1l0 [N,N,M]
+ *                      (computeRamanZlambda!, src/Inelastic/inelastic_helper.jl:457-464, per Fourier moment).
+ *   mom_rt_run_rrs     rt_run.jl:125-215 with RS_type::RRS for the resident scene (LambertianSurfaceScalar); asynchronous.
+ *   mom_get_RT_rrs     R_SFI, T_SFI, ieR_SFI, ieT_SFI [nVza, nStokes, nSpec] (postprocessing_vza!(::RRS),
+ *                      tools/postprocessing_vza.jl:95-147); any pointer may be NULL; gpu_ms (optional) = GPU time of the run. */
+enum {
+  MOM_IE_ADDED_R_PM = 18, MOM_IE_ADDED_R_MP = 19, MOM_IE_ADDED_T_MM = 20, MOM_IE_ADDED_T_PP = 21,
+  MOM_IE_ADDED_J0P = 22, MOM_IE_ADDED_J0M = 23,
+  MOM_IE_COMP_R_MP = 24, MOM_IE_COMP_R_PM = 25, MOM_IE_COMP_T_PP = 26, MOM_IE_COMP_T_MM = 27,
+  MOM_IE_COMP_J0P = 28, MOM_IE_COMP_J0M = 29
+};
+int mom_rrs_set(mom_t *h, int nRaman, const int *i_l1l0, const double *varpi_l1l0, int rrs_strict_reference);
+int mom_rrs_elemental(mom_t *h, int m, int ndoubl, const double *tau_sum, const double *dtau, const double *varpi,
+                      const double *Zpp, const double *Zmp, const double *fscattRayl, const double *Zpp_l1l0,
+                      const double *Zmp_l1l0);
+int mom_rrs_doubling(mom_t *h, int ndoubl, double *expk);
+int mom_rrs_interaction(mom_t *h, int iface, int with_surface_layer);
+int mom_rrs_copy_added_to_composite(mom_t *h);
+int mom_rrs_surface_lambertian(mom_t *h, int m, double albedo, const double *tau_tot);
+int mom_rrs_upload(mom_t *h, int which, const double *src);
+int mom_rrs_download(mom_t *h, int which, double *dst);
+int mom_scene_set_rrs(mom_t *h, const double *fscattRayl, const double *Zpp_l1l0, const double *Zmp_l1l0);
+int mom_rt_run_rrs(mom_t *h);
+int mom_get_RT_rrs(mom_t *h, double *R_SFI, double *T_SFI, double *ieR_SFI, double *ieT_SFI, double *gpu_ms);
 
 /* batch_inv!(X, A) -- gpu_batched.jl:36-87;  X, A: n*n*batch doubles (host). */
 int mom_batch_inv(mom_t *h, int n, int batch, const double *A, double *X);

@@ -20,13 +20,17 @@ c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)
 c_h = C.c_void_p
 
-MOM_OK, MOM_EINVAL, MOM_EHIP, MOM_ESTATE, MOM_ESINGULAR = 0, -1, -2, -3, -4
-_CODES = {MOM_EINVAL: "MOM_EINVAL", MOM_EHIP: "MOM_EHIP", MOM_ESTATE: "MOM_ESTATE", MOM_ESINGULAR: "MOM_ESINGULAR"}
+MOM_OK, MOM_EINVAL, MOM_EHIP, MOM_ESTATE, MOM_ESINGULAR, MOM_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+_CODES = {MOM_EINVAL: "MOM_EINVAL", MOM_EHIP: "MOM_EHIP", MOM_ESTATE: "MOM_ESTATE", MOM_ESINGULAR: "MOM_ESINGULAR",
+          MOM_EUNSUPPORTED: "MOM_EUNSUPPORTED"}
 
 # which-codes of mom_upload / mom_download
 ADDED = dict(r_pm=0, r_mp=1, t_mm=2, t_pp=3, j0p=4, j0m=5)
 COMP = dict(R_mp=6, R_pm=7, T_pp=8, T_mm=9, J0p=10, J0m=11)
 SURF = dict(r_pm=12, r_mp=13, t_mm=14, t_pp=15, j0p=16, j0m=17)
+# ... of mom_rrs_upload / mom_rrs_download: the codes above for the elastic fields of the RRS layers, these for the 4-D fields
+IE_ADDED = dict(ier_pm=18, ier_mp=19, iet_mm=20, iet_pp=21, ieJ0p=22, ieJ0m=23)
+IE_COMP = dict(ieR_mp=24, ieR_pm=25, ieT_pp=26, ieT_mm=27, ieJ0p=28, ieJ0m=29)
 
 MOM_OPT_INVERSE, MOM_OPT_FORCE_GENERIC, MOM_OPT_M0_REDUCTION, MOM_OPT_SMALL_WG, MOM_OPT_STAGGER, MOM_OPT_SMALL_N, MOM_OPT_LAYER_SWEEP = 0, 1, 2, 3, 4, 5, 6
 MOM_OPT_STRIP_PAD = 7
@@ -53,6 +57,17 @@ SIGNATURES = {
     "mom_copy_added_to_composite": (C.c_int, [c_h]),
     "mom_surface_lambertian": (C.c_int, [c_h, C.c_int, C.c_double, c_dp]),
     "mom_elemental_inelastic_rrs": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_ip] + [c_dp] * 13),
+    "mom_rrs_set": (C.c_int, [c_h, C.c_int, c_ip, c_dp, C.c_int]),
+    "mom_rrs_elemental": (C.c_int, [c_h, C.c_int, C.c_int] + [c_dp] * 8),
+    "mom_rrs_doubling": (C.c_int, [c_h, C.c_int, c_dp]),
+    "mom_rrs_interaction": (C.c_int, [c_h, C.c_int, C.c_int]),
+    "mom_rrs_copy_added_to_composite": (C.c_int, [c_h]),
+    "mom_rrs_surface_lambertian": (C.c_int, [c_h, C.c_int, C.c_double, c_dp]),
+    "mom_rrs_upload": (C.c_int, [c_h, C.c_int, c_dp]),
+    "mom_rrs_download": (C.c_int, [c_h, C.c_int, c_dp]),
+    "mom_scene_set_rrs": (C.c_int, [c_h, c_dp, c_dp, c_dp]),
+    "mom_rt_run_rrs": (C.c_int, [c_h]),
+    "mom_get_RT_rrs": (C.c_int, [c_h, c_dp, c_dp, c_dp, c_dp, c_dp]),
     "mom_batch_inv": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp]),
     "mom_batched_mul": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp, c_dp]),
     "mom_batched_mul_dual": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
@@ -217,6 +232,61 @@ class Handle:
         self.check(self.lib.mom_elemental_inelastic_rrs(self._h, int(m), int(ndoubl), nR, ip(il), *[dp(x) for x in v],
                                                         *[dp(x) for x in out]))
         return out
+
+    # -- rotational-Raman path (RS_type::RRS) -------------------------------------------------------
+    def rrs_set(self, i_l1l0, varpi_l1l0, rrs_strict_reference=True):
+        """The RRS fields the path reads (src/Inelastic/types.jl:13-33); allocates AddedLayerRS / CompositeLayerRS."""
+        il, vp = i32(i_l1l0), f64(varpi_l1l0)
+        assert il.size == vp.size
+        self.nRaman = int(il.size)
+        self.check(self.lib.mom_rrs_set(self._h, self.nRaman, ip(il), dp(vp), 1 if rrs_strict_reference else 0))
+
+    def rrs_elemental(self, m, nd, tau_sum, dtau, varpi, Zpp, Zmp, fscatt, Zpp_l1l0, Zmp_l1l0):
+        a = [f64(x).reshape(-1) for x in (tau_sum, dtau, varpi, Zpp, Zmp, fscatt, Zpp_l1l0, Zmp_l1l0)]
+        self.check(self.lib.mom_rrs_elemental(self._h, int(m), int(nd), *[dp(x) for x in a]))
+
+    def rrs_doubling(self, nd, expk):
+        e = f64(expk).copy()
+        self.check(self.lib.mom_rrs_doubling(self._h, int(nd), dp(e)))
+        return e
+
+    def rrs_interaction(self, iface, with_surface_layer=False):
+        self.check(self.lib.mom_rrs_interaction(self._h, int(iface), 1 if with_surface_layer else 0))
+
+    def rrs_copy_added_to_composite(self):
+        self.check(self.lib.mom_rrs_copy_added_to_composite(self._h))
+
+    def rrs_surface_lambertian(self, m, albedo, tau_tot):
+        t = f64(tau_tot)
+        self.check(self.lib.mom_rrs_surface_lambertian(self._h, int(m), float(albedo), dp(t)))
+
+    def rrs_upload(self, which, src):
+        s = f64(src).reshape(-1)
+        assert s.size == self._rrs_count(which)
+        self.check(self.lib.mom_rrs_upload(self._h, int(which), dp(s)))
+
+    def _rrs_count(self, which):
+        return (self.N * self.N if which % 6 < 4 else self.N) * self.S * (self.nRaman if which >= 18 else 1)
+
+    def rrs_download(self, which):
+        out = np.empty(self._rrs_count(which))
+        self.check(self.lib.mom_rrs_download(self._h, int(which), dp(out)))
+        return out
+
+    def scene_set_rrs(self, fscatt, Zpp_l1l0, Zmp_l1l0):
+        a = [f64(x).reshape(-1) for x in (fscatt, Zpp_l1l0, Zmp_l1l0)]
+        self.check(self.lib.mom_scene_set_rrs(self._h, *[dp(x) for x in a]))
+
+    def rt_run_rrs(self):
+        self.check(self.lib.mom_rt_run_rrs(self._h))
+
+    def get_RT_rrs(self):
+        """(R_SFI, T_SFI, ieR_SFI, ieT_SFI), each [nVza, nStokes, S], and the GPU time of the run in ms."""
+        out = [np.empty(self.nVza * self.nS * self.S) for _ in range(4)]
+        ms = np.zeros(1)
+        self.check(self.lib.mom_get_RT_rrs(self._h, *[dp(x) for x in out], dp(ms)))
+        sh = (self.S, self.nS, self.nVza)
+        return tuple(np.transpose(x.reshape(sh), (2, 1, 0)).copy() for x in out) + (float(ms[0]),)
 
     def batch_inv(self, n, batch, A):
         A = f64(A).reshape(-1)

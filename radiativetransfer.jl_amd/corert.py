@@ -737,9 +737,14 @@ def run_scene_device_optics(h: _lib.Handle, model: vSmartMOM_Model, upload_tau_a
         h.absorption_set(model.τ_abs)
     cm = np.array([[cosd(m * a) for a in p.vaz] for m in range(M)])
     sm = np.array([[sind(m * a) for a in p.vaz] for m in range(M)])
+    brdf = p.brdf if p.brdf is not None else LambertianSurfaceScalar(float(p.brdf_albedo))
+    kind, Rs, alb = surface_inputs(brdf, p.polarization_type, qp.qp_μ, M, S)
+    albedo = float(brdf.albedo) if isinstance(brdf, LambertianSurfaceScalar) else 0.0
     h.scene_set_optics(Nz, M, model.τ_rayl, model.ϖ_Cabannes, model.τ_aer, [a.ω̃ for a in model.aerosol_optics],
-                       [a.fᵗ for a in model.aerosol_optics], _abi_mats(Zpp), _abi_mats(Zmp), float(p.brdf_albedo),
+                       [a.fᵗ for a in model.aerosol_optics], _abi_mats(Zpp), _abi_mats(Zmp), albedo,
                        view_nodes(model), cm.reshape(-1), sm.reshape(-1))
+    if kind != 0:
+        h.scene_set_surface(kind, M, None if Rs is None else _abi_mats(Rs), alb)
     h.rt_run()
     return h.get_RT()
 
@@ -789,6 +794,11 @@ def rt_run_operators(model: vSmartMOM_Model):
     R = np.zeros(nV * pol.n * S)  # ABI order [nVza, nStokes, nSpec], v fastest
     T = np.zeros(nV * pol.n * S)
     nodes = view_nodes(model)
+    brdf = p.brdf if p.brdf is not None else LambertianSurfaceScalar(float(p.brdf_albedo))
+    if not isinstance(brdf, LambertianSurfaceScalar):
+        raise NotImplementedError("the operator-level surface entry is mom_surface_lambertian (LambertianSurfaceScalar); "
+                                  "use rt_run / run_scene for %s" % type(brdf).__name__)
+    albedo = float(brdf.albedo)
     with make_handle(model) as h:
         for m in range(p.max_m):
             weight = 0.5 if m == 0 else 1.0
@@ -803,8 +813,71 @@ def rt_run_operators(model: vSmartMOM_Model):
                     h.copy_added_to_composite()
                 else:
                     h.interaction(int(L.iface[z]))
-            h.surface_lambertian(m, p.brdf_albedo, L.τ_sum[:, -1])
+            h.surface_lambertian(m, albedo, L.τ_sum[:, -1])
             h.interaction(int(L.iface[-1]), with_surface_layer=True)
             h.postprocess(m, nodes, p.vaz, weight, R, T)  # postprocessing_vza! (R_SFI += ..., T_SFI += ...)
     shp = (S, pol.n, nV)
     return np.transpose(R.reshape(shp), (2, 1, 0)).copy(), np.transpose(T.reshape(shp), (2, 1, 0)).copy()
+
+
+# ------------------------------------------------------------------------------------------
+# rotational-Raman scattering: rt_run(RS_type::RRS, model, iBand)
+# ------------------------------------------------------------------------------------------
+
+
+@dataclass
+class RRS:
+    """InelasticScattering.RRS (src/Inelastic/types.jl:13-33): the fields the CoreRT hot path reads.  They are produced by
+    getRamanSSProp! (src/CoreRT/tools/raman_atmo_prop.jl:57-73) from the N2/O2 molecular constants, which stays host-side
+    set-up (out of scope, like the Mie code); synthetic line lists for benchmarks: scenes.raman_lines.
+
+    rrs_strict_reference: the reference's RRS text executed as written (True) or with the five documented corrections
+    D1..D5 (False) -- DESIGN.md "RRS", include/momcore.h mom_rrs_set."""
+    greek_raman: GreekCoefs
+    ϖ_Cabannes: float          # elastic (Cabannes) fraction of Rayleigh scattering: the Rayleigh ϖ of the elastic layer optics
+    ϖ_λ1λ0: np.ndarray         # [nRaman]
+    i_λ1λ0: np.ndarray         # [nRaman] grid offsets n₀ - n₁
+    rrs_strict_reference: bool = True
+
+    @property
+    def n_Raman(self):
+        return len(self.i_λ1λ0)
+
+
+def fscatt_rayleigh(model: vSmartMOM_Model) -> np.ndarray:
+    """fScattRayleigh of constructCoreOpticalProperties (compEffectiveLayerProperties.jl:58): rayl.τ ./ combo.τ, combo =
+    Rayleigh + aerosols before the gas absorption is merged.  [nSpec, Nz]."""
+    combo = model.τ_rayl.astype(np.float64).copy()
+    for a, aer in enumerate(model.aerosol_optics):
+        combo = combo + ((1 - aer.fᵗ * aer.ω̃) * model.τ_aer[a])[None, :]
+    return model.τ_rayl / combo
+
+
+def raman_z(RS_type: RRS, model: vSmartMOM_Model):
+    """computeRamanZλ! (src/Inelastic/inelastic_helper.jl:457-464) for m = 0..max_m-1: Z⁺⁺_λ₁λ₀, Z⁻⁺_λ₁λ₀ [M, N, N]."""
+    pol, μ = model.params.polarization_type, model.quad_points.qp_μ
+    Z = [compute_Z_moments(pol, μ, RS_type.greek_raman, m) for m in range(model.params.max_m)]
+    return np.array([z[0] for z in Z]), np.array([z[1] for z in Z])
+
+
+def _with_cabannes(RS_type: RRS, model: vSmartMOM_Model) -> vSmartMOM_Model:
+    import dataclasses
+    return dataclasses.replace(model, ϖ_Cabannes=float(RS_type.ϖ_Cabannes))  # compEffectiveLayerProperties.jl:27
+
+
+def rt_run_rrs(RS_type: RRS, model: vSmartMOM_Model, i_band: int = 1):
+    """rt_run(RS_type::RRS, model, iBand) (rt_run.jl:41-230), SFI = true.  Returns (R_SFI, T_SFI, ieR_SFI, ieT_SFI), each
+    [nVza, nStokes, nSpec] (the first four entries of the reference's return tuple; hdr / bhr are elastic-only extras the
+    RRS entry does not produce)."""
+    model = _with_cabannes(RS_type, model)
+    sc = prepare_scene(model)
+    if sc.surf_kind != 0:
+        raise NotImplementedError("rt_run(::RRS): LambertianSurfaceScalar only")
+    Zr_pp, Zr_mp = raman_z(RS_type, model)
+    with make_handle(model) as h:
+        h.set_option(_lib.MOM_OPT_STRIP_PAD, 0)
+        h.rrs_set(RS_type.i_λ1λ0, RS_type.ϖ_λ1λ0, RS_type.rrs_strict_reference)
+        scene_set(h, sc)
+        h.scene_set_rrs(np.ascontiguousarray(fscatt_rayleigh(model).T), _abi_mats(Zr_pp), _abi_mats(Zr_mp))
+        h.rt_run_rrs()
+        return h.get_RT_rrs()[:4]

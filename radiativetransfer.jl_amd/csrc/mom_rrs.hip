@@ -1,0 +1,943 @@
+// mom_rrs.hip -- the rotational-Raman (RRS) branch of the CoreRT layer loop (BASELINE config 5):
+//   rt_kernel!(::RRS)              src/CoreRT/CoreKernel/rt_kernel.jl:277-340
+//   elemental_inelastic!(::RRS)    CoreKernel/elemental_inelastic.jl:23-91 (+ kernels :93-160, :320-402)
+//   doubling_helper!(::RRS)        CoreKernel/doubling_inelastic.jl:13-134 (+ D kernels :291-311, :345-357)
+//   interaction_helper!(::RRS, .)  CoreKernel/interaction_inelastic.jl:8-22, 28-76, 139-180, 230-340
+//   postprocessing_vza!(::RRS)     tools/postprocessing_vza.jl:95-147
+//
+// Execution model.  The inelastic operators ie*[:, :, n1, dn] couple spectral point n1 with n0 = n1 + i_l1l0[dn], so a
+// doubling step or an interaction cannot stay inside one spectral point's workgroup like the elastic path (mom_kernels.hpp):
+// the ELASTIC state of all points is materialised in HBM per step, and each step is two launches:
+//   * a POINT kernel, one wavefront per spectral point: the elastic update of the step (doubling.jl:43-68 /
+//     interaction.jl:69-117 arithmetic) plus the operands every Raman pair of that point will need -- (I - r r)^-1 t,
+//     t (I - r r)^-1 r, T-- (I - r R+-)^-1 ... -- written once, in the orientation their consumer loads coalesced;
+//     the new elastic state goes to the other half of a double buffer, so the pairs still see the old one;
+//   * a PAIR kernel, one wavefront per (n1, dn): the 9 (doubling) / 18 (interaction 11) operator products and 7 / 8
+//     matrix-vector products of the reference's update formulas as register-tile MFMA products (mom_tile.hpp), reading
+//     and writing each 4-D array block exactly once, in place.  N <= 16: one 16 x 16 tile per operator (the reference's own
+//     RRS shape is N = 15: test/test_parameters/O2Parameters.yaml, IQU, l_trunc 5); N <= 32: 2 x 2 tiles.
+// Pairs are enumerated n1-major, so the nRaman wavefronts that share the n1-side operands run together and the n0-side
+// operands slide through L2.  HBM-bound: 4 (doubling) / 12 (interaction) block transfers of N^2 doubles per pair against
+// 36 / 72 MFMA instructions (NT = 1).
+//
+// The switch `strict_rrs` (rrs_strict_reference): 1 = the reference text as written, with the semantics of a single-threaded
+// run; 0 = corrections D1..D5 listed in DESIGN.md ("RRS") and include/momcore.h (mom_rrs_set) -- and nothing else.
+#include "mom_rrs.hpp"
+
+#include <cstdio>
+#include <vector>
+
+#include "mom_tile.hpp"
+
+namespace momr {
+using namespace momt;
+
+struct KArgs {
+  int N, nS, S, nR, strict_idx, strict_rrs, n_glob0, n1_lo, n1_hi, last, nd, sh, m, imu0, nTerms;
+  double mu0, albedo, weight;
+  double I0[4], D[4];
+  const double *mu, *wt;
+  const int *off;
+  const double *varpiR;
+  double *a_cur[6], *a_nxt[6];
+  double *expk_cur, *expk_nxt;
+  double *sm[10];
+  double *sv[6];
+  double *jpseq;
+  double *ie_a[6], *ie_c[6];
+  double *c_cur[6], *c_nxt[6];
+  double *x[6];  // the added layer of an interaction: the atmospheric one or the surface
+  // elemental inputs
+  const double *tau_sum, *tau, *varpi, *Zpp, *Zmp, *zw, *fscatt, *Zr_pp, *Zr_mp;
+  int *info;
+};
+
+// Stokes component label of the D kernels: strict = mod(i_1based, n) -> 1, 2, .., n-1, 0
+__device__ __forceinline__ int scomp(int i0, int n, int strict) { return strict ? ((i0 + 1) % n) : (i0 % n) + 1; }
+__device__ __forceinline__ double dsgn(int ci, int cj) { return (((ci <= 2) && (cj <= 2)) || ((ci > 2) && (cj > 2))) ? 1.0 : -1.0; }
+
+constexpr int kWavesPerBlock = 4;
+
+template <int NT>
+__device__ __forceinline__ Geo make_geo(int N, unsigned char *smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  Geo g;
+  g.lr = lane & 15;
+  g.lq = lane >> 4;
+  g.N = N;
+  unsigned char *base = smem + (size_t)wave * slice_bytes<NT>();
+  g.xp = reinterpret_cast<double *>(base);
+  g.ipiv = reinterpret_cast<int *>(base + slice_doubles<NT>() * 8);
+  return g;
+}
+
+extern __shared__ __align__(16) unsigned char rrs_smem[];
+
+// element (rho, kappa) of X_t is X[kappa][rho]: apply f(i = kappa, j = rho, value) to every element of an _t tile set
+template <int NT, class F>
+__device__ __forceinline__ void map_t(const Geo &g, Mat<NT> &X, F f) {
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X.t[a][b][r] = f(g.col(b), g.row(a, r), X.t[a][b][r]);
+}
+template <int NT, class F>
+__device__ __forceinline__ void vmap(const Geo &g, Vec<NT> &v, F f) {  // f(row, value)
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v.t[a][r] = f(g.row(a, r), v.t[a][r]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// elastic elemental layer, one wavefront per spectral point: get_elem_rt! / get_elem_rt_SFI! / apply_D_elemental!
+// (CoreKernel/elemental.jl:164-274) into the current half of the added-layer buffer, dtau = tau / 2^sh (sh = ndoubl when
+// the caller passes the layer's tau, 0 when it passes dtau) and
+// expk = exp(-dtau / mu0) (rt_kernel.jl:285-289).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) k_el_point(KArgs a) {
+#pragma clang fp contract(off)
+  const Geo g = make_geo<NT>(a.N, rrs_smem);
+  const int N = a.N, n = a.nS;
+  const size_t NN = (size_t)N * N;
+  const int wave = threadIdx.x >> 6;
+  const double wdiv = (a.m == 0) ? 2.0 : 4.0, wct02 = (a.m == 0) ? 0.5 : 0.25;
+  const int i_start = n * (a.imu0 - 1), i_end = n * a.imu0;
+  for (int pt = blockIdx.x * kWavesPerBlock + wave; pt < a.S; pt += gridDim.x * kWavesPerBlock) {
+    const double dtau = a.tau[pt] / (double)(1ull << a.sh), varpi = a.varpi[pt];
+    Mat<NT> r_t, t_t;
+    // element (rho, kappa) of X_t = X[i = kappa][j = rho]
+#pragma unroll
+    for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int i = g.col(tb), j = g.row(ta, rr);
+          double rv = 0.0, tv = 0.0;
+          if (i < N && j < N) {
+            double zp = 0.0, zm = 0.0;
+            for (int k = 0; k < a.nTerms; ++k) {
+              const double w = a.zw ? a.zw[k + (size_t)a.nTerms * pt] : 1.0;
+              zp += w * a.Zpp[i + (size_t)N * j + NN * k];
+              zm += w * a.Zmp[i + (size_t)N * j + NN * k];
+            }
+            const double mui = a.mu[i], muj = a.mu[j], wj = a.wt[j] / wdiv;
+            if (wj > 1.e-8) {
+              rv = varpi * zm * (muj / (mui + muj)) * wj * (1 - exp(-dtau * ((1 / mui) + (1 / muj))));
+              if (mui == muj) {
+                if (i == j) tv = exp(-dtau / mui) * (1 + varpi * zp * (dtau / mui) * (a.wt[i] / wdiv));
+              } else {
+                tv = varpi * zp * (muj / (mui - muj)) * wj * (exp(-dtau / mui) - exp(-dtau / muj));
+              }
+            } else if (i == j) {
+              tv = exp(-dtau / mui);
+            }
+          }
+          r_t.t[ta][tb][rr] = rv;
+          t_t.t[ta][tb][rr] = tv;
+        }
+    // sources: lanes of column 0 hold row i
+    Vec<NT> jp = vzeros<NT>(), jm = vzeros<NT>();
+    if (g.lr == 0) {
+      const double mus = a.mu[i_start], att = exp(-a.tau_sum[pt] / mus);
+#pragma unroll
+      for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int i = g.row(ta, rr);
+          if (i < N) {
+            double zpI = 0.0, zmI = 0.0;
+            for (int ii = i_start; ii < i_end; ++ii) {
+              double zp = 0.0, zm = 0.0;
+              for (int k = 0; k < a.nTerms; ++k) {
+                const double w = a.zw ? a.zw[k + (size_t)a.nTerms * pt] : 1.0;
+                zp += w * a.Zpp[i + (size_t)N * ii + NN * k];
+                zm += w * a.Zmp[i + (size_t)N * ii + NN * k];
+              }
+              zpI += zp * a.I0[ii - i_start];
+              zmI += zm * a.I0[ii - i_start];
+            }
+            const double mui = a.mu[i];
+            double p;
+            if (i >= i_start && i < i_end) p = wct02 * varpi * zpI * (dtau / mui) * exp(-dtau / mui);
+            else p = wct02 * varpi * zpI * (mus / (mui - mus)) * (exp(-dtau / mui) - exp(-dtau / mus));
+            double q = wct02 * varpi * zmI * (mus / (mui + mus)) * (1 - exp(-dtau * ((1 / mui) + (1 / mus))));
+            p *= att;
+            q *= att;
+            if (a.nd >= 1) q = a.D[i % n] * q;
+            jp.t[ta][rr] = p;
+            jm.t[ta][rr] = q;
+          }
+        }
+    }
+    // apply_D_elemental! (elemental.jl:255-274)
+    if (a.nd < 1) {
+      Mat<NT> rpm = r_t, tmm = t_t;
+      map_t<NT>(g, rpm, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+      map_t<NT>(g, tmm, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+      store_t<NT>(g, a.a_cur[R_PM] + NN * pt, rpm);
+      store_t<NT>(g, a.a_cur[T_MM] + NN * pt, tmm);
+    } else {
+      map_t<NT>(g, r_t, [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
+    }
+    store_t<NT>(g, a.a_cur[R_MP] + NN * pt, r_t);
+    store_t<NT>(g, a.a_cur[T_PP] + NN * pt, t_t);
+    storev<NT>(g, a.a_cur[J0P] + (size_t)N * pt, jp, 0);
+    storev<NT>(g, a.a_cur[J0M] + (size_t)N * pt, jm, 0);
+    if (g.lr == 0 && g.lq == 0) a.expk_cur[pt] = exp(-dtau / a.mu0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// elemental_inelastic!(::RRS) on the PERSISTENT added layer, one thread per element (i, j, n1, dn):
+// get_elem_rt_RRS! (elemental_inelastic.jl:93-160) writes every element of ier-+ / iet++ (zeros off the grid);
+// get_elem_rt_SFI_RRS! (:320-382) writes only on-grid entries of ieJ0+-, then multiplies EVERY entry of ieJ0- by D for
+// ndoubl >= 1 (:378-380); apply_D_elemental_RRS! (:384-402).  dtau[n] = tau[n] / 2^nd.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ie_elemental(KArgs a) {
+#pragma clang fp contract(off)
+  const int N = a.N, n = a.nS;
+  const size_t NN = (size_t)N * N;
+  const size_t npairs = (size_t)(a.n1_hi - a.n1_lo) * a.nR;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= NN * npairs) return;
+  const int i = (int)(e % N), j = (int)((e / N) % N);
+  const size_t pp = e / NN;
+  const int n1 = a.n1_lo + (int)(pp / a.nR), dn = (int)(pp % a.nR);
+  const size_t u = (size_t)n1 + (size_t)a.S * dn;  // block index of the 4-D arrays
+  const size_t o4 = NN * u + i + (size_t)N * j;
+  const int n0 = n1 + a.off[dn];
+  const double scl = (double)(1ull << a.sh);
+  const double wdiv = (a.m == 0) ? 2.0 : 4.0, wct02 = (a.m == 0) ? 0.5 : 0.25;
+  const double mui = a.mu[i], muj = a.mu[j], wj = a.wt[j] / wdiv;
+  double r = 0.0, t = 0.0;
+  const bool in = (n0 >= 0) && (n0 < a.S);
+  if (in && wj > 1.e-8) {
+    const double d1 = a.tau[n1] / scl, d0 = a.tau[n0] / scl;
+    const double pre = a.varpiR[dn] * a.varpi[n0] * a.fscatt[n0];
+    r = a.fscatt[n0] * a.varpiR[dn] * a.varpi[n0] * a.Zr_mp[i + (size_t)N * j] * (1 / ((mui / muj) + (d1 / d0))) *
+        (1 - exp(-((d1 / mui) + (d0 / muj)))) * wj;
+    if (mui == muj) {
+      if (i == j) {
+        const double wi = a.wt[i] / wdiv;
+        if (fabs(d0 - d1) > 1.e-6) t = pre * a.Zr_pp[i + (size_t)N * i] * wi * (exp(-d0 / mui) - exp(-d1 / mui)) / (1 - (d1 / d0));
+        else t = pre * a.Zr_pp[i + (size_t)N * i] * wi * (1 - exp(-d0 / muj));
+      }
+    } else {
+      t = pre * a.Zr_pp[i + (size_t)N * j] * (1 / ((mui / muj) - (d1 / d0))) * wj * (exp(-d1 / mui) - exp(-d0 / muj));
+    }
+  }
+  const int ci = scomp(i, n, a.strict_idx), cj = scomp(j, n, a.strict_idx);
+  if (a.nd < 1) {
+    const double s = dsgn(ci, cj);
+    a.ie_a[R_PM][o4] = s * r;
+    a.ie_a[T_MM][o4] = s * t;
+  } else if (ci > 2) {
+    r = -r;
+  }
+  a.ie_a[R_MP][o4] = r;
+  a.ie_a[T_PP][o4] = t;
+  if (j == 0) {
+    const int i_start = n * (a.imu0 - 1), i_end = n * a.imu0;
+    const size_t o3 = i + (size_t)N * u;
+    if (in) {
+      const double d1 = a.tau[n1] / scl, d0 = a.tau[n0] / scl, mus = a.mu[i_start];
+      double zpI = 0.0, zmI = 0.0;
+      for (int ii = i_start; ii < i_end; ++ii) {
+        zpI += a.Zr_pp[i + (size_t)N * ii] * a.I0[ii - i_start];
+        zmI += a.Zr_mp[i + (size_t)N * ii] * a.I0[ii - i_start];
+      }
+      const double pre = a.varpiR[dn] * a.varpi[n0] * a.fscatt[n0];
+      double jp, jm;
+      if (i >= i_start && i < i_end) {
+        if (fabs(d0 - d1) > 1.e-6) jp = (exp(-d0 / mui) - exp(-d1 / mui)) / ((d1 / d0) - 1) * pre * zpI * wct02;
+        else jp = wct02 * pre * zpI * (1 - exp(-d0 / mus));
+      } else {
+        jp = wct02 * pre * zpI * (1 / ((mui / mus) - (d1 / d0))) * (exp(-d1 / mui) - exp(-d0 / mus));
+      }
+      jm = wct02 * pre * zmI * (1 / ((mui / mus) + (d1 / d0))) * (1 - exp(-((d1 / mui) + (d0 / mus))));
+      const double att = exp(-a.tau_sum[n0] / mus);
+      jp *= att;
+      jm *= att;
+      if (a.nd >= 1) jm = a.D[i % n] * jm;
+      a.ie_a[J0P][o3] = jp;
+      a.ie_a[J0M][o3] = jm;
+    } else if (a.nd >= 1) {
+      a.ie_a[J0M][o3] = a.D[i % n] * a.ie_a[J0M][o3];
+    }
+  }
+}
+
+// scratch matrix / vector slots of a doubling step
+enum { SM_RT = 0, SM_TT = 1, SM_GT = 2, SM_GR = 3, SM_TTGP = 4, SM_TTGPR = 5 };
+enum { SV_TMP1 = 0, SV_TMP2 = 1, SV_J1P = 2, SV_J1M = 3 };
+// ... of an interaction (11)
+enum { SI_T01 = 0, SI_T21 = 1, SI_RPM = 2, SI_TPP = 3, SI_R = 4, SI_TMM = 5, SI_G1RT = 6, SI_G1T = 7, SI_G2T = 8, SI_G2RT = 9 };
+enum { SVI_G1V = 0, SVI_G2V = 1 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// doubling step, POINT kernel (doubling_inelastic.jl:47-59 and the elastic updates :90-95 (D1), :128-131)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) k_dbl_point(KArgs a) {
+  const Geo g = make_geo<NT>(a.N, rrs_smem);
+  const int N = a.N, n = a.nS, wave = threadIdx.x >> 6;
+  const size_t NN = (size_t)N * N;
+  int bad = 0;
+  for (int pt = blockIdx.x * kWavesPerBlock + wave; pt < a.S; pt += gridDim.x * kWavesPerBlock) {
+    const size_t om = NN * pt, ov = (size_t)N * pt;
+    const Mat<NT> r_t = load_t<NT>(g, a.a_cur[R_MP] + om), t_t = load_t<NT>(g, a.a_cur[T_PP] + om);
+    const Mat<NT> r_c = transpose<NT>(g, r_t), t_c = transpose<NT>(g, t_t);
+    const Mat<NT> G_c = inv_one_minus<NT>(g, TN<NT>(g, r_t, r_c), &bad);   // (I - r r)^-1                      :47
+    const Mat<NT> G_t = transpose<NT>(g, G_c);
+    const Mat<NT> ttgp_t = TN<NT>(g, G_c, t_t);                            // (t G)^T                           :48
+    const Mat<NT> ttgpr_t = TN<NT>(g, r_c, ttgp_t);                        // (t G r)^T
+    store_t<NT>(g, a.sm[SM_RT] + om, r_c);
+    store_t<NT>(g, a.sm[SM_TT] + om, t_c);
+    store_t<NT>(g, a.sm[SM_GT] + om, TN<NT>(g, G_t, t_c));                 // G t, row-major
+    store_t<NT>(g, a.sm[SM_GR] + om, TN<NT>(g, G_t, r_c));                 // G r, row-major
+    store_t<NT>(g, a.sm[SM_TTGP] + om, ttgp_t);
+    store_t<NT>(g, a.sm[SM_TTGPR] + om, ttgpr_t);
+    double e = a.expk_cur[pt];
+    Vec<NT> J = loadv2<NT>(g, a.a_cur[J0P] + ov, a.a_cur[J0M] + ov);      // (j0+ | j0-)
+    const Vec<NT> J1 = vscale<NT>(J, e);                                   // (j1+ | j1-)                       :51-55
+    storev<NT>(g, a.sv[SV_J1P] + ov, J1, 0);
+    storev<NT>(g, a.sv[SV_J1M] + ov, J1, 1);
+    // s = (j0+ + r j1- | j1- + r j0+),  tmp = G s = (tmp1 | tmp2)                                              :58-59
+    auto mix = [&](const Vec<NT> &Jc) {
+      Vec<NT> m;  // (j0+ | j1-)
+#pragma unroll
+      for (int ta = 0; ta < NT; ++ta) m.t[ta] = (g.lr == 0) ? Jc.t[ta] : J1.t[ta];
+      return m;
+    };
+    {
+      const Vec<NT> mx = mix(J);
+      const Vec<NT> s = vadd<NT>(mx, TNv<NT>(g, r_t, swap01<NT>(mx)));    // r (j1- | j0+)
+      const Vec<NT> tmp = TNv<NT>(g, G_t, s);
+      storev<NT>(g, a.sv[SV_TMP1] + ov, tmp, 0);
+      storev<NT>(g, a.sv[SV_TMP2] + ov, tmp, 1);
+    }
+    // elastic source update: once (corrected) or nRaman times with expk squared every time (strict, D1)          :90-95
+    const int reps = a.strict_rrs ? a.nR : 1;
+    for (int k = 0; k < reps; ++k) {
+      if (a.strict_rrs) storev<NT>(g, a.jpseq + ov + (size_t)N * a.S * k, J, 0);
+      const Vec<NT> mx = mix(J);
+      const Vec<NT> s = vadd<NT>(mx, TNv<NT>(g, r_t, swap01<NT>(mx)));
+      const Vec<NT> q = TNv<NT>(g, ttgp_t, s);                             // (tG (j0+ + r j1-) | tG (j1- + r j0+))
+      Vec<NT> Jn;
+#pragma unroll
+      for (int ta = 0; ta < NT; ++ta) Jn.t[ta] = ((g.lr == 0) ? J1.t[ta] : J.t[ta]) + q.t[ta];
+      J = Jn;
+      e = e * e;
+    }
+    // r <- r + (tG r) t,  t <- tG t                                                                             :128-131
+    Mat<NT> rn_t = add<NT>(r_t, TN<NT>(g, t_c, ttgpr_t));
+    Mat<NT> tn_t = TN<NT>(g, t_c, ttgp_t);
+    if (a.last) {  // apply_D_matrix! (doubling.jl:93-134) and apply_D_matrix_SFI! (:112-144)
+      if (n > 1) {
+        map_t<NT>(g, rn_t, [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
+        vmap<NT>(g, J, [&](int i, double v) { return (g.lr == 1 && scomp(i, n, a.strict_idx) > 2) ? -v : v; });
+      }
+      Mat<NT> rpm = rn_t, tmm = tn_t;
+      if (n > 1) {
+        map_t<NT>(g, rpm, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+        map_t<NT>(g, tmm, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+      }
+      store_t<NT>(g, a.a_nxt[R_PM] + om, rpm);
+      store_t<NT>(g, a.a_nxt[T_MM] + om, tmm);
+    }
+    store_t<NT>(g, a.a_nxt[R_MP] + om, rn_t);
+    store_t<NT>(g, a.a_nxt[T_PP] + om, tn_t);
+    storev<NT>(g, a.a_nxt[J0P] + ov, J, 0);
+    storev<NT>(g, a.a_nxt[J0M] + ov, J, 1);
+    if (g.lr == 0 && g.lq == 0) a.expk_nxt[pt] = e;
+  }
+  if (bad && g.lr == 0 && g.lq == 0) atomicMax(a.info, bad);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// doubling step, PAIR kernel (doubling_inelastic.jl:61-89 and :98-125)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) k_dbl_pair(KArgs a) {
+  const Geo g = make_geo<NT>(a.N, rrs_smem);
+  const int N = a.N, n = a.nS, wave = threadIdx.x >> 6;
+  const size_t NN = (size_t)N * N;
+  const size_t npairs = (size_t)(a.n1_hi - a.n1_lo) * a.nR;
+  const bool fuseD = a.last && !a.strict_rrs;  // D2/D3 (corrected) folded into the last step's stores
+  for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += (size_t)gridDim.x * kWavesPerBlock) {
+    const int n1 = a.n1_lo + (int)(p / a.nR), dn = (int)(p % a.nR);
+    const int n0 = n1 + a.off[dn];
+    const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = (size_t)N * u;
+    if (n0 < 0 || n0 >= a.S) {  // get_n0_n1 (inelastic_helper.jl:13-21): no update off the grid ...
+      if (fuseD) {              // ... but the corrected D kernels visit every (n, dn)
+        Mat<NT> an_t = load_t<NT>(g, a.ie_a[R_MP] + o4), bn_t = load_t<NT>(g, a.ie_a[T_PP] + o4);
+        if (n > 1) {
+          map_t<NT>(g, an_t, [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
+          store_t<NT>(g, a.ie_a[R_MP] + o4, an_t);
+          Vec<NT> Jm = loadv2<NT>(g, nullptr, a.ie_a[J0M] + o3);
+          vmap<NT>(g, Jm, [&](int i, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
+          storev<NT>(g, a.ie_a[J0M] + o3, Jm, 1);
+          map_t<NT>(g, an_t, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+          map_t<NT>(g, bn_t, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+        }
+        store_t<NT>(g, a.ie_a[R_PM] + o4, an_t);
+        store_t<NT>(g, a.ie_a[T_MM] + o4, bn_t);
+      }
+      continue;
+    }
+    const size_t m1 = NN * n1, m0 = NN * n0, v0 = (size_t)N * n0;
+    const Mat<NT> a_t = load_t<NT>(g, a.ie_a[R_MP] + o4), b_t = load_t<NT>(g, a.ie_a[T_PP] + o4);
+    const Mat<NT> r1_t = load_t<NT>(g, a.a_cur[R_MP] + m1), ttgp1_t = load_t<NT>(g, a.sm[SM_TTGP] + m1);
+    const Mat<NT> r0_c = load_t<NT>(g, a.sm[SM_RT] + m0), gt0_c = load_t<NT>(g, a.sm[SM_GT] + m0);
+    const Mat<NT> a_c = transpose<NT>(g, a_t);
+    // X = ier r0 + r1 ier
+    const Mat<NT> X_t = TNacc<NT>(g, a_c, r1_t, TN<NT>(g, r0_c, a_t));
+    // ---- sources                                                                                              :61-89
+    {
+      const double e1 = a.expk_cur[n1];
+      const Vec<NT> J = loadv2<NT>(g, a.ie_a[J0P] + o3, a.ie_a[J0M] + o3);   // (ieJ0+ | ieJ0-)
+      const Vec<NT> J1 = vscale<NT>(J, e1);                                   // (ieJ1+ | ieJ1-)                 :52-56
+      const double *jp0 = a.strict_rrs ? a.jpseq + v0 + (size_t)N * a.S * dn : a.a_cur[J0P] + v0;
+      const Vec<NT> av = TNv<NT>(g, a_t, loadv2<NT>(g, a.sv[SV_J1M] + v0, jp0));         // (ier j1-[n0] | ier j0+[n0])
+      const Vec<NT> tm = loadv2<NT>(g, a.sv[SV_TMP1] + v0, a.sv[SV_TMP2] + v0);
+      const Vec<NT> Xv = TNv<NT>(g, X_t, tm);                                 // (X tmp1 | X tmp2)
+      Vec<NT> bv = TNv<NT>(g, b_t, tm);                                       // (iet++ tmp1 | iet++ tmp2)
+      if (a.strict_rrs) {                                                     // D5: iet-- as the array holds it
+        const Vec<NT> bm = TNv<NT>(g, load_t<NT>(g, a.ie_a[T_MM] + o4), tm);
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) bv.t[ta] = (g.lr == 1) ? bm.t[ta] : bv.t[ta];
+      }
+      const Vec<NT> rv = TNv<NT>(g, r1_t, swap01<NT>(J1));                    // col 0: r1 ieJ1-
+      const Vec<NT> uu = vadd<NT>(vadd<NT>(J, rv), vadd<NT>(av, Xv));         // col 0
+      const Vec<NT> Jp = vadd<NT>(vadd<NT>(J1, TNv<NT>(g, ttgp1_t, uu)), bv); // col 0: new ieJ0+
+      const Vec<NT> rv2 = swap01<NT>(TNv<NT>(g, r1_t, Jp));                   // col 1: r1 ieJ0+(new)
+      const Vec<NT> u2 = vadd<NT>(vadd<NT>(J1, rv2), vadd<NT>(av, Xv));       // col 1
+      Vec<NT> Jm = vadd<NT>(vadd<NT>(J, TNv<NT>(g, ttgp1_t, u2)), bv);        // col 1: new ieJ0-
+      if (fuseD && n > 1) vmap<NT>(g, Jm, [&](int i, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
+      storev<NT>(g, a.ie_a[J0P] + o3, Jp, 0);
+      storev<NT>(g, a.ie_a[J0M] + o3, Jm, 1);
+    }
+    // ---- operators                                                                                            :98-125
+    const Mat<NT> b_c = transpose<NT>(g, b_t);
+    const Mat<NT> Y_c = TN<NT>(g, X_t, gt0_c);                                // X G t[n0]
+    const Mat<NT> W_c = add<NT>(b_c, Y_c);
+    Mat<NT> bn_t = TNacc<NT>(g, gt0_c, b_t, TN<NT>(g, W_c, ttgp1_t));         // tG (iet + Y) + iet G t[n0]
+    const Mat<NT> bn_c = transpose<NT>(g, bn_t);
+    const Mat<NT> V_c = add<NT>(bn_c, Y_c);
+    const Mat<NT> gr0_c = load_t<NT>(g, a.sm[SM_GR] + m0), t0_c = load_t<NT>(g, a.sm[SM_TT] + m0);
+    const Mat<NT> ttgpr1_t = load_t<NT>(g, a.sm[SM_TTGPR] + m1);
+    const Mat<NT> Q_t = TNacc<NT>(g, a_c, ttgp1_t, TN<NT>(g, gr0_c, bn_t));  // iet(new) G r[n0] + tG ier
+    Mat<NT> an_t = add<NT>(a_t, TNacc<NT>(g, t0_c, Q_t, TN<NT>(g, V_c, ttgpr1_t)));
+    if (fuseD) {  // apply_D_matrix_IE!, corrected indexing (D2)
+      if (n > 1) map_t<NT>(g, an_t, [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
+      Mat<NT> apm = an_t, bmm = bn_t;
+      if (n > 1) {
+        map_t<NT>(g, apm, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+        map_t<NT>(g, bmm, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+      }
+      store_t<NT>(g, a.ie_a[R_PM] + o4, apm);
+      store_t<NT>(g, a.ie_a[T_MM] + o4, bmm);
+    }
+    store_t<NT>(g, a.ie_a[R_MP] + o4, an_t);
+    store_t<NT>(g, a.ie_a[T_PP] + o4, bn_t);
+  }
+}
+
+// apply_D_IE_RRS! / apply_D_SFI_IE_RRS! as written (doubling_inelastic.jl:291-311, :345-357), strict position: the work
+// item (n, dn) addresses the RAMAN axis with n0 = n + i_l1l0[dn] (1-based) when 1 <= n0 <= nRaman.  One thread per
+// (i, n) walks dn in ascending order (single-thread column-major semantics of the overlapping reads/writes of the SFI kernel).
+__global__ void k_strict_D(KArgs a) {
+  const int N = a.N, n = a.nS;
+  const size_t NN = (size_t)N * N;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int span = a.n1_hi - a.n1_lo;
+  if (e >= N * span) return;
+  const int i = e % N, nl = a.n1_lo + e / N;
+  const int ng1 = a.n_glob0 + nl + 1;  // 1-based global spectral index
+  const int ci = scomp(i, n, a.strict_idx);
+  for (int dn = 0; dn < a.nR; ++dn) {
+    const int k1 = ng1 + a.off[dn];
+    if (k1 < 1 || k1 > a.nR) continue;
+    const size_t ub = (size_t)nl + (size_t)a.S * (k1 - 1);
+    for (int j = 0; j < N; ++j) {
+      const size_t o = NN * ub + i + (size_t)N * j;
+      double v = a.ie_a[R_MP][o];
+      if (ci > 2) { v = -v; a.ie_a[R_MP][o] = v; }
+      const double s = dsgn(ci, scomp(j, n, a.strict_idx));
+      a.ie_a[R_PM][o] = s * v;
+      a.ie_a[T_MM][o] = s * a.ie_a[T_PP][o];
+    }
+  }
+  if (ci > 2)
+    for (int dn = 0; dn < a.nR; ++dn) {
+      const int k1 = ng1 + a.off[dn];
+      if (k1 < 1 || k1 > a.nR) continue;
+      a.ie_a[J0M][i + (size_t)N * ((size_t)nl + (size_t)a.S * (k1 - 1))] = -a.ie_a[J0M][i + (size_t)N * ((size_t)nl + (size_t)a.S * dn)];
+    }
+}
+// n_stokes == 1: ier+- = ier-+, iet-- = iet++ for the whole arrays (doubling_inelastic.jl:411-414)
+__global__ void k_copy2(const double *s0, double *d0, const double *s1, double *d1, size_t count) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (size_t)gridDim.x * blockDim.x) {
+    d0[e] = s0[e];
+    d1[e] = s1[e];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// interaction, POINT kernel: the elastic adding equations (interaction.jl:8-117 arithmetic inside
+// interaction_inelastic.jl) into the other half of the composite buffer + the operands of the pair kernel.
+// x[] = the added layer of this interaction (atmospheric or surface).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) k_int_point(KArgs a, int iface) {
+  const Geo g = make_geo<NT>(a.N, rrs_smem);
+  const int N = a.N, wave = threadIdx.x >> 6;
+  const size_t NN = (size_t)N * N;
+  int bad = 0;
+  for (int pt = blockIdx.x * kWavesPerBlock + wave; pt < a.S; pt += gridDim.x * kWavesPerBlock) {
+    const size_t om = NN * pt, ov = (size_t)N * pt;
+    const Mat<NT> r_t = load_t<NT>(g, a.x[R_MP] + om), tpp_t = load_t<NT>(g, a.x[T_PP] + om);
+    const Mat<NT> tmm_t = load_t<NT>(g, a.x[T_MM] + om);
+    const Mat<NT> Rpm_t = load_t<NT>(g, a.c_cur[C_R_PM] + om), Tpp_t = load_t<NT>(g, a.c_cur[C_T_PP] + om);
+    const Mat<NT> Tmm_t = load_t<NT>(g, a.c_cur[C_T_MM] + om), Rmp_t = load_t<NT>(g, a.c_cur[C_R_MP] + om);
+    const Vec<NT> ja = loadv2<NT>(g, a.x[J0P] + ov, a.x[J0M] + ov);                    // (j0+ | j0-) added
+    const Vec<NT> Jc = loadv2<NT>(g, a.c_cur[C_J0P] + ov, a.c_cur[C_J0M] + ov);        // (J0+ | J0-) composite
+    const Mat<NT> tmm_c = transpose<NT>(g, tmm_t), Tpp_c = transpose<NT>(g, Tpp_t);
+    Mat<NT> Rmp_n = Rmp_t, Rpm_n = Rpm_t, Tpp_n, Tmm_n;
+    Vec<NT> Jn;  // (J0+ | J0-) new
+    if (iface == 3) {
+      const Mat<NT> r_c = transpose<NT>(g, r_t), Rpm_c = transpose<NT>(g, Rpm_t);
+      const Mat<NT> G1_c = inv_one_minus<NT>(g, TN<NT>(g, r_t, Rpm_c), &bad);          // (I - r R+-)^-1           :244
+      const Mat<NT> G1_t = transpose<NT>(g, G1_c);
+      const Mat<NT> T01_t = TN<NT>(g, G1_c, Tmm_t);                                    // (T-- G1)^T               :247
+      const Mat<NT> rT_c = TN<NT>(g, r_t, Tpp_c);                                      // r T++
+      store_t<NT>(g, a.sm[SI_T01] + om, T01_t);
+      store_t<NT>(g, a.sm[SI_RPM] + om, Rpm_c);
+      store_t<NT>(g, a.sm[SI_TPP] + om, Tpp_c);
+      store_t<NT>(g, a.sm[SI_R] + om, r_c);
+      store_t<NT>(g, a.sm[SI_TMM] + om, tmm_c);
+      store_t<NT>(g, a.sm[SI_G1RT] + om, TN<NT>(g, G1_t, rT_c));                       // G1 r T++
+      store_t<NT>(g, a.sm[SI_G1T] + om, TN<NT>(g, G1_t, tmm_c));                       // G1 t--
+      const Vec<NT> rJ = TNv<NT>(g, r_t, Jc);                                          // col 0: r J0+
+      const Vec<NT> s1 = vadd<NT>(rJ, swap01<NT>(ja));                                 // col 0: r J0+ + j0-
+      storev<NT>(g, a.sv[SVI_G1V] + ov, TNv<NT>(g, G1_t, s1), 0);                      // G1 (j0- + r J0+)
+      const Vec<NT> dJm = TNv<NT>(g, T01_t, s1);                                       // col 0                    :267
+      Rmp_n = add<NT>(Rmp_t, TN<NT>(g, rT_c, T01_t));                                  //                          :288
+      Tmm_n = TN<NT>(g, tmm_c, T01_t);                                                 //                          :290
+      const Mat<NT> G2_c = inv_one_minus<NT>(g, TN<NT>(g, Rpm_t, r_c), &bad);          // (I - R+- r)^-1           :295
+      const Mat<NT> G2_t = transpose<NT>(g, G2_c);
+      const Mat<NT> T21_t = TN<NT>(g, G2_c, tpp_t);                                    //                          :297
+      const Mat<NT> Rt_c = TN<NT>(g, Rpm_t, tmm_c);                                    // R+- t--
+      store_t<NT>(g, a.sm[SI_T21] + om, T21_t);
+      store_t<NT>(g, a.sm[SI_G2T] + om, TN<NT>(g, G2_t, Tpp_c));
+      store_t<NT>(g, a.sm[SI_G2RT] + om, TN<NT>(g, G2_t, Rt_c));
+      const Vec<NT> Rj = swap01<NT>(TNv<NT>(g, Rpm_t, ja));                            // col 0: R+- j0-
+      const Vec<NT> s2 = vadd<NT>(Jc, Rj);                                             // col 0: J0+ + R+- j0-
+      storev<NT>(g, a.sv[SVI_G2V] + ov, TNv<NT>(g, G2_t, s2), 0);
+      const Vec<NT> dJp = TNv<NT>(g, T21_t, s2);                                       //                          :315
+      const Vec<NT> dJm1 = swap01<NT>(dJm);  // column 1: J0- + dJm (dJm sits in column 0)
+#pragma unroll
+      for (int ta = 0; ta < NT; ++ta) Jn.t[ta] = (g.lr == 0) ? (ja.t[ta] + dJp.t[ta]) : (Jc.t[ta] + dJm1.t[ta]);
+      Tpp_n = TN<NT>(g, Tpp_c, T21_t);                                                 //                          :338
+      Rpm_n = add<NT>(load_t<NT>(g, a.x[R_PM] + om), TN<NT>(g, Rt_c, T21_t));          //                          :340
+    } else {
+      // 00 / 01 / 10 (D4): operands for the pair kernel are the plain layers in the right orientation
+      store_t<NT>(g, a.sm[SI_TPP] + om, Tpp_c);
+      store_t<NT>(g, a.sm[SI_TMM] + om, tmm_c);
+      const Mat<NT> Tmm_c = transpose<NT>(g, Tmm_t);
+      if (iface == 0) {                                                                //                          :8-22
+        const Vec<NT> tJ = TNv<NT>(g, tpp_t, Jc);                                      // col 0: t++ J0+
+        const Vec<NT> Tj = TNv<NT>(g, Tmm_t, ja);                                      // col 1: T-- j0-
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) Jn.t[ta] = (g.lr == 0) ? (ja.t[ta] + tJ.t[ta]) : (Jc.t[ta] + Tj.t[ta]);
+        Tmm_n = TN<NT>(g, Tmm_c, tmm_t);                                               // t-- T--
+        Tpp_n = TN<NT>(g, Tpp_c, tpp_t);                                               // t++ T++
+      } else if (iface == 1) {                                                         //                          :28-76
+        const Vec<NT> rJ = TNv<NT>(g, r_t, Jc);                                        // col 0: r J0+
+        const Vec<NT> s1 = vadd<NT>(rJ, swap01<NT>(ja));                               // col 0: r J0+ + j0-
+        const Vec<NT> dJm = swap01<NT>(TNv<NT>(g, Tmm_t, s1));                         // col 1
+        const Vec<NT> tJ = TNv<NT>(g, tpp_t, Jc);
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) Jn.t[ta] = (g.lr == 0) ? (ja.t[ta] + tJ.t[ta]) : (Jc.t[ta] + dJm.t[ta]);
+        const Mat<NT> rT_c = TN<NT>(g, r_t, Tpp_c);
+        Rmp_n = TN<NT>(g, rT_c, Tmm_t);                                                // T-- r T++
+        Rpm_n = load_t<NT>(g, a.x[R_PM] + om);
+        Tpp_n = TN<NT>(g, Tpp_c, tpp_t);                                               // t++ T++
+        Tmm_n = TN<NT>(g, tmm_c, Tmm_t);                                               // T-- t--
+      } else {                                                                         // 10                       :139-180
+        const Vec<NT> Rj = swap01<NT>(TNv<NT>(g, Rpm_t, ja));                          // col 0: R+- j0-
+        const Vec<NT> dJp = TNv<NT>(g, tpp_t, vadd<NT>(Jc, Rj));                       // col 0
+        const Vec<NT> Tj = TNv<NT>(g, Tmm_t, ja);                                      // col 1: T-- j0-
+#pragma unroll
+        for (int ta = 0; ta < NT; ++ta) Jn.t[ta] = (g.lr == 0) ? (ja.t[ta] + dJp.t[ta]) : (Jc.t[ta] + Tj.t[ta]);
+        Tpp_n = TN<NT>(g, Tpp_c, tpp_t);
+        Tmm_n = TN<NT>(g, tmm_c, Tmm_t);
+        const Mat<NT> Rt_c = TN<NT>(g, Rpm_t, tmm_c);
+        Rpm_n = TN<NT>(g, Rt_c, tpp_t);                                                // t++ R+- t--
+      }
+    }
+    store_t<NT>(g, a.c_nxt[C_R_MP] + om, Rmp_n);
+    store_t<NT>(g, a.c_nxt[C_R_PM] + om, Rpm_n);
+    store_t<NT>(g, a.c_nxt[C_T_PP] + om, Tpp_n);
+    store_t<NT>(g, a.c_nxt[C_T_MM] + om, Tmm_n);
+    storev<NT>(g, a.c_nxt[C_J0P] + ov, Jn, 0);
+    storev<NT>(g, a.c_nxt[C_J0M] + ov, Jn, 1);
+  }
+  if (bad && g.lr == 0 && g.lq == 0) atomicMax(a.info, bad);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// interaction, PAIR kernel.  SURF: the added layer is the surface (all its ie* arrays are zeros and never read).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT, bool SURF>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) k_int_pair(KArgs a, int iface) {
+  const Geo g = make_geo<NT>(a.N, rrs_smem);
+  const int N = a.N, wave = threadIdx.x >> 6;
+  const size_t NN = (size_t)N * N;
+  const size_t npairs = (size_t)(a.n1_hi - a.n1_lo) * a.nR;
+  for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += (size_t)gridDim.x * kWavesPerBlock) {
+    const int n1 = a.n1_lo + (int)(p / a.nR), dn = (int)(p % a.nR);
+    const int n0 = n1 + a.off[dn];
+    if (n0 < 0 || n0 >= a.S) continue;
+    const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = (size_t)N * u;
+    const size_t m1 = NN * n1, m0 = NN * n0, v0 = (size_t)N * n0;
+    auto ldA = [&](int which) { return SURF ? zeros<NT>() : load_t<NT>(g, a.ie_a[which] + o4); };
+    const Vec<NT> Ja = SURF ? vzeros<NT>() : loadv2<NT>(g, a.ie_a[J0P] + o3, a.ie_a[J0M] + o3);   // (ieJ0+ | ieJ0-) added
+    const Vec<NT> Jc = loadv2<NT>(g, a.ie_c[C_J0P] + o3, a.ie_c[C_J0M] + o3);                    // composite
+    if (iface == 3) {
+      const Mat<NT> a_t = ldA(R_MP), bm_t = ldA(T_MM);
+      const Mat<NT> E_t = load_t<NT>(g, a.ie_c[C_R_PM] + o4), C_t = load_t<NT>(g, a.ie_c[C_T_PP] + o4);
+      const Mat<NT> a_c = transpose<NT>(g, a_t), bm_c = transpose<NT>(g, bm_t);
+      const Mat<NT> E_c = transpose<NT>(g, E_t), C_c = transpose<NT>(g, C_t);
+      const Mat<NT> T01_t = load_t<NT>(g, a.sm[SI_T01] + m1), r1_t = load_t<NT>(g, a.x[R_MP] + m1);
+      const Mat<NT> Rpm0_c = load_t<NT>(g, a.sm[SI_RPM] + m0), Tpp0_c = load_t<NT>(g, a.sm[SI_TPP] + m0);
+      // A = T01 (ier R+-[n0] + r ieR+-) + ieT--                                                                  :252-262
+      const Mat<NT> M1_c = TNacc<NT>(g, r1_t, E_c, TN<NT>(g, a_t, Rpm0_c));
+      const Mat<NT> A_t = TNacc<NT>(g, M1_c, T01_t, load_t<NT>(g, a.ie_c[C_T_MM] + o4));
+      // ieJ0- += T01 (ier J0+[n0] + r ieJ0+ + ieJ0-(added)) + A G1 (j0-[n0] + r[n0] J0+[n0])                      :251-264
+      {
+        const Vec<NT> v1 = TNv<NT>(g, a_t, loadv2<NT>(g, a.c_cur[C_J0P] + v0, nullptr));
+        const Vec<NT> v2 = TNv<NT>(g, r1_t, Jc);
+        const Vec<NT> uu = vadd<NT>(vadd<NT>(v1, v2), swap01<NT>(Ja));
+        const Vec<NT> w = TNvacc<NT>(g, A_t, loadv2<NT>(g, a.sv[SVI_G1V] + v0, nullptr), TNv<NT>(g, T01_t, uu));
+        storev<NT>(g, a.ie_c[C_J0M] + o3, vadd<NT>(swap01<NT>(Jc), w), 0);
+      }
+      // ieR-+ += T01 (ier T++[n0] + r ieT++) + A G1 r[n0] T++[n0];  ieT-- = T01 iet-- + A G1 t--[n0]               :271-284
+      {
+        const Mat<NT> N1_c = TNacc<NT>(g, r1_t, C_c, TN<NT>(g, a_t, Tpp0_c));
+        Mat<NT> Rm_t = load_t<NT>(g, a.ie_c[C_R_MP] + o4);
+        Rm_t = TNacc<NT>(g, N1_c, T01_t, Rm_t);
+        Rm_t = TNacc<NT>(g, load_t<NT>(g, a.sm[SI_G1RT] + m0), A_t, Rm_t);
+        store_t<NT>(g, a.ie_c[C_R_MP] + o4, Rm_t);
+        const Mat<NT> F_t = TNacc<NT>(g, load_t<NT>(g, a.sm[SI_G1T] + m0), A_t, TN<NT>(g, bm_c, T01_t));
+        store_t<NT>(g, a.ie_c[C_T_MM] + o4, F_t);
+      }
+      // B = T21 (ieR+- r[n0] + R+- ier) + iet++                                                                   :302-310
+      const Mat<NT> T21_t = load_t<NT>(g, a.sm[SI_T21] + m1), Rpm1_t = load_t<NT>(g, a.c_cur[C_R_PM] + m1);
+      const Mat<NT> M2_c = TNacc<NT>(g, Rpm1_t, a_c, TN<NT>(g, E_t, load_t<NT>(g, a.sm[SI_R] + m0)));
+      const Mat<NT> B_t = TNacc<NT>(g, M2_c, T21_t, ldA(T_PP));
+      // ieJ0+ = ieJ0+(added) + T21 (ieJ0+ + ieR+- j0-[n0] + R+- ieJ0-(added)) + B G2 (J0+[n0] + R+-[n0] j0-[n0])    :301-312
+      {
+        const Vec<NT> v3 = TNv<NT>(g, E_t, loadv2<NT>(g, a.x[J0M] + v0, nullptr));
+        const Vec<NT> v4 = TNv<NT>(g, Rpm1_t, swap01<NT>(Ja));
+        const Vec<NT> uu = vadd<NT>(vadd<NT>(Jc, v3), v4);
+        const Vec<NT> w = TNvacc<NT>(g, B_t, loadv2<NT>(g, a.sv[SVI_G2V] + v0, nullptr), TNv<NT>(g, T21_t, uu));
+        storev<NT>(g, a.ie_c[C_J0P] + o3, vadd<NT>(Ja, w), 0);
+      }
+      // ieT++ = T21 ieT++ + B G2 T++[n0];  ieR+- = ier+- + T21 (ieR+- t--[n0] + R+- iet--) + B G2 R+-[n0] t--[n0]   :320-334
+      {
+        const Mat<NT> Cn_t = TNacc<NT>(g, load_t<NT>(g, a.sm[SI_G2T] + m0), B_t, TN<NT>(g, C_c, T21_t));
+        store_t<NT>(g, a.ie_c[C_T_PP] + o4, Cn_t);
+        const Mat<NT> N2_c = TNacc<NT>(g, Rpm1_t, bm_c, TN<NT>(g, E_t, load_t<NT>(g, a.sm[SI_TMM] + m0)));
+        Mat<NT> En_t = ldA(R_PM);
+        En_t = TNacc<NT>(g, N2_c, T21_t, En_t);
+        En_t = TNacc<NT>(g, load_t<NT>(g, a.sm[SI_G2RT] + m0), B_t, En_t);
+        store_t<NT>(g, a.ie_c[C_R_PM] + o4, En_t);
+      }
+    } else if (iface == 1) {                                                           // 01, corrected (D4)       :40-75
+      const Mat<NT> a_t = ldA(R_MP), b_t = ldA(T_PP), bm_t = ldA(T_MM);
+      const Mat<NT> Tmm1_t = load_t<NT>(g, a.c_cur[C_T_MM] + m1), Tpp0_c = load_t<NT>(g, a.sm[SI_TPP] + m0);
+      const Vec<NT> J0 = loadv2<NT>(g, a.c_cur[C_J0P] + v0, nullptr);
+      const Vec<NT> v1 = vadd<NT>(TNv<NT>(g, a_t, J0), swap01<NT>(Ja));                // col 0: ier J0+[n0] + ieJ0-(added)
+      storev<NT>(g, a.ie_c[C_J0M] + o3, TNv<NT>(g, Tmm1_t, v1), 0);
+      storev<NT>(g, a.ie_c[C_J0P] + o3, vadd<NT>(Ja, TNv<NT>(g, b_t, J0)), 0);
+      store_t<NT>(g, a.ie_c[C_R_MP] + o4, TN<NT>(g, TN<NT>(g, a_t, Tpp0_c), Tmm1_t));  // T-- ier T++[n0]
+      store_t<NT>(g, a.ie_c[C_R_PM] + o4, ldA(R_PM));
+      store_t<NT>(g, a.ie_c[C_T_PP] + o4, TN<NT>(g, Tpp0_c, b_t));                     // iet++ T++[n0]
+      store_t<NT>(g, a.ie_c[C_T_MM] + o4, TN<NT>(g, transpose<NT>(g, bm_t), Tmm1_t)); // T-- iet--
+    } else if (iface == 2) {                                                           // 10, corrected (D4)       :150-178
+      const Mat<NT> E_t = load_t<NT>(g, a.ie_c[C_R_PM] + o4), C_t = load_t<NT>(g, a.ie_c[C_T_PP] + o4);
+      const Mat<NT> F_t = load_t<NT>(g, a.ie_c[C_T_MM] + o4);
+      const Mat<NT> tpp1_t = load_t<NT>(g, a.x[T_PP] + m1), tmm0_c = load_t<NT>(g, a.sm[SI_TMM] + m0);
+      const Vec<NT> j0 = loadv2<NT>(g, a.x[J0M] + v0, nullptr);
+      storev<NT>(g, a.ie_c[C_J0P] + o3, TNv<NT>(g, tpp1_t, vadd<NT>(Jc, TNv<NT>(g, E_t, j0))), 0);
+      storev<NT>(g, a.ie_c[C_J0M] + o3, vadd<NT>(swap01<NT>(Jc), TNv<NT>(g, F_t, j0)), 0);
+      store_t<NT>(g, a.ie_c[C_T_PP] + o4, TN<NT>(g, transpose<NT>(g, C_t), tpp1_t));   // t++ ieT++
+      store_t<NT>(g, a.ie_c[C_T_MM] + o4, TN<NT>(g, tmm0_c, F_t));                     // ieT-- t--[n0]
+      store_t<NT>(g, a.ie_c[C_R_PM] + o4, TN<NT>(g, TN<NT>(g, E_t, tmm0_c), tpp1_t));  // t++ ieR+- t--[n0]
+    }
+  }
+}
+
+// create_surface_layer!(::LambertianSurfaceScalar) (Surfaces/lambertian_surface.jl:20-75) into the surface layer arrays
+__global__ void k_surface_fill(KArgs a, const double *tau_tot) {
+  const int N = a.N, n = a.nS;
+  const size_t NN = (size_t)N * N;
+  const size_t pt = blockIdx.x;
+  const double rho = 2 * a.albedo;
+  const double att = exp(-tau_tot[pt] / a.mu0);
+  const int i_start = n * (a.imu0 - 1), i_end = n * a.imu0;
+  double *const *x = a.x;
+  for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+    const int j = e / N, i = e - j * N;
+    x[R_MP][NN * pt + e] = (a.m == 0 && (i % n == 0) && (j % n == 0)) ? rho * (a.mu[j] * a.wt[j]) : 0.0;
+    if (a.m == 0) x[R_PM][NN * pt + e] = 0.0;
+    x[T_PP][NN * pt + e] = (i == j) ? 1.0 : 0.0;
+    x[T_MM][NN * pt + e] = (i == j) ? 1.0 : 0.0;
+  }
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const bool in_sun = (i >= i_start) && (i < i_end);
+    x[J0P][(size_t)N * pt + i] = (a.m == 0) ? (in_sun ? a.I0[i - i_start] : 0.0) * att : 0.0;
+    x[J0M][(size_t)N * pt + i] = (a.m == 0 && (i % n == 0)) ? (a.mu0 * (rho * a.I0[0])) * att : 0.0;
+  }
+}
+
+// postprocessing_vza!(::RRS) (tools/postprocessing_vza.jl:95-147, SFI): out = [R | T | ieR | ieT][nVza, nS, S]
+__global__ void k_post(KArgs a, int nVza, const int *node, const double *cosm, const double *sinm, int M, double *out) {
+  const int N = a.N, n = a.nS;
+  const size_t tot = (size_t)nVza * n * a.S;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= tot) return;
+  const int v = (int)(e % nVza), s = (int)((e / nVza) % n), pt = (int)(e / ((size_t)nVza * n));
+  if (pt < a.n1_lo || pt >= a.n1_hi) return;
+  const int row = n * (node[v] - 1) + s;
+  const double cs = a.weight * ((s < 2) ? cosm[v + nVza * a.m] : sinm[v + nVza * a.m]);
+  out[e] += cs * a.c_cur[C_J0M][row + (size_t)N * pt];
+  out[tot + e] += cs * a.c_cur[C_J0P][row + (size_t)N * pt];
+  double sm = 0.0, sp = 0.0;
+  for (int t = 0; t < a.nR; ++t) {
+    const size_t o = row + (size_t)N * ((size_t)pt + (size_t)a.S * t);
+    sm += cs * a.ie_c[C_J0M][o];
+    sp += cs * a.ie_c[C_J0P][o];
+  }
+  out[2 * tot + e] += sm;
+  out[3 * tot + e] += sp;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+#define RCHK(call)                                 \
+  do {                                             \
+    hipError_t e__ = (call);                       \
+    if (e__ != hipSuccess) return e__;             \
+  } while (0)
+
+static KArgs base_args(const State *s, const Streams &q) {
+  KArgs a{};
+  a.N = s->N; a.nS = s->nS; a.S = s->S; a.nR = s->nR;
+  a.strict_idx = q.strict_idx; a.strict_rrs = s->strict_rrs;
+  a.n_glob0 = s->n_glob0; a.n1_lo = s->n1_lo; a.n1_hi = s->n1_hi;
+  a.imu0 = q.imu0; a.mu0 = q.mu0;
+  for (int k = 0; k < 4; ++k) { a.I0[k] = q.I0[k]; a.D[k] = q.D[k]; }
+  a.mu = q.mu; a.wt = q.wt; a.off = s->d_off; a.varpiR = s->d_varpiR;
+  for (int k = 0; k < 6; ++k) {
+    a.a_cur[k] = s->added[s->cur][k]; a.a_nxt[k] = s->added[1 - s->cur][k];
+    a.c_cur[k] = s->comp[s->ccur][k]; a.c_nxt[k] = s->comp[1 - s->ccur][k];
+    a.ie_a[k] = s->ie_added[k]; a.ie_c[k] = s->ie_comp[k];
+    a.sv[k] = s->svec[k];
+  }
+  // r+- / t-- of the added layer exist once
+  a.a_cur[R_PM] = a.a_nxt[R_PM] = s->added[0][R_PM];
+  a.a_cur[T_MM] = a.a_nxt[T_MM] = s->added[0][T_MM];
+  a.expk_cur = s->expk[s->cur]; a.expk_nxt = s->expk[1 - s->cur];
+  for (int k = 0; k < 10; ++k) a.sm[k] = s->smat[k];
+  a.jpseq = s->jpseq;
+  a.info = s->d_info;
+  return a;
+}
+
+template <class T>
+static hipError_t dm(T **p, size_t count) {
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
+  if (e == hipSuccess) e = hipMemset(*p, 0, count * sizeof(T));
+  return e;
+}
+
+hipError_t create(State **out, hipStream_t st, int N, int nS, int S, int nR, const int *off_host, const double *varpi_host,
+                  int strict_rrs, std::string *err) {
+  State *s = new State;
+  s->N = N; s->nS = nS; s->S = S; s->nR = nR; s->strict_rrs = strict_rrs; s->stream = st;
+  s->n1_lo = 0; s->n1_hi = S;
+  *out = s;
+  const size_t NN = (size_t)N * N, m3 = NN * S, v3 = (size_t)N * S, m4 = m3 * nR, v4 = v3 * nR;
+  RCHK(dm(&s->d_off, nR));
+  RCHK(dm(&s->d_varpiR, nR));
+  RCHK(hipMemcpy(s->d_off, off_host, sizeof(int) * nR, hipMemcpyHostToDevice));
+  RCHK(hipMemcpy(s->d_varpiR, varpi_host, sizeof(double) * nR, hipMemcpyHostToDevice));
+  for (int k = 0; k < nR; ++k) s->max_off = std::max(s->max_off, std::abs(off_host[k]));
+  for (int b = 0; b < 2; ++b) {
+    for (int k = 0; k < 6; ++k) {
+      if (b == 1 && (k == R_PM || k == T_MM)) continue;
+      RCHK(dm(&s->added[b][k], k < 4 ? m3 : v3));
+    }
+    for (int k = 0; k < 6; ++k) RCHK(dm(&s->comp[b][k], k < 4 ? m3 : v3));
+    RCHK(dm(&s->expk[b], S));
+  }
+  s->added[1][R_PM] = s->added[0][R_PM];
+  s->added[1][T_MM] = s->added[0][T_MM];
+  for (int k = 0; k < 6; ++k) RCHK(dm(&s->surf[k], k < 4 ? m3 : v3));
+  for (int k = 0; k < 10; ++k) RCHK(dm(&s->smat[k], m3));
+  for (int k = 0; k < 6; ++k) RCHK(dm(&s->svec[k], v3));
+  if (strict_rrs) RCHK(dm(&s->jpseq, v4));
+  for (int k = 0; k < 6; ++k) {
+    RCHK(dm(&s->ie_added[k], k < 4 ? m4 : v4));
+    RCHK(dm(&s->ie_comp[k], k < 4 ? m4 : v4));
+  }
+  RCHK(dm(&s->d_info, 1));
+  (void)err;
+  return hipSuccess;
+}
+
+void destroy(State *s) {
+  if (!s) return;
+  (void)hipFree(s->d_off); (void)hipFree(s->d_varpiR); (void)hipFree(s->jpseq); (void)hipFree(s->d_out); (void)hipFree(s->d_info);
+  for (int b = 0; b < 2; ++b) {
+    for (int k = 0; k < 6; ++k) {
+      if (!(b == 1 && (k == R_PM || k == T_MM))) (void)hipFree(s->added[b][k]);
+      (void)hipFree(s->comp[b][k]);
+    }
+    (void)hipFree(s->expk[b]);
+  }
+  for (int k = 0; k < 6; ++k) { (void)hipFree(s->surf[k]); (void)hipFree(s->svec[k]); (void)hipFree(s->ie_added[k]); (void)hipFree(s->ie_comp[k]); }
+  for (int k = 0; k < 10; ++k) (void)hipFree(s->smat[k]);
+  delete s;
+}
+
+static int grid_points(const State *s) { return std::max(1, std::min((s->S + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 8)); }
+static int grid_pairs(const State *s) {
+  const size_t np = (size_t)(s->n1_hi - s->n1_lo) * s->nR;
+  return (int)std::max<size_t>(1, std::min<size_t>((np + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 16));
+}
+template <int NT>
+static size_t lds() { return (size_t)kWavesPerBlock * slice_bytes<NT>(); }
+
+#define LAUNCH_NT(s, kern, grid, ...)                                                                              \
+  do {                                                                                                             \
+    if ((s)->N <= 16) hipLaunchKernelGGL((kern<1>), dim3(grid), dim3(64 * kWavesPerBlock), lds<1>(), (s)->stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((kern<2>), dim3(grid), dim3(64 * kWavesPerBlock), lds<2>(), (s)->stream, __VA_ARGS__);   \
+    RCHK(hipGetLastError());                                                                                       \
+  } while (0)
+
+hipError_t elemental(State *s, const Streams &q, int m, int nd, int shift, const double *tau_sum, const double *tau, const double *varpi,
+                     const double *Zpp, const double *Zmp, int nTerms, const double *zw, const double *fscatt,
+                     const double *Zr_pp, const double *Zr_mp, bool elastic, bool inelastic) {
+  KArgs a = base_args(s, q);
+  a.m = m; a.nd = nd; a.sh = shift; a.tau_sum = tau_sum; a.tau = tau; a.varpi = varpi; a.Zpp = Zpp; a.Zmp = Zmp; a.nTerms = nTerms; a.zw = zw;
+  a.fscatt = fscatt; a.Zr_pp = Zr_pp; a.Zr_mp = Zr_mp;
+  if (elastic) LAUNCH_NT(s, k_el_point, grid_points(s), a);
+  if (inelastic) {
+    const size_t tot = (size_t)s->N * s->N * (size_t)(s->n1_hi - s->n1_lo) * s->nR;
+    hipLaunchKernelGGL(k_ie_elemental, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, a);
+    RCHK(hipGetLastError());
+  }
+  return hipSuccess;
+}
+
+hipError_t doubling(State *s, const Streams &q, int nd) {
+  if (nd == 0) return hipSuccess;  // doubling_inelastic.jl:29
+  for (int k = 0; k < nd; ++k) {
+    KArgs a = base_args(s, q);
+    a.last = (k == nd - 1);
+    LAUNCH_NT(s, k_dbl_point, grid_points(s), a);
+    LAUNCH_NT(s, k_dbl_pair, grid_pairs(s), a);
+    s->cur = 1 - s->cur;
+  }
+  KArgs a = base_args(s, q);
+  if (s->nS == 1) {  // doubling_inelastic.jl:411-414: whole-array copies
+    const size_t cnt = (size_t)s->N * s->N * s->S * s->nR;
+    if (s->strict_rrs) {
+      hipLaunchKernelGGL(k_copy2, dim3(2048), dim3(256), 0, s->stream, s->ie_added[R_MP], s->ie_added[R_PM], s->ie_added[T_PP],
+                         s->ie_added[T_MM], cnt);
+      RCHK(hipGetLastError());
+    }
+  } else if (s->strict_rrs) {
+    const int tot = s->N * (s->n1_hi - s->n1_lo);
+    hipLaunchKernelGGL(k_strict_D, dim3((tot + 127) / 128), dim3(128), 0, s->stream, a);
+    RCHK(hipGetLastError());
+  }
+  return hipSuccess;
+}
+
+hipError_t copy_added_to_composite(State *s) {
+  const size_t NN = (size_t)s->N * s->N, m3 = NN * s->S * 8, v3 = (size_t)s->N * s->S * 8, m4 = m3 * s->nR, v4 = v3 * s->nR;
+  static const int amap[6] = {R_MP, R_PM, T_PP, T_MM, J0P, J0M};  // composite field k <- added field amap[k]
+  for (int k = 0; k < 6; ++k) {
+    RCHK(hipMemcpyAsync(s->comp[s->ccur][k], s->added[s->cur][amap[k]], k < 4 ? m3 : v3, hipMemcpyDeviceToDevice, s->stream));
+    RCHK(hipMemcpyAsync(s->ie_comp[k], s->ie_added[amap[k]], k < 4 ? m4 : v4, hipMemcpyDeviceToDevice, s->stream));
+  }
+  return hipSuccess;
+}
+
+hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface) {
+  if (iface < 0 || iface > 3) return hipErrorInvalidValue;
+  if (iface != 3 && s->strict_rrs) {
+    s->err = "interaction_helper!(::RRS, ::ScatteringInterface_00/01/10): the reference raises a MethodError "
+             "(interaction_inelastic.jl:8-12, 28-37, 139-148); available with rrs_strict_reference = 0";
+    return hipErrorInvalidValue;
+  }
+  KArgs a = base_args(s, q);
+  for (int k = 0; k < 6; ++k) a.x[k] = with_surface ? s->surf[k] : s->added[s->cur][k];
+  if (!with_surface) { a.x[R_PM] = s->added[0][R_PM]; a.x[T_MM] = s->added[0][T_MM]; }
+  LAUNCH_NT(s, k_int_point, grid_points(s), a, iface);
+  if (iface == 0) {  // interaction_inelastic.jl:16-17
+    const size_t v4 = (size_t)s->N * s->S * s->nR * 8;
+    RCHK(hipMemsetAsync(s->ie_comp[C_J0P], 0, v4, s->stream));
+    RCHK(hipMemsetAsync(s->ie_comp[C_J0M], 0, v4, s->stream));
+  } else if (with_surface) {
+    if (s->N <= 16) hipLaunchKernelGGL((k_int_pair<1, true>), dim3(grid_pairs(s)), dim3(64 * kWavesPerBlock), lds<1>(), s->stream, a, iface);
+    else hipLaunchKernelGGL((k_int_pair<2, true>), dim3(grid_pairs(s)), dim3(64 * kWavesPerBlock), lds<2>(), s->stream, a, iface);
+    RCHK(hipGetLastError());
+  } else {
+    if (s->N <= 16) hipLaunchKernelGGL((k_int_pair<1, false>), dim3(grid_pairs(s)), dim3(64 * kWavesPerBlock), lds<1>(), s->stream, a, iface);
+    else hipLaunchKernelGGL((k_int_pair<2, false>), dim3(grid_pairs(s)), dim3(64 * kWavesPerBlock), lds<2>(), s->stream, a, iface);
+    RCHK(hipGetLastError());
+  }
+  s->ccur = 1 - s->ccur;
+  return hipSuccess;
+}
+
+hipError_t surface_lambertian(State *s, const Streams &q, int m, double albedo, const double *tau_tot) {
+  KArgs a = base_args(s, q);
+  a.m = m; a.albedo = albedo;
+  for (int k = 0; k < 6; ++k) a.x[k] = s->surf[k];
+  hipLaunchKernelGGL(k_surface_fill, dim3(s->S), dim3(256), 0, s->stream, a, tau_tot);
+  return hipGetLastError();
+}
+
+hipError_t begin_run(State *s, int nVza) {
+  const size_t cnt = (size_t)4 * nVza * s->nS * s->S;
+  if (s->out_nVza != nVza) {
+    (void)hipFree(s->d_out);
+    s->d_out = nullptr;
+    RCHK(hipMalloc(reinterpret_cast<void **>(&s->d_out), cnt * 8));
+    s->out_nVza = nVza;
+  }
+  return hipMemsetAsync(s->d_out, 0, cnt * 8, s->stream);
+}
+
+hipError_t postprocess(State *s, const Streams &q, int m, int nVza, const int *d_node, const double *d_cos, const double *d_sin,
+                       int M, double weight) {
+  KArgs a = base_args(s, q);
+  a.m = m; a.weight = weight;
+  const size_t tot = (size_t)nVza * s->nS * s->S;
+  hipLaunchKernelGGL(k_post, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, a, nVza, d_node, d_cos, d_sin, M, s->d_out);
+  return hipGetLastError();
+}
+
+}  // namespace momr

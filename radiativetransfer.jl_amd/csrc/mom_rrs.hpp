@@ -1,0 +1,77 @@
+// mom_rrs.hpp -- host interface of the rotational-Raman (RRS) kernels (mom_rrs.hip) towards momcore.hip.
+//
+// State of the inelastic path of rt_run(::RRS) (src/CoreRT/rt_run.jl:41-230): the reference's AddedLayerRS / CompositeLayerRS
+// (types.jl:145-205) as persistent HBM arrays in the reference's own memory order -- elastic operators [N,N,S], sources
+// [N,S], inelastic operators [N,N,S,nRaman], inelastic sources [N,S,nRaman] (Julia column-major) -- plus per-point scratch
+// operands of the current doubling step / interaction.  All device memory is owned by State.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+namespace momr {
+
+struct Streams {
+  const double *mu, *wt;  // [N] device
+  double I0[4], D[4];
+  int N, nS, imu0, strict_idx;
+  double mu0;
+};
+
+// indices into State::added / surf / comp
+enum { R_PM = 0, R_MP = 1, T_MM = 2, T_PP = 3, J0P = 4, J0M = 5 };        // AddedLayer field order of momcore.h
+enum { C_R_MP = 0, C_R_PM = 1, C_T_PP = 2, C_T_MM = 3, C_J0P = 4, C_J0M = 5 };  // CompositeLayer field order
+
+struct State {
+  int N = 0, nS = 0, S = 0, nR = 0;
+  int strict_rrs = 1;      // rrs_strict_reference (DESIGN.md "RRS": D1..D5)
+  int n_glob0 = 0;         // global 0-based spectral index of local index 0 (shards; strict D2/D3 use absolute indices)
+  int n1_lo = 0, n1_hi = 0;  // spectral points this rank owns: pairs (n1, dn) are processed for n1 in [n1_lo, n1_hi)
+  hipStream_t stream = nullptr;
+  int *d_off = nullptr;         // [nR] i_l1l0
+  double *d_varpiR = nullptr;   // [nR]
+  int max_off = 0;
+  // elastic added layer, double-buffered over the doubling steps (cur = buffer holding the current state)
+  double *added[2][6] = {};     // R_PM / T_MM exist once (added[0]) and are written after the doubling
+  double *expk[2] = {};
+  int cur = 0;
+  double *surf[6] = {};
+  double *comp[2][6] = {};
+  int ccur = 0;
+  // per-point scratch operands: up to 10 matrices [N,N,S], 6 vectors [N,S], the j0+ sequence of the strict position
+  double *smat[10] = {};
+  double *svec[6] = {};
+  double *jpseq = nullptr;      // [N,S,nR]
+  // inelastic layers
+  double *ie_added[6] = {};     // ier+-, ier-+, iet--, iet++ [N,N,S,nR]; ieJ0+, ieJ0- [N,S,nR]   (R_PM.. order)
+  double *ie_comp[6] = {};      // ieR-+, ieR+-, ieT++, ieT-- ; ieJ0+, ieJ0-                     (C_R_MP.. order)
+  double *d_out = nullptr;      // ieR_SFI || ieT_SFI [2][nVza,nS,S] and R_SFI || T_SFI [2][nVza,nS,S]
+  int out_nVza = 0;
+  int *d_info = nullptr;
+  std::string err;
+};
+
+hipError_t create(State **out, hipStream_t st, int N, int nS, int S, int nR, const int *off_host, const double *varpi_host,
+                  int strict_rrs, std::string *err);
+void destroy(State *s);
+
+// elemental!(...) elastic part + elemental_inelastic!(::RRS) on the persistent added layer.  Zpp/Zmp: device [N,N] x nTerms with
+// per-point weights zw [nTerms,S] (zw == nullptr: one term of weight 1); Zr*: device [N,N] Raman phase matrices; all
+// spectral vectors device [S]; the elemental optical thickness is tau / 2^shift.
+hipError_t elemental(State *s, const Streams &q, int m, int nd, int shift, const double *tau_sum, const double *tau, const double *varpi,
+                     const double *Zpp, const double *Zmp, int nTerms, const double *zw, const double *fscatt,
+                     const double *Zr_pp, const double *Zr_mp, bool elastic, bool inelastic);
+// doubling_helper!(::RRS): nd steps on the persistent added layer (expk in s->expk[s->cur]); applies the D kernels at the end
+hipError_t doubling(State *s, const Streams &q, int nd);
+// rt_kernel.jl:326-333
+hipError_t copy_added_to_composite(State *s);
+// interaction_helper!(::RRS, iface): returns hipErrorInvalidValue with s->err set where the reference raises (strict position)
+hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface);
+// create_surface_layer!(::LambertianSurfaceScalar) into s->surf (ie* of the surface layer are zeros: never allocated)
+hipError_t surface_lambertian(State *s, const Streams &q, int m, double albedo, const double *tau_tot);
+// postprocessing_vza!(::RRS): accumulates into s->d_out (zeroed by begin_run)
+hipError_t begin_run(State *s, int nVza);
+hipError_t postprocess(State *s, const Streams &q, int m, int nVza, const int *d_node, const double *d_cos, const double *d_sin,
+                       int M, double weight);
+
+}  // namespace momr

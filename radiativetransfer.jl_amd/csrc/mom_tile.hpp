@@ -1,0 +1,305 @@
+// mom_tile.hpp -- one-wavefront register tiles on the FP64 matrix cores (shared by the wave-per-unit kernels).
+//
+// A 16 x 16 tile in the C/D layout of v_mfma_f64_16x16x4_f64 (lane l, register r: row (l >> 4) + 4 r, column l & 15) is
+// four doubles per lane.  Feeding register s of tile U as the A operand and register s of tile V as the B operand of the
+// four k-steps of a 16 x 16 x 16 product gives TN(U, V) = U^T V in the same layout (the A operand is read as
+// A[row = l & 15][k = l >> 4]: a C-layout tile IS the A operand of its transpose).  A matrix of edge N <= 16 NT is
+// NT x NT tiles.  Naming used by the callers: X_c = X in C-layout, X_t = X^T in C-layout; then
+//      (L R)_c = TN(L_t, R_c)          (L R)_t = TN(R_c, L_t)
+// i.e. a product needs its left factor transposed and its right factor plain, and comes out in either orientation.
+// A column-major [N, N] block in memory loads COALESCED into the _t form (lanes l & 15 run along a column) and stores
+// coalesced from it; the _c form of the same block is one pass through a wave-private LDS slice (transpose()).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace momt {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+struct Mat {
+  d4 t[NT][NT];  // t[bi][bj]: rows 16 bi .., columns 16 bj ..
+};
+template <int NT>
+struct Vec {
+  d4 t[NT];  // row block bi; column c of the tile (lanes l & 15 == c) is vector number c
+};
+
+struct Geo {
+  int lr, lq, N;
+  double *xp;  // wave-private LDS slice (slice_doubles<NT>() doubles)
+  int *ipiv;   // 16 NT ints
+  __device__ __forceinline__ int row(int bi, int r) const { return 16 * bi + lq + 4 * r; }
+  __device__ __forceinline__ int col(int bj) const { return 16 * bj + lr; }
+};
+
+constexpr int kTileLd = 17;                 // pitch of a 16 x 16 tile in the LDS slice
+constexpr int kTileDoubles = 16 * kTileLd;  // 272
+template <int NT>
+constexpr int slice_doubles() {
+  return (NT * NT * kTileDoubles > (16 * NT) * (16 * NT + 1) ? NT * NT * kTileDoubles : (16 * NT) * (16 * NT + 1));
+}
+template <int NT>
+constexpr int slice_bytes() { return slice_doubles<NT>() * 8 + 16 * NT * 4; }
+
+template <int NT>
+__device__ __forceinline__ Mat<NT> zeros() {
+  Mat<NT> Z;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) Z.t[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+  return Z;
+}
+template <int NT>
+__device__ __forceinline__ Vec<NT> vzeros() {
+  Vec<NT> Z;
+#pragma unroll
+  for (int a = 0; a < NT; ++a) Z.t[a] = (d4){0.0, 0.0, 0.0, 0.0};
+  return Z;
+}
+
+// acc + U^T V; k-steps whose rows are all >= N (zero padding) are skipped
+template <int NT>
+__device__ __forceinline__ Mat<NT> TNacc(const Geo &g, const Mat<NT> &U, const Mat<NT> &V, Mat<NT> acc) {
+#pragma unroll
+  for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (16 * tk + 4 * s < g.N) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < NT; ++tj)
+            acc.t[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(U.t[tk][ti][s], V.t[tk][tj][s], acc.t[ti][tj], 0, 0, 0);
+      }
+  return acc;
+}
+template <int NT>
+__device__ __forceinline__ Mat<NT> TN(const Geo &g, const Mat<NT> &U, const Mat<NT> &V) {
+  return TNacc<NT>(g, U, V, zeros<NT>());
+}
+// acc + U^T v for the (up to 16) vectors held as tile columns
+template <int NT>
+__device__ __forceinline__ Vec<NT> TNvacc(const Geo &g, const Mat<NT> &U, const Vec<NT> &v, Vec<NT> o) {
+#pragma unroll
+  for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (16 * tk + 4 * s < g.N) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+          o.t[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(U.t[tk][ti][s], v.t[tk][s], o.t[ti], 0, 0, 0);
+      }
+  return o;
+}
+template <int NT>
+__device__ __forceinline__ Vec<NT> TNv(const Geo &g, const Mat<NT> &U, const Vec<NT> &v) {
+  return TNvacc<NT>(g, U, v, vzeros<NT>());
+}
+
+template <int NT>
+__device__ __forceinline__ Mat<NT> add(const Mat<NT> &A, const Mat<NT> &B) {
+  Mat<NT> C;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) C.t[a][b] = A.t[a][b] + B.t[a][b];
+  return C;
+}
+template <int NT>
+__device__ __forceinline__ Vec<NT> vadd(const Vec<NT> &A, const Vec<NT> &B) {
+  Vec<NT> C;
+#pragma unroll
+  for (int a = 0; a < NT; ++a) C.t[a] = A.t[a] + B.t[a];
+  return C;
+}
+template <int NT>
+__device__ __forceinline__ Vec<NT> vscale(const Vec<NT> &A, double s) {
+  Vec<NT> C;
+#pragma unroll
+  for (int a = 0; a < NT; ++a) C.t[a] = A.t[a] * s;
+  return C;
+}
+template <int NT>
+__device__ __forceinline__ Vec<NT> swap01(const Vec<NT> &v) {  // exchange columns 0 <-> 1
+  Vec<NT> o;
+#pragma unroll
+  for (int b = 0; b < NT; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o.t[b][r] = __shfl_xor(v.t[b][r], 1);
+  return o;
+}
+
+// column-major [N, N] block -> X_t (coalesced) / X_c (strided)
+template <int NT>
+__device__ __forceinline__ Mat<NT> load_t(const Geo &g, const double *p) {
+  Mat<NT> X;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ro = g.row(a, r), co = g.col(b);
+        X.t[a][b][r] = (ro < g.N && co < g.N) ? p[co + (size_t)g.N * ro] : 0.0;
+      }
+  return X;
+}
+template <int NT>
+__device__ __forceinline__ Mat<NT> load_c(const Geo &g, const double *p) {
+  Mat<NT> X;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ro = g.row(a, r), co = g.col(b);
+        X.t[a][b][r] = (ro < g.N && co < g.N) ? p[ro + (size_t)g.N * co] : 0.0;
+      }
+  return X;
+}
+template <int NT>
+__device__ __forceinline__ void store_t(const Geo &g, double *p, const Mat<NT> &X) {
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ro = g.row(a, r), co = g.col(b);
+        if (ro < g.N && co < g.N) p[co + (size_t)g.N * ro] = X.t[a][b][r];
+      }
+}
+// two vectors [N] as columns 0 and 1 (nullptr: zeros)
+template <int NT>
+__device__ __forceinline__ Vec<NT> loadv2(const Geo &g, const double *p0, const double *p1) {
+  Vec<NT> v;
+  const double *p = (g.lr == 0) ? p0 : ((g.lr == 1) ? p1 : nullptr);
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ro = g.row(a, r);
+      v.t[a][r] = (p != nullptr && ro < g.N) ? p[ro] : 0.0;
+    }
+  return v;
+}
+template <int NT>
+__device__ __forceinline__ void storev(const Geo &g, double *p, const Vec<NT> &v, int column) {
+  if (g.lr != column) return;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ro = g.row(a, r);
+      if (ro < g.N) p[ro] = v.t[a][r];
+    }
+}
+
+// X^T through the wave's LDS slice: tile (a, b) of the result is the transpose of tile (b, a)
+template <int NT>
+__device__ __forceinline__ Mat<NT> transpose(const Geo &g, const Mat<NT> &X) {
+  double *buf = g.xp;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) buf[(a * NT + b) * kTileDoubles + (g.lq + 4 * r) * kTileLd + g.lr] = X.t[a][b][r];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  Mat<NT> Y;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Y.t[a][b][r] = buf[(b * NT + a) * kTileDoubles + g.lr * kTileLd + g.lq + 4 * r];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  return Y;
+}
+
+template <int NT>
+__device__ __forceinline__ Mat<NT> ident(const Geo &g) {
+  Mat<NT> I;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) I.t[a][b][r] = (a == b && g.lq + 4 * r == g.lr && g.col(b) < g.N) ? 1.0 : 0.0;
+  return I;
+}
+
+// (I - B)^-1 for B given in either orientation (the result comes out in the same one): Gauss-Jordan elimination with
+// implicit partial pivoting, one matrix row per lane through the wave's LDS slice.  *bad_out = 1 + the step of a zero pivot.
+template <int NT>
+__device__ __noinline__ Mat<NT> inv_one_minus(const Geo &g, Mat<NT> B, int *bad_out) {
+  constexpr int NP = 16 * NT, LDM = NP + 1;
+  const int N = g.N, lane = 16 * g.lq + g.lr, lr = g.lr, lq = g.lq;
+  double *lds = g.xp;
+  int *ipiv = g.ipiv;
+  int bad = 0;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * a + lq + 4 * r, j = 16 * b + lr;
+        lds[i * LDM + j] = ((i == j) ? 1.0 : 0.0) - B.t[a][b][r];
+      }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  double v[NP];
+#pragma unroll
+  for (int c = 0; c < NP; ++c) v[c] = (lane < N && c < N) ? lds[lane * LDM + c] : ((lane == c) ? 1.0 : 0.0);
+  bool used = false;
+  int myk = lane;  // rows >= N keep their identity row
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    if (k < N) {
+      const int ah = (!used && lane < N) ? __double2hiint(fabs(v[k])) : -1;
+      int mh = ah;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mh = max(mh, __shfl_xor(mh, off));
+      const unsigned long long mk = __ballot(ah == mh);
+      const int pl = __ffsll((long long)mk) - 1;
+      const double piv = __shfl(v[k], pl);
+      if (!(fabs(piv) > 0.0) && !bad) bad = k + 1;
+      const double d = 1.0 / piv, f = v[k];
+      const bool isp = (lane == pl);
+#pragma unroll
+      for (int c = 0; c < NP; ++c) {
+        const double prow = __shfl(v[c], pl) * d;
+        v[c] = isp ? prow : (v[c] - f * prow);
+      }
+      v[k] = isp ? d : (-f * d);
+      if (isp) { used = true; myk = k; }
+      if (lane == 0) ipiv[k] = pl;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // inv(A)[k][p_j] = S[p_k][j]: lane (row p_k, pivot of step myk) writes row myk with permuted columns
+  if (lane < N) {
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+      if (c < N) lds[myk * LDM + ipiv[c]] = v[c];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  Mat<NT> G;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 16 * a + lq + 4 * r, j = 16 * b + lr;
+        G.t[a][b][r] = (i < N && j < N) ? lds[i * LDM + j] : 0.0;
+      }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  if (bad) *bad_out = bad;
+  return G;
+}
+
+}  // namespace momt

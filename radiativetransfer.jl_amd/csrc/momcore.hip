@@ -17,6 +17,7 @@
 #include "mom_diag.hpp"
 #include "mom_entry.hpp"
 #include "mom_host.hpp"
+#include "mom_rrs.hpp"
 
 using namespace mom;
 
@@ -515,6 +516,12 @@ struct mom_handle {
   hipEvent_t ev[4] = {};
   std::vector<hipEvent_t> ev_full, ev_red;  // start/stop pairs around each full-problem / reduced layer launch
   int launches = 0, launches_full = 0, launches_red = 0;
+  // rotational-Raman path (mom_rrs.hip): the persistent AddedLayerRS / CompositeLayerRS state and the scene's Raman inputs
+  momr::State *rrs = nullptr;
+  double *d_fscatt = nullptr, *d_Zr[2] = {};  // fScattRayleigh [S,Nz]; Raman phase matrices [N,N,M] x2
+  double *d_rrs_op[8] = {};                   // operator-level inputs: tau_sum, dtau, varpi, fscatt [S]; Z x4 [N,N]
+  bool rrs_scene = false;
+  double rrs_ms = 0.0;
   std::string err;
 };
 
@@ -663,6 +670,9 @@ extern "C" int mom_destroy(mom_t *h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   if (h->f32) momf_destroy(h->f32);
+  momr::destroy(h->rrs);
+  (void)hipFree(h->d_fscatt); (void)hipFree(h->d_Zr[0]); (void)hipFree(h->d_Zr[1]);
+  for (int k = 0; k < 8; ++k) (void)hipFree(h->d_rrs_op[k]);
   if (h->comm && g_rccl_destroy) g_rccl_destroy(h->comm);
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(h->d_mu); fr(h->d_wt); fr(h->d_sg);
@@ -702,7 +712,7 @@ extern "C" int mom_set_option(mom_t *h, int option, int value) {
   else if (option == MOM_OPT_M0_REDUCTION) h->opt_m0 = value;
   else if (option == MOM_OPT_SMALL_WG) h->opt_w4 = value;
   else if (option == MOM_OPT_STAGGER) h->opt_stagger = value;
-  else if (option == MOM_OPT_SMALL_N) h->opt_small = value;
+  else if (option == MOM_OPT_SMALL_N) { h->opt_small = value; h->scene_set = false; }  // the padded edge Nk depends on it
   else if (option == MOM_OPT_LAYER_SWEEP) h->opt_sweep = value;
   else if (option == MOM_OPT_STRIP_PAD) { h->opt_pad = value; h->scene_set = false; }
   else if (option == MOM_OPT_FORCE_GENERIC) {
@@ -2190,6 +2200,232 @@ extern "C" int mom_scene_get_layers(mom_t *h, int *ndoubl, int *iface, double *t
   if (zw) HIPCHK(h, hipMemcpyAsync(zw, h->d_zw, (size_t)h->K * S * Nz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (tau_sum) HIPCHK(h, hipMemcpyAsync(tau_sum, h->d_tau_sum, S * (Nz + 1) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+
+// =========================================================================================
+// rotational-Raman path (BASELINE config 5): rt_run(::RRS) -- kernels in mom_rrs.hip
+// =========================================================================================
+#define RRSCHK(h, call)                                                                                        \
+  do {                                                                                                         \
+    hipError_t e__ = (call);                                                                                   \
+    if (e__ != hipSuccess) {                                                                                   \
+      if ((h)->rrs && !(h)->rrs->err.empty()) {                                                                \
+        const std::string m__ = (h)->rrs->err;                                                                 \
+        (h)->rrs->err.clear();                                                                                 \
+        return fail(h, MOM_EUNSUPPORTED, m__.c_str());                                                         \
+      }                                                                                                        \
+      char buf__[512];                                                                                         \
+      snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return fail(h, MOM_EHIP, buf__);                                                                         \
+    }                                                                                                          \
+  } while (0)
+
+static momr::Streams rrs_streams(const mom_t *h) {
+  momr::Streams q{};
+  q.mu = h->d_mu; q.wt = h->d_wt;
+  for (int k = 0; k < 4; ++k) { q.I0[k] = h->q.I0[k]; q.D[k] = h->q.D[k]; }
+  q.N = h->N; q.nS = h->nS; q.imu0 = h->q.imu0; q.strict_idx = h->strict; q.mu0 = h->q.mu0;
+  return q;
+}
+static int rrs_ready(mom_t *h, const char *who) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (h->dtype != 0) return fail(h, MOM_EINVAL, "the RRS path is Float64 only");
+  if (!h->rrs) { static thread_local char b[128]; snprintf(b, sizeof b, "%s: call mom_rrs_set first", who); return fail(h, MOM_ESTATE, b); }
+  if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_set_streams must be called first");
+  HIPCHK(h, hipSetDevice(h->device));
+  return MOM_OK;
+}
+
+extern "C" int mom_rrs_set(mom_t *h, int nRaman, const int *i_l1l0, const double *varpi_l1l0, int rrs_strict_reference) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_rrs_set");
+  if (nRaman <= 0 || !i_l1l0 || !varpi_l1l0) return fail(h, MOM_EINVAL, "mom_rrs_set: bad argument");
+  if (h->N > 32) return fail(h, MOM_EUNSUPPORTED, "mom_rrs_set: the RRS kernels cover operator edges N <= 32 (the reference's RRS shape is N = 15)");
+  for (int k = 0; k < nRaman; ++k)
+    if (std::abs(i_l1l0[k]) >= h->S) return fail(h, MOM_EINVAL, "mom_rrs_set: |i_l1l0| must be < nSpec (get_n0_n1 fails in the reference)");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  momr::destroy(h->rrs);
+  h->rrs = nullptr;
+  h->rrs_scene = false;
+  const hipError_t e = momr::create(&h->rrs, h->stream, h->N, h->nS, h->S, nRaman, i_l1l0, varpi_l1l0, rrs_strict_reference ? 1 : 0, nullptr);
+  if (e != hipSuccess) {
+    momr::destroy(h->rrs);
+    h->rrs = nullptr;
+    char buf[256];
+    snprintf(buf, sizeof buf, "mom_rrs_set: allocating the RRS layers failed: %s", hipGetErrorString(e));
+    return fail(h, MOM_EHIP, buf);
+  }
+  h->rrs->d_info = h->rrs->d_info;  // own flag; reported by rrs_check
+  return MOM_OK;
+}
+
+static int rrs_check(mom_t *h) {
+  int info = 0;
+  HIPCHK(h, hipMemcpyAsync(&info, h->rrs->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (info) {
+    HIPCHK(h, hipMemsetAsync(h->rrs->d_info, 0, sizeof(int), h->stream));
+    char buf[128];
+    snprintf(buf, sizeof buf, "zero pivot at elimination step %d while inverting (I - R r) (RRS path)", info);
+    return fail(h, MOM_ESINGULAR, buf);
+  }
+  return MOM_OK;
+}
+
+static double *rrs_which(mom_t *h, int which, size_t *count) {
+  momr::State *s = h->rrs;
+  const size_t NN = (size_t)s->N * s->N, m3 = NN * s->S, v3 = (size_t)s->N * s->S;
+  if (which < 0 || which >= 30) return nullptr;
+  const int grp = which / 6, k = which % 6;
+  const bool mat = k < 4;
+  *count = (mat ? m3 : v3) * (grp >= 3 ? (size_t)s->nR : 1);
+  switch (grp) {
+    case 0: return s->added[(k == momr::R_PM || k == momr::T_MM) ? 0 : s->cur][k];
+    case 1: return s->comp[s->ccur][k];
+    case 2: return s->surf[k];
+    case 3: return s->ie_added[k];
+    default: return s->ie_comp[k];
+  }
+}
+extern "C" int mom_rrs_upload(mom_t *h, int which, const double *src) {
+  int rc = rrs_ready(h, "mom_rrs_upload");
+  if (rc) return rc;
+  size_t count = 0;
+  double *p = rrs_which(h, which, &count);
+  if (!p || !src) return fail(h, MOM_EINVAL, "mom_rrs_upload: bad argument");
+  HIPCHK(h, hipMemcpyAsync(p, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+extern "C" int mom_rrs_download(mom_t *h, int which, double *dst) {
+  int rc = rrs_ready(h, "mom_rrs_download");
+  if (rc) return rc;
+  size_t count = 0;
+  double *p = rrs_which(h, which, &count);
+  if (!p || !dst) return fail(h, MOM_EINVAL, "mom_rrs_download: bad argument");
+  HIPCHK(h, hipMemcpyAsync(dst, p, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_rrs_elemental(mom_t *h, int m, int ndoubl, const double *tau_sum, const double *dtau, const double *varpi,
+                                 const double *Zpp, const double *Zmp, const double *fscattRayl, const double *Zpp_l1l0,
+                                 const double *Zmp_l1l0) {
+  int rc = rrs_ready(h, "mom_rrs_elemental");
+  if (rc) return rc;
+  if (!tau_sum || !dtau || !varpi || !Zpp || !Zmp || !fscattRayl || !Zpp_l1l0 || !Zmp_l1l0 || ndoubl < 0 || ndoubl > 62)
+    return fail(h, MOM_EINVAL, "mom_rrs_elemental: bad argument");
+  const size_t S = h->S, NN = (size_t)h->N * h->N;
+  const double *src[8] = {tau_sum, dtau, varpi, fscattRayl, Zpp, Zmp, Zpp_l1l0, Zmp_l1l0};
+  for (int k = 0; k < 8; ++k) {
+    const size_t cnt = (k < 4) ? S : NN;
+    if (!h->d_rrs_op[k]) HIPCHK(h, dmalloc(&h->d_rrs_op[k], cnt));
+    HIPCHK(h, hipMemcpyAsync(h->d_rrs_op[k], src[k], cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  double *const *d = h->d_rrs_op;
+  RRSCHK(h, momr::elemental(h->rrs, rrs_streams(h), m, ndoubl, 0, d[0], d[1], d[2], d[4], d[5], 1, nullptr, d[3], d[6], d[7], true, true));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_rrs_doubling(mom_t *h, int ndoubl, double *expk) {
+  int rc = rrs_ready(h, "mom_rrs_doubling");
+  if (rc) return rc;
+  if (ndoubl < 0 || !expk) return fail(h, MOM_EINVAL, "mom_rrs_doubling: bad argument");
+  momr::State *s = h->rrs;
+  HIPCHK(h, hipMemcpyAsync(s->expk[s->cur], expk, (size_t)h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RRSCHK(h, momr::doubling(s, rrs_streams(h), ndoubl));
+  HIPCHK(h, hipMemcpyAsync(expk, s->expk[s->cur], (size_t)h->S * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return rrs_check(h);
+}
+
+extern "C" int mom_rrs_interaction(mom_t *h, int iface, int with_surface_layer) {
+  int rc = rrs_ready(h, "mom_rrs_interaction");
+  if (rc) return rc;
+  if (iface < 0 || iface > 3) return fail(h, MOM_EINVAL, "mom_rrs_interaction: iface must be 0..3");
+  RRSCHK(h, momr::interaction(h->rrs, rrs_streams(h), iface, with_surface_layer != 0));
+  return rrs_check(h);
+}
+
+extern "C" int mom_rrs_copy_added_to_composite(mom_t *h) {
+  int rc = rrs_ready(h, "mom_rrs_copy_added_to_composite");
+  if (rc) return rc;
+  RRSCHK(h, momr::copy_added_to_composite(h->rrs));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_rrs_surface_lambertian(mom_t *h, int m, double albedo, const double *tau_tot) {
+  int rc = rrs_ready(h, "mom_rrs_surface_lambertian");
+  if (rc) return rc;
+  if (!tau_tot) return fail(h, MOM_EINVAL, "mom_rrs_surface_lambertian: bad argument");
+  HIPCHK(h, hipMemcpyAsync(h->d_vec[0], tau_tot, (size_t)h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RRSCHK(h, momr::surface_lambertian(h->rrs, rrs_streams(h), m, albedo, h->d_vec[0]));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_scene_set_rrs(mom_t *h, const double *fscattRayl, const double *Zpp_l1l0, const double *Zmp_l1l0) {
+  int rc = rrs_ready(h, "mom_scene_set_rrs");
+  if (rc) return rc;
+  if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_scene_set_rrs: call mom_scene_set / mom_scene_set_optics first");
+  if (!fscattRayl || !Zpp_l1l0 || !Zmp_l1l0) return fail(h, MOM_EINVAL, "mom_scene_set_rrs: bad argument");
+  if (h->Nk != h->N) return fail(h, MOM_ESTATE, "mom_scene_set_rrs: the scene was set with a padded operator edge (MOM_OPT_STRIP_PAD)");
+  if (h->surf_kind != 0) return fail(h, MOM_EUNSUPPORTED, "mom_scene_set_rrs: the RRS path supports LambertianSurfaceScalar only");
+  const size_t NN = (size_t)h->N * h->N;
+  if ((rc = upload_new(h, &h->d_fscatt, fscattRayl, (size_t)h->S * h->Nz))) return rc;
+  if ((rc = upload_new(h, &h->d_Zr[0], Zpp_l1l0, NN * h->scene_M))) return rc;
+  if ((rc = upload_new(h, &h->d_Zr[1], Zmp_l1l0, NN * h->scene_M))) return rc;
+  h->rrs_scene = true;
+  return MOM_OK;
+}
+
+extern "C" int mom_rt_run_rrs(mom_t *h) {
+  int rc = rrs_ready(h, "mom_rt_run_rrs");
+  if (rc) return rc;
+  if (!h->scene_set || !h->rrs_scene) return fail(h, MOM_ESTATE, "mom_rt_run_rrs: call mom_scene_set and mom_scene_set_rrs first");
+  momr::State *s = h->rrs;
+  const momr::Streams q = rrs_streams(h);
+  const size_t S = h->S, NN = (size_t)h->N * h->N;
+  const int Nz = h->Nz, K = h->K, M = h->scene_M;
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  RRSCHK(h, momr::begin_run(s, h->nVza));
+  for (int m = 0; m < M; ++m) {
+    for (int iz = 0; iz < Nz; ++iz) {                                              // rt_run.jl:143-165
+      const int nd = h->nd[iz];
+      RRSCHK(h, momr::elemental(s, q, m, nd, nd, h->d_tau_sum + S * iz, h->d_tau + S * iz, h->d_varpi + S * iz,
+                                h->d_Zpp + NN * K * m, h->d_Zmp + NN * K * m, K, h->d_zw + (size_t)K * S * iz,
+                                h->d_fscatt + S * iz, h->d_Zr[0] + NN * m, h->d_Zr[1] + NN * m, true, true));
+      RRSCHK(h, momr::doubling(s, q, nd));
+      if (iz == 0) RRSCHK(h, momr::copy_added_to_composite(s));                    // rt_kernel.jl:326-333
+      else RRSCHK(h, momr::interaction(s, q, h->iface[iz], false));
+    }
+    RRSCHK(h, momr::surface_lambertian(s, q, m, h->albedo, h->d_tau_sum + S * Nz));   // rt_run.jl:168-175
+    RRSCHK(h, momr::interaction(s, q, h->iface[Nz - 1], true));                    // rt_run.jl:179-185 (Q6)
+    RRSCHK(h, momr::postprocess(s, q, m, h->nVza, h->d_node, h->d_cos, h->d_sin, M, m == 0 ? 0.5 : 1.0));
+  }
+  HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+  return MOM_OK;
+}
+
+extern "C" int mom_get_RT_rrs(mom_t *h, double *R_SFI, double *T_SFI, double *ieR_SFI, double *ieT_SFI, double *gpu_ms) {
+  int rc = rrs_ready(h, "mom_get_RT_rrs");
+  if (rc) return rc;
+  momr::State *s = h->rrs;
+  if (!s->d_out) return fail(h, MOM_ESTATE, "mom_get_RT_rrs: no run");
+  const size_t tot = (size_t)s->out_nVza * h->nS * h->S;
+  double *dst[4] = {R_SFI, T_SFI, ieR_SFI, ieT_SFI};
+  for (int k = 0; k < 4; ++k)
+    if (dst[k]) HIPCHK(h, hipMemcpyAsync(dst[k], s->d_out + tot * k, tot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if ((rc = rrs_check(h))) return rc;
+  if (gpu_ms) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[3]) != hipSuccess) ms = 0.f;
+    *gpu_ms = ms;
+  }
   return MOM_OK;
 }
 

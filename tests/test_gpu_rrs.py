@@ -1,0 +1,220 @@
+"""GPU parity of the rotational-Raman path (BASELINE config 5) through the C ABI against oracle/rrsref.py, operator by
+operator and scene-level, in both positions of rrs_strict_reference."""
+import copy
+
+import numpy as np
+import pytest
+
+import helpers
+from oracle import momref as mr
+from oracle import rrsref as rr
+
+pytestmark = pytest.mark.gpu
+
+A_EL = ("r_pm", "r_mp", "t_mm", "t_pp", "j0p", "j0m")            # which 0..5
+C_EL = ("R_mp", "R_pm", "T_pp", "T_mm", "J0p", "J0m")            # which 6..11
+A_IE = ("ier_pm", "ier_mp", "iet_mm", "iet_pp", "ieJ0p", "ieJ0m")  # which 18..23
+C_IE = ("ieR_mp", "ieR_pm", "ieT_pp", "ieT_mm", "ieJ0p", "ieJ0m")  # which 24..29
+
+
+def abi(x):
+    """oracle layout -> flat ABI (Julia column-major [i,j,n(,dn)] / [i,n(,dn)])."""
+    x = np.asarray(x)
+    if x.ndim in (3, 4) and x.shape[-1] == x.shape[-2]:
+        return np.ascontiguousarray(np.swapaxes(x, -1, -2)).reshape(-1)
+    return np.ascontiguousarray(x).reshape(-1)
+
+
+def from_abi(buf, like):
+    like = np.asarray(like)
+    x = np.asarray(buf).reshape(like.shape)
+    if like.ndim in (3, 4) and like.shape[-1] == like.shape[-2]:
+        return np.swapaxes(x, -1, -2).copy()
+    return x.copy()
+
+
+def push(h, added=None, comp=None, surf=None):
+    if added is not None:
+        for k, nm in enumerate(A_EL):
+            h.rrs_upload(k, abi(getattr(added, nm)))
+        for k, nm in enumerate(A_IE):
+            h.rrs_upload(18 + k, abi(getattr(added, nm)))
+    if comp is not None:
+        for k, nm in enumerate(C_EL):
+            h.rrs_upload(6 + k, abi(getattr(comp, nm)))
+        for k, nm in enumerate(C_IE):
+            h.rrs_upload(24 + k, abi(getattr(comp, nm)))
+    if surf is not None:
+        for k, nm in enumerate(A_EL):
+            h.rrs_upload(12 + k, abi(getattr(surf, nm)))
+
+
+def check_added(h, ref, what, rtol=1e-11):
+    for k, nm in enumerate(A_EL):
+        helpers.assert_op_close(from_abi(h.rrs_download(k), getattr(ref, nm)), getattr(ref, nm), rtol, f"{what} {nm}")
+    for k, nm in enumerate(A_IE):
+        helpers.assert_op_close(from_abi(h.rrs_download(18 + k), getattr(ref, nm)), getattr(ref, nm), rtol, f"{what} {nm}")
+
+
+def check_comp(h, ref, what, rtol=1e-11):
+    for k, nm in enumerate(C_EL):
+        helpers.assert_op_close(from_abi(h.rrs_download(6 + k), getattr(ref, nm)), getattr(ref, nm), rtol, f"{what} {nm}")
+    for k, nm in enumerate(C_IE):
+        helpers.assert_op_close(from_abi(h.rrs_download(24 + k), getattr(ref, nm)), getattr(ref, nm), rtol, f"{what} {nm}")
+
+
+def random_layers(N, S, nR, rng):
+    scale = 0.4 / N   # row sums of t stay below 1: the doubling recursion does not amplify rounding differences
+    a = rr.make_added_layer_rs(N, S, nR)
+    c = rr.make_composite_layer_rs(N, S, nR)
+    for o, mats, vecs, ie4, ie3 in ((a, ("r_pm", "r_mp", "t_mm", "t_pp"), ("j0p", "j0m"), A_IE[:4], A_IE[4:]),
+                                    (c, ("R_mp", "R_pm", "T_pp", "T_mm"), ("J0p", "J0m"), C_IE[:4], C_IE[4:])):
+        for nm in mats:
+            getattr(o, nm)[:] = scale * rng.random((S, N, N))
+        for nm in vecs:
+            getattr(o, nm)[:] = rng.random((S, N))
+        for nm in ie4:
+            getattr(o, nm)[:] = rng.standard_normal((nR, S, N, N))
+        for nm in ie3:
+            getattr(o, nm)[:] = rng.standard_normal((nR, S, N))
+    for o, ns in ((a, ("t_mm", "t_pp")), (c, ("T_mm", "T_pp"))):
+        for nm in ns:
+            getattr(o, nm)[:] += 0.85 * np.eye(N)
+    return a, c
+
+
+VIEWS = {1: dict(vza=(30.0,), vaz=(20.0,)), 3: {}}   # one view: lt = 5 gives the reference's RRS shape, 5 streams (N = 15 for IQU)
+
+
+def model_and_handle(rtamd, nS, lt, S, Nz=2, seed=1, nv=3):
+    m = rtamd.scenes.make_scene(nS, lt, Nz, S, seed=seed, aerosol_total=0.15, **VIEWS[nv])
+    return m, rtamd.corert.make_handle(m)
+
+
+OFFS = [-3, 1, 0, 5]
+
+
+@pytest.mark.parametrize("nS,lt,nv", [(1, 7, 3), (3, 5, 1), (4, 5, 1), (3, 11, 3), (1, 43, 3), (4, 9, 3)])
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("nd", [1, 3])
+def test_doubling_inelastic(rtamd, nS, lt, nv, strict, nd):
+    """doubling_helper!(::RRS) (doubling_inelastic.jl:13-134) on uploaded layers (including the stale iet-- the strict
+    position reads, D5) against the restatement: all twelve arrays of the added layer and expk."""
+    S = 9
+    m, h = model_and_handle(rtamd, nS, lt, S, nv=nv)
+    with h:
+        N = h.N
+        rng = np.random.default_rng(100 * nS + lt + nd)
+        a, _ = random_layers(N, S, len(OFFS), rng)
+        rrs = rr.RRSInputs(np.array(OFFS), np.ones(len(OFFS)), None, rrs_strict_reference=strict)
+        h.rrs_set(OFFS, np.ones(len(OFFS)), strict)
+        push(h, added=a)
+        expk = 0.9 + 0.1 * rng.random(S)
+        ref = copy.deepcopy(a)
+        ek = expk.copy()
+        pol = mr.pol_from_n(nS)
+        rr.doubling_inelastic(pol, rrs, ek, nd, ref, m.params.strict_reference_indexing)
+        got = h.rrs_doubling(nd, expk)
+        np.testing.assert_allclose(got, ek, rtol=1e-13, atol=1e-300)
+        check_added(h, ref, f"doubling nS={nS} N={N} strict={strict} nd={nd}")
+
+
+@pytest.mark.parametrize("nS,lt,nv", [(1, 7, 3), (3, 5, 1), (4, 5, 1), (3, 11, 3)])
+@pytest.mark.parametrize("iface", [3, 0, 1, 2])
+@pytest.mark.parametrize("surface", [False, True])
+def test_interaction_inelastic(rtamd, nS, lt, nv, iface, surface):
+    """interaction_helper!(::RRS, iface) (interaction_inelastic.jl:8-340): the production case 11 in both switch positions,
+    00/01/10 in the corrected one (the strict one must report that the reference raises)."""
+    S = 8
+    m, h = model_and_handle(rtamd, nS, lt, S, nv=nv)
+    with h:
+        N = h.N
+        rng = np.random.default_rng(7 * nS + lt + iface)
+        a, c = random_layers(N, S, len(OFFS), rng)
+        if surface:  # the surface layer: its ie* arrays are zeros (never written by the reference)
+            for nm in A_IE:
+                getattr(a, nm)[:] = 0.0
+        for strict in (True, False):
+            h.rrs_set(OFFS, np.ones(len(OFFS)), strict)
+            push(h, added=None if surface else a, comp=c, surf=a if surface else None)
+            rrs = rr.RRSInputs(np.array(OFFS), np.ones(len(OFFS)), None, rrs_strict_reference=strict)
+            if iface != 3 and strict:
+                with pytest.raises(rtamd._lib.MomError) as ei:
+                    h.rrs_interaction(iface, surface)
+                assert ei.value.code == rtamd._lib.MOM_EUNSUPPORTED
+                with pytest.raises(rr.ReferenceRaises):
+                    rr.interaction_inelastic(rrs, iface, copy.deepcopy(c), a)
+                continue
+            ref = copy.deepcopy(c)
+            rr.interaction_inelastic(rrs, iface, ref, copy.deepcopy(a))
+            h.rrs_interaction(iface, surface)
+            check_comp(h, ref, f"interaction nS={nS} N={N} iface={iface} surf={surface} strict={strict}")
+
+
+@pytest.mark.parametrize("nS,lt", [(1, 7), (3, 5), (4, 7)])
+@pytest.mark.parametrize("nd", [0, 2])
+@pytest.mark.parametrize("mm", [0, 1])
+def test_elemental_stateful(rtamd, nS, lt, nd, mm):
+    """rt_kernel!(::RRS) rt_kernel.jl:290-304: elemental_inelastic! + elemental! on the persistent added layer (entries whose
+    source index is off the grid keep their previous sources; D is applied to all of ieJ0-)."""
+    S = 10
+    m, h = model_and_handle(rtamd, nS, lt, S)
+    scene = helpers.oracle_scene(m)
+    with h:
+        N = h.N
+        rng = np.random.default_rng(nS + lt + nd)
+        a, _ = random_layers(N, S, len(OFFS), rng)
+        vp = np.array([0.02, 0.03, 0.01, 0.04])
+        h.rrs_set(OFFS, vp, True)
+        push(h, added=a)
+        rrs = rr.RRSInputs(np.array(OFFS), vp, mr.get_greek_rayleigh(0.2), True)
+        layers = mr.construct_core_optical_properties(scene, mm)
+        _, tau_sum = mr.extract_effective_props(layers)
+        lay = layers[1]
+        dtau = lay.tau / 2 ** nd
+        fsc = rr.fscatt_rayleigh(scene)[:, 1]
+        Zr_pp, Zr_mp = mr.compute_Z_moments(nS, scene.quad.qp_mu, rrs.greek_raman, mm)
+        Zpp, Zmp = (x[0] for x in (lay.Zpp_basis, lay.Zmp_basis))   # the Rayleigh basis as THE phase matrix of this call
+        ref = copy.deepcopy(a)
+        rr.elemental_inelastic(scene.pol, scene.quad, rrs, fsc, tau_sum[:, 1], dtau, lay.varpi, Zr_pp, Zr_mp, mm, nd, ref,
+                               scene.strict_reference_indexing)
+        mr.elemental(scene.pol, scene.quad, tau_sum[:, 1], dtau, lay.varpi, Zpp, Zmp, mm, nd, ref,
+                     scene.strict_reference_indexing)
+        h.rrs_elemental(mm, nd, tau_sum[:, 1], dtau, lay.varpi, abi(Zpp[None]), abi(Zmp[None]), fsc, abi(Zr_pp[None]),
+                        abi(Zr_mp[None]))
+        check_added(h, ref, f"elemental nS={nS} nd={nd} m={mm}", rtol=1e-12)
+
+
+def _rrs_inputs(rtamd, offsets, strict, amp=0.02, cab=0.96):
+    nR = len(offsets)
+    vp = amp * (1.0 + 0.1 * np.arange(nR))
+    g = rtamd.corert.get_greek_rayleigh(0.2)
+    RS = rtamd.corert.RRS(greek_raman=g, ϖ_Cabannes=cab, ϖ_λ1λ0=vp, i_λ1λ0=np.asarray(offsets), rrs_strict_reference=strict)
+    ora = rr.RRSInputs(np.asarray(offsets, dtype=np.int64), vp, mr.get_greek_rayleigh(0.2), rrs_strict_reference=strict)
+    return RS, ora
+
+
+@pytest.mark.parametrize("nS,lt,S,Nz,nv", [(1, 3, 24, 3, 3), (3, 5, 20, 3, 1), (4, 5, 16, 2, 1), (3, 11, 12, 2, 3), (3, 5, 40, 5, 1)])
+@pytest.mark.parametrize("strict", [True, False])
+def test_rt_run_rrs_parity(rtamd, nS, lt, S, Nz, nv, strict):
+    """rt_run(RS_type::RRS, model, iBand) for seeded scenes (Rayleigh + one aerosol type + gas absorption, Lambertian surface):
+    R_SFI, T_SFI, ieR_SFI, ieT_SFI against the restatement, both switch positions.  (3, 5, .., 1 view) is the reference's own
+    RRS shape N = 15 (O2Parameters.yaml: IQU, l_trunc 5, one view: 3 Gauss nodes + Sun + view)."""
+    m = rtamd.scenes.make_scene(nS, lt, Nz, S, seed=nS + lt + S, aerosol_total=0.1, **VIEWS[nv])
+    offs = [-4, -1, 2, 7, 3]
+    RS, ora = _rrs_inputs(rtamd, offs, strict)
+    R, T, ieR, ieT = rtamd.corert.rt_run_rrs(RS, m)
+    scene = helpers.oracle_scene(m)
+    scene.varpi_cabannes = RS.ϖ_Cabannes
+    Rr, Tr, ieRr, ieTr = rr.rt_run_rrs(scene, ora)
+    helpers.assert_stokes_close(R, Rr, what="R")
+    helpers.assert_stokes_close(T, Tr, what="T")
+    assert np.abs(ieRr).max() > 0
+    # the inelastic spectra are judged like the elastic ones: relative to the elastic intensity of the same view and point
+    scale = np.abs(Rr[:, 0:1, :])
+    assert np.all(np.abs(ieR - ieRr) <= 1e-10 * scale + 1e-14), np.abs(ieR - ieRr).max()
+    scale = np.abs(Tr[:, 0:1, :])
+    assert np.all(np.abs(ieT - ieTr) <= 1e-10 * scale + 1e-14), np.abs(ieT - ieTr).max()
+    # ... and tightly against their own size
+    helpers.assert_op_close(ieR, ieRr, 1e-9, "ieR_SFI")
+    helpers.assert_op_close(ieT, ieTr, 1e-9, "ieT_SFI")
