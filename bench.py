@@ -17,9 +17,13 @@ anything touches a GPU and exits with its code.  Collective back ends (`--backen
   torch  torch.distributed all_gather_into_tensor on the "nccl" (= RCCL) process group
   gloo   host all-gather over gloo; with --share-device every rank uses GPU 0 (the 1-GPU test box)
 
-Other workloads (`--workload`): C1 (scalar, N = 4: HBM-bound wave-per-point kernel), C4 (IQUV, 64 streams,
-N = 256).  Prints ONE JSON line on rank 0 (contract in the task description).  Weak scaling: every rank owns
-`--points` spectral points of a global axis of N x points; ndoubl / interface codes are computed on the global axis.
+Other workloads (`--workload`): C1 (scalar, N = 4: lane-per-point kernel), C3 (BASELINE configs[2]: three bands,
+29 944 points; `--scaling strong` splits that FIXED axis over the ranks), C4 (IQUV, 64 streams, N = 256), C5 (rotational
+Raman, N = 15, 6 837 points x 178 Raman lines: HBM-bound pair kernels).  Prints ONE JSON line on rank 0 (contract in
+the task description).  Weak scaling (default): every rank owns `--points` spectral points of a global axis of
+N x points; ndoubl / interface codes are computed on the global axis.  The default run (C2, one GPU) also carries
+`extra.workloads.{C1,C4,C5}` -- each with its own `roofline` and `cpu_baseline` -- and `extra.f32`, so that the other
+regimes are driver-timed too (`--no-extras` skips them).
 """
 import argparse
 import json
@@ -37,7 +41,8 @@ sys.path.insert(0, str(ROOT))
 
 PEAK_FP64_MFMA_TFLOPS = 78.6  # AMD MI355X FP64 matrix spec; v_mfma_f64_16x16x4 issue-rate microbenchmark: 77.5
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-DEFAULT_POINTS = {"C2": 10_000, "C1": 200_000, "C4": 2_000}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: FP32 matrix
+DEFAULT_POINTS = {"C2": 10_000, "C1": 200_000, "C3": 29_944, "C4": 2_000, "C5": 6_837}
 
 
 def cpu_baseline(model, workload, budget_s=12.0):
@@ -85,55 +90,24 @@ def spawn_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["C2", "C1", "C4"], default="C2")
-    ap.add_argument("--points", type=int, default=0, help="spectral points per GPU (default: the workload's size)")
-    ap.add_argument("--backend", choices=["rccl", "torch", "gloo"], default="rccl")
-    ap.add_argument("--share-device", action="store_true", help="all ranks on GPU 0 (needs --backend gloo)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-voigt", action="store_true")
-    ap.add_argument("--opt", action="append", default=[], metavar="ID=VALUE", help="mom_set_option(ID, VALUE) before the scene is set (kernel A/B runs)")
-    a = ap.parse_args()
-    if a.gpus < 1:
-        ap.error("--gpus must be >= 1")
-    if a.share_device and a.backend != "gloo":
-        ap.error("--share-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(a))
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); refusing to report a wrong n_gpus",
-              file=sys.stderr)
-        sys.exit(2)
-
+def elastic_leg(a, workload, S_loc, steps, warmup, world, rank, dev, dist, with_cpu=True, cpu_budget=12.0):
+    """One elastic workload (C1..C4) on this rank's GPU: returns the JSON dict of the leg on rank 0 (None elsewhere)."""
     import torch
     import rtamd
-
-    dev_index = 0 if (a.share_device or world == 1) else local
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
+    strong = a.scaling == "strong" and world > 1
+    S_tot = S_loc if strong else S_loc * world
+    if strong:
+        if S_tot % world:
+            raise SystemExit(f"--scaling strong: {S_tot} points do not split evenly over {world} ranks")
+        S_loc = S_tot // world
     nccl_group = None
     collective = "none"
+    backend = a.backend
     if world > 1:
-        import torch.distributed as dist
-        if a.backend == "torch":
-            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-            collective = "torch.distributed all_gather_into_tensor (RCCL)"
-        else:
-            dist.init_process_group("gloo")
-            collective = "mom_allgather_RT_device (RCCL through the C ABI)" if a.backend == "rccl" else "gloo host all_gather"
-
-    S_loc = a.points or DEFAULT_POINTS[a.workload]
-    S_tot = S_loc * world
-    scene_fn = {"C2": rtamd.scenes.scene_C2, "C1": rtamd.scenes.scene_C1, "C4": rtamd.scenes.scene_C4}[a.workload]
+        collective = {"torch": "torch.distributed all_gather_into_tensor (RCCL)",
+                      "rccl": "mom_allgather_RT_device (RCCL through the C ABI)", "gloo": "gloo host all_gather"}[backend]
+    scene_fn = {"C2": rtamd.scenes.scene_C2, "C1": rtamd.scenes.scene_C1, "C3": rtamd.scenes.scene_C3,
+                "C4": rtamd.scenes.scene_C4}[workload]
     model = scene_fn(S=S_tot, architecture=rtamd.MI355X(dev.index))
     scene = rtamd.prepare_scene(model)          # global axis: ndoubl / iface are global (SURVEY 8e)
     shard = scene.spectral_slice(rank * S_loc, (rank + 1) * S_loc) if world > 1 else scene
@@ -146,8 +120,8 @@ def main():
     nout = len(shard.node) * shard.nStokes * S_loc
     RT = torch.empty(2 * nout, dtype=torch.float64, device=dev)           # local R || T
     G = torch.empty(2 * nout * world, dtype=torch.float64, device=dev) if world > 1 else None
-    Gh = torch.empty(2 * nout * world, dtype=torch.float64) if (world > 1 and a.backend == "gloo") else None
-    if world > 1 and a.backend == "rccl":
+    Gh = torch.empty(2 * nout * world, dtype=torch.float64) if (world > 1 and backend == "gloo") else None
+    if world > 1 and backend == "rccl":
         # RCCL through the C ABI.  Should its set-up fail on ANY rank (a mis-matched RCCL/HIP pair in the host process,
         # for instance), every rank falls back -- together -- to torch.distributed's own RCCL group, so that a scaling
         # run still produces its line; the JSON says which collective ran.
@@ -170,16 +144,16 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             nccl_group = dist.new_group(backend="nccl")
-            a.backend = "torch-fallback"
+            backend = "torch-fallback"
             collective = "torch.distributed all_gather_into_tensor (RCCL; fallback: the C-ABI communicator failed to initialise)"
 
     def step():
         h.rt_run()
         if world == 1:
             h.get_RT_device(RT.data_ptr(), RT.data_ptr() + 8 * nout)      # asynchronous, library stream
-        elif a.backend == "rccl":
+        elif backend == "rccl":
             h.allgather_RT_device(G.data_ptr())                           # ONE collective, library stream
-        elif a.backend in ("torch", "torch-fallback"):
+        elif backend in ("torch", "torch-fallback"):
             h.get_RT_device(RT.data_ptr(), RT.data_ptr() + 8 * nout)
             h.sync()
             dist.all_gather_into_tensor(G, RT, group=nccl_group)          # ONE collective: R and T packed
@@ -195,26 +169,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     fence()
     el = time.perf_counter() - t0
     h.check_async()  # deferred singular-operator report of the asynchronous steps
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev if a.backend == "torch" else "cpu")
+        t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "torch" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
         # the gathered block of this rank must be its own spectra, and every block finite
         R_loc, T_loc = h.get_RT()
         mine = np.concatenate([np.transpose(R_loc, (2, 1, 0)).reshape(-1), np.transpose(T_loc, (2, 1, 0)).reshape(-1)])
-        got = (Gh if a.backend == "gloo" else G.cpu()).numpy().reshape(world, 2 * nout)
+        got = (Gh if backend == "gloo" else G.cpu()).numpy().reshape(world, 2 * nout)
         assert np.array_equal(got[rank], mine) and np.all(np.isfinite(got)), "all-gather returned wrong data"
     tm = h.timers()  # of the last step, HIP events on the library's stream
-
+    out = None
     if rank == 0:
         N, M = scene.N, scene.M
         nd = scene.ndoubl.astype(np.float64)
@@ -230,18 +204,17 @@ def main():
         prof = {}
         tf = ROOT / "profiles" / "traffic.json"
         if tf.exists():
-            prof = json.loads(tf.read_text()).get(a.workload, {})
-        if a.workload == "C1":
+            prof = json.loads(tf.read_text()).get(workload, {})
+        if workload == "C1":
             # N = 4: one spectral point per lane, operators in registers (mom_small.hip).  HBM moves only the per-point
             # inputs and outputs -- algorithmic bytes per point = (tau, varpi, tau_sum + K weights) x Nz x 8
             # + 3 x nVza x nStokes x 8 + 2 x nStokes x 8 -- which at the measured rate is < 1 % of the HBM roofline: the
             # bound of this regime is the FP64 vector-FMA pipe (the kernel issues no MFMA: a 4 x 4 operator would use 1/16
-            # of a 16 x 16 tile), whose peak on MI355X equals the FP64 MFMA peak (78.6 TFLOP/s).  `bound` keeps the
-            # contract's vocabulary ("mfma" = the FP64 arithmetic peak); the HBM figures are reported next to it.
+            # of a 16 x 16 tile), whose peak on MI355X equals the FP64 MFMA peak (78.6 TFLOP/s).
             bytes_pt = (3 + scene.K) * scene.Nz * 8 + 3 * len(scene.node) * scene.nStokes * 8 + 2 * scene.nStokes * 8
             gbs = bytes_pt * S_loc / (tm["layers_ms"] * 1e-3) / 1e9
             ach = f_pm * M * S_loc / (tm["layers_ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+            roof = {"bound": "fp64-valu", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": prof.get("hbm_bytes_per_launch"),
                     "kernel": "momsm::k_sweep<4> (FP64 vector FMA, no MFMA issued)",
                     "avg_launch_ms": tm["layers_ms"] / max(tm["layer_launches"], 1), "launches_per_step": tm["layer_launches"],
@@ -259,13 +232,16 @@ def main():
                     # `achieved` counts the reference's op list (full 2N^3 inverses); the hardware-side figure is the
                     # MFMA-busy share of SIMD cycles from the PMC pass (profiles/), not recomputed here
                     "hw_mfma_busy_frac": prof.get("mfma_busy_frac")}
+        names = {"C2": "O2-A band IQU scene", "C3": "OCO-2-style 3-band IQU scene (BASELINE configs[2])"}
         out = {
-            "metric": "spectral points/sec (whole node), O2-A band IQU scene", "value": S_tot / (el / a.steps),
-            "unit": "spectral points/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: N={N} ({N // scene.nStokes} streams x {scene.nStokes} Stokes), Nz={scene.Nz}, "
-                                   f"M={M}, S={S_loc}/GPU, sum(ndoubl)={int(nd.sum())}, Lambertian surface, {len(scene.node)} VZA",
+            "metric": f"spectral points/sec (whole node), {names.get(workload, workload + ' scene')}",
+            "value": S_tot / (el / steps),
+            "unit": "spectral points/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{workload}: N={N} ({N // scene.nStokes} streams x {scene.nStokes} Stokes), Nz={scene.Nz}, "
+                                   f"M={M}, S={S_loc}/GPU ({S_tot} in total), sum(ndoubl)={int(nd.sum())}, Lambertian surface, "
+                                   f"{len(scene.node)} VZA",
                        "sharding": f"spectral axis, {world} x {S_loc} points, one all-gather of R||T" if world > 1 else "none",
                        "collective": collective,
                        "devices": "all ranks on GPU 0 (--share-device)" if a.share_device else "one GPU per rank"},
@@ -273,17 +249,209 @@ def main():
             "stages_ms": {k: tm[k] for k in ("layers_ms", "full_layers_ms", "reduced_layers_ms", "surface_ms",
                                              "postprocess_ms", "total_ms")},
         }
-        if a.workload != "C2":
-            out["metric"] = f"spectral points/sec (whole node), {a.workload} scene"
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, a.workload)
-        if world == 1 and not a.no_voigt and a.workload == "C2":
-            try:
-                out["extra"] = {"voigt": voigt_leg()}
-            except Exception as e:  # the headline number must not depend on the second kernel's leg
-                out["extra"] = {"voigt": {"error": repr(e)}}
-        print(json.dumps(out), flush=True)
+        if world == 1 and with_cpu:
+            out["cpu_baseline"] = cpu_baseline(model, workload, budget_s=cpu_budget)
     h.close()
+    return out
+
+
+def c5_leg(a, S, steps, warmup, dev, with_cpu=True):
+    """BASELINE configs[4]: rt_run(::RRS) on scene_C5 (N = 15, 5 layers, 178 Raman lines), corrected switch position.
+    Bound: HBM -- the pair kernels read and write every block of the 4-D inelastic operators once per doubling step /
+    interaction.  Algorithmic bytes of the dominant kernel (the doubling pair kernel) per (n1, dn) pair with its source
+    point on the grid: ier-+, iet++ in and out + ieJ0+- in and out = (4 N^2 + 4 N) x 8 B."""
+    import torch
+    import rtamd
+    rt = rtamd.corert
+    m, RS = rtamd.scenes.scene_C5(S=S, architecture=rtamd.MI355X(dev.index))
+    m = rt._with_cabannes(RS, m)
+    sc = rtamd.prepare_scene(m)
+    Zr_pp, Zr_mp = rt.raman_z(RS, m)
+    h = rt.make_handle(m)
+    h.set_option(rtamd._lib.MOM_OPT_STRIP_PAD, 0)
+    h.rrs_set(RS.i_λ1λ0, RS.ϖ_λ1λ0, RS.rrs_strict_reference)
+    rt.scene_set(h, sc)
+    h.scene_set_rrs(np.ascontiguousarray(rt.fscatt_rayleigh(m).T), rt._abi_mats(Zr_pp), rt._abi_mats(Zr_mp))
+    for _ in range(warmup):
+        h.rt_run_rrs()
+    h.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        h.rt_run_rrs()
+    h.sync()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tk = h.rrs_timers()
+    res = h.get_RT_rrs()
+    assert np.all(np.isfinite(res[2])) and np.abs(res[2]).max() > 0
+    N, nR = sc.N, RS.n_Raman
+    pairs = int(sum(S - abs(int(o)) for o in RS.i_λ1λ0))
+    bytes_pair = (4 * N * N + 4 * N) * 8
+    ms, nl = tk["dbl_pair"]
+    avg = ms / max(nl, 1)
+    gbs = pairs * bytes_pair / (avg * 1e-3) / 1e9
+    prof = {}
+    tf = ROOT / "profiles" / "traffic.json"
+    if tf.exists():
+        prof = json.loads(tf.read_text()).get("C5", {})
+    out = {"metric": "spectral points/sec (whole node), C5 rotational-Raman scene", "value": S / (el / steps),
+           "unit": "spectral points/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"C5: RRS, N={N} (5 streams x 3 Stokes), Nz={sc.Nz}, M={sc.M}, S={S}, nRaman={nR}, "
+                                  f"sum(ndoubl)={int(sc.ndoubl.sum())}, rrs_strict_reference={int(RS.rrs_strict_reference)}, "
+                                  "Lambertian surface, 1 VZA", "sharding": "none", "collective": "none"},
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                        "traffic": prof.get("hbm_bytes_per_launch"), "kernel": "momr::k_dbl_pair<1>",
+                        "avg_launch_ms": avg, "launches_per_step": nl, "pairs_per_launch": pairs,
+                        "algorithmic_bytes_per_pair": bytes_pair, "algorithmic_bytes_per_avg_launch": pairs * bytes_pair},
+           "stages_ms": {"dbl_pair_ms": tk["dbl_pair"][0], "int_pair_ms": tk["int_pair"][0],
+                         "ie_elemental_ms": tk["ie_elemental"][0], "total_ms": tk["total"][0]}}
+    h.close()
+    if with_cpu:
+        out["cpu_baseline"] = c5_cpu_baseline(S)
+    return out
+
+
+def c5_cpu_baseline(S, n_lines=2):
+    """numpy restatement (oracle/rrsref.py, one core) of the same scene with only the `n_lines` strongest Raman lines;
+    the pair work is linear in the number of lines, so the rate for the full line list is extrapolated from the two
+    timings (elastic-only run, run with n_lines)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import helpers
+    import rtamd
+    from oracle import momref as mr, rrsref as rr
+    m, RS_full = rtamd.scenes.scene_C5(S=S)
+    m, RS = rtamd.scenes.scene_C5(S=S, nRaman=n_lines)
+    scene = helpers.oracle_scene(m)
+    scene.varpi_cabannes = RS.ϖ_Cabannes
+    g = mr.get_greek_rayleigh(0.75)
+    t0 = time.perf_counter()
+    mr.rt_run(scene)
+    t_el = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rr.rt_run_rrs(scene, rr.RRSInputs(np.asarray(RS.i_λ1λ0, dtype=np.int64), RS.ϖ_λ1λ0, g, rrs_strict_reference=False))
+    t_n = time.perf_counter() - t0
+    per_line = max(t_n - t_el, 1e-9) / n_lines
+    t_full = t_el + per_line * RS_full.n_Raman
+    return {"value": S / t_full, "unit": "spectral points/s", "cores": 1, "kind": "port",
+            "sample": f"numpy restatement, one core: the same C5 scene with the {n_lines} strongest of {RS_full.n_Raman} Raman "
+                      f"lines ({t_n:.1f} s; elastic-only run {t_el:.1f} s); extrapolated linearly in the number of lines to "
+                      f"{t_full:.0f} s per run"}
+
+
+def f32_leg(dev, S=20_000, n_streams=8, nd=5, steps=3):
+    """The reference's own GPU micro-benchmark shape (test/gpu_tests/gpu_cpu_tests.jl:21-43, gpu_batched_interaction.jl:20-22:
+    Float32, n = 32, nSpec = 20 000, ndoubl = 5): one layer's elemental + 5 doublings on a Float32 handle (dtype = 1),
+    IQUV with 8 streams = operators of edge 32, against the FP32 matrix roof."""
+    import torch
+    import rtamd
+    rt = rtamd.corert
+    # 8 streams = 4 Gauss nodes + Sun + 3 views  ->  l_trunc 7
+    m = rtamd.scenes.make_scene(4, 7, 1, S, aerosol_total=0.0, absorption=False, architecture=rtamd.MI355X(dev.index))
+    sc = rtamd.prepare_scene(m)
+    sc.ndoubl[:] = nd   # the micro-benchmark's fixed doubling count (the scene's own would be larger)
+    h = rt.make_handle(m, float_type="Float32")
+    h.scene_set(sc.Nz, sc.K, sc.M, sc.tau, sc.varpi, sc.zw, sc.Zpp, sc.Zmp, sc.ndoubl, sc.iface, sc.tau_sum,
+                sc.albedo, sc.node, sc.cos_mphi, sc.sin_mphi)
+    h.rt_run()
+    h.sync()
+    best = 1e30
+    for _ in range(steps):
+        h.rt_run()
+        h.sync()
+        best = min(best, h.timers()["layers_ms"])
+    N, M = sc.N, sc.M
+    flop = M * S * (nd * (12 * N ** 3 + 8 * N ** 2) + N * N * 15)
+    ach = flop / (best * 1e-3) / 1e12
+    h.close()
+    return {"metric": "Float32 doubling, reference GPU micro-benchmark shape", "value": S * M / (best * 1e-3),
+            "unit": "(spectral point, moment) units/s", "dtype": "f32", "layers_ms": best,
+            "config": {"workload": f"N={N} (8 streams x 4 Stokes), S={S}, one layer, ndoubl={nd}, M={M}, dtype=1 (Float32)"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "kernel": "layer kernel of the Float32 build (momcore_f32.hip)",
+                         "algorithmic_flop_per_avg_launch": flop}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["C2", "C1", "C3", "C4", "C5"], default="C2")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="strong: the workload's spectral axis (--points or its default size) is split over the ranks")
+    ap.add_argument("--points", type=int, default=0, help="spectral points per GPU (strong scaling: in total); default: the workload's size")
+    ap.add_argument("--backend", choices=["rccl", "torch", "gloo"], default="rccl")
+    ap.add_argument("--share-device", action="store_true", help="all ranks on GPU 0 (needs --backend gloo)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-voigt", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip extra.workloads / extra.f32 of the default run")
+    ap.add_argument("--opt", action="append", default=[], metavar="ID=VALUE", help="mom_set_option(ID, VALUE) before the scene is set (kernel A/B runs)")
+    a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if a.share_device and a.backend != "gloo":
+        ap.error("--share-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
+    if a.workload == "C5" and a.gpus > 1:
+        ap.error("C5 runs on one GPU (the Raman pairs need a halo exchange across shards: DESIGN.md)")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); refusing to report a wrong n_gpus",
+              file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+
+    dev_index = 0 if (a.share_device or world == 1) else local
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if a.backend == "torch":
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+
+    S_loc = a.points or DEFAULT_POINTS[a.workload]
+    if a.workload == "C5":
+        out = c5_leg(a, S_loc, a.steps, a.warmup, dev, with_cpu=not a.no_cpu_baseline)
+    else:
+        out = elastic_leg(a, a.workload, S_loc, a.steps, a.warmup, world, rank, dev, dist, with_cpu=not a.no_cpu_baseline)
+    if rank == 0:
+        default_run = a.workload == "C2" and world == 1 and not a.points
+        if world == 1 and a.workload == "C2":
+            extra = {}
+            if not a.no_voigt:
+                try:
+                    extra["voigt"] = voigt_leg()
+                except Exception as e:  # the headline number must not depend on the second kernel's leg
+                    extra["voigt"] = {"error": repr(e)}
+            if default_run and not a.no_extras:
+                legs = {}
+                for wl, pts, st in (("C1", DEFAULT_POINTS["C1"], 3), ("C4", 256, 1)):
+                    try:
+                        legs[wl] = elastic_leg(a, wl, pts, st, 1, 1, 0, dev, None, with_cpu=not a.no_cpu_baseline, cpu_budget=6.0)
+                    except Exception as e:
+                        legs[wl] = {"error": repr(e)}
+                try:
+                    legs["C5"] = c5_leg(a, DEFAULT_POINTS["C5"], 2, 1, dev, with_cpu=not a.no_cpu_baseline)
+                except Exception as e:
+                    legs["C5"] = {"error": repr(e)}
+                extra["workloads"] = legs
+                try:
+                    extra["f32"] = f32_leg(dev)
+                except Exception as e:
+                    extra["f32"] = {"error": repr(e)}
+            if extra:
+                out["extra"] = extra
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -155,7 +155,9 @@ int mom_elemental_inelastic_rrs(mom_t *h, int m, int ndoubl, int nRaman, const i
  *                      (computeRamanZlambda!, src/Inelastic/inelastic_helper.jl:457-464, per Fourier moment).
  *   mom_rt_run_rrs     rt_run.jl:125-215 with RS_type::RRS for the resident scene (LambertianSurfaceScalar); asynchronous.
  *   mom_get_RT_rrs     R_SFI, T_SFI, ieR_SFI, ieT_SFI [nVza, nStokes, nSpec] (postprocessing_vza!(::RRS),
- *                      tools/postprocessing_vza.jl:95-147); any pointer may be NULL; gpu_ms (optional) = GPU time of the run. */
+ *                      tools/postprocessing_vza.jl:95-147); any pointer may be NULL; gpu_ms (optional) = GPU time of the run.
+ *   mom_rrs_timers     HIP-event times of the last mom_rt_run_rrs, summed per kernel: ms[0] / launches[0] the doubling pair
+ *                      kernel, [1] the interaction pair kernel, [2] the inelastic elemental kernel, [3] the whole run (n >= 4). */
 enum {
   MOM_IE_ADDED_R_PM = 18, MOM_IE_ADDED_R_MP = 19, MOM_IE_ADDED_T_MM = 20, MOM_IE_ADDED_T_PP = 21,
   MOM_IE_ADDED_J0P = 22, MOM_IE_ADDED_J0M = 23,
@@ -175,6 +177,7 @@ int mom_rrs_download(mom_t *h, int which, double *dst);
 int mom_scene_set_rrs(mom_t *h, const double *fscattRayl, const double *Zpp_l1l0, const double *Zmp_l1l0);
 int mom_rt_run_rrs(mom_t *h);
 int mom_get_RT_rrs(mom_t *h, double *R_SFI, double *T_SFI, double *ieR_SFI, double *ieT_SFI, double *gpu_ms);
+int mom_rrs_timers(mom_t *h, double *ms, int *launches, int n);
 
 /* batch_inv!(X, A) -- gpu_batched.jl:36-87;  X, A: n*n*batch doubles (host). */
 int mom_batch_inv(mom_t *h, int n, int batch, const double *A, double *X);

@@ -68,6 +68,7 @@ SIGNATURES = {
     "mom_scene_set_rrs": (C.c_int, [c_h, c_dp, c_dp, c_dp]),
     "mom_rt_run_rrs": (C.c_int, [c_h]),
     "mom_get_RT_rrs": (C.c_int, [c_h, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "mom_rrs_timers": (C.c_int, [c_h, c_dp, c_ip, C.c_int]),
     "mom_batch_inv": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp]),
     "mom_batched_mul": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp, c_dp]),
     "mom_batched_mul_dual": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]),
@@ -287,6 +288,12 @@ class Handle:
         self.check(self.lib.mom_get_RT_rrs(self._h, *[dp(x) for x in out], dp(ms)))
         sh = (self.S, self.nS, self.nVza)
         return tuple(np.transpose(x.reshape(sh), (2, 1, 0)).copy() for x in out) + (float(ms[0]),)
+
+    def rrs_timers(self):
+        """{kernel: (ms, launches)} of the last rt_run_rrs (HIP events on the library's stream)."""
+        ms, nl = np.zeros(4), np.zeros(4, dtype=np.int32)
+        self.check(self.lib.mom_rrs_timers(self._h, dp(ms), ip(nl), 4))
+        return {k: (float(ms[i]), int(nl[i])) for i, k in enumerate(("dbl_pair", "int_pair", "ie_elemental", "total"))}
 
     def batch_inv(self, n, batch, A):
         A = f64(A).reshape(-1)

@@ -816,7 +816,36 @@ void destroy(State *s) {
   }
   for (int k = 0; k < 6; ++k) { (void)hipFree(s->surf[k]); (void)hipFree(s->svec[k]); (void)hipFree(s->ie_added[k]); (void)hipFree(s->ie_comp[k]); }
   for (int k = 0; k < 10; ++k) (void)hipFree(s->smat[k]);
+  for (auto e : s->ev_pool) (void)hipEventDestroy(e);
   delete s;
+}
+
+void timing_reset(State *s, bool on) {
+  s->timing = on;
+  s->ev_kind.clear();
+}
+static hipError_t tick(State *s, int kind, bool start) {
+  if (!s->timing) return hipSuccess;
+  const size_t idx = 2 * s->ev_kind.size() + (start ? 0 : 1);
+  while (s->ev_pool.size() <= idx) {
+    hipEvent_t e;
+    RCHK(hipEventCreate(&e));
+    s->ev_pool.push_back(e);
+  }
+  RCHK(hipEventRecord(s->ev_pool[idx], s->stream));
+  if (!start) s->ev_kind.push_back(kind);
+  return hipSuccess;
+}
+hipError_t timing_read(State *s, double *ms, int *launches) {
+  for (int k = 0; k < TK_COUNT; ++k) { ms[k] = 0.0; launches[k] = 0; }
+  RCHK(hipStreamSynchronize(s->stream));
+  for (size_t k = 0; k < s->ev_kind.size(); ++k) {
+    float t = 0.f;
+    RCHK(hipEventElapsedTime(&t, s->ev_pool[2 * k], s->ev_pool[2 * k + 1]));
+    ms[s->ev_kind[k]] += t;
+    launches[s->ev_kind[k]] += 1;
+  }
+  return hipSuccess;
 }
 
 static int grid_points(const State *s) { return std::max(1, std::min((s->S + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 8)); }
@@ -843,8 +872,10 @@ hipError_t elemental(State *s, const Streams &q, int m, int nd, int shift, const
   if (elastic) LAUNCH_NT(s, k_el_point, grid_points(s), a);
   if (inelastic) {
     const size_t tot = (size_t)s->N * s->N * (size_t)(s->n1_hi - s->n1_lo) * s->nR;
+    RCHK(tick(s, TK_IE_ELEMENTAL, true));
     hipLaunchKernelGGL(k_ie_elemental, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, a);
     RCHK(hipGetLastError());
+    RCHK(tick(s, TK_IE_ELEMENTAL, false));
   }
   return hipSuccess;
 }
@@ -855,7 +886,9 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
     KArgs a = base_args(s, q);
     a.last = (k == nd - 1);
     LAUNCH_NT(s, k_dbl_point, grid_points(s), a);
+    RCHK(tick(s, TK_DBL_PAIR, true));
     LAUNCH_NT(s, k_dbl_pair, grid_pairs(s), a);
+    RCHK(tick(s, TK_DBL_PAIR, false));
     s->cur = 1 - s->cur;
   }
   KArgs a = base_args(s, q);
@@ -900,13 +933,17 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
     RCHK(hipMemsetAsync(s->ie_comp[C_J0P], 0, v4, s->stream));
     RCHK(hipMemsetAsync(s->ie_comp[C_J0M], 0, v4, s->stream));
   } else if (with_surface) {
+    RCHK(tick(s, TK_INT_PAIR, true));
     if (s->N <= 16) hipLaunchKernelGGL((k_int_pair<1, true>), dim3(grid_pairs(s)), dim3(64 * kWavesPerBlock), lds<1>(), s->stream, a, iface);
     else hipLaunchKernelGGL((k_int_pair<2, true>), dim3(grid_pairs(s)), dim3(64 * kWavesPerBlock), lds<2>(), s->stream, a, iface);
     RCHK(hipGetLastError());
+    RCHK(tick(s, TK_INT_PAIR, false));
   } else {
+    RCHK(tick(s, TK_INT_PAIR, true));
     if (s->N <= 16) hipLaunchKernelGGL((k_int_pair<1, false>), dim3(grid_pairs(s)), dim3(64 * kWavesPerBlock), lds<1>(), s->stream, a, iface);
     else hipLaunchKernelGGL((k_int_pair<2, false>), dim3(grid_pairs(s)), dim3(64 * kWavesPerBlock), lds<2>(), s->stream, a, iface);
     RCHK(hipGetLastError());
+    RCHK(tick(s, TK_INT_PAIR, false));
   }
   s->ccur = 1 - s->ccur;
   return hipSuccess;

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 namespace momr {
 
@@ -48,8 +49,16 @@ struct State {
   double *d_out = nullptr;      // ieR_SFI || ieT_SFI [2][nVza,nS,S] and R_SFI || T_SFI [2][nVza,nS,S]
   int out_nVza = 0;
   int *d_info = nullptr;
+  // HIP-event pairs around the launches of the heavy kernels of the last run (timing_reset .. timing_read)
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<int> ev_kind;  // kind of the launch bracketed by ev_pool[2k], ev_pool[2k+1]
+  bool timing = false;
   std::string err;
 };
+enum { TK_DBL_PAIR = 0, TK_INT_PAIR = 1, TK_IE_ELEMENTAL = 2, TK_COUNT = 3 };
+void timing_reset(State *s, bool on);
+// ms[k], launches[k] for k < TK_COUNT (synchronises the stream)
+hipError_t timing_read(State *s, double *ms, int *launches);
 
 hipError_t create(State **out, hipStream_t st, int N, int nS, int S, int nR, const int *off_host, const double *varpi_host,
                   int strict_rrs, std::string *err);

@@ -2391,6 +2391,7 @@ extern "C" int mom_rt_run_rrs(mom_t *h) {
   const momr::Streams q = rrs_streams(h);
   const size_t S = h->S, NN = (size_t)h->N * h->N;
   const int Nz = h->Nz, K = h->K, M = h->scene_M;
+  momr::timing_reset(s, true);
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   RRSCHK(h, momr::begin_run(s, h->nVza));
   for (int m = 0; m < M; ++m) {
@@ -2408,6 +2409,19 @@ extern "C" int mom_rt_run_rrs(mom_t *h) {
     RRSCHK(h, momr::postprocess(s, q, m, h->nVza, h->d_node, h->d_cos, h->d_sin, M, m == 0 ? 0.5 : 1.0));
   }
   HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+  s->timing = false;
+  return MOM_OK;
+}
+
+extern "C" int mom_rrs_timers(mom_t *h, double *ms, int *launches, int n) {
+  int rc = rrs_ready(h, "mom_rrs_timers");
+  if (rc) return rc;
+  if (!ms || !launches || n < momr::TK_COUNT + 1) return fail(h, MOM_EINVAL, "mom_rrs_timers: need room for 4 values");
+  RRSCHK(h, momr::timing_read(h->rrs, ms, launches));
+  float t = 0.f;
+  if (hipEventElapsedTime(&t, h->ev[0], h->ev[3]) != hipSuccess) t = 0.f;
+  ms[momr::TK_COUNT] = t;
+  launches[momr::TK_COUNT] = 1;
   return MOM_OK;
 }
 

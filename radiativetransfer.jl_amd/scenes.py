@@ -112,6 +112,60 @@ def scene_C4(S: int = 2_000, Nz: int = 40, **kw):
     return make_scene(4, 121, Nz, S, **kw)
 
 
+def raman_lines(Δν_grid: float, T: float = 250.0, Jmax: int = 30, ϖ_Cabannes: float = 0.96, S: Optional[int] = None):
+    """Synthetic rotational-Raman line list in the form the CoreRT hot path consumes (RS_type.i_λ₁λ₀, ϖ_λ₁λ₀): the N₂ and O₂
+    J -> J ± 2 Stokes / anti-Stokes lines (Δν̃ = ± 4B (J + 3/2), Jmax = 30 like inelastic_cross_section.jl:142-160; N₂: all
+    J with 6:3 nuclear-spin weights, B = 1.98957 cm⁻¹; O₂: odd J only, B = 1.43768 cm⁻¹; vmr 0.79 / 0.21), Boltzmann
+    populations at T times the Placzek-Teller factors, each line split 50/50 onto its two neighbouring grid points
+    (apply_gridlines!, src/Inelastic/inelastic_helper.jl:146-216), weights normalised to Σ ϖ_λ₁λ₀ = 1 - ϖ_Cabannes.
+    Stands in for getRamanSSProp! (raman_atmo_prop.jl:57-73), which needs the molecular constants (host set-up, out of scope).
+    Returns (i_λ₁λ₀ [nRaman] int, ϖ_λ₁λ₀ [nRaman]); offsets with |offset| >= S are dropped."""
+    kT = 0.6950348 * T  # cm⁻¹
+    acc = {}
+    for B, vmr, odd_only, gJ in ((1.98957, 0.79, False, lambda J: 6.0 if J % 2 == 0 else 3.0), (1.43768, 0.21, True, lambda J: 1.0)):
+        Js = [J for J in range(Jmax + 1) if (J % 2 == 1 or not odd_only)]
+        pop = np.array([gJ(J) * (2 * J + 1) * math.exp(-B * J * (J + 1) / kT) for J in Js])
+        pop /= pop.sum()
+        for J, pJ in zip(Js, pop):
+            # Stokes J -> J + 2 (scattered light at lower wavenumber: the source index n₀ lies ABOVE n₁) and anti-Stokes J -> J - 2
+            for dJ in (+2, -2):
+                if J + dJ < 0:
+                    continue
+                if dJ > 0:
+                    pt = 3.0 * (J + 1) * (J + 2) / (2.0 * (2 * J + 1) * (2 * J + 3))
+                    shift = 4.0 * B * (J + 1.5)
+                else:
+                    pt = 3.0 * J * (J - 1) / (2.0 * (2 * J + 1) * (2 * J - 1))
+                    shift = -4.0 * B * (J - 0.5)
+                x = shift / Δν_grid
+                lo = math.floor(x)
+                for k in (lo, lo + 1):
+                    acc[k] = acc.get(k, 0.0) + 0.5 * vmr * pJ * pt
+    offs = np.array(sorted(k for k in acc if k != 0 and (S is None or abs(k) < S)), dtype=np.int32)
+    w = np.array([acc[int(k)] for k in offs])
+    return offs, (1.0 - ϖ_Cabannes) * w / w.sum()
+
+
+def scene_C5(S: int = 6_837, Nz: int = 5, nRaman: Optional[int] = None, rrs_strict_reference: bool = False, **kw):
+    """BASELINE config 5, the reference's own RRS driver shape (test/benchmarks/prototype_inelastic.jl:8-93 on
+    test/test_parameters/O2Parameters.yaml): O₂ A-band at 0.05 cm⁻¹ (6 837 points), Stokes IQU, l_trunc 5 -> 3 Gauss nodes +
+    Sun + one view = 5 streams (N = 15), 5 layers (profile_reduction 5), Rayleigh + gas absorption, Lambertian surface;
+    rotational-Raman lines from raman_lines (≈ 190 grid offsets; nRaman keeps the strongest ones -- parity tests use few).
+    Returns (model, RS_type)."""
+    kw.setdefault("aerosol_total", 0.0)
+    kw.setdefault("vza", (30.0,))
+    kw.setdefault("vaz", (20.0,))
+    Δν = 0.05
+    m = make_scene(3, 5, Nz, S, ν_lo=12950.0, ν_hi=12950.0 + Δν * (S - 1), **kw)
+    offs, w = raman_lines(Δν, S=S)
+    if nRaman is not None and nRaman < len(offs):
+        keep = np.sort(np.argsort(-w)[:nRaman])
+        offs, w = offs[keep], w[keep] * (w.sum() / w[keep].sum())
+    RS = rt.RRS(greek_raman=rt.get_greek_rayleigh(0.75), ϖ_Cabannes=0.96, ϖ_λ1λ0=w, i_λ1λ0=offs,
+                rrs_strict_reference=rrs_strict_reference)
+    return m, RS
+
+
 def work_model_flops(N: int, ndoubl, M: int) -> float:
     """ALGORITHMIC flop per spectral point: the reference's op list, GEMM =
     2N³, inverse = 2N³, matvec = 2N², regardless of how the kernels restructure it."""
