@@ -21,12 +21,11 @@ c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)
 
 
-def build(force: bool = False) -> Path:
-    so = _HERE / "libmomref.so"
-    src = _HERE / "momref.c"
-    mk = _HERE / "Makefile"
-    if force or (not so.exists()) or so.stat().st_mtime < max(src.stat().st_mtime, mk.stat().st_mtime):
-        subprocess.check_call(["make", "-C", str(_HERE), "-B" if force else "-s"])
+def build(force: bool = False, ext: bool = False) -> Path:
+    so = _HERE / ("libmomref_ext.so" if ext else "libmomref.so")
+    srcs = [_HERE / "momref.c", _HERE / "Makefile"] + ([_HERE / "momref_ext.c"] if ext else [])
+    if force or (not so.exists()) or so.stat().st_mtime < max(f.stat().st_mtime for f in srcs):
+        subprocess.check_call(["make", "-C", str(_HERE), "-B" if force else "-s", so.name])
     return so
 
 
@@ -38,6 +37,18 @@ def lib():
         _LIB.ora_w_hw32sd_re.restype = C.c_double
         _LIB.ora_w_hw32sd_re.argtypes = [C.c_double, C.c_double]
     return _LIB
+
+
+_LIB_EXT = None
+
+
+def lib_ext():
+    """oracle/libmomref_ext.so: momref.c compiled in x87 extended precision (momref_ext.c)."""
+    global _LIB_EXT
+    if _LIB_EXT is None:
+        assert np.finfo(np.longdouble).nmant == 63, "numpy.longdouble is not the x87 80-bit format on this host"
+        _LIB_EXT = C.CDLL(str(build(ext=True)))
+    return _LIB_EXT
 
 
 def effective_cores() -> int:
@@ -148,6 +159,47 @@ def rt_run(p: Packed, pts=None, nthreads: int = 0):
     else:
         pts = np.ascontiguousarray(pts, dtype=np.int32)
         info = lib().ora_rt_run(C.byref(st), ip(pts), len(pts), nthreads, dp(R), dp(T))
+    shp = (p.S, p.nS, p.nVza)
+    return np.transpose(R.reshape(shp), (2, 1, 0)).copy(), np.transpose(T.reshape(shp), (2, 1, 0)).copy(), info
+
+
+class OraSceneExt(C.Structure):
+    """ora_scene of the extended-precision build: every `double` is a `long double`."""
+    _fields_ = [("N", C.c_int), ("nS", C.c_int), ("S", C.c_int), ("Nz", C.c_int), ("K", C.c_int), ("M", C.c_int),
+                ("imu0", C.c_int), ("strict", C.c_int), ("mu0", C.c_longdouble),
+                ("mu", C.c_void_p), ("wt", C.c_void_p), ("I0", C.c_void_p), ("D", C.c_void_p),
+                ("tau", C.c_void_p), ("varpi", C.c_void_p), ("zw", C.c_void_p), ("Zpp", C.c_void_p), ("Zmp", C.c_void_p),
+                ("nd", c_ip), ("iface", c_ip), ("tau_sum", C.c_void_p), ("albedo", C.c_longdouble),
+                ("nVza", C.c_int), ("node", c_ip), ("cos_mphi", C.c_void_p), ("sin_mphi", C.c_void_p),
+                ("surf_kind", C.c_int), ("Rsurf", C.c_void_p), ("albedo_spec", C.c_void_p)]
+
+
+def rt_run_ext(p: Packed, pts, point_threads: int = 1):
+    """The elastic run of `rt_run` in x87 EXTENDED precision (oracle/momref_ext.c) for the spectral points `pts`.  The inputs
+    are the same Float64 numbers (widened exactly); R_SFI, T_SFI come back as numpy.longdouble [nVza, nStokes, S] (zeros at
+    the points not asked for).  point_threads: OpenMP threads over the points (each point runs serially)."""
+    L = lib_ext()
+    keep = {}
+
+    def ld(name):
+        a = getattr(p, name)
+        if a is None:
+            return None
+        keep[name] = np.ascontiguousarray(a, dtype=np.longdouble)
+        return keep[name].ctypes.data_as(C.c_void_p)
+
+    s = OraSceneExt()
+    s.N, s.nS, s.S, s.Nz, s.K, s.M = p.N, p.nS, p.S, p.Nz, p.K, p.M
+    s.imu0, s.strict, s.mu0 = p.imu0, p.strict, p.mu0
+    for nm in ("mu", "wt", "I0", "D", "tau", "varpi", "zw", "Zpp", "Zmp", "tau_sum", "cos_mphi", "sin_mphi", "Rsurf", "albedo_spec"):
+        setattr(s, nm, ld(nm))
+    s.nd, s.iface, s.node = ip(p.nd), ip(p.iface), ip(p.node)
+    s.albedo, s.nVza, s.surf_kind = p.albedo, p.nVza, p.surf_kind
+    n = p.nVza * p.nS * p.S
+    R, T = np.zeros(n, dtype=np.longdouble), np.zeros(n, dtype=np.longdouble)
+    pts = np.ascontiguousarray(pts, dtype=np.int32)
+    info = L.ora_rt_run(C.byref(s), ip(pts), len(pts), int(point_threads), R.ctypes.data_as(C.c_void_p),
+                        T.ctypes.data_as(C.c_void_p))
     shp = (p.S, p.nS, p.nVza)
     return np.transpose(R.reshape(shp), (2, 1, 0)).copy(), np.transpose(T.reshape(shp), (2, 1, 0)).copy(), info
 

@@ -31,6 +31,20 @@
  * Register-blocked micro-kernel (12 x 4 block of C in 12 AVX2 accumulators, k innermost and sequential, so every
  * element is the same left-to-right sum over k as the textbook triple loop; only the FMA contraction differs): the
  * CPU baseline of bench.py should not be an un-blocked loop. */
+#ifdef ORA_EXT
+/* extended-precision build (momref_ext.c): plain column sweeps, the same left-to-right sum over k per element */
+static void gemm(int N, const double *A, const double *B, double *C) {
+  for (int j = 0; j < N; ++j) {
+    double *c = C + (size_t)j * N;
+    for (int i = 0; i < N; ++i) c[i] = 0.0;
+    for (int k = 0; k < N; ++k) {
+      const double b = B[IDX(k, j, N)];
+      const double *a = A + (size_t)k * N;
+      for (int i = 0; i < N; ++i) c[i] += a[i] * b;
+    }
+  }
+}
+#else
 typedef double v4d __attribute__((vector_size(32), aligned(8)));
 static inline v4d ld4(const double *p) { return *(const v4d *)p; }
 static inline void st4(double *p, v4d v) { *(v4d *)p = v; }
@@ -92,6 +106,8 @@ static void gemm(int N, const double *A, const double *B, double *C) {
     }
   }
 }
+
+#endif
 
 /* y = A*x */
 static void gemv(int N, const double *A, const double *x, double *y) {
@@ -608,9 +624,9 @@ int ora_rt_run_full(const ora_scene *sc, const int *pts, int npts, int nthreads,
                        a_j0p, a_j0m);
           int e = doubling_pt(&q, nd, &expk, a_rmp, a_tpp, a_rpm, a_tmm, a_j0p, a_j0m, work, piv);
           if (z == 0) { /* rt_kernel.jl:227-230 */
-            memcpy(c_Tpp, a_tpp, NN * 8); memcpy(c_Tmm, a_tmm, NN * 8);
-            memcpy(c_Rmp, a_rmp, NN * 8); memcpy(c_Rpm, a_rpm, NN * 8);
-            memcpy(c_J0p, a_j0p, N * 8); memcpy(c_J0m, a_j0m, N * 8);
+            memcpy(c_Tpp, a_tpp, NN * sizeof(double)); memcpy(c_Tmm, a_tmm, NN * sizeof(double));
+            memcpy(c_Rmp, a_rmp, NN * sizeof(double)); memcpy(c_Rpm, a_rpm, NN * sizeof(double));
+            memcpy(c_J0p, a_j0p, N * sizeof(double)); memcpy(c_J0m, a_j0m, N * sizeof(double));
           } else {
             int e2 = interaction_pt(N, sc->iface[z], c_Rmp, c_Rpm, c_Tpp, c_Tmm, c_J0p, c_J0m, a_rpm, a_rmp, a_tmm,
                                     a_tpp, a_j0p, a_j0m, work, piv);
@@ -732,9 +748,9 @@ int ora_rt_run_ms(const ora_scene *sc, const int *pts, int npts, int nthreads, i
             double *cR_mp = MS_COMP(which, ims, 0), *cR_pm = MS_COMP(which, ims, 1), *cT_pp = MS_COMP(which, ims, 2),
                    *cT_mm = MS_COMP(which, ims, 3), *cJ0p = MS_COMP(which, ims, 4), *cJ0m = MS_COMP(which, ims, 5);
             if (copy) {
-              memcpy(cT_pp, a_tpp, NN * 8); memcpy(cT_mm, a_tmm, NN * 8);
-              memcpy(cR_mp, a_rmp, NN * 8); memcpy(cR_pm, a_rpm, NN * 8);
-              memcpy(cJ0p, a_j0p, N * 8); memcpy(cJ0m, a_j0m, N * 8);
+              memcpy(cT_pp, a_tpp, NN * sizeof(double)); memcpy(cT_mm, a_tmm, NN * sizeof(double));
+              memcpy(cR_mp, a_rmp, NN * sizeof(double)); memcpy(cR_pm, a_rpm, NN * sizeof(double));
+              memcpy(cJ0p, a_j0p, N * sizeof(double)); memcpy(cJ0m, a_j0m, N * sizeof(double));
             } else {
               int e2 = interaction_pt(N, sc->iface[z], cR_mp, cR_pm, cT_pp, cT_mm, cJ0p, cJ0m, a_rpm, a_rmp, a_tmm, a_tpp,
                                       a_j0p, a_j0m, work, piv);

@@ -16,8 +16,9 @@
 //     matrix-vector products of the reference's update formulas as register-tile MFMA products (mom_tile.hpp), reading
 //     and writing each 4-D array block exactly once, in place.  N <= 16: one 16 x 16 tile per operator (the reference's own
 //     RRS shape is N = 15: test/test_parameters/O2Parameters.yaml, IQU, l_trunc 5); N <= 32: 2 x 2 tiles.
-// Pairs are enumerated n1-major, so the nRaman wavefronts that share the n1-side operands run together and the n0-side
-// operands slide through L2.  HBM-bound: 4 (doubling) / 12 (interaction) block transfers of N^2 doubles per pair against
+// Pairs are enumerated dn-major (n1 fastest): the blocks of the 4-D arrays are visited in memory order, i.e. every array is
+// one sequential HBM stream per launch (n1-major order -- consecutive pairs 12 MB apart -- ran at 2.6 TB/s instead); the
+// per-point operands (7 x N^2 x S doubles = 86 MB at C5) are re-read once per Raman line from L2 / Infinity Cache.  HBM-bound: 4 (doubling) / 12 (interaction) block transfers of N^2 doubles per pair against
 // 36 / 72 MFMA instructions (NT = 1).
 //
 // The switch `strict_rrs` (rrs_strict_reference): 1 = the reference text as written, with the semantics of a single-threaded
@@ -57,6 +58,11 @@ __device__ __forceinline__ int scomp(int i0, int n, int strict) { return strict 
 __device__ __forceinline__ double dsgn(int ci, int cj) { return (((ci <= 2) && (cj <= 2)) || ((ci > 2) && (cj > 2))) ? 1.0 : -1.0; }
 
 constexpr int kWavesPerBlock = 4;
+// waves per SIMD the pair kernels are compiled for (register budget 512 / MOMR_WPE); measured in profiles/r03_C5_*.txt
+#ifndef MOMR_WPE
+#define MOMR_WPE 2
+#endif
+#define MOMR_PAIR_ATTR __attribute__((amdgpu_waves_per_eu(MOMR_WPE, MOMR_WPE)))
 
 template <int NT>
 __device__ __forceinline__ Geo make_geo(int N, unsigned char *smem) {
@@ -207,7 +213,8 @@ __global__ void __launch_bounds__(256) k_ie_elemental(KArgs a) {
   if (e >= NN * npairs) return;
   const int i = (int)(e % N), j = (int)((e / N) % N);
   const size_t pp = e / NN;
-  const int n1 = a.n1_lo + (int)(pp / a.nR), dn = (int)(pp % a.nR);
+  const int span = a.n1_hi - a.n1_lo;
+  const int n1 = a.n1_lo + (int)(pp % span), dn = (int)(pp / span);   // dn-major: consecutive blocks of the 4-D arrays
   const size_t u = (size_t)n1 + (size_t)a.S * dn;  // block index of the 4-D arrays
   const size_t o4 = NN * u + i + (size_t)N * j;
   const int n0 = n1 + a.off[dn];
@@ -363,14 +370,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_dbl_point(KArgs a) {
 // doubling step, PAIR kernel (doubling_inelastic.jl:61-89 and :98-125)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) k_dbl_pair(KArgs a) {
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair(KArgs a) {
   const Geo g = make_geo<NT>(a.N, rrs_smem);
   const int N = a.N, n = a.nS, wave = threadIdx.x >> 6;
   const size_t NN = (size_t)N * N;
   const size_t npairs = (size_t)(a.n1_hi - a.n1_lo) * a.nR;
   const bool fuseD = a.last && !a.strict_rrs;  // D2/D3 (corrected) folded into the last step's stores
   for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += (size_t)gridDim.x * kWavesPerBlock) {
-    const int n1 = a.n1_lo + (int)(p / a.nR), dn = (int)(p % a.nR);
+    const int n1 = a.n1_lo + (int)(p % (size_t)(a.n1_hi - a.n1_lo)), dn = (int)(p / (size_t)(a.n1_hi - a.n1_lo));
     const int n0 = n1 + a.off[dn];
     const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = (size_t)N * u;
     if (n0 < 0 || n0 >= a.S) {  // get_n0_n1 (inelastic_helper.jl:13-21): no update off the grid ...
@@ -397,30 +404,34 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_dbl_pair(KArgs a) {
     const Mat<NT> a_c = transpose<NT>(g, a_t);
     // X = ier r0 + r1 ier
     const Mat<NT> X_t = TNacc<NT>(g, a_c, r1_t, TN<NT>(g, r0_c, a_t));
-    // ---- sources                                                                                              :61-89
+    // ---- sources (matrix-vector products on the vector ALU: mom_tile.hpp)                                    :61-89
     {
       const double e1 = a.expk_cur[n1];
-      const Vec<NT> J = loadv2<NT>(g, a.ie_a[J0P] + o3, a.ie_a[J0M] + o3);   // (ieJ0+ | ieJ0-)
-      const Vec<NT> J1 = vscale<NT>(J, e1);                                   // (ieJ1+ | ieJ1-)                 :52-56
+      const CV<NT> Jp = loadC<NT>(g, a.ie_a[J0P] + o3), Jm = loadC<NT>(g, a.ie_a[J0M] + o3);     // ieJ0+, ieJ0-
+      const CV<NT> J1p = cscale<NT>(Jp, e1), J1m = cscale<NT>(Jm, e1);                           // ieJ1+, ieJ1-   :52-56
       const double *jp0 = a.strict_rrs ? a.jpseq + v0 + (size_t)N * a.S * dn : a.a_cur[J0P] + v0;
-      const Vec<NT> av = TNv<NT>(g, a_t, loadv2<NT>(g, a.sv[SV_J1M] + v0, jp0));         // (ier j1-[n0] | ier j0+[n0])
-      const Vec<NT> tm = loadv2<NT>(g, a.sv[SV_TMP1] + v0, a.sv[SV_TMP2] + v0);
-      const Vec<NT> Xv = TNv<NT>(g, X_t, tm);                                 // (X tmp1 | X tmp2)
-      Vec<NT> bv = TNv<NT>(g, b_t, tm);                                       // (iet++ tmp1 | iet++ tmp2)
-      if (a.strict_rrs) {                                                     // D5: iet-- as the array holds it
-        const Vec<NT> bm = TNv<NT>(g, load_t<NT>(g, a.ie_a[T_MM] + o4), tm);
+      const CV<NT> a_j1m = mv_t<NT>(g, a_t, loadR<NT>(g, a.sv[SV_J1M] + v0));                    // ier j1-[n0]
+      const CV<NT> a_jp = mv_t<NT>(g, a_t, loadR<NT>(g, jp0));                                   // ier j0+[n0]
+      const Vec<NT> tm1 = loadR<NT>(g, a.sv[SV_TMP1] + v0), tm2 = loadR<NT>(g, a.sv[SV_TMP2] + v0);
+      const CV<NT> X1 = mv_t<NT>(g, X_t, tm1), X2 = mv_t<NT>(g, X_t, tm2);
+      const CV<NT> b1 = mv_t<NT>(g, b_t, tm1);                                                   // iet++ tmp1
+      const CV<NT> b2 = a.strict_rrs ? mv_t<NT>(g, load_t<NT>(g, a.ie_a[T_MM] + o4), tm2)        // D5: iet-- as the array holds it
+                                     : mv_t<NT>(g, b_t, tm2);
+      Vec<NT> J1mR = loadR<NT>(g, a.ie_a[J0M] + o3);
 #pragma unroll
-        for (int ta = 0; ta < NT; ++ta) bv.t[ta] = (g.lr == 1) ? bm.t[ta] : bv.t[ta];
+      for (int ta = 0; ta < NT; ++ta) J1mR.t[ta] = J1mR.t[ta] * e1;
+      const CV<NT> uu = cadd<NT>(cadd<NT>(Jp, mv_t<NT>(g, r1_t, J1mR)), cadd<NT>(a_j1m, X1));
+      const CV<NT> Jpn = cadd<NT>(cadd<NT>(J1p, mv_t<NT>(g, ttgp1_t, c2r<NT>(g, uu))), b1);      // new ieJ0+
+      const CV<NT> rv2 = mv_t<NT>(g, r1_t, c2r<NT>(g, Jpn));                                     // r1 ieJ0+(new)
+      const CV<NT> u2 = cadd<NT>(cadd<NT>(J1m, rv2), cadd<NT>(a_jp, X2));
+      CV<NT> Jmn = cadd<NT>(cadd<NT>(Jm, mv_t<NT>(g, ttgp1_t, c2r<NT>(g, u2))), b2);             // new ieJ0-
+      if (fuseD && n > 1) {
+#pragma unroll
+        for (int tb = 0; tb < NT; ++tb)
+          if (scomp(g.col(tb), n, a.strict_idx) > 2) Jmn.c[tb] = -Jmn.c[tb];
       }
-      const Vec<NT> rv = TNv<NT>(g, r1_t, swap01<NT>(J1));                    // col 0: r1 ieJ1-
-      const Vec<NT> uu = vadd<NT>(vadd<NT>(J, rv), vadd<NT>(av, Xv));         // col 0
-      const Vec<NT> Jp = vadd<NT>(vadd<NT>(J1, TNv<NT>(g, ttgp1_t, uu)), bv); // col 0: new ieJ0+
-      const Vec<NT> rv2 = swap01<NT>(TNv<NT>(g, r1_t, Jp));                   // col 1: r1 ieJ0+(new)
-      const Vec<NT> u2 = vadd<NT>(vadd<NT>(J1, rv2), vadd<NT>(av, Xv));       // col 1
-      Vec<NT> Jm = vadd<NT>(vadd<NT>(J, TNv<NT>(g, ttgp1_t, u2)), bv);        // col 1: new ieJ0-
-      if (fuseD && n > 1) vmap<NT>(g, Jm, [&](int i, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
-      storev<NT>(g, a.ie_a[J0P] + o3, Jp, 0);
-      storev<NT>(g, a.ie_a[J0M] + o3, Jm, 1);
+      storeC<NT>(g, a.ie_a[J0P] + o3, Jpn);
+      storeC<NT>(g, a.ie_a[J0M] + o3, Jmn);
     }
     // ---- operators                                                                                            :98-125
     const Mat<NT> b_c = transpose<NT>(g, b_t);
@@ -595,20 +606,20 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_int_point(KArgs a, int 
 // interaction, PAIR kernel.  SURF: the added layer is the surface (all its ie* arrays are zeros and never read).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NT, bool SURF>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) k_int_pair(KArgs a, int iface) {
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair(KArgs a, int iface) {
   const Geo g = make_geo<NT>(a.N, rrs_smem);
   const int N = a.N, wave = threadIdx.x >> 6;
   const size_t NN = (size_t)N * N;
   const size_t npairs = (size_t)(a.n1_hi - a.n1_lo) * a.nR;
   for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += (size_t)gridDim.x * kWavesPerBlock) {
-    const int n1 = a.n1_lo + (int)(p / a.nR), dn = (int)(p % a.nR);
+    const int n1 = a.n1_lo + (int)(p % (size_t)(a.n1_hi - a.n1_lo)), dn = (int)(p / (size_t)(a.n1_hi - a.n1_lo));
     const int n0 = n1 + a.off[dn];
     if (n0 < 0 || n0 >= a.S) continue;
     const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = (size_t)N * u;
     const size_t m1 = NN * n1, m0 = NN * n0, v0 = (size_t)N * n0;
     auto ldA = [&](int which) { return SURF ? zeros<NT>() : load_t<NT>(g, a.ie_a[which] + o4); };
-    const Vec<NT> Ja = SURF ? vzeros<NT>() : loadv2<NT>(g, a.ie_a[J0P] + o3, a.ie_a[J0M] + o3);   // (ieJ0+ | ieJ0-) added
-    const Vec<NT> Jc = loadv2<NT>(g, a.ie_c[C_J0P] + o3, a.ie_c[C_J0M] + o3);                    // composite
+    const CV<NT> Jap = SURF ? czeros<NT>() : loadC<NT>(g, a.ie_a[J0P] + o3), Jam = SURF ? czeros<NT>() : loadC<NT>(g, a.ie_a[J0M] + o3);
+    const CV<NT> Jcp = loadC<NT>(g, a.ie_c[C_J0P] + o3), Jcm = loadC<NT>(g, a.ie_c[C_J0M] + o3);   // ieJ0+- added / composite
     if (iface == 3) {
       const Mat<NT> a_t = ldA(R_MP), bm_t = ldA(T_MM);
       const Mat<NT> E_t = load_t<NT>(g, a.ie_c[C_R_PM] + o4), C_t = load_t<NT>(g, a.ie_c[C_T_PP] + o4);
@@ -621,11 +632,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_int_pair(KArgs a, int i
       const Mat<NT> A_t = TNacc<NT>(g, M1_c, T01_t, load_t<NT>(g, a.ie_c[C_T_MM] + o4));
       // ieJ0- += T01 (ier J0+[n0] + r ieJ0+ + ieJ0-(added)) + A G1 (j0-[n0] + r[n0] J0+[n0])                      :251-264
       {
-        const Vec<NT> v1 = TNv<NT>(g, a_t, loadv2<NT>(g, a.c_cur[C_J0P] + v0, nullptr));
-        const Vec<NT> v2 = TNv<NT>(g, r1_t, Jc);
-        const Vec<NT> uu = vadd<NT>(vadd<NT>(v1, v2), swap01<NT>(Ja));
-        const Vec<NT> w = TNvacc<NT>(g, A_t, loadv2<NT>(g, a.sv[SVI_G1V] + v0, nullptr), TNv<NT>(g, T01_t, uu));
-        storev<NT>(g, a.ie_c[C_J0M] + o3, vadd<NT>(swap01<NT>(Jc), w), 0);
+        const CV<NT> v1 = mv_t<NT>(g, a_t, loadR<NT>(g, a.c_cur[C_J0P] + v0));
+        const CV<NT> v2 = mv_t<NT>(g, r1_t, loadR<NT>(g, a.ie_c[C_J0P] + o3));
+        const CV<NT> uu = cadd<NT>(cadd<NT>(v1, v2), Jam);
+        const CV<NT> w = cadd<NT>(mv_t<NT>(g, T01_t, c2r<NT>(g, uu)), mv_t<NT>(g, A_t, loadR<NT>(g, a.sv[SVI_G1V] + v0)));
+        storeC<NT>(g, a.ie_c[C_J0M] + o3, cadd<NT>(Jcm, w));
       }
       // ieR-+ += T01 (ier T++[n0] + r ieT++) + A G1 r[n0] T++[n0];  ieT-- = T01 iet-- + A G1 t--[n0]               :271-284
       {
@@ -643,11 +654,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_int_pair(KArgs a, int i
       const Mat<NT> B_t = TNacc<NT>(g, M2_c, T21_t, ldA(T_PP));
       // ieJ0+ = ieJ0+(added) + T21 (ieJ0+ + ieR+- j0-[n0] + R+- ieJ0-(added)) + B G2 (J0+[n0] + R+-[n0] j0-[n0])    :301-312
       {
-        const Vec<NT> v3 = TNv<NT>(g, E_t, loadv2<NT>(g, a.x[J0M] + v0, nullptr));
-        const Vec<NT> v4 = TNv<NT>(g, Rpm1_t, swap01<NT>(Ja));
-        const Vec<NT> uu = vadd<NT>(vadd<NT>(Jc, v3), v4);
-        const Vec<NT> w = TNvacc<NT>(g, B_t, loadv2<NT>(g, a.sv[SVI_G2V] + v0, nullptr), TNv<NT>(g, T21_t, uu));
-        storev<NT>(g, a.ie_c[C_J0P] + o3, vadd<NT>(Ja, w), 0);
+        const CV<NT> v3 = mv_t<NT>(g, E_t, loadR<NT>(g, a.x[J0M] + v0));
+        const CV<NT> v4 = SURF ? czeros<NT>() : mv_t<NT>(g, Rpm1_t, loadR<NT>(g, a.ie_a[J0M] + o3));
+        const CV<NT> uu = cadd<NT>(cadd<NT>(Jcp, v3), v4);
+        const CV<NT> w = cadd<NT>(mv_t<NT>(g, T21_t, c2r<NT>(g, uu)), mv_t<NT>(g, B_t, loadR<NT>(g, a.sv[SVI_G2V] + v0)));
+        storeC<NT>(g, a.ie_c[C_J0P] + o3, cadd<NT>(Jap, w));
       }
       // ieT++ = T21 ieT++ + B G2 T++[n0];  ieR+- = ier+- + T21 (ieR+- t--[n0] + R+- iet--) + B G2 R+-[n0] t--[n0]   :320-334
       {
@@ -662,10 +673,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_int_pair(KArgs a, int i
     } else if (iface == 1) {                                                           // 01, corrected (D4)       :40-75
       const Mat<NT> a_t = ldA(R_MP), b_t = ldA(T_PP), bm_t = ldA(T_MM);
       const Mat<NT> Tmm1_t = load_t<NT>(g, a.c_cur[C_T_MM] + m1), Tpp0_c = load_t<NT>(g, a.sm[SI_TPP] + m0);
-      const Vec<NT> J0 = loadv2<NT>(g, a.c_cur[C_J0P] + v0, nullptr);
-      const Vec<NT> v1 = vadd<NT>(TNv<NT>(g, a_t, J0), swap01<NT>(Ja));                // col 0: ier J0+[n0] + ieJ0-(added)
-      storev<NT>(g, a.ie_c[C_J0M] + o3, TNv<NT>(g, Tmm1_t, v1), 0);
-      storev<NT>(g, a.ie_c[C_J0P] + o3, vadd<NT>(Ja, TNv<NT>(g, b_t, J0)), 0);
+      const Vec<NT> J0 = loadR<NT>(g, a.c_cur[C_J0P] + v0);
+      const CV<NT> v1 = cadd<NT>(mv_t<NT>(g, a_t, J0), Jam);                           // ier J0+[n0] + ieJ0-(added)
+      storeC<NT>(g, a.ie_c[C_J0M] + o3, mv_t<NT>(g, Tmm1_t, c2r<NT>(g, v1)));
+      storeC<NT>(g, a.ie_c[C_J0P] + o3, cadd<NT>(Jap, mv_t<NT>(g, b_t, J0)));
       store_t<NT>(g, a.ie_c[C_R_MP] + o4, TN<NT>(g, TN<NT>(g, a_t, Tpp0_c), Tmm1_t));  // T-- ier T++[n0]
       store_t<NT>(g, a.ie_c[C_R_PM] + o4, ldA(R_PM));
       store_t<NT>(g, a.ie_c[C_T_PP] + o4, TN<NT>(g, Tpp0_c, b_t));                     // iet++ T++[n0]
@@ -674,9 +685,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_int_pair(KArgs a, int i
       const Mat<NT> E_t = load_t<NT>(g, a.ie_c[C_R_PM] + o4), C_t = load_t<NT>(g, a.ie_c[C_T_PP] + o4);
       const Mat<NT> F_t = load_t<NT>(g, a.ie_c[C_T_MM] + o4);
       const Mat<NT> tpp1_t = load_t<NT>(g, a.x[T_PP] + m1), tmm0_c = load_t<NT>(g, a.sm[SI_TMM] + m0);
-      const Vec<NT> j0 = loadv2<NT>(g, a.x[J0M] + v0, nullptr);
-      storev<NT>(g, a.ie_c[C_J0P] + o3, TNv<NT>(g, tpp1_t, vadd<NT>(Jc, TNv<NT>(g, E_t, j0))), 0);
-      storev<NT>(g, a.ie_c[C_J0M] + o3, vadd<NT>(swap01<NT>(Jc), TNv<NT>(g, F_t, j0)), 0);
+      const Vec<NT> j0 = loadR<NT>(g, a.x[J0M] + v0);
+      storeC<NT>(g, a.ie_c[C_J0P] + o3, mv_t<NT>(g, tpp1_t, c2r<NT>(g, cadd<NT>(Jcp, mv_t<NT>(g, E_t, j0)))));
+      storeC<NT>(g, a.ie_c[C_J0M] + o3, cadd<NT>(Jcm, mv_t<NT>(g, F_t, j0)));
       store_t<NT>(g, a.ie_c[C_T_PP] + o4, TN<NT>(g, transpose<NT>(g, C_t), tpp1_t));   // t++ ieT++
       store_t<NT>(g, a.ie_c[C_T_MM] + o4, TN<NT>(g, tmm0_c, F_t));                     // ieT-- t--[n0]
       store_t<NT>(g, a.ie_c[C_R_PM] + o4, TN<NT>(g, TN<NT>(g, E_t, tmm0_c), tpp1_t));  // t++ ieR+- t--[n0]

@@ -198,6 +198,92 @@ __device__ __forceinline__ void storev(const Geo &g, double *p, const Vec<NT> &v
     }
 }
 
+// ---- matrix-vector products on the vector ALU -------------------------------------------------------------------------
+// A 16 x 16 x 4 MFMA spends a whole tile column per vector; for the few matrix-vector products of a kernel that is
+// otherwise bound by the matrix pipe it is cheaper to multiply on the vector ALU and reduce across lanes:
+//   RV ("row layout"):    lane (lq, lr) holds x[16 a + lq + 4 r] in t[a][r] -- the same value in all 16 lanes lr
+//   CV ("column layout"): lane (lq, lr) holds y[16 b + lr] in c[b]          -- the same value in all 4 lane groups lq
+// y = M x with M_t (C-layout tiles of M^T) takes x in row layout and returns y in column layout: 4 NT FMAs per lane and
+// row block, then two cross-lane steps (xor 16, xor 32); c2r converts a column-layout vector to row layout (4 NT shuffles).
+template <int NT>
+struct CV {
+  double c[NT];
+};
+template <int NT>
+__device__ __forceinline__ Vec<NT> loadR(const Geo &g, const double *p) {
+  Vec<NT> v;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ro = g.row(a, r);
+      v.t[a][r] = (ro < g.N) ? p[ro] : 0.0;
+    }
+  return v;
+}
+template <int NT>
+__device__ __forceinline__ CV<NT> loadC(const Geo &g, const double *p) {
+  CV<NT> v;
+#pragma unroll
+  for (int b = 0; b < NT; ++b) v.c[b] = (g.col(b) < g.N) ? p[g.col(b)] : 0.0;
+  return v;
+}
+template <int NT>
+__device__ __forceinline__ CV<NT> czeros() {
+  CV<NT> v;
+#pragma unroll
+  for (int b = 0; b < NT; ++b) v.c[b] = 0.0;
+  return v;
+}
+template <int NT>
+__device__ __forceinline__ void storeC(const Geo &g, double *p, const CV<NT> &v) {
+  if (g.lq != 0) return;
+#pragma unroll
+  for (int b = 0; b < NT; ++b)
+    if (g.col(b) < g.N) p[g.col(b)] = v.c[b];
+}
+template <int NT>
+__device__ __forceinline__ CV<NT> cadd(const CV<NT> &A, const CV<NT> &B) {
+  CV<NT> C;
+#pragma unroll
+  for (int b = 0; b < NT; ++b) C.c[b] = A.c[b] + B.c[b];
+  return C;
+}
+template <int NT>
+__device__ __forceinline__ CV<NT> cscale(const CV<NT> &A, double s) {
+  CV<NT> C;
+#pragma unroll
+  for (int b = 0; b < NT; ++b) C.c[b] = A.c[b] * s;
+  return C;
+}
+// y = M x, M given as M_t
+template <int NT>
+__device__ __forceinline__ CV<NT> mv_t(const Geo &g, const Mat<NT> &M_t, const Vec<NT> &xR) {
+  CV<NT> y;
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    double acc = 0.0;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = fma(M_t.t[a][b][r], xR.t[a][r], acc);
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    y.c[b] = acc;
+  }
+  return y;
+}
+template <int NT>
+__device__ __forceinline__ Vec<NT> c2r(const Geo &g, const CV<NT> &y) {
+  Vec<NT> x;
+  const int base = (g.lq << 4);
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x.t[a][r] = __shfl(y.c[a], base | (g.lq + 4 * r));
+  return x;
+}
+
 // X^T through the wave's LDS slice: tile (a, b) of the result is the transpose of tile (b, a)
 template <int NT>
 __device__ __forceinline__ Mat<NT> transpose(const Geo &g, const Mat<NT> &X) {

@@ -14,17 +14,19 @@ RTOL_OP = 1e-12
 
 
 def stokes_rtol(ndoubl) -> float:
-    """Parity tolerance as a function of the scene's largest doubling number.  1e-10 (north star) holds for the
-    reference's own test inputs and for thin-to-moderate layers.  Each doubling squares the direct transmission,
-    t <- t t, so a one-ulp difference in an elemental exp(-dtau/mu) -- or in any early product -- is doubled nd times:
-    after nd doublings two CORRECT IEEE implementations of the same algorithm differ by a multiple of 2^nd eps.
-    Measured noise floor, C oracle (LU, sequential FMA sums) against its numpy twin (LAPACK getri / OpenBLAS gemm) on the
-    aerosol-tau-0.6 scenes of test_rt_run_parity_strip_sizes (scratch: twin vs C, relative to I):
-        IQUV N=56 nd=16: 8.0e-10 (37 x 2^nd eps)   IQU N=54 nd=17: 2.8e-10   IQU N=66 nd=18: 3.3e-10   I N=36 nd=19: 1.7e-9
-    The reference (Julia: OpenBLAS/LAPACK) is a third such implementation.  Hence rtol = max(1e-10, 64 * 2^nd_max * eps):
-    1e-10 up to nd = 12, 9.3e-10 at nd = 16, 7.5e-9 at nd = 19."""
+    """Parity tolerance of GPU-vs-Float64-oracle comparisons as a function of the scene's largest doubling number:
+    1e-10 (north star) up to ndoubl = 15, then 8 * 2^nd * eps (1.2e-10 at 16, 9.3e-10 at 19, 3.7e-9 at 21, 3.0e-8 at 24).
+
+    Each doubling squares the direct transmission, so a one-ulp difference anywhere early is doubled nd times: every
+    Float64 run of the algorithm -- the LU oracle included -- is a multiple of 2^nd eps away from the exact result of the
+    same equations.  tests/test_gpu_precision.py measures both against the x87 extended-precision build of the oracle
+    (oracle/momref_ext.c) on the thick scenes of this suite: the oracle's own error is 3e-11 at nd = 16, 1.6e-9 at
+    nd = 18, 4.3e-9 at nd = 21, 8.5e-9 at nd = 24 (N = 256); the GPU default path's error is 0.7 .. 1.13 x the oracle's
+    (asserted <= 4 x), and the two differ from each other by 1e-12 (nd 16), 2e-11 (17..18), 1.5e-10 (21), 5.8e-10 (24) --
+    that difference is what this bar bounds.  With MOM_OPT_INVERSE = 1 (pivoted Gauss-Jordan: the oracle's rounding
+    pattern) the GPU agrees with the oracle to 1e-11 on all of them."""
     nd = int(np.max(np.asarray(ndoubl))) if np.size(ndoubl) else 0
-    return max(RTOL_STOKES, 64.0 * 2.0 ** nd * float(np.finfo(np.float64).eps))
+    return max(RTOL_STOKES, 8.0 * 2.0 ** nd * float(np.finfo(np.float64).eps))
 
 
 def assert_stokes_close(X, Xref, rtol=RTOL_STOKES, atol=ATOL_STOKES, what=""):

@@ -65,8 +65,8 @@ def test_small_operator_sweep_kernel(rtamd, cref, lt, vza, kw):
         helpers.assert_stokes_close(R, Rr, rtol=tol, what=f"R small={small}")
         helpers.assert_stokes_close(T, Tr, rtol=tol, what=f"T small={small}")
         helpers.assert_stokes_close(H, Hr, rtol=tol, what=f"hdr small={small}")
-        np.testing.assert_allclose(up, upr, rtol=max(tol, 1e-10), atol=1e-300)
-        np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=1e-300)
+        np.testing.assert_allclose(up, upr, rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
+        np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
 
 
 @pytest.mark.parametrize("nS,lt,vza,kw", [
@@ -110,8 +110,8 @@ def test_wave_per_point_sweep_kernel(rtamd, cref, nS, lt, vza, kw, inverse):
         helpers.assert_stokes_close(R, Rr, rtol=tol, what=f"R small={small}")
         helpers.assert_stokes_close(T, Tr, rtol=tol, what=f"T small={small}")
         helpers.assert_stokes_close(H, Hr, rtol=tol, what=f"hdr small={small}")
-        np.testing.assert_allclose(up, upr, rtol=max(tol, 1e-10), atol=1e-300)
-        np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=1e-300)
+        np.testing.assert_allclose(up, upr, rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
+        np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
 
 
 @pytest.mark.parametrize("surf", ["rpv", "rossli", "legendre"])
@@ -137,8 +137,8 @@ def test_wave_kernel_surfaces_and_many_views(rtamd, cref, surf, nS, lt):
     helpers.assert_stokes_close(R, Rr, rtol=tol, what="R")
     helpers.assert_stokes_close(T, Tr, rtol=tol, what="T")
     helpers.assert_stokes_close(H, Hr, rtol=tol, what="hdr")
-    np.testing.assert_allclose(up, upr, rtol=max(tol, 1e-10), atol=1e-300)
-    np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=1e-300)
+    np.testing.assert_allclose(up, upr, rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
+    np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
 
 
 def test_wave_kernel_falls_back_on_other_interfaces(rtamd, cref):
@@ -205,7 +205,7 @@ def test_config_C3_three_bands(rtamd, cref):
 
 def test_config_C4_iquv_64_streams(rtamd, cref):
     """configs[3]: aerosol + cloud, IQUV, 64 streams: 256 x 256 operators (the large-N kernels).  S = 256 points:
-    finite, reproducible, 8 stratified points against the oracle."""
+    finite, reproducible, 32 stratified points against the oracle."""
     m = rtamd.scenes.scene_C4(S=256)
     sc = rtamd.prepare_scene(m)
     assert (sc.N, sc.nStokes, sc.Nz) == (256, 4, 40)
@@ -215,8 +215,8 @@ def test_config_C4_iquv_64_streams(rtamd, cref):
         R2, T2 = h.get_RT()
     assert np.all(np.isfinite(R)) and np.all(np.isfinite(T))
     assert np.array_equal(R, R2) and np.array_equal(T, T2)
-    pts = _stratified(m, 8)
+    pts = _stratified(m, 32)
     Rr, Tr = _oracle(cref, m, pts=pts)
-    tol = helpers.stokes_rtol(sc.ndoubl)  # tau = 5 cloud: up to 22 doublings of 256 x 256 operators
+    tol = helpers.stokes_rtol(sc.ndoubl)  # tau = 5 cloud: 24 doublings of 256 x 256 operators (arbiter: test_gpu_precision.py)
     helpers.assert_stokes_close(R[:, :, pts], Rr[:, :, pts], rtol=tol, what="C4 sample R")
     helpers.assert_stokes_close(T[:, :, pts], Tr[:, :, pts], rtol=tol, what="C4 sample T")

@@ -88,8 +88,8 @@ def test_strip_padding_to_kernel_sizes(rtamd, cref, nS, lt, N, kw):
         helpers.assert_stokes_close(out[pad][0], Rr, rtol=tol, what=f"R pad={pad}")
         helpers.assert_stokes_close(out[pad][1], Tr, rtol=tol, what=f"T pad={pad}")
     helpers.assert_stokes_close(out[1][2], out[0][2], rtol=tol, what="hdr padded vs unpadded")
-    np.testing.assert_allclose(out[1][3], out[0][3], rtol=max(tol, 1e-10), atol=1e-300)
-    np.testing.assert_allclose(out[1][4], out[0][4], rtol=max(tol, 1e-10), atol=1e-300)
+    np.testing.assert_allclose(out[1][3], out[0][3], rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
+    np.testing.assert_allclose(out[1][4], out[0][4], rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
 
 
 def test_strip_chains_thick_layers_fall_back(rtamd, cref):
