@@ -263,6 +263,29 @@ int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, const doubl
  * mom_scene_get_layers   ndoubl / iface [Nz] and (optionally, NULL to skip) τ, ϖ [nSpec,Nz], zw [K,nSpec,Nz],
  *                        τ_sum [nSpec,Nz+1] of the resident scene */
 int mom_absorption_begin(mom_t *h, int Nz, const double *grid);
+/* The same accumulation with the per-line prefactors formed ON THE DEVICE (last clause):
+ *   mom_absorption_set_lines   ONE resident table per absorber: the HITRAN columns (read_hitran.jl:14-68) of the lines inside
+ *                              the padded grid -- selected once by the host, compute_absorption_cross_section.jl:54-72 --,
+ *                              sqrt_mol_weight = Float64(sqrt(mol_weight(mol, iso)::Float32)) per line, iso_index = the line's
+ *                              row in the TIPS tables below, and for each of the nIso isotopologues in use the TIPS-2017
+ *                              table as qoft! (:197-214) interpolates it: nT[k] knots tips_T, values tips_Q and the second
+ *                              derivatives tips_z of DataInterpolations.CubicSpline ([nTmax, nIso] column-major, i.e. one
+ *                              row of nTmax entries per isotopologue; computed once by the host in the tables' Float32).
+ *   mom_voigt_tau_abs_layer    compute_absorption_profile! for layer iz (atmo_prof.jl:427-449): pressure shift, Lorentz and
+ *                              Doppler widths, y, TIPS ratio, Boltzmann and stimulated-emission factors, grid windows
+ *                              (compute_absorption_cross_section.jl:79-107) by k_line_prefactors, then the Voigt kernel adds
+ *                              sigma * factor into tau_abs[:, iz].  Only (p, T, vmr, wing_cutoff, factor) cross the bus.
+ *                              Agrees with the host route (mom_voigt_tau_abs fed by the host's prefactors) to rounding of
+ *                              exp/pow (device vs host libm), not bitwise.
+ *   mom_absorption_get_prefactors   the prefactors of the last layer call (test access). */
+int mom_absorption_set_lines(mom_t *h, int nLines, const double *nu0, const double *S0, const double *gamma_air,
+                             const double *gamma_self, const double *E_lower, const double *n_air, const double *delta_air,
+                             const double *sqrt_mol_weight, const int *iso_index, int nIso, int nTmax, const int *nT,
+                             const double *tips_T, const double *tips_Q, const double *tips_z);
+int mom_voigt_tau_abs_layer(mom_t *h, int iz_1based, double pressure, double temperature, double vmr, double wing_cutoff,
+                            double factor);
+int mom_absorption_get_prefactors(mom_t *h, int n, double *nu, double *gamma_d, double *y, double *S, int *ind_start_1based,
+                                  int *ind_stop_1based);
 int mom_voigt_tau_abs(mom_t *h, int iz_1based, int nLines, const double *nu, const double *gamma_d, const double *y,
                       const double *S, const int *ind_start_1based, const int *ind_stop_1based, double factor);
 int mom_absorption_set(mom_t *h, int Nz, const double *tau_abs);

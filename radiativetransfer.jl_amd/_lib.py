@@ -78,6 +78,9 @@ SIGNATURES = {
     "mom_scene_set": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip, c_dp,
                                 C.c_double, C.c_int, c_ip, c_dp, c_dp]),
     "mom_absorption_begin": (C.c_int, [c_h, C.c_int, c_dp]),
+    "mom_absorption_set_lines": (C.c_int, [c_h, C.c_int] + [c_dp] * 8 + [c_ip, C.c_int, C.c_int, c_ip, c_dp, c_dp, c_dp]),
+    "mom_voigt_tau_abs_layer": (C.c_int, [c_h, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "mom_absorption_get_prefactors": (C.c_int, [c_h, C.c_int, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip]),
     "mom_voigt_tau_abs": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip, C.c_double]),
     "mom_absorption_set": (C.c_int, [c_h, C.c_int, c_dp]),
     "mom_absorption_get": (C.c_int, [c_h, c_dp]),
@@ -352,6 +355,28 @@ class Handle:
         i0, i1 = i32(ind_start), i32(ind_stop)
         self.check(self.lib.mom_voigt_tau_abs(self._h, int(iz_1based), len(a[0]), *[dp(x) for x in a], ip(i0), ip(i1),
                                               float(factor)))
+
+    def absorption_set_lines(self, cols, sqrt_w, iso_index, nT, tips_T, tips_Q, tips_z):
+        """cols: the eight per-line arrays nu0, S0, gamma_air, gamma_self, E_lower, n_air, delta_air (+ sqrt_w appended here);
+        tips_*: [nIso, nTmax] numpy."""
+        a = [f64(x) for x in cols] + [f64(sqrt_w)]
+        ii, nT = i32(iso_index), i32(nT)
+        tt, tq, tz = (f64(x) for x in (tips_T, tips_Q, tips_z))
+        nIso, nTmax = (tt.shape if tt.ndim == 2 else (0, 0))
+        self._nLines = len(a[0])
+        self.check(self.lib.mom_absorption_set_lines(self._h, self._nLines, *[dp(x) for x in a], ip(ii), int(nIso), int(nTmax),
+                                                     ip(nT), dp(tt.reshape(-1)), dp(tq.reshape(-1)), dp(tz.reshape(-1))))
+
+    def voigt_tau_abs_layer(self, iz_1based, p, T, vmr, wing_cutoff, factor):
+        self.check(self.lib.mom_voigt_tau_abs_layer(self._h, int(iz_1based), float(p), float(T), float(vmr), float(wing_cutoff),
+                                                    float(factor)))
+
+    def absorption_get_prefactors(self, n=None):
+        n = self._nLines if n is None else int(n)
+        d = [np.empty(n) for _ in range(4)]
+        i0, i1 = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32)
+        self.check(self.lib.mom_absorption_get_prefactors(self._h, n, *[dp(x) for x in d], ip(i0), ip(i1)))
+        return d + [i0, i1]
 
     def scene_set_optics(self, Nz, M, tau_rayl, varpi_rayl, tau_aer, omega_aer, ft_aer, Zpp, Zmp, albedo, node, cos_mphi,
                          sin_mphi):

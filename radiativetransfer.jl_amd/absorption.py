@@ -244,13 +244,42 @@ def compute_absorption_cross_section(h: HitranTable, grid, pressure: float, temp
                            device=device)
 
 
+def resident_line_table(h, table: HitranTable, grid, wing_cutoff: float = 40.0):
+    """Uploads ONE resident table of the absorber for mom_voigt_tau_abs_layer (device-side prefactors): the lines inside the
+    padded grid (compute_absorption_cross_section.jl:54-72), sqrt(mol_weight) per line (Float32 square root, :88) and the
+    TIPS-2017 spline tables of the isotopologues in use (qoft!, :197-214).  Returns the number of resident lines."""
+    grid = np.asarray(grid, dtype=np.float64)
+    keep = (grid.min() - wing_cutoff < table.νᵢ) & (table.νᵢ < grid.max() + wing_cutoff)
+    mol, iso = table.mol[keep], table.iso[keep]
+    E = table.E_lower[keep]
+    pairs = sorted(set(zip(mol.tolist(), iso.tolist())))
+    sqw = np.empty(mol.size)
+    iso_index = np.full(mol.size, -1, dtype=np.int32)
+    splines = []
+    for (M, I) in pairs:
+        sel = (mol == M) & (iso == I)
+        sqw[sel] = np.float64(np.sqrt(mol_weight(M, I)))
+        if np.any(E[sel] != -1):
+            iso_index[sel] = len(splines)
+            splines.append(CubicSpline(get_TQ(M, I), get_TT(M, I)))
+    nTmax = max([len(sp.t) for sp in splines], default=0)
+    tabs = np.zeros((3, len(splines), nTmax))
+    for k, sp in enumerate(splines):
+        n = len(sp.t)
+        tabs[0, k, :n], tabs[1, k, :n], tabs[2, k, :n] = sp.t, sp.u, sp.z   # Float32 values, widened exactly
+    cols = [table.νᵢ[keep], table.Sᵢ[keep], table.γ_air[keep], table.γ_self[keep], E, table.n_air[keep], table.δ_air[keep]]
+    h.absorption_set_lines(cols, sqw, iso_index, [len(sp.t) for sp in splines] or [0], tabs[0], tabs[1], tabs[2])
+    return int(mol.size)
+
+
 def compute_absorption_profile(h, table: HitranTable, grid, p_full, T, vcd_dry, vmr, wing_cutoff: float = 40.0,
-                               model_vmr: float = 0.0, qratio=None, begin: bool = True):
+                               model_vmr: float = 0.0, qratio=None, begin: bool = True, device_prefactors: bool = False):
     """compute_absorption_profile!(τ_abs, absorption_model, grid, vmr, profile) (atmo_prof.jl:427-449) on the handle's
     resident τ_abs table: per layer the host builds the line prefactors (O(nLines)), the GPU adds
     σ(ν; p[iz], T[iz]) * vcd_dry[iz] * vmr[iz] into τ_abs[:, iz] (mom_voigt_tau_abs).  `vmr` scalar or per layer (the
     profile's mixing ratio); `model_vmr` is HitranModel.vmr, the self-broadening fraction of the line shape.
-    begin=False adds another absorber to the same table (the reference's `+=` over molecules)."""
+    begin=False adds another absorber to the same table (the reference's `+=` over molecules).  device_prefactors=True
+    forms the per-line prefactors on the GPU from one resident line table (mom_absorption_set_lines / _layer)."""
     p_full, T, vcd_dry = (np.asarray(x, dtype=np.float64) for x in (p_full, T, vcd_dry))
     Nz = p_full.size
     assert T.size == Nz and vcd_dry.size == Nz
@@ -258,6 +287,13 @@ def compute_absorption_profile(h, table: HitranTable, grid, p_full, T, vcd_dry, 
     assert vmr_arr.size == Nz, "Length of VMR array has to match profile size or be uniform"
     if begin:
         h.absorption_begin(Nz, grid)
+    if device_prefactors:   # one resident table, per layer only (p, T, vmr, vcd) cross the bus
+        if qratio is not None:
+            raise ValueError("device_prefactors uses the reference's qoft! (TIPS-2017); qratio overrides are host-route only")
+        resident_line_table(h, table, grid, wing_cutoff)
+        for iz in range(Nz):
+            h.voigt_tau_abs_layer(iz + 1, p_full[iz], T[iz], model_vmr, wing_cutoff, vcd_dry[iz] * vmr_arr[iz])
+        return
     for iz in range(Nz):
         pf = line_prefactors(table, grid, p_full[iz], T[iz], vmr=model_vmr, wing_cutoff=wing_cutoff, qratio=qratio)
         h.voigt_tau_abs(iz + 1, pf.ν, pf.γ_d, pf.y, pf.S, pf.ind_start, pf.ind_stop, vcd_dry[iz] * vmr_arr[iz])

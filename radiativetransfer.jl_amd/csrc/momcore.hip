@@ -522,6 +522,11 @@ struct mom_handle {
   double *d_rrs_op[8] = {};                   // operator-level inputs: tau_sum, dtau, varpi, fscatt [S]; Z x4 [N,N]
   bool rrs_scene = false;
   double rrs_ms = 0.0;
+  // resident HITRAN table + TIPS splines of one absorber (mom_absorption_set_lines)
+  MomLineTable lt{};
+  double *d_lt = nullptr;   // one allocation behind lt's double arrays
+  int *d_lt_i = nullptr;    // iso index [nLines] | knots per isotopologue [nIso] | unsorted flag [1]
+  double lt_Tmin = 0.0, lt_Tmax = 0.0;
   std::string err;
 };
 
@@ -671,6 +676,7 @@ extern "C" int mom_destroy(mom_t *h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->f32) momf_destroy(h->f32);
   momr::destroy(h->rrs);
+  (void)hipFree(h->d_lt); (void)hipFree(h->d_lt_i);
   (void)hipFree(h->d_fscatt); (void)hipFree(h->d_Zr[0]); (void)hipFree(h->d_Zr[1]);
   for (int k = 0; k < 8; ++k) (void)hipFree(h->d_rrs_op[k]);
   if (h->comm && g_rccl_destroy) g_rccl_destroy(h->comm);
@@ -2032,6 +2038,111 @@ extern "C" int mom_voigt_tau_abs(mom_t *h, int iz_1based, int nLines, const doub
   HIPCHK(h, mom_voigt_launch(h->stream, nLines, dl, dl + cap, dl + 2 * cap, dl + 3 * cap, dw, dw + cap, h->S, h->d_grid,
                              h->d_tau_abs + (size_t)h->S * (iz_1based - 1), factor, 1, sorted));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+// Resident line table of one absorber: the HITRAN columns of the lines inside the padded grid (the host selects them once,
+// compute_absorption_cross_section.jl:54-72) and the TIPS-2017 spline tables of their isotopologues (qoft! :197-214: knots,
+// values and the second derivatives of DataInterpolations.CubicSpline, computed once by the host in the tables' Float32).
+extern "C" int mom_absorption_set_lines(mom_t *h, int nLines, const double *nu0, const double *S0, const double *gamma_air,
+                                        const double *gamma_self, const double *E_lower, const double *n_air,
+                                        const double *delta_air, const double *sqrt_mol_weight, const int *iso_index, int nIso,
+                                        int nTmax, const int *nT, const double *tips_T, const double *tips_Q, const double *tips_z) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_absorption_set_lines");
+  if (nLines < 0 || nIso < 0 || nTmax < 0 || (nLines > 0 && (!nu0 || !S0 || !gamma_air || !gamma_self || !E_lower || !n_air ||
+      !delta_air || !sqrt_mol_weight || !iso_index)) || (nIso > 0 && (nTmax < 2 || !nT || !tips_T || !tips_Q || !tips_z)))
+    return fail(h, MOM_EINVAL, "mom_absorption_set_lines: bad argument");
+  for (int j = 0; j < nLines; ++j)
+    if (E_lower[j] != -1.0 && (iso_index[j] < 0 || iso_index[j] >= nIso))
+      return fail(h, MOM_EINVAL, "mom_absorption_set_lines: iso_index out of range");
+  for (int k = 0; k < nIso; ++k)
+    if (nT[k] < 2 || nT[k] > nTmax) return fail(h, MOM_EINVAL, "mom_absorption_set_lines: bad knot count");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  (void)hipFree(h->d_lt); (void)hipFree(h->d_lt_i);
+  h->d_lt = nullptr; h->d_lt_i = nullptr;
+  h->lt = MomLineTable{};
+  const size_t L = (size_t)std::max(nLines, 1), Tn = (size_t)std::max(nIso, 1) * std::max(nTmax, 1);
+  HIPCHK(h, dmalloc(&h->d_lt, 8 * L + 3 * Tn));
+  HIPCHK(h, dmalloc(&h->d_lt_i, L + std::max(nIso, 1) + 1));
+  const double *cols[8] = {nu0, S0, gamma_air, gamma_self, E_lower, n_air, delta_air, sqrt_mol_weight};
+  for (int k = 0; k < 8 && nLines > 0; ++k) HIPCHK(h, hipMemcpy(h->d_lt + k * L, cols[k], (size_t)nLines * sizeof(double), hipMemcpyHostToDevice));
+  const double *tabs[3] = {tips_T, tips_Q, tips_z};
+  for (int k = 0; k < 3 && nIso > 0; ++k) HIPCHK(h, hipMemcpy(h->d_lt + 8 * L + k * Tn, tabs[k], (size_t)nIso * nTmax * sizeof(double), hipMemcpyHostToDevice));
+  if (nLines > 0) HIPCHK(h, hipMemcpy(h->d_lt_i, iso_index, (size_t)nLines * sizeof(int), hipMemcpyHostToDevice));
+  if (nIso > 0) HIPCHK(h, hipMemcpy(h->d_lt_i + L, nT, (size_t)nIso * sizeof(int), hipMemcpyHostToDevice));
+  MomLineTable &t = h->lt;
+  t.nLines = nLines; t.nIso = nIso; t.nTmax = nTmax;
+  t.nu0 = h->d_lt; t.S0 = h->d_lt + L; t.g_air = h->d_lt + 2 * L; t.g_self = h->d_lt + 3 * L; t.E = h->d_lt + 4 * L;
+  t.n_air = h->d_lt + 5 * L; t.d_air = h->d_lt + 6 * L; t.sqw = h->d_lt + 7 * L;
+  t.tT = h->d_lt + 8 * L; t.tQ = t.tT + Tn; t.tZ = t.tQ + Tn;
+  t.iso = h->d_lt_i; t.nT = h->d_lt_i + L;
+  // the common validity range of the TIPS tables in use (qoft! asserts Tmin < T < Tmax, :204)
+  h->lt_Tmin = -1e300; h->lt_Tmax = 1e300;
+  for (int k = 0; k < nIso; ++k) {
+    double lo = 1e300, hi = -1e300;
+    for (int i = 0; i < nT[k]; ++i) { lo = std::min(lo, tips_T[(size_t)k * nTmax + i]); hi = std::max(hi, tips_T[(size_t)k * nTmax + i]); }
+    h->lt_Tmin = std::max(h->lt_Tmin, lo); h->lt_Tmax = std::min(h->lt_Tmax, hi);
+  }
+  return MOM_OK;
+}
+
+// compute_absorption_profile! for ONE layer (atmo_prof.jl:427-449) with the per-line prefactors formed ON THE DEVICE from the
+// resident table: only (p, T, vmr, wing_cutoff, factor) cross the bus.
+extern "C" int mom_voigt_tau_abs_layer(mom_t *h, int iz_1based, double pressure, double temperature, double vmr,
+                                       double wing_cutoff, double factor) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_voigt_tau_abs_layer");
+  if (!h->d_tau_abs || !h->d_grid) return fail(h, MOM_ESTATE, "mom_voigt_tau_abs_layer: call mom_absorption_begin with the spectral grid first");
+  if (!h->d_lt) return fail(h, MOM_ESTATE, "mom_voigt_tau_abs_layer: call mom_absorption_set_lines first");
+  if (iz_1based < 1 || iz_1based > h->abs_Nz || !(temperature > 0.0)) return fail(h, MOM_EINVAL, "mom_voigt_tau_abs_layer: bad argument");
+  if (h->lt.nIso > 0 && !(h->lt_Tmin < temperature && temperature < h->lt_Tmax)) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "TIPS2017: T (%g) must be between %g K and %g K.", temperature, h->lt_Tmin, h->lt_Tmax);
+    return fail(h, MOM_EINVAL, buf);
+  }
+  const int nLines = h->lt.nLines;
+  if (nLines == 0) return MOM_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t lb = (size_t)nLines;
+  if (lb > h->lines_cap) {
+    if (h->d_lines) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_lines); h->d_lines = nullptr; h->lines_cap = 0; }
+    const size_t cap = std::max<size_t>(lb, 1024) * 2;
+    HIPCHK(h, dmalloc(&h->d_lines, 5 * cap));
+    h->lines_cap = cap;
+  }
+  const size_t cap = h->lines_cap;
+  double *dl = h->d_lines;
+  int *dw = reinterpret_cast<int *>(dl + 4 * cap);
+  int *flag = h->d_lt_i + (size_t)std::max(nLines, 1) + std::max(h->lt.nIso, 1);
+  HIPCHK(h, hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+  // γ_d = (cSqrt2Ln2 / cc_) sqrt(cBolts_ / cMassMol) sqrt(T) ν₀ / sqrt(mol_weight)   (:87-88): the scalar part once
+  const double cgd = (1.1774100225 / 2.99792458e8) * std::sqrt(1.3806503e-23 / 1.66053873e-27) * std::sqrt(temperature);
+  HIPCHK(h, mom_line_prefactors_launch(h->stream, h->lt, h->S, h->d_grid, pressure, temperature, vmr, wing_cutoff, cgd, dl, dl + cap,
+                                       dl + 2 * cap, dl + 3 * cap, dw, dw + cap, flag));
+  int unsorted = 0;
+  HIPCHK(h, hipMemcpyAsync(&unsorted, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, mom_voigt_launch(h->stream, nLines, dl, dl + cap, dl + 2 * cap, dl + 3 * cap, dw, dw + cap, h->S, h->d_grid,
+                             h->d_tau_abs + (size_t)h->S * (iz_1based - 1), factor, 1, unsorted ? 0 : 1));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+// the prefactors of the last mom_voigt_tau_abs / mom_voigt_tau_abs_layer call (test access); n = its number of lines
+extern "C" int mom_absorption_get_prefactors(mom_t *h, int n, double *nu, double *gamma_d, double *y, double *S, int *ind_start_1based,
+                                             int *ind_stop_1based) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->d_lines || n < 0 || (size_t)n > h->lines_cap) return fail(h, MOM_ESTATE, "mom_absorption_get_prefactors: no prefactors resident");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t cap = h->lines_cap;
+  double *dst[4] = {nu, gamma_d, y, S};
+  for (int k = 0; k < 4; ++k)
+    if (dst[k]) HIPCHK(h, hipMemcpy(dst[k], h->d_lines + k * cap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  const int *dw = reinterpret_cast<const int *>(h->d_lines + 4 * cap);
+  if (ind_start_1based) HIPCHK(h, hipMemcpy(ind_start_1based, dw, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  if (ind_stop_1based) HIPCHK(h, hipMemcpy(ind_stop_1based, dw + cap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
   return MOM_OK;
 }
 

@@ -166,6 +166,89 @@ thread_local double v_last_ms = 0.0;
 
 // one launch for all lines on `st` (device pointers); used by mom_voigt_xsec below and by the handle-level
 // mom_voigt_tau_abs (momcore.hip), which accumulates straight into the resident tau_abs table
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-line prefactors of compute_absorption_cross_section (compute_absorption_cross_section.jl:73-107) on the device, from
+// ONE resident HITRAN table per absorber: pressure shift (:79), Lorentz half width (:82-84), Doppler half width (:87-88),
+// y (:91), the temperature correction of the strength with the TIPS-2017 partition-sum ratio qoft! (:95-101, :197-214:
+// cubic spline of the isotopologue's table, evaluated at T_ref and T) and the grid window of the line (:104-107: linear
+// interpolation grid -> index, clamped, rounded half-to-even).  One thread per line; per layer only (p, T, vmr, wing) are
+// kernel arguments.  Same expression order as the host route (absorption.line_prefactors); exp / pow come from the
+// device math library, so the two routes agree to a few ulp, not bitwise.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double spline_eval(const double *t, const double *u, const double *z, int n1, double x) {
+  // DataInterpolations.CubicSpline evaluation (restated in absorption.CubicSpline.__call__): interval by searchsortedlast
+  int lo = 0, hi = n1;  // knots t[0 .. n1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (t[mid] <= x) lo = mid; else hi = mid;
+  }
+  const int i = min(max(lo, 0), n1 - 1);
+  // the tables are Float32 (TIPS_2017.nc); products of two table entries are Float32 operations, as in the reference's
+  // (and the host route's) evaluation -- only the terms that involve the Float64 argument x are Float64
+  const float hf = (float)t[i + 1] - (float)t[i];
+  const float cu = (float)u[i + 1] / hf - (float)z[i + 1] * hf / 6.0f;
+  const float du = (float)u[i] / hf - (float)z[i] * hf / 6.0f;
+  const double h6 = (double)(6.0f * hf);
+  const double a = t[i + 1] - x, b = x - t[i];
+  const double I = z[i] * (a * a * a) / h6 + z[i + 1] * (b * b * b) / h6;
+  const double C = (double)cu * b;
+  const double D = (double)du * a;
+  return I + C + D;
+}
+__device__ __forceinline__ double interp_index(const double *grid, int n, double x) {
+  // numpy.interp(x, grid, 1..n): clamped linear interpolation; grid ascending
+  if (n == 1) return 1.0;
+  if (x <= grid[0]) return 1.0;
+  if (x >= grid[n - 1]) return (double)n;
+  int lo = 0, hi = n - 1;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (grid[mid] <= x) lo = mid; else hi = mid;
+  }
+  const double slope = 1.0 / (grid[lo + 1] - grid[lo]);
+  return slope * (x - grid[lo]) + (double)(lo + 1);
+}
+__global__ void k_line_prefactors(MomLineTable tb, int nGrid, const double *grid, double p, double T, double vmr, double wing,
+                                  double cgd, double *nu, double *gd, double *yy, double *SS, int *i0, int *i1, int *unsorted) {
+#pragma clang fp contract(off)
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= tb.nLines) return;
+  const double p_ref = 1013.25, t_ref = 296.0, c2 = 1.4387769, cLn2 = 0.6931471805599;
+  const double nu0 = tb.nu0[j], E = tb.E[j];
+  const double v = nu0 + p / p_ref * tb.d_air[j];
+  const double gl = (tb.g_air[j] * (1 - vmr) * p / p_ref + tb.g_self[j] * vmr * p / p_ref) * pow(t_ref / T, tb.n_air[j]);
+  const double g = cgd * nu0 / tb.sqw[j];
+  double S = tb.S0[j];
+  if (E != -1.0) {
+    const int is = tb.iso[j];
+    const double *t = tb.tT + (size_t)is * tb.nTmax, *u = tb.tQ + (size_t)is * tb.nTmax, *z = tb.tZ + (size_t)is * tb.nTmax;
+    const int n1 = tb.nT[is] - 1;
+    const double rate = spline_eval(t, u, z, n1, t_ref) / spline_eval(t, u, z, n1, T);
+    const double corr = rate * exp(c2 * E * (1 / t_ref - 1 / T)) * (1 - exp(-c2 * nu0 / T)) / (1 - exp(-c2 * nu0 / t_ref));
+    S = S * corr;
+  }
+  nu[j] = v;
+  gd[j] = g;
+  yy[j] = sqrt(cLn2) * gl / g;
+  SS[j] = S;
+  const int a = (int)rint(interp_index(grid, nGrid, v - wing)), b = (int)rint(interp_index(grid, nGrid, v + wing));
+  i0[j] = a;
+  i1[j] = b;
+  if (j > 0) {  // does the Voigt kernel's bisection apply?  (window starts and stops non-decreasing in the line index)
+    const double vp = tb.nu0[j - 1] + p / p_ref * tb.d_air[j - 1];
+    const int ap = (int)rint(interp_index(grid, nGrid, vp - wing)), bp = (int)rint(interp_index(grid, nGrid, vp + wing));
+    if (a < ap || b < bp) atomicOr(unsorted, 1);
+  }
+}
+hipError_t mom_line_prefactors_launch(hipStream_t st, const MomLineTable &tb, int nGrid, const double *grid, double p, double T,
+                                      double vmr, double wing, double cgd, double *nu, double *gd, double *y, double *S, int *i0,
+                                      int *i1, int *unsorted) {
+  if (tb.nLines <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_line_prefactors, dim3((tb.nLines + 255) / 256), dim3(256), 0, st, tb, nGrid, grid, p, T, vmr, wing, cgd, nu,
+                     gd, y, S, i0, i1, unsorted);
+  return hipGetLastError();
+}
+
 hipError_t mom_voigt_launch(hipStream_t st, int nLines, const double *nu, const double *gamma_d, const double *y,
                             const double *S, const int *i0, const int *i1, int nGrid, const double *grid, double *out,
                             double factor, int accumulate, int sorted) {

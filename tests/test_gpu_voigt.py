@@ -114,3 +114,55 @@ def test_voigt_tau_abs_accumulates_into_resident_table(rtamd):
             h.voigt_tau_abs(5, [1.0], [1.0], [1.0], [1.0], [1], [1], 1.0)   # layer out of range
         assert e.value.code == rtamd._lib.MOM_EINVAL
     assert expect.max() > 1e-3 and np.array_equal(got, expect)
+
+
+@pytest.mark.parametrize("lines", ["o2a", "co2_file", "shuffled"])
+def test_device_side_line_prefactors(rtamd, lines):
+    """SURVEY 8f-1, last clause: the per-line prefactors of compute_absorption_cross_section.jl:73-107 (pressure shift, Lorentz
+    and Doppler widths, y, TIPS-2017 spline ratio qoft!, Boltzmann / stimulated-emission factors, grid windows) formed on the
+    device from ONE resident line table (mom_absorption_set_lines); per layer only (p, T, vmr, vcd) are passed.  Against the
+    host route of the product (absorption.line_prefactors -> mom_voigt_tau_abs): windows identical, prefactors to a few ulp
+    (device vs host exp / pow), tau_abs to 1e-12."""
+    ab = rtamd.absorption
+    if lines == "co2_file":
+        tab = ab.hitran_table(ab.read_hitran(GOLD / "testCO2.data"))
+        grid = np.linspace(float(tab.νᵢ.min()) - 2.0, float(tab.νᵢ.max()) + 2.0, 3000)
+        model_vmr, wing = 4e-4, 5.0
+    else:
+        tab = ab.synthetic_o2a_lines(400, seed=5)
+        grid = np.linspace(12920.0, 13230.0, 4000)      # some lines fall outside the padded grid and are dropped
+        model_vmr, wing = 0.21, 8.0
+        if lines == "shuffled":                           # windows not monotone in the line index: the strided search path
+            rng = np.random.default_rng(3)
+            perm = rng.permutation(tab.νᵢ.size)
+            import dataclasses
+            tab = ab.HitranTable(**{f.name: getattr(tab, f.name)[perm] for f in dataclasses.fields(tab)})
+            tab.E_lower[::7] = -1.0                       # "no temperature correction" rows (:96)
+    p_full = np.array([5.0, 120.0, 480.0, 930.0])
+    T = np.array([215.0, 231.5, 262.25, 288.0])
+    vcd = np.array([1.1e23, 2.4e24, 7.7e24, 1.3e25])
+    S = grid.size
+    m = rtamd.scenes.make_scene(1, 3, 4, S)
+    with rtamd.corert.make_handle(m) as h_dev, rtamd.corert.make_handle(m) as h_host:
+        ab.compute_absorption_profile(h_host, tab, grid, p_full, T, vcd, 0.3, wing_cutoff=wing, model_vmr=model_vmr)
+        ab.compute_absorption_profile(h_dev, tab, grid, p_full, T, vcd, 0.3, wing_cutoff=wing, model_vmr=model_vmr,
+                                      device_prefactors=True)
+        # the prefactors of the last layer, device vs host
+        pf = ab.line_prefactors(tab, grid, p_full[-1], T[-1], vmr=model_vmr, wing_cutoff=wing)
+        nu, gd, y, Sl, i0, i1 = h_dev.absorption_get_prefactors()
+        assert nu.size == pf.ν.size
+        assert np.array_equal(i0, pf.ind_start) and np.array_equal(i1, pf.ind_stop)
+        assert np.array_equal(nu, pf.ν)
+        np.testing.assert_allclose(gd, pf.γ_d, rtol=4e-16)
+        np.testing.assert_allclose(y, pf.y, rtol=2e-15)
+        np.testing.assert_allclose(Sl, pf.S, rtol=2e-14)
+        a, b = h_dev.absorption_get(), h_host.absorption_get()
+    assert b.max() > 0
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-300)
+    # a temperature outside the TIPS tables is refused like qoft! does (:204)
+    with rtamd.corert.make_handle(m) as h:
+        h.absorption_begin(1, grid)
+        ab.resident_line_table(h, tab, grid, wing)
+        with pytest.raises(rtamd._lib.MomError) as e:
+            h.voigt_tau_abs_layer(1, 500.0, 0.5, 0.0, wing, 1.0)
+        assert "TIPS2017" in str(e.value)
