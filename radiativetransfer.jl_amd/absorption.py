@@ -194,12 +194,15 @@ class LinePrefactors:
 
 
 def line_prefactors(h: HitranTable, grid: np.ndarray, pressure: float, temperature: float, vmr: float = 0.0,
-                    wing_cutoff: float = 40.0, qratio: Optional[Callable[[float], float]] = None) -> LinePrefactors:
+                    wing_cutoff: float = 40.0, qratio: Optional[Callable[[float], float]] = None,
+                    mol_weights: Optional[dict] = None) -> LinePrefactors:
     """compute_absorption_cross_section.jl:54-107: selection of lines inside the padded grid,
     pressure shift, Lorentz and Doppler half widths (Float32 square root of the Float32 isotopologue weight, as
     `sqrt(mol_weight(mol, iso))` evaluates), y, the TIPS-2017 temperature correction of the strength (`qoft!`) and the
     index window each line touches (linear interpolation of grid -> index, clamped, rounded half-to-even like
-    Julia's `round`).  `qratio` overrides the partition-sum ratio (a callable of T); default = the reference's qoft."""
+    Julia's `round`).  `qratio` overrides the partition-sum ratio (a callable of T); default = the reference's qoft.
+    `mol_weights` {(mol, iso): g/mol} supplies isotopologue weights for molecules outside the bundled TIPS subset
+    (HITRAN molecules 1-7; the full tables are extracted by tools/extract_tips.py from the reference's NetCDF files)."""
     grid = np.asarray(grid, dtype=np.float64)
     temperature = float(temperature)
     keep = (grid.min() - wing_cutoff < h.νᵢ) & (h.νᵢ < grid.max() + wing_cutoff)
@@ -214,7 +217,16 @@ def line_prefactors(h: HitranTable, grid: np.ndarray, pressure: float, temperatu
     E = h.E_lower[keep]
     for (M, I) in pairs:
         sel = (mol == M) & (iso == I)
-        sqw[sel] = np.float64(np.sqrt(mol_weight(M, I)))  # Float32 sqrt, then promoted
+        if mol_weights is not None and (M, I) in mol_weights:
+            w = np.float32(mol_weights[(M, I)])
+        else:
+            try:
+                w = mol_weight(M, I)
+            except KeyError as e:
+                raise KeyError(f"no isotopologue weight for HITRAN molecule {M}, isotopologue {I}: the bundled TIPS subset covers "
+                               "molecules 1-7; pass mol_weights={(mol, iso): g_per_mol} (and qratio=) or extend "
+                               "data/tips_2017_subset.npz with tools/extract_tips.py") from e
+        sqw[sel] = np.float64(np.sqrt(w))  # Float32 sqrt, then promoted
         if np.any(E[sel] != -1):
             rate[sel] = qratio(temperature) if qratio is not None else qoft(M, I, temperature, t_ref)
         else:

@@ -38,3 +38,40 @@ struct MomLineTable {
 hipError_t mom_line_prefactors_launch(hipStream_t st, const MomLineTable &tb, int nGrid, const double *grid, double p, double T,
                                       double vmr, double wing, double cgd, double *nu, double *gd, double *y, double *S, int *i0,
                                       int *i1, int *unsorted);
+
+// argument blocks of the single-launch sweep kernels, shared by the launching translation unit (momcore.hip) and the
+// kernels' own (mom_small.hip: momsm::k_sweep; mom_wave.hip: momw::k_wsweep)
+struct MomSmallSweepArgs {
+  int S, M, K, Nz, nVza, nS, imu0, pad;
+  double mu0, albedo;
+  double I0[4], D[4];
+  // per-scene tables, the same for every spectral point (read through the scalar cache)
+  const double *mu, *wt, *sg;         // [N]
+  const double *F1, *F2, *SI;         // [N,N] i + N j: mu_j/(mu_i+mu_j), mu_j/(mu_i-mu_j), (1/mu_i)+(1/mu_j)
+  const double *Zpp, *Zmp;            // [N,N,K,M]
+  const int *nd, *iface;              // [Nz]
+  const int *node;                    // [nVza]
+  const double *cos_mphi, *sin_mphi;  // [nVza,M]
+  // per-point inputs
+  const double *tau, *varpi, *zw, *tau_sum;  // [S,Nz], [S,Nz], [K,S,Nz], [S,Nz+1]
+  // outputs
+  double *R, *T, *hdr, *bhr_uw, *bhr_dw;  // [nVza,nS,S] x3, [nS,S] x2
+  int *info;
+};
+struct MomWaveSweepArgs {
+  int N, S, M, K, Nz, nVza, nS, imu0, inv_mode, pad;
+  double mu0, albedo;
+  double I0[4], D[4];
+  const double *mu, *wt, *sg;           // [N]
+  const double *Zpp, *Zmp;              // [N,N,K,M]
+  const int *nd;                        // [Nz]
+  const int *node;                      // [nVza]
+  const double *cos_mphi, *sin_mphi;    // [nVza,M]
+  const double *tau, *varpi, *zw, *tau_sum;  // [S,Nz], [S,Nz], [K,S,Nz], [S,Nz+1]
+  double *R, *T, *hdr, *bhr_uw, *bhr_dw;
+  int *info;
+  // surface (mom_scene_set_surface): 0 LambertianSurfaceScalar(albedo), 1 BRDF matrices Rsurf [N,N,M] (every moment),
+  // 2 LambertianSurfaceLegendre (albedo_spec [S]; j0+ = 0, T_SFI from m = 0 only: lambertian_surface.jl:112,131-132)
+  int surf_kind, pad2;
+  const double *Rsurf, *albedo_spec;
+};

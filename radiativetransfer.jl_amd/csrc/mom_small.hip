@@ -109,23 +109,7 @@ __device__ __forceinline__ int inv_one_minus(Mat<N> &X, const Mat<N> &B) {
   return bad;
 }
 
-struct SweepArgs {
-  int S, M, K, Nz, nVza, nS, imu0, pad;
-  double mu0, albedo;
-  double I0[4], D[4];
-  // per-scene tables, the same for every spectral point (read through the scalar cache)
-  const double *mu, *wt, *sg;         // [N]
-  const double *F1, *F2, *SI;         // [N,N] i + N j: mu_j/(mu_i+mu_j), mu_j/(mu_i-mu_j), (1/mu_i)+(1/mu_j)
-  const double *Zpp, *Zmp;            // [N,N,K,M]
-  const int *nd, *iface;              // [Nz]
-  const int *node;                    // [nVza]
-  const double *cos_mphi, *sin_mphi;  // [nVza,M]
-  // per-point inputs
-  const double *tau, *varpi, *zw, *tau_sum;  // [S,Nz], [S,Nz], [K,S,Nz], [S,Nz+1]
-  // outputs
-  double *R, *T, *hdr, *bhr_uw, *bhr_dw;  // [nVza,nS,S] x3, [nS,S] x2
-  int *info;
-};
+using SweepArgs = ::MomSmallSweepArgs;  // mom_host.hpp: the one definition shared with momcore.hip
 
 template <int N>
 __global__ void __launch_bounds__(256, 1) k_sweep(SweepArgs a) {

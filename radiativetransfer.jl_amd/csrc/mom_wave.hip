@@ -120,23 +120,7 @@ __device__ __forceinline__ int series_terms(double beta2) {
   return p;
 }
 
-struct WArgs {
-  int N, S, M, K, Nz, nVza, nS, imu0, inv_mode, pad;
-  double mu0, albedo;
-  double I0[4], D[4];
-  const double *mu, *wt, *sg;           // [N]
-  const double *Zpp, *Zmp;              // [N,N,K,M]
-  const int *nd;                        // [Nz]
-  const int *node;                      // [nVza]
-  const double *cos_mphi, *sin_mphi;    // [nVza,M]
-  const double *tau, *varpi, *zw, *tau_sum;  // [S,Nz], [S,Nz], [K,S,Nz], [S,Nz+1]
-  double *R, *T, *hdr, *bhr_uw, *bhr_dw;
-  int *info;
-  // surface (mom_scene_set_surface): 0 LambertianSurfaceScalar(albedo), 1 BRDF matrices Rsurf [N,N,M] (every moment),
-  // 2 LambertianSurfaceLegendre (albedo_spec [S]; j0+ = 0, T_SFI from m = 0 only: lambertian_surface.jl:112,131-132)
-  int surf_kind, pad2;
-  const double *Rsurf, *albedo_spec;
-};
+using WArgs = ::MomWaveSweepArgs;  // mom_host.hpp: the one definition shared with momcore.hip
 
 // per-lane coordinates; row / column quantities are read from the block's LDS table tab = mu[32] | wt[32] | sg[32]
 // (padding entries: mu = 1, wt = 0, sg = 1)

@@ -522,6 +522,10 @@ struct mom_handle {
   double *d_rrs_op[8] = {};                   // operator-level inputs: tau_sum, dtau, varpi, fscatt [S]; Z x4 [N,N]
   bool rrs_scene = false;
   double rrs_ms = 0.0;
+  // grow-only device workspace of the operator-level batched entry points (no hipMalloc / hipFree per call, no leak on an
+  // error return): slot k holds ws_cap[k] bytes
+  void *ws[4] = {};
+  size_t ws_cap[4] = {};
   // resident HITRAN table + TIPS splines of one absorber (mom_absorption_set_lines)
   MomLineTable lt{};
   double *d_lt = nullptr;   // one allocation behind lt's double arrays
@@ -556,6 +560,24 @@ static int fail(mom_t *h, int code, const char *msg) {
 template <class T>
 static hipError_t dmalloc(T **p, size_t count) {
   return hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
+}
+
+// slot of the handle's grow-only workspace, at least `count` elements of T
+template <class T>
+static hipError_t ws_get(mom_t *h, int slot, T **p, size_t count) {
+  const size_t bytes = count * sizeof(T);
+  if (bytes > h->ws_cap[slot]) {
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return e;
+    (void)hipFree(h->ws[slot]);
+    h->ws[slot] = nullptr;
+    h->ws_cap[slot] = 0;
+    e = hipMalloc(&h->ws[slot], bytes);
+    if (e != hipSuccess) return e;
+    h->ws_cap[slot] = bytes;
+  }
+  *p = reinterpret_cast<T *>(h->ws[slot]);
+  return hipSuccess;
 }
 
 static size_t smem_bytes(const mom_t *h) { return lds_bytes(h->N, h->lds_mode); }
@@ -677,6 +699,7 @@ extern "C" int mom_destroy(mom_t *h) {
   if (h->f32) momf_destroy(h->f32);
   momr::destroy(h->rrs);
   (void)hipFree(h->d_lt); (void)hipFree(h->d_lt_i);
+  for (int k = 0; k < 4; ++k) (void)hipFree(h->ws[k]);
   (void)hipFree(h->d_fscatt); (void)hipFree(h->d_Zr[0]); (void)hipFree(h->d_Zr[1]);
   for (int k = 0; k < 8; ++k) (void)hipFree(h->d_rrs_op[k]);
   if (h->comm && g_rccl_destroy) g_rccl_destroy(h->comm);
@@ -973,18 +996,18 @@ static int blas_common(mom_t *h, int n, int batch, const double *A, const double
   }
   const size_t cnt = (size_t)n * n * batch;
   double *dA = nullptr, *dB = nullptr, *dC = nullptr, *scr = nullptr;
-  HIPCHK(h, dmalloc(&dA, cnt));
-  HIPCHK(h, dmalloc(&dC, cnt));
+  HIPCHK(h, ws_get(h, 0, &dA, cnt));
+  HIPCHK(h, ws_get(h, 1, &dC, cnt));
   HIPCHK(h, hipMemcpyAsync(dA, A, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (!inv) {
-    HIPCHK(h, dmalloc(&dB, cnt));
+    HIPCHK(h, ws_get(h, 2, &dB, cnt));
     HIPCHK(h, hipMemcpyAsync(dB, B, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
   }
   const bool lds = n <= 64 && !h->opt_force_generic;
   const int grid = lds ? batch : std::min(batch, 1024);
   if (!lds) {
     const size_t scn = (size_t)grid * kGenericBufs * mat_elems(n) + (size_t)ld_for(n) * np_for(n);
-    HIPCHK(h, dmalloc(&scr, scn));
+    HIPCHK(h, ws_get(h, 3, &scr, scn));
     HIPCHK(h, hipMemsetAsync(scr, 0, scn * sizeof(double), h->stream));
   }
   BlasArgs a{n, batch, dA, dB, dC, scr, h->d_info};
@@ -999,9 +1022,6 @@ static int blas_common(mom_t *h, int n, int batch, const double *A, const double
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(C, dC, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  (void)hipFree(dA); (void)hipFree(dC);
-  if (dB) (void)hipFree(dB);
-  if (scr) (void)hipFree(scr);
   return inv ? check_info(h) : MOM_OK;
 }
 
@@ -1028,8 +1048,8 @@ extern "C" int mom_elemental_inelastic_rrs(mom_t *h, int m, int ndoubl, int nRam
   const size_t S = h->S, NN = (size_t)N * N, big = NN * S * nRaman, vec = (size_t)N * S * nRaman;
   double *buf = nullptr;
   int *dI = nullptr;
-  HIPCHK(h, dmalloc(&buf, 4 * big + 2 * vec + nRaman + 4 * S + 2 * NN));
-  HIPCHK(h, dmalloc(&dI, (size_t)nRaman));
+  HIPCHK(h, ws_get(h, 0, &buf, 4 * big + 2 * vec + nRaman + 4 * S + 2 * NN));
+  HIPCHK(h, ws_get(h, 1, &dI, (size_t)nRaman));
   double *d_out = buf, *d_vp = buf + 4 * big + 2 * vec, *d_fs = d_vp + nRaman, *d_ts = d_fs + S, *d_dt = d_ts + S,
          *d_w = d_dt + S, *d_zp = d_w + S, *d_zm = d_zp + NN;
   HIPCHK(h, hipMemcpyAsync(dI, i_l1l0, nRaman * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -1052,8 +1072,6 @@ extern "C" int mom_elemental_inelastic_rrs(mom_t *h, int m, int ndoubl, int nRam
   HIPCHK(h, hipMemcpyAsync(dst[4], a.ieJ0p, vec * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(dst[5], a.ieJ0m, vec * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  (void)hipFree(buf);
-  (void)hipFree(dI);
   return MOM_OK;
 }
 
@@ -1067,7 +1085,7 @@ static int dual_common(mom_t *h, int n, int batch, int P, const double *A, const
   const size_t cnt = (size_t)n * n * batch, cntP = cnt * P;
   double *buf = nullptr, *scr = nullptr;
   // one allocation: A, B, C [cnt] and dA, dB, dC [cntP]
-  HIPCHK(h, dmalloc(&buf, 3 * cnt + 3 * cntP + 1));
+  HIPCHK(h, ws_get(h, 0, &buf, 3 * cnt + 3 * cntP + 1));
   double *dA_ = buf + 3 * cnt, *dB_ = dA_ + cntP, *dC_ = dB_ + cntP;
   HIPCHK(h, hipMemcpyAsync(buf, A, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (P) HIPCHK(h, hipMemcpyAsync(dA_, dA, cntP * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -1079,7 +1097,7 @@ static int dual_common(mom_t *h, int n, int batch, int P, const double *A, const
   const int grid = lds ? batch : std::min(batch, 1024);
   if (!lds) {
     const size_t scn = (size_t)grid * kGenericBufs * mat_elems(n) + (size_t)ld_for(n) * np_for(n);
-    HIPCHK(h, dmalloc(&scr, scn));
+    HIPCHK(h, ws_get(h, 3, &scr, scn));
     HIPCHK(h, hipMemsetAsync(scr, 0, scn * sizeof(double), h->stream));
   }
   DualArgs a{n, batch, P, buf, dA_, buf + cnt, dB_, buf + 2 * cnt, dC_, scr, h->d_info};
@@ -1095,8 +1113,7 @@ static int dual_common(mom_t *h, int n, int batch, int P, const double *A, const
   HIPCHK(h, hipMemcpyAsync(C, buf + 2 * cnt, cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (P) HIPCHK(h, hipMemcpyAsync(dC, dC_, cntP * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  (void)hipFree(buf);
-  if (scr) (void)hipFree(scr);
+
   return inv ? check_info(h) : MOM_OK;
 }
 
@@ -1301,18 +1318,7 @@ extern "C" int mom_scene_set_surface(mom_t *h, int kind, int M, const double *Rs
   return MOM_OK;
 }
 
-// The argument block of momsm::k_sweep (mom_small.hip), layout-identical plain data
-struct SmallSweepArgs {
-  int S, M, K, Nz, nVza, nS, imu0, pad;
-  double mu0, albedo;
-  double I0[4], D[4];
-  const double *mu, *wt, *sg, *F1, *F2, *SI, *Zpp, *Zmp;
-  const int *nd, *iface, *node;
-  const double *cos_mphi, *sin_mphi;
-  const double *tau, *varpi, *zw, *tau_sum;
-  double *R, *T, *hdr, *bhr_uw, *bhr_dw;
-  int *info;
-};
+using SmallSweepArgs = MomSmallSweepArgs;  // mom_host.hpp
 
 // N <= 4: one spectral point per lane, all moments / layers / surface / post-processing in ONE launch
 static int rt_run_small(mom_t *h) {
@@ -1364,20 +1370,7 @@ static int rt_run_small(mom_t *h) {
   return MOM_OK;
 }
 
-// The argument block of momw::k_wsweep (mom_wave.hip), layout-identical plain data
-struct WaveSweepArgs {
-  int N, S, M, K, Nz, nVza, nS, imu0, inv_mode, pad;
-  double mu0, albedo;
-  double I0[4], D[4];
-  const double *mu, *wt, *sg, *Zpp, *Zmp;
-  const int *nd, *node;
-  const double *cos_mphi, *sin_mphi;
-  const double *tau, *varpi, *zw, *tau_sum;
-  double *R, *T, *hdr, *bhr_uw, *bhr_dw;
-  int *info;
-  int surf_kind, pad2;
-  const double *Rsurf, *albedo_spec;
-};
+using WaveSweepArgs = MomWaveSweepArgs;  // mom_host.hpp
 
 // the wave-per-point kernel covers ScatteringInterface_11 on every layer after the first and at the surface
 static bool wave_sweep_applies(const mom_t *h) {
