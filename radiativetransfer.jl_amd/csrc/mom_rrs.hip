@@ -26,6 +26,7 @@
 #include "mom_rrs.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "mom_tile.hpp"
@@ -35,6 +36,8 @@ using namespace momt;
 
 struct KArgs {
   int N, nS, S, nR, strict_idx, strict_rrs, n_glob0, n1_lo, n1_hi, last, nd, sh, m, imu0, nTerms;
+  int derive_pm;  // corrected position: ier+- / iet-- are sgn (.) ier-+ / iet++ and are derived where they are read
+  int fuse_el;    // first doubling step of a layer: the inelastic elemental layer is formed in registers, not loaded
   double mu0, albedo, weight;
   double I0[4], D[4];
   const double *mu, *wt;
@@ -59,6 +62,9 @@ __device__ __forceinline__ double dsgn(int ci, int cj) { return (((ci <= 2) && (
 
 constexpr int kWavesPerBlock = 4;
 // waves per SIMD the pair kernels are compiled for (register budget 512 / MOMR_WPE); measured in profiles/r03_C5_*.txt
+#ifndef MOMR_FAST_DEFAULT
+#define MOMR_FAST_DEFAULT 3
+#endif
 #ifndef MOMR_WPE
 #define MOMR_WPE 2
 #endif
@@ -366,10 +372,98 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_dbl_point(KArgs a) {
   if (bad && g.lr == 0 && g.lq == 0) atomicMax(a.info, bad);
 }
 
+// The inelastic elemental layer of ONE pair in registers (the formulas of k_ie_elemental in tile form; ndoubl >= 1): ier-+
+// and iet++ as _t tiles, ieJ0+- in column layout.  exp(-d1/mu_i) and exp(-d0/mu_j) are evaluated once per stream (2 exp per
+// lane + 1 for the attenuation) and combined, i.e. 1 - e1 e0 stands for the reference's 1 - exp(-(d1/mu_i + d0/mu_j)):
+// the same absolute accuracy (both are 1 minus a number rounded near 1).
+template <int NT>
+__device__ __forceinline__ void ie_elem_tile(const Geo &g, const KArgs &a, int n1, int dn, int n0, Mat<NT> &a_t, Mat<NT> &b_t,
+                                             CV<NT> &Jp, CV<NT> &Jm) {
+#pragma clang fp contract(off)
+  const int N = a.N, n = a.nS;
+  const double scl = (double)(1ull << a.sh);
+  const double wdiv = (a.m == 0) ? 2.0 : 4.0, wct02 = (a.m == 0) ? 0.5 : 0.25;
+  const double d1 = a.tau[n1] / scl, d0 = a.tau[n0] / scl, ratio = d1 / d0;
+  const double pre = a.varpiR[dn] * a.varpi[n0] * a.fscatt[n0];
+  const double fs0 = a.fscatt[n0], vR = a.varpiR[dn], v0 = a.varpi[n0];
+  CV<NT> e1C, e0C, muC;
+#pragma unroll
+  for (int tb = 0; tb < NT; ++tb) {
+    const int i = g.col(tb);
+    const double mu = (i < N) ? a.mu[i] : 1.0;
+    muC.c[tb] = mu;
+    e1C.c[tb] = exp(-d1 / mu);
+    e0C.c[tb] = exp(-d0 / mu);
+  }
+  const Vec<NT> e0R = c2r<NT>(g, e0C), muR = c2r<NT>(g, muC);
+  const int i_start = n * (a.imu0 - 1), i_end = n * a.imu0;
+  const int base = (g.lq << 4);
+  double e0s = 0.0, mus = 1.0;
+#pragma unroll
+  for (int tb = 0; tb < NT; ++tb)
+    if ((i_start >> 4) == tb) {
+      e0s = __shfl(e0C.c[tb], base | (i_start & 15));
+      mus = __shfl(muC.c[tb], base | (i_start & 15));
+    }
+#pragma unroll
+  for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < NT; ++tb)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int i = g.col(tb), j = g.row(ta, rr);
+        double r = 0.0, t = 0.0;
+        if (i < N && j < N) {
+          const double mui = muC.c[tb], muj = muR.t[ta][rr], wj = a.wt[j] / wdiv;
+          if (wj > 1.e-8) {
+            const double e1 = e1C.c[tb], e0 = e0R.t[ta][rr];
+            r = fs0 * vR * v0 * a.Zr_mp[i + (size_t)N * j] * (1 / ((mui / muj) + ratio)) * (1 - e1 * e0) * wj;
+            if (mui == muj) {
+              if (i == j) {
+                const double wi = a.wt[i] / wdiv, e0i = e0C.c[tb];
+                if (fabs(d0 - d1) > 1.e-6) t = pre * a.Zr_pp[i + (size_t)N * i] * wi * (e0i - e1) / (1 - ratio);
+                else t = pre * a.Zr_pp[i + (size_t)N * i] * wi * (1 - e0i);
+              }
+            } else {
+              t = pre * a.Zr_pp[i + (size_t)N * j] * (1 / ((mui / muj) - ratio)) * wj * (e1 - e0);
+            }
+          }
+          if (scomp(i, n, a.strict_idx) > 2) r = -r;  // apply_D_elemental_RRS!, ndoubl >= 1
+        }
+        a_t.t[ta][tb][rr] = r;
+        b_t.t[ta][tb][rr] = t;
+      }
+  const double att = exp(-a.tau_sum[n0] / mus);
+#pragma unroll
+  for (int tb = 0; tb < NT; ++tb) {
+    const int i = g.col(tb);
+    double jp = 0.0, jm = 0.0;
+    if (i < N) {
+      double zpI = 0.0, zmI = 0.0;
+      for (int ii = i_start; ii < i_end; ++ii) {
+        zpI += a.Zr_pp[i + (size_t)N * ii] * a.I0[ii - i_start];
+        zmI += a.Zr_mp[i + (size_t)N * ii] * a.I0[ii - i_start];
+      }
+      const double mui = muC.c[tb], e1 = e1C.c[tb];
+      if (i >= i_start && i < i_end) {
+        if (fabs(d0 - d1) > 1.e-6) jp = (e0C.c[tb] - e1) / (ratio - 1) * pre * zpI * wct02;
+        else jp = wct02 * pre * zpI * (1 - e0s);
+      } else {
+        jp = wct02 * pre * zpI * (1 / ((mui / mus) - ratio)) * (e1 - e0s);
+      }
+      jm = wct02 * pre * zmI * (1 / ((mui / mus) + ratio)) * (1 - e1 * e0s);
+      jp *= att;
+      jm = a.D[i % n] * (jm * att);
+    }
+    Jp.c[tb] = jp;
+    Jm.c[tb] = jm;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // doubling step, PAIR kernel (doubling_inelastic.jl:61-89 and :98-125)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool FUSE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair(KArgs a) {
   const Geo g = make_geo<NT>(a.N, rrs_smem);
   const int N = a.N, n = a.nS, wave = threadIdx.x >> 6;
@@ -381,24 +475,46 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair
     const int n0 = n1 + a.off[dn];
     const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = (size_t)N * u;
     if (n0 < 0 || n0 >= a.S) {  // get_n0_n1 (inelastic_helper.jl:13-21): no update off the grid ...
-      if (fuseD) {              // ... but the corrected D kernels visit every (n, dn)
-        Mat<NT> an_t = load_t<NT>(g, a.ie_a[R_MP] + o4), bn_t = load_t<NT>(g, a.ie_a[T_PP] + o4);
+      if (FUSE) {               // ... but the deferred elemental writes zeros there and multiplies ieJ0- by D (:378-380)
+        store_t<NT>(g, a.ie_a[R_MP] + o4, zeros<NT>());
+        store_t<NT>(g, a.ie_a[T_PP] + o4, zeros<NT>());
+        CV<NT> Jm = loadC<NT>(g, a.ie_a[J0M] + o3);
+#pragma unroll
+        for (int tb = 0; tb < NT; ++tb) Jm.c[tb] = a.D[g.col(tb) % n] * Jm.c[tb];
+        storeC<NT>(g, a.ie_a[J0M] + o3, Jm);
+      }
+      if (fuseD) {              // ... and the corrected D kernels visit every (n, dn)
+        Mat<NT> an_t = FUSE ? zeros<NT>() : load_t<NT>(g, a.ie_a[R_MP] + o4);
+        Mat<NT> bn_t = FUSE ? zeros<NT>() : load_t<NT>(g, a.ie_a[T_PP] + o4);
         if (n > 1) {
           map_t<NT>(g, an_t, [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
           store_t<NT>(g, a.ie_a[R_MP] + o4, an_t);
-          Vec<NT> Jm = loadv2<NT>(g, nullptr, a.ie_a[J0M] + o3);
-          vmap<NT>(g, Jm, [&](int i, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
-          storev<NT>(g, a.ie_a[J0M] + o3, Jm, 1);
+          CV<NT> Jm = loadC<NT>(g, a.ie_a[J0M] + o3);
+#pragma unroll
+          for (int tb = 0; tb < NT; ++tb)
+            if (scomp(g.col(tb), n, a.strict_idx) > 2) Jm.c[tb] = -Jm.c[tb];
+          storeC<NT>(g, a.ie_a[J0M] + o3, Jm);
           map_t<NT>(g, an_t, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
           map_t<NT>(g, bn_t, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
         }
-        store_t<NT>(g, a.ie_a[R_PM] + o4, an_t);
-        store_t<NT>(g, a.ie_a[T_MM] + o4, bn_t);
+        if (!a.derive_pm) {
+          store_t<NT>(g, a.ie_a[R_PM] + o4, an_t);
+          store_t<NT>(g, a.ie_a[T_MM] + o4, bn_t);
+        }
       }
       continue;
     }
     const size_t m1 = NN * n1, m0 = NN * n0, v0 = (size_t)N * n0;
-    const Mat<NT> a_t = load_t<NT>(g, a.ie_a[R_MP] + o4), b_t = load_t<NT>(g, a.ie_a[T_PP] + o4);
+    Mat<NT> a_t, b_t;
+    CV<NT> Jp, Jm;  // ieJ0+, ieJ0-
+    if (FUSE) {
+      ie_elem_tile<NT>(g, a, n1, dn, n0, a_t, b_t, Jp, Jm);
+    } else {
+      a_t = load_t<NT>(g, a.ie_a[R_MP] + o4);
+      b_t = load_t<NT>(g, a.ie_a[T_PP] + o4);
+      Jp = loadC<NT>(g, a.ie_a[J0P] + o3);
+      Jm = loadC<NT>(g, a.ie_a[J0M] + o3);
+    }
     const Mat<NT> r1_t = load_t<NT>(g, a.a_cur[R_MP] + m1), ttgp1_t = load_t<NT>(g, a.sm[SM_TTGP] + m1);
     const Mat<NT> r0_c = load_t<NT>(g, a.sm[SM_RT] + m0), gt0_c = load_t<NT>(g, a.sm[SM_GT] + m0);
     const Mat<NT> a_c = transpose<NT>(g, a_t);
@@ -407,7 +523,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair
     // ---- sources (matrix-vector products on the vector ALU: mom_tile.hpp)                                    :61-89
     {
       const double e1 = a.expk_cur[n1];
-      const CV<NT> Jp = loadC<NT>(g, a.ie_a[J0P] + o3), Jm = loadC<NT>(g, a.ie_a[J0M] + o3);     // ieJ0+, ieJ0-
       const CV<NT> J1p = cscale<NT>(Jp, e1), J1m = cscale<NT>(Jm, e1);                           // ieJ1+, ieJ1-   :52-56
       const double *jp0 = a.strict_rrs ? a.jpseq + v0 + (size_t)N * a.S * dn : a.a_cur[J0P] + v0;
       const CV<NT> a_j1m = mv_t<NT>(g, a_t, loadR<NT>(g, a.sv[SV_J1M] + v0));                    // ier j1-[n0]
@@ -417,10 +532,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair
       const CV<NT> b1 = mv_t<NT>(g, b_t, tm1);                                                   // iet++ tmp1
       const CV<NT> b2 = a.strict_rrs ? mv_t<NT>(g, load_t<NT>(g, a.ie_a[T_MM] + o4), tm2)        // D5: iet-- as the array holds it
                                      : mv_t<NT>(g, b_t, tm2);
-      Vec<NT> J1mR = loadR<NT>(g, a.ie_a[J0M] + o3);
-#pragma unroll
-      for (int ta = 0; ta < NT; ++ta) J1mR.t[ta] = J1mR.t[ta] * e1;
-      const CV<NT> uu = cadd<NT>(cadd<NT>(Jp, mv_t<NT>(g, r1_t, J1mR)), cadd<NT>(a_j1m, X1));
+      const CV<NT> uu = cadd<NT>(cadd<NT>(Jp, mv_t<NT>(g, r1_t, c2r<NT>(g, J1m))), cadd<NT>(a_j1m, X1));
       const CV<NT> Jpn = cadd<NT>(cadd<NT>(J1p, mv_t<NT>(g, ttgp1_t, c2r<NT>(g, uu))), b1);      // new ieJ0+
       const CV<NT> rv2 = mv_t<NT>(g, r1_t, c2r<NT>(g, Jpn));                                     // r1 ieJ0+(new)
       const CV<NT> u2 = cadd<NT>(cadd<NT>(J1m, rv2), cadd<NT>(a_jp, X2));
@@ -451,8 +563,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair
         map_t<NT>(g, apm, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
         map_t<NT>(g, bmm, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
       }
-      store_t<NT>(g, a.ie_a[R_PM] + o4, apm);
-      store_t<NT>(g, a.ie_a[T_MM] + o4, bmm);
+      if (!a.derive_pm) {
+        store_t<NT>(g, a.ie_a[R_PM] + o4, apm);
+        store_t<NT>(g, a.ie_a[T_MM] + o4, bmm);
+      }
     }
     store_t<NT>(g, a.ie_a[R_MP] + o4, an_t);
     store_t<NT>(g, a.ie_a[T_PP] + o4, bn_t);
@@ -490,6 +604,16 @@ __global__ void k_strict_D(KArgs a) {
       if (k1 < 1 || k1 > a.nR) continue;
       a.ie_a[J0M][i + (size_t)N * ((size_t)nl + (size_t)a.S * (k1 - 1))] = -a.ie_a[J0M][i + (size_t)N * ((size_t)nl + (size_t)a.S * dn)];
     }
+}
+// ier+- = sgn (.) ier-+, iet-- = sgn (.) iet++ for the whole arrays (the derived form written out: downloads, strict reads)
+__global__ void k_materialise_pm(KArgs a) {
+  const size_t NN = (size_t)a.N * a.N, cnt = NN * a.S * a.nR;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e % a.N), j = (int)((e / a.N) % a.N);
+    const double s = a.nS > 1 ? dsgn(scomp(i, a.nS, a.strict_idx), scomp(j, a.nS, a.strict_idx)) : 1.0;
+    a.ie_a[R_PM][e] = s * a.ie_a[R_MP][e];
+    a.ie_a[T_MM][e] = s * a.ie_a[T_PP][e];
+  }
 }
 // n_stokes == 1: ier+- = ier-+, iet-- = iet++ for the whole arrays (doubling_inelastic.jl:411-414)
 __global__ void k_copy2(const double *s0, double *d0, const double *s1, double *d1, size_t count) {
@@ -605,7 +729,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_int_point(KArgs a, int 
 // ---------------------------------------------------------------------------------------------------------------------
 // interaction, PAIR kernel.  SURF: the added layer is the surface (all its ie* arrays are zeros and never read).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT, bool SURF>
+template <int NT, bool SURF, bool DERIVE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair(KArgs a, int iface) {
   const Geo g = make_geo<NT>(a.N, rrs_smem);
   const int N = a.N, wave = threadIdx.x >> 6;
@@ -617,7 +741,16 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair
     if (n0 < 0 || n0 >= a.S) continue;
     const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = (size_t)N * u;
     const size_t m1 = NN * n1, m0 = NN * n0, v0 = (size_t)N * n0;
-    auto ldA = [&](int which) { return SURF ? zeros<NT>() : load_t<NT>(g, a.ie_a[which] + o4); };
+    auto ldA = [&](int which) {
+      if (SURF) return zeros<NT>();
+      if (DERIVE && (which == T_MM || which == R_PM)) {  // ier+- = sgn (.) ier-+, iet-- = sgn (.) iet++ (corrected D2)
+        Mat<NT> X = load_t<NT>(g, a.ie_a[which == T_MM ? T_PP : R_MP] + o4);
+        if (a.nS > 1)
+          map_t<NT>(g, X, [&](int i, int j, double v) { return dsgn(scomp(i, a.nS, a.strict_idx), scomp(j, a.nS, a.strict_idx)) * v; });
+        return X;
+      }
+      return load_t<NT>(g, a.ie_a[which] + o4);
+    };
     const CV<NT> Jap = SURF ? czeros<NT>() : loadC<NT>(g, a.ie_a[J0P] + o3), Jam = SURF ? czeros<NT>() : loadC<NT>(g, a.ie_a[J0M] + o3);
     const CV<NT> Jcp = loadC<NT>(g, a.ie_c[C_J0P] + o3), Jcm = loadC<NT>(g, a.ie_c[C_J0M] + o3);   // ieJ0+- added / composite
     if (iface == 3) {
@@ -831,6 +964,12 @@ void destroy(State *s) {
   delete s;
 }
 
+// scene-level fast-mode features (A/B switch for profiling: MOM_RRS_FAST = bit 0 deferred elemental, bit 1 derived ier+- / iet--)
+static int fast_bits() {
+  static const int bits = [] { const char *e = getenv("MOM_RRS_FAST"); return e ? atoi(e) : MOMR_FAST_DEFAULT; }();
+  return bits;
+}
+
 void timing_reset(State *s, bool on) {
   s->timing = on;
   s->ev_kind.clear();
@@ -881,44 +1020,82 @@ hipError_t elemental(State *s, const Streams &q, int m, int nd, int shift, const
   a.m = m; a.nd = nd; a.sh = shift; a.tau_sum = tau_sum; a.tau = tau; a.varpi = varpi; a.Zpp = Zpp; a.Zmp = Zmp; a.nTerms = nTerms; a.zw = zw;
   a.fscatt = fscatt; a.Zr_pp = Zr_pp; a.Zr_mp = Zr_mp;
   if (elastic) LAUNCH_NT(s, k_el_point, grid_points(s), a);
+  s->el_pending = false;
   if (inelastic) {
+    if (s->fast && nd >= 1 && (fast_bits() & 1)) {  // deferred into the first doubling step (k_dbl_pair, fuse_el)
+      s->el_pending = true;
+      s->el.m = m; s->el.nd = nd; s->el.sh = shift; s->el.tau_sum = tau_sum; s->el.tau = tau; s->el.varpi = varpi;
+      s->el.fscatt = fscatt; s->el.Zr_pp = Zr_pp; s->el.Zr_mp = Zr_mp;
+      return hipSuccess;
+    }
     const size_t tot = (size_t)s->N * s->N * (size_t)(s->n1_hi - s->n1_lo) * s->nR;
     RCHK(tick(s, TK_IE_ELEMENTAL, true));
     hipLaunchKernelGGL(k_ie_elemental, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, a);
     RCHK(hipGetLastError());
     RCHK(tick(s, TK_IE_ELEMENTAL, false));
+    if (nd < 1) { s->pm_valid = true; s->pm_derivable = true; }  // apply_D_elemental_RRS! wrote both pairs consistently
   }
+  return hipSuccess;
+}
+
+hipError_t ensure_pm(State *s, const Streams &q) {
+  if (s->pm_valid || !s->pm_derivable) return hipSuccess;
+  KArgs a = base_args(s, q);
+  hipLaunchKernelGGL(k_materialise_pm, dim3(2048), dim3(256), 0, s->stream, a);
+  RCHK(hipGetLastError());
+  s->pm_valid = true;
   return hipSuccess;
 }
 
 hipError_t doubling(State *s, const Streams &q, int nd) {
   if (nd == 0) return hipSuccess;  // doubling_inelastic.jl:29
+  const bool derive = s->fast && !s->strict_rrs && (fast_bits() & 2);
   for (int k = 0; k < nd; ++k) {
     KArgs a = base_args(s, q);
     a.last = (k == nd - 1);
+    a.derive_pm = derive ? 1 : 0;
+    if (k == 0 && s->el_pending) {
+      a.fuse_el = 1;
+      a.m = s->el.m; a.nd = s->el.nd; a.sh = s->el.sh; a.tau_sum = s->el.tau_sum; a.tau = s->el.tau; a.varpi = s->el.varpi;
+      a.fscatt = s->el.fscatt; a.Zr_pp = s->el.Zr_pp; a.Zr_mp = s->el.Zr_mp;
+      s->el_pending = false;
+    }
     LAUNCH_NT(s, k_dbl_point, grid_points(s), a);
     RCHK(tick(s, TK_DBL_PAIR, true));
-    LAUNCH_NT(s, k_dbl_pair, grid_pairs(s), a);
+    {
+      const dim3 gr(grid_pairs(s)), bl(64 * kWavesPerBlock);
+      if (s->N <= 16) {
+        if (a.fuse_el) hipLaunchKernelGGL((k_dbl_pair<1, true>), gr, bl, lds<1>(), s->stream, a);
+        else hipLaunchKernelGGL((k_dbl_pair<1, false>), gr, bl, lds<1>(), s->stream, a);
+      } else {
+        if (a.fuse_el) hipLaunchKernelGGL((k_dbl_pair<2, true>), gr, bl, lds<2>(), s->stream, a);
+        else hipLaunchKernelGGL((k_dbl_pair<2, false>), gr, bl, lds<2>(), s->stream, a);
+      }
+      RCHK(hipGetLastError());
+    }
     RCHK(tick(s, TK_DBL_PAIR, false));
     s->cur = 1 - s->cur;
   }
   KArgs a = base_args(s, q);
-  if (s->nS == 1) {  // doubling_inelastic.jl:411-414: whole-array copies
-    const size_t cnt = (size_t)s->N * s->N * s->S * s->nR;
-    if (s->strict_rrs) {
+  if (s->strict_rrs) {
+    if (s->nS == 1) {  // doubling_inelastic.jl:411-414: whole-array copies
+      const size_t cnt = (size_t)s->N * s->N * s->S * s->nR;
       hipLaunchKernelGGL(k_copy2, dim3(2048), dim3(256), 0, s->stream, s->ie_added[R_MP], s->ie_added[R_PM], s->ie_added[T_PP],
                          s->ie_added[T_MM], cnt);
-      RCHK(hipGetLastError());
+    } else {
+      const int tot = s->N * (s->n1_hi - s->n1_lo);
+      hipLaunchKernelGGL(k_strict_D, dim3((tot + 127) / 128), dim3(128), 0, s->stream, a);
     }
-  } else if (s->strict_rrs) {
-    const int tot = s->N * (s->n1_hi - s->n1_lo);
-    hipLaunchKernelGGL(k_strict_D, dim3((tot + 127) / 128), dim3(128), 0, s->stream, a);
     RCHK(hipGetLastError());
+    s->pm_valid = true; s->pm_derivable = false;
+  } else {
+    s->pm_valid = !derive; s->pm_derivable = true;
   }
   return hipSuccess;
 }
 
-hipError_t copy_added_to_composite(State *s) {
+hipError_t copy_added_to_composite(State *s, const Streams &q) {
+  RCHK(ensure_pm(s, q));
   const size_t NN = (size_t)s->N * s->N, m3 = NN * s->S * 8, v3 = (size_t)s->N * s->S * 8, m4 = m3 * s->nR, v4 = v3 * s->nR;
   static const int amap[6] = {R_MP, R_PM, T_PP, T_MM, J0P, J0M};  // composite field k <- added field amap[k]
   for (int k = 0; k < 6; ++k) {
@@ -936,6 +1113,8 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
     return hipErrorInvalidValue;
   }
   KArgs a = base_args(s, q);
+  a.derive_pm = (!with_surface && !s->strict_rrs && s->fast && s->pm_derivable && (fast_bits() & 2)) ? 1 : 0;
+  if (!with_surface && !a.derive_pm) RCHK(ensure_pm(s, q));
   for (int k = 0; k < 6; ++k) a.x[k] = with_surface ? s->surf[k] : s->added[s->cur][k];
   if (!with_surface) { a.x[R_PM] = s->added[0][R_PM]; a.x[T_MM] = s->added[0][T_MM]; }
   LAUNCH_NT(s, k_int_point, grid_points(s), a, iface);
@@ -943,16 +1122,18 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
     const size_t v4 = (size_t)s->N * s->S * s->nR * 8;
     RCHK(hipMemsetAsync(s->ie_comp[C_J0P], 0, v4, s->stream));
     RCHK(hipMemsetAsync(s->ie_comp[C_J0M], 0, v4, s->stream));
-  } else if (with_surface) {
-    RCHK(tick(s, TK_INT_PAIR, true));
-    if (s->N <= 16) hipLaunchKernelGGL((k_int_pair<1, true>), dim3(grid_pairs(s)), dim3(64 * kWavesPerBlock), lds<1>(), s->stream, a, iface);
-    else hipLaunchKernelGGL((k_int_pair<2, true>), dim3(grid_pairs(s)), dim3(64 * kWavesPerBlock), lds<2>(), s->stream, a, iface);
-    RCHK(hipGetLastError());
-    RCHK(tick(s, TK_INT_PAIR, false));
   } else {
     RCHK(tick(s, TK_INT_PAIR, true));
-    if (s->N <= 16) hipLaunchKernelGGL((k_int_pair<1, false>), dim3(grid_pairs(s)), dim3(64 * kWavesPerBlock), lds<1>(), s->stream, a, iface);
-    else hipLaunchKernelGGL((k_int_pair<2, false>), dim3(grid_pairs(s)), dim3(64 * kWavesPerBlock), lds<2>(), s->stream, a, iface);
+    const dim3 gr(grid_pairs(s)), bl(64 * kWavesPerBlock);
+    if (s->N <= 16) {
+      if (with_surface) hipLaunchKernelGGL((k_int_pair<1, true, false>), gr, bl, lds<1>(), s->stream, a, iface);
+      else if (a.derive_pm) hipLaunchKernelGGL((k_int_pair<1, false, true>), gr, bl, lds<1>(), s->stream, a, iface);
+      else hipLaunchKernelGGL((k_int_pair<1, false, false>), gr, bl, lds<1>(), s->stream, a, iface);
+    } else {
+      if (with_surface) hipLaunchKernelGGL((k_int_pair<2, true, false>), gr, bl, lds<2>(), s->stream, a, iface);
+      else if (a.derive_pm) hipLaunchKernelGGL((k_int_pair<2, false, true>), gr, bl, lds<2>(), s->stream, a, iface);
+      else hipLaunchKernelGGL((k_int_pair<2, false, false>), gr, bl, lds<2>(), s->stream, a, iface);
+    }
     RCHK(hipGetLastError());
     RCHK(tick(s, TK_INT_PAIR, false));
   }

@@ -49,6 +49,11 @@ struct State {
   double *d_out = nullptr;      // ieR_SFI || ieT_SFI [2][nVza,nS,S] and R_SFI || T_SFI [2][nVza,nS,S]
   int out_nVza = 0;
   int *d_info = nullptr;
+  // fast scene-level mode (mom_rt_run_rrs): the inelastic elemental of a layer with ndoubl >= 1 is deferred into the first
+  // doubling step (el_pending + its inputs), and in the corrected position ier+- / iet-- are not stored by the doubling but
+  // derived where they are read (pm_derivable); pm_valid says whether the arrays themselves hold the current values
+  bool fast = false, el_pending = false, pm_valid = true, pm_derivable = false;
+  struct { int m, nd, sh; const double *tau_sum, *tau, *varpi, *fscatt, *Zr_pp, *Zr_mp; } el{};
   // HIP-event pairs around the launches of the heavy kernels of the last run (timing_reset .. timing_read)
   std::vector<hipEvent_t> ev_pool;
   std::vector<int> ev_kind;  // kind of the launch bracketed by ev_pool[2k], ev_pool[2k+1]
@@ -73,7 +78,11 @@ hipError_t elemental(State *s, const Streams &q, int m, int nd, int shift, const
 // doubling_helper!(::RRS): nd steps on the persistent added layer (expk in s->expk[s->cur]); applies the D kernels at the end
 hipError_t doubling(State *s, const Streams &q, int nd);
 // rt_kernel.jl:326-333
-hipError_t copy_added_to_composite(State *s);
+hipError_t copy_added_to_composite(State *s, const Streams &q);
+// writes ier+- / iet-- out if they are only derivable at the moment (before downloads, copies and operator-level reads)
+hipError_t ensure_pm(State *s, const Streams &q);
+// an upload replaced layer arrays: whatever is resident is what the arrays hold
+inline void mark_uploaded(State *s) { s->pm_valid = true; s->pm_derivable = false; s->el_pending = false; }
 // interaction_helper!(::RRS, iface): returns hipErrorInvalidValue with s->err set where the reference raises (strict position)
 hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface);
 // create_surface_layer!(::LambertianSurfaceScalar) into s->surf (ie* of the surface layer are zeros: never allocated)

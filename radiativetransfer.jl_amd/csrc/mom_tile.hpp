@@ -256,6 +256,21 @@ __device__ __forceinline__ CV<NT> cscale(const CV<NT> &A, double s) {
   for (int b = 0; b < NT; ++b) C.c[b] = A.c[b] * s;
   return C;
 }
+// lane l <- lane l ^ 16 / l ^ 32 of a double on the vector ALU (gfx950 v_permlane16_swap / v_permlane32_swap: swapping a
+// register with itself exchanges odd and even rows of 16 lanes / the two halves of the wave) -- an order of magnitude
+// less latency than the LDS crossbar (ds_bpermute) behind __shfl_xor, which matters in the dependent reduction chains
+__device__ __forceinline__ double lane_xor16(double v, bool odd_row) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(odd_row ? b[0] : b[1], odd_row ? a[0] : a[1]);
+}
+__device__ __forceinline__ double lane_xor32(double v, bool upper_half) {
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(upper_half ? b[0] : b[1], upper_half ? a[0] : a[1]);
+}
 // y = M x, M given as M_t
 template <int NT>
 __device__ __forceinline__ CV<NT> mv_t(const Geo &g, const Mat<NT> &M_t, const Vec<NT> &xR) {
@@ -267,8 +282,8 @@ __device__ __forceinline__ CV<NT> mv_t(const Geo &g, const Mat<NT> &M_t, const V
     for (int a = 0; a < NT; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc = fma(M_t.t[a][b][r], xR.t[a][r], acc);
-    acc += __shfl_xor(acc, 16);
-    acc += __shfl_xor(acc, 32);
+    acc += lane_xor16(acc, (g.lq & 1) != 0);
+    acc += lane_xor32(acc, (g.lq & 2) != 0);
     y.c[b] = acc;
   }
   return y;

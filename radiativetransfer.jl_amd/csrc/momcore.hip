@@ -2339,6 +2339,7 @@ static int rrs_ready(mom_t *h, const char *who) {
   if (!h->rrs) { static thread_local char b[128]; snprintf(b, sizeof b, "%s: call mom_rrs_set first", who); return fail(h, MOM_ESTATE, b); }
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_set_streams must be called first");
   HIPCHK(h, hipSetDevice(h->device));
+  h->rrs->fast = false;  // only mom_rt_run_rrs switches the deferred / derived mode on, for its own duration
   return MOM_OK;
 }
 
@@ -2400,6 +2401,10 @@ extern "C" int mom_rrs_upload(mom_t *h, int which, const double *src) {
   size_t count = 0;
   double *p = rrs_which(h, which, &count);
   if (!p || !src) return fail(h, MOM_EINVAL, "mom_rrs_upload: bad argument");
+  if (which >= 18 && which < 24) {
+    RRSCHK(h, momr::ensure_pm(h->rrs, rrs_streams(h)));
+    momr::mark_uploaded(h->rrs);
+  }
   HIPCHK(h, hipMemcpyAsync(p, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
@@ -2410,6 +2415,7 @@ extern "C" int mom_rrs_download(mom_t *h, int which, double *dst) {
   size_t count = 0;
   double *p = rrs_which(h, which, &count);
   if (!p || !dst) return fail(h, MOM_EINVAL, "mom_rrs_download: bad argument");
+  if (which >= 18 && which < 24) RRSCHK(h, momr::ensure_pm(h->rrs, rrs_streams(h)));
   HIPCHK(h, hipMemcpyAsync(dst, p, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
@@ -2457,7 +2463,7 @@ extern "C" int mom_rrs_interaction(mom_t *h, int iface, int with_surface_layer) 
 extern "C" int mom_rrs_copy_added_to_composite(mom_t *h) {
   int rc = rrs_ready(h, "mom_rrs_copy_added_to_composite");
   if (rc) return rc;
-  RRSCHK(h, momr::copy_added_to_composite(h->rrs));
+  RRSCHK(h, momr::copy_added_to_composite(h->rrs, rrs_streams(h)));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
 }
@@ -2496,6 +2502,7 @@ extern "C" int mom_rt_run_rrs(mom_t *h) {
   const size_t S = h->S, NN = (size_t)h->N * h->N;
   const int Nz = h->Nz, K = h->K, M = h->scene_M;
   momr::timing_reset(s, true);
+  s->fast = true;   // deferred inelastic elemental, derived ier+- / iet-- (corrected position)
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   RRSCHK(h, momr::begin_run(s, h->nVza));
   for (int m = 0; m < M; ++m) {
@@ -2505,7 +2512,7 @@ extern "C" int mom_rt_run_rrs(mom_t *h) {
                                 h->d_Zpp + NN * K * m, h->d_Zmp + NN * K * m, K, h->d_zw + (size_t)K * S * iz,
                                 h->d_fscatt + S * iz, h->d_Zr[0] + NN * m, h->d_Zr[1] + NN * m, true, true));
       RRSCHK(h, momr::doubling(s, q, nd));
-      if (iz == 0) RRSCHK(h, momr::copy_added_to_composite(s));                    // rt_kernel.jl:326-333
+      if (iz == 0) RRSCHK(h, momr::copy_added_to_composite(s, q));                    // rt_kernel.jl:326-333
       else RRSCHK(h, momr::interaction(s, q, h->iface[iz], false));
     }
     RRSCHK(h, momr::surface_lambertian(s, q, m, h->albedo, h->d_tau_sum + S * Nz));   // rt_run.jl:168-175
@@ -2514,6 +2521,7 @@ extern "C" int mom_rt_run_rrs(mom_t *h) {
   }
   HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
   s->timing = false;
+  s->fast = false;
   return MOM_OK;
 }
 
