@@ -153,9 +153,12 @@ int mom_elemental_inelastic_rrs(mom_t *h, int m, int ndoubl, int nRaman, const i
  *   mom_scene_set_rrs  scene-level inputs on top of mom_scene_set: fscattRayl [nSpec, Nz] (fScattRayleigh of
  *                      constructCoreOpticalProperties, compEffectiveLayerProperties.jl:58, expanded per band), Z*_l1l0 [N,N,M]
  *                      (computeRamanZlambda!, src/Inelastic/inelastic_helper.jl:457-464, per Fourier moment).
- *   mom_rt_run_rrs     rt_run.jl:125-215 with RS_type::RRS for the resident scene (LambertianSurfaceScalar); asynchronous.
+ *   mom_rt_run_rrs     rt_run.jl:125-215 with RS_type::RRS for the resident scene (every surface kind of
+ *                      mom_scene_set_surface); asynchronous.
  *   mom_get_RT_rrs     R_SFI, T_SFI, ieR_SFI, ieT_SFI [nVza, nStokes, nSpec] (postprocessing_vza!(::RRS),
  *                      tools/postprocessing_vza.jl:95-147); any pointer may be NULL; gpu_ms (optional) = GPU time of the run.
+ *   mom_get_hdr_rrs    the elastic RAMI extras of the same return tuple (rt_run.jl:187-213, 226): hdr [nVza, nStokes, nSpec],
+ *                      bhr_uw, bhr_dw [nStokes, nSpec] (interaction_hdrf! + postprocessing_vza_hdrf!).
  *   mom_rrs_timers     HIP-event times of the last mom_rt_run_rrs, summed per kernel: ms[0] / launches[0] the doubling pair
  *                      kernel, [1] the interaction pair kernel, [2] the inelastic elemental kernel, [3] the whole run (n >= 4). */
 enum {
@@ -177,6 +180,7 @@ int mom_rrs_download(mom_t *h, int which, double *dst);
 int mom_scene_set_rrs(mom_t *h, const double *fscattRayl, const double *Zpp_l1l0, const double *Zmp_l1l0);
 int mom_rt_run_rrs(mom_t *h);
 int mom_get_RT_rrs(mom_t *h, double *R_SFI, double *T_SFI, double *ieR_SFI, double *ieT_SFI, double *gpu_ms);
+int mom_get_hdr_rrs(mom_t *h, double *hdr, double *bhr_uw, double *bhr_dw);
 int mom_rrs_timers(mom_t *h, double *ms, int *launches, int n);
 
 /* batch_inv!(X, A) -- gpu_batched.jl:36-87;  X, A: n*n*batch doubles (host). */

@@ -425,15 +425,18 @@ def rt_kernel_rrs(pol, quad, rrs: RRSInputs, Zr_pp, Zr_mp, fscatt, added: AddedL
     return nd
 
 
-def rt_run_rrs(scene: mr.Scene, rrs: RRSInputs, hook=None):
+def rt_run_rrs(scene: mr.Scene, rrs: RRSInputs, hook=None, full: bool = False):
     """rt_run(RS_type::RRS, model, iBand) rt_run.jl:41-230, SFI = true.  Returns (R_SFI, T_SFI, ieR_SFI, ieT_SFI), each
-    [nVza, nStokes, S].  The added / composite / surface layers are allocated once and persist over layers and Fourier
-    moments like the reference's (rt_run.jl:108-116)."""
+    [nVza, nStokes, S]; full=True appends the elastic RAMI extras of the same return tuple (rt_run.jl:187-213, 226): hdr
+    [nVza, nStokes, S], bhr_uw, bhr_dw [nStokes, S] (interaction_hdrf! + postprocessing_vza_hdrf!).  The added / composite /
+    surface layers are allocated once and persist over layers and Fourier moments like the reference's (rt_run.jl:108-116)."""
     pol, quad = scene.pol, scene.quad
     S, Nz, N = scene.S, scene.Nz, scene.N
     nR = rrs.nRaman
     nV = len(scene.vza)
     out = [np.zeros((nV, pol.n, S)) for _ in range(4)]
+    hdr = np.zeros((nV, pol.n, S))
+    bhr_uw, bhr_dw = np.zeros((pol.n, S)), np.zeros((pol.n, S))
     added = make_added_layer_rs(N, S, nR)
     surf = make_added_layer_rs(N, S, nR)
     comp = make_composite_layer_rs(N, S, nR)
@@ -452,5 +455,8 @@ def rt_run_rrs(scene: mr.Scene, rrs: RRSInputs, hook=None):
         interaction_inelastic(rrs, ifaces[-1], comp, surf)
         if hook:
             hook("surface", m, Nz + 1, surf, comp)
+        hdr_J0m = mr.interaction_hdrf(surf, comp, m, pol, quad, bhr_uw, bhr_dw)
         postprocessing_vza_rrs(pol, comp, scene.vza, quad.qp_mu, m, scene.vaz, weight, *out)
-    return tuple(out)
+        dummy = mr.CompositeLayer(None, None, None, None, np.zeros_like(hdr_J0m), hdr_J0m)
+        mr.postprocessing_vza(pol, dummy, scene.vza, quad.qp_mu, m, scene.vaz, weight, hdr, np.zeros_like(hdr))
+    return tuple(out) + ((hdr, bhr_uw, bhr_dw) if full else ())

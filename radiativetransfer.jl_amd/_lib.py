@@ -68,6 +68,7 @@ SIGNATURES = {
     "mom_scene_set_rrs": (C.c_int, [c_h, c_dp, c_dp, c_dp]),
     "mom_rt_run_rrs": (C.c_int, [c_h]),
     "mom_get_RT_rrs": (C.c_int, [c_h, c_dp, c_dp, c_dp, c_dp, c_dp]),
+    "mom_get_hdr_rrs": (C.c_int, [c_h, c_dp, c_dp, c_dp]),
     "mom_rrs_timers": (C.c_int, [c_h, c_dp, c_ip, C.c_int]),
     "mom_batch_inv": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp]),
     "mom_batched_mul": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp, c_dp]),
@@ -291,6 +292,14 @@ class Handle:
         self.check(self.lib.mom_get_RT_rrs(self._h, *[dp(x) for x in out], dp(ms)))
         sh = (self.S, self.nS, self.nVza)
         return tuple(np.transpose(x.reshape(sh), (2, 1, 0)).copy() for x in out) + (float(ms[0]),)
+
+    def get_hdr_rrs(self):
+        """hdr [nVza, nStokes, S], bhr_uw, bhr_dw [nStokes, S] of the last rt_run_rrs."""
+        n = self.nVza * self.nS * self.S
+        H, up, dw = np.empty(n), np.empty(self.nS * self.S), np.empty(self.nS * self.S)
+        self.check(self.lib.mom_get_hdr_rrs(self._h, dp(H), dp(up), dp(dw)))
+        return (np.transpose(H.reshape(self.S, self.nS, self.nVza), (2, 1, 0)).copy(), up.reshape(self.S, self.nS).T.copy(),
+                dw.reshape(self.S, self.nS).T.copy())
 
     def rrs_timers(self):
         """{kernel: (ms, launches)} of the last rt_run_rrs (HIP events on the library's stream)."""

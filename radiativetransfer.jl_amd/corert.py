@@ -866,13 +866,11 @@ def _with_cabannes(RS_type: RRS, model: vSmartMOM_Model) -> vSmartMOM_Model:
 
 
 def rt_run_rrs(RS_type: RRS, model: vSmartMOM_Model, i_band: int = 1):
-    """rt_run(RS_type::RRS, model, iBand) (rt_run.jl:41-230), SFI = true.  Returns (R_SFI, T_SFI, ieR_SFI, ieT_SFI), each
-    [nVza, nStokes, nSpec] (the first four entries of the reference's return tuple; hdr / bhr are elastic-only extras the
-    RRS entry does not produce)."""
+    """rt_run(RS_type::RRS, model, iBand) (rt_run.jl:41-230), SFI = true.  Returns the reference's 7-tuple (rt_run.jl:226):
+        (R_SFI, T_SFI, ieR_SFI, ieT_SFI, hdr, bhr_uw[1,:], bhr_dw[1,:])
+    R/T/ieR/ieT/hdr are [nVza, nStokes, nSpec]; every surface type of `params.brdf`."""
     model = _with_cabannes(RS_type, model)
     sc = prepare_scene(model)
-    if sc.surf_kind != 0:
-        raise NotImplementedError("rt_run(::RRS): LambertianSurfaceScalar only")
     Zr_pp, Zr_mp = raman_z(RS_type, model)
     with make_handle(model) as h:
         h.set_option(_lib.MOM_OPT_STRIP_PAD, 0)
@@ -880,4 +878,6 @@ def rt_run_rrs(RS_type: RRS, model: vSmartMOM_Model, i_band: int = 1):
         scene_set(h, sc)
         h.scene_set_rrs(np.ascontiguousarray(fscatt_rayleigh(model).T), _abi_mats(Zr_pp), _abi_mats(Zr_mp))
         h.rt_run_rrs()
-        return h.get_RT_rrs()[:4]
+        R, T, ieR, ieT = h.get_RT_rrs()[:4]
+        hdr, up, dw = h.get_hdr_rrs()
+    return R, T, ieR, ieT, hdr, up[0], dw[0]

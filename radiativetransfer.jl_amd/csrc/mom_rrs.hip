@@ -828,30 +828,61 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair
   }
 }
 
-// create_surface_layer!(::LambertianSurfaceScalar) (Surfaces/lambertian_surface.jl:20-75) into the surface layer arrays
-__global__ void k_surface_fill(KArgs a, const double *tau_tot) {
+// create_surface_layer! into the surface layer arrays: kind 0 LambertianSurfaceScalar (Surfaces/lambertian_surface.jl:20-75),
+// 1 any BRDF type through its Fourier matrix Rsurf [N,N] of this moment (rpv_surface.jl:20-66), 2 LambertianSurfaceLegendre
+// (lambertian_surface.jl:77-138: spectrally varying albedo, j0+ = 0, t = 0 for m > 0)
+__global__ void k_surface_fill(KArgs a, const double *tau_tot, int kind, const double *Rsurf, const double *albedo_spec) {
   const int N = a.N, n = a.nS;
   const size_t NN = (size_t)N * N;
   const size_t pt = blockIdx.x;
-  const double rho = 2 * a.albedo;
   const double att = exp(-tau_tot[pt] / a.mu0);
   const int i_start = n * (a.imu0 - 1), i_end = n * a.imu0;
   double *const *x = a.x;
+  if (kind == 1) {
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+      const int j = e / N, i = e - j * N;
+      x[R_MP][NN * pt + e] = Rsurf[i + (size_t)N * j] * (a.mu[j] * a.wt[j]);
+      x[R_PM][NN * pt + e] = 0.0;
+      x[T_PP][NN * pt + e] = (i == j) ? 1.0 : 0.0;
+      x[T_MM][NN * pt + e] = (i == j) ? 1.0 : 0.0;
+    }
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      const bool in_sun = (i >= i_start) && (i < i_end);
+      double rI = 0.0;
+      for (int k = 0; k < n; ++k) rI += Rsurf[i + (size_t)N * (i_start + k)] * a.I0[k];
+      x[J0P][(size_t)N * pt + i] = (in_sun ? a.I0[i - i_start] : 0.0) * att;
+      x[J0M][(size_t)N * pt + i] = (a.mu0 * rI) * att;
+    }
+    return;
+  }
+  const double rho = 2 * ((kind == 2) ? albedo_spec[pt] : a.albedo);
+  const double tdiag = (kind == 2 && a.m > 0) ? 0.0 : 1.0;
   for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
     const int j = e / N, i = e - j * N;
     x[R_MP][NN * pt + e] = (a.m == 0 && (i % n == 0) && (j % n == 0)) ? rho * (a.mu[j] * a.wt[j]) : 0.0;
-    if (a.m == 0) x[R_PM][NN * pt + e] = 0.0;
-    x[T_PP][NN * pt + e] = (i == j) ? 1.0 : 0.0;
-    x[T_MM][NN * pt + e] = (i == j) ? 1.0 : 0.0;
+    if (a.m == 0) x[R_PM][NN * pt + e] = 0.0;  // not reset for m > 0 (:68-73)
+    x[T_PP][NN * pt + e] = (i == j) ? tdiag : 0.0;
+    x[T_MM][NN * pt + e] = (i == j) ? tdiag : 0.0;
   }
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     const bool in_sun = (i >= i_start) && (i < i_end);
-    x[J0P][(size_t)N * pt + i] = (a.m == 0) ? (in_sun ? a.I0[i - i_start] : 0.0) * att : 0.0;
-    x[J0M][(size_t)N * pt + i] = (a.m == 0 && (i % n == 0)) ? (a.mu0 * (rho * a.I0[0])) * att : 0.0;
+    double jp = 0.0, jm = 0.0;
+    if (a.m == 0) {
+      if (kind == 2) jm = (i % n == 0) ? (a.mu0 * a.I0[0]) * (rho * att) : 0.0;
+      else {
+        jp = (in_sun ? a.I0[i - i_start] : 0.0) * att;
+        jm = (i % n == 0) ? (a.mu0 * (rho * a.I0[0])) * att : 0.0;
+      }
+    }
+    x[J0P][(size_t)N * pt + i] = jp;
+    x[J0M][(size_t)N * pt + i] = jm;
   }
 }
 
-// postprocessing_vza!(::RRS) (tools/postprocessing_vza.jl:95-147, SFI): out = [R | T | ieR | ieT][nVza, nS, S]
+// postprocessing_vza!(::RRS) (tools/postprocessing_vza.jl:95-147, SFI) and the elastic RAMI extras of rt_run.jl:187-213:
+// interaction_hdrf! (CoreKernel/interaction_hdrf.jl:9-45: hdr_J0- = r-+_surf J0+ + j0-_surf with the composite J0+ after the
+// surface interaction) + postprocessing_vza_hdrf! (postprocessing_vza.jl:63-93).
+// out = [R | T | ieR | ieT | hdr][nVza, nS, S] then bhr_uw, bhr_dw [nS, S]
 __global__ void k_post(KArgs a, int nVza, const int *node, const double *cosm, const double *sinm, int M, double *out) {
   const int N = a.N, n = a.nS;
   const size_t tot = (size_t)nVza * n * a.S;
@@ -861,8 +892,9 @@ __global__ void k_post(KArgs a, int nVza, const int *node, const double *cosm, c
   if (pt < a.n1_lo || pt >= a.n1_hi) return;
   const int row = n * (node[v] - 1) + s;
   const double cs = a.weight * ((s < 2) ? cosm[v + nVza * a.m] : sinm[v + nVza * a.m]);
+  const double *J0p = a.c_cur[C_J0P] + (size_t)N * pt;
   out[e] += cs * a.c_cur[C_J0M][row + (size_t)N * pt];
-  out[tot + e] += cs * a.c_cur[C_J0P][row + (size_t)N * pt];
+  out[tot + e] += cs * J0p[row];
   double sm = 0.0, sp = 0.0;
   for (int t = 0; t < a.nR; ++t) {
     const size_t o = row + (size_t)N * ((size_t)pt + (size_t)a.S * t);
@@ -871,6 +903,22 @@ __global__ void k_post(KArgs a, int nVza, const int *node, const double *cosm, c
   }
   out[2 * tot + e] += sm;
   out[3 * tot + e] += sp;
+  const double *rs = a.x[R_MP] + (size_t)N * N * pt;   // the surface layer
+  double hj = a.x[J0M][row + (size_t)N * pt];
+  for (int j = 0; j < N; ++j) hj += rs[row + (size_t)N * j] * J0p[j];
+  out[4 * tot + e] += cs * hj;
+  if (a.m == 0 && v == 0) {  // bhr_uw / bhr_dw of Stokes component s (interaction_hdrf.jl:28-43)
+    double up = 0.0, dw = 0.0;
+    for (int jj = s; jj < N; jj += n) {
+      double h2 = a.x[J0M][jj + (size_t)N * pt];
+      for (int j = 0; j < N; ++j) h2 += rs[jj + (size_t)N * j] * J0p[j];
+      up += h2 * a.wt[jj] * a.mu[jj];
+      dw += J0p[jj] * a.wt[jj] * a.mu[jj];
+    }
+    const int i0 = n * (a.imu0 - 1);
+    out[5 * tot + s + (size_t)n * pt] = up;
+    out[5 * tot + (size_t)n * a.S + s + (size_t)n * pt] = dw + a.x[J0P][i0 + (size_t)N * pt] * a.mu[i0];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1141,16 +1189,17 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
   return hipSuccess;
 }
 
-hipError_t surface_lambertian(State *s, const Streams &q, int m, double albedo, const double *tau_tot) {
+hipError_t surface(State *s, const Streams &q, int m, int kind, double albedo, const double *tau_tot, const double *Rsurf_m,
+                   const double *albedo_spec) {
   KArgs a = base_args(s, q);
   a.m = m; a.albedo = albedo;
   for (int k = 0; k < 6; ++k) a.x[k] = s->surf[k];
-  hipLaunchKernelGGL(k_surface_fill, dim3(s->S), dim3(256), 0, s->stream, a, tau_tot);
+  hipLaunchKernelGGL(k_surface_fill, dim3(s->S), dim3(256), 0, s->stream, a, tau_tot, kind, Rsurf_m, albedo_spec);
   return hipGetLastError();
 }
 
 hipError_t begin_run(State *s, int nVza) {
-  const size_t cnt = (size_t)4 * nVza * s->nS * s->S;
+  const size_t cnt = (size_t)5 * nVza * s->nS * s->S + (size_t)2 * s->nS * s->S;
   if (s->out_nVza != nVza) {
     (void)hipFree(s->d_out);
     s->d_out = nullptr;
@@ -1164,6 +1213,7 @@ hipError_t postprocess(State *s, const Streams &q, int m, int nVza, const int *d
                        int M, double weight) {
   KArgs a = base_args(s, q);
   a.m = m; a.weight = weight;
+  for (int k = 0; k < 6; ++k) a.x[k] = s->surf[k];
   const size_t tot = (size_t)nVza * s->nS * s->S;
   hipLaunchKernelGGL(k_post, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, a, nVza, d_node, d_cos, d_sin, M, s->d_out);
   return hipGetLastError();

@@ -46,7 +46,7 @@ struct State {
   // inelastic layers
   double *ie_added[6] = {};     // ier+-, ier-+, iet--, iet++ [N,N,S,nR]; ieJ0+, ieJ0- [N,S,nR]   (R_PM.. order)
   double *ie_comp[6] = {};      // ieR-+, ieR+-, ieT++, ieT-- ; ieJ0+, ieJ0-                     (C_R_MP.. order)
-  double *d_out = nullptr;      // ieR_SFI || ieT_SFI [2][nVza,nS,S] and R_SFI || T_SFI [2][nVza,nS,S]
+  double *d_out = nullptr;      // R_SFI | T_SFI | ieR_SFI | ieT_SFI | hdr [5][nVza,nS,S], then bhr_uw | bhr_dw [2][nS,S]
   int out_nVza = 0;
   int *d_info = nullptr;
   // fast scene-level mode (mom_rt_run_rrs): the inelastic elemental of a layer with ndoubl >= 1 is deferred into the first
@@ -85,8 +85,10 @@ hipError_t ensure_pm(State *s, const Streams &q);
 inline void mark_uploaded(State *s) { s->pm_valid = true; s->pm_derivable = false; s->el_pending = false; }
 // interaction_helper!(::RRS, iface): returns hipErrorInvalidValue with s->err set where the reference raises (strict position)
 hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface);
-// create_surface_layer!(::LambertianSurfaceScalar) into s->surf (ie* of the surface layer are zeros: never allocated)
-hipError_t surface_lambertian(State *s, const Streams &q, int m, double albedo, const double *tau_tot);
+// create_surface_layer! into s->surf (ie* of the surface layer are zeros: never allocated).  kind 0 LambertianSurfaceScalar
+// (albedo), 1 BRDF Fourier matrix Rsurf_m [N,N] of moment m (device), 2 LambertianSurfaceLegendre (albedo_spec [S], device)
+hipError_t surface(State *s, const Streams &q, int m, int kind, double albedo, const double *tau_tot, const double *Rsurf_m,
+                   const double *albedo_spec);
 // postprocessing_vza!(::RRS): accumulates into s->d_out (zeroed by begin_run)
 hipError_t begin_run(State *s, int nVza);
 hipError_t postprocess(State *s, const Streams &q, int m, int nVza, const int *d_node, const double *d_cos, const double *d_sin,

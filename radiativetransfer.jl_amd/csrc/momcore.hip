@@ -2473,7 +2473,7 @@ extern "C" int mom_rrs_surface_lambertian(mom_t *h, int m, double albedo, const 
   if (rc) return rc;
   if (!tau_tot) return fail(h, MOM_EINVAL, "mom_rrs_surface_lambertian: bad argument");
   HIPCHK(h, hipMemcpyAsync(h->d_vec[0], tau_tot, (size_t)h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  RRSCHK(h, momr::surface_lambertian(h->rrs, rrs_streams(h), m, albedo, h->d_vec[0]));
+  RRSCHK(h, momr::surface(h->rrs, rrs_streams(h), m, 0, albedo, h->d_vec[0], nullptr, nullptr));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
 }
@@ -2484,7 +2484,6 @@ extern "C" int mom_scene_set_rrs(mom_t *h, const double *fscattRayl, const doubl
   if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_scene_set_rrs: call mom_scene_set / mom_scene_set_optics first");
   if (!fscattRayl || !Zpp_l1l0 || !Zmp_l1l0) return fail(h, MOM_EINVAL, "mom_scene_set_rrs: bad argument");
   if (h->Nk != h->N) return fail(h, MOM_ESTATE, "mom_scene_set_rrs: the scene was set with a padded operator edge (MOM_OPT_STRIP_PAD)");
-  if (h->surf_kind != 0) return fail(h, MOM_EUNSUPPORTED, "mom_scene_set_rrs: the RRS path supports LambertianSurfaceScalar only");
   const size_t NN = (size_t)h->N * h->N;
   if ((rc = upload_new(h, &h->d_fscatt, fscattRayl, (size_t)h->S * h->Nz))) return rc;
   if ((rc = upload_new(h, &h->d_Zr[0], Zpp_l1l0, NN * h->scene_M))) return rc;
@@ -2515,13 +2514,27 @@ extern "C" int mom_rt_run_rrs(mom_t *h) {
       if (iz == 0) RRSCHK(h, momr::copy_added_to_composite(s, q));                    // rt_kernel.jl:326-333
       else RRSCHK(h, momr::interaction(s, q, h->iface[iz], false));
     }
-    RRSCHK(h, momr::surface_lambertian(s, q, m, h->albedo, h->d_tau_sum + S * Nz));   // rt_run.jl:168-175
+    RRSCHK(h, momr::surface(s, q, m, h->surf_kind, h->albedo, h->d_tau_sum + S * Nz,            // rt_run.jl:168-175
+                            h->surf_kind == 1 ? h->d_Rsurf + NN * m : nullptr, h->d_albedo_spec));
     RRSCHK(h, momr::interaction(s, q, h->iface[Nz - 1], true));                    // rt_run.jl:179-185 (Q6)
     RRSCHK(h, momr::postprocess(s, q, m, h->nVza, h->d_node, h->d_cos, h->d_sin, M, m == 0 ? 0.5 : 1.0));
   }
   HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
   s->timing = false;
   s->fast = false;
+  return MOM_OK;
+}
+
+extern "C" int mom_get_hdr_rrs(mom_t *h, double *hdr, double *bhr_uw, double *bhr_dw) {
+  int rc = rrs_ready(h, "mom_get_hdr_rrs");
+  if (rc) return rc;
+  momr::State *s = h->rrs;
+  if (!s->d_out || !hdr || !bhr_uw || !bhr_dw) return fail(h, MOM_ESTATE, "mom_get_hdr_rrs: no run / null output");
+  const size_t tot = (size_t)s->out_nVza * h->nS * h->S, fl = (size_t)h->nS * h->S;
+  HIPCHK(h, hipMemcpyAsync(hdr, s->d_out + 4 * tot, tot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(bhr_uw, s->d_out + 5 * tot, fl * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(bhr_dw, s->d_out + 5 * tot + fl, fl * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
 }
 

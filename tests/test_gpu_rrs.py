@@ -203,12 +203,21 @@ def test_rt_run_rrs_parity(rtamd, nS, lt, S, Nz, nv, strict):
     m = rtamd.scenes.make_scene(nS, lt, Nz, S, seed=nS + lt + S, aerosol_total=0.1, **VIEWS[nv])
     offs = [-4, -1, 2, 7, 3]
     RS, ora = _rrs_inputs(rtamd, offs, strict)
-    R, T, ieR, ieT = rtamd.corert.rt_run_rrs(RS, m)
+    R, T, ieR, ieT, hdr, up, dw = rtamd.corert.rt_run_rrs(RS, m)
     scene = helpers.oracle_scene(m)
     scene.varpi_cabannes = RS.ϖ_Cabannes
-    Rr, Tr, ieRr, ieTr = rr.rt_run_rrs(scene, ora)
+    Rr, Tr, ieRr, ieTr, hdrr, upr, dwr = rr.rt_run_rrs(scene, ora, full=True)
+    _check_rrs_outputs((R, T, ieR, ieT, hdr, up, dw), (Rr, Tr, ieRr, ieTr, hdrr, upr[0], dwr[0]))
+
+
+def _check_rrs_outputs(got, ref):
+    R, T, ieR, ieT, hdr, up, dw = got
+    Rr, Tr, ieRr, ieTr, hdrr, upr, dwr = ref
     helpers.assert_stokes_close(R, Rr, what="R")
     helpers.assert_stokes_close(T, Tr, what="T")
+    helpers.assert_stokes_close(hdr, hdrr, what="hdr")
+    np.testing.assert_allclose(up, upr, rtol=1e-10, atol=helpers.ATOL_STOKES)
+    np.testing.assert_allclose(dw, dwr, rtol=1e-10, atol=helpers.ATOL_STOKES)
     assert np.abs(ieRr).max() > 0
     # the inelastic spectra are judged like the elastic ones: relative to the elastic intensity of the same view and point
     scale = np.abs(Rr[:, 0:1, :])
@@ -218,3 +227,20 @@ def test_rt_run_rrs_parity(rtamd, nS, lt, S, Nz, nv, strict):
     # ... and tightly against their own size
     helpers.assert_op_close(ieR, ieRr, 1e-9, "ieR_SFI")
     helpers.assert_op_close(ieT, ieTr, 1e-9, "ieT_SFI")
+
+
+@pytest.mark.parametrize("surf", ["rpv", "rossli", "legendre"])
+@pytest.mark.parametrize("nS", [1, 3])
+def test_rt_run_rrs_surfaces(rtamd, surf, nS):
+    """The RRS run over the other surface types of create_surface_layer! (rpv_surface.jl:20-66, lambertian_surface.jl:77-138):
+    the surface layer is elastic (its ie* arrays stay zero), so only its r-+, t, j0+- change; incl. hdr / bhr."""
+    rt = rtamd.corert
+    m = rtamd.scenes.make_scene(nS, 5, 3, 14, seed=40 + nS, aerosol_total=0.1, **VIEWS[1])
+    m.params.brdf = {"rpv": rt.rpvSurfaceScalar(0.12, 0.7, -0.15, 0.9), "rossli": rt.RossLiSurfaceScalar(0.05, 0.02, 0.1),
+                     "legendre": rt.LambertianSurfaceLegendre([0.2, 0.05, -0.02])}[surf]
+    RS, ora = _rrs_inputs(rtamd, [-3, 2, 6], strict=False)
+    got = rt.rt_run_rrs(RS, m)
+    scene = helpers.oracle_scene(m)
+    scene.varpi_cabannes = RS.ϖ_Cabannes
+    ref = rr.rt_run_rrs(scene, ora, full=True)
+    _check_rrs_outputs(got, ref[:5] + (ref[5][0], ref[6][0]))

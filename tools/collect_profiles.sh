@@ -3,24 +3,27 @@
 # (FETCH_SIZE and WRITE_SIZE in separate passes, MFMA-busy in a third: MI355X_MICROARCH.md, rocprofv3 PMC slots; never
 # combined with a trace domain other than --kernel-trace).  Output goes to gpurun_out/<round>_*;
 # tools/summarize_profiles.py turns it into profiles/.
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 run() {  # tag, bench args...
   local tag=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${ROUND}_${tag}_stats -o p -- python3 $R/bench.py "$@" --no-cpu-baseline --no-voigt > $O/${ROUND}_${tag}_bench_under_rocprof.json 2> /dev/null
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${ROUND}_${tag}_fetch -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-voigt > /dev/null 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${ROUND}_${tag}_write -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-voigt > /dev/null 2>&1
-  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${ROUND}_${tag}_mfma -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-voigt > /dev/null 2>&1 || true
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${ROUND}_${tag}_stats -o p -- python3 $R/bench.py "$@" --no-cpu-baseline --no-voigt --no-extras > $O/${ROUND}_${tag}_bench_under_rocprof.json 2> /dev/null
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${ROUND}_${tag}_fetch -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${ROUND}_${tag}_write -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${ROUND}_${tag}_mfma -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1 || true
 }
 run C2 --workload C2
 run C4 --workload C4 --points 512 --steps 2
 run C1 --workload C1
+run C5 --workload C5
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${ROUND}_voigt_stats -o p -- python3 $R/bench_voigt.py > $O/${ROUND}_bench_voigt.json 2> /dev/null
 cd $R
 python3 bench.py > $O/${ROUND}_bench.json 2> /dev/null
 python3 bench.py --workload C4 --points 1000 --steps 2 > $O/${ROUND}_bench_C4.json 2> /dev/null
 python3 bench.py --workload C1 > $O/${ROUND}_bench_C1.json 2> /dev/null
+python3 bench.py --workload C5 > $O/${ROUND}_bench_C5.json 2> /dev/null
+python3 bench.py --workload C3 --no-cpu-baseline > $O/${ROUND}_bench_C3.json 2> /dev/null
 python3 bench.py --gpus 2 --backend gloo --share-device --no-voigt > $O/${ROUND}_bench_2ranks_one_gpu.json 2> /dev/null
 echo collected

@@ -13,10 +13,11 @@ import collections, csv, glob, json, os, shutil, sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 out = ROOT / "profiles"
 out.mkdir(exist_ok=True)
-DOMINANT = {"C2": "mom::k_layer<true, 3, 15>", "C4": "mom::k_layer<false, 3, 0>", "C1": "momsm::k_sweep<4>"}
+DOMINANT = {"C2": "mom::k_layer<true, 3, 15>", "C4": "mom::k_layer<false, 3, 0>", "C1": "momsm::k_sweep<4>",
+            "C5": "momr::k_dbl_pair<1, false>"}
 
 
 def newest(pattern):
@@ -25,7 +26,7 @@ def newest(pattern):
 
 
 summ, traffic = {}, {}
-for wl in ("C2", "C4", "C1", "voigt"):
+for wl in ("C2", "C4", "C1", "C5", "voigt"):
     st = newest(f"{rnd}_{wl}_stats/**/*kernel_stats.csv")
     if st:
         shutil.copy(st, out / f"{rnd}_{wl}_kernel_stats.csv")
