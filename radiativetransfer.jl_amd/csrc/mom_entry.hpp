@@ -7,6 +7,7 @@
 namespace MOM_NS {
 
 constexpr int kMaxSweepLayers = 96;
+constexpr int kMaxTargets = 12;
 struct LayerArgs {
   DevStreams q;
   int S, M, K;      // M: number of moments in THIS launch; m_first: Fourier index of the first of them
@@ -24,6 +25,14 @@ struct LayerArgs {
   // lies z * S (z * K * S) elements further; nd / iface come from the tables below.
   int Nz_sweep;
   signed char nd_z[kMaxSweepLayers], iface_z[kMaxSweepLayers];
+  // several composite targets fed by ONE added layer per layer (rt_kernel_multisensor!, rt_kernel_multisensor.jl:51-112:
+  // the added layer of layer iz is built once and joins the composite above or below every sensor).  ntgt > 0: after the
+  // doubling of layer z the workgroup walks the targets, act_z[z][t] = 0 nothing, 1 composite_t <- added (a slab's first
+  // layer), 2 interaction into composite_t, 3 composite_t <- composite_0 (snapshot of the running top slab at a sensor
+  // level; target 0 is processed first).  comp / first are unused then.  Per-layer launches (Nz_sweep = 0) use row 0.
+  int ntgt;
+  real *tgt[kMaxTargets][6];
+  signed char act_z[kMaxSweepLayers][kMaxTargets];
 };
 
 struct ZMix {
@@ -102,7 +111,23 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
 #endif
       expk = doubling_run<LDSM, KS>(c, nd, expk);
       MOM_STAMP(30);
-      if (first) {
+      if (a.ntgt > 0) {
+        const int zr = a.Nz_sweep > 0 ? z : 0;
+        for (int t = 0; t < a.ntgt; ++t) {
+          const int act = a.act_z[zr][t];
+          if (act == 0) continue;
+          CompPtrs gt = comp_ptrs(a.tgt[t], N, comp_pitch(N), pt);
+          if (act == 1) {
+            store_added_as_composite(c, gt);
+            __syncthreads();
+          } else if (act == 2) {
+            interaction_core<LDSM, IFACE, KS>(c, iface, gt, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
+          } else {
+            copy_composite(c, comp_ptrs(a.tgt[0], N, comp_pitch(N), pt), gt);
+            __syncthreads();
+          }
+        }
+      } else if (first) {
         store_added_as_composite(c, g);
         __syncthreads();
         MOM_STAMP(42);

@@ -1071,6 +1071,24 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
   __syncthreads();
 }
 
+// composite_dst <- composite_src for this workgroup's unit (multi-sensor: the running top slab frozen at a sensor level)
+__device__ __forceinline__ void copy_composite(const Ctx &c, const CompPtrs &s, const CompPtrs &d) {
+  const int N = c.N;
+  for (int e = wg_tid(); e < N * N; e += kThreads) {
+    int i, j;
+    c.fd.split(e, i, j);
+    const int o = i + j * s.ld;
+    d.R_mp[o] = s.R_mp[o];
+    d.R_pm[o] = s.R_pm[o];
+    d.T_pp[o] = s.T_pp[o];
+    d.T_mm[o] = s.T_mm[o];
+  }
+  for (int i = wg_tid(); i < N; i += kThreads) {
+    d.J0p[i] = s.J0p[i];
+    d.J0m[i] = s.J0m[i];
+  }
+}
+
 // composite <- added (rt_kernel.jl:227-230) from the context
 __device__ __forceinline__ void store_added_as_composite(const Ctx &c, const CompPtrs &g) {
   const int N = c.N, ld = c.ld;

@@ -494,6 +494,8 @@ struct mom_handle {
   int opt_sweep = 1;       // one launch walks all layers of a unit (LayerArgs::Nz_sweep)
   double *comp_top[6] = {};  // mom_rt_run_multisensor: composite state of the slab above a sensor
   double *d_msJ[2] = {};     // interface fields dwJ, uwJ [Nk,S,M]
+  std::vector<double *> ms_comp;  // multi-sensor: 6 arrays per composite set (snapshot of the top slab + bottom slab per sensor)
+  size_t ms_sets = 0;
   double *d_ms_out = nullptr;  // [2][nVza*nS*S*nSensors]
   size_t ms_out_cap = 0;
   int opt_pad = 1;         // scene-level path: pad the operator edge to the next strip-chained kernel size (strip_pad)
@@ -707,6 +709,7 @@ extern "C" int mom_destroy(mom_t *h) {
   fr(h->d_mu); fr(h->d_wt); fr(h->d_sg);
   for (int k = 0; k < 6; ++k) { fr(h->added[k]); fr(h->surf[k]); fr(h->comp[k]); fr(h->comp_top[k]); }
   fr(h->d_msJ[0]); fr(h->d_msJ[1]); fr(h->d_ms_out);
+  for (auto p : h->ms_comp) fr(p);
   for (int k = 0; k < 4; ++k) fr(h->d_vec[k]);
   fr(h->d_Zop[0]); fr(h->d_Zop[1]);
   fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
@@ -1420,8 +1423,15 @@ static int rt_run_wave(mom_t *h) {
 // the m = 0 sub-problem keeps its own arrays and is used only when allow_red): layer kernels, then (do_surface) the
 // surface layer with its closing interaction, then (do_post) the azimuthal post-processing into d_R / d_T / d_hdr.
 // mom_rt_run: the whole column; mom_rt_run_multisensor: the slabs above and below a sensor.
+// multi-target sweep (mom_rt_run_multisensor): composite targets and the per-layer action table of LayerArgs
+struct TargetSpec {
+  int ntgt = 0;
+  double *tgt[kMaxTargets][6] = {};
+  std::vector<signed char> act;  // [zb - za][kMaxTargets]
+};
+
 static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const compF[6], bool do_surface, bool do_post,
-                       bool cont = false) {
+                       bool cont = false, const TargetSpec *tg = nullptr) {
   const size_t S = h->S;
   const int M = h->scene_M;
   const bool red0 = h->red0 && allow_red;
@@ -1456,6 +1466,14 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
     a.tau_sum = h->d_tau_sum + S * z;
     a.Zpp = Zpp; a.Zmp = Zmp;
     for (int k = 0; k < 6; ++k) a.comp[k] = comp[k];
+    if (tg) {  // every moment of a target lies m_first moments into its arrays, like comp
+      a.ntgt = tg->ntgt;
+      for (int t = 0; t < tg->ntgt; ++t)
+        for (int k = 0; k < 6; ++k) a.tgt[t][k] = tg->tgt[t][k];
+      const int rows = sweep ? nzr : 1, r0 = sweep ? 0 : (z - za);
+      for (int r = 0; r < rows; ++r)
+        for (int t = 0; t < kMaxTargets; ++t) a.act_z[r][t] = tg->act[(size_t)(r0 + r) * kMaxTargets + t];
+    }
     a.scratch = scratch; a.info = h->d_info;
     const bool lds = (q.N <= 64) && !h->opt_force_generic;
     // small operators: 4-wave workgroups, two per CU (momcore_w4.hip), when two LDS images fit
@@ -1614,50 +1632,89 @@ extern "C" int mom_rt_run_multisensor(mom_t *h, int nSensors, const int *sensor_
     h->ms_out_cap = 2 * out1 * nSensors;
   }
   double *d_uw = h->d_ms_out, *d_dw = h->d_ms_out + out1 * nSensors;
-  // sensors in order of depth: the slab above sensor k+1 continues the slab above sensor k (layers 1..L are a prefix),
-  // so all top slabs together cost ONE sweep down to the deepest sensor; each bottom slab is its own sweep
-  std::vector<int> order(nSensors);
-  for (int i = 0; i < nSensors; ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sensor_levels[x] < sensor_levels[y]; });
-  int top_done = 0;  // layers [0, top_done) are in comp_top
-  for (int io = 0; io < nSensors; ++io) {
-    const int ims = order[io];
-    const int L = sensor_levels[ims];
-    int rc;
-    if (L == 0) {  // the TOA/BOA pair: uwJ = R_SFI, dwJ = T_SFI of the whole column (postprocessing_vza_ms.jl:34-36)
-      if ((rc = rt_run_core(h, 0, h->Nz, false, h->comp, true, true))) return rc;
-    } else {
-      if (L > top_done) {
-        if ((rc = rt_run_core(h, top_done, L, false, h->comp_top, false, false, top_done > 0))) return rc;
-        top_done = L;
-      }
-      if ((rc = rt_run_core(h, L, h->Nz, false, h->comp, true, false))) return rc;
-      InterArgs a{};
-      a.q = h->qk; a.S = h->S; a.M = M;
-      for (int k = 0; k < 6; ++k) { a.top[k] = h->comp_top[k]; a.bot[k] = h->comp[k]; }
-      a.dwJ = h->d_msJ[0]; a.uwJ = h->d_msJ[1]; a.scratch = h->d_scratch; a.info = h->d_info;
-      const bool lds = (Nk <= 64) && !h->opt_force_generic;
-      const size_t sm = lds_bytes(Nk, lds);
-      const size_t units = S * M;
-      if (lds) {
-        HIPCHK(h, allow_lds(k_interlayer<true>, sm));
-        hipLaunchKernelGGL(k_interlayer<true>, dim3((unsigned)units), dim3(kThreads), sm, h->stream, a);
-      } else {
-        HIPCHK(h, allow_lds(k_interlayer<false>, sm));
-        hipLaunchKernelGGL(k_interlayer<false>, dim3((unsigned)std::min<size_t>(units, (size_t)h->G)), dim3(kThreads), sm, h->stream, a);
-      }
-      HIPCHK(h, hipGetLastError());
-      PostArgs pa{};
-      pa.N = Nk; pa.nS = h->nS; pa.S = h->S; pa.M = M; pa.nVza = h->nVza; pa.red0 = 0;
-      pa.node = h->d_node; pa.cos_mphi = h->d_cos; pa.sin_mphi = h->d_sin;
-      pa.J0p = h->d_msJ[0]; pa.J0m = h->d_msJ[1];
-      pa.hdrJ = h->d_hdrJ; pa.hdr_all = 0; pa.zeroT_hi = 0; pa.hdrJm = nullptr;
-      pa.R = h->d_R; pa.T = h->d_T; pa.hdr = h->d_hdr;
-      hipLaunchKernelGGL(k_postprocess, dim3((unsigned)((out1 + 255) / 256)), dim3(256), 0, h->stream, pa);
-      HIPCHK(h, hipGetLastError());
+  // rt_kernel_multisensor! (rt_kernel_multisensor.jl:51-112): ONE sweep over the layers builds every layer's added operators
+  // once and feeds all composites -- the running slab above the sensors (target 0, frozen into a per-sensor snapshot when
+  // the sweep passes the sensor's level) and the slab below each sensor -- then per sensor the surface interaction, the
+  // interface solve and the post-processing.  Sensors are processed in chunks of what one kernel's target table holds.
+  const int Na = h->N + kPadMax;
+  const size_t blk[6] = {(size_t)comp_pitch(Na) * Na, (size_t)comp_pitch(Na) * Na, (size_t)comp_pitch(Na) * Na,
+                         (size_t)comp_pitch(Na) * Na, (size_t)Na, (size_t)Na};
+  const int per_chunk = (kMaxTargets - 1) / 2;  // top + (snapshot + bottom) per sensor
+  for (int c0 = 0; c0 < nSensors; c0 += per_chunk) {
+    const int nc = std::min(per_chunk, nSensors - c0);
+    const size_t need = (size_t)2 * nc;  // composite sets beyond h->comp_top: nc snapshots + nc bottoms
+    if (h->ms_sets < need) {
+      for (auto p : h->ms_comp) (void)hipFree(p);
+      h->ms_comp.clear();
+      h->ms_sets = 0;
+      for (size_t sidx = 0; sidx < need; ++sidx)
+        for (int k = 0; k < 6; ++k) {
+          double *p = nullptr;
+          HIPCHK(h, dmalloc(&p, blk[k] * S * h->M));
+          h->ms_comp.push_back(p);
+        }
+      h->ms_sets = need;
     }
-    HIPCHK(h, hipMemcpyAsync(d_uw + out1 * ims, h->d_R, out1 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(d_dw + out1 * ims, h->d_T, out1 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    TargetSpec tg;
+    tg.act.assign((size_t)h->Nz * kMaxTargets, 0);
+    int maxL = 0;
+    for (int i = 0; i < nc; ++i) maxL = std::max(maxL, sensor_levels[c0 + i]);
+    int nt = 0;
+    for (int k = 0; k < 6; ++k) tg.tgt[0][k] = h->comp_top[k];
+    nt = 1;
+    for (int z = 0; z < maxL; ++z) tg.act[(size_t)z * kMaxTargets + 0] = (z == 0) ? 1 : 2;
+    std::vector<int> snap_t(nc, -1), bot_t(nc, -1);
+    for (int i = 0; i < nc; ++i) {
+      const int L = sensor_levels[c0 + i];
+      if (L > 0) {
+        snap_t[i] = nt;
+        for (int k = 0; k < 6; ++k) tg.tgt[nt][k] = h->ms_comp[(size_t)(2 * i) * 6 + k];
+        tg.act[(size_t)(L - 1) * kMaxTargets + nt] = 3;
+        ++nt;
+      }
+      bot_t[i] = nt;
+      for (int k = 0; k < 6; ++k) tg.tgt[nt][k] = h->ms_comp[(size_t)(2 * i + 1) * 6 + k];
+      for (int z = L; z < h->Nz; ++z) tg.act[(size_t)z * kMaxTargets + nt] = (z == L) ? 1 : 2;
+      ++nt;
+    }
+    tg.ntgt = nt;
+    int rc;
+    if ((rc = rt_run_core(h, 0, h->Nz, false, h->comp, false, false, false, &tg))) return rc;
+    for (int i = 0; i < nc; ++i) {
+      const int ims = c0 + i, L = sensor_levels[ims];
+      double *bot[6], *top[6];
+      for (int k = 0; k < 6; ++k) { bot[k] = tg.tgt[bot_t[i]][k]; top[k] = (L > 0) ? tg.tgt[snap_t[i]][k] : nullptr; }
+      // surface interaction with the slab below the sensor (rt_run_multisensor.jl:150-159); L = 0: + post-processing of the
+      // whole column (uwJ = R_SFI, dwJ = T_SFI, postprocessing_vza_ms.jl:34-36)
+      if ((rc = rt_run_core(h, h->Nz, h->Nz, false, bot, true, L == 0))) return rc;
+      if (L > 0) {
+        InterArgs a{};
+        a.q = h->qk; a.S = h->S; a.M = M;
+        for (int k = 0; k < 6; ++k) { a.top[k] = top[k]; a.bot[k] = bot[k]; }
+        a.dwJ = h->d_msJ[0]; a.uwJ = h->d_msJ[1]; a.scratch = h->d_scratch; a.info = h->d_info;
+        const bool lds = (Nk <= 64) && !h->opt_force_generic;
+        const size_t sm = lds_bytes(Nk, lds);
+        const size_t units = S * M;
+        if (lds) {
+          HIPCHK(h, allow_lds(k_interlayer<true>, sm));
+          hipLaunchKernelGGL(k_interlayer<true>, dim3((unsigned)units), dim3(kThreads), sm, h->stream, a);
+        } else {
+          HIPCHK(h, allow_lds(k_interlayer<false>, sm));
+          hipLaunchKernelGGL(k_interlayer<false>, dim3((unsigned)std::min<size_t>(units, (size_t)h->G)), dim3(kThreads), sm, h->stream, a);
+        }
+        HIPCHK(h, hipGetLastError());
+        PostArgs pa{};
+        pa.N = Nk; pa.nS = h->nS; pa.S = h->S; pa.M = M; pa.nVza = h->nVza; pa.red0 = 0;
+        pa.node = h->d_node; pa.cos_mphi = h->d_cos; pa.sin_mphi = h->d_sin;
+        pa.J0p = h->d_msJ[0]; pa.J0m = h->d_msJ[1];
+        pa.hdrJ = h->d_hdrJ; pa.hdr_all = 0; pa.zeroT_hi = 0; pa.hdrJm = nullptr;
+        pa.R = h->d_R; pa.T = h->d_T; pa.hdr = h->d_hdr;
+        hipLaunchKernelGGL(k_postprocess, dim3((unsigned)((out1 + 255) / 256)), dim3(256), 0, h->stream, pa);
+        HIPCHK(h, hipGetLastError());
+      }
+      HIPCHK(h, hipMemcpyAsync(d_uw + out1 * ims, h->d_R, out1 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+      HIPCHK(h, hipMemcpyAsync(d_dw + out1 * ims, h->d_T, out1 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
   }
   HIPCHK(h, hipMemcpyAsync(uwJ, d_uw, out1 * nSensors * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(dwJ, d_dw, out1 * nSensors * sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -540,3 +540,24 @@ def test_multisensor_sweep(rtamd, cref, nS, lt, Nz, kw):
         with rtamd.corert.make_handle(m) as h:
             rtamd.corert.scene_set(h, sc)
             h.rt_run_multisensor([Nz])
+
+
+def test_multisensor_more_sensors_than_one_target_table(rtamd, cref):
+    """Seven sensors: more than one kernel's target table holds (kMaxTargets = 12: the running top slab + a snapshot and a
+    bottom slab per sensor), so the library sweeps twice; every layer's added operators are built once per sweep and feed
+    all composites (rt_kernel_multisensor.jl:51-112)."""
+    Nz = 7
+    m = rtamd.scenes.make_scene(3, 9, Nz, 9, seed=5, aerosol_total=0.25, vaz=(0.0, 60.0, 140.0))
+    sc = rtamd.prepare_scene(m)
+    levels = [3, 0, 6, 1, 5, 2, 4]
+    uwr, dwr, info = cref.rt_run_multisensor(cref.pack_scene(helpers.oracle_scene(m)), levels)
+    assert info == 0
+    with rtamd.corert.make_handle(m) as h:
+        rtamd.corert.scene_set(h, sc)
+        uw, dw = h.rt_run_multisensor(levels)
+        uw1, dw1 = h.rt_run_multisensor([4])
+    tol = helpers.stokes_rtol(sc.ndoubl)
+    for ims in range(len(levels)):
+        helpers.assert_stokes_close(uw[ims], uwr[ims], rtol=tol, what=f"uwJ level {levels[ims]}")
+        helpers.assert_stokes_close(dw[ims], dwr[ims], rtol=tol, what=f"dwJ level {levels[ims]}")
+    assert np.array_equal(uw1[0], uw[6]) and np.array_equal(dw1[0], dw[6])   # a sensor's result does not depend on the others
