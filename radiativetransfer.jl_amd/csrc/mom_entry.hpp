@@ -64,7 +64,9 @@ __device__ __forceinline__ CompPtrs comp_ptrs(real *const comp[6], int N, int pi
 // elemental -> nd doublings -> interaction with its composite state (rt_kernel!,
 // rt_kernel.jl:173-235) inside one workgroup; the added layer never touches HBM.
 // KS > 0: N = 4 KS exactly and the strip-chained paths of mom_strip.hpp are compiled in (8-wave LDS build only)
-template <bool LDSM, int IFACE, int KS = 0>
+// MT: the multi-target form (a.ntgt composites fed by one added layer, see LayerArgs); a separate image so that the
+// single-composite kernels carry none of its code (as a run-time branch it cost the C2 kernel 12 %)
+template <bool LDSM, int IFACE, int KS = 0, bool MT = false>
 __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
   if (KS > 0) a.q.N = 4 * KS;  // the host launches this instantiation only for that size: every dimension folds
   const int N = a.q.N;
@@ -111,7 +113,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
 #endif
       expk = doubling_run<LDSM, KS>(c, nd, expk);
       MOM_STAMP(30);
-      if (a.ntgt > 0) {
+      if constexpr (MT) {
         const int zr = a.Nz_sweep > 0 ? z : 0;
         for (int t = 0; t < a.ntgt; ++t) {
           const int act = a.act_z[zr][t];
@@ -127,13 +129,15 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
             __syncthreads();
           }
         }
-      } else if (first) {
-        store_added_as_composite(c, g);
-        __syncthreads();
-        MOM_STAMP(42);
       } else {
-        interaction_core<LDSM, IFACE, KS>(c, iface, g, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
-        MOM_STAMP(45);
+        if (first) {
+          store_added_as_composite(c, g);
+          __syncthreads();
+          MOM_STAMP(42);
+        } else {
+          interaction_core<LDSM, IFACE, KS>(c, iface, g, ElSigP{c.r, c.sg, c.ld}, ElSigP{c.t, c.sg, c.ld});
+          MOM_STAMP(45);
+        }
       }
     }
   }

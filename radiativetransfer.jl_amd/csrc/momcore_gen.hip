@@ -20,6 +20,16 @@ hipError_t mom_gen_launch_layer(const void *layer_args, int iface, bool lds, int
     if ((e = mom_allow_lds(reinterpret_cast<const void *>(k_layer<false, IF>), smem)) != hipSuccess) return e; \
     hipLaunchKernelGGL((k_layer<false, IF>), dim3(grid), dim3(kThreads), smem, st, a);                         \
   }
+  if (a.ntgt > 0) {  // multi-target form: one image per LDS mode, interface code dispatched at run time (IFACE = -1)
+    if (lds) {
+      if ((e = mom_allow_lds(reinterpret_cast<const void *>(k_layer<true, -1, 0, true>), smem)) != hipSuccess) return e;
+      hipLaunchKernelGGL((k_layer<true, -1, 0, true>), dim3(grid), dim3(kThreads), smem, st, a);
+    } else {
+      if ((e = mom_allow_lds(reinterpret_cast<const void *>(k_layer<false, -1, 0, true>), smem)) != hipSuccess) return e;
+      hipLaunchKernelGGL((k_layer<false, -1, 0, true>), dim3(grid), dim3(kThreads), smem, st, a);
+    }
+    return hipGetLastError();
+  }
   switch (iface) {  // the interface code is a template argument: see interaction_core
     case 0: GEN_LAUNCH(0) break;
     case 1: GEN_LAUNCH(1) break;
@@ -29,3 +39,15 @@ hipError_t mom_gen_launch_layer(const void *layer_args, int iface, bool lds, int
 #undef GEN_LAUNCH
   return hipGetLastError();
 }
+
+#ifdef MOM_DIAG_STAMPS
+// diagnostic builds: the stamp accumulators of THIS translation unit (the general layer kernels)
+extern "C" int mom_diag_read_gen(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mom_diag_acc), 128 * sizeof(unsigned long long)) != hipSuccess) return -2;
+  if (reset) {
+    unsigned long long z[128] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(mom_diag_acc), z, sizeof z) != hipSuccess) return -2;
+  }
+  return 0;
+}
+#endif

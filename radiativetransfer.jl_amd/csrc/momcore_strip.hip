@@ -25,6 +25,11 @@ hipError_t MOM_CAT(MOM_CAT(mom_strip, MOM_STRIP_KS), _launch_layer)(const void *
   if ((e = mom_allow_lds(reinterpret_cast<const void *>(k_layer<true, IF, MOM_STRIP_KS>), smem)) != hipSuccess)     \
     return e;                                                                                                       \
   hipLaunchKernelGGL((k_layer<true, IF, MOM_STRIP_KS>), dim3(grid), dim3(kThreads), smem, st, a);
+  if (a.ntgt > 0) {  // multi-target form (interface code dispatched at run time)
+    if ((e = mom_allow_lds(reinterpret_cast<const void *>(k_layer<true, -1, MOM_STRIP_KS, true>), smem)) != hipSuccess) return e;
+    hipLaunchKernelGGL((k_layer<true, -1, MOM_STRIP_KS, true>), dim3(grid), dim3(kThreads), smem, st, a);
+    return hipGetLastError();
+  }
   switch (iface) {
     case 0: STRIP_LAUNCH(0) break;
     case 1: STRIP_LAUNCH(1) break;

@@ -32,6 +32,16 @@ hipError_t mom4_launch_layer(const void *layer_args, int iface, bool lds, int gr
     if ((e = allow(k_layer<false, IF>, smem)) != hipSuccess) return e;                        \
     hipLaunchKernelGGL((k_layer<false, IF>), dim3(grid), dim3(kThreads), smem, st, a);        \
   }
+  if (a.ntgt > 0) {  // multi-target form (interface code dispatched at run time)
+    if (lds) {
+      if ((e = allow(k_layer<true, -1, 0, true>, smem)) != hipSuccess) return e;
+      hipLaunchKernelGGL((k_layer<true, -1, 0, true>), dim3(grid), dim3(kThreads), smem, st, a);
+    } else {
+      if ((e = allow(k_layer<false, -1, 0, true>, smem)) != hipSuccess) return e;
+      hipLaunchKernelGGL((k_layer<false, -1, 0, true>), dim3(grid), dim3(kThreads), smem, st, a);
+    }
+    return hipGetLastError();
+  }
   switch (iface) {
     case 0: W4_LAUNCH(0) break;
     case 1: W4_LAUNCH(1) break;
