@@ -96,24 +96,32 @@ __host__ __device__ inline int cols_for(int N) {
 __host__ __device__ inline size_t mat_elems(int N) { return (size_t)ld_for(N) * cols_for(N); }
 constexpr int kNumVec = 15 + 2 * kWaves;  // vectors carved from LDS (part = 2*kWaves vectors)
 constexpr int kGenericBufs = 5;
-// generic mode, N > 64: LDS staging tiles of wg_gemm_big behind the vectors: A panels [2][kBigKB][kBigLdA] and
-// B panels [2][256][kBigLdB] doubles
-#ifndef MOM_BIG_KB
-#define MOM_BIG_KB 8
-#endif
-constexpr int kBigKB = MOM_BIG_KB;  // k extent of a panel (MOM_BIG_KB / 4 MFMA k-steps between two barriers)
+// generic mode, N > 64: LDS staging tiles of wg_gemm_big behind the vectors: A panels [kBigStages][kBigKB][kBigLdA] and
+// B panels [kBigStages][256][kBigLdB] reals; the same area holds the wave-private transposition patches of its epilogue
+constexpr int kBigKB = 8;      // k extent of a panel (two MFMA k-steps between two barriers)
+constexpr int kBigStages = 3;  // panel p is multiplied while p + 1 is complete in LDS (its first fragments are read before
+                               // the barrier) and p + 2 is being written
 constexpr int kBigRows = 128;  // rows of the output block of one pass (2 x 4 waves of 64 x 64)
 constexpr int kBigLdA = 144;   // row pitch of an A panel: 128 + 16 (ds_read_b64 of 16 rows x 2 k conflict-free)
-constexpr int kBigLdB = kBigKB + 2;  // k pitch of a B-panel column (ds_read_b64 of 2 k x 16 columns conflict-free for 10, 14, 18)
+constexpr int kBigLdB = kBigKB + 2;  // k pitch of a B-panel column (ds_read_b64 of 2 k x 16 columns conflict-free)
 constexpr int kBigCols = 256;  // largest operator the tiles are sized for
-constexpr int kBigTileDoubles = 2 * kBigKB * kBigLdA + 2 * kBigCols * kBigLdB;
+constexpr int kBigStA = kBigKB * kBigLdA;  // reals per A stage; a B stage holds np_for(N) columns of pitch kBigLdB
+constexpr int kBigPatch = 36;  // row pitch of the epilogue patch (16 columns x 32 rows per wave)
+__host__ __device__ inline int big_stage_b(int N) { return 16 * ((N + 15) / 16) * kBigLdB; }
+__host__ __device__ inline int big_tile_doubles(int N) {
+  const int st = kBigStages * (kBigStA + big_stage_b(N)), pt = 8 * 16 * kBigPatch;
+  return st > pt ? st : pt;
+}
 __host__ __device__ inline size_t vec_area_doubles(int N) {
-  return (size_t)(kNumVec * np_for(N) + 32) + (size_t)((np_for(N) + 4 + 1) / 2);
+  // the vectors, the 32 series thresholds, then np + 4 ints (ipiv, sh, bad) in whole pairs of reals (the Float32 build
+  // needs one real per int: half of them used to overlap the panel area behind)
+  const size_t ints = 2 * ((sizeof(int) * (size_t)(np_for(N) + 4) + 2 * sizeof(real) - 1) / (2 * sizeof(real)));
+  return (size_t)(kNumVec * np_for(N) + 32) + ints;
 }
 __host__ __device__ inline size_t lds_bytes(int N, bool lds_mats) {
   size_t b = vec_area_doubles(N) * sizeof(real);
   if (lds_mats) b += 4 * mat_elems(N) * sizeof(real);
-  else if (N > 64) b += (size_t)kBigTileDoubles * sizeof(real);
+  else if (N > 64) b += (size_t)big_tile_doubles(N) * sizeof(real);
   return b;
 }
 
@@ -302,22 +310,188 @@ __host__ __device__ inline int comp_pitch(int N) { return 16 * ((N + 15) / 16); 
 
 // ---------------------------------------------------------------------------------------
 // C(i,j) <- epi(i, j, sum_k A(i,k) B(k,j)) for 64 < N <= 256 (generic mode): the operands live in global memory
-// (per-workgroup scratch slab or the composite layer); each k panel of 8 is staged once through LDS with coalesced
-// loads and feeds 8 waves x 4 x 4 MFMA tiles (64 x 64 outputs per wave, 128 x 256 per pass), double-buffered: the
-// loads of panel p+1 are in flight while panel p is multiplied, one barrier per panel.  Against the element-functor
-// loop of wg_gemm_n (every MFMA operand a separate 8-byte global load) this reads each operand element once per pass.
+// (per-workgroup scratch slab or the composite layer); each k panel of 8 is staged once through LDS and feeds 8 waves
+// x (<= 4 x 4) MFMA tiles (64 x 64 outputs per wave, 128 x 256 per pass).  Pipeline per panel p: the global loads of
+// panel p + 3 are issued, the first k-step is multiplied from fragments read before the last barrier, panel p + 2 goes
+// from registers to LDS and the first fragments of panel p + 1 are read, the second k-step is multiplied, ONE barrier.
+// Measured on per-workgroup slabs at N = 256 (scratch micro-benchmark, 256 workgroups): 153 us per product against
+// 185 us for the two-stage version with guarded 8-byte loads and accumulator-layout stores (109 us = MFMA peak).
+//  * ElP operands (padded slab buffers) are loaded with unconditional 16-byte loads from clamped addresses, k >= N
+//    zeroed by a select; other functors keep the guarded element loads.
+//  * No per-wave guard around the MFMAs: a wave whose share of the pass is shorter than the register block multiplies
+//    rows / columns that the epilogue discards (a guard that depends on the wave index makes every MFMA an
+//    exec-masked branch); only whole rows of tiles beyond TMr are skipped, by a workgroup-uniform scalar branch.
+//  * Epilogue: the accumulators (row = lq + 4 r within a tile: 32-byte pieces in 16 different columns per store) go
+//    through a wave-private LDS patch and reach epi() as row pairs, 64 consecutive rows of two columns per wave
+//    instruction -- the element-order stores cost 35 us of a 180 us product, the transposed ones 12.
 // All threads must call; C must not alias A or B; ends WITHOUT a barrier after the epilogue (callers add theirs).
 // ---------------------------------------------------------------------------------------
-template <class FA, class FB, class FE>
-__device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
+template <class F> struct is_elp { static constexpr bool value = false; };
+template <> struct is_elp<ElP> { static constexpr bool value = true; };
+
+template <int TN, class FA, class FB, class FE>
+__device__ __attribute__((noinline)) void gemm_big_pass(int N, int NC, FA A, FB B, FE epi, int row0, int tcnt, int TMr, int TNr) {
+  static_assert(kBigKB == 8 && kThreads == 512, "thread -> panel element mapping below");
+  constexpr int TM = 4;
+  typedef real r2 __attribute__((ext_vector_type(2)));
   real *tA = mom_smem + vec_area_doubles(N);
-  real *tB = tA + 2 * kBigKB * kBigLdA;
+  real *tB = tA + kBigStages * kBigStA;
   const int tid = wg_tid(), lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
   const int wr = (wave >> 2) & 1, wc = wave & 3;  // 2 x 4 wave grid (8-wave build only, see wg_gemm_nc)
   const int P = (N + kBigKB - 1) / kBigKB;
+  const int Np = np_for(N), ntc = (NC + 15) >> 4, StB = big_stage_b(N);
+  const bool two_b = Np > 128;  // the second B column of a thread (+ 128) exists (workgroup-uniform)
+  // panel element of this thread: A rows (2 lane, 2 lane + 1) of k = wave; B k = (2 kq, 2 kq + 1) of columns tid / 4, + 128
+  const int kq2 = 2 * (tid & 3), cb0 = tid >> 2, cb1 = cb0 + 128;
+  const int ia = row0 + 2 * lane;
+  r2 ga[2], gb0[2], gb1[2];
+  const real *pa = nullptr, *pb0 = nullptr, *pb1 = nullptr;
+  if constexpr (is_elp<FA>::value) pa = A.p + (ia < Np - 2 ? ia : Np - 2);
+  if constexpr (is_elp<FB>::value) {
+    pb0 = B.p + kq2 + (size_t)(cb0 < NC - 1 ? cb0 : NC - 1) * B.ld;
+    pb1 = B.p + kq2 + (size_t)(cb1 < NC - 1 ? cb1 : NC - 1) * B.ld;
+  }
+  gb1[0] = gb1[1] = (r2){0.0, 0.0};
+  r4 acc[TM][TN];
+#pragma unroll
+  for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TN; ++tj) acc[ti][tj] = (r4){0.0, 0.0, 0.0, 0.0};
+  auto fetch = [&](int p, int set) {
+    const int k0 = p * kBigKB;
+    {
+      const int k = k0 + wave;
+      if constexpr (is_elp<FA>::value) {
+        ga[set] = *(const r2 *)(pa + (size_t)(k < N ? k : N - 1) * A.ld);  // k >= N: zeroed by the stash
+      } else {
+        ga[set].x = (ia < N && k < N) ? A(ia, k) : 0.0;
+        ga[set].y = (ia + 1 < N && k < N) ? A(ia + 1, k) : 0.0;
+      }
+    }
+    {
+      const int k = k0 + kq2;
+      if constexpr (is_elp<FB>::value) {
+        gb0[set] = *(const r2 *)(pb0 + k0);  // k >= N: zeroed by the stash (a select here would wait for the load)
+        if (two_b) gb1[set] = *(const r2 *)(pb1 + k0);
+        (void)k;
+      } else {
+        gb0[set].x = (k < N && cb0 < NC) ? B(k, cb0) : 0.0;
+        gb0[set].y = (k + 1 < N && cb0 < NC) ? B(k + 1, cb0) : 0.0;
+        if (two_b) {
+          gb1[set].x = (k < N && cb1 < NC) ? B(k, cb1) : 0.0;
+          gb1[set].y = (k + 1 < N && cb1 < NC) ? B(k + 1, cb1) : 0.0;
+        }
+      }
+    }
+  };
+  const int wa = wave * kBigLdA + 2 * lane, wb = cb0 * kBigLdB + kq2;
+  auto stash = [&](int p, int set) {
+    const int st = p % kBigStages, k0 = p * kBigKB;
+    r2 va = ga[set], v0 = gb0[set], v1 = gb1[set];
+    if (k0 + kBigKB > N) {  // last panel of an operator whose edge is not a multiple of 8 (uniform branch)
+      if constexpr (is_elp<FA>::value) {
+        if (k0 + wave >= N) va = (r2){0.0, 0.0};
+      }
+      if constexpr (is_elp<FB>::value) {
+        if (k0 + kq2 >= N) { v0.x = 0.0; v1.x = 0.0; }
+        if (k0 + kq2 + 1 >= N) { v0.y = 0.0; v1.y = 0.0; }
+      }
+    }
+    *(r2 *)(tA + st * kBigStA + wa) = va;
+    if (cb0 < Np) *(r2 *)(tB + st * StB + wb) = v0;
+    if (cb1 < Np) *(r2 *)(tB + st * StB + wb + 128 * kBigLdB) = v1;
+  };
+  const int fa = 16 * TMr * wr + lr + lq * kBigLdA, fb = lq + (16 * TNr * wc + lr) * kBigLdB;
+  real a0[TM], b0[TN], a1[TM], b1[TN];
+  auto frags = [&](int p, int ks, real (&a)[TM], real (&b)[TN]) {
+    const int st = p % kBigStages;
+    const real *sa = tA + st * kBigStA + fa + 4 * ks * kBigLdA, *sb = tB + st * StB + fb + 4 * ks;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) a[t] = sa[16 * t];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) b[t] = sb[16 * t * kBigLdB];
+  };
+  auto mfmas = [&](real (&a)[TM], real (&b)[TN]) {
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+      if (ti < 2 || ti < TMr) {  // workgroup-uniform (a function of N): a scalar branch per row of tiles
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj) acc[ti][tj] = mma16(a[ti], b[tj], acc[ti][tj]);
+      }
+  };
+  __syncthreads();  // the previous pass (or the caller) is done with the tiles
+  fetch(0, 0);
+  if (P > 1) fetch(1, 1);
+  stash(0, 0);
+  if (P > 2) fetch(2, 0);
+  if (P > 1) stash(1, 1);
+  __syncthreads();
+  frags(0, 0, a0, b0);
+  // panels are walked two per trip so that the register-set index is a compile-time constant
+  auto panel = [&](int p, auto setc) {
+    constexpr int SET = decltype(setc)::value;  // set holding panel p + 2
+    frags(p, 1, a1, b1);
+    if (p + 3 < P) fetch(p + 3, 1 - SET);  // -> the set panel p + 1 came from, free since its stash
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (p + 2 < P) stash(p + 2, SET);
+    if (p + 1 < P) frags(p + 1, 0, a0, b0);  // stage complete since the last barrier; a0 / b0 are free (in-order issue)
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  };
+  for (int p = 0; p < P; p += 2) {
+    panel(p, std::integral_constant<int, 0>{});
+    if (p + 1 < P) panel(p + 1, std::integral_constant<int, 1>{});
+  }
+  // epilogue through the wave-private patch [16 columns][32 rows, pitch kBigPatch], two rounds of two row tiles per
+  // column tile (the panel area is free: every wave is past the barrier of the last panel; the next pass / caller
+  // starts with a barrier)
+  real *tw = tA + wave * (16 * kBigPatch);
+  const int nvt = tcnt - TMr * wr < TMr ? tcnt - TMr * wr : TMr;  // valid row tiles of this wave (may be <= 0)
+#pragma unroll
+  for (int tj = 0; tj < TN; ++tj) {
+    if (!(tj < TNr && TNr * wc + tj < ntc)) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (2 * h >= nvt) continue;
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tw[lr * kBigPatch + 16 * tl + cd_row(lq, r)] = acc[2 * h + tl][tj][r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int cl = 4 * it + (lane >> 4), rp = 2 * (lane & 15);
+        const r2 v = *(const r2 *)(tw + cl * kBigPatch + rp);
+        const int col = 16 * (TNr * wc + tj) + cl, rb = 32 * h + rp, rw = row0 + 16 * TMr * wr + rb;
+        if (rb < 16 * nvt && col < NC) {
+          if (rw + 1 < N) {
+            // an epilogue may offer a row-pair form epi(i, j, v_i, v_i+1) (i even) to use 16-byte accesses
+            if constexpr (std::is_invocable_v<FE, int, int, real, real>) {
+              epi(rw, col, v.x, v.y);
+            } else {
+              epi(rw, col, v.x);
+              epi(rw + 1, col, v.y);
+            }
+          } else if (rw < N) {
+            epi(rw, col, v.x);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+template <class FA, class FB, class FE>
+__device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
   // Wave tiling fitted to the operator: a wave owns TMr x TNr MFMA tiles (each <= 4), TNr = ceil(column tiles / 4) and
   // TMr = ceil(row tiles of this pass / 2), the row tiles split evenly over ceil(row tiles / 8) passes.  N = 256 keeps
   // the 4 x 4 register block of two passes; N = 66 (5 x 5 tiles) runs 3 x 2 per wave instead of one wave carrying 16.
+  // The register block is compiled for 4 x TN tiles, TN = 2, 3, 4; rows of tiles beyond TMr are skipped by a scalar branch.
   const int ntr = (N + 15) >> 4, ntc = (NC + 15) >> 4;
   const int TNr = (ntc + 3) >> 2;
   const int npass = (ntr + 7) >> 3;
@@ -325,95 +499,11 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
   for (int pass = 0; pass < npass; ++pass) {
     const int tcnt = (ntr - t0 + (npass - pass) - 1) / (npass - pass);  // row tiles of this pass
     const int TMr = (tcnt + 1) >> 1;
-    const int row0 = 16 * t0, rows_pass = 16 * tcnt;
+    const int row0 = 16 * t0;
     t0 += tcnt;
-    bool vr[4], vc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      vr[t] = t < TMr && TMr * wr + t < tcnt;
-      vc[t] = t < TNr && TNr * wc + t < ntc;
-    }
-    r4 acc[4][4];
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj) acc[ti][tj] = (r4){0.0, 0.0, 0.0, 0.0};
-    // two register sets: the loads of panel p + 2 are issued while panel p is multiplied and reach LDS one iteration
-    // later -- two panel times (~8 k cycles) to cover an HBM / Infinity-Cache round trip
-    constexpr int kNA = kBigRows * kBigKB / kThreads, kNB = kBigCols * kBigKB / kThreads;  // elements per thread and panel
-    static_assert(kNA * kThreads == kBigRows * kBigKB && kNB * kThreads == kBigCols * kBigKB, "panel must divide over the threads");
-    real ra[2][kNA], rb[2][kNB];
-    auto fetch = [&](int p, int set) {
-      const int k0 = p * kBigKB;
-#pragma unroll
-      for (int u = 0; u < kNA; ++u) {
-        const int e = tid + kThreads * u, row = e & (kBigRows - 1), kk = e >> 7;
-        const int i = row0 + row, k = k0 + kk;
-        ra[set][u] = (row < rows_pass && i < N && k < N) ? A(i, k) : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < kNB; ++u) {
-        const int e = tid + kThreads * u, col = e / kBigKB, kk = e - col * kBigKB;
-        const int k = k0 + kk;
-        rb[set][u] = (k < N && col < NC) ? B(k, col) : 0.0;
-      }
-    };
-    auto stash = [&](int stage, int set) {
-      real *sa = tA + stage * kBigKB * kBigLdA, *sb = tB + stage * kBigCols * kBigLdB;
-#pragma unroll
-      for (int u = 0; u < kNA; ++u) {
-        const int e = tid + kThreads * u, row = e & (kBigRows - 1), kk = e >> 7;
-        sa[row + kk * kBigLdA] = ra[set][u];
-      }
-#pragma unroll
-      for (int u = 0; u < kNB; ++u) {
-        const int e = tid + kThreads * u, col = e / kBigKB, kk = e - col * kBigKB;
-        sb[kk + col * kBigLdB] = rb[set][u];
-      }
-    };
-    __syncthreads();  // the previous pass (or the caller) is done with the tiles
-    fetch(0, 0);
-    if (P > 1) fetch(1, 1);
-    stash(0, 0);
-    __syncthreads();
-    // panels are walked two per trip so that the register-set index is a compile-time constant
-    auto panel = [&](int p, auto setc) {
-      constexpr int SET = decltype(setc)::value;  // set holding panel p + 1 (fetched one iteration ago)
-      if (p + 2 < P) fetch(p + 2, 1 - SET);        // -> the set panel p's data came from, free since its stash
-      const real *sa = tA + (p & 1) * kBigKB * kBigLdA + 16 * TMr * wr + lr + lq * kBigLdA;
-      const real *sb = tB + (p & 1) * kBigCols * kBigLdB + lq + (16 * TNr * wc + lr) * kBigLdB;
-#pragma unroll
-      for (int ks = 0; ks < kBigKB / 4; ++ks) {
-        real a[4], b[4];
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) a[ti] = vr[ti] ? sa[16 * ti + 4 * ks * kBigLdA] : 0.0;
-#pragma unroll
-        for (int tj = 0; tj < 4; ++tj) b[tj] = vc[tj] ? sb[4 * ks + 16 * tj * kBigLdB] : 0.0;
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-          for (int tj = 0; tj < 4; ++tj)
-            if (vr[ti] && vc[tj]) acc[ti][tj] = mma16(a[ti], b[tj], acc[ti][tj]);
-      }
-      if (p + 1 < P) stash((p + 1) & 1, SET);
-      __syncthreads();
-    };
-    for (int p = 0; p < P; p += 2) {
-      panel(p, std::integral_constant<int, 1>{});
-      if (p + 1 < P) panel(p + 1, std::integral_constant<int, 0>{});
-    }
-#pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
-#pragma unroll
-      for (int tj = 0; tj < 4; ++tj) {
-        if (!(vr[ti] && vc[tj])) continue;
-        const int col = 16 * (TNr * wc + tj) + lr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int rw = row0 + 16 * (TMr * wr + ti) + cd_row(lq, r);
-          if (rw < N && col < NC) epi(rw, col, acc[ti][tj][r]);
-        }
-      }
+    if (TNr <= 2) gemm_big_pass<2>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
+    else if (TNr == 3) gemm_big_pass<3>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
+    else gemm_big_pass<4>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
   }
 }
 

@@ -8,6 +8,7 @@
 #define MOM_NS mom4
 #include <hip/hip_runtime.h>
 
+#include "mom_diag.hpp"
 #include "mom_entry.hpp"
 #include "mom_host.hpp"
 
