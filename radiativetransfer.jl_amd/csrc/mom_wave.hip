@@ -592,6 +592,19 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
 
 }  // namespace momw
 
+// The MFMAs of these 4-wave kernels (512 registers per lane) must be in the VGPR form: with the accumulators in AGPRs
+// v_mfma_f64_16x16x4 issues at half rate on gfx950 (tools/mfma_peak.hip).  The Makefile passes
+// -mllvm -amdgpu-mfma-vgpr-form for this file; that option crashes the compiler on k_wsweep<2, 8>, which is therefore
+// built as a second object (mom_wave8.o, -DMOMW_ONLY_KS8) without it.
+hipError_t momw_launch_sweep8(const void *args, hipStream_t st);
+#ifdef MOMW_ONLY_KS8
+hipError_t momw_launch_sweep8(const void *args, hipStream_t st) {
+  const momw::WArgs a = *reinterpret_cast<const momw::WArgs *>(args);
+  const dim3 grid((unsigned)((a.S + 3) / 4)), block(256);
+  hipLaunchKernelGGL((momw::k_wsweep<2, 8>), grid, block, 0, st, a);
+  return hipGetLastError();
+}
+#else
 hipError_t momw_launch_sweep(const void *args, hipStream_t st) {
   const momw::WArgs a = *reinterpret_cast<const momw::WArgs *>(args);
   const dim3 grid((unsigned)((a.S + 3) / 4)), block(256);
@@ -602,8 +615,9 @@ hipError_t momw_launch_sweep(const void *args, hipStream_t st) {
     case 5: hipLaunchKernelGGL((momw::k_wsweep<2, 5>), grid, block, 0, st, a); break;
     case 6: hipLaunchKernelGGL((momw::k_wsweep<2, 6>), grid, block, 0, st, a); break;
     case 7: hipLaunchKernelGGL((momw::k_wsweep<2, 7>), grid, block, 0, st, a); break;
-    case 8: hipLaunchKernelGGL((momw::k_wsweep<2, 8>), grid, block, 0, st, a); break;
+    case 8: return momw_launch_sweep8(args, st);
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
+#endif
