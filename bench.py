@@ -255,60 +255,104 @@ def elastic_leg(a, workload, S_loc, steps, warmup, world, rank, dev, dist, with_
     return out
 
 
-def c5_leg(a, S, steps, warmup, dev, with_cpu=True):
+def c5_leg(a, S, steps, warmup, dev, with_cpu=True, world=1, rank=0, dist=None):
     """BASELINE configs[4]: rt_run(::RRS) on scene_C5 (N = 15, 5 layers, 178 Raman lines), corrected switch position.
     Bound: HBM -- the pair kernels read and write every block of the 4-D inelastic operators once per doubling step /
     interaction.  Algorithmic bytes of the dominant kernel (the doubling pair kernel) per (n1, dn) pair with its source
-    point on the grid: ier-+, iet++ in and out + ieJ0+- in and out = (4 N^2 + 4 N) x 8 B."""
+    point on the grid: ier-+, iet++ in and out + ieJ0+- in and out = (4 N^2 + 4 N) x 8 B.
+    world > 1 (weak scaling): a global axis of S x world points, every rank owns S of them and runs the window widened by
+    the halo max |i_l1l0| (mom_rrs_set_shard; the halo is recomputed, not exchanged); one all-gather of the five spectra."""
     import torch
     import rtamd
     rt = rtamd.corert
-    m, RS = rtamd.scenes.scene_C5(S=S, architecture=rtamd.MI355X(dev.index))
+    S_tot = S * world
+    m, RS = rtamd.scenes.scene_C5(S=S_tot, architecture=rtamd.MI355X(dev.index))
     m = rt._with_cabannes(RS, m)
-    sc = rtamd.prepare_scene(m)
+    sc_full = rtamd.prepare_scene(m)
+    lo, hi, wlo, whi = rtamd.sharding.rrs_window(S_tot, world, rank, RS.i_λ1λ0)
+    sc = sc_full if world == 1 else sc_full.spectral_slice(wlo, whi)
     Zr_pp, Zr_mp = rt.raman_z(RS, m)
-    h = rt.make_handle(m)
+    h = rt.make_handle(m, S=whi - wlo)
     h.set_option(rtamd._lib.MOM_OPT_STRIP_PAD, 0)
     h.rrs_set(RS.i_λ1λ0, RS.ϖ_λ1λ0, RS.rrs_strict_reference)
+    h.rrs_set_shard(S_tot, wlo, lo - wlo, hi - wlo)
     rt.scene_set(h, sc)
-    h.scene_set_rrs(np.ascontiguousarray(rt.fscatt_rayleigh(m).T), rt._abi_mats(Zr_pp), rt._abi_mats(Zr_mp))
-    for _ in range(warmup):
+    h.scene_set_rrs(np.ascontiguousarray(rt.fscatt_rayleigh(m)[wlo:whi].T), rt._abi_mats(Zr_pp), rt._abi_mats(Zr_mp))
+    backend = a.backend if world > 1 else "none"
+    gdev = dev if backend in ("torch", "rccl") else None
+    group = None
+    if world > 1 and backend == "rccl":  # the RRS leg gathers through torch.distributed's RCCL group
+        group = dist.new_group(backend="nccl")
+    full = None
+
+    def step():
+        nonlocal full
         h.rt_run_rrs()
-    h.sync()
-    torch.cuda.synchronize()
+        if world > 1:
+            res = h.get_RT_rrs()[:4] + h.get_hdr_rrs()[:1]
+            own = [r[..., lo - wlo:hi - wlo] for r in res]
+            full = gather_c5(own, S_tot, dist, gdev, group)
+
+    def gather_c5(own, S_tot, dist, gdev, group):
+        nrow = sum(int(np.prod(o.shape[:-1])) for o in own)
+        buf = torch.from_numpy(np.concatenate([o.reshape(-1, S) for o in own], axis=0)).to(gdev if gdev is not None else "cpu")
+        out = torch.empty((world, nrow, S), dtype=torch.float64, device=buf.device)
+        dist.all_gather_into_tensor(out.reshape(-1), buf.reshape(-1), group=group)  # ONE collective: the five spectra
+        return out
+
+    def fence():
+        h.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        h.rt_run_rrs()
-    h.sync()
-    torch.cuda.synchronize()
+        step()
+    fence()
     el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=gdev if gdev is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        el = float(t.item())
+        assert bool(torch.isfinite(full).all()), "all-gather returned non-finite spectra"
     tk = h.rrs_timers()
     res = h.get_RT_rrs()
-    assert np.all(np.isfinite(res[2])) and np.abs(res[2]).max() > 0
+    assert np.all(np.isfinite(res[2][..., lo - wlo:hi - wlo])) and np.abs(res[2]).max() > 0
     N, nR = sc.N, RS.n_Raman
-    pairs = int(sum(S - abs(int(o)) for o in RS.i_λ1λ0))
+    pairs = int(sum(max(0, min(hi, S_tot - int(o)) - max(lo, -int(o))) for o in RS.i_λ1λ0))  # owned n1 with n1 + offset on the grid
     bytes_pair = (4 * N * N + 4 * N) * 8
     ms, nl = tk["dbl_pair"]
     avg = ms / max(nl, 1)
     gbs = pairs * bytes_pair / (avg * 1e-3) / 1e9
-    prof = {}
-    tf = ROOT / "profiles" / "traffic.json"
-    if tf.exists():
-        prof = json.loads(tf.read_text()).get("C5", {})
-    out = {"metric": "spectral points/sec (whole node), C5 rotational-Raman scene", "value": S / (el / steps),
-           "unit": "spectral points/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"C5: RRS, N={N} (5 streams x 3 Stokes), Nz={sc.Nz}, M={sc.M}, S={S}, nRaman={nR}, "
-                                  f"sum(ndoubl)={int(sc.ndoubl.sum())}, rrs_strict_reference={int(RS.rrs_strict_reference)}, "
-                                  "Lambertian surface, 1 VZA", "sharding": "none", "collective": "none"},
-           "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                        "traffic": prof.get("hbm_bytes_per_launch"), "kernel": "momr::k_dbl_pair<1>",
-                        "avg_launch_ms": avg, "launches_per_step": nl, "pairs_per_launch": pairs,
-                        "algorithmic_bytes_per_pair": bytes_pair, "algorithmic_bytes_per_avg_launch": pairs * bytes_pair},
-           "stages_ms": {"dbl_pair_ms": tk["dbl_pair"][0], "int_pair_ms": tk["int_pair"][0],
-                         "ie_elemental_ms": tk["ie_elemental"][0], "total_ms": tk["total"][0]}}
+    out = None
+    if rank == 0:
+        prof = {}
+        tf = ROOT / "profiles" / "traffic.json"
+        if tf.exists():
+            prof = json.loads(tf.read_text()).get("C5", {})
+        out = {"metric": "spectral points/sec (whole node), C5 rotational-Raman scene", "value": S_tot / (el / steps),
+               "unit": "spectral points/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"C5: RRS, N={N} (5 streams x 3 Stokes), Nz={sc.Nz}, M={sc.M}, S={S}/GPU ({S_tot} in total), "
+                                      f"nRaman={nR}, sum(ndoubl)={int(sc.ndoubl.sum())}, "
+                                      f"rrs_strict_reference={int(RS.rrs_strict_reference)}, Lambertian surface, 1 VZA",
+                          "sharding": "none" if world == 1 else
+                          f"contiguous spectral slices + recomputed halo of max|i_l1l0| = {int(np.abs(RS.i_λ1λ0).max())} points "
+                          f"(rank 0 window: {whi - wlo} points)",
+                          "collective": "none" if world == 1 else "one all_gather_into_tensor of R, T, ieR, ieT, hdr"},
+               "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                            "traffic": prof.get("hbm_bytes_per_launch"), "kernel": "momr::k_dbl_pair<1>",
+                            "avg_launch_ms": avg, "launches_per_step": nl, "pairs_per_launch": pairs,
+                            "algorithmic_bytes_per_pair": bytes_pair, "algorithmic_bytes_per_avg_launch": pairs * bytes_pair},
+               "stages_ms": {"dbl_pair_ms": tk["dbl_pair"][0], "int_pair_ms": tk["int_pair"][0],
+                             "ie_elemental_ms": tk["ie_elemental"][0], "total_ms": tk["total"][0]}}
     h.close()
-    if with_cpu:
+    if with_cpu and rank == 0 and world == 1:
         out["cpu_baseline"] = c5_cpu_baseline(S)
     return out
 
@@ -393,8 +437,6 @@ def main():
         ap.error("--gpus must be >= 1")
     if a.share_device and a.backend != "gloo":
         ap.error("--share-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
-    if a.workload == "C5" and a.gpus > 1:
-        ap.error("C5 runs on one GPU (the Raman pairs need a halo exchange across shards: DESIGN.md)")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
 
@@ -421,7 +463,7 @@ def main():
 
     S_loc = a.points or DEFAULT_POINTS[a.workload]
     if a.workload == "C5":
-        out = c5_leg(a, S_loc, a.steps, a.warmup, dev, with_cpu=not a.no_cpu_baseline)
+        out = c5_leg(a, S_loc, a.steps, a.warmup, dev, with_cpu=not a.no_cpu_baseline, world=world, rank=rank, dist=dist)
     else:
         out = elastic_leg(a, a.workload, S_loc, a.steps, a.warmup, world, rank, dev, dist, with_cpu=not a.no_cpu_baseline)
     if rank == 0:

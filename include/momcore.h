@@ -155,6 +155,14 @@ int mom_elemental_inelastic_rrs(mom_t *h, int m, int ndoubl, int nRaman, const i
  *                      (computeRamanZlambda!, src/Inelastic/inelastic_helper.jl:457-464, per Fourier moment).
  *   mom_rt_run_rrs     rt_run.jl:125-215 with RS_type::RRS for the resident scene (every surface kind of
  *                      mom_scene_set_surface); asynchronous.
+ *   mom_rrs_set_shard  spectral sharding of the RRS path (the Raman operators couple spectral points at the
+ *                      offsets i_l1l0, inelastic_helper.jl:13-21, so a shard carries a halo): the handle's nSpec points are the
+ *                      window [n_glob0, n_glob0 + nSpec) of a global axis of nSpec_global points, of which this rank OWNS the
+ *                      local indices [n1_lo, n1_hi).  The elastic layers are computed for the whole window (they are the
+ *                      operands at n0 = n1 + i_l1l0), the inelastic pairs (n1, dn) and the spectra only for the owned
+ *                      points; on an interior edge the halo must be at least max |i_l1l0| long (MOM_EINVAL otherwise).
+ *                      ndoubl / interface codes must come from the GLOBAL axis (rt_kernel.jl:241-242), as in the elastic
+ *                      sharding.  Call after mom_rrs_set; the default is the whole window, n_glob0 = 0.
  *   mom_get_RT_rrs     R_SFI, T_SFI, ieR_SFI, ieT_SFI [nVza, nStokes, nSpec] (postprocessing_vza!(::RRS),
  *                      tools/postprocessing_vza.jl:95-147); any pointer may be NULL; gpu_ms (optional) = GPU time of the run.
  *   mom_get_hdr_rrs    the elastic RAMI extras of the same return tuple (rt_run.jl:187-213, 226): hdr [nVza, nStokes, nSpec],
@@ -168,6 +176,7 @@ enum {
   MOM_IE_COMP_J0P = 28, MOM_IE_COMP_J0M = 29
 };
 int mom_rrs_set(mom_t *h, int nRaman, const int *i_l1l0, const double *varpi_l1l0, int rrs_strict_reference);
+int mom_rrs_set_shard(mom_t *h, int nSpec_global, int n_glob0, int n1_lo, int n1_hi);
 int mom_rrs_elemental(mom_t *h, int m, int ndoubl, const double *tau_sum, const double *dtau, const double *varpi,
                       const double *Zpp, const double *Zmp, const double *fscattRayl, const double *Zpp_l1l0,
                       const double *Zmp_l1l0);

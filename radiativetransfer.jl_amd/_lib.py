@@ -58,6 +58,7 @@ SIGNATURES = {
     "mom_surface_lambertian": (C.c_int, [c_h, C.c_int, C.c_double, c_dp]),
     "mom_elemental_inelastic_rrs": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, c_ip] + [c_dp] * 13),
     "mom_rrs_set": (C.c_int, [c_h, C.c_int, c_ip, c_dp, C.c_int]),
+    "mom_rrs_set_shard": (C.c_int, [c_h, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mom_rrs_elemental": (C.c_int, [c_h, C.c_int, C.c_int] + [c_dp] * 8),
     "mom_rrs_doubling": (C.c_int, [c_h, C.c_int, c_dp]),
     "mom_rrs_interaction": (C.c_int, [c_h, C.c_int, C.c_int]),
@@ -245,6 +246,10 @@ class Handle:
         assert il.size == vp.size
         self.nRaman = int(il.size)
         self.check(self.lib.mom_rrs_set(self._h, self.nRaman, ip(il), dp(vp), 1 if rrs_strict_reference else 0))
+
+    def rrs_set_shard(self, nSpec_global, n_glob0, n1_lo, n1_hi):
+        """The handle's points are the window [n_glob0, n_glob0 + S) of a global axis; this rank owns [n1_lo, n1_hi)."""
+        self.check(self.lib.mom_rrs_set_shard(self._h, int(nSpec_global), int(n_glob0), int(n1_lo), int(n1_hi)))
 
     def rrs_elemental(self, m, nd, tau_sum, dtau, varpi, Zpp, Zmp, fscatt, Zpp_l1l0, Zmp_l1l0):
         a = [f64(x).reshape(-1) for x in (tau_sum, dtau, varpi, Zpp, Zmp, fscatt, Zpp_l1l0, Zmp_l1l0)]

@@ -869,15 +869,47 @@ def rt_run_rrs(RS_type: RRS, model: vSmartMOM_Model, i_band: int = 1):
     """rt_run(RS_type::RRS, model, iBand) (rt_run.jl:41-230), SFI = true.  Returns the reference's 7-tuple (rt_run.jl:226):
         (R_SFI, T_SFI, ieR_SFI, ieT_SFI, hdr, bhr_uw[1,:], bhr_dw[1,:])
     R/T/ieR/ieT/hdr are [nVza, nStokes, nSpec]; every surface type of `params.brdf`."""
+    S = model.τ_rayl.shape[0]
+    return rt_run_rrs_window(RS_type, model, 0, S)
+
+
+def rt_run_rrs_window(RS_type: RRS, model: vSmartMOM_Model, lo: int, hi: int, window=None):
+    """The owned slice [lo, hi) of rt_run(::RRS): runs the window `window` = (wlo, whi) ⊇ [lo, hi) (default: [lo, hi) widened
+    by max |i_λ₁λ₀| and clipped, sharding.rrs_window) with the GLOBAL ndoubl / interface codes and returns the 7-tuple
+    restricted to the owned points (last axis hi - lo)."""
     model = _with_cabannes(RS_type, model)
-    sc = prepare_scene(model)
+    sc_full = prepare_scene(model)
+    S = sc_full.S
+    if window is None:
+        H = int(np.max(np.abs(RS_type.i_λ1λ0)))
+        window = (max(0, lo - H), min(S, hi + H))
+    wlo, whi = window
+    sc = sc_full if (wlo, whi) == (0, S) else sc_full.spectral_slice(wlo, whi)
     Zr_pp, Zr_mp = raman_z(RS_type, model)
-    with make_handle(model) as h:
+    fs = fscatt_rayleigh(model)[wlo:whi]
+    with make_handle(model, S=whi - wlo) as h:
         h.set_option(_lib.MOM_OPT_STRIP_PAD, 0)
         h.rrs_set(RS_type.i_λ1λ0, RS_type.ϖ_λ1λ0, RS_type.rrs_strict_reference)
+        h.rrs_set_shard(S, wlo, lo - wlo, hi - wlo)
         scene_set(h, sc)
-        h.scene_set_rrs(np.ascontiguousarray(fscatt_rayleigh(model).T), _abi_mats(Zr_pp), _abi_mats(Zr_mp))
+        h.scene_set_rrs(np.ascontiguousarray(fs.T), _abi_mats(Zr_pp), _abi_mats(Zr_mp))
         h.rt_run_rrs()
         R, T, ieR, ieT = h.get_RT_rrs()[:4]
         hdr, up, dw = h.get_hdr_rrs()
-    return R, T, ieR, ieT, hdr, up[0], dw[0]
+    own = slice(lo - wlo, hi - wlo)
+    return R[..., own], T[..., own], ieR[..., own], ieT[..., own], hdr[..., own], up[0][..., own], dw[0][..., own]
+
+
+def rt_run_rrs_sharded(RS_type: RRS, model: vSmartMOM_Model, dist, device=None):
+    """rt_run(::RRS) over the ranks of an initialised torch.distributed group (one process per GPU): every rank runs its
+    window (sharding.rrs_window) and one all-gather assembles the 7-tuple on every rank.  No exchange during the run."""
+    from . import sharding
+    S = model.τ_rayl.shape[0]
+    lo, hi, wlo, whi = sharding.rrs_window(S, dist.get_world_size(), dist.get_rank(), RS_type.i_λ1λ0)
+    p = model.params
+    nV, nS = len(p.vza), p.polarization_type.n
+    if hi > lo:
+        loc = list(rt_run_rrs_window(RS_type, model, lo, hi, (wlo, whi)))
+    else:
+        loc = [np.zeros((nV, nS, 0))] * 5 + [np.zeros((0,))] * 2
+    return tuple(sharding.gather_spectra(loc, S, dist, device))

@@ -2424,6 +2424,23 @@ extern "C" int mom_rrs_set(mom_t *h, int nRaman, const int *i_l1l0, const double
   return MOM_OK;
 }
 
+extern "C" int mom_rrs_set_shard(mom_t *h, int nSpec_global, int n_glob0, int n1_lo, int n1_hi) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->rrs) return fail(h, MOM_ESTATE, "mom_rrs_set_shard: call mom_rrs_set first");
+  if (n_glob0 < 0 || n_glob0 + h->S > nSpec_global || n1_lo < 0 || n1_lo > n1_hi || n1_hi > h->S)
+    return fail(h, MOM_EINVAL, "mom_rrs_set_shard: need 0 <= n_glob0, n_glob0 + nSpec <= nSpec_global, 0 <= n1_lo <= n1_hi <= nSpec");
+  if (n1_hi > n1_lo) {
+    // every source index n1 + i_l1l0 of an owned point must be local or off the GLOBAL grid
+    const int H = h->rrs->max_off;
+    if ((n_glob0 > 0 && n1_lo < H) || (n_glob0 + h->S < nSpec_global && h->S - n1_hi < H))
+      return fail(h, MOM_EINVAL, "mom_rrs_set_shard: the halo is shorter than max |i_l1l0| on an interior edge");
+  }
+  h->rrs->n_glob0 = n_glob0;
+  h->rrs->n1_lo = n1_lo;
+  h->rrs->n1_hi = n1_hi;
+  return MOM_OK;
+}
+
 static int rrs_check(mom_t *h) {
   int info = 0;
   HIPCHK(h, hipMemcpyAsync(&info, h->rrs->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));

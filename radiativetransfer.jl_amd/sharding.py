@@ -7,6 +7,13 @@ WHOLE axis (rt_kernel.jl:241-242, compEffectiveLayerProperties.jl:104) -- are co
 prepare_scene() on the global axis before slicing, so an N-way run reproduces the 1-way run bit
 for bit.  The single collective is an all-gather of the R/T spectra (RCCL over xGMI when the
 process group backend is "nccl"; gloo in the CPU tests).
+
+The rotational-Raman path couples spectral points at the offsets i_λ₁λ₀ (inelastic_helper.jl:13-21): element [.., n₁, Δn]
+of the inelastic operators takes radiation from n₀ = n₁ + i_λ₁λ₀[Δn].  A shard therefore carries a HALO of
+H = max |i_λ₁λ₀| points on each interior edge: the elastic layers are computed on the window [lo - H, hi + H) (they are
+the operands at n₀), the inelastic pairs and the spectra only for the owned [lo, hi) (mom_rrs_set_shard).  No exchange
+is needed during the run -- the halo is recomputed, not communicated (elastic work is 1 / nRaman of the pair work) --
+and the collective stays the one all-gather of the spectra.
 """
 from __future__ import annotations
 
@@ -20,6 +27,39 @@ def shard_bounds(S: int, world: int, rank: int) -> Tuple[int, int]:
     per = -(-S // world)
     lo = min(S, rank * per)
     return lo, min(S, lo + per)
+
+
+def rrs_window(S: int, world: int, rank: int, offsets) -> Tuple[int, int, int, int]:
+    """(lo, hi, wlo, whi): the owned slice [lo, hi) of rank `rank` and its window [wlo, whi) = the owned slice widened by
+    H = max |offsets| and clipped to the axis."""
+    lo, hi = shard_bounds(S, world, rank)
+    H = int(np.max(np.abs(np.asarray(offsets)))) if len(offsets) else 0
+    if hi <= lo:
+        return lo, hi, lo, hi
+    return lo, hi, max(0, lo - H), min(S, hi + H)
+
+
+def gather_spectra(local, S: int, dist, device=None):
+    """All-gather per-rank slices of spectra: `local` = list of arrays whose LAST axis is this rank's owned points (possibly
+    empty); returns the list of full arrays (last axis S) on every rank.  One collective for all of them."""
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = -(-S // world)
+    lo, hi = shard_bounds(S, world, rank)
+    rows = [int(np.prod(a.shape[:-1])) for a in local]
+    buf = torch.zeros((sum(rows), per), dtype=torch.float64, device=device)
+    if hi > lo:
+        flat = np.concatenate([np.asarray(a, dtype=np.float64).reshape(r, hi - lo) for a, r in zip(local, rows)], axis=0)
+        buf[:, : hi - lo] = torch.from_numpy(np.ascontiguousarray(flat)).to(buf.device)
+    out = torch.empty(world * buf.numel(), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, buf.reshape(-1))
+    out = out.cpu().numpy().reshape(world, sum(rows), per).transpose(1, 0, 2).reshape(sum(rows), world * per)[:, :S]
+    res, r0 = [], 0
+    for a, r in zip(local, rows):
+        res.append(out[r0:r0 + r].reshape(a.shape[:-1] + (S,)).copy())
+        r0 += r
+    return res
 
 
 def rt_run_sharded(scene, run_local: Callable, dist, device=None):

@@ -66,3 +66,62 @@ def test_bench_launches_two_ranks_itself():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["sharding"].startswith("spectral axis, 2 x 1024")
     assert j["value"] > 0 and j["scaling"] == "weak"
+
+
+def _rrs_worker(rank, world, port, S, strict, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+    import rtamd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model, RS = _rrs_case(rtamd, S, strict)
+    res = rtamd.corert.rt_run_rrs_sharded(RS, model, dist)
+    if rank == world - 1:
+        q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _rrs_case(rtamd, S, strict):
+    rt = rtamd.corert
+    model = rtamd.scenes.make_scene(3, 5, 3, S, seed=31, aerosol_total=0.1, vza=(30.0,), vaz=(20.0,))
+    offs = np.array([-5, -2, 3, 6])
+    RS = rt.RRS(greek_raman=rt.get_greek_rayleigh(0.2), ϖ_Cabannes=0.96, ϖ_λ1λ0=0.02 * (1.0 + 0.1 * np.arange(4)), i_λ1λ0=offs,
+                rrs_strict_reference=strict)
+    return model, RS
+
+
+@pytest.mark.parametrize("S,strict", [(30, False), (23, True)])  # even split / ragged tail; both switch positions
+def test_rrs_two_ranks_with_halo_match_single_rank_bitwise(rtamd, S, strict):
+    """rt_run(::RRS) sharded over two processes (windows with a recomputed halo of max |i_λ₁λ₀| = 6 points, one all-gather
+    of the seven spectra) against the one-rank run."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rrs_worker, args=(r, 2, port, S, strict, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model, RS = _rrs_case(rtamd, S, strict)
+    one = rtamd.corert.rt_run_rrs(RS, model)
+    assert np.abs(one[2]).max() > 0
+    for got, ref in zip(res, one):
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_bench_C5_two_ranks():
+    """`python bench.py --workload C5 --gpus 2`: the RRS leg shards with halos and reports the whole-job rate."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "C5", "--gpus", "2", "--backend", "gloo", "--share-device",
+                          "--points", "600", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and "1200 in total" in j["config"]["workload"] and "halo" in j["config"]["sharding"]
+    assert j["value"] > 0 and j["roofline"]["bound"] == "hbm"

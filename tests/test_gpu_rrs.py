@@ -244,3 +244,36 @@ def test_rt_run_rrs_surfaces(rtamd, surf, nS):
     scene.varpi_cabannes = RS.ϖ_Cabannes
     ref = rr.rt_run_rrs(scene, ora, full=True)
     _check_rrs_outputs(got, ref[:5] + (ref[5][0], ref[6][0]))
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_rrs_windows_reassemble_the_full_run(rtamd, strict, world):
+    """Spectral sharding of the RRS path: every rank runs its window = owned slice + halo of max |i_λ₁λ₀|
+    (mom_rrs_set_shard) with the global ndoubl; the owned slices, put side by side, are the unsharded run BIT FOR BIT
+    (same kernels, same per-point arithmetic, no exchange).  world = 5: slices of 8 points, halo 7."""
+    rt = rtamd.corert
+    m = rtamd.scenes.make_scene(3, 5, 3, 40, seed=77, aerosol_total=0.1, **VIEWS[1])
+    RS, _ = _rrs_inputs(rtamd, [-4, -1, 2, 7, 3], strict)
+    full = rt.rt_run_rrs(RS, m)
+    assert np.abs(full[2]).max() > 0
+    parts = []
+    for rank in range(world):
+        lo, hi, wlo, whi = rtamd.sharding.rrs_window(40, world, rank, RS.i_λ1λ0)
+        assert wlo == max(0, lo - 7) and whi == min(40, hi + 7)
+        parts.append(rt.rt_run_rrs_window(RS, m, lo, hi, (wlo, whi)))
+    for k, name in enumerate(("R", "T", "ieR", "ieT", "hdr", "bhr_uw", "bhr_dw")):
+        got = np.concatenate([p[k] for p in parts], axis=-1)
+        assert np.array_equal(got, full[k]), (name, np.abs(got - full[k]).max())
+
+
+def test_rrs_shard_halo_too_short_is_refused(rtamd):
+    rt = rtamd.corert
+    m = rtamd.scenes.make_scene(1, 3, 2, 30, seed=5)
+    RS, _ = _rrs_inputs(rtamd, [-6, 3], False)
+    with pytest.raises(rtamd._lib.MomError, match="halo"):
+        rt.rt_run_rrs_window(RS, m, 10, 20, (7, 26))      # 3 points below, needs 6
+    with pytest.raises(rtamd._lib.MomError, match="halo"):
+        rt.rt_run_rrs_window(RS, m, 10, 20, (4, 22))      # 2 points above
+    got = rt.rt_run_rrs_window(RS, m, 0, 10, (0, 16))      # window starting at the global edge: no lower halo needed
+    assert got[0].shape[-1] == 10

@@ -71,3 +71,55 @@ def test_shard_bounds():
     assert [sb(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert [sb(2, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
     assert sb(29_944, 8, 7) == (26_201, 29_944)
+
+
+def test_rrs_window():
+    """Owned slice + halo of max |i_λ₁λ₀| on interior edges, clipped at the ends of the axis; empty tails stay empty."""
+    import rtamd
+    rw = rtamd.sharding.rrs_window
+    offs = [-4, -1, 2, 7, 3]
+    assert [rw(40, 5, r, offs) for r in range(5)] == [(0, 8, 0, 15), (8, 16, 1, 23), (16, 24, 9, 31), (24, 32, 17, 39), (32, 40, 25, 40)]
+    assert rw(6837, 8, 3, [-5000, 4000]) == (2565, 3420, 0, 6837)   # halo longer than the axis: the whole axis
+    assert rw(2, 4, 3, offs) == (2, 2, 2, 2)
+    for S, world in ((40, 3), (7, 4), (6837, 8)):
+        b = [rw(S, world, r, offs) for r in range(world)]
+        assert b[0][0] == 0 and b[-1][1] == S and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        assert all(w[2] <= w[0] and w[1] <= w[3] for w in b)
+
+
+def _gather_worker(rank, world, port, S, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+    import rtamd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = rtamd.sharding.shard_bounds(S, world, rank)
+    n = np.arange(lo, hi, dtype=np.float64)
+    loc = [np.stack([[n + 100 * v + 10 * k for k in range(3)] for v in range(2)]), -n, np.stack([n * n, 2 * n])]  # [2,3,.], [.], [2,.]
+    full = rtamd.sharding.gather_spectra(loc, S, dist)
+    if rank == 1:
+        q.put(full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S,world", [(10, 2), (7, 2), (2, 3)])  # even, ragged, a rank with no points
+def test_gather_spectra_over_gloo(S, world):
+    """The collective of the sharded RRS run: one all-gather of the seven spectra of the return tuple (any leading shape)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = np.arange(S, dtype=np.float64)
+    assert np.array_equal(full[0], np.stack([[n + 100 * v + 10 * k for k in range(3)] for v in range(2)]))
+    assert np.array_equal(full[1], -n) and np.array_equal(full[2], np.stack([n * n, 2 * n]))
