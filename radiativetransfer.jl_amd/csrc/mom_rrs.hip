@@ -36,6 +36,7 @@ using namespace momt;
 
 struct KArgs {
   int N, nS, S, nR, strict_idx, strict_rrs, n_glob0, n1_lo, n1_hi, last, nd, sh, m, imu0, nTerms;
+  int P;          // row pitch of the device blocks: 16 (N <= 16) or 32; a matrix block is P x P doubles, a vector block P (zero padding)
   int derive_pm;  // corrected position: ier+- / iet-- are sgn (.) ier-+ / iet++ and are derived where they are read
   int fuse_el;    // first doubling step of a layer: the inelastic elemental layer is formed in registers, not loaded
   double mu0, albedo, weight;
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_el_point(KArgs a) {
 #pragma clang fp contract(off)
   const Geo g = make_geo<NT>(a.N, rrs_smem);
   const int N = a.N, n = a.nS;
-  const size_t NN = (size_t)N * N;
+  const size_t NN = (size_t)N * N, BS = (size_t)a.P * a.P, VS = a.P;
   const int wave = threadIdx.x >> 6;
   const double wdiv = (a.m == 0) ? 2.0 : 4.0, wct02 = (a.m == 0) ? 0.5 : 0.25;
   const int i_start = n * (a.imu0 - 1), i_end = n * a.imu0;
@@ -191,15 +192,15 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_el_point(KArgs a) {
       Mat<NT> rpm = r_t, tmm = t_t;
       map_t<NT>(g, rpm, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
       map_t<NT>(g, tmm, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
-      store_t<NT>(g, a.a_cur[R_PM] + NN * pt, rpm);
-      store_t<NT>(g, a.a_cur[T_MM] + NN * pt, tmm);
+      store_t<NT>(g, a.a_cur[R_PM] + BS * pt, rpm);
+      store_t<NT>(g, a.a_cur[T_MM] + BS * pt, tmm);
     } else {
       map_t<NT>(g, r_t, [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
     }
-    store_t<NT>(g, a.a_cur[R_MP] + NN * pt, r_t);
-    store_t<NT>(g, a.a_cur[T_PP] + NN * pt, t_t);
-    storev<NT>(g, a.a_cur[J0P] + (size_t)N * pt, jp, 0);
-    storev<NT>(g, a.a_cur[J0M] + (size_t)N * pt, jm, 0);
+    store_t<NT>(g, a.a_cur[R_MP] + BS * pt, r_t);
+    store_t<NT>(g, a.a_cur[T_PP] + BS * pt, t_t);
+    storev<NT>(g, a.a_cur[J0P] + VS * pt, jp, 0);
+    storev<NT>(g, a.a_cur[J0M] + VS * pt, jm, 0);
     if (g.lr == 0 && g.lq == 0) a.expk_cur[pt] = exp(-dtau / a.mu0);
   }
 }
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(256) k_ie_elemental(KArgs a) {
   const int span = a.n1_hi - a.n1_lo;
   const int n1 = a.n1_lo + (int)(pp % span), dn = (int)(pp / span);   // dn-major: consecutive blocks of the 4-D arrays
   const size_t u = (size_t)n1 + (size_t)a.S * dn;  // block index of the 4-D arrays
-  const size_t o4 = NN * u + i + (size_t)N * j;
+  const size_t o4 = (size_t)a.P * a.P * u + i + (size_t)a.P * j;
   const int n0 = n1 + a.off[dn];
   const double scl = (double)(1ull << a.sh);
   const double wdiv = (a.m == 0) ? 2.0 : 4.0, wct02 = (a.m == 0) ? 0.5 : 0.25;
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(256) k_ie_elemental(KArgs a) {
   a.ie_a[T_PP][o4] = t;
   if (j == 0) {
     const int i_start = n * (a.imu0 - 1), i_end = n * a.imu0;
-    const size_t o3 = i + (size_t)N * u;
+    const size_t o3 = i + (size_t)a.P * u;
     if (in) {
       const double d1 = a.tau[n1] / scl, d0 = a.tau[n0] / scl, mus = a.mu[i_start];
       double zpI = 0.0, zmI = 0.0;
@@ -298,11 +299,11 @@ enum { SVI_G1V = 0, SVI_G2V = 1 };
 template <int NT>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) k_dbl_point(KArgs a) {
   const Geo g = make_geo<NT>(a.N, rrs_smem);
-  const int N = a.N, n = a.nS, wave = threadIdx.x >> 6;
-  const size_t NN = (size_t)N * N;
+  const int n = a.nS, wave = threadIdx.x >> 6;
+  const size_t NN = (size_t)a.P * a.P, VS = a.P;  // block strides (padded pitch)
   int bad = 0;
   for (int pt = blockIdx.x * kWavesPerBlock + wave; pt < a.S; pt += gridDim.x * kWavesPerBlock) {
-    const size_t om = NN * pt, ov = (size_t)N * pt;
+    const size_t om = NN * pt, ov = VS * pt;
     const Mat<NT> r_t = load_t<NT>(g, a.a_cur[R_MP] + om), t_t = load_t<NT>(g, a.a_cur[T_PP] + om);
     const Mat<NT> r_c = transpose<NT>(g, r_t), t_c = transpose<NT>(g, t_t);
     const Mat<NT> G_c = inv_one_minus<NT>(g, TN<NT>(g, r_t, r_c), &bad);   // (I - r r)^-1                      :47
@@ -337,7 +338,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_dbl_point(KArgs a) {
     // elastic source update: once (corrected) or nRaman times with expk squared every time (strict, D1)          :90-95
     const int reps = a.strict_rrs ? a.nR : 1;
     for (int k = 0; k < reps; ++k) {
-      if (a.strict_rrs) storev<NT>(g, a.jpseq + ov + (size_t)N * a.S * k, J, 0);
+      if (a.strict_rrs) storev<NT>(g, a.jpseq + ov + VS * a.S * k, J, 0);
       const Vec<NT> mx = mix(J);
       const Vec<NT> s = vadd<NT>(mx, TNv<NT>(g, r_t, swap01<NT>(mx)));
       const Vec<NT> q = TNv<NT>(g, ttgp_t, s);                             // (tG (j0+ + r j1-) | tG (j1- + r j0+))
@@ -466,14 +467,14 @@ __device__ __forceinline__ void ie_elem_tile(const Geo &g, const KArgs &a, int n
 template <int NT, bool FUSE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair(KArgs a) {
   const Geo g = make_geo<NT>(a.N, rrs_smem);
-  const int N = a.N, n = a.nS, wave = threadIdx.x >> 6;
-  const size_t NN = (size_t)N * N;
+  const int n = a.nS, wave = threadIdx.x >> 6;
+  const size_t NN = (size_t)a.P * a.P, VS = a.P;  // block strides (padded pitch)
   const size_t npairs = (size_t)(a.n1_hi - a.n1_lo) * a.nR;
   const bool fuseD = a.last && !a.strict_rrs;  // D2/D3 (corrected) folded into the last step's stores
   for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += (size_t)gridDim.x * kWavesPerBlock) {
     const int n1 = a.n1_lo + (int)(p % (size_t)(a.n1_hi - a.n1_lo)), dn = (int)(p / (size_t)(a.n1_hi - a.n1_lo));
     const int n0 = n1 + a.off[dn];
-    const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = (size_t)N * u;
+    const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = VS * u;
     if (n0 < 0 || n0 >= a.S) {  // get_n0_n1 (inelastic_helper.jl:13-21): no update off the grid ...
       if (FUSE) {               // ... but the deferred elemental writes zeros there and multiplies ieJ0- by D (:378-380)
         store_t<NT>(g, a.ie_a[R_MP] + o4, zeros<NT>());
@@ -504,7 +505,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair
       }
       continue;
     }
-    const size_t m1 = NN * n1, m0 = NN * n0, v0 = (size_t)N * n0;
+    const size_t m1 = NN * n1, m0 = NN * n0, v0 = VS * n0;
     Mat<NT> a_t, b_t;
     CV<NT> Jp, Jm;  // ieJ0+, ieJ0-
     if (FUSE) {
@@ -524,7 +525,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair
     {
       const double e1 = a.expk_cur[n1];
       const CV<NT> J1p = cscale<NT>(Jp, e1), J1m = cscale<NT>(Jm, e1);                           // ieJ1+, ieJ1-   :52-56
-      const double *jp0 = a.strict_rrs ? a.jpseq + v0 + (size_t)N * a.S * dn : a.a_cur[J0P] + v0;
+      const double *jp0 = a.strict_rrs ? a.jpseq + v0 + VS * a.S * dn : a.a_cur[J0P] + v0;
       const CV<NT> a_j1m = mv_t<NT>(g, a_t, loadR<NT>(g, a.sv[SV_J1M] + v0));                    // ier j1-[n0]
       const CV<NT> a_jp = mv_t<NT>(g, a_t, loadR<NT>(g, jp0));                                   // ier j0+[n0]
       const Vec<NT> tm1 = loadR<NT>(g, a.sv[SV_TMP1] + v0), tm2 = loadR<NT>(g, a.sv[SV_TMP2] + v0);
@@ -577,8 +578,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair
 // item (n, dn) addresses the RAMAN axis with n0 = n + i_l1l0[dn] (1-based) when 1 <= n0 <= nRaman.  One thread per
 // (i, n) walks dn in ascending order (single-thread column-major semantics of the overlapping reads/writes of the SFI kernel).
 __global__ void k_strict_D(KArgs a) {
-  const int N = a.N, n = a.nS;
-  const size_t NN = (size_t)N * N;
+  const int N = a.N, n = a.nS, P = a.P;
+  const size_t NN = (size_t)P * P;  // block stride (padded pitch P)
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   const int span = a.n1_hi - a.n1_lo;
   if (e >= N * span) return;
@@ -590,7 +591,7 @@ __global__ void k_strict_D(KArgs a) {
     if (k1 < 1 || k1 > a.nR) continue;
     const size_t ub = (size_t)nl + (size_t)a.S * (k1 - 1);
     for (int j = 0; j < N; ++j) {
-      const size_t o = NN * ub + i + (size_t)N * j;
+      const size_t o = NN * ub + i + (size_t)P * j;
       double v = a.ie_a[R_MP][o];
       if (ci > 2) { v = -v; a.ie_a[R_MP][o] = v; }
       const double s = dsgn(ci, scomp(j, n, a.strict_idx));
@@ -602,14 +603,14 @@ __global__ void k_strict_D(KArgs a) {
     for (int dn = 0; dn < a.nR; ++dn) {
       const int k1 = ng1 + a.off[dn];
       if (k1 < 1 || k1 > a.nR) continue;
-      a.ie_a[J0M][i + (size_t)N * ((size_t)nl + (size_t)a.S * (k1 - 1))] = -a.ie_a[J0M][i + (size_t)N * ((size_t)nl + (size_t)a.S * dn)];
+      a.ie_a[J0M][i + (size_t)P * ((size_t)nl + (size_t)a.S * (k1 - 1))] = -a.ie_a[J0M][i + (size_t)P * ((size_t)nl + (size_t)a.S * dn)];
     }
 }
 // ier+- = sgn (.) ier-+, iet-- = sgn (.) iet++ for the whole arrays (the derived form written out: downloads, strict reads)
 __global__ void k_materialise_pm(KArgs a) {
-  const size_t NN = (size_t)a.N * a.N, cnt = NN * a.S * a.nR;
+  const size_t NN = (size_t)a.P * a.P, cnt = NN * a.S * a.nR;  // every element of the padded blocks (padding: s x 0)
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (size_t)gridDim.x * blockDim.x) {
-    const int i = (int)(e % a.N), j = (int)((e / a.N) % a.N);
+    const int i = (int)(e % a.P), j = (int)((e / a.P) % a.P);
     const double s = a.nS > 1 ? dsgn(scomp(i, a.nS, a.strict_idx), scomp(j, a.nS, a.strict_idx)) : 1.0;
     a.ie_a[R_PM][e] = s * a.ie_a[R_MP][e];
     a.ie_a[T_MM][e] = s * a.ie_a[T_PP][e];
@@ -631,11 +632,11 @@ __global__ void k_copy2(const double *s0, double *d0, const double *s1, double *
 template <int NT>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) k_int_point(KArgs a, int iface) {
   const Geo g = make_geo<NT>(a.N, rrs_smem);
-  const int N = a.N, wave = threadIdx.x >> 6;
-  const size_t NN = (size_t)N * N;
+  const int wave = threadIdx.x >> 6;
+  const size_t NN = (size_t)a.P * a.P, VS = a.P;  // block strides (padded pitch)
   int bad = 0;
   for (int pt = blockIdx.x * kWavesPerBlock + wave; pt < a.S; pt += gridDim.x * kWavesPerBlock) {
-    const size_t om = NN * pt, ov = (size_t)N * pt;
+    const size_t om = NN * pt, ov = VS * pt;
     const Mat<NT> r_t = load_t<NT>(g, a.x[R_MP] + om), tpp_t = load_t<NT>(g, a.x[T_PP] + om);
     const Mat<NT> tmm_t = load_t<NT>(g, a.x[T_MM] + om);
     const Mat<NT> Rpm_t = load_t<NT>(g, a.c_cur[C_R_PM] + om), Tpp_t = load_t<NT>(g, a.c_cur[C_T_PP] + om);
@@ -732,15 +733,15 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_int_point(KArgs a, int 
 template <int NT, bool SURF, bool DERIVE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair(KArgs a, int iface) {
   const Geo g = make_geo<NT>(a.N, rrs_smem);
-  const int N = a.N, wave = threadIdx.x >> 6;
-  const size_t NN = (size_t)N * N;
+  const int wave = threadIdx.x >> 6;
+  const size_t NN = (size_t)a.P * a.P, VS = a.P;  // block strides (padded pitch)
   const size_t npairs = (size_t)(a.n1_hi - a.n1_lo) * a.nR;
   for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += (size_t)gridDim.x * kWavesPerBlock) {
     const int n1 = a.n1_lo + (int)(p % (size_t)(a.n1_hi - a.n1_lo)), dn = (int)(p / (size_t)(a.n1_hi - a.n1_lo));
     const int n0 = n1 + a.off[dn];
     if (n0 < 0 || n0 >= a.S) continue;
-    const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = (size_t)N * u;
-    const size_t m1 = NN * n1, m0 = NN * n0, v0 = (size_t)N * n0;
+    const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = VS * u;
+    const size_t m1 = NN * n1, m0 = NN * n0, v0 = VS * n0;
     auto ldA = [&](int which) {
       if (SURF) return zeros<NT>();
       if (DERIVE && (which == T_MM || which == R_PM)) {  // ier+- = sgn (.) ier-+, iet-- = sgn (.) iet++ (corrected D2)
@@ -832,8 +833,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair
 // 1 any BRDF type through its Fourier matrix Rsurf [N,N] of this moment (rpv_surface.jl:20-66), 2 LambertianSurfaceLegendre
 // (lambertian_surface.jl:77-138: spectrally varying albedo, j0+ = 0, t = 0 for m > 0)
 __global__ void k_surface_fill(KArgs a, const double *tau_tot, int kind, const double *Rsurf, const double *albedo_spec) {
-  const int N = a.N, n = a.nS;
-  const size_t NN = (size_t)N * N;
+  const int N = a.N, n = a.nS, P = a.P;
+  const size_t BS = (size_t)P * P;  // block stride (padded pitch P; the padding stays zero)
   const size_t pt = blockIdx.x;
   const double att = exp(-tau_tot[pt] / a.mu0);
   const int i_start = n * (a.imu0 - 1), i_end = n * a.imu0;
@@ -841,17 +842,18 @@ __global__ void k_surface_fill(KArgs a, const double *tau_tot, int kind, const d
   if (kind == 1) {
     for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
       const int j = e / N, i = e - j * N;
-      x[R_MP][NN * pt + e] = Rsurf[i + (size_t)N * j] * (a.mu[j] * a.wt[j]);
-      x[R_PM][NN * pt + e] = 0.0;
-      x[T_PP][NN * pt + e] = (i == j) ? 1.0 : 0.0;
-      x[T_MM][NN * pt + e] = (i == j) ? 1.0 : 0.0;
+      const size_t o = BS * pt + i + (size_t)P * j;
+      x[R_MP][o] = Rsurf[i + (size_t)N * j] * (a.mu[j] * a.wt[j]);
+      x[R_PM][o] = 0.0;
+      x[T_PP][o] = (i == j) ? 1.0 : 0.0;
+      x[T_MM][o] = (i == j) ? 1.0 : 0.0;
     }
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
       const bool in_sun = (i >= i_start) && (i < i_end);
       double rI = 0.0;
       for (int k = 0; k < n; ++k) rI += Rsurf[i + (size_t)N * (i_start + k)] * a.I0[k];
-      x[J0P][(size_t)N * pt + i] = (in_sun ? a.I0[i - i_start] : 0.0) * att;
-      x[J0M][(size_t)N * pt + i] = (a.mu0 * rI) * att;
+      x[J0P][(size_t)P * pt + i] = (in_sun ? a.I0[i - i_start] : 0.0) * att;
+      x[J0M][(size_t)P * pt + i] = (a.mu0 * rI) * att;
     }
     return;
   }
@@ -859,10 +861,11 @@ __global__ void k_surface_fill(KArgs a, const double *tau_tot, int kind, const d
   const double tdiag = (kind == 2 && a.m > 0) ? 0.0 : 1.0;
   for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
     const int j = e / N, i = e - j * N;
-    x[R_MP][NN * pt + e] = (a.m == 0 && (i % n == 0) && (j % n == 0)) ? rho * (a.mu[j] * a.wt[j]) : 0.0;
-    if (a.m == 0) x[R_PM][NN * pt + e] = 0.0;  // not reset for m > 0 (:68-73)
-    x[T_PP][NN * pt + e] = (i == j) ? tdiag : 0.0;
-    x[T_MM][NN * pt + e] = (i == j) ? tdiag : 0.0;
+    const size_t o = BS * pt + i + (size_t)P * j;
+    x[R_MP][o] = (a.m == 0 && (i % n == 0) && (j % n == 0)) ? rho * (a.mu[j] * a.wt[j]) : 0.0;
+    if (a.m == 0) x[R_PM][o] = 0.0;  // not reset for m > 0 (:68-73)
+    x[T_PP][o] = (i == j) ? tdiag : 0.0;
+    x[T_MM][o] = (i == j) ? tdiag : 0.0;
   }
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     const bool in_sun = (i >= i_start) && (i < i_end);
@@ -874,8 +877,8 @@ __global__ void k_surface_fill(KArgs a, const double *tau_tot, int kind, const d
         jm = (i % n == 0) ? (a.mu0 * (rho * a.I0[0])) * att : 0.0;
       }
     }
-    x[J0P][(size_t)N * pt + i] = jp;
-    x[J0M][(size_t)N * pt + i] = jm;
+    x[J0P][(size_t)P * pt + i] = jp;
+    x[J0M][(size_t)P * pt + i] = jm;
   }
 }
 
@@ -884,7 +887,7 @@ __global__ void k_surface_fill(KArgs a, const double *tau_tot, int kind, const d
 // surface interaction) + postprocessing_vza_hdrf! (postprocessing_vza.jl:63-93).
 // out = [R | T | ieR | ieT | hdr][nVza, nS, S] then bhr_uw, bhr_dw [nS, S]
 __global__ void k_post(KArgs a, int nVza, const int *node, const double *cosm, const double *sinm, int M, double *out) {
-  const int N = a.N, n = a.nS;
+  const int N = a.N, n = a.nS, P = a.P;
   const size_t tot = (size_t)nVza * n * a.S;
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= tot) return;
@@ -892,32 +895,51 @@ __global__ void k_post(KArgs a, int nVza, const int *node, const double *cosm, c
   if (pt < a.n1_lo || pt >= a.n1_hi) return;
   const int row = n * (node[v] - 1) + s;
   const double cs = a.weight * ((s < 2) ? cosm[v + nVza * a.m] : sinm[v + nVza * a.m]);
-  const double *J0p = a.c_cur[C_J0P] + (size_t)N * pt;
-  out[e] += cs * a.c_cur[C_J0M][row + (size_t)N * pt];
+  const double *J0p = a.c_cur[C_J0P] + (size_t)P * pt;
+  out[e] += cs * a.c_cur[C_J0M][row + (size_t)P * pt];
   out[tot + e] += cs * J0p[row];
   double sm = 0.0, sp = 0.0;
   for (int t = 0; t < a.nR; ++t) {
-    const size_t o = row + (size_t)N * ((size_t)pt + (size_t)a.S * t);
+    const size_t o = row + (size_t)P * ((size_t)pt + (size_t)a.S * t);
     sm += cs * a.ie_c[C_J0M][o];
     sp += cs * a.ie_c[C_J0P][o];
   }
   out[2 * tot + e] += sm;
   out[3 * tot + e] += sp;
-  const double *rs = a.x[R_MP] + (size_t)N * N * pt;   // the surface layer
-  double hj = a.x[J0M][row + (size_t)N * pt];
-  for (int j = 0; j < N; ++j) hj += rs[row + (size_t)N * j] * J0p[j];
+  const double *rs = a.x[R_MP] + (size_t)P * P * pt;   // the surface layer
+  double hj = a.x[J0M][row + (size_t)P * pt];
+  for (int j = 0; j < N; ++j) hj += rs[row + (size_t)P * j] * J0p[j];
   out[4 * tot + e] += cs * hj;
   if (a.m == 0 && v == 0) {  // bhr_uw / bhr_dw of Stokes component s (interaction_hdrf.jl:28-43)
     double up = 0.0, dw = 0.0;
     for (int jj = s; jj < N; jj += n) {
-      double h2 = a.x[J0M][jj + (size_t)N * pt];
-      for (int j = 0; j < N; ++j) h2 += rs[jj + (size_t)N * j] * J0p[j];
+      double h2 = a.x[J0M][jj + (size_t)P * pt];
+      for (int j = 0; j < N; ++j) h2 += rs[jj + (size_t)P * j] * J0p[j];
       up += h2 * a.wt[jj] * a.mu[jj];
       dw += J0p[jj] * a.wt[jj] * a.mu[jj];
     }
     const int i0 = n * (a.imu0 - 1);
     out[5 * tot + s + (size_t)n * pt] = up;
-    out[5 * tot + (size_t)n * a.S + s + (size_t)n * pt] = dw + a.x[J0P][i0 + (size_t)N * pt] * a.mu[i0];
+    out[5 * tot + (size_t)n * a.S + s + (size_t)n * pt] = dw + a.x[J0P][i0 + (size_t)P * pt] * a.mu[i0];
+  }
+}
+
+// ABI order <-> device blocks: `nat` holds nblk blocks of rows x cols doubles (column-major, the reference's memory order),
+// `dev` the same blocks at pitch P with zero padding (cols = 1: vectors, block stride P; else block stride P x P).
+__global__ void k_pack(double *dev, const double *nat, int rows, int cols, int P, size_t nblk) {
+  const size_t bs = (cols == 1) ? (size_t)P : (size_t)P * P, tot = bs * nblk;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = e / bs;
+    const int w = (int)(e - b * bs), i = w % P, j = w / P;
+    dev[e] = (i < rows && j < cols) ? nat[(size_t)rows * cols * b + i + (size_t)rows * j] : 0.0;
+  }
+}
+__global__ void k_unpack(double *nat, const double *dev, int rows, int cols, int P, size_t nblk) {
+  const size_t nb = (size_t)rows * cols, tot = nb * nblk, bs = (cols == 1) ? (size_t)P : (size_t)P * P;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = e / nb;
+    const int w = (int)(e - b * nb), i = w % rows, j = w / rows;
+    nat[e] = dev[bs * b + i + (size_t)P * j];
   }
 }
 
@@ -932,7 +954,7 @@ __global__ void k_post(KArgs a, int nVza, const int *node, const double *cosm, c
 
 static KArgs base_args(const State *s, const Streams &q) {
   KArgs a{};
-  a.N = s->N; a.nS = s->nS; a.S = s->S; a.nR = s->nR;
+  a.N = s->N; a.nS = s->nS; a.S = s->S; a.nR = s->nR; a.P = s->P;
   a.strict_idx = q.strict_idx; a.strict_rrs = s->strict_rrs;
   a.n_glob0 = s->n_glob0; a.n1_lo = s->n1_lo; a.n1_hi = s->n1_hi;
   a.imu0 = q.imu0; a.mu0 = q.mu0;
@@ -966,8 +988,9 @@ hipError_t create(State **out, hipStream_t st, int N, int nS, int S, int nR, con
   State *s = new State;
   s->N = N; s->nS = nS; s->S = S; s->nR = nR; s->strict_rrs = strict_rrs; s->stream = st;
   s->n1_lo = 0; s->n1_hi = S;
+  s->P = N <= 16 ? 16 : 32;  // device blocks are zero-padded to the MFMA tiling: P x P per matrix, P per vector
   *out = s;
-  const size_t NN = (size_t)N * N, m3 = NN * S, v3 = (size_t)N * S, m4 = m3 * nR, v4 = v3 * nR;
+  const size_t NN = (size_t)s->P * s->P, m3 = NN * S, v3 = (size_t)s->P * S, m4 = m3 * nR, v4 = v3 * nR;
   RCHK(dm(&s->d_off, nR));
   RCHK(dm(&s->d_varpiR, nR));
   RCHK(hipMemcpy(s->d_off, off_host, sizeof(int) * nR, hipMemcpyHostToDevice));
@@ -996,8 +1019,37 @@ hipError_t create(State **out, hipStream_t st, int N, int nS, int S, int nR, con
   return hipSuccess;
 }
 
+// one array of the layers between the ABI's memory order (host) and the padded device blocks; nblk = S or S x nR
+hipError_t upload(State *s, double *dev, const double *host, bool matrix, size_t nblk) {
+  const size_t nat = (size_t)s->N * (matrix ? s->N : 1) * nblk;
+  if (nat > s->stage_cap) {
+    (void)hipFree(s->d_stage);
+    s->d_stage = nullptr; s->stage_cap = 0;
+    RCHK(hipMalloc(reinterpret_cast<void **>(&s->d_stage), nat * sizeof(double)));
+    s->stage_cap = nat;
+  }
+  RCHK(hipMemcpyAsync(s->d_stage, host, nat * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_pack, dim3(2048), dim3(256), 0, s->stream, dev, s->d_stage, s->N, matrix ? s->N : 1, s->P, nblk);
+  RCHK(hipGetLastError());
+  return hipStreamSynchronize(s->stream);
+}
+hipError_t download(State *s, double *host, const double *dev, bool matrix, size_t nblk) {
+  const size_t nat = (size_t)s->N * (matrix ? s->N : 1) * nblk;
+  if (nat > s->stage_cap) {
+    (void)hipFree(s->d_stage);
+    s->d_stage = nullptr; s->stage_cap = 0;
+    RCHK(hipMalloc(reinterpret_cast<void **>(&s->d_stage), nat * sizeof(double)));
+    s->stage_cap = nat;
+  }
+  hipLaunchKernelGGL(k_unpack, dim3(2048), dim3(256), 0, s->stream, s->d_stage, dev, s->N, matrix ? s->N : 1, s->P, nblk);
+  RCHK(hipGetLastError());
+  RCHK(hipMemcpyAsync(host, s->d_stage, nat * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  return hipStreamSynchronize(s->stream);
+}
+
 void destroy(State *s) {
   if (!s) return;
+  (void)hipFree(s->d_stage);
   (void)hipFree(s->d_off); (void)hipFree(s->d_varpiR); (void)hipFree(s->jpseq); (void)hipFree(s->d_out); (void)hipFree(s->d_info);
   for (int b = 0; b < 2; ++b) {
     for (int k = 0; k < 6; ++k) {
@@ -1127,7 +1179,7 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
   KArgs a = base_args(s, q);
   if (s->strict_rrs) {
     if (s->nS == 1) {  // doubling_inelastic.jl:411-414: whole-array copies
-      const size_t cnt = (size_t)s->N * s->N * s->S * s->nR;
+      const size_t cnt = (size_t)s->P * s->P * s->S * s->nR;
       hipLaunchKernelGGL(k_copy2, dim3(2048), dim3(256), 0, s->stream, s->ie_added[R_MP], s->ie_added[R_PM], s->ie_added[T_PP],
                          s->ie_added[T_MM], cnt);
     } else {
@@ -1144,7 +1196,7 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
 
 hipError_t copy_added_to_composite(State *s, const Streams &q) {
   RCHK(ensure_pm(s, q));
-  const size_t NN = (size_t)s->N * s->N, m3 = NN * s->S * 8, v3 = (size_t)s->N * s->S * 8, m4 = m3 * s->nR, v4 = v3 * s->nR;
+  const size_t NN = (size_t)s->P * s->P, m3 = NN * s->S * 8, v3 = (size_t)s->P * s->S * 8, m4 = m3 * s->nR, v4 = v3 * s->nR;
   static const int amap[6] = {R_MP, R_PM, T_PP, T_MM, J0P, J0M};  // composite field k <- added field amap[k]
   for (int k = 0; k < 6; ++k) {
     RCHK(hipMemcpyAsync(s->comp[s->ccur][k], s->added[s->cur][amap[k]], k < 4 ? m3 : v3, hipMemcpyDeviceToDevice, s->stream));
@@ -1167,7 +1219,7 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
   if (!with_surface) { a.x[R_PM] = s->added[0][R_PM]; a.x[T_MM] = s->added[0][T_MM]; }
   LAUNCH_NT(s, k_int_point, grid_points(s), a, iface);
   if (iface == 0) {  // interaction_inelastic.jl:16-17
-    const size_t v4 = (size_t)s->N * s->S * s->nR * 8;
+    const size_t v4 = (size_t)s->P * s->S * s->nR * 8;
     RCHK(hipMemsetAsync(s->ie_comp[C_J0P], 0, v4, s->stream));
     RCHK(hipMemsetAsync(s->ie_comp[C_J0M], 0, v4, s->stream));
   } else {

@@ -25,6 +25,8 @@ enum { C_R_MP = 0, C_R_PM = 1, C_T_PP = 2, C_T_MM = 3, C_J0P = 4, C_J0M = 5 };  
 
 struct State {
   int N = 0, nS = 0, S = 0, nR = 0;
+  int P = 16;              // row pitch of every device block: 16 (N <= 16) or 32; matrices P x P, vectors P, zero padding --
+                           // the tile loads of the kernels are then unmasked, 128-byte aligned and at immediate offsets
   int strict_rrs = 1;      // rrs_strict_reference (DESIGN.md "RRS": D1..D5)
   int n_glob0 = 0;         // global 0-based spectral index of local index 0 (shards; strict D2/D3 use absolute indices)
   int n1_lo = 0, n1_hi = 0;  // spectral points this rank owns: pairs (n1, dn) are processed for n1 in [n1_lo, n1_hi)
@@ -49,6 +51,8 @@ struct State {
   double *d_out = nullptr;      // R_SFI | T_SFI | ieR_SFI | ieT_SFI | hdr [5][nVza,nS,S], then bhr_uw | bhr_dw [2][nS,S]
   int out_nVza = 0;
   int *d_info = nullptr;
+  double *d_stage = nullptr;    // ABI-order staging of upload / download
+  size_t stage_cap = 0;
   // fast scene-level mode (mom_rt_run_rrs): the inelastic elemental of a layer with ndoubl >= 1 is deferred into the first
   // doubling step (el_pending + its inputs), and in the corrected position ier+- / iet-- are not stored by the doubling but
   // derived where they are read (pm_derivable); pm_valid says whether the arrays themselves hold the current values
@@ -68,6 +72,9 @@ hipError_t timing_read(State *s, double *ms, int *launches);
 hipError_t create(State **out, hipStream_t st, int N, int nS, int S, int nR, const int *off_host, const double *varpi_host,
                   int strict_rrs, std::string *err);
 void destroy(State *s);
+// one layer array between the ABI's memory order (host, [N,N,nblk] or [N,nblk]) and the padded device blocks (synchronous)
+hipError_t upload(State *s, double *dev, const double *host, bool matrix, size_t nblk);
+hipError_t download(State *s, double *host, const double *dev, bool matrix, size_t nblk);
 
 // elemental!(...) elastic part + elemental_inelastic!(::RRS) on the persistent added layer.  Zpp/Zmp: device [N,N] x nTerms with
 // per-point weights zw [nTerms,S] (zw == nullptr: one term of weight 1); Zr*: device [N,N] Raman phase matrices; all

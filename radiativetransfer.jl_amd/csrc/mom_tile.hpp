@@ -131,7 +131,17 @@ __device__ __forceinline__ Vec<NT> swap01(const Vec<NT> &v) {  // exchange colum
   return o;
 }
 
-// column-major [N, N] block -> X_t (coalesced) / X_c (strided)
+// Device blocks are stored at the pitch of the tiling, 16 NT, with ZERO padding (matrices 16 NT x 16 NT, vectors 16 NT):
+// the loads below carry no edge masks (the padding reads as the zeros a mask would have put there), their addresses are
+// one per-lane base plus immediates and every 16-lane row is one aligned 128-byte line; the stores keep the masks, so
+// the padding is never written (mom_rrs.hpp State::P).  Measured on the N = 16 RRS scene: 315 -> 275 ms per run.
+// The stores of the one-tile kernels (NT = 1, the reference's RRS shape N = 15) write the whole tile: every stored quantity
+// is a product / sum / sign flip of zero-padded operands or is built with its own i, j < N guards, so the padding stays zero by
+// value (C5: 331 -> 313 ms per run).  The 2 x 2-tile kernels keep masked stores: with unmasked ones k_dbl_pair<2, .> raised a
+// GPU memory fault at an address far from every buffer (scratch addressing of the 256-register image; not understood).
+template <int NT>
+__device__ __forceinline__ constexpr bool mask_store() { return NT > 1; }
+// column-major [N, N] block at pitch 16 NT -> X_t (coalesced) / X_c (strided)
 template <int NT>
 __device__ __forceinline__ Mat<NT> load_t(const Geo &g, const double *p) {
   Mat<NT> X;
@@ -142,7 +152,7 @@ __device__ __forceinline__ Mat<NT> load_t(const Geo &g, const double *p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ro = g.row(a, r), co = g.col(b);
-        X.t[a][b][r] = (ro < g.N && co < g.N) ? p[co + (size_t)g.N * ro] : 0.0;
+        X.t[a][b][r] = p[co + (16 * NT) * ro];
       }
   return X;
 }
@@ -156,7 +166,7 @@ __device__ __forceinline__ Mat<NT> load_c(const Geo &g, const double *p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ro = g.row(a, r), co = g.col(b);
-        X.t[a][b][r] = (ro < g.N && co < g.N) ? p[ro + (size_t)g.N * co] : 0.0;
+        X.t[a][b][r] = p[ro + (16 * NT) * co];
       }
   return X;
 }
@@ -169,7 +179,7 @@ __device__ __forceinline__ void store_t(const Geo &g, double *p, const Mat<NT> &
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ro = g.row(a, r), co = g.col(b);
-        if (ro < g.N && co < g.N) p[co + (size_t)g.N * ro] = X.t[a][b][r];
+        if (!mask_store<NT>() || (ro < g.N && co < g.N)) p[co + (16 * NT) * ro] = X.t[a][b][r];
       }
 }
 // two vectors [N] as columns 0 and 1 (nullptr: zeros)
@@ -182,7 +192,7 @@ __device__ __forceinline__ Vec<NT> loadv2(const Geo &g, const double *p0, const 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ro = g.row(a, r);
-      v.t[a][r] = (p != nullptr && ro < g.N) ? p[ro] : 0.0;
+      v.t[a][r] = (p != nullptr) ? p[ro] : 0.0;
     }
   return v;
 }
@@ -194,7 +204,7 @@ __device__ __forceinline__ void storev(const Geo &g, double *p, const Vec<NT> &v
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ro = g.row(a, r);
-      if (ro < g.N) p[ro] = v.t[a][r];
+      if (!mask_store<NT>() || ro < g.N) p[ro] = v.t[a][r];
     }
 }
 
@@ -217,7 +227,7 @@ __device__ __forceinline__ Vec<NT> loadR(const Geo &g, const double *p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ro = g.row(a, r);
-      v.t[a][r] = (ro < g.N) ? p[ro] : 0.0;
+      v.t[a][r] = p[ro];
     }
   return v;
 }
@@ -225,7 +235,7 @@ template <int NT>
 __device__ __forceinline__ CV<NT> loadC(const Geo &g, const double *p) {
   CV<NT> v;
 #pragma unroll
-  for (int b = 0; b < NT; ++b) v.c[b] = (g.col(b) < g.N) ? p[g.col(b)] : 0.0;
+  for (int b = 0; b < NT; ++b) v.c[b] = p[g.col(b)];
   return v;
 }
 template <int NT>
@@ -240,7 +250,7 @@ __device__ __forceinline__ void storeC(const Geo &g, double *p, const CV<NT> &v)
   if (g.lq != 0) return;
 #pragma unroll
   for (int b = 0; b < NT; ++b)
-    if (g.col(b) < g.N) p[g.col(b)] = v.c[b];
+    if (!mask_store<NT>() || g.col(b) < g.N) p[g.col(b)] = v.c[b];
 }
 template <int NT>
 __device__ __forceinline__ CV<NT> cadd(const CV<NT> &A, const CV<NT> &B) {

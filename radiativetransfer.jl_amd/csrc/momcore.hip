@@ -2454,13 +2454,12 @@ static int rrs_check(mom_t *h) {
   return MOM_OK;
 }
 
-static double *rrs_which(mom_t *h, int which, size_t *count) {
+static double *rrs_which(mom_t *h, int which, bool *matrix, size_t *nblk) {
   momr::State *s = h->rrs;
-  const size_t NN = (size_t)s->N * s->N, m3 = NN * s->S, v3 = (size_t)s->N * s->S;
   if (which < 0 || which >= 30) return nullptr;
   const int grp = which / 6, k = which % 6;
-  const bool mat = k < 4;
-  *count = (mat ? m3 : v3) * (grp >= 3 ? (size_t)s->nR : 1);
+  *matrix = k < 4;
+  *nblk = (size_t)s->S * (grp >= 3 ? (size_t)s->nR : 1);
   switch (grp) {
     case 0: return s->added[(k == momr::R_PM || k == momr::T_MM) ? 0 : s->cur][k];
     case 1: return s->comp[s->ccur][k];
@@ -2472,26 +2471,26 @@ static double *rrs_which(mom_t *h, int which, size_t *count) {
 extern "C" int mom_rrs_upload(mom_t *h, int which, const double *src) {
   int rc = rrs_ready(h, "mom_rrs_upload");
   if (rc) return rc;
-  size_t count = 0;
-  double *p = rrs_which(h, which, &count);
+  bool matrix = false;
+  size_t nblk = 0;
+  double *p = rrs_which(h, which, &matrix, &nblk);
   if (!p || !src) return fail(h, MOM_EINVAL, "mom_rrs_upload: bad argument");
   if (which >= 18 && which < 24) {
     RRSCHK(h, momr::ensure_pm(h->rrs, rrs_streams(h)));
     momr::mark_uploaded(h->rrs);
   }
-  HIPCHK(h, hipMemcpyAsync(p, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, momr::upload(h->rrs, p, src, matrix, nblk));  // ABI memory order -> padded device blocks
   return MOM_OK;
 }
 extern "C" int mom_rrs_download(mom_t *h, int which, double *dst) {
   int rc = rrs_ready(h, "mom_rrs_download");
   if (rc) return rc;
-  size_t count = 0;
-  double *p = rrs_which(h, which, &count);
+  bool matrix = false;
+  size_t nblk = 0;
+  double *p = rrs_which(h, which, &matrix, &nblk);
   if (!p || !dst) return fail(h, MOM_EINVAL, "mom_rrs_download: bad argument");
   if (which >= 18 && which < 24) RRSCHK(h, momr::ensure_pm(h->rrs, rrs_streams(h)));
-  HIPCHK(h, hipMemcpyAsync(dst, p, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, momr::download(h->rrs, dst, p, matrix, nblk));
   return MOM_OK;
 }
 
