@@ -464,13 +464,16 @@ __device__ __forceinline__ void ie_elem_tile(const Geo &g, const KArgs &a, int n
 // ---------------------------------------------------------------------------------------------------------------------
 // doubling step, PAIR kernel (doubling_inelastic.jl:61-89 and :98-125)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT, bool FUSE>
+// MODE: 0 corrected position, not the last step; 1 corrected, last step (D2 / D3 folded into the stores); 2 strict position.
+// The mode is a template parameter like FUSE: as run-time flags these branches cost a register move per tile element.
+template <int NT, bool FUSE, int MODE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair(KArgs a) {
+  constexpr bool STRICT = (MODE == 2);
   const Geo g = make_geo<NT>(a.N, rrs_smem);
   const int n = a.nS, wave = threadIdx.x >> 6;
   const size_t NN = (size_t)a.P * a.P, VS = a.P;  // block strides (padded pitch)
   const size_t npairs = (size_t)(a.n1_hi - a.n1_lo) * a.nR;
-  const bool fuseD = a.last && !a.strict_rrs;  // D2/D3 (corrected) folded into the last step's stores
+  constexpr bool fuseD = (MODE == 1);  // a.last && !strict: D2/D3 (corrected) folded into the last step's stores
   for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += (size_t)gridDim.x * kWavesPerBlock) {
     const int n1 = a.n1_lo + (int)(p % (size_t)(a.n1_hi - a.n1_lo)), dn = (int)(p / (size_t)(a.n1_hi - a.n1_lo));
     const int n0 = n1 + a.off[dn];
@@ -525,13 +528,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair
     {
       const double e1 = a.expk_cur[n1];
       const CV<NT> J1p = cscale<NT>(Jp, e1), J1m = cscale<NT>(Jm, e1);                           // ieJ1+, ieJ1-   :52-56
-      const double *jp0 = a.strict_rrs ? a.jpseq + v0 + VS * a.S * dn : a.a_cur[J0P] + v0;
+      const double *jp0 = STRICT ? a.jpseq + v0 + VS * a.S * dn : a.a_cur[J0P] + v0;
       const CV<NT> a_j1m = mv_t<NT>(g, a_t, loadR<NT>(g, a.sv[SV_J1M] + v0));                    // ier j1-[n0]
       const CV<NT> a_jp = mv_t<NT>(g, a_t, loadR<NT>(g, jp0));                                   // ier j0+[n0]
       const Vec<NT> tm1 = loadR<NT>(g, a.sv[SV_TMP1] + v0), tm2 = loadR<NT>(g, a.sv[SV_TMP2] + v0);
       const CV<NT> X1 = mv_t<NT>(g, X_t, tm1), X2 = mv_t<NT>(g, X_t, tm2);
       const CV<NT> b1 = mv_t<NT>(g, b_t, tm1);                                                   // iet++ tmp1
-      const CV<NT> b2 = a.strict_rrs ? mv_t<NT>(g, load_t<NT>(g, a.ie_a[T_MM] + o4), tm2)        // D5: iet-- as the array holds it
+      const CV<NT> b2 = STRICT ? mv_t<NT>(g, load_t<NT>(g, a.ie_a[T_MM] + o4), tm2)        // D5: iet-- as the array holds it
                                      : mv_t<NT>(g, b_t, tm2);
       const CV<NT> uu = cadd<NT>(cadd<NT>(Jp, mv_t<NT>(g, r1_t, c2r<NT>(g, J1m))), cadd<NT>(a_j1m, X1));
       const CV<NT> Jpn = cadd<NT>(cadd<NT>(J1p, mv_t<NT>(g, ttgp1_t, c2r<NT>(g, uu))), b1);      // new ieJ0+
@@ -1164,13 +1167,16 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
     RCHK(tick(s, TK_DBL_PAIR, true));
     {
       const dim3 gr(grid_pairs(s)), bl(64 * kWavesPerBlock);
+      const int mode = s->strict_rrs ? 2 : (a.last ? 1 : 0);
+#define DBL_PAIR(NT_, FUSE_, MODE_) hipLaunchKernelGGL((k_dbl_pair<NT_, FUSE_, MODE_>), gr, bl, lds<NT_>(), s->stream, a)
+#define DBL_PAIR_M(NT_, FUSE_) do { if (mode == 0) DBL_PAIR(NT_, FUSE_, 0); else if (mode == 1) DBL_PAIR(NT_, FUSE_, 1); else DBL_PAIR(NT_, FUSE_, 2); } while (0)
       if (s->N <= 16) {
-        if (a.fuse_el) hipLaunchKernelGGL((k_dbl_pair<1, true>), gr, bl, lds<1>(), s->stream, a);
-        else hipLaunchKernelGGL((k_dbl_pair<1, false>), gr, bl, lds<1>(), s->stream, a);
+        if (a.fuse_el) DBL_PAIR_M(1, true); else DBL_PAIR_M(1, false);
       } else {
-        if (a.fuse_el) hipLaunchKernelGGL((k_dbl_pair<2, true>), gr, bl, lds<2>(), s->stream, a);
-        else hipLaunchKernelGGL((k_dbl_pair<2, false>), gr, bl, lds<2>(), s->stream, a);
+        if (a.fuse_el) DBL_PAIR_M(2, true); else DBL_PAIR_M(2, false);
       }
+#undef DBL_PAIR_M
+#undef DBL_PAIR
       RCHK(hipGetLastError());
     }
     RCHK(tick(s, TK_DBL_PAIR, false));

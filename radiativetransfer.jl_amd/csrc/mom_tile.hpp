@@ -59,14 +59,14 @@ __device__ __forceinline__ Vec<NT> vzeros() {
   return Z;
 }
 
-// acc + U^T V; k-steps whose rows are all >= N (zero padding) are skipped
+// acc + U^T V; in the 2 x 2-tile kernels k-steps whose rows are all >= N (zero padding) are skipped
 template <int NT>
 __device__ __forceinline__ Mat<NT> TNacc(const Geo &g, const Mat<NT> &U, const Mat<NT> &V, Mat<NT> acc) {
 #pragma unroll
   for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      if (16 * tk + 4 * s < g.N) {
+      if (NT == 1 || 16 * tk + 4 * s < g.N) {  // one tile: all four k-steps, unguarded (a guard is a branch around every MFMA)
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -86,7 +86,7 @@ __device__ __forceinline__ Vec<NT> TNvacc(const Geo &g, const Mat<NT> &U, const 
   for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      if (16 * tk + 4 * s < g.N) {
+      if (NT == 1 || 16 * tk + 4 * s < g.N) {  // one tile: all four k-steps, unguarded (a guard is a branch around every MFMA)
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
           o.t[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(U.t[tk][ti][s], v.t[tk][s], o.t[ti], 0, 0, 0);

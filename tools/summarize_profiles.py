@@ -17,7 +17,7 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 out = ROOT / "profiles"
 out.mkdir(exist_ok=True)
 DOMINANT = {"C2": "mom::k_layer<true, 3, 15>", "C4": "mom::k_layer<false, 3, 0>", "C1": "momsm::k_sweep<4>",
-            "C5": "momr::k_dbl_pair<1, false>"}
+            "C5": "momr::k_dbl_pair<1, false, 0>"}
 
 
 def newest(pattern):
