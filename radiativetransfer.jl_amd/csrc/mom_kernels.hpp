@@ -243,6 +243,61 @@ __device__ __forceinline__ void wg_matvec(const Ctx &c, FM M, const real *x, rea
   __syncthreads();
 }
 
+// Generic mode: M is a padded buffer of the GLOBAL slab (N > 64: 512 KB at N = 256).  The element loop above keeps four
+// 8-byte loads in flight per lane and is latency-bound there (two passes over r and Q per doubling step: 7.7 % of the C4
+// run); here a lane owns two row pairs and walks its wave's column chunk eight columns at a time: sixteen 16-byte loads
+// in flight.  NV = 1: y1 = M x1; NV = 2: also y2 = M x2 in the same pass.  y may alias x.  Ends with a barrier.
+template <int NV>
+__device__ __forceinline__ void wg_matvec_slab(const Ctx &c, const real *M, const real *x1, const real *x2, real *y1, real *y2) {
+  typedef real r2 __attribute__((ext_vector_type(2)));
+  const int N = c.N, ld = c.ld, lane = wg_lane(), wave = wg_wave();
+  const int chunk = (N + kWaves - 1) / kWaves;
+  const int k0 = wave * chunk, k1 = min(N, k0 + chunk);
+  for (int ib = 0; ib < N; ib += 256) {
+    int i0 = ib + 2 * lane, i1 = i0 + 128;
+    const int c0 = i0 < c.Np - 2 ? i0 : c.Np - 2, c1 = i1 < c.Np - 2 ? i1 : c.Np - 2;  // rows < ld = Np + 2 exist
+    r2 s10 = {0.0, 0.0}, s11 = {0.0, 0.0}, s20 = {0.0, 0.0}, s21 = {0.0, 0.0};
+    for (int k = k0; k < k1; k += 8) {
+      r2 m0[8], m1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = k + u < k1 ? k + u : k1 - 1;
+        m0[u] = *(const r2 *)(M + c0 + (size_t)kk * ld);
+        m1[u] = *(const r2 *)(M + c1 + (size_t)kk * ld);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool in = k + u < k1;
+        const real a = in ? x1[k + u] : 0.0;
+        s10 += m0[u] * a;
+        s11 += m1[u] * a;
+        if (NV == 2) {
+          const real b = in ? x2[k + u] : 0.0;
+          s20 += m0[u] * b;
+          s21 += m1[u] * b;
+        }
+      }
+    }
+    real *p1 = c.part + wave * c.ldv, *p2 = c.part + (kWaves + wave) * c.ldv;
+    if (i0 < N) { p1[i0] = s10.x; if (NV == 2) p2[i0] = s20.x; }
+    if (i0 + 1 < N) { p1[i0 + 1] = s10.y; if (NV == 2) p2[i0 + 1] = s20.y; }
+    if (i1 < N) { p1[i1] = s11.x; if (NV == 2) p2[i1] = s21.x; }
+    if (i1 + 1 < N) { p1[i1 + 1] = s11.y; if (NV == 2) p2[i1 + 1] = s21.y; }
+  }
+  __syncthreads();
+  for (int i = wg_tid(); i < N; i += kThreads) {
+    real s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      s1 += c.part[w * c.ldv + i];
+      if (NV == 2) s2 += c.part[(kWaves + w) * c.ldv + i];
+    }
+    y1[i] = s1;
+    if (NV == 2) y2[i] = s2;
+  }
+  __syncthreads();
+}
+
 // dst(i,j) <- f(i, j, sum_k A(i,k) B(k,j), dst_old(i,j)); dst may be an operand of A/B.
 // LDS mode: true in place (SYNC); generic mode: written to the spare buffer, then swapped.
 template <bool LDSM, class FA, class FB, class FV>
@@ -869,13 +924,15 @@ __device__ __forceinline__ real doubling_run(Ctx &c, int nd, real expk) {
       }
       __syncthreads();
       // v1 = r j0+ ; v2 = r j1-
-      wg_matvec2(N, c.ldv, ElP{r, ld}, c.jp, c.j1m, c.v1, c.v2, c.part);
+      if constexpr (LDSM) wg_matvec2(N, c.ldv, ElP{r, ld}, c.jp, c.j1m, c.v1, c.v2, c.part);
+      else wg_matvec_slab<2>(c, r, c.jp, c.j1m, c.v1, c.v2);
       for (int i = wg_tid(); i < N; i += kThreads) {
         c.v1[i] = c.j1m[i] + c.v1[i];  // j1- + r j0+
         c.v2[i] = c.jp[i] + c.v2[i];   // j0+ (old) + r j1-
       }
       __syncthreads();
-      wg_matvec2(N, c.ldv, ElP{Q, ld}, c.v1, c.v2, c.v1, c.v2, c.part);
+      if constexpr (LDSM) wg_matvec2(N, c.ldv, ElP{Q, ld}, c.v1, c.v2, c.v1, c.v2, c.part);
+      else wg_matvec_slab<2>(c, Q, c.v1, c.v2, c.v1, c.v2);
       for (int i = wg_tid(); i < N; i += kThreads) {
         c.jm[i] = c.jm[i] + c.v1[i];   // :57
         c.jp[i] = c.j1p[i] + c.v2[i];  // :60
@@ -1055,10 +1112,12 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     MOM_STAMP(13);
     if (!ride) {
       // J0- = J0- + T01 (r-+ J0+ + j0-)                          (:90)
-      wg_matvec(c, ElP{r, ld}, c.Jp, c.v1);
+      if constexpr (LDSM) wg_matvec(c, ElP{r, ld}, c.Jp, c.v1);
+      else wg_matvec_slab<1>(c, r, c.Jp, nullptr, c.v1, nullptr);
       for (int i = wg_tid(); i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
       __syncthreads();
-      wg_matvec(c, ElP{c.P, ld}, c.v1, c.v2);
+      if constexpr (LDSM) wg_matvec(c, ElP{c.P, ld}, c.v1, c.v2);
+      else wg_matvec_slab<1>(c, c.P, c.v1, nullptr, c.v2, nullptr);
       for (int i = wg_tid(); i < N; i += kThreads) c.Jm[i] = c.Jm[i] + c.v2[i];
     }
     MOM_STAMP(14);
@@ -1089,7 +1148,8 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     }
     if (!ride) {
       // w = J0+ + R+- j0-  (kept in j1p; j1p/j1m are free outside doubling)
-      wg_matvec(c, ElP{c.Q, ld}, c.jm, c.v1);
+      if constexpr (LDSM) wg_matvec(c, ElP{c.Q, ld}, c.jm, c.v1);
+      else wg_matvec_slab<1>(c, c.Q, c.jm, nullptr, c.v1, nullptr);
       for (int i = wg_tid(); i < N; i += kThreads) c.j1p[i] = c.Jp[i] + c.v1[i];
     }
     {
@@ -1111,7 +1171,8 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     MOM_STAMP(20);
     if (!ride) {
       // J0+ = j0+ + T21 (J0+ + R+- j0-)                          (:110)
-      wg_matvec(c, ElP{c.Q, ld}, c.j1p, c.v2);
+      if constexpr (LDSM) wg_matvec(c, ElP{c.Q, ld}, c.j1p, c.v2);
+      else wg_matvec_slab<1>(c, c.Q, c.j1p, nullptr, c.v2, nullptr);
       for (int i = wg_tid(); i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.v2[i];
     }
     MOM_STAMP(21);
