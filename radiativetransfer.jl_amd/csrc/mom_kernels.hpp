@@ -243,6 +243,63 @@ __device__ __forceinline__ void wg_matvec(const Ctx &c, FM M, const real *x, rea
   __syncthreads();
 }
 
+// Generic mode: dst = I + src (NEG: I - src) over a padded slab buffer, flat 16-byte pairs with eight in flight per lane
+// (the padding rows are copied along; dst may be src).  Needs a barrier after.
+template <bool NEG>
+__device__ __forceinline__ void slab_eye_plus(const Ctx &c, real *dst, const real *src) {
+  typedef real r2 __attribute__((ext_vector_type(2)));
+  const int N = c.N, ld = c.ld, tot2 = (ld * N) >> 1;  // ld is even
+  for (int e0 = wg_tid(); e0 < tot2; e0 += 8 * kThreads) {
+    r2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * kThreads;
+      if (e < tot2) v[u] = *(const r2 *)(src + 2 * e);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * kThreads;
+      if (e < tot2) {
+        r2 w = NEG ? -v[u] : v[u];
+        // element 2 e is (i, j) with i + j ld = 2 e: the diagonal i = j sits at j (ld + 1)
+        const int j = (2 * e) / ld, i = 2 * e - j * ld;
+        if (i == j) w.x += 1.0;
+        if (i + 1 == j) w.y += 1.0;
+        *(r2 *)(dst + 2 * e) = w;
+      }
+    }
+  }
+}
+
+// Generic mode: composite block (global, pitch ld_s) -> slab buffer (pitch ld_d) as 16-byte row pairs, eight columns in
+// flight per lane (wg_copy_mat moves 8-byte elements four at a time and divides per element: 3.6 % of the C4 run for the
+// five copies of an interaction).  N odd: element copy.
+template <bool LDSM, class PS>
+__device__ __forceinline__ void copy_to_slab(const Ctx &c, PS src, int ld_s, real *dst, int ld_d) {
+  const int N = c.N;
+  if (LDSM || (N & 1) || (ld_s & 1) || (ld_d & 1)) {
+    wg_copy_mat(N, c.fd, src, ld_s, dst, ld_d);
+    return;
+  }
+  typedef real r2 __attribute__((ext_vector_type(2)));
+  const real *sp = (const real *)src;
+  const int lane = wg_lane(), wave = wg_wave(), hp = N >> 1;
+  for (int j0 = wave; j0 < N; j0 += 8 * kWaves)
+    for (int ip = lane; ip < hp; ip += 64) {
+      r2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + kWaves * u;
+        if (j < N) v[u] = *(const r2 *)(sp + 2 * ip + (size_t)j * ld_s);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + kWaves * u;
+        if (j < N) *(r2 *)(dst + 2 * ip + (size_t)j * ld_d) = v[u];
+      }
+    }
+}
+
 // Generic mode: M is a padded buffer of the GLOBAL slab (N > 64: 512 KB at N = 256).  The element loop above keeps four
 // 8-byte loads in flight per lane and is latency-bound there (two passes over r and Q per doubling step: 7.7 % of the C4
 // run); here a lane owns two row pairs and walks its wave's column chunk eight columns at a time: sixteen 16-byte loads
@@ -593,7 +650,10 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, real *&Bb, real *&Ob, re
     }
   } else if (p <= 32) {
     // G = (I + B)(I + B^2)(I + B^4)... ; Ob <- T G
-    {
+    if constexpr (!LDSM) {
+      slab_eye_plus<false>(c, Ob, Bb);
+      __syncthreads();
+    } else {
       real *o = Ob, *b = Bb;
       for (int e = wg_tid(); e < NN; e += kThreads) {
         int i, j;
@@ -609,10 +669,14 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, real *&Bb, real *&Ob, re
     gemm_to<LDSM>(c, Ob, T, ElP{Ob, ld}, [=](int, int, real v, real) { return v; });
   } else {
     real *b = Bb, *o = Ob;
-    for (int e = wg_tid(); e < NN; e += kThreads) {
-      int i, j;
-      c.fd.split(e, i, j);
-      b[i + j * ld] = ((i == j) ? 1.0 : 0.0) - b[i + j * ld];
+    if constexpr (!LDSM) {
+      slab_eye_plus<true>(c, b, b);
+    } else {
+      for (int e = wg_tid(); e < NN; e += kThreads) {
+        int i, j;
+        c.fd.split(e, i, j);
+        b[i + j * ld] = ((i == j) ? 1.0 : 0.0) - b[i + j * ld];
+      }
     }
     __syncthreads();
     if (N <= 64) wg_inverse_reg(N, b, ld, c.part, c.prow, c.ipiv, c.bad);  // part: >= 128 doubles (2*kWaves*ldv)
@@ -1021,14 +1085,14 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       c.Jm[i] = c.Jm[i] + c.v2[i];
     }
     // T-- = t-- T-- ; T++ = t++ T++                          (:20-21)
-    wg_copy_mat(N, c.fd, g.T_mm, cl, c.P, ld);
-    wg_copy_mat(N, c.fd, g.T_pp, cl, c.Q, ld);
+    copy_to_slab<LDSM>(c, g.T_mm, cl, c.P, ld);
+    copy_to_slab<LDSM>(c, g.T_pp, cl, c.Q, ld);
     __syncthreads();
     gdouble *Tmm = g.T_mm, *Tpp = g.T_pp;
     wg_gemm<false, !LDSM>(N, tmm, ElP{c.P, ld}, [=](int i, int j, real v) { Tmm[i + j * cl] = v; });
     wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{c.Q, ld}, [=](int i, int j, real v) { Tpp[i + j * cl] = v; });
   } else if ((IFACE < 0 || IFACE == 1) && iface == 1) {
-    wg_copy_mat(N, c.fd, g.T_mm, cl, c.P, ld);  // P = T--
+    copy_to_slab<LDSM>(c, g.T_mm, cl, c.P, ld);  // P = T--
     // J0- = J0- + T-- (r-+ J0+ + j0-) ; J0+ = j0+ + t++ J0+  (:36-37)
     wg_matvec(c, ElP{r, ld}, c.Jp, c.v1);
     for (int i = wg_tid(); i < N; i += kThreads) c.v1[i] = c.v1[i] + c.jm[i];
@@ -1046,7 +1110,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     gdouble *Rmp = g.R_mp, *Rpm = g.R_pm, *Tpp = g.T_pp, *Tmm = g.T_mm;
     wg_gemm<false, !LDSM>(N, ElP{Q, ld}, El{g.T_pp, cl, N}, [=](int i, int j, real v) { Rmp[i + j * cl] = v; });
     __syncthreads();
-    wg_copy_mat(N, c.fd, g.T_pp, cl, Q, ld);
+    copy_to_slab<LDSM>(c, g.T_pp, cl, Q, ld);
     __syncthreads();
     wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, real v) { Tpp[i + j * cl] = v; });
     wg_gemm<false, !LDSM>(N, ElP{P, ld}, tmm, [=](int i, int j, real v) { Tmm[i + j * cl] = v; });
@@ -1057,8 +1121,8 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     }
   } else if ((IFACE < 0 || IFACE == 2) && iface == 2) {
     real *P = c.P, *Q = c.Q;
-    wg_copy_mat(N, c.fd, g.R_pm, cl, P, ld);  // P = R+-
-    wg_copy_mat(N, c.fd, g.T_mm, cl, Q, ld);  // Q = T--
+    copy_to_slab<LDSM>(c, g.R_pm, cl, P, ld);  // P = R+-
+    copy_to_slab<LDSM>(c, g.T_mm, cl, Q, ld);  // Q = T--
     __syncthreads();
     // J0+ = j0+ + t++ (J0+ + R+- j0-) ; J0- = J0- + T-- j0-   (:58-59)
     wg_matvec(c, ElP{P, ld}, c.jm, c.v1);
@@ -1074,7 +1138,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     gdouble *Tpp = g.T_pp, *Tmm = g.T_mm, *Rpm = g.R_pm;
     wg_gemm<false, !LDSM>(N, ElP{Q, ld}, tmm, [=](int i, int j, real v) { Tmm[i + j * cl] = v; });
     __syncthreads();
-    wg_copy_mat(N, c.fd, g.T_pp, cl, Q, ld);
+    copy_to_slab<LDSM>(c, g.T_pp, cl, Q, ld);
     __syncthreads();
     wg_gemm<false, !LDSM>(N, ElP{t, ld}, ElP{Q, ld}, [=](int i, int j, real v) { Tpp[i + j * cl] = v; });
     __syncthreads();
@@ -1087,7 +1151,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
     // column in the last tile and no K padding (see doubling_run).
     const bool ride = (N % 4 == 0) && (c.nc - N >= 1);
     MOM_STAMP(10);
-    wg_copy_mat(N, c.fd, g.R_pm, cl, c.P, ld);  // P = R+-
+    copy_to_slab<LDSM>(c, g.R_pm, cl, c.P, ld);  // P = R+-
     if (ride)
       for (int i = wg_tid(); i < N; i += kThreads) c.P[i + N * ld] = c.Jp[i];
     __syncthreads();
@@ -1135,14 +1199,14 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
           c.Jm[i] = c.Jm[i] + Q[i + N * ld];
           r[i + N * ld] = c.jm[i];
         }
-      wg_copy_mat(N, c.fd, g.T_pp, cl, P, ld);  // P = T++ (old)
+      copy_to_slab<LDSM>(c, g.T_pp, cl, P, ld);  // P = T++ (old)
       __syncthreads();
       MOM_STAMP(16);
       // R-+ = R-+ + (T01 r-+) T++                              (:93)
       wg_gemm<false, !LDSM>(N, ElP{Q, ld}, ElP{P, ld}, [=](int i, int j, real v) { Rmp[i + j * cl] = Rmp[i + j * cl] + v; });
       __syncthreads();
       MOM_STAMP(17);
-      wg_copy_mat(N, c.fd, g.R_pm, cl, Q, ld);  // Q = R+- (old)
+      copy_to_slab<LDSM>(c, g.R_pm, cl, Q, ld);  // Q = R+- (old)
       __syncthreads();
       MOM_STAMP(18);
     }
@@ -1176,7 +1240,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       for (int i = wg_tid(); i < N; i += kThreads) c.Jp[i] = c.jp[i] + c.v2[i];
     }
     MOM_STAMP(21);
-    wg_copy_mat(N, c.fd, g.R_pm, cl, c.P, ld);  // P = R+- (old)
+    copy_to_slab<LDSM>(c, g.R_pm, cl, c.P, ld);  // P = R+- (old)
     if (ride)
       for (int i = wg_tid(); i < N; i += kThreads) c.P[i + N * ld] = c.j1p[i];
     __syncthreads();
@@ -1206,7 +1270,7 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       MOM_STAMP(24);
       if (ride)
         for (int i = wg_tid(); i < N; i += kThreads) { P[i + N * ld] = 0.0; r[i + N * ld] = 0.0; Q[i + N * ld] = 0.0; }
-      wg_copy_mat(N, c.fd, g.T_pp, cl, P, ld);  // P = T++ (old)
+      copy_to_slab<LDSM>(c, g.T_pp, cl, P, ld);  // P = T++ (old)
       __syncthreads();
       MOM_STAMP(25);
       // T++ = T21 T++                                          (:113)
