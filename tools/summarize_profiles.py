@@ -45,6 +45,8 @@ for wl in ("C2", "C4", "C1", "C5", "voigt"):
     if per:
         summ[wl] = per
     dom = DOMINANT.get(wl)
+    if dom and dom not in per:  # later template parameters (k_layer's MT flag) follow the ones named here
+        dom = next((k for k in per if k.startswith(dom[:-1] + ",")), dom)
     kl = per.get(dom, {})
     if kl:
         t = {"kernel": dom, "round": rnd}
