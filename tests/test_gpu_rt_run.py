@@ -42,6 +42,23 @@ def test_rt_run_parity(rtamd, cref, nS, lt, mode):
     helpers.assert_stokes_close(T, Tr, what=f"T {mode}")
 
 
+# operator edges above 64 (generic mode, panel GEMM from the slab): every register-block variant of wg_gemm_big (4 x 2, 4 x 3,
+# 4 x 4 tiles), one and two passes, an odd edge (element copies, k tail of the last panel) and the slab mat-vec / copy helpers
+@pytest.mark.parametrize("nS,lt,N", [(3, 43, 75), (4, 43, 100), (3, 79, 129), (4, 65, 144), (4, 93, 200)])
+def test_rt_run_parity_generic_sizes(rtamd, cref, nS, lt, N):
+    m = rtamd.scenes.make_scene(nS, lt, 3, 4, seed=nS + lt, aerosol_total=0.3)
+    sc = rtamd.prepare_scene(m)
+    assert sc.N == N
+    R, T = _gpu(rtamd, m)
+    Rr, Tr = _oracle(cref, m)
+    tol = helpers.stokes_rtol(sc.ndoubl)
+    helpers.assert_stokes_close(R, Rr, rtol=tol, what=f"R N={N}")
+    helpers.assert_stokes_close(T, Tr, rtol=tol, what=f"T N={N}")
+    R3, T3 = _gpu(rtamd, m, force_gj=True)
+    helpers.assert_stokes_close(R3, Rr, rtol=1e-11, what="R gauss-jordan")
+    helpers.assert_stokes_close(T3, Tr, rtol=1e-11, what="T gauss-jordan")
+
+
 # operator sizes with strip-chained kernels (mom_strip.hpp): N = 52, 56, 60 in the 8-wave build (IQUV with 13, 14,
 # 15 streams; scalar with 60), N = 36, 40, 44 in the 4-wave build (scalar scenes; the m = 0 (I,Q) sub-problems of
 # IQU scenes with 18, 20, 22 streams -- their full problems have N = 54 (plain LDS path), 60, 66 (generic path))
