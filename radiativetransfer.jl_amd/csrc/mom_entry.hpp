@@ -296,4 +296,30 @@ __global__ void __launch_bounds__(kThreads, 2) k_interlayer(InterArgs a) {
   if (wg_tid() == 0 && *c.bad) atomicMax(a.info, *c.bad);
 }
 
+// top <- top (+) bot for two composite slabs, bot below top: the adding equations of interaction_helper!(::ScatteringInterface_11)
+// (CoreKernel/interaction.jl:69-117) with the lower slab in the role of the added layer -- its R-+, T++ and sources go to the
+// unit's buffers, its R+- and T-- are read through element functors.  Used by mom_rt_run_multisensor: the slab below sensor k is
+// the segment between sensors k and k + 1 (built in the shared sweep) joined to the slab below sensor k + 1.
+template <bool LDSM>
+__global__ void __launch_bounds__(kThreads, 2) k_combine(InterArgs a) {
+  const int N = a.q.N;
+  Ctx c;
+  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
+  const int ld = c.ld;
+  const size_t units = (size_t)a.S * a.M;
+  for (size_t pt = blockIdx.x; pt < units; pt += gridDim.x) {
+    const CompPtrs gt = comp_ptrs(a.top, N, comp_pitch(N), pt), gb = comp_ptrs(a.bot, N, comp_pitch(N), pt);
+    const int cl = gb.ld;
+    wg_copy_mat(N, c.fd, gb.R_mp, cl, c.r, ld);
+    wg_copy_mat(N, c.fd, gb.T_pp, cl, c.t, ld);
+    for (int i = wg_tid(); i < N; i += kThreads) {
+      c.jp[i] = gb.J0p[i];
+      c.jm[i] = gb.J0m[i];
+    }
+    __syncthreads();
+    interaction_core<LDSM, -1>(c, 3, gt, El{gb.R_pm, cl, N}, El{gb.T_mm, cl, N});
+  }
+  if (wg_tid() == 0 && *c.bad) atomicMax(a.info, *c.bad);
+}
+
 }  // namespace MOM_NS

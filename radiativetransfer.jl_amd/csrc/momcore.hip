@@ -1655,6 +1655,12 @@ extern "C" int mom_rt_run_multisensor(mom_t *h, int nSensors, const int *sensor_
         }
       h->ms_sets = need;
     }
+    // sensors of this chunk in order of depth: the slab below sensor i is the SEGMENT of layers [L_i, L_i+1) -- built in the
+    // shared sweep, so every layer feeds the running top slab and exactly one segment whatever the number of sensors --
+    // joined afterwards to the slab below sensor i + 1 (k_combine); the deepest sensor's segment runs to the last layer
+    std::vector<int> ord(nc);
+    for (int i = 0; i < nc; ++i) ord[i] = c0 + i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return sensor_levels[x] < sensor_levels[y]; });
     TargetSpec tg;
     tg.act.assign((size_t)h->Nz * kMaxTargets, 0);
     int maxL = 0;
@@ -1665,7 +1671,7 @@ extern "C" int mom_rt_run_multisensor(mom_t *h, int nSensors, const int *sensor_
     for (int z = 0; z < maxL; ++z) tg.act[(size_t)z * kMaxTargets + 0] = (z == 0) ? 1 : 2;
     std::vector<int> snap_t(nc, -1), bot_t(nc, -1);
     for (int i = 0; i < nc; ++i) {
-      const int L = sensor_levels[c0 + i];
+      const int L = sensor_levels[ord[i]], Lnext = (i + 1 < nc) ? sensor_levels[ord[i + 1]] : h->Nz;
       if (L > 0) {
         snap_t[i] = nt;
         for (int k = 0; k < 6; ++k) tg.tgt[nt][k] = h->ms_comp[(size_t)(2 * i) * 6 + k];
@@ -1674,14 +1680,37 @@ extern "C" int mom_rt_run_multisensor(mom_t *h, int nSensors, const int *sensor_
       }
       bot_t[i] = nt;
       for (int k = 0; k < 6; ++k) tg.tgt[nt][k] = h->ms_comp[(size_t)(2 * i + 1) * 6 + k];
-      for (int z = L; z < h->Nz; ++z) tg.act[(size_t)z * kMaxTargets + nt] = (z == L) ? 1 : 2;
+      for (int z = L; z < Lnext; ++z) tg.act[(size_t)z * kMaxTargets + nt] = (z == L) ? 1 : 2;
       ++nt;
     }
     tg.ntgt = nt;
     int rc;
     if ((rc = rt_run_core(h, 0, h->Nz, false, h->comp, false, false, false, &tg))) return rc;
+    for (int i = nc - 2; i >= 0; --i) {  // slab below sensor i = its segment (+) the slab below sensor i + 1
+      const int L = sensor_levels[ord[i]], Lnext = sensor_levels[ord[i + 1]];
+      if (L == Lnext) {  // same level: same slab
+        for (int k = 0; k < 6; ++k)
+          HIPCHK(h, hipMemcpyAsync(tg.tgt[bot_t[i]][k], tg.tgt[bot_t[i + 1]][k], blk[k] * S * h->M * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        continue;
+      }
+      InterArgs a{};
+      a.q = h->qk; a.S = h->S; a.M = M;
+      for (int k = 0; k < 6; ++k) { a.top[k] = tg.tgt[bot_t[i]][k]; a.bot[k] = tg.tgt[bot_t[i + 1]][k]; }
+      a.scratch = h->d_scratch; a.info = h->d_info;
+      const bool lds = (Nk <= 64) && !h->opt_force_generic;
+      const size_t sm = lds_bytes(Nk, lds);
+      const size_t units = S * M;
+      if (lds) {
+        HIPCHK(h, allow_lds(k_combine<true>, sm));
+        hipLaunchKernelGGL(k_combine<true>, dim3((unsigned)units), dim3(kThreads), sm, h->stream, a);
+      } else {
+        HIPCHK(h, allow_lds(k_combine<false>, sm));
+        hipLaunchKernelGGL(k_combine<false>, dim3((unsigned)std::min<size_t>(units, (size_t)h->G)), dim3(kThreads), sm, h->stream, a);
+      }
+      HIPCHK(h, hipGetLastError());
+    }
     for (int i = 0; i < nc; ++i) {
-      const int ims = c0 + i, L = sensor_levels[ims];
+      const int ims = ord[i], L = sensor_levels[ims];
       double *bot[6], *top[6];
       for (int k = 0; k < 6; ++k) { bot[k] = tg.tgt[bot_t[i]][k]; top[k] = (L > 0) ? tg.tgt[snap_t[i]][k] : nullptr; }
       // surface interaction with the slab below the sensor (rt_run_multisensor.jl:150-159); L = 0: + post-processing of the

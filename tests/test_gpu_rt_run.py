@@ -577,4 +577,7 @@ def test_multisensor_more_sensors_than_one_target_table(rtamd, cref):
     for ims in range(len(levels)):
         helpers.assert_stokes_close(uw[ims], uwr[ims], rtol=tol, what=f"uwJ level {levels[ims]}")
         helpers.assert_stokes_close(dw[ims], dwr[ims], rtol=tol, what=f"dwJ level {levels[ims]}")
-    assert np.array_equal(uw1[0], uw[6]) and np.array_equal(dw1[0], dw[6])   # a sensor's result does not depend on the others
+    # a sensor's result depends on the others only through rounding: the slab below it is its segment joined to the slab
+    # below the next sensor (k_combine), not a layer-by-layer sum of its own
+    helpers.assert_stokes_close(uw1[0], uw[6], rtol=1e-12, what="sensor alone vs among others (uwJ)")
+    helpers.assert_stokes_close(dw1[0], dw[6], rtol=1e-12, what="sensor alone vs among others (dwJ)")
