@@ -630,7 +630,17 @@ namespace MOM_NS {
 template <bool LDSM, class FT>
 __device__ __forceinline__ void times_inv(Ctx &c, FT T, real *&Bb, real *&Ob, real beta2) {
   const int N = c.N, ld = c.ld, NN = N * N;
-  const int p = (c.inv_mode == 1) ? 1000 : neumann_terms(c.thr, beta2);
+  int p = (c.inv_mode == 1) ? 1000 : neumann_terms(c.thr, beta2);
+  if constexpr (!LDSM && kF64) {
+    // Generic mode: the pivoted Gauss-Jordan works in the global slab and costs ~50 products of a step at N = 256, so the
+    // series is carried further than the table (beta <= 0.29): the smallest p with beta^p / (1 - beta) <= 2^-56 from the
+    // norm itself, up to beta = 0.9 (p <= 512: nine squarings, 19 products).  Same bound as the table's, same products.
+    if (p > 32 && c.inv_mode != 1 && beta2 < 0.81) {
+      const real beta = sqrt(beta2);
+      p = (int)ceil((38.816242111356935 - log(1.0 - beta)) / -log(beta));
+      if (p < 33) p = 33;
+    }
+  }
   MOM_STAMP(6);
   if (p <= 4) {
     // Horner: A_1 = T, A_{k+1} = T + A_k B
@@ -648,7 +658,7 @@ __device__ __forceinline__ void times_inv(Ctx &c, FT T, real *&Bb, real *&Ob, re
       for (int k = 3; k <= p; ++k)
         gemm_to<LDSM>(c, Ob, ElP{Ob, ld}, ElP{Bb, ld}, [=](int i, int j, real v, real) { return T(i, j) + v; });
     }
-  } else if (p <= 32) {
+  } else if (p <= 512) {
     // G = (I + B)(I + B^2)(I + B^4)... ; Ob <- T G
     if constexpr (!LDSM) {
       slab_eye_plus<false>(c, Ob, Bb);

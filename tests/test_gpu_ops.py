@@ -95,6 +95,34 @@ def test_doubling_thick_layer_all_inverse_paths(rtamd, cref, mode):
         assert np.abs(ref[1]).max() > 0.05  # the layer really is reflective
 
 
+def test_doubling_thick_layer_panel_gemm_series(rtamd, cref):
+    """The same strongly reflecting layer at an operator edge above 64 (N = 81: panel GEMM from the slab): where the norm of
+    r r leaves the series table (beta > 0.29) the generic mode carries the series on (p from the norm, up to 512 terms by
+    repeated squaring) instead of the global-memory Gauss-Jordan; against the oracle's LU and against the forced pivoted path."""
+    rt = rtamd.corert
+    pol, q = _streams(rt, 3, Nquad=27)
+    N, S, nd = len(q.qp_μN), 3, 14
+    assert N == 81
+    rng = np.random.default_rng(4)
+    Zpp, Zmp = rt.compute_Z_moments(pol, q.qp_μ, rtamd.scenes.hg_like_greek(0.75, 11), 0)
+    dtau = np.full(S, 2e-4) * rng.uniform(0.5, 1.0, S)
+    varpi = np.full(S, 0.999999)
+    p = _P(pol, q)
+    ref = cref.elemental(p, 0, nd, np.zeros(S), dtau, varpi, mr.to_abi(Zpp[None]), mr.to_abi(Zmp[None]), 1, S)
+    assert cref.doubling(p, nd, np.exp(-dtau / q.μ0), ref, S) == 0
+    got = {}
+    for gj in (False, True):
+        with _handle(rtamd, pol, q, S, force_gj=gj) as h:
+            h.elemental(0, nd, np.zeros(S), dtau, varpi, mr.to_abi(Zpp[None]), mr.to_abi(Zmp[None]), 1)
+            h.doubling(nd, np.exp(-dtau / q.μ0))
+            got[gj] = [h.download(k) for k in range(6)]
+    for k, nm in enumerate(NAMES):
+        helpers.assert_op_close(got[False][k], ref[k], rtol=1e-10, what=f"series {nm}")
+        helpers.assert_op_close(got[True][k], ref[k], rtol=1e-10, what=f"gauss-jordan {nm}")
+    r = np.asarray(ref[1]).reshape(S, N, N)[0]
+    assert np.linalg.norm(r @ r) > 0.3   # beyond the table's beta = 0.29: the extended series really ran
+
+
 @pytest.mark.parametrize("iface", [0, 1, 2, 3])
 @pytest.mark.parametrize("N,S,generic", [(16, 100, False), (16, 100, True), (32, 40, False), (72, 3, False)])
 def test_interaction(rtamd, cref, iface, N, S, generic):
