@@ -7,7 +7,7 @@
 namespace MOM_NS {
 
 constexpr int kMaxSweepLayers = 96;
-constexpr int kMaxTargets = 12;
+constexpr int kMaxTargets = 20;
 struct LayerArgs {
   DevStreams q;
   int S, M, K;      // M: number of moments in THIS launch; m_first: Fourier index of the first of them

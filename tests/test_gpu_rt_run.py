@@ -560,13 +560,13 @@ def test_multisensor_sweep(rtamd, cref, nS, lt, Nz, kw):
 
 
 def test_multisensor_more_sensors_than_one_target_table(rtamd, cref):
-    """Seven sensors: more than one kernel's target table holds (kMaxTargets = 12: the running top slab + a snapshot and a
-    bottom slab per sensor), so the library sweeps twice; every layer's added operators are built once per sweep and feed
-    all composites (rt_kernel_multisensor.jl:51-112)."""
+    """Eleven sensors: more than one kernel's target table holds (kMaxTargets = 20: the running top slab + a snapshot and a
+    segment per sensor, 9 sensors), so the library sweeps twice; every layer's added operators are built once per sweep and
+    feed all composites (rt_kernel_multisensor.jl:51-112)."""
     Nz = 7
     m = rtamd.scenes.make_scene(3, 9, Nz, 9, seed=5, aerosol_total=0.25, vaz=(0.0, 60.0, 140.0))
     sc = rtamd.prepare_scene(m)
-    levels = [3, 0, 6, 1, 5, 2, 4]
+    levels = [3, 0, 6, 1, 5, 2, 4, 3, 6, 1, 2]
     uwr, dwr, info = cref.rt_run_multisensor(cref.pack_scene(helpers.oracle_scene(m)), levels)
     assert info == 0
     with rtamd.corert.make_handle(m) as h:
