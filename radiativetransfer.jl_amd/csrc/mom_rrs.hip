@@ -27,6 +27,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "mom_tile.hpp"
@@ -1206,7 +1207,15 @@ hipError_t copy_added_to_composite(State *s, const Streams &q) {
   static const int amap[6] = {R_MP, R_PM, T_PP, T_MM, J0P, J0M};  // composite field k <- added field amap[k]
   for (int k = 0; k < 6; ++k) {
     RCHK(hipMemcpyAsync(s->comp[s->ccur][k], s->added[s->cur][amap[k]], k < 4 ? m3 : v3, hipMemcpyDeviceToDevice, s->stream));
-    RCHK(hipMemcpyAsync(s->ie_comp[k], s->ie_added[amap[k]], k < 4 ? m4 : v4, hipMemcpyDeviceToDevice, s->stream));
+    if (s->fast && !s->strict_rrs && k < 4) {
+      // scene-level run, corrected position (the strict one reads stale ier+- / iet-- of the added layer's OWN arrays, D5):
+      // the four 4-D operator arrays (2.5 GB each at C5) change roles instead of being copied -- the next
+      // layer's elemental overwrites every block of the added layer's arrays before anything reads them, and the entries
+      // off the grid are zero in both sets (nothing ever writes them)
+      std::swap(s->ie_comp[k], s->ie_added[amap[k]]);
+    } else {
+      RCHK(hipMemcpyAsync(s->ie_comp[k], s->ie_added[amap[k]], k < 4 ? m4 : v4, hipMemcpyDeviceToDevice, s->stream));
+    }
   }
   return hipSuccess;
 }
