@@ -413,7 +413,7 @@ def f32_leg(dev, S=20_000, n_streams=8, nd=5, steps=3):
             "unit": "(spectral point, moment) units/s", "dtype": "f32", "layers_ms": best,
             "config": {"workload": f"N={N} (8 streams x 4 Stokes), S={S}, one layer, ndoubl={nd}, M={M}, dtype=1 (Float32)"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "kernel": "layer kernel of the Float32 build (momcore_f32.hip)",
+                         "frac": ach / PEAK_FP32_MFMA_TFLOPS, "kernel": "momwf::k_wsweep<2, 7> (wave per spectral point, Float32 build of mom_wave.hip)",
                          "algorithmic_flop_per_avg_launch": flop}}
 
 

@@ -58,20 +58,23 @@ struct MomSmallSweepArgs {
   double *R, *T, *hdr, *bhr_uw, *bhr_dw;  // [nVza,nS,S] x3, [nS,S] x2
   int *info;
 };
-struct MomWaveSweepArgs {
+template <class Real>
+struct MomWaveSweepArgsT {
   int N, S, M, K, Nz, nVza, nS, imu0, inv_mode, pad;
-  double mu0, albedo;
-  double I0[4], D[4];
-  const double *mu, *wt, *sg;           // [N]
-  const double *Zpp, *Zmp;              // [N,N,K,M]
+  Real mu0, albedo;
+  Real I0[4], D[4];
+  const Real *mu, *wt, *sg;           // [N]
+  const Real *Zpp, *Zmp;              // [N,N,K,M]
   const int *nd;                        // [Nz]
   const int *node;                      // [nVza]
   const double *cos_mphi, *sin_mphi;    // [nVza,M]
-  const double *tau, *varpi, *zw, *tau_sum;  // [S,Nz], [S,Nz], [K,S,Nz], [S,Nz+1]
-  double *R, *T, *hdr, *bhr_uw, *bhr_dw;
+  const Real *tau, *varpi, *zw, *tau_sum;  // [S,Nz], [S,Nz], [K,S,Nz], [S,Nz+1]
+  Real *R, *T, *hdr, *bhr_uw, *bhr_dw;
   int *info;
   // surface (mom_scene_set_surface): 0 LambertianSurfaceScalar(albedo), 1 BRDF matrices Rsurf [N,N,M] (every moment),
   // 2 LambertianSurfaceLegendre (albedo_spec [S]; j0+ = 0, T_SFI from m = 0 only: lambertian_surface.jl:112,131-132)
   int surf_kind, pad2;
-  const double *Rsurf, *albedo_spec;
+  const Real *Rsurf, *albedo_spec;
 };
+using MomWaveSweepArgs = MomWaveSweepArgsT<double>;   // Float64 wave-per-point sweep (mom_wave.hip)
+using MomWaveSweepArgsF = MomWaveSweepArgsT<float>;   // Float32 build of the same kernels (mom_wave.hip with -DMOMW_FLOAT)

@@ -24,22 +24,44 @@
 
 #include "mom_host.hpp"
 
-namespace momw {
+// The same source builds the Float32 kernels (-DMOMW_FLOAT: namespace momwf, v_mfma_f32_16x16x4, MomWaveSweepArgsF).  The f32
+// accumulator layout puts row 4 lq + r (not lq + 4 r) into register r; tiles stay valid MFMA operands of U^T V because both
+// operands map the contraction index the same way, but every k-step then touches rows below N, so none is skipped.
+#ifdef MOMW_FLOAT
+#define MOMW_NS momwf
+typedef float real;
+#else
+#define MOMW_NS momw
+typedef double real;
+#endif
 
-typedef double d4 __attribute__((ext_vector_type(4)));
+namespace MOMW_NS {
+
+typedef real r4 __attribute__((ext_vector_type(4)));
+#ifdef MOMW_FLOAT
+constexpr bool kF32 = true;
+__device__ __forceinline__ r4 mma(real a, real b, r4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int absbits(real v) { return __float_as_int(fabsf(v)); }
+#else
+constexpr bool kF32 = false;
+__device__ __forceinline__ r4 mma(real a, real b, r4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int absbits(real v) { return __double2hiint(fabs(v)); }
+#endif
+// row of accumulator register r within a 16 x 16 tile
+__device__ __forceinline__ constexpr int crow(int lq, int r) { return kF32 ? 4 * lq + r : lq + 4 * r; }
 
 template <int NT>
 struct Mat {
-  d4 t[NT][NT];  // t[bi][bj]: rows 16 bi .., columns 16 bj ..
+  r4 t[NT][NT];  // t[bi][bj]: rows 16 bi .., columns 16 bj ..
 };
 template <int NT>
 struct Vec {
-  d4 t[NT];  // row block bi; column 0 = the "+" vector, column 1 = the "-" vector (lanes l & 15 == 0 / 1)
+  r4 t[NT];  // row block bi; column 0 = the "+" vector, column 1 = the "-" vector (lanes l & 15 == 0 / 1)
 };
 
 // k-steps of row block tk
 template <int KS>
-__device__ __forceinline__ constexpr int ksteps(int tk) { return (KS - 4 * tk) >= 4 ? 4 : ((KS - 4 * tk) > 0 ? (KS - 4 * tk) : 0); }
+__device__ __forceinline__ constexpr int ksteps(int tk) { return kF32 ? 4 : ((KS - 4 * tk) >= 4 ? 4 : ((KS - 4 * tk) > 0 ? (KS - 4 * tk) : 0)); }
 
 template <int NT, int KS>
 __device__ __forceinline__ Mat<NT> TNacc(const Mat<NT> &U, const Mat<NT> &V, Mat<NT> acc) {  // acc + U^T V
@@ -52,7 +74,7 @@ __device__ __forceinline__ Mat<NT> TNacc(const Mat<NT> &U, const Mat<NT> &V, Mat
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
           for (int tj = 0; tj < NT; ++tj)
-            acc.t[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(U.t[tk][ti][s], V.t[tk][tj][s], acc.t[ti][tj], 0, 0, 0);
+            acc.t[ti][tj] = mma(U.t[tk][ti][s], V.t[tk][tj][s], acc.t[ti][tj]);
       }
   return acc;
 }
@@ -62,7 +84,7 @@ __device__ __forceinline__ Mat<NT> zeros() {
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < NT; ++b) Z.t[a][b] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < NT; ++b) Z.t[a][b] = (r4){0.0, 0.0, 0.0, 0.0};
   return Z;
 }
 template <int NT, int KS>
@@ -73,7 +95,7 @@ template <int NT, int KS>
 __device__ __forceinline__ Vec<NT> TNv(const Mat<NT> &U, const Vec<NT> &v) {  // U^T v
   Vec<NT> o;
 #pragma unroll
-  for (int ti = 0; ti < NT; ++ti) o.t[ti] = (d4){0.0, 0.0, 0.0, 0.0};
+  for (int ti = 0; ti < NT; ++ti) o.t[ti] = (r4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
@@ -81,12 +103,12 @@ __device__ __forceinline__ Vec<NT> TNv(const Mat<NT> &U, const Vec<NT> &v) {  //
       if (s < ksteps<KS>(tk)) {
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
-          o.t[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(U.t[tk][ti][s], v.t[tk][s], o.t[ti], 0, 0, 0);
+          o.t[ti] = mma(U.t[tk][ti][s], v.t[tk][s], o.t[ti]);
       }
   return o;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
+__device__ __forceinline__ real wave_sum(real v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
   return v;
@@ -103,7 +125,19 @@ __device__ __forceinline__ Vec<NT> swap01(const Vec<NT> &v) {  // exchange colum
 
 // series length for (I - B)^-1 from beta^2 = ||B||_F^2: the rule of mom_kernels.hpp (kNeumannThr2: tail <= 2^-56, the
 // first-order term always kept); 1000 = use the pivoted inverse
-__device__ const double kThr2[32] = {
+#ifdef MOMW_FLOAT
+// Float32: beta^p / (1 - beta) <= 2^-26 (mom_kernels.hpp, MOM_REAL_IS_FLOAT)
+__device__ const real kThr2[32] = {
+    0.000000000e+00f, 1.489934232e-08f, 6.045524421e-06f, 1.213959655e-04f,
+    7.320204349e-04f, 2.419753539e-03f, 5.676200029e-03f, 1.075029447e-02f,
+    1.765854019e-02f, 2.625958398e-02f, 3.632882835e-02f, 4.761229038e-02f,
+    5.985942527e-02f, 7.284045577e-02f, 8.635379794e-02f, 1.002277241e-01f,
+    1.143189633e-01f, 1.285098733e-01f, 1.427051184e-01f, 1.568283537e-01f,
+    1.708191621e-01f, 1.846303449e-01f, 1.982255889e-01f, 2.115774909e-01f,
+    2.246659062e-01f, 2.374765770e-01f, 2.500000000e-01f, 2.622304965e-01f,
+    2.741654486e-01f, 2.858046753e-01f, 2.971499218e-01f, 3.082044441e-01f};
+#else
+__device__ const real kThr2[32] = {
     0.0, 1.38777877561156685e-17, 5.77492213356056750e-12, 3.72517661162420568e-09,
     1.80656771560518035e-07, 2.40186660760962690e-06, 1.52417448931310540e-05, 6.09157135028591602e-05,
     1.78874927371965362e-04, 4.23309807394842467e-04, 8.56292603484697687e-04, 1.53988783074545245e-03,
@@ -112,7 +146,8 @@ __device__ const double kThr2[32] = {
     2.44051136922726897e-02, 2.88492300492497432e-02, 3.36098586497813809e-02, 3.86607216385354419e-02,
     4.39753040322414940e-02, 4.95274191527264318e-02, 5.52916244610413068e-02, 6.12435157546498479e-02,
     6.73599244364155580e-02, 7.36190389296255826e-02, 8.00004677634075928e-02, 8.64852586225294262e-02};
-__device__ __forceinline__ int series_terms(double beta2) {
+#endif
+__device__ __forceinline__ int series_terms(real beta2) {
   if (!(beta2 <= kThr2[31])) return 1000;
   int p = 1;
 #pragma unroll
@@ -120,20 +155,20 @@ __device__ __forceinline__ int series_terms(double beta2) {
   return p;
 }
 
-using WArgs = ::MomWaveSweepArgs;  // mom_host.hpp: the one definition shared with momcore.hip
+using WArgs = ::MomWaveSweepArgsT<real>;  // mom_host.hpp: the one definition shared with momcore.hip / momcore_f32.hip
 
 // per-lane coordinates; row / column quantities are read from the block's LDS table tab = mu[32] | wt[32] | sg[32]
 // (padding entries: mu = 1, wt = 0, sg = 1)
 struct Lay {
   int lr, lq, N, nS;
-  const double *tab;
-  double *xp;  // wave-private LDS slice: transposes / pivoted inverse / output gather
+  const real *tab;
+  real *xp;  // wave-private LDS slice: transposes / pivoted inverse / output gather
   int *ipiv;
-  __device__ __forceinline__ int row(int bi, int r) const { return 16 * bi + lq + 4 * r; }
+  __device__ __forceinline__ int row(int bi, int r) const { return 16 * bi + crow(lq, r); }
   __device__ __forceinline__ int col(int bj) const { return 16 * bj + lr; }
-  __device__ __forceinline__ double mu(int i) const { return tab[i]; }
-  __device__ __forceinline__ double wt(int i) const { return tab[32 + i]; }
-  __device__ __forceinline__ double sg(int i) const { return tab[64 + i]; }
+  __device__ __forceinline__ real mu(int i) const { return tab[i]; }
+  __device__ __forceinline__ real wt(int i) const { return tab[32 + i]; }
+  __device__ __forceinline__ real sg(int i) const { return tab[64 + i]; }
 };
 
 template <int NT>
@@ -144,7 +179,7 @@ __device__ __forceinline__ Mat<NT> ident(const Lay &L) {
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) I.t[a][b][r] = (a == b && L.lq + 4 * r == L.lr && L.col(b) < L.N) ? 1.0 : 0.0;
+      for (int r = 0; r < 4; ++r) I.t[a][b][r] = (a == b && crow(L.lq, r) == L.lr && L.col(b) < L.N) ? 1.0 : 0.0;
   return I;
 }
 template <int NT>
@@ -178,13 +213,13 @@ constexpr int slice_doubles() {
 // X^T through the wave's LDS slice: tile (a, b) of the result is the transpose of tile (b, a)
 template <int NT>
 __device__ __forceinline__ Mat<NT> transpose(const Lay &L, const Mat<NT> &X) {
-  double *buf = L.xp;
+  real *buf = L.xp;
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) buf[(a * NT + b) * kTileDoubles + (L.lq + 4 * r) * kTileLd + L.lr] = X.t[a][b][r];
+      for (int r = 0; r < 4; ++r) buf[(a * NT + b) * kTileDoubles + crow(L.lq, r) * kTileLd + L.lr] = X.t[a][b][r];
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   Mat<NT> Y;
 #pragma unroll
@@ -192,7 +227,7 @@ __device__ __forceinline__ Mat<NT> transpose(const Lay &L, const Mat<NT> &X) {
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Y.t[a][b][r] = buf[(b * NT + a) * kTileDoubles + L.lr * kTileLd + L.lq + 4 * r];
+      for (int r = 0; r < 4; ++r) Y.t[a][b][r] = buf[(b * NT + a) * kTileDoubles + L.lr * kTileLd + crow(L.lq, r)];
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   return Y;
 }
@@ -200,7 +235,7 @@ __device__ __forceinline__ Mat<NT> transpose(const Lay &L, const Mat<NT> &X) {
 // (I - B)^-1 by Gauss-Jordan elimination with implicit partial pivoting, one matrix row per lane through the wave's LDS
 // slice (the register-resident scheme of wg_inverse_reg, mom_device.hpp, for a single wave)
 template <int NT>
-__device__ __noinline__ Mat<NT> inverse_gj(Mat<NT> B, int N, double *lds, int *ipiv, int *bad_out) {
+__device__ __noinline__ Mat<NT> inverse_gj(Mat<NT> B, int N, real *lds, int *ipiv, int *bad_out) {
   constexpr int NP = 16 * NT, LDM = NP + 1;
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   int bad = 0;
@@ -210,11 +245,11 @@ __device__ __noinline__ Mat<NT> inverse_gj(Mat<NT> B, int N, double *lds, int *i
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = 16 * a + lq + 4 * r, j = 16 * b + lr;
+        const int i = 16 * a + crow(lq, r), j = 16 * b + lr;
         lds[i * LDM + j] = ((i == j) ? 1.0 : 0.0) - B.t[a][b][r];
       }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  double v[NP];
+  real v[NP];
 #pragma unroll
   for (int c = 0; c < NP; ++c) v[c] = (lane < N && c < N) ? lds[lane * LDM + c] : ((lane == c) ? 1.0 : 0.0);
   bool used = false;
@@ -222,19 +257,19 @@ __device__ __noinline__ Mat<NT> inverse_gj(Mat<NT> B, int N, double *lds, int *i
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     if (k < N) {
-      const int ah = (!used && lane < N) ? __double2hiint(fabs(v[k])) : -1;
+      const int ah = (!used && lane < N) ? absbits(v[k]) : -1;
       int mh = ah;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) mh = max(mh, __shfl_xor(mh, off));
       const unsigned long long mk = __ballot(ah == mh);
       const int pl = __ffsll((long long)mk) - 1;
-      const double piv = __shfl(v[k], pl);
+      const real piv = __shfl(v[k], pl);
       if (!(fabs(piv) > 0.0) && !bad) bad = k + 1;
-      const double d = 1.0 / piv, f = v[k];
+      const real d = 1.0 / piv, f = v[k];
       const bool isp = (lane == pl);
 #pragma unroll
       for (int c = 0; c < NP; ++c) {
-        const double prow = __shfl(v[c], pl) * d;
+        const real prow = __shfl(v[c], pl) * d;
         v[c] = isp ? prow : (v[c] - f * prow);
       }
       v[k] = isp ? d : (-f * d);
@@ -257,7 +292,7 @@ __device__ __noinline__ Mat<NT> inverse_gj(Mat<NT> B, int N, double *lds, int *i
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int i = 16 * a + lq + 4 * r, j = 16 * b + lr;
+        const int i = 16 * a + crow(lq, r), j = 16 * b + lr;
         G.t[a][b][r] = (i < N && j < N) ? lds[i * LDM + j] : 0.0;
       }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -269,14 +304,14 @@ __device__ __noinline__ Mat<NT> inverse_gj(Mat<NT> B, int N, double *lds, int *i
 // the pivoted inverse
 template <int NT, int KS>
 __device__ __forceinline__ Mat<NT> inv_one_minus(const Lay &L, const Mat<NT> &B, int inv_mode, int &bad) {
-  double ss = 0.0;
+  real ss = 0.0;
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ss += B.t[a][b][r] * B.t[a][b][r];
-  const double beta2 = wave_sum(ss);
+  const real beta2 = wave_sum(ss);
   const int p = (inv_mode == 1) ? 1000 : series_terms(beta2);
   const Mat<NT> I = ident<NT>(L);
   if (p <= 32) {
@@ -356,9 +391,9 @@ __device__ __forceinline__ Mat<NT> interact11(const Lay &L, Comp<NT> &C, const M
 
 template <int NT, int KS>
 __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs a) {
-  __shared__ double s_lds[4][slice_doubles<NT>()];
+  __shared__ real s_lds[4][slice_doubles<NT>()];
   __shared__ int s_piv[4][16 * NT];
-  __shared__ double s_tab[96];
+  __shared__ real s_tab[96];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 4 + wave;  // spectral point of this wave
   const int N = a.N, nS = a.nS, S = a.S, K = a.K;
@@ -372,9 +407,9 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
   if (n >= S) return;
   Lay L;
   L.lr = lane & 15; L.lq = lane >> 4; L.N = N; L.nS = nS; L.tab = s_tab; L.xp = s_lds[wave]; L.ipiv = s_piv[wave];
-  double *post = L.xp + slice_doubles<NT>() - 3 * 16 * NT;  // J0+ | J0- | hdr_J0-, 16 NT each
+  real *post = L.xp + slice_doubles<NT>() - 3 * 16 * NT;  // J0+ | J0- | hdr_J0-, 16 NT each
   const int i_start = nS * (a.imu0 - 1), i_end = nS * a.imu0;
-  const double mus = a.mu[i_start];
+  const real mus = a.mu[i_start];
   int bad = 0;
   // accumulators of the outputs: lane x < nVza * nS handles (view v = x / nS, component k = x % nS)
   // outputs: lane x (+ 64 per pass) handles (view v = x / nS, component k = x % nS); the sums over the Fourier moments
@@ -382,20 +417,20 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
   const int nout = a.nVza * nS;
 
   for (int m = 0; m < a.M; ++m) {
-    const double wdiv = (m == 0) ? 2.0 : 4.0, wct02 = (m == 0) ? 0.5 : 0.25;
-    const double *Zp_m = a.Zpp + (size_t)N * N * K * m, *Zm_m = a.Zmp + (size_t)N * N * K * m;
+    const real wdiv = (m == 0) ? 2.0 : 4.0, wct02 = (m == 0) ? 0.5 : 0.25;
+    const real *Zp_m = a.Zpp + (size_t)N * N * K * m, *Zm_m = a.Zmp + (size_t)N * N * K * m;
     Comp<NT> C;
     for (int z = 0; z < a.Nz; ++z) {
       const int nd = a.nd[z];
       const size_t o = n + (size_t)S * z;
-      const double tau = a.tau[o], varpi = a.varpi[o], tau_sum = a.tau_sum[o];
-      const double dtau = ldexp(tau, -nd);
-      double expk = exp(-dtau / a.mu0);
+      const real tau = a.tau[o], varpi = a.varpi[o], tau_sum = a.tau_sum[o];
+      const real dtau = ldexp(tau, -nd);
+      real expk = exp(-dtau / a.mu0);
       // ------------------------------------------------ elemental! (elemental.jl:164-253)
       Mat<NT> r, t;
       Vec<NT> jv;
       {
-        const double att = exp(-tau_sum / mus), es = exp(-dtau / mus);
+        const real att = exp(-tau_sum / mus), es = exp(-dtau / mus);
         // one register row (of every tile of a row block) per iteration, NOT unrolled over q: the live set of one
         // iteration is what the register budget affords next to the composite tiles
 #pragma unroll
@@ -404,22 +439,22 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
           for (int q = 0; q < 4; ++q) {
             const int i = L.row(bi, q);
             const bool rok = i < N;
-            const double mui = L.mu(i), wir = L.wt(i) / wdiv;
-            const double er = exp(-dtau / mui);
+            const real mui = L.mu(i), wir = L.wt(i) / wdiv;
+            const real er = exp(-dtau / mui);
 #pragma unroll
             for (int bj = 0; bj < NT; ++bj) {
               const int j = L.col(bj);
               const bool ok = rok && j < N;
-              const double muj = L.mu(j), wjc = L.wt(j) / wdiv;
-              double zp = 0.0, zm = 0.0;
+              const real muj = L.mu(j), wjc = L.wt(j) / wdiv;
+              real zp = 0.0, zm = 0.0;
               if (ok)
                 for (int k = 0; k < K; ++k) {
-                  const double w = a.zw[k + (size_t)K * o];
+                  const real w = a.zw[k + (size_t)K * o];
                   const size_t b = (size_t)N * N * k + i + (size_t)N * j;
                   zp += w * Zp_m[b];
                   zm += w * Zm_m[b];
                 }
-              double rij, tij;
+              real rij, tij;
               if (wjc > 1.e-8) {
                 rij = varpi * zm * (muj / (mui + muj)) * wjc * (1 - exp(-dtau * ((1 / mui) + (1 / muj))));
                 if (mui == muj) tij = (i == j) ? er * (1 + varpi * zp * (dtau / mui) * wir) : 0.0;
@@ -433,10 +468,10 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
               t.t[bi][bj][q] = ok ? tij : 0.0;
             }
             // source rows: Z I0 over the sun's Stokes block (lanes of columns 0 and 1)             (elemental.jl:224-251)
-            double jx = 0.0;
+            real jx = 0.0;
             if (rok && L.lr < 2) {
-              const double *Zs = (L.lr == 0) ? Zp_m : Zm_m;
-              double zI = 0.0;
+              const real *Zs = (L.lr == 0) ? Zp_m : Zm_m;
+              real zI = 0.0;
               for (int ks = 0; ks < nS; ++ks)
                 for (int k = 0; k < K; ++k)
                   zI += a.zw[k + (size_t)K * o] * Zs[(size_t)N * N * k + i + (size_t)N * (i_start + ks)] * a.I0[ks];
@@ -481,7 +516,7 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
         for (int bi = 0; bi < NT; ++bi)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const double s = L.sg(L.row(bi, q));
+            const real s = L.sg(L.row(bi, q));
 #pragma unroll
             for (int bj = 0; bj < NT; ++bj) r.t[bi][bj][q] *= s;
             if (L.lr == 1) jv.t[bi][q] *= s;
@@ -497,11 +532,11 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
     // ---------------------------------------------------- Lambertian surface (m = 0) + closing interaction (Q6)
     Vec<NT> hdrJ;
 #pragma unroll
-    for (int b = 0; b < NT; ++b) hdrJ.t[b] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int b = 0; b < NT; ++b) hdrJ.t[b] = (r4){0.0, 0.0, 0.0, 0.0};
     if (m == 0 || a.surf_kind == 1) {
-      const double rho = 2 * ((a.surf_kind == 2) ? a.albedo_spec[n] : a.albedo);  // lambertian_surface.jl:37 / :97
-      const double att = exp(-a.tau_sum[n + (size_t)S * a.Nz] / a.mu0);
-      const double *Rs = a.Rsurf + (size_t)N * N * m;  // kind 1: rho_m [N,N] (rpv_surface.jl:39-43)
+      const real rho = 2 * ((a.surf_kind == 2) ? a.albedo_spec[n] : a.albedo);  // lambertian_surface.jl:37 / :97
+      const real att = exp(-a.tau_sum[n + (size_t)S * a.Nz] / a.mu0);
+      const real *Rs = a.Rsurf + (size_t)N * N * m;  // kind 1: rho_m [N,N] (rpv_surface.jl:39-43)
       Mat<NT> rs;
       Vec<NT> jv;
 #pragma unroll
@@ -513,16 +548,16 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
           for (int bj = 0; bj < NT; ++bj) {
             const int j = L.col(bj);
             const bool in = i < N && j < N;
-            double v;
+            real v;
             if (a.surf_kind == 1) v = in ? Rs[i + (size_t)N * j] * (L.mu(j) * L.wt(j)) : 0.0;       // rpv_surface.jl:58-62
             else v = (in && (i % nS == 0) && (j % nS == 0)) ? rho * (L.mu(j) * L.wt(j)) : 0.0;      // r-+ = R_surf Diagonal(mu w)  (:41-43,:58)
             rs.t[bi][bj][q] = v;
           }
           const bool in_sun = (i >= i_start) && (i < i_end);
-          double jp = (in_sun ? a.I0[i - i_start] : 0.0) * att;                           // :55
-          double jm = (i % nS == 0) ? (a.mu0 * (rho * a.I0[0])) * att : 0.0;             // :56
+          real jp = (in_sun ? a.I0[i - i_start] : 0.0) * att;                           // :55
+          real jm = (i % nS == 0) ? (a.mu0 * (rho * a.I0[0])) * att : 0.0;             // :56
           if (a.surf_kind == 1 && i < N) {                                                // j0- = mu0 (R_surf I0N) e^(-tau/mu0)  (rpv_surface.jl:48-56)
-            double rI = 0.0;
+            real rI = 0.0;
             for (int k = 0; k < nS; ++k) rI += Rs[i + (size_t)N * (i_start + k)] * a.I0[k];
             jm = (a.mu0 * rI) * att;
           }
@@ -542,7 +577,7 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
         for (int q = 0; q < 4; ++q) hdrJ.t[b][q] = (L.lr == 0) ? rJ.t[b][q] + jsw.t[b][q] : 0.0;
       // BHR flux sums over the streams of each Stokes component (column-0 lanes hold hdr_J0- and J0+), m = 0 only
       for (int k = 0; k < (m == 0 ? nS : 0); ++k) {
-        double up = 0.0, dw = 0.0;
+        real up = 0.0, dw = 0.0;
 #pragma unroll
         for (int b = 0; b < NT; ++b)
 #pragma unroll
@@ -556,7 +591,7 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
         up = wave_sum(up);
         dw = wave_sum(dw);
         // + j0+_surf[i_start] mu[i_start]: the direct beam (interaction_hdrf.jl:30)
-        const double direct = ((a.surf_kind == 2) ? 0.0 : a.I0[0] * att) * mus;  // j0+_surf[i_start] mu[i_start]
+        const real direct = ((a.surf_kind == 2) ? 0.0 : a.I0[0] * att) * mus;  // j0+_surf[i_start] mu[i_start]
         if (lane == 0) {
           a.bhr_uw[k + (size_t)nS * n] = up;
           a.bhr_dw[k + (size_t)nS * n] = dw + direct;
@@ -575,12 +610,12 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int x = lane; x < nout; x += 64) {
       const int xv = x / nS, xk = x - xv * nS;
-      const double weight = (m == 0) ? 0.5 : 1.0;
-      const double cs = weight * ((xk < 2) ? a.cos_mphi[xv + a.nVza * m] : a.sin_mphi[xv + a.nVza * m]);
+      const real weight = (m == 0) ? 0.5 : 1.0;
+      const real cs = weight * ((xk < 2) ? a.cos_mphi[xv + a.nVza * m] : a.sin_mphi[xv + a.nVza * m]);
       const int row = (a.node[xv] - 1) * nS + xk;
       const size_t idx = xv + (size_t)a.nVza * xk + (size_t)nout * n;  // [nVza, nStokes, S]
-      const double tv = (a.surf_kind == 2 && m > 0) ? 0.0 : cs * post[row];  // Legendre surface: t = 0 for m > 0
-      const double hv = (m == 0 || a.surf_kind == 1) ? cs * post[32 * NT + row] : 0.0;  // BRDF surfaces: hdr over all moments
+      const real tv = (a.surf_kind == 2 && m > 0) ? 0.0 : cs * post[row];  // Legendre surface: t = 0 for m > 0
+      const real hv = (m == 0 || a.surf_kind == 1) ? cs * post[32 * NT + row] : 0.0;  // BRDF surfaces: hdr over all moments
       a.T[idx] = (m == 0) ? tv : a.T[idx] + tv;
       a.R[idx] = (m == 0) ? cs * post[16 * NT + row] : a.R[idx] + cs * post[16 * NT + row];
       a.hdr[idx] = (m == 0) ? hv : a.hdr[idx] + hv;
@@ -590,32 +625,39 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
   if (bad && lane == 0) atomicMax(a.info, bad);
 }
 
-}  // namespace momw
+}  // namespace MOMW_NS
 
 // The MFMAs of these 4-wave kernels (512 registers per lane) must be in the VGPR form: with the accumulators in AGPRs
 // v_mfma_f64_16x16x4 issues at half rate on gfx950 (tools/mfma_peak.hip).  The Makefile passes
 // -mllvm -amdgpu-mfma-vgpr-form for this file; that option crashes the compiler on k_wsweep<2, 8>, which is therefore
 // built as a second object (mom_wave8.o, -DMOMW_ONLY_KS8) without it.
-hipError_t momw_launch_sweep8(const void *args, hipStream_t st);
+#ifdef MOMW_FLOAT
+#define MOMW_LAUNCH momwf_launch_sweep
+#define MOMW_LAUNCH8 momwf_launch_sweep8
+#else
+#define MOMW_LAUNCH momw_launch_sweep
+#define MOMW_LAUNCH8 momw_launch_sweep8
+#endif
+hipError_t MOMW_LAUNCH8(const void *args, hipStream_t st);
 #ifdef MOMW_ONLY_KS8
-hipError_t momw_launch_sweep8(const void *args, hipStream_t st) {
-  const momw::WArgs a = *reinterpret_cast<const momw::WArgs *>(args);
+hipError_t MOMW_LAUNCH8(const void *args, hipStream_t st) {
+  const MOMW_NS::WArgs a = *reinterpret_cast<const MOMW_NS::WArgs *>(args);
   const dim3 grid((unsigned)((a.S + 3) / 4)), block(256);
-  hipLaunchKernelGGL((momw::k_wsweep<2, 8>), grid, block, 0, st, a);
+  hipLaunchKernelGGL((MOMW_NS::k_wsweep<2, 8>), grid, block, 0, st, a);
   return hipGetLastError();
 }
 #else
-hipError_t momw_launch_sweep(const void *args, hipStream_t st) {
-  const momw::WArgs a = *reinterpret_cast<const momw::WArgs *>(args);
+hipError_t MOMW_LAUNCH(const void *args, hipStream_t st) {
+  const MOMW_NS::WArgs a = *reinterpret_cast<const MOMW_NS::WArgs *>(args);
   const dim3 grid((unsigned)((a.S + 3) / 4)), block(256);
   switch ((a.N + 3) / 4) {
-    case 2: hipLaunchKernelGGL((momw::k_wsweep<1, 2>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((momw::k_wsweep<1, 3>), grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL((momw::k_wsweep<1, 4>), grid, block, 0, st, a); break;
-    case 5: hipLaunchKernelGGL((momw::k_wsweep<2, 5>), grid, block, 0, st, a); break;
-    case 6: hipLaunchKernelGGL((momw::k_wsweep<2, 6>), grid, block, 0, st, a); break;
-    case 7: hipLaunchKernelGGL((momw::k_wsweep<2, 7>), grid, block, 0, st, a); break;
-    case 8: return momw_launch_sweep8(args, st);
+    case 2: hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 2>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 3>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 4>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((MOMW_NS::k_wsweep<2, 5>), grid, block, 0, st, a); break;
+    case 6: hipLaunchKernelGGL((MOMW_NS::k_wsweep<2, 6>), grid, block, 0, st, a); break;
+    case 7: hipLaunchKernelGGL((MOMW_NS::k_wsweep<2, 7>), grid, block, 0, st, a); break;
+    case 8: return MOMW_LAUNCH8(args, st);
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

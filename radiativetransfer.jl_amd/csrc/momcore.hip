@@ -424,7 +424,7 @@ struct momf_scene;
 int momf_create(momf_scene **out, int device, hipStream_t stream, int N, int nS, int S, int max_m, int *d_info);
 void momf_destroy(momf_scene *s);
 const char *momf_error(const momf_scene *s);
-void momf_set_options(momf_scene *s, int inv_mode, int force_generic, int sweep);
+void momf_set_options(momf_scene *s, int inv_mode, int force_generic, int sweep, int small_n);
 int momf_set_streams(momf_scene *s, const double *mu, const double *wt, const double *sg, int imu0, double mu0, const double *I0,
                      const double *D, int regular);
 int momf_scene_set(momf_scene *s, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
@@ -751,7 +751,7 @@ extern "C" int mom_set_option(mom_t *h, int option, int value) {
     h->opt_force_generic = value;
     h->lds_mode = (h->N <= 64) && !value;
   } else return fail(h, MOM_EINVAL, "mom_set_option: unknown option");
-  if (h->f32) momf_set_options(h->f32, h->opt_inverse, h->opt_force_generic, h->opt_sweep);
+  if (h->f32) momf_set_options(h->f32, h->opt_inverse, h->opt_force_generic, h->opt_sweep, h->opt_small);
   return MOM_OK;
 }
 
@@ -785,7 +785,7 @@ extern "C" int mom_set_streams(mom_t *h, const double *qp_muN, const double *wt_
   for (int i = 0; i < N; ++i)
     if (qp_muN[i] != qp_muN[(i / h->nS) * h->nS]) q.regular = 0;
   if (h->f32) {
-    momf_set_options(h->f32, h->opt_inverse, h->opt_force_generic, h->opt_sweep);
+    momf_set_options(h->f32, h->opt_inverse, h->opt_force_generic, h->opt_sweep, h->opt_small);
     const int rc = momf_set_streams(h->f32, qp_muN, wt_muN, sg.data(), imu0_1based, mu0, I0, D, q.regular);
     if (rc) return fail(h, rc, momf_error(h->f32));
   }

@@ -132,7 +132,8 @@ struct momf_scene {
   float *d_R = nullptr, *d_T = nullptr, *d_hdr = nullptr, *d_hdrJ = nullptr, *d_hdrJm = nullptr, *d_bhr_uw = nullptr,
         *d_bhr_dw = nullptr, *d_scratch = nullptr, *d_Rsurf = nullptr, *d_albedo_spec = nullptr;
   double *d_cos = nullptr, *d_sin = nullptr;
-  int *d_node = nullptr, *d_info = nullptr;
+  int *d_node = nullptr, *d_info = nullptr, *d_nd = nullptr;  // d_nd: ndoubl per layer for the wave-per-point kernel
+  bool small_n = true;                    // MOM_OPT_SMALL_N: 4 < N <= 32 on the wave-per-point kernels (mom_wave.hip, Float32 build)
   int Nz = 0, K = 0, M = 0, nVza = 0, surf_kind = 0, G = 1024;
   float albedo = 0.f;
   std::vector<int> nd, iface;
@@ -185,12 +186,13 @@ void momf_destroy(momf_scene *s) {
   for (int k = 0; k < 6; ++k) fr(s->comp[k]);
   fr(s->d_tau); fr(s->d_varpi); fr(s->d_zw); fr(s->d_tau_sum); fr(s->d_Zpp); fr(s->d_Zmp); fr(s->d_R); fr(s->d_hdr);
   fr(s->d_hdrJ); fr(s->d_hdrJm); fr(s->d_bhr_uw); fr(s->d_bhr_dw); fr(s->d_scratch); fr(s->d_Rsurf); fr(s->d_albedo_spec);
-  fr(s->d_cos); fr(s->d_sin); fr(s->d_node);
+  fr(s->d_cos); fr(s->d_sin); fr(s->d_node); fr(s->d_nd);
   for (int k = 0; k < 4; ++k) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
   delete s;
 }
 
-void momf_set_options(momf_scene *s, int inv_mode, int force_generic, int sweep) {
+void momf_set_options(momf_scene *s, int inv_mode, int force_generic, int sweep, int small_n) {
+  s->small_n = small_n != 0;
   s->q.inv_mode = inv_mode;
   s->force_generic = force_generic != 0;
   s->lds = (s->N <= 64) && !s->force_generic;
@@ -274,8 +276,44 @@ int momf_scene_set_surface(momf_scene *s, int kind, int M, const double *Rsurf, 
 template <class K>
 static hipError_t allow(K kernel, size_t bytes) { return mom_allow_lds(reinterpret_cast<const void *>(kernel), bytes); }
 
+hipError_t momwf_launch_sweep(const void *args, hipStream_t st);  // mom_wave.hip built with -DMOMW_FLOAT
+
+// 4 < N <= 32: one spectral point per wavefront, operators in MFMA-layout registers, the whole run in ONE launch -- the
+// Float32 build of momw::k_wsweep (the Float64 path: rt_run_wave in momcore.hip).  Covers ScatteringInterface_11 on every
+// layer after the first and at the surface.
+static bool wave_applies_f32(const momf_scene *s) {
+  if (!(s->N > 4 && s->N <= 32 && s->small_n && !s->force_generic && s->nVza * s->nS <= 256)) return false;
+  for (int z = 1; z < s->Nz; ++z)
+    if (s->iface[z] != 3) return false;
+  return s->iface[s->Nz - 1] == 3;
+}
+static int rt_run_wave_f32(momf_scene *s) {
+  if (!s->d_nd) FCHK(s, hipMalloc((void **)&s->d_nd, sizeof(int) * kMaxSweepLayers * 4));
+  if (s->Nz > kMaxSweepLayers * 4) { s->err = "Float32 wave sweep: too many layers"; return MOM_EINVAL; }
+  FCHK(s, hipMemcpyAsync(s->d_nd, s->nd.data(), sizeof(int) * s->Nz, hipMemcpyHostToDevice, s->stream));
+  MomWaveSweepArgsF a{};
+  a.N = s->N; a.S = s->S; a.M = s->M; a.K = s->K; a.Nz = s->Nz; a.nVza = s->nVza; a.nS = s->nS; a.imu0 = s->q.imu0;
+  a.inv_mode = s->q.inv_mode;
+  a.mu0 = s->q.mu0; a.albedo = s->albedo;
+  for (int k = 0; k < 4; ++k) { a.I0[k] = s->q.I0[k]; a.D[k] = s->q.D[k]; }
+  a.mu = s->d_mu; a.wt = s->d_wt; a.sg = s->d_sg;
+  a.Zpp = s->d_Zpp; a.Zmp = s->d_Zmp;
+  a.nd = s->d_nd; a.node = s->d_node; a.cos_mphi = s->d_cos; a.sin_mphi = s->d_sin;
+  a.tau = s->d_tau; a.varpi = s->d_varpi; a.zw = s->d_zw; a.tau_sum = s->d_tau_sum;
+  a.R = s->d_R; a.T = s->d_T; a.hdr = s->d_hdr; a.bhr_uw = s->d_bhr_uw; a.bhr_dw = s->d_bhr_dw;
+  a.info = s->d_info;
+  a.surf_kind = s->surf_kind; a.Rsurf = s->d_Rsurf; a.albedo_spec = s->d_albedo_spec;
+  FCHK(s, hipEventRecord(s->ev[0], s->stream));
+  FCHK(s, momwf_launch_sweep(&a, s->stream));
+  for (int k = 1; k < 4; ++k) FCHK(s, hipEventRecord(s->ev[k], s->stream));
+  FCHK(s, hipStreamSynchronize(s->stream));  // s->nd may be rewritten by the next scene_set
+  s->launches = 1;
+  return MOM_OK;
+}
+
 int momf_rt_run(momf_scene *s) {
   FCHK(s, hipSetDevice(s->device));
+  if (wave_applies_f32(s)) return rt_run_wave_f32(s);
   const size_t S = s->S;
   const int N = s->N, M = s->M, Nz = s->Nz;
   const bool lds = s->lds;
