@@ -41,23 +41,26 @@ hipError_t mom_line_prefactors_launch(hipStream_t st, const MomLineTable &tb, in
 
 // argument blocks of the single-launch sweep kernels, shared by the launching translation unit (momcore.hip) and the
 // kernels' own (mom_small.hip: momsm::k_sweep; mom_wave.hip: momw::k_wsweep)
-struct MomSmallSweepArgs {
+template <class Real>
+struct MomSmallSweepArgsT {
   int S, M, K, Nz, nVza, nS, imu0, pad;
-  double mu0, albedo;
-  double I0[4], D[4];
+  Real mu0, albedo;
+  Real I0[4], D[4];
   // per-scene tables, the same for every spectral point (read through the scalar cache)
-  const double *mu, *wt, *sg;         // [N]
-  const double *F1, *F2, *SI;         // [N,N] i + N j: mu_j/(mu_i+mu_j), mu_j/(mu_i-mu_j), (1/mu_i)+(1/mu_j)
-  const double *Zpp, *Zmp;            // [N,N,K,M]
+  const Real *mu, *wt, *sg;         // [N]
+  const Real *F1, *F2, *SI;         // [N,N] i + N j: mu_j/(mu_i+mu_j), mu_j/(mu_i-mu_j), (1/mu_i)+(1/mu_j)
+  const Real *Zpp, *Zmp;            // [N,N,K,M]
   const int *nd, *iface;              // [Nz]
   const int *node;                    // [nVza]
   const double *cos_mphi, *sin_mphi;  // [nVza,M]
   // per-point inputs
-  const double *tau, *varpi, *zw, *tau_sum;  // [S,Nz], [S,Nz], [K,S,Nz], [S,Nz+1]
+  const Real *tau, *varpi, *zw, *tau_sum;  // [S,Nz], [S,Nz], [K,S,Nz], [S,Nz+1]
   // outputs
-  double *R, *T, *hdr, *bhr_uw, *bhr_dw;  // [nVza,nS,S] x3, [nS,S] x2
+  Real *R, *T, *hdr, *bhr_uw, *bhr_dw;  // [nVza,nS,S] x3, [nS,S] x2
   int *info;
 };
+using MomSmallSweepArgs = MomSmallSweepArgsT<double>;
+using MomSmallSweepArgsF = MomSmallSweepArgsT<float>;  // mom_small.hip with -DMOMS_FLOAT
 template <class Real>
 struct MomWaveSweepArgsT {
   int N, S, M, K, Nz, nVza, nS, imu0, inv_mode, pad;

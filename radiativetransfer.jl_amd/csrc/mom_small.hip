@@ -20,15 +20,25 @@
 
 #include "mom_host.hpp"
 
-namespace momsm {
+// The same source builds the Float32 lane-per-point kernels (-DMOMS_FLOAT: namespace momsmf, MomSmallSweepArgsF).
+#ifdef MOMS_FLOAT
+#define MOMS_NS momsmf
+#define MOMS_LAUNCH momsmf_launch_sweep
+typedef float real;
+#else
+#define MOMS_NS momsm
+#define MOMS_LAUNCH momsm_launch_sweep
+typedef double real;
+#endif
+namespace MOMS_NS {
 
 template <int N>
 struct Mat {
-  double a[N][N];  // a[i][j]: row i, column j
+  real a[N][N];  // a[i][j]: row i, column j
 };
 template <int N>
 struct Vec {
-  double v[N];
+  real v[N];
 };
 
 template <int N>
@@ -37,7 +47,7 @@ __device__ __forceinline__ void mul(Mat<N> &C, const Mat<N> &A, const Mat<N> &B)
   for (int i = 0; i < N; ++i)
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-      double s = 0.0;
+      real s = 0.0;
 #pragma unroll
       for (int k = 0; k < N; ++k) s += A.a[i][k] * B.a[k][j];
       C.a[i][j] = s;
@@ -47,7 +57,7 @@ template <int N>
 __device__ __forceinline__ void mulv(Vec<N> &y, const Mat<N> &A, const Vec<N> &x) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    double s = 0.0;
+    real s = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) s += A.a[i][k] * x.v[k];
     y.v[i] = s;
@@ -69,11 +79,11 @@ __device__ __forceinline__ int inv_one_minus(Mat<N> &X, const Mat<N> &B) {
   int bad = 0;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    double best = fabs(A.a[k][k]);
+    real best = fabs(A.a[k][k]);
     int p = k;
 #pragma unroll
     for (int i = k + 1; i < N; ++i) {
-      const double v = fabs(A.a[i][k]);
+      const real v = fabs(A.a[i][k]);
       if (v > best) { best = v; p = i; }
     }
 #pragma unroll
@@ -81,7 +91,7 @@ __device__ __forceinline__ int inv_one_minus(Mat<N> &X, const Mat<N> &B) {
       const bool sw = (p == i);
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        const double ak = A.a[k][j], ai = A.a[i][j], xk = X.a[k][j], xi = X.a[i][j];
+        const real ak = A.a[k][j], ai = A.a[i][j], xk = X.a[k][j], xi = X.a[i][j];
         A.a[k][j] = sw ? ai : ak;
         A.a[i][j] = sw ? ak : ai;
         X.a[k][j] = sw ? xi : xk;
@@ -89,7 +99,7 @@ __device__ __forceinline__ int inv_one_minus(Mat<N> &X, const Mat<N> &B) {
       }
     }
     if (!(best > 0.0) && !bad) bad = k + 1;
-    const double d = 1.0 / A.a[k][k];
+    const real d = 1.0 / A.a[k][k];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       A.a[k][j] *= d;
@@ -98,7 +108,7 @@ __device__ __forceinline__ int inv_one_minus(Mat<N> &X, const Mat<N> &B) {
 #pragma unroll
     for (int i = 0; i < N; ++i)
       if (i != k) {
-        const double f = A.a[i][k];
+        const real f = A.a[i][k];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
           A.a[i][j] -= f * A.a[k][j];
@@ -109,7 +119,7 @@ __device__ __forceinline__ int inv_one_minus(Mat<N> &X, const Mat<N> &B) {
   return bad;
 }
 
-using SweepArgs = ::MomSmallSweepArgs;  // mom_host.hpp: the one definition shared with momcore.hip
+using SweepArgs = ::MomSmallSweepArgsT<real>;  // mom_host.hpp: the one definition shared with momcore.hip / momcore_f32.hip
 
 template <int N>
 __global__ void __launch_bounds__(256, 1) k_sweep(SweepArgs a) {
@@ -120,30 +130,30 @@ __global__ void __launch_bounds__(256, 1) k_sweep(SweepArgs a) {
   int bad = 0;
   // R_SFI / T_SFI / hdr accumulate over the moments in registers (at most 4 views x 4 components kept here; the host
   // dispatches larger view sets to the general kernels)
-  double accR[16], accT[16], accH[16];
+  real accR[16], accT[16], accH[16];
 #pragma unroll
   for (int x = 0; x < 16; ++x) accR[x] = accT[x] = accH[x] = 0.0;
-  double bup[4] = {0, 0, 0, 0}, bdw[4] = {0, 0, 0, 0};
+  real bup[4] = {0, 0, 0, 0}, bdw[4] = {0, 0, 0, 0};
 
   for (int m = 0; m < a.M; ++m) {
-    const double wdiv = (m == 0) ? 2.0 : 4.0, wct02 = (m == 0) ? 0.5 : 0.25;
+    const real wdiv = (m == 0) ? 2.0 : 4.0, wct02 = (m == 0) ? 0.5 : 0.25;
     Mat<N> Rmp, Rpm, Tpp, Tmm;  // composite layer
     Vec<N> Jp, Jm;
-    const double *Zp_m = a.Zpp + (size_t)N * N * K * m, *Zm_m = a.Zmp + (size_t)N * N * K * m;
+    const real *Zp_m = a.Zpp + (size_t)N * N * K * m, *Zm_m = a.Zmp + (size_t)N * N * K * m;
     for (int z = 0; z < a.Nz; ++z) {
       const int nd = a.nd[z], iface = a.iface[z];
       const size_t o = n + (size_t)S * z;
-      const double tau = a.tau[o], varpi = a.varpi[o], tau_sum = a.tau_sum[o];
-      const double dtau = ldexp(tau, -nd);  // τ ./ 2^ndoubl (rt_kernel.jl:244)
-      double expk = exp(-dtau / a.mu0);     // init_layer (rt_kernel.jl:273)
-      double zw[4];
+      const real tau = a.tau[o], varpi = a.varpi[o], tau_sum = a.tau_sum[o];
+      const real dtau = ldexp(tau, -nd);  // τ ./ 2^ndoubl (rt_kernel.jl:244)
+      real expk = exp(-dtau / a.mu0);     // init_layer (rt_kernel.jl:273)
+      real zw[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) zw[k] = (k < K) ? a.zw[k + (size_t)K * o] : 0.0;
       // ---------------- elemental! (elemental.jl:164-253)
       Mat<N> r, t;
       Vec<N> jp, jm;
       {
-        double ei[N];
+        real ei[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) ei[i] = exp(-dtau / a.mu[i]);
         Vec<N> zpI, zmI;  // Z I0 over the sun's Stokes block (:225-228)
@@ -151,10 +161,10 @@ __global__ void __launch_bounds__(256, 1) k_sweep(SweepArgs a) {
         for (int i = 0; i < N; ++i) zpI.v[i] = zmI.v[i] = 0.0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-          const double wj = a.wt[j] / wdiv;
+          const real wj = a.wt[j] / wdiv;
 #pragma unroll
           for (int i = 0; i < N; ++i) {
-            double zp = 0.0, zm = 0.0;  // Z = sum_k w_k Z_k, in k order (types.jl:656-661)
+            real zp = 0.0, zm = 0.0;  // Z = sum_k w_k Z_k, in k order (types.jl:656-661)
             for (int k = 0; k < K; ++k) {
               zp += zw[k] * Zp_m[i + N * j + N * N * k];
               zm += zw[k] * Zm_m[i + N * j + N * N * k];
@@ -163,7 +173,7 @@ __global__ void __launch_bounds__(256, 1) k_sweep(SweepArgs a) {
               zpI.v[i] += zp * a.I0[j - i_start];
               zmI.v[i] += zm * a.I0[j - i_start];
             }
-            double rr, tt;
+            real rr, tt;
             if (wj > 1.e-8) {
               rr = varpi * zm * a.F1[i + N * j] * wj * (1 - exp(-dtau * a.SI[i + N * j]));
               if (a.mu[i] == a.mu[j]) {
@@ -180,11 +190,11 @@ __global__ void __launch_bounds__(256, 1) k_sweep(SweepArgs a) {
             t.a[i][j] = tt;
           }
         }
-        const double mus = a.mu[i_start], att = exp(-tau_sum / mus);
+        const real mus = a.mu[i_start], att = exp(-tau_sum / mus);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-          const double mui = a.mu[i];
-          double p, q;
+          const real mui = a.mu[i];
+          real p, q;
           if (i >= i_start && i < i_end)
             p = wct02 * varpi * zpI.v[i] * (dtau / mui) * ei[i];
           else
@@ -245,7 +255,7 @@ __global__ void __launch_bounds__(256, 1) k_sweep(SweepArgs a) {
       for (int i = 0; i < N; ++i)
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-          const double s = a.sg[i] * a.sg[j];
+          const real s = a.sg[i] * a.sg[j];
           rpm.a[i][j] = s * r.a[i][j];
           tmm.a[i][j] = s * t.a[i][j];
         }
@@ -335,8 +345,8 @@ __global__ void __launch_bounds__(256, 1) k_sweep(SweepArgs a) {
     for (int i = 0; i < N; ++i) hdrJ.v[i] = 0.0;
     if (m == 0) {
       const int iface = a.iface[a.Nz - 1];
-      const double rho = 2 * a.albedo;
-      const double att = exp(-a.tau_sum[n + (size_t)S * a.Nz] / a.mu0);
+      const real rho = 2 * a.albedo;
+      const real att = exp(-a.tau_sum[n + (size_t)S * a.Nz] / a.mu0);
       Mat<N> rs;
       Vec<N> jp, jm;
 #pragma unroll
@@ -399,7 +409,7 @@ __global__ void __launch_bounds__(256, 1) k_sweep(SweepArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (k < nS) {
-          double up = 0.0, dw = 0.0;
+          real up = 0.0, dw = 0.0;
 #pragma unroll
           for (int j = 0; j < N; ++j)
             if (j % nS == k) {
@@ -411,14 +421,14 @@ __global__ void __launch_bounds__(256, 1) k_sweep(SweepArgs a) {
         }
     }
     // ---------------- postprocessing_vza! / postprocessing_vza_hdrf! (postprocessing_vza.jl:9-93)
-    const double weight = (m == 0) ? 0.5 : 1.0;
+    const real weight = (m == 0) ? 0.5 : 1.0;
     for (int v = 0; v < a.nVza; ++v) {
       const int row0 = (a.node[v] - 1) * nS;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (k < nS) {
-          const double cs = weight * ((k < 2) ? a.cos_mphi[v + a.nVza * m] : a.sin_mphi[v + a.nVza * m]);
-          double jmv = 0.0, jpv = 0.0, hv = 0.0;
+          const real cs = weight * ((k < 2) ? a.cos_mphi[v + a.nVza * m] : a.sin_mphi[v + a.nVza * m]);
+          real jmv = 0.0, jpv = 0.0, hv = 0.0;
 #pragma unroll
           for (int i = 0; i < N; ++i)
             if (i == row0 + k) { jmv = Jm.v[i]; jpv = Jp.v[i]; hv = hdrJ.v[i]; }
@@ -454,18 +464,20 @@ __global__ void __launch_bounds__(256, 1) k_sweep(SweepArgs a) {
   if (bad) atomicMax(a.info, bad);
 }
 
-}  // namespace momsm
+}  // namespace MOMS_NS
 
-// host entry used by momcore.hip (argument block = momsm::SweepArgs, passed as bytes)
-size_t momsm_args_bytes() { return sizeof(momsm::SweepArgs); }
-hipError_t momsm_launch_sweep(const void *args, int N, hipStream_t st) {
-  const momsm::SweepArgs a = *reinterpret_cast<const momsm::SweepArgs *>(args);
+// host entry used by momcore.hip (argument block = MOMS_NS::SweepArgs, passed as bytes)
+#ifndef MOMS_FLOAT
+size_t momsm_args_bytes() { return sizeof(MOMS_NS::SweepArgs); }
+#endif
+hipError_t MOMS_LAUNCH(const void *args, int N, hipStream_t st) {
+  const MOMS_NS::SweepArgs a = *reinterpret_cast<const MOMS_NS::SweepArgs *>(args);
   const dim3 grid((unsigned)((a.S + 255) / 256)), block(256);
   switch (N) {
-    case 1: hipLaunchKernelGGL(momsm::k_sweep<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(momsm::k_sweep<2>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(momsm::k_sweep<3>, grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(momsm::k_sweep<4>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(MOMS_NS::k_sweep<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(MOMS_NS::k_sweep<2>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(MOMS_NS::k_sweep<3>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(MOMS_NS::k_sweep<4>, grid, block, 0, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

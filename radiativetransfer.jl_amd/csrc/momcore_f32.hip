@@ -132,6 +132,7 @@ struct momf_scene {
   float *d_R = nullptr, *d_T = nullptr, *d_hdr = nullptr, *d_hdrJ = nullptr, *d_hdrJm = nullptr, *d_bhr_uw = nullptr,
         *d_bhr_dw = nullptr, *d_scratch = nullptr, *d_Rsurf = nullptr, *d_albedo_spec = nullptr;
   double *d_cos = nullptr, *d_sin = nullptr;
+  float *d_smtab = nullptr;               // N <= 4: the three stream-pair tables of the lane-per-point kernel
   int *d_node = nullptr, *d_info = nullptr, *d_nd = nullptr;  // d_nd: ndoubl per layer for the wave-per-point kernel
   bool small_n = true;                    // MOM_OPT_SMALL_N: 4 < N <= 32 on the wave-per-point kernels (mom_wave.hip, Float32 build)
   int Nz = 0, K = 0, M = 0, nVza = 0, surf_kind = 0, G = 1024;
@@ -186,7 +187,7 @@ void momf_destroy(momf_scene *s) {
   for (int k = 0; k < 6; ++k) fr(s->comp[k]);
   fr(s->d_tau); fr(s->d_varpi); fr(s->d_zw); fr(s->d_tau_sum); fr(s->d_Zpp); fr(s->d_Zmp); fr(s->d_R); fr(s->d_hdr);
   fr(s->d_hdrJ); fr(s->d_hdrJm); fr(s->d_bhr_uw); fr(s->d_bhr_dw); fr(s->d_scratch); fr(s->d_Rsurf); fr(s->d_albedo_spec);
-  fr(s->d_cos); fr(s->d_sin); fr(s->d_node); fr(s->d_nd);
+  fr(s->d_cos); fr(s->d_sin); fr(s->d_node); fr(s->d_nd); fr(s->d_smtab);
   for (int k = 0; k < 4; ++k) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
   delete s;
 }
@@ -311,8 +312,48 @@ static int rt_run_wave_f32(momf_scene *s) {
   return MOM_OK;
 }
 
+hipError_t momsmf_launch_sweep(const void *args, int N, hipStream_t st);  // mom_small.hip built with -DMOMS_FLOAT
+
+// N <= 4: one spectral point per lane, the whole run in ONE launch (the Float64 path: rt_run_small in momcore.hip)
+static int rt_run_small_f32(momf_scene *s) {
+  const int N = s->N, Nz = s->Nz;
+  if (!s->d_smtab) FCHK(s, hipMalloc((void **)&s->d_smtab, sizeof(float) * 48));
+  if (!s->d_nd) FCHK(s, hipMalloc((void **)&s->d_nd, sizeof(int) * kMaxSweepLayers * 4));
+  if (2 * Nz > kMaxSweepLayers * 4) { s->err = "Float32 lane sweep: too many layers"; return MOM_EINVAL; }
+  float tab[48] = {0};
+  for (int j = 0; j < N; ++j)
+    for (int i = 0; i < N; ++i) {  // the expressions of elemental.jl:176-186 in Float32, evaluated once
+      const float mui = s->h_mu[i], muj = s->h_mu[j];
+      tab[i + N * j] = muj / (mui + muj);
+      tab[16 + i + N * j] = muj / (mui - muj);
+      tab[32 + i + N * j] = (1 / mui) + (1 / muj);
+    }
+  FCHK(s, hipMemcpyAsync(s->d_smtab, tab, sizeof tab, hipMemcpyHostToDevice, s->stream));
+  std::vector<int> v(s->nd);
+  v.insert(v.end(), s->iface.begin(), s->iface.end());
+  FCHK(s, hipMemcpyAsync(s->d_nd, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+  FCHK(s, hipStreamSynchronize(s->stream));
+  MomSmallSweepArgsF a{};
+  a.S = s->S; a.M = s->M; a.K = s->K; a.Nz = Nz; a.nVza = s->nVza; a.nS = s->nS; a.imu0 = s->q.imu0;
+  a.mu0 = s->q.mu0; a.albedo = s->albedo;
+  for (int k = 0; k < 4; ++k) { a.I0[k] = s->q.I0[k]; a.D[k] = s->q.D[k]; }
+  a.mu = s->d_mu; a.wt = s->d_wt; a.sg = s->d_sg;
+  a.F1 = s->d_smtab; a.F2 = s->d_smtab + 16; a.SI = s->d_smtab + 32;
+  a.Zpp = s->d_Zpp; a.Zmp = s->d_Zmp;
+  a.nd = s->d_nd; a.iface = s->d_nd + Nz; a.node = s->d_node; a.cos_mphi = s->d_cos; a.sin_mphi = s->d_sin;
+  a.tau = s->d_tau; a.varpi = s->d_varpi; a.zw = s->d_zw; a.tau_sum = s->d_tau_sum;
+  a.R = s->d_R; a.T = s->d_T; a.hdr = s->d_hdr; a.bhr_uw = s->d_bhr_uw; a.bhr_dw = s->d_bhr_dw;
+  a.info = s->d_info;
+  FCHK(s, hipEventRecord(s->ev[0], s->stream));
+  FCHK(s, momsmf_launch_sweep(&a, N, s->stream));
+  for (int k = 1; k < 4; ++k) FCHK(s, hipEventRecord(s->ev[k], s->stream));
+  s->launches = 1;
+  return MOM_OK;
+}
+
 int momf_rt_run(momf_scene *s) {
   FCHK(s, hipSetDevice(s->device));
+  if (s->N <= 4 && s->small_n && !s->force_generic && s->nVza <= 4 && s->surf_kind == 0 && s->K <= 4) return rt_run_small_f32(s);
   if (wave_applies_f32(s)) return rt_run_wave_f32(s);
   const size_t S = s->S;
   const int N = s->N, M = s->M, Nz = s->Nz;

@@ -484,10 +484,12 @@ def test_surface_types(rtamd, cref, surf, nS, lt, mode):
     assert np.abs(R0 - R).max() > 1e-6
 
 
-@pytest.mark.parametrize("nS,lt,kw", [(3, 9, {}), (1, 5, {}), (4, 7, {}), (3, 33, {}), (4, 31, dict(generic=True)), (3, 9, dict(surf="rpv"))])
+@pytest.mark.parametrize("nS,lt,kw", [(3, 9, {}), (1, 5, {}), (4, 7, {}), (3, 33, {}), (4, 31, dict(generic=True)), (3, 9, dict(surf="rpv")),
+                                      (1, 1, {}), (1, 1, dict(generic=True)), (4, 7, dict(generic=True))])
 def test_float32_scene_level_path(rtamd, cref, nS, lt, kw):
-    """dtype = 1 (the reference's float_type = Float32): the same scene through the f32 build of the fused kernels
-    (v_mfma_f32_16x16x4_f32, operators in f32) against the Float64 oracle.  Tolerance: the elemental layer has
+    """dtype = 1 (the reference's float_type = Float32): the same scene through the f32 builds -- the lane-per-point kernel
+    (N = 4), the wave-per-point kernels (N = 6, 27, 28: v_mfma_f32_16x16x4_f32) and the fused workgroup kernels (N = 60, forced
+    generic cases) -- against the Float64 oracle.  Tolerance: the elemental layer has
     dtau <= 1e-3 min(mu) (rt_kernel.jl:241), so its transmission along the most vertical stream, t = exp(-dtau/mu_max)
     ~ 1 - 1e-3 min(mu)/max(mu), is stored in Float32 with an absolute error of eps32 = 6e-8: a RELATIVE error of
     eps32 / (1e-3 min(mu)) of that stream's optical depth, which the doublings carry into the layer transmission.
