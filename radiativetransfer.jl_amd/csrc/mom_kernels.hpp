@@ -438,8 +438,13 @@ __host__ __device__ inline int comp_pitch(int N) { return 16 * ((N + 15) / 16); 
 //    instruction -- the element-order stores cost 35 us of a 180 us product, the transposed ones 12.
 // All threads must call; C must not alias A or B; ends WITHOUT a barrier after the epilogue (callers add theirs).
 // ---------------------------------------------------------------------------------------
+// operands that are padded slab buffers: ElP, and ElSigP = diag(sg) buffer diag(sg) (the added layer's r+- / t-- in the
+// interaction: the signs are applied when the panel goes from registers to LDS)
 template <class F> struct is_elp { static constexpr bool value = false; };
 template <> struct is_elp<ElP> { static constexpr bool value = true; };
+template <> struct is_elp<ElSigP> { static constexpr bool value = true; };
+template <class F> struct has_sig { static constexpr bool value = false; };
+template <> struct has_sig<ElSigP> { static constexpr bool value = true; };
 
 template <int TN, class FA, class FB, class FE>
 __device__ __attribute__((noinline)) void gemm_big_pass(int N, int NC, FA A, FB B, FE epi, int row0, int tcnt, int TMr, int TNr) {
@@ -464,6 +469,17 @@ __device__ __attribute__((noinline)) void gemm_big_pass(int N, int NC, FA A, FB 
     pb1 = B.p + kq2 + (size_t)(cb1 < NC - 1 ? cb1 : NC - 1) * B.ld;
   }
   gb1[0] = gb1[1] = (r2){0.0, 0.0};
+  // ElSigP: the signs of this thread's fixed coordinates (rows of its A pair, columns of its B pairs)
+  real sra0 = 1.0, sra1 = 1.0, scb0 = 1.0, scb1 = 1.0;
+  if constexpr (has_sig<FA>::value) {
+    const int ic = ia < Np - 2 ? ia : Np - 2;
+    sra0 = A.sg[ic < N ? ic : N - 1];
+    sra1 = A.sg[ic + 1 < N ? ic + 1 : N - 1];
+  }
+  if constexpr (has_sig<FB>::value) {
+    scb0 = B.sg[cb0 < N ? cb0 : N - 1];
+    scb1 = B.sg[cb1 < N ? cb1 : N - 1];
+  }
   r4 acc[TM][TN];
 #pragma unroll
   for (int ti = 0; ti < TM; ++ti)
@@ -500,6 +516,18 @@ __device__ __attribute__((noinline)) void gemm_big_pass(int N, int NC, FA A, FB 
   auto stash = [&](int p, int set) {
     const int st = p % kBigStages, k0 = p * kBigKB;
     r2 va = ga[set], v0 = gb0[set], v1 = gb1[set];
+    if constexpr (has_sig<FA>::value) {
+      const int k = k0 + wave;
+      const real sk = A.sg[k < N ? k : N - 1];
+      va.x *= sra0 * sk;
+      va.y *= sra1 * sk;
+    }
+    if constexpr (has_sig<FB>::value) {
+      const int k = k0 + kq2;
+      const real s0 = B.sg[k < N ? k : N - 1], s1 = B.sg[k + 1 < N ? k + 1 : N - 1];
+      v0.x *= s0 * scb0; v0.y *= s1 * scb0;
+      v1.x *= s0 * scb1; v1.y *= s1 * scb1;
+    }
     if (k0 + kBigKB > N) {  // last panel of an operator whose edge is not a multiple of 8 (uniform branch)
       if constexpr (is_elp<FA>::value) {
         if (k0 + wave >= N) va = (r2){0.0, 0.0};
