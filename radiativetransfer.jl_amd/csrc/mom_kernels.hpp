@@ -443,9 +443,6 @@ __host__ __device__ inline int comp_pitch(int N) { return 16 * ((N + 15) / 16); 
 template <class F> struct is_elp { static constexpr bool value = false; };
 template <> struct is_elp<ElP> { static constexpr bool value = true; };
 template <> struct is_elp<ElSigP> { static constexpr bool value = true; };
-template <> struct is_elp<El> { static constexpr bool value = true; };  // composite block [ld >= N rows, N columns]: no padding to read
-template <class F> struct is_padded { static constexpr bool value = true; };   // rows / k up to np_for(N) + 1 exist behind every column
-template <> struct is_padded<El> { static constexpr bool value = false; };
 template <class F> struct has_sig { static constexpr bool value = false; };
 template <> struct has_sig<ElSigP> { static constexpr bool value = true; };
 
@@ -466,13 +463,10 @@ __device__ __attribute__((noinline)) void gemm_big_pass(int N, int NC, FA A, FB 
   const int ia = row0 + 2 * lane;
   r2 ga[2], gb0[2], gb1[2];
   const real *pa = nullptr, *pb0 = nullptr, *pb1 = nullptr;
-  if constexpr (is_elp<FA>::value) {
-    const int rmax = is_padded<FA>::value ? Np - 2 : N - 2;  // rows beyond feed outputs the epilogue discards
-    pa = (const real *)A.p + (ia < rmax ? ia : rmax);
-  }
+  if constexpr (is_elp<FA>::value) pa = A.p + (ia < Np - 2 ? ia : Np - 2);
   if constexpr (is_elp<FB>::value) {
-    pb0 = (const real *)B.p + (size_t)(cb0 < NC - 1 ? cb0 : NC - 1) * B.ld;
-    pb1 = (const real *)B.p + (size_t)(cb1 < NC - 1 ? cb1 : NC - 1) * B.ld;
+    pb0 = B.p + kq2 + (size_t)(cb0 < NC - 1 ? cb0 : NC - 1) * B.ld;
+    pb1 = B.p + kq2 + (size_t)(cb1 < NC - 1 ? cb1 : NC - 1) * B.ld;
   }
   gb1[0] = gb1[1] = (r2){0.0, 0.0};
   // ElSigP: the signs of this thread's fixed coordinates (rows of its A pair, columns of its B pairs)
@@ -505,9 +499,9 @@ __device__ __attribute__((noinline)) void gemm_big_pass(int N, int NC, FA A, FB 
     {
       const int k = k0 + kq2;
       if constexpr (is_elp<FB>::value) {
-        const int kc = (is_padded<FB>::value || k < N - 2) ? k : N - 2;  // k >= N: zeroed by the stash (a select here would wait for the load)
-        gb0[set] = *(const r2 *)(pb0 + kc);
-        if (two_b) gb1[set] = *(const r2 *)(pb1 + kc);
+        gb0[set] = *(const r2 *)(pb0 + k0);  // k >= N: zeroed by the stash (a select here would wait for the load)
+        if (two_b) gb1[set] = *(const r2 *)(pb1 + k0);
+        (void)k;
       } else {
         gb0[set].x = (k < N && cb0 < NC) ? B(k, cb0) : 0.0;
         gb0[set].y = (k + 1 < N && cb0 < NC) ? B(k + 1, cb0) : 0.0;
@@ -534,15 +528,9 @@ __device__ __attribute__((noinline)) void gemm_big_pass(int N, int NC, FA A, FB 
       v0.x *= s0 * scb0; v0.y *= s1 * scb0;
       v1.x *= s0 * scb1; v1.y *= s1 * scb1;
     }
-    if constexpr (is_elp<FA>::value && !is_padded<FA>::value) {
-      if (ia == N - 1) va.x = va.y;  // odd N: the pair was read one row up (rows N - 2, N - 1); row N is discarded
-    }
     if (k0 + kBigKB > N) {  // last panel of an operator whose edge is not a multiple of 8 (uniform branch)
       if constexpr (is_elp<FA>::value) {
         if (k0 + wave >= N) va = (r2){0.0, 0.0};
-      }
-      if constexpr (is_elp<FB>::value && !is_padded<FB>::value) {
-        if (k0 + kq2 == N - 1) { v0.x = v0.y; v1.x = v1.y; }  // odd N: the pair was read one k down (k = N - 2, N - 1)
       }
       if constexpr (is_elp<FB>::value) {
         if (k0 + kq2 >= N) { v0.x = 0.0; v1.x = 0.0; }
