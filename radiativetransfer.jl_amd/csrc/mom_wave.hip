@@ -147,12 +147,12 @@ __device__ const real kThr2[32] = {
     4.39753040322414940e-02, 4.95274191527264318e-02, 5.52916244610413068e-02, 6.12435157546498479e-02,
     6.73599244364155580e-02, 7.36190389296255826e-02, 8.00004677634075928e-02, 8.64852586225294262e-02};
 #endif
-__device__ __forceinline__ int series_terms(real beta2) {
-  if (!(beta2 <= kThr2[31])) return 1000;
-  int p = 1;
-#pragma unroll
-  for (int k = 0; k < 31; ++k) p += (beta2 > kThr2[k]) ? 1 : 0;
-  return p;
+// thr = kThr2[lane & 31], held in a register for the whole kernel: ONE compare + ballot instead of 31 compares with
+// 64-bit literals (a product of two one-tile operators is only four MFMAs: the scan cost as much as a product)
+__device__ __forceinline__ int series_terms(real beta2, real thr) {
+  const unsigned m = (unsigned)__ballot(beta2 > thr);  // lanes 0..31
+  if (!(beta2 <= beta2) || (m >> 31)) return 1000;     // NaN, or beyond the table
+  return 1 + __popc(m & 0x7fffffffu);
 }
 
 using WArgs = ::MomWaveSweepArgsT<real>;  // mom_host.hpp: the one definition shared with momcore.hip / momcore_f32.hip
@@ -162,6 +162,7 @@ using WArgs = ::MomWaveSweepArgsT<real>;  // mom_host.hpp: the one definition sh
 struct Lay {
   int lr, lq, N, nS;
   const real *tab;
+  real thr;    // kThr2[lane & 31] (series_terms)
   real *xp;  // wave-private LDS slice: transposes / pivoted inverse / output gather
   int *ipiv;
   __device__ __forceinline__ int row(int bi, int r) const { return 16 * bi + crow(lq, r); }
@@ -312,7 +313,7 @@ __device__ __forceinline__ Mat<NT> inv_one_minus(const Lay &L, const Mat<NT> &B,
 #pragma unroll
       for (int r = 0; r < 4; ++r) ss += B.t[a][b][r] * B.t[a][b][r];
   const real beta2 = wave_sum(ss);
-  const int p = (inv_mode == 1) ? 1000 : series_terms(beta2);
+  const int p = (inv_mode == 1) ? 1000 : series_terms(beta2, L.thr);
   const Mat<NT> I = ident<NT>(L);
   if (p <= 32) {
     if (p == 1) return I;
@@ -406,7 +407,7 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
   __syncthreads();
   if (n >= S) return;
   Lay L;
-  L.lr = lane & 15; L.lq = lane >> 4; L.N = N; L.nS = nS; L.tab = s_tab; L.xp = s_lds[wave]; L.ipiv = s_piv[wave];
+  L.lr = lane & 15; L.lq = lane >> 4; L.N = N; L.nS = nS; L.tab = s_tab; L.xp = s_lds[wave]; L.ipiv = s_piv[wave]; L.thr = kThr2[lane & 31];
   real *post = L.xp + slice_doubles<NT>() - 3 * 16 * NT;  // J0+ | J0- | hdr_J0-, 16 NT each
   const int i_start = nS * (a.imu0 - 1), i_end = nS * a.imu0;
   const real mus = a.mu[i_start];
