@@ -108,9 +108,59 @@ __device__ __forceinline__ Vec<NT> TNv(const Mat<NT> &U, const Vec<NT> &v) {  //
   return o;
 }
 
+// Cross-lane moves without the LDS crossbar (ds_bpermute behind __shfl_xor: ~100 cycles each in a dependent chain):
+// DPP within a row of 16 lanes, gfx950's permlane swaps across rows / halves.
+template <int CTRL>
+__device__ __forceinline__ real dpp_mov(real v) {
+#ifdef MOMW_FLOAT
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+#else
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+#endif
+}
+__device__ __forceinline__ real swap_rows16(real v) {  // lane ^ 16
+#ifdef MOMW_FLOAT
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(((threadIdx.x >> 4) & 1) ? a[0] : a[1]);
+#else
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const bool odd = (threadIdx.x >> 4) & 1;
+  return __hiloint2double(odd ? b[0] : b[1], odd ? a[0] : a[1]);
+#endif
+}
+__device__ __forceinline__ real swap_halves32(real v) {  // lane ^ 32
+#ifdef MOMW_FLOAT
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(((threadIdx.x >> 5) & 1) ? a[0] : a[1]);
+#else
+  const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const bool up = (threadIdx.x >> 5) & 1;
+  return __hiloint2double(up ? b[0] : b[1], up ? a[0] : a[1]);
+#endif
+}
+// (the Float64 2 x 2-tile images keep the __shfl_xor forms: with the DPP ones the compiler's AGPR rewrite pass crashes
+// on k_wsweep<2, 7> under -amdgpu-mfma-vgpr-form, as it does on k_wsweep<2, 8> anyway)
+template <int NT>
 __device__ __forceinline__ real wave_sum(real v) {
+  if constexpr (NT > 1 && !kF32) {
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+  }
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_mov<0x124>(v);  // row_ror 4
+  v += dpp_mov<0x128>(v);  // row_ror 8: every lane of a row now holds the row's sum
+  v += swap_rows16(v);
+  v += swap_halves32(v);
   return v;
 }
 template <int NT>
@@ -119,7 +169,7 @@ __device__ __forceinline__ Vec<NT> swap01(const Vec<NT> &v) {  // exchange colum
 #pragma unroll
   for (int b = 0; b < NT; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o.t[b][r] = __shfl_xor(v.t[b][r], 1);
+    for (int r = 0; r < 4; ++r) o.t[b][r] = (NT > 1 && !kF32) ? __shfl_xor(v.t[b][r], 1) : dpp_mov<0xB1>(v.t[b][r]);  // lane ^ 1
   return o;
 }
 
@@ -312,7 +362,7 @@ __device__ __forceinline__ Mat<NT> inv_one_minus(const Lay &L, const Mat<NT> &B,
     for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) ss += B.t[a][b][r] * B.t[a][b][r];
-  const real beta2 = wave_sum(ss);
+  const real beta2 = wave_sum<NT>(ss);
   const int p = (inv_mode == 1) ? 1000 : series_terms(beta2, L.thr);
   const Mat<NT> I = ident<NT>(L);
   if (p <= 32) {
@@ -589,8 +639,8 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
               dw += C.Jv.t[b][q] * L.wt(i) * L.mu(i);
             }
           }
-        up = wave_sum(up);
-        dw = wave_sum(dw);
+        up = wave_sum<NT>(up);
+        dw = wave_sum<NT>(dw);
         // + j0+_surf[i_start] mu[i_start]: the direct beam (interaction_hdrf.jl:30)
         const real direct = ((a.surf_kind == 2) ? 0.0 : a.I0[0] * att) * mus;  // j0+_surf[i_start] mu[i_start]
         if (lane == 0) {
