@@ -86,8 +86,44 @@ def spawn_ranks(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
     env = dict(os.environ)
+    # RCCL / CUDA-tensor sharing between processes needs dmabuf IPC on this image's host driver (the legacy IPC mode fails
+    # with hipIpcGetMemHandle: invalid argument); the variable is already exported on the pool's boxes, kept for others
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def init_collective(h, backend, rank, world, dist, collective):
+    """The communicator of the run's ONE collective.  backend "rccl": RCCL through the C ABI (mom_comm_init).  Should its
+    set-up fail on ANY rank (a mis-matched RCCL/HIP pair in the host process, for instance), every rank falls back -- together
+    -- to torch.distributed's own RCCL group, so that a scaling run still produces its line; the JSON says which collective
+    ran.  Returns (backend, torch group or None, description)."""
+    import torch
+    import rtamd
+    group = None
+    if backend != "rccl":
+        return backend, group, collective
+    ok = 1
+    try:
+        ident = [rtamd._lib.comm_unique_id() if rank == 0 else None]
+    except Exception as e:
+        ident, ok = [None], 0
+        print(f"bench.py: mom_comm_unique_id failed on rank {rank}: {e}", file=sys.stderr)
+    dist.broadcast_object_list(ident, src=0)
+    if ok and ident[0] is not None:
+        try:
+            h.comm_init(rank, world, ident[0])
+        except Exception as e:
+            ok = 0
+            print(f"bench.py: mom_comm_init failed on rank {rank}: {e}", file=sys.stderr)
+    else:
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        group = dist.new_group(backend="nccl")
+        backend = "torch-fallback"
+        collective = "torch.distributed all_gather_into_tensor (RCCL; fallback: the C-ABI communicator failed to initialise)"
+    return backend, group, collective
 
 
 def elastic_leg(a, workload, S_loc, steps, warmup, world, rank, dev, dist, with_cpu=True, cpu_budget=12.0):
@@ -121,31 +157,8 @@ def elastic_leg(a, workload, S_loc, steps, warmup, world, rank, dev, dist, with_
     RT = torch.empty(2 * nout, dtype=torch.float64, device=dev)           # local R || T
     G = torch.empty(2 * nout * world, dtype=torch.float64, device=dev) if world > 1 else None
     Gh = torch.empty(2 * nout * world, dtype=torch.float64) if (world > 1 and backend == "gloo") else None
-    if world > 1 and backend == "rccl":
-        # RCCL through the C ABI.  Should its set-up fail on ANY rank (a mis-matched RCCL/HIP pair in the host process,
-        # for instance), every rank falls back -- together -- to torch.distributed's own RCCL group, so that a scaling
-        # run still produces its line; the JSON says which collective ran.
-        ok = 1
-        try:
-            ident = [rtamd._lib.comm_unique_id() if rank == 0 else None]
-        except Exception as e:
-            ident, ok = [None], 0
-            print(f"bench.py: mom_comm_unique_id failed on rank {rank}: {e}", file=sys.stderr)
-        dist.broadcast_object_list(ident, src=0)
-        if ok and ident[0] is not None:
-            try:
-                h.comm_init(rank, world, ident[0])
-            except Exception as e:
-                ok = 0
-                print(f"bench.py: mom_comm_init failed on rank {rank}: {e}", file=sys.stderr)
-        else:
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            nccl_group = dist.new_group(backend="nccl")
-            backend = "torch-fallback"
-            collective = "torch.distributed all_gather_into_tensor (RCCL; fallback: the C-ABI communicator failed to initialise)"
+    if world > 1:
+        backend, nccl_group, collective = init_collective(h, a.backend, rank, world, dist, collective)
 
     def step():
         h.rt_run()
@@ -187,6 +200,13 @@ def elastic_leg(a, workload, S_loc, steps, warmup, world, rank, dev, dist, with_
         mine = np.concatenate([np.transpose(R_loc, (2, 1, 0)).reshape(-1), np.transpose(T_loc, (2, 1, 0)).reshape(-1)])
         got = (Gh if backend == "gloo" else G.cpu()).numpy().reshape(world, 2 * nout)
         assert np.array_equal(got[rank], mine) and np.all(np.isfinite(got)), "all-gather returned wrong data"
+        if a.dump_spectra and rank == 0:     # [world][R|T][S_loc, nStokes, nVza] -> R, T [nVza, nStokes, S_tot]
+            g5 = got.reshape(world, 2, S_loc, shard.nStokes, len(shard.node))
+            RT_full = np.transpose(g5, (1, 4, 3, 0, 2)).reshape(2, len(shard.node), shard.nStokes, S_tot)
+            np.save(a.dump_spectra, RT_full)
+    elif a.dump_spectra:
+        R_loc, T_loc = h.get_RT()
+        np.save(a.dump_spectra, np.stack([R_loc, T_loc]))
     tm = h.timers()  # of the last step, HIP events on the library's stream
     out = None
     if rank == 0:
@@ -279,26 +299,33 @@ def c5_leg(a, S, steps, warmup, dev, with_cpu=True, world=1, rank=0, dist=None):
     rt.scene_set(h, sc)
     h.scene_set_rrs(np.ascontiguousarray(rt.fscatt_rayleigh(m)[wlo:whi].T), rt._abi_mats(Zr_pp), rt._abi_mats(Zr_mp))
     backend = a.backend if world > 1 else "none"
-    gdev = dev if backend in ("torch", "rccl") else None
-    group = None
-    if world > 1 and backend == "rccl":  # the RRS leg gathers through torch.distributed's RCCL group
-        group = dist.new_group(backend="nccl")
-    full = None
+    group, collective = None, "none"
+    per = hi - lo                                  # owned points of this rank (weak scaling: S on every rank)
+    assert per == S
+    cnt = h.rrs_spectra_count(per)                 # (5 nVza nStokes + 2 nStokes) x per: the seven spectra of the return tuple
+    loc = G = Gh = None
+    if world > 1:
+        collective = {"torch": "torch.distributed all_gather_into_tensor (RCCL) of the packed owned spectra",
+                      "rccl": "mom_allgather_rrs_device (RCCL through the C ABI): R, T, ieR, ieT, hdr, bhr_uw, bhr_dw in one all-gather",
+                      "gloo": "gloo host all_gather of the packed owned spectra"}[backend]
+        backend, group, collective = init_collective(h, backend, rank, world, dist, collective)
+        loc = torch.empty(cnt, dtype=torch.float64, device=dev)
+        G = torch.empty(world * cnt, dtype=torch.float64, device=dev)
+        Gh = torch.empty(world * cnt, dtype=torch.float64) if backend == "gloo" else None
 
     def step():
-        nonlocal full
         h.rt_run_rrs()
-        if world > 1:
-            res = h.get_RT_rrs()[:4] + h.get_hdr_rrs()[:1]
-            own = [r[..., lo - wlo:hi - wlo] for r in res]
-            full = gather_c5(own, S_tot, dist, gdev, group)
-
-    def gather_c5(own, S_tot, dist, gdev, group):
-        nrow = sum(int(np.prod(o.shape[:-1])) for o in own)
-        buf = torch.from_numpy(np.concatenate([o.reshape(-1, S) for o in own], axis=0)).to(gdev if gdev is not None else "cpu")
-        out = torch.empty((world, nrow, S), dtype=torch.float64, device=buf.device)
-        dist.all_gather_into_tensor(out.reshape(-1), buf.reshape(-1), group=group)  # ONE collective: the five spectra
-        return out
+        if world == 1:
+            return
+        if backend == "rccl":
+            h.allgather_rrs_device(per, G.data_ptr())                 # pack + ONE collective on the library's stream
+        else:
+            h.get_spectra_rrs_device(per, loc.data_ptr())             # device-side pack of the owned slices
+            h.sync()
+            if backend == "gloo":
+                dist.all_gather_into_tensor(Gh, loc.cpu())
+            else:
+                dist.all_gather_into_tensor(G, loc, group=group)
 
     def fence():
         h.sync()
@@ -316,10 +343,18 @@ def c5_leg(a, S, steps, warmup, dev, with_cpu=True, world=1, rank=0, dist=None):
     fence()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=gdev if gdev is not None else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-        assert bool(torch.isfinite(full).all()), "all-gather returned non-finite spectra"
+        got = (Gh if backend == "gloo" else G.cpu()).numpy().reshape(world, cnt)
+        # this rank's block of the gathered buffer must be its own owned spectra; every block finite
+        res = h.get_RT_rrs()[:4] + h.get_hdr_rrs()
+        own = [np.ascontiguousarray(r[..., lo - wlo:hi - wlo].T).reshape(-1) for r in res]   # ABI order: spectral index slowest
+        assert np.array_equal(got[rank], np.concatenate(own)) and np.all(np.isfinite(got)), "all-gather returned wrong data"
+        if a.dump_spectra and rank == 0:
+            np.save(a.dump_spectra, np.stack(rtamd.sharding.unpack_rrs_spectra(got, len(sc.node), sc.nStokes, per)[:5]))
+    elif a.dump_spectra:
+        np.save(a.dump_spectra, np.stack(h.get_RT_rrs()[:4] + h.get_hdr_rrs()[:1]))
     tk = h.rrs_timers()
     res = h.get_RT_rrs()
     assert np.all(np.isfinite(res[2][..., lo - wlo:hi - wlo])) and np.abs(res[2]).max() > 0
@@ -344,7 +379,7 @@ def c5_leg(a, S, steps, warmup, dev, with_cpu=True, world=1, rank=0, dist=None):
                           "sharding": "none" if world == 1 else
                           f"contiguous spectral slices + recomputed halo of max|i_l1l0| = {int(np.abs(RS.i_λ1λ0).max())} points "
                           f"(rank 0 window: {whi - wlo} points)",
-                          "collective": "none" if world == 1 else "one all_gather_into_tensor of R, T, ieR, ieT, hdr"},
+                          "collective": collective},
                "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                             "traffic": prof.get("hbm_bytes_per_launch"), "kernel": "momr::k_dbl_pair<1>",
                             "avg_launch_ms": avg, "launches_per_step": nl, "pairs_per_launch": pairs,
@@ -431,6 +466,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-voigt", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip extra.workloads / extra.f32 of the default run")
+    ap.add_argument("--dump-spectra", default="", metavar="FILE.npy",
+                    help="rank 0 saves the gathered spectra of the last step (parity of an N-rank run against the 1-rank run)")
     ap.add_argument("--opt", action="append", default=[], metavar="ID=VALUE", help="mom_set_option(ID, VALUE) before the scene is set (kernel A/B runs)")
     a = ap.parse_args()
     if a.gpus < 1:

@@ -168,7 +168,14 @@ int mom_elemental_inelastic_rrs(mom_t *h, int m, int ndoubl, int nRaman, const i
  *   mom_get_hdr_rrs    the elastic RAMI extras of the same return tuple (rt_run.jl:187-213, 226): hdr [nVza, nStokes, nSpec],
  *                      bhr_uw, bhr_dw [nStokes, nSpec] (interaction_hdrf! + postprocessing_vza_hdrf!).
  *   mom_rrs_timers     HIP-event times of the last mom_rt_run_rrs, summed per kernel: ms[0] / launches[0] the doubling pair
- *                      kernel, [1] the interaction pair kernel, [2] the inelastic elemental kernel, [3] the whole run (n >= 4). */
+ *                      kernel, [1] the interaction pair kernel, [2] the inelastic elemental kernel, [3] the whole run (n >= 4).
+ *   mom_get_spectra_rrs_device  the SEVEN spectra of the return tuple (rt_run.jl:226) restricted to the owned points
+ *                      [n1_lo, n1_hi) of mom_rrs_set_shard, packed into the caller's DEVICE buffer as
+ *                      [R | T | ieR | ieT | hdr][nVza, nStokes, per] then [bhr_uw | bhr_dw][nStokes, per]; per >= owned count,
+ *                      tails zero (ragged last shard); mom_rrs_spectra_count(h, per) doubles; asynchronous.
+ *   mom_allgather_rrs_device    the ONE collective of a sharded RRS run: that block of every rank into d_global
+ *                      [nranks][mom_rrs_spectra_count(h, per)] (RCCL on the handle's stream; the reference has no
+ *                      multi-GPU path -- SURVEY section 8e / 8f-3; needs mom_comm_init). */
 enum {
   MOM_IE_ADDED_R_PM = 18, MOM_IE_ADDED_R_MP = 19, MOM_IE_ADDED_T_MM = 20, MOM_IE_ADDED_T_PP = 21,
   MOM_IE_ADDED_J0P = 22, MOM_IE_ADDED_J0M = 23,
@@ -191,6 +198,9 @@ int mom_rt_run_rrs(mom_t *h);
 int mom_get_RT_rrs(mom_t *h, double *R_SFI, double *T_SFI, double *ieR_SFI, double *ieT_SFI, double *gpu_ms);
 int mom_get_hdr_rrs(mom_t *h, double *hdr, double *bhr_uw, double *bhr_dw);
 int mom_rrs_timers(mom_t *h, double *ms, int *launches, int n);
+size_t mom_rrs_spectra_count(mom_t *h, int per);
+int mom_get_spectra_rrs_device(mom_t *h, int per, void *d_local);
+int mom_allgather_rrs_device(mom_t *h, int per, void *d_global);
 
 /* batch_inv!(X, A) -- gpu_batched.jl:36-87;  X, A: n*n*batch doubles (host). */
 int mom_batch_inv(mom_t *h, int n, int batch, const double *A, double *X);

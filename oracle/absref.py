@@ -122,9 +122,11 @@ def line_parameters(hit: dict, grid: np.ndarray, pressure: float, temperature: f
             S = S * rate * math.exp(C2 * E * (1 / T_REF - 1 / temperature)) * \
                 (1 - math.exp(-C2 * nu_j / temperature)) / (1 - math.exp(-C2 * nu_j / T_REF))
         if nG > 1:
-            # LinearInterpolation(grid, 1:n, extrapolation_bc = 1 / n): flat outside the grid
-            lo = np.interp(nu - wing_cutoff, grid, np.arange(1, nG + 1), left=1, right=nG)
-            hi = np.interp(nu + wing_cutoff, grid, np.arange(1, nG + 1), left=1, right=nG)
+            # grid_idx_interp_low / _high (:60-61): LinearInterpolation(grid, 1:n, extrapolation_bc = 1) and (… = n) -- each
+            # returns ITS constant on both sides of the grid (a pressure-shifted line whose nu - wing lies beyond the last
+            # grid point starts at 1; one whose nu + wing lies before the first grid point stops at n)
+            lo = np.interp(nu - wing_cutoff, grid, np.arange(1, nG + 1), left=1, right=1)
+            hi = np.interp(nu + wing_cutoff, grid, np.arange(1, nG + 1), left=nG, right=nG)
             i0, i1 = julia_round(lo), julia_round(hi)
         else:
             i0 = i1 = 1

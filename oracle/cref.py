@@ -21,9 +21,10 @@ c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int)
 
 
-def build(force: bool = False, ext: bool = False) -> Path:
-    so = _HERE / ("libmomref_ext.so" if ext else "libmomref.so")
-    srcs = [_HERE / "momref.c", _HERE / "Makefile"] + ([_HERE / "momref_ext.c"] if ext else [])
+def build(force: bool = False, ext: bool = False, which: str = "") -> Path:
+    which = which or ("ext" if ext else "")
+    so = _HERE / (f"libmomref_{which}.so" if which else "libmomref.so")
+    srcs = [_HERE / "momref.c", _HERE / "Makefile"] + ([_HERE / f"momref_{which}.c"] if which else [])
     if force or (not so.exists()) or so.stat().st_mtime < max(f.stat().st_mtime for f in srcs):
         subprocess.check_call(["make", "-C", str(_HERE), "-B" if force else "-s", so.name])
     return so
@@ -163,45 +164,72 @@ def rt_run(p: Packed, pts=None, nthreads: int = 0):
     return np.transpose(R.reshape(shp), (2, 1, 0)).copy(), np.transpose(T.reshape(shp), (2, 1, 0)).copy(), info
 
 
-class OraSceneExt(C.Structure):
-    """ora_scene of the extended-precision build: every `double` is a `long double`."""
-    _fields_ = [("N", C.c_int), ("nS", C.c_int), ("S", C.c_int), ("Nz", C.c_int), ("K", C.c_int), ("M", C.c_int),
-                ("imu0", C.c_int), ("strict", C.c_int), ("mu0", C.c_longdouble),
-                ("mu", C.c_void_p), ("wt", C.c_void_p), ("I0", C.c_void_p), ("D", C.c_void_p),
-                ("tau", C.c_void_p), ("varpi", C.c_void_p), ("zw", C.c_void_p), ("Zpp", C.c_void_p), ("Zmp", C.c_void_p),
-                ("nd", c_ip), ("iface", c_ip), ("tau_sum", C.c_void_p), ("albedo", C.c_longdouble),
-                ("nVza", C.c_int), ("node", c_ip), ("cos_mphi", C.c_void_p), ("sin_mphi", C.c_void_p),
-                ("surf_kind", C.c_int), ("Rsurf", C.c_void_p), ("albedo_spec", C.c_void_p)]
+def _typed_scene_struct(cfloat):
+    """ora_scene of a build whose `double` is another C type (long double: momref_ext.c, float: momref_f32.c)."""
+    class S(C.Structure):
+        _fields_ = [("N", C.c_int), ("nS", C.c_int), ("S", C.c_int), ("Nz", C.c_int), ("K", C.c_int), ("M", C.c_int),
+                    ("imu0", C.c_int), ("strict", C.c_int), ("mu0", cfloat),
+                    ("mu", C.c_void_p), ("wt", C.c_void_p), ("I0", C.c_void_p), ("D", C.c_void_p),
+                    ("tau", C.c_void_p), ("varpi", C.c_void_p), ("zw", C.c_void_p), ("Zpp", C.c_void_p), ("Zmp", C.c_void_p),
+                    ("nd", c_ip), ("iface", c_ip), ("tau_sum", C.c_void_p), ("albedo", cfloat),
+                    ("nVza", C.c_int), ("node", c_ip), ("cos_mphi", C.c_void_p), ("sin_mphi", C.c_void_p),
+                    ("surf_kind", C.c_int), ("Rsurf", C.c_void_p), ("albedo_spec", C.c_void_p)]
+    return S
+
+
+OraSceneExt = _typed_scene_struct(C.c_longdouble)
+OraSceneF32 = _typed_scene_struct(C.c_float)
+
+
+def _rt_run_typed(L, Struct, npdtype, p: Packed, pts, point_threads: int):
+    keep = {}
+
+    def conv(name):
+        a = getattr(p, name)
+        if a is None:
+            return None
+        keep[name] = np.ascontiguousarray(a, dtype=npdtype)
+        return keep[name].ctypes.data_as(C.c_void_p)
+
+    s = Struct()
+    s.N, s.nS, s.S, s.Nz, s.K, s.M = p.N, p.nS, p.S, p.Nz, p.K, p.M
+    s.imu0, s.strict, s.mu0 = p.imu0, p.strict, p.mu0
+    for nm in ("mu", "wt", "I0", "D", "tau", "varpi", "zw", "Zpp", "Zmp", "tau_sum", "cos_mphi", "sin_mphi", "Rsurf", "albedo_spec"):
+        setattr(s, nm, conv(nm))
+    s.nd, s.iface, s.node = ip(p.nd), ip(p.iface), ip(p.node)
+    s.albedo, s.nVza, s.surf_kind = p.albedo, p.nVza, p.surf_kind
+    n = p.nVza * p.nS * p.S
+    R, T = np.zeros(n, dtype=npdtype), np.zeros(n, dtype=npdtype)
+    pts = np.ascontiguousarray(np.arange(p.S) if pts is None else pts, dtype=np.int32)
+    info = L.ora_rt_run(C.byref(s), ip(pts), len(pts), int(point_threads), R.ctypes.data_as(C.c_void_p),
+                        T.ctypes.data_as(C.c_void_p))
+    shp = (p.S, p.nS, p.nVza)
+    return np.transpose(R.reshape(shp), (2, 1, 0)).copy(), np.transpose(T.reshape(shp), (2, 1, 0)).copy(), info
 
 
 def rt_run_ext(p: Packed, pts, point_threads: int = 1):
     """The elastic run of `rt_run` in x87 EXTENDED precision (oracle/momref_ext.c) for the spectral points `pts`.  The inputs
     are the same Float64 numbers (widened exactly); R_SFI, T_SFI come back as numpy.longdouble [nVza, nStokes, S] (zeros at
     the points not asked for).  point_threads: OpenMP threads over the points (each point runs serially)."""
-    L = lib_ext()
-    keep = {}
+    return _rt_run_typed(lib_ext(), OraSceneExt, np.longdouble, p, pts, point_threads)
 
-    def ld(name):
-        a = getattr(p, name)
-        if a is None:
-            return None
-        keep[name] = np.ascontiguousarray(a, dtype=np.longdouble)
-        return keep[name].ctypes.data_as(C.c_void_p)
 
-    s = OraSceneExt()
-    s.N, s.nS, s.S, s.Nz, s.K, s.M = p.N, p.nS, p.S, p.Nz, p.K, p.M
-    s.imu0, s.strict, s.mu0 = p.imu0, p.strict, p.mu0
-    for nm in ("mu", "wt", "I0", "D", "tau", "varpi", "zw", "Zpp", "Zmp", "tau_sum", "cos_mphi", "sin_mphi", "Rsurf", "albedo_spec"):
-        setattr(s, nm, ld(nm))
-    s.nd, s.iface, s.node = ip(p.nd), ip(p.iface), ip(p.node)
-    s.albedo, s.nVza, s.surf_kind = p.albedo, p.nVza, p.surf_kind
-    n = p.nVza * p.nS * p.S
-    R, T = np.zeros(n, dtype=np.longdouble), np.zeros(n, dtype=np.longdouble)
-    pts = np.ascontiguousarray(pts, dtype=np.int32)
-    info = L.ora_rt_run(C.byref(s), ip(pts), len(pts), int(point_threads), R.ctypes.data_as(C.c_void_p),
-                        T.ctypes.data_as(C.c_void_p))
-    shp = (p.S, p.nS, p.nVza)
-    return np.transpose(R.reshape(shp), (2, 1, 0)).copy(), np.transpose(T.reshape(shp), (2, 1, 0)).copy(), info
+_LIB_F32 = None
+
+
+def lib_f32():
+    """oracle/libmomref_f32.so: momref.c compiled in Float32 (momref_f32.c)."""
+    global _LIB_F32
+    if _LIB_F32 is None:
+        _LIB_F32 = C.CDLL(str(build(which="f32")))
+    return _LIB_F32
+
+
+def rt_run_f32(p: Packed, pts=None, point_threads: int = 0):
+    """The elastic run of `rt_run` in FLOAT32 (oracle/momref_f32.c): the inputs are the Float64 numbers of `p` rounded to
+    Float32 (what a Float32 model of the reference holds, and what the library's dtype = 1 handle makes of the Float64
+    arrays of the ABI); R_SFI, T_SFI come back as numpy.float32 [nVza, nStokes, S]."""
+    return _rt_run_typed(lib_f32(), OraSceneF32, np.float32, p, pts, point_threads or effective_cores())
 
 
 def rt_run_full(p: Packed, pts=None, nthreads: int = 0):

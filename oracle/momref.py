@@ -704,7 +704,7 @@ def batch_inv(A: np.ndarray) -> np.ndarray:
 
 
 def elemental_inelastic_rrs(pol: PolType, quad: QuadPoints, i_l1l0, varpi_l1l0, fscatt, tau_sum, dtau, varpi, Zpp, Zmp, m: int,
-                            nd: int, strict: bool = True):
+                            nd: int, strict: bool = True, owned=None):
     """elemental_inelastic!(RS_type::RRS, ...) CoreKernel/elemental_inelastic.jl:23-91 with get_elem_rt_RRS! (:93-160),
     get_elem_rt_SFI_RRS! (:320-382) and apply_D_elemental_RRS! (:384-402; apply_D_elemental_SFI! :404-412 changes nothing).
     i_l1l0 [nR]: grid offsets n0 - n1; Zpp/Zmp [N,N]; dtau, varpi, fscatt, tau_sum [S].  Returns ier_mp, iet_pp, ier_pm,
@@ -719,32 +719,35 @@ def elemental_inelastic_rrs(pol: PolType, quad: QuadPoints, i_l1l0, varpi_l1l0, 
     ier = np.zeros((nR, S, N, N)); iet = np.zeros((nR, S, N, N))
     jp = np.zeros((nR, S, N)); jm = np.zeros((nR, S, N))
     comp = stokes_comp(np.arange(N), n, strict)
+    # loop invariants (hoisted; the per-(n1, dn) arithmetic below is the reference's expression for expression)
+    mi, mj = mu[:, None], mu[None, :]
+    eq = mi == mj
+    live = (wct2 > 1.e-8)[None, :]
+    dZpp = np.diag(Zpp).copy()
+    zpI = Zpp[:, i_start:i_start + n] @ I0
+    zmI = Zmp[:, i_start:i_start + n] @ I0
+    mus = mu[i_start]
+    idx = np.arange(N)
+    sun = (idx >= i_start) & (idx < i_start + n)
     with np.errstate(divide="ignore", invalid="ignore"):
         for dn in range(nR):
-            for n1 in range(S):
+            for n1 in range(*(owned or (0, S))):          # owned: test-side window of n1 (rrsref.RRSInputs.owned)
                 n0 = n1 + int(i_l1l0[dn])
                 if not 0 <= n0 < S:
                     continue
                 d1, d0 = dtau[n1], dtau[n0]
                 pre = varpi_l1l0[dn] * varpi[n0] * fscatt[n0]
-                mi, mj = mu[:, None], mu[None, :]
                 r = fscatt[n0] * varpi_l1l0[dn] * varpi[n0] * Zmp * (1 / ((mi / mj) + (d1 / d0))) * \
                     (1 - np.exp(-((d1 / mi) + (d0 / mj)))) * wct2[None, :]
                 t_off = pre * Zpp * (1 / ((mi / mj) - (d1 / d0))) * wct2[None, :] * (np.exp(-d1 / mi) - np.exp(-d0 / mj))
                 if abs(d0 - d1) > 1.e-6:
-                    t_dia = pre * np.diag(Zpp) * wct2 * (np.exp(-d0 / mu) - np.exp(-d1 / mu)) / (1 - (d1 / d0))
+                    t_dia = pre * dZpp * wct2 * (np.exp(-d0 / mu) - np.exp(-d1 / mu)) / (1 - (d1 / d0))
                 else:
-                    t_dia = pre * np.diag(Zpp) * wct2 * (1 - np.exp(-d0 / mu))
-                eq = mi == mj
+                    t_dia = pre * dZpp * wct2 * (1 - np.exp(-d0 / mu))
                 t = np.where(eq, 0.0, t_off)
-                t[np.arange(N), np.arange(N)] = t_dia
-                live = (wct2 > 1.e-8)[None, :]
+                t[idx, idx] = t_dia
                 ier[dn, n1] = np.where(live, r, 0.0)
                 iet[dn, n1] = np.where(live, t, 0.0)
-                zpI = Zpp[:, i_start:i_start + n] @ I0
-                zmI = Zmp[:, i_start:i_start + n] @ I0
-                mus = mu[i_start]
-                sun = (np.arange(N) >= i_start) & (np.arange(N) < i_start + n)
                 if abs(d0 - d1) > 1.e-6:
                     jp_sun = (np.exp(-d0 / mu) - np.exp(-d1 / mu)) / ((d1 / d0) - 1) * pre * zpI * wct02
                 else:

@@ -63,6 +63,11 @@ class RRSInputs:
     varpi_l1l0: np.ndarray      # [nRaman] Raman single-scattering albedo per offset
     greek_raman: mr.GreekCoefs
     rrs_strict_reference: bool = True
+    # test-side window (not a reference field): restrict the inelastic pairs (n1, dn) to n1 in [lo, hi).  The pair (n1, dn)
+    # reads the elastic operators at n1 and n0 = n1 + i_l1l0[dn] and the inelastic ones at (n1, dn) only, so the owned
+    # entries are those of the unrestricted run (the GPU's spectral shards rest on the same fact);
+    # corrected position only (the strict position's defects D2/D3 index across the Raman axis).
+    owned: tuple = None
 
     @property
     def nRaman(self):
@@ -106,11 +111,15 @@ def make_composite_layer_rs(N, S, nR) -> CompositeLayerRS:
                             np.zeros((nR, S, N)))
 
 
-def get_n0_n1(S: int, delta: int):
-    """get_n0_n1 (src/Inelastic/inelastic_helper.jl:13-21): 0-based slices (n0, n1) of the valid index pairs."""
+def get_n0_n1(S: int, delta: int, owned=None):
+    """get_n0_n1 (src/Inelastic/inelastic_helper.jl:13-21): 0-based slices (n0, n1) of the valid index pairs
+    (owned = (lo, hi): only those with lo <= n1 < hi, possibly none)."""
     if abs(delta) >= S:
         raise ReferenceRaises("get_n0_n1: no valid index (BoundsError on sub[1])")
     a, b = max(0, -delta), min(S, S - delta)
+    if owned is not None:
+        a, b = max(a, owned[0]), min(b, owned[1])
+        b = max(a, b)
     return slice(a + delta, b + delta), slice(a, b)
 
 
@@ -126,11 +135,11 @@ def elemental_inelastic(pol, quad, rrs: RRSInputs, fscatt, tau_sum, dtau, varpi,
     n, N = pol.n, len(quad.qp_muN)
     S, nR = len(dtau), rrs.nRaman
     ier, iet, _, _, jp, jm = mr.elemental_inelastic_rrs(pol, quad, rrs.i_l1l0, rrs.varpi_l1l0, fscatt, tau_sum, dtau, varpi,
-                                                        Zpp, Zmp, m, 0, strict_idx)  # nd = 0: no D applied in there
+                                                        Zpp, Zmp, m, 0, strict_idx, rrs.owned)  # nd = 0: no D applied in there
     added.ier_mp[:] = ier
     added.iet_pp[:] = iet
     for dn in range(nR):
-        n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]))
+        n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]), rrs.owned)
         added.ieJ0p[dn, n1] = jp[dn, n1]
         added.ieJ0m[dn, n1] = jm[dn, n1]
     if nd >= 1:
@@ -222,7 +231,7 @@ def doubling_inelastic(pol, rrs: RRSInputs, expk, nd, added: AddedLayerRS, stric
         tmp1 = _mv(gp, jp + _mv(r, j1m))                                       # :58
         tmp2 = _mv(gp, j1m + _mv(r, jp))                                       # :59
         for dn in range(nR):                                                   # :61-96
-            n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]))
+            n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]), rrs.owned)
             X = r[n1] @ ier[dn, n1] + ier[dn, n1] @ r[n0]
             ieJp[dn, n1] = ieJ1p[dn, n1] + _mv(ttgp[n1], ieJp[dn, n1] + _mv(r[n1], ieJ1m[dn, n1]) +
                                                _mv(ier[dn, n1], j1m[n0]) + _mv(X, tmp1[n0])) + _mv(iet[dn, n1], tmp1[n0])
@@ -243,7 +252,7 @@ def doubling_inelastic(pol, rrs: RRSInputs, expk, nd, added: AddedLayerRS, stric
             jp[:] = jp_new
             expk[:] = expk ** 2
         for dn in range(nR):                                                   # :98-125
-            n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]))
+            n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]), rrs.owned)
             X = ier[dn, n1] @ r[n0] + r[n1] @ ier[dn, n1]
             tg1 = t[n1] @ gp[n1]
             Y = (X @ gp[n0]) @ t[n0]
@@ -295,7 +304,7 @@ def interaction_inelastic(rrs: RRSInputs, iface: int, comp: CompositeLayerRS, ad
         return
     if iface == 1:
         for dn in range(nR):
-            n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]))
+            n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]), rrs.owned)
             c.ieJ0m[dn, n1] = _mv(c.T_mm[n1], _mv(a.ier_mp[dn, n1], c.J0p[n0]) + a.ieJ0m[dn, n1])
             c.ieJ0p[dn, n1] = a.ieJ0p[dn, n1] + _mv(a.iet_pp[dn, n1], c.J0p[n0])
         J0m = c.J0m + _mv(c.T_mm, _mv(a.r_mp, c.J0p) + a.j0m)
@@ -303,7 +312,7 @@ def interaction_inelastic(rrs: RRSInputs, iface: int, comp: CompositeLayerRS, ad
         c.J0m[:] = J0m
         c.J0p[:] = J0p
         for dn in range(nR):
-            n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]))
+            n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]), rrs.owned)
             c.ieR_mp[dn, n1] = (c.T_mm[n1] @ a.ier_mp[dn, n1]) @ c.T_pp[n0]
             c.ieR_pm[dn, n1] = a.ier_pm[dn, n1]
             c.ieT_pp[dn, n1] = a.iet_pp[dn, n1] @ c.T_pp[n0]
@@ -315,7 +324,7 @@ def interaction_inelastic(rrs: RRSInputs, iface: int, comp: CompositeLayerRS, ad
         return
     if iface == 2:
         for dn in range(nR):
-            n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]))
+            n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]), rrs.owned)
             c.ieJ0p[dn, n1] = _mv(a.t_pp[n1], c.ieJ0p[dn, n1] + _mv(c.ieR_pm[dn, n1], a.j0m[n0]))
             c.ieJ0m[dn, n1] = c.ieJ0m[dn, n1] + _mv(c.ieT_mm[dn, n1], a.j0m[n0])
         J0p = a.j0p + _mv(a.t_pp, c.J0p + _mv(c.R_pm, a.j0m))
@@ -323,7 +332,7 @@ def interaction_inelastic(rrs: RRSInputs, iface: int, comp: CompositeLayerRS, ad
         c.J0p[:] = J0p
         c.J0m[:] = J0m
         for dn in range(nR):
-            n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]))
+            n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]), rrs.owned)
             c.ieT_pp[dn, n1] = a.t_pp[n1] @ c.ieT_pp[dn, n1]
             c.ieT_mm[dn, n1] = c.ieT_mm[dn, n1] @ a.t_mm[n0]
             c.ieR_pm[dn, n1] = (a.t_pp[n1] @ c.ieR_pm[dn, n1]) @ a.t_mm[n0]
@@ -337,7 +346,7 @@ def interaction_inelastic(rrs: RRSInputs, iface: int, comp: CompositeLayerRS, ad
     tmp_inv = mr.batch_inv(I - r @ c.R_pm)                                     # :244
     T01 = c.T_mm @ tmp_inv                                                     # :247
     for dn in range(nR):                                                       # :249-265
-        n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]))
+        n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]), rrs.owned)
         A = T01[n1] @ (a.ier_mp[dn, n1] @ c.R_pm[n0] + r[n1] @ c.ieR_pm[dn, n1]) + c.ieT_mm[dn, n1]
         c.ieJ0m[dn, n1] = c.ieJ0m[dn, n1] + \
             _mv(T01[n1], _mv(a.ier_mp[dn, n1], c.J0p[n0]) + _mv(r[n1], c.ieJ0p[dn, n1]) + a.ieJ0m[dn, n1]) + \
@@ -345,7 +354,7 @@ def interaction_inelastic(rrs: RRSInputs, iface: int, comp: CompositeLayerRS, ad
     J0m = c.J0m + _mv(T01, _mv(r, c.J0p) + a.j0m)                              # :267
     c.J0m[:] = J0m
     for dn in range(nR):                                                       # :269-285
-        n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]))
+        n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]), rrs.owned)
         A = T01[n1] @ (a.ier_mp[dn, n1] @ c.R_pm[n0] + r[n1] @ c.ieR_pm[dn, n1]) + c.ieT_mm[dn, n1]
         c.ieR_mp[dn, n1] = c.ieR_mp[dn, n1] + T01[n1] @ (a.ier_mp[dn, n1] @ c.T_pp[n0] + r[n1] @ c.ieT_pp[dn, n1]) + \
             ((A @ tmp_inv[n0]) @ r[n0]) @ c.T_pp[n0]
@@ -355,7 +364,7 @@ def interaction_inelastic(rrs: RRSInputs, iface: int, comp: CompositeLayerRS, ad
     tmp_inv = mr.batch_inv(I - c.R_pm @ r)                                     # :295
     T21 = t_pp @ tmp_inv                                                       # :297
     for dn in range(nR):                                                       # :299-313
-        n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]))
+        n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]), rrs.owned)
         B = T21[n1] @ (c.ieR_pm[dn, n1] @ r[n0] + c.R_pm[n1] @ a.ier_mp[dn, n1]) + a.iet_pp[dn, n1]
         c.ieJ0p[dn, n1] = a.ieJ0p[dn, n1] + \
             _mv(T21[n1], c.ieJ0p[dn, n1] + _mv(c.ieR_pm[dn, n1], a.j0m[n0]) + _mv(c.R_pm[n1], a.ieJ0m[dn, n1])) + \
@@ -363,7 +372,7 @@ def interaction_inelastic(rrs: RRSInputs, iface: int, comp: CompositeLayerRS, ad
     J0p = a.j0p + _mv(T21, c.J0p + _mv(c.R_pm, a.j0m))                         # :315
     c.J0p[:] = J0p
     for dn in range(nR):                                                       # :317-335
-        n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]))
+        n0, n1 = get_n0_n1(S, int(rrs.i_l1l0[dn]), rrs.owned)
         B = T21[n1] @ (c.ieR_pm[dn, n1] @ r[n0] + c.R_pm[n1] @ a.ier_mp[dn, n1]) + a.iet_pp[dn, n1]
         c.ieT_pp[dn, n1] = T21[n1] @ c.ieT_pp[dn, n1] + (B @ tmp_inv[n0]) @ c.T_pp[n0]
         c.ieR_pm[dn, n1] = a.ier_pm[dn, n1] + T21[n1] @ (c.ieR_pm[dn, n1] @ t_mm[n0] + c.R_pm[n1] @ a.iet_mm[dn, n1]) + \

@@ -100,6 +100,9 @@ SIGNATURES = {
     "mom_comm_init": (C.c_int, [c_h, C.c_int, C.c_int, C.c_void_p]),
     "mom_comm_destroy": (C.c_int, [c_h]),
     "mom_allgather": (C.c_int, [c_h, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mom_rrs_spectra_count": (C.c_size_t, [c_h, C.c_int]),
+    "mom_get_spectra_rrs_device": (C.c_int, [c_h, C.c_int, C.c_void_p]),
+    "mom_allgather_rrs_device": (C.c_int, [c_h, C.c_int, C.c_void_p]),
     "mom_allgather_RT_device": (C.c_int, [c_h, C.c_void_p]),
     "mom_allgather_RT": (C.c_int, [c_h, c_dp, c_dp]),
     "mom_timers": (C.c_int, [c_h, c_dp, C.c_int, c_ip]),
@@ -305,6 +308,17 @@ class Handle:
         self.check(self.lib.mom_get_hdr_rrs(self._h, dp(H), dp(up), dp(dw)))
         return (np.transpose(H.reshape(self.S, self.nS, self.nVza), (2, 1, 0)).copy(), up.reshape(self.S, self.nS).T.copy(),
                 dw.reshape(self.S, self.nS).T.copy())
+
+    def rrs_spectra_count(self, per: int) -> int:
+        return int(self.lib.mom_rrs_spectra_count(self._h, int(per)))
+
+    def get_spectra_rrs_device(self, per: int, d_local_ptr: int):
+        """Owned slices of the seven spectra packed into a device buffer of rrs_spectra_count(per) doubles (asynchronous)."""
+        self.check(self.lib.mom_get_spectra_rrs_device(self._h, int(per), C.c_void_p(d_local_ptr)))
+
+    def allgather_rrs_device(self, per: int, d_global_ptr: int):
+        """One RCCL all-gather of every rank's packed owned spectra into [nranks][rrs_spectra_count(per)] (asynchronous)."""
+        self.check(self.lib.mom_allgather_rrs_device(self._h, int(per), C.c_void_p(d_global_ptr)))
 
     def rrs_timers(self):
         """{kernel: (ms, launches)} of the last rt_run_rrs (HIP events on the library's stream)."""

@@ -199,8 +199,8 @@ def line_prefactors(h: HitranTable, grid: np.ndarray, pressure: float, temperatu
     """compute_absorption_cross_section.jl:54-107: selection of lines inside the padded grid,
     pressure shift, Lorentz and Doppler half widths (Float32 square root of the Float32 isotopologue weight, as
     `sqrt(mol_weight(mol, iso))` evaluates), y, the TIPS-2017 temperature correction of the strength (`qoft!`) and the
-    index window each line touches (linear interpolation of grid -> index, clamped, rounded half-to-even like
-    Julia's `round`).  `qratio` overrides the partition-sum ratio (a callable of T); default = the reference's qoft.
+    index window each line touches (linear interpolation of grid -> index with the reference's constant fill values outside
+    the grid -- 1 for the start, n for the stop, on either side -- rounded half-to-even like Julia's `round`).  `qratio` overrides the partition-sum ratio (a callable of T); default = the reference's qoft.
     `mol_weights` {(mol, iso): g/mol} supplies isotopologue weights for molecules outside the bundled TIPS subset
     (HITRAN molecules 1-7; the full tables are extracted by tools/extract_tips.py from the reference's NetCDF files)."""
     grid = np.asarray(grid, dtype=np.float64)
@@ -238,8 +238,10 @@ def line_prefactors(h: HitranTable, grid: np.ndarray, pressure: float, temperatu
     S = np.where(E != -1, S0 * corr, S0)
     idx = np.arange(1, grid.size + 1, dtype=np.float64)
     if grid.size > 1:
-        i0 = np.rint(np.interp(ν - wing_cutoff, grid, idx)).astype(np.int32)
-        i1 = np.rint(np.interp(ν + wing_cutoff, grid, idx)).astype(np.int32)
+        # LinearInterpolation(grid, 1:n, extrapolation_bc = 1) / (… = n) (:60-61): the constant on BOTH sides of the grid
+        n = float(grid.size)
+        i0 = np.rint(np.interp(ν - wing_cutoff, grid, idx, left=1.0, right=1.0)).astype(np.int32)
+        i1 = np.rint(np.interp(ν + wing_cutoff, grid, idx, left=n, right=n)).astype(np.int32)
     else:
         i0 = np.ones(ν.size, dtype=np.int32)
         i1 = np.ones(ν.size, dtype=np.int32)

@@ -832,12 +832,15 @@ class RRS:
     set-up (out of scope, like the Mie code); synthetic line lists for benchmarks: scenes.raman_lines.
 
     rrs_strict_reference: the reference's RRS text executed as written (True) or with the five documented corrections
-    D1..D5 (False) -- DESIGN.md "RRS", include/momcore.h mom_rrs_set."""
+    D1..D5 (False, the default: every published number of this repository uses it) -- DESIGN.md section 7,
+    include/momcore.h mom_rrs_set.  As written the path is barely usable: any scene with a 00 / 01 / 10 interface raises
+    (D4: MethodError in the reference -> MOM_EUNSUPPORTED here) and with realistic line counts expk underflows in the first
+    doubling step (D1: expk -> expk^(2^nRaman)); True exists for line-by-line comparison with the reference's text."""
     greek_raman: GreekCoefs
     ϖ_Cabannes: float          # elastic (Cabannes) fraction of Rayleigh scattering: the Rayleigh ϖ of the elastic layer optics
     ϖ_λ1λ0: np.ndarray         # [nRaman]
     i_λ1λ0: np.ndarray         # [nRaman] grid offsets n₀ - n₁
-    rrs_strict_reference: bool = True
+    rrs_strict_reference: bool = False
 
     @property
     def n_Raman(self):
@@ -868,7 +871,9 @@ def _with_cabannes(RS_type: RRS, model: vSmartMOM_Model) -> vSmartMOM_Model:
 def rt_run_rrs(RS_type: RRS, model: vSmartMOM_Model, i_band: int = 1):
     """rt_run(RS_type::RRS, model, iBand) (rt_run.jl:41-230), SFI = true.  Returns the reference's 7-tuple (rt_run.jl:226):
         (R_SFI, T_SFI, ieR_SFI, ieT_SFI, hdr, bhr_uw[1,:], bhr_dw[1,:])
-    R/T/ieR/ieT/hdr are [nVza, nStokes, nSpec]; every surface type of `params.brdf`."""
+    R/T/ieR/ieT/hdr are [nVza, nStokes, nSpec]; every surface type of `params.brdf`.  With RS_type.rrs_strict_reference =
+    True the run raises MomError (MOM_EUNSUPPORTED) for scenes with a 00 / 01 / 10 scattering interface, as the reference's
+    text does (D4); the default (False) runs them."""
     S = model.τ_rayl.shape[0]
     return rt_run_rrs_window(RS_type, model, 0, S)
 

@@ -988,7 +988,7 @@ static hipError_t dm(T **p, size_t count) {
 }
 
 hipError_t create(State **out, hipStream_t st, int N, int nS, int S, int nR, const int *off_host, const double *varpi_host,
-                  int strict_rrs, std::string *err) {
+                  int strict_rrs) {
   State *s = new State;
   s->N = N; s->nS = nS; s->S = S; s->nR = nR; s->strict_rrs = strict_rrs; s->stream = st;
   s->n1_lo = 0; s->n1_hi = S;
@@ -1019,7 +1019,6 @@ hipError_t create(State **out, hipStream_t st, int N, int nS, int S, int nR, con
     RCHK(dm(&s->ie_comp[k], k < 4 ? m4 : v4));
   }
   RCHK(dm(&s->d_info, 1));
-  (void)err;
   return hipSuccess;
 }
 
@@ -1134,7 +1133,7 @@ hipError_t elemental(State *s, const Streams &q, int m, int nd, int shift, const
     }
     const size_t tot = (size_t)s->N * s->N * (size_t)(s->n1_hi - s->n1_lo) * s->nR;
     RCHK(tick(s, TK_IE_ELEMENTAL, true));
-    hipLaunchKernelGGL(k_ie_elemental, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, a);
+    if (tot) hipLaunchKernelGGL(k_ie_elemental, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s->stream, a);  // empty owned range: nothing to do
     RCHK(hipGetLastError());
     RCHK(tick(s, TK_IE_ELEMENTAL, false));
     if (nd < 1) { s->pm_valid = true; s->pm_derivable = true; }  // apply_D_elemental_RRS! wrote both pairs consistently
@@ -1191,7 +1190,7 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
                          s->ie_added[T_MM], cnt);
     } else {
       const int tot = s->N * (s->n1_hi - s->n1_lo);
-      hipLaunchKernelGGL(k_strict_D, dim3((tot + 127) / 128), dim3(128), 0, s->stream, a);
+      if (tot) hipLaunchKernelGGL(k_strict_D, dim3((tot + 127) / 128), dim3(128), 0, s->stream, a);
     }
     RCHK(hipGetLastError());
     s->pm_valid = true; s->pm_derivable = false;
@@ -1265,7 +1264,35 @@ hipError_t surface(State *s, const Streams &q, int m, int kind, double albedo, c
   return hipGetLastError();
 }
 
+// rt_run allocates its added / composite / surface layers zeroed on every call (rt_run.jl:108-116: make_added_layer /
+// make_composite_layer).  The persistent arrays of a handle are brought to that state before a scene-level run whenever
+// anything but a corrected-position scene-level run has touched them (State::dirty): the strict position reads entries the
+// current run has not written (D5: iet-- of the previous layer; k_strict_D / the off-grid ieJ0- are read-modify-written), and
+// operator-level uploads leave arbitrary values.  A corrected-position scene-level run itself is stateless: every block
+// it reads it has written before in the same run, and the entries off the grid are never written (they stay zero).
+hipError_t reset_layers(State *s) {
+  const size_t NN = (size_t)s->P * s->P, m3 = NN * s->S * 8, v3 = (size_t)s->P * s->S * 8, m4 = m3 * s->nR, v4 = v3 * s->nR;
+  for (int b = 0; b < 2; ++b) {
+    for (int k = 0; k < 6; ++k) {
+      if (!(b == 1 && (k == R_PM || k == T_MM))) RCHK(hipMemsetAsync(s->added[b][k], 0, k < 4 ? m3 : v3, s->stream));
+      RCHK(hipMemsetAsync(s->comp[b][k], 0, k < 4 ? m3 : v3, s->stream));
+    }
+    RCHK(hipMemsetAsync(s->expk[b], 0, (size_t)s->S * 8, s->stream));
+  }
+  for (int k = 0; k < 6; ++k) {
+    RCHK(hipMemsetAsync(s->surf[k], 0, k < 4 ? m3 : v3, s->stream));
+    RCHK(hipMemsetAsync(s->ie_added[k], 0, k < 4 ? m4 : v4, s->stream));
+    RCHK(hipMemsetAsync(s->ie_comp[k], 0, k < 4 ? m4 : v4, s->stream));
+  }
+  if (s->jpseq) RCHK(hipMemsetAsync(s->jpseq, 0, v4, s->stream));
+  return hipSuccess;
+}
+
 hipError_t begin_run(State *s, int nVza) {
+  if (s->dirty || s->strict_rrs) RCHK(reset_layers(s));
+  s->dirty = s->strict_rrs != 0;  // a strict-position run leaves state the next run must not see
+  s->cur = 0; s->ccur = 0;
+  s->pm_valid = true; s->pm_derivable = false; s->el_pending = false;
   const size_t cnt = (size_t)5 * nVza * s->nS * s->S + (size_t)2 * s->nS * s->S;
   if (s->out_nVza != nVza) {
     (void)hipFree(s->d_out);

@@ -57,6 +57,9 @@ struct State {
   // doubling step (el_pending + its inputs), and in the corrected position ier+- / iet-- are not stored by the doubling but
   // derived where they are read (pm_derivable); pm_valid says whether the arrays themselves hold the current values
   bool fast = false, el_pending = false, pm_valid = true, pm_derivable = false;
+  // true once an operator-level entry may have written the layers (uploads, mom_rrs_elemental ...) or a strict-position run
+  // has ended: the next scene-level run zeroes the layers first (the reference allocates them zeroed per rt_run)
+  bool dirty = false;
   struct { int m, nd, sh; const double *tau_sum, *tau, *varpi, *fscatt, *Zr_pp, *Zr_mp; } el{};
   // HIP-event pairs around the launches of the heavy kernels of the last run (timing_reset .. timing_read)
   std::vector<hipEvent_t> ev_pool;
@@ -70,7 +73,7 @@ void timing_reset(State *s, bool on);
 hipError_t timing_read(State *s, double *ms, int *launches);
 
 hipError_t create(State **out, hipStream_t st, int N, int nS, int S, int nR, const int *off_host, const double *varpi_host,
-                  int strict_rrs, std::string *err);
+                  int strict_rrs);
 void destroy(State *s);
 // one layer array between the ABI's memory order (host, [N,N,nblk] or [N,nblk]) and the padded device blocks (synchronous)
 hipError_t upload(State *s, double *dev, const double *host, bool matrix, size_t nblk);
@@ -96,7 +99,8 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
 // (albedo), 1 BRDF Fourier matrix Rsurf_m [N,N] of moment m (device), 2 LambertianSurfaceLegendre (albedo_spec [S], device)
 hipError_t surface(State *s, const Streams &q, int m, int kind, double albedo, const double *tau_tot, const double *Rsurf_m,
                    const double *albedo_spec);
-// postprocessing_vza!(::RRS): accumulates into s->d_out (zeroed by begin_run)
+// start of a scene-level run: zeroed layers where needed (State::dirty, strict position), double-buffer / pm flags reset,
+// output block zeroed (postprocessing_vza!(::RRS) accumulates into s->d_out)
 hipError_t begin_run(State *s, int nVza);
 hipError_t postprocess(State *s, const Streams &q, int m, int nVza, const int *d_node, const double *d_cos, const double *d_sin,
                        int M, double weight);

@@ -467,6 +467,8 @@ struct mom_handle {
   int comm_rank = 0, comm_size = 1;
   double *d_gather = nullptr;
   size_t gather_cap = 0;
+  double *d_rrs_send = nullptr;  // packed owned spectra of the RRS run: send buffer of mom_allgather_rrs_device
+  size_t rrs_send_cap = 0;
   // device-side layer optics (mom_absorption_* / mom_voigt_tau_abs / mom_scene_set_optics)
   double *d_tau_abs = nullptr, *d_grid = nullptr, *d_lines = nullptr, *d_tau_rayl = nullptr, *d_layer_max = nullptr,
          *d_aer = nullptr;
@@ -715,7 +717,7 @@ extern "C" int mom_destroy(mom_t *h) {
   fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
   fr(h->d_mu0); fr(h->d_wt0); fr(h->d_sg0); fr(h->d_Zpp0); fr(h->d_Zmp0); fr(h->d_hdrJ0); fr(h->d_scratch0);
   for (int k = 0; k < 6; ++k) fr(h->comp0[k]);
-  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_Rsurf); fr(h->d_Rsurf0); fr(h->d_albedo_spec); fr(h->d_hdrJm); fr(h->d_smtab); if (h->d_ndif) (void)hipFree(h->d_ndif); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_tau_rayl);
+  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_rrs_send); fr(h->d_Rsurf); fr(h->d_Rsurf0); fr(h->d_albedo_spec); fr(h->d_hdrJm); fr(h->d_smtab); if (h->d_ndif) (void)hipFree(h->d_ndif); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_tau_rayl);
   fr(h->d_layer_max); fr(h->d_aer); if (h->d_aer_mode) (void)hipFree(h->d_aer_mode); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
   for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (auto e : h->ev_full) (void)hipEventDestroy(e);
@@ -2441,7 +2443,7 @@ extern "C" int mom_rrs_set(mom_t *h, int nRaman, const int *i_l1l0, const double
   momr::destroy(h->rrs);
   h->rrs = nullptr;
   h->rrs_scene = false;
-  const hipError_t e = momr::create(&h->rrs, h->stream, h->N, h->nS, h->S, nRaman, i_l1l0, varpi_l1l0, rrs_strict_reference ? 1 : 0, nullptr);
+  const hipError_t e = momr::create(&h->rrs, h->stream, h->N, h->nS, h->S, nRaman, i_l1l0, varpi_l1l0, rrs_strict_reference ? 1 : 0);
   if (e != hipSuccess) {
     momr::destroy(h->rrs);
     h->rrs = nullptr;
@@ -2449,7 +2451,6 @@ extern "C" int mom_rrs_set(mom_t *h, int nRaman, const int *i_l1l0, const double
     snprintf(buf, sizeof buf, "mom_rrs_set: allocating the RRS layers failed: %s", hipGetErrorString(e));
     return fail(h, MOM_EHIP, buf);
   }
-  h->rrs->d_info = h->rrs->d_info;  // own flag; reported by rrs_check
   return MOM_OK;
 }
 
@@ -2500,6 +2501,7 @@ static double *rrs_which(mom_t *h, int which, bool *matrix, size_t *nblk) {
 extern "C" int mom_rrs_upload(mom_t *h, int which, const double *src) {
   int rc = rrs_ready(h, "mom_rrs_upload");
   if (rc) return rc;
+  h->rrs->dirty = true;  // operator-level write: the next scene-level run starts from zeroed layers again
   bool matrix = false;
   size_t nblk = 0;
   double *p = rrs_which(h, which, &matrix, &nblk);
@@ -2528,6 +2530,7 @@ extern "C" int mom_rrs_elemental(mom_t *h, int m, int ndoubl, const double *tau_
                                  const double *Zmp_l1l0) {
   int rc = rrs_ready(h, "mom_rrs_elemental");
   if (rc) return rc;
+  h->rrs->dirty = true;  // operator-level write: the next scene-level run starts from zeroed layers again
   if (!tau_sum || !dtau || !varpi || !Zpp || !Zmp || !fscattRayl || !Zpp_l1l0 || !Zmp_l1l0 || ndoubl < 0 || ndoubl > 62)
     return fail(h, MOM_EINVAL, "mom_rrs_elemental: bad argument");
   const size_t S = h->S, NN = (size_t)h->N * h->N;
@@ -2546,6 +2549,7 @@ extern "C" int mom_rrs_elemental(mom_t *h, int m, int ndoubl, const double *tau_
 extern "C" int mom_rrs_doubling(mom_t *h, int ndoubl, double *expk) {
   int rc = rrs_ready(h, "mom_rrs_doubling");
   if (rc) return rc;
+  h->rrs->dirty = true;  // operator-level write: the next scene-level run starts from zeroed layers again
   if (ndoubl < 0 || !expk) return fail(h, MOM_EINVAL, "mom_rrs_doubling: bad argument");
   momr::State *s = h->rrs;
   HIPCHK(h, hipMemcpyAsync(s->expk[s->cur], expk, (size_t)h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -2557,6 +2561,7 @@ extern "C" int mom_rrs_doubling(mom_t *h, int ndoubl, double *expk) {
 extern "C" int mom_rrs_interaction(mom_t *h, int iface, int with_surface_layer) {
   int rc = rrs_ready(h, "mom_rrs_interaction");
   if (rc) return rc;
+  h->rrs->dirty = true;  // operator-level write: the next scene-level run starts from zeroed layers again
   if (iface < 0 || iface > 3) return fail(h, MOM_EINVAL, "mom_rrs_interaction: iface must be 0..3");
   RRSCHK(h, momr::interaction(h->rrs, rrs_streams(h), iface, with_surface_layer != 0));
   return rrs_check(h);
@@ -2565,6 +2570,7 @@ extern "C" int mom_rrs_interaction(mom_t *h, int iface, int with_surface_layer) 
 extern "C" int mom_rrs_copy_added_to_composite(mom_t *h) {
   int rc = rrs_ready(h, "mom_rrs_copy_added_to_composite");
   if (rc) return rc;
+  h->rrs->dirty = true;  // operator-level write: the next scene-level run starts from zeroed layers again
   RRSCHK(h, momr::copy_added_to_composite(h->rrs, rrs_streams(h)));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
@@ -2573,6 +2579,7 @@ extern "C" int mom_rrs_copy_added_to_composite(mom_t *h) {
 extern "C" int mom_rrs_surface_lambertian(mom_t *h, int m, double albedo, const double *tau_tot) {
   int rc = rrs_ready(h, "mom_rrs_surface_lambertian");
   if (rc) return rc;
+  h->rrs->dirty = true;  // operator-level write: the next scene-level run starts from zeroed layers again
   if (!tau_tot) return fail(h, MOM_EINVAL, "mom_rrs_surface_lambertian: bad argument");
   HIPCHK(h, hipMemcpyAsync(h->d_vec[0], tau_tot, (size_t)h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
   RRSCHK(h, momr::surface(h->rrs, rrs_streams(h), m, 0, albedo, h->d_vec[0], nullptr, nullptr));
@@ -2638,6 +2645,58 @@ extern "C" int mom_get_hdr_rrs(mom_t *h, double *hdr, double *bhr_uw, double *bh
   HIPCHK(h, hipMemcpyAsync(bhr_dw, s->d_out + 5 * tot + fl, fl * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
+}
+
+// The seven spectra of rt_run(::RRS)'s return tuple (rt_run.jl:226), restricted to the points this rank owns
+// (mom_rrs_set_shard: [n1_lo, n1_hi) of the window), packed on the device: [R | T | ieR | ieT | hdr][nVza, nStokes, per],
+// then [bhr_uw | bhr_dw][nStokes, per]; `per` >= the owned count, the tail of every spectrum is zero (ragged last shard).
+// The spectral index is the slowest one of every output array, so an owned slice is one contiguous piece per spectrum.
+static int rrs_pack_owned(mom_t *h, int per, double *d_dst) {
+  momr::State *s = h->rrs;
+  if (!s->d_out) return fail(h, MOM_ESTATE, "mom_get_spectra_rrs_device: no run");
+  const int own = s->n1_hi - s->n1_lo;
+  if (per < own || per <= 0) return fail(h, MOM_EINVAL, "mom_get_spectra_rrs_device: per must be >= the owned point count");
+  const size_t a = (size_t)s->out_nVza * h->nS, b = (size_t)h->nS, S = (size_t)h->S;
+  if (own < per) HIPCHK(h, hipMemsetAsync(d_dst, 0, mom_rrs_spectra_count(h, per) * sizeof(double), h->stream));
+  for (int k = 0; k < 7; ++k) {
+    const size_t row = k < 5 ? a : b;
+    const double *src = (k < 5 ? s->d_out + (size_t)k * a * S : s->d_out + 5 * a * S + (size_t)(k - 5) * b * S) + row * s->n1_lo;
+    double *dst = k < 5 ? d_dst + (size_t)k * a * per : d_dst + 5 * a * per + (size_t)(k - 5) * b * per;
+    if (own > 0) HIPCHK(h, hipMemcpyAsync(dst, src, row * own * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  }
+  return MOM_OK;
+}
+
+extern "C" size_t mom_rrs_spectra_count(mom_t *h, int per) {
+  if (!h || !h->rrs || per <= 0) return 0;
+  const int nV = h->rrs->out_nVza > 0 ? h->rrs->out_nVza : h->nVza;
+  return ((size_t)5 * nV * h->nS + (size_t)2 * h->nS) * (size_t)per;
+}
+
+extern "C" int mom_get_spectra_rrs_device(mom_t *h, int per, void *d_local) {
+  int rc = rrs_ready(h, "mom_get_spectra_rrs_device");
+  if (rc) return rc;
+  if (!d_local) return fail(h, MOM_EINVAL, "mom_get_spectra_rrs_device: null buffer");
+  return rrs_pack_owned(h, per, static_cast<double *>(d_local));
+}
+
+// The ONE collective of a sharded RRS run: every rank contributes the packed block of its owned points
+// (above) and receives d_global [nranks][mom_rrs_spectra_count(h, per)]; asynchronous on the handle's stream, nothing
+// crosses the host.
+extern "C" int mom_allgather_rrs_device(mom_t *h, int per, void *d_global) {
+  int rc = rrs_ready(h, "mom_allgather_rrs_device");
+  if (rc) return rc;
+  if (!h->comm) return fail(h, MOM_ESTATE, "mom_allgather_rrs_device: call mom_comm_init first");
+  if (!d_global) return fail(h, MOM_EINVAL, "mom_allgather_rrs_device: null buffer");
+  const size_t cnt = mom_rrs_spectra_count(h, per);
+  if (cnt > h->rrs_send_cap) {
+    if (h->d_rrs_send) (void)hipFree(h->d_rrs_send);
+    h->d_rrs_send = nullptr; h->rrs_send_cap = 0;
+    HIPCHK(h, dmalloc(&h->d_rrs_send, cnt));
+    h->rrs_send_cap = cnt;
+  }
+  if ((rc = rrs_pack_owned(h, per, h->d_rrs_send))) return rc;
+  return mom_allgather(h, h->d_rrs_send, d_global, cnt);
 }
 
 extern "C" int mom_rrs_timers(mom_t *h, double *ms, int *launches, int n) {

@@ -171,7 +171,7 @@ thread_local double v_last_ms = 0.0;
 // ONE resident HITRAN table per absorber: pressure shift (:79), Lorentz half width (:82-84), Doppler half width (:87-88),
 // y (:91), the temperature correction of the strength with the TIPS-2017 partition-sum ratio qoft! (:95-101, :197-214:
 // cubic spline of the isotopologue's table, evaluated at T_ref and T) and the grid window of the line (:104-107: linear
-// interpolation grid -> index, clamped, rounded half-to-even).  One thread per line; per layer only (p, T, vmr, wing) are
+// interpolation grid -> index with the constant fill values 1 / n outside the grid, rounded half-to-even).  One thread per line; per layer only (p, T, vmr, wing) are
 // kernel arguments.  Same expression order as the host route (absorption.line_prefactors); exp / pow come from the
 // device math library, so the two routes agree to a few ulp, not bitwise.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -195,11 +195,12 @@ __device__ __forceinline__ double spline_eval(const double *t, const double *u, 
   const double D = (double)du * a;
   return I + C + D;
 }
-__device__ __forceinline__ double interp_index(const double *grid, int n, double x) {
-  // numpy.interp(x, grid, 1..n): clamped linear interpolation; grid ascending
+__device__ __forceinline__ double interp_index(const double *grid, int n, double x, double fill) {
+  // LinearInterpolation(grid, 1:n, extrapolation_bc = fill) (compute_absorption_cross_section.jl:60-61): linear inside the
+  // grid, the CONSTANT `fill` on BOTH sides outside it (fill = 1 for the window start, n for the stop); grid ascending
   if (n == 1) return 1.0;
-  if (x <= grid[0]) return 1.0;
-  if (x >= grid[n - 1]) return (double)n;
+  if (x < grid[0] || x > grid[n - 1]) return fill;
+  if (x == grid[n - 1]) return (double)n;
   int lo = 0, hi = n - 1;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
@@ -231,12 +232,12 @@ __global__ void k_line_prefactors(MomLineTable tb, int nGrid, const double *grid
   gd[j] = g;
   yy[j] = sqrt(cLn2) * gl / g;
   SS[j] = S;
-  const int a = (int)rint(interp_index(grid, nGrid, v - wing)), b = (int)rint(interp_index(grid, nGrid, v + wing));
+  const int a = (int)rint(interp_index(grid, nGrid, v - wing, 1.0)), b = (int)rint(interp_index(grid, nGrid, v + wing, (double)nGrid));
   i0[j] = a;
   i1[j] = b;
   if (j > 0) {  // does the Voigt kernel's bisection apply?  (window starts and stops non-decreasing in the line index)
     const double vp = tb.nu0[j - 1] + p / p_ref * tb.d_air[j - 1];
-    const int ap = (int)rint(interp_index(grid, nGrid, vp - wing)), bp = (int)rint(interp_index(grid, nGrid, vp + wing));
+    const int ap = (int)rint(interp_index(grid, nGrid, vp - wing, 1.0)), bp = (int)rint(interp_index(grid, nGrid, vp + wing, (double)nGrid));
     if (a < ap || b < bp) atomicOr(unsorted, 1);
   }
 }

@@ -62,6 +62,25 @@ def gather_spectra(local, S: int, dist, device=None):
     return res
 
 
+def unpack_rrs_spectra(G, nVza: int, nStokes: int, per: int, S: int = None):
+    """The receive buffer of mom_allgather_rrs_device, G [world, (5 nVza nStokes + 2 nStokes) per] (per rank: [R | T | ieR |
+    ieT | hdr][per, nStokes, nVza] then [bhr_uw | bhr_dw][per, nStokes], the ABI's memory order), as the 7-tuple of
+    rt_run(::RRS) on the whole axis: five arrays [nVza, nStokes, S] and two [nStokes, S] (S defaults to world * per; a
+    ragged tail is cut off)."""
+    G = np.asarray(G)
+    world = G.shape[0]
+    S = world * per if S is None else S
+    a, b = nVza * nStokes * per, nStokes * per
+    out = []
+    for k in range(5):
+        x = G[:, k * a:(k + 1) * a].reshape(world * per, nStokes, nVza)
+        out.append(np.transpose(x, (2, 1, 0))[..., :S].copy())
+    for k in range(2):
+        x = G[:, 5 * a + k * b:5 * a + (k + 1) * b].reshape(world * per, nStokes)
+        out.append(x.T[..., :S].copy())
+    return tuple(out)
+
+
 def rt_run_sharded(scene, run_local: Callable, dist, device=None):
     """Run `run_local(shard) -> (R, T)` ([nVza, nStokes, S_loc] numpy) on this rank's slice and
     all-gather the spectra.  `dist` is torch.distributed (initialised).  Returns the full

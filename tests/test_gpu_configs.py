@@ -220,3 +220,82 @@ def test_config_C4_iquv_64_streams(rtamd, cref):
     tol = helpers.stokes_rtol(sc.ndoubl)  # tau = 5 cloud: 24 doublings of 256 x 256 operators (arbiter: test_gpu_precision.py)
     helpers.assert_stokes_close(R[:, :, pts], Rr[:, :, pts], rtol=tol, what="C4 sample R")
     helpers.assert_stokes_close(T[:, :, pts], Tr[:, :, pts], rtol=tol, what="C4 sample T")
+
+
+def _c5_line_subsets(RS):
+    """(A, B): A = 24 of the scene's real Raman offsets -- the two extreme ones, 20 spread over the sorted list and the four
+    strongest lines -- B = the rest.  Weights as in the full list (no renormalisation), so the subsets add up to it."""
+    offs, w = np.asarray(RS.i_λ1λ0), np.asarray(RS.ϖ_λ1λ0)
+    order = np.argsort(offs)
+    A = np.unique(np.concatenate([[order[0], order[-1]], order[np.linspace(0, len(offs) - 1, 20).round().astype(int)],
+                                  np.argsort(-w)[:4]]))
+    B = np.setdiff1d(np.arange(len(offs)), A)
+    return A, B
+
+
+def test_config_C5_rotational_raman(rtamd):
+    """configs[4] at FULL size on the GPU: S = 6 837, N = 15, 5 layers, all 178 Raman offsets (|Δn| up to 5 014 grid points;
+    804 233 valid (n₁, Δn) pairs), corrected switch position.
+
+      (1) the run with the 24 offsets of subset A (incl. both extreme offsets) against the oracle (oracle/rrsref.py) on an
+          two owned windows of 150 points chosen so that each extreme offset has its source index on the grid in one of
+          them and runs off it inside the other: 1e-10 of the elastic intensity / 1e-9 of the inelastic maximum -- the index arithmetic at
+          the full range of offsets;
+      (2) linearity in the line list (each Δn evolves independently of the others in every operator of the path,
+          doubling_inelastic.jl:61-125, interaction_inelastic.jl:249-335): ie spectra of the 178-line run = A-run + B-run,
+          and the elastic spectra of all three runs are bitwise equal -- ties the full run to (1);
+      (3) elastic limit at full size: zero Raman weights give zero inelastic spectra and the elastic spectra of (2), and the
+          elastic spectra equal rt_run(::noRS) with the Cabannes albedo to 1e-10;
+      (4) the 2-way spectral split (window = owned + halo of 5 014) reproduces the full run bit for bit."""
+    from oracle import momref as mr, rrsref as rr
+    rt = rtamd.corert
+    m, RS = rtamd.scenes.scene_C5()
+    S, nR = m.τ_rayl.shape[0], RS.n_Raman
+    offs, w = np.asarray(RS.i_λ1λ0), np.asarray(RS.ϖ_λ1λ0)
+    assert (S, nR) == (6_837, 178) and rtamd.prepare_scene(m).N == 15 and not RS.rrs_strict_reference
+    assert np.abs(offs).max() == 5_014 and offs.min() == -4_696
+    sub = lambda k: rt.RRS(greek_raman=RS.greek_raman, ϖ_Cabannes=RS.ϖ_Cabannes, ϖ_λ1λ0=w[k], i_λ1λ0=offs[k],
+                           rrs_strict_reference=False)
+    A, B = _c5_line_subsets(RS)
+    full = rt.rt_run_rrs(RS, m)
+    gA = rt.rt_run_rrs(sub(A), m)
+    gB = rt.rt_run_rrs(sub(B), m)
+    for x in full:
+        assert np.all(np.isfinite(x))
+    assert np.abs(full[2]).max() > 1e-4 and np.abs(full[3]).max() > 1e-5
+    # (2) linearity and the elastic part
+    for k in (0, 1, 4, 5, 6):
+        assert np.array_equal(full[k], gA[k]) and np.array_equal(full[k], gB[k]), k
+    for k in (2, 3):
+        helpers.assert_op_close(gA[k] + gB[k], full[k], 1e-12, f"C5 linearity [{k}]")
+    # (1) oracle windows (2 x 150 owned points).  n0 = n1 + off must stay in [0, S): in [1700, 1850) the offset +5014 runs
+    # off the grid from n1 = 1823 on and -4696 is off it throughout; in [4700, 4850) -4696 is on the grid, +5014 is not.
+    scene = helpers.oracle_scene(m)
+    scene.varpi_cabannes = RS.ϖ_Cabannes
+    g = mr.get_greek_rayleigh(0.75)
+    for lo, hi in ((1_700, 1_850), (4_700, 4_850)):
+        ora = rr.RRSInputs(offs[A].astype(np.int64), w[A], g, rrs_strict_reference=False, owned=(lo, hi))
+        Rr, Tr, ieRr, ieTr = rr.rt_run_rrs(scene, ora)
+        own = slice(lo, hi)
+        helpers.assert_stokes_close(gA[0][..., own], Rr[..., own], what="C5 R")
+        helpers.assert_stokes_close(gA[1][..., own], Tr[..., own], what="C5 T")
+        assert np.abs(ieRr[..., own]).max() > 0
+        for got, ref, el in ((gA[2], ieRr, Rr), (gA[3], ieTr, Tr)):
+            scale = np.abs(el[:, 0:1, own])
+            assert np.all(np.abs(got[..., own] - ref[..., own]) <= 1e-10 * scale + 1e-14), np.abs(got[..., own] - ref[..., own]).max()
+            helpers.assert_op_close(got[..., own], ref[..., own], 1e-9, "C5 ie spectra")
+    # (3) elastic limit
+    zero = rt.RRS(greek_raman=RS.greek_raman, ϖ_Cabannes=RS.ϖ_Cabannes, ϖ_λ1λ0=np.zeros(nR), i_λ1λ0=offs, rrs_strict_reference=False)
+    g0 = rt.rt_run_rrs(zero, m)
+    assert not np.any(g0[2]) and not np.any(g0[3])
+    assert np.array_equal(g0[0], full[0]) and np.array_equal(g0[1], full[1])
+    Re, Te = rt.rt_run(rt._with_cabannes(RS, m))[:2]
+    helpers.assert_stokes_close(full[0], Re, what="C5 elastic R vs rt_run(noRS)")
+    helpers.assert_stokes_close(full[1], Te, what="C5 elastic T vs rt_run(noRS)")
+    # (4) two windows
+    parts = []
+    for rank in range(2):
+        lo, hi, wlo, whi = rtamd.sharding.rrs_window(S, 2, rank, offs)
+        parts.append(rt.rt_run_rrs_window(RS, m, lo, hi, (wlo, whi)))
+    for k in range(7):
+        assert np.array_equal(np.concatenate([p[k] for p in parts], axis=-1), full[k]), k

@@ -125,3 +125,42 @@ def test_bench_C5_two_ranks():
     j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert j["n_gpus"] == 2 and "1200 in total" in j["config"]["workload"] and "halo" in j["config"]["sharding"]
     assert j["value"] > 0 and j["roofline"]["bound"] == "hbm"
+
+
+def _bench(args, timeout=1200):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py")] + args + ["--no-cpu-baseline", "--no-voigt", "--no-extras"],
+                         env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_bench_C3_strong_scaling_two_ranks_gathered_spectra_bitwise(tmp_path):
+    """BASELINE configs[2] as bench.py runs it on N GPUs (--workload C3 --scaling strong): the spectra rank 0 holds after
+    the all-gather of the 2-rank run are, bit for bit, the spectra of the 1-rank run of the same axis (every rank's block,
+    not only the rank's own: global ndoubl / interface codes, slice boundaries, the order of the gathered blocks)."""
+    f1, f2 = tmp_path / "one.npy", tmp_path / "two.npy"
+    common = ["--workload", "C3", "--points", "2048", "--steps", "1", "--warmup", "0"]
+    j1 = _bench(common + ["--gpus", "1", "--dump-spectra", str(f1)])
+    j2 = _bench(common + ["--gpus", "2", "--scaling", "strong", "--backend", "gloo", "--share-device", "--dump-spectra", str(f2)])
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    assert "2 x 1024 points" in j2["config"]["sharding"]
+    a, b = np.load(f1), np.load(f2)
+    assert a.shape == b.shape and a.shape[0] == 2 and a.shape[-1] == 2048
+    assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
+    assert np.array_equal(a, b)
+
+
+def test_bench_C5_two_ranks_gathered_spectra_bitwise(tmp_path):
+    """The RRS leg over two ranks (windows with a recomputed halo; device-side pack of the owned slices,
+    mom_get_spectra_rrs_device, then one all-gather) against the one-rank run of the same 1 200-point axis: R, T, ieR, ieT,
+    hdr bit for bit."""
+    f1, f2 = tmp_path / "one.npy", tmp_path / "two.npy"
+    j1 = _bench(["--workload", "C5", "--points", "1200", "--steps", "1", "--warmup", "0", "--gpus", "1", "--dump-spectra", str(f1)])
+    j2 = _bench(["--workload", "C5", "--points", "600", "--steps", "1", "--warmup", "0", "--gpus", "2", "--backend", "gloo",
+                 "--share-device", "--dump-spectra", str(f2)])
+    assert "1200 in total" in j1["config"]["workload"].replace("1200/GPU (1200 in total)", "1200 in total") and "1200 in total" in j2["config"]["workload"]
+    a, b = np.load(f1), np.load(f2)
+    assert a.shape == b.shape == (5,) + a.shape[1:] and a.shape[-1] == 1200
+    assert np.abs(a[2]).max() > 0
+    assert np.array_equal(a, b)

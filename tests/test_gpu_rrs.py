@@ -277,3 +277,71 @@ def test_rrs_shard_halo_too_short_is_refused(rtamd):
         rt.rt_run_rrs_window(RS, m, 10, 20, (4, 22))      # 2 points above
     got = rt.rt_run_rrs_window(RS, m, 0, 10, (0, 16))      # window starting at the global edge: no lower halo needed
     assert got[0].shape[-1] == 10
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_rt_run_rrs_twice_on_one_handle(rtamd, strict):
+    """rt_run allocates zeroed layers on every call (rt_run.jl:108-116); the handle's persistent layers must behave the same:
+    a second mom_rt_run_rrs on the same handle, and a run after operator-level uploads of arbitrary layer contents, reproduce
+    the first run bit for bit.  The strict position is the sensitive one (D5 reads iet-- of the previous layer, k_strict_D and
+    the off-grid ieJ0- are read-modify-written); the corrected position's pointer hand-over is covered too."""
+    rt = rtamd.corert
+    m = rtamd.scenes.make_scene(3, 5, 3, 24, seed=9, aerosol_total=0.1, **VIEWS[1])
+    offs = [-4, -1, 2, 7, 3]
+    RS, _ = _rrs_inputs(rtamd, offs, strict)
+    model = rt._with_cabannes(RS, m)
+    sc = rtamd.prepare_scene(model)
+    Zr_pp, Zr_mp = rt.raman_z(RS, model)
+    fs = rt.fscatt_rayleigh(model)
+    fresh = rt.rt_run_rrs(RS, m)
+
+    def spectra(h):
+        h.rt_run_rrs()
+        return h.get_RT_rrs()[:4] + h.get_hdr_rrs()
+
+    with rt.make_handle(model) as h:
+        h.set_option(rtamd._lib.MOM_OPT_STRIP_PAD, 0)
+        h.rrs_set(RS.i_λ1λ0, RS.ϖ_λ1λ0, strict)
+        rt.scene_set(h, sc)
+        h.scene_set_rrs(np.ascontiguousarray(fs.T), rt._abi_mats(Zr_pp), rt._abi_mats(Zr_mp))
+        first = spectra(h)
+        second = spectra(h)
+        # arbitrary layer contents through the operator-level API, then a third run
+        rng = np.random.default_rng(3)
+        a, c = random_layers(h.N, 24, len(offs), rng)
+        push(h, added=a, comp=c, surf=a)
+        third = spectra(h)
+        # an operator-level read after a scene-level run sees consistent layers (ier+- / iet-- materialised on demand)
+        ier_mp = from_abi(h.rrs_download(19), a.ier_mp)
+        ier_pm = from_abi(h.rrs_download(18), a.ier_pm)
+        assert np.all(np.isfinite(ier_mp)) and np.all(np.isfinite(ier_pm))
+    for k in range(4):
+        assert np.array_equal(first[k], fresh[k]), k
+    for k, (x, y, z) in enumerate(zip(first, second, third)):
+        assert np.array_equal(x, y), ("second run", k)
+        assert np.array_equal(x, z), ("run after uploads", k)
+
+
+def test_rrs_empty_owned_range(rtamd):
+    """mom_rrs_set_shard with n1_lo == n1_hi (a rank beyond the end of the axis when world > S / per): the run completes
+    (no zero-sized launch), the inelastic spectra are zero and the elastic ones those of the plain window."""
+    rt = rtamd.corert
+    m = rtamd.scenes.make_scene(1, 3, 2, 20, seed=5)
+    RS, _ = _rrs_inputs(rtamd, [-3, 2], False)
+    model = rt._with_cabannes(RS, m)
+    sc = rtamd.prepare_scene(model)
+    Zr_pp, Zr_mp = rt.raman_z(RS, model)
+    fs = rt.fscatt_rayleigh(model)
+    full = rt.rt_run_rrs(RS, m)
+    for strict in (False, True):
+        with rt.make_handle(model) as h:
+            h.set_option(rtamd._lib.MOM_OPT_STRIP_PAD, 0)
+            h.rrs_set(RS.i_λ1λ0, RS.ϖ_λ1λ0, strict)
+            h.rrs_set_shard(20, 0, 7, 7)
+            rt.scene_set(h, sc)
+            h.scene_set_rrs(np.ascontiguousarray(fs.T), rt._abi_mats(Zr_pp), rt._abi_mats(Zr_mp))
+            h.rt_run_rrs()
+            R, T, ieR, ieT = h.get_RT_rrs()[:4]
+        assert not np.any(ieR) and not np.any(ieT)
+        if not strict:
+            assert np.array_equal(R, full[0]) and np.array_equal(T, full[1])

@@ -116,18 +116,36 @@ def test_voigt_tau_abs_accumulates_into_resident_table(rtamd):
     assert expect.max() > 1e-3 and np.array_equal(got, expect)
 
 
-@pytest.mark.parametrize("lines", ["o2a", "co2_file", "shuffled"])
-def test_device_side_line_prefactors(rtamd, lines):
+def _hit(tab):
+    """product HitranTable -> the read_hitran-style columns oracle/absref.py takes"""
+    return {"mol": tab.mol, "iso": tab.iso, "νᵢ": tab.νᵢ, "Sᵢ": tab.Sᵢ, "γ_air": tab.γ_air, "γ_self": tab.γ_self,
+            "E_lower": tab.E_lower, "n_air": tab.n_air, "δ_air": tab.δ_air}
+
+
+@pytest.mark.parametrize("lines", ["o2a", "co2_file", "shuffled", "edge_shift"])
+def test_device_side_line_prefactors(rtamd, cref, lines):
     """SURVEY 8f-1, last clause: the per-line prefactors of compute_absorption_cross_section.jl:73-107 (pressure shift, Lorentz
     and Doppler widths, y, TIPS-2017 spline ratio qoft!, Boltzmann / stimulated-emission factors, grid windows) formed on the
-    device from ONE resident line table (mom_absorption_set_lines); per layer only (p, T, vmr, vcd) are passed.  Against the
-    host route of the product (absorption.line_prefactors -> mom_voigt_tau_abs): windows identical, prefactors to a few ulp
-    (device vs host exp / pow), tau_abs to 1e-12."""
+    device from ONE resident line table (mom_absorption_set_lines); per layer only (p, T, vmr, vcd) are passed.  Asserted
+    DIRECTLY against the oracle (oracle/absref.line_parameters: the host loop of the reference restated line by line, no code
+    shared with the product): windows identical, prefactors to rounding (Float32 spline set-up differs by ~3e-11 between
+    the routes, device exp / pow by a few ulp), tau_abs of every layer against absref + the oracle's Voigt sum; and, as
+    before, against the product's host route.  "edge_shift": lines inside the padded grid whose pressure-shifted centre puts
+    nu - wing beyond the last grid point or nu + wing before the first one -- the reference's two interpolators return their
+    constant (1 / n) on BOTH sides of the grid (compute_absorption_cross_section.jl:60-61), so those lines act on the whole
+    grid."""
+    from oracle import absref
     ab = rtamd.absorption
     if lines == "co2_file":
         tab = ab.hitran_table(ab.read_hitran(GOLD / "testCO2.data"))
         grid = np.linspace(float(tab.νᵢ.min()) - 2.0, float(tab.νᵢ.max()) + 2.0, 3000)
         model_vmr, wing = 4e-4, 5.0
+    elif lines == "edge_shift":
+        tab = ab.synthetic_o2a_lines(60, seed=9)
+        grid = np.linspace(12990.0, 13010.0, 900)
+        model_vmr, wing = 0.21, 2.0
+        tab.νᵢ[:] = np.sort(np.concatenate([np.linspace(12988.001, 13011.999, 56), [12988.0005, 12988.002, 13011.998, 13011.9995]]))
+        tab.δ_air[:] = np.where(tab.νᵢ < 13000.0, -0.02, 0.02)     # shifts the outermost lines past the padded edge at p ~ 1 atm
     else:
         tab = ab.synthetic_o2a_lines(400, seed=5)
         grid = np.linspace(12920.0, 13230.0, 4000)      # some lines fall outside the padded grid and are dropped
@@ -156,9 +174,22 @@ def test_device_side_line_prefactors(rtamd, lines):
         np.testing.assert_allclose(gd, pf.γ_d, rtol=4e-16)
         np.testing.assert_allclose(y, pf.y, rtol=2e-15)
         np.testing.assert_allclose(Sl, pf.S, rtol=2e-14)
+        # ... and the oracle's, directly
+        onu, ogd, oy, oS, oi0, oi1 = absref.line_parameters(_hit(tab), grid, p_full[-1], T[-1], model_vmr, wing)
+        assert onu.size == nu.size and np.array_equal(i0, oi0) and np.array_equal(i1, oi1)
+        assert np.array_equal(nu, onu)
+        np.testing.assert_allclose(gd, ogd, rtol=1e-15)
+        np.testing.assert_allclose(y, oy, rtol=4e-15)
+        np.testing.assert_allclose(Sl, oS, rtol=1e-9)
+        if lines == "edge_shift":
+            assert np.any((i0 == 1) & (i1 == S) & (nu - wing > grid[-1])) and np.any((i0 == 1) & (i1 == S) & (nu + wing < grid[0]))
         a, b = h_dev.absorption_get(), h_host.absorption_get()
     assert b.max() > 0
     np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-300)
+    for iz in range(4):     # tau_abs[:, iz] = sigma(p, T) * (vcd * vmr) with sigma from the oracle alone (atmo_prof.jl:446)
+        prm = absref.line_parameters(_hit(tab), grid, p_full[iz], T[iz], model_vmr, wing)
+        ref = cref.voigt_xsec(*prm, grid) * (vcd[iz] * 0.3)
+        assert np.max(np.abs(a[:, iz] - ref)) <= 1e-9 * ref.max()
     # a temperature outside the TIPS tables is refused like qoft! does (:204)
     with rtamd.corert.make_handle(m) as h:
         h.absorption_begin(1, grid)

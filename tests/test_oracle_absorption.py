@@ -59,6 +59,28 @@ def test_line_prefactors_product_vs_oracle(rtamd, p, T, vmr):
     np.testing.assert_array_equal(pf.ind_stop, i1)
 
 
+def test_window_fill_values_outside_the_grid(rtamd):
+    """compute_absorption_cross_section.jl:60-61, :104-105: grid_idx_interp_low / _high are LinearInterpolations with the
+    CONSTANT extrapolation values 1 and length(grid) on both sides.  A line inside the padded grid whose pressure-shifted
+    centre puts nu - wing beyond the last grid point starts at index 1 (not n), one whose nu + wing falls before the first
+    grid point stops at n (not 1): both act on the whole grid.  Product host code and oracle, hand-derived expectation."""
+    ab = rtamd.absorption
+    tab = ab.synthetic_o2a_lines(4, seed=1)
+    grid = np.linspace(12990.0, 13010.0, 900)
+    tab.νᵢ[:] = [12988.0005, 12995.0, 13005.0, 13011.9995]
+    tab.δ_air[:] = [-0.02, -0.02, 0.02, 0.02]
+    hit = {"mol": tab.mol, "iso": tab.iso, "νᵢ": tab.νᵢ, "Sᵢ": tab.Sᵢ, "γ_air": tab.γ_air, "γ_self": tab.γ_self,
+            "E_lower": tab.E_lower, "n_air": tab.n_air, "δ_air": tab.δ_air}
+    pf = ab.line_prefactors(tab, grid, 930.0, 288.0, vmr=0.21, wing_cutoff=2.0)
+    _, _, _, _, i0, i1 = absref.line_parameters(hit, grid, 930.0, 288.0, 0.21, 2.0)
+    assert list(i0) == list(pf.ind_start) and list(i1) == list(pf.ind_stop)
+    assert (i0[0], i1[0]) == (1, 900) and (i0[3], i1[3]) == (1, 900)          # whole grid
+    assert 1 < i0[1] < i1[1] < 900 and 1 < i0[2] < i1[2] < 900                  # interior lines: ordinary windows
+    # at p = 5 hPa the shift is 1e-4 cm-1: the same outer lines keep one-point windows at the grid's ends
+    pf5 = ab.line_prefactors(tab, grid, 5.0, 215.0, vmr=0.21, wing_cutoff=2.0)
+    assert (pf5.ind_start[0], pf5.ind_stop[0]) == (1, 1) and (pf5.ind_start[3], pf5.ind_stop[3]) == (900, 900)
+
+
 def test_golden_spectrum_is_the_oracles():
     g = np.load(GOLD / "voigt_co2.npz")
     for tag in ("a", "b"):

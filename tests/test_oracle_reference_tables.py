@@ -13,21 +13,21 @@ from oracle import momref as mr
 G = json.loads((Path(__file__).parent / "golden" / "reference_tables.json").read_text())
 
 
-def _scene(sza, vza, vaz, tau, rho):
-    pol = mr.Stokes_IQUV()
+def _scene(sza, vza, vaz, tau, rho, pol=None, strict=True):
+    pol = pol or mr.Stokes_IQUV()
     quad = mr.rt_set_streams("RadauQuad", 20, sza, vza, pol.n)
     return mr.Scene(pol=pol, quad=quad, max_m=3, tau_rayl=np.full((1, 1), tau), tau_abs=np.zeros((1, 1)),
                     greek_rayleigh=mr.get_greek_rayleigh(0.0), albedo=rho, vza=np.asarray(vza, float),
-                    vaz=np.asarray(vaz, float))
+                    vaz=np.asarray(vaz, float), strict_reference_indexing=strict)
 
 
-def natraj_scene():
+def natraj_scene(pol=None, strict=True):
     mu = np.array(G["natraj_mu"])
     vza1 = np.degrees(np.arccos(mu))
     phis = G["natraj_phi"]
     vza = np.tile(vza1, len(phis))
     vaz = np.repeat(phis, len(mu))
-    return _scene(float(np.degrees(np.arccos(G["natraj_mu0"]))), vza, vaz, G["natraj_tau"], 0.0)
+    return _scene(float(np.degrees(np.arccos(G["natraj_mu0"]))), vza, vaz, G["natraj_tau"], 0.0, pol, strict)
 
 
 def natraj_errors(R):
@@ -71,6 +71,82 @@ def test_6sv1_c_oracle(cref, case):
         Rm = (R[:, 0, 0] / sc.quad.mu0).reshape(3, 16)
         worst = max(worst, float(np.max(np.abs(Rt[si] - Rm) / Rt[si])))
     assert worst < 0.006
+
+
+# --- the nStokes = 3 code path on the same reference-held tables -----------------------------------------------------
+# For Rayleigh scattering V decouples from (I, Q, U) (the greek coefficient δ couples V only to itself, ε = 0), so a
+# Stokes_IQU run of the same scene must land on the same I/Q/U.  With the zero-based Stokes-component rule
+# (strict_reference_indexing = False) it does, to the digits of the IQUV run: that pins the whole N = 3 * Nquad path
+# (headline configuration: IQU) on natraj_trues.jl / 6SV1_R_trues.jl.  With the reference's 1-based rule (quirk Q1,
+# elemental.jl:259-269, doubling.jl:93-118) nothing is negated for nStokes = 3 and the run leaves the tables by the
+# fingerprint SURVEY.md section 8a-Q1 recorded.
+Q1_U_IQU = (-0.0740, -0.0603, -0.0506, -0.0404)      # U[1:4] at phi = 90 deg, IQU as written
+Q1_U_IQUV = (0.0812, 0.0715, 0.0635, 0.0539)
+
+
+def q1_fingerprint(R_iqu_strict, R_iquv):
+    """(max |ΔI|, max |ΔQ|, U_IQU[1:4], U_IQUV[1:4]) at phi = 90 deg of the Natraj slab."""
+    k = G["natraj_phi"].index(90.0)
+    U3 = R_iqu_strict[:, 2, 0].reshape(7, 16)[k, :4]
+    U4 = R_iquv[:, 2, 0].reshape(7, 16)[k, :4]
+    dI = float(np.max(np.abs(R_iqu_strict[:, 0, 0] - R_iquv[:, 0, 0])))
+    dQ = float(np.max(np.abs(R_iqu_strict[:, 1, 0] - R_iquv[:, 1, 0])))
+    return dI, dQ, U3, U4
+
+
+def assert_q1_fingerprint(R_iqu_strict, R_iquv):
+    dI, dQ, U3, U4 = q1_fingerprint(R_iqu_strict, R_iquv)
+    assert 0.5e-3 < dI < 3e-3 and 0.5e-3 < dQ < 3e-3, (dI, dQ)            # "≈ 1.2e-3 absolute" at phi = 90, ≤ 2.1e-3 overall
+    np.testing.assert_allclose(U3, Q1_U_IQU, atol=6e-5)
+    np.testing.assert_allclose(U4, Q1_U_IQUV, atol=6e-5)
+
+
+def test_natraj_iqu_nonstrict_c_oracle(cref):
+    """Natraj scene as Stokes_IQU, zero-based Stokes rule: N = 102, the reference's thresholds AND the same error
+    fingerprints as the IQUV run (V decouples)."""
+    sc = natraj_scene(mr.Stokes_IQU(), strict=False)
+    assert sc.N == 102 and sc.quad.imu0 == 10
+    p = cref.pack_scene(sc)
+    assert list(p.nd) == [18]
+    R, _, info = cref.rt_run(p)
+    assert info == 0
+    eI, eQ, eU = natraj_errors(R)
+    assert eI < 0.002 and eQ < 0.008 and eU < 0.008
+    assert abs(eI - 1.3668e-3) < 2e-7 and abs(eQ - 7.7745e-3) < 2e-7 and abs(eU - 3.7466e-3) < 2e-7
+    R4, _, _ = cref.rt_run(cref.pack_scene(natraj_scene()))
+    np.testing.assert_allclose(R[:, :3, 0], R4[:, :3, 0], rtol=0, atol=1e-12)
+
+
+def test_natraj_iqu_strict_q1_fingerprint(cref):
+    """Stokes_IQU as written (Q1): I, Q move by ≈ 1e-3, U flips sign with a 10-25 % magnitude change."""
+    R3, _, info = cref.rt_run(cref.pack_scene(natraj_scene(mr.Stokes_IQU(), strict=True)))
+    assert info == 0
+    R4, _, _ = cref.rt_run(cref.pack_scene(natraj_scene()))
+    assert_q1_fingerprint(R3, R4)
+    eI, eQ, _ = natraj_errors(R3)
+    assert eI > 0.002 and eQ > 0.008      # the IQU run as written does NOT meet the tables (1.3 % / 10 %)
+    Ut = np.array(G["natraj"]["U_trues"]).T
+    assert np.max(np.abs(Ut - R3[:, 2, 0].reshape(7, 16))) > 0.1
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_6sv1_iqu_nonstrict_c_oracle(cref, case):
+    """The six 6SV1 cases as Stokes_IQU with the zero-based rule: same ε = 0.006 on R/μ₀ (adds the Lambertian surface
+    with ρ = 0.25 to the nStokes = 3 pin)."""
+    c = G["sixsv_cases"][case]
+    Rt = np.array(G["sixsv_R"][case])
+    vza1 = np.array(G["sixsv_vza"])
+    for si, sza in enumerate(c["sza"]):
+        vza = np.tile(vza1, 3)
+        vaz = np.repeat(np.array(c["az"], float), 16)
+        sc = _scene(sza, vza, vaz, c["tau"], c["rho"], mr.Stokes_IQU(), strict=False)
+        assert sc.N % 3 == 0
+        R, _, info = cref.rt_run(cref.pack_scene(sc))
+        assert info == 0
+        Rm = (R[:, 0, 0] / sc.quad.mu0).reshape(3, 16)
+        assert float(np.max(np.abs(Rt[si] - Rm) / Rt[si])) < 0.006
+        R4, _, _ = cref.rt_run(cref.pack_scene(_scene(sza, vza, vaz, c["tau"], c["rho"])))
+        np.testing.assert_allclose(R[:, :3, 0], R4[:, :3, 0], rtol=0, atol=1e-12)
 
 
 def test_numpy_twin_natraj_subset():

@@ -123,3 +123,19 @@ def test_gather_spectra_over_gloo(S, world):
     n = np.arange(S, dtype=np.float64)
     assert np.array_equal(full[0], np.stack([[n + 100 * v + 10 * k for k in range(3)] for v in range(2)]))
     assert np.array_equal(full[1], -n) and np.array_equal(full[2], np.stack([n * n, 2 * n]))
+
+
+def test_unpack_rrs_spectra_layout():
+    """sharding.unpack_rrs_spectra inverts the packing of mom_get_spectra_rrs_device / mom_allgather_rrs_device: per rank
+    [R | T | ieR | ieT | hdr][per, nStokes, nVza] then [bhr_uw | bhr_dw][per, nStokes] (the ABI's order: spectral index
+    slowest); ragged tail cut off."""
+    import rtamd
+    rng = np.random.default_rng(0)
+    nV, nS, per, world, S = 3, 4, 5, 3, 13
+    full = [rng.standard_normal((nV, nS, world * per)) for _ in range(5)] + [rng.standard_normal((nS, world * per)) for _ in range(2)]
+    G = np.stack([np.concatenate([np.ascontiguousarray(x[..., r * per:(r + 1) * per].T).reshape(-1) for x in full])
+                  for r in range(world)])
+    assert G.shape == (world, (5 * nV * nS + 2 * nS) * per)
+    got = rtamd.sharding.unpack_rrs_spectra(G, nV, nS, per, S)
+    for x, y in zip(got, full):
+        assert np.array_equal(x, y[..., :S])
