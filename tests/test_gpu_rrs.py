@@ -324,7 +324,7 @@ def test_rt_run_rrs_twice_on_one_handle(rtamd, strict):
 
 def test_rrs_empty_owned_range(rtamd):
     """mom_rrs_set_shard with n1_lo == n1_hi (a rank beyond the end of the axis when world > S / per): the run completes
-    (no zero-sized launch), the inelastic spectra are zero and the elastic ones those of the plain window."""
+    (no zero-sized launch) and every spectrum is zero (outputs exist for owned points only)."""
     rt = rtamd.corert
     m = rtamd.scenes.make_scene(1, 3, 2, 20, seed=5)
     RS, _ = _rrs_inputs(rtamd, [-3, 2], False)
@@ -332,7 +332,6 @@ def test_rrs_empty_owned_range(rtamd):
     sc = rtamd.prepare_scene(model)
     Zr_pp, Zr_mp = rt.raman_z(RS, model)
     fs = rt.fscatt_rayleigh(model)
-    full = rt.rt_run_rrs(RS, m)
     for strict in (False, True):
         with rt.make_handle(model) as h:
             h.set_option(rtamd._lib.MOM_OPT_STRIP_PAD, 0)
@@ -342,6 +341,4 @@ def test_rrs_empty_owned_range(rtamd):
             h.scene_set_rrs(np.ascontiguousarray(fs.T), rt._abi_mats(Zr_pp), rt._abi_mats(Zr_mp))
             h.rt_run_rrs()
             R, T, ieR, ieT = h.get_RT_rrs()[:4]
-        assert not np.any(ieR) and not np.any(ieT)
-        if not strict:
-            assert np.array_equal(R, full[0]) and np.array_equal(T, full[1])
+        assert not np.any(ieR) and not np.any(ieT) and not np.any(R) and not np.any(T)

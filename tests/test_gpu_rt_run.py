@@ -537,7 +537,7 @@ def test_surface_types(rtamd, cref, surf, nS, lt, mode):
     assert np.abs(R0 - R).max() > 1e-6
 
 
-F32_ERR_RATIO = 4.0      # GPU Float32 error / oracle Float32 error, both against the Float64 oracle
+F32_ERR_RATIO = 2.5      # GPU Float32 error / oracle Float32 error, both against the Float64 oracle (measured 0.9 ... 1.34)
 F32_PAIR_ULPS = 50.0     # GPU Float32 vs oracle Float32, in units of eps32 2^nd
 
 
@@ -579,15 +579,21 @@ def test_float32_scene_level_path(rtamd, cref, nS, lt, kw):
     #   (a) the GPU's distance from the Float64 result is at most F32_ERR_RATIO x the Float32 oracle's own distance
     #       (+ the 1e-6 floor) -- the arbiter construction of test_gpu_precision.py, one precision down;
     #   (b) GPU Float32 against oracle Float32 directly, within F32_PAIR_ULPS eps32 2^nd (each doubling squares the direct
-    #       transmission, so two Float32 runs that round differently once are 2^nd eps32 apart at the end).
+    #       transmission, so two Float32 runs that round differently once are 2^nd eps32 apart at the end).  Measured: the
+    #       two Float32 runs are as far from each other as each is from the Float64 result (x 1.1 ... 1.4: independent
+    #       rounding), i.e. 0.1 ... 0.8 of this bound -- it is (a) that separates "rounds differently" from "wrong".
     Rf, Tf, info32 = cref.rt_run_f32(cref.pack_scene(helpers.oracle_scene(m)))
     assert info32 == 0
     nd = int(sc.ndoubl.max())
     oR = float(np.max(np.abs(Rf - Rr) / np.maximum(np.abs(Rr[:, 0:1, :]), 1e-6 / tol)))
     oT = float(np.max(np.abs(Tf - Tr) / np.maximum(np.abs(Tr[:, 0:1, :]), 1e-6 / tol)))
     pair = F32_PAIR_ULPS * 6e-8 * 2.0 ** nd
-    pR = helpers.assert_stokes_close(R, Rf.astype(np.float64), rtol=pair, atol=1e-6, what="f32 R vs f32 oracle")
-    pT = helpers.assert_stokes_close(T, Tf.astype(np.float64), rtol=pair, atol=1e-6, what="f32 T vs f32 oracle")
+    def pair_err(X, Xf, Xref, what):   # |GPU f32 - oracle f32| relative to the FLOAT64 intensity of the same view and point
+        d = np.abs(X - Xf.astype(np.float64)) / np.maximum(np.abs(Xref[:, 0:1, :]), 1e-6 / pair)
+        assert np.all(d <= pair), f"{what}: {d.max():.3e} > {pair:.3e}"
+        return float(d.max())
+    pR = pair_err(R, Rf, Rr, "f32 R vs f32 oracle")
+    pT = pair_err(T, Tf, Tr, "f32 T vs f32 oracle")
     print(f"float32 vs f64 oracle: GPU {eR:.2e} / {eT:.2e}, f32 oracle {oR:.2e} / {oT:.2e}; GPU vs f32 oracle {pR:.2e} / {pT:.2e} "
           f"(bound {pair:.2e}; old bound {tol:.2e}), nd max {nd}")
     assert eR <= F32_ERR_RATIO * oR + 2e-6 and eT <= F32_ERR_RATIO * oT + 2e-6
