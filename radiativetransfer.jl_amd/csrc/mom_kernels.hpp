@@ -112,16 +112,24 @@ __host__ __device__ inline int big_tile_doubles(int N) {
   const int st = kBigStages * (kBigStA + big_stage_b(N)), pt = 8 * 16 * kBigPatch;
   return st > pt ? st : pt;
 }
-__host__ __device__ inline size_t vec_area_doubles(int N) {
-  // the vectors, the 32 series thresholds, then np + 4 ints (ipiv, sh, bad) in whole pairs of reals (the Float32 build
-  // needs one real per int: half of them used to overlap the panel area behind)
-  const size_t ints = 2 * ((sizeof(int) * (size_t)(np_for(N) + 4) + 2 * sizeof(real) - 1) / (2 * sizeof(real)));
-  return (size_t)(kNumVec * np_for(N) + 32) + ints;
+// Vector area: 15 vectors, the 32 series thresholds, np + 4 ints (ipiv, sh, bad) in whole pairs of reals (the Float32
+// build needs one real per int), then `part` (2 kWaves vectors of scratch).  `part` comes last so that the
+// register-resident doubling (mom_regdbl.hpp) can lay its two operand slots over it and the panel area behind.
+__host__ __device__ inline size_t vec_ints_doubles(int N) {
+  return 2 * ((sizeof(int) * (size_t)(np_for(N) + 4) + 2 * sizeof(real) - 1) / (2 * sizeof(real)));
 }
+__host__ __device__ inline size_t part_offset_doubles(int N) { return (size_t)(15 * np_for(N) + 32) + vec_ints_doubles(N); }
+__host__ __device__ inline size_t vec_area_doubles(int N) { return part_offset_doubles(N) + (size_t)(2 * kWaves) * np_for(N); }
 __host__ __device__ inline size_t lds_bytes(int N, bool lds_mats) {
   size_t b = vec_area_doubles(N) * sizeof(real);
   if (lds_mats) b += 4 * mat_elems(N) * sizeof(real);
-  else if (N > 64) b += (size_t)big_tile_doubles(N) * sizeof(real);
+  else if (N > 64) {
+    b += (size_t)big_tile_doubles(N) * sizeof(real);
+    if (sizeof(real) == 8 && kWaves == 8 && N <= 96) {  // register-resident doubling: 16 reals of part + two slots (rg_applies)
+      const size_t rg = (part_offset_doubles(N) + 16 + 2 * (size_t)np_for(N) * ld_for(N)) * sizeof(real);
+      if (rg > b) b = rg;
+    }
+  }
   return b;
 }
 
@@ -145,10 +153,11 @@ __device__ __forceinline__ void make_ctx(Ctx &c, int N, int inv_mode, real *smem
   const int lv = c.ldv;
   c.jp = p; c.jm = p + lv; c.j1p = p + 2 * lv; c.j1m = p + 3 * lv; c.v1 = p + 4 * lv; c.v2 = p + 5 * lv;
   c.Jp = p + 6 * lv; c.Jm = p + 7 * lv; c.prow = p + 8 * lv; c.pcol = p + 9 * lv; c.rowk = p + 10 * lv;
-  c.ei = p + 11 * lv; c.mu = p + 12 * lv; c.wt = p + 13 * lv; c.sg = p + 14 * lv; c.part = p + 15 * lv;
-  c.thr = p + (size_t)kNumVec * lv;
+  c.ei = p + 11 * lv; c.mu = p + 12 * lv; c.wt = p + 13 * lv; c.sg = p + 14 * lv;
+  c.thr = p + 15 * lv;
   int *ip = reinterpret_cast<int *>(c.thr + 32);
   c.ipiv = ip; c.sh = ip + lv; c.bad = ip + lv + 1;
+  c.part = p + part_offset_doubles(N);
 }
 
 // zero the padding (rows/cols >= N) of the LDS matrix buffers; vectors fully
@@ -649,6 +658,7 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
 
 }  // namespace MOM_NS
 #include "mom_strip.hpp"
+#include "mom_regdbl.hpp"
 namespace MOM_NS {
 
 // ---------------------------------------------------------------------------------------
@@ -965,14 +975,22 @@ __device__ __forceinline__ real doubling_run(Ctx &c, int nd, real expk) {
   // r j and Q (..) come out of the MFMA products for free.  Needs two spare columns in the last
   // column tile and no K padding (N % 4 == 0); otherwise: separate mat-vec passes.
   const bool ride = (N % 4 == 0) && (c.nc - N >= 2);
-  if (ride) {
+  int it0 = 0;
+  if constexpr (!LDSM && kF64 && kWaves == 8) {
+    // 64 < N <= 96: the operators of the loop live in registers (mom_regdbl.hpp); what it cannot do (forced pivoting, a
+    // series beyond 512 terms) comes back here with r, t, j0+- of the step it stopped at
+    if (rg_applies(N) && c.inv_mode == 0) {
+      it0 = (np_for(N) == 80) ? rg_doubling<5>(c, nd, &expk) : rg_doubling<6>(c, nd, &expk);
+    }
+  }
+  if (ride && it0 < nd) {
     for (int i = wg_tid(); i < N; i += kThreads) {
       c.r[i + N * ld] = c.jp[i];
       c.r[i + (N + 1) * ld] = c.jm[i];
     }
     __syncthreads();
   }
-  for (int it = 0; it < nd; ++it) {
+  for (int it = it0; it < nd; ++it) {
     bool strip_ok = false;
     if constexpr (LDSM && KS > 0) strip_ok = ride && c.inv_mode == 0 && N == 4 * KS;
     // r r on strips where the general product has no straight-line schedule (4-wave build); the 8-wave build's

@@ -59,6 +59,32 @@ def test_rt_run_parity_generic_sizes(rtamd, cref, nS, lt, N):
     helpers.assert_stokes_close(T3, Tr, rtol=1e-11, what="T gauss-jordan")
 
 
+# 64 < N <= 96: the doubling loop runs with register-resident operators (csrc/mom_regdbl.hpp: tiles dealt over the 8 waves,
+# operands staged through two LDS slots), elemental and interaction in the slab as before.  5 x 5 tile grids (N = 66, 75,
+# 80) and 6 x 6 (N = 84, 96: no spare column / full tiles), N odd, thin and thick layers: Horner (p <= 4), the squaring
+# series (p <= 512) and the hand-back to the general path (pivoted inverse beyond).  inverse = 2 switches the register
+# path off (the r3 slab path): both against the oracle and against each other.
+@pytest.mark.parametrize("nS,lt,N,kw", [(3, 37, 66, {}), (3, 43, 75, {}), (4, 33, 80, {}), (3, 49, 84, {}), (4, 41, 96, {}),
+                                        (3, 49, 84, dict(aerosol_total=3.0, absorption=False)),
+                                        (4, 41, 96, dict(aerosol_total=8.0, absorption=False, aerosol_p0=600.0, aerosol_σp=250.0)),
+                                        (1, 143, 75, dict(aerosol_total=1.0))])
+def test_register_resident_doubling_sizes(rtamd, cref, nS, lt, N, kw):
+    kw = dict(dict(aerosol_total=0.3), **kw)
+    m = rtamd.scenes.make_scene(nS, lt, 4, 6, seed=nS + lt, **kw)
+    sc = rtamd.prepare_scene(m)
+    assert sc.N == N
+    Rr, Tr = _oracle(cref, m)
+    tol = helpers.stokes_rtol(sc.ndoubl)
+    R, T = _gpu(rtamd, m)
+    helpers.assert_stokes_close(R, Rr, rtol=tol, what=f"R N={N}")
+    helpers.assert_stokes_close(T, Tr, rtol=tol, what=f"T N={N}")
+    R2, T2 = _gpu(rtamd, m, inverse=2)
+    helpers.assert_stokes_close(R2, Rr, rtol=tol, what=f"R N={N} slab path")
+    helpers.assert_stokes_close(R, R2, rtol=tol, what="register path vs slab path R")
+    helpers.assert_stokes_close(T, T2, rtol=tol, what="register path vs slab path T")
+    assert not np.array_equal(R, R2)     # the two paths really are different code (summation order of the mat-vecs)
+
+
 # operator sizes with strip-chained kernels (mom_strip.hpp): N = 52, 56, 60 in the 8-wave build (IQUV with 13, 14,
 # 15 streams; scalar with 60), N = 36, 40, 44 in the 4-wave build (scalar scenes; the m = 0 (I,Q) sub-problems of
 # IQU scenes with 18, 20, 22 streams -- their full problems have N = 54 (plain LDS path), 60, 66 (generic path))

@@ -7,8 +7,13 @@ sys.path.insert(0, ROOT)
 os.environ["MOM_LIBRARY"] = os.environ.get("MOM_LIBRARY", os.path.join(ROOT, "scratch", "ab", "lib_diag.so"))
 import numpy as np
 import rtamd
+# usage: phase_stamps_gen.py [S]                 -> the C4 scene (N = 256)
+#        phase_stamps_gen.py S nStokes l_trunc   -> a make_scene of the size sweep (20 layers; e.g. 1024 3 49 -> N = 84)
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-model = rtamd.scenes.scene_C4(S=S)
+if len(sys.argv) > 3:
+    model = rtamd.scenes.make_scene(int(sys.argv[2]), int(sys.argv[3]), 20, S, vza=(0.0, 30.0), vaz=(0.0, 20.0))
+else:
+    model = rtamd.scenes.scene_C4(S=S)
 sc = rtamd.prepare_scene(model)
 lib = rtamd._lib.load()
 rd = lib.mom_diag_read_gen; rd.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
@@ -27,7 +32,7 @@ names = {40: "prologue", 43: "loop top (scalars)", 46: "elem: tables+barrier", 4
          16: "int: copy T++", 17: "int: R-+ += (T01 r) T++ (gemm)", 18: "int: copy R+-", 19: "int: P = R+- r (gemm + norm)", 20: "int: times_inv T21", 21: "int: J0+ (no-ride)",
          22: "int: copy R+- again", 23: "int: P = T21 R+- (gemm)", 24: "int: R+- = r+- + P t-- (gemm)", 25: "int: copy T++", 26: "int: T++ = T21 T++ (gemm)", 45: "interaction: rest", 42: "store first"}
 tot = sum(a[k] for k in names)
-print(f"C4 (N = 256, S = {S}): share of k_layer<false,3,0>'s run time per code section (wave 0 of the middle workgroup)")
+print(f"N = {sc.N}, S = {S}, sum(ndoubl) = {int(sc.ndoubl.sum())}: share of k_layer<false,3,0>'s run time per code section (wave 0 of the middle workgroup)")
 for k in sorted(names, key=lambda k: -a[k]):
     if a[k] > 0:
         print(f"{k:3d} {names[k]:44s} {100 * a[k] / tot:6.2f} %")
