@@ -1126,6 +1126,13 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
       if (interaction_strip<KS>(c, g)) return;
     }
   }
+  if constexpr (!LDSM && kF64 && kWaves == 8 && std::is_same<FRPM, ElSigP>::value && std::is_same<FTMM, ElSigP>::value) {
+    // 64 < N <= 96, interface 11, r+- / t-- the sign conjugates of the layer in c.r, c.t: register-resident operators
+    // (mom_regdbl.hpp); returns false before it has stored anything when an inverse needs the pivoted form
+    if ((IFACE < 0 || IFACE == 3) && iface == 3 && c.inv_mode == 0 && rg_applies(N) && rpm.p == c.r && tmm.p == c.t) {
+      if ((np_for(N) == 80) ? rg_interaction<5>(c, g) : rg_interaction<6>(c, g)) return;
+    }
+  }
   // composite sources -> LDS
   for (int i = wg_tid(); i < N; i += kThreads) {
     c.Jp[i] = g.J0p[i];

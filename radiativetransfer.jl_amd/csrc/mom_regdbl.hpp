@@ -113,16 +113,137 @@ __device__ __forceinline__ real rg_sumsq(const RgMat<NTS> &X) {
   return ss;
 }
 
-// y1[i] = a1[i] + sum_k M[i,k] x1[k] (threads 0..127) and y2[i] = a2[i] + sum_k M[i,k] x2[k] (threads 128..255);
-// M column-major in a slot.  xs: scale applied to x (x1: sx1, x2: sx2).  No barrier inside.
-__device__ __forceinline__ void rg_matvec2(const real *M, int ld, int N, const real *x1, real sx1, const real *x2, real sx2,
-                                           const real *a1, real sa1, const real *a2, real sa2, real *y1, real *y2) {
+// Q = T (I - B)^-1 by the truncated Neumann series of p terms (times_inv of mom_kernels.hpp: Horner for p <= 4, repeated
+// squaring up to 512 terms); B in P (destroyed), T in registers.  Both slots must be free on entry (a barrier since their
+// last readers); ends with a product reading both.
+template <int NTS>
+__device__ __forceinline__ void rg_series(RgMat<NTS> &Q, RgMat<NTS> &P, const RgMat<NTS> &T, int p, const RgGeom<NTS> &g, real *S0,
+                                          real *S1, int so, int ld, int KS, int N) {
+  if (p <= 4) {
+    Q = T;
+    if (p >= 2) {
+      rg_stage(S1, g, P);
+      rg_stage(S0, g, T);
+      __syncthreads();
+      rg_mm<NTS, true>(Q, 0, 1, g, so, ld, KS);    // T + T B
+      for (int k = 3; k <= p; ++k) {
+        __syncthreads();
+        rg_stage(S0, g, Q);
+        __syncthreads();
+        Q = T;
+        rg_mm<NTS, true>(Q, 0, 1, g, so, ld, KS);  // T + Q B
+      }
+    }
+  } else {
+    // G = (I + B)(I + B^2)(I + B^4) ... in Q; then Q = T G
+    const int lane = wg_lane(), lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < NTS; ++s) {
+      Q.t[s] = P.t[s];
+      if (g.ti[s] == g.tj[s]) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          if (lq + 4 * rr == lr && 16 * g.ti[s] + lr < N) Q.t[s][rr] += 1.0;
+      }
+    }
+    for (int terms = 2; terms < p; terms *= 2) {
+      rg_stage(S0, g, P);
+      __syncthreads();
+      rg_mm<NTS, false>(P, 0, 0, g, so, ld, KS);   // B <- B B
+      __syncthreads();
+      rg_stage(S0, g, Q);
+      rg_stage(S1, g, P);
+      __syncthreads();
+      rg_mm<NTS, true>(Q, 0, 1, g, so, ld, KS);    // G <- G + G B
+      __syncthreads();
+    }
+    rg_stage(S0, g, T);
+    rg_stage(S1, g, Q);
+    __syncthreads();
+    rg_mm<NTS, false>(Q, 0, 1, g, so, ld, KS);     // Q = T G
+  }
+}
+
+// series length for ||B||_F^2 = beta2, as times_inv chooses it in generic mode; > 512: pivoted inverse (not done here)
+__device__ __forceinline__ int rg_terms(const Ctx &c, real beta2) {
+  int p = neumann_terms(c.thr, beta2);
+  if (p > 32 && beta2 < 0.81) {
+    const real beta = sqrt(beta2);
+    p = (int)ceil((38.816242111356935 - log(1.0 - beta)) / -log(beta));
+    if (p < 33) p = 33;
+  }
+  return p;
+}
+
+typedef real rg_r2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rg_r2 rg_ld2(const real *p) { return *(const rg_r2 *)p; }
+__device__ __forceinline__ rg_r2 rg_ld2(const gdouble *p) { return *(const __attribute__((address_space(1))) rg_r2 *)p; }
+__device__ __forceinline__ void rg_st2(real *p, rg_r2 v) { *(rg_r2 *)p = v; }
+__device__ __forceinline__ void rg_st2(gdouble *p, rg_r2 v) { *(__attribute__((address_space(1))) rg_r2 *)p = v; }
+
+// N x N block of a column-major array (pitch ps: a composite block or a slab buffer) -> slot, zero padding up to Np x Np
+// written along; SIG: diag(sg) block diag(sg) (the added layer's r+- / t--).  16-byte accesses (ps, ld even).
+template <int NT, bool SIG, class PS>
+__device__ __forceinline__ void rg_load(real *L, PS src, int ps, const real *sg, int N, int ld) {
+  typedef real r2 __attribute__((ext_vector_type(2)));
+  constexpr int Np = 16 * NT, H = Np / 2;
+  for (int e = wg_tid(); e < H * Np; e += kThreads) {
+    const int j = e / H, i = 2 * (e - j * H);
+    r2 v = {0.0, 0.0};
+    if (j < N) {
+      if (i + 1 < N) v = rg_ld2(src + i + (size_t)j * ps);
+      else if (i < N) v.x = src[i + (size_t)j * ps];
+      if (SIG) { const real sj = sg[j]; v.x *= sg[i] * sj; v.y *= sg[i + 1] * sj; }
+    }
+    *(r2 *)(L + i + j * ld) = v;
+  }
+}
+
+// slot -> N x N block of a column-major global array (pitch ps)
+template <int NT, class PD>
+__device__ __forceinline__ void rg_unload(PD dst, int ps, const real *L, int N, int ld) {
+  typedef real r2 __attribute__((ext_vector_type(2)));
+  constexpr int Np = 16 * NT, H = Np / 2;
+  for (int e = wg_tid(); e < H * N; e += kThreads) {
+    const int j = e / H, i = 2 * (e - j * H);
+    const r2 v = *(const r2 *)(L + i + j * ld);
+    if (i + 1 < N) rg_st2(dst + i + (size_t)j * ps, v);
+    else if (i < N) dst[i + (size_t)j * ps] = v.x;
+  }
+}
+
+// N x N block of a column-major array -> registers (accumulator layout), zero outside; SIG as above
+template <int NTS, bool SIG, class PS>
+__device__ __forceinline__ void rg_fetch_global(RgMat<NTS> &X, PS src, int ps, const real *sg, const RgGeom<NTS> &g, int N) {
+  const int lane = wg_lane(), lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < NTS; ++s) {
+    const int col = 16 * g.tj[s] + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * g.ti[s] + lq + 4 * r;
+      real v = 0.0;
+      if (row < N && col < N) {
+        v = src[row + (size_t)col * ps];
+        if (SIG) v *= sg[row] * sg[col];
+      }
+      X.t[s][r] = v;
+    }
+  }
+}
+
+// y1[i] = sa1 a1[i] + sx1 sum_k M1[i,k] x1[k] (threads 0..127) and y2[i] = sa2 a2[i] + sx2 sum_k M2[i,k] x2[k] (threads
+// 128..255); M1, M2 column-major in slots (y2 == nullptr: only the first).  No barrier inside.
+__device__ __forceinline__ void rg_matvec2(const real *M1, const real *M2, int ld, int N, const real *x1, real sx1, const real *x2,
+                                           real sx2, const real *a1, real sa1, const real *a2, real sa2, real *y1, real *y2) {
   const int tid = wg_tid();
   if (tid >= 256) return;
   const int i = tid & 127;
   if (i >= N) return;
   const bool second = tid >= 128;
+  if (second && y2 == nullptr) return;
   const real *x = second ? x2 : x1;
+  const real *M = second ? M2 : M1;
   const real sx = second ? sx2 : sx1;
   real s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   int k = 0;
@@ -167,8 +288,8 @@ __device__ __forceinline__ int rg_body(Ctx &c, int nd, real *expk_io) {
   real expk = *expk_io;
   // slab -> slots -> registers
   __syncthreads();
-  rg_copy(S0, c.r, N * ld);
-  rg_copy(S1, c.t, N * ld);
+  rg_load<NT, false>(S0, (const real *)c.r, ld, nullptr, N, ld);
+  rg_load<NT, false>(S1, (const real *)c.t, ld, nullptr, N, ld);
   __syncthreads();
   rg_fetch(r, S0, g, N);
   rg_fetch(t, S1, g, N);
@@ -178,68 +299,20 @@ __device__ __forceinline__ int rg_body(Ctx &c, int nd, real *expk_io) {
     rg_stage(S0, g, r);
     __syncthreads();
     // w1 = j1- + r j0+ ; w2 = j0+ + r j1-   with j1± = j0± expk   (doubling.jl:51-60)
-    rg_matvec2(S0, ld, N, c.jp, 1.0, c.jm, expk, c.jm, expk, c.jp, 1.0, c.v1, c.v2);
+    rg_matvec2(S0, S0, ld, N, c.jp, 1.0, c.jm, expk, c.jm, expk, c.jp, 1.0, c.v1, c.v2);
     rg_mm<NTS, false>(P, 0, 0, g, so, ld, KS);       // P = r r   (:44)
     wg_sumsq_put(c, rg_sumsq(P));
     __syncthreads();
     const real beta2 = wg_sumsq_get(c);
-    int p = neumann_terms(c.thr, beta2);
-    if (p > 32 && beta2 < 0.81) {     // the series beyond the table, as times_inv does in generic mode
-      const real beta = sqrt(beta2);
-      p = (int)ceil((38.816242111356935 - log(1.0 - beta)) / -log(beta));
-      if (p < 33) p = 33;
-    }
+    const int p = rg_terms(c, beta2);
     if (p > 512) break;               // pivoted inverse: the general path (r, t, j are still those of step `it`)
-    // Q = t (I - P)^-1   (:47-48)
-    if (p <= 4) {
-      Q = t;
-      if (p >= 2) {
-        rg_stage(S1, g, P);
-        rg_stage(S0, g, t);           // S0: every wave is past its reads of r (barrier above)
-        __syncthreads();
-        rg_mm<NTS, true>(Q, 0, 1, g, so, ld, KS);    // t + t P
-        for (int k = 3; k <= p; ++k) {
-          __syncthreads();
-          rg_stage(S0, g, Q);
-          __syncthreads();
-          Q = t;
-          rg_mm<NTS, true>(Q, 0, 1, g, so, ld, KS);  // t + Q P
-        }
-      }
-    } else {
-      // G = (I + B)(I + B^2)(I + B^4) ... in Q, B in P; then Q = t G
-      const int lane = wg_lane(), lr = lane & 15, lq = lane >> 4;
-#pragma unroll
-      for (int s = 0; s < NTS; ++s) {
-        Q.t[s] = P.t[s];
-        if (g.ti[s] == g.tj[s]) {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr)
-            if (lq + 4 * rr == lr && 16 * g.ti[s] + lr < N) Q.t[s][rr] += 1.0;
-        }
-      }
-      for (int terms = 2; terms < p; terms *= 2) {
-        rg_stage(S0, g, P);
-        __syncthreads();
-        rg_mm<NTS, false>(P, 0, 0, g, so, ld, KS);   // B <- B B
-        __syncthreads();
-        rg_stage(S0, g, Q);
-        rg_stage(S1, g, P);
-        __syncthreads();
-        rg_mm<NTS, true>(Q, 0, 1, g, so, ld, KS);    // G <- G + G B
-        __syncthreads();
-      }
-      rg_stage(S0, g, t);
-      rg_stage(S1, g, Q);
-      __syncthreads();
-      rg_mm<NTS, false>(Q, 0, 1, g, so, ld, KS);     // Q = t G
-    }
+    rg_series<NTS>(Q, P, t, p, g, S0, S1, so, ld, KS, N);   // Q = t (I - P)^-1   (:47-48)
     // P = Q r   (the reference's (tt gp) r, :64) ; j0- += Q w1 (:57) ; j0+ = j1+ + Q w2 (:60)
     __syncthreads();
     rg_stage(S0, g, Q);
     rg_stage(S1, g, r);
     __syncthreads();
-    rg_matvec2(S0, ld, N, c.v1, 1.0, c.v2, 1.0, c.jm, 1.0, c.jp, expk, c.jm, c.jp);
+    rg_matvec2(S0, S0, ld, N, c.v1, 1.0, c.v2, 1.0, c.jm, 1.0, c.jp, expk, c.jm, c.jp);
     rg_mm<NTS, false>(P, 0, 1, g, so, ld, KS);
     // t <- Q t (:67) ; r <- r + P t (:64)
     __syncthreads();
@@ -270,6 +343,123 @@ __device__ __attribute__((noinline)) int rg_doubling(Ctx &c, int nd, real *expk_
   const int wave = __builtin_amdgcn_readfirstlane(wg_wave());
   if (wave < full) return rg_body<NT, TS>(c, nd, expk_io);
   return rg_body<NT, TS - 1>(c, nd, expk_io);
+}
+
+// ScatteringInterface_11 (interaction_helper!, CoreKernel/interaction.jl:69-117) of the composite block g with the added
+// layer in the slab (c.r = r-+, c.t = t++, r+- = S r-+ S, t-- = S t++ S with S = diag(sg); c.jp, c.jm) -- the same
+// register-resident scheme: every operand is staged into a slot (composite blocks straight from global memory, zero
+// padding written along), results go back through a slot as 16-byte rows.  Returns false BEFORE anything is stored if one
+// of the two inverses needs more than the series (the general path then does the whole interaction).  All threads; ends
+// with a barrier.
+template <int NT, int NTS>
+__device__ __forceinline__ bool rg_interaction_body(Ctx &c, const CompPtrs &cp) {
+  const int N = __builtin_amdgcn_readfirstlane(c.N), ld = ld_for(N), KS = (N + 3) >> 2, cl = cp.ld;
+  const int so = (int)rg_slot_doubles(N);
+  real *S0 = mom_smem + part_offset_doubles(N) + 16, *S1 = S0 + so;
+  const real *sr = c.r, *st = c.t;
+  const gdouble *gRmp = cp.R_mp, *gRpm = cp.R_pm, *gTpp = cp.T_pp, *gTmm = cp.T_mm;
+  RgGeom<NTS> g;
+  rg_geom<NT, NTS>(g, S0, ld);
+  RgMat<NTS> A, B, C, D;
+  // composite sources -> LDS
+  for (int i = wg_tid(); i < N; i += kThreads) {
+    c.Jp[i] = cp.J0p[i];
+    c.Jm[i] = cp.J0m[i];
+  }
+  __syncthreads();
+  // B1 = r-+ R+- (:81) and B2 = R+- r-+ (:104) from one staging; v1 = j0- + r-+ J0+ ; w = J0+ + R+- j0-
+  rg_load<NT, false>(S0, sr, ld, nullptr, N, ld);
+  rg_load<NT, false>(S1, gRpm, cl, nullptr, N, ld);
+  __syncthreads();
+  rg_matvec2(S0, S1, ld, N, c.Jp, 1.0, c.jm, 1.0, c.jm, 1.0, c.Jp, 1.0, c.v1, c.j1p);
+  rg_mm<NTS, false>(A, 0, 1, g, so, ld, KS);       // A = B1
+  rg_mm<NTS, false>(D, 1, 0, g, so, ld, KS);       // D = B2 (kept until the second inverse)
+  wg_sumsq_put(c, rg_sumsq(A));
+  __syncthreads();
+  const real b1 = wg_sumsq_get(c);
+  __syncthreads();
+  wg_sumsq_put(c, rg_sumsq(D));
+  __syncthreads();
+  const real b2 = wg_sumsq_get(c);
+  const int p1 = rg_terms(c, b1), p2 = rg_terms(c, b2);
+  if (p1 > 512 || p2 > 512) return false;
+  // T01 = T-- (I - B1)^-1   (:83-87)
+  rg_load<NT, false>(S0, gTmm, cl, nullptr, N, ld);
+  __syncthreads();
+  rg_fetch(B, S0, g, N);                           // B = T--
+  __syncthreads();
+  rg_series<NTS>(C, A, B, p1, g, S0, S1, so, ld, KS, N);   // C = T01
+  // J0- += T01 v1 (:90) ; T-- = T01 t-- (:96)
+  __syncthreads();
+  rg_stage(S0, g, C);
+  rg_load<NT, true>(S1, st, ld, c.sg, N, ld);
+  __syncthreads();
+  rg_matvec2(S0, S0, ld, N, c.v1, 1.0, nullptr, 1.0, c.Jm, 1.0, nullptr, 1.0, c.Jm, nullptr);
+  rg_mm<NTS, false>(A, 0, 1, g, so, ld, KS);       // A = new T--
+  __syncthreads();
+  rg_stage(S1, g, A);
+  __syncthreads();
+  rg_unload<NT>(cp.T_mm, cl, S1, N, ld);
+  // X = T01 r-+ ; R-+ += X T++   (:93)
+  __syncthreads();
+  rg_load<NT, false>(S1, sr, ld, nullptr, N, ld);
+  __syncthreads();
+  rg_mm<NTS, false>(A, 0, 1, g, so, ld, KS);       // A = T01 r-+
+  __syncthreads();
+  rg_stage(S0, g, A);
+  rg_load<NT, false>(S1, gTpp, cl, nullptr, N, ld);
+  rg_fetch_global<NTS, false>(B, gRmp, cl, nullptr, g, N);
+  __syncthreads();
+  rg_mm<NTS, true>(B, 0, 1, g, so, ld, KS);        // B = new R-+
+  __syncthreads();
+  rg_stage(S0, g, B);
+  __syncthreads();
+  rg_unload<NT>(cp.R_mp, cl, S0, N, ld);
+  // T21 = t++ (I - B2)^-1   (:105-107)
+  __syncthreads();
+  rg_load<NT, false>(S0, st, ld, nullptr, N, ld);
+  __syncthreads();
+  rg_fetch(B, S0, g, N);                           // B = t++
+  __syncthreads();
+  rg_series<NTS>(C, D, B, p2, g, S0, S1, so, ld, KS, N);   // C = T21
+  // J0+ = j0+ + T21 w (:110) ; Y = T21 R+- ; T++ = T21 T++ (:113)
+  __syncthreads();
+  rg_stage(S0, g, C);
+  rg_load<NT, false>(S1, gRpm, cl, nullptr, N, ld);
+  __syncthreads();
+  rg_matvec2(S0, S0, ld, N, c.j1p, 1.0, nullptr, 1.0, c.jp, 1.0, nullptr, 1.0, c.Jp, nullptr);
+  rg_mm<NTS, false>(A, 0, 1, g, so, ld, KS);       // A = T21 R+-
+  __syncthreads();
+  rg_load<NT, false>(S1, gTpp, cl, nullptr, N, ld);
+  __syncthreads();
+  rg_mm<NTS, false>(D, 0, 1, g, so, ld, KS);       // D = new T++
+  // R+- = r+- + Y t--   (:116)
+  __syncthreads();
+  rg_stage(S0, g, A);
+  rg_load<NT, true>(S1, st, ld, c.sg, N, ld);
+  rg_fetch_global<NTS, true>(B, sr, ld, c.sg, g, N);       // B = r+- = S r-+ S
+  __syncthreads();
+  rg_mm<NTS, true>(B, 0, 1, g, so, ld, KS);        // B = new R+-
+  __syncthreads();
+  rg_stage(S0, g, D);
+  rg_stage(S1, g, B);
+  __syncthreads();
+  rg_unload<NT>(cp.T_pp, cl, S0, N, ld);
+  rg_unload<NT>(cp.R_pm, cl, S1, N, ld);
+  for (int i = wg_tid(); i < N; i += kThreads) {
+    cp.J0p[i] = c.Jp[i];
+    cp.J0m[i] = c.Jm[i];
+  }
+  __syncthreads();
+  return true;
+}
+
+template <int NT>
+__device__ __attribute__((noinline)) bool rg_interaction(Ctx &c, const CompPtrs &cp) {
+  constexpr int T = NT * NT, TS = (T + 7) / 8, full = (T % 8 == 0) ? 8 : T % 8;
+  const int wave = __builtin_amdgcn_readfirstlane(wg_wave());
+  if (wave < full) return rg_interaction_body<NT, TS>(c, cp);
+  return rg_interaction_body<NT, TS - 1>(c, cp);
 }
 
 }  // namespace MOM_NS
