@@ -67,5 +67,64 @@ def run(repeats=5, cpu_lines=4000):
     return out
 
 
+def profile_workload(n_lines=300, dnu=0.015, wing=40.0, Nz=40):
+    """The reference's operating point of compute_absorption_profile! (atmo_prof.jl:427-449): the O2 A-band window
+    12 903 ... 13 245 cm^-1 at 0.015 cm^-1 (DefaultParameters.yaml: 22 801 grid points), wing cut-off 40 cm^-1
+    (parameters_from_yaml.jl), 40 layers (log-spaced pressures 0.1 ... 1000 hPa), a seeded O2-A-like list of 300 lines
+    (SURVEY section 8d).  Evaluations = sum over layers and lines of the window width; the |x| + y < 8 core is counted per
+    layer from the host-side prefactors."""
+    import rtamd
+    ab = rtamd.absorption
+    tab = ab.synthetic_o2a_lines(n_lines)
+    grid = np.arange(12903.0, 13245.0 + 0.5 * dnu, dnu)
+    p_full = np.exp(np.linspace(np.log(0.1), np.log(1000.0), Nz))
+    T = 216.0 + (288.0 - 216.0) * (p_full / 1000.0) ** 0.19
+    vcd = np.gradient(p_full) * 2.1e22
+    evals = core = 0
+    for iz in range(Nz):
+        pf = ab.line_prefactors(tab, grid, p_full[iz], T[iz], vmr=0.21, wing_cutoff=wing)
+        evals += int(np.maximum(pf.ind_stop - pf.ind_start + 1, 0).sum())
+        half = np.maximum(8.0 - pf.y, 0.0) * pf.γ_d / 0.8325546111577
+        lo = np.searchsorted(grid, pf.ν - half, side="right")
+        hi = np.searchsorted(grid, pf.ν + half, side="left")
+        core += int(np.sum(np.clip(np.minimum(hi, pf.ind_stop) - np.maximum(lo, pf.ind_start - 1), 0, None)))
+    return tab, grid, p_full, T, vcd, evals, core
+
+
+def run_profile(repeats=5):
+    """extra.voigt.operating_point: the f1 product path -- resident line table, device-side prefactors, all 40 layers in two
+    launches (mom_voigt_tau_abs_profile) accumulating into the resident tau_abs -- next to the same work issued layer by
+    layer (mom_voigt_tau_abs_layer: two host round trips per layer, 90 workgroups per launch)."""
+    import rtamd
+    ab = rtamd.absorption
+    tab, grid, p_full, T, vcd, evals, core = profile_workload()
+    flops = core * FLOP_CORE + (evals - core) * FLOP_WING
+    m = rtamd.scenes.make_scene(1, 3, len(p_full), grid.size)
+    best, wall, wall_layers = 1e30, 1e30, 1e30
+    with rtamd.corert.make_handle(m) as h:
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            ms = ab.compute_absorption_profile(h, tab, grid, p_full, T, vcd, 0.21, wing_cutoff=40.0, model_vmr=0.21, device_prefactors=True)
+            wall = min(wall, time.perf_counter() - t0)
+            best = min(best, ms)
+        tau = h.absorption_get()
+        for _ in range(2):
+            t0 = time.perf_counter()
+            ab.compute_absorption_profile(h, tab, grid, p_full, T, vcd, 0.21, wing_cutoff=40.0, model_vmr=0.21, device_prefactors=True,
+                                          layer_by_layer=True)
+            wall_layers = min(wall_layers, time.perf_counter() - t0)
+        assert np.array_equal(tau, h.absorption_get()) and np.all(np.isfinite(tau)) and tau.max() > 0
+    ach = flops / (best * 1e-3) / 1e12
+    return {"workload": f"O2 A-band 12903-13245 cm^-1 at 0.015 cm^-1 ({grid.size} points), wing cut-off 40 cm^-1, {len(p_full)} layers, "
+                        f"{len(tab.Sᵢ)} lines: compute_absorption_profile! through mom_voigt_tau_abs_profile (device-side prefactors)",
+            "value": evals / (best * 1e-3), "unit": "evaluations/s", "kernels": "k_line_prefactors_profile + k_voigt_profile",
+            "kernels_ms": best, "evaluations": evals, "weideman32_fraction": core / evals,
+            "call_wall_ms": wall * 1e3, "layer_by_layer_wall_ms": wall_layers * 1e3,
+            "roofline": {"bound": "fp64-valu", "achieved": ach, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_FP64_VALU_TFLOPS, "flop_model": {"weideman32": FLOP_CORE, "humlicek2": FLOP_WING}}}
+
+
 if __name__ == "__main__":
-    print(json.dumps(run()))
+    out = run()
+    out["operating_point"] = run_profile()
+    print(json.dumps(out))

@@ -307,6 +307,12 @@ int mom_absorption_set_lines(mom_t *h, int nLines, const double *nu0, const doub
                              const double *tips_T, const double *tips_Q, const double *tips_z);
 int mom_voigt_tau_abs_layer(mom_t *h, int iz_1based, double pressure, double temperature, double vmr, double wing_cutoff,
                             double factor);
+/* compute_absorption_profile! (atmo_prof.jl:427-449) for layers 1..Nz of the profile in TWO launches (prefactors of every
+ * (layer, line) pair, line shapes of every (layer, grid point) pair) instead of the reference's host loop over layers with
+ * one launch per line: tau_abs[:, z] += sigma(nu; pressure[z], temperature[z]) * factor[z], factor[z] = vcd_dry[z] * vmr[z].
+ * Same arithmetic per layer as mom_voigt_tau_abs_layer (bitwise).  gpu_ms (may be NULL): HIP-event time of the two kernels. */
+int mom_voigt_tau_abs_profile(mom_t *h, int Nz, const double *pressure, const double *temperature, double vmr, double wing_cutoff,
+                              const double *factor, double *gpu_ms);
 int mom_absorption_get_prefactors(mom_t *h, int n, double *nu, double *gamma_d, double *y, double *S, int *ind_start_1based,
                                   int *ind_stop_1based);
 int mom_voigt_tau_abs(mom_t *h, int iz_1based, int nLines, const double *nu, const double *gamma_d, const double *y,

@@ -82,6 +82,7 @@ SIGNATURES = {
     "mom_absorption_begin": (C.c_int, [c_h, C.c_int, c_dp]),
     "mom_absorption_set_lines": (C.c_int, [c_h, C.c_int] + [c_dp] * 8 + [c_ip, C.c_int, C.c_int, c_ip, c_dp, c_dp, c_dp]),
     "mom_voigt_tau_abs_layer": (C.c_int, [c_h, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "mom_voigt_tau_abs_profile": (C.c_int, [c_h, C.c_int, c_dp, c_dp, C.c_double, C.c_double, c_dp, c_dp]),
     "mom_absorption_get_prefactors": (C.c_int, [c_h, C.c_int, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip]),
     "mom_voigt_tau_abs": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_ip, c_ip, C.c_double]),
     "mom_absorption_set": (C.c_int, [c_h, C.c_int, c_dp]),
@@ -398,6 +399,14 @@ class Handle:
     def voigt_tau_abs_layer(self, iz_1based, p, T, vmr, wing_cutoff, factor):
         self.check(self.lib.mom_voigt_tau_abs_layer(self._h, int(iz_1based), float(p), float(T), float(vmr), float(wing_cutoff),
                                                     float(factor)))
+
+    def voigt_tau_abs_profile(self, p, T, vmr, wing_cutoff, factor) -> float:
+        """All layers 1..len(p) in two launches (mom_voigt_tau_abs_profile); returns the GPU time of the two kernels in ms."""
+        p, T, f = f64(p), f64(T), f64(factor)
+        assert p.size == T.size == f.size
+        ms = np.zeros(1)
+        self.check(self.lib.mom_voigt_tau_abs_profile(self._h, int(p.size), dp(p), dp(T), float(vmr), float(wing_cutoff), dp(f), dp(ms)))
+        return float(ms[0])
 
     def absorption_get_prefactors(self, n=None):
         n = self._nLines if n is None else int(n)

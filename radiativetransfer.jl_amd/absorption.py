@@ -287,13 +287,16 @@ def resident_line_table(h, table: HitranTable, grid, wing_cutoff: float = 40.0):
 
 
 def compute_absorption_profile(h, table: HitranTable, grid, p_full, T, vcd_dry, vmr, wing_cutoff: float = 40.0,
-                               model_vmr: float = 0.0, qratio=None, begin: bool = True, device_prefactors: bool = False):
+                               model_vmr: float = 0.0, qratio=None, begin: bool = True, device_prefactors: bool = False,
+                               layer_by_layer: bool = False):
     """compute_absorption_profile!(τ_abs, absorption_model, grid, vmr, profile) (atmo_prof.jl:427-449) on the handle's
     resident τ_abs table: per layer the host builds the line prefactors (O(nLines)), the GPU adds
     σ(ν; p[iz], T[iz]) * vcd_dry[iz] * vmr[iz] into τ_abs[:, iz] (mom_voigt_tau_abs).  `vmr` scalar or per layer (the
     profile's mixing ratio); `model_vmr` is HitranModel.vmr, the self-broadening fraction of the line shape.
     begin=False adds another absorber to the same table (the reference's `+=` over molecules).  device_prefactors=True
-    forms the per-line prefactors on the GPU from one resident line table (mom_absorption_set_lines / _layer)."""
+    forms the per-line prefactors on the GPU from one resident line table (mom_absorption_set_lines) and runs ALL layers in
+    two launches (mom_voigt_tau_abs_profile; returns their GPU time in ms); layer_by_layer=True keeps one
+    mom_voigt_tau_abs_layer call per layer (same arithmetic, bitwise)."""
     p_full, T, vcd_dry = (np.asarray(x, dtype=np.float64) for x in (p_full, T, vcd_dry))
     Nz = p_full.size
     assert T.size == Nz and vcd_dry.size == Nz
@@ -305,9 +308,11 @@ def compute_absorption_profile(h, table: HitranTable, grid, p_full, T, vcd_dry, 
         if qratio is not None:
             raise ValueError("device_prefactors uses the reference's qoft! (TIPS-2017); qratio overrides are host-route only")
         resident_line_table(h, table, grid, wing_cutoff)
-        for iz in range(Nz):
-            h.voigt_tau_abs_layer(iz + 1, p_full[iz], T[iz], model_vmr, wing_cutoff, vcd_dry[iz] * vmr_arr[iz])
-        return
+        if layer_by_layer:
+            for iz in range(Nz):
+                h.voigt_tau_abs_layer(iz + 1, p_full[iz], T[iz], model_vmr, wing_cutoff, vcd_dry[iz] * vmr_arr[iz])
+            return None
+        return h.voigt_tau_abs_profile(p_full, T, model_vmr, wing_cutoff, vcd_dry * vmr_arr)   # all layers in two launches
     for iz in range(Nz):
         pf = line_prefactors(table, grid, p_full[iz], T[iz], vmr=model_vmr, wing_cutoff=wing_cutoff, qratio=qratio)
         h.voigt_tau_abs(iz + 1, pf.ν, pf.γ_d, pf.y, pf.S, pf.ind_start, pf.ind_stop, vcd_dry[iz] * vmr_arr[iz])

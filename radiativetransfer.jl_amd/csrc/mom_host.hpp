@@ -35,6 +35,10 @@ struct MomLineTable {
   const double *tT, *tQ, *tZ;                                         // [nIso, nTmax] knots, values, second derivatives
 };
 // voigt.hip: per-line prefactors of one (p, T) on the device; *unsorted is set when the windows are not monotone
+// every layer of a profile: prefactors of all (layer, line) pairs, then the line shapes of all (layer, grid point) pairs
+hipError_t mom_voigt_profile_launch(hipStream_t st, const MomLineTable &tb, int Nz, size_t cap, int nGrid, const double *grid,
+                                    const double *prm, double vmr, double wing, double *pf, int *win, int *unsorted, double *tau_abs,
+                                    const double *factor);
 hipError_t mom_line_prefactors_launch(hipStream_t st, const MomLineTable &tb, int nGrid, const double *grid, double p, double T,
                                       double vmr, double wing, double cgd, double *nu, double *gd, double *y, double *S, int *i0,
                                       int *i1, int *unsorted);

@@ -474,7 +474,10 @@ struct mom_handle {
          *d_aer = nullptr;
   int *d_aer_mode = nullptr;
   int abs_Nz = 0;
-  size_t lines_cap = 0;
+  size_t lines_cap = 0;   // line capacity of ONE layer's block of d_lines
+  int lines_nz = 1;       // layers held in d_lines: arrays [nu | gamma_d | y | S][lines_nz][lines_cap], then the two window arrays as ints
+  double *d_prof = nullptr;  // per-layer scalars of mom_voigt_tau_abs_profile
+  size_t prof_cap = 0;
   double *d_vec[4] = {};  // S-length temporaries (tau_sum, dtau, varpi, expk)
   double *d_Zop[2] = {};
   size_t Zop_cap = 0;
@@ -717,7 +720,7 @@ extern "C" int mom_destroy(mom_t *h) {
   fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
   fr(h->d_mu0); fr(h->d_wt0); fr(h->d_sg0); fr(h->d_Zpp0); fr(h->d_Zmp0); fr(h->d_hdrJ0); fr(h->d_scratch0);
   for (int k = 0; k < 6; ++k) fr(h->comp0[k]);
-  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_rrs_send); fr(h->d_Rsurf); fr(h->d_Rsurf0); fr(h->d_albedo_spec); fr(h->d_hdrJm); fr(h->d_smtab); if (h->d_ndif) (void)hipFree(h->d_ndif); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_tau_rayl);
+  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_rrs_send); fr(h->d_Rsurf); fr(h->d_Rsurf0); fr(h->d_albedo_spec); fr(h->d_hdrJm); fr(h->d_smtab); if (h->d_ndif) (void)hipFree(h->d_ndif); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_prof); fr(h->d_tau_rayl);
   fr(h->d_layer_max); fr(h->d_aer); if (h->d_aer_mode) (void)hipFree(h->d_aer_mode); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
   for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (auto e : h->ev_full) (void)hipEventDestroy(e);
@@ -2102,7 +2105,8 @@ extern "C" int mom_voigt_tau_abs(mom_t *h, int iz_1based, int nLines, const doub
     if (ind_start_1based[j] < ind_start_1based[j - 1] || ind_stop_1based[j] < ind_stop_1based[j - 1]) { sorted = 0; break; }
   HIPCHK(h, hipSetDevice(h->device));
   const size_t lb = (size_t)nLines;
-  if (lb > h->lines_cap) {  // 4 double + 2 int arrays per line, grown geometrically: no allocation in steady state
+  if (lb > h->lines_cap || h->lines_nz != 1) {  // 4 double + 2 int arrays per line, grown geometrically: no allocation in steady state
+    h->lines_nz = 1;
     if (h->d_lines) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_lines); h->d_lines = nullptr; h->lines_cap = 0; }
     const size_t cap = std::max<size_t>(lb, 1024) * 2;
     HIPCHK(h, dmalloc(&h->d_lines, 5 * cap));
@@ -2187,7 +2191,8 @@ extern "C" int mom_voigt_tau_abs_layer(mom_t *h, int iz_1based, double pressure,
   if (nLines == 0) return MOM_OK;
   HIPCHK(h, hipSetDevice(h->device));
   const size_t lb = (size_t)nLines;
-  if (lb > h->lines_cap) {
+  if (lb > h->lines_cap || h->lines_nz != 1) {
+    h->lines_nz = 1;
     if (h->d_lines) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_lines); h->d_lines = nullptr; h->lines_cap = 0; }
     const size_t cap = std::max<size_t>(lb, 1024) * 2;
     HIPCHK(h, dmalloc(&h->d_lines, 5 * cap));
@@ -2211,19 +2216,86 @@ extern "C" int mom_voigt_tau_abs_layer(mom_t *h, int iz_1based, double pressure,
   return MOM_OK;
 }
 
+// compute_absorption_profile! for ALL layers of a profile (atmo_prof.jl:427-449) in two launches: the reference walks the
+// layers on the host and, per layer, launches one line-shape kernel per line; at its operating point (O2 A-band at
+// 0.015 cm^-1, wing cut-off 40 cm^-1, 40 layers) a per-layer launch covers 90 workgroups -- a third of the GPU -- and the
+// host round trips between the layers cost more than the arithmetic.  Here blockIdx.y = layer.  gpu_ms (optional): HIP-event
+// time of the two kernels.
+extern "C" int mom_voigt_tau_abs_profile(mom_t *h, int Nz, const double *pressure, const double *temperature, double vmr,
+                                         double wing_cutoff, const double *factor, double *gpu_ms) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_voigt_tau_abs_profile");
+  if (!h->d_tau_abs || !h->d_grid) return fail(h, MOM_ESTATE, "mom_voigt_tau_abs_profile: call mom_absorption_begin with the spectral grid first");
+  if (!h->d_lt) return fail(h, MOM_ESTATE, "mom_voigt_tau_abs_profile: call mom_absorption_set_lines first");
+  if (Nz < 1 || Nz > h->abs_Nz || !pressure || !temperature || !factor) return fail(h, MOM_EINVAL, "mom_voigt_tau_abs_profile: bad argument");
+  for (int z = 0; z < Nz; ++z) {
+    if (!(temperature[z] > 0.0)) return fail(h, MOM_EINVAL, "mom_voigt_tau_abs_profile: bad argument");
+    if (h->lt.nIso > 0 && !(h->lt_Tmin < temperature[z] && temperature[z] < h->lt_Tmax)) {
+      char buf[160];
+      snprintf(buf, sizeof buf, "TIPS2017: T (%g) must be between %g K and %g K.", temperature[z], h->lt_Tmin, h->lt_Tmax);
+      return fail(h, MOM_EINVAL, buf);
+    }
+  }
+  if (gpu_ms) *gpu_ms = 0.0;
+  const int nLines = h->lt.nLines;
+  if (nLines == 0) return MOM_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t per = std::max<size_t>((size_t)nLines, 1024) * 2;       // line capacity of one layer's block
+  const size_t need = per * (size_t)Nz;
+  if (need > h->lines_cap * (size_t)std::max(h->lines_nz, 1) || h->lines_nz != Nz) {
+    if (h->d_lines) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_lines); h->d_lines = nullptr; h->lines_cap = 0; }
+    HIPCHK(h, dmalloc(&h->d_lines, 5 * need));
+    h->lines_cap = per;
+    h->lines_nz = Nz;
+  }
+  const size_t cap = h->lines_cap;
+  // per-layer scalars [p | T | cgd | factor][Nz] and the Nz sortedness flags
+  const size_t prm_doubles = 4 * (size_t)Nz + ((size_t)Nz + 1) / 2;
+  if (prm_doubles > h->prof_cap) {
+    if (h->d_prof) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_prof); h->d_prof = nullptr; h->prof_cap = 0; }
+    HIPCHK(h, dmalloc(&h->d_prof, prm_doubles));
+    h->prof_cap = prm_doubles;
+  }
+  std::vector<double> prm(4 * (size_t)Nz);
+  for (int z = 0; z < Nz; ++z) {
+    prm[z] = pressure[z];
+    prm[Nz + z] = temperature[z];
+    // γ_d = (cSqrt2Ln2 / cc_) sqrt(cBolts_ / cMassMol) sqrt(T) ν₀ / sqrt(mol_weight)   (:87-88): the scalar part
+    prm[2 * (size_t)Nz + z] = (1.1774100225 / 2.99792458e8) * std::sqrt(1.3806503e-23 / 1.66053873e-27) * std::sqrt(temperature[z]);
+    prm[3 * (size_t)Nz + z] = factor[z];
+  }
+  HIPCHK(h, hipMemcpyAsync(h->d_prof, prm.data(), prm.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  int *flags = reinterpret_cast<int *>(h->d_prof + 4 * (size_t)Nz);
+  HIPCHK(h, hipMemsetAsync(flags, 0, sizeof(int) * (size_t)Nz, h->stream));
+  double *pf = h->d_lines;
+  int *win = reinterpret_cast<int *>(pf + 4 * cap * (size_t)Nz);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (gpu_ms) { HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1)); HIPCHK(h, hipEventRecord(e0, h->stream)); }
+  HIPCHK(h, mom_voigt_profile_launch(h->stream, h->lt, Nz, cap, h->S, h->d_grid, h->d_prof, vmr, wing_cutoff, pf, win, flags,
+                                     h->d_tau_abs, h->d_prof + 3 * (size_t)Nz));
+  if (gpu_ms) HIPCHK(h, hipEventRecord(e1, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // prm is a host temporary
+  if (gpu_ms) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *gpu_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  return MOM_OK;
+}
+
 // the prefactors of the last mom_voigt_tau_abs / mom_voigt_tau_abs_layer call (test access); n = its number of lines
 extern "C" int mom_absorption_get_prefactors(mom_t *h, int n, double *nu, double *gamma_d, double *y, double *S, int *ind_start_1based,
                                              int *ind_stop_1based) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   if (!h->d_lines || n < 0 || (size_t)n > h->lines_cap) return fail(h, MOM_ESTATE, "mom_absorption_get_prefactors: no prefactors resident");
   HIPCHK(h, hipSetDevice(h->device));
-  const size_t cap = h->lines_cap;
+  const size_t cap = h->lines_cap, nz = (size_t)std::max(h->lines_nz, 1), last = (nz - 1) * cap;  // the LAST layer of a profile call
   double *dst[4] = {nu, gamma_d, y, S};
   for (int k = 0; k < 4; ++k)
-    if (dst[k]) HIPCHK(h, hipMemcpy(dst[k], h->d_lines + k * cap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-  const int *dw = reinterpret_cast<const int *>(h->d_lines + 4 * cap);
-  if (ind_start_1based) HIPCHK(h, hipMemcpy(ind_start_1based, dw, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-  if (ind_stop_1based) HIPCHK(h, hipMemcpy(ind_stop_1based, dw + cap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    if (dst[k]) HIPCHK(h, hipMemcpy(dst[k], h->d_lines + k * nz * cap + last, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  const int *dw = reinterpret_cast<const int *>(h->d_lines + 4 * nz * cap);
+  if (ind_start_1based) HIPCHK(h, hipMemcpy(ind_start_1based, dw + last, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  if (ind_stop_1based) HIPCHK(h, hipMemcpy(ind_stop_1based, dw + nz * cap + last, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
   return MOM_OK;
 }
 

@@ -68,12 +68,12 @@ __device__ __forceinline__ double w_hw32sd_re(double x, double y) {
 #endif
 constexpr int kBlock = MOM_VOIGT_BLOCK;  // grid points per workgroup
 
-__global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__restrict__ nu,
-                                                  const double *__restrict__ gamma_d, const double *__restrict__ y,
-                                                  const double *__restrict__ S, const int *__restrict__ i0,
-                                                  const int *__restrict__ i1, int nGrid,
-                                                  const double *__restrict__ grid, double *__restrict__ sigma,
-                                                  double factor, int accumulate, int sorted) {
+__device__ __forceinline__ void voigt_block(int nLines, const double *__restrict__ nu,
+                                            const double *__restrict__ gamma_d, const double *__restrict__ y,
+                                            const double *__restrict__ S, const int *__restrict__ i0,
+                                            const int *__restrict__ i1, int nGrid,
+                                            const double *__restrict__ grid, double *__restrict__ sigma,
+                                            double factor, int accumulate, int sorted) {
   // per-line constants of the candidates, staged once per workgroup: centre, S c/gamma_d, c'/gamma_d, y and the
   // 0-based window -- the two divisions by gamma_d are per LINE here, not per evaluation (same expressions, same values)
   __shared__ double c_nu[kBlock], c_a[kBlock], c_b[kBlock], c_y[kBlock];
@@ -160,6 +160,28 @@ __global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__re
   }
 }
 
+__global__ void __launch_bounds__(kBlock) k_voigt(int nLines, const double *__restrict__ nu,
+                                                  const double *__restrict__ gamma_d, const double *__restrict__ y,
+                                                  const double *__restrict__ S, const int *__restrict__ i0,
+                                                  const int *__restrict__ i1, int nGrid,
+                                                  const double *__restrict__ grid, double *__restrict__ sigma,
+                                                  double factor, int accumulate, int sorted) {
+  voigt_block(nLines, nu, gamma_d, y, S, i0, i1, nGrid, grid, sigma, factor, accumulate, sorted);
+}
+
+// All layers of a profile in ONE launch (blockIdx.y = layer): the per-line prefactors of layer z sit at [k][z][cap]
+// (k = nu, gamma_d, y, S; the two window arrays likewise as ints), tau_abs[:, z] += sigma_z * factor[z]; whether the
+// bisection applies is read from the layer's flag on the device (no host round trip between the two kernels).
+__global__ void __launch_bounds__(kBlock) k_voigt_profile(int nLines, int Nz, size_t cap, const double *__restrict__ pf,
+                                                          const int *__restrict__ win, int nGrid, const double *__restrict__ grid,
+                                                          double *__restrict__ tau_abs, const double *__restrict__ factor,
+                                                          const int *__restrict__ unsorted) {
+  const int z = blockIdx.y;
+  const size_t lz = (size_t)z * cap, ks = (size_t)Nz * cap;
+  voigt_block(nLines, pf + lz, pf + ks + lz, pf + 2 * ks + lz, pf + 3 * ks + lz, win + lz, win + ks + lz, nGrid, grid,
+              tau_abs + (size_t)nGrid * z, factor[z], 1, unsorted[z] ? 0 : 1);
+}
+
 thread_local double v_last_ms = 0.0;
 
 }  // namespace
@@ -209,10 +231,10 @@ __device__ __forceinline__ double interp_index(const double *grid, int n, double
   const double slope = 1.0 / (grid[lo + 1] - grid[lo]);
   return slope * (x - grid[lo]) + (double)(lo + 1);
 }
-__global__ void k_line_prefactors(MomLineTable tb, int nGrid, const double *grid, double p, double T, double vmr, double wing,
-                                  double cgd, double *nu, double *gd, double *yy, double *SS, int *i0, int *i1, int *unsorted) {
+__device__ __forceinline__ void line_prefactors_one(int j, const MomLineTable &tb, int nGrid, const double *grid, double p, double T,
+                                                    double vmr, double wing, double cgd, double *nu, double *gd, double *yy, double *SS,
+                                                    int *i0, int *i1, int *unsorted) {
 #pragma clang fp contract(off)
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= tb.nLines) return;
   const double p_ref = 1013.25, t_ref = 296.0, c2 = 1.4387769, cLn2 = 0.6931471805599;
   const double nu0 = tb.nu0[j], E = tb.E[j];
@@ -240,6 +262,30 @@ __global__ void k_line_prefactors(MomLineTable tb, int nGrid, const double *grid
     const int ap = (int)rint(interp_index(grid, nGrid, vp - wing, 1.0)), bp = (int)rint(interp_index(grid, nGrid, vp + wing, (double)nGrid));
     if (a < ap || b < bp) atomicOr(unsorted, 1);
   }
+}
+__global__ void k_line_prefactors(MomLineTable tb, int nGrid, const double *grid, double p, double T, double vmr, double wing,
+                                  double cgd, double *nu, double *gd, double *yy, double *SS, int *i0, int *i1, int *unsorted) {
+  line_prefactors_one(blockIdx.x * blockDim.x + threadIdx.x, tb, nGrid, grid, p, T, vmr, wing, cgd, nu, gd, yy, SS, i0, i1, unsorted);
+}
+// blockIdx.y = layer; prm = [p | T | cgd][Nz]; outputs at [k][z][cap] (see k_voigt_profile)
+__global__ void k_line_prefactors_profile(MomLineTable tb, int Nz, size_t cap, int nGrid, const double *grid, const double *prm,
+                                          double vmr, double wing, double *pf, int *win, int *unsorted) {
+  const int z = blockIdx.y;
+  const size_t lz = (size_t)z * cap, ks = (size_t)Nz * cap;
+  line_prefactors_one(blockIdx.x * blockDim.x + threadIdx.x, tb, nGrid, grid, prm[z], prm[Nz + z], vmr, wing, prm[2 * Nz + z], pf + lz,
+                      pf + ks + lz, pf + 2 * ks + lz, pf + 3 * ks + lz, win + lz, win + ks + lz, unsorted + z);
+}
+hipError_t mom_voigt_profile_launch(hipStream_t st, const MomLineTable &tb, int Nz, size_t cap, int nGrid, const double *grid,
+                                    const double *prm, double vmr, double wing, double *pf, int *win, int *unsorted, double *tau_abs,
+                                    const double *factor) {
+  if (tb.nLines <= 0 || Nz <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_line_prefactors_profile, dim3((tb.nLines + 255) / 256, Nz), dim3(256), 0, st, tb, Nz, cap, nGrid, grid, prm, vmr,
+                     wing, pf, win, unsorted);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_voigt_profile, dim3((nGrid + kBlock - 1) / kBlock, Nz), dim3(kBlock), 0, st, tb.nLines, Nz, cap, pf, win, nGrid,
+                     grid, tau_abs, factor, unsorted);
+  return hipGetLastError();
 }
 hipError_t mom_line_prefactors_launch(hipStream_t st, const MomLineTable &tb, int nGrid, const double *grid, double p, double T,
                                       double vmr, double wing, double cgd, double *nu, double *gd, double *y, double *S, int *i0,

@@ -184,6 +184,10 @@ def test_device_side_line_prefactors(rtamd, cref, lines):
         if lines == "edge_shift":
             assert np.any((i0 == 1) & (i1 == S) & (nu - wing > grid[-1])) and np.any((i0 == 1) & (i1 == S) & (nu + wing < grid[0]))
         a, b = h_dev.absorption_get(), h_host.absorption_get()
+        # the profile entry (all layers in two launches) against the layer-by-layer entry: the same arithmetic, bit for bit
+        ab.compute_absorption_profile(h_host, tab, grid, p_full, T, vcd, 0.3, wing_cutoff=wing, model_vmr=model_vmr,
+                                      device_prefactors=True, layer_by_layer=True)
+        assert np.array_equal(a, h_host.absorption_get())
     assert b.max() > 0
     np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-300)
     for iz in range(4):     # tau_abs[:, iz] = sigma(p, T) * (vcd * vmr) with sigma from the oracle alone (atmo_prof.jl:446)
