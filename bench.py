@@ -256,7 +256,11 @@ def elastic_leg(a, workload, S_loc, steps, warmup, world, rank, dev, dist, with_
                     "all_layer_kernels_achieved": whole, "all_layer_kernels_frac": whole / PEAK_FP64_MFMA_TFLOPS,
                     # `achieved` counts the reference's op list (full 2N^3 inverses); the hardware-side figure is the
                     # MFMA-busy share of SIMD cycles from the PMC pass (profiles/), not recomputed here
-                    "hw_mfma_busy_frac": prof.get("mfma_busy_frac")}
+                    "hw_mfma_busy_frac": prof.get("mfma_busy_frac"),
+                    # `traffic` and `hw_mfma_busy_frac` are NOT measured in this run: they are the PMC figures of the
+                    # committed collection named here (rocprofv3 --pmc passes cannot run inside the timed bench)
+                    "pmc_source": ("profiles/traffic.json: " + prof.get("source", prof.get("round", "?"))) if prof else None,
+                    "traffic_step_all_launches": prof.get("hbm_bytes_per_step_all_launches")}
         names = {"C2": "O2-A band IQU scene", "C3": "OCO-2-style 3-band IQU scene (BASELINE configs[2])"}
         out = {
             "metric": f"spectral points/sec (whole node), {names.get(workload, workload + ' scene')}",
@@ -387,6 +391,7 @@ def c5_leg(a, S, steps, warmup, dev, with_cpu=True, world=1, rank=0, dist=None):
                           "collective": collective},
                "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                             "traffic": prof.get("hbm_bytes_per_launch"), "kernel": "momr::k_dbl_pair<1>",
+                            "pmc_source": ("profiles/traffic.json: " + prof.get("source", prof.get("round", "?"))) if prof else None,
                             "avg_launch_ms": avg, "launches_per_step": nl, "pairs_per_launch": pairs,
                             "algorithmic_bytes_per_pair": bytes_pair, "algorithmic_bytes_per_avg_launch": pairs * bytes_pair},
                "stages_ms": {"dbl_pair_ms": tk["dbl_pair"][0], "int_pair_ms": tk["int_pair"][0],
@@ -419,9 +424,11 @@ def c5_cpu_baseline(S, n_lines=2):
     per_line = max(t_n - t_el, 1e-9) / n_lines
     t_full = t_el + per_line * RS_full.n_Raman
     return {"value": S / t_full, "unit": "spectral points/s", "cores": 1, "kind": "port",
-            "sample": f"numpy restatement, one core: the same C5 scene with the {n_lines} strongest of {RS_full.n_Raman} Raman "
-                      f"lines ({t_n:.1f} s; elastic-only run {t_el:.1f} s); extrapolated linearly in the number of lines to "
-                      f"{t_full:.0f} s per run"}
+            "extrapolated": True,
+            "sample": f"EXTRAPOLATED, not timed at full size: numpy restatement (oracle/rrsref.py) on ONE core, the same C5 scene "
+                      f"with the {n_lines} strongest of {RS_full.n_Raman} Raman lines ({t_n:.1f} s; elastic-only run {t_el:.1f} s); "
+                      f"the pair work is linear in the number of lines: {t_full:.0f} s per run at {RS_full.n_Raman} lines "
+                      f"(x {RS_full.n_Raman / n_lines:.0f} on the inelastic part)"}
 
 
 def f32_leg(dev, S=20_000, n_streams=8, nd=5, steps=3):

@@ -406,7 +406,9 @@ int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
  *                         run the lane-per-spectral-point sweep kernel: the whole of mom_rt_run in one launch, all
  *                         operators in registers (csrc/mom_small.hip); edges 4 < N <= 32 (scattering in every layer after the
  *                         first, at most 256 view x Stokes outputs) the wave-per-spectral-point sweep kernel
- *                         (csrc/mom_wave.hip); 0 = the general workgroup-per-point kernels
+ *                         (csrc/mom_wave.hip), with 3 (N = 5) or 2 (N = 6..8) spectral points per wavefront as diagonal
+ *                         blocks of one MFMA tile; 2 = the same kernels with one point per wavefront throughout;
+ *                         0 = the general workgroup-per-point kernels
  *   MOM_OPT_LAYER_SWEEP   1 (default) = one launch per problem size walks ALL layers of a (spectral point, moment)
  *                         unit before the next unit: the composite blocks stay in the storing CU's L2 between layers,
  *                         one tail per sweep instead of one per layer (needs one interface code for all layers >= 2,

@@ -111,7 +111,11 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
       elemental_build(c, a.q, m, nd, as_global(a.tau_sum)[n + zo], dtau, varpi, zpp, zmp);
       MOM_STAMP(44);
 #endif
+#ifdef MOM_QPREFETCH
+      expk = doubling_run<LDSM, KS>(c, nd, expk, (!MT && !first && iface == 3) ? &g : nullptr);
+#else
       expk = doubling_run<LDSM, KS>(c, nd, expk);
+#endif
       MOM_STAMP(30);
       if constexpr (MT) {
         const int zr = a.Nz_sweep > 0 ? z : 0;

@@ -82,6 +82,7 @@ struct Ctx {
   real *jp, *jm, *j1p, *j1m, *v1, *v2, *Jp, *Jm, *prow, *pcol, *rowk, *ei, *mu, *wt, *sg, *part, *thr;
   int *ipiv, *sh, *bad;
   int inv_mode;
+  int qpre;  // MOM_QPREFETCH experiment: c.Q already holds the composite T++ (+ J0+ riding) for the coming interaction
 };
 
 __host__ __device__ inline int np_for(int N) { return 16 * ((N + 15) / 16); }
@@ -142,6 +143,7 @@ __device__ __forceinline__ void make_ctx(Ctx &c, int N, int inv_mode, real *smem
   c.ldv = c.Np;
   c.fd.init(N);
   c.inv_mode = inv_mode;
+  c.qpre = 0;
   const size_t msz = mat_elems(N);
   real *p = smem;
   if (LDSM) {
@@ -968,7 +970,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
 // expk: this point's exp(-dtau/mu0) (returned squared nd times).  Ends with a barrier.
 // ---------------------------------------------------------------------------------------
 template <bool LDSM, int KS = 0>
-__device__ __forceinline__ real doubling_run(Ctx &c, int nd, real expk) {
+__device__ __forceinline__ real doubling_run(Ctx &c, int nd, real expk, const CompPtrs *pre = nullptr) {
   const int N = c.N, ld = c.ld;
   if (nd == 0) return expk;
   // "ride": the source vectors travel as columns N, N+1 of the B operand r (buffer padding), so
@@ -1018,7 +1020,11 @@ __device__ __forceinline__ real doubling_run(Ctx &c, int nd, real expk) {
       if (strip_ok) {
         const int p = neumann_terms_12(beta2);
         if (p <= kStripMaxP) {
+#ifdef MOM_QPREFETCH
+          doubling_step_strip<KS>(c, p, expk, (it == nd - 1) ? pre : nullptr);
+#else
           doubling_step_strip<KS>(c, p, expk);
+#endif
           expk = expk * expk;
           continue;
         }

@@ -221,7 +221,7 @@ __device__ __forceinline__ void doubling_rr_strip(const Ctx &c) {
 // c.jm; out: c.r, c.t, c.jp, c.jm and the riding columns N, N+1 of c.r (= new j0+, j0-) for the next step.
 // ---------------------------------------------------------------------------------------
 template <int KS>
-__device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, real expk) {
+__device__ __forceinline__ void doubling_step_strip(Ctx &c, int p, real expk, const CompPtrs *pre = nullptr) {
   using G = StripGeom<KS>;
   constexpr int N = G::N, NT = G::NT, LD = G::LD;
   const int lane = wg_lane(), wave = wg_wave(), lr = lane & 15, lq = lane >> 4;
@@ -260,6 +260,34 @@ __device__ __forceinline__ void doubling_step_strip(const Ctx &c, int p, real ex
     strip_zero(Tn);
     strip_mul<KS>(t, lr, lq, Y, Tn);   // t^T A^T                (:67)
   }
+#ifdef MOM_QPREFETCH
+  // experiment (profiles/r04_C2_ab.txt): the waves that idle during the chains of the LAST doubling step fetch the coming
+  // interaction's T++ block (+ J0+ as its riding column) into Q, which no strip step uses
+  if (pre != nullptr && kWaves == 8 && (wave >> 2) == 1) {
+    constexpr int NN = N * N, U = 8, TH = 256;
+    real *Q = c.Q;
+    const int tid4 = wg_tid() - 256;
+    for (int e0 = tid4; e0 < NN; e0 += U * TH) {
+      real vt[U];
+      int o[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * TH;
+        if (e < NN) {
+          int i, j;
+          c.fd.split(e, i, j);
+          vt[u] = MOM_NT_LOAD(pre->T_pp + i + j * G::CP);
+          o[u] = i + j * LD;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (e0 + u * TH < NN) Q[o[u]] = vt[u];
+    }
+    for (int i = tid4; i < N; i += TH) Q[i + N * LD] = pre->J0p[i];
+  }
+  if (pre != nullptr && kWaves == 8) c.qpre = 1;
+#endif
   MOM_STAMP(71);
   __syncthreads();
   MOM_STAMP(72);
@@ -302,6 +330,8 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
   const bool do1 = strip && grp == 0, do2 = strip && grp == kStripGroups - 1;
   real *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
   r4 T1[NT], W0[NT];  // chain 1: T--^T strip ; chain 2: W0 = R+-^T t++^T
+  const bool qpre = c.qpre != 0;  // MOM_QPREFETCH: Q = T++ (+ J0+) was fetched during the last doubling step
+  c.qpre = 0;
   if (do1) strip_load_glb<KS>(g.T_mm, lr, lq, c0, colok, T1);
   // P = R+-, Q = T++ ; riding rows: column N of Q = J0+, column N of r = j0-.  All global loads of both blocks are
   // issued before the first LDS store: one exposed HBM latency instead of one per batch.
@@ -317,7 +347,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
           int i, j;
           c.fd.split(e, i, j);
           vr[u] = MOM_NT_LOAD(g.R_pm + i + j * G::CP);
-          vt[u] = MOM_NT_LOAD(g.T_pp + i + j * G::CP);
+          if (!qpre) vt[u] = MOM_NT_LOAD(g.T_pp + i + j * G::CP);
           o[u] = i + j * LD;
         }
       }
@@ -325,12 +355,12 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
       for (int u = 0; u < U; ++u)
         if (e0 + u * kThreads < NN) {
           P[o[u]] = vr[u];
-          Q[o[u]] = vt[u];
+          if (!qpre) Q[o[u]] = vt[u];
         }
     }
   }
   for (int i = wg_tid(); i < N; i += kThreads) {
-    Q[i + N * LD] = g.J0p[i];
+    if (!qpre) Q[i + N * LD] = g.J0p[i];
     r[i + N * LD] = c.jm[i];
   }
   MOM_STAMP(50);

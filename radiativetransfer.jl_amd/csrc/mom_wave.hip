@@ -440,68 +440,113 @@ __device__ __forceinline__ Mat<NT> interact11(const Lay &L, Comp<NT> &C, const M
 #define MOMW_OCC1 2  // waves per SIMD of the NT = 1 images
 #endif
 
-template <int NT, int KS>
+// PK > 1 (NT = 1 only): PK spectral points per wavefront, their operators as the diagonal blocks of ONE 16 x 16 tile (block b
+// = rows / columns [b Nb, (b + 1) Nb) of the packed edge N = PK Nb <= 16).  U^T V of block-diagonal tiles is block-diagonal
+// and a packed vector is the concatenation of the points' vectors, so every product, transpose, series and pivoted inverse
+// of the sweep runs unchanged on the packed operator; only the elemental layer, the surface layer and the outputs know
+// about the blocks (per-block tau, varpi, weights, expk; entries outside the diagonal blocks are exact zeros).  The
+// series length comes from the Frobenius norm of the whole tile (>= every block's: never fewer terms than a point alone
+// would take).  N = 5: three points per wave, N = 6..8: two -- the tile of a single point is at most a quarter full there.
+template <int PK>
+struct Blk {
+  real v[PK];
+  __device__ __forceinline__ real at(int b) const {
+    if constexpr (PK == 1) return v[0];
+    else if constexpr (PK == 2) return b == 0 ? v[0] : v[1];
+    else return b == 0 ? v[0] : (b == 1 ? v[1] : v[2]);
+  }
+};
+
+template <int NT, int KS, int PK = 1>
 __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs a) {
+  static_assert(PK == 1 || NT == 1, "packing is for one-tile operators");
   __shared__ real s_lds[4][slice_doubles<NT>()];
   __shared__ int s_piv[4][16 * NT];
   __shared__ real s_tab[96];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = blockIdx.x * 4 + wave;  // spectral point of this wave
-  const int N = a.N, nS = a.nS, S = a.S, K = a.K;
+  const int n0 = (blockIdx.x * 4 + wave) * PK;  // first spectral point of this wave
+  const int Nb = a.N, N = PK * Nb, nS = a.nS, S = a.S, K = a.K;  // Nb: edge of one point's operators; N: packed edge
   if (threadIdx.x < 32) {
-    const int i = threadIdx.x;
-    s_tab[i] = i < N ? a.mu[i] : 1.0;
-    s_tab[32 + i] = i < N ? a.wt[i] : 0.0;
-    s_tab[64 + i] = i < N ? a.sg[i] : 1.0;
+    const int i = threadIdx.x, il = i % Nb;
+    s_tab[i] = i < N ? a.mu[il] : 1.0;
+    s_tab[32 + i] = i < N ? a.wt[il] : 0.0;
+    s_tab[64 + i] = i < N ? a.sg[il] : 1.0;
   }
   __syncthreads();
-  if (n >= S) return;
+  if (n0 >= S) return;
   Lay L;
   L.lr = lane & 15; L.lq = lane >> 4; L.N = N; L.nS = nS; L.tab = s_tab; L.xp = s_lds[wave]; L.ipiv = s_piv[wave]; L.thr = kThr2[lane & 31];
   real *post = L.xp + slice_doubles<NT>() - 3 * 16 * NT;  // J0+ | J0- | hdr_J0-, 16 NT each
   const int i_start = nS * (a.imu0 - 1), i_end = nS * a.imu0;
   const real mus = a.mu[i_start];
   int bad = 0;
-  // accumulators of the outputs: lane x < nVza * nS handles (view v = x / nS, component k = x % nS)
+  // block coordinates of this lane: column block cb / local column jl, and per accumulator register q the row block
+  // rb[q] / local row il[q] (PK = 1: block 0, local = global)
+  int cb = 0, jl = L.lr, rb[4 * NT], il[4 * NT], np[PK];
+#pragma unroll
+  for (int b = 0; b < PK; ++b) np[b] = min(n0 + b, S - 1);  // tail: the last wave repeats a point, its outputs are not stored
+  if constexpr (PK > 1) {
+    cb = min(L.lr / Nb, PK - 1);
+    jl = L.lr - cb * Nb;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = L.row(0, q);
+      rb[q] = min(i / Nb, PK - 1);
+      il[q] = i - rb[q] * Nb;
+    }
+  }
   // outputs: lane x (+ 64 per pass) handles (view v = x / nS, component k = x % nS); the sums over the Fourier moments
   // are kept in the output arrays themselves (one read-modify-write per moment: no registers held across the sweep)
   const int nout = a.nVza * nS;
 
   for (int m = 0; m < a.M; ++m) {
     const real wdiv = (m == 0) ? 2.0 : 4.0, wct02 = (m == 0) ? 0.5 : 0.25;
-    const real *Zp_m = a.Zpp + (size_t)N * N * K * m, *Zm_m = a.Zmp + (size_t)N * N * K * m;
+    const real *Zp_m = a.Zpp + (size_t)Nb * Nb * K * m, *Zm_m = a.Zmp + (size_t)Nb * Nb * K * m;
     Comp<NT> C;
     for (int z = 0; z < a.Nz; ++z) {
       const int nd = a.nd[z];
-      const size_t o = n + (size_t)S * z;
-      const real tau = a.tau[o], varpi = a.varpi[o], tau_sum = a.tau_sum[o];
-      const real dtau = ldexp(tau, -nd);
-      real expk = exp(-dtau / a.mu0);
+      Blk<PK> tau_b, varpi_b, dtau_b, expk_b, att_b, es_b;
+      size_t ob[PK];
+#pragma unroll
+      for (int b = 0; b < PK; ++b) {
+        ob[b] = np[b] + (size_t)S * z;
+        tau_b.v[b] = a.tau[ob[b]];
+        varpi_b.v[b] = a.varpi[ob[b]];
+        dtau_b.v[b] = ldexp(tau_b.v[b], -nd);
+        expk_b.v[b] = exp(-dtau_b.v[b] / a.mu0);
+        att_b.v[b] = exp(-a.tau_sum[ob[b]] / mus);
+        es_b.v[b] = exp(-dtau_b.v[b] / mus);
+      }
       // ------------------------------------------------ elemental! (elemental.jl:164-253)
       Mat<NT> r, t;
       Vec<NT> jv;
       {
-        const real att = exp(-tau_sum / mus), es = exp(-dtau / mus);
+        // matrix entries belong to the lane's COLUMN block (a diagonal-block entry has row block == column block)
+        const real dtau = dtau_b.at(cb), varpi = varpi_b.at(cb);
+        const size_t o = (PK == 1) ? ob[0] : (cb == 0 ? ob[0] : (cb == 1 ? ob[PK > 1 ? 1 : 0] : ob[PK - 1]));
         // one register row (of every tile of a row block) per iteration, NOT unrolled over q: the live set of one
         // iteration is what the register budget affords next to the composite tiles
 #pragma unroll
         for (int bi = 0; bi < NT; ++bi) {
 #pragma unroll 1
           for (int q = 0; q < 4; ++q) {
-            const int i = L.row(bi, q);
-            const bool rok = i < N;
-            const real mui = L.mu(i), wir = L.wt(i) / wdiv;
+            const int ip = L.row(bi, q);                       // packed row
+            const int i = (PK == 1) ? ip : il[q];              // row inside its block
+            const int rbq = (PK == 1) ? 0 : rb[q];
+            const bool rok = ip < N;
+            const real mui = L.mu(ip), wir = L.wt(ip) / wdiv;
             const real er = exp(-dtau / mui);
 #pragma unroll
             for (int bj = 0; bj < NT; ++bj) {
-              const int j = L.col(bj);
-              const bool ok = rok && j < N;
-              const real muj = L.mu(j), wjc = L.wt(j) / wdiv;
+              const int jp_ = L.col(bj);
+              const int j = (PK == 1) ? jp_ : jl;
+              const bool ok = rok && jp_ < N && rbq == cb;
+              const real muj = L.mu(jp_), wjc = L.wt(jp_) / wdiv;
               real zp = 0.0, zm = 0.0;
               if (ok)
                 for (int k = 0; k < K; ++k) {
                   const real w = a.zw[k + (size_t)K * o];
-                  const size_t b = (size_t)N * N * k + i + (size_t)N * j;
+                  const size_t b = (size_t)Nb * Nb * k + i + (size_t)Nb * j;
                   zp += w * Zp_m[b];
                   zm += w * Zm_m[b];
                 }
@@ -514,25 +559,28 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
                 rij = 0.0;
                 tij = (i == j) ? er : 0.0;
               }
-              if (nd >= 1) rij *= L.sg(i);  // apply_D_elemental!: rows of r-+ (elemental.jl:265-269)
+              if (nd >= 1) rij *= L.sg(ip);  // apply_D_elemental!: rows of r-+ (elemental.jl:265-269)
               r.t[bi][bj][q] = ok ? rij : 0.0;
               t.t[bi][bj][q] = ok ? tij : 0.0;
             }
             // source rows: Z I0 over the sun's Stokes block (lanes of columns 0 and 1)             (elemental.jl:224-251)
+            // -- a vector entry belongs to its ROW block
             real jx = 0.0;
             if (rok && L.lr < 2) {
+              const real dtv = dtau_b.at(rbq), vpv = varpi_b.at(rbq), erv = (PK == 1) ? er : exp(-dtv / mui);
+              const size_t ov = (PK == 1) ? ob[0] : (rbq == 0 ? ob[0] : (rbq == 1 ? ob[PK > 1 ? 1 : 0] : ob[PK - 1]));
               const real *Zs = (L.lr == 0) ? Zp_m : Zm_m;
               real zI = 0.0;
               for (int ks = 0; ks < nS; ++ks)
                 for (int k = 0; k < K; ++k)
-                  zI += a.zw[k + (size_t)K * o] * Zs[(size_t)N * N * k + i + (size_t)N * (i_start + ks)] * a.I0[ks];
+                  zI += a.zw[k + (size_t)K * ov] * Zs[(size_t)Nb * Nb * k + i + (size_t)Nb * (i_start + ks)] * a.I0[ks];
               if (L.lr == 0) {
-                if (i >= i_start && i < i_end) jx = wct02 * varpi * zI * (dtau / mui) * er;
-                else jx = wct02 * varpi * zI * (mus / (mui - mus)) * (er - es);
-                jx *= att;
+                if (i >= i_start && i < i_end) jx = wct02 * vpv * zI * (dtv / mui) * erv;
+                else jx = wct02 * vpv * zI * (mus / (mui - mus)) * (erv - es_b.at(rbq));
+                jx *= att_b.at(rbq);
               } else {
-                jx = wct02 * varpi * zI * (mus / (mui + mus)) * (1 - exp(-dtau * ((1 / mui) + (1 / mus))));
-                jx *= att;
+                jx = wct02 * vpv * zI * (mus / (mui + mus)) * (1 - exp(-dtv * ((1 / mui) + (1 / mus))));
+                jx *= att_b.at(rbq);
                 if (nd >= 1) jx = a.D[i % nS] * jx;
               }
             }
@@ -550,15 +598,20 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
 #pragma unroll
         for (int b = 0; b < NT; ++b)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)  // column 0: w2 = j0+ + r j1-  ; column 1: w1 = j1- + r j0+   (:51-60)
+          for (int q = 0; q < 4; ++q) {  // column 0: w2 = j0+ + r j1-  ; column 1: w1 = j1- + r j0+   (:51-60)
+            const real expk = expk_b.at((PK == 1) ? 0 : rb[q]);
             Wv.t[b][q] = (L.lr == 0) ? jv.t[b][q] + expk * Us.t[b][q] : ((L.lr == 1) ? jv.t[b][q] * expk + Us.t[b][q] : 0.0);
+          }
         const Vec<NT> AW = TNv<NT, KS>(At, Wv);
 #pragma unroll
         for (int b = 0; b < NT; ++b)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)  // j0+ = j1+ + A w2 (:60) ; j0- = j0- + A w1 (:57)
+          for (int q = 0; q < 4; ++q) {  // j0+ = j1+ + A w2 (:60) ; j0- = j0- + A w1 (:57)
+            const real expk = expk_b.at((PK == 1) ? 0 : rb[q]);
             jv.t[b][q] = (L.lr == 0) ? jv.t[b][q] * expk + AW.t[b][q] : ((L.lr == 1) ? jv.t[b][q] + AW.t[b][q] : 0.0);
-        expk = expk * expk;                                   // :61
+          }
+#pragma unroll
+        for (int b = 0; b < PK; ++b) expk_b.v[b] = expk_b.v[b] * expk_b.v[b];   // :61
         r = TNacc<NT, KS>(At, TN<NT, KS>(rT, t), r);          // r + A (r t), old t                 (:64)
         t = TN<NT, KS>(At, t);                                // A t                               (:67)
       }
@@ -585,38 +638,46 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
 #pragma unroll
     for (int b = 0; b < NT; ++b) hdrJ.t[b] = (r4){0.0, 0.0, 0.0, 0.0};
     if (m == 0 || a.surf_kind == 1) {
-      const real rho = 2 * ((a.surf_kind == 2) ? a.albedo_spec[n] : a.albedo);  // lambertian_surface.jl:37 / :97
-      const real att = exp(-a.tau_sum[n + (size_t)S * a.Nz] / a.mu0);
-      const real *Rs = a.Rsurf + (size_t)N * N * m;  // kind 1: rho_m [N,N] (rpv_surface.jl:39-43)
+      Blk<PK> rho_b, att_b;
+#pragma unroll
+      for (int b = 0; b < PK; ++b) {
+        rho_b.v[b] = 2 * ((a.surf_kind == 2) ? a.albedo_spec[np[b]] : a.albedo);  // lambertian_surface.jl:37 / :97
+        att_b.v[b] = exp(-a.tau_sum[np[b] + (size_t)S * a.Nz] / a.mu0);
+      }
+      const real *Rs = a.Rsurf + (size_t)Nb * Nb * m;  // kind 1: rho_m [N,N] (rpv_surface.jl:39-43)
       Mat<NT> rs;
       Vec<NT> jv;
 #pragma unroll
       for (int bi = 0; bi < NT; ++bi)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int i = L.row(bi, q);
+          const int ip = L.row(bi, q);
+          const int i = (PK == 1) ? ip : il[q];
+          const int rbq = (PK == 1) ? 0 : rb[q];
+          const real rho = rho_b.at(rbq), att = att_b.at(rbq);
 #pragma unroll
           for (int bj = 0; bj < NT; ++bj) {
-            const int j = L.col(bj);
-            const bool in = i < N && j < N;
+            const int jp_ = L.col(bj);
+            const int j = (PK == 1) ? jp_ : jl;
+            const bool in = ip < N && jp_ < N && rbq == cb;
             real v;
-            if (a.surf_kind == 1) v = in ? Rs[i + (size_t)N * j] * (L.mu(j) * L.wt(j)) : 0.0;       // rpv_surface.jl:58-62
-            else v = (in && (i % nS == 0) && (j % nS == 0)) ? rho * (L.mu(j) * L.wt(j)) : 0.0;      // r-+ = R_surf Diagonal(mu w)  (:41-43,:58)
+            if (a.surf_kind == 1) v = in ? Rs[i + (size_t)Nb * j] * (L.mu(jp_) * L.wt(jp_)) : 0.0;       // rpv_surface.jl:58-62
+            else v = (in && (i % nS == 0) && (j % nS == 0)) ? rho * (L.mu(jp_) * L.wt(jp_)) : 0.0;      // r-+ = R_surf Diagonal(mu w)  (:41-43,:58)
             rs.t[bi][bj][q] = v;
           }
           const bool in_sun = (i >= i_start) && (i < i_end);
           real jp = (in_sun ? a.I0[i - i_start] : 0.0) * att;                           // :55
           real jm = (i % nS == 0) ? (a.mu0 * (rho * a.I0[0])) * att : 0.0;             // :56
-          if (a.surf_kind == 1 && i < N) {                                                // j0- = mu0 (R_surf I0N) e^(-tau/mu0)  (rpv_surface.jl:48-56)
+          if (a.surf_kind == 1 && ip < N) {                                               // j0- = mu0 (R_surf I0N) e^(-tau/mu0)  (rpv_surface.jl:48-56)
             real rI = 0.0;
-            for (int k = 0; k < nS; ++k) rI += Rs[i + (size_t)N * (i_start + k)] * a.I0[k];
+            for (int k = 0; k < nS; ++k) rI += Rs[i + (size_t)Nb * (i_start + k)] * a.I0[k];
             jm = (a.mu0 * rI) * att;
           }
           if (a.surf_kind == 2) {                                                         // lambertian_surface.jl:112-114
             jp = 0.0;
             jm = (i % nS == 0) ? (a.mu0 * a.I0[0]) * (rho * att) : 0.0;
           }
-          jv.t[bi][q] = !(i < N) ? 0.0 : (L.lr == 0 ? jp : (L.lr == 1 ? jm : 0.0));
+          jv.t[bi][q] = !(ip < N) ? 0.0 : (L.lr == 0 ? jp : (L.lr == 1 ? jm : 0.0));
         }
       const Mat<NT> rsT = interact11<NT, KS, true>(L, C, rs, rs, jv, a.inv_mode, bad);  // (t operand unused)
       // interaction_hdrf! (interaction_hdrf.jl:9-45): hdr_J0- = r-+_surf J0+ + j0-_surf  -> column 0
@@ -627,27 +688,30 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
 #pragma unroll
         for (int q = 0; q < 4; ++q) hdrJ.t[b][q] = (L.lr == 0) ? rJ.t[b][q] + jsw.t[b][q] : 0.0;
       // BHR flux sums over the streams of each Stokes component (column-0 lanes hold hdr_J0- and J0+), m = 0 only
-      for (int k = 0; k < (m == 0 ? nS : 0); ++k) {
-        real up = 0.0, dw = 0.0;
+      for (int pb = 0; pb < PK; ++pb)
+        for (int k = 0; k < (m == 0 ? nS : 0); ++k) {
+          real up = 0.0, dw = 0.0;
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
+          for (int b = 0; b < NT; ++b)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int i = L.row(b, q);
-            if (L.lr == 0 && i < N && (i % nS == k)) {
-              up += hdrJ.t[b][q] * L.wt(i) * L.mu(i);
-              dw += C.Jv.t[b][q] * L.wt(i) * L.mu(i);
+            for (int q = 0; q < 4; ++q) {
+              const int ip = L.row(b, q);
+              const int i = (PK == 1) ? ip : il[q];
+              const bool mine = (PK == 1) || rb[q] == pb;
+              if (L.lr == 0 && ip < N && mine && (i % nS == k)) {
+                up += hdrJ.t[b][q] * L.wt(ip) * L.mu(ip);
+                dw += C.Jv.t[b][q] * L.wt(ip) * L.mu(ip);
+              }
             }
+          up = wave_sum<NT>(up);
+          dw = wave_sum<NT>(dw);
+          // + j0+_surf[i_start] mu[i_start]: the direct beam (interaction_hdrf.jl:30)
+          const real direct = ((a.surf_kind == 2) ? 0.0 : a.I0[0] * att_b.at(pb)) * mus;  // j0+_surf[i_start] mu[i_start]
+          if (lane == 0 && n0 + pb < S) {
+            a.bhr_uw[k + (size_t)nS * (n0 + pb)] = up;
+            a.bhr_dw[k + (size_t)nS * (n0 + pb)] = dw + direct;
           }
-        up = wave_sum<NT>(up);
-        dw = wave_sum<NT>(dw);
-        // + j0+_surf[i_start] mu[i_start]: the direct beam (interaction_hdrf.jl:30)
-        const real direct = ((a.surf_kind == 2) ? 0.0 : a.I0[0] * att) * mus;  // j0+_surf[i_start] mu[i_start]
-        if (lane == 0) {
-          a.bhr_uw[k + (size_t)nS * n] = up;
-          a.bhr_dw[k + (size_t)nS * n] = dw + direct;
         }
-      }
     }
     // ---------------------------------------------------- postprocessing_vza! (+ hdrf) through the wave's LDS slice
 #pragma unroll
@@ -659,12 +723,14 @@ __global__ void __launch_bounds__(256, (NT == 1 ? MOMW_OCC1 : 1)) k_wsweep(WArgs
         if (L.lr == 1) post[16 * NT + i] = C.Jv.t[b][q];
       }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int x = lane; x < nout; x += 64) {
+    for (int xx = lane; xx < nout * PK; xx += 64) {
+      const int pb = (PK == 1) ? 0 : xx / nout, x = xx - pb * nout;
+      if (n0 + pb >= S) continue;
       const int xv = x / nS, xk = x - xv * nS;
       const real weight = (m == 0) ? 0.5 : 1.0;
       const real cs = weight * ((xk < 2) ? a.cos_mphi[xv + a.nVza * m] : a.sin_mphi[xv + a.nVza * m]);
-      const int row = (a.node[xv] - 1) * nS + xk;
-      const size_t idx = xv + (size_t)a.nVza * xk + (size_t)nout * n;  // [nVza, nStokes, S]
+      const int row = pb * Nb + (a.node[xv] - 1) * nS + xk;
+      const size_t idx = xv + (size_t)a.nVza * xk + (size_t)nout * (n0 + pb);  // [nVza, nStokes, S]
       const real tv = (a.surf_kind == 2 && m > 0) ? 0.0 : cs * post[row];  // Legendre surface: t = 0 for m > 0
       const real hv = (m == 0 || a.surf_kind == 1) ? cs * post[32 * NT + row] : 0.0;  // BRDF surfaces: hdr over all moments
       a.T[idx] = (m == 0) ? tv : a.T[idx] + tv;
@@ -701,6 +767,19 @@ hipError_t MOMW_LAUNCH8(const void *args, hipStream_t st) {
 hipError_t MOMW_LAUNCH(const void *args, hipStream_t st) {
   const MOMW_NS::WArgs a = *reinterpret_cast<const MOMW_NS::WArgs *>(args);
   const dim3 grid((unsigned)((a.S + 3) / 4)), block(256);
+#ifndef MOMW_FLOAT
+  // a.pad = points per wavefront (block-diagonal packing of small operators, k_wsweep's PK): 3 at N = 5, 2 at N = 6..8
+  if (a.pad == 3 && a.N == 5) {
+    hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 4, 3>), dim3((unsigned)((a.S + 11) / 12)), block, 0, st, a);
+    return hipGetLastError();
+  }
+  if (a.pad == 2 && a.N >= 5 && a.N <= 8) {
+    const dim3 g2((unsigned)((a.S + 7) / 8));
+    if (2 * a.N <= 12) hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 3, 2>), g2, block, 0, st, a);
+    else hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 4, 2>), g2, block, 0, st, a);
+    return hipGetLastError();
+  }
+#endif
   switch ((a.N + 3) / 4) {
     case 2: hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 2>), grid, block, 0, st, a); break;
     case 3: hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 3>), grid, block, 0, st, a); break;

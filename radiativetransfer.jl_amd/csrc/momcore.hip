@@ -1402,6 +1402,8 @@ static int rt_run_wave(mom_t *h) {
   WaveSweepArgs a{};
   a.N = h->N; a.S = h->S; a.M = h->scene_M; a.K = h->K; a.Nz = Nz; a.nVza = h->nVza; a.nS = h->nS; a.imu0 = h->q.imu0;
   a.inv_mode = h->opt_inverse;
+  // points per wavefront (mom_wave.hip, block-diagonal packing): MOM_OPT_SMALL_N = 2 keeps one point per wave
+  a.pad = (h->opt_small == 1) ? (h->N == 5 ? 3 : (h->N >= 6 && h->N <= 8 ? 2 : 1)) : 1;
   a.mu0 = h->q.mu0; a.albedo = h->albedo;
   for (int k = 0; k < 4; ++k) { a.I0[k] = h->q.I0[k]; a.D[k] = h->q.D[k]; }
   a.mu = h->d_mu; a.wt = h->d_wt; a.sg = h->d_sg;
@@ -1887,8 +1889,8 @@ extern "C" int mom_postprocess(mom_t *h, int m, int nVza, const int *node_1based
     for (int v = 0; v < nVza; ++v) cs[v + (size_t)nVza * k] = weight * ((k < 2) ? cosd(m * vaz_deg[v]) : sind(m * vaz_deg[v]));
   int *d_node = nullptr;
   double *d_cs = nullptr;
-  HIPCHK(h, dmalloc(&d_node, (size_t)nVza));
-  HIPCHK(h, dmalloc(&d_cs, cs.size()));
+  HIPCHK(h, ws_get(h, 2, &d_node, (size_t)nVza));   // grow-only workspace of the handle: no allocation per call, nothing to leak
+  HIPCHK(h, ws_get(h, 3, &d_cs, cs.size()));
   HIPCHK(h, hipMemcpyAsync(d_node, node_1based, (size_t)nVza * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipMemcpyAsync(d_cs, cs.data(), cs.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_op_postprocess, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, h->N, h->nS, h->S, nVza,
@@ -1898,7 +1900,6 @@ extern "C" int mom_postprocess(mom_t *h, int m, int nVza, const int *node_1based
   HIPCHK(h, hipMemcpyAsync(hr.data(), h->d_post[0], total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(ht.data(), h->d_post[1], total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  (void)hipFree(d_node); (void)hipFree(d_cs);
   for (size_t i = 0; i < total; ++i) { R_SFI[i] += hr[i]; T_SFI[i] += ht[i]; }  // `+=` like :48-49
   return MOM_OK;
 }

@@ -114,6 +114,48 @@ def test_wave_per_point_sweep_kernel(rtamd, cref, nS, lt, vza, kw, inverse):
         np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
 
 
+@pytest.mark.parametrize("lt,vza,N,kw", [
+    (5, (0.0,), 5, {}),                                          # three points per wavefront (packed edge 15)
+    (5, (0.0,), 5, dict(aerosol_total=3.0, albedo=0.05)),        # thick aerosol: long series / pivoted inverse of the packed tile
+    (5, (0.0,), 5, dict(brdf="rpv")),
+    (5, (0.0, 30.0), 6, {}),                                     # two points per wavefront (packed edge 12)
+    (7, (0.0, 30.0), 7, dict(albedo=0.5)),                       # packed edge 14
+    (9, (0.0, 30.0), 8, {}),                                     # packed edge 16: a full tile
+    (9, (0.0, 30.0), 8, dict(brdf="legendre")),
+    (7, (0.0,) * 40, 6, {}),                                     # 40 views x 2 points = 80 outputs per wave: two output passes
+])
+def test_wave_kernel_packed_points(rtamd, cref, lt, vza, N, kw):
+    """N = 5 ... 8: several spectral points per wavefront as diagonal blocks of one MFMA tile (mom_wave.hip, PK = 3 / 2).
+    Against the oracle and against the one-point-per-wave form of the same kernel (MOM_OPT_SMALL_N = 2); S = 301 leaves
+    the last wave with one point (the tail repeats a point and does not store it)."""
+    kw = dict(kw)
+    brdf = kw.pop("brdf", None)
+    rt = rtamd.corert
+    m = rtamd.scenes.make_scene(1, lt, 7, 301, seed=3 + lt + N, vza=vza, vaz=tuple(9.0 * i for i in range(len(vza))), **kw)
+    if brdf:
+        m.params.brdf = {"rpv": rt.rpvSurfaceScalar(0.1, 0.8, 0.7, -0.1), "legendre": rt.LambertianSurfaceLegendre((0.2, 0.05, -0.02))}[brdf]
+    sc = rtamd.prepare_scene(m)
+    assert sc.N == N
+    Rr, Tr, Hr, upr, dwr, info = cref.rt_run_full(cref.pack_scene(helpers.oracle_scene(m)))
+    assert info == 0
+    out = {}
+    for small in (1, 2):
+        with rt.make_handle(m) as h:
+            h.set_option(rtamd._lib.MOM_OPT_SMALL_N, small)
+            R, T = rt.run_scene(h, sc)
+            out[small] = (R, T) + h.get_hdr() + (h.timers()["layer_launches"],)
+        assert out[small][5] == 1
+    tol = helpers.stokes_rtol(sc.ndoubl)
+    for small in (1, 2):
+        R, T, H, up, dw, _ = out[small]
+        helpers.assert_stokes_close(R, Rr, rtol=tol, what=f"R small={small}")
+        helpers.assert_stokes_close(T, Tr, rtol=tol, what=f"T small={small}")
+        helpers.assert_stokes_close(H, Hr, rtol=tol, what=f"hdr small={small}")
+        np.testing.assert_allclose(up, upr, rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
+        np.testing.assert_allclose(dw, dwr, rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
+    helpers.assert_stokes_close(out[1][0], out[2][0], rtol=tol, what="packed vs one point per wave")
+
+
 @pytest.mark.parametrize("surf", ["rpv", "rossli", "legendre"])
 @pytest.mark.parametrize("nS,lt", [(3, 3), (4, 7)])
 def test_wave_kernel_surfaces_and_many_views(rtamd, cref, surf, nS, lt):

@@ -9,11 +9,15 @@ Corrections follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are 
 1/2 of the bytes of a wide coalesced read, so the read side is doubled (our composite reads are 8 B/lane, an access
 width the guide marks as uncalibrated: the doubled figure is an upper estimate, the raw one a lower).  MFMA-busy share =
 SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)."""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, json, os, shutil, subprocess, sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+try:
+    commit = subprocess.check_output(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    commit = "unknown"
 out = ROOT / "profiles"
 out.mkdir(exist_ok=True)
 DOMINANT = {"C2": "mom::k_layer<true, 3, 15>", "C4": "mom::k_layer<false, 3, 0>", "C1": "momsm::k_sweep<4>",
@@ -40,8 +44,8 @@ for wl in ("C2", "C4", "C1", "C5", "voigt"):
             name = row["Kernel_Name"].split("(")[0].replace("void ", "")
             acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, d in acc.items():
-            for cn, v in d.items():
-                per.setdefault(k, {})[cn] = {"launches": len(v), "mean": sum(v) / len(v)}
+            for cn, v in d.items():   # v: one value per launch, in dispatch order
+                per.setdefault(k, {})[cn] = {"launches": len(v), "mean": sum(v) / len(v), "sum": sum(v), "values": v if len(v) <= 64 else None}
     if per:
         summ[wl] = per
     dom = DOMINANT.get(wl)
@@ -49,14 +53,36 @@ for wl in ("C2", "C4", "C1", "C5", "voigt"):
         dom = next((k for k in per if k.startswith(dom[:-1] + ",")), dom)
     kl = per.get(dom, {})
     if kl:
-        t = {"kernel": dom, "round": rnd}
-        if "FETCH_SIZE" in kl and "WRITE_SIZE" in kl:
-            rd_raw, wr = kl["FETCH_SIZE"]["mean"] * 1024, kl["WRITE_SIZE"]["mean"] * 1024
-            t.update(hbm_bytes_per_launch=2 * rd_raw + wr, fetch_bytes_raw=rd_raw, fetch_bytes_corrected_x2=2 * rd_raw, write_bytes=wr)
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in kl and "GRBM_GUI_ACTIVE" in kl and kl["GRBM_GUI_ACTIVE"]["mean"] > 0:
-            t["mfma_busy_frac"] = kl["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (kl["GRBM_GUI_ACTIVE"]["mean"] / 8 * 1024)
-        t["note"] = ("means over the launches of the dominant kernel in one bench step; FETCH_SIZE doubled per MI355X_MICROARCH.md; "
-                     "layer-sweep mode: ONE launch of the kernel covers all layers of the step")
+        t = {"kernel": dom, "round": rnd, "source": f"tools/collect_profiles.sh {rnd} @ {commit}"}
+        # One kernel NAME can cover dissimilar launches (C4: the m = 0 sub-problem at N0 = 128 and the full problem at
+        # N = 256 are both k_layer<false, 3, 0>): "per launch" is the LARGEST launch of the step (the full problem, the one
+        # roofline.achieved is computed for), taken at the same position of the dispatch order in every counter pass;
+        # the step total is reported next to it.
+        def pick(cn):
+            e = kl.get(cn)
+            if not e:
+                return None, None
+            v = e.get("values")
+            if not v:
+                return e["mean"], e["sum"]
+            ref = kl.get("FETCH_SIZE", e).get("values") or v
+            if max(ref) <= 2 * min(ref):     # similar launches (C5: 51 doubling steps): their mean
+                return e["mean"], e["sum"]
+            idx = max(range(len(ref)), key=lambda i: ref[i]) if len(ref) == len(v) else max(range(len(v)), key=lambda i: v[i])
+            return v[idx], sum(v)
+        fmax, fsum = pick("FETCH_SIZE")
+        wmax, wsum = pick("WRITE_SIZE")
+        if fmax is not None and wmax is not None:
+            rd_raw, wr = fmax * 1024, wmax * 1024
+            t.update(hbm_bytes_per_launch=2 * rd_raw + wr, fetch_bytes_raw=rd_raw, fetch_bytes_corrected_x2=2 * rd_raw, write_bytes=wr,
+                     hbm_bytes_per_step_all_launches=2 * fsum * 1024 + wsum * 1024, launches_per_step=kl["FETCH_SIZE"]["launches"])
+        bmax, _ = pick("SQ_VALU_MFMA_BUSY_CYCLES")
+        gmax, _ = pick("GRBM_GUI_ACTIVE")
+        if bmax is not None and gmax:
+            t["mfma_busy_frac"] = bmax / (gmax / 8 * 1024)
+        t["note"] = ("the LARGEST launch of the dominant kernel in one bench step where its launches differ by more than 2 x, else "
+                     "their mean (one profiled step per counter pass); FETCH_SIZE "
+                     "doubled per MI355X_MICROARCH.md; layer-sweep mode: ONE launch of the kernel covers all layers of the step")
         traffic[wl] = t
 (out / f"{rnd}_pmc_summary.json").write_text(json.dumps(summ, indent=1))
 (out / "traffic.json").write_text(json.dumps(traffic, indent=1))
