@@ -71,6 +71,12 @@ constexpr int kWavesPerBlock = 4;
 #define MOMR_WPE 2
 #endif
 #define MOMR_PAIR_ATTR __attribute__((amdgpu_waves_per_eu(MOMR_WPE, MOMR_WPE)))
+// software pipeline of the pair kernels' operand loads (next pair requested before the current one is computed): measured
+// SLOWER on C5 (profiles/r04_C5_ab.txt: k_dbl_pair 160 -> 169 ms, k_int_pair 84 -> 119 ms per run) -- the kernels are
+// bound by instruction issue, not by the latency of their first loads; kept as an experiment switch
+#ifndef MOMR_PIPELINE
+#define MOMR_PIPELINE 0
+#endif
 
 template <int NT>
 __device__ __forceinline__ Geo make_geo(int N, unsigned char *smem) {
@@ -475,11 +481,43 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair
   const size_t NN = (size_t)a.P * a.P, VS = a.P;  // block strides (padded pitch)
   const size_t npairs = (size_t)(a.n1_hi - a.n1_lo) * a.nR;
   constexpr bool fuseD = (MODE == 1);  // a.last && !strict: D2/D3 (corrected) folded into the last step's stores
-  for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += (size_t)gridDim.x * kWavesPerBlock) {
-    const int n1 = a.n1_lo + (int)(p % (size_t)(a.n1_hi - a.n1_lo)), dn = (int)(p / (size_t)(a.n1_hi - a.n1_lo));
+  // Software pipeline over the pairs of this wave (one-tile images: the register budget of the 2 x 2-tile ones is spent):
+  // the operand tiles of pair p + stride are requested before pair p is computed, so their HBM / L2 latency (a wave waits
+  // for ~40 loads per pair, and only two waves share a SIMD) runs under the MFMA chains of the current pair.
+  constexpr bool PIPE = (NT == 1) && MOMR_PIPELINE;
+  struct Pre {
+    Mat<NT> a_t, b_t, r1_t, ttgp1_t, r0_c, gt0_c;
+    CV<NT> Jp, Jm;
+    bool have;
+  } nx;
+  nx.have = false;
+  const size_t stride = (size_t)gridDim.x * kWavesPerBlock, span = (size_t)(a.n1_hi - a.n1_lo);
+  auto prefetch = [&](size_t q) {
+    nx.have = false;
+    if (!PIPE || q >= npairs) return;
+    const int qn1 = a.n1_lo + (int)(q % span), qdn = (int)(q / span);
+    const int qn0 = qn1 + a.off[qdn];
+    if (qn0 < 0 || qn0 >= a.S) return;
+    const size_t qu = (size_t)qn1 + (size_t)a.S * qdn, q4 = NN * qu, q3 = VS * qu, qm1 = NN * qn1, qm0 = NN * qn0;
+    if (!FUSE) {
+      nx.a_t = load_t<NT>(g, a.ie_a[R_MP] + q4);
+      nx.b_t = load_t<NT>(g, a.ie_a[T_PP] + q4);
+      nx.Jp = loadC<NT>(g, a.ie_a[J0P] + q3);
+      nx.Jm = loadC<NT>(g, a.ie_a[J0M] + q3);
+    }
+    nx.r1_t = load_t<NT>(g, a.a_cur[R_MP] + qm1);
+    nx.ttgp1_t = load_t<NT>(g, a.sm[SM_TTGP] + qm1);
+    nx.r0_c = load_t<NT>(g, a.sm[SM_RT] + qm0);
+    nx.gt0_c = load_t<NT>(g, a.sm[SM_GT] + qm0);
+    nx.have = true;
+  };
+  prefetch((size_t)blockIdx.x * kWavesPerBlock + wave);
+  for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += stride) {
+    const int n1 = a.n1_lo + (int)(p % span), dn = (int)(p / span);
     const int n0 = n1 + a.off[dn];
     const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = VS * u;
     if (n0 < 0 || n0 >= a.S) {  // get_n0_n1 (inelastic_helper.jl:13-21): no update off the grid ...
+      if (PIPE) prefetch(p + stride);
       if (FUSE) {               // ... but the deferred elemental writes zeros there and multiplies ieJ0- by D (:378-380)
         store_t<NT>(g, a.ie_a[R_MP] + o4, zeros<NT>());
         store_t<NT>(g, a.ie_a[T_PP] + o4, zeros<NT>());
@@ -512,16 +550,28 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair
     const size_t m1 = NN * n1, m0 = NN * n0, v0 = VS * n0;
     Mat<NT> a_t, b_t;
     CV<NT> Jp, Jm;  // ieJ0+, ieJ0-
-    if (FUSE) {
-      ie_elem_tile<NT>(g, a, n1, dn, n0, a_t, b_t, Jp, Jm);
+    Mat<NT> r1_t, ttgp1_t, r0_c, gt0_c;
+    if (PIPE && nx.have) {  // requested one iteration ago
+      if (!FUSE) { a_t = nx.a_t; b_t = nx.b_t; Jp = nx.Jp; Jm = nx.Jm; }
+      r1_t = nx.r1_t; ttgp1_t = nx.ttgp1_t; r0_c = nx.r0_c; gt0_c = nx.gt0_c;
     } else {
-      a_t = load_t<NT>(g, a.ie_a[R_MP] + o4);
-      b_t = load_t<NT>(g, a.ie_a[T_PP] + o4);
-      Jp = loadC<NT>(g, a.ie_a[J0P] + o3);
-      Jm = loadC<NT>(g, a.ie_a[J0M] + o3);
+      if (!FUSE) {
+        a_t = load_t<NT>(g, a.ie_a[R_MP] + o4);
+        b_t = load_t<NT>(g, a.ie_a[T_PP] + o4);
+        Jp = loadC<NT>(g, a.ie_a[J0P] + o3);
+        Jm = loadC<NT>(g, a.ie_a[J0M] + o3);
+      }
+      r1_t = load_t<NT>(g, a.a_cur[R_MP] + m1); ttgp1_t = load_t<NT>(g, a.sm[SM_TTGP] + m1);
+      r0_c = load_t<NT>(g, a.sm[SM_RT] + m0); gt0_c = load_t<NT>(g, a.sm[SM_GT] + m0);
     }
-    const Mat<NT> r1_t = load_t<NT>(g, a.a_cur[R_MP] + m1), ttgp1_t = load_t<NT>(g, a.sm[SM_TTGP] + m1);
-    const Mat<NT> r0_c = load_t<NT>(g, a.sm[SM_RT] + m0), gt0_c = load_t<NT>(g, a.sm[SM_GT] + m0);
+    if (FUSE) ie_elem_tile<NT>(g, a, n1, dn, n0, a_t, b_t, Jp, Jm);
+    // the three operands of the last products, requested up front as well (they used to be loaded between the products)
+    Mat<NT> gr0_c, t0_c, ttgpr1_t;
+    if (PIPE) {
+      gr0_c = load_t<NT>(g, a.sm[SM_GR] + m0); t0_c = load_t<NT>(g, a.sm[SM_TT] + m0);
+      ttgpr1_t = load_t<NT>(g, a.sm[SM_TTGPR] + m1);
+    }
+    if (PIPE) prefetch(p + stride);
     const Mat<NT> a_c = transpose<NT>(g, a_t);
     // X = ier r0 + r1 ier
     const Mat<NT> X_t = TNacc<NT>(g, a_c, r1_t, TN<NT>(g, r0_c, a_t));
@@ -557,8 +607,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair
     Mat<NT> bn_t = TNacc<NT>(g, gt0_c, b_t, TN<NT>(g, W_c, ttgp1_t));         // tG (iet + Y) + iet G t[n0]
     const Mat<NT> bn_c = transpose<NT>(g, bn_t);
     const Mat<NT> V_c = add<NT>(bn_c, Y_c);
-    const Mat<NT> gr0_c = load_t<NT>(g, a.sm[SM_GR] + m0), t0_c = load_t<NT>(g, a.sm[SM_TT] + m0);
-    const Mat<NT> ttgpr1_t = load_t<NT>(g, a.sm[SM_TTGPR] + m1);
+    if (!PIPE) {  // default: loaded where they are used
+      gr0_c = load_t<NT>(g, a.sm[SM_GR] + m0); t0_c = load_t<NT>(g, a.sm[SM_TT] + m0);
+      ttgpr1_t = load_t<NT>(g, a.sm[SM_TTGPR] + m1);
+    }
     const Mat<NT> Q_t = TNacc<NT>(g, a_c, ttgp1_t, TN<NT>(g, gr0_c, bn_t));  // iet(new) G r[n0] + tG ier
     Mat<NT> an_t = add<NT>(a_t, TNacc<NT>(g, t0_c, Q_t, TN<NT>(g, V_c, ttgpr1_t)));
     if (fuseD) {  // apply_D_matrix_IE!, corrected indexing (D2)
@@ -740,31 +792,70 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair
   const int wave = threadIdx.x >> 6;
   const size_t NN = (size_t)a.P * a.P, VS = a.P;  // block strides (padded pitch)
   const size_t npairs = (size_t)(a.n1_hi - a.n1_lo) * a.nR;
-  for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += (size_t)gridDim.x * kWavesPerBlock) {
-    const int n1 = a.n1_lo + (int)(p % (size_t)(a.n1_hi - a.n1_lo)), dn = (int)(p / (size_t)(a.n1_hi - a.n1_lo));
+  // software pipeline of the interface-11 case (one-tile images), as in k_dbl_pair: the first operand tiles of pair
+  // p + stride are requested before pair p is computed
+  constexpr bool PIPE = (NT == 1) && MOMR_PIPELINE;
+  struct Pre {
+    Mat<NT> a_raw, bm_raw, E_t, C_t;   // the pair's own blocks of the 4-D arrays (HBM streams); the per-point operands are L2-hot
+    CV<NT> Jap, Jam, Jcp, Jcm;
+    bool have;
+  } nx;
+  nx.have = false;
+  const size_t stride = (size_t)gridDim.x * kWavesPerBlock, span = (size_t)(a.n1_hi - a.n1_lo);
+  auto raw_a = [&](size_t q4) { return SURF ? zeros<NT>() : load_t<NT>(g, a.ie_a[R_MP] + q4); };
+  auto raw_bm = [&](size_t q4) { return SURF ? zeros<NT>() : load_t<NT>(g, a.ie_a[DERIVE ? T_PP : T_MM] + q4); };
+  auto prefetch = [&](size_t q) {
+    nx.have = false;
+    if (!PIPE || iface != 3 || q >= npairs) return;
+    const int qn1 = a.n1_lo + (int)(q % span), qdn = (int)(q / span);
+    const int qn0 = qn1 + a.off[qdn];
+    if (qn0 < 0 || qn0 >= a.S) return;
+    const size_t qu = (size_t)qn1 + (size_t)a.S * qdn, q4 = NN * qu, q3 = VS * qu;
+    nx.Jap = SURF ? czeros<NT>() : loadC<NT>(g, a.ie_a[J0P] + q3);
+    nx.Jam = SURF ? czeros<NT>() : loadC<NT>(g, a.ie_a[J0M] + q3);
+    nx.Jcp = loadC<NT>(g, a.ie_c[C_J0P] + q3);
+    nx.Jcm = loadC<NT>(g, a.ie_c[C_J0M] + q3);
+    nx.a_raw = raw_a(q4);
+    nx.bm_raw = raw_bm(q4);
+    nx.E_t = load_t<NT>(g, a.ie_c[C_R_PM] + q4);
+    nx.C_t = load_t<NT>(g, a.ie_c[C_T_PP] + q4);
+    nx.have = true;
+  };
+  prefetch((size_t)blockIdx.x * kWavesPerBlock + wave);
+  for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += stride) {
+    const int n1 = a.n1_lo + (int)(p % span), dn = (int)(p / span);
     const int n0 = n1 + a.off[dn];
-    if (n0 < 0 || n0 >= a.S) continue;
+    if (n0 < 0 || n0 >= a.S) {
+      if (PIPE) prefetch(p + stride);
+      continue;
+    }
     const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = VS * u;
     const size_t m1 = NN * n1, m0 = NN * n0, v0 = VS * n0;
+    auto flip_pm = [&](Mat<NT> X) {  // ier+- = sgn (.) ier-+, iet-- = sgn (.) iet++ (corrected D2)
+      if (a.nS > 1)
+        map_t<NT>(g, X, [&](int i, int j, double v) { return dsgn(scomp(i, a.nS, a.strict_idx), scomp(j, a.nS, a.strict_idx)) * v; });
+      return X;
+    };
     auto ldA = [&](int which) {
       if (SURF) return zeros<NT>();
-      if (DERIVE && (which == T_MM || which == R_PM)) {  // ier+- = sgn (.) ier-+, iet-- = sgn (.) iet++ (corrected D2)
-        Mat<NT> X = load_t<NT>(g, a.ie_a[which == T_MM ? T_PP : R_MP] + o4);
-        if (a.nS > 1)
-          map_t<NT>(g, X, [&](int i, int j, double v) { return dsgn(scomp(i, a.nS, a.strict_idx), scomp(j, a.nS, a.strict_idx)) * v; });
-        return X;
-      }
+      if (DERIVE && (which == T_MM || which == R_PM)) return flip_pm(load_t<NT>(g, a.ie_a[which == T_MM ? T_PP : R_MP] + o4));
       return load_t<NT>(g, a.ie_a[which] + o4);
     };
-    const CV<NT> Jap = SURF ? czeros<NT>() : loadC<NT>(g, a.ie_a[J0P] + o3), Jam = SURF ? czeros<NT>() : loadC<NT>(g, a.ie_a[J0M] + o3);
-    const CV<NT> Jcp = loadC<NT>(g, a.ie_c[C_J0P] + o3), Jcm = loadC<NT>(g, a.ie_c[C_J0M] + o3);   // ieJ0+- added / composite
+    const bool pre = PIPE && nx.have;   // (nx is only ever filled for iface == 3)
+    const CV<NT> Jap = pre ? nx.Jap : (SURF ? czeros<NT>() : loadC<NT>(g, a.ie_a[J0P] + o3));
+    const CV<NT> Jam = pre ? nx.Jam : (SURF ? czeros<NT>() : loadC<NT>(g, a.ie_a[J0M] + o3));
+    const CV<NT> Jcp = pre ? nx.Jcp : loadC<NT>(g, a.ie_c[C_J0P] + o3);   // ieJ0+- added / composite
+    const CV<NT> Jcm = pre ? nx.Jcm : loadC<NT>(g, a.ie_c[C_J0M] + o3);
     if (iface == 3) {
-      const Mat<NT> a_t = ldA(R_MP), bm_t = ldA(T_MM);
-      const Mat<NT> E_t = load_t<NT>(g, a.ie_c[C_R_PM] + o4), C_t = load_t<NT>(g, a.ie_c[C_T_PP] + o4);
-      const Mat<NT> a_c = transpose<NT>(g, a_t), bm_c = transpose<NT>(g, bm_t);
-      const Mat<NT> E_c = transpose<NT>(g, E_t), C_c = transpose<NT>(g, C_t);
+      const Mat<NT> a_t = pre ? nx.a_raw : raw_a(o4);
+      Mat<NT> bm_t = pre ? nx.bm_raw : raw_bm(o4);
+      if (DERIVE && !SURF) bm_t = flip_pm(bm_t);
+      const Mat<NT> E_t = pre ? nx.E_t : load_t<NT>(g, a.ie_c[C_R_PM] + o4), C_t = pre ? nx.C_t : load_t<NT>(g, a.ie_c[C_T_PP] + o4);
       const Mat<NT> T01_t = load_t<NT>(g, a.sm[SI_T01] + m1), r1_t = load_t<NT>(g, a.x[R_MP] + m1);
       const Mat<NT> Rpm0_c = load_t<NT>(g, a.sm[SI_RPM] + m0), Tpp0_c = load_t<NT>(g, a.sm[SI_TPP] + m0);
+      if (PIPE) prefetch(p + stride);
+      const Mat<NT> a_c = transpose<NT>(g, a_t), bm_c = transpose<NT>(g, bm_t);
+      const Mat<NT> E_c = transpose<NT>(g, E_t), C_c = transpose<NT>(g, C_t);
       // A = T01 (ier R+-[n0] + r ieR+-) + ieT--                                                                  :252-262
       const Mat<NT> M1_c = TNacc<NT>(g, r1_t, E_c, TN<NT>(g, a_t, Rpm0_c));
       const Mat<NT> A_t = TNacc<NT>(g, M1_c, T01_t, load_t<NT>(g, a.ie_c[C_T_MM] + o4));

@@ -30,7 +30,10 @@ constexpr int kStripMaxP = MOM_STRIP_MAXP;  // series terms up to which the Horn
 constexpr int kStripGroups = kWaves / 4;
 // k-steps whose A fragments the scheduler may have in flight at once (a scheduling barrier every kStripChunk steps):
 // without it it hoists most of a product's 60 LDS reads to the front, 120 VGPRs that the fused kernel does not have
-constexpr int kStripChunk = 4;
+#ifndef MOM_STRIP_CHUNK
+#define MOM_STRIP_CHUNK 4
+#endif
+constexpr int kStripChunk = MOM_STRIP_CHUNK;
 
 // composite blocks are touched once per launch: streaming (non-temporal) accesses keep them from evicting the
 // phase-matrix bases, which every unit re-reads, from L2
@@ -231,6 +234,9 @@ __device__ __forceinline__ void doubling_step_strip(Ctx &c, int p, real expk, co
   const real *P = c.P;
   r4 Rn[NT], Tn[NT];
   real aw = 0.0;
+#ifdef MOM_CHAIN_PRIO
+  if (active) __builtin_amdgcn_s_setprio(MOM_CHAIN_PRIO);  // experiment (profiles/r04_C2_ab.txt): static priority of the chain waves
+#endif
   if (active) {
     // riding rows of the multiplier r^T: w1 = j1- + r j0+, w2 = j0+ + r j1-  (doubling.jl:51-60); every strip wave
     // writes the same values, so each reads back its own writes in order
@@ -287,6 +293,9 @@ __device__ __forceinline__ void doubling_step_strip(Ctx &c, int p, real expk, co
     for (int i = tid4; i < N; i += TH) Q[i + N * LD] = pre->J0p[i];
   }
   if (pre != nullptr && kWaves == 8) c.qpre = 1;
+#endif
+#ifdef MOM_CHAIN_PRIO
+  if (active) __builtin_amdgcn_s_setprio(0);
 #endif
   MOM_STAMP(71);
   __syncthreads();
