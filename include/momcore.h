@@ -198,6 +198,9 @@ int mom_rt_run_rrs(mom_t *h);
 int mom_get_RT_rrs(mom_t *h, double *R_SFI, double *T_SFI, double *ieR_SFI, double *ieT_SFI, double *gpu_ms);
 int mom_get_hdr_rrs(mom_t *h, double *hdr, double *bhr_uw, double *bhr_dw);
 int mom_rrs_timers(mom_t *h, double *ms, int *launches, int n);
+/* test access: number of nonzero entries in the zero padding of the handle's RRS layer arrays (device blocks are padded to the
+ * MFMA tiling and the kernels store whole tiles: the padding must stay zero by value); 0 = intact */
+int mom_rrs_check_padding(mom_t *h, unsigned long long *violations);
 size_t mom_rrs_spectra_count(mom_t *h, int per);
 int mom_get_spectra_rrs_device(mom_t *h, int per, void *d_local);
 int mom_allgather_rrs_device(mom_t *h, int per, void *d_global);

@@ -101,6 +101,7 @@ SIGNATURES = {
     "mom_comm_init": (C.c_int, [c_h, C.c_int, C.c_int, C.c_void_p]),
     "mom_comm_destroy": (C.c_int, [c_h]),
     "mom_allgather": (C.c_int, [c_h, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mom_rrs_check_padding": (C.c_int, [c_h, C.POINTER(C.c_ulonglong)]),
     "mom_rrs_spectra_count": (C.c_size_t, [c_h, C.c_int]),
     "mom_get_spectra_rrs_device": (C.c_int, [c_h, C.c_int, C.c_void_p]),
     "mom_allgather_rrs_device": (C.c_int, [c_h, C.c_int, C.c_void_p]),
@@ -309,6 +310,12 @@ class Handle:
         self.check(self.lib.mom_get_hdr_rrs(self._h, dp(H), dp(up), dp(dw)))
         return (np.transpose(H.reshape(self.S, self.nS, self.nVza), (2, 1, 0)).copy(), up.reshape(self.S, self.nS).T.copy(),
                 dw.reshape(self.S, self.nS).T.copy())
+
+    def rrs_check_padding(self) -> int:
+        """Nonzero entries in the zero padding of the RRS layer arrays (0 = the whole-tile stores kept the invariant)."""
+        v = C.c_ulonglong(0)
+        self.check(self.lib.mom_rrs_check_padding(self._h, C.byref(v)))
+        return int(v.value)
 
     def rrs_spectra_count(self, per: int) -> int:
         return int(self.lib.mom_rrs_spectra_count(self._h, int(per)))

@@ -71,6 +71,10 @@ constexpr int kWavesPerBlock = 4;
 #define MOMR_WPE 2
 #endif
 #define MOMR_PAIR_ATTR __attribute__((amdgpu_waves_per_eu(MOMR_WPE, MOMR_WPE)))
+#ifndef MOMR_WPE2
+#define MOMR_WPE2 1
+#endif
+#define MOMR_PAIR_ATTR2 __attribute__((amdgpu_waves_per_eu(MOMR_WPE2, MOMR_WPE2)))
 // software pipeline of the pair kernels' operand loads (next pair requested before the current one is computed): measured
 // SLOWER on C5 (profiles/r04_C5_ab.txt: k_dbl_pair 160 -> 169 ms, k_int_pair 84 -> 119 ms per run) -- the kernels are
 // bound by instruction issue, not by the latency of their first loads; kept as an experiment switch
@@ -474,7 +478,7 @@ __device__ __forceinline__ void ie_elem_tile(const Geo &g, const KArgs &a, int n
 // MODE: 0 corrected position, not the last step; 1 corrected, last step (D2 / D3 folded into the stores); 2 strict position.
 // The mode is a template parameter like FUSE: as run-time flags these branches cost a register move per tile element.
 template <int NT, bool FUSE, int MODE>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair(KArgs a) {
+__device__ __forceinline__ void dbl_pair_body(const KArgs &a) {
   constexpr bool STRICT = (MODE == 2);
   const Geo g = make_geo<NT>(a.N, rrs_smem);
   const int n = a.nS, wave = threadIdx.x >> 6;
@@ -629,6 +633,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair
     store_t<NT>(g, a.ie_a[T_PP] + o4, bn_t);
   }
 }
+
+// The kernel images: the one-tile form at MOMR_WPE waves per SIMD (256 registers), the 2 x 2-tile form at MOMR_WPE2 (its ~320
+// live registers spill to scratch at 256; at one wave per SIMD the register file holds them)
+template <int NT, bool FUSE, int MODE, std::enable_if_t<NT == 1, int> = 0>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair(KArgs a) { dbl_pair_body<NT, FUSE, MODE>(a); }
+template <int NT, bool FUSE, int MODE, std::enable_if_t<NT == 2, int> = 0>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_dbl_pair(KArgs a) { dbl_pair_body<NT, FUSE, MODE>(a); }
 
 // apply_D_IE_RRS! / apply_D_SFI_IE_RRS! as written (doubling_inelastic.jl:291-311, :345-357), strict position: the work
 // item (n, dn) addresses the RAMAN axis with n0 = n + i_l1l0[dn] (1-based) when 1 <= n0 <= nRaman.  One thread per
@@ -787,7 +798,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_int_point(KArgs a, int 
 // interaction, PAIR kernel.  SURF: the added layer is the surface (all its ie* arrays are zeros and never read).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NT, bool SURF, bool DERIVE>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair(KArgs a, int iface) {
+__device__ __forceinline__ void int_pair_body(const KArgs &a, int iface) {
   const Geo g = make_geo<NT>(a.N, rrs_smem);
   const int wave = threadIdx.x >> 6;
   const size_t NN = (size_t)a.P * a.P, VS = a.P;  // block strides (padded pitch)
@@ -923,6 +934,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair
     }
   }
 }
+
+template <int NT, bool SURF, bool DERIVE, std::enable_if_t<NT == 1, int> = 0>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair(KArgs a, int iface) { int_pair_body<NT, SURF, DERIVE>(a, iface); }
+template <int NT, bool SURF, bool DERIVE, std::enable_if_t<NT == 2, int> = 0>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_int_pair(KArgs a, int iface) { int_pair_body<NT, SURF, DERIVE>(a, iface); }
 
 // create_surface_layer! into the surface layer arrays: kind 0 LambertianSurfaceScalar (Surfaces/lambertian_surface.jl:20-75),
 // 1 any BRDF type through its Fourier matrix Rsurf [N,N] of this moment (rpv_surface.jl:20-66), 2 LambertianSurfaceLegendre
@@ -1353,6 +1369,43 @@ hipError_t surface(State *s, const Streams &q, int m, int kind, double albedo, c
   for (int k = 0; k < 6; ++k) a.x[k] = s->surf[k];
   hipLaunchKernelGGL(k_surface_fill, dim3(s->S), dim3(256), 0, s->stream, a, tau_tot, kind, Rsurf_m, albedo_spec);
   return hipGetLastError();
+}
+
+// Invariant of the padded device layout (mom_tile.hpp: whole-tile stores): every entry of a layer block outside the
+// N x N (or N) part is an exact zero.  Counts the violations over all layer arrays (test access: mom_rrs_check_padding).
+__global__ void k_count_padding(const double *p, int N, int P, int matrix, size_t nblk, unsigned long long *cnt) {
+  const size_t bs = matrix ? (size_t)P * P : (size_t)P, tot = bs * nblk;
+  unsigned long long mine = 0;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t w = e % bs;
+    const int i = (int)(w % P), j = (int)(w / P);
+    if ((i >= N || (matrix && j >= N)) && p[e] != 0.0) ++mine;   // NaN counts as well
+  }
+  if (mine) atomicAdd(cnt, mine);
+}
+hipError_t count_padding(State *s, unsigned long long *out) {
+  unsigned long long *d = nullptr;
+  RCHK(hipMalloc(reinterpret_cast<void **>(&d), sizeof(unsigned long long)));
+  RCHK(hipMemsetAsync(d, 0, sizeof(unsigned long long), s->stream));
+  auto scan = [&](const double *p, bool matrix, size_t nblk) {
+    if (p) hipLaunchKernelGGL(k_count_padding, dim3(1024), dim3(256), 0, s->stream, p, s->N, s->P, matrix ? 1 : 0, nblk, d);
+  };
+  const size_t S = s->S, SR = S * (size_t)s->nR;
+  for (int b = 0; b < 2; ++b)
+    for (int k = 0; k < 6; ++k) {
+      if (!(b == 1 && (k == R_PM || k == T_MM))) scan(s->added[b][k], k < 4, S);
+      scan(s->comp[b][k], k < 4, S);
+    }
+  for (int k = 0; k < 6; ++k) {
+    scan(s->surf[k], k < 4, S);
+    scan(s->ie_added[k], k < 4, SR);
+    scan(s->ie_comp[k], k < 4, SR);
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+  (void)hipFree(d);
+  return e;
 }
 
 // rt_run allocates its added / composite / surface layers zeroed on every call (rt_run.jl:108-116: make_added_layer /

@@ -99,6 +99,8 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
 // (albedo), 1 BRDF Fourier matrix Rsurf_m [N,N] of moment m (device), 2 LambertianSurfaceLegendre (albedo_spec [S], device)
 hipError_t surface(State *s, const Streams &q, int m, int kind, double albedo, const double *tau_tot, const double *Rsurf_m,
                    const double *albedo_spec);
+// number of nonzero (or NaN) entries in the zero padding of all layer arrays (the invariant the whole-tile stores rest on)
+hipError_t count_padding(State *s, unsigned long long *out);
 // start of a scene-level run: zeroed layers where needed (State::dirty, strict position), double-buffer / pm flags reset,
 // output block zeroed (postprocessing_vza!(::RRS) accumulates into s->d_out)
 hipError_t begin_run(State *s, int nVza);

@@ -133,14 +133,22 @@ __device__ __forceinline__ Vec<NT> swap01(const Vec<NT> &v) {  // exchange colum
 
 // Device blocks are stored at the pitch of the tiling, 16 NT, with ZERO padding (matrices 16 NT x 16 NT, vectors 16 NT):
 // the loads below carry no edge masks (the padding reads as the zeros a mask would have put there), their addresses are
-// one per-lane base plus immediates and every 16-lane row is one aligned 128-byte line; the stores keep the masks, so
-// the padding is never written (mom_rrs.hpp State::P).  Measured on the N = 16 RRS scene: 315 -> 275 ms per run.
-// The stores of the one-tile kernels (NT = 1, the reference's RRS shape N = 15) write the whole tile: every stored quantity
-// is a product / sum / sign flip of zero-padded operands or is built with its own i, j < N guards, so the padding stays zero by
-// value (C5: 331 -> 313 ms per run).  The 2 x 2-tile kernels keep masked stores: with unmasked ones k_dbl_pair<2, .> raised a
-// GPU memory fault at an address far from every buffer (scratch addressing of the 256-register image; not understood).
+// one per-lane base plus immediates and every 16-lane row is one aligned 128-byte line (mom_rrs.hpp State::P).  Measured on
+// the N = 16 RRS scene: 315 -> 275 ms per run.
+// The stores write the whole tile as well: every stored quantity is a product / sum / sign flip of zero-padded operands or
+// is built with its own i, j < N guards, so the padding stays zero by value (C5: 331 -> 313 ms per run) -- an invariant that
+// mom_rrs_check_padding counts violations of and tests/test_gpu_rrs.py::test_rrs_zero_padding_invariant asserts for N = 15,
+// 20, 27, 32 in both switch positions.  Round 3 kept masked stores in the 2 x 2-tile kernels because an unmasked build had
+// raised a GPU memory fault there; in round 4 that build (-DMOMR_UNMASK2 at the time) passes all 106 RRS tests, the padding
+// check and the NT = 2 stress scenes (profiles/r04_C5_ab.txt), so the fault belonged to an intermediate state of the r3
+// layout change, not to the stores.  -DMOMR_MASK2 restores the masked form.
+#ifdef MOMR_MASK2
 template <int NT>
 __device__ __forceinline__ constexpr bool mask_store() { return NT > 1; }
+#else
+template <int NT>
+__device__ __forceinline__ constexpr bool mask_store() { return false; }
+#endif
 // column-major [N, N] block at pitch 16 NT -> X_t (coalesced) / X_c (strided)
 template <int NT>
 __device__ __forceinline__ Mat<NT> load_t(const Geo &g, const double *p) {

@@ -2772,6 +2772,16 @@ extern "C" int mom_allgather_rrs_device(mom_t *h, int per, void *d_global) {
   return mom_allgather(h, h->d_rrs_send, d_global, cnt);
 }
 
+// test access: violations of the zero-padding invariant of the RRS layer arrays (mom_rrs.hip count_padding); 0 = intact
+extern "C" int mom_rrs_check_padding(mom_t *h, unsigned long long *violations) {
+  int rc = rrs_ready(h, "mom_rrs_check_padding");
+  if (rc) return rc;
+  if (!violations) return fail(h, MOM_EINVAL, "mom_rrs_check_padding: null output");
+  RRSCHK(h, momr::ensure_pm(h->rrs, rrs_streams(h)));
+  RRSCHK(h, momr::count_padding(h->rrs, violations));
+  return MOM_OK;
+}
+
 extern "C" int mom_rrs_timers(mom_t *h, double *ms, int *launches, int n) {
   int rc = rrs_ready(h, "mom_rrs_timers");
   if (rc) return rc;

@@ -342,3 +342,29 @@ def test_rrs_empty_owned_range(rtamd):
             h.rt_run_rrs()
             R, T, ieR, ieT = h.get_RT_rrs()[:4]
         assert not np.any(ieR) and not np.any(ieT) and not np.any(R) and not np.any(T)
+
+
+@pytest.mark.parametrize("nS,lt,nv", [(3, 5, 1), (4, 5, 1), (3, 11, 3), (4, 9, 3)])   # N = 15, 20 (one view), 27, 32
+@pytest.mark.parametrize("strict", [True, False])
+def test_rrs_zero_padding_invariant(rtamd, nS, lt, nv, strict):
+    """The device blocks of the RRS layers are zero-padded to the MFMA tiling (16 x 16 at N <= 16, 32 x 32 above) and the kernels
+    store WHOLE tiles: every stored quantity must keep the padding at exact zeros.  mom_rrs_check_padding counts
+    the violations over all layer arrays after a scene-level run (which goes through every kernel of the path)."""
+    rt = rtamd.corert
+    m = rtamd.scenes.make_scene(nS, lt, 3, 26, seed=2 + nS + lt, aerosol_total=0.1, **VIEWS[nv])
+    RS, _ = _rrs_inputs(rtamd, [-4, -1, 2, 7, 3], strict)
+    model = rt._with_cabannes(RS, m)
+    sc = rtamd.prepare_scene(model)
+    Zr_pp, Zr_mp = rt.raman_z(RS, model)
+    fs = rt.fscatt_rayleigh(model)
+    with rt.make_handle(model) as h:
+        h.set_option(rtamd._lib.MOM_OPT_STRIP_PAD, 0)
+        h.rrs_set(RS.i_λ1λ0, RS.ϖ_λ1λ0, strict)
+        assert h.rrs_check_padding() == 0
+        rt.scene_set(h, sc)
+        h.scene_set_rrs(np.ascontiguousarray(fs.T), rt._abi_mats(Zr_pp), rt._abi_mats(Zr_mp))
+        h.rt_run_rrs()
+        assert np.abs(h.get_RT_rrs()[2]).max() > 0
+        assert h.rrs_check_padding() == 0
+        h.rt_run_rrs()
+        assert h.rrs_check_padding() == 0

@@ -3,7 +3,7 @@
 # (FETCH_SIZE and WRITE_SIZE in separate passes, MFMA-busy in a third: MI355X_MICROARCH.md, rocprofv3 PMC slots; never
 # combined with a trace domain other than --kernel-trace).  Output goes to gpurun_out/<round>_*;
 # tools/summarize_profiles.py turns it into profiles/.
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
@@ -26,4 +26,7 @@ python3 bench.py --workload C1 > $O/${ROUND}_bench_C1.json 2> /dev/null
 python3 bench.py --workload C5 > $O/${ROUND}_bench_C5.json 2> /dev/null
 python3 bench.py --workload C3 --no-cpu-baseline > $O/${ROUND}_bench_C3.json 2> /dev/null
 python3 bench.py --gpus 2 --backend gloo --share-device --no-voigt > $O/${ROUND}_bench_2ranks_one_gpu.json 2> /dev/null
+python3 bench.py --workload C3 --scaling strong --gpus 2 --backend gloo --share-device --no-cpu-baseline > $O/${ROUND}_bench_C3_strong_2ranks_one_gpu.json 2> /dev/null
+python3 bench.py --workload C5 --gpus 2 --backend gloo --share-device --no-cpu-baseline > $O/${ROUND}_bench_C5_2ranks_one_gpu.json 2> /dev/null
+python3 tools/size_sweep.py > $O/${ROUND}_size_sweep.txt 2> /dev/null
 echo collected
