@@ -85,8 +85,8 @@ def hitran_table(cols: dict) -> HitranTable:
 
 # ------------------------------------------------------------------------------------------
 # TIPS-2017 partition sums and isotopologue weights (constants/TIPS_2017.jl, mol_weights.jl).
-# The tables are the reference's NetCDF files, extracted for HITRAN molecules 1-7 by
-# tools/extract_tips.py into data/tips_2017_subset.npz (Float32 like the originals).
+# The tables are the reference's NetCDF files, extracted for every HITRAN molecule they cover (ids 1-49, 157 (molecule,
+# isotopologue) pairs; rounds 1-3 shipped ids 1-7) by tools/extract_tips.py into data/tips_2017_subset.npz (Float32 like the originals).
 # ------------------------------------------------------------------------------------------
 
 _TIPS = None
@@ -201,8 +201,8 @@ def line_prefactors(h: HitranTable, grid: np.ndarray, pressure: float, temperatu
     `sqrt(mol_weight(mol, iso))` evaluates), y, the TIPS-2017 temperature correction of the strength (`qoft!`) and the
     index window each line touches (linear interpolation of grid -> index with the reference's constant fill values outside
     the grid -- 1 for the start, n for the stop, on either side -- rounded half-to-even like Julia's `round`).  `qratio` overrides the partition-sum ratio (a callable of T); default = the reference's qoft.
-    `mol_weights` {(mol, iso): g/mol} supplies isotopologue weights for molecules outside the bundled TIPS subset
-    (HITRAN molecules 1-7; the full tables are extracted by tools/extract_tips.py from the reference's NetCDF files)."""
+    `mol_weights` {(mol, iso): g/mol} supplies isotopologue weights for (molecule, isotopologue) pairs the bundled tables do
+    not hold (they cover HITRAN molecules 1-49 as the reference's NetCDF files do; tools/extract_tips.py)."""
     grid = np.asarray(grid, dtype=np.float64)
     temperature = float(temperature)
     keep = (grid.min() - wing_cutoff < h.νᵢ) & (h.νᵢ < grid.max() + wing_cutoff)
@@ -223,9 +223,9 @@ def line_prefactors(h: HitranTable, grid: np.ndarray, pressure: float, temperatu
             try:
                 w = mol_weight(M, I)
             except KeyError as e:
-                raise KeyError(f"no isotopologue weight for HITRAN molecule {M}, isotopologue {I}: the bundled TIPS subset covers "
-                               "molecules 1-7; pass mol_weights={(mol, iso): g_per_mol} (and qratio=) or extend "
-                               "data/tips_2017_subset.npz with tools/extract_tips.py") from e
+                raise KeyError(f"no isotopologue weight for HITRAN molecule {M}, isotopologue {I}: the bundled TIPS-2017 tables (HITRAN "
+                               "molecules 1-49, as in the reference) do not hold this pair; pass mol_weights={(mol, iso): g_per_mol} "
+                               "(and qratio=)") from e
         sqw[sel] = np.float64(np.sqrt(w))  # Float32 sqrt, then promoted
         if np.any(E[sel] != -1):
             rate[sel] = qratio(temperature) if qratio is not None else qoft(M, I, temperature, t_ref)

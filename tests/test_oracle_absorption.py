@@ -99,3 +99,15 @@ def test_spline_reproduces_nodes_and_is_smooth(rtamd):
     xs = np.linspace(150.0, 350.0, 41)
     q = np.array([sp(x) for x in xs])
     assert np.all(np.diff(q) > 0)  # partition sums grow with temperature
+
+
+def test_tips_tables_cover_every_molecule_of_the_reference(rtamd):
+    """The bundled TIPS-2017 / isotopologue tables hold every HITRAN molecule of the reference's NetCDF files (ids 1-49, 157
+    (molecule, isotopologue) pairs): qoft! and mol_weight work beyond the first seven molecules (CH3Cl = 24, HCN = 23, NH3 = 11)."""
+    ab = rtamd.absorption
+    tab = absref.tables()
+    assert list(tab["molecules"]) == list(range(1, 50)) and len(tab["pairs"]) == 157
+    for M, I in ((11, 1), (23, 1), (24, 2), (26, 1)):
+        q_prod, q_ora = ab.qoft(M, I, 250.0, 296.0), absref.qoft(M, I, 250.0, 296.0)
+        assert 1.0 < q_prod < 5.0 and abs(q_prod - q_ora) <= 1e-9 * q_ora
+        assert float(ab.mol_weight(M, I)) == float(absref.mol_weight(M, I)) > 10.0
