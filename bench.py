@@ -260,7 +260,7 @@ def elastic_leg(a, workload, S_loc, steps, warmup, world, rank, dev, dist, with_
                     # `traffic` and `hw_mfma_busy_frac` are NOT measured in this run: they are the PMC figures of the
                     # committed collection named here (rocprofv3 --pmc passes cannot run inside the timed bench)
                     "pmc_source": ("profiles/traffic.json: " + prof.get("source", prof.get("round", "?"))) if prof else None,
-                    "traffic_step_all_launches": prof.get("hbm_bytes_per_step_all_launches")}
+                    "traffic_all_launches_of_the_pmc_pass": prof.get("hbm_bytes_all_launches_of_the_pass")}
         names = {"C2": "O2-A band IQU scene", "C3": "OCO-2-style 3-band IQU scene (BASELINE configs[2])"}
         out = {
             "metric": f"spectral points/sec (whole node), {names.get(workload, workload + ' scene')}",
@@ -390,7 +390,7 @@ def c5_leg(a, S, steps, warmup, dev, with_cpu=True, world=1, rank=0, dist=None):
                           f"(rank 0 window: {whi - wlo} points)",
                           "collective": collective},
                "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                            "traffic": prof.get("hbm_bytes_per_launch"), "kernel": "momr::k_dbl_pair<1>",
+                            "traffic": prof.get("hbm_bytes_per_launch"), "kernel": "momr::k_dbl_pair1<FUSE, MODE> (one-tile doubling pair kernel)",
                             "pmc_source": ("profiles/traffic.json: " + prof.get("source", prof.get("round", "?"))) if prof else None,
                             "avg_launch_ms": avg, "launches_per_step": nl, "pairs_per_launch": pairs,
                             "algorithmic_bytes_per_pair": bytes_pair, "algorithmic_bytes_per_avg_launch": pairs * bytes_pair},

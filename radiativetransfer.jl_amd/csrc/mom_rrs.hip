@@ -636,10 +636,10 @@ __device__ __forceinline__ void dbl_pair_body(const KArgs &a) {
 
 // The kernel images: the one-tile form at MOMR_WPE waves per SIMD (256 registers), the 2 x 2-tile form at MOMR_WPE2 (its ~320
 // live registers spill to scratch at 256; at one wave per SIMD the register file holds them)
-template <int NT, bool FUSE, int MODE, std::enable_if_t<NT == 1, int> = 0>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair(KArgs a) { dbl_pair_body<NT, FUSE, MODE>(a); }
-template <int NT, bool FUSE, int MODE, std::enable_if_t<NT == 2, int> = 0>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_dbl_pair(KArgs a) { dbl_pair_body<NT, FUSE, MODE>(a); }
+template <bool FUSE, int MODE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair1(KArgs a) { dbl_pair_body<1, FUSE, MODE>(a); }
+template <bool FUSE, int MODE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_dbl_pair2(KArgs a) { dbl_pair_body<2, FUSE, MODE>(a); }
 
 // apply_D_IE_RRS! / apply_D_SFI_IE_RRS! as written (doubling_inelastic.jl:291-311, :345-357), strict position: the work
 // item (n, dn) addresses the RAMAN axis with n0 = n + i_l1l0[dn] (1-based) when 1 <= n0 <= nRaman.  One thread per
@@ -935,10 +935,10 @@ __device__ __forceinline__ void int_pair_body(const KArgs &a, int iface) {
   }
 }
 
-template <int NT, bool SURF, bool DERIVE, std::enable_if_t<NT == 1, int> = 0>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair(KArgs a, int iface) { int_pair_body<NT, SURF, DERIVE>(a, iface); }
-template <int NT, bool SURF, bool DERIVE, std::enable_if_t<NT == 2, int> = 0>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_int_pair(KArgs a, int iface) { int_pair_body<NT, SURF, DERIVE>(a, iface); }
+template <bool SURF, bool DERIVE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair1(KArgs a, int iface) { int_pair_body<1, SURF, DERIVE>(a, iface); }
+template <bool SURF, bool DERIVE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_int_pair2(KArgs a, int iface) { int_pair_body<2, SURF, DERIVE>(a, iface); }
 
 // create_surface_layer! into the surface layer arrays: kind 0 LambertianSurfaceScalar (Surfaces/lambertian_surface.jl:20-75),
 // 1 any BRDF type through its Fourier matrix Rsurf [N,N] of this moment (rpv_surface.jl:20-66), 2 LambertianSurfaceLegendre
@@ -1275,7 +1275,7 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
     {
       const dim3 gr(grid_pairs(s)), bl(64 * kWavesPerBlock);
       const int mode = s->strict_rrs ? 2 : (a.last ? 1 : 0);
-#define DBL_PAIR(NT_, FUSE_, MODE_) hipLaunchKernelGGL((k_dbl_pair<NT_, FUSE_, MODE_>), gr, bl, lds<NT_>(), s->stream, a)
+#define DBL_PAIR(NT_, FUSE_, MODE_) hipLaunchKernelGGL((k_dbl_pair##NT_<FUSE_, MODE_>), gr, bl, lds<NT_>(), s->stream, a)
 #define DBL_PAIR_M(NT_, FUSE_) do { if (mode == 0) DBL_PAIR(NT_, FUSE_, 0); else if (mode == 1) DBL_PAIR(NT_, FUSE_, 1); else DBL_PAIR(NT_, FUSE_, 2); } while (0)
       if (s->N <= 16) {
         if (a.fuse_el) DBL_PAIR_M(1, true); else DBL_PAIR_M(1, false);
@@ -1347,13 +1347,13 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
     RCHK(tick(s, TK_INT_PAIR, true));
     const dim3 gr(grid_pairs(s)), bl(64 * kWavesPerBlock);
     if (s->N <= 16) {
-      if (with_surface) hipLaunchKernelGGL((k_int_pair<1, true, false>), gr, bl, lds<1>(), s->stream, a, iface);
-      else if (a.derive_pm) hipLaunchKernelGGL((k_int_pair<1, false, true>), gr, bl, lds<1>(), s->stream, a, iface);
-      else hipLaunchKernelGGL((k_int_pair<1, false, false>), gr, bl, lds<1>(), s->stream, a, iface);
+      if (with_surface) hipLaunchKernelGGL((k_int_pair1<true, false>), gr, bl, lds<1>(), s->stream, a, iface);
+      else if (a.derive_pm) hipLaunchKernelGGL((k_int_pair1<false, true>), gr, bl, lds<1>(), s->stream, a, iface);
+      else hipLaunchKernelGGL((k_int_pair1<false, false>), gr, bl, lds<1>(), s->stream, a, iface);
     } else {
-      if (with_surface) hipLaunchKernelGGL((k_int_pair<2, true, false>), gr, bl, lds<2>(), s->stream, a, iface);
-      else if (a.derive_pm) hipLaunchKernelGGL((k_int_pair<2, false, true>), gr, bl, lds<2>(), s->stream, a, iface);
-      else hipLaunchKernelGGL((k_int_pair<2, false, false>), gr, bl, lds<2>(), s->stream, a, iface);
+      if (with_surface) hipLaunchKernelGGL((k_int_pair2<true, false>), gr, bl, lds<2>(), s->stream, a, iface);
+      else if (a.derive_pm) hipLaunchKernelGGL((k_int_pair2<false, true>), gr, bl, lds<2>(), s->stream, a, iface);
+      else hipLaunchKernelGGL((k_int_pair2<false, false>), gr, bl, lds<2>(), s->stream, a, iface);
     }
     RCHK(hipGetLastError());
     RCHK(tick(s, TK_INT_PAIR, false));

@@ -10,9 +10,9 @@ O=$R/gpurun_out
 run() {  # tag, bench args...
   local tag=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${ROUND}_${tag}_stats -o p -- python3 $R/bench.py "$@" --no-cpu-baseline --no-voigt --no-extras > $O/${ROUND}_${tag}_bench_under_rocprof.json 2> /dev/null
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${ROUND}_${tag}_fetch -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${ROUND}_${tag}_write -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1
-  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${ROUND}_${tag}_mfma -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1 || true
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${ROUND}_${tag}_fetch -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${ROUND}_${tag}_write -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${ROUND}_${tag}_mfma -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1 || true
 }
 run C2 --workload C2
 run C4 --workload C4 --points 512 --steps 2

@@ -21,7 +21,7 @@ except Exception:
 out = ROOT / "profiles"
 out.mkdir(exist_ok=True)
 DOMINANT = {"C2": "mom::k_layer<true, 3, 15>", "C4": "mom::k_layer<false, 3, 0>", "C1": "momsm::k_sweep<4>",
-            "C5": "momr::k_dbl_pair<1, false, 0>"}
+            "C5": "momr::k_dbl_pair1<false, 0>"}
 
 
 def newest(pattern):
@@ -66,8 +66,8 @@ for wl in ("C2", "C4", "C1", "C5", "voigt"):
             if not v:
                 return e["mean"], e["sum"]
             ref = kl.get("FETCH_SIZE", e).get("values") or v
-            if max(ref) <= 2 * min(ref):     # similar launches (C5: 51 doubling steps): their mean
-                return e["mean"], e["sum"]
+            if max(ref) <= 2 * min(ref):     # similar launches: the LAST one (after the warm-up step of the counter pass)
+                return v[-1], e["sum"]
             idx = max(range(len(ref)), key=lambda i: ref[i]) if len(ref) == len(v) else max(range(len(v)), key=lambda i: v[i])
             return v[idx], sum(v)
         fmax, fsum = pick("FETCH_SIZE")
@@ -75,13 +75,13 @@ for wl in ("C2", "C4", "C1", "C5", "voigt"):
         if fmax is not None and wmax is not None:
             rd_raw, wr = fmax * 1024, wmax * 1024
             t.update(hbm_bytes_per_launch=2 * rd_raw + wr, fetch_bytes_raw=rd_raw, fetch_bytes_corrected_x2=2 * rd_raw, write_bytes=wr,
-                     hbm_bytes_per_step_all_launches=2 * fsum * 1024 + wsum * 1024, launches_per_step=kl["FETCH_SIZE"]["launches"])
+                     hbm_bytes_all_launches_of_the_pass=2 * fsum * 1024 + wsum * 1024, launches_in_the_pass=kl["FETCH_SIZE"]["launches"])
         bmax, _ = pick("SQ_VALU_MFMA_BUSY_CYCLES")
         gmax, _ = pick("GRBM_GUI_ACTIVE")
         if bmax is not None and gmax:
             t["mfma_busy_frac"] = bmax / (gmax / 8 * 1024)
-        t["note"] = ("the LARGEST launch of the dominant kernel in one bench step where its launches differ by more than 2 x, else "
-                     "their mean (one profiled step per counter pass); FETCH_SIZE "
+        t["note"] = ("the LARGEST launch of the dominant kernel where its launches differ by more than 2 x, else the last one of the "
+                     "counter pass (one warm-up + one profiled step; more than 64 launches: their mean); FETCH_SIZE "
                      "doubled per MI355X_MICROARCH.md; layer-sweep mode: ONE launch of the kernel covers all layers of the step")
         traffic[wl] = t
 (out / f"{rnd}_pmc_summary.json").write_text(json.dumps(summ, indent=1))
