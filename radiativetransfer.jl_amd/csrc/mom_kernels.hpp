@@ -91,8 +91,14 @@ __host__ __device__ inline int ld_for(int N) { return np_for(N) + 2; }
 // columns N, N+1; MFMA B-operand reads of the remaining columns of the last tile (< Np) run past the buffer
 // into whatever follows (finite or not, they only feed output columns that are never stored).
 __host__ __device__ inline int cols_for(int N) {
+#ifdef MOM_REAL_IS_FLOAT
+  // Float32 build: every column of the padded buffers is stored (and zeroed): the Float32 strip chains run all 4 NT k-steps of
+  // a row tile, so the strip rows >= N + 2 (multiplier columns >= N + 2) must be exact zeros, not whatever follows the buffer
+  return np_for(N);
+#else
   const int need = ((N + 3) / 4) * 4 > N + 2 ? ((N + 3) / 4) * 4 : N + 2;
   return need < np_for(N) ? need : np_for(N);
+#endif
 }
 __host__ __device__ inline size_t mat_elems(int N) { return (size_t)ld_for(N) * cols_for(N); }
 constexpr int kNumVec = 15 + 2 * kWaves;  // vectors carved from LDS (part = 2*kWaves vectors)
@@ -167,8 +173,9 @@ template <bool LDSM>
 __device__ __forceinline__ void zero_padding(const Ctx &c) {
   const int N = c.N, Np = c.nc, ld = c.ld;
   // the padding is only ever read as a K index when N is not a multiple of the MFMA K step (4);
-  // otherwise padded rows/columns only feed output rows/columns that are never stored
-  if (LDSM && (N % 4 != 0)) {
+  // otherwise padded rows/columns only feed output rows/columns that are never stored.  Float32: the strip chains reach
+  // every row of the last row tile (mom_strip.hpp, StripGeom::NKS), so the padding is always zeroed
+  if (LDSM && (N % 4 != 0 || !kF64)) {
     const int padr = ld - N;
     for (int e = wg_tid(); e < padr * Np; e += kThreads) {
       const int j = e / padr, i = N + (e - j * padr);
@@ -188,7 +195,7 @@ __device__ __forceinline__ void zero_padding(const Ctx &c) {
 // restore the zero padding of one buffer after it was used as scratch (only matters if N % 4 != 0)
 __device__ __forceinline__ void rezero_padding(const Ctx &c, real *buf) {
   const int N = c.N, Np = c.nc, ld = c.ld;
-  if (N % 4 == 0) return;
+  if (N % 4 == 0 && kF64) return;
   const int padr = ld - N;
   for (int e = wg_tid(); e < padr * Np; e += kThreads) {
     const int j = e / padr, i = N + (e - j * padr);
@@ -398,6 +405,14 @@ __device__ __forceinline__ int neumann_terms(const real *thr, real beta2) {
 
 // the same for p <= 12 without memory: thresholds as immediates (the strip chains' range); 1000 beyond or NaN
 __device__ __forceinline__ int neumann_terms_12(real beta2) {
+#ifdef MOM_REAL_IS_FLOAT
+  if (!(beta2 <= 4.761229038e-02f)) return 1000;
+  int q = 1;
+  q += beta2 > 0.0f; q += beta2 > 1.489934232e-08f; q += beta2 > 6.045524421e-06f; q += beta2 > 1.213959655e-04f;
+  q += beta2 > 7.320204349e-04f; q += beta2 > 2.419753539e-03f; q += beta2 > 5.676200029e-03f; q += beta2 > 1.075029447e-02f;
+  q += beta2 > 1.765854019e-02f; q += beta2 > 2.625958398e-02f; q += beta2 > 3.632882835e-02f;
+  return q;
+#endif
   if (!(beta2 <= 1.53988783074545245e-03)) return 1000;
   int p = 1;
   p += beta2 > 0.0; p += beta2 > 1.38777877561156685e-17; p += beta2 > 5.77492213356056750e-12;

@@ -51,8 +51,30 @@ struct StripGeom {
   static constexpr int NT = (N + 15) / 16;
   static constexpr int LD = 16 * NT + 2;
   static constexpr int CP = 16 * NT;               // row pitch of the scene-level composite blocks (comp_pitch)
-  static constexpr int RT = KS >> 2, RR = KS & 3;  // tile / register of rows N (lanes lq == 0) and N+1 (lq == 1)
+  // The riding rows N and N + 1 of a strip in its accumulators (tile RT).  Float64 layout (row = 16 rt + 4 r + lq): both in
+  // register KS & 3, row N in the lanes lq == 0, row N + 1 in the lanes lq == 1.  Float32 layout (row = 16 rt + 4 lq + r):
+  // both in the lanes lq == (N mod 16) / 4, row N in register 0, row N + 1 in register 1.
+  static constexpr int RT = kF64 ? (KS >> 2) : (N / 16);
+  static constexpr int RR0 = kF64 ? (KS & 3) : 0, RR1 = kF64 ? (KS & 3) : 1;
+  static constexpr int LQ0 = kF64 ? 0 : ((N % 16) / 4), LQ1 = kF64 ? 1 : ((N % 16) / 4);
+  // k-steps of a strip product.  Float64: the k-steps beyond N are skipped.  Float32: register r of tile rt as a B operand
+  // supplies k = 16 rt + 4 lq + r -- a permutation of the contraction index that the A fragment follows -- so a k-step of
+  // the last row tile reaches rows >= N; they contribute nothing because the LDS buffers keep rows N .. 16 NT - 1 at zero
+  // (zero_padding), and all 4 NT k-steps run.
+  static constexpr int NKS = kF64 ? KS : 4 * NT;
+  static_assert(kF64 || (N % 16) != 0, "riding rows need a partly filled last row tile");
 };
+// contraction index of k-step ks relative to the lane's base (Float64: + lq, Float32: + 4 lq, added in the base pointer)
+__device__ __forceinline__ constexpr int strip_kofs(int ks) { return kF64 ? 4 * ks : 16 * (ks >> 2) + (ks & 3); }
+// row of register r of row tile rt relative to the lane's base row (Float64: lq, Float32: 4 lq)
+__device__ __forceinline__ constexpr int strip_rofs(int rt, int r) { return 16 * rt + (kF64 ? 4 * r : r); }
+__device__ __forceinline__ int strip_lq_base(int lq) { return kF64 ? lq : 4 * lq; }
+// does (tile rt, register r) of this lane hold a row < N ?
+template <int KS>
+__device__ __forceinline__ bool strip_rowok(int rt, int r, int lq) {
+  if constexpr (kF64) return 4 * rt + r < KS;
+  else return 16 * rt + 4 * lq + r < 4 * KS;
+}
 
 __device__ __forceinline__ r4 mfma_f64(real a, real b, r4 c) {
   return mma16(a, b, c);
@@ -64,12 +86,12 @@ __device__ __forceinline__ void strip_mul(const real *M, int lr, int lq, const r
                                           r4 (&acc)[StripGeom<KS>::NT]) {
   constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
   asm volatile("" : "+v"(lr), "+v"(lq));  // keep the address arithmetic inside (see item_straight)
-  const real *base = M + lq + lr * LD;
+  const real *base = M + strip_lq_base(lq) + lr * LD;
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
+  for (int ks = 0; ks < StripGeom<KS>::NKS; ++ks) {
     real a[NT];
 #pragma unroll
-    for (int rt = 0; rt < NT; ++rt) a[rt] = base[4 * ks + 16 * rt * LD];
+    for (int rt = 0; rt < NT; ++rt) a[rt] = base[strip_kofs(ks) + 16 * rt * LD];
     const real b = B[ks >> 2][ks & 3];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) acc[rt] = mfma_f64(a[rt], b, acc[rt]);
@@ -84,12 +106,12 @@ __device__ __forceinline__ void strip_mul2(const real *M, int lr, int lq, const 
                                            r4 (&acc2)[StripGeom<KS>::NT]) {
   constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
   asm volatile("" : "+v"(lr), "+v"(lq));
-  const real *base = M + lq + lr * LD;
+  const real *base = M + strip_lq_base(lq) + lr * LD;
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
+  for (int ks = 0; ks < StripGeom<KS>::NKS; ++ks) {
     real a[NT];
 #pragma unroll
-    for (int rt = 0; rt < NT; ++rt) a[rt] = base[4 * ks + 16 * rt * LD];
+    for (int rt = 0; rt < NT; ++rt) a[rt] = base[strip_kofs(ks) + 16 * rt * LD];
     const real b1 = B1[ks >> 2][ks & 3], b2 = B2[ks >> 2][ks & 3];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) {
@@ -118,24 +140,24 @@ template <int KS>
 __device__ __forceinline__ void strip_load_lds(const real *X, int lr, int lq, int c0, r4 (&W)[StripGeom<KS>::NT]) {
   asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
-  const real *base = X + c0 + lr + lq * LD;
+  const real *base = X + c0 + lr + strip_lq_base(lq) * LD;
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS) ? base[(16 * rt + 4 * r) * LD] : 0.0;
+    for (int r = 0; r < 4; ++r) W[rt][r] = strip_rowok<KS>(rt, r, lq) ? base[strip_rofs(rt, r) * LD] : 0.0;
 }
 template <int KS>
 __device__ __forceinline__ void strip_store_lds(real *X, int lr, int lq, int c0, bool colok,
                                                 const r4 (&W)[StripGeom<KS>::NT]) {
   asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
-  real *base = X + c0 + lr + lq * LD;
+  real *base = X + c0 + lr + strip_lq_base(lq) * LD;
   if (colok) {
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (4 * rt + r < KS) base[(16 * rt + 4 * r) * LD] = W[rt][r];
+        if (strip_rowok<KS>(rt, r, lq)) base[strip_rofs(rt, r) * LD] = W[rt][r];
   }
 }
 template <int KS>
@@ -143,24 +165,24 @@ __device__ __forceinline__ void strip_load_glb(const gdouble *__restrict__ X, in
                                                r4 (&W)[StripGeom<KS>::NT]) {
   asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, CP = StripGeom<KS>::CP;
-  const gdouble *base = X + c0 + lr + lq * CP;
+  const gdouble *base = X + c0 + lr + strip_lq_base(lq) * CP;
 #pragma unroll
   for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) W[rt][r] = (4 * rt + r < KS && colok) ? MOM_NT_LOAD(base + (16 * rt + 4 * r) * CP) : 0.0;
+    for (int r = 0; r < 4; ++r) W[rt][r] = (strip_rowok<KS>(rt, r, lq) && colok) ? MOM_NT_LOAD(base + strip_rofs(rt, r) * CP) : 0.0;
 }
 template <int KS>
 __device__ __forceinline__ void strip_store_glb(gdouble *__restrict__ X, int lr, int lq, int c0, bool colok,
                                                 const r4 (&W)[StripGeom<KS>::NT]) {
   asm volatile("" : "+v"(lr), "+v"(lq));
   constexpr int NT = StripGeom<KS>::NT, CP = StripGeom<KS>::CP;
-  gdouble *base = X + c0 + lr + lq * CP;
+  gdouble *base = X + c0 + lr + strip_lq_base(lq) * CP;
   if (colok) {
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (4 * rt + r < KS) MOM_NT_STORE(W[rt][r], base + (16 * rt + 4 * r) * CP);
+        if (strip_rowok<KS>(rt, r, lq)) MOM_NT_STORE(W[rt][r], base + strip_rofs(rt, r) * CP);
   }
 }
 
@@ -169,7 +191,7 @@ __device__ __forceinline__ unsigned strip_sign_mask(const real *sg, int lq, int 
   unsigned m = 0;
 #pragma unroll
   for (int b = 0; b < 16; ++b) {
-    const int row = 4 * b + lq;
+    const int row = 16 * (b >> 2) + cd_row(lq, b & 3);   // bit 4 rt + r <-> (tile rt, register r)
     if (row < N && sg[row] < 0.0) m |= 1u << b;
   }
   return m;
@@ -206,13 +228,13 @@ __device__ __forceinline__ void doubling_rr_strip(const Ctx &c) {
     strip_mul<KS>(c.r, lr, lq, W, B);
     strip_store_lds<KS>(c.P, lr, lq, c0, colok, B);
     if (colok) {
-      if (lq == 0) c.P[col + N * LD] = B[G::RT][G::RR];        // (r j0+)[col]
-      if (lq == 1) c.P[col + (N + 1) * LD] = B[G::RT][G::RR];  // (r j0-)[col]
+      if (lq == G::LQ0) c.P[col + N * LD] = B[G::RT][G::RR0];        // (r j0+)[col]
+      if (lq == G::LQ1) c.P[col + (N + 1) * LD] = B[G::RT][G::RR1];  // (r j0-)[col]
 #pragma unroll
       for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (4 * rt + r < KS) ss += B[rt][r] * B[rt][r];
+          if (strip_rowok<KS>(rt, r, lq)) ss += B[rt][r] * B[rt][r];
     }
   }
   wg_sumsq_put(c, ss);
@@ -233,7 +255,7 @@ __device__ __forceinline__ void doubling_step_strip(Ctx &c, int p, real expk, co
   real *r = c.r, *t = c.t;
   const real *P = c.P;
   r4 Rn[NT], Tn[NT];
-  real aw = 0.0;
+  real aw = 0.0, aw2 = 0.0;  // (A w1)[col] in the lanes lq == LQ0, (A w2)[col] in the lanes lq == LQ1
 #ifdef MOM_CHAIN_PRIO
   if (active) __builtin_amdgcn_s_setprio(MOM_CHAIN_PRIO);  // experiment (profiles/r04_C2_ab.txt): static priority of the chain waves
 #endif
@@ -258,7 +280,8 @@ __device__ __forceinline__ void doubling_step_strip(Ctx &c, int p, real expk, co
     r4 Zt[NT];
     strip_zero(Zt);
     strip_mul<KS>(r, lr, lq, Y, Zt);  // (A r)^T ; rows N, N+1: (A w1)^T, (A w2)^T
-    aw = Zt[G::RT][G::RR];  // lanes lq == 0: (A w1)[col] ; lq == 1: (A w2)[col]
+    aw = Zt[G::RT][G::RR0];   // riding row N
+    aw2 = Zt[G::RT][G::RR1];  // riding row N + 1
     // two single-strip products rather than one pass over t with shared A fragments (strip_mul2): the real product
     // needs 32 more live VGPRs, which the fused kernel pays for with spills inside the chain
     strip_load_lds<KS>(r, lr, lq, c0, Rn);
@@ -304,13 +327,13 @@ __device__ __forceinline__ void doubling_step_strip(Ctx &c, int p, real expk, co
     strip_store_lds<KS>(r, lr, lq, c0, colok, Rn);
     strip_store_lds<KS>(t, lr, lq, c0, colok, Tn);
     const int col = c0 + lr;
-    if (colok && lq == 0) {  // j0- += A w1 (:57)
+    if (colok && lq == G::LQ0) {  // j0- += A w1 (:57)
       const real jm = c.jm[col] + aw;
       c.jm[col] = jm;
       r[col + (N + 1) * LD] = jm;
     }
-    if (colok && lq == 1) {  // j0+ = j1+ + A w2 (:60)
-      const real jp = c.jp[col] * expk + aw;
+    if (colok && lq == G::LQ1) {  // j0+ = j1+ + A w2 (:60)
+      const real jp = c.jp[col] * expk + aw2;
       c.jp[col] = jp;
       r[col + N * LD] = jp;
     }
@@ -390,7 +413,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
       for (int rt = 0; rt < NT; ++rt)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
-          if (4 * rt + rr < KS) ss += Bs[rt][rr] * Bs[rt][rr];
+          if (strip_rowok<KS>(rt, rr, lq)) ss += Bs[rt][rr] * Bs[rt][rr];
     }
   }
   if (do2) {
@@ -424,7 +447,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
     MOM_STAMP(54);
     r4 Radd[NT];
     strip_load_glb<KS>(g.R_mp, lr, lq, c0, colok, Radd);
-    const real j0m = (colok && lq == 0) ? g.J0m[col] : 0.0;
+    const real j0m = (colok && lq == G::LQ0) ? g.J0m[col] : 0.0;
     // T-- = T01 t--  ->  (t--)^T T01^T = D t^T D Y                                   (:96)
     {
       r4 Yf[NT], o[NT];
@@ -443,7 +466,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
     strip_mul<KS>(Q, lr, lq, V, Radd);
     strip_store_glb<KS>(g.R_mp, lr, lq, c0, colok, Radd);
     // J0- = J0- + T01 (r-+ J0+ + j0-)                                                (:90)
-    if (colok && lq == 0) g.J0m[col] = j0m + (Radd[G::RT][G::RR] + V[G::RT][G::RR]);
+    if (colok && lq == G::LQ0) g.J0m[col] = j0m + (Radd[G::RT][G::RR0] + V[G::RT][G::RR0]);
     MOM_STAMP(55);
   }
   if (do2) {
@@ -467,7 +490,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
     strip_mul<KS>(Q, lr, lq, T21, o);
     strip_store_glb<KS>(g.T_pp, lr, lq, c0, colok, o);
     // J0+ = j0+ + T21 (J0+ + R+- j0-)                                                (:110)
-    if (colok && lq == 0) g.J0p[col] = c.jp[col] + (o[G::RT][G::RR] + T21[G::RT][G::RR]);
+    if (colok && lq == G::LQ0) g.J0p[col] = c.jp[col] + (o[G::RT][G::RR0] + T21[G::RT][G::RR0]);
     // R+- = r+- + X t--  ->  r+-^T + D t^T D X^T = D (D r+-^T + t^T D X^T), D r+-^T[row][col] = sg[col] r-+[col][row]   (:116)
     r4 acc[NT];
     strip_load_lds<KS>(r, lr, lq, c0, acc);

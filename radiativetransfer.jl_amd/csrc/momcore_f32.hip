@@ -6,8 +6,9 @@
 // momf: operators and sources in f32, products on v_mfma_f32_16x16x4_f32 (32 cycles per instruction per SIMD: twice
 // the f64 rate), LDS images half the size.  What runs: the fused per-layer kernels of the general path (LDS-resident
 // for N <= 64, generic mode above), layer-sweep mode, the surface layer (all three surface kinds) with HDRF/BHR, and
-// post-processing.  Not built for f32: the strip-chained images, the (I,Q) reduction of moment 0, the lane-per-point
-// kernel and the operator-level API (mom_elemental ... return MOM_EINVAL on a dtype = 1 handle).
+// post-processing; r4: the strip-chained images of the 8-wave build (N = 44, 52, 56, 60: momcore_strip.hip compiled for
+// float, momf_strip<KS>_launch_layer).  Not built for f32: the (I,Q) reduction of moment 0, the padding of other edges to
+// the strip sizes and the operator-level API (mom_elemental ... return MOM_EINVAL on a dtype = 1 handle).
 //
 // The C ABI keeps Float64 host arrays for both dtypes (a Float32 Julia host passes Float64.(x) and converts back):
 // inputs are rounded to f32 on upload, outputs widened on download.
@@ -139,7 +140,7 @@ struct momf_scene {
   float albedo = 0.f;
   std::vector<int> nd, iface;
   std::vector<float> h_mu;
-  bool lds = true, force_generic = false, sweep = true;
+  bool lds = true, force_generic = false, sweep = true, strips = true;
   hipEvent_t ev[4] = {};
   int launches = 0;
   std::string err;
@@ -278,6 +279,11 @@ template <class K>
 static hipError_t allow(K kernel, size_t bytes) { return mom_allow_lds(reinterpret_cast<const void *>(kernel), bytes); }
 
 hipError_t momwf_launch_sweep(const void *args, hipStream_t st);  // mom_wave.hip built with -DMOMW_FLOAT
+// momcore_strip.hip built for float (Makefile: momcore_fs<KS>.o)
+hipError_t momf_strip11_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
+hipError_t momf_strip13_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
+hipError_t momf_strip14_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
+hipError_t momf_strip15_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 
 // 4 < N <= 32: one spectral point per wavefront, operators in MFMA-layout registers, the whole run in ONE launch -- the
 // Float32 build of momw::k_wsweep (the Float64 path: rt_run_wave in momcore.hip).  Covers ScatteringInterface_11 on every
@@ -390,6 +396,21 @@ int momf_rt_run(momf_scene *s) {
     FCHK(s, allow(k_layer<false, IF>, sm));                                                       \
     hipLaunchKernelGGL((k_layer<false, IF>), dim3(grid), dim3(kThreads), sm, s->stream, a);        \
   }
+    // strip-chained images (Float32 builds of mom_strip.hpp's chains) for the edges that have one; MOM_OPT_INVERSE != 0 keeps
+    // the general path inside the same image, MOM_OPT_STRIPS_F32 = 0 (s->strips) the general image
+    const int ks4 = (N % 4 == 0) ? N / 4 : 0;
+    if (lds && s->strips && (ks4 == 11 || ks4 == 13 || ks4 == 14 || ks4 == 15)) {
+      hipError_t e = hipSuccess;
+      switch (ks4) {
+        case 11: e = momf_strip11_launch_layer(&a, a.iface, grid, sm, s->stream); break;
+        case 13: e = momf_strip13_launch_layer(&a, a.iface, grid, sm, s->stream); break;
+        case 14: e = momf_strip14_launch_layer(&a, a.iface, grid, sm, s->stream); break;
+        default: e = momf_strip15_launch_layer(&a, a.iface, grid, sm, s->stream); break;
+      }
+      FCHK(s, e);
+      s->launches++;
+      continue;
+    }
     switch (a.iface) {
       case 0: F32_LAUNCH(0) break;
       case 1: F32_LAUNCH(1) break;

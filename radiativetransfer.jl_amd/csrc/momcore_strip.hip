@@ -15,9 +15,14 @@ using namespace MOM_NS;
 
 #define MOM_CAT2(a, b) a##b
 #define MOM_CAT(a, b) MOM_CAT2(a, b)
+// entry-point prefix: mom_strip (Float64 builds) or momf_strip (the Float32 build of the same images: -DMOM_REAL=float
+// -DMOM_REAL_IS_FLOAT=1 -DMOM_NS=momf -DMOM_STRIP_PREFIX=momf_strip)
+#ifndef MOM_STRIP_PREFIX
+#define MOM_STRIP_PREFIX mom_strip
+#endif
 
 // host entry used by momcore.hip: mom_strip<KS>_launch_layer(args, iface, grid, smem, stream)
-hipError_t MOM_CAT(MOM_CAT(mom_strip, MOM_STRIP_KS), _launch_layer)(const void *layer_args, int iface, int grid, size_t smem,
+hipError_t MOM_CAT(MOM_CAT(MOM_STRIP_PREFIX, MOM_STRIP_KS), _launch_layer)(const void *layer_args, int iface, int grid, size_t smem,
                                                                      hipStream_t st) {
   const LayerArgs a = *reinterpret_cast<const LayerArgs *>(layer_args);
   hipError_t e = hipSuccess;
@@ -41,7 +46,7 @@ hipError_t MOM_CAT(MOM_CAT(mom_strip, MOM_STRIP_KS), _launch_layer)(const void *
 }
 
 #ifdef MOM_DIAG_STAMPS
-extern "C" int MOM_CAT(mom_diag_read_strip, MOM_STRIP_KS)(unsigned long long *out, int reset) {
+extern "C" int MOM_CAT(MOM_CAT(MOM_STRIP_PREFIX, _diag_read), MOM_STRIP_KS)(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mom_diag_acc), 128 * sizeof(unsigned long long)) != hipSuccess) return 1;
   if (reset) {
     unsigned long long z[128] = {0};

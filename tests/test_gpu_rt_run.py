@@ -629,6 +629,44 @@ def test_float32_scene_level_path(rtamd, cref, nS, lt, kw):
     assert not np.array_equal(R, Rr)  # it really is a different precision
 
 
+@pytest.mark.parametrize("nS,lt,N", [(4, 15, 44), (4, 19, 52), (4, 21, 56), (4, 23, 60), (3, 33, 60)])
+def test_float32_strip_chains(rtamd, cref, nS, lt, N):
+    """dtype = 1 at the edges that have a strip-chained image (N = 44, 52, 56, 60): the Float32 build of mom_strip.hpp's chains
+    (accumulator layout row = 4 lq + r: the B operand of k-step (rt, r) supplies k = 16 rt + 4 lq + r and the A fragment follows;
+    all 4 NT k-steps run against zero padding rows) against the same image with the chains switched off (MOM_OPT_INVERSE = 2),
+    against the Float32 oracle (error ratio) and against the Float64 oracle (the bound every Float32 run owes it)."""
+    m = rtamd.scenes.make_scene(nS, lt, 5, 24, seed=7 * nS + lt, aerosol_total=0.4)
+    sc = rtamd.prepare_scene(m)
+    assert sc.N == N
+    p = cref.pack_scene(helpers.oracle_scene(m))
+    Rr, Tr, info = cref.rt_run(p)
+    Rf, Tf, info32 = cref.rt_run_f32(p)
+    assert info == 0 and info32 == 0
+    out = {}
+    for inv in (0, 2):
+        with rtamd.corert.make_handle(m, float_type="Float32") as h:
+            h.set_option(rtamd._lib.MOM_OPT_INVERSE, inv)
+            out[inv] = rtamd.corert.run_scene(h, sc)
+    nd = int(sc.ndoubl.max())
+    tol64 = 16 * 6e-8 / (1e-3 * float(m.quad_points.qp_μ.min()))
+    pair = F32_PAIR_ULPS * 6e-8 * 2.0 ** nd
+    errs = {}
+    for inv in (0, 2):
+        R, T = out[inv]
+        errs[inv] = (helpers.assert_stokes_close(R, Rr, rtol=tol64, atol=1e-6, what=f"f32 R inv={inv}"),
+                     helpers.assert_stokes_close(T, Tr, rtol=tol64, atol=1e-6, what=f"f32 T inv={inv}"))
+    oR = float(np.max(np.abs(Rf - Rr) / np.maximum(np.abs(Rr[:, 0:1, :]), 1e-6 / tol64)))
+    oT = float(np.max(np.abs(Tf - Tr) / np.maximum(np.abs(Tr[:, 0:1, :]), 1e-6 / tol64)))
+    assert errs[0][0] <= F32_ERR_RATIO * oR + 2e-6 and errs[0][1] <= F32_ERR_RATIO * oT + 2e-6, (errs, oR, oT)
+    for X, Y, Xr in ((out[0][0], out[2][0], Rr), (out[0][1], out[2][1], Tr)):
+        Imax = np.abs(Xr[:, 0:1, :]).max(axis=2, keepdims=True)
+        d = np.abs(X - Y) / Imax
+        assert np.all(d <= pair), f"strips vs general path: {d.max():.3e} > {pair:.3e}"
+    assert not np.array_equal(out[0][0], out[2][0])      # the chains did run
+    print(f"f32 strips N={N}: vs f64 oracle {errs[0][0]:.2e}/{errs[0][1]:.2e} (general path {errs[2][0]:.2e}/{errs[2][1]:.2e}, "
+          f"f32 oracle {oR:.2e}/{oT:.2e}), nd {nd}")
+
+
 @pytest.mark.parametrize("nS,lt,Nz,kw", [(3, 9, 6, {}), (1, 5, 5, {}), (4, 7, 5, dict(generic=True)), (3, 33, 6, {}),
                                           (3, 27, 5, dict(brdf="rpv")), (3, 9, 5, dict(brdf="legendre")),
                                           (4, 31, 4, {}), (3, 9, 5, dict(zero=(0, 1)))])
