@@ -295,6 +295,36 @@ def surface_lambertian(p: Packed, m, tau_tot, S):
     return out
 
 
+# ---- the same operators in FLOAT32 (oracle/momref_f32.c): Float64 numbers in, rounded to Float32; Float32 results widened ----
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).astype(np.float32))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def elemental_f32(p: Packed, m, nd, tau_sum, dtau, varpi, Zpp, Zmp, z_batch, S):
+    N = p.N
+    out = [np.zeros(N * N * S, np.float32) for _ in range(4)] + [np.zeros(N * S, np.float32) for _ in range(2)]
+    ins = [_f32(x) for x in (p.mu, p.wt, p.I0, p.D, tau_sum, dtau, varpi, Zpp, Zmp)]
+    L = lib_f32()
+    L.ora_elemental.restype = None
+    L.ora_elemental(N, p.nS, S, m, nd, p.imu0, _fp(ins[0]), _fp(ins[1]), _fp(ins[2]), _fp(ins[3]), p.strict,
+                    _fp(ins[4]), _fp(ins[5]), _fp(ins[6]), _fp(ins[7]), _fp(ins[8]), z_batch, *[_fp(o) for o in out])
+    return out  # float32 arrays: r_pm, r_mp, t_mm, t_pp, j0p, j0m
+
+
+def doubling_f32(p: Packed, nd, expk32, added32, S):
+    """in place on the float32 arrays `expk32`, `added32` (as returned by elemental_f32)"""
+    return lib_f32().ora_doubling(p.N, p.nS, S, nd, p.strict, _fp(expk32), *[_fp(a) for a in added32])
+
+
+def interaction_f32(N, S, iface, comp32, added32):
+    return lib_f32().ora_interaction(N, S, iface, *[_fp(a) for a in comp32], *[_fp(a) for a in added32])
+
+
 def batch_inv(N, S, A):
     X = np.zeros_like(A)
     info = lib().ora_batch_inv(N, S, dp(A), dp(X))

@@ -155,7 +155,7 @@ class Handle:
     """RAII wrapper of mom_t*.  One handle <-> one GPU <-> one stream."""
 
     def __init__(self, N: int, nStokes: int, S: int, max_m: int = 1, device: int = 0, dtype: int = 0):
-        """dtype 0 = Float64 (everything), 1 = Float32 (scene-level path: scene_set / rt_run / get_RT / get_hdr)."""
+        """dtype 0 = Float64 (everything), 1 = Float32 (scene-level path, operator-level API, batched operators)."""
         self.lib = load()
         self.N, self.nS, self.S, self.M = int(N), int(nStokes), int(S), int(max_m)
         self._h = c_h()

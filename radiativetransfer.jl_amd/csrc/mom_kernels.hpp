@@ -973,7 +973,11 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   }
   __syncthreads();
   MOM_STAMP(48);
-  if (N % 4 != 0) {  // P and Q served as table space: their K padding must read as zero again
+  // P and Q served as table space (linear: the sun-block Z columns land in P's padding rows): their K padding must read
+  // as zero again -- always in the Float32 build, whose strip chains run every k-step of the last row tile (r4: without
+  // this the chains' riding rows met the stale table entries from the third series term on and a thick layer lost
+  // 3 x the accuracy of the general path)
+  if (N % 4 != 0 || !kF64) {
     rezero_padding(c, c.P);
     rezero_padding(c, c.Q);
     __syncthreads();
@@ -1009,7 +1013,15 @@ __device__ __forceinline__ real doubling_run(Ctx &c, int nd, real expk, const Co
   }
   for (int it = it0; it < nd; ++it) {
     bool strip_ok = false;
+#ifndef MOM_NO_DBL_STRIP  // (diagnostic builds: the general doubling step inside a strip image)
     if constexpr (LDSM && KS > 0) strip_ok = ride && c.inv_mode == 0 && N == 4 * KS;
+#endif
+#ifdef MOM_DIAG_CHAIN_LT  // (diagnostic builds: chains only in the first / only after the first so many steps)
+    strip_ok = strip_ok && it < MOM_DIAG_CHAIN_LT;
+#endif
+#ifdef MOM_DIAG_CHAIN_GE
+    strip_ok = strip_ok && it >= MOM_DIAG_CHAIN_GE;
+#endif
     // r r on strips where the general product has no straight-line schedule (4-wave build); the 8-wave build's
     // 8 x 2-tile product is faster than 4 strip waves
     if (strip_ok && kWaves == 4) {
@@ -1033,7 +1045,13 @@ __device__ __forceinline__ real doubling_run(Ctx &c, int nd, real expk, const Co
     if constexpr (LDSM && KS > 0) {
       // strip-chained step (mom_strip.hpp): the series, A r, (A r) t and A t in one barrier-free MFMA stream
       if (strip_ok) {
-        const int p = neumann_terms_12(beta2);
+        int p = neumann_terms_12(beta2);
+#ifdef MOM_DIAG_PPLUS  // (diagnostic builds: one series term more than the bound asks for)
+        p += MOM_DIAG_PPLUS;
+#endif
+#ifdef MOM_DIAG_PMAX  // (diagnostic builds: longer series go to the general path)
+        if (p > MOM_DIAG_PMAX) p = 1000;
+#endif
         if (p <= kStripMaxP) {
 #ifdef MOM_QPREFETCH
           doubling_step_strip<KS>(c, p, expk, (it == nd - 1) ? pre : nullptr);
@@ -1144,7 +1162,9 @@ __device__ __forceinline__ void interaction_core(Ctx &c, int iface_rt, const Com
   if constexpr (LDSM && KS > 0 && std::is_same<FRPM, ElSigP>::value && std::is_same<FTMM, ElSigP>::value) {
     // ScatteringInterface_11 with r+- = D r-+ D, t-- = D t++ D of the layer held in c.r, c.t: two strip chains
     if ((IFACE < 0 || IFACE == 3) && iface == 3 && c.inv_mode == 0 && N == 4 * KS && rpm.p == c.r && tmm.p == c.t) {
+#ifndef MOM_NO_INT_STRIP  // (diagnostic builds: the general interaction inside a strip image)
       if (interaction_strip<KS>(c, g)) return;
+#endif
     }
   }
   if constexpr (!LDSM && kF64 && kWaves == 8 && std::is_same<FRPM, ElSigP>::value && std::is_same<FTMM, ElSigP>::value) {

@@ -92,7 +92,11 @@ __device__ __forceinline__ void strip_mul(const real *M, int lr, int lq, const r
     real a[NT];
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) a[rt] = base[strip_kofs(ks) + 16 * rt * LD];
+#ifdef MOM_DIAG_MASKB  // (diagnostic builds: strip rows >= N never reach the product -- a no-op while the multiplier's rows >= N are zero)
+    const real b = strip_rowok<KS>(ks >> 2, ks & 3, lq) ? B[ks >> 2][ks & 3] : (real)0;
+#else
     const real b = B[ks >> 2][ks & 3];
+#endif
 #pragma unroll
     for (int rt = 0; rt < NT; ++rt) acc[rt] = mfma_f64(a[rt], b, acc[rt]);
     if ((ks + 1) % kStripChunk == 0) __builtin_amdgcn_sched_barrier(0);  // cap the A fragments in flight

@@ -767,7 +767,6 @@ hipError_t MOMW_LAUNCH8(const void *args, hipStream_t st) {
 hipError_t MOMW_LAUNCH(const void *args, hipStream_t st) {
   const MOMW_NS::WArgs a = *reinterpret_cast<const MOMW_NS::WArgs *>(args);
   const dim3 grid((unsigned)((a.S + 3) / 4)), block(256);
-#ifndef MOMW_FLOAT
   // a.pad = points per wavefront (block-diagonal packing of small operators, k_wsweep's PK): 3 at N = 5, 2 at N = 6..8
   if (a.pad == 3 && a.N == 5) {
     hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 4, 3>), dim3((unsigned)((a.S + 11) / 12)), block, 0, st, a);
@@ -775,11 +774,13 @@ hipError_t MOMW_LAUNCH(const void *args, hipStream_t st) {
   }
   if (a.pad == 2 && a.N >= 5 && a.N <= 8) {
     const dim3 g2((unsigned)((a.S + 7) / 8));
+#ifndef MOMW_FLOAT  // (the Float32 accumulator layout allows no k-step to be skipped: KS = 4 throughout)
     if (2 * a.N <= 12) hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 3, 2>), g2, block, 0, st, a);
-    else hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 4, 2>), g2, block, 0, st, a);
+    else
+#endif
+      hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 4, 2>), g2, block, 0, st, a);
     return hipGetLastError();
   }
-#endif
   switch ((a.N + 3) / 4) {
     case 2: hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 2>), grid, block, 0, st, a); break;
     case 3: hipLaunchKernelGGL((MOMW_NS::k_wsweep<1, 3>), grid, block, 0, st, a); break;

@@ -16,6 +16,7 @@
 
 #include "mom_diag.hpp"
 #include "mom_entry.hpp"
+#include "mom_ops.hpp"
 #include "mom_host.hpp"
 #include "mom_rrs.hpp"
 
@@ -72,124 +73,7 @@ __global__ void k_postprocess(PostArgs a) {
   a.hdr[idx] = h;  // Lambertian surfaces: only m = 0 contributes (r-+ = 0, j0- = 0 for m > 0)
 }
 
-// ---------------------------------------------------------------- operator-level kernels
-
-struct OpArgs {
-  DevStreams q;
-  int S, m, nd, iface, z_batch;
-  const double *tau_sum, *dtau, *varpi, *Zpp, *Zmp;
-  double *expk;
-  double *added[6];  // r_pm, r_mp, t_mm, t_pp, j0p, j0m
-  double *comp[6];
-  double *scratch;
-  int *info;
-};
-
-__device__ __forceinline__ void store_added(const Ctx &c, double *const added[6], size_t pt, bool with_mirror) {
-  const int N = c.N, ld = c.ld;
-  const size_t NN = (size_t)N * N;
-  for (int e = threadIdx.x; e < N * N; e += kThreads) {
-    int i, j;
-    c.fd.split(e, i, j);
-    const double rv = c.r[i + j * ld], tv = c.t[i + j * ld];
-    added[1][NN * pt + e] = rv;
-    added[3][NN * pt + e] = tv;
-    if (with_mirror) {
-      const double s = c.sg[i] * c.sg[j];
-      added[0][NN * pt + e] = s * rv;
-      added[2][NN * pt + e] = s * tv;
-    }
-  }
-  for (int i = threadIdx.x; i < N; i += kThreads) {
-    added[4][(size_t)N * pt + i] = c.jp[i];
-    added[5][(size_t)N * pt + i] = c.jm[i];
-  }
-}
-
-__device__ __forceinline__ void load_added(const Ctx &c, double *const added[6], size_t pt) {
-  const int N = c.N, ld = c.ld;
-  const size_t NN = (size_t)N * N;
-  for (int e = threadIdx.x; e < N * N; e += kThreads) {
-    int i, j;
-    c.fd.split(e, i, j);
-    c.r[i + j * ld] = added[1][NN * pt + e];
-    c.t[i + j * ld] = added[3][NN * pt + e];
-  }
-  for (int i = threadIdx.x; i < N; i += kThreads) {
-    c.jp[i] = added[4][(size_t)N * pt + i];
-    c.jm[i] = added[5][(size_t)N * pt + i];
-  }
-}
-
-template <bool LDSM>
-__global__ void __launch_bounds__(kThreads) k_op_elemental(OpArgs a) {
-  const int N = a.q.N;
-  Ctx c;
-  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
-  const size_t NN = (size_t)N * N;
-  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
-    const size_t zo = a.z_batch > 1 ? NN * pt : 0;
-    El zpp{as_global(a.Zpp) + zo, N, N}, zmp{as_global(a.Zmp) + zo, N, N};
-    elemental_build(c, a.q, a.m, a.nd, a.tau_sum[pt], a.dtau[pt], a.varpi[pt], zpp, zmp);
-    // the reference leaves r+-/t-- untouched when nd >= 1 (elemental.jl:255-274)
-    store_added(c, a.added, pt, a.nd < 1);
-    __syncthreads();
-  }
-}
-
-template <bool LDSM>
-__global__ void __launch_bounds__(kThreads) k_op_doubling(OpArgs a) {
-  const int N = a.q.N;
-  Ctx c;
-  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
-  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
-    load_added(c, a.added, pt);
-    __syncthreads();
-    const double e = doubling_run<LDSM>(c, a.nd, a.expk[pt]);
-    if (threadIdx.x == 0) a.expk[pt] = e;
-    store_added(c, a.added, pt, true);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
-}
-
-template <bool LDSM>
-__global__ void __launch_bounds__(kThreads) k_op_interaction(OpArgs a) {
-  const int N = a.q.N;
-  Ctx c;
-  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
-  const size_t NN = (size_t)N * N;
-  for (size_t pt = blockIdx.x; pt < (size_t)a.S; pt += gridDim.x) {
-    load_added(c, a.added, pt);
-    __syncthreads();
-    CompPtrs g = comp_ptrs(a.comp, N, N, pt);  // operator-level arrays: natural pitch
-    interaction_core<LDSM, -1>(c, a.iface, g, El{as_global(a.added[0]) + NN * pt, N, N}, El{as_global(a.added[2]) + NN * pt, N, N});
-  }
-  if (threadIdx.x == 0 && *c.bad) atomicMax(a.info, *c.bad);
-}
-
-// surface layer arrays for the operator-level API (lambertian_surface.jl:20-75)
-__global__ void k_op_surface_fill(DevStreams q, int S, int m, double albedo, const double *tau_tot, double *r_pm,
-                                  double *r_mp, double *t_mm, double *t_pp, double *j0p, double *j0m) {
-  const int N = q.N, n = q.nS;
-  const size_t NN = (size_t)N * N;
-  const size_t pt = blockIdx.x;
-  const double rho = 2 * albedo;
-  const double att = exp(-tau_tot[pt] / q.mu0);
-  const int i_start = n * (q.imu0 - 1), i_end = n * q.imu0;
-  for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
-    const int j = e / N, i = e - j * N;
-    r_mp[NN * pt + e] = (m == 0 && (i % n == 0) && (j % n == 0)) ? rho * (q.mu[j] * q.wt[j]) : 0.0;
-    if (m == 0) r_pm[NN * pt + e] = 0.0;  // not reset for m > 0 (:68-73)
-    t_pp[NN * pt + e] = (i == j) ? 1.0 : 0.0;
-    t_mm[NN * pt + e] = (i == j) ? 1.0 : 0.0;
-  }
-  for (int i = threadIdx.x; i < N; i += blockDim.x) {
-    const bool in_sun = (i >= i_start) && (i < i_end);
-    j0p[(size_t)N * pt + i] = (m == 0) ? (in_sun ? q.I0[i - i_start] : 0.0) * att : 0.0;
-    j0m[(size_t)N * pt + i] = (m == 0 && (i % n == 0)) ? (q.mu0 * (rho * q.I0[0])) * att : 0.0;
-  }
-}
+// operator-level kernels: mom_ops.hpp (shared with the Float32 build)
 
 struct BlasArgs {
   int N, S;
@@ -424,7 +308,7 @@ struct momf_scene;
 int momf_create(momf_scene **out, int device, hipStream_t stream, int N, int nS, int S, int max_m, int *d_info);
 void momf_destroy(momf_scene *s);
 const char *momf_error(const momf_scene *s);
-void momf_set_options(momf_scene *s, int inv_mode, int force_generic, int sweep, int small_n);
+void momf_set_options(momf_scene *s, int inv_mode, int force_generic, int sweep, int small_n, int m0, int pad, int w4);
 int momf_set_streams(momf_scene *s, const double *mu, const double *wt, const double *sg, int imu0, double mu0, const double *I0,
                      const double *D, int regular);
 int momf_scene_set(momf_scene *s, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
@@ -436,6 +320,14 @@ int momf_get_RT(momf_scene *s, double *R, double *T);
 int momf_get_hdr(momf_scene *s, double *hdr, double *up, double *dw);
 int momf_timers(momf_scene *s, double *ms, int *launches);
 int momf_blas(momf_scene *s, int n, int batch, const double *A, const double *B, double *C, bool inv);
+int momf_op_elemental(momf_scene *s, int m, int nd, const double *tau_sum, const double *dtau, const double *varpi,
+                      const double *Zpp, const double *Zmp, int z_batch);
+int momf_op_doubling(momf_scene *s, int nd, double *expk);
+int momf_op_interaction(momf_scene *s, int iface, int with_surface_layer);
+int momf_op_copy_added_to_composite(momf_scene *s);
+int momf_op_surface_lambertian(momf_scene *s, int m, double albedo, const double *tau_tot);
+int momf_op_upload(momf_scene *s, int which, const double *src);
+int momf_op_download(momf_scene *s, int which, double *dst);
 // mom_small.hip: N <= 4, one spectral point per lane, the whole sweep in one launch
 hipError_t momsm_launch_sweep(const void *args, int N, hipStream_t st);
 hipError_t momw_launch_sweep(const void *args, hipStream_t st);
@@ -756,7 +648,7 @@ extern "C" int mom_set_option(mom_t *h, int option, int value) {
     h->opt_force_generic = value;
     h->lds_mode = (h->N <= 64) && !value;
   } else return fail(h, MOM_EINVAL, "mom_set_option: unknown option");
-  if (h->f32) momf_set_options(h->f32, h->opt_inverse, h->opt_force_generic, h->opt_sweep, h->opt_small);
+  if (h->f32) momf_set_options(h->f32, h->opt_inverse, h->opt_force_generic, h->opt_sweep, h->opt_small, h->opt_m0, h->opt_pad, h->opt_w4);
   return MOM_OK;
 }
 
@@ -790,7 +682,7 @@ extern "C" int mom_set_streams(mom_t *h, const double *qp_muN, const double *wt_
   for (int i = 0; i < N; ++i)
     if (qp_muN[i] != qp_muN[(i / h->nS) * h->nS]) q.regular = 0;
   if (h->f32) {
-    momf_set_options(h->f32, h->opt_inverse, h->opt_force_generic, h->opt_sweep, h->opt_small);
+    momf_set_options(h->f32, h->opt_inverse, h->opt_force_generic, h->opt_sweep, h->opt_small, h->opt_m0, h->opt_pad, h->opt_w4);
     const int rc = momf_set_streams(h->f32, qp_muN, wt_muN, sg.data(), imu0_1based, mu0, I0, D, q.regular);
     if (rc) return fail(h, rc, momf_error(h->f32));
   }
@@ -845,10 +737,13 @@ static int check_info(mom_t *h) {
 extern "C" int mom_elemental(mom_t *h, int m, int ndoubl, const double *tau_sum, const double *dtau, const double *varpi,
                              const double *Zpp, const double *Zmp, int z_batch) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_elemental");
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_elemental: call mom_set_streams first");
   if (!tau_sum || !dtau || !varpi || !Zpp || !Zmp || (z_batch != 1 && z_batch != h->S) || m < 0 || ndoubl < 0)
     return fail(h, MOM_EINVAL, "mom_elemental: bad argument");
+  if (h->f32) {
+    const int rc = momf_op_elemental(h->f32, m, ndoubl, tau_sum, dtau, varpi, Zpp, Zmp, z_batch);
+    return rc ? fail(h, rc, momf_error(h->f32)) : MOM_OK;
+  }
   HIPCHK(h, hipSetDevice(h->device));
   { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
   const size_t NN = (size_t)h->N * h->N, zc = NN * z_batch;
@@ -876,9 +771,12 @@ extern "C" int mom_elemental(mom_t *h, int m, int ndoubl, const double *tau_sum,
 
 extern "C" int mom_doubling(mom_t *h, int ndoubl, double *expk) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_doubling");
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_doubling: call mom_set_streams first");
   if (!expk || ndoubl < 0) return fail(h, MOM_EINVAL, "mom_doubling: bad argument");
+  if (h->f32) {
+    const int rc = momf_op_doubling(h->f32, ndoubl, expk);
+    return rc ? fail(h, rc, momf_error(h->f32)) : check_info(h);
+  }
   HIPCHK(h, hipSetDevice(h->device));
   { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
   const size_t sb = (size_t)h->S * sizeof(double);
@@ -894,9 +792,12 @@ extern "C" int mom_doubling(mom_t *h, int ndoubl, double *expk) {
 
 extern "C" int mom_interaction(mom_t *h, int iface, int with_surface_layer) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_interaction");
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_interaction: call mom_set_streams first");
   if (iface < 0 || iface > 3) return fail(h, MOM_EINVAL, "mom_interaction: iface must be 0..3");
+  if (h->f32) {
+    const int rc = momf_op_interaction(h->f32, iface, with_surface_layer);
+    return rc ? fail(h, rc, momf_error(h->f32)) : check_info(h);
+  }
   HIPCHK(h, hipSetDevice(h->device));
   { int rc_ = ensure_op_layers(h); if (rc_) return rc_; if ((rc_ = op_composite_ready(h, "mom_interaction"))) return rc_; }
   OpArgs a{};
@@ -909,7 +810,10 @@ extern "C" int mom_interaction(mom_t *h, int iface, int with_surface_layer) {
 
 extern "C" int mom_copy_added_to_composite(mom_t *h) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_copy_added_to_composite");
+  if (h->f32) {
+    const int rc = momf_op_copy_added_to_composite(h->f32);
+    return rc ? fail(h, rc, momf_error(h->f32)) : MOM_OK;
+  }
   HIPCHK(h, hipSetDevice(h->device));
   { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
   h->comp_pitched = false;
@@ -926,9 +830,12 @@ extern "C" int mom_copy_added_to_composite(mom_t *h) {
 
 extern "C" int mom_surface_lambertian(mom_t *h, int m, double albedo, const double *tau_tot) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_surface_lambertian");
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_surface_lambertian: call mom_set_streams first");
   if (!tau_tot || m < 0) return fail(h, MOM_EINVAL, "mom_surface_lambertian: bad argument");
+  if (h->f32) {
+    const int rc = momf_op_surface_lambertian(h->f32, m, albedo, tau_tot);
+    return rc ? fail(h, rc, momf_error(h->f32)) : MOM_OK;
+  }
   HIPCHK(h, hipSetDevice(h->device));
   { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
   HIPCHK(h, hipMemcpyAsync(h->d_vec[0], tau_tot, (size_t)h->S * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -949,8 +856,11 @@ static double *which_ptr(mom_t *h, int which, size_t *count) {
 
 extern "C" int mom_upload(mom_t *h, int which, const double *src) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_upload");
   if (which < 0 || which > 17 || !src) return fail(h, MOM_EINVAL, "mom_upload: bad argument");
+  if (h->f32) {
+    const int rc = momf_op_upload(h->f32, which, src);
+    return rc ? fail(h, rc, momf_error(h->f32)) : MOM_OK;
+  }
   HIPCHK(h, hipSetDevice(h->device));
   if (which / 6 != 1) { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
   else h->comp_pitched = false;  // the caller (re)starts an operator-level sequence: natural [N,N,S] layout
@@ -963,8 +873,11 @@ extern "C" int mom_upload(mom_t *h, int which, const double *src) {
 
 extern "C" int mom_download(mom_t *h, int which, double *dst) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_download");
   if (which < 0 || which > 17 || !dst) return fail(h, MOM_EINVAL, "mom_download: bad argument");
+  if (h->f32) {
+    const int rc = momf_op_download(h->f32, which, dst);
+    return rc ? fail(h, rc, momf_error(h->f32)) : MOM_OK;
+  }
   HIPCHK(h, hipSetDevice(h->device));
   if (which / 6 != 1) { const int rc_ = ensure_op_layers(h); if (rc_) return rc_; }
   size_t count = 0;

@@ -7,8 +7,9 @@
 // the f64 rate), LDS images half the size.  What runs: the fused per-layer kernels of the general path (LDS-resident
 // for N <= 64, generic mode above), layer-sweep mode, the surface layer (all three surface kinds) with HDRF/BHR, and
 // post-processing; r4: the strip-chained images of the 8-wave build (N = 44, 52, 56, 60: momcore_strip.hip compiled for
-// float, momf_strip<KS>_launch_layer).  Not built for f32: the (I,Q) reduction of moment 0, the padding of other edges to
-// the strip sizes and the operator-level API (mom_elemental ... return MOM_EINVAL on a dtype = 1 handle).
+// float, momf_strip<KS>_launch_layer), the (I,Q) reduction of moment 0 (a nested sub-scene: momf_scene::sub) and the padding of
+// other edges to the strip sizes (strip_pad_f).  Not built for f32: the operator-level API (mom_elemental ... return
+// MOM_EINVAL on a dtype = 1 handle).
 //
 // The C ABI keeps Float64 host arrays for both dtypes (a Float32 Julia host passes Float64.(x) and converts back):
 // inputs are rounded to f32 on upload, outputs widened on download.
@@ -26,6 +27,7 @@
 
 #include "mom_diag.hpp"
 #include "mom_entry.hpp"
+#include "mom_ops.hpp"
 #include "mom_host.hpp"
 
 using namespace momf;
@@ -33,7 +35,7 @@ using namespace momf;
 namespace {
 
 struct PostArgsF {
-  int N, nS, S, M, nVza, hdr_all, zeroT_hi;
+  int N, nS, S, M, nVza, hdr_all, zeroT_hi, m_first;  // M moments starting at Fourier index m_first
   const int *node;
   const double *cos_mphi, *sin_mphi;
   const float *J0p, *J0m, *hdrJ0, *hdrJm;
@@ -50,18 +52,47 @@ __global__ void k_postprocess_f32(PostArgsF a) {
   const size_t s = idx / ((size_t)a.nVza * a.nS);
   const int row = (a.node[v] - 1) * a.nS + k;
   float r = 0.f, t = 0.f, h = 0.f;
-  for (int m = 0; m < a.M; ++m) {
+  for (int mr = 0; mr < a.M; ++mr) {
+    const int m = a.m_first + mr;
     const double weight = (m == 0) ? 0.5 : 1.0;
     const float cs = (float)(weight * ((k < 2) ? a.cos_mphi[v + (size_t)a.nVza * m] : a.sin_mphi[v + (size_t)a.nVza * m]));
-    const size_t o = row + (size_t)a.N * (s + (size_t)a.S * m);
+    const size_t o = row + (size_t)a.N * (s + (size_t)a.S * mr);
     r += cs * a.J0m[o];
     if (!(a.zeroT_hi && m > 0)) t += cs * a.J0p[o];
     if (m == 0) h += cs * a.hdrJ0[row + (size_t)a.N * s];
-    else if (a.hdr_all) h += cs * a.hdrJm[o];
+    else if (a.hdr_all) h += cs * a.hdrJm[row + (size_t)a.N * (s + (size_t)a.S * m)];
   }
   a.R[idx] = r;
   a.T[idx] = t;
   a.hdr[idx] = h;
+}
+
+// m = 0 reduction: the (I,Q) sub-scene's spectra [nVza,nS0,S] and BHR [nS0,S] are added to / become the first nS0 Stokes
+// components of the full scene's (whose own moments start at m = 1); components >= nS0 get no m = 0 term (exactly 0)
+struct CombineArgsF {
+  int nVza, nS, nS0, S;
+  float *R, *T, *hdr, *bhr_uw, *bhr_dw;
+  const float *R0, *T0, *hdr0, *bhr0_uw, *bhr0_dw;
+};
+__global__ void k_combine_m0_f32(CombineArgsF a) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)a.nVza * a.nS * a.S;
+  if (idx < total) {
+    const int v = (int)(idx % a.nVza), k = (int)((idx / a.nVza) % a.nS);
+    const size_t s = idx / ((size_t)a.nVza * a.nS);
+    if (k < a.nS0) {
+      const size_t o = v + (size_t)a.nVza * (k + (size_t)a.nS0 * s);
+      a.R[idx] += a.R0[o];
+      a.T[idx] += a.T0[o];
+      a.hdr[idx] += a.hdr0[o];
+    }
+  }
+  if (idx < (size_t)a.nS * a.S) {
+    const int k = (int)(idx % a.nS);
+    const size_t s = idx / a.nS;
+    a.bhr_uw[idx] = (k < a.nS0) ? a.bhr0_uw[k + (size_t)a.nS0 * s] : 0.f;
+    a.bhr_dw[idx] = (k < a.nS0) ? a.bhr0_dw[k + (size_t)a.nS0 * s] : 0.f;
+  }
 }
 
 template <class T>
@@ -123,8 +154,39 @@ std::vector<float> tof(const double *src, size_t n) {
 
 }  // namespace
 
+// Edges with a Float32 strip-chained image; other edges are padded with up to 4 dummy stream entries (mu = 1, weight 0, zero
+// rows and columns in every phase-matrix basis and BRDF matrix: decoupled exactly, see strip_pad in momcore.hip) to reach one
+constexpr int kPadMaxF = 4;
+static bool strip_size_f(int N) { return N == 36 || N == 40 || N == 44 || N == 52 || N == 56 || N == 60; }
+static int strip_pad_f(int N) {
+  if (strip_size_f(N)) return N;
+  for (int p = N + 1; p <= N + kPadMaxF; ++p)
+    if (strip_size_f(p)) return p;
+  return N;
+}
+// [N,N,B] -> [Nk,Nk,B], zero padded
+static std::vector<double> pad_blocks_f(const double *src, int N, int Nk, size_t B) {
+  std::vector<double> out((size_t)Nk * Nk * B, 0.0);
+  for (size_t b = 0; b < B; ++b)
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < N; ++i) out[i + (size_t)Nk * (j + (size_t)Nk * b)] = src[i + (size_t)N * (j + (size_t)N * b)];
+  return out;
+}
+
 struct momf_scene {
   int device = 0, N = 0, nS = 0, S = 0, Mmax = 0;
+  int Nu = 0, Nmax = 0;  // Nu: the caller's operator edge; N: the kernels' (strip_pad_f, decided in momf_set_streams); Nmax: allocated
+  // m = 0 reduction (include/momcore.h, MOM_OPT_M0_REDUCTION): moment 0 runs as its own scene `sub` on the (I,Q) streams,
+  // this scene's launches start at Fourier index m_first = 1
+  momf_scene *sub = nullptr;
+  int m_first = 0;
+  bool opt_m0 = true, opt_pad = true;
+  // operator-level API (mom_ops.hpp): added / surface / composite layers in the reference's [N,N,S] layout, allocated on first use
+  float *op_added[6] = {}, *op_surf[6] = {}, *op_comp[6] = {}, *op_vec[4] = {}, *op_Z[2] = {};
+  size_t op_Zcap = 0;
+  bool op_ready = false, op_comp_set = false;
+  std::vector<double> hd_mu, hd_wt, hd_sg;  // the caller's Float64 streams (the sub-scene is cut from them)
+  double hd_I0[4] = {}, hd_D[4] = {}, hd_mu0 = 0;
   hipStream_t stream = nullptr;
   DevStreams q{};
   float *d_mu = nullptr, *d_wt = nullptr, *d_sg = nullptr;
@@ -135,12 +197,13 @@ struct momf_scene {
   double *d_cos = nullptr, *d_sin = nullptr;
   float *d_smtab = nullptr;               // N <= 4: the three stream-pair tables of the lane-per-point kernel
   int *d_node = nullptr, *d_info = nullptr, *d_nd = nullptr;  // d_nd: ndoubl per layer for the wave-per-point kernel
+  bool pack = true;                       // MOM_OPT_SMALL_N = 1 (2: one point per wavefront)
   bool small_n = true;                    // MOM_OPT_SMALL_N: 4 < N <= 32 on the wave-per-point kernels (mom_wave.hip, Float32 build)
   int Nz = 0, K = 0, M = 0, nVza = 0, surf_kind = 0, G = 1024;
   float albedo = 0.f;
   std::vector<int> nd, iface;
   std::vector<float> h_mu;
-  bool lds = true, force_generic = false, sweep = true, strips = true;
+  bool lds = true, force_generic = false, sweep = true, strips = true, w4 = true;  // w4: MOM_OPT_SMALL_WG
   hipEvent_t ev[4] = {};
   int launches = 0;
   std::string err;
@@ -162,18 +225,19 @@ const char *momf_error(const momf_scene *s) { return s->err.c_str(); }
 int momf_create(momf_scene **out, int device, hipStream_t stream, int N, int nS, int S, int max_m, int *d_info) {
   momf_scene *s = new momf_scene();
   *out = s;
-  s->device = device; s->N = N; s->nS = nS; s->S = S; s->Mmax = max_m; s->stream = stream; s->d_info = d_info;
+  s->device = device; s->N = s->Nu = N; s->nS = nS; s->S = S; s->Mmax = max_m; s->stream = stream; s->d_info = d_info;
+  const int Nm = s->Nmax = strip_pad_f(N);
   s->lds = N <= 64;
   FCHK(s, hipSetDevice(device));
-  FCHK(s, dmallocf(&s->d_mu, N));
-  FCHK(s, dmallocf(&s->d_wt, N));
-  FCHK(s, dmallocf(&s->d_sg, N));
+  FCHK(s, dmallocf(&s->d_mu, Nm));
+  FCHK(s, dmallocf(&s->d_wt, Nm));
+  FCHK(s, dmallocf(&s->d_sg, Nm));
   for (int k = 0; k < 6; ++k) {
-    const size_t per = (k < 4) ? (size_t)comp_pitch(N) * N : (size_t)N;
+    const size_t per = (k < 4) ? (size_t)comp_pitch(Nm) * Nm : (size_t)Nm;
     FCHK(s, dmallocf(&s->comp[k], per * S * max_m));
     FCHK(s, hipMemsetAsync(s->comp[k], 0, per * S * max_m * sizeof(float), stream));
   }
-  const size_t scr = (size_t)s->G * kGenericBufs * mat_elems(N) + (size_t)ld_for(N) * np_for(N);
+  const size_t scr = (size_t)s->G * kGenericBufs * mat_elems(Nm) + (size_t)ld_for(Nm) * np_for(Nm);
   FCHK(s, dmallocf(&s->d_scratch, scr));
   FCHK(s, hipMemsetAsync(s->d_scratch, 0, scr * sizeof(float), stream));
   for (int k = 0; k < 4; ++k) FCHK(s, hipEventCreate(&s->ev[k]));
@@ -183,41 +247,63 @@ int momf_create(momf_scene **out, int device, hipStream_t stream, int N, int nS,
 
 void momf_destroy(momf_scene *s) {
   if (!s) return;
+  momf_destroy(s->sub);
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(s->d_mu); fr(s->d_wt); fr(s->d_sg);
   for (int k = 0; k < 6; ++k) fr(s->comp[k]);
   fr(s->d_tau); fr(s->d_varpi); fr(s->d_zw); fr(s->d_tau_sum); fr(s->d_Zpp); fr(s->d_Zmp); fr(s->d_R); fr(s->d_hdr);
   fr(s->d_hdrJ); fr(s->d_hdrJm); fr(s->d_bhr_uw); fr(s->d_bhr_dw); fr(s->d_scratch); fr(s->d_Rsurf); fr(s->d_albedo_spec);
   fr(s->d_cos); fr(s->d_sin); fr(s->d_node); fr(s->d_nd); fr(s->d_smtab);
+  for (int k = 0; k < 6; ++k) { fr(s->op_added[k]); fr(s->op_surf[k]); fr(s->op_comp[k]); }
+  for (int k = 0; k < 4; ++k) fr(s->op_vec[k]);
+  fr(s->op_Z[0]); fr(s->op_Z[1]);
   for (int k = 0; k < 4; ++k) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
   delete s;
 }
 
-void momf_set_options(momf_scene *s, int inv_mode, int force_generic, int sweep, int small_n) {
+void momf_set_options(momf_scene *s, int inv_mode, int force_generic, int sweep, int small_n, int m0, int pad, int w4) {
+  s->w4 = w4 != 0;
   s->small_n = small_n != 0;
+  s->pack = small_n == 1;
   s->q.inv_mode = inv_mode;
   s->force_generic = force_generic != 0;
   s->lds = (s->N <= 64) && !s->force_generic;
   s->sweep = sweep != 0;
+  s->opt_m0 = m0 != 0;
+  s->opt_pad = pad != 0;
+  if (s->sub) momf_set_options(s->sub, inv_mode, force_generic, sweep, small_n, 0, 0, w4);
 }
 
 int momf_set_streams(momf_scene *s, const double *mu, const double *wt, const double *sg, int imu0, double mu0,
                      const double *I0, const double *D, int regular) {
-  FCHK(s, hipSetDevice(s->device));
-  const int N = s->N;
-  const std::vector<float> fm = tof(mu, N), fw = tof(wt, N), fs = tof(sg, N);
+  const int Nu = s->Nu;
+  s->hd_mu.assign(mu, mu + Nu); s->hd_wt.assign(wt, wt + Nu); s->hd_sg.assign(sg, sg + Nu);
+  for (int k = 0; k < 4; ++k) { s->hd_I0[k] = (k < s->nS) ? I0[k] : 0.0; s->hd_D[k] = (k < s->nS) ? D[k] : 1.0; }
+  s->hd_mu0 = mu0;
+  DevStreams &q = s->q;
+  for (int k = 0; k < 4; ++k) { q.I0[k] = (float)s->hd_I0[k]; q.D[k] = (float)s->hd_D[k]; }
+  q.nS = s->nS; q.imu0 = imu0; q.mu0 = (float)mu0; q.regular = regular;
+  // `regular` was decided on the Float64 streams; two distinct f64 nodes may round to one f32 value, which only makes
+  // more stream pairs take the equal-mu branch of get_elem_rt! -- exactly what a Float32 reference run does
+  return MOM_OK;
+}
+
+// The kernel edge and the device copies of the streams, at scene time (the options that decide the edge may be set after
+// momf_set_streams): padded to a strip-chained image where one is within reach; edges up to 32 belong to the wave-per-point
+// kernel, which takes the operators as they are
+static int apply_streams(momf_scene *s) {
+  const int Nu = s->Nu;
+  if ((int)s->hd_mu.size() != Nu) { s->err = "Float32 scene: streams not set"; return MOM_ESTATE; }
+  const int N = s->N = (s->opt_pad && !s->force_generic && !(Nu <= 32 && s->small_n)) ? strip_pad_f(Nu) : Nu;
+  s->lds = (N <= 64) && !s->force_generic;
+  std::vector<float> fm = tof(s->hd_mu.data(), Nu), fw = tof(s->hd_wt.data(), Nu), fs = tof(s->hd_sg.data(), Nu);
+  fm.resize(N, 1.f); fw.resize(N, 0.f); fs.resize(N, 1.f);  // dummy entries
   s->h_mu = fm;
   FCHK(s, hipMemcpyAsync(s->d_mu, fm.data(), N * sizeof(float), hipMemcpyHostToDevice, s->stream));
   FCHK(s, hipMemcpyAsync(s->d_wt, fw.data(), N * sizeof(float), hipMemcpyHostToDevice, s->stream));
   FCHK(s, hipMemcpyAsync(s->d_sg, fs.data(), N * sizeof(float), hipMemcpyHostToDevice, s->stream));
   FCHK(s, hipStreamSynchronize(s->stream));
-  DevStreams &q = s->q;
-  const int inv = q.inv_mode;
-  q.mu = s->d_mu; q.wt = s->d_wt; q.sg = s->d_sg;
-  for (int k = 0; k < 4; ++k) { q.I0[k] = (k < s->nS) ? (float)I0[k] : 0.f; q.D[k] = (k < s->nS) ? (float)D[k] : 1.f; }
-  q.N = N; q.nS = s->nS; q.imu0 = imu0; q.mu0 = (float)mu0; q.inv_mode = inv; q.regular = regular;
-  // `regular` was decided on the Float64 streams; two distinct f64 nodes may round to one f32 value, which only makes
-  // more stream pairs take the equal-mu branch of get_elem_rt! -- exactly what a Float32 reference run does
+  s->q.mu = s->d_mu; s->q.wt = s->d_wt; s->q.sg = s->d_sg; s->q.N = N;
   return MOM_OK;
 }
 
@@ -232,44 +318,131 @@ static int upload_f(momf_scene *s, T **dst, const U *src, size_t n) {
   return MOM_OK;
 }
 
+static bool wave_applies_f32(const momf_scene *s);
+
 int momf_scene_set(momf_scene *s, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
                    const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface, const double *tau_sum,
                    double albedo, int nVza, const int *node, const double *cos_mphi, const double *sin_mphi) {
   FCHK(s, hipSetDevice(s->device));
-  const size_t S = s->S, NN = (size_t)s->N * s->N;
   int rc;
+  if ((rc = apply_streams(s))) return rc;
+  const int N = s->N, Nu = s->Nu, nS = s->nS;
+  const size_t S = s->S, NN = (size_t)N * N;
   if ((rc = upload_f(s, &s->d_tau, tau, S * Nz))) return rc;
   if ((rc = upload_f(s, &s->d_varpi, varpi, S * Nz))) return rc;
   if ((rc = upload_f(s, &s->d_zw, zw, (size_t)K * S * Nz))) return rc;
   if ((rc = upload_f(s, &s->d_tau_sum, tau_sum, S * (Nz + 1)))) return rc;
-  if ((rc = upload_f(s, &s->d_Zpp, Zpp, NN * K * M))) return rc;
-  if ((rc = upload_f(s, &s->d_Zmp, Zmp, NN * K * M))) return rc;
+  if (N == Nu) {
+    if ((rc = upload_f(s, &s->d_Zpp, Zpp, NN * K * M))) return rc;
+    if ((rc = upload_f(s, &s->d_Zmp, Zmp, NN * K * M))) return rc;
+  } else {
+    const std::vector<double> zp = pad_blocks_f(Zpp, Nu, N, (size_t)K * M), zm = pad_blocks_f(Zmp, Nu, N, (size_t)K * M);
+    if ((rc = upload_f(s, &s->d_Zpp, zp.data(), zp.size()))) return rc;
+    if ((rc = upload_f(s, &s->d_Zmp, zm.data(), zm.size()))) return rc;
+  }
   if ((rc = upload_f(s, &s->d_node, node, (size_t)nVza))) return rc;
   if ((rc = upload_f(s, &s->d_cos, cos_mphi, (size_t)nVza * M))) return rc;
   if ((rc = upload_f(s, &s->d_sin, sin_mphi, (size_t)nVza * M))) return rc;
   auto renew = [&](float **p, size_t n) -> hipError_t { if (*p) { (void)hipFree(*p); *p = nullptr; } return dmallocf(p, n); };
-  const size_t nout = (size_t)nVza * s->nS * S;
+  const size_t nout = (size_t)nVza * nS * S;
   FCHK(s, renew(&s->d_R, 2 * nout));
   s->d_T = s->d_R + nout;
   FCHK(s, renew(&s->d_hdr, nout));
-  FCHK(s, renew(&s->d_hdrJ, (size_t)s->N * S));
-  FCHK(s, renew(&s->d_bhr_uw, (size_t)s->nS * S));
-  FCHK(s, renew(&s->d_bhr_dw, (size_t)s->nS * S));
+  FCHK(s, renew(&s->d_hdrJ, (size_t)N * S));
+  FCHK(s, renew(&s->d_bhr_uw, (size_t)nS * S));
+  FCHK(s, renew(&s->d_bhr_dw, (size_t)nS * S));
   s->Nz = Nz; s->K = K; s->M = M; s->nVza = nVza; s->albedo = (float)albedo; s->surf_kind = 0;
   s->nd.assign(ndoubl, ndoubl + Nz);
   s->iface.assign(iface, iface + Nz);
+  // ---- m = 0 reduction (include/momcore.h): the same conditions as the Float64 driver, checked on the data, bitwise.
+  // Scenes that run on the lane- or wave-per-point kernels (all moments in one launch) keep moment 0 there.
+  s->m_first = 0;
+  const int Nq = Nu / nS;
+  bool ok = s->opt_m0 && nS >= 3 && s->q.regular && !(Nu <= 4 && s->small_n) && !wave_applies_f32(s);
+  for (int k = 2; k < nS && ok; ++k) ok = (s->hd_I0[k] == 0.0);
+  for (int kb = 0; kb < K && ok; ++kb)
+    for (int j = 0; j < Nu && ok; ++j)
+      for (int i = 0; i < Nu; ++i) {
+        if (((i % nS) < 2) == ((j % nS) < 2)) continue;
+        const size_t o = i + (size_t)Nu * (j + (size_t)Nu * kb);  // moment 0 block
+        if (Zpp[o] != 0.0 || Zmp[o] != 0.0) { ok = false; break; }
+      }
+  if (!ok) {
+    momf_destroy(s->sub);
+    s->sub = nullptr;
+    return MOM_OK;
+  }
+  // N0r real entries; the kernels run on N0 >= N0r (dummy entries at the end) unless the wave-per-point kernel takes the scene
+  const int nS0 = 2, N0r = nS0 * Nq;
+  const int N0 = (s->opt_pad && !s->force_generic && !(N0r <= 32 && s->small_n)) ? strip_pad_f(N0r) : N0r;
+  if (s->sub && !(s->sub->Nu == N0 && s->sub->S == s->S)) { momf_destroy(s->sub); s->sub = nullptr; }
+  if (!s->sub) {
+    if ((rc = momf_create(&s->sub, s->device, s->stream, N0, nS0, s->S, 1, s->d_info))) {
+      s->err = s->sub->err;
+      momf_destroy(s->sub);
+      s->sub = nullptr;
+      return rc;
+    }
+  }
+  momf_scene *u = s->sub;
+  momf_set_options(u, s->q.inv_mode, s->force_generic, s->sweep, s->small_n, 0, 0, s->w4);
+  u->strips = s->strips;
+  std::vector<double> mu0v(N0, 1.0), wt0v(N0, 0.0), sg0v(N0, 1.0), zp((size_t)N0 * N0 * K, 0.0), zm((size_t)N0 * N0 * K, 0.0);
+  auto full = [&](int i0) { return (i0 / nS0) * nS + (i0 % nS0); };
+  for (int i = 0; i < N0r; ++i) { mu0v[i] = s->hd_mu[full(i)]; wt0v[i] = s->hd_wt[full(i)]; }
+  for (int kb = 0; kb < K; ++kb)
+    for (int j = 0; j < N0r; ++j)
+      for (int i = 0; i < N0r; ++i) {
+        const size_t src = full(i) + (size_t)Nu * (full(j) + (size_t)Nu * kb);
+        zp[i + (size_t)N0 * (j + (size_t)N0 * kb)] = Zpp[src];
+        zm[i + (size_t)N0 * (j + (size_t)N0 * kb)] = Zmp[src];
+      }
+  const double one[4] = {1.0, 1.0, 1.0, 1.0};
+  auto sub_fail = [&](int code) { s->err = u->err; return code; };
+  if ((rc = momf_set_streams(u, mu0v.data(), wt0v.data(), sg0v.data(), s->q.imu0, s->hd_mu0, s->hd_I0, one, s->q.regular)))
+    return sub_fail(rc);
+  if ((rc = momf_scene_set(u, Nz, K, 1, tau, varpi, zw, zp.data(), zm.data(), ndoubl, iface, tau_sum, albedo, nVza, node, cos_mphi,
+                           sin_mphi)))
+    return sub_fail(rc);
+  s->m_first = 1;
   return MOM_OK;
 }
 
 int momf_scene_set_surface(momf_scene *s, int kind, int M, const double *Rsurf, const double *albedo_spec) {
   FCHK(s, hipSetDevice(s->device));
+  const int N = s->N, Nu = s->Nu, nS = s->nS;
   int rc;
   if (kind == 1) {
-    if ((rc = upload_f(s, &s->d_Rsurf, Rsurf, (size_t)s->N * s->N * M))) return rc;
+    if (N == Nu) {
+      if ((rc = upload_f(s, &s->d_Rsurf, Rsurf, (size_t)N * N * M))) return rc;
+    } else {
+      const std::vector<double> rp = pad_blocks_f(Rsurf, Nu, N, (size_t)M);
+      if ((rc = upload_f(s, &s->d_Rsurf, rp.data(), rp.size()))) return rc;
+    }
     if (s->d_hdrJm) { (void)hipFree(s->d_hdrJm); s->d_hdrJm = nullptr; }
-    FCHK(s, dmallocf(&s->d_hdrJm, (size_t)s->N * s->S * M));
+    FCHK(s, dmallocf(&s->d_hdrJm, (size_t)N * s->S * M));
+    if (s->m_first) {
+      // moment 0 runs on the (I,Q) sub-scene: its surface matrix must not couple (I,Q) with (U,V) either
+      const int nS0 = s->sub->nS, N0 = s->sub->Nu;
+      std::vector<double> r0((size_t)N0 * N0, 0.0);
+      for (int j = 0; j < Nu; ++j)
+        for (int i = 0; i < Nu; ++i) {
+          const bool iq_i = (i % nS) < nS0, iq_j = (j % nS) < nS0;
+          const double v = Rsurf[i + (size_t)Nu * j];
+          if (iq_i != iq_j && v != 0.0) {
+            s->err = "mom_scene_set_surface: the m = 0 BRDF matrix couples (I,Q) with (U,V); set MOM_OPT_M0_REDUCTION = 0 before "
+                     "mom_scene_set for this surface";
+            return MOM_EINVAL;
+          }
+          if (iq_i && iq_j) r0[(i / nS) * nS0 + (i % nS) + (size_t)N0 * ((j / nS) * nS0 + (j % nS))] = v;
+        }
+      if ((rc = momf_scene_set_surface(s->sub, 1, 1, r0.data(), nullptr))) { s->err = s->sub->err; return rc; }
+    }
   } else if (kind == 2) {
     if ((rc = upload_f(s, &s->d_albedo_spec, albedo_spec, (size_t)s->S))) return rc;
+    if (s->m_first && (rc = momf_scene_set_surface(s->sub, 2, 1, nullptr, albedo_spec))) { s->err = s->sub->err; return rc; }
+  } else if (s->m_first) {
+    s->sub->surf_kind = 0;
   }
   s->surf_kind = kind;
   return MOM_OK;
@@ -284,6 +457,12 @@ hipError_t momf_strip11_launch_layer(const void *layer_args, int iface, int grid
 hipError_t momf_strip13_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t momf_strip14_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t momf_strip15_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
+// ... and their 4-wave builds (momcore_f4s<KS>.o, namespace momf4): two workgroups per CU
+#define MOMF4_DECL(KS)                                                                                          \
+  hipError_t momf4_strip##KS##_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st); \
+  size_t momf4_strip##KS##_lds_bytes();
+MOMF4_DECL(9) MOMF4_DECL(10) MOMF4_DECL(11) MOMF4_DECL(13) MOMF4_DECL(14) MOMF4_DECL(15)
+#undef MOMF4_DECL
 
 // 4 < N <= 32: one spectral point per wavefront, operators in MFMA-layout registers, the whole run in ONE launch -- the
 // Float32 build of momw::k_wsweep (the Float64 path: rt_run_wave in momcore.hip).  Covers ScatteringInterface_11 on every
@@ -301,6 +480,7 @@ static int rt_run_wave_f32(momf_scene *s) {
   MomWaveSweepArgsF a{};
   a.N = s->N; a.S = s->S; a.M = s->M; a.K = s->K; a.Nz = s->Nz; a.nVza = s->nVza; a.nS = s->nS; a.imu0 = s->q.imu0;
   a.inv_mode = s->q.inv_mode;
+  a.pad = s->pack ? (s->N == 5 ? 3 : (s->N >= 6 && s->N <= 8 ? 2 : 1)) : 1;  // points per wavefront (k_wsweep's PK)
   a.mu0 = s->q.mu0; a.albedo = s->albedo;
   for (int k = 0; k < 4; ++k) { a.I0[k] = s->q.I0[k]; a.D[k] = s->q.D[k]; }
   a.mu = s->d_mu; a.wt = s->d_wt; a.sg = s->d_sg;
@@ -362,7 +542,8 @@ int momf_rt_run(momf_scene *s) {
   if (s->N <= 4 && s->small_n && !s->force_generic && s->nVza <= 4 && s->surf_kind == 0 && s->K <= 4) return rt_run_small_f32(s);
   if (wave_applies_f32(s)) return rt_run_wave_f32(s);
   const size_t S = s->S;
-  const int N = s->N, M = s->M, Nz = s->Nz;
+  const int N = s->N, Nz = s->Nz;
+  const int m_first = s->m_first, M = s->M - m_first;  // this scene's own moments: m_first ... s->M - 1
   const bool lds = s->lds;
   const size_t sm = lds_bytes(N, lds);
   s->launches = 0;
@@ -370,9 +551,15 @@ int momf_rt_run(momf_scene *s) {
   for (int z = 2; z < Nz && can_sweep; ++z) can_sweep = (s->iface[z] == s->iface[1]);
   for (int z = 0; z < Nz && can_sweep; ++z) can_sweep = (s->nd[z] <= 127);
   FCHK(s, hipEventRecord(s->ev[0], s->stream));
-  for (int z = (can_sweep ? -1 : 0); z < (can_sweep ? 0 : Nz); ++z) {
+  if (m_first) {  // moment 0 on the (I,Q) sub-scene (same stream: in order with what follows)
+    const int rc = momf_rt_run(s->sub);
+    if (rc) { s->err = s->sub->err; return rc; }
+    s->launches += s->sub->launches;
+    FCHK(s, hipSetDevice(s->device));
+  }
+  for (int z = (can_sweep ? -1 : 0); z < (can_sweep ? 0 : Nz) && M > 0; ++z) {
     LayerArgs a{};
-    a.q = s->q; a.S = s->S; a.M = M; a.K = s->K; a.m_first = 0;
+    a.q = s->q; a.S = s->S; a.M = M; a.K = s->K; a.m_first = m_first;
     int zz = z;
     if (z < 0) {
       zz = 0;
@@ -384,7 +571,7 @@ int momf_rt_run(momf_scene *s) {
     }
     a.tau = s->d_tau + S * zz; a.varpi = s->d_varpi + S * zz; a.zw = s->d_zw + (size_t)s->K * S * zz;
     a.tau_sum = s->d_tau_sum + S * zz;
-    a.Zpp = s->d_Zpp; a.Zmp = s->d_Zmp;
+    a.Zpp = s->d_Zpp + (size_t)N * N * s->K * m_first; a.Zmp = s->d_Zmp + (size_t)N * N * s->K * m_first;
     for (int k = 0; k < 6; ++k) a.comp[k] = s->comp[k];
     a.scratch = s->d_scratch; a.info = s->d_info;
     const int grid = lds ? (int)((S >= 2048) ? S : S * M) : (int)std::min<size_t>(S * M, (size_t)s->G);
@@ -399,6 +586,21 @@ int momf_rt_run(momf_scene *s) {
     // strip-chained images (Float32 builds of mom_strip.hpp's chains) for the edges that have one; MOM_OPT_INVERSE != 0 keeps
     // the general path inside the same image, MOM_OPT_STRIPS_F32 = 0 (s->strips) the general image
     const int ks4 = (N % 4 == 0) ? N / 4 : 0;
+    if (lds && s->strips && s->w4 && (ks4 == 9 || ks4 == 10 || ks4 == 11 || ks4 == 13 || ks4 == 14 || ks4 == 15)) {
+      // 4-wave images (N = 36, 40 have no other): two workgroups per CU
+      hipError_t e = hipSuccess;
+      switch (ks4) {
+        case 9: e = momf4_strip9_launch_layer(&a, a.iface, grid, momf4_strip9_lds_bytes(), s->stream); break;
+        case 10: e = momf4_strip10_launch_layer(&a, a.iface, grid, momf4_strip10_lds_bytes(), s->stream); break;
+        case 11: e = momf4_strip11_launch_layer(&a, a.iface, grid, momf4_strip11_lds_bytes(), s->stream); break;
+        case 13: e = momf4_strip13_launch_layer(&a, a.iface, grid, momf4_strip13_lds_bytes(), s->stream); break;
+        case 14: e = momf4_strip14_launch_layer(&a, a.iface, grid, momf4_strip14_lds_bytes(), s->stream); break;
+        default: e = momf4_strip15_launch_layer(&a, a.iface, grid, momf4_strip15_lds_bytes(), s->stream); break;
+      }
+      FCHK(s, e);
+      s->launches++;
+      continue;
+    }
     if (lds && s->strips && (ks4 == 11 || ks4 == 13 || ks4 == 14 || ks4 == 15)) {
       hipError_t e = hipSuccess;
       switch (ks4) {
@@ -422,13 +624,15 @@ int momf_rt_run(momf_scene *s) {
     s->launches++;
   }
   FCHK(s, hipEventRecord(s->ev[1], s->stream));
-  for (int m = 0; m < ((s->surf_kind == 1) ? M : 1); ++m) {
+  // surface: every moment of a BRDF surface, moment 0 only otherwise (m > 0: r = 0, t = I, j = 0 -- the interaction is the identity)
+  for (int m = m_first; m < ((s->surf_kind == 1) ? s->M : 1); ++m) {
     SurfArgs a{};
     a.q = s->q; a.S = s->S; a.iface = s->iface[Nz - 1];
     a.albedo = s->albedo; a.tau_tot = s->d_tau_sum + S * Nz;
     a.kind = s->surf_kind; a.m = m; a.albedo_spec = s->d_albedo_spec;
     a.Rsurf = (s->surf_kind == 1) ? s->d_Rsurf + (size_t)N * N * m : nullptr;
-    for (int k = 0; k < 6; ++k) a.comp[k] = s->comp[k] + ((k < 4) ? (size_t)comp_pitch(N) * N : (size_t)N) * S * m;
+    for (int k = 0; k < 6; ++k)
+      a.comp[k] = s->comp[k] + ((k < 4) ? (size_t)comp_pitch(N) * N : (size_t)N) * S * (m - m_first);
     a.hdrJ = (m == 0) ? s->d_hdrJ : s->d_hdrJm + (size_t)N * S * m;
     a.bhr_uw = s->d_bhr_uw; a.bhr_dw = s->d_bhr_dw; a.nS_out = s->nS;
     a.scratch = s->d_scratch; a.info = s->d_info;
@@ -446,13 +650,21 @@ int momf_rt_run(momf_scene *s) {
   {
     const size_t total = (size_t)s->nVza * s->nS * S;
     PostArgsF pa{};
-    pa.N = N; pa.nS = s->nS; pa.S = s->S; pa.M = M; pa.nVza = s->nVza;
+    pa.N = N; pa.nS = s->nS; pa.S = s->S; pa.M = M; pa.nVza = s->nVza; pa.m_first = m_first;
     pa.hdr_all = (s->surf_kind == 1); pa.zeroT_hi = (s->surf_kind == 2);
     pa.node = s->d_node; pa.cos_mphi = s->d_cos; pa.sin_mphi = s->d_sin;
     pa.J0p = s->comp[4]; pa.J0m = s->comp[5]; pa.hdrJ0 = s->d_hdrJ; pa.hdrJm = s->d_hdrJm;
     pa.R = s->d_R; pa.T = s->d_T; pa.hdr = s->d_hdr;
     hipLaunchKernelGGL(k_postprocess_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s->stream, pa);
     FCHK(s, hipGetLastError());
+    if (m_first) {
+      const momf_scene *u = s->sub;
+      CombineArgsF ca{s->nVza, s->nS, u->nS, s->S, s->d_R, s->d_T, s->d_hdr, s->d_bhr_uw, s->d_bhr_dw,
+                      u->d_R, u->d_T, u->d_hdr, u->d_bhr_uw, u->d_bhr_dw};
+      const size_t tot2 = std::max(total, (size_t)s->nS * S);
+      hipLaunchKernelGGL(k_combine_m0_f32, dim3((unsigned)((tot2 + 255) / 256)), dim3(256), 0, s->stream, ca);
+      FCHK(s, hipGetLastError());
+    }
   }
   FCHK(s, hipEventRecord(s->ev[3], s->stream));
   return MOM_OK;
@@ -526,4 +738,166 @@ int momf_blas(momf_scene *s, int n, int batch, const double *A, const double *B,
   if (dB) (void)hipFree(dB);
   if (scr) (void)hipFree(scr);
   return rc;
+}
+
+// =========================================================================================
+// operator-level API on a Float32 handle: Float64 host arrays at the ABI (rounded on upload, widened on download), the
+// kernels of mom_ops.hpp in namespace momf.  The operators run on the caller's edge (no padding) and their own layer arrays.
+// =========================================================================================
+static int op_begin(momf_scene *s, DevStreams *q) {
+  FCHK(s, hipSetDevice(s->device));
+  const int N = s->Nu;
+  if ((int)s->hd_mu.size() != N) { s->err = "operator-level call: streams not set"; return MOM_ESTATE; }
+  if (!s->op_ready) {
+    const size_t NN = (size_t)N * N;
+    for (int k = 0; k < 6; ++k) {
+      const size_t per = ((k < 4) ? NN : (size_t)N) * s->S;
+      FCHK(s, dmallocf(&s->op_added[k], per));
+      FCHK(s, dmallocf(&s->op_surf[k], per));
+      FCHK(s, dmallocf(&s->op_comp[k], per));
+      FCHK(s, hipMemsetAsync(s->op_added[k], 0, per * sizeof(float), s->stream));
+      FCHK(s, hipMemsetAsync(s->op_surf[k], 0, per * sizeof(float), s->stream));
+      FCHK(s, hipMemsetAsync(s->op_comp[k], 0, per * sizeof(float), s->stream));
+    }
+    for (int k = 0; k < 4; ++k) FCHK(s, dmallocf(&s->op_vec[k], (size_t)s->S));
+    s->op_ready = true;
+  }
+  // the caller's streams (a scene on this handle may have padded the device copies BEHIND entry Nu - 1; rewritten here anyway)
+  const std::vector<float> fm = tof(s->hd_mu.data(), N), fw = tof(s->hd_wt.data(), N), fs = tof(s->hd_sg.data(), N);
+  FCHK(s, hipMemcpyAsync(s->d_mu, fm.data(), N * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  FCHK(s, hipMemcpyAsync(s->d_wt, fw.data(), N * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  FCHK(s, hipMemcpyAsync(s->d_sg, fs.data(), N * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  FCHK(s, hipStreamSynchronize(s->stream));
+  *q = s->q;
+  q->mu = s->d_mu; q->wt = s->d_wt; q->sg = s->d_sg; q->N = N;
+  return MOM_OK;
+}
+static int up_vec(momf_scene *s, float *dst, const double *src, size_t n) {
+  const std::vector<float> v = tof(src, n);
+  FCHK(s, hipMemcpyAsync(dst, v.data(), n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  FCHK(s, hipStreamSynchronize(s->stream));
+  return MOM_OK;
+}
+#define OP_LAUNCH(s, KERN, grid, args)                                                            \
+  do {                                                                                            \
+    const bool l__ = (s)->Nu <= 64 && !(s)->force_generic;                                        \
+    const size_t sm__ = lds_bytes((s)->Nu, l__);                                                  \
+    if (l__) {                                                                                    \
+      FCHK(s, allow(KERN<true>, sm__));                                                           \
+      hipLaunchKernelGGL(KERN<true>, dim3(grid), dim3(kThreads), sm__, (s)->stream, args);        \
+    } else {                                                                                      \
+      FCHK(s, allow(KERN<false>, sm__));                                                          \
+      hipLaunchKernelGGL(KERN<false>, dim3(grid), dim3(kThreads), sm__, (s)->stream, args);       \
+    }                                                                                             \
+    FCHK(s, hipGetLastError());                                                                   \
+  } while (0)
+static int op_grid(const momf_scene *s) {
+  return (s->Nu <= 64 && !s->force_generic) ? s->S : (int)std::min<size_t>((size_t)s->S, (size_t)s->G);
+}
+
+int momf_op_elemental(momf_scene *s, int m, int nd, const double *tau_sum, const double *dtau, const double *varpi,
+                      const double *Zpp, const double *Zmp, int z_batch) {
+  OpArgs a{};
+  int rc;
+  if ((rc = op_begin(s, &a.q))) return rc;
+  const size_t zc = (size_t)s->Nu * s->Nu * z_batch;
+  if (zc > s->op_Zcap) {
+    if (s->op_Z[0]) { (void)hipFree(s->op_Z[0]); (void)hipFree(s->op_Z[1]); s->op_Z[0] = s->op_Z[1] = nullptr; }
+    FCHK(s, dmallocf(&s->op_Z[0], zc));
+    FCHK(s, dmallocf(&s->op_Z[1], zc));
+    s->op_Zcap = zc;
+  }
+  if ((rc = up_vec(s, s->op_vec[0], tau_sum, s->S)) || (rc = up_vec(s, s->op_vec[1], dtau, s->S)) ||
+      (rc = up_vec(s, s->op_vec[2], varpi, s->S)) || (rc = up_vec(s, s->op_Z[0], Zpp, zc)) || (rc = up_vec(s, s->op_Z[1], Zmp, zc)))
+    return rc;
+  a.S = s->S; a.m = m; a.nd = nd; a.z_batch = z_batch;
+  a.tau_sum = s->op_vec[0]; a.dtau = s->op_vec[1]; a.varpi = s->op_vec[2]; a.Zpp = s->op_Z[0]; a.Zmp = s->op_Z[1];
+  for (int k = 0; k < 6; ++k) a.added[k] = s->op_added[k];
+  a.scratch = s->d_scratch; a.info = s->d_info;
+  OP_LAUNCH(s, k_op_elemental, op_grid(s), a);
+  FCHK(s, hipStreamSynchronize(s->stream));
+  return MOM_OK;
+}
+
+int momf_op_doubling(momf_scene *s, int nd, double *expk) {
+  OpArgs a{};
+  int rc;
+  if ((rc = op_begin(s, &a.q))) return rc;
+  if ((rc = up_vec(s, s->op_vec[3], expk, s->S))) return rc;
+  a.S = s->S; a.nd = nd; a.expk = s->op_vec[3];
+  for (int k = 0; k < 6; ++k) a.added[k] = s->op_added[k];
+  a.scratch = s->d_scratch; a.info = s->d_info;
+  if (nd > 0) OP_LAUNCH(s, k_op_doubling, op_grid(s), a);  // doubling.jl:28 returns early for 0
+  return download_f(s, expk, s->op_vec[3], s->S);
+}
+
+int momf_op_interaction(momf_scene *s, int iface, int with_surface_layer) {
+  OpArgs a{};
+  int rc;
+  if ((rc = op_begin(s, &a.q))) return rc;
+  if (!s->op_comp_set) {
+    s->err = "mom_interaction: start the operator-level sequence with mom_copy_added_to_composite or mom_upload";
+    return MOM_ESTATE;
+  }
+  a.S = s->S; a.iface = iface;
+  for (int k = 0; k < 6; ++k) { a.added[k] = with_surface_layer ? s->op_surf[k] : s->op_added[k]; a.comp[k] = s->op_comp[k]; }
+  a.scratch = s->d_scratch; a.info = s->d_info;
+  OP_LAUNCH(s, k_op_interaction, op_grid(s), a);
+  FCHK(s, hipStreamSynchronize(s->stream));
+  return MOM_OK;
+}
+
+int momf_op_copy_added_to_composite(momf_scene *s) {
+  DevStreams q;
+  int rc;
+  if ((rc = op_begin(s, &q))) return rc;
+  const size_t NN = (size_t)s->Nu * s->Nu;
+  const int src[6] = {1, 0, 3, 2, 4, 5};  // composite order R_mp, R_pm, T_pp, T_mm, J0p, J0m ; added order r_pm, r_mp, t_mm, t_pp, j0p, j0m
+  for (int k = 0; k < 6; ++k) {
+    const size_t bytes = ((k < 4) ? NN : (size_t)s->Nu) * s->S * sizeof(float);
+    FCHK(s, hipMemcpyAsync(s->op_comp[k], s->op_added[src[k]], bytes, hipMemcpyDeviceToDevice, s->stream));
+  }
+  FCHK(s, hipStreamSynchronize(s->stream));
+  s->op_comp_set = true;
+  return MOM_OK;
+}
+
+int momf_op_surface_lambertian(momf_scene *s, int m, double albedo, const double *tau_tot) {
+  DevStreams q;
+  int rc;
+  if ((rc = op_begin(s, &q))) return rc;
+  if ((rc = up_vec(s, s->op_vec[0], tau_tot, s->S))) return rc;
+  hipLaunchKernelGGL(k_op_surface_fill, dim3(s->S), dim3(256), 0, s->stream, q, s->S, m, (float)albedo, s->op_vec[0], s->op_surf[0],
+                     s->op_surf[1], s->op_surf[2], s->op_surf[3], s->op_surf[4], s->op_surf[5]);
+  FCHK(s, hipGetLastError());
+  FCHK(s, hipStreamSynchronize(s->stream));
+  return MOM_OK;
+}
+
+static float *op_which(momf_scene *s, int which, size_t *count) {
+  const int grp = which / 6, k = which % 6;
+  *count = ((k < 4) ? (size_t)s->Nu * s->Nu : (size_t)s->Nu) * s->S;
+  return grp == 0 ? s->op_added[k] : (grp == 1 ? s->op_comp[k] : s->op_surf[k]);
+}
+int momf_op_upload(momf_scene *s, int which, const double *src) {
+  DevStreams q;
+  int rc;
+  if ((rc = op_begin(s, &q))) return rc;
+  size_t count = 0;
+  float *p = op_which(s, which, &count);
+  if (which / 6 == 1) s->op_comp_set = true;
+  return up_vec(s, p, src, count);
+}
+int momf_op_download(momf_scene *s, int which, double *dst) {
+  DevStreams q;
+  int rc;
+  if ((rc = op_begin(s, &q))) return rc;
+  if (which / 6 == 1 && !s->op_comp_set) {
+    s->err = "mom_download: a Float32 handle keeps the operator-level composite layer apart from the scene-level state; start "
+             "the operator-level sequence with mom_copy_added_to_composite or mom_upload";
+    return MOM_ESTATE;
+  }
+  size_t count = 0;
+  float *p = op_which(s, which, &count);
+  return download_f(s, dst, p, count);
 }

@@ -45,6 +45,9 @@ hipError_t MOM_CAT(MOM_CAT(MOM_STRIP_PREFIX, MOM_STRIP_KS), _launch_layer)(const
   return hipGetLastError();
 }
 
+// LDS bytes of one workgroup of this image (the vector area depends on the workgroup shape of the build)
+size_t MOM_CAT(MOM_CAT(MOM_STRIP_PREFIX, MOM_STRIP_KS), _lds_bytes)() { return lds_bytes(4 * MOM_STRIP_KS, true); }
+
 #ifdef MOM_DIAG_STAMPS
 extern "C" int MOM_CAT(MOM_CAT(MOM_STRIP_PREFIX, _diag_read), MOM_STRIP_KS)(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mom_diag_acc), 128 * sizeof(unsigned long long)) != hipSuccess) return 1;

@@ -250,6 +250,80 @@ def test_batch_inv_and_mul_float32(rtamd, n, batch):
     helpers.assert_op_close(Cg, mr.to_abi(A @ B), rtol=2e-6, what="batched_mul f32")
 
 
+@pytest.mark.parametrize("nS,Nquad,nd,generic", [(3, 8, 5, False), (1, 6, 3, False), (4, 8, 7, False), (3, 20, 6, False), (3, 9, 4, True),
+                                                 (3, 27, 5, False)])
+def test_float32_operator_level(rtamd, cref, nS, Nquad, nd, generic):
+    """dtype = 1 through every operator (the reference's float_type = Float32, parameters_from_yaml.jl:160; its GPU tests run
+    the batched operators in Float32, test/gpu_tests/gpu_batched_interaction.jl): mom_elemental -> mom_doubling ->
+    mom_copy_added_to_composite -> second layer -> mom_interaction (case 11) -> mom_surface_lambertian -> mom_interaction on a
+    Float32 handle, each step against the Float32 oracle (oracle/momref_f32.c: the same operations rounded to Float32) and the
+    Float64 oracle.  Operator edges 9 ... 81: LDS-resident kernels, forced generic mode, the panel GEMM."""
+    rt = rtamd.corert
+    pol, q = _streams(rt, nS, Nquad=Nquad)
+    N, S = len(q.qp_μN), 9
+    rng = np.random.default_rng(nS + Nquad)
+    Zpp, Zmp = rt.compute_Z_moments(pol, q.qp_μ, rtamd.scenes.hg_like_greek(0.6, 9), 0)
+    Zp, Zm = mr.to_abi(Zpp[None]), mr.to_abi(Zmp[None])
+    p = _P(pol, q)
+    eps = 6e-8
+
+    def close(got, ref32, ref64, what, amp):
+        # against the Float32 oracle: eps32 x the error amplification of the step; against Float64: that + the oracle's own distance
+        e32 = helpers.assert_op_close(got, np.asarray(ref32, np.float64), rtol=amp * eps, what=f"{what} vs f32 oracle")
+        d = float(np.max(np.abs(np.asarray(ref32, np.float64) - ref64))) / max(float(np.max(np.abs(ref64))), 1e-300)
+        helpers.assert_op_close(got, ref64, rtol=amp * eps + 2 * d, what=f"{what} vs f64 oracle")
+        return e32
+
+    h = rtamd.Handle(N, pol.n, S, 1, dtype=1)
+    if generic:
+        h.set_option(rtamd._lib.MOM_OPT_FORCE_GENERIC, 1)
+    h.set_streams(q.qp_μN, q.wt_μN, q.iμ0, q.μ0, pol.I0, pol.D, True)
+    with h:
+        layers32, layers64 = [], []
+        for z in range(2):
+            dtau = 10.0 ** rng.uniform(-4, -3.3, S)
+            varpi = rng.uniform(0.3, 1.0, S)
+            tau_sum = rng.uniform(0.0, 1.0, S)
+            a64 = cref.elemental(p, 0, nd, tau_sum, dtau, varpi, Zp, Zm, 1, S)
+            a32 = cref.elemental_f32(p, 0, nd, tau_sum, dtau, varpi, Zp, Zm, 1, S)
+            h.elemental(0, nd, tau_sum, dtau, varpi, Zp, Zm, 1)
+            for k, nm in enumerate(NAMES):
+                if nm in ("r_pm", "t_mm"):
+                    continue                     # not written for nd >= 1 (elemental.jl:255-274)
+                # 1 - exp(-x), x = dtau (1/mu_i + 1/mu_j), in Float32: one ulp of the exponential is eps32 / x of the result, and
+                # the GPU's expf and the C library's differ by an ulp
+                close(h.download(k), a32[k], a64[k], f"layer {z} elemental {nm}", 8.0 / float(dtau.min()))
+            expk = np.exp(-dtau / q.μ0)
+            e64, e32 = expk.copy(), expk.astype(np.float32)
+            assert cref.doubling(p, nd, e64, a64, S) == 0 and cref.doubling_f32(p, nd, e32, a32, S) == 0
+            e_gpu = h.doubling(nd, expk)
+            np.testing.assert_allclose(e_gpu, e32.astype(np.float64), rtol=4 * eps * 2 ** nd)
+            # the elemental layer's relative error stays; each doubling squares the direct transmission (absolute rounding doubles)
+            amp = 8.0 / float(dtau.min()) + 64 * 2.0 ** nd
+            for k, nm in enumerate(NAMES):
+                close(h.download(k), a32[k], a64[k], f"layer {z} doubling {nm}", amp)
+            layers32.append(a32); layers64.append(a64)
+            if z == 0:
+                h.copy_added_to_composite()
+                order = [1, 0, 3, 2, 4, 5]       # composite R_mp, R_pm, T_pp, T_mm, J0p, J0m <- added r_mp, r_pm, t_pp, t_mm, j0p, j0m
+                c32 = [a32[i].copy() for i in order]
+                c64 = [a64[i].copy() for i in order]
+        h.interaction(3)
+        assert cref.interaction(N, S, 3, c64, layers64[1]) == 0 and cref.interaction_f32(N, S, 3, c32, layers32[1]) == 0
+        for k, nm in enumerate(["R_mp", "R_pm", "T_pp", "T_mm", "J0p", "J0m"]):
+            close(h.download(6 + k), c32[k], c64[k], f"interaction {nm}", 2 * amp)
+        tau_tot = rng.uniform(0.1, 2.0, S)
+        s64 = cref.surface_lambertian(p, 0, tau_tot, S)
+        h.surface_lambertian(0, p.albedo, tau_tot)
+        for k, nm in enumerate(NAMES):
+            helpers.assert_op_close(h.download(12 + k), s64[k], rtol=8 * eps, what=f"surface {nm}")
+        h.interaction(3, with_surface_layer=True)
+        s32 = [np.asarray(x, np.float64).astype(np.float32) for x in s64]
+        assert cref.interaction(N, S, 3, c64, s64) == 0 and cref.interaction_f32(N, S, 3, c32, s32) == 0
+        for k, nm in enumerate(["R_mp", "R_pm", "T_pp", "T_mm", "J0p", "J0m"]):
+            close(h.download(6 + k), c32[k], c64[k], f"surface interaction {nm}", 2 * amp)
+
+
 def test_singular_operator_is_reported(rtamd):
     """The reference ignores cuBLAS `info` (gpu_batched.jl:65-70); here a zero pivot surfaces as MOM_ESINGULAR."""
     n, batch = 12, 4
