@@ -476,6 +476,13 @@ template <int TN, class FA, class FB, class FE>
 __device__ __attribute__((noinline)) void gemm_big_pass(int N, int NC, FA A, FB B, FE epi, int row0, int tcnt, int TMr, int TNr) {
   static_assert(kBigKB == 8 && kThreads == 512, "thread -> panel element mapping below");
   constexpr int TM = 4;
+  // the arguments of a noinline function arrive in vector registers: made scalar again, the "workgroup-uniform" branches
+  // below are s_cbranch instead of exec-masked regions and the panel addresses come from scalar bases
+  // (profiles/r04_C4_ab.txt: one product per workgroup 3-6 % faster at N = 128 ... 256)
+#ifndef MOM_BIG_VECTOR_ARGS
+  N = __builtin_amdgcn_readfirstlane(N); NC = __builtin_amdgcn_readfirstlane(NC); row0 = __builtin_amdgcn_readfirstlane(row0);
+  tcnt = __builtin_amdgcn_readfirstlane(tcnt); TMr = __builtin_amdgcn_readfirstlane(TMr); TNr = __builtin_amdgcn_readfirstlane(TNr);
+#endif
   typedef real r2 __attribute__((ext_vector_type(2)));
   real *tA = mom_smem + vec_area_doubles(N);
   real *tB = tA + kBigStages * kBigStA;
@@ -685,7 +692,7 @@ namespace MOM_NS {
 template <bool LDSM, class FT>
 __device__ __forceinline__ void times_inv(Ctx &c, FT T, real *&Bb, real *&Ob, real beta2) {
   const int N = c.N, ld = c.ld, NN = N * N;
-  int p = (c.inv_mode == 1) ? 1000 : neumann_terms(c.thr, beta2);
+  int p = __builtin_amdgcn_readfirstlane((c.inv_mode == 1) ? 1000 : neumann_terms(c.thr, beta2));  // uniform
   if constexpr (!LDSM && kF64) {
     // Generic mode: the pivoted Gauss-Jordan works in the global slab and costs ~50 products of a step at N = 256, so the
     // series is carried further than the table (beta <= 0.29): the smallest p with beta^p / (1 - beta) <= 2^-56 from the
@@ -1045,7 +1052,7 @@ __device__ __forceinline__ real doubling_run(Ctx &c, int nd, real expk, const Co
     if constexpr (LDSM && KS > 0) {
       // strip-chained step (mom_strip.hpp): the series, A r, (A r) t and A t in one barrier-free MFMA stream
       if (strip_ok) {
-        int p = neumann_terms_12(beta2);
+        int p = __builtin_amdgcn_readfirstlane(neumann_terms_12(beta2));  // workgroup-uniform: scalar loop control in the chains
 #ifdef MOM_DIAG_PPLUS  // (diagnostic builds: one series term more than the bound asks for)
         p += MOM_DIAG_PPLUS;
 #endif

@@ -435,7 +435,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
   MOM_STAMP(53);
   MOM_STAMP4(93);
   const real beta2 = wg_sumsq_get(c);
-  const int p = neumann_terms_12(beta2);
+  const int p = __builtin_amdgcn_readfirstlane(neumann_terms_12(beta2));  // workgroup-uniform: scalar loop control
   if (p > kStripMaxP) return false;
   const unsigned mask = strip_sign_mask(c.sg, lq, N);
   if (do1) {
