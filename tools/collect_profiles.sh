@@ -29,4 +29,5 @@ python3 bench.py --gpus 2 --backend gloo --share-device --no-voigt > $O/${ROUND}
 python3 bench.py --workload C3 --scaling strong --gpus 2 --backend gloo --share-device --no-cpu-baseline > $O/${ROUND}_bench_C3_strong_2ranks_one_gpu.json 2> /dev/null
 python3 bench.py --workload C5 --gpus 2 --backend gloo --share-device --no-cpu-baseline > $O/${ROUND}_bench_C5_2ranks_one_gpu.json 2> /dev/null
 python3 tools/size_sweep.py > $O/${ROUND}_size_sweep.txt 2> /dev/null
+python3 tools/f32_vs_f64.py > $O/${ROUND}_f32_vs_f64.txt 2> /dev/null
 echo collected
