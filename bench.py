@@ -456,7 +456,27 @@ def f32_leg(dev, S=20_000, n_streams=8, nd=5, steps=3):
     flop = M * S * (nd * (12 * N ** 3 + 8 * N ** 2) + N * N * 15)
     ach = flop / (best * 1e-3) / 1e12
     h.close()
-    return {"metric": "Float32 doubling, reference GPU micro-benchmark shape", "value": S * M / (best * 1e-3),
+    # the BASELINE scene itself (C2: IQU, N = 60, 40 layers, M = 3) on a Float32 handle: strip-chained Float32 images (4-wave
+    # builds, two workgroups per CU), moment 0 on the (I,Q) sub-scene -- whole runs incl. surface and post-processing
+    c2 = {}
+    try:
+        S2 = 4096
+        m2 = rtamd.scenes.scene_C2(S=S2, architecture=rtamd.MI355X(dev.index))
+        sc2 = rtamd.prepare_scene(m2)
+        t = {}
+        for ft in ("Float64", "Float32"):
+            with rt.make_handle(m2, float_type=ft) as h2:
+                rt.scene_set(h2, sc2)
+                h2.rt_run(); h2.sync()
+                tb = 1e30
+                for _ in range(2):
+                    t0 = time.perf_counter(); h2.rt_run(); h2.sync(); tb = min(tb, time.perf_counter() - t0)
+                t[ft] = tb
+        c2 = {"workload": f"C2 scene at S = {S2} (N = {sc2.N}, Nz = {sc2.Nz}, M = {sc2.M})", "float64_ms": t["Float64"] * 1e3,
+              "float32_ms": t["Float32"] * 1e3, "float32_points_per_s": S2 / t["Float32"], "speedup_over_float64": t["Float64"] / t["Float32"]}
+    except Exception as e:
+        c2 = {"error": repr(e)}
+    return {"metric": "Float32 doubling, reference GPU micro-benchmark shape", "value": S * M / (best * 1e-3), "c2_scene_float32": c2,
             "unit": "(spectral point, moment) units/s", "dtype": "f32", "layers_ms": best,
             "config": {"workload": f"N={N} (8 streams x 4 Stokes), S={S}, one layer, ndoubl={nd}, M={M}, dtype=1 (Float32)"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

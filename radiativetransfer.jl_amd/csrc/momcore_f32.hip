@@ -184,6 +184,8 @@ struct momf_scene {
   // operator-level API (mom_ops.hpp): added / surface / composite layers in the reference's [N,N,S] layout, allocated on first use
   float *op_added[6] = {}, *op_surf[6] = {}, *op_comp[6] = {}, *op_vec[4] = {}, *op_Z[2] = {};
   size_t op_Zcap = 0;
+  float *blas_buf[4] = {};  // mom_batch_inv / mom_batched_mul: A, B, C, generic-mode scratch (grow-only)
+  size_t blas_cap[4] = {};
   bool op_ready = false, op_comp_set = false;
   std::vector<double> hd_mu, hd_wt, hd_sg;  // the caller's Float64 streams (the sub-scene is cut from them)
   double hd_I0[4] = {}, hd_D[4] = {}, hd_mu0 = 0;
@@ -257,6 +259,7 @@ void momf_destroy(momf_scene *s) {
   for (int k = 0; k < 6; ++k) { fr(s->op_added[k]); fr(s->op_surf[k]); fr(s->op_comp[k]); }
   for (int k = 0; k < 4; ++k) fr(s->op_vec[k]);
   fr(s->op_Z[0]); fr(s->op_Z[1]);
+  for (int k = 0; k < 4; ++k) fr(s->blas_buf[k]);
   for (int k = 0; k < 4; ++k) if (s->ev[k]) (void)hipEventDestroy(s->ev[k]);
   delete s;
 }
@@ -707,20 +710,33 @@ int momf_timers(momf_scene *s, double *ms, int *launches) {
   return MOM_OK;
 }
 
-// batch_inv!(X, A) / A ⊠ B on a Float32 handle: Float64 host arrays at the ABI, f32 on the device
+// batch_inv!(X, A) / A ⊠ B on a Float32 handle: Float64 host arrays at the ABI, f32 on the device; the device buffers are a
+// grow-only workspace of the handle (no hipMalloc / hipFree per call, nothing to leak on an early return)
+static int up_vec(momf_scene *s, float *dst, const double *src, size_t n);
+static int blas_ws(momf_scene *s, int slot, size_t count, float **out) {
+  if (s->blas_cap[slot] < count) {
+    if (s->blas_buf[slot]) { FCHK(s, hipStreamSynchronize(s->stream)); (void)hipFree(s->blas_buf[slot]); s->blas_buf[slot] = nullptr; s->blas_cap[slot] = 0; }
+    FCHK(s, dmallocf(&s->blas_buf[slot], count));
+    s->blas_cap[slot] = count;
+  }
+  *out = s->blas_buf[slot];
+  return MOM_OK;
+}
 int momf_blas(momf_scene *s, int n, int batch, const double *A, const double *B, double *C, bool inv) {
   FCHK(s, hipSetDevice(s->device));
   const size_t cnt = (size_t)n * n * batch;
   float *dA = nullptr, *dB = nullptr, *dC = nullptr, *scr = nullptr;
   int rc;
-  if ((rc = upload_f(s, &dA, A, cnt))) return rc;
-  if (!inv && (rc = upload_f(s, &dB, B, cnt))) return rc;
-  FCHK(s, dmallocf(&dC, cnt));
+  if ((rc = blas_ws(s, 0, cnt, &dA)) || (rc = blas_ws(s, 2, cnt, &dC))) return rc;
+  if ((rc = up_vec(s, dA, A, cnt))) return rc;
+  if (!inv) {
+    if ((rc = blas_ws(s, 1, cnt, &dB)) || (rc = up_vec(s, dB, B, cnt))) return rc;
+  }
   const bool lds = n <= 64 && !s->force_generic;
   const int grid = lds ? batch : std::min(batch, 1024);
   if (!lds) {
     const size_t scn = (size_t)grid * kGenericBufs * mat_elems(n) + (size_t)ld_for(n) * np_for(n);
-    FCHK(s, dmallocf(&scr, scn));
+    if ((rc = blas_ws(s, 3, scn, &scr))) return rc;
     FCHK(s, hipMemsetAsync(scr, 0, scn * sizeof(float), s->stream));
   }
   BlasArgsF a{n, batch, dA, dB, dC, scr, s->d_info};
@@ -733,11 +749,7 @@ int momf_blas(momf_scene *s, int n, int batch, const double *A, const double *B,
     else { FCHK(s, allow(k_batched_mul_f32<false>, sm)); hipLaunchKernelGGL(k_batched_mul_f32<false>, dim3(grid), dim3(kThreads), sm, s->stream, a); }
   }
   FCHK(s, hipGetLastError());
-  rc = download_f(s, C, dC, cnt);
-  (void)hipFree(dA); (void)hipFree(dC);
-  if (dB) (void)hipFree(dB);
-  if (scr) (void)hipFree(scr);
-  return rc;
+  return download_f(s, C, dC, cnt);
 }
 
 // =========================================================================================
