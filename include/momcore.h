@@ -136,7 +136,8 @@ int mom_elemental_inelastic_rrs(mom_t *h, int m, int ndoubl, int nRaman, const i
  *
  *   mom_rrs_set        the fields of the RRS struct (src/Inelastic/types.jl:13-33) the path reads: i_l1l0 [nRaman] (grid
  *                      offsets n0 - n1, |offset| < nSpec), varpi_l1l0 [nRaman]; allocates the layers (zeros, like
- *                      make_added_layer(::RRS, ...) rt_helper_functions.jl:127-141).  N <= 32.
+ *                      make_added_layer(::RRS, ...) rt_helper_functions.jl:127-141).  N <= 64 (N <= 16: one MFMA tile per operator and wavefront,
+ *                      <= 32: 2 x 2 tiles in registers, <= 48 / <= 64: 3 x 3 / 4 x 4 tiles with the operators in scratch).
  *                      rrs_strict_reference: the reference's RRS text has defects (DESIGN.md "RRS", D1..D5); != 0 executes
  *                      it AS WRITTEN with the semantics of a single-threaded Julia run -- and returns MOM_EUNSUPPORTED
  *                      where the reference raises (interaction_helper! for interfaces 00/01/10, a MethodError) --,

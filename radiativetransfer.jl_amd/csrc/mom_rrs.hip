@@ -15,7 +15,7 @@
 //   * a PAIR kernel, one wavefront per (n1, dn): the 9 (doubling) / 18 (interaction 11) operator products and 7 / 8
 //     matrix-vector products of the reference's update formulas as register-tile MFMA products (mom_tile.hpp), reading
 //     and writing each 4-D array block exactly once, in place.  N <= 16: one 16 x 16 tile per operator (the reference's own
-//     RRS shape is N = 15: test/test_parameters/O2Parameters.yaml, IQU, l_trunc 5); N <= 32: 2 x 2 tiles.
+//     RRS shape is N = 15: test/test_parameters/O2Parameters.yaml, IQU, l_trunc 5); N <= 32: 2 x 2 tiles; N <= 48 / <= 64: 3 x 3 / 4 x 4 tiles (second object, MOMR_BIG_TU).
 // Pairs are enumerated dn-major (n1 fastest): the blocks of the 4-D arrays are visited in memory order, i.e. every array is
 // one sequential HBM stream per launch (n1-major order -- consecutive pairs 12 MB apart -- ran at 2.6 TB/s instead); the
 // per-point operands (7 x N^2 x S doubles = 86 MB at C5) are re-read once per Raman line from L2 / Infinity Cache.  HBM-bound: 4 (doubling) / 12 (interaction) block transfers of N^2 doubles per pair against
@@ -32,8 +32,20 @@
 
 #include "mom_tile.hpp"
 
-namespace momr {
+hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, void *stream, const void *args, int iface);
+
+// The 3 x 3- and 4 x 4-tile images (32 < N <= 64) are built as a second object from this source (-DMOMR_BIG_TU, namespace
+// momr_big, without -amdgpu-mfma-vgpr-form, which crashes the compiler on them): device code + ONE launcher, momr_big_launch
+#ifdef MOMR_BIG_TU
+#define MOMR_NS momr_big
+#else
+#define MOMR_NS momr
+#endif
+namespace MOMR_NS {
 using namespace momt;
+#ifdef MOMR_BIG_TU
+using namespace momr;  // the enumerations and constants of mom_rrs.hpp
+#endif
 
 struct KArgs {
   int N, nS, S, nR, strict_idx, strict_rrs, n_glob0, n1_lo, n1_hi, last, nd, sh, m, imu0, nTerms;
@@ -640,6 +652,15 @@ template <bool FUSE, int MODE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair1(KArgs a) { dbl_pair_body<1, FUSE, MODE>(a); }
 template <bool FUSE, int MODE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_dbl_pair2(KArgs a) { dbl_pair_body<2, FUSE, MODE>(a); }
+// 32 < N <= 64 (r4): the same bodies on 3 x 3 and 4 x 4 tiles.  Nine / sixteen tiles per operator do not fit the register file
+// of a wave (a pair holds about ten operators), so these images live on scratch: they exist so that rt_run(::RRS) has no
+// size limit below N = 64, not for speed (tools/bench_rrs_nt2.py has their timings)
+#ifdef MOMR_BIG_TU
+template <bool FUSE, int MODE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_dbl_pair3(KArgs a) { dbl_pair_body<3, FUSE, MODE>(a); }
+template <bool FUSE, int MODE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_dbl_pair4(KArgs a) { dbl_pair_body<4, FUSE, MODE>(a); }
+#endif
 
 // apply_D_IE_RRS! / apply_D_SFI_IE_RRS! as written (doubling_inelastic.jl:291-311, :345-357), strict position: the work
 // item (n, dn) addresses the RAMAN axis with n0 = n + i_l1l0[dn] (1-based) when 1 <= n0 <= nRaman.  One thread per
@@ -939,6 +960,12 @@ template <bool SURF, bool DERIVE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair1(KArgs a, int iface) { int_pair_body<1, SURF, DERIVE>(a, iface); }
 template <bool SURF, bool DERIVE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_int_pair2(KArgs a, int iface) { int_pair_body<2, SURF, DERIVE>(a, iface); }
+#ifdef MOMR_BIG_TU
+template <bool SURF, bool DERIVE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_int_pair3(KArgs a, int iface) { int_pair_body<3, SURF, DERIVE>(a, iface); }
+template <bool SURF, bool DERIVE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_int_pair4(KArgs a, int iface) { int_pair_body<4, SURF, DERIVE>(a, iface); }
+#endif
 
 // create_surface_layer! into the surface layer arrays: kind 0 LambertianSurfaceScalar (Surfaces/lambertian_surface.jl:20-75),
 // 1 any BRDF type through its Fourier matrix Rsurf [N,N] of this moment (rpv_surface.jl:20-66), 2 LambertianSurfaceLegendre
@@ -1057,6 +1084,43 @@ __global__ void k_unpack(double *nat, const double *dev, int rows, int cols, int
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
+#ifdef MOMR_BIG_TU
+}  // namespace momr_big
+// which: 0 k_el_point, 1 k_dbl_point, 2 k_int_point, 3 k_dbl_pair (v0 = fused elemental, v1 = mode), 4 k_int_pair (v0 = surface,
+// v1 = derived +- / -- blocks); nt = 3 or 4; args: the KArgs of the caller (layout-identical in both namespaces)
+hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, void *stream, const void *args, int iface) {
+  using namespace momr_big;
+  const KArgs a = *reinterpret_cast<const KArgs *>(args);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 gr(grid), bl(64 * kWavesPerBlock);
+  const size_t lds = (size_t)kWavesPerBlock * (nt == 3 ? slice_bytes<3>() : slice_bytes<4>());
+#define BIG_GO(KERN, ...)                                                                                                      \
+  do {                                                                                                                         \
+    const hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void *>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e__ != hipSuccess) return e__;                                                                                         \
+    hipLaunchKernelGGL(KERN, gr, bl, lds, st, __VA_ARGS__);                                                                    \
+    return hipGetLastError();                                                                                                  \
+  } while (0)
+#define BIG_NT(KERN3, KERN4, ...) do { if (nt == 3) BIG_GO(KERN3, __VA_ARGS__); else BIG_GO(KERN4, __VA_ARGS__); } while (0)
+  switch (which) {
+    case 0: BIG_NT(k_el_point<3>, k_el_point<4>, a);
+    case 1: BIG_NT(k_dbl_point<3>, k_dbl_point<4>, a);
+    case 2: BIG_NT(k_int_point<3>, k_int_point<4>, a, iface);
+    case 3:
+#define BIG_DBL(F, M) BIG_NT((k_dbl_pair3<F, M>), (k_dbl_pair4<F, M>), a)
+      if (v0) { if (v1 == 0) BIG_DBL(true, 0); else if (v1 == 1) BIG_DBL(true, 1); else BIG_DBL(true, 2); }
+      else { if (v1 == 0) BIG_DBL(false, 0); else if (v1 == 1) BIG_DBL(false, 1); else BIG_DBL(false, 2); }
+#undef BIG_DBL
+    case 4:
+      if (v0) BIG_NT((k_int_pair3<true, false>), (k_int_pair4<true, false>), a, iface);
+      else if (v1) BIG_NT((k_int_pair3<false, true>), (k_int_pair4<false, true>), a, iface);
+      else BIG_NT((k_int_pair3<false, false>), (k_int_pair4<false, false>), a, iface);
+    default: return hipErrorInvalidValue;
+  }
+#undef BIG_NT
+#undef BIG_GO
+}
+#else
 #define RCHK(call)                                 \
   do {                                             \
     hipError_t e__ = (call);                       \
@@ -1099,7 +1163,7 @@ hipError_t create(State **out, hipStream_t st, int N, int nS, int S, int nR, con
   State *s = new State;
   s->N = N; s->nS = nS; s->S = S; s->nR = nR; s->strict_rrs = strict_rrs; s->stream = st;
   s->n1_lo = 0; s->n1_hi = S;
-  s->P = N <= 16 ? 16 : 32;  // device blocks are zero-padded to the MFMA tiling: P x P per matrix, P per vector
+  s->P = 16 * ((N + 15) / 16);  // device blocks are zero-padded to the MFMA tiling: P x P per matrix, P per vector
   *out = s;
   const size_t NN = (size_t)s->P * s->P, m3 = NN * S, v3 = (size_t)s->P * S, m4 = m3 * nR, v4 = v3 * nR;
   RCHK(dm(&s->d_off, nR));
@@ -1216,11 +1280,26 @@ static int grid_pairs(const State *s) {
 template <int NT>
 static size_t lds() { return (size_t)kWavesPerBlock * slice_bytes<NT>(); }
 
-#define LAUNCH_NT(s, kern, grid, ...)                                                                              \
-  do {                                                                                                             \
-    if ((s)->N <= 16) hipLaunchKernelGGL((kern<1>), dim3(grid), dim3(64 * kWavesPerBlock), lds<1>(), (s)->stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((kern<2>), dim3(grid), dim3(64 * kWavesPerBlock), lds<2>(), (s)->stream, __VA_ARGS__);   \
-    RCHK(hipGetLastError());                                                                                       \
+// launch with the dynamic LDS of the image's tile count (above 64 KB the limit of the function has to be raised first)
+template <class K, class... Args>
+static hipError_t launch_lds(K kern, dim3 grid, size_t lds_bytes, hipStream_t st, Args... args) {
+  if (lds_bytes > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(64 * kWavesPerBlock), lds_bytes, st, args...);
+  return hipGetLastError();
+}
+template <class T> static const void *first_arg(const T &a) { return &a; }
+template <class T, class U> static const void *first_arg(const T &a, const U &) { return &a; }
+template <class T> static int iface_arg(const T &) { return 0; }
+template <class T> static int iface_arg(const T &, int iface) { return iface; }
+#define LAUNCH_NT(s, kern, which, grid, ...)                                                               \
+  do {                                                                                                    \
+    if ((s)->N <= 16) RCHK(launch_lds(kern<1>, dim3(grid), lds<1>(), (s)->stream, __VA_ARGS__));          \
+    else if ((s)->N <= 32) RCHK(launch_lds(kern<2>, dim3(grid), lds<2>(), (s)->stream, __VA_ARGS__));     \
+    else RCHK(momr_big_launch(which, (s)->N <= 48 ? 3 : 4, 0, 0, (unsigned)(grid), (void *)(s)->stream,   \
+                              first_arg(__VA_ARGS__), iface_arg(__VA_ARGS__)));                           \
   } while (0)
 
 hipError_t elemental(State *s, const Streams &q, int m, int nd, int shift, const double *tau_sum, const double *tau, const double *varpi,
@@ -1229,7 +1308,7 @@ hipError_t elemental(State *s, const Streams &q, int m, int nd, int shift, const
   KArgs a = base_args(s, q);
   a.m = m; a.nd = nd; a.sh = shift; a.tau_sum = tau_sum; a.tau = tau; a.varpi = varpi; a.Zpp = Zpp; a.Zmp = Zmp; a.nTerms = nTerms; a.zw = zw;
   a.fscatt = fscatt; a.Zr_pp = Zr_pp; a.Zr_mp = Zr_mp;
-  if (elastic) LAUNCH_NT(s, k_el_point, grid_points(s), a);
+  if (elastic) LAUNCH_NT(s, k_el_point, 0, grid_points(s), a);
   s->el_pending = false;
   if (inelastic) {
     if (s->fast && nd >= 1 && (fast_bits() & 1)) {  // deferred into the first doubling step (k_dbl_pair, fuse_el)
@@ -1270,18 +1349,18 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
       a.fscatt = s->el.fscatt; a.Zr_pp = s->el.Zr_pp; a.Zr_mp = s->el.Zr_mp;
       s->el_pending = false;
     }
-    LAUNCH_NT(s, k_dbl_point, grid_points(s), a);
+    LAUNCH_NT(s, k_dbl_point, 1, grid_points(s), a);
     RCHK(tick(s, TK_DBL_PAIR, true));
     {
-      const dim3 gr(grid_pairs(s)), bl(64 * kWavesPerBlock);
+      const dim3 gr(grid_pairs(s));
       const int mode = s->strict_rrs ? 2 : (a.last ? 1 : 0);
-#define DBL_PAIR(NT_, FUSE_, MODE_) hipLaunchKernelGGL((k_dbl_pair##NT_<FUSE_, MODE_>), gr, bl, lds<NT_>(), s->stream, a)
+#define DBL_PAIR(NT_, FUSE_, MODE_) RCHK(launch_lds(k_dbl_pair##NT_<FUSE_, MODE_>, gr, lds<NT_>(), s->stream, a))
 #define DBL_PAIR_M(NT_, FUSE_) do { if (mode == 0) DBL_PAIR(NT_, FUSE_, 0); else if (mode == 1) DBL_PAIR(NT_, FUSE_, 1); else DBL_PAIR(NT_, FUSE_, 2); } while (0)
-      if (s->N <= 16) {
-        if (a.fuse_el) DBL_PAIR_M(1, true); else DBL_PAIR_M(1, false);
-      } else {
-        if (a.fuse_el) DBL_PAIR_M(2, true); else DBL_PAIR_M(2, false);
-      }
+#define DBL_PAIR_F(NT_) do { if (a.fuse_el) DBL_PAIR_M(NT_, true); else DBL_PAIR_M(NT_, false); } while (0)
+      if (s->N <= 16) DBL_PAIR_F(1);
+      else if (s->N <= 32) DBL_PAIR_F(2);
+      else RCHK(momr_big_launch(3, s->N <= 48 ? 3 : 4, a.fuse_el ? 1 : 0, mode, gr.x, (void *)s->stream, &a, 0));
+#undef DBL_PAIR_F
 #undef DBL_PAIR_M
 #undef DBL_PAIR
       RCHK(hipGetLastError());
@@ -1338,23 +1417,24 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
   if (!with_surface && !a.derive_pm) RCHK(ensure_pm(s, q));
   for (int k = 0; k < 6; ++k) a.x[k] = with_surface ? s->surf[k] : s->added[s->cur][k];
   if (!with_surface) { a.x[R_PM] = s->added[0][R_PM]; a.x[T_MM] = s->added[0][T_MM]; }
-  LAUNCH_NT(s, k_int_point, grid_points(s), a, iface);
+  LAUNCH_NT(s, k_int_point, 2, grid_points(s), a, iface);
   if (iface == 0) {  // interaction_inelastic.jl:16-17
     const size_t v4 = (size_t)s->P * s->S * s->nR * 8;
     RCHK(hipMemsetAsync(s->ie_comp[C_J0P], 0, v4, s->stream));
     RCHK(hipMemsetAsync(s->ie_comp[C_J0M], 0, v4, s->stream));
   } else {
     RCHK(tick(s, TK_INT_PAIR, true));
-    const dim3 gr(grid_pairs(s)), bl(64 * kWavesPerBlock);
-    if (s->N <= 16) {
-      if (with_surface) hipLaunchKernelGGL((k_int_pair1<true, false>), gr, bl, lds<1>(), s->stream, a, iface);
-      else if (a.derive_pm) hipLaunchKernelGGL((k_int_pair1<false, true>), gr, bl, lds<1>(), s->stream, a, iface);
-      else hipLaunchKernelGGL((k_int_pair1<false, false>), gr, bl, lds<1>(), s->stream, a, iface);
-    } else {
-      if (with_surface) hipLaunchKernelGGL((k_int_pair2<true, false>), gr, bl, lds<2>(), s->stream, a, iface);
-      else if (a.derive_pm) hipLaunchKernelGGL((k_int_pair2<false, true>), gr, bl, lds<2>(), s->stream, a, iface);
-      else hipLaunchKernelGGL((k_int_pair2<false, false>), gr, bl, lds<2>(), s->stream, a, iface);
-    }
+    const dim3 gr(grid_pairs(s));
+#define INT_PAIR(NT_)                                                                                                      \
+  do {                                                                                                                     \
+    if (with_surface) RCHK(launch_lds(k_int_pair##NT_<true, false>, gr, lds<NT_>(), s->stream, a, iface));                 \
+    else if (a.derive_pm) RCHK(launch_lds(k_int_pair##NT_<false, true>, gr, lds<NT_>(), s->stream, a, iface));             \
+    else RCHK(launch_lds(k_int_pair##NT_<false, false>, gr, lds<NT_>(), s->stream, a, iface));                             \
+  } while (0)
+    if (s->N <= 16) INT_PAIR(1);
+    else if (s->N <= 32) INT_PAIR(2);
+    else RCHK(momr_big_launch(4, s->N <= 48 ? 3 : 4, with_surface ? 1 : 0, a.derive_pm ? 1 : 0, gr.x, (void *)s->stream, &a, iface));
+#undef INT_PAIR
     RCHK(hipGetLastError());
     RCHK(tick(s, TK_INT_PAIR, false));
   }
@@ -1458,3 +1538,4 @@ hipError_t postprocess(State *s, const Streams &q, int m, int nVza, const int *d
 }
 
 }  // namespace momr
+#endif  // MOMR_BIG_TU

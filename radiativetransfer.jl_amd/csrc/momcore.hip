@@ -2421,7 +2421,7 @@ extern "C" int mom_rrs_set(mom_t *h, int nRaman, const int *i_l1l0, const double
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   F64_ONLY(h, "mom_rrs_set");
   if (nRaman <= 0 || !i_l1l0 || !varpi_l1l0) return fail(h, MOM_EINVAL, "mom_rrs_set: bad argument");
-  if (h->N > 32) return fail(h, MOM_EUNSUPPORTED, "mom_rrs_set: the RRS kernels cover operator edges N <= 32 (the reference's RRS shape is N = 15)");
+  if (h->N > 64) return fail(h, MOM_EUNSUPPORTED, "mom_rrs_set: the RRS kernels cover operator edges N <= 64 (the reference's RRS shape is N = 15)");
   for (int k = 0; k < nRaman; ++k)
     if (std::abs(i_l1l0[k]) >= h->S) return fail(h, MOM_EINVAL, "mom_rrs_set: |i_l1l0| must be < nSpec (get_n0_n1 fails in the reference)");
   HIPCHK(h, hipSetDevice(h->device));

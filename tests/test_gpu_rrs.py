@@ -94,7 +94,7 @@ def model_and_handle(rtamd, nS, lt, S, Nz=2, seed=1, nv=3):
 OFFS = [-3, 1, 0, 5]
 
 
-@pytest.mark.parametrize("nS,lt,nv", [(1, 7, 3), (3, 5, 1), (4, 5, 1), (3, 11, 3), (1, 43, 3), (4, 9, 3)])
+@pytest.mark.parametrize("nS,lt,nv", [(1, 7, 3), (3, 5, 1), (4, 5, 1), (3, 11, 3), (1, 43, 3), (4, 9, 3), (3, 21, 3), (4, 21, 3), (3, 33, 3)])   # ... N = 42, 56, 60: 3 x 3 / 4 x 4 tiles
 @pytest.mark.parametrize("strict", [True, False])
 @pytest.mark.parametrize("nd", [1, 3])
 def test_doubling_inelastic(rtamd, nS, lt, nv, strict, nd):
@@ -119,7 +119,7 @@ def test_doubling_inelastic(rtamd, nS, lt, nv, strict, nd):
         check_added(h, ref, f"doubling nS={nS} N={N} strict={strict} nd={nd}")
 
 
-@pytest.mark.parametrize("nS,lt,nv", [(1, 7, 3), (3, 5, 1), (4, 5, 1), (3, 11, 3)])
+@pytest.mark.parametrize("nS,lt,nv", [(1, 7, 3), (3, 5, 1), (4, 5, 1), (3, 11, 3), (3, 21, 3), (4, 21, 3)])
 @pytest.mark.parametrize("iface", [3, 0, 1, 2])
 @pytest.mark.parametrize("surface", [False, True])
 def test_interaction_inelastic(rtamd, nS, lt, nv, iface, surface):
@@ -151,7 +151,7 @@ def test_interaction_inelastic(rtamd, nS, lt, nv, iface, surface):
             check_comp(h, ref, f"interaction nS={nS} N={N} iface={iface} surf={surface} strict={strict}")
 
 
-@pytest.mark.parametrize("nS,lt", [(1, 7), (3, 5), (4, 7)])
+@pytest.mark.parametrize("nS,lt", [(1, 7), (3, 5), (4, 7), (3, 21), (4, 21)])
 @pytest.mark.parametrize("nd", [0, 2])
 @pytest.mark.parametrize("mm", [0, 1])
 def test_elemental_stateful(rtamd, nS, lt, nd, mm):
@@ -194,7 +194,8 @@ def _rrs_inputs(rtamd, offsets, strict, amp=0.02, cab=0.96):
     return RS, ora
 
 
-@pytest.mark.parametrize("nS,lt,S,Nz,nv", [(1, 3, 24, 3, 3), (3, 5, 20, 3, 1), (4, 5, 16, 2, 1), (3, 11, 12, 2, 3), (3, 5, 40, 5, 1)])
+@pytest.mark.parametrize("nS,lt,S,Nz,nv", [(1, 3, 24, 3, 3), (3, 5, 20, 3, 1), (4, 5, 16, 2, 1), (3, 11, 12, 2, 3), (3, 5, 40, 5, 1),
+                                            (3, 21, 10, 2, 3), (4, 21, 8, 2, 3)])   # the last two: N = 42, 56
 @pytest.mark.parametrize("strict", [True, False])
 def test_rt_run_rrs_parity(rtamd, nS, lt, S, Nz, nv, strict):
     """rt_run(RS_type::RRS, model, iBand) for seeded scenes (Rayleigh + one aerosol type + gas absorption, Lambertian surface):
@@ -344,7 +345,7 @@ def test_rrs_empty_owned_range(rtamd):
         assert not np.any(ieR) and not np.any(ieT) and not np.any(R) and not np.any(T)
 
 
-@pytest.mark.parametrize("nS,lt,nv", [(3, 5, 1), (4, 5, 1), (3, 11, 3), (4, 9, 3)])   # N = 15, 20 (one view), 27, 32
+@pytest.mark.parametrize("nS,lt,nv", [(3, 5, 1), (4, 5, 1), (3, 11, 3), (4, 9, 3), (3, 21, 3), (4, 21, 3)])   # N = 15, 20 (one view), 27, 32, 42, 56
 @pytest.mark.parametrize("strict", [True, False])
 def test_rrs_zero_padding_invariant(rtamd, nS, lt, nv, strict):
     """The device blocks of the RRS layers are zero-padded to the MFMA tiling (16 x 16 at N <= 16, 32 x 32 above) and the kernels

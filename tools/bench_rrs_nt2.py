@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Timing of the 2 x 2-tile RRS kernels (17 <= N <= 32): mom_rt_run_rrs on seeded scenes of edge 24 and 30, S = 2000,
-40 Raman offsets, corrected switch position.  usage: python tools/bench_rrs_nt2.py > profiles/rNN_rrs_nt2.txt"""
+"""Timing of the multi-tile RRS kernels: mom_rt_run_rrs on seeded scenes of edge 24, 30, 32 (2 x 2 tiles), 42 (3 x 3) and 56,
+60 (4 x 4: scratch-resident operators), 40 Raman offsets, corrected switch position.
+usage: python tools/bench_rrs_nt2.py > profiles/rNN_rrs_nt2.txt"""
 import sys
 import time
 from pathlib import Path
@@ -12,11 +13,12 @@ import rtamd  # noqa: E402
 
 rt = rtamd.corert
 print(f"{'nStokes':>7} {'N':>3} {'S':>5} {'nRaman':>6} {'sum nd':>6} {'ms/run':>8} {'points/s':>9} {'dbl_pair ms':>11} {'int_pair ms':>11}  pairs/launch  GB/s (alg.) of 8 TB/s")
-for nS, lt, vza in ((4, 7, (0.0,)), (3, 13, (0.0, 30.0)), (4, 9, (0.0, 30.0))):
-    S, nR = 2000, 40
+for nS, lt, vza, S in ((4, 7, (0.0,), 2000), (3, 13, (0.0, 30.0), 2000), (4, 9, (0.0, 30.0), 2000), (3, 21, (0.0, 30.0, 60.0), 500),
+                       (4, 21, (0.0, 30.0, 60.0), 500), (3, 33, (0.0, 30.0, 60.0), 500)):
+    nR = 40
     m = rtamd.scenes.make_scene(nS, lt, 5, S, seed=3, aerosol_total=0.1, vza=vza, vaz=tuple(20.0 * i for i in range(len(vza))))
     rng = np.random.default_rng(1)
-    offs = np.unique(rng.integers(-600, 600, 2 * nR))[:nR]
+    offs = np.unique(rng.integers(-min(600, S // 2), min(600, S // 2), 2 * nR))[:nR]
     offs = offs[offs != 0]
     RS = rt.RRS(greek_raman=rt.get_greek_rayleigh(0.2), ϖ_Cabannes=0.96, ϖ_λ1λ0=np.full(len(offs), 0.04 / len(offs)), i_λ1λ0=offs,
                 rrs_strict_reference=False)
