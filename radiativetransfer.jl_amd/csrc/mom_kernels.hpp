@@ -115,8 +115,15 @@ constexpr int kBigCols = 256;  // largest operator the tiles are sized for
 constexpr int kBigStA = kBigKB * kBigLdA;  // reals per A stage; a B stage holds np_for(N) columns of pitch kBigLdB
 constexpr int kBigPatch = 36;  // row pitch of the epilogue patch (16 columns x 32 rows per wave)
 __host__ __device__ inline int big_stage_b(int N) { return 16 * ((N + 15) / 16) * kBigLdB; }
+// r4: operators up to kBig16MaxN take k panels of 16 in TWO stages (gemm_big_pass16: half the barriers per product)
+constexpr int kBig16KB = 16;
+constexpr int kBig16LdB = kBig16KB + 2;
+constexpr int kBig16MaxN = 192;
+__host__ __device__ inline int big16_stage_doubles(int N) { return kBig16KB * kBigLdA + 16 * ((N + 15) / 16) * kBig16LdB; }
 __host__ __device__ inline int big_tile_doubles(int N) {
-  const int st = kBigStages * (kBigStA + big_stage_b(N)), pt = 8 * 16 * kBigPatch;
+  int st = kBigStages * (kBigStA + big_stage_b(N));
+  const int pt = 8 * 16 * kBigPatch;
+  if (N <= kBig16MaxN && 2 * big16_stage_doubles(N) > st) st = 2 * big16_stage_doubles(N);
   return st > pt ? st : pt;
 }
 // Vector area: 15 vectors, the 32 series thresholds, np + 4 ints (ipiv, sh, bad) in whole pairs of reals (the Float32
@@ -659,6 +666,232 @@ __device__ __attribute__((noinline)) void gemm_big_pass(int N, int NC, FA A, FB 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// r4: the same pass with k panels of 16 in two LDS stages, for N <= kBig16MaxN (the three-stage K = 8 form does not leave the
+// LDS for more).  Per panel: the next panel goes from registers to the other stage, the loads of the one after are issued, FOUR
+// k-steps are multiplied (fragments of k-step ks + 1 requested under the MFMAs of ks), one barrier.  A mid-size pass pays its
+// per-panel cost (barrier, exposed LDS / global latency: ~2 000 cycles, tools/gemm_big_bench.hip) for 16-32 MFMAs per wave in
+// the K = 8 form; here for 32-64.  Panel elements per thread: A units (k, row pair of the pass's 128 rows), B units (column,
+// k pair); a unit index past the end repeats the last unit (the same value stored twice): no lane-dependent branch.
+// ---------------------------------------------------------------------------------------
+template <int TN, class FA, class FB, class FE>
+__device__ __attribute__((noinline)) void gemm_big_pass16(int N, int NC, FA A, FB B, FE epi, int row0, int tcnt, int TMr, int TNr) {
+  static_assert(kThreads == 512, "thread -> panel element mapping below");
+  constexpr int TM = 4, KB = kBig16KB, LdB = kBig16LdB, LdA = kBigLdA, MAXU = 3;
+  N = __builtin_amdgcn_readfirstlane(N); NC = __builtin_amdgcn_readfirstlane(NC); row0 = __builtin_amdgcn_readfirstlane(row0);
+  tcnt = __builtin_amdgcn_readfirstlane(tcnt); TMr = __builtin_amdgcn_readfirstlane(TMr); TNr = __builtin_amdgcn_readfirstlane(TNr);
+  typedef real r2 __attribute__((ext_vector_type(2)));
+  const int tid = wg_tid(), lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int wr = (wave >> 2) & 1, wc = wave & 3;  // 2 x 4 wave grid
+  const int Np = np_for(N), ntc = (NC + 15) >> 4;
+  constexpr int StA = KB * LdA;
+  const int St = StA + Np * LdB;
+  real *tS = mom_smem + vec_area_doubles(N);
+  const int P = (N + KB - 1) / KB;
+  // ---- panel elements of this thread
+  // A: 16 k x 64 row pairs (128 rows of the pass) = two units per thread
+  const int nUB = (KB / 2) * Np;
+  const int ub = (nUB + kThreads - 1) / kThreads;  // <= MAXU (uniform)
+  auto unitA = [&](int j, int &k, int &i) {
+    const int u = tid + kThreads * j;          // < 16 x 64 for j < 2
+    k = u >> 6;
+    i = row0 + 2 * (u & 63);
+  };
+  auto unitB = [&](int j, int &k, int &c) {
+    const int u = tid + kThreads * j, uB = u < nUB ? u : nUB - 1;
+    c = uB >> 3;
+    k = 2 * (uB & 7);
+  };
+  int la[2], lb[MAXU];
+  unsigned goa[2], gob[MAXU];
+  real sa0[2], sa1[2], sb[MAXU];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int ak, ai;
+    unitA(j, ak, ai);
+    la[j] = ak * LdA + (ai - row0);
+    goa[j] = 0;
+    if constexpr (is_elp<FA>::value) goa[j] = (unsigned)((ai < Np - 2 ? ai : Np - 2) + ak * A.ld);
+    sa0[j] = sa1[j] = 1.0;
+    if constexpr (has_sig<FA>::value) {
+      const int ic = ai < Np - 2 ? ai : Np - 2;
+      sa0[j] = A.sg[ic < N ? ic : N - 1];
+      sa1[j] = A.sg[ic + 1 < N ? ic + 1 : N - 1];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXU; ++j) {
+    int bk, bc;
+    unitB(j, bk, bc);
+    lb[j] = StA + bc * LdB + bk;
+    gob[j] = 0;
+    if constexpr (is_elp<FB>::value) gob[j] = (unsigned)(bk + (bc < NC - 1 ? bc : NC - 1) * B.ld);
+    sb[j] = 1.0;
+    if constexpr (has_sig<FB>::value) sb[j] = B.sg[bc < N ? bc : N - 1];
+  }
+  r2 ga[2], gb[MAXU];
+  auto fetch = [&](int p) {
+    const int k0 = p * KB;
+    const bool tail = k0 + KB > N;  // last panel of an operator whose edge is not a multiple of 16 (uniform)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if constexpr (is_elp<FA>::value) {
+        int kc = k0;
+        if (tail) {
+          int ak, ai;
+          unitA(j, ak, ai);
+          kc = (k0 + ak < N ? k0 + ak : N - 1) - ak;
+        }
+        ga[j] = *(const r2 *)(A.p + (size_t)kc * A.ld + goa[j]);
+      } else {
+        int ak, i;
+        unitA(j, ak, i);
+        const int k = k0 + ak;
+        ga[j].x = (i < N && k < N) ? A(i, k) : 0.0;
+        ga[j].y = (i + 1 < N && k < N) ? A(i + 1, k) : 0.0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXU; ++j) {
+      if (j < ub) {
+        if constexpr (is_elp<FB>::value) {
+          gb[j] = *(const r2 *)(B.p + k0 + gob[j]);  // (k >= N: inside the padded column; zeroed by the stash)
+        } else {
+          int bk, c;
+          unitB(j, bk, c);
+          const int k = k0 + bk;
+          gb[j].x = (k < N && c < NC) ? B(k, c) : 0.0;
+          gb[j].y = (k + 1 < N && c < NC) ? B(k + 1, c) : 0.0;
+        }
+      }
+    }
+  };
+  auto stash = [&](int p) {
+    real *st = tS + (p & 1) * St;
+    const int k0 = p * KB;
+    const bool tail = k0 + KB > N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      r2 v = ga[j];
+      if constexpr (has_sig<FA>::value) {
+        const int k = k0 + ((tid + kThreads * j) >> 6);
+        const real sk = A.sg[k < N ? k : N - 1];
+        v.x *= sa0[j] * sk;
+        v.y *= sa1[j] * sk;
+      }
+      if constexpr (is_elp<FA>::value) {
+        if (tail && k0 + ((tid + kThreads * j) >> 6) >= N) v = (r2){0.0, 0.0};
+      }
+      *(r2 *)(st + la[j]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < MAXU; ++j) {
+      if (j < ub) {
+        r2 v = gb[j];
+        int bk = 0, bc = 0;
+        if (has_sig<FB>::value || tail) unitB(j, bk, bc);
+        if constexpr (has_sig<FB>::value) {
+          const int k = k0 + bk;
+          v.x *= B.sg[k < N ? k : N - 1] * sb[j];
+          v.y *= B.sg[k + 1 < N ? k + 1 : N - 1] * sb[j];
+        }
+        if constexpr (is_elp<FB>::value) {
+          if (tail) {
+            if (k0 + bk >= N) v.x = 0.0;
+            if (k0 + bk + 1 >= N) v.y = 0.0;
+          }
+        }
+        *(r2 *)(st + lb[j]) = v;
+      }
+    }
+  };
+  r4 acc[TM][TN];
+#pragma unroll
+  for (int ti = 0; ti < TM; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < TN; ++tj) acc[ti][tj] = (r4){0.0, 0.0, 0.0, 0.0};
+  const int fa = 16 * TMr * wr + lr + lq * LdA, fb = StA + lq + (16 * TNr * wc + lr) * LdB;
+  real a0[TM], b0[TN], a1[TM], b1[TN];
+  auto frags = [&](const real *st, int ks, real (&a)[TM], real (&b)[TN]) {
+    const real *sa = st + fa + 4 * ks * LdA, *sb_ = st + fb + 4 * ks;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) a[t] = sa[16 * t];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) b[t] = sb_[16 * t * LdB];
+  };
+  auto mfmas = [&](real (&a)[TM], real (&b)[TN]) {
+#pragma unroll
+    for (int ti = 0; ti < TM; ++ti)
+      if (ti < 2 || ti < TMr) {  // workgroup-uniform (a function of N): a scalar branch per row of tiles
+#pragma unroll
+        for (int tj = 0; tj < TN; ++tj) acc[ti][tj] = mma16(a[ti], b[tj], acc[ti][tj]);
+      }
+  };
+  __syncthreads();  // the previous pass (or the caller) is done with the stages
+  fetch(0);
+  stash(0);
+  if (P > 1) fetch(1);
+  __syncthreads();
+  for (int p = 0; p < P; ++p) {
+    const real *st = tS + (p & 1) * St;
+    frags(st, 0, a0, b0);
+#ifndef BIG16_NOFETCH
+    if (p + 1 < P) stash(p + 1);       // stage (p + 1) & 1: free since the barrier that ended panel p - 1
+    if (p + 2 < P) fetch(p + 2);
+#endif
+    frags(st, 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    frags(st, 2, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    frags(st, 3, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  // epilogue through the wave-private patch, as in gemm_big_pass
+  real *tw = tS + wave * (16 * kBigPatch);
+  const int nvt = tcnt - TMr * wr < TMr ? tcnt - TMr * wr : TMr;  // valid row tiles of this wave (may be <= 0)
+#pragma unroll
+  for (int tj = 0; tj < TN; ++tj) {
+    if (!(tj < TNr && TNr * wc + tj < ntc)) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (2 * h >= nvt) continue;
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tw[lr * kBigPatch + 16 * tl + cd_row(lq, r)] = acc[2 * h + tl][tj][r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int cl = 4 * it + (lane >> 4), rp = 2 * (lane & 15);
+        const r2 v = *(const r2 *)(tw + cl * kBigPatch + rp);
+        const int col = 16 * (TNr * wc + tj) + cl, rb = 32 * h + rp, rw = row0 + 16 * TMr * wr + rb;
+        if (rb < 16 * nvt && col < NC) {
+          if (rw + 1 < N) {
+            if constexpr (std::is_invocable_v<FE, int, int, real, real>) {
+              epi(rw, col, v.x, v.y);
+            } else {
+              epi(rw, col, v.x);
+              epi(rw + 1, col, v.y);
+            }
+          } else if (rw < N) {
+            epi(rw, col, v.x);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 template <class FA, class FB, class FE>
 __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
   // Wave tiling fitted to the operator: a wave owns TMr x TNr MFMA tiles (each <= 4), TNr = ceil(column tiles / 4) and
@@ -674,6 +907,13 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
     const int TMr = (tcnt + 1) >> 1;
     const int row0 = 16 * t0;
     t0 += tcnt;
+#ifndef MOM_NO_BIG16
+    if (N <= kBig16MaxN) {
+      if (TNr <= 2) gemm_big_pass16<2>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
+      else gemm_big_pass16<3>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);   // N <= 192: at most 12 column tiles
+      continue;
+    }
+#endif
     if (TNr <= 2) gemm_big_pass<2>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
     else if (TNr == 3) gemm_big_pass<3>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
     else gemm_big_pass<4>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
