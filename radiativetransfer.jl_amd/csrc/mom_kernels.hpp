@@ -115,15 +115,20 @@ constexpr int kBigCols = 256;  // largest operator the tiles are sized for
 constexpr int kBigStA = kBigKB * kBigLdA;  // reals per A stage; a B stage holds np_for(N) columns of pitch kBigLdB
 constexpr int kBigPatch = 36;  // row pitch of the epilogue patch (16 columns x 32 rows per wave)
 __host__ __device__ inline int big_stage_b(int N) { return 16 * ((N + 15) / 16) * kBigLdB; }
-// r4: operators up to kBig16MaxN take k panels of 16 in TWO stages (gemm_big_pass16: half the barriers per product)
+// r4: k panels of 16 in TWO stages (gemm_big_pass16: half the barriers per product) wherever the LDS holds them -- every
+// N <= 256 once the staging tiles are laid over `part` (the 2 kWaves scratch vectors of the mat-vecs, dead during a product; the
+// first 16 reals stay: wg_sumsq_put writes part[wave] from inside an epilogue)
 constexpr int kBig16KB = 16;
 constexpr int kBig16LdB = kBig16KB + 2;
-constexpr int kBig16MaxN = 192;
+constexpr int kBig16MaxN = 256;
 __host__ __device__ inline int big16_stage_doubles(int N) { return kBig16KB * kBigLdA + 16 * ((N + 15) / 16) * kBig16LdB; }
 __host__ __device__ inline int big_tile_doubles(int N) {
   int st = kBigStages * (kBigStA + big_stage_b(N));
   const int pt = 8 * 16 * kBigPatch;
-  if (N <= kBig16MaxN && 2 * big16_stage_doubles(N) > st) st = 2 * big16_stage_doubles(N);
+  if (N <= kBig16MaxN) st = 2 * big16_stage_doubles(N);  // (the K = 8 pass is then not used: MOM_NO_BIG16 builds keep its size)
+#ifdef MOM_NO_BIG16
+  st = kBigStages * (kBigStA + big_stage_b(N));
+#endif
   return st > pt ? st : pt;
 }
 // Vector area: 15 vectors, the 32 series thresholds, np + 4 ints (ipiv, sh, bad) in whole pairs of reals (the Float32
@@ -134,11 +139,14 @@ __host__ __device__ inline size_t vec_ints_doubles(int N) {
 }
 __host__ __device__ inline size_t part_offset_doubles(int N) { return (size_t)(15 * np_for(N) + 32) + vec_ints_doubles(N); }
 __host__ __device__ inline size_t vec_area_doubles(int N) { return part_offset_doubles(N) + (size_t)(2 * kWaves) * np_for(N); }
+// start of the staging tiles of the panel GEMM (generic mode): over `part`, behind its first 16 reals
+__host__ __device__ inline size_t big_tile_base_doubles(int N) { return part_offset_doubles(N) + 16; }
 __host__ __device__ inline size_t lds_bytes(int N, bool lds_mats) {
   size_t b = vec_area_doubles(N) * sizeof(real);
   if (lds_mats) b += 4 * mat_elems(N) * sizeof(real);
   else if (N > 64) {
-    b += (size_t)big_tile_doubles(N) * sizeof(real);
+    const size_t bt = (big_tile_base_doubles(N) + (size_t)big_tile_doubles(N)) * sizeof(real);
+    if (bt > b) b = bt;
     if (sizeof(real) == 8 && kWaves == 8 && N <= 96) {  // register-resident doubling: 16 reals of part + two slots (rg_applies)
       const size_t rg = (part_offset_doubles(N) + 16 + 2 * (size_t)np_for(N) * ld_for(N)) * sizeof(real);
       if (rg > b) b = rg;
@@ -491,7 +499,7 @@ __device__ __attribute__((noinline)) void gemm_big_pass(int N, int NC, FA A, FB 
   tcnt = __builtin_amdgcn_readfirstlane(tcnt); TMr = __builtin_amdgcn_readfirstlane(TMr); TNr = __builtin_amdgcn_readfirstlane(TNr);
 #endif
   typedef real r2 __attribute__((ext_vector_type(2)));
-  real *tA = mom_smem + vec_area_doubles(N);
+  real *tA = mom_smem + big_tile_base_doubles(N);
   real *tB = tA + kBigStages * kBigStA;
   const int tid = wg_tid(), lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
   const int wr = (wave >> 2) & 1, wc = wave & 3;  // 2 x 4 wave grid (8-wave build only, see wg_gemm_nc)
@@ -677,7 +685,7 @@ __device__ __attribute__((noinline)) void gemm_big_pass(int N, int NC, FA A, FB 
 template <int TN, class FA, class FB, class FE>
 __device__ __attribute__((noinline)) void gemm_big_pass16(int N, int NC, FA A, FB B, FE epi, int row0, int tcnt, int TMr, int TNr) {
   static_assert(kThreads == 512, "thread -> panel element mapping below");
-  constexpr int TM = 4, KB = kBig16KB, LdB = kBig16LdB, LdA = kBigLdA, MAXU = 3;
+  constexpr int TM = 4, KB = kBig16KB, LdB = kBig16LdB, LdA = kBigLdA, MAXU = (TN == 4) ? 4 : 3;  // B units: 8 Np / 512
   N = __builtin_amdgcn_readfirstlane(N); NC = __builtin_amdgcn_readfirstlane(NC); row0 = __builtin_amdgcn_readfirstlane(row0);
   tcnt = __builtin_amdgcn_readfirstlane(tcnt); TMr = __builtin_amdgcn_readfirstlane(TMr); TNr = __builtin_amdgcn_readfirstlane(TNr);
   typedef real r2 __attribute__((ext_vector_type(2)));
@@ -686,7 +694,7 @@ __device__ __attribute__((noinline)) void gemm_big_pass16(int N, int NC, FA A, F
   const int Np = np_for(N), ntc = (NC + 15) >> 4;
   constexpr int StA = KB * LdA;
   const int St = StA + Np * LdB;
-  real *tS = mom_smem + vec_area_doubles(N);
+  real *tS = mom_smem + big_tile_base_doubles(N);
   const int P = (N + KB - 1) / KB;
   // ---- panel elements of this thread
   // A: 16 k x 64 row pairs (128 rows of the pass) = two units per thread
@@ -910,7 +918,8 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
 #ifndef MOM_NO_BIG16
     if (N <= kBig16MaxN) {
       if (TNr <= 2) gemm_big_pass16<2>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
-      else gemm_big_pass16<3>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);   // N <= 192: at most 12 column tiles
+      else if (TNr == 3) gemm_big_pass16<3>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
+      else gemm_big_pass16<4>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
       continue;
     }
 #endif
