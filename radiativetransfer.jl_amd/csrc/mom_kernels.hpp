@@ -86,7 +86,10 @@ struct Ctx {
 };
 
 __host__ __device__ inline int np_for(int N) { return 16 * ((N + 15) / 16); }
-__host__ __device__ inline int ld_for(int N) { return np_for(N) + 2; }
+// Row pitch of the padded operator buffers: 16 NT + 2 (ds_read_b64 of 16 columns x 2 k conflict-free: pitch / 2 odd).  One
+// exception (r4): the Float64 4-wave image of N = 44 takes N + 2 = 46 (23 odd as well) -- 76.9 instead of 82.9 KB of LDS, so that
+// TWO workgroups share a CU like the N = 36, 40 images do (no k-step of a Float64 product reads a row >= N when N % 4 = 0)
+__host__ __device__ inline int ld_for(int N) { return (kF64 && kWaves == 4 && N == 44) ? 46 : np_for(N) + 2; }
 // columns actually stored per buffer: the K padding (up to the next multiple of 4) and the two riding
 // columns N, N+1; MFMA B-operand reads of the remaining columns of the last tile (< Np) run past the buffer
 // into whatever follows (finite or not, they only feed output columns that are never stored).

@@ -298,6 +298,7 @@ hipError_t mom_gen_launch_layer(const void *layer_args, int iface, bool lds, int
 hipError_t mom_strip9_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom_strip10_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom_strip11_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
+hipError_t mom4_strip11_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);  // 4-wave build of N = 44
 hipError_t mom_strip13_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom_strip14_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom_strip15_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
@@ -1399,9 +1400,9 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
     // small operators: 4-wave workgroups, two per CU (momcore_w4.hip), when two LDS images fit
     if (lds && h->opt_w4 && np_for(q.N) <= 48 && 2 * mom4_lds_bytes(q.N, true) + 2048 <= 160 * 1024) {
       const int grid4 = (int)((S >= 2048) ? S : S * Mcount);
-      if (q.N == 36 || q.N == 40) {  // strip-chained kernels of the 4-wave build (momcore_strip.hip)
+      if (q.N == 36 || q.N == 40 || q.N == 44) {  // strip-chained kernels of the 4-wave build (momcore_strip.hip)
         const int gridp = (int)std::min<size_t>(S * Mcount, (size_t)2 * h->num_cu);  // persistent, two per CU
-        HIPCHK(h, (q.N == 40 ? mom_strip10_launch_layer : mom_strip9_launch_layer)(
+        HIPCHK(h, (q.N == 44 ? mom4_strip11_launch_layer : q.N == 40 ? mom_strip10_launch_layer : mom_strip9_launch_layer)(
                       &a, a.iface, gridp, mom4_lds_bytes(q.N, true), h->stream));
         h->launches++;
         return MOM_OK;
