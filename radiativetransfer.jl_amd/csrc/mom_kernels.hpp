@@ -685,16 +685,24 @@ __device__ __attribute__((noinline)) void gemm_big_pass(int N, int NC, FA A, FB 
 // the K = 8 form; here for 32-64.  Panel elements per thread: A units (k, row pair of the pass's 128 rows), B units (column,
 // k pair); a unit index past the end repeats the last unit (the same value stored twice): no lane-dependent branch.
 // ---------------------------------------------------------------------------------------
-template <int TN, class FA, class FB, class FE>
+template <int TN, bool GUARD, class FA, class FB, class FE>
 __device__ __attribute__((noinline)) void gemm_big_pass16(int N, int NC, FA A, FB B, FE epi, int row0, int tcnt, int TMr, int TNr) {
   static_assert(kThreads == 512, "thread -> panel element mapping below");
   constexpr int TM = 4, KB = kBig16KB, LdB = kBig16LdB, LdA = kBigLdA, MAXU = (TN == 4) ? 4 : 3;  // B units: 8 Np / 512
   N = __builtin_amdgcn_readfirstlane(N); NC = __builtin_amdgcn_readfirstlane(NC); row0 = __builtin_amdgcn_readfirstlane(row0);
   tcnt = __builtin_amdgcn_readfirstlane(tcnt); TMr = __builtin_amdgcn_readfirstlane(TMr); TNr = __builtin_amdgcn_readfirstlane(TNr);
   typedef real r2 __attribute__((ext_vector_type(2)));
-  const int tid = wg_tid(), lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int tid = wg_tid(), lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the tile guards below are s_cbranch, not exec masks
   const int wr = (wave >> 2) & 1, wc = wave & 3;  // 2 x 4 wave grid
   const int Np = np_for(N), ntc = (NC + 15) >> 4;
+  // Column tiles of this wave: the ntc tiles are shared out as evenly as they go (shares differ by one), and the second wave
+  // row takes the shares in REVERSE order -- wave (wr, wc) sits on SIMD wc, so a SIMD's two waves then carry a long and a short
+  // share (9 column tiles: 3 + 2 on every SIMD instead of 3 + 3 on three of them and none on the fourth).  Tiles a wave does not
+  // own are skipped by scalar branches (wave-uniform), rows likewise.
+  const int cbase = ntc >> 2, crem = ntc & 3, ci = (GUARD && wr) ? 3 - wc : wc;  // (full blocks: both wave rows in the same order --
+  // the two waves of a column block then store adjacent row ranges of the same columns, which the N = 256 epilogue is 2.5 % faster with)
+  const int cstart = ci * cbase + (ci < crem ? ci : crem), nvc = cbase + (ci < crem ? 1 : 0);
   constexpr int StA = KB * LdA;
   const int St = StA + Np * LdB;
   real *tS = mom_smem + big_tile_base_doubles(N);
@@ -821,7 +829,8 @@ __device__ __attribute__((noinline)) void gemm_big_pass16(int N, int NC, FA A, F
   for (int ti = 0; ti < TM; ++ti)
 #pragma unroll
     for (int tj = 0; tj < TN; ++tj) acc[ti][tj] = (r4){0.0, 0.0, 0.0, 0.0};
-  const int fa = 16 * TMr * wr + lr + lq * LdA, fb = StA + lq + (16 * TNr * wc + lr) * LdB;
+  const int nvt = tcnt - TMr * wr < TMr ? tcnt - TMr * wr : TMr;  // valid row tiles of this wave (may be <= 0)
+  const int fa = 16 * TMr * wr + lr + lq * LdA, fb = StA + lq + (16 * cstart + lr) * LdB;
   real a0[TM], b0[TN], a1[TM], b1[TN];
   auto frags = [&](const real *st, int ks, real (&a)[TM], real (&b)[TN]) {
     const real *sa = st + fa + 4 * ks * LdA, *sb_ = st + fb + 4 * ks;
@@ -830,12 +839,16 @@ __device__ __attribute__((noinline)) void gemm_big_pass16(int N, int NC, FA A, F
 #pragma unroll
     for (int t = 0; t < TN; ++t) b[t] = sb_[16 * t * LdB];
   };
+  // GUARD (template parameter: two separately compiled functions -- both loops in one function cost either of them 5-8 %):
+  // tiles this wave does not own are skipped by scalar branches; without it every wave multiplies the full TM x TN block,
+  // which costs nothing when all blocks are full (N = 128, 256: the branches themselves cost ~2 %)
   auto mfmas = [&](real (&a)[TM], real (&b)[TN]) {
 #pragma unroll
     for (int ti = 0; ti < TM; ++ti)
-      if (ti < 2 || ti < TMr) {  // workgroup-uniform (a function of N): a scalar branch per row of tiles
+      if (GUARD ? ti < nvt : (ti < 2 || ti < TMr)) {  // wave- / workgroup-uniform: scalar branches
 #pragma unroll
-        for (int tj = 0; tj < TN; ++tj) acc[ti][tj] = mma16(a[ti], b[tj], acc[ti][tj]);
+        for (int tj = 0; tj < TN; ++tj)
+          if (!GUARD || tj < nvc) acc[ti][tj] = mma16(a[ti], b[tj], acc[ti][tj]);
       }
   };
   __syncthreads();  // the previous pass (or the caller) is done with the stages
@@ -868,10 +881,9 @@ __device__ __attribute__((noinline)) void gemm_big_pass16(int N, int NC, FA A, F
   }
   // epilogue through the wave-private patch, as in gemm_big_pass
   real *tw = tS + wave * (16 * kBigPatch);
-  const int nvt = tcnt - TMr * wr < TMr ? tcnt - TMr * wr : TMr;  // valid row tiles of this wave (may be <= 0)
 #pragma unroll
   for (int tj = 0; tj < TN; ++tj) {
-    if (!(tj < TNr && TNr * wc + tj < ntc)) continue;
+    if (!(tj < nvc)) continue;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (2 * h >= nvt) continue;
@@ -884,7 +896,7 @@ __device__ __attribute__((noinline)) void gemm_big_pass16(int N, int NC, FA A, F
       for (int it = 0; it < 4; ++it) {
         const int cl = 4 * it + (lane >> 4), rp = 2 * (lane & 15);
         const r2 v = *(const r2 *)(tw + cl * kBigPatch + rp);
-        const int col = 16 * (TNr * wc + tj) + cl, rb = 32 * h + rp, rw = row0 + 16 * TMr * wr + rb;
+        const int col = 16 * (cstart + tj) + cl, rb = 32 * h + rp, rw = row0 + 16 * TMr * wr + rb;
         if (rb < 16 * nvt && col < NC) {
           if (rw + 1 < N) {
             if constexpr (std::is_invocable_v<FE, int, int, real, real>) {
@@ -920,9 +932,17 @@ __device__ void wg_gemm_big(int N, int NC, FA A, FB B, FE epi) {
     t0 += tcnt;
 #ifndef MOM_NO_BIG16
     if (N <= kBig16MaxN) {
-      if (TNr <= 2) gemm_big_pass16<2>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
-      else if (TNr == 3) gemm_big_pass16<3>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
-      else gemm_big_pass16<4>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
+      // full register blocks on every wave (column tiles a multiple of 4, an even number of row tiles): the unguarded image
+      const bool full = (ntc & 3) == 0 && tcnt == 2 * TMr;
+      if (full) {
+        if (TNr <= 2) gemm_big_pass16<2, false>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
+        else if (TNr == 3) gemm_big_pass16<3, false>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
+        else gemm_big_pass16<4, false>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
+      } else {
+        if (TNr <= 2) gemm_big_pass16<2, true>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
+        else if (TNr == 3) gemm_big_pass16<3, true>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);
+        else gemm_big_pass16<4, false>(N, NC, A, B, epi, row0, tcnt, TMr, TNr);  // N > 192: the unguarded image (13-16 column tiles: at most one of 16 blocks short)
+      }
       continue;
     }
 #endif
