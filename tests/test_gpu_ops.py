@@ -166,7 +166,8 @@ def test_surface_lambertian(rtamd, cref, nS):
                                         rtol=1e-14, what=f"surface m={m} {nm}")
 
 
-@pytest.mark.parametrize("n,batch", [(32, 1000), (60, 64), (7, 33), (100, 5), (65, 3), (127, 3), (129, 2), (192, 2), (250, 2), (255, 2)])
+@pytest.mark.parametrize("n,batch", [(32, 1000), (60, 64), (7, 33), (100, 5), (65, 3), (127, 3), (129, 2), (144, 2), (160, 2), (176, 2), (192, 2),
+                                     (250, 2), (255, 2)])   # 144 ... 176: 9 ... 11 column tiles, unevenly shared over the wave columns
 def test_batch_inv_and_mul(rtamd, cref, n, batch):
     """matrix_inv_test.jl: n=32, batch 10 000 (reduced)."""
     rng = np.random.default_rng(n)
