@@ -352,8 +352,9 @@ def c5_leg(a, S, steps, warmup, dev, with_cpu=True, world=1, rank=0, dist=None):
     fence()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # a torch / torch-fallback run's default (or fallback) group is NCCL-only: the tensor must live on the device
+        t = torch.tensor([el], dtype=torch.float64, device=dev if backend in ("torch", "torch-fallback") else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         el = float(t.item())
         got = (Gh if backend == "gloo" else G.cpu()).numpy().reshape(world, cnt)
         # this rank's block of the gathered buffer must be its own owned spectra; every block finite
@@ -438,9 +439,11 @@ def f32_leg(dev, S=20_000, n_streams=8, nd=5, steps=3):
     import torch
     import rtamd
     rt = rtamd.corert
-    # 8 streams = 4 Gauss nodes + Sun + 3 views  ->  l_trunc 7
-    m = rtamd.scenes.make_scene(4, 7, 1, S, aerosol_total=0.0, absorption=False, architecture=rtamd.MI355X(dev.index))
+    # 8 streams = 4 Gauss nodes (l_trunc 7) + 3 views + the Sun at 50 deg (at the default 60 deg it merges with the third view
+    # under rt_set_streams' `unique`: 7 streams, N = 28 -- what this leg ran on up to round 4)
+    m = rtamd.scenes.make_scene(4, 7, 1, S, sza=50.0, aerosol_total=0.0, absorption=False, architecture=rtamd.MI355X(dev.index))
     sc = rtamd.prepare_scene(m)
+    assert sc.N == 4 * n_streams, (sc.N, n_streams)
     sc.ndoubl[:] = nd   # the micro-benchmark's fixed doubling count (the scene's own would be larger)
     h = rt.make_handle(m, float_type="Float32")
     h.scene_set(sc.Nz, sc.K, sc.M, sc.tau, sc.varpi, sc.zw, sc.Zpp, sc.Zmp, sc.ndoubl, sc.iface, sc.tau_sum,
@@ -478,7 +481,7 @@ def f32_leg(dev, S=20_000, n_streams=8, nd=5, steps=3):
         c2 = {"error": repr(e)}
     return {"metric": "Float32 doubling, reference GPU micro-benchmark shape", "value": S * M / (best * 1e-3), "c2_scene_float32": c2,
             "unit": "(spectral point, moment) units/s", "dtype": "f32", "layers_ms": best,
-            "config": {"workload": f"N={N} (8 streams x 4 Stokes), S={S}, one layer, ndoubl={nd}, M={M}, dtype=1 (Float32)"},
+            "config": {"workload": f"N={N} ({n_streams} streams x 4 Stokes), S={S}, one layer, ndoubl={nd}, M={M}, dtype=1 (Float32)"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP32_MFMA_TFLOPS, "kernel": "momwf::k_wsweep<2, 7> (wave per spectral point, Float32 build of mom_wave.hip)",
                          "algorithmic_flop_per_avg_launch": flop}}

@@ -414,6 +414,7 @@ struct mom_handle {
   int num_cu = 256;
   int *d_info = nullptr;
   hipEvent_t ev[4] = {};
+  hipEvent_t ev_voigt[2] = {};  // mom_voigt_tau_abs_profile's timing pair (created on first use, owned by the handle)
   std::vector<hipEvent_t> ev_full, ev_red;  // start/stop pairs around each full-problem / reduced layer launch
   int launches = 0, launches_full = 0, launches_red = 0;
   // rotational-Raman path (mom_rrs.hip): the persistent AddedLayerRS / CompositeLayerRS state and the scene's Raman inputs
@@ -616,6 +617,7 @@ extern "C" int mom_destroy(mom_t *h) {
   fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_rrs_send); fr(h->d_Rsurf); fr(h->d_Rsurf0); fr(h->d_albedo_spec); fr(h->d_hdrJm); fr(h->d_smtab); if (h->d_ndif) (void)hipFree(h->d_ndif); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_prof); fr(h->d_tau_rayl);
   fr(h->d_layer_max); fr(h->d_aer); if (h->d_aer_mode) (void)hipFree(h->d_aer_mode); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
   for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
+  for (int k = 0; k < 2; ++k) if (h->ev_voigt[k]) (void)hipEventDestroy(h->ev_voigt[k]);
   for (auto e : h->ev_full) (void)hipEventDestroy(e);
   for (auto e : h->ev_red) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -2184,16 +2186,18 @@ extern "C" int mom_voigt_tau_abs_profile(mom_t *h, int Nz, const double *pressur
   HIPCHK(h, hipMemsetAsync(flags, 0, sizeof(int) * (size_t)Nz, h->stream));
   double *pf = h->d_lines;
   int *win = reinterpret_cast<int *>(pf + 4 * cap * (size_t)Nz);
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (gpu_ms) { HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1)); HIPCHK(h, hipEventRecord(e0, h->stream)); }
+  if (gpu_ms) {
+    for (int k = 0; k < 2; ++k)
+      if (!h->ev_voigt[k]) HIPCHK(h, hipEventCreate(&h->ev_voigt[k]));
+    HIPCHK(h, hipEventRecord(h->ev_voigt[0], h->stream));
+  }
   HIPCHK(h, mom_voigt_profile_launch(h->stream, h->lt, Nz, cap, h->S, h->d_grid, h->d_prof, vmr, wing_cutoff, pf, win, flags,
                                      h->d_tau_abs, h->d_prof + 3 * (size_t)Nz));
-  if (gpu_ms) HIPCHK(h, hipEventRecord(e1, h->stream));
+  if (gpu_ms) HIPCHK(h, hipEventRecord(h->ev_voigt[1], h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));   // prm is a host temporary
   if (gpu_ms) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *gpu_ms = ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (hipEventElapsedTime(&ms, h->ev_voigt[0], h->ev_voigt[1]) == hipSuccess) *gpu_ms = ms;
   }
   return MOM_OK;
 }

@@ -8,8 +8,8 @@
 // for N <= 64, generic mode above), layer-sweep mode, the surface layer (all three surface kinds) with HDRF/BHR, and
 // post-processing; r4: the strip-chained images of the 8-wave build (N = 44, 52, 56, 60: momcore_strip.hip compiled for
 // float, momf_strip<KS>_launch_layer), the (I,Q) reduction of moment 0 (a nested sub-scene: momf_scene::sub) and the padding of
-// other edges to the strip sizes (strip_pad_f).  Not built for f32: the operator-level API (mom_elemental ... return
-// MOM_EINVAL on a dtype = 1 handle).
+// other edges to the strip sizes (strip_pad_f), and the operator-level API on dtype = 1 handles (mom_ops.hpp compiled for float:
+// mom_elemental ... mom_download).  Not built for f32: multi-sensor, RRS, the device-side optics route.
 //
 // The C ABI keeps Float64 host arrays for both dtypes (a Float32 Julia host passes Float64.(x) and converts back):
 // inputs are rounded to f32 on upload, outputs widened on download.

@@ -268,8 +268,9 @@ def test_natraj_on_gpu(rtamd):
 
 
 @pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
-def test_6sv1_on_gpu(rtamd, case):
-    """test/test_CoreRT.jl:3-38 on the GPU: R/μ₀ within 0.006 of the 6SV1 tables."""
+def test_6sv1_on_gpu(rtamd, cref, case):
+    """test/test_CoreRT.jl:3-38 on the GPU: R/μ₀ within 0.006 of the 6SV1 tables, and every one of the scenes at the
+    1e-10 level against the oracle run of the same scene."""
     G = json.loads((GOLD / "reference_tables.json").read_text())
     c = G["sixsv_cases"][case]
     Rt = np.array(G["sixsv_R"][case])
@@ -277,9 +278,13 @@ def test_6sv1_on_gpu(rtamd, case):
     for si, sza in enumerate(c["sza"]):
         m = helpers.one_layer_rayleigh(rtamd.corert, sza, np.tile(vza1, 3), np.repeat(np.array(c["az"], float), 16),
                                        c["tau"], c["rho"])
-        R = rtamd.rt_run(m)[0]
+        R, T = rtamd.rt_run(m)[:2]
         Rm = (R[:, 0, 0] / m.quad_points.μ0).reshape(3, 16)
         assert np.max(np.abs(Rt[si] - Rm) / Rt[si]) < 0.006
+        Rr, Tr = _oracle(cref, m)
+        nd = int(rtamd.prepare_scene(m).ndoubl.max())
+        helpers.assert_stokes_close(R, Rr, rtol=helpers.stokes_rtol(nd), what=f"6SV1 case {case} sza {sza} R vs oracle")
+        helpers.assert_stokes_close(T, Tr, rtol=helpers.stokes_rtol(nd), what=f"6SV1 case {case} sza {sza} T vs oracle")
 
 
 def _natraj_model(rtamd, pol, strict):
@@ -319,9 +324,10 @@ def test_natraj_iqu_strict_q1_fingerprint_on_gpu(rtamd, cref):
 
 
 @pytest.mark.parametrize("case", [0, 1, 2, 3, 4, 5])
-def test_6sv1_iqu_nonstrict_on_gpu(rtamd, case):
+def test_6sv1_iqu_nonstrict_on_gpu(rtamd, cref, case):
     """The six 6SV1 cases as Stokes_IQU (zero-based rule) on the GPU: ε = 0.006 on R/μ₀; cases 2, 4, 6 carry the
-    Lambertian surface with ρ = 0.25 (lambertian_surface.jl:20-75) into the nStokes = 3 pin."""
+    Lambertian surface with ρ = 0.25 (lambertian_surface.jl:20-75) into the nStokes = 3 pin; each scene also at the 1e-10
+    level against the oracle run of the same scene."""
     G = json.loads((GOLD / "reference_tables.json").read_text())
     c = G["sixsv_cases"][case]
     Rt = np.array(G["sixsv_R"][case])
@@ -330,9 +336,13 @@ def test_6sv1_iqu_nonstrict_on_gpu(rtamd, case):
         m = helpers.one_layer_rayleigh(rtamd.corert, sza, np.tile(vza1, 3), np.repeat(np.array(c["az"], float), 16),
                                        c["tau"], c["rho"], pol=rtamd.corert.Stokes_IQU())
         m.params.strict_reference_indexing = False
-        R = rtamd.rt_run(m)[0]
+        R, T = rtamd.rt_run(m)[:2]
         Rm = (R[:, 0, 0] / m.quad_points.μ0).reshape(3, 16)
         assert np.max(np.abs(Rt[si] - Rm) / Rt[si]) < 0.006
+        Rr, Tr = _oracle(cref, m)
+        nd = int(rtamd.prepare_scene(m).ndoubl.max())
+        helpers.assert_stokes_close(R, Rr, rtol=helpers.stokes_rtol(nd), what=f"6SV1 IQU case {case} sza {sza} R vs oracle")
+        helpers.assert_stokes_close(T, Tr, rtol=helpers.stokes_rtol(nd), what=f"6SV1 IQU case {case} sza {sza} T vs oracle")
 
 
 def test_sharded_equals_unsharded_bitwise(rtamd):
