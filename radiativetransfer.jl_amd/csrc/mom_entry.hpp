@@ -6,6 +6,10 @@
 
 namespace MOM_NS {
 
+// waves per SIMD the layer kernels are compiled for (register budget 512 / MOM_LB_WAVES per lane)
+#ifndef MOM_LB_WAVES
+#define MOM_LB_WAVES 2
+#endif
 constexpr int kMaxSweepLayers = 96;
 constexpr int kMaxTargets = 20;
 struct LayerArgs {
@@ -37,7 +41,7 @@ struct LayerArgs {
 
 struct ZMix {
   const gdouble *base;  // Z[:,:,0,m]
-  const gdouble *w;     // K weights of this point
+  const real *w;        // K weights of this point (r5: staged in LDS with the layer's other scalars, see k_layer)
   int K, N;
   // Z(i,j) = sum_k w[k] Z_k(i,j), accumulated in k order (elemental_build walks the terms)
   __device__ __forceinline__ int terms() const { return K; }
@@ -67,7 +71,7 @@ __device__ __forceinline__ CompPtrs comp_ptrs(real *const comp[6], int N, int pi
 // MT: the multi-target form (a.ntgt composites fed by one added layer, see LayerArgs); a separate image so that the
 // single-composite kernels carry none of its code (as a run-time branch it cost the C2 kernel 12 %)
 template <bool LDSM, int IFACE, int KS = 0, bool MT = false>
-__global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
+__global__ void __launch_bounds__(kThreads, MOM_LB_WAVES) k_layer(LayerArgs a) {
   if (KS > 0) a.q.N = 4 * KS;  // the host launches this instantiation only for that size: every dimension folds
   const int N = a.q.N;
   const size_t total = (size_t)a.S * a.M;
@@ -77,6 +81,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
   if (wg_tid() == 256 && blockIdx.x == (gridDim.x >> 1)) mom_diag_last4 = mom_diag_now();
 #endif
   wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
+  if constexpr (KS > 0) strip_slot_init(c);
   MOM_STAMP(40);
   if (KS > 0 && kWaves == 8 && a.stagger > 0) {
     // persistent workgroups run identical units in lockstep, so every CU would store (and load) its composite
@@ -91,24 +96,42 @@ __global__ void __launch_bounds__(kThreads, 2) k_layer(LayerArgs a) {
     const size_t NN = (size_t)N * N;
     CompPtrs g = comp_ptrs(a.comp, N, comp_pitch(N), pt);
     for (int z = 0; z < nz; ++z) {
+      // The per-(point, layer) scalars tau, varpi, tau_sum and the K phase-matrix weights: kLayTab / (3 + K) layers at a time go
+      // from their [S, Nz] tables into the LDS tail in ONE batch of independent loads -- a unit pays one memory latency per
+      // batch instead of two dependent ones per layer (tau before the first exponential, the weights before the element math;
+      // r4 had tried registers one layer ahead: -1.5 % from the ten live registers; LDS costs none)
+      // (the host refuses K > kLayTab - 3 scatterer types)
+      const int LW = 3 + a.K, LZ = lay_cap_reals(N, LDSM) / LW;
+      real *lay = mom_smem + lay_offset_reals(N, LDSM);
+      const int zl = z % LZ;
+      if (zl == 0) {
+        const int cnt = ((nz - z < LZ) ? nz - z : LZ) * LW;
+        for (int i = wg_tid(); i < cnt; i += kThreads) {
+          const int zz = i / LW, k = i - zz * LW;
+          const size_t o = (size_t)n + (size_t)a.S * (z + zz);
+          lay[i] = (k == 0) ? as_global(a.tau)[o] : (k == 1) ? as_global(a.varpi)[o] : (k == 2) ? as_global(a.tau_sum)[o]
+                                                                                                : as_global(a.zw)[(size_t)a.K * o + (k - 3)];
+        }
+        __syncthreads();
+      }
       const int nd = a.Nz_sweep > 0 ? a.nd_z[z] : a.nd;
       const int iface = a.Nz_sweep > 0 ? a.iface_z[z] : a.iface;
       // first layer of a slab: the added layer becomes the composite (rt_kernel.jl:227-230); a sweep that CONTINUES a
       // composite already in memory (multi-sensor top slabs, a.first = 0) interacts from its first layer on
       const bool first = (a.Nz_sweep > 0 ? (z == 0) : true) && (a.first != 0);
-      const size_t zo = (size_t)a.S * z;
-      const real tau = as_global(a.tau)[n + zo], varpi = as_global(a.varpi)[n + zo];
+      const real *ls = lay + zl * LW;
+      const real tau = ls[0], varpi = ls[1], tau_sum = ls[2];
       const real dtau = ldexp(tau, -nd);         // τ ./ 2^ndoubl   (rt_kernel.jl:244)
       real expk = exp(-dtau / a.q.mu0);          // init_layer      (rt_kernel.jl:273)
-      ZMix zpp{as_global(a.Zpp) + NN * a.K * mrel, as_global(a.zw) + (size_t)a.K * (n + zo), a.K, N};
-      ZMix zmp{as_global(a.Zmp) + NN * a.K * mrel, as_global(a.zw) + (size_t)a.K * (n + zo), a.K, N};
+      ZMix zpp{as_global(a.Zpp) + NN * a.K * mrel, ls + 3, a.K, N};
+      ZMix zmp{as_global(a.Zmp) + NN * a.K * mrel, ls + 3, a.K, N};
 #ifdef MOM_DIAG_STAMPS
       MOM_STAMP(43);
 #endif
-      elemental_build(c, a.q, m, nd, as_global(a.tau_sum)[n + zo], dtau, varpi, zpp, zmp);
+      elemental_build(c, a.q, m, nd, tau_sum, dtau, varpi, zpp, zmp);
       MOM_STAMP(41);
 #ifdef MOM_DIAG_TWICE
-      elemental_build(c, a.q, m, nd, as_global(a.tau_sum)[n + zo], dtau, varpi, zpp, zmp);
+      elemental_build(c, a.q, m, nd, tau_sum, dtau, varpi, zpp, zmp);
       MOM_STAMP(44);
 #endif
 #ifdef MOM_QPREFETCH

@@ -62,6 +62,9 @@ struct MomSmallSweepArgsT {
   // outputs
   Real *R, *T, *hdr, *bhr_uw, *bhr_dw;  // [nVza,nS,S] x3, [nS,S] x2
   int *info;
+  // r5: one (point, moment) per lane when `part` is given and M > 1: the terms of R_SFI / T_SFI go to part[m][R | T][nVza,nS,S]
+  // and a second kernel adds them in ascending m (the order of the accumulator they replace); the lanes of m = 0 write hdr / bhr
+  Real *part;
 };
 using MomSmallSweepArgs = MomSmallSweepArgsT<double>;
 using MomSmallSweepArgsF = MomSmallSweepArgsT<float>;  // mom_small.hip with -DMOMS_FLOAT

@@ -83,6 +83,7 @@ struct Ctx {
   int *ipiv, *sh, *bad;
   int inv_mode;
   int qpre;  // MOM_QPREFETCH experiment: c.Q already holds the composite T++ (+ J0+ riding) for the coming interaction
+  int slot;  // MOM_SIMD_AWARE experiment: the column strip this wave owns (mom_strip.hpp strip_slot)
 };
 
 __host__ __device__ inline int np_for(int N) { return 16 * ((N + 15) / 16); }
@@ -144,7 +145,20 @@ __host__ __device__ inline size_t part_offset_doubles(int N) { return (size_t)(1
 __host__ __device__ inline size_t vec_area_doubles(int N) { return part_offset_doubles(N) + (size_t)(2 * kWaves) * np_for(N); }
 // start of the staging tiles of the panel GEMM (generic mode): over `part`, behind its first 16 reals
 __host__ __device__ inline size_t big_tile_base_doubles(int N) { return part_offset_doubles(N) + 16; }
-__host__ __device__ inline size_t lds_bytes(int N, bool lds_mats) {
+// LDS tail of k_layer: the staged per-(point, layer) scalars (mom_entry.hpp), kLayTab reals behind everything else
+// (the register-resident doubling at N = 96 leaves 1 KB of the CU's 160 KB: the tail shrinks to what is left there -- 126
+// doubles, still 25 layers of a two-basis scene per batch; the host refuses more than 64 bases, 67 reals per layer)
+constexpr int kLayTab = 256;
+constexpr size_t kLdsPerCU = 160 * 1024;
+__host__ __device__ inline size_t lds_body_bytes(int N, bool lds_mats);
+__host__ __device__ inline size_t lay_offset_reals(int N, bool lds_mats) { return (lds_body_bytes(N, lds_mats) + sizeof(real) - 1) / sizeof(real); }
+__host__ __device__ inline int lay_cap_reals(int N, bool lds_mats) {
+  const size_t used = lay_offset_reals(N, lds_mats) * sizeof(real);
+  const size_t left = used < kLdsPerCU ? (kLdsPerCU - used) / sizeof(real) : 0;
+  return left < (size_t)kLayTab ? (int)left : kLayTab;
+}
+__host__ __device__ inline size_t lds_bytes(int N, bool lds_mats) { return (lay_offset_reals(N, lds_mats) + lay_cap_reals(N, lds_mats)) * sizeof(real); }
+__host__ __device__ inline size_t lds_body_bytes(int N, bool lds_mats) {
   size_t b = vec_area_doubles(N) * sizeof(real);
   if (lds_mats) b += 4 * mat_elems(N) * sizeof(real);
   else if (N > 64) {
@@ -168,6 +182,7 @@ __device__ __forceinline__ void make_ctx(Ctx &c, int N, int inv_mode, real *smem
   c.fd.init(N);
   c.inv_mode = inv_mode;
   c.qpre = 0;
+  c.slot = 0;
   const size_t msz = mat_elems(N);
   real *p = smem;
   if (LDSM) {

@@ -86,16 +86,21 @@ __device__ __forceinline__ int inv_one_minus(Mat<N> &X, const Mat<N> &B) {
       const real v = fabs(A.a[i][k]);
       if (v > best) { best = v; p = i; }
     }
+    // the interchange itself only if SOME lane of the wavefront needs one (a wave-uniform branch): I - B with ||B|| < 1 is
+    // close to diagonally dominant and hardly ever pivots, while the selects of an unconditional interchange (192 v_cndmask
+    // per 4 x 4 inverse) outnumber the elimination's own 128 FMAs
+    if (__builtin_amdgcn_ballot_w64(p != k) != 0) {
 #pragma unroll
-    for (int i = k + 1; i < N; ++i) {
-      const bool sw = (p == i);
+      for (int i = k + 1; i < N; ++i) {
+        const bool sw = (p == i);
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
-        const real ak = A.a[k][j], ai = A.a[i][j], xk = X.a[k][j], xi = X.a[i][j];
-        A.a[k][j] = sw ? ai : ak;
-        A.a[i][j] = sw ? ak : ai;
-        X.a[k][j] = sw ? xi : xk;
-        X.a[i][j] = sw ? xk : xi;
+        for (int j = 0; j < N; ++j) {
+          const real ak = A.a[k][j], ai = A.a[i][j], xk = X.a[k][j], xi = X.a[i][j];
+          A.a[k][j] = sw ? ai : ak;
+          A.a[i][j] = sw ? ak : ai;
+          X.a[k][j] = sw ? xi : xk;
+          X.a[i][j] = sw ? xk : xi;
+        }
       }
     }
     if (!(best > 0.0) && !bad) bad = k + 1;
@@ -121,34 +126,64 @@ __device__ __forceinline__ int inv_one_minus(Mat<N> &X, const Mat<N> &B) {
 
 using SweepArgs = ::MomSmallSweepArgsT<real>;  // mom_host.hpp: the one definition shared with momcore.hip / momcore_f32.hip
 
-template <int N>
-__global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {  // two waves per SIMD: C1 107.7 -> 112.5 M points/s (one wave with 504 registers was slower)
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+// Register budget (r5).  Up to r4 the N = 3, 4 images were built for two waves per SIMD (256 VGPRs) and SPILLED: k_sweep<4> 522
+// VGPRs, 996 B of scratch per lane -- 6.5 GB of scratch traffic per 1.7 ms launch against 88 MB of algorithmic bytes (74 x; the
+// kernel ran at the speed of its spill traffic, 3.8 TB/s, not of the FP64 pipe).  Now: ONE wave per SIMD for N >= 3 (512
+// registers: the ~190 live doubles of a point fit, no scratch), and what made one wave per SIMD slower than two in r2 is gone:
+//   * the per-(point, layer) inputs tau, varpi, tau_sum, zw of layer z + 1 are requested before layer z is computed (one wave
+//     per SIMD has nobody to hide a dependent HBM round trip per layer behind);
+//   * the view accumulators (48 doubles held across the whole kernel for at most 4 x 4 outputs) live in LDS, [3][nVza nStokes]
+//     [thread] (dynamic: 6 KB for C1) -- NOT in the output arrays: a global store inside the loops costs every table read of the
+//     kernel its scalar-cache path (the compiler can no longer prove the tables unclobbered: 201 s_load became 190 per-lane
+//     global loads and the kernel ran 12 % slower than the spilling one; measured, profiles/r05_C1_ab.txt);
+//   * r+- = D r-+ D and t-- = D t++ D are formed where they are consumed (sg = +-1: exact) instead of being held per layer.
+#ifndef MOMS_WAVES_N34
+#define MOMS_WAVES_N34 1  // waves per SIMD of the N = 3, 4 images (A/B: profiles/r05_C1_ab.txt)
+#endif
+//   * SPLIT (r5): one (point, MOMENT) per lane instead of one point.  The moments of a point are independent until the final sum
+//     over m, so S M lanes of a third of the work each fill the GPU's 65 536 lane slots far more evenly than S lanes do (S =
+//     2 10^5: 3.05 rounds of whole points = 4, against 9.16 rounds of thirds = 10: 1.2 x); each lane stores its term of R_SFI /
+//     T_SFI after its last load, k_sum adds the terms in ascending m.
+template <int N, bool SPLIT>
+__global__ void __launch_bounds__(256, (N >= 3) ? MOMS_WAVES_N34 : 2) k_sweep(SweepArgs a) {
+  // SPLIT: ceil(S / 256) workgroups per moment, so that m is a scalar (the Z bases of the moment stay on the scalar cache path)
+  const int bpm = (a.S + (int)blockDim.x - 1) / (int)blockDim.x;
+  const int m_lo = SPLIT ? (int)blockIdx.x / bpm : 0, m_hi = SPLIT ? m_lo + 1 : a.M;
+  const int n = (SPLIT ? (int)blockIdx.x - m_lo * bpm : (int)blockIdx.x) * (int)blockDim.x + (int)threadIdx.x;
   if (n >= a.S) return;
   const int nS = a.nS, S = a.S, K = a.K;
   const int i_start = nS * (a.imu0 - 1), i_end = nS * a.imu0;
   int bad = 0;
-  // R_SFI / T_SFI / hdr accumulate over the moments in registers (at most 4 views x 4 components kept here; the host
-  // dispatches larger view sets to the general kernels)
-  real accR[16], accT[16], accH[16];
-#pragma unroll
-  for (int x = 0; x < 16; ++x) accR[x] = accT[x] = accH[x] = 0.0;
   real bup[4] = {0, 0, 0, 0}, bdw[4] = {0, 0, 0, 0};
+  extern __shared__ real acc_lds[];  // [R | T | hdr][nVza nS][blockDim.x] (unsplit kernel only)
+  const int nslot = a.nVza * nS;
+  real *accR = acc_lds + threadIdx.x, *accT = accR + (size_t)nslot * blockDim.x, *accH = accT + (size_t)nslot * blockDim.x;
+  (void)accR; (void)accT; (void)accH;
 
-  for (int m = 0; m < a.M; ++m) {
-    const real wdiv = (m == 0) ? 2.0 : 4.0, wct02 = (m == 0) ? 0.5 : 0.25;
+  for (int m = m_lo; m < m_hi; ++m) {
+    // wt / wdiv with wdiv = 2 (m = 0) or 4: the same value as wt * 0.5 or wt * 0.25 (a power of two: exact), without the division
+    const real winv = (m == 0) ? 0.5 : 0.25, wct02 = (m == 0) ? 0.5 : 0.25;
     Mat<N> Rmp, Rpm, Tpp, Tmm;  // composite layer
     Vec<N> Jp, Jm;
     const real *Zp_m = a.Zpp + (size_t)N * N * K * m, *Zm_m = a.Zmp + (size_t)N * N * K * m;
+    // inputs of layer 0; inside the loop: of layer z + 1 while layer z is computed
+    real tau_n = a.tau[n], varpi_n = a.varpi[n], tsum_n = a.tau_sum[n], zw_n[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) zw_n[k] = (k < K) ? a.zw[k + (size_t)K * n] : 0.0;
     for (int z = 0; z < a.Nz; ++z) {
       const int nd = a.nd[z], iface = a.iface[z];
-      const size_t o = n + (size_t)S * z;
-      const real tau = a.tau[o], varpi = a.varpi[o], tau_sum = a.tau_sum[o];
-      const real dtau = ldexp(tau, -nd);  // τ ./ 2^ndoubl (rt_kernel.jl:244)
-      real expk = exp(-dtau / a.mu0);     // init_layer (rt_kernel.jl:273)
+      const real tau = tau_n, varpi = varpi_n, tau_sum = tsum_n;
       real zw[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) zw[k] = (k < K) ? a.zw[k + (size_t)K * o] : 0.0;
+      for (int k = 0; k < 4; ++k) zw[k] = zw_n[k];
+      if (z + 1 < a.Nz) {
+        const size_t o1 = n + (size_t)S * (z + 1);
+        tau_n = a.tau[o1]; varpi_n = a.varpi[o1]; tsum_n = a.tau_sum[o1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) zw_n[k] = (k < K) ? a.zw[k + (size_t)K * o1] : 0.0;
+      }
+      const real dtau = ldexp(tau, -nd);  // τ ./ 2^ndoubl (rt_kernel.jl:244)
+      real expk = exp(-dtau / a.mu0);     // init_layer (rt_kernel.jl:273)
       // ---------------- elemental! (elemental.jl:164-253)
       Mat<N> r, t;
       Vec<N> jp, jm;
@@ -159,9 +194,21 @@ __global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {  // two waves p
         Vec<N> zpI, zmI;  // Z I0 over the sun's Stokes block (:225-228)
 #pragma unroll
         for (int i = 0; i < N; ++i) zpI.v[i] = zmI.v[i] = 0.0;
+        // E[i][j] = 1 - exp(-dtau (1/mu_i + 1/mu_j)): SI[i + N j] and SI[j + N i] are the same sum of the same two quotients, so
+        // the N (N + 1) / 2 entries with i <= j are evaluated and mirrored (same operands, same value: 10 exponentials instead
+        // of the 12 + 4 of the element loop and the j0- vector)
+        Mat<N> E;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+          for (int i = 0; i <= j; ++i) {
+            const real e = 1 - exp(-dtau * a.SI[i + N * j]);
+            E.a[i][j] = e;
+            E.a[j][i] = e;
+          }
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-          const real wj = a.wt[j] / wdiv;
+          const real wj = a.wt[j] * winv;
 #pragma unroll
           for (int i = 0; i < N; ++i) {
             real zp = 0.0, zm = 0.0;  // Z = sum_k w_k Z_k, in k order (types.jl:656-661)
@@ -175,9 +222,9 @@ __global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {  // two waves p
             }
             real rr, tt;
             if (wj > 1.e-8) {
-              rr = varpi * zm * a.F1[i + N * j] * wj * (1 - exp(-dtau * a.SI[i + N * j]));
+              rr = varpi * zm * a.F1[i + N * j] * wj * E.a[i][j];
               if (a.mu[i] == a.mu[j]) {
-                tt = (i == j) ? ei[i] * (1 + varpi * zp * (dtau / a.mu[i]) * (a.wt[i] / wdiv)) : 0.0;
+                tt = (i == j) ? ei[i] * (1 + varpi * zp * (dtau / a.mu[i]) * (a.wt[i] * winv)) : 0.0;
               } else {
                 tt = varpi * zp * a.F2[i + N * j] * wj * (ei[i] - ei[j]);
               }
@@ -199,7 +246,11 @@ __global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {  // two waves p
             p = wct02 * varpi * zpI.v[i] * (dtau / mui) * ei[i];
           else
             p = wct02 * varpi * zpI.v[i] * a.F2[i + N * i_start] * (ei[i] - ei[i_start]);
-          q = wct02 * varpi * zmI.v[i] * a.F1[i + N * i_start] * (1 - exp(-dtau * a.SI[i + N * i_start]));
+          real Eis = 0.0;  // E[i][i_start] (i_start is a run-time index)
+#pragma unroll
+          for (int j = 0; j < N; ++j)
+            if (j == i_start) Eis = E.a[i][j];
+          q = wct02 * varpi * zmI.v[i] * a.F1[i + N * i_start] * Eis;
           p *= att;
           q *= att;
           if (nd >= 1) q = a.D[i % nS] * q;  // elemental.jl:249-251
@@ -249,26 +300,24 @@ __global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {  // two waves p
           jm.v[i] *= a.sg[i];
         }
       }
-      // r+- = D r-+ D, t-- = D t++ D (elemental.jl:255-263 for nd < 1, doubling.jl:95-108 otherwise)
-      Mat<N> rpm, tmm;
+      // r+- = D r-+ D, t-- = D t++ D (elemental.jl:255-263 for nd < 1, doubling.jl:95-108 otherwise): formed where consumed
+      auto dsd = [&](Mat<N> &o, const Mat<N> &x) {
 #pragma unroll
-      for (int i = 0; i < N; ++i)
+        for (int i = 0; i < N; ++i)
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-          const real s = a.sg[i] * a.sg[j];
-          rpm.a[i][j] = s * r.a[i][j];
-          tmm.a[i][j] = s * t.a[i][j];
-        }
+          for (int j = 0; j < N; ++j) o.a[i][j] = (a.sg[i] * a.sg[j]) * x.a[i][j];
+      };
       // ---------------- composite <- added (rt_kernel.jl:227-230) or interaction! (interaction.jl:8-117)
       if (z == 0) {
-        Rmp = r; Rpm = rpm; Tpp = t; Tmm = tmm; Jp = jp; Jm = jm;
+        Rmp = r; dsd(Rpm, r); Tpp = t; dsd(Tmm, t); Jp = jp; Jm = jm;
       } else if (iface == 0) {
         Vec<N> v1, v2;
         mulv(v1, t, Jp);
         mulv(v2, Tmm, jm);
 #pragma unroll
         for (int i = 0; i < N; ++i) { Jp.v[i] = jp.v[i] + v1.v[i]; Jm.v[i] = Jm.v[i] + v2.v[i]; }
-        Mat<N> W;
+        Mat<N> W, tmm;
+        dsd(tmm, t);
         mul(W, tmm, Tmm); Tmm = W;
         mul(W, t, Tpp); Tpp = W;
       } else if (iface == 1) {
@@ -284,9 +333,10 @@ __global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {  // two waves p
         for (int i = 0; i < N; ++i) Jp.v[i] = jp.v[i] + v1.v[i];
         Mat<N> W1, W2;
         mul(W1, Tmm, r); mul(W2, W1, Tpp); Rmp = W2;
-        Rpm = rpm;
+        dsd(Rpm, r);
         mul(W1, t, Tpp); Tpp = W1;
-        mul(W1, Tmm, tmm); Tmm = W1;
+        dsd(W2, t);
+        mul(W1, Tmm, W2); Tmm = W1;
       } else if (iface == 2) {
         Vec<N> v1, v2;
         mulv(v1, Rpm, jm);
@@ -298,7 +348,8 @@ __global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {  // two waves p
         mulv(v1, Tmm, jm);
 #pragma unroll
         for (int i = 0; i < N; ++i) Jm.v[i] = Jm.v[i] + v1.v[i];
-        Mat<N> W1, W2;
+        Mat<N> W1, W2, tmm;
+        dsd(tmm, t);
         mul(W1, t, Tpp); Tpp = W1;
         mul(W1, Tmm, tmm); Tmm = W1;
         mul(W1, t, Rpm); mul(W2, W1, tmm); Rpm = W2;
@@ -320,7 +371,8 @@ __global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {  // two waves p
         for (int i = 0; i < N; ++i)
 #pragma unroll
           for (int j = 0; j < N; ++j) Rmp.a[i][j] = Rmp.a[i][j] + W2.a[i][j];  // :93
-        mul(W1, W3, tmm); Tmm = W1;                                          // :96
+        dsd(W2, t);
+        mul(W1, W3, W2); Tmm = W1;                                           // :96
         mul(W1, Rpm, r);
         e = inv_one_minus(W2, W1);  // (I - R+- r-+)^-1 (:104-105)
         if (e && !bad) bad = e;
@@ -332,11 +384,11 @@ __global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {  // two waves p
 #pragma unroll
         for (int i = 0; i < N; ++i) Jp.v[i] = jp.v[i] + v2.v[i];  // :110
         mul(W1, W3, Tpp); Tpp = W1;                              // :113
-        mul(W1, W3, Rpm); mul(W2, W1, tmm);
+        mul(W1, W3, Rpm); dsd(W3, t); mul(W2, W1, W3);
 #pragma unroll
         for (int i = 0; i < N; ++i)
 #pragma unroll
-          for (int j = 0; j < N; ++j) Rpm.a[i][j] = rpm.a[i][j] + W2.a[i][j];  // :116
+          for (int j = 0; j < N; ++j) Rpm.a[i][j] = (a.sg[i] * a.sg[j]) * r.a[i][j] + W2.a[i][j];  // :116
       }
     }
     // ---------------- Lambertian surface (m = 0) + closing interaction with the LAST layer's interface code (Q6)
@@ -432,36 +484,59 @@ __global__ void __launch_bounds__(256, 2) k_sweep(SweepArgs a) {  // two waves p
 #pragma unroll
           for (int i = 0; i < N; ++i)
             if (i == row0 + k) { jmv = Jm.v[i]; jpv = Jp.v[i]; hv = hdrJ.v[i]; }
-          const int x = v * 4 + k;
-          // (x is a run-time index only through v: at most 4 views)
-          switch (x >> 2) {
-            case 0: accR[k] += cs * jmv; accT[k] += cs * jpv; if (m == 0) accH[k] = cs * hv; break;
-            case 1: accR[4 + k] += cs * jmv; accT[4 + k] += cs * jpv; if (m == 0) accH[4 + k] = cs * hv; break;
-            case 2: accR[8 + k] += cs * jmv; accT[8 + k] += cs * jpv; if (m == 0) accH[8 + k] = cs * hv; break;
-            default: accR[12 + k] += cs * jmv; accT[12 + k] += cs * jpv; if (m == 0) accH[12 + k] = cs * hv; break;
+          // the sum over the moments is kept in LDS (same order of additions as a register accumulator that starts at zero)
+          if constexpr (SPLIT) {  // (the loop over m runs once: these stores follow every load of the lane)
+            const size_t cnt = (size_t)a.nVza * nS * S, idx = v + (size_t)a.nVza * (k + (size_t)nS * n);
+            a.part[(size_t)(2 * m) * cnt + idx] = cs * jmv;
+            a.part[(size_t)(2 * m + 1) * cnt + idx] = cs * jpv;
+            if (m == 0) a.hdr[idx] = cs * hv;
+          } else {
+            const int x = (v * nS + k) * blockDim.x;
+            if (m == 0) {
+              accR[x] = cs * jmv;
+              accT[x] = cs * jpv;
+              accH[x] = cs * hv;
+            } else {
+              accR[x] += cs * jmv;
+              accT[x] += cs * jpv;
+            }
           }
         }
     }
   }
+  if constexpr (!SPLIT) {
+    for (int v = 0; v < a.nVza; ++v)
+      for (int k = 0; k < nS; ++k) {
+        const size_t idx = v + (size_t)a.nVza * (k + (size_t)nS * n);
+        const int x = (v * nS + k) * blockDim.x;
+        a.R[idx] = accR[x];
+        a.T[idx] = accT[x];
+        a.hdr[idx] = accH[x];
+      }
+  }
+  if (!SPLIT || m_lo == 0) {
 #pragma unroll
-  for (int v = 0; v < 4; ++v)
-    if (v < a.nVza) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (k < nS) {
-          const size_t idx = v + (size_t)a.nVza * (k + (size_t)nS * n);
-          a.R[idx] = accR[v * 4 + k];
-          a.T[idx] = accT[v * 4 + k];
-          a.hdr[idx] = accH[v * 4 + k];
-        }
-    }
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (k < nS) {
-      a.bhr_uw[k + (size_t)nS * n] = bup[k];
-      a.bhr_dw[k + (size_t)nS * n] = bdw[k];
-    }
+    for (int k = 0; k < 4; ++k)
+      if (k < nS) {
+        a.bhr_uw[k + (size_t)nS * n] = bup[k];
+        a.bhr_dw[k + (size_t)nS * n] = bdw[k];
+      }
+  }
   if (bad) atomicMax(a.info, bad);
+}
+
+// R_SFI / T_SFI = sum over the moments of the SPLIT kernel's terms, in ascending m from zero like the accumulator of the
+// unsplit kernel (postprocessing_vza.jl:9-60 adds the moments into R_SFI in the order of rt_run.jl:125)
+__global__ void k_sum(SweepArgs a) {
+  const size_t cnt = (size_t)a.nVza * a.nS * a.S, idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= cnt) return;
+  real r = 0.0, t = 0.0;
+  for (int m = 0; m < a.M; ++m) {
+    r += a.part[(size_t)(2 * m) * cnt + idx];
+    t += a.part[(size_t)(2 * m + 1) * cnt + idx];
+  }
+  a.R[idx] = r;
+  a.T[idx] = t;
 }
 
 }  // namespace MOMS_NS
@@ -472,12 +547,27 @@ size_t momsm_args_bytes() { return sizeof(MOMS_NS::SweepArgs); }
 #endif
 hipError_t MOMS_LAUNCH(const void *args, int N, hipStream_t st) {
   const MOMS_NS::SweepArgs a = *reinterpret_cast<const MOMS_NS::SweepArgs *>(args);
-  const dim3 grid((unsigned)((a.S + 255) / 256)), block(256);
+  const dim3 block(256);
+  if (a.part != nullptr && a.M > 1) {  // one (point, moment) per lane, then the sum over the moments
+    const dim3 grid((unsigned)(((size_t)a.S + 255) / 256 * a.M));
+    switch (N) {
+      case 1: hipLaunchKernelGGL((MOMS_NS::k_sweep<1, true>), grid, block, 0, st, a); break;
+      case 2: hipLaunchKernelGGL((MOMS_NS::k_sweep<2, true>), grid, block, 0, st, a); break;
+      case 3: hipLaunchKernelGGL((MOMS_NS::k_sweep<3, true>), grid, block, 0, st, a); break;
+      case 4: hipLaunchKernelGGL((MOMS_NS::k_sweep<4, true>), grid, block, 0, st, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    const size_t cnt = (size_t)a.nVza * a.nS * a.S;
+    hipLaunchKernelGGL(MOMS_NS::k_sum, dim3((unsigned)((cnt + 255) / 256)), block, 0, st, a);
+    return hipGetLastError();
+  }
+  const dim3 grid((unsigned)((a.S + 255) / 256));
+  const size_t lds = (size_t)3 * a.nVza * a.nS * 256 * sizeof(real);  // the view accumulators (<= 48 KB: nVza, nS <= 4)
   switch (N) {
-    case 1: hipLaunchKernelGGL(MOMS_NS::k_sweep<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(MOMS_NS::k_sweep<2>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(MOMS_NS::k_sweep<3>, grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(MOMS_NS::k_sweep<4>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((MOMS_NS::k_sweep<1, false>), grid, block, lds, st, a); break;
+    case 2: hipLaunchKernelGGL((MOMS_NS::k_sweep<2, false>), grid, block, lds, st, a); break;
+    case 3: hipLaunchKernelGGL((MOMS_NS::k_sweep<3, false>), grid, block, lds, st, a); break;
+    case 4: hipLaunchKernelGGL((MOMS_NS::k_sweep<4, false>), grid, block, lds, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -76,6 +76,33 @@ __device__ __forceinline__ bool strip_rowok(int rt, int r, int lq) {
   else return 16 * rt + 4 * lq + r < 4 * KS;
 }
 
+// Which column strip (0 .. 3) a wave owns.  Default: wave & 3.  -DMOM_SIMD_AWARE (experiment, profiles/r05_mid_ab.txt; 4-wave
+// build): from the SIMD the wave sits on and the workgroup's slot on the CU (HW_REG_HW_ID: simd_id bits 5:4, tg_id bits 19:16), so
+// that the idle fourth wave (NT = 3) of co-resident workgroups falls on different SIMDs.  c.slot is set (and validated: the four
+// waves of the workgroup must sit on four distinct SIMDs, else wave & 3) once in the prologue.
+#define MOM_GETREG(id, off, size) ((((size)-1) << 11) | ((off) << 6) | (id))
+__device__ __forceinline__ int strip_slot(const Ctx &c, int wave) {
+#ifdef MOM_SIMD_AWARE
+  if (kWaves == 4) return __builtin_amdgcn_readfirstlane(c.slot);
+#endif
+  return wave & 3;
+}
+__device__ __forceinline__ void strip_slot_init(Ctx &c) {
+#ifdef MOM_SIMD_AWARE
+  if (kWaves == 4) {
+    const int wave = wg_wave();
+    const unsigned simd = __builtin_amdgcn_s_getreg(MOM_GETREG(4, 4, 2)), tg = __builtin_amdgcn_s_getreg(MOM_GETREG(4, 16, 4));
+    const int mine = (int)((simd + tg) & 3u);
+    if (wg_lane() == 0) c.ipiv[wave] = mine;
+    __syncthreads();
+    unsigned seen = 0;
+    for (int w = 0; w < 4; ++w) seen |= 1u << c.ipiv[w];
+    c.slot = (seen == 15u) ? mine : wave;
+    __syncthreads();
+  }
+#endif
+}
+
 __device__ __forceinline__ r4 mfma_f64(real a, real b, r4 c) {
   return mma16(a, b, c);
 }
@@ -222,8 +249,9 @@ __device__ __forceinline__ void doubling_rr_strip(const Ctx &c) {
   using G = StripGeom<KS>;
   constexpr int N = G::N, NT = G::NT, LD = G::LD;
   const int lane = wg_lane(), wave = wg_wave(), lr = lane & 15, lq = lane >> 4;
-  const int c0 = 16 * (wave & 3), col = c0 + lr;
-  const bool active = (wave >> 2) == 0 && (wave & 3) < NT, colok = col < N;
+  const int slot = strip_slot(c, wave);
+  const int c0 = 16 * slot, col = c0 + lr;
+  const bool active = (wave >> 2) == 0 && slot < NT, colok = col < N;
   real ss = 0.0;
   if (active) {
     r4 W[NT], B[NT];
@@ -254,8 +282,9 @@ __device__ __forceinline__ void doubling_step_strip(Ctx &c, int p, real expk, co
   using G = StripGeom<KS>;
   constexpr int N = G::N, NT = G::NT, LD = G::LD;
   const int lane = wg_lane(), wave = wg_wave(), lr = lane & 15, lq = lane >> 4;
-  const int c0 = 16 * (wave & 3);
-  const bool active = (wave >> 2) == 0 && (wave & 3) < NT, colok = c0 + lr < N;
+  const int slot = strip_slot(c, wave);
+  const int c0 = 16 * slot;
+  const bool active = (wave >> 2) == 0 && slot < NT, colok = c0 + lr < N;
   real *r = c.r, *t = c.t;
   const real *P = c.P;
   r4 Rn[NT], Tn[NT];
@@ -296,10 +325,12 @@ __device__ __forceinline__ void doubling_step_strip(Ctx &c, int p, real expk, co
 #ifdef MOM_QPREFETCH
   // experiment (profiles/r04_C2_ab.txt): the waves that idle during the chains of the LAST doubling step fetch the coming
   // interaction's T++ block (+ J0+ as its riding column) into Q, which no strip step uses
-  if (pre != nullptr && kWaves == 8 && (wave >> 2) == 1) {
-    constexpr int NN = N * N, U = 8, TH = 256;
+  // (4-wave build: the idle waves are the ones without a strip, slot >= NT -- on a SIMD of their own, no chain wave to disturb)
+  constexpr int kIdle0 = (kWaves == 8) ? 4 : NT;
+  if (pre != nullptr && kIdle0 < kWaves && (kWaves == 8 ? (wave >> 2) == 1 : slot >= NT)) {
+    constexpr int NN = N * N, U = 8, TH = 64 * (kWaves - kIdle0);
     real *Q = c.Q;
-    const int tid4 = wg_tid() - 256;
+    const int tid4 = (kWaves == 8) ? wg_tid() - 256 : 64 * (slot - NT) + lane;
     for (int e0 = tid4; e0 < NN; e0 += U * TH) {
       real vt[U];
       int o[U];
@@ -319,7 +350,7 @@ __device__ __forceinline__ void doubling_step_strip(Ctx &c, int p, real expk, co
     }
     for (int i = tid4; i < N; i += TH) Q[i + N * LD] = pre->J0p[i];
   }
-  if (pre != nullptr && kWaves == 8) c.qpre = 1;
+  if (pre != nullptr && kIdle0 < kWaves) c.qpre = 1;
 #endif
 #ifdef MOM_CHAIN_PRIO
   if (active) __builtin_amdgcn_s_setprio(0);
@@ -361,8 +392,9 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
   using G = StripGeom<KS>;
   constexpr int N = G::N, NT = G::NT, LD = G::LD;
   const int lane = wg_lane(), wave = wg_wave(), lr = lane & 15, lq = lane >> 4;
-  const int grp = wave >> 2, c0 = 16 * (wave & 3), col = c0 + lr;
-  const bool strip = (wave & 3) < NT, colok = col < N;
+  const int slot = strip_slot(c, wave);
+  const int grp = wave >> 2, c0 = 16 * slot, col = c0 + lr;
+  const bool strip = slot < NT, colok = col < N;
   const bool do1 = strip && grp == 0, do2 = strip && grp == kStripGroups - 1;
   real *r = c.r, *t = c.t, *P = c.P, *Q = c.Q;
   r4 T1[NT], W0[NT];  // chain 1: T--^T strip ; chain 2: W0 = R+-^T t++^T
@@ -484,6 +516,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
       strip_copy(Y, acc);
     }
     MOM_STAMP4(94);
+    if (kWaves == 4) MOM_STAMP(58);  // (4-wave build: the same waves run chain 2 after chain 1)
     // T21^T = t++^T + r-+^T X^T ; row N: (X j0-)^T = (T21 R+- j0-)^T
     r4 T21[NT];
     strip_load_lds<KS>(t, lr, lq, c0, T21);
@@ -506,6 +539,7 @@ __device__ __forceinline__ bool interaction_strip(Ctx &c, const CompPtrs &g) {
     strip_flip(acc, mask);
     strip_store_glb<KS>(g.R_pm, lr, lq, c0, colok, acc);
     MOM_STAMP4(95);
+    if (kWaves == 4) MOM_STAMP(59);
   }
   __syncthreads();
   MOM_STAMP(56);

@@ -401,6 +401,8 @@ struct mom_handle {
   DevStreams qk{};         // q with N = Nk
   int opt_small = 1;       // N <= 4: lane-per-point sweep kernel (mom_small.hip)
   double *d_smtab = nullptr;  // F1 | F2 | SI tables [3][N,N]
+  double *d_smpart = nullptr; // N <= 4, one (point, moment) per lane: the per-moment terms of R_SFI / T_SFI [M][2][nVza,nS,S]
+  size_t smpart_cap = 0;
   int *d_ndif = nullptr;      // ndoubl | iface [2][Nz]
   size_t ndif_cap = 0;
   bool red0 = false;
@@ -614,7 +616,7 @@ extern "C" int mom_destroy(mom_t *h) {
   fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
   fr(h->d_mu0); fr(h->d_wt0); fr(h->d_sg0); fr(h->d_Zpp0); fr(h->d_Zmp0); fr(h->d_hdrJ0); fr(h->d_scratch0);
   for (int k = 0; k < 6; ++k) fr(h->comp0[k]);
-  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_rrs_send); fr(h->d_Rsurf); fr(h->d_Rsurf0); fr(h->d_albedo_spec); fr(h->d_hdrJm); fr(h->d_smtab); if (h->d_ndif) (void)hipFree(h->d_ndif); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_prof); fr(h->d_tau_rayl);
+  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_rrs_send); fr(h->d_Rsurf); fr(h->d_Rsurf0); fr(h->d_albedo_spec); fr(h->d_hdrJm); fr(h->d_smtab); fr(h->d_smpart); if (h->d_ndif) (void)hipFree(h->d_ndif); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_prof); fr(h->d_tau_rayl);
   fr(h->d_layer_max); fr(h->d_aer); if (h->d_aer_mode) (void)hipFree(h->d_aer_mode); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
   for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (int k = 0; k < 2; ++k) if (h->ev_voigt[k]) (void)hipEventDestroy(h->ev_voigt[k]);
@@ -1073,6 +1075,7 @@ extern "C" int mom_scene_set(mom_t *h, int Nz, int K, int M, const double *tau, 
   if (Nz <= 0 || K <= 0 || M <= 0 || M > h->M || nVza <= 0 || !tau || !varpi || !zw || !Zpp || !Zmp || !ndoubl ||
       !iface || !tau_sum || !node_1based || !cos_mphi || !sin_mphi)
     return fail(h, MOM_EINVAL, "mom_scene_set: bad argument");
+  if (K > 64) return fail(h, MOM_EINVAL, "mom_scene_set: at most 64 phase-matrix bases (Rayleigh + aerosol types)");
   for (int z = 0; z < Nz; ++z)
     if (ndoubl[z] < 0 || ndoubl[z] > 60 || iface[z] < 0 || iface[z] > 3)
       return fail(h, MOM_EINVAL, "mom_scene_set: ndoubl/iface out of range");
@@ -1282,6 +1285,15 @@ static int rt_run_small(mom_t *h) {
   a.R = h->d_R; a.T = h->d_T; a.hdr = h->d_hdr; a.bhr_uw = h->d_bhr_uw; a.bhr_dw = h->d_bhr_dw;
   a.info = h->d_info;
   if (h->K > 4) return fail(h, MOM_EINVAL, "mom_rt_run: the N <= 4 sweep kernel handles at most 4 phase-matrix bases");
+  if (a.M > 1 && h->opt_small != 2) {  // one (point, moment) per lane (mom_small.hip SPLIT); MOM_OPT_SMALL_N = 2: one point per lane
+    const size_t need = (size_t)a.M * 2 * a.nVza * a.nS * a.S;
+    if (need > h->smpart_cap) {  // grow-only: no allocation in steady state
+      if (h->d_smpart) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_smpart); h->d_smpart = nullptr; h->smpart_cap = 0; }
+      HIPCHK(h, dmalloc(&h->d_smpart, need));
+      h->smpart_cap = need;
+    }
+    a.part = h->d_smpart;
+  }
   while (h->ev_full.size() < 2) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev_full.push_back(e); }
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   HIPCHK(h, hipEventRecord(h->ev_full[0], h->stream));

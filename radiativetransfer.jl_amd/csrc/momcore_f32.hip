@@ -198,6 +198,8 @@ struct momf_scene {
         *d_bhr_dw = nullptr, *d_scratch = nullptr, *d_Rsurf = nullptr, *d_albedo_spec = nullptr;
   double *d_cos = nullptr, *d_sin = nullptr;
   float *d_smtab = nullptr;               // N <= 4: the three stream-pair tables of the lane-per-point kernel
+  float *d_smpart = nullptr;              // ... and the per-moment terms of R_SFI / T_SFI of its (point, moment) form
+  size_t smpart_cap = 0;
   int *d_node = nullptr, *d_info = nullptr, *d_nd = nullptr;  // d_nd: ndoubl per layer for the wave-per-point kernel
   bool pack = true;                       // MOM_OPT_SMALL_N = 1 (2: one point per wavefront)
   bool small_n = true;                    // MOM_OPT_SMALL_N: 4 < N <= 32 on the wave-per-point kernels (mom_wave.hip, Float32 build)
@@ -255,7 +257,7 @@ void momf_destroy(momf_scene *s) {
   for (int k = 0; k < 6; ++k) fr(s->comp[k]);
   fr(s->d_tau); fr(s->d_varpi); fr(s->d_zw); fr(s->d_tau_sum); fr(s->d_Zpp); fr(s->d_Zmp); fr(s->d_R); fr(s->d_hdr);
   fr(s->d_hdrJ); fr(s->d_hdrJm); fr(s->d_bhr_uw); fr(s->d_bhr_dw); fr(s->d_scratch); fr(s->d_Rsurf); fr(s->d_albedo_spec);
-  fr(s->d_cos); fr(s->d_sin); fr(s->d_node); fr(s->d_nd); fr(s->d_smtab);
+  fr(s->d_cos); fr(s->d_sin); fr(s->d_node); fr(s->d_nd); fr(s->d_smtab); fr(s->d_smpart);
   for (int k = 0; k < 6; ++k) { fr(s->op_added[k]); fr(s->op_surf[k]); fr(s->op_comp[k]); }
   for (int k = 0; k < 4; ++k) fr(s->op_vec[k]);
   fr(s->op_Z[0]); fr(s->op_Z[1]);
@@ -533,6 +535,15 @@ static int rt_run_small_f32(momf_scene *s) {
   a.tau = s->d_tau; a.varpi = s->d_varpi; a.zw = s->d_zw; a.tau_sum = s->d_tau_sum;
   a.R = s->d_R; a.T = s->d_T; a.hdr = s->d_hdr; a.bhr_uw = s->d_bhr_uw; a.bhr_dw = s->d_bhr_dw;
   a.info = s->d_info;
+  if (a.M > 1 && s->pack) {  // one (point, moment) per lane; MOM_OPT_SMALL_N = 2: one point per lane
+    const size_t need = (size_t)a.M * 2 * a.nVza * a.nS * a.S;
+    if (need > s->smpart_cap) {
+      if (s->d_smpart) { FCHK(s, hipStreamSynchronize(s->stream)); (void)hipFree(s->d_smpart); s->d_smpart = nullptr; s->smpart_cap = 0; }
+      FCHK(s, hipMalloc((void **)&s->d_smpart, need * sizeof(float)));
+      s->smpart_cap = need;
+    }
+    a.part = s->d_smpart;
+  }
   FCHK(s, hipEventRecord(s->ev[0], s->stream));
   FCHK(s, momsmf_launch_sweep(&a, N, s->stream));
   for (int k = 1; k < 4; ++k) FCHK(s, hipEventRecord(s->ev[k], s->stream));
