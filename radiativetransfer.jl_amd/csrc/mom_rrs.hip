@@ -47,11 +47,47 @@ using namespace momt;
 using namespace momr;  // the enumerations and constants of mom_rrs.hpp
 #endif
 
+// diagnostic builds only (-DMOMR_DIAG_STAMPS, tools/phase_stamps_rrs.py): s_memtime deltas per code section of the pair
+// kernels, wave 0 of the middle workgroup; every stamp first waits for the wave's outstanding memory operations, so a section's
+// time includes the latency of the loads it consumes.  Never part of the shipped library.
+#ifdef MOMR_DIAG_STAMPS
+__device__ unsigned long long momr_diag_acc[64];
+__device__ unsigned long long momr_diag_last;
+#define MOMR_STAMP(id)                                                                                        \
+  do {                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1)) {                                                 \
+      unsigned long long n__;                                                                                 \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n__)::"memory"); \
+      momr_diag_acc[id] += n__ - momr_diag_last;                                                              \
+      momr_diag_last = n__;                                                                                   \
+    }                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  } while (0)
+// ... without the wait for outstanding vector-memory operations (dbl_pair_body1: its prefetch must stay in flight)
+#define MOMR_STAMP_NW(id)                                                                                     \
+  do {                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1)) {                                                 \
+      unsigned long long n__;                                                                                 \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n__)::"memory");                            \
+      momr_diag_acc[id] += n__ - momr_diag_last;                                                              \
+      momr_diag_last = n__;                                                                                   \
+    }                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  } while (0)
+#else
+#define MOMR_STAMP(id)
+#define MOMR_STAMP_NW(id)
+#endif
+
+
 struct KArgs {
   int N, nS, S, nR, strict_idx, strict_rrs, n_glob0, n1_lo, n1_hi, last, nd, sh, m, imu0, nTerms;
   int P;          // row pitch of the device blocks: 16 (N <= 16) or 32; a matrix block is P x P doubles, a vector block P (zero padding)
   int derive_pm;  // corrected position: ier+- / iet-- are sgn (.) ier-+ / iet++ and are derived where they are read
   int fuse_el;    // first doubling step of a layer: the inelastic elemental layer is formed in registers, not loaded
+  int dn_chunk;   // one-tile doubling pair kernel (dbl_pair_body1): Raman offsets per work item (n1, chunk)
   double mu0, albedo, weight;
   double I0[4], D[4];
   const double *mu, *wt;
@@ -492,6 +528,13 @@ __device__ __forceinline__ void ie_elem_tile(const Geo &g, const KArgs &a, int n
 template <int NT, bool FUSE, int MODE>
 __device__ __forceinline__ void dbl_pair_body(const KArgs &a) {
   constexpr bool STRICT = (MODE == 2);
+#ifdef MOMR_DIAG_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1)) {
+    unsigned long long n__;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n__)::"memory");
+    momr_diag_last = n__;
+  }
+#endif
   const Geo g = make_geo<NT>(a.N, rrs_smem);
   const int n = a.nS, wave = threadIdx.x >> 6;
   const size_t NN = (size_t)a.P * a.P, VS = a.P;  // block strides (padded pitch)
@@ -563,6 +606,7 @@ __device__ __forceinline__ void dbl_pair_body(const KArgs &a) {
       }
       continue;
     }
+    MOMR_STAMP(0);  // loop overhead, off-grid pairs
     const size_t m1 = NN * n1, m0 = NN * n0, v0 = VS * n0;
     Mat<NT> a_t, b_t;
     CV<NT> Jp, Jm;  // ieJ0+, ieJ0-
@@ -588,9 +632,12 @@ __device__ __forceinline__ void dbl_pair_body(const KArgs &a) {
       ttgpr1_t = load_t<NT>(g, a.sm[SM_TTGPR] + m1);
     }
     if (PIPE) prefetch(p + stride);
+    MOMR_STAMP(1);  // the pair's first eight operand loads (+ the fused elemental layer)
     const Mat<NT> a_c = transpose<NT>(g, a_t);
+    MOMR_STAMP(2);  // transpose of ier
     // X = ier r0 + r1 ier
     const Mat<NT> X_t = TNacc<NT>(g, a_c, r1_t, TN<NT>(g, r0_c, a_t));
+    MOMR_STAMP(3);  // X: two products
     // ---- sources (matrix-vector products on the vector ALU: mom_tile.hpp)                                    :61-89
     {
       const double e1 = a.expk_cur[n1];
@@ -616,6 +663,7 @@ __device__ __forceinline__ void dbl_pair_body(const KArgs &a) {
       storeC<NT>(g, a.ie_a[J0P] + o3, Jpn);
       storeC<NT>(g, a.ie_a[J0M] + o3, Jmn);
     }
+    MOMR_STAMP(4);  // source vectors: 4 vector loads, 10 mat-vecs, 4 column -> row conversions, 2 stores
     // ---- operators                                                                                            :98-125
     const Mat<NT> b_c = transpose<NT>(g, b_t);
     const Mat<NT> Y_c = TN<NT>(g, X_t, gt0_c);                                // X G t[n0]
@@ -623,12 +671,15 @@ __device__ __forceinline__ void dbl_pair_body(const KArgs &a) {
     Mat<NT> bn_t = TNacc<NT>(g, gt0_c, b_t, TN<NT>(g, W_c, ttgp1_t));         // tG (iet + Y) + iet G t[n0]
     const Mat<NT> bn_c = transpose<NT>(g, bn_t);
     const Mat<NT> V_c = add<NT>(bn_c, Y_c);
+    MOMR_STAMP(5);  // iet: 2 transposes, 3 products
     if (!PIPE) {  // default: loaded where they are used
       gr0_c = load_t<NT>(g, a.sm[SM_GR] + m0); t0_c = load_t<NT>(g, a.sm[SM_TT] + m0);
       ttgpr1_t = load_t<NT>(g, a.sm[SM_TTGPR] + m1);
     }
+    MOMR_STAMP(6);  // the three late operand loads
     const Mat<NT> Q_t = TNacc<NT>(g, a_c, ttgp1_t, TN<NT>(g, gr0_c, bn_t));  // iet(new) G r[n0] + tG ier
     Mat<NT> an_t = add<NT>(a_t, TNacc<NT>(g, t0_c, Q_t, TN<NT>(g, V_c, ttgpr1_t)));
+    MOMR_STAMP(7);  // ier: 4 products
     if (fuseD) {  // apply_D_matrix_IE!, corrected indexing (D2)
       if (n > 1) map_t<NT>(g, an_t, [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
       Mat<NT> apm = an_t, bmm = bn_t;
@@ -643,13 +694,252 @@ __device__ __forceinline__ void dbl_pair_body(const KArgs &a) {
     }
     store_t<NT>(g, a.ie_a[R_MP] + o4, an_t);
     store_t<NT>(g, a.ie_a[T_PP] + o4, bn_t);
+    MOMR_STAMP(8);  // D signs and the stores of the two (four) operator blocks
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// r5: the one-tile doubling pair kernel with its operands PREFETCHED INTO LDS by direct global -> LDS loads
+// (global_load_lds_dwordx4, gfx950), -DMOMR_LDSPF=0 restores the body above for NT = 1.
+//
+// What bounds the body above (tools/phase_stamps_rrs.py, profiles/r05_C5_ab.txt): a wave spends ~50 % of a pair waiting for
+// memory -- the first eight operand loads 20 %, the three late ones 9 %, the four vector loads inside the source block, the
+// stores -- at 3 waves per SIMD with ~1.1 us per round trip, and 14 % in the loop head (64-bit div / mod of the pair index and
+// the dependent load of the offset).  A register prefetch of the next pair (r4, MOMR_PIPELINE) costs a wave per SIMD and was
+// slower.  Here:
+//   * a work item is (n1, a chunk of dn_chunk consecutive Raman offsets): the three n1-side tiles r[n1], (t G)[n1]^T,
+//     (t G r)[n1]^T and expk[n1] are loaded ONCE per item and stay in registers; no division in the pair loop;
+//   * while pair (n1, dn) is computed, the pair-specific and n0-side operands of the NEXT on-grid pair of the chunk -- ier-+,
+//     iet++ (2 x 2 KB), r[n0]^T, (G t)[n0] (2 x 2 KB), ieJ0+-, j1-[n0], j0+[n0], tmp1, tmp2 (6 x 128 B) -- travel from global
+//     memory straight into the wave's LDS slots: no VGPRs are held for them, the wave count per SIMD stays at 3;
+//   * the two late operands (G r)[n0], t[n0]^T are requested at the top of the pair, before the prefetch, and are consumed in
+//     its second half;
+//   * the stores of a pair are issued at the top of the NEXT pair (results carried in registers), so that the one
+//     s_waitcnt vmcnt(0) of a pair -- "my prefetch has landed" -- finds them a whole pair old.
+// Pairs whose source point is off the grid are handled in line, as above.  Semantics identical to dbl_pair_body<1, ..>: every
+// block is still read and written exactly once by exactly one wave (tests/test_gpu_rrs.py).
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef MOMR_LDSPF
+#define MOMR_LDSPF 1
+#endif
+constexpr int kPfTile = 256;                              // doubles of a 16 x 16 block
+constexpr int kPfDoubles = 4 * kPfTile + 6 * 16;          // ier-+, iet++, r[n0]^T, (G t)[n0] + six vectors
+constexpr size_t kPfBytes = (size_t)kPfDoubles * 8;       // 8 960 B per wave
+typedef __attribute__((address_space(1))) const void momr_gptr;
+typedef __attribute__((address_space(3))) void momr_lptr;
+
+// 2 KB block at `src` -> LDS at `dst` (wave-uniform), bit for bit: lane l moves bytes [16 l, 16 l + 16) of each KB
+__device__ __forceinline__ void pf_tile(const double *src, double *dst, int lane) {
+  __builtin_amdgcn_global_load_lds((momr_gptr *)(src + 2 * lane), (momr_lptr *)dst, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((momr_gptr *)(src + 128 + 2 * lane), (momr_lptr *)(dst + 128), 16, 0, 0);
+}
+__device__ __forceinline__ Mat<1> lds_tile(const Geo &g, const double *t) {  // the _t form of the block, as load_t<1>
+  Mat<1> X;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) X.t[0][0][r] = t[g.lr + 16 * (g.lq + 4 * r)];
+  return X;
+}
+
+template <bool FUSE, int MODE>
+__device__ __forceinline__ void dbl_pair_body1(const KArgs &a) {
+  constexpr int NT = 1;
+  constexpr bool STRICT = (MODE == 2), fuseD = (MODE == 1);
+#ifdef MOMR_DIAG_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1)) {
+    unsigned long long n__;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n__)::"memory");
+    momr_diag_last = n__;
+  }
+#endif
+  const Geo g = make_geo<NT>(a.N, rrs_smem);
+  const int n = a.nS, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t NN = 256, VS = 16;  // one-tile images: P = 16
+  double *pf = reinterpret_cast<double *>(rrs_smem + (size_t)kWavesPerBlock * slice_bytes<NT>()) + (size_t)wave * kPfDoubles;
+  double *pfA = pf, *pfB = pf + kPfTile, *pfR0 = pf + 2 * kPfTile, *pfGT = pf + 3 * kPfTile, *pfV = pf + 4 * kPfTile;
+  const int span = a.n1_hi - a.n1_lo, CH = a.dn_chunk, nch = (a.nR + CH - 1) / CH;
+  const unsigned items = (unsigned)span * (unsigned)nch, istride = gridDim.x * kWavesPerBlock;
+  const bool sgnD = fuseD && n > 1;
+
+  for (unsigned w = blockIdx.x * kWavesPerBlock + wave; w < items; w += istride) {
+    const int ch = (int)(w / (unsigned)span), n1 = a.n1_lo + (int)(w - (unsigned)ch * (unsigned)span);
+    const int dn_lo = ch * CH, dn_hi = (dn_lo + CH < a.nR) ? dn_lo + CH : a.nR;
+    const size_t m1 = NN * n1;
+    // the n1 side: once per item
+    const Mat<NT> r1_t = load_t<NT>(g, a.a_cur[R_MP] + m1), ttgp1_t = load_t<NT>(g, a.sm[SM_TTGP] + m1);
+    const Mat<NT> ttgpr1_t = load_t<NT>(g, a.sm[SM_TTGPR] + m1);
+    const double e1 = a.expk_cur[n1];
+
+    // The chunk's offsets live in the lanes of one register (lane k: offset dn_lo + k; dn_chunk <= 64) and its on-grid pairs in
+    // a 64-bit scalar mask: the pair loop reads neither memory nor a divider for its bookkeeping
+    const int cnt = dn_hi - dn_lo;
+    const int off_l = (lane < cnt) ? a.off[dn_lo + lane] : 0;
+    const unsigned long long gmask = __builtin_amdgcn_ballot_w64(lane < cnt && n1 + off_l >= 0 && n1 + off_l < a.S);
+    auto off_of = [&](int dn) { return __builtin_amdgcn_readlane(off_l, dn - dn_lo); };
+    // prefetch of pair (n1, dn) into the wave's LDS slots; dn on the grid
+    auto prefetch = [&](int dn) {
+      const int n0 = n1 + off_of(dn);
+      const size_t u = (size_t)n1 + (size_t)a.S * dn, m0 = NN * n0, v0 = VS * n0;
+      if (!FUSE) {
+        pf_tile(a.ie_a[R_MP] + NN * u, pfA, lane);
+        pf_tile(a.ie_a[T_PP] + NN * u, pfB, lane);
+      }
+      pf_tile(a.sm[SM_RT] + m0, pfR0, lane);
+      pf_tile(a.sm[SM_GT] + m0, pfGT, lane);
+      // six vectors of 16 doubles in ONE instruction: lane l moves 16 bytes of vector l / 8
+      const double *jp0 = STRICT ? a.jpseq + v0 + VS * a.S * dn : a.a_cur[J0P] + v0;
+      const int q = lane >> 3;
+      const double *vp = (q == 0) ? a.ie_a[J0P] + VS * u : (q == 1) ? a.ie_a[J0M] + VS * u : (q == 2) ? a.sv[SV_J1M] + v0
+                       : (q == 3) ? jp0 : (q == 4) ? a.sv[SV_TMP1] + v0 : a.sv[SV_TMP2] + v0;
+      if (lane < 48 && !(FUSE && q < 2))
+        __builtin_amdgcn_global_load_lds((momr_gptr *)(vp + 2 * (lane & 7)), (momr_lptr *)pfV, 16, 0, 0);
+    };
+    auto next_on_grid = [&](int dn) {  // first on-grid offset of the chunk after dn (dn_hi if none)
+      const int k = dn + 1 - dn_lo;    // 0 .. cnt
+      const unsigned long long rest = (k < 64) ? (gmask >> k) : 0ull;
+      return rest ? dn + 1 + (int)__builtin_ctzll(rest) : dn_hi;
+    };
+
+    // results of the previous on-grid pair, stored at the top of the next one
+    Mat<NT> an_d, bn_d;
+    CV<NT> Jpn_d, Jmn_d;
+    size_t o4_d = 0, o3_d = 0;
+    bool have_d = false;
+    auto flush = [&]() {
+      if (!have_d) return;
+      if (fuseD) {  // apply_D_matrix_IE!, corrected indexing (D2): the row signs are already in an_d
+        if (!a.derive_pm) {
+          Mat<NT> apm = an_d, bmm = bn_d;
+          if (n > 1) {
+            map_t<NT>(g, apm, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+            map_t<NT>(g, bmm, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+          }
+          store_t<NT>(g, a.ie_a[R_PM] + o4_d, apm);
+          store_t<NT>(g, a.ie_a[T_MM] + o4_d, bmm);
+        }
+      }
+      store_t<NT>(g, a.ie_a[R_MP] + o4_d, an_d);
+      store_t<NT>(g, a.ie_a[T_PP] + o4_d, bn_d);
+      storeC<NT>(g, a.ie_a[J0P] + o3_d, Jpn_d);
+      storeC<NT>(g, a.ie_a[J0M] + o3_d, Jmn_d);
+      have_d = false;
+    };
+
+    int dn_pf = dn_lo - 1;
+    dn_pf = next_on_grid(dn_pf);
+    if (dn_pf < dn_hi) prefetch(dn_pf);
+
+    // (the variants without off-grid work -- not the fused first step, not the last corrected step -- walk the mask's set bits)
+    constexpr bool OFFGRID_WORK = FUSE || fuseD;
+    for (int dn = OFFGRID_WORK ? dn_lo : next_on_grid(dn_lo - 1); dn < dn_hi; dn = OFFGRID_WORK ? dn + 1 : dn_pf) {
+      const int n0 = n1 + off_of(dn);
+      const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = VS * u;
+      if (OFFGRID_WORK && !((gmask >> (dn - dn_lo)) & 1ull)) {  // get_n0_n1 (inelastic_helper.jl:13-21): no update off the grid ...
+        if (FUSE) {               // ... but the deferred elemental writes zeros there and multiplies ieJ0- by D (:378-380)
+          store_t<NT>(g, a.ie_a[R_MP] + o4, zeros<NT>());
+          store_t<NT>(g, a.ie_a[T_PP] + o4, zeros<NT>());
+          CV<NT> Jm = loadC<NT>(g, a.ie_a[J0M] + o3);
+          Jm.c[0] = a.D[g.col(0) % n] * Jm.c[0];
+          storeC<NT>(g, a.ie_a[J0M] + o3, Jm);
+        }
+        if (fuseD) {              // ... and the corrected D kernels visit every (n, dn)
+          Mat<NT> an_t = FUSE ? zeros<NT>() : load_t<NT>(g, a.ie_a[R_MP] + o4);
+          Mat<NT> bn_t = FUSE ? zeros<NT>() : load_t<NT>(g, a.ie_a[T_PP] + o4);
+          if (n > 1) {
+            map_t<NT>(g, an_t, [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
+            store_t<NT>(g, a.ie_a[R_MP] + o4, an_t);
+            CV<NT> Jm = loadC<NT>(g, a.ie_a[J0M] + o3);
+            if (scomp(g.col(0), n, a.strict_idx) > 2) Jm.c[0] = -Jm.c[0];
+            storeC<NT>(g, a.ie_a[J0M] + o3, Jm);
+            map_t<NT>(g, an_t, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+            map_t<NT>(g, bn_t, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+          }
+          if (!a.derive_pm) {
+            store_t<NT>(g, a.ie_a[R_PM] + o4, an_t);
+            store_t<NT>(g, a.ie_a[T_MM] + o4, bn_t);
+          }
+        }
+        continue;
+      }
+      const size_t m0 = NN * n0;
+      MOMR_STAMP_NW(10);  // loop head, off-grid pairs, item set-up (n1-side loads)
+      // ---- this pair's operands have landed in LDS (requested one pair ago); everything older has completed too
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      MOMR_STAMP_NW(11);  // wait for the prefetch (and the previous pair's stores)
+      Mat<NT> a_t, b_t;
+      CV<NT> Jp, Jm;
+      if (!FUSE) {
+        a_t = lds_tile(g, pfA); b_t = lds_tile(g, pfB);
+        Jp.c[0] = pfV[g.lr]; Jm.c[0] = pfV[16 + g.lr];
+      }
+      const Mat<NT> r0_c = lds_tile(g, pfR0), gt0_c = lds_tile(g, pfGT);
+      Vec<NT> j1mR, jp0R, tm1, tm2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        j1mR.t[0][r] = pfV[32 + g.lq + 4 * r];
+        jp0R.t[0][r] = pfV[48 + g.lq + 4 * r];
+        tm1.t[0][r] = pfV[64 + g.lq + 4 * r];
+        tm2.t[0][r] = pfV[80 + g.lq + 4 * r];
+      }
+      // the two late operands first (consumed in the second half of the pair), then the next pair's prefetch, then the
+      // previous pair's stores
+      const Mat<NT> gr0_c = load_t<NT>(g, a.sm[SM_GR] + m0), t0_c = load_t<NT>(g, a.sm[SM_TT] + m0);
+      Mat<NT> bmm_strict;
+      if (STRICT) bmm_strict = load_t<NT>(g, a.ie_a[T_MM] + o4);  // D5: iet-- as the array holds it
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slots are free again
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      dn_pf = next_on_grid(dn);
+      if (dn_pf < dn_hi) prefetch(dn_pf);
+      flush();
+      MOMR_STAMP_NW(12);  // LDS reads, late loads / next prefetch / deferred stores issued
+      if (FUSE) ie_elem_tile<NT>(g, a, n1, dn, n0, a_t, b_t, Jp, Jm);
+
+      const Mat<NT> a_c = transpose<NT>(g, a_t);
+      // X = ier r0 + r1 ier
+ const Mat<NT> X_t = TNacc<NT>(g, a_c, r1_t, TN<NT>(g, r0_c, a_t));
+      MOMR_STAMP_NW(13);  // (fused elemental), transpose ier, X
+      // ---- sources                                                                                            :61-89
+      CV<NT> Jpn, Jmn;
+      {
+        const CV<NT> J1p = cscale<NT>(Jp, e1), J1m = cscale<NT>(Jm, e1);                         // ieJ1+, ieJ1-   :52-56
+        const CV<NT> a_j1m = mv_t<NT>(g, a_t, j1mR);                                             // ier j1-[n0]
+        const CV<NT> a_jp = mv_t<NT>(g, a_t, jp0R);                                              // ier j0+[n0]
+        const CV<NT> X1 = mv_t<NT>(g, X_t, tm1), X2 = mv_t<NT>(g, X_t, tm2);
+        const CV<NT> b1 = mv_t<NT>(g, b_t, tm1);                                                 // iet++ tmp1
+        const CV<NT> b2 = STRICT ? mv_t<NT>(g, bmm_strict, tm2) : mv_t<NT>(g, b_t, tm2);
+        const CV<NT> uu = cadd<NT>(cadd<NT>(Jp, mv_t<NT>(g, r1_t, c2r<NT>(g, J1m))), cadd<NT>(a_j1m, X1));
+        Jpn = cadd<NT>(cadd<NT>(J1p, mv_t<NT>(g, ttgp1_t, c2r<NT>(g, uu))), b1);                 // new ieJ0+
+        const CV<NT> rv2 = mv_t<NT>(g, r1_t, c2r<NT>(g, Jpn));                                   // r1 ieJ0+(new)
+        const CV<NT> u2 = cadd<NT>(cadd<NT>(J1m, rv2), cadd<NT>(a_jp, X2));
+        Jmn = cadd<NT>(cadd<NT>(Jm, mv_t<NT>(g, ttgp1_t, c2r<NT>(g, u2))), b2);                  // new ieJ0-
+        if (sgnD && scomp(g.col(0), n, a.strict_idx) > 2) Jmn.c[0] = -Jmn.c[0];
+      }
+      MOMR_STAMP_NW(14);  // source vectors
+      // ---- operators                                                                                          :98-125
+      const Mat<NT> b_c = transpose<NT>(g, b_t);
+      const Mat<NT> Y_c = TN<NT>(g, X_t, gt0_c);                                // X G t[n0]
+      const Mat<NT> W_c = add<NT>(b_c, Y_c);
+      Mat<NT> bn_t = TNacc<NT>(g, gt0_c, b_t, TN<NT>(g, W_c, ttgp1_t));         // tG (iet + Y) + iet G t[n0]
+      const Mat<NT> bn_c = transpose<NT>(g, bn_t);
+      const Mat<NT> V_c = add<NT>(bn_c, Y_c);
+      MOMR_STAMP_NW(15);  // iet: 2 transposes, 3 products
+      const Mat<NT> Q_t = TNacc<NT>(g, a_c, ttgp1_t, TN<NT>(g, gr0_c, bn_t));  // iet(new) G r[n0] + tG ier
+      Mat<NT> an_t = add<NT>(a_t, TNacc<NT>(g, t0_c, Q_t, TN<NT>(g, V_c, ttgpr1_t)));
+      if (sgnD) map_t<NT>(g, an_t, [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; });
+      an_d = an_t; bn_d = bn_t; Jpn_d = Jpn; Jmn_d = Jmn; o4_d = o4; o3_d = o3; have_d = true;
+      MOMR_STAMP_NW(16);  // ier: 4 products (waits for the two late operands)
+    }
+    flush();
   }
 }
 
 // The kernel images: the one-tile form at MOMR_WPE waves per SIMD (256 registers), the 2 x 2-tile form at MOMR_WPE2 (its ~320
 // live registers spill to scratch at 256; at one wave per SIMD the register file holds them)
 template <bool FUSE, int MODE>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair1(KArgs a) { dbl_pair_body<1, FUSE, MODE>(a); }
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_dbl_pair1(KArgs a) {
+  if constexpr (MOMR_LDSPF != 0) dbl_pair_body1<FUSE, MODE>(a);
+  else dbl_pair_body<1, FUSE, MODE>(a);
+}
 template <bool FUSE, int MODE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_dbl_pair2(KArgs a) { dbl_pair_body<2, FUSE, MODE>(a); }
 // 32 < N <= 64 (r4): the same bodies on 3 x 3 and 4 x 4 tiles.  Nine / sixteen tiles per operator do not fit the register file
@@ -1352,9 +1642,21 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
     LAUNCH_NT(s, k_dbl_point, 1, grid_points(s), a);
     RCHK(tick(s, TK_DBL_PAIR, true));
     {
-      const dim3 gr(grid_pairs(s));
+      dim3 gr(grid_pairs(s));
+      size_t lds1 = lds<1>();
+      if (MOMR_LDSPF != 0 && s->N <= 16) {
+        // work items (n1, chunk of Raman offsets) of dbl_pair_body1: about eight items per resident wave (3 per SIMD), so that
+        // the n1-side operands are loaded once per ~nR / nch pairs and the tail of the launch stays short
+        static const int ipw = getenv("MOMR_ITEMS_PER_WAVE") ? atoi(getenv("MOMR_ITEMS_PER_WAVE")) : 8;  // (experiments)
+        const size_t span = (size_t)(s->n1_hi - s->n1_lo), want = (size_t)std::max(ipw, 1) * 3 * 4 * 256;
+        const size_t nch = std::max<size_t>(1, std::min<size_t>((size_t)s->nR, (want + span - 1) / std::max<size_t>(span, 1)));
+        a.dn_chunk = std::min(64, (int)(((size_t)s->nR + nch - 1) / nch));  // the offsets of a chunk live in the lanes of a wave
+        const size_t items = span * (((size_t)s->nR + a.dn_chunk - 1) / a.dn_chunk);
+        gr = dim3((unsigned)std::max<size_t>(1, std::min<size_t>((items + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 16)));
+        lds1 = (size_t)kWavesPerBlock * (slice_bytes<1>() + kPfBytes);
+      }
       const int mode = s->strict_rrs ? 2 : (a.last ? 1 : 0);
-#define DBL_PAIR(NT_, FUSE_, MODE_) RCHK(launch_lds(k_dbl_pair##NT_<FUSE_, MODE_>, gr, lds<NT_>(), s->stream, a))
+#define DBL_PAIR(NT_, FUSE_, MODE_) RCHK(launch_lds(k_dbl_pair##NT_<FUSE_, MODE_>, gr, (NT_ == 1) ? lds1 : lds<NT_>(), s->stream, a))
 #define DBL_PAIR_M(NT_, FUSE_) do { if (mode == 0) DBL_PAIR(NT_, FUSE_, 0); else if (mode == 1) DBL_PAIR(NT_, FUSE_, 1); else DBL_PAIR(NT_, FUSE_, 2); } while (0)
 #define DBL_PAIR_F(NT_) do { if (a.fuse_el) DBL_PAIR_M(NT_, true); else DBL_PAIR_M(NT_, false); } while (0)
       if (s->N <= 16) DBL_PAIR_F(1);
@@ -1539,3 +1841,14 @@ hipError_t postprocess(State *s, const Streams &q, int m, int nVza, const int *d
 
 }  // namespace momr
 #endif  // MOMR_BIG_TU
+
+#if defined(MOMR_DIAG_STAMPS) && !defined(MOMR_BIG_TU)
+extern "C" int momr_diag_read(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(momr::momr_diag_acc), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(momr::momr_diag_acc), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
