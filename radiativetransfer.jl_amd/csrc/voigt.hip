@@ -31,6 +31,21 @@ __constant__ double kW32A[32] = {
     -5.2310170266050247e-10, 4.1537465934749353e-10,  1.1658312885903929e-10,  -5.5441820344468828e-11,
     -2.1542618451370239e-11, 8.0314997274316680e-12,  3.7424975634801558e-12,  -1.3031797863050087e-12};
 
+// 1 / d and n / d for d in a range where neither scaling nor special cases are needed (here 22 <= d <= 1e60): v_rcp_f64
+// refined by two Newton steps, the quotient by one residual step -- 8 instructions instead of the 12 of the IEEE division
+// sequence (2 v_div_scale, v_div_fmas, v_div_fixup around the same Newton steps).  The result is within 1 ulp of the correctly
+// rounded quotient (2e-16 relative, inside the 1e-13 parity bar of tests/test_gpu_voigt.py).
+__device__ __forceinline__ double rcp_refined(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double div_refined(double n, double d) {
+  const double r = rcp_refined(d), q = n * r;
+  return fma(fma(-d, q, n), r, q);
+}
+
 __device__ __forceinline__ double w_hw32sd_re(double x, double y) {
   const double rsp = 0.5641895835477563;  // 1/sqrt(pi)
   if (fabs(x) + y >= 8.0) {               // humlicek2, t = y - i x
@@ -42,14 +57,14 @@ __device__ __forceinline__ double w_hw32sd_re(double x, double y) {
     den.re += 0.75;
     // only the real part of num/den is needed: one division (|den| ~ |t|^4 >= 4e3 here and < 1e30 for any
     // line/grid distance in cm^-1 units, so the squares neither overflow nor underflow)
-    return (num.re * den.re + num.im * den.im) / (den.re * den.re + den.im * den.im);
+    return div_refined(num.re * den.re + num.im * den.im, den.re * den.re + den.im * den.im);
   }
   const double L = 4.756828460010884;  // sqrt(32/sqrt(2))
   const cplx lpiz = {L - y, x}, lmiz = {L + y, -x};
   // 1 / (L - i z) = conj / |.|^2: ONE division and no branch (Julia's complex division, complex.jl, is Smith's
   // branching three-division scheme; |L - i z|^2 lies in [22, 200] here, so the plain form differs from it by rounding
   // only -- a few 1e-16 relative, inside the 1e-13 parity bar -- and a wave no longer executes both branches)
-  const double inv = 1.0 / (lmiz.re * lmiz.re + lmiz.im * lmiz.im);
+  const double inv = rcp_refined(lmiz.re * lmiz.re + lmiz.im * lmiz.im);
   const cplx rec = {lmiz.re * inv, -lmiz.im * inv};
   const cplx Z = cmul(lpiz, rec);
   cplx p = {kW32A[31], 0.0};
@@ -77,7 +92,7 @@ __device__ __forceinline__ void voigt_block(int nLines, const double *__restrict
   // per-line constants of the candidates, staged once per workgroup: centre, S c/gamma_d, c'/gamma_d, y and the
   // 0-based window -- the two divisions by gamma_d are per LINE here, not per evaluation (same expressions, same values)
   __shared__ double c_nu[kBlock], c_a[kBlock], c_b[kBlock], c_y[kBlock];
-  __shared__ int c_lo[kBlock], c_hi[kBlock];
+  __shared__ int2 c_win[kBlock];  // {first point, last - first} of the window: ONE read and ONE unsigned compare per candidate
   __shared__ int wcount[kBlock / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g0 = blockIdx.x * kBlock;             // 0-based first grid index of this block
@@ -125,7 +140,7 @@ __device__ __forceinline__ void voigt_block(int nLines, const double *__restrict
     if (j <= jhi) {
       lo = i0[j] - 1;
       hi = i1[j] - 1;
-      hit = (lo <= g1) && (hi >= g0);
+      hit = (lo <= g1) && (hi >= g0) && (hi >= lo);
     }
     const unsigned long long mask = __ballot(hit);
     if (lane == 0) wcount[wave] = __popcll(mask);
@@ -139,16 +154,33 @@ __device__ __forceinline__ void voigt_block(int nLines, const double *__restrict
       c_a[pos] = S[j] * cSqrtLn2divSqrtPi / gd;
       c_b[pos] = cSqrtLn2 / gd;
       c_y[pos] = y[j];
-      c_lo[pos] = lo;
-      c_hi[pos] = hi;
+      c_win[pos] = make_int2(lo, hi - lo);  // hi >= lo for a hit
     }
     int nc = 0;
 #pragma unroll
     for (int w = 0; w < kBlock / 64; ++w) nc += wcount[w];
+    nc = __builtin_amdgcn_readfirstlane(nc);  // workgroup-uniform: scalar loop control
     __syncthreads();
+    // r5 (0.37 -> 0.40 of the vector peak, profiles/r05_voigt_ab.txt): the window as ONE LDS read and one unsigned compare
+    // (r4: first point, last point and then the four doubles in three dependent round trips, each behind its own exec-masked
+    // region); the evaluation is skipped only when the WHOLE wavefront lies outside the window; the quotient of the Humlicek
+    // branch by the refined reciprocal.  Measured and NOT shipped: two / four grid points per thread (0.39 / 0.34: the two
+    // evaluations of a thread do not overlap better than two wavefronts do, and the core workload loses its early exits), a
+    // straight-line two-point Humlicek path, the strided range pass instead of the bisection for short line lists.
+    const int gt = (gi < nGrid) ? gi : -1;  // a point past the end of the grid lies in no window: (unsigned)(-1 - lo) > any span
+#ifndef MOM_VOIGT_DIAG_NOEVAL
     for (int c = 0; c < nc; ++c) {
-      if (gi >= c_lo[c] && gi <= c_hi[c] && gi < nGrid) acc += c_a[c] * w_hw32sd_re(c_b[c] * (gx - c_nu[c]), c_y[c]);
+      const int2 win = c_win[c];
+      const double cn = c_nu[c], ca = c_a[c], cb = c_b[c], cy = c_y[c];
+      const bool in = (unsigned)(gt - win.x) <= (unsigned)win.y;
+      if (__builtin_amdgcn_ballot_w64(in) == 0) continue;
+      const double w = w_hw32sd_re(cb * (gx - cn), cy);
+      if (in) acc = fma(ca, w, acc);   // acc += a w, one rounding as before
     }
+#else
+    (void)gt;
+    if (nc > 0) acc += c_a[nc - 1] + c_nu[0] + c_b[0] + c_y[0] + c_win[0].x;   // (diagnostic build: the setup without the evaluations)
+#endif
     __syncthreads();
   }
   // accumulate: tau_abs[:, iz] += sigma * (vcd_dry[iz] * vmr)  (atmo_prof.jl:446), fused into the line-shape kernel
@@ -197,14 +229,38 @@ thread_local double v_last_ms = 0.0;
 // kernel arguments.  Same expression order as the host route (absorption.line_prefactors); exp / pow come from the
 // device math library, so the two routes agree to a few ulp, not bitwise.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double spline_eval(const double *t, const double *u, const double *z, int n1, double x) {
-  // DataInterpolations.CubicSpline evaluation (restated in absorption.CubicSpline.__call__): interval by searchsortedlast
-  int lo = 0, hi = n1;  // knots t[0 .. n1]
+// searchsortedlast restricted to [0, n - 2]: the interval lo with a[lo] <= x < a[lo + 1] (lo = 0 below a[0], n - 2 from a[n - 1]
+// on) of an ascending table a[0 .. n - 1].  r5: a guess from the mean spacing of a[first .. n - 1] and a walk of at most three
+// steps replace the bisection wherever the table is (nearly) uniform -- the wavenumber grid always, the TIPS temperature
+// knots from the second one on: two dependent memory latencies instead of log2(n).  k_line_prefactors_profile ran 76 dependent
+// loads per thread (four window indices on a 22 801-point grid, two spline intervals on 251 knots): 23 us of the operating
+// point's 132 us.  Any other table falls through to the bisection; the interval, hence every value computed from it, is the
+// same either way.
+__device__ __forceinline__ int locate_interval(const double *a, int n, double x, int first) {
+  if (n < 2) return 0;
+  const double a0 = a[first], a1 = a[n - 1];
+  if (n - 1 > first && a1 > a0) {
+    const double g = (x - a0) * ((double)(n - 1 - first) / (a1 - a0));
+    int lo = first + (int)fmin(fmax(g, 0.0), (double)(n - 2 - first));
+#pragma unroll 1
+    for (int k = 0; k < 3; ++k) {
+      if (a[lo] > x) { if (lo == 0) break; --lo; }
+      else if (a[lo + 1] <= x) { if (lo == n - 2) break; ++lo; }
+      else break;
+    }
+    const bool below = (lo == 0 && x < a[0]), above = (lo == n - 2 && a[n - 1] <= x);
+    if (below || above || (a[lo] <= x && x < a[lo + 1])) return lo;
+  }
+  int lo = 0, hi = n - 1;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (t[mid] <= x) lo = mid; else hi = mid;
+    if (a[mid] <= x) lo = mid; else hi = mid;
   }
-  const int i = min(max(lo, 0), n1 - 1);
+  return lo;
+}
+__device__ __forceinline__ double spline_eval(const double *t, const double *u, const double *z, int n1, double x) {
+  // DataInterpolations.CubicSpline evaluation (restated in absorption.CubicSpline.__call__): interval by searchsortedlast
+  const int i = min(max(locate_interval(t, n1 + 1, x, n1 >= 2 ? 1 : 0), 0), n1 - 1);  // knots t[0 .. n1]
   // the tables are Float32 (TIPS_2017.nc); products of two table entries are Float32 operations, as in the reference's
   // (and the host route's) evaluation -- only the terms that involve the Float64 argument x are Float64
   const float hf = (float)t[i + 1] - (float)t[i];
@@ -223,11 +279,7 @@ __device__ __forceinline__ double interp_index(const double *grid, int n, double
   if (n == 1) return 1.0;
   if (x < grid[0] || x > grid[n - 1]) return fill;
   if (x == grid[n - 1]) return (double)n;
-  int lo = 0, hi = n - 1;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (grid[mid] <= x) lo = mid; else hi = mid;
-  }
+  const int lo = locate_interval(grid, n, x, 0);
   const double slope = 1.0 / (grid[lo + 1] - grid[lo]);
   return slope * (x - grid[lo]) + (double)(lo + 1);
 }
