@@ -1246,8 +1246,168 @@ __device__ __forceinline__ void int_pair_body(const KArgs &a, int iface) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// r5: ScatteringInterface_11 of the one-tile interaction pair kernel in the form of dbl_pair_body1 -- work items (n1, chunk of
+// offsets) with the four n1-side tiles T01, r, T21, R+-[n1] resident in registers, the pair's first six operand tiles (ier-+,
+// iet-- / iet++, ieR+-, ieT++ of the pair, R+-[n0], T++[n0]) and its eight source vectors prefetched into LDS while the
+// previous pair is computed (one global_load_lds per 1 KB), the on-grid pairs of the chunk as a scalar bit mask, the last two
+// operator stores deferred to the top of the next pair.  The ten late operand tiles are loaded where they are used, as in
+// int_pair_body.  The other interface cases (and -DMOMR_LDSPF=0) run int_pair_body<1, ..>.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kPfIntDoubles = 6 * kPfTile + 8 * 16;      // 13 312 B per wave
+constexpr size_t kPfIntBytes = (size_t)kPfIntDoubles * 8;
+
 template <bool SURF, bool DERIVE>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair1(KArgs a, int iface) { int_pair_body<1, SURF, DERIVE>(a, iface); }
+__device__ __forceinline__ void int_pair_body1(const KArgs &a) {
+  constexpr int NT = 1;
+  const Geo g = make_geo<NT>(a.N, rrs_smem);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t NN = 256, VS = 16;
+  double *pf = reinterpret_cast<double *>(rrs_smem + (size_t)kWavesPerBlock * slice_bytes<NT>()) + (size_t)wave * kPfIntDoubles;
+  double *pfA = pf, *pfBm = pf + kPfTile, *pfE = pf + 2 * kPfTile, *pfC = pf + 3 * kPfTile, *pfRpm0 = pf + 4 * kPfTile,
+         *pfTpp0 = pf + 5 * kPfTile, *pfV = pf + 6 * kPfTile;
+  const int span = a.n1_hi - a.n1_lo, CH = a.dn_chunk, nch = (a.nR + CH - 1) / CH;
+  const unsigned items = (unsigned)span * (unsigned)nch, istride = gridDim.x * kWavesPerBlock;
+  auto flip_pm = [&](Mat<NT> X) {  // ier+- = sgn (.) ier-+, iet-- = sgn (.) iet++ (corrected D2)
+    if (a.nS > 1)
+      map_t<NT>(g, X, [&](int i, int j, double v) { return dsgn(scomp(i, a.nS, a.strict_idx), scomp(j, a.nS, a.strict_idx)) * v; });
+    return X;
+  };
+
+  for (unsigned w = blockIdx.x * kWavesPerBlock + wave; w < items; w += istride) {
+    const int ch = (int)(w / (unsigned)span), n1 = a.n1_lo + (int)(w - (unsigned)ch * (unsigned)span);
+    const int dn_lo = ch * CH, dn_hi = (dn_lo + CH < a.nR) ? dn_lo + CH : a.nR;
+    const size_t m1 = NN * n1;
+    const Mat<NT> T01_t = load_t<NT>(g, a.sm[SI_T01] + m1), r1_t = load_t<NT>(g, a.x[R_MP] + m1);
+    const Mat<NT> T21_t = load_t<NT>(g, a.sm[SI_T21] + m1), Rpm1_t = load_t<NT>(g, a.c_cur[C_R_PM] + m1);
+    const int cnt = dn_hi - dn_lo;
+    const int off_l = (lane < cnt) ? a.off[dn_lo + lane] : 0;
+    const unsigned long long gmask = __builtin_amdgcn_ballot_w64(lane < cnt && n1 + off_l >= 0 && n1 + off_l < a.S);
+    auto off_of = [&](int dn) { return __builtin_amdgcn_readlane(off_l, dn - dn_lo); };
+    auto next_on_grid = [&](int dn) {
+      const int k = dn + 1 - dn_lo;
+      const unsigned long long rest = (k < 64) ? (gmask >> k) : 0ull;
+      return rest ? dn + 1 + (int)__builtin_ctzll(rest) : dn_hi;
+    };
+    auto prefetch = [&](int dn) {
+      const int n0 = n1 + off_of(dn);
+      const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = VS * u, m0 = NN * n0, v0 = VS * n0;
+      if (!SURF) {
+        pf_tile(a.ie_a[R_MP] + o4, pfA, lane);
+        pf_tile(a.ie_a[DERIVE ? T_PP : T_MM] + o4, pfBm, lane);
+      }
+      pf_tile(a.ie_c[C_R_PM] + o4, pfE, lane);
+      pf_tile(a.ie_c[C_T_PP] + o4, pfC, lane);
+      pf_tile(a.sm[SI_RPM] + m0, pfRpm0, lane);
+      pf_tile(a.sm[SI_TPP] + m0, pfTpp0, lane);
+      // eight vectors of 16 doubles in one instruction: ieJ0+, ieJ0- (added), ieJ0+, ieJ0- (composite), J0+[n0], G1 v[n0],
+      // j0-[n0] of the added layer, G2 v[n0]
+      const int q = lane >> 3;
+      const double *vp = (q == 0) ? a.ie_a[J0P] + o3 : (q == 1) ? a.ie_a[J0M] + o3 : (q == 2) ? a.ie_c[C_J0P] + o3
+                       : (q == 3) ? a.ie_c[C_J0M] + o3 : (q == 4) ? a.c_cur[C_J0P] + v0 : (q == 5) ? a.sv[SVI_G1V] + v0
+                       : (q == 6) ? a.x[J0M] + v0 : a.sv[SVI_G2V] + v0;
+      if (!(SURF && q < 2))
+        __builtin_amdgcn_global_load_lds((momr_gptr *)(vp + 2 * (lane & 7)), (momr_lptr *)pfV, 16, 0, 0);
+    };
+    // the last two operator blocks of the previous pair, stored at the top of the next one
+    Mat<NT> Cn_d, En_d;
+    size_t o4_d = 0;
+    bool have_d = false;
+    auto flush = [&]() {
+      if (!have_d) return;
+      store_t<NT>(g, a.ie_c[C_T_PP] + o4_d, Cn_d);
+      store_t<NT>(g, a.ie_c[C_R_PM] + o4_d, En_d);
+      have_d = false;
+    };
+    int dn_pf = next_on_grid(dn_lo - 1);
+    if (dn_pf < dn_hi) prefetch(dn_pf);
+    for (int dn = dn_pf; dn < dn_hi; dn = dn_pf) {
+      const int n0 = n1 + off_of(dn);
+      const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = VS * u, m0 = NN * n0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const Mat<NT> a_t = SURF ? zeros<NT>() : lds_tile(g, pfA);
+      const Mat<NT> bm_raw = SURF ? zeros<NT>() : lds_tile(g, pfBm);
+      const Mat<NT> E_t = lds_tile(g, pfE), C_t = lds_tile(g, pfC);
+      const Mat<NT> Rpm0_c = lds_tile(g, pfRpm0), Tpp0_c = lds_tile(g, pfTpp0);
+      CV<NT> Jap, Jam, Jcp, Jcm;
+      Jap.c[0] = SURF ? 0.0 : pfV[g.lr]; Jam.c[0] = SURF ? 0.0 : pfV[16 + g.lr];
+      Jcp.c[0] = pfV[32 + g.lr]; Jcm.c[0] = pfV[48 + g.lr];
+      Vec<NT> JcpR, JamR, J0pR, g1vR, j0mR, g2vR;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = g.lq + 4 * r;
+        JamR.t[0][r] = SURF ? 0.0 : pfV[16 + k];
+        JcpR.t[0][r] = pfV[32 + k];
+        J0pR.t[0][r] = pfV[64 + k];
+        g1vR.t[0][r] = pfV[80 + k];
+        j0mR.t[0][r] = pfV[96 + k];
+        g2vR.t[0][r] = pfV[112 + k];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      dn_pf = next_on_grid(dn);
+      if (dn_pf < dn_hi) prefetch(dn_pf);
+      flush();
+
+      Mat<NT> bm_t = bm_raw;
+      if (DERIVE && !SURF) bm_t = flip_pm(bm_t);
+      const Mat<NT> a_c = transpose<NT>(g, a_t), bm_c = transpose<NT>(g, bm_t);
+      const Mat<NT> E_c = transpose<NT>(g, E_t), C_c = transpose<NT>(g, C_t);
+      // A = T01 (ier R+-[n0] + r ieR+-) + ieT--                                                                  :252-262
+      const Mat<NT> M1_c = TNacc<NT>(g, r1_t, E_c, TN<NT>(g, a_t, Rpm0_c));
+      const Mat<NT> A_t = TNacc<NT>(g, M1_c, T01_t, load_t<NT>(g, a.ie_c[C_T_MM] + o4));
+      // ieJ0- += T01 (ier J0+[n0] + r ieJ0+ + ieJ0-(added)) + A G1 (j0-[n0] + r[n0] J0+[n0])                      :251-264
+      {
+        const CV<NT> v1 = mv_t<NT>(g, a_t, J0pR);
+        const CV<NT> v2 = mv_t<NT>(g, r1_t, JcpR);
+        const CV<NT> uu = cadd<NT>(cadd<NT>(v1, v2), Jam);
+        const CV<NT> wv = cadd<NT>(mv_t<NT>(g, T01_t, c2r<NT>(g, uu)), mv_t<NT>(g, A_t, g1vR));
+        storeC<NT>(g, a.ie_c[C_J0M] + o3, cadd<NT>(Jcm, wv));
+      }
+      // ieR-+ += T01 (ier T++[n0] + r ieT++) + A G1 r[n0] T++[n0];  ieT-- = T01 iet-- + A G1 t--[n0]               :271-284
+      {
+        const Mat<NT> N1_c = TNacc<NT>(g, r1_t, C_c, TN<NT>(g, a_t, Tpp0_c));
+        Mat<NT> Rm_t = load_t<NT>(g, a.ie_c[C_R_MP] + o4);
+        Rm_t = TNacc<NT>(g, N1_c, T01_t, Rm_t);
+        Rm_t = TNacc<NT>(g, load_t<NT>(g, a.sm[SI_G1RT] + m0), A_t, Rm_t);
+        store_t<NT>(g, a.ie_c[C_R_MP] + o4, Rm_t);
+        const Mat<NT> F_t = TNacc<NT>(g, load_t<NT>(g, a.sm[SI_G1T] + m0), A_t, TN<NT>(g, bm_c, T01_t));
+        store_t<NT>(g, a.ie_c[C_T_MM] + o4, F_t);
+      }
+      // B = T21 (ieR+- r[n0] + R+- ier) + iet++                                                                   :302-310
+      const Mat<NT> M2_c = TNacc<NT>(g, Rpm1_t, a_c, TN<NT>(g, E_t, load_t<NT>(g, a.sm[SI_R] + m0)));
+      // iet++ of the added layer: with DERIVE the block just read as iet-- IS iet++ (before the sign flip)
+      const Mat<NT> b_t = SURF ? zeros<NT>() : (DERIVE ? bm_raw : load_t<NT>(g, a.ie_a[T_PP] + o4));
+      const Mat<NT> B_t = TNacc<NT>(g, M2_c, T21_t, b_t);
+      // ieJ0+ = ieJ0+(added) + T21 (ieJ0+ + ieR+- j0-[n0] + R+- ieJ0-(added)) + B G2 (J0+[n0] + R+-[n0] j0-[n0])    :301-312
+      {
+        const CV<NT> v3 = mv_t<NT>(g, E_t, j0mR);
+        const CV<NT> v4 = SURF ? czeros<NT>() : mv_t<NT>(g, Rpm1_t, JamR);
+        const CV<NT> uu = cadd<NT>(cadd<NT>(Jcp, v3), v4);
+        const CV<NT> wv = cadd<NT>(mv_t<NT>(g, T21_t, c2r<NT>(g, uu)), mv_t<NT>(g, B_t, g2vR));
+        storeC<NT>(g, a.ie_c[C_J0P] + o3, cadd<NT>(Jap, wv));
+      }
+      // ieT++ = T21 ieT++ + B G2 T++[n0];  ieR+- = ier+- + T21 (ieR+- t--[n0] + R+- iet--) + B G2 R+-[n0] t--[n0]   :320-334
+      {
+        Cn_d = TNacc<NT>(g, load_t<NT>(g, a.sm[SI_G2T] + m0), B_t, TN<NT>(g, C_c, T21_t));
+        const Mat<NT> N2_c = TNacc<NT>(g, Rpm1_t, bm_c, TN<NT>(g, E_t, load_t<NT>(g, a.sm[SI_TMM] + m0)));
+        // ier+- of the added layer: with DERIVE the sign-flipped ier-+
+        Mat<NT> En_t = SURF ? zeros<NT>() : (DERIVE ? flip_pm(a_t) : load_t<NT>(g, a.ie_a[R_PM] + o4));
+        En_t = TNacc<NT>(g, N2_c, T21_t, En_t);
+        En_d = TNacc<NT>(g, load_t<NT>(g, a.sm[SI_G2RT] + m0), B_t, En_t);
+        o4_d = o4; have_d = true;
+      }
+    }
+    flush();
+  }
+}
+
+template <bool SURF, bool DERIVE>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR k_int_pair1(KArgs a, int iface) {
+  if (MOMR_LDSPF != 0 && iface == 3) int_pair_body1<SURF, DERIVE>(a);
+  else int_pair_body<1, SURF, DERIVE>(a, iface);
+}
 template <bool SURF, bool DERIVE>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) MOMR_PAIR_ATTR2 k_int_pair2(KArgs a, int iface) { int_pair_body<2, SURF, DERIVE>(a, iface); }
 #ifdef MOMR_BIG_TU
@@ -1447,6 +1607,24 @@ static hipError_t dm(T **p, size_t count) {
   if (e == hipSuccess) e = hipMemset(*p, 0, count * sizeof(T));
   return e;
 }
+// Layer arrays sit between two GUARD BANDS of kGuard doubles filled with a canary pattern (r5, ADVICE r4: the kernels store whole
+// tiles without edge masks; the zero-padding invariant only sees writes that land INSIDE an array).  count_padding checks the
+// bands of every array too: a store before the first or behind the last block of any layer array shows up as a violation
+// (tests/test_gpu_rrs.py::test_rrs_zero_padding_invariant, N = 15 ... 60, both switch positions).
+constexpr size_t kGuard = 2048;               // doubles per band (16 KB: more than a 4 x 4-tile block row)
+constexpr unsigned kCanary = 0xDEADBEEFu;     // both halves of a canary double
+static hipError_t dmg(State *s, double **p, size_t count) {
+  double *base = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&base), (count + 2 * kGuard) * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(base + kGuard, 0, count * sizeof(double));
+  if (e == hipSuccess) e = hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(base), (int)kCanary, 2 * kGuard);
+  if (e == hipSuccess) e = hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(base + kGuard + count), (int)kCanary, 2 * kGuard);
+  if (e != hipSuccess) { (void)hipFree(base); return e; }
+  *p = base + kGuard;
+  s->guarded.emplace_back(*p, count);
+  return hipSuccess;
+}
+static void dfreeg(double *p) { if (p) (void)hipFree(p - kGuard); }
 
 hipError_t create(State **out, hipStream_t st, int N, int nS, int S, int nR, const int *off_host, const double *varpi_host,
                   int strict_rrs) {
@@ -1464,20 +1642,20 @@ hipError_t create(State **out, hipStream_t st, int N, int nS, int S, int nR, con
   for (int b = 0; b < 2; ++b) {
     for (int k = 0; k < 6; ++k) {
       if (b == 1 && (k == R_PM || k == T_MM)) continue;
-      RCHK(dm(&s->added[b][k], k < 4 ? m3 : v3));
+      RCHK(dmg(s, &s->added[b][k], k < 4 ? m3 : v3));
     }
-    for (int k = 0; k < 6; ++k) RCHK(dm(&s->comp[b][k], k < 4 ? m3 : v3));
-    RCHK(dm(&s->expk[b], S));
+    for (int k = 0; k < 6; ++k) RCHK(dmg(s, &s->comp[b][k], k < 4 ? m3 : v3));
+    RCHK(dmg(s, &s->expk[b], S));
   }
   s->added[1][R_PM] = s->added[0][R_PM];
   s->added[1][T_MM] = s->added[0][T_MM];
-  for (int k = 0; k < 6; ++k) RCHK(dm(&s->surf[k], k < 4 ? m3 : v3));
-  for (int k = 0; k < 10; ++k) RCHK(dm(&s->smat[k], m3));
-  for (int k = 0; k < 6; ++k) RCHK(dm(&s->svec[k], v3));
-  if (strict_rrs) RCHK(dm(&s->jpseq, v4));
+  for (int k = 0; k < 6; ++k) RCHK(dmg(s, &s->surf[k], k < 4 ? m3 : v3));
+  for (int k = 0; k < 10; ++k) RCHK(dmg(s, &s->smat[k], m3));
+  for (int k = 0; k < 6; ++k) RCHK(dmg(s, &s->svec[k], v3));
+  if (strict_rrs) RCHK(dmg(s, &s->jpseq, v4));
   for (int k = 0; k < 6; ++k) {
-    RCHK(dm(&s->ie_added[k], k < 4 ? m4 : v4));
-    RCHK(dm(&s->ie_comp[k], k < 4 ? m4 : v4));
+    RCHK(dmg(s, &s->ie_added[k], k < 4 ? m4 : v4));
+    RCHK(dmg(s, &s->ie_comp[k], k < 4 ? m4 : v4));
   }
   RCHK(dm(&s->d_info, 1));
   return hipSuccess;
@@ -1514,16 +1692,8 @@ hipError_t download(State *s, double *host, const double *dev, bool matrix, size
 void destroy(State *s) {
   if (!s) return;
   (void)hipFree(s->d_stage);
-  (void)hipFree(s->d_off); (void)hipFree(s->d_varpiR); (void)hipFree(s->jpseq); (void)hipFree(s->d_out); (void)hipFree(s->d_info);
-  for (int b = 0; b < 2; ++b) {
-    for (int k = 0; k < 6; ++k) {
-      if (!(b == 1 && (k == R_PM || k == T_MM))) (void)hipFree(s->added[b][k]);
-      (void)hipFree(s->comp[b][k]);
-    }
-    (void)hipFree(s->expk[b]);
-  }
-  for (int k = 0; k < 6; ++k) { (void)hipFree(s->surf[k]); (void)hipFree(s->svec[k]); (void)hipFree(s->ie_added[k]); (void)hipFree(s->ie_comp[k]); }
-  for (int k = 0; k < 10; ++k) (void)hipFree(s->smat[k]);
+  (void)hipFree(s->d_off); (void)hipFree(s->d_varpiR); (void)hipFree(s->d_out); (void)hipFree(s->d_info);
+  for (auto &g : s->guarded) dfreeg(g.first);   // every layer array (added, comp, expk, surf, smat, svec, jpseq, ie_added, ie_comp)
   for (auto e : s->ev_pool) (void)hipEventDestroy(e);
   delete s;
 }
@@ -1645,9 +1815,9 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
       dim3 gr(grid_pairs(s));
       size_t lds1 = lds<1>();
       if (MOMR_LDSPF != 0 && s->N <= 16) {
-        // work items (n1, chunk of Raman offsets) of dbl_pair_body1: about eight items per resident wave (3 per SIMD), so that
+        // work items (n1, chunk of Raman offsets) of dbl_pair_body1: about four items per resident wave, so that
         // the n1-side operands are loaded once per ~nR / nch pairs and the tail of the launch stays short
-        static const int ipw = getenv("MOMR_ITEMS_PER_WAVE") ? atoi(getenv("MOMR_ITEMS_PER_WAVE")) : 8;  // (experiments)
+        static const int ipw = getenv("MOMR_ITEMS_PER_WAVE") ? atoi(getenv("MOMR_ITEMS_PER_WAVE")) : 4;  // (experiments)
         const size_t span = (size_t)(s->n1_hi - s->n1_lo), want = (size_t)std::max(ipw, 1) * 3 * 4 * 256;
         const size_t nch = std::max<size_t>(1, std::min<size_t>((size_t)s->nR, (want + span - 1) / std::max<size_t>(span, 1)));
         a.dn_chunk = std::min(64, (int)(((size_t)s->nR + nch - 1) / nch));  // the offsets of a chunk live in the lanes of a wave
@@ -1726,12 +1896,23 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
     RCHK(hipMemsetAsync(s->ie_comp[C_J0M], 0, v4, s->stream));
   } else {
     RCHK(tick(s, TK_INT_PAIR, true));
-    const dim3 gr(grid_pairs(s));
+    dim3 gr(grid_pairs(s));
+    size_t lds1 = lds<1>();
+    if (MOMR_LDSPF != 0 && s->N <= 16 && iface == 3) {  // int_pair_body1: (n1, chunk) items, as for the doubling pair kernel
+      static const int ipw = getenv("MOMR_ITEMS_PER_WAVE") ? atoi(getenv("MOMR_ITEMS_PER_WAVE")) : 4;
+      const size_t span = (size_t)(s->n1_hi - s->n1_lo), want = (size_t)std::max(ipw, 1) * 2 * 4 * 256;
+      const size_t nch = std::max<size_t>(1, std::min<size_t>((size_t)s->nR, (want + span - 1) / std::max<size_t>(span, 1)));
+      a.dn_chunk = std::min(64, (int)(((size_t)s->nR + nch - 1) / nch));
+      const size_t items = span * (((size_t)s->nR + a.dn_chunk - 1) / a.dn_chunk);
+      gr = dim3((unsigned)std::max<size_t>(1, std::min<size_t>((items + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 16)));
+      lds1 = (size_t)kWavesPerBlock * (slice_bytes<1>() + kPfIntBytes);
+    }
 #define INT_PAIR(NT_)                                                                                                      \
   do {                                                                                                                     \
-    if (with_surface) RCHK(launch_lds(k_int_pair##NT_<true, false>, gr, lds<NT_>(), s->stream, a, iface));                 \
-    else if (a.derive_pm) RCHK(launch_lds(k_int_pair##NT_<false, true>, gr, lds<NT_>(), s->stream, a, iface));             \
-    else RCHK(launch_lds(k_int_pair##NT_<false, false>, gr, lds<NT_>(), s->stream, a, iface));                             \
+    const size_t l_ = (NT_ == 1) ? lds1 : lds<NT_>();                                                                       \
+    if (with_surface) RCHK(launch_lds(k_int_pair##NT_<true, false>, gr, l_, s->stream, a, iface));                         \
+    else if (a.derive_pm) RCHK(launch_lds(k_int_pair##NT_<false, true>, gr, l_, s->stream, a, iface));                     \
+    else RCHK(launch_lds(k_int_pair##NT_<false, false>, gr, l_, s->stream, a, iface));                                     \
   } while (0)
     if (s->N <= 16) INT_PAIR(1);
     else if (s->N <= 32) INT_PAIR(2);
@@ -1765,6 +1946,12 @@ __global__ void k_count_padding(const double *p, int N, int P, int matrix, size_
   }
   if (mine) atomicAdd(cnt, mine);
 }
+__global__ void k_count_canary(const unsigned *p, size_t n, unsigned long long *cnt) {
+  unsigned long long mine = 0;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+    if (p[e] != kCanary) ++mine;
+  if (mine) atomicAdd(cnt, mine);
+}
 hipError_t count_padding(State *s, unsigned long long *out) {
   unsigned long long *d = nullptr;
   RCHK(hipMalloc(reinterpret_cast<void **>(&d), sizeof(unsigned long long)));
@@ -1782,6 +1969,10 @@ hipError_t count_padding(State *s, unsigned long long *out) {
     scan(s->surf[k], k < 4, S);
     scan(s->ie_added[k], k < 4, SR);
     scan(s->ie_comp[k], k < 4, SR);
+  }
+  for (auto &g : s->guarded) {
+    hipLaunchKernelGGL(k_count_canary, dim3(8), dim3(256), 0, s->stream, reinterpret_cast<const unsigned *>(g.first - kGuard), 2 * kGuard, d);
+    hipLaunchKernelGGL(k_count_canary, dim3(8), dim3(256), 0, s->stream, reinterpret_cast<const unsigned *>(g.first + g.second), 2 * kGuard, d);
   }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(out, d, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->stream);

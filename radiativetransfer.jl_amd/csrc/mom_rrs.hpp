@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace momr {
@@ -62,6 +63,7 @@ struct State {
   bool dirty = false;
   struct { int m, nd, sh; const double *tau_sum, *tau, *varpi, *fscatt, *Zr_pp, *Zr_mp; } el{};
   // HIP-event pairs around the launches of the heavy kernels of the last run (timing_reset .. timing_read)
+  std::vector<std::pair<double *, size_t>> guarded;  // layer arrays allocated between guard bands (mom_rrs.hip dmg): pointer, doubles
   std::vector<hipEvent_t> ev_pool;
   std::vector<int> ev_kind;  // kind of the launch bracketed by ev_pool[2k], ev_pool[2k+1]
   bool timing = false;

@@ -350,7 +350,9 @@ def test_rrs_empty_owned_range(rtamd):
 def test_rrs_zero_padding_invariant(rtamd, nS, lt, nv, strict):
     """The device blocks of the RRS layers are zero-padded to the MFMA tiling (16 x 16 at N <= 16, 32 x 32 above) and the kernels
     store WHOLE tiles: every stored quantity must keep the padding at exact zeros.  mom_rrs_check_padding counts
-    the violations over all layer arrays after a scene-level run (which goes through every kernel of the path)."""
+    the violations over all layer arrays after a scene-level run (which goes through every kernel of the path) -- and, r5, the
+    damaged words of the 16 KB guard bands every layer array is allocated between (mom_rrs.hip dmg): an unmasked store that lands
+    before the first or behind the last block of ANY array is a violation too, for one-tile ... 4 x 4-tile images."""
     rt = rtamd.corert
     m = rtamd.scenes.make_scene(nS, lt, 3, 26, seed=2 + nS + lt, aerosol_total=0.1, **VIEWS[nv])
     RS, _ = _rrs_inputs(rtamd, [-4, -1, 2, 7, 3], strict)

@@ -575,6 +575,7 @@ def test_surface_types(rtamd, cref, surf, nS, lt, mode):
 
 F32_ERR_RATIO = 2.5      # GPU Float32 error / oracle Float32 error, both against the Float64 oracle (measured 0.9 ... 1.34)
 F32_PAIR_ULPS = 80.0     # GPU Float32 vs oracle Float32, in units of eps32 2^nd (measured up to 51 on T at N = 6)
+F32_ABS_CEIL = 5.0e-2    # ... and never looser than this, whatever nd (80 eps32 2^nd is ~5 at nd = 20: vacuous)
 
 
 @pytest.mark.parametrize("nS,lt,surf,N,N0", [(3, 33, None, 60, 40), (3, 31, None, 57, 38), (3, 25, None, 48, 32), (4, 21, None, 56, 28),
@@ -605,7 +606,7 @@ def test_float32_m0_reduction_and_padding(rtamd, cref, nS, lt, surf, N, N0):
     assert launches[1] > launches[0]          # moment 0 ran as its own scene
     nd = int(sc.ndoubl.max())
     tol64 = 16 * 6e-8 / (1e-3 * float(m.quad_points.qp_μ.min()))
-    pair = F32_PAIR_ULPS * 6e-8 * 2.0 ** nd
+    pair = min(F32_PAIR_ULPS * 6e-8 * 2.0 ** nd, F32_ABS_CEIL)
     oR = float(np.max(np.abs(Rf - Rr) / np.maximum(np.abs(Rr[:, 0:1, :]), 1e-6 / tol64)))
     oT = float(np.max(np.abs(Tf - Tr) / np.maximum(np.abs(Tr[:, 0:1, :]), 1e-6 / tol64)))
     # the Float64 bound of test_float32_scene_level_path, widened to what the Float32 ORACLE itself loses on scenes whose
@@ -674,7 +675,7 @@ def test_float32_scene_level_path(rtamd, cref, nS, lt, kw):
     nd = int(sc.ndoubl.max())
     oR = float(np.max(np.abs(Rf - Rr) / np.maximum(np.abs(Rr[:, 0:1, :]), 1e-6 / tol)))
     oT = float(np.max(np.abs(Tf - Tr) / np.maximum(np.abs(Tr[:, 0:1, :]), 1e-6 / tol)))
-    pair = F32_PAIR_ULPS * 6e-8 * 2.0 ** nd
+    pair = min(F32_PAIR_ULPS * 6e-8 * 2.0 ** nd, F32_ABS_CEIL)
     def pair_err(X, Xf, Xref, what):   # |GPU f32 - oracle f32| relative to the view's brightest FLOAT64 intensity of the
         # spectrum (continuum-relative: a dim point's own relative error grows with its optical depth; the dim points are
         # held by (a) and by the bound against the Float64 oracle above)
@@ -713,7 +714,7 @@ def test_float32_strip_chains(rtamd, cref, nS, lt, N):
             out[inv] = rtamd.corert.run_scene(h, sc)
     nd = int(sc.ndoubl.max())
     tol64 = 16 * 6e-8 / (1e-3 * float(m.quad_points.qp_μ.min()))
-    pair = F32_PAIR_ULPS * 6e-8 * 2.0 ** nd
+    pair = min(F32_PAIR_ULPS * 6e-8 * 2.0 ** nd, F32_ABS_CEIL)
     for X, Y, Xr in ((out[0][0], out[8][0], Rr), (out[0][1], out[8][1], Tr)):
         Imax = np.abs(Xr[:, 0:1, :]).max(axis=2, keepdims=True)
         assert np.all(np.abs(X - Y) / Imax <= pair), "4-wave vs 8-wave image"
