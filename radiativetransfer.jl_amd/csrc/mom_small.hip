@@ -64,6 +64,19 @@ __device__ __forceinline__ void mulv(Vec<N> &y, const Mat<N> &A, const Vec<N> &x
   }
 }
 
+// 1 / x for a pivot: the hardware reciprocal refined by two Newton steps (within 1 ulp of the IEEE quotient, 5 instructions
+// instead of ~14; a zero pivot gives inf either way and is reported through `bad`).  Float32 build: the plain division.
+__device__ __forceinline__ real rcp_pivot(real x) {
+#ifdef MOMS_FLOAT
+  return 1.0f / x;
+#else
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#endif
+}
+
 // X = inv(I - B) by Gauss-Jordan elimination with partial (row) pivoting; the row interchange is a select, every index
 // is a compile-time constant after unrolling.  Returns 0 or k + 1 for a zero pivot at step k.
 template <int N>
@@ -104,7 +117,7 @@ __device__ __forceinline__ int inv_one_minus(Mat<N> &X, const Mat<N> &B) {
       }
     }
     if (!(best > 0.0) && !bad) bad = k + 1;
-    const real d = 1.0 / A.a[k][k];
+    const real d = rcp_pivot(A.a[k][k]);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       A.a[k][j] *= d;
@@ -121,6 +134,68 @@ __device__ __forceinline__ int inv_one_minus(Mat<N> &X, const Mat<N> &B) {
         }
       }
   }
+  return bad;
+}
+
+// X = T (I - B)^-1 without forming the inverse: Gauss-Jordan on (I - B)^T with T^T as the right-hand side (all indices are
+// compile-time constants, so the transpositions are only names) -- the elimination costs what the inverse costs, the N^3 product
+// that followed it is gone.  Partial pivoting over the columns of I - B; interchange only if some lane needs one (see above).
+template <int N>
+__device__ __forceinline__ int solve_right(Mat<N> &X, const Mat<N> &B, const Mat<N> &T) {
+  Mat<N> A, R;
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      A.a[i][j] = ((i == j) ? 1.0 : 0.0) - B.a[j][i];
+      R.a[i][j] = T.a[j][i];
+    }
+  int bad = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    real best = fabs(A.a[k][k]);
+    int p = k;
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const real v = fabs(A.a[i][k]);
+      if (v > best) { best = v; p = i; }
+    }
+    if (__builtin_amdgcn_ballot_w64(p != k) != 0) {
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) {
+        const bool sw = (p == i);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const real ak = A.a[k][j], ai = A.a[i][j], xk = R.a[k][j], xi = R.a[i][j];
+          A.a[k][j] = sw ? ai : ak;
+          A.a[i][j] = sw ? ak : ai;
+          R.a[k][j] = sw ? xi : xk;
+          R.a[i][j] = sw ? xk : xi;
+        }
+      }
+    }
+    if (!(best > 0.0) && !bad) bad = k + 1;
+    const real d = rcp_pivot(A.a[k][k]);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      A.a[k][j] *= d;
+      R.a[k][j] *= d;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (i != k) {
+        const real f = A.a[i][k];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          A.a[i][j] -= f * A.a[k][j];
+          R.a[i][j] -= f * R.a[k][j];
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) X.a[i][j] = R.a[j][i];
   return bad;
 }
 
@@ -262,9 +337,8 @@ __global__ void __launch_bounds__(256, (N >= 3) ? MOMS_WAVES_N34 : 2) k_sweep(Sw
       for (int it = 0; it < nd; ++it) {
         Mat<N> B, G, A, W;
         mul(B, r, r);
-        const int e = inv_one_minus(G, B);  // (I - r r)^-1
+        const int e = solve_right(A, B, t);  // t (I - r r)^-1: tt++_gp_refl (doubling.jl:44-48)
         if (e && !bad) bad = e;
-        mul(A, t, G);  // tt++_gp_refl
         Vec<N> j1p, j1m, v1, v2;
 #pragma unroll
         for (int i = 0; i < N; ++i) { j1p.v[i] = jp.v[i] * expk; j1m.v[i] = jm.v[i] * expk; }
@@ -357,9 +431,8 @@ __global__ void __launch_bounds__(256, (N >= 3) ? MOMS_WAVES_N34 : 2) k_sweep(Sw
         Mat<N> W1, W2, W3;
         Vec<N> v1, v2;
         mul(W1, r, Rpm);
-        int e = inv_one_minus(W2, W1);  // (I - r-+ R+-)^-1 (:81-83)
+        int e = solve_right(W3, W1, Tmm);  // T01 = T-- (I - r-+ R+-)^-1 (:81-87)
         if (e && !bad) bad = e;
-        mul(W3, Tmm, W2);               // T01 (:87)
         mulv(v1, r, Jp);
 #pragma unroll
         for (int i = 0; i < N; ++i) v1.v[i] = v1.v[i] + jm.v[i];
@@ -374,9 +447,8 @@ __global__ void __launch_bounds__(256, (N >= 3) ? MOMS_WAVES_N34 : 2) k_sweep(Sw
         dsd(W2, t);
         mul(W1, W3, W2); Tmm = W1;                                           // :96
         mul(W1, Rpm, r);
-        e = inv_one_minus(W2, W1);  // (I - R+- r-+)^-1 (:104-105)
+        e = solve_right(W3, W1, t);  // T21 = t++ (I - R+- r-+)^-1 (:104-107)
         if (e && !bad) bad = e;
-        mul(W3, t, W2);             // T21 (:107)
         mulv(v1, Rpm, jm);
 #pragma unroll
         for (int i = 0; i < N; ++i) v1.v[i] = Jp.v[i] + v1.v[i];
@@ -435,9 +507,8 @@ __global__ void __launch_bounds__(256, (N >= 3) ? MOMS_WAVES_N34 : 2) k_sweep(Sw
         Mat<N> W1, W2, W3;
         Vec<N> v1, v2;
         mul(W1, rs, Rpm);
-        int e = inv_one_minus(W2, W1);
+        int e = solve_right(W3, W1, Tmm);  // T01
         if (e && !bad) bad = e;
-        mul(W3, Tmm, W2);  // T01
         mulv(v1, rs, Jp);
 #pragma unroll
         for (int i = 0; i < N; ++i) v1.v[i] = v1.v[i] + jm.v[i];
