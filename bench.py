@@ -239,12 +239,23 @@ def elastic_leg(a, workload, S_loc, steps, warmup, world, rank, dev, dist, with_
             bytes_pt = (3 + scene.K) * scene.Nz * 8 + 3 * len(scene.node) * scene.nStokes * 8 + 2 * scene.nStokes * 8
             gbs = bytes_pt * S_loc / (tm["layers_ms"] * 1e-3) / 1e9
             ach = f_pm * M * S_loc / (tm["layers_ms"] * 1e-3) / 1e12
+            # counter traffic of the committed PMC collection next to the algorithmic bytes (the r4 kernel moved
+            # 74 x its algorithmic bytes as spill traffic while this block reported 0.006 of the HBM roof from the latter)
+            ctr = prof.get("hbm_bytes_per_launch")
+            alg_launch = bytes_pt * S_loc
+            launch_s = tm["layers_ms"] * 1e-3 / max(tm["layer_launches"], 1)
             roof = {"bound": "fp64-valu", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": prof.get("hbm_bytes_per_launch"),
-                    "kernel": "momsm::k_sweep<4> (FP64 vector FMA, no MFMA issued)",
+                    "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": ctr,
+                    "kernel": "momsm::k_sweep<4, true> + k_sum (FP64 vector FMA, one (point, moment) per lane, no MFMA issued)",
                     "avg_launch_ms": tm["layers_ms"] / max(tm["layer_launches"], 1), "launches_per_step": tm["layer_launches"],
                     "algorithmic_flop_per_avg_launch": f_pm * M * S_loc,
-                    "hbm": {"algorithmic_bytes_per_point": bytes_pt, "achieved_GBps": gbs, "frac_of_8TBps": gbs / PEAK_HBM_GBS}}
+                    "pmc_source": ("profiles/traffic.json: " + prof.get("source", prof.get("round", "?"))) if prof else None,
+                    "hbm": {"algorithmic_bytes_per_point": bytes_pt, "algorithmic_bytes_per_launch": alg_launch,
+                            "achieved_GBps": gbs, "frac_of_8TBps": gbs / PEAK_HBM_GBS,
+                            "counter_bytes_per_launch": ctr,
+                            "counter_over_algorithmic": (ctr / alg_launch) if ctr else None,
+                            "counter_GBps_at_this_run": (ctr / launch_s / 1e9) if ctr else None,
+                            "counter_frac_of_8TBps": (ctr / launch_s / 1e9 / PEAK_HBM_GBS) if ctr else None}}
         else:
             achieved = flop_dom / (tm["full_layers_ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -82,6 +82,21 @@ __global__ void __launch_bounds__(kThreads, MOM_LB_WAVES) k_layer(LayerArgs a) {
 #endif
   wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
   if constexpr (KS > 0) strip_slot_init(c);
+  if constexpr (kF64 && KS > 0) {  // the persistent stream-pair tables of the elemental layer (mom_kernels.hpp ptab_reals)
+    const int ns = a.q.regular ? a.q.nS : 1, nt = ptab_reals(N, ns), Nq = N / ns;
+    if (nt > 0) {
+      real *pt = mom_smem + lay_offset_reals(N, LDSM) + lay_cap_reals(N, LDSM);
+      for (int e = wg_tid(); e < Nq * Nq; e += kThreads) {
+        const int jq = e / Nq, iq = e - jq * Nq;
+        const real mui = c.mu[iq * ns], muj = c.mu[jq * ns];
+        pt[e] = muj / (mui + muj);
+        pt[Nq * Nq + e] = muj / (mui - muj);
+        pt[2 * Nq * Nq + e] = (1 / mui) + (1 / muj);
+      }
+      c.ptab = pt;
+      __syncthreads();
+    }
+  }
   MOM_STAMP(40);
   if (KS > 0 && kWaves == 8 && a.stagger > 0) {
     // persistent workgroups run identical units in lockstep, so every CU would store (and load) its composite

@@ -84,13 +84,15 @@ struct Ctx {
   int inv_mode;
   int qpre;  // MOM_QPREFETCH experiment: c.Q already holds the composite T++ (+ J0+ riding) for the coming interaction
   int slot;  // MOM_SIMD_AWARE experiment: the column strip this wave owns (mom_strip.hpp strip_slot)
+  const real *ptab;  // strip images (r5): F1 | F2 | SI per stream pair, built once per workgroup (nullptr: per layer, in Q)
 };
 
 __host__ __device__ inline int np_for(int N) { return 16 * ((N + 15) / 16); }
 // Row pitch of the padded operator buffers: 16 NT + 2 (ds_read_b64 of 16 columns x 2 k conflict-free: pitch / 2 odd).  One
 // exception (r4): the Float64 4-wave image of N = 44 takes N + 2 = 46 (23 odd as well) -- 76.9 instead of 82.9 KB of LDS, so that
 // TWO workgroups share a CU like the N = 36, 40 images do (no k-step of a Float64 product reads a row >= N when N % 4 = 0)
-__host__ __device__ inline int ld_for(int N) { return (kF64 && kWaves == 4 && N == 44) ? 46 : np_for(N) + 2; }
+// r5: N = 36, 40 likewise (pitch 38 / 42: 19, 21 odd) -- room for the persistent stream-pair tables next to two images per CU
+__host__ __device__ inline int ld_for(int N) { return (kF64 && kWaves == 4 && (N == 36 || N == 40 || N == 44)) ? N + 2 : np_for(N) + 2; }
 // columns actually stored per buffer: the K padding (up to the next multiple of 4) and the two riding
 // columns N, N+1; MFMA B-operand reads of the remaining columns of the last tile (< Np) run past the buffer
 // into whatever follows (finite or not, they only feed output columns that are never stored).
@@ -158,6 +160,19 @@ __host__ __device__ inline int lay_cap_reals(int N, bool lds_mats) {
   return left < (size_t)kLayTab ? (int)left : kLayTab;
 }
 __host__ __device__ inline size_t lds_bytes(int N, bool lds_mats) { return (lay_offset_reals(N, lds_mats) + lay_cap_reals(N, lds_mats)) * sizeof(real); }
+// Strip images, Float64 (r5): the layer-independent tables of the elemental layer -- per PAIR OF STREAMS F1 = mu_j / (mu_i + mu_j),
+// F2 = mu_j / (mu_i - mu_j), SI = 1 / mu_i + 1 / mu_j -- are built ONCE per (persistent) workgroup behind the tail above instead
+// of once per layer in Q: a layer's table pass is then one exponential per pair, E = 1 - exp(-dtau SI), no division (the same
+// expressions on the same operands as before: identical values).  ns: Stokes components per stream (1 if the streams are not
+// regular); 0 if the per-layer tables do not apply either (3 Nq^2 reals must fit a matrix buffer, elemental_build).
+__host__ __device__ inline int ptab_reals(int N, int ns) {
+  const int Nq = N / (ns > 0 ? ns : 1), nt = 3 * Nq * Nq;
+  if (nt > (int)mat_elems(N)) return 0;
+  // 4-wave images live on two workgroups per CU: no tables where they would cost the second one (N = 44)
+  if (kWaves == 4 && 2 * (lds_bytes(N, true) + (size_t)nt * sizeof(real)) + 2048 > kLdsPerCU) return 0;
+  return nt;
+}
+__host__ __device__ inline size_t strip_lds_bytes(int N, int ns) { return lds_bytes(N, true) + (kF64 ? (size_t)ptab_reals(N, ns) * sizeof(real) : 0); }
 __host__ __device__ inline size_t lds_body_bytes(int N, bool lds_mats) {
   size_t b = vec_area_doubles(N) * sizeof(real);
   if (lds_mats) b += 4 * mat_elems(N) * sizeof(real);
@@ -183,6 +198,7 @@ __device__ __forceinline__ void make_ctx(Ctx &c, int N, int inv_mode, real *smem
   c.inv_mode = inv_mode;
   c.qpre = 0;
   c.slot = 0;
+  c.ptab = nullptr;
   const size_t msz = mat_elems(N);
   real *p = smem;
   if (LDSM) {
@@ -1074,7 +1090,7 @@ template <class FZP, class FZM>
 __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &q, int m, int nd, real tau_sum,
                                                 real dtau, real varpi, FZP Zpp, FZM Zmp) {
   const int N = c.N, ld = c.ld, n = q.nS;
-  const real wdiv = (m == 0) ? 2.0 : 4.0;
+  const real winv = (m == 0) ? 0.5 : 0.25;   // wt / wdiv with wdiv = 2 or 4: a power of two, the product is the same value
   const real wct02 = (m == 0) ? 0.5 : 0.25;
   // exp(-dtau/mu_i) per stream and 1 - exp(-dtau (1/mu_i + 1/mu_j)) per PAIR OF STREAMS: the Stokes
   // components of a stream share mu, so the nS^2-fold repeated exponentials of get_elem_rt!
@@ -1086,7 +1102,10 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   FastDiv fq;
   fq.init(Nq);
   // per stream pair (iq, jq): E = 1 - exp(..), F1 = mu_j/(mu_i+mu_j), F2 = mu_j/(mu_i-mu_j); the Q buffer is free here
-  real *E = c.Q, *F1 = c.Q + Nq * Nq, *F2 = c.Q + 2 * Nq * Nq;
+  // (strip images: F1, F2 and SI = 1/mu_i + 1/mu_j come from the workgroup's persistent tables, c.ptab)
+  const bool pt = c.ptab != nullptr;
+  real *E = c.Q, *F1q = c.Q + Nq * Nq, *F2q = c.Q + 2 * Nq * Nq;
+  const real *F1 = pt ? c.ptab : F1q, *F2 = pt ? c.ptab + Nq * Nq : F2q, *SIp = pt ? c.ptab + 2 * Nq * Nq : nullptr;
   // two-term phase matrices (Rayleigh + one aerosol type): the 32 basis loads of this thread's first 8 elements go
   // out before the tables are built and are consumed after them
   // Element enumeration: lane = row (in blocks of 64), wave = column (strided by kWaves).  A thread's elements share
@@ -1131,20 +1150,22 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   if (pre) issue_z2(0);
   for (int i = wg_tid(); i < N; i += kThreads) {
     c.ei[i] = exp(-dtau / c.mu[i]);
-    c.v1[i] = c.wt[i] / wdiv;   // wct
+    c.v1[i] = c.wt[i] * winv;   // wct
     c.v2[i] = dtau / c.mu[i];
   }
   // the tables pay (and fit the buffer) when several Stokes components share a stream; scalar problems with
   // large N evaluate the same expressions per element instead
   const bool tab = 3 * Nq * Nq <= (int)mat_elems(N);
-  if (tab)
+  if (tab && pt) {
+    for (int e = wg_tid(); e < Nq * Nq; e += kThreads) E[e] = 1 - exp(-dtau * SIp[e]);
+  } else if (tab)
     for (int e = wg_tid(); e < Nq * Nq; e += kThreads) {
       int iq, jq;
       fq.split(e, iq, jq);
       const real mui = c.mu[iq * ns], muj = c.mu[jq * ns];
       E[e] = 1 - exp(-dtau * ((1 / mui) + (1 / muj)));
-      F1[e] = muj / (mui + muj);
-      F2[e] = muj / (mui - muj);
+      F1q[e] = muj / (mui + muj);
+      F2q[e] = muj / (mui - muj);
     }
   __syncthreads();
   MOM_STAMP(46);

@@ -49,7 +49,7 @@ template <int KS>
 struct StripGeom {
   static constexpr int N = 4 * KS;
   static constexpr int NT = (N + 15) / 16;
-  static constexpr int LD = (kF64 && kWaves == 4 && N == 44) ? 46 : 16 * NT + 2;  // = ld_for(N)
+  static constexpr int LD = (kF64 && kWaves == 4 && (N == 36 || N == 40 || N == 44)) ? N + 2 : 16 * NT + 2;  // = ld_for(N)
   static constexpr int CP = 16 * NT;               // row pitch of the scene-level composite blocks (comp_pitch)
   // The riding rows N and N + 1 of a strip in its accumulators (tile RT).  Float64 layout (row = 16 rt + 4 r + lq): both in
   // register KS & 3, row N in the lanes lq == 0, row N + 1 in the lanes lq == 1.  Float32 layout (row = 16 rt + 4 lq + r):

@@ -291,6 +291,7 @@ __global__ void __launch_bounds__(kThreads) k_batch_inv_dual(DualArgs a) {
 // momcore_w4.hip: the same kernels built for 4-wave workgroups (2 workgroups per CU when the operators are
 // small enough for two LDS images: the m = 0 (I,Q) sub-problem of N = 60 is N0 = 40 -> 77 KB).
 size_t mom4_lds_bytes(int N, bool lds_mats);
+size_t mom4_strip_lds_bytes(int N, int ns);
 hipError_t mom4_launch_layer(const void *layer_args, int iface, bool lds, int grid, size_t smem, hipStream_t st);
 // momcore_gen.hip: the general layer kernels k_layer<LDSM, IFACE> of the 8-wave build
 hipError_t mom_gen_launch_layer(const void *layer_args, int iface, bool lds, int grid, size_t smem, hipStream_t st);
@@ -1412,12 +1413,15 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
     a.scratch = scratch; a.info = h->d_info;
     const bool lds = (q.N <= 64) && !h->opt_force_generic;
     // small operators: 4-wave workgroups, two per CU (momcore_w4.hip), when two LDS images fit
-    if (lds && h->opt_w4 && np_for(q.N) <= 48 && 2 * mom4_lds_bytes(q.N, true) + 2048 <= 160 * 1024) {
+    const int ns_tab = q.regular ? q.nS : 1;  // Stokes components per stream of the elemental layer's stream-pair tables
+    const bool strip4 = (q.N == 36 || q.N == 40 || q.N == 44);
+    if (lds && h->opt_w4 && np_for(q.N) <= 48 &&
+        2 * (strip4 ? mom4_strip_lds_bytes(q.N, ns_tab) : mom4_lds_bytes(q.N, true)) + 2048 <= 160 * 1024) {
       const int grid4 = (int)((S >= 2048) ? S : S * Mcount);
-      if (q.N == 36 || q.N == 40 || q.N == 44) {  // strip-chained kernels of the 4-wave build (momcore_strip.hip)
+      if (strip4) {  // strip-chained kernels of the 4-wave build (momcore_strip.hip)
         const int gridp = (int)std::min<size_t>(S * Mcount, (size_t)2 * h->num_cu);  // persistent, two per CU
         HIPCHK(h, (q.N == 44 ? mom4_strip11_launch_layer : q.N == 40 ? mom_strip10_launch_layer : mom_strip9_launch_layer)(
-                      &a, a.iface, gridp, mom4_lds_bytes(q.N, true), h->stream));
+                      &a, a.iface, gridp, mom4_strip_lds_bytes(q.N, ns_tab), h->stream));
         h->launches++;
         return MOM_OK;
       }
@@ -1425,8 +1429,9 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
       h->launches++;
       return MOM_OK;
     }
-    const size_t sm = lds_bytes(q.N, lds);
+    size_t sm = lds_bytes(q.N, lds);
     if (lds && (q.N == 44 || q.N == 52 || q.N == 56 || q.N == 60)) {  // strip-chained kernels (momcore_strip.hip), one image per N
+      sm = strip_lds_bytes(q.N, ns_tab);  // + the persistent stream-pair tables
       // persistent workgroups, one per CU (only one 135 KB LDS image fits a CU): the prologue is paid once;
       // their start is staggered over about one unit time (~ (44 + 17 nd) us at N = 60)
       if (S * Mcount >= 8 * (size_t)h->num_cu && h->opt_stagger) {

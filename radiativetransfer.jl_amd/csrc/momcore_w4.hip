@@ -15,6 +15,7 @@
 using namespace mom4;
 
 size_t mom4_lds_bytes(int N, bool lds_mats) { return lds_bytes(N, lds_mats); }
+size_t mom4_strip_lds_bytes(int N, int ns) { return strip_lds_bytes(N, ns); }  // strip images: + the persistent stream-pair tables
 int mom4_generic_bufs_elems(int N) { return (int)(kGenericBufs * mat_elems(N)); }
 
 template <class K>

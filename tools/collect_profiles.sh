@@ -3,7 +3,7 @@
 # (FETCH_SIZE and WRITE_SIZE in separate passes, MFMA-busy in a third: MI355X_MICROARCH.md, rocprofv3 PMC slots; never
 # combined with a trace domain other than --kernel-trace).  Output goes to gpurun_out/<round>_*;
 # tools/summarize_profiles.py turns it into profiles/.
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out

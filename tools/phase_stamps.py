@@ -4,13 +4,13 @@ per code section of the middle workgroup (ids: MOM_STAMP in csrc/)."""
 import sys, os, ctypes as C
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
-os.environ["MOM_LIBRARY"] = os.environ.get("MOM_LIBRARY", os.path.join(ROOT, "scratch", "lib_diag.so"))
+os.environ["MOM_LIBRARY"] = os.environ.get("MOM_LIBRARY", os.path.join(ROOT, "scratch", "ab", "lib_diag15.so"))
 import numpy as np
 import rtamd
 model = rtamd.scenes.scene_C2(S=10000)
 sc = rtamd.prepare_scene(model)
 lib = rtamd._lib.load()
-rd = lib.mom_diag_read_strip15; rd.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+rd = lib.mom_strip_diag_read15; rd.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 buf = (C.c_ulonglong * 128)()
 with rtamd.corert.make_handle(model) as h:
     rtamd.corert.run_scene(h, sc)
