@@ -97,6 +97,22 @@ def spawn_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
+class stdout_to_stderr:
+    """File descriptor 1 -> 2 for the duration of the block (C-level writers included), see main()."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def init_collective(h, backend, rank, world, dist, collective):
     """The communicator of the run's ONE collective.  backend "rccl": RCCL through the C ABI (mom_comm_init).  Should its
     set-up fail on ANY rank (a mis-matched RCCL/HIP pair in the host process, for instance), every rank falls back -- together
@@ -125,7 +141,8 @@ def init_collective(h, backend, rank, world, dist, collective):
     flag = torch.tensor([ok], dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
-        group = dist.new_group(backend="nccl")
+        with stdout_to_stderr():
+            group = dist.new_group(backend="nccl")
         backend = "torch-fallback"
         collective = "torch.distributed all_gather_into_tensor (RCCL; fallback: the C-ABI communicator failed to initialise)"
     return backend, group, collective
@@ -539,10 +556,17 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if a.backend == "torch":
-            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group("gloo")
+        # The JSON line of rank 0 must be the ONLY thing on stdout: gloo's transport logs "[Gloo] Rank r is connected to ..." on
+        # the C-level stdout of every rank while a group connects.  Ranks > 0 send their stdout to stderr for good, rank 0
+        # while process groups are being set up (stdout_to_stderr).
+        if rank != 0:
+            sys.stdout.flush()
+            os.dup2(2, 1)
+        with stdout_to_stderr():
+            if a.backend == "torch":
+                dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group("gloo")
 
     S_loc = a.points or DEFAULT_POINTS[a.workload]
     if a.workload == "C5":

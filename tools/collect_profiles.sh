@@ -28,6 +28,12 @@ python3 bench.py --workload C3 --no-cpu-baseline > $O/${ROUND}_bench_C3.json 2> 
 python3 bench.py --gpus 2 --backend gloo --share-device --no-voigt > $O/${ROUND}_bench_2ranks_one_gpu.json 2> /dev/null
 python3 bench.py --workload C3 --scaling strong --gpus 2 --backend gloo --share-device --no-cpu-baseline > $O/${ROUND}_bench_C3_strong_2ranks_one_gpu.json 2> /dev/null
 python3 bench.py --workload C5 --gpus 2 --backend gloo --share-device --no-cpu-baseline > $O/${ROUND}_bench_C5_2ranks_one_gpu.json 2> /dev/null
+# two ranks over RCCL through torch.distributed (the C5 timing all-reduce of bench.py: ADVICE r4) -- needs two GPUs
+if [ "$(python3 -c 'import torch; print(torch.cuda.device_count())')" -ge 2 ]; then
+  python3 bench.py --workload C5 --gpus 2 --backend torch --no-cpu-baseline > $O/${ROUND}_bench_C5_2gpus_torch.json 2> /dev/null
+  python3 bench.py --gpus 2 --no-voigt --no-cpu-baseline > $O/${ROUND}_bench_2gpus_rccl.json 2> /dev/null
+fi
+python3 tools/bench_rrs_nt2.py > $O/${ROUND}_rrs_nt.txt 2> /dev/null
 python3 tools/size_sweep.py > $O/${ROUND}_size_sweep.txt 2> /dev/null
 python3 tools/f32_vs_f64.py > $O/${ROUND}_f32_vs_f64.txt 2> /dev/null
 echo collected
