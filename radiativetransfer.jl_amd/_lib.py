@@ -34,6 +34,7 @@ IE_COMP = dict(ieR_mp=24, ieR_pm=25, ieT_pp=26, ieT_mm=27, ieJ0p=28, ieJ0m=29)
 
 MOM_OPT_INVERSE, MOM_OPT_FORCE_GENERIC, MOM_OPT_M0_REDUCTION, MOM_OPT_SMALL_WG, MOM_OPT_STAGGER, MOM_OPT_SMALL_N, MOM_OPT_LAYER_SWEEP = 0, 1, 2, 3, 4, 5, 6
 MOM_OPT_STRIP_PAD = 7
+MOM_OPT_LEAN = 8
 
 
 class MomError(RuntimeError):

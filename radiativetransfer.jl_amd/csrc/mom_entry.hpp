@@ -37,6 +37,10 @@ struct LayerArgs {
   int ntgt;
   real *tgt[kMaxTargets][6];
   signed char act_z[kMaxSweepLayers][kMaxTargets];
+  // lean strip image (mom_lean.hpp): resume[unit] = the layer at which the lean workgroup left the unit (Nz_sweep: finished).
+  // The lean kernel writes it; the full image, launched afterwards with the same pointer, starts every unit at that layer
+  // (its composite state in global memory is the one after layer resume - 1) and skips the finished ones.  nullptr: all layers.
+  int *resume;
 };
 
 struct ZMix {
@@ -110,7 +114,8 @@ __global__ void __launch_bounds__(kThreads, MOM_LB_WAVES) k_layer(LayerArgs a) {
     const int n = (int)(pt % a.S), mrel = (int)(pt / a.S), m = a.m_first + mrel;
     const size_t NN = (size_t)N * N;
     CompPtrs g = comp_ptrs(a.comp, N, comp_pitch(N), pt);
-    for (int z = 0; z < nz; ++z) {
+    const int z0 = (a.resume != nullptr) ? a.resume[pt] : 0;  // (workgroup-uniform)
+    for (int z = z0; z < nz; ++z) {
       // The per-(point, layer) scalars tau, varpi, tau_sum and the K phase-matrix weights: kLayTab / (3 + K) layers at a time go
       // from their [S, Nz] tables into the LDS tail in ONE batch of independent loads -- a unit pays one memory latency per
       // batch instead of two dependent ones per layer (tau before the first exponential, the weights before the element math;
@@ -119,11 +124,11 @@ __global__ void __launch_bounds__(kThreads, MOM_LB_WAVES) k_layer(LayerArgs a) {
       const int LW = 3 + a.K, LZ = lay_cap_reals(N, LDSM) / LW;
       real *lay = mom_smem + lay_offset_reals(N, LDSM);
       const int zl = z % LZ;
-      if (zl == 0) {
-        const int cnt = ((nz - z < LZ) ? nz - z : LZ) * LW;
+      if (zl == 0 || z == z0) {   // a batch starts at a multiple of LZ; a resumed unit may enter in the middle of one
+        const int zb = z - zl, cnt = ((nz - zb < LZ) ? nz - zb : LZ) * LW;
         for (int i = wg_tid(); i < cnt; i += kThreads) {
           const int zz = i / LW, k = i - zz * LW;
-          const size_t o = (size_t)n + (size_t)a.S * (z + zz);
+          const size_t o = (size_t)n + (size_t)a.S * (zb + zz);
           lay[i] = (k == 0) ? as_global(a.tau)[o] : (k == 1) ? as_global(a.varpi)[o] : (k == 2) ? as_global(a.tau_sum)[o]
                                                                                                 : as_global(a.zw)[(size_t)a.K * o + (k - 3)];
         }

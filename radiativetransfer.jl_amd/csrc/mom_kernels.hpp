@@ -85,6 +85,7 @@ struct Ctx {
   int qpre;  // MOM_QPREFETCH experiment: c.Q already holds the composite T++ (+ J0+ riding) for the coming interaction
   int slot;  // MOM_SIMD_AWARE experiment: the column strip this wave owns (mom_strip.hpp strip_slot)
   const real *ptab;  // strip images (r5): F1 | F2 | SI per stream pair, built once per workgroup (nullptr: per layer, in Q)
+  real *tabE, *tabZS;  // table space of elemental_build: E | F1 | F2 per stream pair and the sun-block Z columns (nullptr: the current Q / P)
 };
 
 __host__ __device__ inline int np_for(int N) { return 16 * ((N + 15) / 16); }
@@ -215,6 +216,8 @@ __device__ __forceinline__ void make_ctx(Ctx &c, int N, int inv_mode, real *smem
   int *ip = reinterpret_cast<int *>(c.thr + 32);
   c.ipiv = ip; c.sh = ip + lv; c.bad = ip + lv + 1;
   c.part = p + part_offset_doubles(N);
+  c.tabE = nullptr;   // elemental_build: the CURRENT Q / P (the generic mode rotates its buffer pointers between layers)
+  c.tabZS = nullptr;
 }
 
 // zero the padding (rows/cols >= N) of the LDS matrix buffers; vectors fully
@@ -1104,7 +1107,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   // per stream pair (iq, jq): E = 1 - exp(..), F1 = mu_j/(mu_i+mu_j), F2 = mu_j/(mu_i-mu_j); the Q buffer is free here
   // (strip images: F1, F2 and SI = 1/mu_i + 1/mu_j come from the workgroup's persistent tables, c.ptab)
   const bool pt = c.ptab != nullptr;
-  real *E = c.Q, *F1q = c.Q + Nq * Nq, *F2q = c.Q + 2 * Nq * Nq;
+  real *E = c.tabE ? c.tabE : c.Q, *F1q = E + Nq * Nq, *F2q = E + 2 * Nq * Nq;
   const real *F1 = pt ? c.ptab : F1q, *F2 = pt ? c.ptab + Nq * Nq : F2q, *SIp = pt ? c.ptab + 2 * Nq * Nq : nullptr;
   // two-term phase matrices (Rayleigh + one aerosol type): the 32 basis loads of this thread's first 8 elements go
   // out before the tables are built and are consumed after them
@@ -1170,7 +1173,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   __syncthreads();
   MOM_STAMP(46);
   const int i_start = n * (q.imu0 - 1), i_end = n * q.imu0;
-  real *ZS = c.P;  // mixed Z++ / Z-+ of the sun-block columns, [N x nS] each (P is free here)
+  real *ZS = c.tabZS ? c.tabZS : c.P;  // mixed Z++ / Z-+ of the sun-block columns, [N x nS] each (P is free here)
   for (int s0 = 0; s0 < slots; s0 += 8) {
     real zp[8], zm[8];
 #pragma unroll

@@ -1,6 +1,7 @@
 // momcore.hip -- __global__ kernels and the C ABI (include/momcore.h) of libmomcore.so.
 // gfx950 (MI355X) only.  See DESIGN.md for the data layout and the kernel inventory.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cmath>
 #include <cstdio>
@@ -298,6 +299,10 @@ hipError_t mom_gen_launch_layer(const void *layer_args, int iface, bool lds, int
 // momcore_strip.hip, one object per operator size N = 4 KS
 hipError_t mom_strip9_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom_strip10_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
+hipError_t mom_strip9_launch_lean(const void *layer_args, int grid, hipStream_t st);   // momcore_strip.hip with mom_lean.hpp
+hipError_t mom_strip10_launch_lean(const void *layer_args, int grid, hipStream_t st);
+size_t mom_strip9_lean_lds_bytes(int ns);
+size_t mom_strip10_lean_lds_bytes(int ns);
 hipError_t mom_strip11_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom4_strip11_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);  // 4-wave build of N = 44
 hipError_t mom_strip13_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
@@ -398,6 +403,9 @@ struct mom_handle {
   double *d_ms_out = nullptr;  // [2][nVza*nS*S*nSensors]
   size_t ms_out_cap = 0;
   int opt_pad = 1;         // scene-level path: pad the operator edge to the next strip-chained kernel size (strip_pad)
+  int opt_lean = 1;        // N = 36, 40: the lean 4-wave strip image (three workgroups per CU) + the full image's resume launch
+  int *d_resume = nullptr; // resume[unit] of the lean image (mom_lean.hpp)
+  size_t resume_cap = 0;
   int Nk = 0;              // operator edge the scene-level kernels of the full problem run with (>= N)
   DevStreams qk{};         // q with N = Nk
   int opt_small = 1;       // N <= 4: lane-per-point sweep kernel (mom_small.hip)
@@ -617,7 +625,7 @@ extern "C" int mom_destroy(mom_t *h) {
   fr(h->d_tau); fr(h->d_varpi); fr(h->d_zw); fr(h->d_Zpp); fr(h->d_Zmp); fr(h->d_tau_sum); fr(h->d_cos); fr(h->d_sin);
   fr(h->d_mu0); fr(h->d_wt0); fr(h->d_sg0); fr(h->d_Zpp0); fr(h->d_Zmp0); fr(h->d_hdrJ0); fr(h->d_scratch0);
   for (int k = 0; k < 6; ++k) fr(h->comp0[k]);
-  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_rrs_send); fr(h->d_Rsurf); fr(h->d_Rsurf0); fr(h->d_albedo_spec); fr(h->d_hdrJm); fr(h->d_smtab); fr(h->d_smpart); if (h->d_ndif) (void)hipFree(h->d_ndif); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_prof); fr(h->d_tau_rayl);
+  fr(h->d_R); fr(h->d_hdr); fr(h->d_post[0]); fr(h->d_gather); fr(h->d_rrs_send); fr(h->d_Rsurf); fr(h->d_Rsurf0); fr(h->d_albedo_spec); fr(h->d_hdrJm); fr(h->d_smtab); fr(h->d_smpart); if (h->d_resume) (void)hipFree(h->d_resume); if (h->d_ndif) (void)hipFree(h->d_ndif); fr(h->d_tau_abs); fr(h->d_grid); fr(h->d_lines); fr(h->d_prof); fr(h->d_tau_rayl);
   fr(h->d_layer_max); fr(h->d_aer); if (h->d_aer_mode) (void)hipFree(h->d_aer_mode); fr(h->d_hdrJ); fr(h->d_bhr_uw); fr(h->d_bhr_dw); fr(h->d_node); fr(h->d_scratch); fr(h->d_info);
   for (int k = 0; k < 4; ++k) if (h->ev[k]) (void)hipEventDestroy(h->ev[k]);
   for (int k = 0; k < 2; ++k) if (h->ev_voigt[k]) (void)hipEventDestroy(h->ev_voigt[k]);
@@ -650,6 +658,7 @@ extern "C" int mom_set_option(mom_t *h, int option, int value) {
   else if (option == MOM_OPT_SMALL_N) { h->opt_small = value; h->scene_set = false; }  // the padded edge Nk depends on it
   else if (option == MOM_OPT_LAYER_SWEEP) h->opt_sweep = value;
   else if (option == MOM_OPT_STRIP_PAD) { h->opt_pad = value; h->scene_set = false; }
+  else if (option == MOM_OPT_LEAN) h->opt_lean = value;
   else if (option == MOM_OPT_FORCE_GENERIC) {
     h->opt_force_generic = value;
     h->lds_mode = (h->N <= 64) && !value;
@@ -1420,6 +1429,24 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
       const int grid4 = (int)((S >= 2048) ? S : S * Mcount);
       if (strip4) {  // strip-chained kernels of the 4-wave build (momcore_strip.hip)
         const int gridp = (int)std::min<size_t>(S * Mcount, (size_t)2 * h->num_cu);  // persistent, two per CU
+        // N = 36, 40: the lean image first (three workgroups per CU; mom_lean.hpp), then the full image resumes what it left
+        bool lean = h->opt_lean && sweep && !tg && q.inv_mode == 0 && (q.N == 36 || q.N == 40) &&
+                    (q.N == 40 ? mom_strip10_lean_lds_bytes(ns_tab) : mom_strip9_lean_lds_bytes(ns_tab)) > 0;
+        for (int k = 1; k < nzr && lean; ++k) lean = (a.iface_z[k] == 3);
+        if (lean && !a.first) lean = (a.iface_z[0] == 3);
+        if (lean) {
+          const size_t units = S * (size_t)Mcount;
+          if (units > h->resume_cap) {  // grow-only
+            if (h->d_resume) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_resume); h->d_resume = nullptr; h->resume_cap = 0; }
+            HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_resume), units * sizeof(int)));
+            h->resume_cap = units;
+          }
+          a.resume = h->d_resume;
+          static const int lean_per_cu = getenv("MOM_LEAN_PER_CU") ? atoi(getenv("MOM_LEAN_PER_CU")) : 3;  // (experiments)
+          const int gridl = (int)std::min<size_t>(units, (size_t)std::max(lean_per_cu, 1) * h->num_cu);
+          HIPCHK(h, (q.N == 40 ? mom_strip10_launch_lean : mom_strip9_launch_lean)(&a, gridl, h->stream));
+          h->launches++;
+        }
         HIPCHK(h, (q.N == 44 ? mom4_strip11_launch_layer : q.N == 40 ? mom_strip10_launch_layer : mom_strip9_launch_layer)(
                       &a, a.iface, gridp, mom4_strip_lds_bytes(q.N, ns_tab), h->stream));
         h->launches++;

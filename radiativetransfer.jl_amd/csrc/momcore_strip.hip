@@ -10,6 +10,11 @@
 #include "mom_diag.hpp"
 #include "mom_entry.hpp"
 #include "mom_host.hpp"
+// the lean image (three operator buffers, three workgroups per CU): Float64, 4-wave build, N = 36, 40
+#if defined(MOM_WAVES) && MOM_WAVES == 4 && !defined(MOM_REAL_IS_FLOAT) && (MOM_STRIP_KS == 9 || MOM_STRIP_KS == 10)
+#define MOM_HAVE_LEAN 1
+#include "mom_lean.hpp"
+#endif
 
 using namespace MOM_NS;
 
@@ -47,6 +52,22 @@ hipError_t MOM_CAT(MOM_CAT(MOM_STRIP_PREFIX, MOM_STRIP_KS), _launch_layer)(const
 
 // LDS bytes of one workgroup of this image (the vector area depends on the workgroup shape of the build)
 size_t MOM_CAT(MOM_CAT(MOM_STRIP_PREFIX, MOM_STRIP_KS), _lds_bytes)() { return lds_bytes(4 * MOM_STRIP_KS, true); }
+
+#ifdef MOM_HAVE_LEAN
+// mom_strip<KS>_launch_lean(args, grid, stream): the lean sweep kernel; mom_strip<KS>_lean_lds_bytes(ns): its LDS bytes, 0 if the
+// image does not apply to ns Stokes components per stream
+hipError_t MOM_CAT(MOM_CAT(MOM_STRIP_PREFIX, MOM_STRIP_KS), _launch_lean)(const void *layer_args, int grid, hipStream_t st) {
+  const LayerArgs a = *reinterpret_cast<const LayerArgs *>(layer_args);
+  const size_t smem = lean_lds_bytes(4 * MOM_STRIP_KS);
+  hipError_t e = mom_allow_lds(reinterpret_cast<const void *>(k_layer_lean<MOM_STRIP_KS>), smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_layer_lean<MOM_STRIP_KS>), dim3(grid), dim3(kThreads), smem, st, a);
+  return hipGetLastError();
+}
+size_t MOM_CAT(MOM_CAT(MOM_STRIP_PREFIX, MOM_STRIP_KS), _lean_lds_bytes)(int ns) {
+  return lean_applies(4 * MOM_STRIP_KS, ns) ? lean_lds_bytes(4 * MOM_STRIP_KS) : 0;
+}
+#endif
 
 #ifdef MOM_DIAG_STAMPS
 extern "C" int MOM_CAT(MOM_CAT(MOM_STRIP_PREFIX, _diag_read), MOM_STRIP_KS)(unsigned long long *out, int reset) {

@@ -135,6 +135,36 @@ def test_strip_padding_to_kernel_sizes(rtamd, cref, nS, lt, N, kw):
     np.testing.assert_allclose(out[1][4], out[0][4], rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
 
 
+@pytest.mark.parametrize("nS,lt,N,thick", [(4, 11, 36, False), (4, 13, 40, False), (4, 13, 40, True), (4, 11, 36, True),
+                                           (3, 33, 60, False), (3, 33, 60, True)])
+def test_lean_strip_image_and_resume(rtamd, cref, nS, lt, N, thick):
+    """MOM_OPT_LEAN (r5): operators of edge 36 / 40 -- and the m = 0 (I,Q) sub-problem of an N = 60 IQU scene, N0 = 40 -- run on
+    the lean 4-wave strip image (three operator buffers, three workgroups per CU; csrc/mom_lean.hpp) followed by the full
+    image's resume launch.  Thin layers: every unit finishes in the lean image.  Thick layers (aerosol optical depth 2: series
+    beyond 12 terms in the late doubling steps and the interactions): the lean workgroup leaves the unit at that layer and the
+    full image redoes the layer and finishes the unit.  Either way the spectra are BITWISE those of the full image alone (the
+    chains perform the same operations in the same order) and agree with the oracle."""
+    kw = dict(aerosol_total=2.0, aerosol_p0=600.0, aerosol_σp=200.0, absorption=False) if thick else dict(aerosol_total=0.3)
+    m = rtamd.scenes.make_scene(nS, lt, 6, 40, seed=11 * nS + lt, **kw)
+    sc = rtamd.prepare_scene(m)
+    assert sc.N == N
+    out = {}
+    for lean in (1, 0):
+        with rtamd.corert.make_handle(m) as h:
+            h.set_option(rtamd._lib.MOM_OPT_LEAN, lean)
+            R, T = rtamd.corert.run_scene(h, sc)
+            out[lean] = (R, T) + h.get_hdr() + (h.timers()["layer_launches"],)
+            R2, T2 = rtamd.corert.run_scene(h, sc)                       # the resume table is reused: same answer again
+            assert np.array_equal(R, R2) and np.array_equal(T, T2)
+    for k in range(5):
+        assert np.array_equal(out[1][k], out[0][k]), f"lean vs full image, output {k}"
+    assert out[1][5] > out[0][5]                                         # the lean launch + the resume launch
+    Rr, Tr = _oracle(cref, m)
+    tol = helpers.stokes_rtol(sc.ndoubl)
+    helpers.assert_stokes_close(out[1][0], Rr, rtol=tol, what="R lean")
+    helpers.assert_stokes_close(out[1][1], Tr, rtol=tol, what="T lean")
+
+
 def test_strip_chains_thick_layers_fall_back(rtamd, cref):
     """optically thick scattering layers: the series length exceeds the strip chains' limit for part of the
     doubling steps and interactions, which must then take the general path inside the same kernels"""
