@@ -24,13 +24,29 @@
 namespace MOM_NS {
 
 constexpr int kLeanLay = 128;  // reals of the layer-scalar tail
+// The SIX-wave flavour (-DMOM_WAVES=6, namespace mom6; "lean6"): the doubling chains run on HALF-STRIPS -- the two waves 2 s, 2 s + 1
+// of strip s split the contraction (k-steps 0 .. KH - 1 and KH .. KS - 1), each multiplies its half of the running strip into
+// partial sums of the whole strip (15 MFMAs instead of 30 at N = 40) and the two exchange, through a 3 KB LDS slot per wave, the
+// partial sums of the rows the OTHER one owns.  Six chain waves per unit, two units per CU: three chains on every SIMD -- the
+// 54 ms floor of wave-owned strips (profiles/r05_mid_ab.txt: 1/3 of the MFMA time on the busiest SIMD) becomes 1/4.
+// MEASURED (same file): 104.5 ms against the four-wave lean image's 73 ms on the headline's m = 0 launch -- a workgroup's six waves
+// sit (2,2,1,1) on the SIMDs, so ITS product still takes two half-strip times on two of them (1 920 cycles, what a full strip
+// takes); the gain has to come from the second workgroup filling the other SIMDs in phase, and the two workgroup barriers per
+// product (partial sums must meet) cost more than those 25 %.  Kept as MOM_OPT_LEAN = 2 (tested), not the default.
+constexpr bool kLean6 = (kWaves == 6);
+constexpr int kHalfSlots = 6;   // k-step slots of a half-strip: up to 5 k-steps + the riding rows
 __host__ __device__ inline size_t lean_vec_reals(int N) { return part_offset_doubles(N) + 16; }
-__host__ __device__ inline size_t lean_lds_bytes(int N) { return (3 * mat_elems(N) + lean_vec_reals(N) + kLeanLay) * sizeof(real); }
-// does the image apply to operators of edge N with ns Stokes components per stream?  (the tables must fit P)
+__host__ __device__ inline size_t lean_exch_reals() { return kLean6 ? (size_t)kWaves * kHalfSlots * 64 : 0; }
+__host__ __device__ inline size_t lean_lds_bytes(int N) {
+  return (3 * mat_elems(N) + lean_vec_reals(N) + lean_exch_reals() + kLeanLay) * sizeof(real);
+}
+// does the image apply to operators of edge N with ns Stokes components per stream?  (the tables must fit P; three workgroups
+// of four waves or two of six per CU)
 __host__ __device__ inline bool lean_applies(int N, int ns) {
   const int Nq = N / (ns > 0 ? ns : 1);
-  return kF64 && kWaves == 4 && (N == 36 || N == 40) && 3 * Nq * Nq + 2 * ns * N <= (int)mat_elems(N) &&
-         3 * lean_lds_bytes(N) + 3 * 1024 <= kLdsPerCU;
+  const int per_cu = kLean6 ? 2 : 3;
+  return kF64 && (kWaves == 4 || kLean6) && (N == 36 || N == 40) && 3 * Nq * Nq + 2 * ns * N <= (int)mat_elems(N) &&
+         per_cu * (lean_lds_bytes(N) + 1024) <= kLdsPerCU;
 }
 
 __device__ __forceinline__ void make_ctx_lean(Ctx &c, int N, int inv_mode, real *smem) {
@@ -95,13 +111,224 @@ __device__ __forceinline__ real doubling_run_lean(Ctx &c, int nd, real expk, boo
   return expk;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// lean6: half-strip chains.  Wave w = 2 s + h (s = column strip, h = half).  A half-strip holds, per lane, the rows of the
+// running strip that are the B operand of ITS k-steps: slot j <-> k-step ks0 + j, i.e. register (ks & 3) of row tile (ks >> 2)
+// of the full strip's accumulator layout; half 1 also owns the slot of the riding rows N, N + 1 (k-step index KS).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS>
+struct HalfGeom {
+  static constexpr int KH = (KS + 1) / 2;           // k-steps of half 0 (half 1: KS - KH)
+  static_assert(KH <= kHalfSlots - 1 && KS - KH + 1 <= kHalfSlots, "slots of a half-strip");
+};
+// Every function below takes the half H as a TEMPLATE argument: the slots of a half map to accumulator registers
+// acc[ks >> 2][ks & 3] with ks = ks0(H) + j, and a register index must be a compile-time constant (with H as a run-time value
+// the first version of this image indexed its accumulators through scratch and ran 2.3 x slower than the four-wave one).
+template <int KS, int H> struct HalfOf {
+  static constexpr int KH = HalfGeom<KS>::KH;
+  static constexpr int ks0 = H ? KH : 0;               // first k-step
+  static constexpr int nk = H ? KS - KH : KH;          // k-steps (slots that are B operands)
+  static constexpr int ns = H ? KS - KH + 1 : KH;      // owned slots (half 1: + the riding rows, k-step index KS)
+};
+
+// x[j] = X[col][row] (the transposed strip of the column-major LDS buffer X), rows of my k-steps; other slots read 0
+template <int KS, int H>
+__device__ __forceinline__ void half_load_lds(const real *X, int lr, int lq, int c0, real (&x)[kHalfSlots]) {
+  constexpr int LD = StripGeom<KS>::LD;
+  using O = HalfOf<KS, H>;
+  const real *base = X + c0 + lr + lq * LD;
+#pragma unroll
+  for (int j = 0; j < kHalfSlots; ++j) x[j] = (j < O::nk) ? base[4 * (O::ks0 + j) * LD] : 0.0;
+}
+template <int KS, int H>
+__device__ __forceinline__ void half_store_lds(real *X, int lr, int lq, int c0, bool colok, const real (&x)[kHalfSlots]) {
+  constexpr int LD = StripGeom<KS>::LD;
+  using O = HalfOf<KS, H>;
+  real *base = X + c0 + lr + lq * LD;
+  if (colok) {
+#pragma unroll
+    for (int j = 0; j < kHalfSlots; ++j)
+      if (j < O::nk) base[4 * (O::ks0 + j) * LD] = x[j];
+  }
+}
+// acc[rt] += sum over MY k-steps of M^T fragments x my slots
+template <int KS, int H>
+__device__ __forceinline__ void half_mul(const real *M, int lr, int lq, const real (&x)[kHalfSlots], r4 (&acc)[StripGeom<KS>::NT]) {
+  constexpr int NT = StripGeom<KS>::NT, LD = StripGeom<KS>::LD;
+  using O = HalfOf<KS, H>;
+  asm volatile("" : "+v"(lr), "+v"(lq));
+  const real *base = M + lq + lr * LD + 4 * O::ks0;
+#pragma unroll
+  for (int j = 0; j < O::nk; ++j) {
+    real a[NT];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) a[rt] = base[4 * j + 16 * rt * LD];
+#pragma unroll
+    for (int rt = 0; rt < NT; ++rt) acc[rt] = mma16(a[rt], x[j], acc[rt]);
+  }
+}
+// partial sums of the whole strip -> the summed values of MY slots: write the partner's slots, barrier, read mine, add.
+// All six waves call it together (the two barriers of a call are the only synchronisation of a product).
+template <int KS, int H>
+__device__ __forceinline__ void half_reduce(real *exch, int wave, int lane, const r4 (&acc)[StripGeom<KS>::NT], real (&out)[kHalfSlots]) {
+  using O = HalfOf<KS, H>;
+  using P = HalfOf<KS, 1 - H>;
+  real *mine = exch + (size_t)wave * kHalfSlots * 64 + lane, *theirs = exch + (size_t)(wave ^ 1) * kHalfSlots * 64 + lane;
+  __syncthreads();   // every wave has read what the previous exchange left in the slots
+#pragma unroll
+  for (int j = 0; j < P::ns; ++j) {
+    constexpr int dummy = 0; (void)dummy;
+    const int ks = P::ks0 + j;
+    mine[j * 64] = acc[ks >> 2][ks & 3];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kHalfSlots; ++j) {
+    const int ks = O::ks0 + j;
+    out[j] = (j < O::ns) ? acc[(j < O::ns ? ks : 0) >> 2][(j < O::ns ? ks : 0) & 3] + theirs[j * 64] : 0.0;
+  }
+}
+
+// one doubling step (doubling.jl:44-67) on the half-strip of this wave; returns false before anything is changed if the series is
+// too long.  r, t, P, jp, jm as in doubling_step_strip.
+template <int KS, int H>
+__device__ __forceinline__ bool doubling_step_half(Ctx &c, real *exch, real expk) {
+  using G = StripGeom<KS>;
+  using O = HalfOf<KS, H>;
+  constexpr int N = G::N, NT = G::NT, LD = G::LD, RS = O::ns - 1;  // RS: the riding slot (half 1 only)
+  const int lane = wg_lane(), wave = wg_wave(), lr = lane & 15, lq = lane >> 4;
+  const int c0 = 16 * (wave >> 1), col = c0 + lr;
+  const bool colok = col < N;
+  real *r = c.r, *t = c.t, *P = c.P;
+  // ---- P = r r (+ riding columns r j0+, r j0-) and ||r r||_F^2
+  real rh[kHalfSlots], ph[kHalfSlots];
+  half_load_lds<KS, H>(r, lr, lq, c0, rh);
+  {
+    r4 acc[NT];
+    strip_zero(acc);
+    half_mul<KS, H>(r, lr, lq, rh, acc);
+    half_reduce<KS, H>(exch, wave, lane, acc, ph);
+  }
+  real ss = 0.0;
+  half_store_lds<KS, H>(P, lr, lq, c0, colok, ph);
+  if (colok) {
+    if (H) {  // the riding rows: (r j0+)[col] in the lanes lq == 0, (r j0-)[col] in lq == 1
+      if (lq == G::LQ0) P[col + N * LD] = ph[RS];
+      if (lq == G::LQ1) P[col + (N + 1) * LD] = ph[RS];
+    }
+#pragma unroll
+    for (int j = 0; j < O::nk; ++j) ss += ph[j] * ph[j];
+  }
+  wg_sumsq_put(c, ss);
+  __syncthreads();
+  const real beta2 = wg_sumsq_get(c);
+  const int p = __builtin_amdgcn_readfirstlane(neumann_terms_12(beta2));
+  if (p > kStripMaxP || c.inv_mode != 0) return false;
+  // ---- riding rows of the multiplier r^T: w1 = j1- + r j0+, w2 = j0+ + r j1-  (doubling.jl:51-60); every wave writes the same values
+  if (lane < N) {
+    r[lane + N * LD] = c.jm[lane] * expk + P[lane + N * LD];
+    r[lane + (N + 1) * LD] = c.jp[lane] + expk * P[lane + (N + 1) * LD];
+  }
+  real t0[kHalfSlots], y[kHalfSlots];
+  half_load_lds<KS, H>(t, lr, lq, c0, t0);
+#pragma unroll
+  for (int j = 0; j < kHalfSlots; ++j) y[j] = t0[j];
+  // Y = A^T = (t (I - r r)^-1)^T by Horner: Y <- t^T + (r r)^T Y
+#pragma nounroll
+  for (int k = 1; k < p; ++k) {
+    r4 acc[NT];
+    strip_zero(acc);
+    half_mul<KS, H>(P, lr, lq, y, acc);
+    real yn[kHalfSlots];
+    half_reduce<KS, H>(exch, wave, lane, acc, yn);
+#pragma unroll
+    for (int j = 0; j < kHalfSlots; ++j) y[j] = t0[j] + yn[j];
+  }
+  // (A r)^T ; riding rows: (A w1)^T, (A w2)^T
+  real zt[kHalfSlots];
+  {
+    r4 acc[NT];
+    strip_zero(acc);
+    half_mul<KS, H>(r, lr, lq, y, acc);
+    half_reduce<KS, H>(exch, wave, lane, acc, zt);
+  }
+  const real aw = zt[RS];   // half 1: (A w1)[col] in the lanes lq == 0, (A w2)[col] in lq == 1
+  // r^T + t^T (A r)^T (:64) and t^T A^T (:67)
+  real rn[kHalfSlots], tn[kHalfSlots];
+  {
+    r4 acc[NT];
+    strip_zero(acc);
+    half_mul<KS, H>(t, lr, lq, zt, acc);   // (only the k-step slots of zt are operands)
+    half_reduce<KS, H>(exch, wave, lane, acc, rn);
+#pragma unroll
+    for (int j = 0; j < kHalfSlots; ++j) rn[j] = rh[j] + rn[j];
+  }
+  {
+    r4 acc[NT];
+    strip_zero(acc);
+    half_mul<KS, H>(t, lr, lq, y, acc);
+    half_reduce<KS, H>(exch, wave, lane, acc, tn);
+  }
+  __syncthreads();   // every wave is done reading r, t, P of this step
+  half_store_lds<KS, H>(r, lr, lq, c0, colok, rn);
+  half_store_lds<KS, H>(t, lr, lq, c0, colok, tn);
+  if (H && colok && lq == G::LQ0) {  // j0- += A w1 (:57)
+    const real jm = c.jm[col] + aw;
+    c.jm[col] = jm;
+    r[col + (N + 1) * LD] = jm;
+  }
+  if (H && colok && lq == G::LQ1) {  // j0+ = j1+ + A w2 (:60)
+    const real jp = c.jp[col] * expk + aw;
+    c.jp[col] = jp;
+    r[col + N * LD] = jp;
+  }
+  __syncthreads();
+  return true;
+}
+
+// nd doubling steps on half-strips; same contract as doubling_run_lean
+template <int KS>
+__device__ __forceinline__ real doubling_run_half(Ctx &c, real *exch, int nd, real expk, bool &bail) {
+  constexpr int N = 4 * KS, LD = StripGeom<KS>::LD;
+  bail = false;
+  if (nd == 0) return expk;
+  const int h = wg_wave() & 1;
+  real *r = c.r, *P = c.P;
+  for (int i = wg_tid(); i < N; i += kThreads) {
+    r[i + N * LD] = c.jp[i];
+    r[i + (N + 1) * LD] = c.jm[i];
+  }
+  __syncthreads();
+  for (int it = 0; it < nd; ++it) {
+    // (the two halves run the same barrier sequence; the series length is workgroup-uniform)
+    const bool ok = h ? doubling_step_half<KS, 1>(c, exch, expk) : doubling_step_half<KS, 0>(c, exch, expk);
+    if (!ok) {
+      bail = true;
+      return expk;
+    }
+    expk = expk * expk;
+  }
+  // apply_D! (doubling.jl:93-110) and apply_D_SFI! (:112-118): r-+ rows and j0- scaled by sg
+  for (int e = wg_tid(); e < N * N; e += kThreads) {
+    int i, j;
+    c.fd.split(e, i, j);
+    r[i + j * LD] *= c.sg[i];
+  }
+  for (int i = wg_tid(); i < N; i += kThreads) {
+    c.jm[i] *= c.sg[i];
+    r[i + N * LD] = 0.0; r[i + (N + 1) * LD] = 0.0; P[i + N * LD] = 0.0; P[i + (N + 1) * LD] = 0.0;
+  }
+  __syncthreads();
+  return expk;
+}
+
 // ScatteringInterface_11 on three buffers (see interaction_strip for the algebra).  Returns false, nothing stored, if the series
 // is too long.  Ends with a barrier.
 template <int KS>
 __device__ __forceinline__ bool interaction_strip_lean(Ctx &c, const CompPtrs &g) {
   using G = StripGeom<KS>;
   constexpr int N = G::N, NT = G::NT, LD = G::LD, NN = N * N;
-  static_assert(kWaves == 4 && NT == 3, "lean image: 4-wave build, 3 x 3 tiles");
+  static_assert(NT == 3 && kWaves > NT, "lean images: 3 x 3 tiles, at least one wave without a strip");
   const int lane = wg_lane(), wave = wg_wave(), lr = lane & 15, lq = lane >> 4;
   const int c0 = 16 * wave, col = c0 + lr;
   const bool strip = wave < NT, colok = col < N;
@@ -161,7 +388,8 @@ __device__ __forceinline__ bool interaction_strip_lean(Ctx &c, const CompPtrs &g
   const unsigned mask = strip_sign_mask(c.sg, lq, N);
   // the two Horner loops (multiplier B^T in P) on the strip waves; the idle wave fetches T++ (+ J0+) into registers meanwhile
   r4 Y1[NT], Y2[NT];
-  constexpr int UT = (NN + 63) / 64;
+  constexpr int IL = 64 * (kWaves - NT), UT = (NN + IL - 1) / IL;  // lanes without a strip (4-wave build: one wave; lean6: three)
+  const int il = wg_tid() - 64 * NT;
   real vt[UT], vj = 0.0;
   if (strip) {
     strip_copy(Y2, W0);
@@ -185,27 +413,27 @@ __device__ __forceinline__ bool interaction_strip_lean(Ctx &c, const CompPtrs &g
   } else {
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
-      const int e = lane + u * 64;
+      const int e = il + u * IL;
       if (e < NN) {
         int i, j;
         c.fd.split(e, i, j);
         vt[u] = MOM_NT_LOAD(g.T_pp + i + j * G::CP);
       }
     }
-    if (lane < N) vj = g.J0p[lane];
+    if (il < N) vj = g.J0p[il];
   }
   __syncthreads();   // every strip wave is done with B
   if (!strip) {      // P = T++ ; riding row: column N = J0+
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
-      const int e = lane + u * 64;
+      const int e = il + u * IL;
       if (e < NN) {
         int i, j;
         c.fd.split(e, i, j);
         P[i + j * LD] = vt[u];
       }
     }
-    if (lane < N) P[lane + N * LD] = vj;
+    if (il < N) P[il + N * LD] = vj;
   }
   __syncthreads();
   if (strip) {
@@ -277,7 +505,8 @@ __global__ void __launch_bounds__(kThreads, MOM_LEAN_WAVES) k_layer_lean(const L
   __syncthreads();
   load_streams(c, a.q);
   __syncthreads();
-  real *lay = mom_smem + 3 * mat_elems(N) + lean_vec_reals(N);
+  real *exch = mom_smem + 3 * mat_elems(N) + lean_vec_reals(N);   // lean6: the half-strip exchange slots
+  real *lay = exch + lean_exch_reals();
   const int nz = a.Nz_sweep;
   const int LW = 3 + a.K, LZ = kLeanLay / LW;
   for (size_t pt = blockIdx.x; pt < total; pt += gridDim.x) {
@@ -307,7 +536,8 @@ __global__ void __launch_bounds__(kThreads, MOM_LEAN_WAVES) k_layer_lean(const L
       ZMix zmp{as_global(a.Zmp) + NNs * a.K * mrel, ls + 3, a.K, N};
       elemental_build(c, a.q, m, nd, tau_sum, dtau, varpi, zpp, zmp);
       bool bail;
-      expk = doubling_run_lean<KS>(c, nd, expk, bail);
+      if constexpr (kLean6) expk = doubling_run_half<KS>(c, exch, nd, expk, bail);
+      else expk = doubling_run_lean<KS>(c, nd, expk, bail);
       if (!bail) {
         if (first) {
           store_added_as_composite(c, g);

@@ -303,6 +303,10 @@ hipError_t mom_strip9_launch_lean(const void *layer_args, int grid, hipStream_t 
 hipError_t mom_strip10_launch_lean(const void *layer_args, int grid, hipStream_t st);
 size_t mom_strip9_lean_lds_bytes(int ns);
 size_t mom_strip10_lean_lds_bytes(int ns);
+hipError_t mom6_lean9_launch(const void *layer_args, int grid, hipStream_t st);        // momcore_lean6.hip: the six-wave lean image
+hipError_t mom6_lean10_launch(const void *layer_args, int grid, hipStream_t st);
+size_t mom6_lean9_lds_bytes(int ns);
+size_t mom6_lean10_lds_bytes(int ns);
 hipError_t mom_strip11_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom4_strip11_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);  // 4-wave build of N = 44
 hipError_t mom_strip13_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
@@ -403,7 +407,9 @@ struct mom_handle {
   double *d_ms_out = nullptr;  // [2][nVza*nS*S*nSensors]
   size_t ms_out_cap = 0;
   int opt_pad = 1;         // scene-level path: pad the operator edge to the next strip-chained kernel size (strip_pad)
-  int opt_lean = 1;        // N = 36, 40: the lean 4-wave strip image (three workgroups per CU) + the full image's resume launch
+  int opt_lean = 1;        // N = 36, 40: 1 = the four-wave lean strip image (three workgroups per CU), 2 = the six-wave one (half-strip
+                           // doubling chains, two per CU: measured slower, profiles/r05_mid_ab.txt), each followed by the full image's
+                           // resume launch; 0 = the full image only
   int *d_resume = nullptr; // resume[unit] of the lean image (mom_lean.hpp)
   size_t resume_cap = 0;
   int Nk = 0;              // operator edge the scene-level kernels of the full problem run with (>= N)
@@ -1442,9 +1448,12 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
             h->resume_cap = units;
           }
           a.resume = h->d_resume;
-          static const int lean_per_cu = getenv("MOM_LEAN_PER_CU") ? atoi(getenv("MOM_LEAN_PER_CU")) : 3;  // (experiments)
-          const int gridl = (int)std::min<size_t>(units, (size_t)std::max(lean_per_cu, 1) * h->num_cu);
-          HIPCHK(h, (q.N == 40 ? mom_strip10_launch_lean : mom_strip9_launch_lean)(&a, gridl, h->stream));
+          const bool six = h->opt_lean >= 2 && (q.N == 40 ? mom6_lean10_lds_bytes(ns_tab) : mom6_lean9_lds_bytes(ns_tab)) > 0;
+          static const int lean_per_cu = getenv("MOM_LEAN_PER_CU") ? atoi(getenv("MOM_LEAN_PER_CU")) : 0;  // (experiments)
+          const int per_cu = lean_per_cu > 0 ? lean_per_cu : (six ? 2 : 3);
+          const int gridl = (int)std::min<size_t>(units, (size_t)per_cu * h->num_cu);
+          if (six) HIPCHK(h, (q.N == 40 ? mom6_lean10_launch : mom6_lean9_launch)(&a, gridl, h->stream));
+          else HIPCHK(h, (q.N == 40 ? mom_strip10_launch_lean : mom_strip9_launch_lean)(&a, gridl, h->stream));
           h->launches++;
         }
         HIPCHK(h, (q.N == 44 ? mom4_strip11_launch_layer : q.N == 40 ? mom_strip10_launch_layer : mom_strip9_launch_layer)(

@@ -142,14 +142,15 @@ def test_lean_strip_image_and_resume(rtamd, cref, nS, lt, N, thick):
     the lean 4-wave strip image (three operator buffers, three workgroups per CU; csrc/mom_lean.hpp) followed by the full
     image's resume launch.  Thin layers: every unit finishes in the lean image.  Thick layers (aerosol optical depth 2: series
     beyond 12 terms in the late doubling steps and the interactions): the lean workgroup leaves the unit at that layer and the
-    full image redoes the layer and finishes the unit.  Either way the spectra are BITWISE those of the full image alone (the
-    chains perform the same operations in the same order) and agree with the oracle."""
+    full image redoes the layer and finishes the unit.  The four-wave lean image (MOM_OPT_LEAN = 1) is BITWISE the full image (the
+    chains perform the same operations in the same order); the six-wave one (= 2, default: half-strip doubling chains) agrees with
+    the oracle at the suite's tolerance."""
     kw = dict(aerosol_total=2.0, aerosol_p0=600.0, aerosol_σp=200.0, absorption=False) if thick else dict(aerosol_total=0.3)
     m = rtamd.scenes.make_scene(nS, lt, 6, 40, seed=11 * nS + lt, **kw)
     sc = rtamd.prepare_scene(m)
     assert sc.N == N
     out = {}
-    for lean in (1, 0):
+    for lean in (2, 1, 0):
         with rtamd.corert.make_handle(m) as h:
             h.set_option(rtamd._lib.MOM_OPT_LEAN, lean)
             R, T = rtamd.corert.run_scene(h, sc)
@@ -157,12 +158,14 @@ def test_lean_strip_image_and_resume(rtamd, cref, nS, lt, N, thick):
             R2, T2 = rtamd.corert.run_scene(h, sc)                       # the resume table is reused: same answer again
             assert np.array_equal(R, R2) and np.array_equal(T, T2)
     for k in range(5):
-        assert np.array_equal(out[1][k], out[0][k]), f"lean vs full image, output {k}"
-    assert out[1][5] > out[0][5]                                         # the lean launch + the resume launch
+        assert np.array_equal(out[1][k], out[0][k]), f"four-wave lean vs full image, output {k}"
+    assert out[1][5] > out[0][5] and out[2][5] > out[0][5]               # the lean launch + the resume launch
     Rr, Tr = _oracle(cref, m)
     tol = helpers.stokes_rtol(sc.ndoubl)
-    helpers.assert_stokes_close(out[1][0], Rr, rtol=tol, what="R lean")
-    helpers.assert_stokes_close(out[1][1], Tr, rtol=tol, what="T lean")
+    for lean in (2, 1):   # the six-wave image sums a contraction in two halves: equal to the oracle's tolerance, not bitwise
+        helpers.assert_stokes_close(out[lean][0], Rr, rtol=tol, what=f"R lean={lean}")
+        helpers.assert_stokes_close(out[lean][1], Tr, rtol=tol, what=f"T lean={lean}")
+    helpers.assert_stokes_close(out[2][2], out[0][2], rtol=tol, what="hdr six-wave lean vs full")
 
 
 def test_strip_chains_thick_layers_fall_back(rtamd, cref):
