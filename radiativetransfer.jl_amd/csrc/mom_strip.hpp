@@ -327,7 +327,31 @@ __device__ __forceinline__ void doubling_step_strip(Ctx &c, int p, real expk, co
   // interaction's T++ block (+ J0+ as its riding column) into Q, which no strip step uses
   // (4-wave build: the idle waves are the ones without a strip, slot >= NT -- on a SIMD of their own, no chain wave to disturb)
   constexpr int kIdle0 = (kWaves == 8) ? 4 : NT;
+#if MOM_QPREFETCH == 2
+  // r5 variant: the idle waves REQUEST T++ during the chains and keep it in registers; the LDS stores into Q happen after the
+  // chain barrier, next to the strip waves' write-back (r4's variant stored during the chains and lost 1.3 % to the LDS /
+  // issue slots it took from the chain wave of the same SIMD)
+  constexpr int kPreTH = (kIdle0 < kWaves) ? 64 * (kWaves - kIdle0) : 64, kPreU = (N * N + kPreTH - 1) / kPreTH;
+  real pvt[kPreU], pvj = 0.0;
+  const bool prefetcher = pre != nullptr && kIdle0 < kWaves && (kWaves == 8 ? (wave >> 2) == 1 : slot >= NT);
+  const int ptid = (kWaves == 8) ? wg_tid() - 256 : 64 * (slot - NT) + lane;
+  if (prefetcher) {
+    constexpr int TH = kPreTH;
+#pragma unroll
+    for (int u = 0; u < kPreU; ++u) {
+      const int e = ptid + u * TH;
+      if (e < N * N) {
+        int i, j;
+        c.fd.split(e, i, j);
+        pvt[u] = MOM_NT_LOAD(pre->T_pp + i + j * G::CP);
+      }
+    }
+    if (ptid < N) pvj = pre->J0p[ptid];
+  }
+  if (false) {
+#else
   if (pre != nullptr && kIdle0 < kWaves && (kWaves == 8 ? (wave >> 2) == 1 : slot >= NT)) {
+#endif
     constexpr int NN = N * N, U = 8, TH = 64 * (kWaves - kIdle0);
     real *Q = c.Q;
     const int tid4 = (kWaves == 8) ? wg_tid() - 256 : 64 * (slot - NT) + lane;
@@ -358,6 +382,22 @@ __device__ __forceinline__ void doubling_step_strip(Ctx &c, int p, real expk, co
   MOM_STAMP(71);
   __syncthreads();
   MOM_STAMP(72);
+#if defined(MOM_QPREFETCH) && MOM_QPREFETCH == 2
+  if (prefetcher) {
+    constexpr int TH = kPreTH;
+    real *Q = c.Q;
+#pragma unroll
+    for (int u = 0; u < kPreU; ++u) {
+      const int e = ptid + u * TH;
+      if (e < N * N) {
+        int i, j;
+        c.fd.split(e, i, j);
+        Q[i + j * LD] = pvt[u];
+      }
+    }
+    if (ptid < N) Q[ptid + N * LD] = pvj;
+  }
+#endif
   if (active) {
     strip_store_lds<KS>(r, lr, lq, c0, colok, Rn);
     strip_store_lds<KS>(t, lr, lq, c0, colok, Tn);
