@@ -1535,9 +1535,11 @@ __global__ void k_unpack(double *nat, const double *dev, int rows, int cols, int
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 #ifdef MOMR_BIG_TU
+#include "mom_rrs_wg.hpp"
 }  // namespace momr_big
 // which: 0 k_el_point, 1 k_dbl_point, 2 k_int_point, 3 k_dbl_pair (v0 = fused elemental, v1 = mode), 4 k_int_pair (v0 = surface,
-// v1 = derived +- / -- blocks); nt = 3 or 4; args: the KArgs of the caller (layout-identical in both namespaces)
+// v1 = derived +- / -- blocks), 5 k_dbl_pair_wg (workgroup per pair, mom_rrs_wg.hpp; grid = workgroups); nt = 3 or 4; args: the
+// KArgs of the caller (layout-identical in both namespaces)
 hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, void *stream, const void *args, int iface) {
   using namespace momr_big;
   const KArgs a = *reinterpret_cast<const KArgs *>(args);
@@ -1565,8 +1567,24 @@ hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, voi
       if (v0) BIG_NT((k_int_pair3<true, false>), (k_int_pair4<true, false>), a, iface);
       else if (v1) BIG_NT((k_int_pair3<false, true>), (k_int_pair4<false, true>), a, iface);
       else BIG_NT((k_int_pair3<false, false>), (k_int_pair4<false, false>), a, iface);
+    case 5: {
+      const dim3 blw(64 * nt);
+      const size_t ldw = (nt == 3) ? wg_lds_bytes<3>(4) : wg_lds_bytes<4>(4);
+#define WG_GO(KERN)                                                                                                            \
+  do {                                                                                                                         \
+    const hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void *>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldw); \
+    if (e__ != hipSuccess) return e__;                                                                                         \
+    hipLaunchKernelGGL(KERN, gr, blw, ldw, st, a);                                                                             \
+    return hipGetLastError();                                                                                                  \
+  } while (0)
+#define WG_DBL(F, M) do { if (nt == 3) WG_GO((k_dbl_pair_wg3<F, M>)); else WG_GO((k_dbl_pair_wg4<F, M>)); } while (0)
+      if (v0) { if (v1 == 0) WG_DBL(true, 0); else if (v1 == 1) WG_DBL(true, 1); else WG_DBL(true, 2); }
+      else { if (v1 == 0) WG_DBL(false, 0); else if (v1 == 1) WG_DBL(false, 1); else WG_DBL(false, 2); }
+#undef WG_DBL
+    }
     default: return hipErrorInvalidValue;
   }
+#undef WG_GO
 #undef BIG_NT
 #undef BIG_GO
 }
@@ -1732,6 +1750,11 @@ hipError_t timing_read(State *s, double *ms, int *launches) {
   return hipSuccess;
 }
 
+// 32 < N <= 64: the pair kernels as one workgroup per pair (mom_rrs_wg.hpp); MOM_RRS_WG=0 selects the wave-per-pair bodies
+static bool wg_pairs() {
+  static const bool on = !(getenv("MOM_RRS_WG") && atoi(getenv("MOM_RRS_WG")) == 0);
+  return on;
+}
 static int grid_points(const State *s) { return std::max(1, std::min((s->S + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 8)); }
 static int grid_pairs(const State *s) {
   const size_t np = (size_t)(s->n1_hi - s->n1_lo) * s->nR;
@@ -1831,7 +1854,11 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
 #define DBL_PAIR_F(NT_) do { if (a.fuse_el) DBL_PAIR_M(NT_, true); else DBL_PAIR_M(NT_, false); } while (0)
       if (s->N <= 16) DBL_PAIR_F(1);
       else if (s->N <= 32) DBL_PAIR_F(2);
-      else RCHK(momr_big_launch(3, s->N <= 48 ? 3 : 4, a.fuse_el ? 1 : 0, mode, gr.x, (void *)s->stream, &a, 0));
+      else if (wg_pairs()) {  // one workgroup per pair (mom_rrs_wg.hpp)
+        const size_t np = (size_t)(s->n1_hi - s->n1_lo) * s->nR;
+        RCHK(momr_big_launch(5, s->N <= 48 ? 3 : 4, a.fuse_el ? 1 : 0, mode, (unsigned)std::max<size_t>(1, std::min<size_t>(np, 256 * 16)),
+                             (void *)s->stream, &a, 0));
+      } else RCHK(momr_big_launch(3, s->N <= 48 ? 3 : 4, a.fuse_el ? 1 : 0, mode, gr.x, (void *)s->stream, &a, 0));
 #undef DBL_PAIR_F
 #undef DBL_PAIR_M
 #undef DBL_PAIR

@@ -2,6 +2,7 @@
 """Timing of the multi-tile RRS kernels: mom_rt_run_rrs on seeded scenes of edge 24, 30, 32 (2 x 2 tiles), 42 (3 x 3) and 56,
 60 (4 x 4: scratch-resident operators), 40 Raman offsets, corrected switch position.
 usage: python tools/bench_rrs_nt2.py > profiles/rNN_rrs_nt2.txt"""
+import os
 import sys
 import time
 from pathlib import Path
@@ -24,6 +25,8 @@ for nS, lt, vza, S in ((4, 7, (0.0,), 2000), (3, 13, (0.0, 30.0), 2000), (4, 9, 
                 rrs_strict_reference=False)
     model = rt._with_cabannes(RS, m)
     sc = rtamd.prepare_scene(model)
+    if os.environ.get("MOM_NT_ONLY") and str(sc.N) not in os.environ["MOM_NT_ONLY"].split(","):   # e.g. MOM_NT_ONLY=42,56,60
+        continue
     Zr_pp, Zr_mp = rt.raman_z(RS, model)
     with rt.make_handle(model) as h:
         h.set_option(rtamd._lib.MOM_OPT_STRIP_PAD, 0)
