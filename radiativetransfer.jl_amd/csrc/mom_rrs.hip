@@ -1538,7 +1538,7 @@ __global__ void k_unpack(double *nat, const double *dev, int rows, int cols, int
 #include "mom_rrs_wg.hpp"
 }  // namespace momr_big
 // which: 0 k_el_point, 1 k_dbl_point, 2 k_int_point, 3 k_dbl_pair (v0 = fused elemental, v1 = mode), 4 k_int_pair (v0 = surface,
-// v1 = derived +- / -- blocks), 5 k_dbl_pair_wg (workgroup per pair, mom_rrs_wg.hpp; grid = workgroups); nt = 3 or 4; args: the
+// v1 = derived +- / -- blocks), 5 k_dbl_pair_wg, 6 k_int_pair_wg (workgroup per pair, mom_rrs_wg.hpp; grid = workgroups); nt = 3 or 4; args: the
 // KArgs of the caller (layout-identical in both namespaces)
 hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, void *stream, const void *args, int iface) {
   using namespace momr_big;
@@ -1554,6 +1554,15 @@ hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, voi
     return hipGetLastError();                                                                                                  \
   } while (0)
 #define BIG_NT(KERN3, KERN4, ...) do { if (nt == 3) BIG_GO(KERN3, __VA_ARGS__); else BIG_GO(KERN4, __VA_ARGS__); } while (0)
+  const dim3 blw(64 * nt);
+  const size_t ldw = (nt == 3) ? wg_lds_bytes<3>(4) : wg_lds_bytes<4>(4);
+#define WG_GO(KERN)                                                                                                            \
+  do {                                                                                                                         \
+    const hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void *>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldw); \
+    if (e__ != hipSuccess) return e__;                                                                                         \
+    hipLaunchKernelGGL(KERN, gr, blw, ldw, st, a);                                                                             \
+    return hipGetLastError();                                                                                                  \
+  } while (0)
   switch (which) {
     case 0: BIG_NT(k_el_point<3>, k_el_point<4>, a);
     case 1: BIG_NT(k_dbl_point<3>, k_dbl_point<4>, a);
@@ -1568,19 +1577,17 @@ hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, voi
       else if (v1) BIG_NT((k_int_pair3<false, true>), (k_int_pair4<false, true>), a, iface);
       else BIG_NT((k_int_pair3<false, false>), (k_int_pair4<false, false>), a, iface);
     case 5: {
-      const dim3 blw(64 * nt);
-      const size_t ldw = (nt == 3) ? wg_lds_bytes<3>(4) : wg_lds_bytes<4>(4);
-#define WG_GO(KERN)                                                                                                            \
-  do {                                                                                                                         \
-    const hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void *>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldw); \
-    if (e__ != hipSuccess) return e__;                                                                                         \
-    hipLaunchKernelGGL(KERN, gr, blw, ldw, st, a);                                                                             \
-    return hipGetLastError();                                                                                                  \
-  } while (0)
 #define WG_DBL(F, M) do { if (nt == 3) WG_GO((k_dbl_pair_wg3<F, M>)); else WG_GO((k_dbl_pair_wg4<F, M>)); } while (0)
       if (v0) { if (v1 == 0) WG_DBL(true, 0); else if (v1 == 1) WG_DBL(true, 1); else WG_DBL(true, 2); }
       else { if (v1 == 0) WG_DBL(false, 0); else if (v1 == 1) WG_DBL(false, 1); else WG_DBL(false, 2); }
 #undef WG_DBL
+    }
+    case 6: {  // ScatteringInterface_11 only
+#define WG_INT(SF, DV) do { if (nt == 3) WG_GO((k_int_pair_wg3<SF, DV>)); else WG_GO((k_int_pair_wg4<SF, DV>)); } while (0)
+      if (v0) WG_INT(true, false);
+      else if (v1) WG_INT(false, true);
+      else WG_INT(false, false);
+#undef WG_INT
     }
     default: return hipErrorInvalidValue;
   }
@@ -1856,7 +1863,10 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
       else if (s->N <= 32) DBL_PAIR_F(2);
       else if (wg_pairs()) {  // one workgroup per pair (mom_rrs_wg.hpp)
         const size_t np = (size_t)(s->n1_hi - s->n1_lo) * s->nR;
-        RCHK(momr_big_launch(5, s->N <= 48 ? 3 : 4, a.fuse_el ? 1 : 0, mode, (unsigned)std::max<size_t>(1, std::min<size_t>(np, 256 * 16)),
+        // persistent workgroups, one round of the chip (two per CU at 3 x 3 tiles): each walks ~np / grid pairs, the next one prefetched
+        static const int mult = getenv("MOM_RRS_WG_GRID") ? std::max(1, atoi(getenv("MOM_RRS_WG_GRID"))) : 1;  // (experiments)
+        const size_t res = (size_t)256 * (s->N <= 48 ? 2 : 1) * mult;
+        RCHK(momr_big_launch(5, s->N <= 48 ? 3 : 4, a.fuse_el ? 1 : 0, mode, (unsigned)std::max<size_t>(1, std::min<size_t>(np, res)),
                              (void *)s->stream, &a, 0));
       } else RCHK(momr_big_launch(3, s->N <= 48 ? 3 : 4, a.fuse_el ? 1 : 0, mode, gr.x, (void *)s->stream, &a, 0));
 #undef DBL_PAIR_F
@@ -1943,7 +1953,12 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
   } while (0)
     if (s->N <= 16) INT_PAIR(1);
     else if (s->N <= 32) INT_PAIR(2);
-    else RCHK(momr_big_launch(4, s->N <= 48 ? 3 : 4, with_surface ? 1 : 0, a.derive_pm ? 1 : 0, gr.x, (void *)s->stream, &a, iface));
+    else if (wg_pairs() && iface == 3) {  // one workgroup per pair (mom_rrs_wg.hpp)
+      static const int mult = getenv("MOM_RRS_WG_GRID") ? std::max(1, atoi(getenv("MOM_RRS_WG_GRID"))) : 1;  // (experiments)
+      const size_t np = (size_t)(s->n1_hi - s->n1_lo) * s->nR, res = (size_t)256 * (s->N <= 48 ? 2 : 1) * mult;
+      RCHK(momr_big_launch(6, s->N <= 48 ? 3 : 4, with_surface ? 1 : 0, a.derive_pm ? 1 : 0,
+                           (unsigned)std::max<size_t>(1, std::min<size_t>(np, res)), (void *)s->stream, &a, iface));
+    } else RCHK(momr_big_launch(4, s->N <= 48 ? 3 : 4, with_surface ? 1 : 0, a.derive_pm ? 1 : 0, gr.x, (void *)s->stream, &a, iface));
 #undef INT_PAIR
     RCHK(hipGetLastError());
     RCHK(tick(s, TK_INT_PAIR, false));

@@ -21,6 +21,12 @@
 // The order of the products and of every accumulation is that of dbl_pair_body / int_pair_body: the results are bitwise those
 // of the one-wave kernels (tests/test_gpu_rrs.py compares both, MOM_RRS_WG=0 selects the old ones).
 #pragma once
+#ifndef MOMR_WG_PREFETCH
+#define MOMR_WG_PREFETCH 0   // measured: no gain at NT = 4, slower at NT = 3 (profiles/r05_rrs_wg_ab.txt)
+#endif
+#ifndef MOMR_WG3_WPE
+#define MOMR_WG3_WPE 2   // waves per SIMD the 3-wave image is compiled for (2: two workgroups per CU)
+#endif
 
 template <int NT>
 struct Strip {
@@ -81,6 +87,16 @@ __device__ __forceinline__ void spublish(const Geo &g, int w, double *M, const S
   for (int a = 0; a < NT; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) q[a * NT * kTileDoubles + 4 * r * kTileLd] = X.t[a][r];
+}
+template <int NT>
+__device__ __forceinline__ Strip<NT> sread(const Geo &g, int w, const double *M) {  // the wave's own strip back from LDS
+  Strip<NT> X;
+  const double *q = M + w * kTileDoubles + g.lq * kTileLd + g.lr;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X.t[a][r] = q[a * NT * kTileDoubles + 4 * r * kTileLd];
+  return X;
 }
 // register s of tile (tk, ti) of the LDS matrix M (TR = false) or of its transpose (TR = true) in the C / A-operand layout
 template <int NT, bool TR>
@@ -248,6 +264,33 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
   const size_t span = (size_t)(a.n1_hi - a.n1_lo), npairs = span * a.nR;
   auto sgn_i = [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; };
   auto sgn_ij = [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; };
+  // The pair's own two blocks (the HBM streams) and the two strips its first products need, r[n0]^T and r[n1], are requested
+  // while the LAST two products of the previous pair run (a workgroup keeps one wave per SIMD, or two at NT = 3: little else
+  // hides their latency); more than these four strips does not fit the register file.  A pair off the grid is not prefetched.
+  struct Top {
+    Strip<NT> a_s, b_s, r0_s, r1_s;
+    double Jp, Jm, e1;
+    bool have;
+  } nx;
+  nx.have = false;
+  auto fetch = [&](size_t q, Top &t) {
+    t.have = false;
+    if (q >= npairs) return;
+    const int qn1 = a.n1_lo + (int)(q % span), qdn = (int)(q / span);
+    const int qn0 = qn1 + a.off[qdn];
+    if (qn0 < 0 || qn0 >= a.S) return;
+    const size_t qu = (size_t)qn1 + (size_t)a.S * qdn, q4 = NN * qu, q3 = VS * qu;
+    if (!FUSE) {
+      t.a_s = sload<NT>(g, w, a.ie_a[R_MP] + q4);
+      t.b_s = sload<NT>(g, w, a.ie_a[T_PP] + q4);
+      t.Jp = a.ie_a[J0P][q3 + cw];
+      t.Jm = a.ie_a[J0M][q3 + cw];
+    }
+    t.r0_s = sload<NT>(g, w, a.sm[SM_RT] + NN * qn0);
+    t.r1_s = sload<NT>(g, w, a.a_cur[R_MP] + NN * qn1);
+    t.e1 = a.expk_cur[qn1];
+    t.have = true;
+  };
   for (size_t p = blockIdx.x; p < npairs; p += gridDim.x) {
     const int n1 = a.n1_lo + (int)(p % span), dn = (int)(p / span);
     const int n0 = n1 + a.off[dn];
@@ -280,17 +323,14 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
       continue;
     }
     const size_t m1 = NN * n1, m0 = NN * n0, v0 = VS * n0;
-    Strip<NT> a_s, b_s;
-    double Jp, Jm;
-    if (!FUSE) {
-      a_s = sload<NT>(g, w, a.ie_a[R_MP] + o4);
-      b_s = sload<NT>(g, w, a.ie_a[T_PP] + o4);
-      Jp = a.ie_a[J0P][o3 + cw];
-      Jm = a.ie_a[J0M][o3 + cw];
-    }
-    const Strip<NT> r0_s = sload<NT>(g, w, a.sm[SM_RT] + m0), r1_s = sload<NT>(g, w, a.a_cur[R_MP] + m1);
-    const Strip<NT> gt0_s = sload<NT>(g, w, a.sm[SM_GT] + m0), ttgp1_s = sload<NT>(g, w, a.sm[SM_TTGP] + m1);
-    const double e1 = a.expk_cur[n1];
+    if (!nx.have) fetch(p, nx);  // first pair of the workgroup, or the pair after one off the grid
+    Strip<NT> a_s = nx.a_s, b_s = nx.b_s;
+    double Jp = nx.Jp, Jm = nx.Jm;
+    const Strip<NT> r0_s = nx.r0_s, r1_s = nx.r1_s;
+    const double e1 = nx.e1;
+    nx.have = false;
+    // Register economy: a strip that has a copy in LDS is READ BACK from there where it is needed again (a, b, bn), and the
+    // strips / vectors from global memory are requested one or two products before their first use, not at the top.
     const double *jp0 = STRICT ? a.jpseq + v0 + VS * a.S * dn : a.a_cur[J0P] + v0;
     const Vec<NT> j1m0 = loadR<NT>(g, a.sv[SV_J1M] + v0), jp0R = loadR<NT>(g, jp0);
     const Vec<NT> tm1 = loadR<NT>(g, a.sv[SV_TMP1] + v0), tm2 = loadR<NT>(g, a.sv[SV_TMP2] + v0);
@@ -301,24 +341,23 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     spublish<NT>(g, w, S_b, b_s);
     spublish<NT>(g, w, S_g, r0_s);
     vput(g, w, vb0, J1m);
+    // the products of the pair's own blocks with the source vectors of n0                                         :61-89
+    const double a_j1m = smv<NT>(g, a_s, j1m0);  // ier j1-[n0]
+    const double a_jp = smv<NT>(g, a_s, jp0R);   // ier j0+[n0]
+    const double b1 = smv<NT>(g, b_s, tm1);      // iet++ tmp1
+    const double b2 = STRICT ? smv<NT>(g, sload<NT>(g, w, a.ie_a[T_MM] + o4), tm2)  // D5: iet-- as the array holds it
+                             : smv<NT>(g, b_s, tm2);
+    const Strip<NT> gt0_s = sload<NT>(g, w, a.sm[SM_GT] + m0), ttgp1_s = sload<NT>(g, w, a.sm[SM_TTGP] + m1);
     wg_sync();
     // X = ier r0 + r1 ier
     Strip<NT> X_s = sTNacc<NT, false>(g, S_g, a_s, szeros<NT>());  // U = r0_c
     X_s = sTNacc<NT, true>(g, S_a, r1_s, X_s);                     // U = a_c = (a_t)^T
+    const double X1 = smv<NT>(g, X_s, tm1), X2 = smv<NT>(g, X_s, tm2);
     wg_sync();  // r0 has been read by everybody
     spublish<NT>(g, w, S_x, X_s);
     spublish<NT>(g, w, S_g, gt0_s);
-    // the late operands: requested here, consumed after the next two products
-    const Strip<NT> gr0_s = sload<NT>(g, w, a.sm[SM_GR] + m0), t0_s = sload<NT>(g, w, a.sm[SM_TT] + m0);
-    const Strip<NT> ttgpr1_s = sload<NT>(g, w, a.sm[SM_TTGPR] + m1);
-    // ---- sources                                                                                               :61-89
+    // ---- sources
     {
-      const double a_j1m = smv<NT>(g, a_s, j1m0);  // ier j1-[n0]
-      const double a_jp = smv<NT>(g, a_s, jp0R);   // ier j0+[n0]
-      const double X1 = smv<NT>(g, X_s, tm1), X2 = smv<NT>(g, X_s, tm2);
-      const double b1 = smv<NT>(g, b_s, tm1);      // iet++ tmp1
-      const double b2 = STRICT ? smv<NT>(g, sload<NT>(g, w, a.ie_a[T_MM] + o4), tm2)  // D5: iet-- as the array holds it
-                               : smv<NT>(g, b_s, tm2);
       const double uu = (Jp + smv<NT>(g, r1_s, vget<NT>(g, vb0))) + (a_j1m + X1);
       vput(g, w, vb1, uu);
       wg_sync();  // (also: X and (G t)[n0] are in LDS)
@@ -337,24 +376,29 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
       }
     }
     // ---- operators                                                                                              :98-125
-    const Strip<NT> Y_s = sTNacc<NT, false>(g, S_x, gt0_s, szeros<NT>());  // Y_c = X G t[n0]          (U = X_t)
+    const Strip<NT> gr0_s = sload<NT>(g, w, a.sm[SM_GR] + m0);              // consumed three products later
+    const Strip<NT> Y_s = sTNacc<NT, false>(g, S_x, sread<NT>(g, w, S_g), szeros<NT>());  // Y_c = X G t[n0]   (U = X_t)
     wg_sync();                                                              // X has been read
     spublish<NT>(g, w, S_x, Y_s);
     wg_sync();
     Strip<NT> bn_s = sTNacc_sum<NT>(g, S_b, S_x, ttgp1_s, szeros<NT>());    // tG (iet + Y)            (U = W_c = b_c + Y_c)
-    bn_s = sTNacc<NT, false>(g, S_g, b_s, bn_s);                            // + iet G t[n0]           (U = (G t)[n0]_c)
+    const Strip<NT> t0_s = sload<NT>(g, w, a.sm[SM_TT] + m0);               // consumed after three more products
+    bn_s = sTNacc<NT, false>(g, S_g, sread<NT>(g, w, S_b), bn_s);           // + iet G t[n0]           (U = (G t)[n0]_c)
     wg_sync();                                                              // b and (G t)[n0] have been read
     spublish<NT>(g, w, S_b, bn_s);
     spublish<NT>(g, w, S_g, gr0_s);
     wg_sync();
     Strip<NT> Q_s = sTNacc<NT, false>(g, S_g, bn_s, szeros<NT>());          // iet(new) G r[n0]        (U = (G r)[n0]_c)
+    const Strip<NT> ttgpr1_s = sload<NT>(g, w, a.sm[SM_TTGPR] + m1);
     Q_s = sTNacc<NT, true>(g, S_a, ttgp1_s, Q_s);                           // + tG ier                (U = a_c)
     wg_sync();                                                              // (G r)[n0] has been read
     spublish<NT>(g, w, S_g, t0_s);
     wg_sync();
+    if (MOMR_WG_PREFETCH) fetch(p + gridDim.x, nx);
     Strip<NT> an_s = sTNacc_sum<NT>(g, S_b, S_x, ttgpr1_s, szeros<NT>());   // (iet(new) + Y) ...      (U = V_c = bn_c + Y_c)
     an_s = sTNacc<NT, false>(g, S_g, Q_s, an_s);                            // + t[n0]-side product    (U = t0_c)
-    an_s = sadd<NT>(a_s, an_s);
+    an_s = sadd<NT>(sread<NT>(g, w, S_a), an_s);
+    bn_s = sread<NT>(g, w, S_b);
     if (fuseD) {  // apply_D_matrix_IE!, corrected indexing (D2)
       if (n > 1) smap<NT>(g, w, an_s, sgn_i);
       Strip<NT> apm = an_s, bmm = bn_s;
@@ -372,8 +416,160 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
   }
 }
 
-#define MOMR_WG_ATTR(NT_) __launch_bounds__(64 * NT_) __attribute__((amdgpu_waves_per_eu(1, (NT_ == 3 ? 2 : 1))))
+// column strip w of the _c form (the transpose of what sload returns) straight from global memory: lane groups read 32-byte
+// pieces of 16 lines per instruction, the 4 NT instructions of a strip consume every line of the strip's 8 NT x 128 B region
+template <int NT>
+__device__ __forceinline__ Strip<NT> sloadT(const Geo &g, int w, const double *p) {
+  Strip<NT> X;
+  const double *q = p + g.lq + (size_t)(16 * NT) * (16 * w + g.lr);
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X.t[a][r] = q[16 * a + 4 * r];
+  return X;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// interaction, ScatteringInterface_11, pair kernel, one workgroup of NT waves per pair (int_pair_body, iface == 3, in strips).
+// Four LDS matrices P, Q, R, T take the twelve left factors of the eighteen products in turn (in brackets: the slot):
+//   M1 = a Rpm0 + r1 E [a: P, r1: Q]      N1 = a Tpp0 + r1 C [P, Q]        A = ieT-- + M1 T01 [M1: P]
+//   ieR-+ += N1 T01 [N1: Q] + G1RT0 A [T]     ieT-- = bm^T T01 [bm: R, read transposed] + G1T0 A [P]
+//   M2 = E R0 [E: Q] + Rpm1 a^T [Rpm1: R]     N2 = E TMM0 [Q] + Rpm1 bm^T [R]     B = iet++ + M2 T21 [M2: P]
+//   ieR+- = ier+- + N2 T21 [N2: Q] + G2RT0 B [T]     ieT++ = C^T T21 [C: R, read transposed] + G2T0 B [P]
+// (written with the operand names of int_pair_body; every product in its order).  Right factors that are transposes of
+// blocks in memory (E^T, C^T, a^T, bm^T) are loaded as transposed strips (sloadT).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT, bool SURF, bool DERIVE>
+__device__ __forceinline__ void int_pair_wg(const KArgs &a) {
+  constexpr int MD = wg_mat_doubles<NT>();
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  Geo g;
+  g.lr = lane & 15;
+  g.lq = lane >> 4;
+  g.N = a.N;
+  g.xp = nullptr;
+  g.ipiv = nullptr;
+  double *S_p = reinterpret_cast<double *>(rrs_smem), *S_q = S_p + MD, *S_r = S_q + MD, *S_t = S_r + MD, *vb = S_t + MD;
+  double *vb0 = vb, *vb1 = vb + 16 * NT;
+  const int n = a.nS, cw = 16 * w + g.lr;
+  const size_t NN = (size_t)a.P * a.P, VS = a.P;
+  const size_t span = (size_t)(a.n1_hi - a.n1_lo), npairs = span * a.nR;
+  auto sgn_ij = [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; };
+  auto flip = [&](Strip<NT> X) {  // ier+- = sgn (.) ier-+, iet-- = sgn (.) iet++ (corrected D2); sgn is symmetric in (i, j)
+    if (n > 1) smap<NT>(g, w, X, sgn_ij);
+    return X;
+  };
+  for (size_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const int n1 = a.n1_lo + (int)(p % span), dn = (int)(p / span);
+    const int n0 = n1 + a.off[dn];
+    if (n0 < 0 || n0 >= a.S) continue;
+    const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = VS * u;
+    const size_t m1 = NN * n1, m0 = NN * n0, v0 = VS * n0;
+    const double *pa = a.ie_a[R_MP] + o4, *pbm = a.ie_a[DERIVE ? T_PP : T_MM] + o4;
+    // ---- stage 0: a -> P, r1 -> Q, bm -> R, G1RT0 -> T
+    const Strip<NT> a_s = SURF ? szeros<NT>() : sload<NT>(g, w, pa);
+    const Strip<NT> r1_s = sload<NT>(g, w, a.x[R_MP] + m1);
+    Strip<NT> bm_s = SURF ? szeros<NT>() : sload<NT>(g, w, pbm);
+    if (DERIVE && !SURF) bm_s = flip(bm_s);
+    const Strip<NT> g1rt_s = sload<NT>(g, w, a.sm[SI_G1RT] + m0);
+    const Strip<NT> Rpm0_s = sload<NT>(g, w, a.sm[SI_RPM] + m0), Tpp0_s = sload<NT>(g, w, a.sm[SI_TPP] + m0);
+    const double Jap = SURF ? 0.0 : a.ie_a[J0P][o3 + cw], Jam = SURF ? 0.0 : a.ie_a[J0M][o3 + cw];
+    const double Jcp = a.ie_c[C_J0P][o3 + cw], Jcm = a.ie_c[C_J0M][o3 + cw];
+    const double v1 = smv<NT>(g, a_s, loadR<NT>(g, a.c_cur[C_J0P] + v0));   // ier J0+[n0]
+    const double v2 = smv<NT>(g, r1_s, loadR<NT>(g, a.ie_c[C_J0P] + o3));   // r ieJ0+
+    const double uu1 = (v1 + v2) + Jam;
+    wg_sync();  // the previous pair has finished with the LDS matrices
+    spublish<NT>(g, w, S_p, a_s);
+    spublish<NT>(g, w, S_q, r1_s);
+    spublish<NT>(g, w, S_r, bm_s);
+    spublish<NT>(g, w, S_t, g1rt_s);
+    vput(g, w, vb0, uu1);
+    const Strip<NT> Ec_s = sloadT<NT>(g, w, a.ie_c[C_R_PM] + o4), Cc_s = sloadT<NT>(g, w, a.ie_c[C_T_PP] + o4);
+    wg_sync();
+    // A = T01 (ier R+-[n0] + r ieR+-) + ieT--                                                                     :252-262
+    Strip<NT> M1_s = sTNacc<NT, false>(g, S_p, Rpm0_s, szeros<NT>());
+    Strip<NT> N1_s = sTNacc<NT, false>(g, S_p, Tpp0_s, szeros<NT>());
+    const Strip<NT> T01_s = sload<NT>(g, w, a.sm[SI_T01] + m1);
+    M1_s = sTNacc<NT, false>(g, S_q, Ec_s, M1_s);
+    Strip<NT> A_s = sload<NT>(g, w, a.ie_c[C_T_MM] + o4);
+    N1_s = sTNacc<NT, false>(g, S_q, Cc_s, N1_s);
+    wg_sync();  // a and r have been read
+    spublish<NT>(g, w, S_p, M1_s);
+    spublish<NT>(g, w, S_q, N1_s);
+    wg_sync();
+    A_s = sTNacc<NT, false>(g, S_p, T01_s, A_s);
+    // ieJ0- += T01 (ier J0+[n0] + r ieJ0+ + ieJ0-(added)) + A G1 (j0-[n0] + r[n0] J0+[n0])                         :251-264
+    {
+      const double wv = smv<NT>(g, T01_s, vget<NT>(g, vb0)) + smv<NT>(g, A_s, loadR<NT>(g, a.sv[SVI_G1V] + v0));
+      if (g.lq == 0) a.ie_c[C_J0M][o3 + cw] = Jcm + wv;
+    }
+    // ieR-+ += T01 (ier T++[n0] + r ieT++) + A G1 r[n0] T++[n0];  ieT-- = T01 iet-- + A G1 t--[n0]                  :271-284
+    Strip<NT> Rm_s = sload<NT>(g, w, a.ie_c[C_R_MP] + o4);
+    const Strip<NT> g1t_s = sload<NT>(g, w, a.sm[SI_G1T] + m0);
+    Rm_s = sTNacc<NT, false>(g, S_q, T01_s, Rm_s);
+    Rm_s = sTNacc<NT, false>(g, S_t, A_s, Rm_s);
+    sstore<NT>(g, w, a.ie_c[C_R_MP] + o4, Rm_s);
+    // the operands of the second half (E as a left factor, R+-[n1], G2 R+-[n0] t--[n0])
+    const Strip<NT> E_s = sload<NT>(g, w, a.ie_c[C_R_PM] + o4), Rpm1_s = sload<NT>(g, w, a.c_cur[C_R_PM] + m1);
+    const Strip<NT> g2rt_s = sload<NT>(g, w, a.sm[SI_G2RT] + m0);
+    Strip<NT> F_s = sTNacc<NT, true>(g, S_r, T01_s, szeros<NT>());  // U = bm_c = (bm_t)^T
+    wg_sync();  // M1, N1, bm, G1RT0 have been read
+    spublish<NT>(g, w, S_p, g1t_s);
+    spublish<NT>(g, w, S_q, E_s);
+    spublish<NT>(g, w, S_r, Rpm1_s);
+    spublish<NT>(g, w, S_t, g2rt_s);
+    {
+      const double v3 = smv<NT>(g, E_s, loadR<NT>(g, a.x[J0M] + v0));                              // ieR+- j0-[n0]
+      const double v4 = SURF ? 0.0 : smv<NT>(g, Rpm1_s, loadR<NT>(g, a.ie_a[J0M] + o3));           // R+- ieJ0-(added)
+      vput(g, w, vb1, (Jcp + v3) + v4);
+    }
+    const Strip<NT> R0_s = sload<NT>(g, w, a.sm[SI_R] + m0), Tmm0_s = sload<NT>(g, w, a.sm[SI_TMM] + m0);
+    wg_sync();
+    F_s = sTNacc<NT, false>(g, S_p, A_s, F_s);
+    sstore<NT>(g, w, a.ie_c[C_T_MM] + o4, F_s);
+    // B = T21 (ieR+- r[n0] + R+- ier) + iet++                                                                     :302-310
+    Strip<NT> ac_s = SURF ? szeros<NT>() : sloadT<NT>(g, w, pa);
+    Strip<NT> bmc_s = SURF ? szeros<NT>() : sloadT<NT>(g, w, pbm);
+    if (DERIVE && !SURF) bmc_s = flip(bmc_s);
+    Strip<NT> M2_s = sTNacc<NT, false>(g, S_q, R0_s, szeros<NT>());
+    Strip<NT> N2_s = sTNacc<NT, false>(g, S_q, Tmm0_s, szeros<NT>());
+    const Strip<NT> T21_s = sload<NT>(g, w, a.sm[SI_T21] + m1);
+    M2_s = sTNacc<NT, false>(g, S_r, ac_s, M2_s);
+    N2_s = sTNacc<NT, false>(g, S_r, bmc_s, N2_s);
+    Strip<NT> B_s = SURF ? szeros<NT>() : sload<NT>(g, w, a.ie_a[T_PP] + o4);
+    const Strip<NT> C_s = sload<NT>(g, w, a.ie_c[C_T_PP] + o4);
+    wg_sync();  // G1T0, E, R+-[n1] have been read
+    spublish<NT>(g, w, S_p, M2_s);
+    spublish<NT>(g, w, S_q, N2_s);
+    spublish<NT>(g, w, S_r, C_s);
+    wg_sync();
+    B_s = sTNacc<NT, false>(g, S_p, T21_s, B_s);
+    // ieJ0+ = ieJ0+(added) + T21 (ieJ0+ + ieR+- j0-[n0] + R+- ieJ0-(added)) + B G2 (J0+[n0] + R+-[n0] j0-[n0])      :301-312
+    {
+      const double wv = smv<NT>(g, T21_s, vget<NT>(g, vb1)) + smv<NT>(g, B_s, loadR<NT>(g, a.sv[SVI_G2V] + v0));
+      if (g.lq == 0) a.ie_c[C_J0P][o3 + cw] = Jap + wv;
+    }
+    // ieT++ = T21 ieT++ + B G2 T++[n0];  ieR+- = ier+- + T21 (ieR+- t--[n0] + R+- iet--) + B G2 R+-[n0] t--[n0]     :320-334
+    Strip<NT> En_s = SURF ? szeros<NT>() : (DERIVE ? flip(sload<NT>(g, w, pa)) : sload<NT>(g, w, a.ie_a[R_PM] + o4));
+    const Strip<NT> g2t_s = sload<NT>(g, w, a.sm[SI_G2T] + m0);
+    En_s = sTNacc<NT, false>(g, S_q, T21_s, En_s);
+    En_s = sTNacc<NT, false>(g, S_t, B_s, En_s);
+    sstore<NT>(g, w, a.ie_c[C_R_PM] + o4, En_s);
+    Strip<NT> Cn_s = sTNacc<NT, true>(g, S_r, T21_s, szeros<NT>());  // U = C_c = (C_t)^T
+    wg_sync();  // M2 has been read
+    spublish<NT>(g, w, S_p, g2t_s);
+    wg_sync();
+    Cn_s = sTNacc<NT, false>(g, S_p, B_s, Cn_s);
+    sstore<NT>(g, w, a.ie_c[C_T_PP] + o4, Cn_s);
+  }
+}
+
+#define MOMR_WG_ATTR(NT_) __launch_bounds__(64 * NT_) __attribute__((amdgpu_waves_per_eu((NT_ == 3 ? MOMR_WG3_WPE : 1), (NT_ == 3 ? MOMR_WG3_WPE : 1))))
 template <bool FUSE, int MODE>
 __global__ void MOMR_WG_ATTR(3) k_dbl_pair_wg3(KArgs a) { dbl_pair_wg<3, FUSE, MODE>(a); }
 template <bool FUSE, int MODE>
 __global__ void MOMR_WG_ATTR(4) k_dbl_pair_wg4(KArgs a) { dbl_pair_wg<4, FUSE, MODE>(a); }
+template <bool SURF, bool DERIVE>
+__global__ void MOMR_WG_ATTR(3) k_int_pair_wg3(KArgs a) { int_pair_wg<3, SURF, DERIVE>(a); }
+template <bool SURF, bool DERIVE>
+__global__ void MOMR_WG_ATTR(4) k_int_pair_wg4(KArgs a) { int_pair_wg<4, SURF, DERIVE>(a); }
