@@ -1555,7 +1555,7 @@ hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, voi
   } while (0)
 #define BIG_NT(KERN3, KERN4, ...) do { if (nt == 3) BIG_GO(KERN3, __VA_ARGS__); else BIG_GO(KERN4, __VA_ARGS__); } while (0)
   const dim3 blw(64 * nt);
-  const size_t ldw = (nt == 3) ? wg_lds_bytes<3>(4) : wg_lds_bytes<4>(4);
+  const size_t ldw = (nt == 2) ? wg_lds_bytes<2>(4) : ((nt == 3) ? wg_lds_bytes<3>(4) : wg_lds_bytes<4>(4));
 #define WG_GO(KERN)                                                                                                            \
   do {                                                                                                                         \
     const hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void *>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldw); \
@@ -1577,13 +1577,13 @@ hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, voi
       else if (v1) BIG_NT((k_int_pair3<false, true>), (k_int_pair4<false, true>), a, iface);
       else BIG_NT((k_int_pair3<false, false>), (k_int_pair4<false, false>), a, iface);
     case 5: {
-#define WG_DBL(F, M) do { if (nt == 3) WG_GO((k_dbl_pair_wg3<F, M>)); else WG_GO((k_dbl_pair_wg4<F, M>)); } while (0)
+#define WG_DBL(F, M) do { if (nt == 2) WG_GO((k_dbl_pair_wg2<F, M>)); else if (nt == 3) WG_GO((k_dbl_pair_wg3<F, M>)); else WG_GO((k_dbl_pair_wg4<F, M>)); } while (0)
       if (v0) { if (v1 == 0) WG_DBL(true, 0); else if (v1 == 1) WG_DBL(true, 1); else WG_DBL(true, 2); }
       else { if (v1 == 0) WG_DBL(false, 0); else if (v1 == 1) WG_DBL(false, 1); else WG_DBL(false, 2); }
 #undef WG_DBL
     }
     case 6: {  // ScatteringInterface_11 only
-#define WG_INT(SF, DV) do { if (nt == 3) WG_GO((k_int_pair_wg3<SF, DV>)); else WG_GO((k_int_pair_wg4<SF, DV>)); } while (0)
+#define WG_INT(SF, DV) do { if (nt == 2) WG_GO((k_int_pair_wg2<SF, DV>)); else if (nt == 3) WG_GO((k_int_pair_wg3<SF, DV>)); else WG_GO((k_int_pair_wg4<SF, DV>)); } while (0)
       if (v0) WG_INT(true, false);
       else if (v1) WG_INT(false, true);
       else WG_INT(false, false);
@@ -1762,6 +1762,18 @@ static bool wg_pairs() {
   static const bool on = !(getenv("MOM_RRS_WG") && atoi(getenv("MOM_RRS_WG")) == 0);
   return on;
 }
+// tile count of the workgroup-per-pair image for this edge, 0 = wave-per-pair kernels (N <= 16; 16 < N <= 32 with MOM_RRS_WG2=0)
+static int wg_nt(const State *s) {
+  static const bool two = !(getenv("MOM_RRS_WG2") && atoi(getenv("MOM_RRS_WG2")) == 0);
+  if (!wg_pairs() || s->N <= 16) return 0;
+  if (s->N <= 32) return two ? 2 : 0;
+  return s->N <= 48 ? 3 : 4;
+}
+static size_t wg_grid(const State *s, int nt) {  // persistent workgroups, one round of the chip
+  static const int mult = getenv("MOM_RRS_WG_GRID") ? std::max(1, atoi(getenv("MOM_RRS_WG_GRID"))) : 1;  // (experiments)
+  const size_t np = (size_t)(s->n1_hi - s->n1_lo) * s->nR, per_cu = (nt == 2) ? 4 : ((nt == 3) ? 2 : 1);
+  return std::max<size_t>(1, std::min<size_t>(np, 256 * per_cu * mult));
+}
 static int grid_points(const State *s) { return std::max(1, std::min((s->S + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 8)); }
 static int grid_pairs(const State *s) {
   const size_t np = (size_t)(s->n1_hi - s->n1_lo) * s->nR;
@@ -1859,16 +1871,11 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
 #define DBL_PAIR(NT_, FUSE_, MODE_) RCHK(launch_lds(k_dbl_pair##NT_<FUSE_, MODE_>, gr, (NT_ == 1) ? lds1 : lds<NT_>(), s->stream, a))
 #define DBL_PAIR_M(NT_, FUSE_) do { if (mode == 0) DBL_PAIR(NT_, FUSE_, 0); else if (mode == 1) DBL_PAIR(NT_, FUSE_, 1); else DBL_PAIR(NT_, FUSE_, 2); } while (0)
 #define DBL_PAIR_F(NT_) do { if (a.fuse_el) DBL_PAIR_M(NT_, true); else DBL_PAIR_M(NT_, false); } while (0)
-      if (s->N <= 16) DBL_PAIR_F(1);
+      if (const int nt = wg_nt(s)) {  // one workgroup per pair (mom_rrs_wg.hpp): each walks ~np / grid pairs
+        RCHK(momr_big_launch(5, nt, a.fuse_el ? 1 : 0, mode, (unsigned)wg_grid(s, nt), (void *)s->stream, &a, 0));
+      } else if (s->N <= 16) DBL_PAIR_F(1);
       else if (s->N <= 32) DBL_PAIR_F(2);
-      else if (wg_pairs()) {  // one workgroup per pair (mom_rrs_wg.hpp)
-        const size_t np = (size_t)(s->n1_hi - s->n1_lo) * s->nR;
-        // persistent workgroups, one round of the chip (two per CU at 3 x 3 tiles): each walks ~np / grid pairs, the next one prefetched
-        static const int mult = getenv("MOM_RRS_WG_GRID") ? std::max(1, atoi(getenv("MOM_RRS_WG_GRID"))) : 1;  // (experiments)
-        const size_t res = (size_t)256 * (s->N <= 48 ? 2 : 1) * mult;
-        RCHK(momr_big_launch(5, s->N <= 48 ? 3 : 4, a.fuse_el ? 1 : 0, mode, (unsigned)std::max<size_t>(1, std::min<size_t>(np, res)),
-                             (void *)s->stream, &a, 0));
-      } else RCHK(momr_big_launch(3, s->N <= 48 ? 3 : 4, a.fuse_el ? 1 : 0, mode, gr.x, (void *)s->stream, &a, 0));
+      else RCHK(momr_big_launch(3, s->N <= 48 ? 3 : 4, a.fuse_el ? 1 : 0, mode, gr.x, (void *)s->stream, &a, 0));
 #undef DBL_PAIR_F
 #undef DBL_PAIR_M
 #undef DBL_PAIR
@@ -1951,14 +1958,12 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
     else if (a.derive_pm) RCHK(launch_lds(k_int_pair##NT_<false, true>, gr, l_, s->stream, a, iface));                     \
     else RCHK(launch_lds(k_int_pair##NT_<false, false>, gr, l_, s->stream, a, iface));                                     \
   } while (0)
-    if (s->N <= 16) INT_PAIR(1);
+    const int nt_wg = (iface == 3) ? wg_nt(s) : 0;
+    if (nt_wg) {  // one workgroup per pair (mom_rrs_wg.hpp)
+      RCHK(momr_big_launch(6, nt_wg, with_surface ? 1 : 0, a.derive_pm ? 1 : 0, (unsigned)wg_grid(s, nt_wg), (void *)s->stream, &a, iface));
+    } else if (s->N <= 16) INT_PAIR(1);
     else if (s->N <= 32) INT_PAIR(2);
-    else if (wg_pairs() && iface == 3) {  // one workgroup per pair (mom_rrs_wg.hpp)
-      static const int mult = getenv("MOM_RRS_WG_GRID") ? std::max(1, atoi(getenv("MOM_RRS_WG_GRID"))) : 1;  // (experiments)
-      const size_t np = (size_t)(s->n1_hi - s->n1_lo) * s->nR, res = (size_t)256 * (s->N <= 48 ? 2 : 1) * mult;
-      RCHK(momr_big_launch(6, s->N <= 48 ? 3 : 4, with_surface ? 1 : 0, a.derive_pm ? 1 : 0,
-                           (unsigned)std::max<size_t>(1, std::min<size_t>(np, res)), (void *)s->stream, &a, iface));
-    } else RCHK(momr_big_launch(4, s->N <= 48 ? 3 : 4, with_surface ? 1 : 0, a.derive_pm ? 1 : 0, gr.x, (void *)s->stream, &a, iface));
+    else RCHK(momr_big_launch(4, s->N <= 48 ? 3 : 4, with_surface ? 1 : 0, a.derive_pm ? 1 : 0, gr.x, (void *)s->stream, &a, iface));
 #undef INT_PAIR
     RCHK(hipGetLastError());
     RCHK(tick(s, TK_INT_PAIR, false));
@@ -2075,6 +2080,16 @@ hipError_t postprocess(State *s, const Streams &q, int m, int nVza, const int *d
 }  // namespace momr
 #endif  // MOMR_BIG_TU
 
+#if defined(MOMR_DIAG_STAMPS) && defined(MOMR_BIG_TU)
+extern "C" int momr_big_diag_read(unsigned long long *out, int reset) {  // the stamps of the big-tile object (mom_rrs_wg.hpp)
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(momr_big::momr_diag_acc), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[64] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(momr_big::momr_diag_acc), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 #if defined(MOMR_DIAG_STAMPS) && !defined(MOMR_BIG_TU)
 extern "C" int momr_diag_read(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(momr::momr_diag_acc), 64 * sizeof(unsigned long long)) != hipSuccess) return 1;

@@ -22,7 +22,7 @@
 // of the one-wave kernels (tests/test_gpu_rrs.py compares both, MOM_RRS_WG=0 selects the old ones).
 #pragma once
 #ifndef MOMR_WG_PREFETCH
-#define MOMR_WG_PREFETCH 0   // measured: no gain at NT = 4, slower at NT = 3 (profiles/r05_rrs_wg_ab.txt)
+#define MOMR_WG_PREFETCH 0   // bit mask of the tile counts with the next-pair prefetch: 1 (NT = 2) | 2 (NT = 3) | 4 (NT = 4)
 #endif
 #ifndef MOMR_WG3_WPE
 #define MOMR_WG3_WPE 2   // waves per SIMD the 3-wave image is compiled for (2: two workgroups per CU)
@@ -36,7 +36,7 @@ struct Strip {
 template <int NT>
 constexpr int wg_mat_doubles() { return NT * NT * kTileDoubles; }
 template <int NT>
-constexpr size_t wg_lds_bytes(int nmat) { return ((size_t)nmat * wg_mat_doubles<NT>() + 4 * 16 * NT) * 8; }
+constexpr size_t wg_lds_bytes(int nmat) { return ((size_t)nmat * wg_mat_doubles<NT>() + 8 * 16 * NT) * 8; }  // + 4 exchange buffers + 4 source vectors
 
 template <int NT>
 __device__ __forceinline__ Strip<NT> szeros() {
@@ -160,6 +160,21 @@ __device__ __forceinline__ Vec<NT> vget(const Geo &g, const double *buf) {
   return x;
 }
 __device__ __forceinline__ void wg_sync() { __syncthreads(); }
+// (diagnostic builds, tools/phase_stamps_rrs_wg.py: the barrier time of the doubling kernel as its own section, id 26)
+#ifdef MOMR_DIAG_STAMPS
+#define WG_SYNC_ST() do { wg_sync(); MOMR_STAMP_NW(26); } while (0)
+#define MOMR_STAMP_INIT()                                                                \
+  do {                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x == (gridDim.x >> 1)) {                            \
+      unsigned long long n__;                                                            \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n__)::"memory");      \
+      momr_diag_last = n__;                                                              \
+    }                                                                                    \
+  } while (0)
+#else
+#define WG_SYNC_ST() wg_sync()
+#define MOMR_STAMP_INIT()
+#endif
 
 // The inelastic elemental layer of one pair, strip w (ie_elem_tile restricted to tile column w; same expressions, same
 // order): ier-+ and iet++ strips of the _t form, the wave's 16 entries of ieJ0+ / ieJ0-.
@@ -258,7 +273,7 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
   g.xp = nullptr;
   g.ipiv = nullptr;
   double *S_a = reinterpret_cast<double *>(rrs_smem), *S_b = S_a + MD, *S_x = S_b + MD, *S_g = S_x + MD, *vb = S_g + MD;
-  double *vb0 = vb, *vb1 = vb + 16 * NT, *vb2 = vb + 32 * NT, *vb3 = vb + 48 * NT;
+  double *vb0 = vb, *vb1 = vb + 16 * NT, *vb2 = vb + 32 * NT, *vb3 = vb + 48 * NT, *vsv = vb + 64 * NT;
   const int n = a.nS, cw = 16 * w + g.lr;  // the lane's column of the strip / entry of a column-layout vector
   const size_t NN = (size_t)a.P * a.P, VS = a.P;
   const size_t span = (size_t)(a.n1_hi - a.n1_lo), npairs = span * a.nR;
@@ -273,24 +288,29 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     bool have;
   } nx;
   nx.have = false;
-  auto fetch = [&](size_t q, Top &t) {
-    t.have = false;
+  // two batches (a wave may have 63 memory operations outstanding; one batch of four strips at NT = 4 is 67 and would stall
+  // at issue for a full round trip): which = 1 the pair's own blocks and source entries, 2 the two per-point strips, 3 both
+  auto fetch = [&](size_t q, Top &t, int which) {
+    if (which & 1) t.have = false;
     if (q >= npairs) return;
     const int qn1 = a.n1_lo + (int)(q % span), qdn = (int)(q / span);
     const int qn0 = qn1 + a.off[qdn];
     if (qn0 < 0 || qn0 >= a.S) return;
     const size_t qu = (size_t)qn1 + (size_t)a.S * qdn, q4 = NN * qu, q3 = VS * qu;
-    if (!FUSE) {
+    if ((which & 1) && !FUSE) {
       t.a_s = sload<NT>(g, w, a.ie_a[R_MP] + q4);
       t.b_s = sload<NT>(g, w, a.ie_a[T_PP] + q4);
       t.Jp = a.ie_a[J0P][q3 + cw];
       t.Jm = a.ie_a[J0M][q3 + cw];
     }
-    t.r0_s = sload<NT>(g, w, a.sm[SM_RT] + NN * qn0);
-    t.r1_s = sload<NT>(g, w, a.a_cur[R_MP] + NN * qn1);
-    t.e1 = a.expk_cur[qn1];
-    t.have = true;
+    if (which & 2) {
+      t.r0_s = sload<NT>(g, w, a.sm[SM_RT] + NN * qn0);
+      t.r1_s = sload<NT>(g, w, a.a_cur[R_MP] + NN * qn1);
+      t.e1 = a.expk_cur[qn1];
+      t.have = true;
+    }
   };
+  MOMR_STAMP_INIT();
   for (size_t p = blockIdx.x; p < npairs; p += gridDim.x) {
     const int n1 = a.n1_lo + (int)(p % span), dn = (int)(p / span);
     const int n0 = n1 + a.off[dn];
@@ -322,52 +342,80 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
       }
       continue;
     }
+    MOMR_STAMP_NW(20);  // loop head, off-grid pairs
     const size_t m1 = NN * n1, m0 = NN * n0, v0 = VS * n0;
-    if (!nx.have) fetch(p, nx);  // first pair of the workgroup, or the pair after one off the grid
+    if (!nx.have) fetch(p, nx, 3);  // first pair of the workgroup, or the pair after one off the grid
     Strip<NT> a_s = nx.a_s, b_s = nx.b_s;
     double Jp = nx.Jp, Jm = nx.Jm;
     const Strip<NT> r0_s = nx.r0_s, r1_s = nx.r1_s;
     const double e1 = nx.e1;
     nx.have = false;
     // Register economy: a strip that has a copy in LDS is READ BACK from there where it is needed again (a, b, bn), and the
-    // strips / vectors from global memory are requested one or two products before their first use, not at the top.
+    // strips from global memory are requested one or two products before their first use, not at the top.
+    // The four source vectors of n0 (j1-, j0+, tmp1, tmp2) take ONE load instruction per wave -- lane (lq, lr) fetches entry
+    // 16 w + lr of vector lq -- and reach their row layout through LDS (as 16 NT-entry row-layout loads each they were 64 NT
+    // of the ~100 NT load instructions of a pair, against a 63-deep in-order counter of outstanding memory operations).
     const double *jp0 = STRICT ? a.jpseq + v0 + VS * a.S * dn : a.a_cur[J0P] + v0;
-    const Vec<NT> j1m0 = loadR<NT>(g, a.sv[SV_J1M] + v0), jp0R = loadR<NT>(g, jp0);
-    const Vec<NT> tm1 = loadR<NT>(g, a.sv[SV_TMP1] + v0), tm2 = loadR<NT>(g, a.sv[SV_TMP2] + v0);
+    // (NT = 3 keeps the row-layout loads: at its 256-register budget the LDS form spills more than it saves,
+    // profiles/r05_rrs_wg_ab.txt)
+    constexpr bool VLDS = (NT != 3);
+    const double *vsrc = (g.lq == 0) ? a.sv[SV_J1M] + v0 : ((g.lq == 1) ? jp0 : ((g.lq == 2) ? a.sv[SV_TMP1] + v0 : a.sv[SV_TMP2] + v0));
+    double vch = 0.0;
+    Vec<NT> j1m0, jp0R, tm1, tm2;
+    if (VLDS) {
+      vch = vsrc[cw];
+    } else {
+      j1m0 = loadR<NT>(g, a.sv[SV_J1M] + v0); jp0R = loadR<NT>(g, jp0);
+      tm1 = loadR<NT>(g, a.sv[SV_TMP1] + v0); tm2 = loadR<NT>(g, a.sv[SV_TMP2] + v0);
+    }
     if (FUSE) ie_elem_strip<NT>(g, w, a, n1, dn, n0, a_s, b_s, Jp, Jm);
     const double J1p = Jp * e1, J1m = Jm * e1;  // ieJ1+, ieJ1-   :52-56
-    wg_sync();  // the previous pair has finished with the LDS matrices
+    MOMR_STAMP_NW(21);  // first loads issued, (fused elemental), wait for ieJ0+-
+    WG_SYNC_ST();  // the previous pair has finished with the LDS matrices
     spublish<NT>(g, w, S_a, a_s);
     spublish<NT>(g, w, S_b, b_s);
     spublish<NT>(g, w, S_g, r0_s);
     vput(g, w, vb0, J1m);
+    if (VLDS) vsv[16 * NT * g.lq + cw] = vch;
     // the products of the pair's own blocks with the source vectors of n0                                         :61-89
-    const double a_j1m = smv<NT>(g, a_s, j1m0);  // ier j1-[n0]
-    const double a_jp = smv<NT>(g, a_s, jp0R);   // ier j0+[n0]
-    const double b1 = smv<NT>(g, b_s, tm1);      // iet++ tmp1
-    const double b2 = STRICT ? smv<NT>(g, sload<NT>(g, w, a.ie_a[T_MM] + o4), tm2)  // D5: iet-- as the array holds it
-                             : smv<NT>(g, b_s, tm2);
+    double a_j1m, a_jp, b1, b2;
+    auto own_mv = [&]() {
+      a_j1m = smv<NT>(g, a_s, j1m0);  // ier j1-[n0]
+      a_jp = smv<NT>(g, a_s, jp0R);   // ier j0+[n0]
+      b1 = smv<NT>(g, b_s, tm1);      // iet++ tmp1
+      b2 = STRICT ? smv<NT>(g, sload<NT>(g, w, a.ie_a[T_MM] + o4), tm2)  // D5: iet-- as the array holds it
+                  : smv<NT>(g, b_s, tm2);
+    };
+    if (!VLDS) own_mv();
     const Strip<NT> gt0_s = sload<NT>(g, w, a.sm[SM_GT] + m0), ttgp1_s = sload<NT>(g, w, a.sm[SM_TTGP] + m1);
-    wg_sync();
+    MOMR_STAMP_NW(23);  // publish a, b, r0 (waits for the pair's blocks)
+    WG_SYNC_ST();
+    if (VLDS) {
+      j1m0 = vget<NT>(g, vsv); jp0R = vget<NT>(g, vsv + 16 * NT);
+      tm1 = vget<NT>(g, vsv + 32 * NT); tm2 = vget<NT>(g, vsv + 48 * NT);
+      own_mv();
+    }
     // X = ier r0 + r1 ier
     Strip<NT> X_s = sTNacc<NT, false>(g, S_g, a_s, szeros<NT>());  // U = r0_c
     X_s = sTNacc<NT, true>(g, S_a, r1_s, X_s);                     // U = a_c = (a_t)^T
     const double X1 = smv<NT>(g, X_s, tm1), X2 = smv<NT>(g, X_s, tm2);
-    wg_sync();  // r0 has been read by everybody
+    MOMR_STAMP_NW(25);  // 4 + 2 mat-vecs, X: 2 products
+    WG_SYNC_ST();  // r0 has been read by everybody
     spublish<NT>(g, w, S_x, X_s);
     spublish<NT>(g, w, S_g, gt0_s);
+    MOMR_STAMP_NW(27);  // publications
     // ---- sources
     {
       const double uu = (Jp + smv<NT>(g, r1_s, vget<NT>(g, vb0))) + (a_j1m + X1);
       vput(g, w, vb1, uu);
-      wg_sync();  // (also: X and (G t)[n0] are in LDS)
+      WG_SYNC_ST();  // (also: X and (G t)[n0] are in LDS)
       const double Jpn = (J1p + smv<NT>(g, ttgp1_s, vget<NT>(g, vb1))) + b1;  // new ieJ0+
       vput(g, w, vb2, Jpn);
-      wg_sync();
+      WG_SYNC_ST();
       const double rv2 = smv<NT>(g, r1_s, vget<NT>(g, vb2));                  // r1 ieJ0+(new)
       const double u2 = (J1m + rv2) + (a_jp + X2);
       vput(g, w, vb3, u2);
-      wg_sync();
+      WG_SYNC_ST();
       double Jmn = (Jm + smv<NT>(g, ttgp1_s, vget<NT>(g, vb3))) + b2;         // new ieJ0-
       if (fuseD && n > 1 && scomp(cw, n, a.strict_idx) > 2) Jmn = -Jmn;
       if (g.lq == 0) {
@@ -375,30 +423,46 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
         a.ie_a[J0M][o3 + cw] = Jmn;
       }
     }
+    MOMR_STAMP_NW(24);  // source chain: 4 mat-vecs, 3 exchanges (their barriers: 26)
     // ---- operators                                                                                              :98-125
     const Strip<NT> gr0_s = sload<NT>(g, w, a.sm[SM_GR] + m0);              // consumed three products later
     const Strip<NT> Y_s = sTNacc<NT, false>(g, S_x, sread<NT>(g, w, S_g), szeros<NT>());  // Y_c = X G t[n0]   (U = X_t)
-    wg_sync();                                                              // X has been read
+    MOMR_STAMP_NW(28);  // Y: 1 product
+    WG_SYNC_ST();                                                              // X has been read
     spublish<NT>(g, w, S_x, Y_s);
-    wg_sync();
+    MOMR_STAMP_NW(27);
+    WG_SYNC_ST();
     Strip<NT> bn_s = sTNacc_sum<NT>(g, S_b, S_x, ttgp1_s, szeros<NT>());    // tG (iet + Y)            (U = W_c = b_c + Y_c)
     const Strip<NT> t0_s = sload<NT>(g, w, a.sm[SM_TT] + m0);               // consumed after three more products
     bn_s = sTNacc<NT, false>(g, S_g, sread<NT>(g, w, S_b), bn_s);           // + iet G t[n0]           (U = (G t)[n0]_c)
-    wg_sync();                                                              // b and (G t)[n0] have been read
+    MOMR_STAMP_NW(29);  // iet: 2 products
+    WG_SYNC_ST();                                                              // b and (G t)[n0] have been read
     spublish<NT>(g, w, S_b, bn_s);
     spublish<NT>(g, w, S_g, gr0_s);
-    wg_sync();
+    MOMR_STAMP_NW(27);
+    WG_SYNC_ST();
     Strip<NT> Q_s = sTNacc<NT, false>(g, S_g, bn_s, szeros<NT>());          // iet(new) G r[n0]        (U = (G r)[n0]_c)
     const Strip<NT> ttgpr1_s = sload<NT>(g, w, a.sm[SM_TTGPR] + m1);
     Q_s = sTNacc<NT, true>(g, S_a, ttgp1_s, Q_s);                           // + tG ier                (U = a_c)
-    wg_sync();                                                              // (G r)[n0] has been read
+    MOMR_STAMP_NW(30);  // Q: 2 products
+    WG_SYNC_ST();                                                              // (G r)[n0] has been read
     spublish<NT>(g, w, S_g, t0_s);
-    wg_sync();
-    if (MOMR_WG_PREFETCH) fetch(p + gridDim.x, nx);
+    MOMR_STAMP_NW(27);
+    WG_SYNC_ST();
+    constexpr bool PF = (MOMR_WG_PREFETCH & (NT == 2 ? 1 : (NT == 3 ? 2 : 4))) != 0;
+    if (PF) {
+      fetch(p + gridDim.x, nx, 1);
+      __builtin_amdgcn_sched_barrier(0);  // the requests stay HERE, ahead of the product (the scheduler sinks them otherwise)
+    }
     Strip<NT> an_s = sTNacc_sum<NT>(g, S_b, S_x, ttgpr1_s, szeros<NT>());   // (iet(new) + Y) ...      (U = V_c = bn_c + Y_c)
+    if (PF) {
+      fetch(p + gridDim.x, nx, 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     an_s = sTNacc<NT, false>(g, S_g, Q_s, an_s);                            // + t[n0]-side product    (U = t0_c)
     an_s = sadd<NT>(sread<NT>(g, w, S_a), an_s);
     bn_s = sread<NT>(g, w, S_b);
+    MOMR_STAMP_NW(31);  // ier: 2 products, read-back of a and bn
     if (fuseD) {  // apply_D_matrix_IE!, corrected indexing (D2)
       if (n > 1) smap<NT>(g, w, an_s, sgn_i);
       Strip<NT> apm = an_s, bmm = bn_s;
@@ -413,6 +477,7 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     }
     sstore<NT>(g, w, a.ie_a[R_MP] + o4, an_s);
     sstore<NT>(g, w, a.ie_a[T_PP] + o4, bn_s);
+    MOMR_STAMP_NW(32);  // D signs, operator stores issued
   }
 }
 
@@ -564,7 +629,10 @@ __device__ __forceinline__ void int_pair_wg(const KArgs &a) {
   }
 }
 
-#define MOMR_WG_ATTR(NT_) __launch_bounds__(64 * NT_) __attribute__((amdgpu_waves_per_eu((NT_ == 3 ? MOMR_WG3_WPE : 1), (NT_ == 3 ? MOMR_WG3_WPE : 1))))
+#define MOMR_WG_WPE(NT_) (NT_ == 2 ? 2 : (NT_ == 3 ? MOMR_WG3_WPE : 1))
+#define MOMR_WG_ATTR(NT_) __launch_bounds__(64 * NT_) __attribute__((amdgpu_waves_per_eu(MOMR_WG_WPE(NT_), MOMR_WG_WPE(NT_))))
+template <bool FUSE, int MODE>
+__global__ void MOMR_WG_ATTR(2) k_dbl_pair_wg2(KArgs a) { dbl_pair_wg<2, FUSE, MODE>(a); }
 template <bool FUSE, int MODE>
 __global__ void MOMR_WG_ATTR(3) k_dbl_pair_wg3(KArgs a) { dbl_pair_wg<3, FUSE, MODE>(a); }
 template <bool FUSE, int MODE>
@@ -573,3 +641,5 @@ template <bool SURF, bool DERIVE>
 __global__ void MOMR_WG_ATTR(3) k_int_pair_wg3(KArgs a) { int_pair_wg<3, SURF, DERIVE>(a); }
 template <bool SURF, bool DERIVE>
 __global__ void MOMR_WG_ATTR(4) k_int_pair_wg4(KArgs a) { int_pair_wg<4, SURF, DERIVE>(a); }
+template <bool SURF, bool DERIVE>
+__global__ void MOMR_WG_ATTR(2) k_int_pair_wg2(KArgs a) { int_pair_wg<2, SURF, DERIVE>(a); }
