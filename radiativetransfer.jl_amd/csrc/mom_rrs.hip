@@ -16,6 +16,8 @@
 //     matrix-vector products of the reference's update formulas as register-tile MFMA products (mom_tile.hpp), reading
 //     and writing each 4-D array block exactly once, in place.  N <= 16: one 16 x 16 tile per operator (the reference's own
 //     RRS shape is N = 15: test/test_parameters/O2Parameters.yaml, IQU, l_trunc 5); N <= 32: 2 x 2 tiles; N <= 48 / <= 64: 3 x 3 / 4 x 4 tiles (second object, MOMR_BIG_TU).
+//     r5: above N = 16 the pair kernels of the doubling step and of interface 11 run as one WORKGROUP of NT waves per pair instead
+//     (mom_rrs_wg.hpp: a wave owns a tile column of every operator, left factors are read from LDS copies).
 // Pairs are enumerated dn-major (n1 fastest): the blocks of the 4-D arrays are visited in memory order, i.e. every array is
 // one sequential HBM stream per launch (n1-major order -- consecutive pairs 12 MB apart -- ran at 2.6 TB/s instead); the
 // per-point operands (7 x N^2 x S doubles = 86 MB at C5) are re-read once per Raman line from L2 / Infinity Cache.  HBM-bound: 4 (doubling) / 12 (interaction) block transfers of N^2 doubles per pair against

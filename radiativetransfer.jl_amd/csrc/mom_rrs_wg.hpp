@@ -1,11 +1,12 @@
-// mom_rrs_wg.hpp -- the RRS pair kernels above N = 32 as ONE WORKGROUP PER PAIR (included by mom_rrs.hip inside its
-// namespace, big-tile object only: 3 x 3 tiles for 32 < N <= 48, 4 x 4 for 48 < N <= 64).
+// mom_rrs_wg.hpp -- the RRS pair kernels above N = 16 as ONE WORKGROUP PER PAIR (included by mom_rrs.hip inside its
+// namespace, big-tile object only: 2 x 2 tiles for 16 < N <= 32, 3 x 3 for 32 < N <= 48, 4 x 4 for 48 < N <= 64).
 //   doubling_helper!(::RRS)            CoreKernel/doubling_inelastic.jl:61-89 (sources), :98-125 (operators)
 //   interaction_helper!(::RRS, 11)     CoreKernel/interaction_inelastic.jl:249-335
 //
 // Why.  The wave-per-pair bodies (dbl_pair_body / int_pair_body) keep every operator of a pair as NT x NT register tiles of one
 // wave: at NT = 3 / 4 the dozen live operators of a pair are 1 700 ... 3 000 registers per lane against 512, and the kernels
-// ran from scratch memory (profiles/r05_rrs_nt.txt: 0.02-0.04 of the HBM roofline).  Here a pair belongs to a workgroup of NT
+// ran from scratch memory (r4: 0.02-0.04 of the HBM roofline; profiles/r05_rrs_wg_ab.txt); at NT = 2 they fit, at one wave
+// per SIMD.  Here a pair belongs to a workgroup of NT
 // waves and every operator is split into COLUMN STRIPS: wave w owns tile column w (NT tiles = 4 NT registers per lane).  With
 // TN(U, V) = U^T V of mom_tile.hpp, column strip w of a product needs the whole left factor U and only strip w of V:
 //   * V strips stay in the registers of their wave (they are loaded from global memory as strips, or are the wave's own
@@ -15,11 +16,13 @@
 //     different index expression of the same copy, and W = b^T + Y, V = bn^T + Y are formed fragment-wise from two copies;
 //   * computed left factors (X, Y, bn) are published strip-wise into LDS between two barriers; left factors that come from
 //     global memory (r[n0]^T, (G t)[n0] ...) are loaded as strips -- one per wave, coalesced -- and published the same way.
-// Four LDS matrices (a, b / bn, X / Y, the rotating global one) = 78 KB (NT = 3: two workgroups per CU) / 139 KB (NT = 4).
+// Four LDS matrices (a, b / bn, X / Y, the rotating global one) = 35 KB (NT = 2: four workgroups per CU) / 78 KB (NT = 3: two) /
+// 139 KB (NT = 4: one).
 // The source vectors go through the vector ALU as in the one-wave bodies: a wave multiplies its strip with the full vector
 // (row layout) and owns 16 entries of the result; full vectors are exchanged through four small LDS buffers.
 // The order of the products and of every accumulation is that of dbl_pair_body / int_pair_body: the results are bitwise those
-// of the one-wave kernels (tests/test_gpu_rrs.py compares both, MOM_RRS_WG=0 selects the old ones).
+// of the one-wave kernels up to the scheduling of independent roundings (tests/test_gpu_rrs.py::
+// test_rrs_workgroup_and_wave_kernels_agree compares both at 1e-13; MOM_RRS_WG=0 selects the old ones, MOM_RRS_WG2=0 for N <= 32 only).
 #pragma once
 #ifndef MOMR_WG_PREFETCH
 #define MOMR_WG_PREFETCH 0   // bit mask of the tile counts with the next-pair prefetch: 1 (NT = 2) | 2 (NT = 3) | 4 (NT = 4)

@@ -371,3 +371,30 @@ def test_rrs_zero_padding_invariant(rtamd, nS, lt, nv, strict):
         assert h.rrs_check_padding() == 0
         h.rt_run_rrs()
         assert h.rrs_check_padding() == 0
+
+
+@pytest.mark.parametrize("nS,lt,S,Nz", [(4, 9, 12, 2), (3, 21, 10, 2), (4, 21, 8, 2), (3, 33, 8, 2)])   # N = 32, 42, 56, 60: 2, 3, 4, 4 waves per pair
+@pytest.mark.parametrize("strict", [True, False])
+def test_rrs_workgroup_and_wave_kernels_agree(tmp_path, nS, lt, S, Nz, strict):
+    """Above N = 16 the RRS pair kernels run as one WORKGROUP per pair (mom_rrs_wg.hpp: column strips per wave, left factors from
+    LDS); MOM_RRS_WG=0 selects the wave-per-pair bodies they replace.  Both execute the same products in the same order on the
+    same operands, so a scene-level run must agree to rounding of the last place -- asserted at 1e-13 of the elastic intensity,
+    three orders below the parity bound against the restatement (which test_rt_run_rrs_parity holds for the workgroup form)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    out = {}
+    for wg in ("0", "1"):
+        f = tmp_path / f"wg{wg}.npz"
+        env = dict(os.environ, MOM_RRS_WG=wg)
+        subprocess.run([sys.executable, str(root / "tests" / "rrs_probe.py"), str(nS), str(lt), str(S), str(Nz), str(int(strict)), str(f)],
+                       check=True, env=env, timeout=600)
+        out[wg] = np.load(f)
+    assert int(out["0"]["N"]) == {(4, 9): 32, (3, 21): 42, (4, 21): 56, (3, 33): 60}[(nS, lt)]
+    scale = np.abs(out["0"]["R"][:, 0:1, :]).max()
+    assert np.abs(out["0"]["ieR"]).max() > 0
+    for k in ("R", "T", "ieR", "ieT", "hdr", "up", "dw"):
+        d = np.abs(out["0"][k] - out["1"][k]).max()
+        assert d <= 1e-13 * scale, (k, d, scale)
