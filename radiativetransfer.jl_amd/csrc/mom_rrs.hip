@@ -1540,7 +1540,7 @@ __global__ void k_unpack(double *nat, const double *dev, int rows, int cols, int
 #include "mom_rrs_wg.hpp"
 }  // namespace momr_big
 // which: 0 k_el_point, 1 k_dbl_point, 2 k_int_point, 3 k_dbl_pair (v0 = fused elemental, v1 = mode), 4 k_int_pair (v0 = surface,
-// v1 = derived +- / -- blocks), 5 k_dbl_pair_wg, 6 k_int_pair_wg (workgroup per pair, mom_rrs_wg.hpp; grid = workgroups); nt = 3 or 4; args: the
+// v1 = derived +- / -- blocks), 5 k_dbl_pair_wg, 6 k_int_pair_wg (workgroup per pair, mom_rrs_wg.hpp; grid = workgroups), 7 k_dbl_point_wg (workgroup per point, nt >= 3); nt = 3 or 4; args: the
 // KArgs of the caller (layout-identical in both namespaces)
 hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, void *stream, const void *args, int iface) {
   using namespace momr_big;
@@ -1590,6 +1590,15 @@ hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, voi
       else if (v1) WG_INT(false, true);
       else WG_INT(false, false);
 #undef WG_INT
+    }
+    case 7: {  // k_dbl_point_wg: one workgroup per spectral point (grid = workgroups)
+      const size_t ldp = (nt == 3) ? wg_point_lds_bytes<3>() : wg_point_lds_bytes<4>();
+      const void *kp = (nt == 3) ? reinterpret_cast<const void *>(k_dbl_point_wg3) : reinterpret_cast<const void *>(k_dbl_point_wg4);
+      const hipError_t e__ = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldp);
+      if (e__ != hipSuccess) return e__;
+      if (nt == 3) hipLaunchKernelGGL(k_dbl_point_wg3, gr, blw, ldp, st, a);
+      else hipLaunchKernelGGL(k_dbl_point_wg4, gr, blw, ldp, st, a);
+      return hipGetLastError();
     }
     default: return hipErrorInvalidValue;
   }
@@ -1853,7 +1862,13 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
       a.fscatt = s->el.fscatt; a.Zr_pp = s->el.Zr_pp; a.Zr_mp = s->el.Zr_mp;
       s->el_pending = false;
     }
-    LAUNCH_NT(s, k_dbl_point, 1, grid_points(s), a);
+    // one workgroup per point (mom_rrs_wg.hpp dbl_point_wg): opt-in, MOM_RRS_WG_POINT=1.  Measured SLOWER than the wave-per-point
+    // kernel at S = 500 (profiles/r05_rrs_wg_ab.txt (6)): the Gauss-Jordan inverse runs on one wave either way, and a
+    // 157 KB workgroup per CU runs the points of a launch in two rounds where 500 independent waves ran in one
+    static const bool wg_point = getenv("MOM_RRS_WG_POINT") && atoi(getenv("MOM_RRS_WG_POINT")) != 0;
+    if (wg_point && wg_nt(s) >= 3)
+      RCHK(momr_big_launch(7, wg_nt(s), 0, 0, (unsigned)std::max(1, std::min(s->S, 256 * 8)), (void *)s->stream, &a, 0));
+    else LAUNCH_NT(s, k_dbl_point, 1, grid_points(s), a);
     RCHK(tick(s, TK_DBL_PAIR, true));
     {
       dim3 gr(grid_pairs(s));

@@ -632,6 +632,198 @@ __device__ __forceinline__ void int_pair_wg(const KArgs &a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// doubling step, POINT kernel above N = 32 as one workgroup of NT waves per spectral point (k_dbl_point in strips): the
+// wave-per-point form keeps r, t, their transposes, G and four products as NT x NT register tiles -- 1 000+ registers per lane
+// at NT = 3 / 4, i.e. scratch memory -- and a launch has only S waves.  Here r, t, G = (I - r r)^-1 and (t G)^T live in four LDS
+// matrices, every product is computed in column strips (transposed factors are the transposed index expression of the same
+// copy), the Gauss-Jordan inverse runs on wave 0 (inv_one_minus of mom_tile.hpp, its workspace is the fourth matrix), and the
+// 2-column source products are split by row blocks with the full vectors exchanged through LDS.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ Strip<NT> sreadT(const Geo &g, int w, const double *M) {  // strip w of M^T from the LDS copy of M
+  Strip<NT> X;
+  const double *q = M + w * NT * kTileDoubles + g.lr * kTileLd + g.lq;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X.t[a][r] = q[a * kTileDoubles + 4 * r];
+  return X;
+}
+template <int NT>
+__device__ __forceinline__ Mat<NT> mread(const Geo &g, const double *M) {
+  Mat<NT> X;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X.t[a][b][r] = M[(a * NT + b) * kTileDoubles + (g.lq + 4 * r) * kTileLd + g.lr];
+  return X;
+}
+template <int NT>
+__device__ __forceinline__ void mpublish(const Geo &g, double *M, const Mat<NT> &X) {
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) M[(a * NT + b) * kTileDoubles + (g.lq + 4 * r) * kTileLd + g.lr] = X.t[a][b][r];
+}
+// row block w of U^T v (TNv of mom_tile.hpp restricted to ti = w), U = M or M^T from LDS, v = the 2 (.. 16) vectors held as tile columns
+template <int NT, bool TR>
+__device__ __forceinline__ d4 sTNv(const Geo &g, int w, const double *M, const Vec<NT> &v) {
+  d4 o = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (16 * tk + 4 * s < g.N) o = __builtin_amdgcn_mfma_f64_16x16x4f64(ufrag<NT, TR>(g, M, tk, w, s), v.t[tk][s], o, 0, 0, 0);
+  return o;
+}
+template <int NT>
+__device__ __forceinline__ d4 vpick(const Vec<NT> &v, int w) {  // v.t[w] without indexing the register array
+  d4 o = v.t[0];
+#pragma unroll
+  for (int a = 1; a < NT; ++a)
+    if (a == w) o = v.t[a];
+  return o;
+}
+// row block w of a vector tile -> LDS; all row blocks <- LDS (16 x 16 tiles of pitch kTileLd)
+__device__ __forceinline__ void vxput(const Geo &g, int w, double *buf, const d4 &o) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) buf[w * kTileDoubles + (g.lq + 4 * r) * kTileLd + g.lr] = o[r];
+}
+template <int NT>
+__device__ __forceinline__ Vec<NT> vxget(const Geo &g, const double *buf) {
+  Vec<NT> v;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v.t[a][r] = buf[a * kTileDoubles + (g.lq + 4 * r) * kTileLd + g.lr];
+  return v;
+}
+template <int NT>
+constexpr size_t wg_point_lds_bytes() { return ((size_t)4 * wg_mat_doubles<NT>() + 2 * NT * kTileDoubles + 8 * NT) * 8; }
+
+template <int NT>
+__device__ __forceinline__ void dbl_point_wg(const KArgs &a) {
+  constexpr int MD = wg_mat_doubles<NT>();
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *S_r = reinterpret_cast<double *>(rrs_smem), *S_t = S_r + MD, *S_G = S_t + MD, *S_x = S_G + MD;
+  double *vx = S_x + MD, *vx2 = vx + NT * kTileDoubles;
+  Geo g;
+  g.lr = lane & 15;
+  g.lq = lane >> 4;
+  g.N = a.N;
+  g.xp = S_x;                                                 // workspace of the inverse (wave 0)
+  g.ipiv = reinterpret_cast<int *>(vx2 + NT * kTileDoubles);
+  const int n = a.nS;
+  const size_t NN = (size_t)a.P * a.P, VS = a.P;
+  int bad = 0;
+  auto sgn_i = [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; };
+  auto sgn_ij = [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; };
+  // rows [16 w, 16 w + 16) of the vectors in columns 0 / 1 of a row block -> two arrays
+  auto store_rows = [&](double *p0, double *p1, const d4 &o) {
+    double *p = (g.lr == 0) ? p0 : ((g.lr == 1) ? p1 : nullptr);
+    if (p != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[16 * w + g.lq + 4 * r] = o[r];
+    }
+  };
+  for (int pt = blockIdx.x; pt < a.S; pt += gridDim.x) {
+    const size_t om = NN * pt, ov = VS * pt;
+    const Strip<NT> r_s = sload<NT>(g, w, a.a_cur[R_MP] + om), t_s = sload<NT>(g, w, a.a_cur[T_PP] + om);
+    double e = a.expk_cur[pt];
+    Vec<NT> J = loadv2<NT>(g, a.a_cur[J0P] + ov, a.a_cur[J0M] + ov);      // (j0+ | j0-)
+    wg_sync();  // the previous point has finished with the LDS matrices
+    spublish<NT>(g, w, S_r, r_s);
+    spublish<NT>(g, w, S_t, t_s);
+    wg_sync();
+    const Strip<NT> rc_s = sreadT<NT>(g, w, S_r), tc_s = sreadT<NT>(g, w, S_t);
+    sstore<NT>(g, w, a.sm[SM_RT] + om, rc_s);
+    sstore<NT>(g, w, a.sm[SM_TT] + om, tc_s);
+    spublish<NT>(g, w, S_G, sTNacc<NT, false>(g, S_r, rc_s, szeros<NT>()));  // r r (as TN(r_t, r_c))
+    wg_sync();
+    if (w == 0) {                                                             // (I - r r)^-1                      :47
+      const Mat<NT> G_c = inv_one_minus<NT>(g, mread<NT>(g, S_G), &bad);
+      mpublish<NT>(g, S_G, G_c);
+    }
+    wg_sync();
+    const Strip<NT> ttgp_s = sTNacc<NT, false>(g, S_G, t_s, szeros<NT>());    // (t G)^T = TN(G_c, t_t)            :48
+    const Strip<NT> ttgpr_s = sTNacc<NT, true>(g, S_r, ttgp_s, szeros<NT>()); // (t G r)^T = TN(r_c, .)
+    sstore<NT>(g, w, a.sm[SM_GT] + om, sTNacc<NT, true>(g, S_G, tc_s, szeros<NT>()));  // G t, row-major: TN(G_t, t_c)
+    sstore<NT>(g, w, a.sm[SM_GR] + om, sTNacc<NT, true>(g, S_G, rc_s, szeros<NT>()));  // G r, row-major
+    sstore<NT>(g, w, a.sm[SM_TTGP] + om, ttgp_s);
+    sstore<NT>(g, w, a.sm[SM_TTGPR] + om, ttgpr_s);
+    spublish<NT>(g, w, S_x, ttgp_s);  // (the inverse's workspace is free again)
+    const Vec<NT> J1 = vscale<NT>(J, e);                                      // (j1+ | j1-)                       :51-55
+    store_rows(a.sv[SV_J1P] + ov, a.sv[SV_J1M] + ov, vpick<NT>(J1, w));
+    auto mix = [&](const Vec<NT> &Jc) {
+      Vec<NT> m;  // (j0+ | j1-)
+#pragma unroll
+      for (int ta = 0; ta < NT; ++ta) m.t[ta] = (g.lr == 0) ? Jc.t[ta] : J1.t[ta];
+      return m;
+    };
+    // s = (j0+ + r j1- | j1- + r j0+): every wave its row block, the full tile through LDS
+    auto s_of = [&](const Vec<NT> &Jc) {
+      const Vec<NT> mx = mix(Jc);
+      vxput(g, w, vx, vpick<NT>(mx, w) + sTNv<NT, false>(g, w, S_r, swap01<NT>(mx)));  // + r (j1- | j0+)
+      wg_sync();
+      return vxget<NT>(g, vx);
+    };
+    {
+      const Vec<NT> s = s_of(J);  // (the barrier inside also publishes (t G)^T)
+      const d4 tmp = sTNv<NT, true>(g, w, S_G, s);                            // tmp = G s = (tmp1 | tmp2)          :58-59
+      store_rows(a.sv[SV_TMP1] + ov, a.sv[SV_TMP2] + ov, tmp);
+      // elastic source update: once (corrected) or nRaman times with expk squared every time (strict, D1)        :90-95
+      const int reps = a.strict_rrs ? a.nR : 1;
+      Vec<NT> sk = s;
+      for (int k = 0; k < reps; ++k) {
+        if (a.strict_rrs) store_rows(a.jpseq + ov + VS * a.S * k, nullptr, vpick<NT>(J, w));
+        if (k > 0) {
+          wg_sync();  // everybody has read the previous s
+          sk = s_of(J);
+        }
+        const d4 q = sTNv<NT, false>(g, w, S_x, sk);                         // (tG (j0+ + r j1-) | tG (j1- + r j0+))
+        const d4 j1b = vpick<NT>(J1, w), jb = vpick<NT>(J, w);
+        d4 jn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) jn[r] = ((g.lr == 0) ? j1b[r] : jb[r]) + q[r];
+        if (k > 0) wg_sync();  // ... and the previous J
+        vxput(g, w, vx2, jn);
+        wg_sync();
+        J = vxget<NT>(g, vx2);
+        e = e * e;
+      }
+    }
+    // r <- r + (tG r) t,  t <- tG t                                                                             :128-131
+    Strip<NT> rn_s = sadd<NT>(sread<NT>(g, w, S_r), sTNacc<NT, true>(g, S_t, ttgpr_s, szeros<NT>()));  // U = t_c
+    Strip<NT> tn_s = sTNacc<NT, true>(g, S_t, ttgp_s, szeros<NT>());
+    d4 jout = vpick<NT>(J, w);
+    if (a.last) {  // apply_D_matrix! (doubling.jl:93-134) and apply_D_matrix_SFI! (:112-144)
+      if (n > 1) {
+        smap<NT>(g, w, rn_s, sgn_i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (g.lr == 1 && scomp(16 * w + g.lq + 4 * r, n, a.strict_idx) > 2) jout[r] = -jout[r];
+      }
+      Strip<NT> rpm = rn_s, tmm = tn_s;
+      if (n > 1) {
+        smap<NT>(g, w, rpm, sgn_ij);
+        smap<NT>(g, w, tmm, sgn_ij);
+      }
+      sstore<NT>(g, w, a.a_nxt[R_PM] + om, rpm);
+      sstore<NT>(g, w, a.a_nxt[T_MM] + om, tmm);
+    }
+    sstore<NT>(g, w, a.a_nxt[R_MP] + om, rn_s);
+    sstore<NT>(g, w, a.a_nxt[T_PP] + om, tn_s);
+    store_rows(a.a_nxt[J0P] + ov, a.a_nxt[J0M] + ov, jout);
+    if (threadIdx.x == 0) a.expk_nxt[pt] = e;
+  }
+  if (bad && threadIdx.x == 0) atomicMax(a.info, bad);
+}
+
 #define MOMR_WG_WPE(NT_) (NT_ == 2 ? 2 : (NT_ == 3 ? MOMR_WG3_WPE : 1))
 #define MOMR_WG_ATTR(NT_) __launch_bounds__(64 * NT_) __attribute__((amdgpu_waves_per_eu(MOMR_WG_WPE(NT_), MOMR_WG_WPE(NT_))))
 template <bool FUSE, int MODE>
@@ -646,3 +838,5 @@ template <bool SURF, bool DERIVE>
 __global__ void MOMR_WG_ATTR(4) k_int_pair_wg4(KArgs a) { int_pair_wg<4, SURF, DERIVE>(a); }
 template <bool SURF, bool DERIVE>
 __global__ void MOMR_WG_ATTR(2) k_int_pair_wg2(KArgs a) { int_pair_wg<2, SURF, DERIVE>(a); }
+__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 1))) k_dbl_point_wg3(KArgs a) { dbl_point_wg<3>(a); }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_dbl_point_wg4(KArgs a) { dbl_point_wg<4>(a); }

@@ -34,6 +34,8 @@ if [ "$(python3 -c 'import torch; print(torch.cuda.device_count())')" -ge 2 ]; t
   python3 bench.py --gpus 2 --no-voigt --no-cpu-baseline > $O/${ROUND}_bench_2gpus_rccl.json 2> /dev/null
 fi
 python3 tools/bench_rrs_nt2.py > $O/${ROUND}_rrs_nt.txt 2> /dev/null
+# the multi-tile RRS kernels (workgroup per pair above N = 16) under the kernel trace: per-kernel durations of the same six scenes
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${ROUND}_rrs_nt_stats -o p -- python3 $R/tools/bench_rrs_nt2.py > /dev/null 2>&1
 python3 tools/size_sweep.py > $O/${ROUND}_size_sweep.txt 2> /dev/null
 python3 tools/f32_vs_f64.py > $O/${ROUND}_f32_vs_f64.txt 2> /dev/null
 echo collected

@@ -30,7 +30,7 @@ def newest(pattern):
 
 
 summ, traffic = {}, {}
-for wl in ("C2", "C4", "C1", "C5", "voigt"):
+for wl in ("C2", "C4", "C1", "C5", "voigt", "rrs_nt"):
     st = newest(f"{rnd}_{wl}_stats/**/*kernel_stats.csv")
     if st:
         shutil.copy(st, out / f"{rnd}_{wl}_kernel_stats.csv")
