@@ -121,6 +121,52 @@ __device__ __forceinline__ Strip<NT> sTNacc(const Geo &g, const double *M, const
       }
   return acc;
 }
+// The same products with a JOB per k-step: job(tk, s) is called once per k-step, ahead of its MFMAs -- the callers use it to issue
+// ONE load instruction of a strip they need later (StripReq), so that the 4 NT loads of a strip go out between the products'
+// MFMAs instead of as a burst in front of them.  (A burst stalls the wave at issue: phase stamps with the next pair's 67 loads
+// requested in front of the last two products put 4 400 cycles on that section, 66 per load -- the CU takes a strip set at L2 -> L1
+// bandwidth, and a wave blocked in the memory queue issues no MFMAs.  The k-step guards are branches, so the compiler's scheduler
+// cannot interleave across them by itself.)
+template <int NT, bool TR, class J>
+__device__ __forceinline__ Strip<NT> sTNacc_job(const Geo &g, const double *M, const Strip<NT> &V, Strip<NT> acc, J job) {
+#pragma unroll
+  for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      job(tk, s);
+      if (16 * tk + 4 * s < g.N) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+          acc.t[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(ufrag<NT, TR>(g, M, tk, ti, s), V.t[tk][s], acc.t[ti], 0, 0, 0);
+      }
+    }
+  return acc;
+}
+template <int NT, class J>
+__device__ __forceinline__ Strip<NT> sTNacc_sum_job(const Geo &g, const double *M1, const double *M2, const Strip<NT> &V, Strip<NT> acc, J job) {
+#pragma unroll
+  for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      job(tk, s);
+      if (16 * tk + 4 * s < g.N) {
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+          const double u = ufrag<NT, true>(g, M1, tk, ti, s) + ufrag<NT, false>(g, M2, tk, ti, s);
+          acc.t[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(u, V.t[tk][s], acc.t[ti], 0, 0, 0);
+        }
+      }
+    }
+  return acc;
+}
+// a strip requested one element row per call: step(a, r) issues the load of X.t[a][r] (sload spread over 4 NT calls)
+template <int NT>
+struct StripReq {
+  Strip<NT> X;
+  const double *q;
+  __device__ __forceinline__ void init(const Geo &g, int w, const double *p) { q = p + 16 * w + g.lr + (16 * NT) * g.lq; }
+  __device__ __forceinline__ void step(int a, int r) { X.t[a][r] = q[(16 * NT) * (16 * a + 4 * r)]; }
+};
 // ... with U = M1^T + M2 formed fragment-wise (W = b^T + Y, V = bn^T + Y of the doubling step)
 template <int NT>
 __device__ __forceinline__ Strip<NT> sTNacc_sum(const Geo &g, const double *M1, const double *M2, const Strip<NT> &V, Strip<NT> acc) {
@@ -282,36 +328,52 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
   const size_t span = (size_t)(a.n1_hi - a.n1_lo), npairs = span * a.nR;
   auto sgn_i = [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; };
   auto sgn_ij = [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; };
-  // The pair's own two blocks (the HBM streams) and the two strips its first products need, r[n0]^T and r[n1], are requested
-  // while the LAST two products of the previous pair run (a workgroup keeps one wave per SIMD, or two at NT = 3: little else
-  // hides their latency); more than these four strips does not fit the register file.  A pair off the grid is not prefetched.
+  // The pair's own two blocks (the HBM streams) and the two strips its first products need, r[n0]^T and r[n1]: as a burst at the
+  // top of the pair (fetch), or -- MOMR_WG_PREFETCH -- for the NEXT pair, row by row between the MFMAs of the last four products
+  // of the current one (pf_begin + the jobs of those products).  A pair off the grid is not prefetched.
   struct Top {
-    Strip<NT> a_s, b_s, r0_s, r1_s;
+    StripReq<NT> a_q, b_q, r0_q, r1_q;
     double Jp, Jm, e1;
     bool have;
   } nx;
   nx.have = false;
-  // two batches (a wave may have 63 memory operations outstanding; one batch of four strips at NT = 4 is 67 and would stall
-  // at issue for a full round trip): which = 1 the pair's own blocks and source entries, 2 the two per-point strips, 3 both
-  auto fetch = [&](size_t q, Top &t, int which) {
-    if (which & 1) t.have = false;
+  bool pf_on = false;
+  auto fetch = [&](size_t q, Top &t) {
+    t.have = false;
     if (q >= npairs) return;
     const int qn1 = a.n1_lo + (int)(q % span), qdn = (int)(q / span);
     const int qn0 = qn1 + a.off[qdn];
     if (qn0 < 0 || qn0 >= a.S) return;
     const size_t qu = (size_t)qn1 + (size_t)a.S * qdn, q4 = NN * qu, q3 = VS * qu;
-    if ((which & 1) && !FUSE) {
-      t.a_s = sload<NT>(g, w, a.ie_a[R_MP] + q4);
-      t.b_s = sload<NT>(g, w, a.ie_a[T_PP] + q4);
+    if (!FUSE) {
+      t.a_q.X = sload<NT>(g, w, a.ie_a[R_MP] + q4);
+      t.b_q.X = sload<NT>(g, w, a.ie_a[T_PP] + q4);
       t.Jp = a.ie_a[J0P][q3 + cw];
       t.Jm = a.ie_a[J0M][q3 + cw];
     }
-    if (which & 2) {
-      t.r0_s = sload<NT>(g, w, a.sm[SM_RT] + NN * qn0);
-      t.r1_s = sload<NT>(g, w, a.a_cur[R_MP] + NN * qn1);
-      t.e1 = a.expk_cur[qn1];
-      t.have = true;
+    t.r0_q.X = sload<NT>(g, w, a.sm[SM_RT] + NN * qn0);
+    t.r1_q.X = sload<NT>(g, w, a.a_cur[R_MP] + NN * qn1);
+    t.e1 = a.expk_cur[qn1];
+    t.have = true;
+  };
+  auto pf_begin = [&](size_t q, Top &t) {
+    pf_on = false;
+    t.have = false;
+    if (q >= npairs) return;
+    const int qn1 = a.n1_lo + (int)(q % span), qdn = (int)(q / span);
+    const int qn0 = qn1 + a.off[qdn];
+    if (qn0 < 0 || qn0 >= a.S) return;
+    const size_t qu = (size_t)qn1 + (size_t)a.S * qdn, q4 = NN * qu, q3 = VS * qu;
+    if (!FUSE) {
+      t.a_q.init(g, w, a.ie_a[R_MP] + q4);
+      t.b_q.init(g, w, a.ie_a[T_PP] + q4);
+      t.Jp = a.ie_a[J0P][q3 + cw];
+      t.Jm = a.ie_a[J0M][q3 + cw];
     }
+    t.r0_q.init(g, w, a.sm[SM_RT] + NN * qn0);
+    t.r1_q.init(g, w, a.a_cur[R_MP] + NN * qn1);
+    t.e1 = a.expk_cur[qn1];
+    pf_on = true;
   };
   MOMR_STAMP_INIT();
   for (size_t p = blockIdx.x; p < npairs; p += gridDim.x) {
@@ -347,10 +409,10 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     }
     MOMR_STAMP_NW(20);  // loop head, off-grid pairs
     const size_t m1 = NN * n1, m0 = NN * n0, v0 = VS * n0;
-    if (!nx.have) fetch(p, nx, 3);  // first pair of the workgroup, or the pair after one off the grid
-    Strip<NT> a_s = nx.a_s, b_s = nx.b_s;
+    if (!nx.have) fetch(p, nx);  // first pair of the workgroup, or the pair after one off the grid
+    Strip<NT> a_s = nx.a_q.X, b_s = nx.b_q.X;
     double Jp = nx.Jp, Jm = nx.Jm;
-    const Strip<NT> r0_s = nx.r0_s, r1_s = nx.r1_s;
+    const Strip<NT> r0_s = nx.r0_q.X, r1_s = nx.r1_q.X;
     const double e1 = nx.e1;
     nx.have = false;
     // Register economy: a strip that has a copy in LDS is READ BACK from there where it is needed again (a, b, bn), and the
@@ -390,7 +452,9 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
                   : smv<NT>(g, b_s, tm2);
     };
     if (!VLDS) own_mv();
-    const Strip<NT> gt0_s = sload<NT>(g, w, a.sm[SM_GT] + m0), ttgp1_s = sload<NT>(g, w, a.sm[SM_TTGP] + m1);
+    StripReq<NT> gt0_q, ttgp1_q, gr0_q, t0_q, ttgpr1_q;  // requested row by row between the MFMAs of the products below
+    gt0_q.init(g, w, a.sm[SM_GT] + m0); ttgp1_q.init(g, w, a.sm[SM_TTGP] + m1); gr0_q.init(g, w, a.sm[SM_GR] + m0);
+    t0_q.init(g, w, a.sm[SM_TT] + m0); ttgpr1_q.init(g, w, a.sm[SM_TTGPR] + m1);
     MOMR_STAMP_NW(23);  // publish a, b, r0 (waits for the pair's blocks)
     WG_SYNC_ST();
     if (VLDS) {
@@ -399,8 +463,9 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
       own_mv();
     }
     // X = ier r0 + r1 ier
-    Strip<NT> X_s = sTNacc<NT, false>(g, S_g, a_s, szeros<NT>());  // U = r0_c
-    X_s = sTNacc<NT, true>(g, S_a, r1_s, X_s);                     // U = a_c = (a_t)^T
+    Strip<NT> X_s = sTNacc_job<NT, false>(g, S_g, a_s, szeros<NT>(), [&](int tk, int s) { gt0_q.step(tk, s); });   // U = r0_c
+    X_s = sTNacc_job<NT, true>(g, S_a, r1_s, X_s, [&](int tk, int s) { ttgp1_q.step(tk, s); });                   // U = a_c = (a_t)^T
+    const Strip<NT> &gt0_s = gt0_q.X, &ttgp1_s = ttgp1_q.X;
     const double X1 = smv<NT>(g, X_s, tm1), X2 = smv<NT>(g, X_s, tm2);
     MOMR_STAMP_NW(25);  // 4 + 2 mat-vecs, X: 2 products
     WG_SYNC_ST();  // r0 has been read by everybody
@@ -428,41 +493,41 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     }
     MOMR_STAMP_NW(24);  // source chain: 4 mat-vecs, 3 exchanges (their barriers: 26)
     // ---- operators                                                                                              :98-125
-    const Strip<NT> gr0_s = sload<NT>(g, w, a.sm[SM_GR] + m0);              // consumed three products later
-    const Strip<NT> Y_s = sTNacc<NT, false>(g, S_x, sread<NT>(g, w, S_g), szeros<NT>());  // Y_c = X G t[n0]   (U = X_t)
+    const Strip<NT> Y_s = sTNacc_job<NT, false>(g, S_x, sread<NT>(g, w, S_g), szeros<NT>(),  // Y_c = X G t[n0]   (U = X_t)
+                                                [&](int tk, int s) { gr0_q.step(tk, s); });   // (G r)[n0]: consumed three products later
+    const Strip<NT> &gr0_s = gr0_q.X;
     MOMR_STAMP_NW(28);  // Y: 1 product
     WG_SYNC_ST();                                                              // X has been read
     spublish<NT>(g, w, S_x, Y_s);
     MOMR_STAMP_NW(27);
     WG_SYNC_ST();
-    Strip<NT> bn_s = sTNacc_sum<NT>(g, S_b, S_x, ttgp1_s, szeros<NT>());    // tG (iet + Y)            (U = W_c = b_c + Y_c)
-    const Strip<NT> t0_s = sload<NT>(g, w, a.sm[SM_TT] + m0);               // consumed after three more products
-    bn_s = sTNacc<NT, false>(g, S_g, sread<NT>(g, w, S_b), bn_s);           // + iet G t[n0]           (U = (G t)[n0]_c)
+    Strip<NT> bn_s = sTNacc_sum_job<NT>(g, S_b, S_x, ttgp1_s, szeros<NT>(),   // tG (iet + Y)            (U = W_c = b_c + Y_c)
+                                        [&](int tk, int s) { t0_q.step(tk, s); });
+    bn_s = sTNacc_job<NT, false>(g, S_g, sread<NT>(g, w, S_b), bn_s,           // + iet G t[n0]           (U = (G t)[n0]_c)
+                                 [&](int tk, int s) { ttgpr1_q.step(tk, s); });
+    const Strip<NT> &t0_s = t0_q.X, &ttgpr1_s = ttgpr1_q.X;
     MOMR_STAMP_NW(29);  // iet: 2 products
     WG_SYNC_ST();                                                              // b and (G t)[n0] have been read
     spublish<NT>(g, w, S_b, bn_s);
     spublish<NT>(g, w, S_g, gr0_s);
     MOMR_STAMP_NW(27);
     WG_SYNC_ST();
-    Strip<NT> Q_s = sTNacc<NT, false>(g, S_g, bn_s, szeros<NT>());          // iet(new) G r[n0]        (U = (G r)[n0]_c)
-    const Strip<NT> ttgpr1_s = sload<NT>(g, w, a.sm[SM_TTGPR] + m1);
-    Q_s = sTNacc<NT, true>(g, S_a, ttgp1_s, Q_s);                           // + tG ier                (U = a_c)
+    constexpr bool PF = (MOMR_WG_PREFETCH & (NT == 2 ? 1 : (NT == 3 ? 2 : 4))) != 0;
+    if (PF) pf_begin(p + gridDim.x, nx);
+    Strip<NT> Q_s = sTNacc_job<NT, false>(g, S_g, bn_s, szeros<NT>(),          // iet(new) G r[n0]        (U = (G r)[n0]_c)
+                                          [&](int tk, int s) { if (PF && pf_on) nx.r0_q.step(tk, s); });
+    Q_s = sTNacc_job<NT, true>(g, S_a, ttgp1_s, Q_s,                           // + tG ier                (U = a_c)
+                               [&](int tk, int s) { if (PF && pf_on) nx.r1_q.step(tk, s); });
     MOMR_STAMP_NW(30);  // Q: 2 products
     WG_SYNC_ST();                                                              // (G r)[n0] has been read
     spublish<NT>(g, w, S_g, t0_s);
     MOMR_STAMP_NW(27);
     WG_SYNC_ST();
-    constexpr bool PF = (MOMR_WG_PREFETCH & (NT == 2 ? 1 : (NT == 3 ? 2 : 4))) != 0;
-    if (PF) {
-      fetch(p + gridDim.x, nx, 1);
-      __builtin_amdgcn_sched_barrier(0);  // the requests stay HERE, ahead of the product (the scheduler sinks them otherwise)
-    }
-    Strip<NT> an_s = sTNacc_sum<NT>(g, S_b, S_x, ttgpr1_s, szeros<NT>());   // (iet(new) + Y) ...      (U = V_c = bn_c + Y_c)
-    if (PF) {
-      fetch(p + gridDim.x, nx, 2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    an_s = sTNacc<NT, false>(g, S_g, Q_s, an_s);                            // + t[n0]-side product    (U = t0_c)
+    Strip<NT> an_s = sTNacc_sum_job<NT>(g, S_b, S_x, ttgpr1_s, szeros<NT>(),   // (iet(new) + Y) ...      (U = V_c = bn_c + Y_c)
+                                        [&](int tk, int s) { if (PF && !FUSE && pf_on) nx.a_q.step(tk, s); });
+    an_s = sTNacc_job<NT, false>(g, S_g, Q_s, an_s,                            // + t[n0]-side product    (U = t0_c)
+                                 [&](int tk, int s) { if (PF && !FUSE && pf_on) nx.b_q.step(tk, s); });
+    if (PF && pf_on) nx.have = true;
     an_s = sadd<NT>(sread<NT>(g, w, S_a), an_s);
     bn_s = sread<NT>(g, w, S_b);
     MOMR_STAMP_NW(31);  // ier: 2 products, read-back of a and bn
