@@ -248,13 +248,14 @@ def test_rt_run_rrs_surfaces(rtamd, surf, nS):
 
 
 @pytest.mark.parametrize("strict", [True, False])
-@pytest.mark.parametrize("world", [2, 3, 5])
-def test_rrs_windows_reassemble_the_full_run(rtamd, strict, world):
+@pytest.mark.parametrize("world,nS,lt,nv", [(2, 3, 5, 1), (3, 3, 5, 1), (5, 3, 5, 1), (3, 3, 11, 3), (2, 3, 21, 3), (3, 4, 21, 3)])
+def test_rrs_windows_reassemble_the_full_run(rtamd, strict, world, nS, lt, nv):
     """Spectral sharding of the RRS path: every rank runs its window = owned slice + halo of max |i_λ₁λ₀|
     (mom_rrs_set_shard) with the global ndoubl; the owned slices, put side by side, are the unsharded run BIT FOR BIT
-    (same kernels, same per-point arithmetic, no exchange).  world = 5: slices of 8 points, halo 7."""
+    (same kernels, same per-point arithmetic, no exchange).  world = 5: slices of 8 points, halo 7.  N = 15 (one wave per pair),
+    and -- r5 -- N = 27, 42, 56: the workgroup-per-pair kernels with an owned range that is not the whole axis."""
     rt = rtamd.corert
-    m = rtamd.scenes.make_scene(3, 5, 3, 40, seed=77, aerosol_total=0.1, **VIEWS[1])
+    m = rtamd.scenes.make_scene(nS, lt, 3, 40, seed=77, aerosol_total=0.1, **VIEWS[nv])
     RS, _ = _rrs_inputs(rtamd, [-4, -1, 2, 7, 3], strict)
     full = rt.rt_run_rrs(RS, m)
     assert np.abs(full[2]).max() > 0
