@@ -438,7 +438,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_dbl_point(KArgs a) {
 // and iet++ as _t tiles, ieJ0+- in column layout.  exp(-d1/mu_i) and exp(-d0/mu_j) are evaluated once per stream (2 exp per
 // lane + 1 for the attenuation) and combined, i.e. 1 - e1 e0 stands for the reference's 1 - exp(-(d1/mu_i + d0/mu_j)):
 // the same absolute accuracy (both are 1 minus a number rounded near 1).
-template <int NT>
+// ND0: the layer has ndoubl = 0 (k_ie_elemental_tile below): no D sign on ier-+ and none on ieJ0- (elemental_inelastic.jl:378-402).
+template <int NT, bool ND0 = false>
 __device__ __forceinline__ void ie_elem_tile(const Geo &g, const KArgs &a, int n1, int dn, int n0, Mat<NT> &a_t, Mat<NT> &b_t,
                                              CV<NT> &Jp, CV<NT> &Jm) {
 #pragma clang fp contract(off)
@@ -490,7 +491,7 @@ __device__ __forceinline__ void ie_elem_tile(const Geo &g, const KArgs &a, int n
               t = pre * a.Zr_pp[i + (size_t)N * j] * (1 / ((mui / muj) - ratio)) * wj * (e1 - e0);
             }
           }
-          if (scomp(i, n, a.strict_idx) > 2) r = -r;  // apply_D_elemental_RRS!, ndoubl >= 1
+          if (!ND0 && scomp(i, n, a.strict_idx) > 2) r = -r;  // apply_D_elemental_RRS!, ndoubl >= 1
         }
         a_t.t[ta][tb][rr] = r;
         b_t.t[ta][tb][rr] = t;
@@ -515,10 +516,55 @@ __device__ __forceinline__ void ie_elem_tile(const Geo &g, const KArgs &a, int n
       }
       jm = wct02 * pre * zmI * (1 / ((mui / mus) + ratio)) * (1 - e1 * e0s);
       jp *= att;
-      jm = a.D[i % n] * (jm * att);
+      jm = ND0 ? (jm * att) : a.D[i % n] * (jm * att);
     }
     Jp.c[tb] = jp;
     Jm.c[tb] = jm;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// r5: the inelastic elemental layer of a layer WITHOUT doublings (ndoubl = 0; with doublings it is formed inside the first
+// doubling step, FUSE above) in tile form, scene-level fast mode only: one wavefront per (n1, dn) forms ier-+ / iet++ / ieJ0+- of
+// the pair with ie_elem_tile -- 2 exp per lane and stream instead of 3 exp and a handful of divisions per ELEMENT in
+// k_ie_elemental (C5: 4.2 ms per launch, 12 % of a run, at 1.2 TB/s of stores) -- and stores whole zero-padded tiles.  In the
+// corrected position ier+- / iet-- are not written at all: they are sgn (.) ier-+ / sgn (.) iet++ and are derived where they are
+// read (derive_pm, as after a doubling).  Off the grid: zeros (get_elem_rt_RRS! writes every element), sources untouched.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) k_ie_elemental_tile(KArgs a) {
+  const Geo g = make_geo<NT>(a.N, rrs_smem);
+  const int n = a.nS, wave = threadIdx.x >> 6;
+  const size_t NN = (size_t)a.P * a.P, VS = a.P;
+  const size_t span = (size_t)(a.n1_hi - a.n1_lo), npairs = span * a.nR, stride = (size_t)gridDim.x * kWavesPerBlock;
+  for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += stride) {
+    const int n1 = a.n1_lo + (int)(p % span), dn = (int)(p / span);
+    const int n0 = n1 + a.off[dn];
+    const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = VS * u;
+    if (n0 < 0 || n0 >= a.S) {
+      store_t<NT>(g, a.ie_a[R_MP] + o4, zeros<NT>());
+      store_t<NT>(g, a.ie_a[T_PP] + o4, zeros<NT>());
+      if (!a.derive_pm) {
+        store_t<NT>(g, a.ie_a[R_PM] + o4, zeros<NT>());
+        store_t<NT>(g, a.ie_a[T_MM] + o4, zeros<NT>());
+      }
+      continue;
+    }
+    Mat<NT> a_t, b_t;
+    CV<NT> Jp, Jm;
+    ie_elem_tile<NT, true>(g, a, n1, dn, n0, a_t, b_t, Jp, Jm);
+    store_t<NT>(g, a.ie_a[R_MP] + o4, a_t);
+    store_t<NT>(g, a.ie_a[T_PP] + o4, b_t);
+    storeC<NT>(g, a.ie_a[J0P] + o3, Jp);
+    storeC<NT>(g, a.ie_a[J0M] + o3, Jm);
+    if (!a.derive_pm) {
+      if (n > 1) {
+        map_t<NT>(g, a_t, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+        map_t<NT>(g, b_t, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
+      }
+      store_t<NT>(g, a.ie_a[R_PM] + o4, a_t);
+      store_t<NT>(g, a.ie_a[T_MM] + o4, b_t);
+    }
   }
 }
 
@@ -1540,7 +1586,7 @@ __global__ void k_unpack(double *nat, const double *dev, int rows, int cols, int
 #include "mom_rrs_wg.hpp"
 }  // namespace momr_big
 // which: 0 k_el_point, 1 k_dbl_point, 2 k_int_point, 3 k_dbl_pair (v0 = fused elemental, v1 = mode), 4 k_int_pair (v0 = surface,
-// v1 = derived +- / -- blocks), 5 k_dbl_pair_wg, 6 k_int_pair_wg (workgroup per pair, mom_rrs_wg.hpp; grid = workgroups), 7 k_dbl_point_wg (workgroup per point, nt >= 3); nt = 3 or 4; args: the
+// v1 = derived +- / -- blocks), 5 k_dbl_pair_wg, 6 k_int_pair_wg (workgroup per pair, mom_rrs_wg.hpp; grid = workgroups), 7 k_dbl_point_wg (workgroup per point, nt >= 3), 8 k_ie_elemental_tile; nt = 3 or 4; args: the
 // KArgs of the caller (layout-identical in both namespaces)
 hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, void *stream, const void *args, int iface) {
   using namespace momr_big;
@@ -1591,6 +1637,7 @@ hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, voi
       else WG_INT(false, false);
 #undef WG_INT
     }
+    case 8: BIG_NT(k_ie_elemental_tile<3>, k_ie_elemental_tile<4>, a);
     case 7: {  // k_dbl_point_wg: one workgroup per spectral point (grid = workgroups)
       const size_t ldp = (nt == 3) ? wg_point_lds_bytes<3>() : wg_point_lds_bytes<4>();
       const void *kp = (nt == 3) ? reinterpret_cast<const void *>(k_dbl_point_wg3) : reinterpret_cast<const void *>(k_dbl_point_wg4);
@@ -1828,6 +1875,16 @@ hipError_t elemental(State *s, const Streams &q, int m, int nd, int shift, const
       s->el_pending = true;
       s->el.m = m; s->el.nd = nd; s->el.sh = shift; s->el.tau_sum = tau_sum; s->el.tau = tau; s->el.varpi = varpi;
       s->el.fscatt = fscatt; s->el.Zr_pp = Zr_pp; s->el.Zr_mp = Zr_mp;
+      return hipSuccess;
+    }
+    static const bool el_tile = !(getenv("MOM_RRS_EL_TILE") && atoi(getenv("MOM_RRS_EL_TILE")) == 0);
+    if (s->fast && nd < 1 && (fast_bits() & 1) && el_tile) {  // tile form (k_ie_elemental_tile); +- / -- blocks derived where read
+      const bool derive = !s->strict_rrs && (fast_bits() & 2);
+      a.derive_pm = derive ? 1 : 0;
+      RCHK(tick(s, TK_IE_ELEMENTAL, true));
+      if ((size_t)(s->n1_hi - s->n1_lo) * s->nR) LAUNCH_NT(s, k_ie_elemental_tile, 8, grid_pairs(s), a);
+      RCHK(tick(s, TK_IE_ELEMENTAL, false));
+      s->pm_valid = !derive; s->pm_derivable = true;
       return hipSuccess;
     }
     const size_t tot = (size_t)s->N * s->N * (size_t)(s->n1_hi - s->n1_lo) * s->nR;
