@@ -524,14 +524,15 @@ __device__ __forceinline__ void ie_elem_tile(const Geo &g, const KArgs &a, int n
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// r5: the inelastic elemental layer of a layer WITHOUT doublings (ndoubl = 0; with doublings it is formed inside the first
-// doubling step, FUSE above) in tile form, scene-level fast mode only: one wavefront per (n1, dn) forms ier-+ / iet++ / ieJ0+- of
-// the pair with ie_elem_tile -- 2 exp per lane and stream instead of 3 exp and a handful of divisions per ELEMENT in
-// k_ie_elemental (C5: 4.2 ms per launch, 12 % of a run, at 1.2 TB/s of stores) -- and stores whole zero-padded tiles.  In the
-// corrected position ier+- / iet-- are not written at all: they are sgn (.) ier-+ / sgn (.) iet++ and are derived where they are
-// read (derive_pm, as after a doubling).  Off the grid: zeros (get_elem_rt_RRS! writes every element), sources untouched.
+// r5: the inelastic elemental layer in tile form, scene-level fast mode only: one wavefront per (n1, dn) forms ier-+ / iet++ /
+// ieJ0+- of the pair with ie_elem_tile -- 2 exp per lane and stream instead of 3 exp and a handful of divisions per ELEMENT in
+// k_ie_elemental (C5: 4.2 ms per launch, 12 % of a run, at 1.2 TB/s of stores) -- and stores whole zero-padded tiles.
+// ND0 (ndoubl = 0): in the corrected position ier+- / iet-- are not written at all: they are sgn (.) ier-+ / sgn (.) iet++ and
+// are derived where they are read (derive_pm, as after a doubling).  Off the grid: zeros (get_elem_rt_RRS! writes every
+// element), sources untouched.  !ND0 (ndoubl >= 1; alternative to forming the layer inside the first doubling step, FUSE above):
+// the D signs of apply_D_elemental_RRS!, off the grid ieJ0- is multiplied by D (elemental_inelastic.jl:378-380).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool ND0>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) k_ie_elemental_tile(KArgs a) {
   const Geo g = make_geo<NT>(a.N, rrs_smem);
   const int n = a.nS, wave = threadIdx.x >> 6;
@@ -544,20 +545,26 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_ie_elemental_tile(KArgs
     if (n0 < 0 || n0 >= a.S) {
       store_t<NT>(g, a.ie_a[R_MP] + o4, zeros<NT>());
       store_t<NT>(g, a.ie_a[T_PP] + o4, zeros<NT>());
-      if (!a.derive_pm) {
+      if (ND0 && !a.derive_pm) {
         store_t<NT>(g, a.ie_a[R_PM] + o4, zeros<NT>());
         store_t<NT>(g, a.ie_a[T_MM] + o4, zeros<NT>());
+      }
+      if (!ND0) {
+        CV<NT> Jm = loadC<NT>(g, a.ie_a[J0M] + o3);
+#pragma unroll
+        for (int tb = 0; tb < NT; ++tb) Jm.c[tb] = a.D[g.col(tb) % n] * Jm.c[tb];
+        storeC<NT>(g, a.ie_a[J0M] + o3, Jm);
       }
       continue;
     }
     Mat<NT> a_t, b_t;
     CV<NT> Jp, Jm;
-    ie_elem_tile<NT, true>(g, a, n1, dn, n0, a_t, b_t, Jp, Jm);
+    ie_elem_tile<NT, ND0>(g, a, n1, dn, n0, a_t, b_t, Jp, Jm);
     store_t<NT>(g, a.ie_a[R_MP] + o4, a_t);
     store_t<NT>(g, a.ie_a[T_PP] + o4, b_t);
     storeC<NT>(g, a.ie_a[J0P] + o3, Jp);
     storeC<NT>(g, a.ie_a[J0M] + o3, Jm);
-    if (!a.derive_pm) {
+    if (ND0 && !a.derive_pm) {
       if (n > 1) {
         map_t<NT>(g, a_t, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
         map_t<NT>(g, b_t, [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; });
@@ -1586,7 +1593,7 @@ __global__ void k_unpack(double *nat, const double *dev, int rows, int cols, int
 #include "mom_rrs_wg.hpp"
 }  // namespace momr_big
 // which: 0 k_el_point, 1 k_dbl_point, 2 k_int_point, 3 k_dbl_pair (v0 = fused elemental, v1 = mode), 4 k_int_pair (v0 = surface,
-// v1 = derived +- / -- blocks), 5 k_dbl_pair_wg, 6 k_int_pair_wg (workgroup per pair, mom_rrs_wg.hpp; grid = workgroups), 7 k_dbl_point_wg (workgroup per point, nt >= 3), 8 k_ie_elemental_tile; nt = 3 or 4; args: the
+// v1 = derived +- / -- blocks), 5 k_dbl_pair_wg, 6 k_int_pair_wg (workgroup per pair, mom_rrs_wg.hpp; grid = workgroups), 7 k_dbl_point_wg (workgroup per point, nt >= 3), 8 k_ie_elemental_tile (v0 = layer without doublings); nt = 3 or 4; args: the
 // KArgs of the caller (layout-identical in both namespaces)
 hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, void *stream, const void *args, int iface) {
   using namespace momr_big;
@@ -1637,7 +1644,9 @@ hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, voi
       else WG_INT(false, false);
 #undef WG_INT
     }
-    case 8: BIG_NT(k_ie_elemental_tile<3>, k_ie_elemental_tile<4>, a);
+    case 8:
+      if (v0) BIG_NT((k_ie_elemental_tile<3, true>), (k_ie_elemental_tile<4, true>), a);
+      else BIG_NT((k_ie_elemental_tile<3, false>), (k_ie_elemental_tile<4, false>), a);
     case 7: {  // k_dbl_point_wg: one workgroup per spectral point (grid = workgroups)
       const size_t ldp = (nt == 3) ? wg_point_lds_bytes<3>() : wg_point_lds_bytes<4>();
       const void *kp = (nt == 3) ? reinterpret_cast<const void *>(k_dbl_point_wg3) : reinterpret_cast<const void *>(k_dbl_point_wg4);
@@ -1871,20 +1880,30 @@ hipError_t elemental(State *s, const Streams &q, int m, int nd, int shift, const
   if (elastic) LAUNCH_NT(s, k_el_point, 0, grid_points(s), a);
   s->el_pending = false;
   if (inelastic) {
-    if (s->fast && nd >= 1 && (fast_bits() & 1)) {  // deferred into the first doubling step (k_dbl_pair, fuse_el)
+    // scene-level fast mode: the tile form (k_ie_elemental_tile).  For a layer with doublings the alternative is to form the layer
+    // inside the first doubling step (fuse_el): MOM_RRS_EL_FUSE=1 (default: only above N = 48; below, the separate tile kernel +
+    // the plain first step measured faster, profiles/r05_C5_ab.txt (5)).  MOM_RRS_EL_TILE=0: the element-wise kernel below / the fused form as in r4.
+    static const bool el_tile = !(getenv("MOM_RRS_EL_TILE") && atoi(getenv("MOM_RRS_EL_TILE")) == 0);
+    static const int el_fuse_env = getenv("MOM_RRS_EL_FUSE") ? (atoi(getenv("MOM_RRS_EL_FUSE")) != 0 ? 1 : 0) : -1;
+    const bool el_fuse = el_fuse_env >= 0 ? el_fuse_env == 1 : s->N > 48;  // 4 x 4 tiles: the fused form stays ahead (N = 60: 414 vs 420 ms per run)
+    if (s->fast && nd >= 1 && (fast_bits() & 1) && (el_fuse || !el_tile)) {  // deferred into the first doubling step (k_dbl_pair, fuse_el)
       s->el_pending = true;
       s->el.m = m; s->el.nd = nd; s->el.sh = shift; s->el.tau_sum = tau_sum; s->el.tau = tau; s->el.varpi = varpi;
       s->el.fscatt = fscatt; s->el.Zr_pp = Zr_pp; s->el.Zr_mp = Zr_mp;
       return hipSuccess;
     }
-    static const bool el_tile = !(getenv("MOM_RRS_EL_TILE") && atoi(getenv("MOM_RRS_EL_TILE")) == 0);
-    if (s->fast && nd < 1 && (fast_bits() & 1) && el_tile) {  // tile form (k_ie_elemental_tile); +- / -- blocks derived where read
+    if (s->fast && (fast_bits() & 1) && el_tile) {
       const bool derive = !s->strict_rrs && (fast_bits() & 2);
-      a.derive_pm = derive ? 1 : 0;
+      a.derive_pm = derive ? 1 : 0;  // (read by the ND0 image only)
       RCHK(tick(s, TK_IE_ELEMENTAL, true));
-      if ((size_t)(s->n1_hi - s->n1_lo) * s->nR) LAUNCH_NT(s, k_ie_elemental_tile, 8, grid_pairs(s), a);
+      if ((size_t)(s->n1_hi - s->n1_lo) * s->nR) {
+        const dim3 gr(grid_pairs(s));
+        if (s->N <= 16) { if (nd < 1) RCHK(launch_lds((k_ie_elemental_tile<1, true>), gr, lds<1>(), s->stream, a)); else RCHK(launch_lds((k_ie_elemental_tile<1, false>), gr, lds<1>(), s->stream, a)); }
+        else if (s->N <= 32) { if (nd < 1) RCHK(launch_lds((k_ie_elemental_tile<2, true>), gr, lds<2>(), s->stream, a)); else RCHK(launch_lds((k_ie_elemental_tile<2, false>), gr, lds<2>(), s->stream, a)); }
+        else RCHK(momr_big_launch(8, s->N <= 48 ? 3 : 4, nd < 1 ? 1 : 0, 0, gr.x, (void *)s->stream, &a, 0));
+      }
       RCHK(tick(s, TK_IE_ELEMENTAL, false));
-      s->pm_valid = !derive; s->pm_derivable = true;
+      if (nd < 1) { s->pm_valid = !derive; s->pm_derivable = true; }
       return hipSuccess;
     }
     const size_t tot = (size_t)s->N * s->N * (size_t)(s->n1_hi - s->n1_lo) * s->nR;

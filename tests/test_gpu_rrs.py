@@ -387,16 +387,22 @@ def test_rrs_workgroup_and_wave_kernels_agree(tmp_path, nS, lt, S, Nz, strict):
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
     out = {}
-    for wg in ("0", "1", "point"):   # "point": also the doubling point kernel as a workgroup per point (opt-in, N > 32)
+    # "point": also the doubling point kernel as a workgroup per point (opt-in, N > 32); "fuse": the inelastic elemental layer
+    # formed inside the first doubling step of a layer (MOM_RRS_EL_FUSE=1) instead of by the separate tile kernel (default)
+    envs = {"0": dict(MOM_RRS_WG="0"), "1": dict(MOM_RRS_WG="1"), "point": dict(MOM_RRS_WG="1", MOM_RRS_WG_POINT="1"),
+            "fuse": dict(MOM_RRS_WG="1", MOM_RRS_EL_FUSE="1"), "fuse0": dict(MOM_RRS_WG="0", MOM_RRS_EL_FUSE="1"),
+            "elementwise": dict(MOM_RRS_WG="1", MOM_RRS_EL_TILE="0")}
+    for wg in envs:
         f = tmp_path / f"wg{wg}.npz"
-        env = dict(os.environ, MOM_RRS_WG="1", MOM_RRS_WG_POINT="1") if wg == "point" else dict(os.environ, MOM_RRS_WG=wg)
+        env = dict(os.environ, **envs[wg])
         subprocess.run([sys.executable, str(root / "tests" / "rrs_probe.py"), str(nS), str(lt), str(S), str(Nz), str(int(strict)), str(f)],
                        check=True, env=env, timeout=600)
         out[wg] = np.load(f)
     assert int(out["0"]["N"]) == {(4, 9): 32, (3, 21): 42, (4, 21): 56, (3, 33): 60}[(nS, lt)]
     scale = np.abs(out["0"]["R"][:, 0:1, :]).max()
     assert np.abs(out["0"]["ieR"]).max() > 0
-    for other in ("1", "point"):
+    for other in ("1", "point", "fuse", "fuse0", "elementwise"):
         for k in ("R", "T", "ieR", "ieT", "hdr", "up", "dw"):
             d = np.abs(out["0"][k] - out[other][k]).max()
-            assert d <= 1e-13 * scale, (other, k, d, scale)
+            # the element-wise elemental kernel evaluates 1 - exp(-(x + y)) where the tile forms evaluate 1 - exp(-x) exp(-y)
+            assert d <= (1e-11 if other == "elementwise" else 1e-13) * scale, (other, k, d, scale)
