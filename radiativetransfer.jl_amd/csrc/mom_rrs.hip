@@ -439,9 +439,40 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_dbl_point(KArgs a) {
 // lane + 1 for the attenuation) and combined, i.e. 1 - e1 e0 stands for the reference's 1 - exp(-(d1/mu_i + d0/mu_j)):
 // the same absolute accuracy (both are 1 minus a number rounded near 1).
 // ND0: the layer has ndoubl = 0 (k_ie_elemental_tile below): no D sign on ier-+ and none on ieJ0- (elemental_inelastic.jl:378-402).
-template <int NT, bool ND0 = false>
+// ElemPre (k_ie_elemental_tile, NT <= 2): what an element needs that does not depend on the pair -- the two Raman phase-matrix
+// entries, mu_i / mu_j and w_j / wdiv -- computed once per wave in front of its pair loop (the same values: two of the four
+// divisions and three loads per element and pair less).
+template <int NT>
+struct ElemPre {
+  Mat<NT> zmp, zpp, q;
+  Vec<NT> wj;
+};
+template <int NT>
+__device__ __forceinline__ ElemPre<NT> ie_elem_pre(const Geo &g, const KArgs &a) {
+#pragma clang fp contract(off)
+  ElemPre<NT> P;
+  const int N = a.N;
+  const double wdiv = (a.m == 0) ? 2.0 : 4.0;
+#pragma unroll
+  for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int j = g.row(ta, rr);
+      P.wj.t[ta][rr] = (j < N) ? a.wt[j] / wdiv : 0.0;
+#pragma unroll
+      for (int tb = 0; tb < NT; ++tb) {
+        const int i = g.col(tb);
+        const bool in = (i < N && j < N);
+        P.zmp.t[ta][tb][rr] = in ? a.Zr_mp[i + (size_t)N * j] : 0.0;
+        P.zpp.t[ta][tb][rr] = in ? a.Zr_pp[i + (size_t)N * j] : 0.0;
+        P.q.t[ta][tb][rr] = in ? a.mu[i] / a.mu[j] : 1.0;
+      }
+    }
+  return P;
+}
+template <int NT, bool ND0 = false, bool PRE = false>
 __device__ __forceinline__ void ie_elem_tile(const Geo &g, const KArgs &a, int n1, int dn, int n0, Mat<NT> &a_t, Mat<NT> &b_t,
-                                             CV<NT> &Jp, CV<NT> &Jm) {
+                                             CV<NT> &Jp, CV<NT> &Jm, const ElemPre<NT> *P = nullptr) {
 #pragma clang fp contract(off)
   const int N = a.N, n = a.nS;
   const double scl = (double)(1ull << a.sh);
@@ -477,18 +508,22 @@ __device__ __forceinline__ void ie_elem_tile(const Geo &g, const KArgs &a, int n
         const int i = g.col(tb), j = g.row(ta, rr);
         double r = 0.0, t = 0.0;
         if (i < N && j < N) {
-          const double mui = muC.c[tb], muj = muR.t[ta][rr], wj = a.wt[j] / wdiv;
+          const double mui = muC.c[tb], muj = muR.t[ta][rr], wj = PRE ? P->wj.t[ta][rr] : a.wt[j] / wdiv;
           if (wj > 1.e-8) {
             const double e1 = e1C.c[tb], e0 = e0R.t[ta][rr];
-            r = fs0 * vR * v0 * a.Zr_mp[i + (size_t)N * j] * (1 / ((mui / muj) + ratio)) * (1 - e1 * e0) * wj;
+            const double q = PRE ? P->q.t[ta][tb][rr] : mui / muj;
+            const double zmp = PRE ? P->zmp.t[ta][tb][rr] : a.Zr_mp[i + (size_t)N * j];
+            r = fs0 * vR * v0 * zmp * (1 / (q + ratio)) * (1 - e1 * e0) * wj;
             if (mui == muj) {
               if (i == j) {
-                const double wi = a.wt[i] / wdiv, e0i = e0C.c[tb];
-                if (fabs(d0 - d1) > 1.e-6) t = pre * a.Zr_pp[i + (size_t)N * i] * wi * (e0i - e1) / (1 - ratio);
-                else t = pre * a.Zr_pp[i + (size_t)N * i] * wi * (1 - e0i);
+                const double wi = PRE ? wj : a.wt[i] / wdiv, e0i = e0C.c[tb];   // (i == j: the same weight)
+                const double zpp = PRE ? P->zpp.t[ta][tb][rr] : a.Zr_pp[i + (size_t)N * i];
+                if (fabs(d0 - d1) > 1.e-6) t = pre * zpp * wi * (e0i - e1) / (1 - ratio);
+                else t = pre * zpp * wi * (1 - e0i);
               }
             } else {
-              t = pre * a.Zr_pp[i + (size_t)N * j] * (1 / ((mui / muj) - ratio)) * wj * (e1 - e0);
+              const double zpp = PRE ? P->zpp.t[ta][tb][rr] : a.Zr_pp[i + (size_t)N * j];
+              t = pre * zpp * (1 / (q - ratio)) * wj * (e1 - e0);
             }
           }
           if (!ND0 && scomp(i, n, a.strict_idx) > 2) r = -r;  // apply_D_elemental_RRS!, ndoubl >= 1
@@ -538,6 +573,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_ie_elemental_tile(KArgs
   const int n = a.nS, wave = threadIdx.x >> 6;
   const size_t NN = (size_t)a.P * a.P, VS = a.P;
   const size_t span = (size_t)(a.n1_hi - a.n1_lo), npairs = span * a.nR, stride = (size_t)gridDim.x * kWavesPerBlock;
+  constexpr bool PRE = (NT <= 2);  // (3 x 3 / 4 x 4 tiles: the three tile sets would not stay in registers)
+  ElemPre<NT> P;
+  if (PRE) P = ie_elem_pre<NT>(g, a);
   for (size_t p = (size_t)blockIdx.x * kWavesPerBlock + wave; p < npairs; p += stride) {
     const int n1 = a.n1_lo + (int)(p % span), dn = (int)(p / span);
     const int n0 = n1 + a.off[dn];
@@ -559,7 +597,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) k_ie_elemental_tile(KArgs
     }
     Mat<NT> a_t, b_t;
     CV<NT> Jp, Jm;
-    ie_elem_tile<NT, ND0>(g, a, n1, dn, n0, a_t, b_t, Jp, Jm);
+    ie_elem_tile<NT, ND0, PRE>(g, a, n1, dn, n0, a_t, b_t, Jp, Jm, &P);
     store_t<NT>(g, a.ie_a[R_MP] + o4, a_t);
     store_t<NT>(g, a.ie_a[T_PP] + o4, b_t);
     storeC<NT>(g, a.ie_a[J0P] + o3, Jp);
