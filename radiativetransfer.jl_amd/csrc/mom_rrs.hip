@@ -1976,10 +1976,9 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
       a.fscatt = s->el.fscatt; a.Zr_pp = s->el.Zr_pp; a.Zr_mp = s->el.Zr_mp;
       s->el_pending = false;
     }
-    // one workgroup per point (mom_rrs_wg.hpp dbl_point_wg): opt-in, MOM_RRS_WG_POINT=1.  Measured SLOWER than the wave-per-point
-    // kernel at S = 500 (profiles/r05_rrs_wg_ab.txt (6)): the Gauss-Jordan inverse runs on one wave either way, and a
-    // 157 KB workgroup per CU runs the points of a launch in two rounds where 500 independent waves ran in one
-    static const bool wg_point = getenv("MOM_RRS_WG_POINT") && atoi(getenv("MOM_RRS_WG_POINT")) != 0;
+    // above N = 32: one workgroup per point (mom_rrs_wg.hpp dbl_point_wg: products in strips from LDS copies, Gauss-Jordan inverse
+    // over all waves); MOM_RRS_WG_POINT=0 selects the wave-per-point kernel (operators in scratch, inverse on one wave)
+    static const bool wg_point = !(getenv("MOM_RRS_WG_POINT") && atoi(getenv("MOM_RRS_WG_POINT")) == 0);
     if (wg_point && wg_nt(s) >= 3)
       RCHK(momr_big_launch(7, wg_nt(s), 0, 0, (unsigned)std::max(1, std::min(s->S, 256 * 8)), (void *)s->stream, &a, 0));
     else LAUNCH_NT(s, k_dbl_point, 1, grid_points(s), a);

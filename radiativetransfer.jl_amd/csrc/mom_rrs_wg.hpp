@@ -702,7 +702,7 @@ __device__ __forceinline__ void int_pair_wg(const KArgs &a) {
 // wave-per-point form keeps r, t, their transposes, G and four products as NT x NT register tiles -- 1 000+ registers per lane
 // at NT = 3 / 4, i.e. scratch memory -- and a launch has only S waves.  Here r, t, G = (I - r r)^-1 and (t G)^T live in four LDS
 // matrices, every product is computed in column strips (transposed factors are the transposed index expression of the same
-// copy), the Gauss-Jordan inverse runs on wave 0 (inv_one_minus of mom_tile.hpp, its workspace is the fourth matrix), and the
+// copy), the Gauss-Jordan inverse runs on all NT waves (wg_inv_one_minus: a wave holds 16 columns of every matrix row), and the
 // 2-column source products are split by row blocks with the full vectors exchanged through LDS.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NT>
@@ -768,8 +768,84 @@ __device__ __forceinline__ Vec<NT> vxget(const Geo &g, const double *buf) {
     for (int r = 0; r < 4; ++r) v.t[a][r] = buf[a * kTileDoubles + (g.lq + 4 * r) * kTileLd + g.lr];
   return v;
 }
+constexpr int kWgInvDoubles = 32 + 128 + 2 + 2;  // ipiv (64 ints), two multiplier columns, two reciprocal pivots, two pivot rows (ints)
 template <int NT>
-constexpr size_t wg_point_lds_bytes() { return ((size_t)4 * wg_mat_doubles<NT>() + 2 * NT * kTileDoubles + 8 * NT) * 8; }
+constexpr size_t wg_point_lds_bytes() { return ((size_t)4 * wg_mat_doubles<NT>() + 2 * NT * kTileDoubles + kWgInvDoubles) * 8; }
+
+// (I - B)^-1 IN PLACE in the LDS matrix S (tile layout; B on entry), by all NT waves of the workgroup: Gauss-Jordan elimination
+// with implicit partial pivoting as inv_one_minus of mom_tile.hpp (one matrix row per lane, the same operations on every element
+// in the same order: the same result), but wave w holds only columns [16 w, 16 w + 16) of its row -- 16 registers instead of
+// 16 NT, nothing in scratch.  Per step the wave that owns column k finds the pivot row and publishes the multiplier column, the
+// pivot's lane and reciprocal through LDS (double-buffered: ONE barrier per step); every wave then updates its 16 columns.
+// *bad_out = 1 + the step of a zero pivot.  `aux`: kWgInvDoubles doubles of LDS.
+template <int NT>
+__device__ __forceinline__ void wg_inv_one_minus(const Geo &g, int w, double *S, double *aux, int *bad_out) {
+  const int N = g.N, lane = 16 * g.lq + g.lr;
+  int *ipiv = reinterpret_cast<int *>(aux);
+  double *colbuf = aux + 32, *dbuf = aux + 160;
+  int *plbuf = reinterpret_cast<int *>(aux + 162);
+  double v[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const int col = 16 * w + c;
+    const double id = (lane == col) ? 1.0 : 0.0;
+    v[c] = (lane < N && col < N) ? id - S[((lane >> 4) * NT + w) * kTileDoubles + (lane & 15) * kTileLd + c] : id;
+  }
+  bool used = false;
+  int myk = lane, bad = 0, par = 0;
+#pragma unroll
+  for (int kb = 0; kb < NT; ++kb)
+#pragma unroll
+    for (int kc = 0; kc < 16; ++kc) {
+      const int k = 16 * kb + kc;
+      if (k < N) {
+        if (w == kb) {  // the owner of column k
+          const int ah = (!used && lane < N) ? __double2hiint(fabs(v[kc])) : -1;
+          int mh = ah;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) mh = max(mh, __shfl_xor(mh, off));
+          const unsigned long long mk = __ballot(ah == mh);
+          const int pl = __ffsll((long long)mk) - 1;
+          const double piv = __shfl(v[kc], pl);
+          if (!(fabs(piv) > 0.0) && !bad) bad = k + 1;
+          colbuf[64 * par + lane] = v[kc];
+          if (lane == 0) {
+            dbuf[par] = 1.0 / piv;
+            plbuf[par] = pl;
+          }
+        }
+        wg_sync();
+        const int pl = plbuf[par];
+        const double d = dbuf[par], f = colbuf[64 * par + lane];
+        const bool isp = (lane == pl);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const double prow = __shfl(v[c], pl) * d;
+          v[c] = isp ? prow : (v[c] - f * prow);
+        }
+        if (w == kb) v[kc] = isp ? d : (-f * d);
+        if (isp) { used = true; myk = k; }
+        if (threadIdx.x == 0) ipiv[k] = pl;
+        par ^= 1;
+      }
+    }
+  wg_sync();  // all reads of S (at the top) and all ipiv entries are done
+  spublish<NT>(g, w, S, szeros<NT>());
+  wg_sync();
+  // inv(A)[k][p_j] = S[p_k][j]: lane (row p_k, pivot of step myk) writes row myk with permuted columns
+  if (lane < N) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int col = 16 * w + c;
+      if (col < N) {
+        const int pc = ipiv[col];
+        S[((myk >> 4) * NT + (pc >> 4)) * kTileDoubles + (myk & 15) * kTileLd + (pc & 15)] = v[c];
+      }
+    }
+  }
+  wg_sync();
+  if (bad) *bad_out = bad;
+}
 
 template <int NT>
 __device__ __forceinline__ void dbl_point_wg(const KArgs &a) {
@@ -781,8 +857,9 @@ __device__ __forceinline__ void dbl_point_wg(const KArgs &a) {
   g.lr = lane & 15;
   g.lq = lane >> 4;
   g.N = a.N;
-  g.xp = S_x;                                                 // workspace of the inverse (wave 0)
-  g.ipiv = reinterpret_cast<int *>(vx2 + NT * kTileDoubles);
+  g.xp = nullptr;
+  g.ipiv = nullptr;
+  double *inv_aux = vx2 + NT * kTileDoubles;                  // small buffers of the workgroup inverse
   const int n = a.nS;
   const size_t NN = (size_t)a.P * a.P, VS = a.P;
   int bad = 0;
@@ -810,11 +887,7 @@ __device__ __forceinline__ void dbl_point_wg(const KArgs &a) {
     sstore<NT>(g, w, a.sm[SM_TT] + om, tc_s);
     spublish<NT>(g, w, S_G, sTNacc<NT, false>(g, S_r, rc_s, szeros<NT>()));  // r r (as TN(r_t, r_c))
     wg_sync();
-    if (w == 0) {                                                             // (I - r r)^-1                      :47
-      const Mat<NT> G_c = inv_one_minus<NT>(g, mread<NT>(g, S_G), &bad);
-      mpublish<NT>(g, S_G, G_c);
-    }
-    wg_sync();
+    wg_inv_one_minus<NT>(g, w, S_G, inv_aux, &bad);                           // (I - r r)^-1, in place             :47
     const Strip<NT> ttgp_s = sTNacc<NT, false>(g, S_G, t_s, szeros<NT>());    // (t G)^T = TN(G_c, t_t)            :48
     const Strip<NT> ttgpr_s = sTNacc<NT, true>(g, S_r, ttgp_s, szeros<NT>()); // (t G r)^T = TN(r_c, .)
     sstore<NT>(g, w, a.sm[SM_GT] + om, sTNacc<NT, true>(g, S_G, tc_s, szeros<NT>()));  // G t, row-major: TN(G_t, t_c)
@@ -886,7 +959,7 @@ __device__ __forceinline__ void dbl_point_wg(const KArgs &a) {
     store_rows(a.a_nxt[J0P] + ov, a.a_nxt[J0M] + ov, jout);
     if (threadIdx.x == 0) a.expk_nxt[pt] = e;
   }
-  if (bad && threadIdx.x == 0) atomicMax(a.info, bad);
+  if (bad && lane == 0) atomicMax(a.info, bad);
 }
 
 #define MOMR_WG_WPE(NT_) (NT_ == 2 ? 2 : (NT_ == 3 ? MOMR_WG3_WPE : 1))

@@ -387,9 +387,9 @@ def test_rrs_workgroup_and_wave_kernels_agree(tmp_path, nS, lt, S, Nz, strict):
     from pathlib import Path
     root = Path(__file__).resolve().parents[1]
     out = {}
-    # "point": also the doubling point kernel as a workgroup per point (opt-in, N > 32); "fuse": the inelastic elemental layer
+    # "point": the doubling point kernel as one wave per point (default above N = 32: a workgroup per point); "fuse": the inelastic elemental layer
     # formed inside the first doubling step of a layer (MOM_RRS_EL_FUSE=1) instead of by the separate tile kernel (default)
-    envs = {"0": dict(MOM_RRS_WG="0"), "1": dict(MOM_RRS_WG="1"), "point": dict(MOM_RRS_WG="1", MOM_RRS_WG_POINT="1"),
+    envs = {"0": dict(MOM_RRS_WG="0"), "1": dict(MOM_RRS_WG="1"), "point": dict(MOM_RRS_WG="1", MOM_RRS_WG_POINT="0"),
             "fuse": dict(MOM_RRS_WG="1", MOM_RRS_EL_FUSE="1"), "fuse0": dict(MOM_RRS_WG="0", MOM_RRS_EL_FUSE="1"),
             "elementwise": dict(MOM_RRS_WG="1", MOM_RRS_EL_TILE="0")}
     for wg in envs:
