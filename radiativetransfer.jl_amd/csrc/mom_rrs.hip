@@ -1631,7 +1631,7 @@ __global__ void k_unpack(double *nat, const double *dev, int rows, int cols, int
 #include "mom_rrs_wg.hpp"
 }  // namespace momr_big
 // which: 0 k_el_point, 1 k_dbl_point, 2 k_int_point, 3 k_dbl_pair (v0 = fused elemental, v1 = mode), 4 k_int_pair (v0 = surface,
-// v1 = derived +- / -- blocks), 5 k_dbl_pair_wg, 6 k_int_pair_wg (workgroup per pair, mom_rrs_wg.hpp; grid = workgroups), 7 k_dbl_point_wg (workgroup per point, nt >= 3), 8 k_ie_elemental_tile (v0 = layer without doublings); nt = 3 or 4; args: the
+// v1 = derived +- / -- blocks), 5 k_dbl_pair_wg, 6 k_int_pair_wg (workgroup per pair, mom_rrs_wg.hpp; grid = workgroups), 7 k_dbl_point_wg (workgroup per point, nt >= 3), 8 k_ie_elemental_tile (v0 = layer without doublings), 9 k_int_point_wg; nt = 3 or 4; args: the
 // KArgs of the caller (layout-identical in both namespaces)
 hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, void *stream, const void *args, int iface) {
   using namespace momr_big;
@@ -1682,15 +1682,28 @@ hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, voi
       else WG_INT(false, false);
 #undef WG_INT
     }
+    case 9: {  // k_int_point_wg (interface 11): one workgroup per spectral point
+      const size_t ldp = (nt == 2) ? wg_point_lds_bytes<2>() : ((nt == 3) ? wg_point_lds_bytes<3>() : wg_point_lds_bytes<4>());
+      const void *kp = (nt == 2) ? reinterpret_cast<const void *>(k_int_point_wg2)
+                                 : ((nt == 3) ? reinterpret_cast<const void *>(k_int_point_wg3) : reinterpret_cast<const void *>(k_int_point_wg4));
+      const hipError_t e__ = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldp);
+      if (e__ != hipSuccess) return e__;
+      if (nt == 2) hipLaunchKernelGGL(k_int_point_wg2, gr, blw, ldp, st, a);
+      else if (nt == 3) hipLaunchKernelGGL(k_int_point_wg3, gr, blw, ldp, st, a);
+      else hipLaunchKernelGGL(k_int_point_wg4, gr, blw, ldp, st, a);
+      return hipGetLastError();
+    }
     case 8:
       if (v0) BIG_NT((k_ie_elemental_tile<3, true>), (k_ie_elemental_tile<4, true>), a);
       else BIG_NT((k_ie_elemental_tile<3, false>), (k_ie_elemental_tile<4, false>), a);
     case 7: {  // k_dbl_point_wg: one workgroup per spectral point (grid = workgroups)
-      const size_t ldp = (nt == 3) ? wg_point_lds_bytes<3>() : wg_point_lds_bytes<4>();
-      const void *kp = (nt == 3) ? reinterpret_cast<const void *>(k_dbl_point_wg3) : reinterpret_cast<const void *>(k_dbl_point_wg4);
+      const size_t ldp = (nt == 2) ? wg_point_lds_bytes<2>() : ((nt == 3) ? wg_point_lds_bytes<3>() : wg_point_lds_bytes<4>());
+      const void *kp = (nt == 2) ? reinterpret_cast<const void *>(k_dbl_point_wg2)
+                                 : ((nt == 3) ? reinterpret_cast<const void *>(k_dbl_point_wg3) : reinterpret_cast<const void *>(k_dbl_point_wg4));
       const hipError_t e__ = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldp);
       if (e__ != hipSuccess) return e__;
-      if (nt == 3) hipLaunchKernelGGL(k_dbl_point_wg3, gr, blw, ldp, st, a);
+      if (nt == 2) hipLaunchKernelGGL(k_dbl_point_wg2, gr, blw, ldp, st, a);
+      else if (nt == 3) hipLaunchKernelGGL(k_dbl_point_wg3, gr, blw, ldp, st, a);
       else hipLaunchKernelGGL(k_dbl_point_wg4, gr, blw, ldp, st, a);
       return hipGetLastError();
     }
@@ -1976,10 +1989,11 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
       a.fscatt = s->el.fscatt; a.Zr_pp = s->el.Zr_pp; a.Zr_mp = s->el.Zr_mp;
       s->el_pending = false;
     }
-    // above N = 32: one workgroup per point (mom_rrs_wg.hpp dbl_point_wg: products in strips from LDS copies, Gauss-Jordan inverse
+    // above N = 16: one workgroup per point (mom_rrs_wg.hpp dbl_point_wg: products in strips from LDS copies, Gauss-Jordan inverse
     // over all waves); MOM_RRS_WG_POINT=0 selects the wave-per-point kernel (operators in scratch, inverse on one wave)
     static const bool wg_point = !(getenv("MOM_RRS_WG_POINT") && atoi(getenv("MOM_RRS_WG_POINT")) == 0);
-    if (wg_point && wg_nt(s) >= 3)
+    static const int wg_point_min = getenv("MOM_RRS_WG_POINT_MIN") ? atoi(getenv("MOM_RRS_WG_POINT_MIN")) : 2;  // smallest tile count (experiments)
+    if (wg_point && wg_nt(s) >= wg_point_min)
       RCHK(momr_big_launch(7, wg_nt(s), 0, 0, (unsigned)std::max(1, std::min(s->S, 256 * 8)), (void *)s->stream, &a, 0));
     else LAUNCH_NT(s, k_dbl_point, 1, grid_points(s), a);
     RCHK(tick(s, TK_DBL_PAIR, true));
@@ -2063,7 +2077,11 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
   if (!with_surface && !a.derive_pm) RCHK(ensure_pm(s, q));
   for (int k = 0; k < 6; ++k) a.x[k] = with_surface ? s->surf[k] : s->added[s->cur][k];
   if (!with_surface) { a.x[R_PM] = s->added[0][R_PM]; a.x[T_MM] = s->added[0][T_MM]; }
-  LAUNCH_NT(s, k_int_point, 2, grid_points(s), a, iface);
+  static const bool wg_point = !(getenv("MOM_RRS_WG_POINT") && atoi(getenv("MOM_RRS_WG_POINT")) == 0);
+  static const int wg_point_min = getenv("MOM_RRS_WG_POINT_MIN") ? atoi(getenv("MOM_RRS_WG_POINT_MIN")) : 2;
+  if (wg_point && iface == 3 && wg_nt(s) >= wg_point_min)  // one workgroup per point (mom_rrs_wg.hpp int_point_wg)
+    RCHK(momr_big_launch(9, wg_nt(s), 0, 0, (unsigned)std::max(1, std::min(s->S, 256 * 8)), (void *)s->stream, &a, 0));
+  else LAUNCH_NT(s, k_int_point, 2, grid_points(s), a, iface);
   if (iface == 0) {  // interaction_inelastic.jl:16-17
     const size_t v4 = (size_t)s->P * s->S * s->nR * 8;
     RCHK(hipMemsetAsync(s->ie_comp[C_J0P], 0, v4, s->stream));

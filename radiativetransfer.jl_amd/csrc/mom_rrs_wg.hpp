@@ -962,6 +962,111 @@ __device__ __forceinline__ void dbl_point_wg(const KArgs &a) {
   if (bad && lane == 0) atomicMax(a.info, bad);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// interaction, ScatteringInterface_11, POINT kernel above N = 32 as one workgroup of NT waves per spectral point (k_int_point,
+// iface == 3, in strips; interaction_inelastic.jl:244-340 elastic part).  Four LDS matrices in turn:
+//   A: r | rT | Rt        B: R+-[comp]        C: (I - r R+-) -> G1 -> T01, (I - R+- r) -> G2 -> T21        D: t-- | T++[comp]
+// Transposed right factors are transposed strips from global memory (sloadT) or from an LDS copy (sreadT).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void int_point_wg(const KArgs &a) {
+  constexpr int MD = wg_mat_doubles<NT>();
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double *S_a = reinterpret_cast<double *>(rrs_smem), *S_b = S_a + MD, *S_c = S_b + MD, *S_d = S_c + MD;
+  double *vx = S_d + MD, *vx2 = vx + NT * kTileDoubles, *inv_aux = vx2 + NT * kTileDoubles;
+  Geo g;
+  g.lr = lane & 15;
+  g.lq = lane >> 4;
+  g.N = a.N;
+  g.xp = nullptr;
+  g.ipiv = nullptr;
+  const size_t NN = (size_t)a.P * a.P, VS = a.P;
+  int bad = 0;
+  auto store_rows = [&](double *p0, double *p1, const d4 &o) {  // columns 0 / 1 of a row block -> two arrays (nullptr: none)
+    double *p = (g.lr == 0) ? p0 : ((g.lr == 1) ? p1 : nullptr);
+    if (p != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[16 * w + g.lq + 4 * r] = o[r];
+    }
+  };
+  auto swap01b = [&](const d4 &v) {  // exchange columns 0 <-> 1 of a row block
+    d4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = __shfl_xor(v[r], 1);
+    return o;
+  };
+  for (int pt = blockIdx.x; pt < a.S; pt += gridDim.x) {
+    const size_t om = NN * pt, ov = VS * pt;
+    const Strip<NT> r_s = sload<NT>(g, w, a.x[R_MP] + om), Rpm_s = sload<NT>(g, w, a.c_cur[C_R_PM] + om);
+    const Strip<NT> tmm_s = sload<NT>(g, w, a.x[T_MM] + om);
+    const Vec<NT> ja = loadv2<NT>(g, a.x[J0P] + ov, a.x[J0M] + ov);                    // (j0+ | j0-) added
+    const Vec<NT> Jc = loadv2<NT>(g, a.c_cur[C_J0P] + ov, a.c_cur[C_J0M] + ov);        // (J0+ | J0-) composite
+    wg_sync();  // the previous point has finished with the LDS matrices
+    spublish<NT>(g, w, S_a, r_s);
+    spublish<NT>(g, w, S_b, Rpm_s);
+    spublish<NT>(g, w, S_d, tmm_s);
+    wg_sync();
+    const Strip<NT> r_c = sreadT<NT>(g, w, S_a), Rpm_c = sreadT<NT>(g, w, S_b), tmm_c = sreadT<NT>(g, w, S_d);
+    const Strip<NT> Tpp_c = sloadT<NT>(g, w, a.c_cur[C_T_PP] + om);
+    sstore<NT>(g, w, a.sm[SI_RPM] + om, Rpm_c);
+    sstore<NT>(g, w, a.sm[SI_TPP] + om, Tpp_c);
+    sstore<NT>(g, w, a.sm[SI_R] + om, r_c);
+    sstore<NT>(g, w, a.sm[SI_TMM] + om, tmm_c);
+    spublish<NT>(g, w, S_c, sTNacc<NT, false>(g, S_a, Rpm_c, szeros<NT>()));          // r R+-  (as TN(r_t, Rpm_c))
+    wg_sync();
+    wg_inv_one_minus<NT>(g, w, S_c, inv_aux, &bad);                                    // G1 = (I - r R+-)^-1        :244
+    const Strip<NT> T01_s = sTNacc<NT, false>(g, S_c, sload<NT>(g, w, a.c_cur[C_T_MM] + om), szeros<NT>());  // (T-- G1)^T  :247
+    const Strip<NT> rT_s = sTNacc<NT, false>(g, S_a, Tpp_c, szeros<NT>());             // r T++ (as TN(r_t, Tpp_c))
+    sstore<NT>(g, w, a.sm[SI_T01] + om, T01_s);
+    sstore<NT>(g, w, a.sm[SI_G1RT] + om, sTNacc<NT, true>(g, S_c, rT_s, szeros<NT>()));   // G1 r T++
+    sstore<NT>(g, w, a.sm[SI_G1T] + om, sTNacc<NT, true>(g, S_c, tmm_c, szeros<NT>()));   // G1 t--
+    // s1 = r J0+ + j0-  (column 0): every wave its row block, the full tile through LDS
+    vxput(g, w, vx, sTNv<NT, false>(g, w, S_a, Jc) + swap01b(vpick<NT>(ja, w)));
+    wg_sync();
+    const Vec<NT> s1 = vxget<NT>(g, vx);
+    store_rows(a.sv[SVI_G1V] + ov, nullptr, sTNv<NT, true>(g, w, S_c, s1));            // G1 (j0- + r J0+)
+    wg_sync();  // r, G1 have been read
+    spublish<NT>(g, w, S_c, T01_s);
+    spublish<NT>(g, w, S_a, rT_s);
+    wg_sync();
+    const d4 dJm = sTNv<NT, false>(g, w, S_c, s1);                                     // column 0                  :267
+    const Strip<NT> Rmp_n = sadd<NT>(sload<NT>(g, w, a.c_cur[C_R_MP] + om), sTNacc<NT, false>(g, S_a, T01_s, szeros<NT>()));  // :288
+    const Strip<NT> Tmm_n = sTNacc<NT, true>(g, S_d, T01_s, szeros<NT>());             // U = t--_c                 :290
+    sstore<NT>(g, w, a.c_nxt[C_R_MP] + om, Rmp_n);
+    sstore<NT>(g, w, a.c_nxt[C_T_MM] + om, Tmm_n);
+    const Strip<NT> B2_s = sTNacc<NT, false>(g, S_b, r_c, szeros<NT>());               // R+- r (as TN(Rpm_t, r_c))
+    const Strip<NT> Rt_s = sTNacc<NT, false>(g, S_b, tmm_c, szeros<NT>());             // R+- t--
+    wg_sync();  // T01, rT, t-- have been read
+    spublish<NT>(g, w, S_c, B2_s);
+    spublish<NT>(g, w, S_d, sload<NT>(g, w, a.c_cur[C_T_PP] + om));                    // T++[comp]: left factor of the last product but one
+    wg_sync();
+    wg_inv_one_minus<NT>(g, w, S_c, inv_aux, &bad);                                    // G2 = (I - R+- r)^-1        :295
+    const Strip<NT> T21_s = sTNacc<NT, false>(g, S_c, sload<NT>(g, w, a.x[T_PP] + om), szeros<NT>());  //            :297
+    sstore<NT>(g, w, a.sm[SI_T21] + om, T21_s);
+    sstore<NT>(g, w, a.sm[SI_G2T] + om, sTNacc<NT, true>(g, S_c, Tpp_c, szeros<NT>()));
+    sstore<NT>(g, w, a.sm[SI_G2RT] + om, sTNacc<NT, true>(g, S_c, Rt_s, szeros<NT>()));
+    // s2 = J0+ + R+- j0-  (column 0)
+    vxput(g, w, vx2, vpick<NT>(Jc, w) + swap01b(sTNv<NT, false>(g, w, S_b, ja)));
+    wg_sync();
+    const Vec<NT> s2 = vxget<NT>(g, vx2);
+    store_rows(a.sv[SVI_G2V] + ov, nullptr, sTNv<NT, true>(g, w, S_c, s2));
+    wg_sync();  // G2 has been read
+    spublish<NT>(g, w, S_c, T21_s);
+    spublish<NT>(g, w, S_a, Rt_s);
+    wg_sync();
+    const d4 dJp = sTNv<NT, false>(g, w, S_c, s2);                                     //                           :315
+    const d4 dJm1 = swap01b(dJm), jab = vpick<NT>(ja, w), Jcb = vpick<NT>(Jc, w);
+    d4 Jn;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Jn[r] = (g.lr == 0) ? (jab[r] + dJp[r]) : (Jcb[r] + dJm1[r]);
+    store_rows(a.c_nxt[C_J0P] + ov, a.c_nxt[C_J0M] + ov, Jn);
+    sstore<NT>(g, w, a.c_nxt[C_T_PP] + om, sTNacc<NT, true>(g, S_d, T21_s, szeros<NT>()));   // U = T++_c          :338
+    sstore<NT>(g, w, a.c_nxt[C_R_PM] + om,
+               sadd<NT>(sload<NT>(g, w, a.x[R_PM] + om), sTNacc<NT, false>(g, S_a, T21_s, szeros<NT>())));  //      :340
+  }
+  if (bad && lane == 0) atomicMax(a.info, bad);
+}
+
 #define MOMR_WG_WPE(NT_) (NT_ == 2 ? 2 : (NT_ == 3 ? MOMR_WG3_WPE : 1))
 #define MOMR_WG_ATTR(NT_) __launch_bounds__(64 * NT_) __attribute__((amdgpu_waves_per_eu(MOMR_WG_WPE(NT_), MOMR_WG_WPE(NT_))))
 template <bool FUSE, int MODE>
@@ -976,5 +1081,9 @@ template <bool SURF, bool DERIVE>
 __global__ void MOMR_WG_ATTR(4) k_int_pair_wg4(KArgs a) { int_pair_wg<4, SURF, DERIVE>(a); }
 template <bool SURF, bool DERIVE>
 __global__ void MOMR_WG_ATTR(2) k_int_pair_wg2(KArgs a) { int_pair_wg<2, SURF, DERIVE>(a); }
+__global__ void __launch_bounds__(128) k_dbl_point_wg2(KArgs a) { dbl_point_wg<2>(a); }
 __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 1))) k_dbl_point_wg3(KArgs a) { dbl_point_wg<3>(a); }
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_dbl_point_wg4(KArgs a) { dbl_point_wg<4>(a); }
+__global__ void __launch_bounds__(128) k_int_point_wg2(KArgs a) { int_point_wg<2>(a); }
+__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 1))) k_int_point_wg3(KArgs a) { int_point_wg<3>(a); }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_int_point_wg4(KArgs a) { int_point_wg<4>(a); }
