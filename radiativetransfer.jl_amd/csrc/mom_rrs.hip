@@ -1670,10 +1670,16 @@ hipError_t momr_big_launch(int which, int nt, int v0, int v1, unsigned grid, voi
       else if (v1) BIG_NT((k_int_pair3<false, true>), (k_int_pair4<false, true>), a, iface);
       else BIG_NT((k_int_pair3<false, false>), (k_int_pair4<false, false>), a, iface);
     case 5: {
-#define WG_DBL(F, M) do { if (nt == 2) WG_GO((k_dbl_pair_wg2<F, M>)); else if (nt == 3) WG_GO((k_dbl_pair_wg3<F, M>)); else WG_GO((k_dbl_pair_wg4<F, M>)); } while (0)
+      // products without the per-k-step guards where no k-step lies in the zero padding, or one of sixteen (mom_rrs_wg.hpp NG;
+      // one of twelve -- N = 42 ... 44 -- measured slower than the guards: profiles/r05_rrs_wg_ab.txt (13))
+      const int padded_steps = (16 * nt - a.N) / 4;
+      const bool ng = padded_steps == 0 || (padded_steps == 1 && nt == 4);
+#define WG_DBL_G(F, M, G) do { if (nt == 2) WG_GO((k_dbl_pair_wg2<F, M, G>)); else if (nt == 3) WG_GO((k_dbl_pair_wg3<F, M, G>)); else WG_GO((k_dbl_pair_wg4<F, M, G>)); } while (0)
+#define WG_DBL(F, M) do { if (ng) WG_DBL_G(F, M, true); else WG_DBL_G(F, M, false); } while (0)
       if (v0) { if (v1 == 0) WG_DBL(true, 0); else if (v1 == 1) WG_DBL(true, 1); else WG_DBL(true, 2); }
       else { if (v1 == 0) WG_DBL(false, 0); else if (v1 == 1) WG_DBL(false, 1); else WG_DBL(false, 2); }
 #undef WG_DBL
+#undef WG_DBL_G
     }
     case 6: {  // ScatteringInterface_11 only
 #define WG_INT(SF, DV) do { if (nt == 2) WG_GO((k_int_pair_wg2<SF, DV>)); else if (nt == 3) WG_GO((k_int_pair_wg3<SF, DV>)); else WG_GO((k_int_pair_wg4<SF, DV>)); } while (0)

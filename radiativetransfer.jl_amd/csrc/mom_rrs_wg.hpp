@@ -108,13 +108,16 @@ __device__ __forceinline__ double ufrag(const Geo &g, const double *M, int tk, i
             : M[(tk * NT + ti) * kTileDoubles + (g.lq + 4 * s) * kTileLd + g.lr];
 }
 // acc + (column strip of) U^T V;  U = M (TR = false) or M^T (TR = true) from LDS.  k-steps in the zero padding are skipped.
-template <int NT, bool TR>
+// NG ("no guard"): ALL k-steps are executed, the ones in the zero padding included (they add zeros), without a branch per step --
+// the doubling pair kernel uses it when at most one k-step of a product lies in the padding (N = 32, 48, 60, 64 ...): the straight
+// code gains 4-6 % there (profiles/r05_rrs_wg_ab.txt (13)); with more padding, or in the interaction kernel, the guards win.
+template <int NT, bool TR, bool NG = false>
 __device__ __forceinline__ Strip<NT> sTNacc(const Geo &g, const double *M, const Strip<NT> &V, Strip<NT> acc) {
 #pragma unroll
   for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      if (16 * tk + 4 * s < g.N) {
+      if (NG || 16 * tk + 4 * s < g.N) {
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
           acc.t[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(ufrag<NT, TR>(g, M, tk, ti, s), V.t[tk][s], acc.t[ti], 0, 0, 0);
@@ -127,14 +130,14 @@ __device__ __forceinline__ Strip<NT> sTNacc(const Geo &g, const double *M, const
 // requested in front of the last two products put 4 400 cycles on that section, 66 per load -- the CU takes a strip set at L2 -> L1
 // bandwidth, and a wave blocked in the memory queue issues no MFMAs.  The k-step guards are branches, so the compiler's scheduler
 // cannot interleave across them by itself.)
-template <int NT, bool TR, class J>
+template <int NT, bool TR, bool NG, class J>
 __device__ __forceinline__ Strip<NT> sTNacc_job(const Geo &g, const double *M, const Strip<NT> &V, Strip<NT> acc, J job) {
 #pragma unroll
   for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       job(tk, s);
-      if (16 * tk + 4 * s < g.N) {
+      if (NG || 16 * tk + 4 * s < g.N) {
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti)
           acc.t[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(ufrag<NT, TR>(g, M, tk, ti, s), V.t[tk][s], acc.t[ti], 0, 0, 0);
@@ -142,14 +145,14 @@ __device__ __forceinline__ Strip<NT> sTNacc_job(const Geo &g, const double *M, c
     }
   return acc;
 }
-template <int NT, class J>
+template <int NT, bool NG, class J>
 __device__ __forceinline__ Strip<NT> sTNacc_sum_job(const Geo &g, const double *M1, const double *M2, const Strip<NT> &V, Strip<NT> acc, J job) {
 #pragma unroll
   for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       job(tk, s);
-      if (16 * tk + 4 * s < g.N) {
+      if (NG || 16 * tk + 4 * s < g.N) {
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
           const double u = ufrag<NT, true>(g, M1, tk, ti, s) + ufrag<NT, false>(g, M2, tk, ti, s);
@@ -168,13 +171,13 @@ struct StripReq {
   __device__ __forceinline__ void step(int a, int r) { X.t[a][r] = q[(16 * NT) * (16 * a + 4 * r)]; }
 };
 // ... with U = M1^T + M2 formed fragment-wise (W = b^T + Y, V = bn^T + Y of the doubling step)
-template <int NT>
+template <int NT, bool NG = false>
 __device__ __forceinline__ Strip<NT> sTNacc_sum(const Geo &g, const double *M1, const double *M2, const Strip<NT> &V, Strip<NT> acc) {
 #pragma unroll
   for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-      if (16 * tk + 4 * s < g.N) {
+      if (NG || 16 * tk + 4 * s < g.N) {
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
           const double u = ufrag<NT, true>(g, M1, tk, ti, s) + ufrag<NT, false>(g, M2, tk, ti, s);
@@ -310,7 +313,7 @@ __device__ __forceinline__ void ie_elem_strip(const Geo &g, int w, const KArgs &
 // ---------------------------------------------------------------------------------------------------------------------
 // doubling step, pair kernel, one workgroup of NT waves per pair (dbl_pair_body in strips)
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT, bool FUSE, int MODE>
+template <int NT, bool FUSE, int MODE, bool NG>
 __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
   constexpr bool STRICT = (MODE == 2), fuseD = (MODE == 1);
   constexpr int MD = wg_mat_doubles<NT>();
@@ -463,8 +466,8 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
       own_mv();
     }
     // X = ier r0 + r1 ier
-    Strip<NT> X_s = sTNacc_job<NT, false>(g, S_g, a_s, szeros<NT>(), [&](int tk, int s) { gt0_q.step(tk, s); });   // U = r0_c
-    X_s = sTNacc_job<NT, true>(g, S_a, r1_s, X_s, [&](int tk, int s) { ttgp1_q.step(tk, s); });                   // U = a_c = (a_t)^T
+    Strip<NT> X_s = sTNacc_job<NT, false, NG>(g, S_g, a_s, szeros<NT>(), [&](int tk, int s) { gt0_q.step(tk, s); });   // U = r0_c
+    X_s = sTNacc_job<NT, true, NG>(g, S_a, r1_s, X_s, [&](int tk, int s) { ttgp1_q.step(tk, s); });                   // U = a_c = (a_t)^T
     const Strip<NT> &gt0_s = gt0_q.X, &ttgp1_s = ttgp1_q.X;
     const double X1 = smv<NT>(g, X_s, tm1), X2 = smv<NT>(g, X_s, tm2);
     MOMR_STAMP_NW(25);  // 4 + 2 mat-vecs, X: 2 products
@@ -493,7 +496,7 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     }
     MOMR_STAMP_NW(24);  // source chain: 4 mat-vecs, 3 exchanges (their barriers: 26)
     // ---- operators                                                                                              :98-125
-    const Strip<NT> Y_s = sTNacc_job<NT, false>(g, S_x, sread<NT>(g, w, S_g), szeros<NT>(),  // Y_c = X G t[n0]   (U = X_t)
+    const Strip<NT> Y_s = sTNacc_job<NT, false, NG>(g, S_x, sread<NT>(g, w, S_g), szeros<NT>(),  // Y_c = X G t[n0]   (U = X_t)
                                                 [&](int tk, int s) { gr0_q.step(tk, s); });   // (G r)[n0]: consumed three products later
     const Strip<NT> &gr0_s = gr0_q.X;
     MOMR_STAMP_NW(28);  // Y: 1 product
@@ -501,9 +504,9 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     spublish<NT>(g, w, S_x, Y_s);
     MOMR_STAMP_NW(27);
     WG_SYNC_ST();
-    Strip<NT> bn_s = sTNacc_sum_job<NT>(g, S_b, S_x, ttgp1_s, szeros<NT>(),   // tG (iet + Y)            (U = W_c = b_c + Y_c)
+    Strip<NT> bn_s = sTNacc_sum_job<NT, NG>(g, S_b, S_x, ttgp1_s, szeros<NT>(),   // tG (iet + Y)            (U = W_c = b_c + Y_c)
                                         [&](int tk, int s) { t0_q.step(tk, s); });
-    bn_s = sTNacc_job<NT, false>(g, S_g, sread<NT>(g, w, S_b), bn_s,           // + iet G t[n0]           (U = (G t)[n0]_c)
+    bn_s = sTNacc_job<NT, false, NG>(g, S_g, sread<NT>(g, w, S_b), bn_s,           // + iet G t[n0]           (U = (G t)[n0]_c)
                                  [&](int tk, int s) { ttgpr1_q.step(tk, s); });
     const Strip<NT> &t0_s = t0_q.X, &ttgpr1_s = ttgpr1_q.X;
     MOMR_STAMP_NW(29);  // iet: 2 products
@@ -514,18 +517,18 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     WG_SYNC_ST();
     constexpr bool PF = (MOMR_WG_PREFETCH & (NT == 2 ? 1 : (NT == 3 ? 2 : 4))) != 0;
     if (PF) pf_begin(p + gridDim.x, nx);
-    Strip<NT> Q_s = sTNacc_job<NT, false>(g, S_g, bn_s, szeros<NT>(),          // iet(new) G r[n0]        (U = (G r)[n0]_c)
+    Strip<NT> Q_s = sTNacc_job<NT, false, NG>(g, S_g, bn_s, szeros<NT>(),          // iet(new) G r[n0]        (U = (G r)[n0]_c)
                                           [&](int tk, int s) { if (PF && pf_on) nx.r0_q.step(tk, s); });
-    Q_s = sTNacc_job<NT, true>(g, S_a, ttgp1_s, Q_s,                           // + tG ier                (U = a_c)
+    Q_s = sTNacc_job<NT, true, NG>(g, S_a, ttgp1_s, Q_s,                           // + tG ier                (U = a_c)
                                [&](int tk, int s) { if (PF && pf_on) nx.r1_q.step(tk, s); });
     MOMR_STAMP_NW(30);  // Q: 2 products
     WG_SYNC_ST();                                                              // (G r)[n0] has been read
     spublish<NT>(g, w, S_g, t0_s);
     MOMR_STAMP_NW(27);
     WG_SYNC_ST();
-    Strip<NT> an_s = sTNacc_sum_job<NT>(g, S_b, S_x, ttgpr1_s, szeros<NT>(),   // (iet(new) + Y) ...      (U = V_c = bn_c + Y_c)
+    Strip<NT> an_s = sTNacc_sum_job<NT, NG>(g, S_b, S_x, ttgpr1_s, szeros<NT>(),   // (iet(new) + Y) ...      (U = V_c = bn_c + Y_c)
                                         [&](int tk, int s) { if (PF && !FUSE && pf_on) nx.a_q.step(tk, s); });
-    an_s = sTNacc_job<NT, false>(g, S_g, Q_s, an_s,                            // + t[n0]-side product    (U = t0_c)
+    an_s = sTNacc_job<NT, false, NG>(g, S_g, Q_s, an_s,                            // + t[n0]-side product    (U = t0_c)
                                  [&](int tk, int s) { if (PF && !FUSE && pf_on) nx.b_q.step(tk, s); });
     if (PF && pf_on) nx.have = true;
     an_s = sadd<NT>(sread<NT>(g, w, S_a), an_s);
@@ -1069,12 +1072,12 @@ __device__ __forceinline__ void int_point_wg(const KArgs &a) {
 
 #define MOMR_WG_WPE(NT_) (NT_ == 2 ? 2 : (NT_ == 3 ? MOMR_WG3_WPE : 1))
 #define MOMR_WG_ATTR(NT_) __launch_bounds__(64 * NT_) __attribute__((amdgpu_waves_per_eu(MOMR_WG_WPE(NT_), MOMR_WG_WPE(NT_))))
-template <bool FUSE, int MODE>
-__global__ void MOMR_WG_ATTR(2) k_dbl_pair_wg2(KArgs a) { dbl_pair_wg<2, FUSE, MODE>(a); }
-template <bool FUSE, int MODE>
-__global__ void MOMR_WG_ATTR(3) k_dbl_pair_wg3(KArgs a) { dbl_pair_wg<3, FUSE, MODE>(a); }
-template <bool FUSE, int MODE>
-__global__ void MOMR_WG_ATTR(4) k_dbl_pair_wg4(KArgs a) { dbl_pair_wg<4, FUSE, MODE>(a); }
+template <bool FUSE, int MODE, bool NG>
+__global__ void MOMR_WG_ATTR(2) k_dbl_pair_wg2(KArgs a) { dbl_pair_wg<2, FUSE, MODE, NG>(a); }
+template <bool FUSE, int MODE, bool NG>
+__global__ void MOMR_WG_ATTR(3) k_dbl_pair_wg3(KArgs a) { dbl_pair_wg<3, FUSE, MODE, NG>(a); }
+template <bool FUSE, int MODE, bool NG>
+__global__ void MOMR_WG_ATTR(4) k_dbl_pair_wg4(KArgs a) { dbl_pair_wg<4, FUSE, MODE, NG>(a); }
 template <bool SURF, bool DERIVE>
 __global__ void MOMR_WG_ATTR(3) k_int_pair_wg3(KArgs a) { int_pair_wg<3, SURF, DERIVE>(a); }
 template <bool SURF, bool DERIVE>
