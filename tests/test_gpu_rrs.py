@@ -324,11 +324,12 @@ def test_rt_run_rrs_twice_on_one_handle(rtamd, strict):
         assert np.array_equal(x, z), ("run after uploads", k)
 
 
-def test_rrs_empty_owned_range(rtamd):
+@pytest.mark.parametrize("nS,lt", [(1, 3), (3, 11), (3, 21)])   # one wave per pair; workgroup kernels at 2 x 2 and 3 x 3 tiles
+def test_rrs_empty_owned_range(rtamd, nS, lt):
     """mom_rrs_set_shard with n1_lo == n1_hi (a rank beyond the end of the axis when world > S / per): the run completes
     (no zero-sized launch) and every spectrum is zero (outputs exist for owned points only)."""
     rt = rtamd.corert
-    m = rtamd.scenes.make_scene(1, 3, 2, 20, seed=5)
+    m = rtamd.scenes.make_scene(nS, lt, 2, 20, seed=5)
     RS, _ = _rrs_inputs(rtamd, [-3, 2], False)
     model = rt._with_cabannes(RS, m)
     sc = rtamd.prepare_scene(model)
