@@ -24,9 +24,6 @@
 // of the one-wave kernels up to the scheduling of independent roundings (tests/test_gpu_rrs.py::
 // test_rrs_workgroup_and_wave_kernels_agree compares both at 1e-13; MOM_RRS_WG=0 selects the old ones, MOM_RRS_WG2=0 for N <= 32 only).
 #pragma once
-#ifndef MOMR_WG_PREFETCH
-#define MOMR_WG_PREFETCH 0   // bit mask of the tile counts with the next-pair prefetch: 1 (NT = 2) | 2 (NT = 3) | 4 (NT = 4)
-#endif
 #ifndef MOMR_WG3_WPE
 #define MOMR_WG3_WPE 2   // waves per SIMD the 3-wave image is compiled for (2: two workgroups per CU)
 #endif
@@ -331,53 +328,7 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
   const size_t span = (size_t)(a.n1_hi - a.n1_lo), npairs = span * a.nR;
   auto sgn_i = [&](int i, int, double v) { return scomp(i, n, a.strict_idx) > 2 ? -v : v; };
   auto sgn_ij = [&](int i, int j, double v) { return dsgn(scomp(i, n, a.strict_idx), scomp(j, n, a.strict_idx)) * v; };
-  // The pair's own two blocks (the HBM streams) and the two strips its first products need, r[n0]^T and r[n1]: as a burst at the
-  // top of the pair (fetch), or -- MOMR_WG_PREFETCH -- for the NEXT pair, row by row between the MFMAs of the last four products
-  // of the current one (pf_begin + the jobs of those products).  A pair off the grid is not prefetched.
-  struct Top {
-    StripReq<NT> a_q, b_q, r0_q, r1_q;
-    double Jp, Jm, e1;
-    bool have;
-  } nx;
-  nx.have = false;
-  bool pf_on = false;
-  auto fetch = [&](size_t q, Top &t) {
-    t.have = false;
-    if (q >= npairs) return;
-    const int qn1 = a.n1_lo + (int)(q % span), qdn = (int)(q / span);
-    const int qn0 = qn1 + a.off[qdn];
-    if (qn0 < 0 || qn0 >= a.S) return;
-    const size_t qu = (size_t)qn1 + (size_t)a.S * qdn, q4 = NN * qu, q3 = VS * qu;
-    if (!FUSE) {
-      t.a_q.X = sload<NT>(g, w, a.ie_a[R_MP] + q4);
-      t.b_q.X = sload<NT>(g, w, a.ie_a[T_PP] + q4);
-      t.Jp = a.ie_a[J0P][q3 + cw];
-      t.Jm = a.ie_a[J0M][q3 + cw];
-    }
-    t.r0_q.X = sload<NT>(g, w, a.sm[SM_RT] + NN * qn0);
-    t.r1_q.X = sload<NT>(g, w, a.a_cur[R_MP] + NN * qn1);
-    t.e1 = a.expk_cur[qn1];
-    t.have = true;
-  };
-  auto pf_begin = [&](size_t q, Top &t) {
-    pf_on = false;
-    t.have = false;
-    if (q >= npairs) return;
-    const int qn1 = a.n1_lo + (int)(q % span), qdn = (int)(q / span);
-    const int qn0 = qn1 + a.off[qdn];
-    if (qn0 < 0 || qn0 >= a.S) return;
-    const size_t qu = (size_t)qn1 + (size_t)a.S * qdn, q4 = NN * qu, q3 = VS * qu;
-    if (!FUSE) {
-      t.a_q.init(g, w, a.ie_a[R_MP] + q4);
-      t.b_q.init(g, w, a.ie_a[T_PP] + q4);
-      t.Jp = a.ie_a[J0P][q3 + cw];
-      t.Jm = a.ie_a[J0M][q3 + cw];
-    }
-    t.r0_q.init(g, w, a.sm[SM_RT] + NN * qn0);
-    t.r1_q.init(g, w, a.a_cur[R_MP] + NN * qn1);
-    t.e1 = a.expk_cur[qn1];
-    pf_on = true;
-  };
+  // (Four forms of prefetching the NEXT pair's first strips were measured and dropped: profiles/r05_rrs_wg_ab.txt (4), (7).)
   MOMR_STAMP_INIT();
   for (size_t p = blockIdx.x; p < npairs; p += gridDim.x) {
     const int n1 = a.n1_lo + (int)(p % span), dn = (int)(p / span);
@@ -412,12 +363,24 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     }
     MOMR_STAMP_NW(20);  // loop head, off-grid pairs
     const size_t m1 = NN * n1, m0 = NN * n0, v0 = VS * n0;
-    if (!nx.have) fetch(p, nx);  // first pair of the workgroup, or the pair after one off the grid
-    Strip<NT> a_s = nx.a_q.X, b_s = nx.b_q.X;
-    double Jp = nx.Jp, Jm = nx.Jm;
-    const Strip<NT> r0_s = nx.r0_q.X, r1_s = nx.r1_q.X;
-    const double e1 = nx.e1;
-    nx.have = false;
+    // At the top only what the first product needs is requested as a burst -- the pair's ier-+ block and r[n0]^T (+ the source
+    // entries); iet++ and r[n1] follow row by row between the MFMAs of the first product (StripReq), like every later strip.
+    // (NT = 3, at its 256-register budget, keeps all four in the burst: the late form measured 2 % slower there.)
+    constexpr bool LATE = (NT != 3);
+    Strip<NT> a_s, b_s;
+    double Jp = 0.0, Jm = 0.0;
+    StripReq<NT> b_q, r1_q;
+    if (!FUSE) {
+      a_s = sload<NT>(g, w, a.ie_a[R_MP] + o4);
+      Jp = a.ie_a[J0P][o3 + cw];
+      Jm = a.ie_a[J0M][o3 + cw];
+      if (LATE) b_q.init(g, w, a.ie_a[T_PP] + o4);
+      else b_s = sload<NT>(g, w, a.ie_a[T_PP] + o4);
+    }
+    const Strip<NT> r0_s = sload<NT>(g, w, a.sm[SM_RT] + m0);
+    if (LATE) r1_q.init(g, w, a.a_cur[R_MP] + m1);
+    else r1_q.X = sload<NT>(g, w, a.a_cur[R_MP] + m1);
+    const double e1 = a.expk_cur[n1];
     // Register economy: a strip that has a copy in LDS is READ BACK from there where it is needed again (a, b, bn), and the
     // strips from global memory are requested one or two products before their first use, not at the top.
     // The four source vectors of n0 (j1-, j0+, tmp1, tmp2) take ONE load instruction per wave -- lane (lq, lr) fetches entry
@@ -441,20 +404,23 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     MOMR_STAMP_NW(21);  // first loads issued, (fused elemental), wait for ieJ0+-
     WG_SYNC_ST();  // the previous pair has finished with the LDS matrices
     spublish<NT>(g, w, S_a, a_s);
-    spublish<NT>(g, w, S_b, b_s);
     spublish<NT>(g, w, S_g, r0_s);
+    if (!LATE || FUSE) spublish<NT>(g, w, S_b, b_s);  // (LATE: when it has arrived, with X)
     vput(g, w, vb0, J1m);
     if (VLDS) vsv[16 * NT * g.lq + cw] = vch;
     // the products of the pair's own blocks with the source vectors of n0                                         :61-89
-    double a_j1m, a_jp, b1, b2;
+    double a_j1m, a_jp, b1 = 0.0, b2 = 0.0;
     auto own_mv = [&]() {
       a_j1m = smv<NT>(g, a_s, j1m0);  // ier j1-[n0]
       a_jp = smv<NT>(g, a_s, jp0R);   // ier j0+[n0]
-      b1 = smv<NT>(g, b_s, tm1);      // iet++ tmp1
-      b2 = STRICT ? smv<NT>(g, sload<NT>(g, w, a.ie_a[T_MM] + o4), tm2)  // D5: iet-- as the array holds it
-                  : smv<NT>(g, b_s, tm2);
+      if (!LATE || FUSE) {
+        b1 = smv<NT>(g, b_s, tm1);    // iet++ tmp1
+        b2 = STRICT ? smv<NT>(g, sload<NT>(g, w, a.ie_a[T_MM] + o4), tm2) : smv<NT>(g, b_s, tm2);  // D5: iet-- as the array holds it
+      }
     };
     if (!VLDS) own_mv();
+    Strip<NT> bmm_s;
+    if (STRICT && LATE && !FUSE) bmm_s = sload<NT>(g, w, a.ie_a[T_MM] + o4);  // D5: iet-- as the array holds it
     StripReq<NT> gt0_q, ttgp1_q, gr0_q, t0_q, ttgpr1_q;  // requested row by row between the MFMAs of the products below
     gt0_q.init(g, w, a.sm[SM_GT] + m0); ttgp1_q.init(g, w, a.sm[SM_TTGP] + m1); gr0_q.init(g, w, a.sm[SM_GR] + m0);
     t0_q.init(g, w, a.sm[SM_TT] + m0); ttgpr1_q.init(g, w, a.sm[SM_TTGPR] + m1);
@@ -466,14 +432,27 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
       own_mv();
     }
     // X = ier r0 + r1 ier
-    Strip<NT> X_s = sTNacc_job<NT, false, NG>(g, S_g, a_s, szeros<NT>(), [&](int tk, int s) { gt0_q.step(tk, s); });   // U = r0_c
-    X_s = sTNacc_job<NT, true, NG>(g, S_a, r1_s, X_s, [&](int tk, int s) { ttgp1_q.step(tk, s); });                   // U = a_c = (a_t)^T
+    Strip<NT> X_s = sTNacc_job<NT, false, NG>(g, S_g, a_s, szeros<NT>(), [&](int tk, int s) {                          // U = r0_c
+      if (LATE) r1_q.step(tk, s);
+      if (LATE && !FUSE) b_q.step(tk, s);
+    });
+    const Strip<NT> &r1_s = r1_q.X;
+    if (LATE && !FUSE) b_s = b_q.X;
+    X_s = sTNacc_job<NT, true, NG>(g, S_a, r1_s, X_s, [&](int tk, int s) {                                            // U = a_c = (a_t)^T
+      gt0_q.step(tk, s);
+      ttgp1_q.step(tk, s);
+    });
     const Strip<NT> &gt0_s = gt0_q.X, &ttgp1_s = ttgp1_q.X;
     const double X1 = smv<NT>(g, X_s, tm1), X2 = smv<NT>(g, X_s, tm2);
+    if (LATE && !FUSE) {
+      b1 = smv<NT>(g, b_s, tm1);                                                     // iet++ tmp1
+      b2 = STRICT ? smv<NT>(g, bmm_s, tm2) : smv<NT>(g, b_s, tm2);
+    }
     MOMR_STAMP_NW(25);  // 4 + 2 mat-vecs, X: 2 products
     WG_SYNC_ST();  // r0 has been read by everybody
     spublish<NT>(g, w, S_x, X_s);
     spublish<NT>(g, w, S_g, gt0_s);
+    if (LATE && !FUSE) spublish<NT>(g, w, S_b, b_s);
     MOMR_STAMP_NW(27);  // publications
     // ---- sources
     {
@@ -515,22 +494,15 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     spublish<NT>(g, w, S_g, gr0_s);
     MOMR_STAMP_NW(27);
     WG_SYNC_ST();
-    constexpr bool PF = (MOMR_WG_PREFETCH & (NT == 2 ? 1 : (NT == 3 ? 2 : 4))) != 0;
-    if (PF) pf_begin(p + gridDim.x, nx);
-    Strip<NT> Q_s = sTNacc_job<NT, false, NG>(g, S_g, bn_s, szeros<NT>(),          // iet(new) G r[n0]        (U = (G r)[n0]_c)
-                                          [&](int tk, int s) { if (PF && pf_on) nx.r0_q.step(tk, s); });
-    Q_s = sTNacc_job<NT, true, NG>(g, S_a, ttgp1_s, Q_s,                           // + tG ier                (U = a_c)
-                               [&](int tk, int s) { if (PF && pf_on) nx.r1_q.step(tk, s); });
+    Strip<NT> Q_s = sTNacc<NT, false, NG>(g, S_g, bn_s, szeros<NT>());      // iet(new) G r[n0]        (U = (G r)[n0]_c)
+    Q_s = sTNacc<NT, true, NG>(g, S_a, ttgp1_s, Q_s);                       // + tG ier                (U = a_c)
     MOMR_STAMP_NW(30);  // Q: 2 products
     WG_SYNC_ST();                                                              // (G r)[n0] has been read
     spublish<NT>(g, w, S_g, t0_s);
     MOMR_STAMP_NW(27);
     WG_SYNC_ST();
-    Strip<NT> an_s = sTNacc_sum_job<NT, NG>(g, S_b, S_x, ttgpr1_s, szeros<NT>(),   // (iet(new) + Y) ...      (U = V_c = bn_c + Y_c)
-                                        [&](int tk, int s) { if (PF && !FUSE && pf_on) nx.a_q.step(tk, s); });
-    an_s = sTNacc_job<NT, false, NG>(g, S_g, Q_s, an_s,                            // + t[n0]-side product    (U = t0_c)
-                                 [&](int tk, int s) { if (PF && !FUSE && pf_on) nx.b_q.step(tk, s); });
-    if (PF && pf_on) nx.have = true;
+    Strip<NT> an_s = sTNacc_sum<NT, NG>(g, S_b, S_x, ttgpr1_s, szeros<NT>());  // (iet(new) + Y) ...      (U = V_c = bn_c + Y_c)
+    an_s = sTNacc<NT, false, NG>(g, S_g, Q_s, an_s);                           // + t[n0]-side product    (U = t0_c)
     an_s = sadd<NT>(sread<NT>(g, w, S_a), an_s);
     bn_s = sread<NT>(g, w, S_b);
     MOMR_STAMP_NW(31);  // ier: 2 products, read-back of a and bn
