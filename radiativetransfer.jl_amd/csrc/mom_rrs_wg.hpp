@@ -494,7 +494,10 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     spublish<NT>(g, w, S_g, gr0_s);
     MOMR_STAMP_NW(27);
     WG_SYNC_ST();
-    Strip<NT> Q_s = sTNacc<NT, false, NG>(g, S_g, bn_s, szeros<NT>());      // iet(new) G r[n0]        (U = (G r)[n0]_c)
+    // (the new iet++ is final: its stores go out row by row between the MFMAs of this product, not in the burst at the end)
+    double *bn_st = a.ie_a[T_PP] + o4 + 16 * w + g.lr + (16 * NT) * g.lq;
+    Strip<NT> Q_s = sTNacc_job<NT, false, NG>(g, S_g, bn_s, szeros<NT>(),      // iet(new) G r[n0]        (U = (G r)[n0]_c)
+                                              [&](int tk, int s) { bn_st[(16 * NT) * (16 * tk + 4 * s)] = bn_s.t[tk][s]; });
     Q_s = sTNacc<NT, true, NG>(g, S_a, ttgp1_s, Q_s);                       // + tG ier                (U = a_c)
     MOMR_STAMP_NW(30);  // Q: 2 products
     WG_SYNC_ST();                                                              // (G r)[n0] has been read
@@ -504,11 +507,10 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
     Strip<NT> an_s = sTNacc_sum<NT, NG>(g, S_b, S_x, ttgpr1_s, szeros<NT>());  // (iet(new) + Y) ...      (U = V_c = bn_c + Y_c)
     an_s = sTNacc<NT, false, NG>(g, S_g, Q_s, an_s);                           // + t[n0]-side product    (U = t0_c)
     an_s = sadd<NT>(sread<NT>(g, w, S_a), an_s);
-    bn_s = sread<NT>(g, w, S_b);
-    MOMR_STAMP_NW(31);  // ier: 2 products, read-back of a and bn
+    MOMR_STAMP_NW(31);  // ier: 2 products, read-back of a
     if (fuseD) {  // apply_D_matrix_IE!, corrected indexing (D2)
       if (n > 1) smap<NT>(g, w, an_s, sgn_i);
-      Strip<NT> apm = an_s, bmm = bn_s;
+      Strip<NT> apm = an_s, bmm = sread<NT>(g, w, S_b);
       if (n > 1) {
         smap<NT>(g, w, apm, sgn_ij);
         smap<NT>(g, w, bmm, sgn_ij);
@@ -519,7 +521,6 @@ __device__ __forceinline__ void dbl_pair_wg(const KArgs &a) {
       }
     }
     sstore<NT>(g, w, a.ie_a[R_MP] + o4, an_s);
-    sstore<NT>(g, w, a.ie_a[T_PP] + o4, bn_s);
     MOMR_STAMP_NW(32);  // D signs, operator stores issued
   }
 }
