@@ -167,6 +167,14 @@ struct StripReq {
   __device__ __forceinline__ void init(const Geo &g, int w, const double *p) { q = p + 16 * w + g.lr + (16 * NT) * g.lq; }
   __device__ __forceinline__ void step(int a, int r) { X.t[a][r] = q[(16 * NT) * (16 * a + 4 * r)]; }
 };
+// ... the same for a strip of the _c form (sloadT spread over 4 NT calls)
+template <int NT>
+struct StripReqT {
+  Strip<NT> X;
+  const double *q;
+  __device__ __forceinline__ void init(const Geo &g, int w, const double *p) { q = p + g.lq + (size_t)(16 * NT) * (16 * w + g.lr); }
+  __device__ __forceinline__ void step(int a, int r) { X.t[a][r] = q[16 * a + 4 * r]; }
+};
 // ... with U = M1^T + M2 formed fragment-wise (W = b^T + Y, V = bn^T + Y of the doubling step)
 template <int NT, bool NG = false>
 __device__ __forceinline__ Strip<NT> sTNacc_sum(const Geo &g, const double *M1, const double *M2, const Strip<NT> &V, Strip<NT> acc) {
@@ -575,13 +583,25 @@ __device__ __forceinline__ void int_pair_wg(const KArgs &a) {
     const size_t u = (size_t)n1 + (size_t)a.S * dn, o4 = NN * u, o3 = VS * u;
     const size_t m1 = NN * n1, m0 = NN * n0, v0 = VS * n0;
     const double *pa = a.ie_a[R_MP] + o4, *pbm = a.ie_a[DERIVE ? T_PP : T_MM] + o4;
-    // ---- stage 0: a -> P, r1 -> Q, bm -> R, G1RT0 -> T
+    // ---- stage 0: a -> P, r1 -> Q.  Only these two strips and R+-[n0] are requested as a burst; the other six strips of the first
+    // four products (and bm, G1RT0 for the second LDS round) follow row by row between the MFMAs of the products before their use
     const Strip<NT> a_s = SURF ? szeros<NT>() : sload<NT>(g, w, pa);
     const Strip<NT> r1_s = sload<NT>(g, w, a.x[R_MP] + m1);
-    Strip<NT> bm_s = SURF ? szeros<NT>() : sload<NT>(g, w, pbm);
-    if (DERIVE && !SURF) bm_s = flip(bm_s);
-    const Strip<NT> g1rt_s = sload<NT>(g, w, a.sm[SI_G1RT] + m0);
-    const Strip<NT> Rpm0_s = sload<NT>(g, w, a.sm[SI_RPM] + m0), Tpp0_s = sload<NT>(g, w, a.sm[SI_TPP] + m0);
+    const Strip<NT> Rpm0_s = sload<NT>(g, w, a.sm[SI_RPM] + m0);
+    // (4 x 4 tiles only: -4 % there, nothing at 2 x 2, and 3 x 3 at its 256-register budget spills and loses 7 %:
+    // profiles/r05_rrs_wg_ab.txt (16); the other tile counts request the same strips in two bursts)
+    constexpr bool LATE = (NT == 4);
+    StripReq<NT> Tpp0_q, T01_q, A_q, bm_q, g1rt_q;
+    StripReqT<NT> Ec_q, Cc_q;
+    if (LATE) {
+      Tpp0_q.init(g, w, a.sm[SI_TPP] + m0); T01_q.init(g, w, a.sm[SI_T01] + m1); A_q.init(g, w, a.ie_c[C_T_MM] + o4);
+      bm_q.init(g, w, pbm); g1rt_q.init(g, w, a.sm[SI_G1RT] + m0);
+      Ec_q.init(g, w, a.ie_c[C_R_PM] + o4); Cc_q.init(g, w, a.ie_c[C_T_PP] + o4);
+    } else {
+      if (!SURF) bm_q.X = sload<NT>(g, w, pbm);
+      g1rt_q.X = sload<NT>(g, w, a.sm[SI_G1RT] + m0);
+      Tpp0_q.X = sload<NT>(g, w, a.sm[SI_TPP] + m0);
+    }
     const double Jap = SURF ? 0.0 : a.ie_a[J0P][o3 + cw], Jam = SURF ? 0.0 : a.ie_a[J0M][o3 + cw];
     const double Jcp = a.ie_c[C_J0P][o3 + cw], Jcm = a.ie_c[C_J0M][o3 + cw];
     const double v1 = smv<NT>(g, a_s, loadR<NT>(g, a.c_cur[C_J0P] + v0));   // ier J0+[n0]
@@ -590,21 +610,30 @@ __device__ __forceinline__ void int_pair_wg(const KArgs &a) {
     wg_sync();  // the previous pair has finished with the LDS matrices
     spublish<NT>(g, w, S_p, a_s);
     spublish<NT>(g, w, S_q, r1_s);
-    spublish<NT>(g, w, S_r, bm_s);
-    spublish<NT>(g, w, S_t, g1rt_s);
     vput(g, w, vb0, uu1);
-    const Strip<NT> Ec_s = sloadT<NT>(g, w, a.ie_c[C_R_PM] + o4), Cc_s = sloadT<NT>(g, w, a.ie_c[C_T_PP] + o4);
+    if (!LATE) {
+      spublish<NT>(g, w, S_r, (DERIVE && !SURF) ? flip(bm_q.X) : (SURF ? szeros<NT>() : bm_q.X));
+      spublish<NT>(g, w, S_t, g1rt_q.X);
+      Ec_q.X = sloadT<NT>(g, w, a.ie_c[C_R_PM] + o4);
+      Cc_q.X = sloadT<NT>(g, w, a.ie_c[C_T_PP] + o4);
+    }
     wg_sync();
     // A = T01 (ier R+-[n0] + r ieR+-) + ieT--                                                                     :252-262
-    Strip<NT> M1_s = sTNacc<NT, false>(g, S_p, Rpm0_s, szeros<NT>());
-    Strip<NT> N1_s = sTNacc<NT, false>(g, S_p, Tpp0_s, szeros<NT>());
-    const Strip<NT> T01_s = sload<NT>(g, w, a.sm[SI_T01] + m1);
-    M1_s = sTNacc<NT, false>(g, S_q, Ec_s, M1_s);
-    Strip<NT> A_s = sload<NT>(g, w, a.ie_c[C_T_MM] + o4);
-    N1_s = sTNacc<NT, false>(g, S_q, Cc_s, N1_s);
+    Strip<NT> M1_s = sTNacc_job<NT, false, false>(g, S_p, Rpm0_s, szeros<NT>(), [&](int tk, int s) { if (LATE) { Tpp0_q.step(tk, s); Ec_q.step(tk, s); } });
+    Strip<NT> N1_s = sTNacc_job<NT, false, false>(g, S_p, Tpp0_q.X, szeros<NT>(), [&](int tk, int s) { if (LATE) { Cc_q.step(tk, s); T01_q.step(tk, s); } });
+    if (!LATE) T01_q.X = sload<NT>(g, w, a.sm[SI_T01] + m1);
+    M1_s = sTNacc_job<NT, false, false>(g, S_q, Ec_q.X, M1_s, [&](int tk, int s) { if (LATE) { A_q.step(tk, s); if (!SURF) bm_q.step(tk, s); } });
+    if (!LATE) A_q.X = sload<NT>(g, w, a.ie_c[C_T_MM] + o4);
+    N1_s = sTNacc_job<NT, false, false>(g, S_q, Cc_q.X, N1_s, [&](int tk, int s) { if (LATE) g1rt_q.step(tk, s); });
+    const Strip<NT> &T01_s = T01_q.X;
+    Strip<NT> A_s = A_q.X;
     wg_sync();  // a and r have been read
     spublish<NT>(g, w, S_p, M1_s);
     spublish<NT>(g, w, S_q, N1_s);
+    if (LATE) {
+      spublish<NT>(g, w, S_r, (DERIVE && !SURF) ? flip(bm_q.X) : (SURF ? szeros<NT>() : bm_q.X));
+      spublish<NT>(g, w, S_t, g1rt_q.X);
+    }
     wg_sync();
     A_s = sTNacc<NT, false>(g, S_p, T01_s, A_s);
     // ieJ0- += T01 (ier J0+[n0] + r ieJ0+ + ieJ0-(added)) + A G1 (j0-[n0] + r[n0] J0+[n0])                         :251-264
@@ -617,11 +646,13 @@ __device__ __forceinline__ void int_pair_wg(const KArgs &a) {
     const Strip<NT> g1t_s = sload<NT>(g, w, a.sm[SI_G1T] + m0);
     Rm_s = sTNacc<NT, false>(g, S_q, T01_s, Rm_s);
     Rm_s = sTNacc<NT, false>(g, S_t, A_s, Rm_s);
-    sstore<NT>(g, w, a.ie_c[C_R_MP] + o4, Rm_s);
+    double *Rm_st = a.ie_c[C_R_MP] + o4 + 16 * w + g.lr + (16 * NT) * g.lq;  // (LATE: stored row by row inside the next product)
+    if (!LATE) sstore<NT>(g, w, a.ie_c[C_R_MP] + o4, Rm_s);
     // the operands of the second half (E as a left factor, R+-[n1], G2 R+-[n0] t--[n0])
     const Strip<NT> E_s = sload<NT>(g, w, a.ie_c[C_R_PM] + o4), Rpm1_s = sload<NT>(g, w, a.c_cur[C_R_PM] + m1);
     const Strip<NT> g2rt_s = sload<NT>(g, w, a.sm[SI_G2RT] + m0);
-    Strip<NT> F_s = sTNacc<NT, true>(g, S_r, T01_s, szeros<NT>());  // U = bm_c = (bm_t)^T
+    Strip<NT> F_s = sTNacc_job<NT, true, false>(g, S_r, T01_s, szeros<NT>(),  // U = bm_c = (bm_t)^T
+                                                [&](int tk, int s) { if (LATE) Rm_st[(16 * NT) * (16 * tk + 4 * s)] = Rm_s.t[tk][s]; });
     wg_sync();  // M1, N1, bm, G1RT0 have been read
     spublish<NT>(g, w, S_p, g1t_s);
     spublish<NT>(g, w, S_q, E_s);
