@@ -431,33 +431,44 @@ def c5_leg(a, S, steps, warmup, dev, with_cpu=True, world=1, rank=0, dist=None):
     return out
 
 
-def c5_cpu_baseline(S, n_lines=2):
-    """numpy restatement (oracle/rrsref.py, one core) of the same scene with only the `n_lines` strongest Raman lines;
-    the pair work is linear in the number of lines, so the rate for the full line list is extrapolated from the two
-    timings (elastic-only run, run with n_lines)."""
+def c5_cpu_baseline(S, budget_s=20.0):
+    """The C port of the Raman restatement (oracle/momref.c ora_rt_run_rrs, OpenMP over points and (n1, dn) pairs) TIMED on
+    all usable host cores on the same C5 scene with ALL its Raman lines, on an owned window of n1 in the middle of the grid
+    sized to the time budget (a 64-point pilot window gives the rate; the elastic operators cover all S points in either
+    run, as in the full problem).  value = owned points / wall time of the window run: nothing is extrapolated over lines."""
     sys.path.insert(0, str(ROOT / "tests"))
     import helpers
     import rtamd
-    from oracle import momref as mr, rrsref as rr
-    m, RS_full = rtamd.scenes.scene_C5(S=S)
-    m, RS = rtamd.scenes.scene_C5(S=S, nRaman=n_lines)
+    from oracle import cref, momref as mr, rrsref as rr
+    m, RS = rtamd.scenes.scene_C5(S=S)
     scene = helpers.oracle_scene(m)
     scene.varpi_cabannes = RS.ϖ_Cabannes
     g = mr.get_greek_rayleigh(0.75)
-    t0 = time.perf_counter()
-    mr.rt_run(scene)
-    t_el = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    rr.rt_run_rrs(scene, rr.RRSInputs(np.asarray(RS.i_λ1λ0, dtype=np.int64), RS.ϖ_λ1λ0, g, rrs_strict_reference=False))
-    t_n = time.perf_counter() - t0
-    per_line = max(t_n - t_el, 1e-9) / n_lines
-    t_full = t_el + per_line * RS_full.n_Raman
-    return {"value": S / t_full, "unit": "spectral points/s", "cores": 1, "kind": "port",
-            "extrapolated": True,
-            "sample": f"EXTRAPOLATED, not timed at full size: numpy restatement (oracle/rrsref.py) on ONE core, the same C5 scene "
-                      f"with the {n_lines} strongest of {RS_full.n_Raman} Raman lines ({t_n:.1f} s; elastic-only run {t_el:.1f} s); "
-                      f"the pair work is linear in the number of lines: {t_full:.0f} s per run at {RS_full.n_Raman} lines "
-                      f"(x {RS_full.n_Raman / n_lines:.0f} on the inelastic part)"}
+    p = cref.pack_scene(scene)
+    cores = cref.effective_cores()
+    offs = np.asarray(RS.i_λ1λ0, dtype=np.int64)
+
+    def run(lo, hi):
+        ora = rr.RRSInputs(offs, RS.ϖ_λ1λ0, g, rrs_strict_reference=bool(RS.rrs_strict_reference), owned=(lo, hi))
+        t0 = time.perf_counter()
+        out = cref.rt_run_rrs(scene, ora, nthreads=cores, p=p)
+        assert out[4] == 0 and np.all(np.isfinite(out[2]))
+        return time.perf_counter() - t0
+
+    mid = S // 2
+    w1, w2 = 1, min(256, S)                             # two pilot windows: t = a (elastic part over all S points) + b W
+    t1, t2 = run(mid, mid + w1), run(mid, mid + w2)
+    b = max((t2 - t1) / max(w2 - w1, 1), 1e-6)
+    a_fix = max(t1 - b * w1, 0.0)
+    W = int(min(S, max(w2, 0.6 * (budget_s - a_fix) / b)))   # 0.6: the pair arrays leave the caches as W grows
+    lo = max(0, mid - W // 2)
+    t_w = run(lo, lo + W)
+    return {"value": W / t_w, "unit": "spectral points/s", "cores": cores, "kind": "port",
+            "sample": f"C port of the Raman restatement (oracle/momref.c ora_rt_run_rrs), {cores} OpenMP threads, the same C5 scene "
+                      f"with all {RS.n_Raman} Raman lines, rrs_strict_reference={int(RS.rrs_strict_reference)}: owned window of {W} "
+                      f"of {S} points [{lo}, {lo + W}) TIMED at {t_w:.1f} s, of which ~{a_fix:.1f} s are the elastic operators of all "
+                      f"{S} points (pilot windows of {w1} / {w2} points: {t1:.1f} / {t2:.1f} s); the reference itself is Julia and "
+                      f"not runnable here"}
 
 
 def f32_leg(dev, S=20_000, n_streams=8, nd=5, steps=3):

@@ -344,3 +344,46 @@ def voigt_xsec(nu, gamma_d, y, Sline, ind_start, ind_stop, grid):
     lib().ora_voigt_xsec(len(nu), dp(nu), dp(gamma_d), dp(y), dp(Sline), ip(ind_start), ip(ind_stop), len(grid),
                          dp(np.ascontiguousarray(grid, dtype=np.float64)), dp(sigma))
     return sigma
+
+
+# ---- rotational Raman: rt_run(::RRS) on the C oracle (momref.c ora_rt_run_rrs; twin of oracle/rrsref.py) -----------------
+
+class OraRRS(C.Structure):
+    _fields_ = [("nR", C.c_int), ("off", c_ip), ("wR", c_dp), ("ZRpp", c_dp), ("ZRmp", c_dp), ("fscatt", c_dp),
+                ("rrs_strict", C.c_int), ("own_lo", C.c_int), ("own_hi", C.c_int)]
+
+
+class ReferenceRaises(RuntimeError):
+    """The reference's text raises a Julia exception on this path (see oracle/rrsref.py)."""
+
+
+def rt_run_rrs(scene: mr.Scene, rrs, nthreads: int = 0, p: Packed = None):
+    """rt_run(RS_type::RRS, model, iBand) on the C oracle.  `rrs` is an oracle/rrsref.py RRSInputs (offsets, weights, Raman
+    greek coefficients, switch position, optional owned window of n1); `scene` carries the Cabannes albedo
+    (scene.varpi_cabannes).  Returns R_SFI, T_SFI, ieR_SFI, ieT_SFI [nVza, nStokes, S] (inelastic spectra: owned points only)."""
+    from . import rrsref as rr
+    p = p or Packed(scene)
+    if nthreads <= 0:
+        nthreads = effective_cores()
+    N, M, S = p.N, p.M, p.S
+    Z = [mr.compute_Z_moments(scene.pol.n, scene.quad.qp_mu, rrs.greek_raman, m) for m in range(M)]
+    ZRpp = np.ascontiguousarray(np.transpose(np.array([z[0] for z in Z]), (0, 2, 1))).reshape(-1)   # [m][j][i]
+    ZRmp = np.ascontiguousarray(np.transpose(np.array([z[1] for z in Z]), (0, 2, 1))).reshape(-1)
+    fs = np.ascontiguousarray(rr.fscatt_rayleigh(scene).T).reshape(-1)                              # [z][n]
+    off = np.ascontiguousarray(rrs.i_l1l0, dtype=np.int32)
+    wR = np.ascontiguousarray(rrs.varpi_l1l0, dtype=np.float64)
+    lo, hi = rrs.owned if rrs.owned is not None else (0, S)
+    st = p.c_struct()
+    r = OraRRS(len(off), ip(off), dp(wR), dp(ZRpp), dp(ZRmp), dp(fs), 1 if rrs.rrs_strict_reference else 0, int(lo), int(hi))
+    out = [np.zeros(p.nVza * p.nS * S) for _ in range(4)]
+    L = lib()
+    L.ora_rt_run_rrs.restype = C.c_int
+    info = L.ora_rt_run_rrs(C.byref(st), C.byref(r), int(nthreads), *[dp(o) for o in out])
+    if info == -2:
+        raise ReferenceRaises("get_n0_n1: no valid index (BoundsError)")
+    if info == -3:
+        raise ReferenceRaises("interaction_helper!(::RRS, 00/01/10): MethodError in the reference")
+    if info == -1:
+        raise MemoryError("ora_rt_run_rrs: allocation failed or bad window")
+    shp = (S, p.nS, p.nVza)
+    return tuple(np.transpose(o.reshape(shp), (2, 1, 0)).copy() for o in out) + (info,)

@@ -888,3 +888,689 @@ void ora_voigt_xsec(int nLines, const double *nu, const double *gamma_d, const d
                   ora_w_hw32sd_re(cSqrtLn2 / gamma_d[j] * (grid[i] - nu[j]), y[j]);
   }
 }
+
+/* ---------------------------------------------------------------- rotational Raman: rt_run(RS_type::RRS, model, iBand)
+ *
+ * C twin of oracle/rrsref.py (which states the defects D1..D5 of the reference's RRS text and the meaning of the switch
+ * `rrs_strict`): rt_kernel!(::RRS) rt_kernel.jl:277-340 = elemental_inelastic!(::RRS) (elemental_inelastic.jl:23-91) +
+ * elemental! + doubling_helper!(::RRS) (doubling_inelastic.jl:13-134) + interaction_helper!(::RRS, iface)
+ * (interaction_inelastic.jl:8-340), the surface interaction with an added layer whose ie* arrays are zeros, and
+ * postprocessing_vza!(::RRS) (tools/postprocessing_vza.jl:95-147).  PARITY UNPINNED like the numpy twin (the reference holds
+ * no known-answer test of its Raman path); this file is checked against the twin in tests/test_oracle_rrs.py.
+ *
+ * A Raman operator ie[.,.,n1,dn] takes radiation from spectral index n0 = n1 + off[dn] to n1.  Every pair (n1, dn) reads
+ * elastic operators at n1 and n0 and inelastic ones at (n1, dn) only, so the run can be restricted to an OWNED window
+ * [own_lo, own_hi) of n1: the owned entries are those of the unrestricted run.  Elastic arrays cover all S points;
+ * inelastic arrays are [N,N,W,nR] / [N,1,W,nR] with W = own_hi - own_lo (element (dn, n1) at (dn*W + n1 - own_lo)).
+ * In the strict position the defects D2/D3 index the RAMAN axis with n + off[dn]: they stay inside one spectral index n,
+ * so the window applies to them as well. */
+
+typedef struct {
+  int nR;
+  const int *off;             /* [nR] i_l1l0 = n0 - n1 in grid points (inelastic_helper.jl:13-21) */
+  const double *wR;           /* [nR] varpi_l1l0 */
+  const double *ZRpp, *ZRmp;  /* [N,N,M] Raman phase-matrix moments (computeRamanZλ!, inelastic_helper.jl:457-464) */
+  const double *fscatt;       /* [S,Nz] fScattRayleigh (compEffectiveLayerProperties.jl:58) */
+  int rrs_strict;             /* 1 = the reference's text as written, 0 = corrections D1..D5 */
+  int own_lo, own_hi;         /* 0-based window of n1, hi exclusive */
+} ora_rrs;
+
+typedef struct { /* AddedLayerRS / CompositeLayerRS (types.jl:145-205): elastic part [.,.,S], inelastic part [.,.,W,nR] */
+  double *pm, *mp, *mm, *pp, *Jp, *Jm;             /* r+-/R+-, r-+/R-+, t--/T--, t++/T++, j0+/J0+, j0-/J0- */
+  double *ie_pm, *ie_mp, *ie_mm, *ie_pp, *ieJp, *ieJm;
+} rrs_layer;
+
+static int rrs_layer_alloc(rrs_layer *L, size_t NN, size_t N, size_t S, size_t P, int with_ie) {
+  memset(L, 0, sizeof(*L));
+  L->pm = (double *)calloc(NN * S, sizeof(double)); L->mp = (double *)calloc(NN * S, sizeof(double));
+  L->mm = (double *)calloc(NN * S, sizeof(double)); L->pp = (double *)calloc(NN * S, sizeof(double));
+  L->Jp = (double *)calloc(N * S, sizeof(double)); L->Jm = (double *)calloc(N * S, sizeof(double));
+  int ok = L->pm && L->mp && L->mm && L->pp && L->Jp && L->Jm;
+  if (with_ie) {
+    L->ie_pm = (double *)calloc(NN * P, sizeof(double)); L->ie_mp = (double *)calloc(NN * P, sizeof(double));
+    L->ie_mm = (double *)calloc(NN * P, sizeof(double)); L->ie_pp = (double *)calloc(NN * P, sizeof(double));
+    L->ieJp = (double *)calloc(N * P, sizeof(double)); L->ieJm = (double *)calloc(N * P, sizeof(double));
+    ok = ok && L->ie_pm && L->ie_mp && L->ie_mm && L->ie_pp && L->ieJp && L->ieJm;
+  }
+  return ok;
+}
+
+static void rrs_layer_free(rrs_layer *L) {
+  free(L->pm); free(L->mp); free(L->mm); free(L->pp); free(L->Jp); free(L->Jm);
+  free(L->ie_pm); free(L->ie_mp); free(L->ie_mm); free(L->ie_pp); free(L->ieJp); free(L->ieJm);
+}
+
+static inline void madd(size_t n, const double *A, const double *B, double *C) {
+  for (size_t x = 0; x < n; ++x) C[x] = A[x] + B[x];
+}
+
+/* get_elem_rt_RRS! elemental_inelastic.jl:93-160 and get_elem_rt_SFI_RRS! :320-382 for ONE on-grid pair (n1, dn):
+ * d1 = dtau[n1], d0 = dtau[n0], pre-factors at n0, att = exp(-tau_sum[n0]/mu_sun). */
+static void rrs_elemental_pair(const ora_streams *q, int m, double wR, double varpi0, double fs0, double d1, double d0,
+                               double tau_sum0, const double *Zpp, const double *Zmp, double *ier, double *iet,
+                               double *jp, double *jm) {
+  const int N = q->N, n = q->nS;
+  const double *mu = q->mu;
+  const double wct02 = (m == 0) ? 0.5 : 0.25;
+  const double pre = wR * varpi0 * fs0;
+  const int far = fabs(d0 - d1) > 1.e-6;
+  for (int j = 0; j < N; ++j) {
+    const double wj = (m == 0) ? q->wt[j] / 2 : q->wt[j] / 4;
+    for (int i = 0; i < N; ++i) {
+      double r = 0.0, t = 0.0;
+      if (wj > 1.e-8) {
+        r = fs0 * wR * varpi0 * Zmp[IDX(i, j, N)] * (1 / ((mu[i] / mu[j]) + (d1 / d0))) *
+            (1 - exp(-((d1 / mu[i]) + (d0 / mu[j])))) * wj;
+        if (mu[i] == mu[j]) {
+          if (i == j) {
+            const double wi = (m == 0) ? q->wt[i] / 2 : q->wt[i] / 4;
+            if (far)
+              t = pre * Zpp[IDX(i, i, N)] * wi * (exp(-d0 / mu[i]) - exp(-d1 / mu[i])) / (1 - (d1 / d0));
+            else
+              t = pre * Zpp[IDX(i, i, N)] * wi * (1 - exp(-d0 / mu[j]));
+          } else
+            t = 0.0;
+        } else
+          t = pre * Zpp[IDX(i, j, N)] * (1 / ((mu[i] / mu[j]) - (d1 / d0))) * wj * (exp(-d1 / mu[i]) - exp(-d0 / mu[j]));
+      }
+      ier[IDX(i, j, N)] = r;
+      iet[IDX(i, j, N)] = t;
+    }
+  }
+  const int i_start = n * (q->imu0 - 1), i_end = n * q->imu0;
+  const double mus = mu[i_start];
+  const double att = exp(-tau_sum0 / mus);
+  for (int i = 0; i < N; ++i) {
+    double zp = 0.0, zm = 0.0;
+    for (int ii = i_start; ii < i_end; ++ii) {
+      zp += Zpp[IDX(i, ii, N)] * q->I0[ii - i_start];
+      zm += Zmp[IDX(i, ii, N)] * q->I0[ii - i_start];
+    }
+    double p;
+    if (i >= i_start && i < i_end) {
+      if (far)
+        p = (exp(-d0 / mu[i]) - exp(-d1 / mu[i])) / ((d1 / d0) - 1) * pre * zp * wct02;
+      else
+        p = wct02 * pre * zp * (1 - exp(-d0 / mus));
+    } else
+      p = wct02 * pre * zp * (1 / ((mu[i] / mus) - (d1 / d0))) * (exp(-d1 / mu[i]) - exp(-d0 / mus));
+    jp[i] = p * att;
+    jm[i] = wct02 * pre * zm * (1 / ((mu[i] / mus) + (d1 / d0))) * (1 - exp(-((d1 / mu[i]) + (d0 / mus)))) * att;
+  }
+}
+
+/* per-thread scratch of the pair loops: 10 matrices + 8 vectors */
+#define RRS_WORK(NN, N) (10 * (NN) + 8 * (size_t)(N))
+
+/* interaction_helper!(::RRS, iface, ...) interaction_inelastic.jl:8-22 (00), :28-76 (01), :139-180 (10), :230-340 (11) on
+ * whole layers; `a` = added layer (a->ie_* == NULL: a surface layer, whose inelastic arrays are zeros).  wsE: 2*NN*S
+ * doubles (tmp_inv, T01 / T21 per point).  Returns LU info, -3 for a non-11 interface in the strict position (D4). */
+static int rrs_interaction(const ora_scene *sc, const ora_rrs *rs, int iface, rrs_layer *c, const rrs_layer *a, double *wsE,
+                           const double *zeroM, int nthreads) {
+  const int N = sc->N, S = sc->S, nR = rs->nR, lo = rs->own_lo, W = rs->own_hi - rs->own_lo;
+  const size_t NN = (size_t)N * N;
+  int info = 0;
+  if (iface != 3 && rs->rrs_strict) return -3;
+  double *tinv = wsE, *T1 = wsE + NN * S;
+#define PAIR(dn, n1) ((size_t)(dn) * W + (size_t)((n1) - lo))
+#define AIE(arr, p) (a->arr ? a->arr + NN * (p) : zeroM)
+#define AIEV(arr, p) (a->arr ? a->arr + (size_t)N * (p) : zeroM)
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+  {
+    double *w = (double *)malloc(RRS_WORK(NN, N) * sizeof(double));
+    int *piv = (int *)malloc(N * sizeof(int));
+    double *M1 = w, *M2 = w + NN, *M3 = w + 2 * NN, *M4 = w + 3 * NN;
+    double *v1 = w + 10 * NN, *v2 = v1 + N, *v3 = v2 + N, *v4 = v3 + N;
+    if (iface == 0) { /* :8-22 */
+#pragma omp for schedule(static)
+      for (size_t x = 0; x < (size_t)N * W * nR; ++x) { c->ieJp[x] = 0.0; c->ieJm[x] = 0.0; }
+#pragma omp for schedule(static)
+      for (int s = 0; s < S; ++s) {
+        double *Jp = c->Jp + (size_t)N * s, *Jm = c->Jm + (size_t)N * s;
+        gemv(N, a->pp + NN * s, Jp, v1);
+        gemv(N, c->mm + NN * s, a->Jm + (size_t)N * s, v2);
+        for (int i = 0; i < N; ++i) { Jp[i] = a->Jp[(size_t)N * s + i] + v1[i]; Jm[i] = Jm[i] + v2[i]; }
+        gemm(N, a->mm + NN * s, c->mm + NN * s, M1); memcpy(c->mm + NN * s, M1, NN * sizeof(double));
+        gemm(N, a->pp + NN * s, c->pp + NN * s, M1); memcpy(c->pp + NN * s, M1, NN * sizeof(double));
+      }
+    } else if (iface == 1) { /* :28-76 (D4) */
+#pragma omp for schedule(dynamic, 8) collapse(2)
+      for (int dn = 0; dn < nR; ++dn)
+        for (int n1 = lo; n1 < lo + W; ++n1) {
+          const int n0 = n1 + rs->off[dn];
+          if (n0 < 0 || n0 >= S) continue;
+          const size_t p = PAIR(dn, n1);
+          gemv(N, AIE(ie_mp, p), c->Jp + (size_t)N * n0, v1);
+          for (int i = 0; i < N; ++i) v1[i] = v1[i] + AIEV(ieJm, p)[i];
+          gemv(N, c->mm + NN * n1, v1, c->ieJm + (size_t)N * p);
+          gemv(N, AIE(ie_pp, p), c->Jp + (size_t)N * n0, v1);
+          for (int i = 0; i < N; ++i) c->ieJp[(size_t)N * p + i] = AIEV(ieJp, p)[i] + v1[i];
+        }
+#pragma omp for schedule(static)
+      for (int s = 0; s < S; ++s) { /* new J0 into T1 (read by nobody else: the operators below use T++/T-- only) */
+        double *Jp = c->Jp + (size_t)N * s, *Jm = c->Jm + (size_t)N * s;
+        gemv(N, a->mp + NN * s, Jp, v1);
+        for (int i = 0; i < N; ++i) v1[i] = v1[i] + a->Jm[(size_t)N * s + i];
+        gemv(N, c->mm + NN * s, v1, v2);
+        gemv(N, a->pp + NN * s, Jp, v3);
+        for (int i = 0; i < N; ++i) { Jm[i] = Jm[i] + v2[i]; Jp[i] = a->Jp[(size_t)N * s + i] + v3[i]; }
+      }
+#pragma omp for schedule(dynamic, 8) collapse(2)
+      for (int dn = 0; dn < nR; ++dn)
+        for (int n1 = lo; n1 < lo + W; ++n1) {
+          const int n0 = n1 + rs->off[dn];
+          if (n0 < 0 || n0 >= S) continue;
+          const size_t p = PAIR(dn, n1);
+          gemm(N, c->mm + NN * n1, AIE(ie_mp, p), M1); gemm(N, M1, c->pp + NN * n0, c->ie_mp + NN * p);
+          memcpy(c->ie_pm + NN * p, AIE(ie_pm, p), NN * sizeof(double));
+          gemm(N, AIE(ie_pp, p), c->pp + NN * n0, c->ie_pp + NN * p);
+          gemm(N, c->mm + NN * n1, AIE(ie_mm, p), c->ie_mm + NN * p);
+        }
+#pragma omp for schedule(static)
+      for (int s = 0; s < S; ++s) {
+        gemm(N, c->mm + NN * s, a->mp + NN * s, M1); gemm(N, M1, c->pp + NN * s, c->mp + NN * s);
+        memcpy(c->pm + NN * s, a->pm + NN * s, NN * sizeof(double));
+        gemm(N, a->pp + NN * s, c->pp + NN * s, M1); memcpy(c->pp + NN * s, M1, NN * sizeof(double));
+        gemm(N, c->mm + NN * s, a->mm + NN * s, M1); memcpy(c->mm + NN * s, M1, NN * sizeof(double));
+      }
+    } else if (iface == 2) { /* :139-180 (D4) */
+#pragma omp for schedule(dynamic, 8) collapse(2)
+      for (int dn = 0; dn < nR; ++dn)
+        for (int n1 = lo; n1 < lo + W; ++n1) {
+          const int n0 = n1 + rs->off[dn];
+          if (n0 < 0 || n0 >= S) continue;
+          const size_t p = PAIR(dn, n1);
+          double *iJp = c->ieJp + (size_t)N * p, *iJm = c->ieJm + (size_t)N * p;
+          gemv(N, c->ie_pm + NN * p, a->Jm + (size_t)N * n0, v1);
+          for (int i = 0; i < N; ++i) v1[i] = iJp[i] + v1[i];
+          gemv(N, a->pp + NN * n1, v1, v2);
+          gemv(N, c->ie_mm + NN * p, a->Jm + (size_t)N * n0, v3);
+          for (int i = 0; i < N; ++i) { iJp[i] = v2[i]; iJm[i] = iJm[i] + v3[i]; }
+        }
+#pragma omp for schedule(static)
+      for (int s = 0; s < S; ++s) {
+        double *Jp = c->Jp + (size_t)N * s, *Jm = c->Jm + (size_t)N * s;
+        gemv(N, c->pm + NN * s, a->Jm + (size_t)N * s, v1);
+        for (int i = 0; i < N; ++i) v1[i] = Jp[i] + v1[i];
+        gemv(N, a->pp + NN * s, v1, v2);
+        gemv(N, c->mm + NN * s, a->Jm + (size_t)N * s, v3);
+        for (int i = 0; i < N; ++i) { Jp[i] = a->Jp[(size_t)N * s + i] + v2[i]; Jm[i] = Jm[i] + v3[i]; }
+      }
+#pragma omp for schedule(dynamic, 8) collapse(2)
+      for (int dn = 0; dn < nR; ++dn)
+        for (int n1 = lo; n1 < lo + W; ++n1) {
+          const int n0 = n1 + rs->off[dn];
+          if (n0 < 0 || n0 >= S) continue;
+          const size_t p = PAIR(dn, n1);
+          gemm(N, a->pp + NN * n1, c->ie_pp + NN * p, M1); memcpy(c->ie_pp + NN * p, M1, NN * sizeof(double));
+          gemm(N, c->ie_mm + NN * p, a->mm + NN * n0, M1); memcpy(c->ie_mm + NN * p, M1, NN * sizeof(double));
+          gemm(N, a->pp + NN * n1, c->ie_pm + NN * p, M1); gemm(N, M1, a->mm + NN * n0, c->ie_pm + NN * p);
+        }
+#pragma omp for schedule(static)
+      for (int s = 0; s < S; ++s) {
+        gemm(N, a->pp + NN * s, c->pp + NN * s, M1); memcpy(c->pp + NN * s, M1, NN * sizeof(double));
+        gemm(N, c->mm + NN * s, a->mm + NN * s, M1); memcpy(c->mm + NN * s, M1, NN * sizeof(double));
+        gemm(N, a->pp + NN * s, c->pm + NN * s, M1); gemm(N, M1, a->mm + NN * s, c->pm + NN * s);
+      }
+    } else { /* ScatteringInterface_11 :230-340 */
+#pragma omp for schedule(static)
+      for (int s = 0; s < S; ++s) { /* tmp_inv = (I - r-+ R+-)^-1 (:244), T01 = T-- tmp_inv (:247) */
+        gemm(N, a->mp + NN * s, c->pm + NN * s, M1);
+        for (size_t x = 0; x < NN; ++x) M1[x] = -M1[x];
+        for (int i = 0; i < N; ++i) M1[IDX(i, i, N)] += 1.0;
+        int e = inv_lu(N, M1, tinv + NN * s, piv);
+        if (e) {
+#pragma omp atomic write
+          info = e;
+        }
+        gemm(N, c->mm + NN * s, tinv + NN * s, T1 + NN * s);
+      }
+#pragma omp for schedule(dynamic, 8) collapse(2)
+      for (int dn = 0; dn < nR; ++dn) /* :249-265 */
+        for (int n1 = lo; n1 < lo + W; ++n1) {
+          const int n0 = n1 + rs->off[dn];
+          if (n0 < 0 || n0 >= S) continue;
+          const size_t p = PAIR(dn, n1);
+          const double *r1 = a->mp + NN * n1, *r0 = a->mp + NN * n0, *T01 = T1 + NN * n1;
+          gemm(N, AIE(ie_mp, p), c->pm + NN * n0, M1); gemm(N, r1, c->ie_pm + NN * p, M2); madd(NN, M1, M2, M3);
+          gemm(N, T01, M3, M1); madd(NN, M1, c->ie_mm + NN * p, M2);       /* A */
+          gemm(N, M2, tinv + NN * n0, M3);                                  /* A tmp_inv[n0] */
+          gemv(N, AIE(ie_mp, p), c->Jp + (size_t)N * n0, v1);
+          gemv(N, r1, c->ieJp + (size_t)N * p, v2);
+          for (int i = 0; i < N; ++i) v1[i] = (v1[i] + v2[i]) + AIEV(ieJm, p)[i];
+          gemv(N, T01, v1, v3);
+          gemv(N, r0, c->Jp + (size_t)N * n0, v1);
+          for (int i = 0; i < N; ++i) v1[i] = a->Jm[(size_t)N * n0 + i] + v1[i];
+          gemv(N, M3, v1, v4);
+          double *iJm = c->ieJm + (size_t)N * p;
+          for (int i = 0; i < N; ++i) iJm[i] = (iJm[i] + v3[i]) + v4[i];
+        }
+#pragma omp for schedule(static)
+      for (int s = 0; s < S; ++s) { /* :267 */
+        gemv(N, a->mp + NN * s, c->Jp + (size_t)N * s, v1);
+        for (int i = 0; i < N; ++i) v1[i] = v1[i] + a->Jm[(size_t)N * s + i];
+        gemv(N, T1 + NN * s, v1, v2);
+        for (int i = 0; i < N; ++i) c->Jm[(size_t)N * s + i] += v2[i];
+      }
+#pragma omp for schedule(dynamic, 8) collapse(2)
+      for (int dn = 0; dn < nR; ++dn) /* :269-285 */
+        for (int n1 = lo; n1 < lo + W; ++n1) {
+          const int n0 = n1 + rs->off[dn];
+          if (n0 < 0 || n0 >= S) continue;
+          const size_t p = PAIR(dn, n1);
+          const double *r1 = a->mp + NN * n1, *r0 = a->mp + NN * n0, *T01 = T1 + NN * n1;
+          gemm(N, AIE(ie_mp, p), c->pm + NN * n0, M1); gemm(N, r1, c->ie_pm + NN * p, M2); madd(NN, M1, M2, M3);
+          gemm(N, T01, M3, M1); madd(NN, M1, c->ie_mm + NN * p, M2);       /* A */
+          gemm(N, M2, tinv + NN * n0, M3);                                  /* A tmp_inv[n0] */
+          gemm(N, AIE(ie_mp, p), c->pp + NN * n0, M1); gemm(N, r1, c->ie_pp + NN * p, M2); madd(NN, M1, M2, M4);
+          gemm(N, T01, M4, M1);
+          gemm(N, M3, r0, M2); gemm(N, M2, c->pp + NN * n0, M4);
+          double *ieR = c->ie_mp + NN * p;
+          for (size_t x = 0; x < NN; ++x) ieR[x] = (ieR[x] + M1[x]) + M4[x];
+          gemm(N, T01, AIE(ie_mm, p), M1); gemm(N, M3, a->mm + NN * n0, M2);
+          madd(NN, M1, M2, c->ie_mm + NN * p);
+        }
+#pragma omp for schedule(static)
+      for (int s = 0; s < S; ++s) { /* :288, :290, then tmp_inv = (I - R+- r-+)^-1 (:295), T21 = t++ tmp_inv (:297) */
+        gemm(N, T1 + NN * s, a->mp + NN * s, M1); gemm(N, M1, c->pp + NN * s, M2);
+        double *R = c->mp + NN * s;
+        for (size_t x = 0; x < NN; ++x) R[x] = R[x] + M2[x];
+        gemm(N, T1 + NN * s, a->mm + NN * s, c->mm + NN * s);
+        gemm(N, c->pm + NN * s, a->mp + NN * s, M1);
+        for (size_t x = 0; x < NN; ++x) M1[x] = -M1[x];
+        for (int i = 0; i < N; ++i) M1[IDX(i, i, N)] += 1.0;
+        int e = inv_lu(N, M1, tinv + NN * s, piv);
+        if (e) {
+#pragma omp atomic write
+          info = e;
+        }
+        gemm(N, a->pp + NN * s, tinv + NN * s, T1 + NN * s);
+      }
+#pragma omp for schedule(dynamic, 8) collapse(2)
+      for (int dn = 0; dn < nR; ++dn) /* :299-313 */
+        for (int n1 = lo; n1 < lo + W; ++n1) {
+          const int n0 = n1 + rs->off[dn];
+          if (n0 < 0 || n0 >= S) continue;
+          const size_t p = PAIR(dn, n1);
+          const double *r0 = a->mp + NN * n0, *T21 = T1 + NN * n1;
+          gemm(N, c->ie_pm + NN * p, r0, M1); gemm(N, c->pm + NN * n1, AIE(ie_mp, p), M2); madd(NN, M1, M2, M3);
+          gemm(N, T21, M3, M1); madd(NN, M1, AIE(ie_pp, p), M2);           /* B */
+          gemm(N, M2, tinv + NN * n0, M3);                                  /* B tmp_inv[n0] */
+          double *iJp = c->ieJp + (size_t)N * p;
+          gemv(N, c->ie_pm + NN * p, a->Jm + (size_t)N * n0, v1);
+          gemv(N, c->pm + NN * n1, AIEV(ieJm, p), v2);
+          for (int i = 0; i < N; ++i) v1[i] = (iJp[i] + v1[i]) + v2[i];
+          gemv(N, T21, v1, v3);
+          gemv(N, c->pm + NN * n0, a->Jm + (size_t)N * n0, v1);
+          for (int i = 0; i < N; ++i) v1[i] = c->Jp[(size_t)N * n0 + i] + v1[i];
+          gemv(N, M3, v1, v4);
+          for (int i = 0; i < N; ++i) iJp[i] = (AIEV(ieJp, p)[i] + v3[i]) + v4[i];
+        }
+#pragma omp for schedule(static)
+      for (int s = 0; s < S; ++s) { /* :315 */
+        gemv(N, c->pm + NN * s, a->Jm + (size_t)N * s, v1);
+        for (int i = 0; i < N; ++i) v1[i] = c->Jp[(size_t)N * s + i] + v1[i];
+        gemv(N, T1 + NN * s, v1, v2);
+        for (int i = 0; i < N; ++i) c->Jp[(size_t)N * s + i] = a->Jp[(size_t)N * s + i] + v2[i];
+      }
+#pragma omp for schedule(dynamic, 8) collapse(2)
+      for (int dn = 0; dn < nR; ++dn) /* :317-335 */
+        for (int n1 = lo; n1 < lo + W; ++n1) {
+          const int n0 = n1 + rs->off[dn];
+          if (n0 < 0 || n0 >= S) continue;
+          const size_t p = PAIR(dn, n1);
+          const double *r0 = a->mp + NN * n0, *T21 = T1 + NN * n1;
+          gemm(N, c->ie_pm + NN * p, r0, M1); gemm(N, c->pm + NN * n1, AIE(ie_mp, p), M2); madd(NN, M1, M2, M3);
+          gemm(N, T21, M3, M1); madd(NN, M1, AIE(ie_pp, p), M2);           /* B */
+          gemm(N, M2, tinv + NN * n0, M3);                                  /* B tmp_inv[n0] */
+          gemm(N, T21, c->ie_pp + NN * p, M1); gemm(N, M3, c->pp + NN * n0, M2);
+          madd(NN, M1, M2, c->ie_pp + NN * p);
+          gemm(N, c->ie_pm + NN * p, a->mm + NN * n0, M1); gemm(N, c->pm + NN * n1, AIE(ie_mm, p), M2); madd(NN, M1, M2, M4);
+          gemm(N, T21, M4, M1);
+          gemm(N, M3, c->pm + NN * n0, M2); gemm(N, M2, a->mm + NN * n0, M4);
+          double *ieR = c->ie_pm + NN * p;
+          const double *aie = AIE(ie_pm, p);
+          for (size_t x = 0; x < NN; ++x) ieR[x] = (aie[x] + M1[x]) + M4[x];
+        }
+#pragma omp for schedule(static)
+      for (int s = 0; s < S; ++s) { /* :338, :340 */
+        gemm(N, T1 + NN * s, c->pp + NN * s, M1); memcpy(c->pp + NN * s, M1, NN * sizeof(double));
+        gemm(N, T1 + NN * s, c->pm + NN * s, M1); gemm(N, M1, a->mm + NN * s, M2);
+        madd(NN, a->pm + NN * s, M2, c->pm + NN * s);
+      }
+    }
+    free(w); free(piv);
+  }
+#undef AIE
+#undef AIEV
+  return info;
+}
+
+/* doubling_helper!(::RRS) doubling_inelastic.jl:13-134 on the whole added layer, then apply_D_matrix! (doubling.jl:120-134),
+ * apply_D_matrix_IE!(::RRS) (:410-425 -> apply_D_IE_RRS! :291-311, D2), apply_D_matrix_SFI! and apply_D_matrix_SFI_IE!
+ * (:441-451 -> apply_D_SFI_IE_RRS! :345-357, D3).  expk [S] is updated in place.
+ * wsE: (3*NN + 4*N + 1) * S doubles (gp_refl, tt++ gp_refl, (tt++ gp_refl) r-+, j1+, j1-, tmp1, tmp2, expk of the step's
+ * start per point). */
+static int rrs_doubling(const ora_scene *sc, const ora_rrs *rs, const ora_streams *q, int nd, double *expk, rrs_layer *a,
+                        double *wsE, int nthreads) {
+  const int N = sc->N, n = sc->nS, S = sc->S, nR = rs->nR, lo = rs->own_lo, W = rs->own_hi - rs->own_lo;
+  const int strict = rs->rrs_strict;
+  const size_t NN = (size_t)N * N;
+  int info = 0;
+  if (nd == 0) return 0;
+  double *gp = wsE, *ttgp = gp + NN * S, *ttgpr = ttgp + NN * S;
+  double *j1p = ttgpr + NN * S, *j1m = j1p + (size_t)N * S, *tmp1 = j1m + (size_t)N * S, *tmp2 = tmp1 + (size_t)N * S;
+  double *expk0 = tmp2 + (size_t)N * S;
+  double *r = a->mp, *t = a->pp, *jp = a->Jp, *jm = a->Jm;
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+  {
+    double *w = (double *)malloc(RRS_WORK(NN, N) * sizeof(double));
+    int *piv = (int *)malloc(N * sizeof(int));
+    double *M1 = w, *M2 = w + NN, *X = w + 2 * NN, *Y = w + 3 * NN, *Wm = w + 4 * NN, *G = w + 5 * NN, *M3 = w + 6 * NN,
+           *M4 = w + 7 * NN;
+    double *v1 = w + 10 * NN, *v2 = v1 + N, *v3 = v2 + N, *v4 = v3 + N, *e1p = v4 + N, *e1m = e1p + N, *v5 = e1m + N;
+    for (int it = 0; it < nd; ++it) {
+#pragma omp for schedule(static)
+      for (int s = 0; s < S; ++s) { /* :47-59 */
+        gemm(N, r + NN * s, r + NN * s, M1);
+        for (size_t x = 0; x < NN; ++x) M1[x] = -M1[x];
+        for (int i = 0; i < N; ++i) M1[IDX(i, i, N)] += 1.0;
+        int e = inv_lu(N, M1, gp + NN * s, piv);
+        if (e) {
+#pragma omp atomic write
+          info = e;
+        }
+        gemm(N, t + NN * s, gp + NN * s, ttgp + NN * s);
+        gemm(N, ttgp + NN * s, r + NN * s, ttgpr + NN * s);
+        expk0[s] = expk[s];
+        double *p1 = j1p + (size_t)N * s, *m1 = j1m + (size_t)N * s;
+        for (int i = 0; i < N; ++i) { p1[i] = jp[(size_t)N * s + i] * expk[s]; m1[i] = jm[(size_t)N * s + i] * expk[s]; }
+        gemv(N, r + NN * s, m1, v1);
+        for (int i = 0; i < N; ++i) v1[i] = jp[(size_t)N * s + i] + v1[i];
+        gemv(N, gp + NN * s, v1, tmp1 + (size_t)N * s);
+        gemv(N, r + NN * s, jp + (size_t)N * s, v1);
+        for (int i = 0; i < N; ++i) v1[i] = m1[i] + v1[i];
+        gemv(N, gp + NN * s, v1, tmp2 + (size_t)N * s);
+      }
+      for (int dn = 0; dn < nR; ++dn) { /* :61-96; ieJ1+- = ieJ0+- .* expk' of :52,:56 formed per pair */
+        if (abs(rs->off[dn]) < S) {
+#pragma omp for schedule(dynamic, 16)
+          for (int n1 = lo; n1 < lo + W; ++n1) {
+            const int n0 = n1 + rs->off[dn];
+            if (n0 < 0 || n0 >= S) continue;
+            const size_t p = PAIR(dn, n1);
+            const double *r1 = r + NN * n1, *r0 = r + NN * n0, *e = a->ie_mp + NN * p;
+            double *iJp = a->ieJp + (size_t)N * p, *iJm = a->ieJm + (size_t)N * p;
+            const double ek = expk0[n1]; /* ieJ1+- are formed ONCE per step (:52,:56), before D1 squares expk inside the loop */
+            for (int i = 0; i < N; ++i) { e1p[i] = iJp[i] * ek; e1m[i] = iJm[i] * ek; }
+            gemm(N, r1, e, M1); gemm(N, e, r0, M2); madd(NN, M1, M2, X);
+            gemv(N, r1, e1m, v1); gemv(N, e, j1m + (size_t)N * n0, v2); gemv(N, X, tmp1 + (size_t)N * n0, v3);
+            for (int i = 0; i < N; ++i) v1[i] = ((iJp[i] + v1[i]) + v2[i]) + v3[i];
+            gemv(N, ttgp + NN * n1, v1, v4);
+            gemv(N, a->ie_pp + NN * p, tmp1 + (size_t)N * n0, v5);
+            for (int i = 0; i < N; ++i) iJp[i] = (e1p[i] + v4[i]) + v5[i];
+            const double *itm = strict ? a->ie_mm + NN * p : a->ie_pp + NN * p; /* D5 */
+            gemv(N, e, jp + (size_t)N * n0, v1); gemv(N, r1, iJp, v2); gemv(N, X, tmp2 + (size_t)N * n0, v3);
+            for (int i = 0; i < N; ++i) v1[i] = ((e1m[i] + v1[i]) + v2[i]) + v3[i];
+            gemv(N, ttgp + NN * n1, v1, v4);
+            gemv(N, itm, tmp2 + (size_t)N * n0, v5);
+            for (int i = 0; i < N; ++i) iJm[i] = (iJm[i] + v4[i]) + v5[i];
+          }
+        }
+        if (strict) { /* D1: :90-95 inside the loop over dn */
+#pragma omp for schedule(static)
+          for (int s = 0; s < S; ++s) {
+            double *p0 = jp + (size_t)N * s, *m0 = jm + (size_t)N * s;
+            const double *p1 = j1p + (size_t)N * s, *m1 = j1m + (size_t)N * s;
+            gemv(N, r + NN * s, p0, v1);
+            for (int i = 0; i < N; ++i) v1[i] = m1[i] + v1[i];
+            gemv(N, ttgp + NN * s, v1, v2);
+            gemv(N, r + NN * s, m1, v1);
+            for (int i = 0; i < N; ++i) v1[i] = p0[i] + v1[i];
+            gemv(N, ttgp + NN * s, v1, v3);
+            for (int i = 0; i < N; ++i) { m0[i] = m0[i] + v2[i]; p0[i] = p1[i] + v3[i]; }
+            expk[s] = expk[s] * expk[s];
+          }
+        }
+      }
+      if (!strict) {
+#pragma omp for schedule(static)
+        for (int s = 0; s < S; ++s) {
+          double *p0 = jp + (size_t)N * s, *m0 = jm + (size_t)N * s;
+          const double *p1 = j1p + (size_t)N * s, *m1 = j1m + (size_t)N * s;
+          gemv(N, r + NN * s, p0, v1);
+          for (int i = 0; i < N; ++i) v1[i] = m1[i] + v1[i];
+          gemv(N, ttgp + NN * s, v1, v2);
+          gemv(N, r + NN * s, m1, v1);
+          for (int i = 0; i < N; ++i) v1[i] = p0[i] + v1[i];
+          gemv(N, ttgp + NN * s, v1, v3);
+          for (int i = 0; i < N; ++i) { m0[i] = m0[i] + v2[i]; p0[i] = p1[i] + v3[i]; }
+          expk[s] = expk[s] * expk[s];
+        }
+      }
+#pragma omp for schedule(dynamic, 8) collapse(2)
+      for (int dn = 0; dn < nR; ++dn) /* :98-125 */
+        for (int n1 = lo; n1 < lo + W; ++n1) {
+          const int n0 = n1 + rs->off[dn];
+          if (n0 < 0 || n0 >= S) continue;
+          const size_t p = PAIR(dn, n1);
+          const double *r1 = r + NN * n1, *r0 = r + NN * n0, *tg1 = ttgp + NN * n1;
+          double *e = a->ie_mp + NN * p, *et = a->ie_pp + NN * p;
+          gemm(N, e, r0, M1); gemm(N, r1, e, M2); madd(NN, M1, M2, X);
+          gemm(N, X, gp + NN * n0, M1); gemm(N, M1, t + NN * n0, Y);
+          madd(NN, et, Y, Wm);
+          gemm(N, et, gp + NN * n0, G);
+          gemm(N, tg1, Wm, M1); gemm(N, G, t + NN * n0, M2);
+          madd(NN, M1, M2, et);                                            /* new iet++ */
+          madd(NN, et, Y, Wm);
+          gemm(N, ttgpr + NN * n1, Wm, M1);                                /* (tt++ gp r-+)[n1] (iet++ + Y) */
+          gemm(N, et, gp + NN * n0, G); gemm(N, G, r0, M2); gemm(N, tg1, e, M3); madd(NN, M2, M3, M4);
+          gemm(N, M4, t + NN * n0, M2);
+          for (size_t x = 0; x < NN; ++x) e[x] = (e[x] + M1[x]) + M2[x];
+        }
+#pragma omp for schedule(static)
+      for (int s = 0; s < S; ++s) { /* :128, :131 */
+        gemm(N, ttgpr + NN * s, t + NN * s, M1);
+        double *rs_ = r + NN * s;
+        for (size_t x = 0; x < NN; ++x) rs_[x] = rs_[x] + M1[x];
+        gemm(N, ttgp + NN * s, t + NN * s, M1);
+        memcpy(t + NN * s, M1, NN * sizeof(double));
+      }
+    }
+    free(w); free(piv);
+  }
+  /* D back-transformations */
+  const size_t P = (size_t)W * nR;
+  if (n == 1) {
+    memcpy(a->pm, r, NN * S * sizeof(double)); memcpy(a->mm, t, NN * S * sizeof(double));
+    memcpy(a->ie_pm, a->ie_mp, NN * P * sizeof(double)); memcpy(a->ie_mm, a->ie_pp, NN * P * sizeof(double));
+    return info;
+  }
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+  for (int s = 0; s < S; ++s) {
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < N; ++i) {
+        const int ci = scomp(i, n, q->strict), cj = scomp(j, n, q->strict);
+        const size_t o = NN * s + IDX(i, j, N);
+        if (ci > 2) r[o] = -r[o];
+        const double sg = dsign(ci, cj);
+        a->pm[o] = sg * r[o];
+        a->mm[o] = sg * t[o];
+      }
+    for (int i = 0; i < N; ++i)
+      if (scomp(i, n, q->strict) > 2) jm[(size_t)N * s + i] = -jm[(size_t)N * s + i];
+  }
+  if (!strict) {
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (size_t p = 0; p < P; ++p) {
+      for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i) {
+          const int ci = scomp(i, n, q->strict), cj = scomp(j, n, q->strict);
+          const size_t o = NN * p + IDX(i, j, N);
+          if (ci > 2) a->ie_mp[o] = -a->ie_mp[o];
+          const double sg = dsign(ci, cj);
+          a->ie_pm[o] = sg * a->ie_mp[o];
+          a->ie_mm[o] = sg * a->ie_pp[o];
+        }
+      for (int i = 0; i < N; ++i)
+        if (scomp(i, n, q->strict) > 2) a->ieJm[(size_t)N * p + i] = -a->ieJm[(size_t)N * p + i];
+    }
+    return info;
+  }
+  /* strict: work item (n, dn) touches the element [.., n, kk] with kk = n + off[dn] taken as a RAMAN index (D2, D3);
+   * single-thread column-major order, dn slowest */
+  for (int dn = 0; dn < nR; ++dn)
+    for (int n1 = lo; n1 < lo + W; ++n1) {
+      const long kk = (long)n1 + rs->off[dn];
+      if (kk < 0 || kk >= nR) continue;
+      const size_t p = PAIR(kk, n1);
+      for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i) {
+          const int ci = scomp(i, n, q->strict), cj = scomp(j, n, q->strict);
+          const size_t o = NN * p + IDX(i, j, N);
+          if (ci > 2) a->ie_mp[o] = -a->ie_mp[o];
+          const double sg = dsign(ci, cj);
+          a->ie_pm[o] = sg * a->ie_mp[o];
+          a->ie_mm[o] = sg * a->ie_pp[o];
+        }
+    }
+  for (int dn = 0; dn < nR; ++dn)
+    for (int n1 = lo; n1 < lo + W; ++n1) {
+      const long kk = (long)n1 + rs->off[dn];
+      if (kk < 0 || kk >= nR) continue;
+      const size_t p = PAIR(kk, n1), ps = PAIR(dn, n1);
+      for (int i = 0; i < N; ++i)
+        if (scomp(i, n, q->strict) > 2) a->ieJm[(size_t)N * p + i] = -a->ieJm[(size_t)N * ps + i];
+    }
+  return info;
+}
+
+/* rt_run(RS_type::RRS, model, iBand) rt_run.jl:41-230 with SFI = true.  R_SFI, T_SFI, ieR_SFI, ieT_SFI: [nVza,nStokes,S]
+ * column-major, zero-initialised by the caller; the inelastic spectra are produced for the owned points only.
+ * The added, composite and surface layers persist over layers and Fourier moments like the reference's (rt_run.jl:108-116).
+ * Returns 0, an LU info > 0, -1 (allocation), -2 (an offset with |off| >= S: get_n0_n1 raises a BoundsError,
+ * inelastic_helper.jl:13-21), -3 (a 00 / 01 / 10 interface in the strict position: MethodError in the reference, D4). */
+int ora_rt_run_rrs(const ora_scene *sc, const ora_rrs *rs, int nthreads, double *R_SFI, double *T_SFI, double *ieR_SFI,
+                   double *ieT_SFI) {
+  const int N = sc->N, n = sc->nS, S = sc->S, Nz = sc->Nz, K = sc->K, M = sc->M, nR = rs->nR;
+  const int lo = rs->own_lo, W = rs->own_hi - rs->own_lo;
+  const size_t NN = (size_t)N * N, P = (size_t)W * nR;
+  if (nthreads <= 0) nthreads = 1;
+  if (lo < 0 || rs->own_hi > S || W <= 0) return -1;
+  for (int dn = 0; dn < nR; ++dn)
+    if (abs(rs->off[dn]) >= S) return -2;
+  ora_streams q = {N, n, sc->imu0, sc->mu, sc->wt, sc->I0, sc->D, sc->strict, sc->mu0};
+  rrs_layer added, comp, surf;
+  int ok = rrs_layer_alloc(&added, NN, N, S, P, 1);
+  ok = rrs_layer_alloc(&comp, NN, N, S, P, 1) && ok;
+  ok = rrs_layer_alloc(&surf, NN, N, S, P, 0) && ok;
+  double *wsE = (double *)malloc(((3 * NN + 4 * (size_t)N + 1) * S) * sizeof(double));
+  double *expk = (double *)malloc((size_t)S * sizeof(double)), *dtau = (double *)malloc((size_t)S * sizeof(double));
+  double *zeroM = (double *)calloc(NN, sizeof(double));
+  int info = 0;
+  if (!(ok && wsE && expk && dtau && zeroM)) { info = -1; goto done; }
+  for (int m = 0; m < M && info >= 0; ++m) {
+    const double weight = (m == 0) ? 0.5 : 1.0;
+    const double *ZRp = rs->ZRpp + NN * m, *ZRm = rs->ZRmp + NN * m;
+    for (int z = 0; z < Nz && info >= 0; ++z) {
+      const int nd = sc->nd[z];
+      const double *tau = sc->tau + (size_t)S * z, *varpi = sc->varpi + (size_t)S * z, *fs = rs->fscatt + (size_t)S * z;
+      const double *tsum = sc->tau_sum + (size_t)S * z;
+      for (int s = 0; s < S; ++s) { dtau[s] = tau[s] / ldexp(1.0, nd); expk[s] = exp(-dtau[s] / sc->mu0); } /* rt_kernel.jl:269-275 */
+      /* elemental_inelastic!(::RRS) elemental_inelastic.jl:23-91 on the persistent added layer */
+#pragma omp parallel num_threads(nthreads)
+      {
+        double *Zp = (double *)malloc(2 * NN * sizeof(double)), *Zm = Zp + NN;
+#pragma omp for schedule(dynamic, 8) collapse(2)
+        for (int dn = 0; dn < nR; ++dn)
+          for (int n1 = lo; n1 < lo + W; ++n1) {
+            const int n0 = n1 + rs->off[dn];
+            const size_t p = PAIR(dn, n1);
+            double *ier = added.ie_mp + NN * p, *iet = added.ie_pp + NN * p;
+            double *iJp = added.ieJp + (size_t)N * p, *iJm = added.ieJm + (size_t)N * p;
+            if (n0 < 0 || n0 >= S) { /* get_elem_rt_RRS! zeroes the operators (:153-160); the SFI kernel leaves the sources (:345) */
+              for (size_t x = 0; x < NN; ++x) { ier[x] = 0.0; iet[x] = 0.0; }
+            } else
+              rrs_elemental_pair(&q, m, rs->wR[dn], varpi[n0], fs[n0], dtau[n1], dtau[n0], tsum[n0], ZRp, ZRm, ier, iet, iJp, iJm);
+            if (nd >= 1) /* :378-380: every entry, on the grid or not */
+              for (int i = 0; i < N; ++i) iJm[i] = sc->D[i % n] * iJm[i];
+            /* apply_D_elemental_RRS! :384-402 */
+            if (nd < 1) {
+              for (int j = 0; j < N; ++j)
+                for (int i = 0; i < N; ++i) {
+                  const double sg = dsign(scomp(i, n, q.strict), scomp(j, n, q.strict));
+                  added.ie_pm[NN * p + IDX(i, j, N)] = sg * ier[IDX(i, j, N)];
+                  added.ie_mm[NN * p + IDX(i, j, N)] = sg * iet[IDX(i, j, N)];
+                }
+            } else {
+              for (int j = 0; j < N; ++j)
+                for (int i = 0; i < N; ++i)
+                  if (scomp(i, n, q.strict) > 2) ier[IDX(i, j, N)] = -ier[IDX(i, j, N)];
+            }
+          }
+        /* elemental! (elastic) on the same added layer */
+#pragma omp for schedule(static)
+        for (int s = 0; s < S; ++s) {
+          for (size_t x = 0; x < NN; ++x) { Zp[x] = 0; Zm[x] = 0; }
+          for (int k = 0; k < K; ++k) {
+            const double w = sc->zw[k + (size_t)K * (s + (size_t)S * z)];
+            const double *bp = sc->Zpp + NN * (k + (size_t)K * m), *bm = sc->Zmp + NN * (k + (size_t)K * m);
+            for (size_t x = 0; x < NN; ++x) { Zp[x] += w * bp[x]; Zm[x] += w * bm[x]; }
+          }
+          elemental_pt(&q, m, nd, tsum[s], dtau[s], varpi[s], Zp, Zm, added.mp + NN * s, added.pp + NN * s, added.pm + NN * s,
+                       added.mm + NN * s, added.Jp + (size_t)N * s, added.Jm + (size_t)N * s);
+        }
+        free(Zp);
+      }
+      int e = rrs_doubling(sc, rs, &q, nd, expk, &added, wsE, nthreads);
+      if (e && !info) info = e;
+      if (z == 0) { /* rt_kernel.jl:326-333 */
+        memcpy(comp.pp, added.pp, NN * S * sizeof(double)); memcpy(comp.mm, added.mm, NN * S * sizeof(double));
+        memcpy(comp.mp, added.mp, NN * S * sizeof(double)); memcpy(comp.pm, added.pm, NN * S * sizeof(double));
+        memcpy(comp.Jp, added.Jp, (size_t)N * S * sizeof(double)); memcpy(comp.Jm, added.Jm, (size_t)N * S * sizeof(double));
+        memcpy(comp.ie_pp, added.ie_pp, NN * P * sizeof(double)); memcpy(comp.ie_mm, added.ie_mm, NN * P * sizeof(double));
+        memcpy(comp.ie_mp, added.ie_mp, NN * P * sizeof(double)); memcpy(comp.ie_pm, added.ie_pm, NN * P * sizeof(double));
+        memcpy(comp.ieJp, added.ieJp, (size_t)N * P * sizeof(double)); memcpy(comp.ieJm, added.ieJm, (size_t)N * P * sizeof(double));
+      } else {
+        e = rrs_interaction(sc, rs, sc->iface[z], &comp, &added, wsE, zeroM, nthreads);
+        if (e < 0) info = e; else if (e && !info) info = e;
+      }
+    }
+    if (info < 0) break;
+    /* surface (rt_run.jl:169-185): its inelastic arrays are never written (zeros) */
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int s = 0; s < S; ++s) {
+      double *s_rpm = surf.pm + NN * s, *s_rmp = surf.mp + NN * s, *s_tmm = surf.mm + NN * s, *s_tpp = surf.pp + NN * s;
+      double *s_jp = surf.Jp + (size_t)N * s, *s_jm = surf.Jm + (size_t)N * s;
+      const double tt = sc->tau_sum[s + (size_t)S * Nz];
+      if (sc->surf_kind == 1) surface_brdf_pt(&q, sc->Rsurf + NN * m, tt, s_rpm, s_rmp, s_tmm, s_tpp, s_jp, s_jm);
+      else if (sc->surf_kind == 2) surface_legendre_pt(&q, m, sc->albedo_spec[s], tt, s_rpm, s_rmp, s_tmm, s_tpp, s_jp, s_jm);
+      else surface_lambertian_pt(&q, m, sc->albedo, tt, s_rpm, s_rmp, s_tmm, s_tpp, s_jp, s_jm);
+    }
+    int e = rrs_interaction(sc, rs, sc->iface[Nz - 1], &comp, &surf, wsE, zeroM, nthreads);
+    if (e < 0) { info = e; break; } else if (e && !info) info = e;
+    /* postprocessing_vza!(::RRS) tools/postprocessing_vza.jl:95-147 (SFI branch): the sum runs over EVERY Raman index */
+    for (int s = 0; s < S; ++s)
+      for (int v = 0; v < sc->nVza; ++v) {
+        const int istart = (sc->node[v] - 1) * n;
+        const double c = sc->cos_mphi[v + (size_t)sc->nVza * m], sn = sc->sin_mphi[v + (size_t)sc->nVza * m];
+        for (int k = 0; k < n; ++k) {
+          const double cs = weight * ((k < 2) ? c : sn);
+          const size_t o = v + (size_t)sc->nVza * (k + (size_t)n * s);
+          R_SFI[o] += cs * comp.Jm[(size_t)N * s + istart + k];
+          T_SFI[o] += cs * comp.Jp[(size_t)N * s + istart + k];
+          if (s >= lo && s < lo + W)
+            for (int dn = 0; dn < nR; ++dn) {
+              const size_t p = PAIR(dn, s);
+              ieR_SFI[o] += cs * comp.ieJm[(size_t)N * p + istart + k];
+              ieT_SFI[o] += cs * comp.ieJp[(size_t)N * p + istart + k];
+            }
+        }
+      }
+  }
+done:
+  rrs_layer_free(&added); rrs_layer_free(&comp); rrs_layer_free(&surf);
+  free(wsE); free(expk); free(dtau); free(zeroM);
+  return info;
+}
+#undef PAIR

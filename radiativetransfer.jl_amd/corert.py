@@ -831,16 +831,17 @@ class RRS:
     getRamanSSProp! (src/CoreRT/tools/raman_atmo_prop.jl:57-73) from the N2/O2 molecular constants, which stays host-side
     set-up (out of scope, like the Mie code); synthetic line lists for benchmarks: scenes.raman_lines.
 
-    rrs_strict_reference: the reference's RRS text executed as written (True) or with the five documented corrections
-    D1..D5 (False, the default: every published number of this repository uses it) -- DESIGN.md section 7,
-    include/momcore.h mom_rrs_set.  As written the path is barely usable: any scene with a 00 / 01 / 10 interface raises
-    (D4: MethodError in the reference -> MOM_EUNSUPPORTED here) and with realistic line counts expk underflows in the first
-    doubling step (D1: expk -> expk^(2^nRaman)); True exists for line-by-line comparison with the reference's text."""
+    rrs_strict_reference: the reference's RRS text executed as written (True: the default here and in the Julia shim
+    integration/MomCoreRT.jl -- a drop-in reproduces the reference) or with the five documented corrections D1..D5 (False:
+    what scenes.scene_C5 and therefore every C5 benchmark number of this repository selects EXPLICITLY, and says so) --
+    DESIGN.md section 7, include/momcore.h mom_rrs_set.  As written the path is barely usable: any scene with a 00 / 01 / 10
+    interface raises (D4: MethodError in the reference -> MOM_EUNSUPPORTED here) and with realistic line counts expk underflows
+    in the first doubling step (D1: expk -> expk^(2^nRaman))."""
     greek_raman: GreekCoefs
     ϖ_Cabannes: float          # elastic (Cabannes) fraction of Rayleigh scattering: the Rayleigh ϖ of the elastic layer optics
     ϖ_λ1λ0: np.ndarray         # [nRaman]
     i_λ1λ0: np.ndarray         # [nRaman] grid offsets n₀ - n₁
-    rrs_strict_reference: bool = False
+    rrs_strict_reference: bool = True
 
     @property
     def n_Raman(self):
@@ -873,7 +874,7 @@ def rt_run_rrs(RS_type: RRS, model: vSmartMOM_Model, i_band: int = 1):
         (R_SFI, T_SFI, ieR_SFI, ieT_SFI, hdr, bhr_uw[1,:], bhr_dw[1,:])
     R/T/ieR/ieT/hdr are [nVza, nStokes, nSpec]; every surface type of `params.brdf`.  With RS_type.rrs_strict_reference =
     True the run raises MomError (MOM_EUNSUPPORTED) for scenes with a 00 / 01 / 10 scattering interface, as the reference's
-    text does (D4); the default (False) runs them."""
+    text does (D4); False runs them."""
     S = model.τ_rayl.shape[0]
     return rt_run_rrs_window(RS_type, model, 0, S)
 

@@ -275,31 +275,60 @@ def _c5_line_subsets(RS):
     return A, B
 
 
-def test_config_C5_rotational_raman(rtamd):
-    """configs[4] at FULL size on the GPU: S = 6 837, N = 15, 5 layers, all 178 Raman offsets (|Δn| up to 5 014 grid points;
-    804 233 valid (n₁, Δn) pairs), corrected switch position.
+# owned windows of the C5 oracle comparisons: both grid edges (where the source index of half the lines runs off the grid),
+# the middle, and the two stretches where the extreme offsets (+5014 / -4696) enter and leave the grid: 1 150 points
+C5_WINDOWS = ((0, 300), (1_700, 1_850), (3_300, 3_550), (4_700, 4_850), (6_537, 6_837))
 
-      (1) the run with the 24 offsets of subset A (incl. both extreme offsets) against the oracle (oracle/rrsref.py) on an
-          two owned windows of 150 points chosen so that each extreme offset has its source index on the grid in one of
-          them and runs off it inside the other: 1e-10 of the elastic intensity / 1e-9 of the inelastic maximum -- the index arithmetic at
-          the full range of offsets;
+
+def _c5_compare(cref, scene, p, offs, w, g, strict, got, windows, what):
+    """GPU 4-tuple (R, T, ieR, ieT) against the C oracle (oracle/momref.c ora_rt_run_rrs, ALL lines) on owned windows:
+    elastic spectra 1e-10 of I; inelastic spectra 1e-10 of the elastic intensity of the same view and point, and 1e-9 of the
+    largest inelastic value."""
+    from oracle import rrsref as rr
+    n = 0
+    for lo, hi in windows:
+        ora = rr.RRSInputs(offs.astype(np.int64), w, g, rrs_strict_reference=strict, owned=(lo, hi))
+        Rr, Tr, ieRr, ieTr, info = cref.rt_run_rrs(scene, ora, p=p)
+        assert info == 0
+        own = slice(lo, hi)
+        helpers.assert_stokes_close(got[0][..., own], Rr[..., own], what=f"{what} R [{lo},{hi})")
+        helpers.assert_stokes_close(got[1][..., own], Tr[..., own], what=f"{what} T [{lo},{hi})")
+        assert np.abs(ieRr[..., own]).max() > 0
+        for x, ref, el in ((got[2], ieRr, Rr), (got[3], ieTr, Tr)):
+            scale = np.abs(el[:, 0:1, own])
+            d = np.abs(x[..., own] - ref[..., own])
+            assert np.all(d <= 1e-10 * scale + 1e-14), (what, lo, hi, d.max())
+            helpers.assert_op_close(x[..., own], ref[..., own], 1e-9, f"{what} ie spectra [{lo},{hi})")
+        n += hi - lo
+    return n
+
+
+def test_config_C5_rotational_raman(rtamd, cref):
+    """configs[4] at FULL size on the GPU: S = 6 837, N = 15, 5 layers, all 178 Raman offsets (|Δn| up to 5 014 grid points;
+    804 233 valid (n₁, Δn) pairs).
+
+      (1) the full run -- ALL 178 lines -- against the C oracle (oracle/momref.c ora_rt_run_rrs, the C port of oracle/rrsref.py)
+          on 1 150 owned points in five windows incl. both grid edges, corrected switch position (DESIGN section 7);
+      (1s) the STRICT position (the reference's text as written, defects D1..D5 included) at full size: finite, and equal to
+          the C oracle's strict run on 450 owned points in three windows;
       (2) linearity in the line list (each Δn evolves independently of the others in every operator of the path,
           doubling_inelastic.jl:61-125, interaction_inelastic.jl:249-335): ie spectra of the 178-line run = A-run + B-run,
-          and the elastic spectra of all three runs are bitwise equal -- ties the full run to (1);
+          and the elastic spectra of all three runs are bitwise equal;
       (3) elastic limit at full size: zero Raman weights give zero inelastic spectra and the elastic spectra of (2), and the
           elastic spectra equal rt_run(::noRS) with the Cabannes albedo to 1e-10;
       (4) the 2-way spectral split (window = owned + halo of 5 014) reproduces the full run bit for bit."""
-    from oracle import momref as mr, rrsref as rr
+    from oracle import momref as mr
     rt = rtamd.corert
     m, RS = rtamd.scenes.scene_C5()
     S, nR = m.τ_rayl.shape[0], RS.n_Raman
     offs, w = np.asarray(RS.i_λ1λ0), np.asarray(RS.ϖ_λ1λ0)
-    assert (S, nR) == (6_837, 178) and rtamd.prepare_scene(m).N == 15 and not RS.rrs_strict_reference
+    assert (S, nR) == (6_837, 178) and rtamd.prepare_scene(m).N == 15
     assert np.abs(offs).max() == 5_014 and offs.min() == -4_696
-    sub = lambda k: rt.RRS(greek_raman=RS.greek_raman, ϖ_Cabannes=RS.ϖ_Cabannes, ϖ_λ1λ0=w[k], i_λ1λ0=offs[k],
-                           rrs_strict_reference=False)
+    sub = lambda k, strict=False: rt.RRS(greek_raman=RS.greek_raman, ϖ_Cabannes=RS.ϖ_Cabannes, ϖ_λ1λ0=w[k], i_λ1λ0=offs[k],
+                                         rrs_strict_reference=strict)
+    allk = np.arange(nR)
     A, B = _c5_line_subsets(RS)
-    full = rt.rt_run_rrs(RS, m)
+    full = rt.rt_run_rrs(sub(allk), m)
     gA = rt.rt_run_rrs(sub(A), m)
     gB = rt.rt_run_rrs(sub(B), m)
     for x in full:
@@ -310,22 +339,18 @@ def test_config_C5_rotational_raman(rtamd):
         assert np.array_equal(full[k], gA[k]) and np.array_equal(full[k], gB[k]), k
     for k in (2, 3):
         helpers.assert_op_close(gA[k] + gB[k], full[k], 1e-12, f"C5 linearity [{k}]")
-    # (1) oracle windows (2 x 150 owned points).  n0 = n1 + off must stay in [0, S): in [1700, 1850) the offset +5014 runs
-    # off the grid from n1 = 1823 on and -4696 is off it throughout; in [4700, 4850) -4696 is on the grid, +5014 is not.
+    # (1) the C oracle, all 178 lines
     scene = helpers.oracle_scene(m)
     scene.varpi_cabannes = RS.ϖ_Cabannes
     g = mr.get_greek_rayleigh(0.75)
-    for lo, hi in ((1_700, 1_850), (4_700, 4_850)):
-        ora = rr.RRSInputs(offs[A].astype(np.int64), w[A], g, rrs_strict_reference=False, owned=(lo, hi))
-        Rr, Tr, ieRr, ieTr = rr.rt_run_rrs(scene, ora)
-        own = slice(lo, hi)
-        helpers.assert_stokes_close(gA[0][..., own], Rr[..., own], what="C5 R")
-        helpers.assert_stokes_close(gA[1][..., own], Tr[..., own], what="C5 T")
-        assert np.abs(ieRr[..., own]).max() > 0
-        for got, ref, el in ((gA[2], ieRr, Rr), (gA[3], ieTr, Tr)):
-            scale = np.abs(el[:, 0:1, own])
-            assert np.all(np.abs(got[..., own] - ref[..., own]) <= 1e-10 * scale + 1e-14), np.abs(got[..., own] - ref[..., own]).max()
-            helpers.assert_op_close(got[..., own], ref[..., own], 1e-9, "C5 ie spectra")
+    p = cref.pack_scene(scene)
+    assert _c5_compare(cref, scene, p, offs, w, g, False, full, C5_WINDOWS, "C5") >= 1_000
+    # (1s) the strict position at full size (all interfaces of this scene are 11, so D4 does not raise)
+    strict = rt.rt_run_rrs(sub(allk, True), m)
+    for x in strict[:4]:
+        assert np.all(np.isfinite(x))
+    assert not np.allclose(strict[0], full[0], rtol=1e-6)                   # D1 advances the elastic sources nRaman times per step
+    _c5_compare(cref, scene, p, offs, w, g, True, strict, ((0, 150), (3_300, 3_450), (6_687, 6_837)), "C5 strict")
     # (3) elastic limit
     zero = rt.RRS(greek_raman=RS.greek_raman, ϖ_Cabannes=RS.ϖ_Cabannes, ϖ_λ1λ0=np.zeros(nR), i_λ1λ0=offs, rrs_strict_reference=False)
     g0 = rt.rt_run_rrs(zero, m)
@@ -338,6 +363,6 @@ def test_config_C5_rotational_raman(rtamd):
     parts = []
     for rank in range(2):
         lo, hi, wlo, whi = rtamd.sharding.rrs_window(S, 2, rank, offs)
-        parts.append(rt.rt_run_rrs_window(RS, m, lo, hi, (wlo, whi)))
+        parts.append(rt.rt_run_rrs_window(sub(allk), m, lo, hi, (wlo, whi)))
     for k in range(7):
-        assert np.array_equal(np.concatenate([p[k] for p in parts], axis=-1), full[k]), k
+        assert np.array_equal(np.concatenate([p_[k] for p_ in parts], axis=-1), full[k]), k

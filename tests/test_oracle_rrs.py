@@ -194,3 +194,69 @@ def test_strict_and_corrected_positions(rtamd, nS):
     assert not np.allclose(Rs, R0, rtol=1e-6)                     # strict: D1 advances the elastic sources nRaman times
     assert np.isfinite(ieRs).all() and np.isfinite(ieRc).all()
     assert np.abs(ieRc).max() > 0 and np.abs(ieRs).max() > 0
+
+
+# ---- the C port of this path (oracle/momref.c ora_rt_run_rrs) against the numpy twin -------------------------------------
+
+def _cmp4(got, ref, own=slice(None), tol=1e-11):   # the bar of the elastic C-vs-numpy twin tests (LU + FMA rounding x 2^nd)
+    for k in range(4):
+        g, r = got[k][..., own], ref[k][..., own]
+        scale = max(float(np.abs(ref[k]).max()), 1e-300)
+        assert np.abs(g - r).max() <= tol * scale, (k, np.abs(g - r).max() / scale)
+
+
+@pytest.mark.parametrize("nS,S,Nz,aer,offs", [(1, 9, 3, False, [-2, 1, 3]), (3, 8, 3, True, [-2, 1, 3]), (4, 8, 2, True, [-5, 0, 2, 7]),
+                                               (3, 14, 4, True, [-13, -1, 4, 13])])
+@pytest.mark.parametrize("strict", [False, True])
+def test_c_port_equals_numpy_twin(rtamd, cref, nS, S, Nz, aer, offs, strict):
+    """Whole runs, both switch positions, IQ(U)(V) and scalar, offsets up to S - 1 (a single on-grid pair), zero offset, several
+    layers (persistent added layer: D5 reads the previous layer's iet--; stale off-grid ieJ0 entries; D2 / D3 cross-indexing)."""
+    scene = small_scene(rtamd, nS=nS, S=S, Nz=Nz, aerosol=aer, seed=7 + nS)
+    scene.varpi_cabannes = 0.96
+    rrs = _rrs_for(scene, offs, strict=strict)
+    ref = rr.rt_run_rrs(scene, rrs)
+    got = cref.rt_run_rrs(scene, rrs)
+    assert got[4] == 0
+    assert np.abs(ref[2]).max() > 0
+    _cmp4(got, ref)
+    for lo, hi in ((0, 3), (2, S - 1), (S - 2, S)):                        # owned windows: the owned entries of the full run
+        rrs_w = _rrs_for(scene, offs, strict=strict)
+        rrs_w.owned = (lo, hi)
+        w = cref.rt_run_rrs(scene, rrs_w)
+        _cmp4(w, ref, own=slice(lo, hi))
+        assert not np.any(w[2][..., :lo]) and not np.any(w[2][..., hi:])
+
+
+def test_c_port_other_interfaces_and_zero_doublings(rtamd, cref):
+    """Layers without scattering at the top (interfaces 00 / 01 / 10 of the corrected position, D4) and nd = 0 layers
+    (apply_D_elemental_RRS!'s ndoubl < 1 branch); the strict position raises like the twin."""
+    m = rtamd.scenes.make_scene(3, 5, 5, 10, seed=3, aerosol_total=0.0)
+    for z in (0, 1, 3):
+        m.τ_rayl[:, z] = 0.0
+    m.τ_rayl[:, 2] *= 1e-4                                                  # below the doubling threshold: nd = 0
+    scene = helpers.oracle_scene(m)
+    scene.varpi_cabannes = 0.95
+    p = cref.pack_scene(scene)
+    assert set(p.iface.tolist()) >= {0, 1, 2, 3} or len(set(p.iface.tolist())) >= 3, p.iface
+    assert 0 in p.nd.tolist()
+    rrs = _rrs_for(scene, [-3, 0, 2], strict=False)
+    ref = rr.rt_run_rrs(scene, rrs)
+    got = cref.rt_run_rrs(scene, rrs, p=p)
+    _cmp4(got, ref)
+    with pytest.raises(rr.ReferenceRaises):
+        rr.rt_run_rrs(scene, _rrs_for(scene, [-3, 0, 2], strict=True))
+    with pytest.raises(cref.ReferenceRaises):
+        cref.rt_run_rrs(scene, _rrs_for(scene, [-3, 0, 2], strict=True), p=p)
+    with pytest.raises(cref.ReferenceRaises):                              # |offset| >= S: get_n0_n1's BoundsError
+        cref.rt_run_rrs(scene, _rrs_for(scene, [10], strict=False), p=p)
+
+
+def test_c_port_surfaces(rtamd, cref):
+    rt = rtamd.corert
+    for brdf in (rt.rpvSurfaceScalar(0.1, 0.8, 0.7, -0.1), rt.LambertianSurfaceLegendre((0.2, 0.05, -0.02))):
+        m = rtamd.scenes.make_scene(3, 3, 3, 7, seed=2)
+        m.params.brdf = brdf
+        scene = helpers.oracle_scene(m)
+        scene.varpi_cabannes = 0.96
+        rrs = _rrs_for(scene, [-1, 2], strict=False)
+        _cmp4(cref.rt_run_rrs(scene, rrs), rr.rt_run_rrs(scene, rrs))
