@@ -424,12 +424,13 @@ int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
  *   MOM_OPT_STRIP_PAD     1 (default) = an operator edge N (or the m = 0 sub-problem's) without a strip-chained kernel
  *                         image is padded with up to 4 decoupled dummy stream entries (mu = 1, weight 0, zero
  *                         phase-matrix rows and columns) when that reaches a size with one (36, 40, 44, 52, 56, 60);
- *                         results for the real streams are unchanged; 0 = run the edge as given *   MOM_OPT_LEAN          operators of edge 36 / 40 (Float64, layer-sweep mode, ScatteringInterface_11 after the first layer):
+ *                         results for the real streams are unchanged; 0 = run the edge as given
+ *   MOM_OPT_LEAN          operators of edge 36 / 40 (Float64, layer-sweep mode, ScatteringInterface_11 after the first layer):
  *                         1 (default) = the four-wave LEAN strip image (three operator buffers, 168 registers: three workgroups per
  *                         CU; bitwise the full image's strip path), 2 = the six-wave lean image (doubling chains on half-strips, two
  *                         workgroups per CU, three chain waves on every SIMD: an experiment, measured slower), each followed by one
- *                         launch of the full image that finishes the units the lean one left (series beyond 12 terms); 0 = the full
- *                         image only.
+ *                         launch of the full image that finishes the units the lean one left (series beyond 12 terms) -- TWO launches
+ *                         per sweep, both counted in mom_timers' kernel_launches; 0 = the full image only.
  */
 int mom_set_option(mom_t *h, int option, int value);
 enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1, MOM_OPT_M0_REDUCTION = 2, MOM_OPT_SMALL_WG = 3, MOM_OPT_STAGGER = 4,

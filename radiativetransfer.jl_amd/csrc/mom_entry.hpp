@@ -75,16 +75,19 @@ __device__ __forceinline__ CompPtrs comp_ptrs(real *const comp[6], int N, int pi
 // MT: the multi-target form (a.ntgt composites fed by one added layer, see LayerArgs); a separate image so that the
 // single-composite kernels carry none of its code (as a run-time branch it cost the C2 kernel 12 %)
 template <bool LDSM, int IFACE, int KS = 0, bool MT = false>
-__global__ void __launch_bounds__(kThreads, MOM_LB_WAVES) k_layer(LayerArgs a) {
-  if (KS > 0) a.q.N = 4 * KS;  // the host launches this instantiation only for that size: every dimension folds
-  const int N = a.q.N;
+__global__ void __launch_bounds__(kThreads, MOM_LB_WAVES) k_layer(const LayerArgs a) {
+  // KS > 0: the host launches this instantiation only for N = 4 KS, every dimension folds.  The argument block is never
+  // written (r6): a store to it -- the former `a.q.N = 4 * KS` -- made the compiler keep a private copy of the whole 3.3 KB
+  // struct per LANE in scratch (mom_lean.hpp found the same); its dynamically indexed tables (nd_z[z], act_z[z][t]) are scalar
+  // loads from the kernel-argument segment now.
+  const int N = KS > 0 ? 4 * KS : a.q.N;
   const size_t total = (size_t)a.S * a.M;
   Ctx c;
 #ifdef MOM_DIAG_STAMPS
   if (wg_tid() == 0 && blockIdx.x == (gridDim.x >> 1)) mom_diag_last = mom_diag_now();
   if (wg_tid() == 256 && blockIdx.x == (gridDim.x >> 1)) mom_diag_last4 = mom_diag_now();
 #endif
-  wg_prologue<LDSM>(c, a.q, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
+  wg_prologue<LDSM>(c, a.q, N, mom_smem, LDSM ? nullptr : a.scratch + (size_t)blockIdx.x * kGenericBufs * mat_elems(N));
   if constexpr (KS > 0) strip_slot_init(c);
   if constexpr (kF64 && KS > 0) {  // the persistent stream-pair tables of the elemental layer (mom_kernels.hpp ptab_reals)
     const int ns = a.q.regular ? a.q.nS : 1, nt = ptab_reals(N, ns), Nq = N / ns;

@@ -171,6 +171,9 @@ __host__ __device__ inline int ptab_reals(int N, int ns) {
   if (nt > (int)mat_elems(N)) return 0;
   // 4-wave images live on two workgroups per CU: no tables where they would cost the second one (N = 44)
   if (kWaves == 4 && 2 * (lds_bytes(N, true) + (size_t)nt * sizeof(real)) + 2048 > kLdsPerCU) return 0;
+  // any image: the tables must fit the CU next to the image itself (8-wave N = 60 with two Stokes components per stream --
+  // the m = 0 sub-problem of a 30-stream IQU / IQUV scene -- would need 171 KB); the kernel then keeps the per-layer tables in Q
+  if (lds_bytes(N, true) + (size_t)nt * sizeof(real) > kLdsPerCU) return 0;
   return nt;
 }
 __host__ __device__ inline size_t strip_lds_bytes(int N, int ns) { return lds_bytes(N, true) + (kF64 ? (size_t)ptab_reals(N, ns) * sizeof(real) : 0); }
@@ -1077,12 +1080,16 @@ __device__ __forceinline__ void load_streams(const Ctx &c, const DevStreams &q) 
 }
 
 template <bool LDSM>
-__device__ __forceinline__ void wg_prologue(Ctx &c, const DevStreams &q, real *smem, real *gscratch) {
-  make_ctx<LDSM>(c, q.N, q.inv_mode, smem, gscratch);
+__device__ __forceinline__ void wg_prologue(Ctx &c, const DevStreams &q, int N, real *smem, real *gscratch) {
+  make_ctx<LDSM>(c, N, q.inv_mode, smem, gscratch);   // N: q.N, or the compile-time size of a strip image
   zero_padding<LDSM>(c);
   __syncthreads();
   load_streams(c, q);
   __syncthreads();
+}
+template <bool LDSM>
+__device__ __forceinline__ void wg_prologue(Ctx &c, const DevStreams &q, real *smem, real *gscratch) {
+  wg_prologue<LDSM>(c, q, q.N, smem, gscratch);
 }
 
 // ---------------------------------------------------------------------------------------

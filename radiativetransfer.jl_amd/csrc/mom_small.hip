@@ -633,13 +633,19 @@ hipError_t MOMS_LAUNCH(const void *args, int N, hipStream_t st) {
     return hipGetLastError();
   }
   const dim3 grid((unsigned)((a.S + 255) / 256));
-  const size_t lds = (size_t)3 * a.nVza * a.nS * 256 * sizeof(real);  // the view accumulators (<= 48 KB: nVza, nS <= 4)
+  // the view accumulators: up to 96 KB in Float64 at nVza = nS = 4 -- above the 64 KB a kernel gets without asking
+  const size_t lds = (size_t)3 * a.nVza * a.nS * 256 * sizeof(real);
+  hipError_t e = hipSuccess;
+#define MOMS_UNSPLIT(NN)                                                                                         \
+  if ((e = mom_allow_lds(reinterpret_cast<const void *>(MOMS_NS::k_sweep<NN, false>), lds)) != hipSuccess) return e; \
+  hipLaunchKernelGGL((MOMS_NS::k_sweep<NN, false>), grid, block, lds, st, a);
   switch (N) {
-    case 1: hipLaunchKernelGGL((MOMS_NS::k_sweep<1, false>), grid, block, lds, st, a); break;
-    case 2: hipLaunchKernelGGL((MOMS_NS::k_sweep<2, false>), grid, block, lds, st, a); break;
-    case 3: hipLaunchKernelGGL((MOMS_NS::k_sweep<3, false>), grid, block, lds, st, a); break;
-    case 4: hipLaunchKernelGGL((MOMS_NS::k_sweep<4, false>), grid, block, lds, st, a); break;
+    case 1: MOMS_UNSPLIT(1) break;
+    case 2: MOMS_UNSPLIT(2) break;
+    case 3: MOMS_UNSPLIT(3) break;
+    case 4: MOMS_UNSPLIT(4) break;
     default: return hipErrorInvalidValue;
   }
+#undef MOMS_UNSPLIT
   return hipGetLastError();
 }

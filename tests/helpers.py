@@ -1,4 +1,7 @@
 """Shared test helpers: model <-> oracle scene conversion and the parity tolerances."""
+import json
+import os
+
 import numpy as np
 
 from oracle import momref as mr
@@ -13,28 +16,54 @@ ATOL_STOKES = 1e-14
 RTOL_OP = 1e-12
 
 
+# GPU-vs-Float64-oracle distance MEASURED on MI355X over every comparison of this suite (round 6: PARITY_LOG run of the whole
+# `-m gpu` suite, 739 comparisons incl. all 10 000 points of C2, 3 072 of C3, all 256 of C4; profiles/r06_parity_distances.txt),
+# largest value per largest-doubling-number of the scene, made monotone in nd.  Up to nd = 15 the largest is 3.1e-11.
+STOKES_MEASURED = {16: 1.08e-10, 17: 1.56e-10, 18: 3.76e-10, 19: 3.76e-10, 20: 5.93e-10, 21: 7.48e-10, 22: 7.48e-10, 23: 9.22e-10,
+                   24: 9.22e-10}
+
+
 def stokes_rtol(ndoubl) -> float:
     """Parity tolerance of GPU-vs-Float64-oracle comparisons as a function of the scene's largest doubling number:
-    1e-10 (north star) up to ndoubl = 15, then 8 * 2^nd * eps (1.2e-10 at 16, 9.3e-10 at 19, 3.7e-9 at 21, 3.0e-8 at 24).
+    1e-10 (north star) up to ndoubl = 15, then TWICE the measured distance (STOKES_MEASURED: 2.2e-10 at 16, 7.5e-10 at 18,
+    1.5e-9 at 21, 1.8e-9 at 24; r5 had 8 * 2^nd * eps = 3.0e-8 at 24, 30 x what is measured).  Relative to the INTENSITY of
+    the same view and spectral point (assert_stokes_close), for Q, U, V as well.
 
-    Each doubling squares the direct transmission, so a one-ulp difference anywhere early is doubled nd times: every
-    Float64 run of the algorithm -- the LU oracle included -- is a multiple of 2^nd eps away from the exact result of the
-    same equations.  tests/test_gpu_precision.py measures both against the x87 extended-precision build of the oracle
-    (oracle/momref_ext.c) on the thick scenes of this suite: the oracle's own error is 3e-11 at nd = 16, 1.6e-9 at
-    nd = 18, 4.3e-9 at nd = 21, 8.5e-9 at nd = 24 (N = 256); the GPU default path's error is 0.7 .. 1.13 x the oracle's
-    (asserted <= 4 x), and the two differ from each other by 1e-12 (nd 16), 2e-11 (17..18), 1.5e-10 (21), 5.8e-10 (24) --
-    that difference is what this bar bounds.  With MOM_OPT_INVERSE = 1 (pivoted Gauss-Jordan: the oracle's rounding
-    pattern) the GPU agrees with the oracle to 1e-11 on all of them."""
+    Why anything above 1e-10: each doubling squares the direct transmission, so a one-ulp difference anywhere early is
+    amplified over the following doublings: every Float64 run of the algorithm -- the LU oracle included -- is away from
+    the exact result of the same equations by much more than it is from another correct Float64 run.
+    tests/test_gpu_precision.py measures both against the x87 extended-precision build of the oracle (oracle/momref_ext.c)
+    on the thick scenes of this suite: the oracle's own error is 3e-11 at nd = 16, 1.6e-9 at nd = 18, 4.3e-9 at nd = 21,
+    8.5e-9 at nd = 24 (N = 256); the GPU default path's error is 0.7 .. 1.13 x the oracle's (asserted <= 4 x).  With
+    MOM_OPT_INVERSE = 1 (pivoted Gauss-Jordan: the oracle's rounding pattern) the GPU agrees with the oracle to 1e-11 on
+    all of them."""
     nd = int(np.max(np.asarray(ndoubl))) if np.size(ndoubl) else 0
-    return max(RTOL_STOKES, 8.0 * 2.0 ** nd * float(np.finfo(np.float64).eps))
+    if nd <= 15:
+        return RTOL_STOKES
+    top = max(STOKES_MEASURED)
+    meas = STOKES_MEASURED[min(nd, top)] * 2.0 ** max(0, nd - top)
+    return max(RTOL_STOKES, 2.0 * meas)
+
+
+def _log_parity(what, rtol, measured, n):
+    """PARITY_LOG=<file>: append one JSON line per comparison (the measured distance in units of the bar's scale) -- how the
+    constants of stokes_rtol were taken (tools/parity_distances.py summarises the file)."""
+    path = os.environ.get("PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), "what": what, "rtol": float(rtol),
+                                "measured": float(measured), "n": int(n)}) + "\n")
 
 
 def assert_stokes_close(X, Xref, rtol=RTOL_STOKES, atol=ATOL_STOKES, what=""):
+    """|X - Xref| <= rtol |I_ref| + atol elementwise, I_ref = the INTENSITY (Stokes component 0) of the same view and spectral
+    point: Q, U, V are held relative to I, not to themselves (they cross zero)."""
     X, Xref = np.asarray(X), np.asarray(Xref)
     assert X.shape == Xref.shape, (X.shape, Xref.shape)
     assert np.all(np.isfinite(X)), f"{what}: non-finite values"
     scale = np.abs(Xref[:, 0:1, :])
     err = np.abs(X - Xref)
+    _log_parity(what, rtol, np.max(err / np.maximum(scale, atol / rtol)) if err.size else 0.0, err.size)
     bad = err > rtol * scale + atol
     if np.any(bad):
         idx = np.unravel_index(np.argmax(err / (rtol * scale + atol)), err.shape)

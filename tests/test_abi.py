@@ -60,3 +60,19 @@ def test_argument_validation(rtamd):
     assert lib.mom_sync(None) == rtamd._lib.MOM_EINVAL and lib.mom_destroy(None) == 0
     g = np.ones(4)
     assert lib.mom_voigt_xsec(0, 1, None, None, None, None, None, None, 4, rtamd._lib.dp(g), rtamd._lib.dp(g)) == -1
+
+
+@pytest.mark.parametrize("flags", [[], ["-DMOM_WAVES=4", "-DMOM_TJ=3", "-DMOM_NO_STRAIGHT", "-DMOM_NS=mom4"]])
+def test_strip_images_fit_the_cu_lds(tmp_path, flags):
+    """strip_lds_bytes(N, ns) <= 160 KB for every strip image size and 1..4 Stokes components per stream, in the
+    8-wave and the 4-wave build (tools/lds_budget_check.hip: host code only, compiled by hipcc, needs no GPU)."""
+    import subprocess
+    exe = tmp_path / "lds_budget_check"
+    csrc = ROOT / "radiativetransfer.jl_amd" / "csrc"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-std=c++17", "--offload-arch=gfx950", f"-I{ROOT / 'include'}", f"-I{csrc}",
+                           *flags, str(ROOT / "tools" / "lds_budget_check.hip"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "OVER" not in out.stdout, out.stdout
+    assert out.stdout.count(" ok") == 24
+    if not flags:   # the 8-wave N = 60 image with two components per stream: no tables (they would need 171 KB)
+        assert "N=60 ns=2 image=149392 tables=0" in out.stdout

@@ -418,11 +418,12 @@ def test_hdrf_bhr_extras(rtamd, cref, nS, lt, mode):
     np.testing.assert_allclose(out[6], dw[0], rtol=1e-11)
 
 
-@pytest.mark.parametrize("nS,lt,generic", [(3, 9, False), (4, 9, False), (3, 33, False), (4, 7, True)])
+@pytest.mark.parametrize("nS,lt,generic", [(3, 9, False), (4, 9, False), (3, 33, False), (4, 7, True), (3, 53, False), (4, 53, False)])
 def test_m0_reduction_matches_full_problem(rtamd, cref, nS, lt, generic):
     """Fourier moment 0 on the (I,Q) sub-problem (include/momcore.h, mom_scene_set) gives the outputs of
     the full nStokes problem: both against the oracle (which always solves the full problem) and against
-    each other."""
+    each other.  lt = 53: 30 streams, N = 90 / 120, sub-problem N0 = 60 with TWO Stokes components per stream on the 8-wave
+    strip image -- the case whose persistent stream-pair tables do not fit the CU (ptab_reals must return 0)."""
     m = rtamd.scenes.make_scene(nS, lt, 5, 12, seed=17, vaz=(10.0, 95.0, 170.0))
     sc = rtamd.prepare_scene(m)
     Rr, Tr, Hr, upr, dwr, _ = cref.rt_run_full(cref.pack_scene(helpers.oracle_scene(m)))
@@ -437,7 +438,7 @@ def test_m0_reduction_matches_full_problem(rtamd, cref, nS, lt, generic):
         helpers.assert_stokes_close(R, Rr, what=f"R red={red}")
         helpers.assert_stokes_close(T, Tr, what=f"T red={red}")
         helpers.assert_stokes_close(res[red][2], Hr, what=f"hdr red={red}")
-        np.testing.assert_allclose(res[red][4], dwr, rtol=1e-10, atol=1e-300)
+        np.testing.assert_allclose(res[red][4], dwr, rtol=1e-10, atol=helpers.ATOL_STOKES)
     helpers.assert_stokes_close(res[1][0], res[0][0], rtol=1e-11, what="reduced vs full R")
     helpers.assert_stokes_close(res[1][1], res[0][1], rtol=1e-11, what="reduced vs full T")
 
@@ -608,7 +609,19 @@ def test_surface_types(rtamd, cref, surf, nS, lt, mode):
 
 F32_ERR_RATIO = 2.5      # GPU Float32 error / oracle Float32 error, both against the Float64 oracle (measured 0.9 ... 1.34)
 F32_PAIR_ULPS = 80.0     # GPU Float32 vs oracle Float32, in units of eps32 2^nd (measured up to 51 on T at N = 6)
-F32_ABS_CEIL = 0.1       # ... and never looser than this, whatever nd (80 eps32 2^nd is ~5 at nd = 20: vacuous; measured: up to 6.4e-2 on the C2 scene, nd = 14)
+
+
+def f32_pair_bound(nd, pairs):
+    """Bound on |GPU Float32 - other Float32 result| relative to the view's brightest Float64 intensity: 80 eps32 2^nd, and never
+    looser than what the Float32 ORACLE's own error on THIS scene allows: both Float32 results lie within their
+    errors of the Float64 oracle, the GPU's being <= F32_ERR_RATIO x the Float32 oracle's (asserted separately), so the two
+    differ by at most (1 + F32_ERR_RATIO) x the Float32 oracle's error, measured here in the same continuum-relative norm.
+    pairs: iterable of (Float32-oracle spectrum, Float64-oracle spectrum)."""
+    o = 0.0
+    for Xf, Xr in pairs:
+        Imax = np.abs(Xr[:, 0:1, :]).max(axis=2, keepdims=True)
+        o = max(o, float(np.max(np.abs(Xf.astype(np.float64) - Xr) / np.maximum(Imax, 1e-300))))
+    return min(F32_PAIR_ULPS * 6e-8 * 2.0 ** nd, (1.0 + F32_ERR_RATIO) * o + 1e-5)
 
 
 @pytest.mark.parametrize("nS,lt,surf,N,N0", [(3, 33, None, 60, 40), (3, 31, None, 57, 38), (3, 25, None, 48, 32), (4, 21, None, 56, 28),
@@ -639,7 +652,7 @@ def test_float32_m0_reduction_and_padding(rtamd, cref, nS, lt, surf, N, N0):
     assert launches[1] > launches[0]          # moment 0 ran as its own scene
     nd = int(sc.ndoubl.max())
     tol64 = 16 * 6e-8 / (1e-3 * float(m.quad_points.qp_μ.min()))
-    pair = min(F32_PAIR_ULPS * 6e-8 * 2.0 ** nd, F32_ABS_CEIL)
+    pair = f32_pair_bound(nd, ((Rf, Rr), (Tf, Tr)))
     oR = float(np.max(np.abs(Rf - Rr) / np.maximum(np.abs(Rr[:, 0:1, :]), 1e-6 / tol64)))
     oT = float(np.max(np.abs(Tf - Tr) / np.maximum(np.abs(Tr[:, 0:1, :]), 1e-6 / tol64)))
     # the Float64 bound of test_float32_scene_level_path, widened to what the Float32 ORACLE itself loses on scenes whose
@@ -708,7 +721,7 @@ def test_float32_scene_level_path(rtamd, cref, nS, lt, kw):
     nd = int(sc.ndoubl.max())
     oR = float(np.max(np.abs(Rf - Rr) / np.maximum(np.abs(Rr[:, 0:1, :]), 1e-6 / tol)))
     oT = float(np.max(np.abs(Tf - Tr) / np.maximum(np.abs(Tr[:, 0:1, :]), 1e-6 / tol)))
-    pair = min(F32_PAIR_ULPS * 6e-8 * 2.0 ** nd, F32_ABS_CEIL)
+    pair = f32_pair_bound(nd, ((Rf, Rr), (Tf, Tr)))
     def pair_err(X, Xf, Xref, what):   # |GPU f32 - oracle f32| relative to the view's brightest FLOAT64 intensity of the
         # spectrum (continuum-relative: a dim point's own relative error grows with its optical depth; the dim points are
         # held by (a) and by the bound against the Float64 oracle above)
@@ -747,7 +760,7 @@ def test_float32_strip_chains(rtamd, cref, nS, lt, N):
             out[inv] = rtamd.corert.run_scene(h, sc)
     nd = int(sc.ndoubl.max())
     tol64 = 16 * 6e-8 / (1e-3 * float(m.quad_points.qp_μ.min()))
-    pair = min(F32_PAIR_ULPS * 6e-8 * 2.0 ** nd, F32_ABS_CEIL)
+    pair = f32_pair_bound(nd, ((Rf, Rr), (Tf, Tr)))
     for X, Y, Xr in ((out[0][0], out[8][0], Rr), (out[0][1], out[8][1], Tr)):
         Imax = np.abs(Xr[:, 0:1, :]).max(axis=2, keepdims=True)
         assert np.all(np.abs(X - Y) / Imax <= pair), "4-wave vs 8-wave image"
