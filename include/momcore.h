@@ -431,10 +431,22 @@ int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
  *                         workgroups per CU, three chain waves on every SIMD: an experiment, measured slower), each followed by one
  *                         launch of the full image that finishes the units the lean one left (series beyond 12 terms) -- TWO launches
  *                         per sweep, both counted in mom_timers' kernel_launches; 0 = the full image only.
+ *   MOM_OPT_OVERLAP       1 (default) = when Fourier moment 0 runs on the (I,Q) sub-problem (MOM_OPT_M0_REDUCTION) in layer-sweep
+ *                         mode, its launches and its surface interaction go to a second, high-priority stream of the handle and
+ *                         overlap the launch of moments 1..M-1: the partial last round of the persistent workgroups of either
+ *                         launch is filled by the other; results are unchanged (the launches are independent); mom_timers then
+ *                         reports overlapping intervals for the two.  0 = everything on the handle's one stream.
+ *   MOM_OPT_RRS_KERNELS   kernel forms of the rotational-Raman path, a mask (default 15; every form executes the same products in
+ *                         the same order, results agree to 1e-13): 1 = one workgroup per (n1, dn) pair above N = 16 (else one
+ *                         wavefront per pair), 2 = ... also for 16 < N <= 32, 4 = one workgroup per spectral point above N = 16 for
+ *                         the per-point operands (Gauss-Jordan inverse over all waves), 8 = the inelastic elemental layer as a tile
+ *                         kernel, 16 / 32 = form it inside the first doubling step always / never (neither: above N = 48 only).
+ *                         (r5 read these from environment variables, once per process.)
  */
 int mom_set_option(mom_t *h, int option, int value);
 enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1, MOM_OPT_M0_REDUCTION = 2, MOM_OPT_SMALL_WG = 3, MOM_OPT_STAGGER = 4,
-       MOM_OPT_SMALL_N = 5, MOM_OPT_LAYER_SWEEP = 6, MOM_OPT_STRIP_PAD = 7, MOM_OPT_LEAN = 8 };
+       MOM_OPT_SMALL_N = 5, MOM_OPT_LAYER_SWEEP = 6, MOM_OPT_STRIP_PAD = 7, MOM_OPT_LEAN = 8, MOM_OPT_OVERLAP = 9,
+       MOM_OPT_RRS_KERNELS = 10 };
 
 /* ---- Voigt line-by-line cross section --------------------------------------------------
  * compute_absorption_cross_section(model::HitranModel, grid, p, T)

@@ -35,6 +35,8 @@ IE_COMP = dict(ieR_mp=24, ieR_pm=25, ieT_pp=26, ieT_mm=27, ieJ0p=28, ieJ0m=29)
 MOM_OPT_INVERSE, MOM_OPT_FORCE_GENERIC, MOM_OPT_M0_REDUCTION, MOM_OPT_SMALL_WG, MOM_OPT_STAGGER, MOM_OPT_SMALL_N, MOM_OPT_LAYER_SWEEP = 0, 1, 2, 3, 4, 5, 6
 MOM_OPT_STRIP_PAD = 7
 MOM_OPT_LEAN = 8
+MOM_OPT_OVERLAP = 9
+MOM_OPT_RRS_KERNELS = 10   # mask: 1 WG pairs, 2 ... for 16 < N <= 32, 4 WG points, 8 tile elemental, 16 / 32 fused elemental always / never
 
 
 class MomError(RuntimeError):

@@ -869,20 +869,20 @@ def _with_cabannes(RS_type: RRS, model: vSmartMOM_Model) -> vSmartMOM_Model:
     return dataclasses.replace(model, ϖ_Cabannes=float(RS_type.ϖ_Cabannes))  # compEffectiveLayerProperties.jl:27
 
 
-def rt_run_rrs(RS_type: RRS, model: vSmartMOM_Model, i_band: int = 1):
+def rt_run_rrs(RS_type: RRS, model: vSmartMOM_Model, i_band: int = 1, kernels: Optional[int] = None):
     """rt_run(RS_type::RRS, model, iBand) (rt_run.jl:41-230), SFI = true.  Returns the reference's 7-tuple (rt_run.jl:226):
         (R_SFI, T_SFI, ieR_SFI, ieT_SFI, hdr, bhr_uw[1,:], bhr_dw[1,:])
     R/T/ieR/ieT/hdr are [nVza, nStokes, nSpec]; every surface type of `params.brdf`.  With RS_type.rrs_strict_reference =
     True the run raises MomError (MOM_EUNSUPPORTED) for scenes with a 00 / 01 / 10 scattering interface, as the reference's
     text does (D4); False runs them."""
     S = model.τ_rayl.shape[0]
-    return rt_run_rrs_window(RS_type, model, 0, S)
+    return rt_run_rrs_window(RS_type, model, 0, S, kernels=kernels)
 
 
-def rt_run_rrs_window(RS_type: RRS, model: vSmartMOM_Model, lo: int, hi: int, window=None):
+def rt_run_rrs_window(RS_type: RRS, model: vSmartMOM_Model, lo: int, hi: int, window=None, kernels: Optional[int] = None):
     """The owned slice [lo, hi) of rt_run(::RRS): runs the window `window` = (wlo, whi) ⊇ [lo, hi) (default: [lo, hi) widened
     by max |i_λ₁λ₀| and clipped, sharding.rrs_window) with the GLOBAL ndoubl / interface codes and returns the 7-tuple
-    restricted to the owned points (last axis hi - lo)."""
+    restricted to the owned points (last axis hi - lo).  kernels: MOM_OPT_RRS_KERNELS mask (None: the library's default forms)."""
     model = _with_cabannes(RS_type, model)
     sc_full = prepare_scene(model)
     S = sc_full.S
@@ -895,6 +895,8 @@ def rt_run_rrs_window(RS_type: RRS, model: vSmartMOM_Model, lo: int, hi: int, wi
     fs = fscatt_rayleigh(model)[wlo:whi]
     with make_handle(model, S=whi - wlo) as h:
         h.set_option(_lib.MOM_OPT_STRIP_PAD, 0)
+        if kernels is not None:
+            h.set_option(_lib.MOM_OPT_RRS_KERNELS, int(kernels))
         h.rrs_set(RS_type.i_λ1λ0, RS_type.ϖ_λ1λ0, RS_type.rrs_strict_reference)
         h.rrs_set_shard(S, wlo, lo - wlo, hi - wlo)
         scene_set(h, sc)

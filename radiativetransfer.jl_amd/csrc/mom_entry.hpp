@@ -75,12 +75,17 @@ __device__ __forceinline__ CompPtrs comp_ptrs(real *const comp[6], int N, int pi
 // MT: the multi-target form (a.ntgt composites fed by one added layer, see LayerArgs); a separate image so that the
 // single-composite kernels carry none of its code (as a run-time branch it cost the C2 kernel 12 %)
 template <bool LDSM, int IFACE, int KS = 0, bool MT = false>
+#ifdef MOM_CONST_LAYER_ARGS
+// r6 A/B (profiles/r06_C2_ab.txt): the argument block never written -- scratch 3 392 -> 200 B per lane, but 49 spilled VGPRs
+// instead of 8 and the N = 60 launch 1.9 % SLOWER (292.8 -> 298.3 ms): the private copy of the block costs nothing that matters
+// (it is read through scalar-uniform scratch loads outside the chains), the registers the compiler spends instead do.
 __global__ void __launch_bounds__(kThreads, MOM_LB_WAVES) k_layer(const LayerArgs a) {
-  // KS > 0: the host launches this instantiation only for N = 4 KS, every dimension folds.  The argument block is never
-  // written (r6): a store to it -- the former `a.q.N = 4 * KS` -- made the compiler keep a private copy of the whole 3.3 KB
-  // struct per LANE in scratch (mom_lean.hpp found the same); its dynamically indexed tables (nd_z[z], act_z[z][t]) are scalar
-  // loads from the kernel-argument segment now.
   const int N = KS > 0 ? 4 * KS : a.q.N;
+#else
+__global__ void __launch_bounds__(kThreads, MOM_LB_WAVES) k_layer(LayerArgs a) {
+  if (KS > 0) a.q.N = 4 * KS;  // the host launches this instantiation only for that size: every dimension folds
+  const int N = a.q.N;
+#endif
   const size_t total = (size_t)a.S * a.M;
   Ctx c;
 #ifdef MOM_DIAG_STAMPS

@@ -1849,8 +1849,22 @@ void destroy(State *s) {
 
 // scene-level fast-mode features (A/B switch for profiling: MOM_RRS_FAST = bit 0 deferred elemental, bit 1 derived ier+- / iet--)
 static int fast_bits() {
+#ifdef MOM_EXPERIMENTS
   static const int bits = [] { const char *e = getenv("MOM_RRS_FAST"); return e ? atoi(e) : MOMR_FAST_DEFAULT; }();
   return bits;
+#else
+  return MOMR_FAST_DEFAULT;
+#endif
+}
+// experiment-only knobs: environment variables in -DMOM_EXPERIMENTS builds, constants in the shipped library
+static int exp_int(const char *name, int dflt) {
+#ifdef MOM_EXPERIMENTS
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
 }
 
 void timing_reset(State *s, bool on) {
@@ -1881,20 +1895,17 @@ hipError_t timing_read(State *s, double *ms, int *launches) {
   return hipSuccess;
 }
 
-// 32 < N <= 64: the pair kernels as one workgroup per pair (mom_rrs_wg.hpp); MOM_RRS_WG=0 selects the wave-per-pair bodies
-static bool wg_pairs() {
-  static const bool on = !(getenv("MOM_RRS_WG") && atoi(getenv("MOM_RRS_WG")) == 0);
-  return on;
-}
-// tile count of the workgroup-per-pair image for this edge, 0 = wave-per-pair kernels (N <= 16; 16 < N <= 32 with MOM_RRS_WG2=0)
+// Kernel-form switches of the handle (State::kopt, MOM_OPT_RRS_KERNELS of mom_set_option; r5 read them from the environment):
+// 16 < N <= 64: the pair kernels as one workgroup per pair (mom_rrs_wg.hpp); KOPT_WG off selects the wave-per-pair bodies
+static bool wg_pairs(const State *s) { return (s->kopt & KOPT_WG) != 0; }
+// tile count of the workgroup-per-pair image for this edge, 0 = wave-per-pair kernels (N <= 16; 16 < N <= 32 without KOPT_WG2)
 static int wg_nt(const State *s) {
-  static const bool two = !(getenv("MOM_RRS_WG2") && atoi(getenv("MOM_RRS_WG2")) == 0);
-  if (!wg_pairs() || s->N <= 16) return 0;
-  if (s->N <= 32) return two ? 2 : 0;
+  if (!wg_pairs(s) || s->N <= 16) return 0;
+  if (s->N <= 32) return (s->kopt & KOPT_WG2) ? 2 : 0;
   return s->N <= 48 ? 3 : 4;
 }
 static size_t wg_grid(const State *s, int nt) {  // persistent workgroups, one round of the chip
-  static const int mult = getenv("MOM_RRS_WG_GRID") ? std::max(1, atoi(getenv("MOM_RRS_WG_GRID"))) : 1;  // (experiments)
+  static const int mult = std::max(1, exp_int("MOM_RRS_WG_GRID", 1));
   const size_t np = (size_t)(s->n1_hi - s->n1_lo) * s->nR, per_cu = (nt == 2) ? 4 : ((nt == 3) ? 2 : 1);
   return std::max<size_t>(1, std::min<size_t>(np, 256 * per_cu * mult));
 }
@@ -1938,10 +1949,10 @@ hipError_t elemental(State *s, const Streams &q, int m, int nd, int shift, const
   s->el_pending = false;
   if (inelastic) {
     // scene-level fast mode: the tile form (k_ie_elemental_tile).  For a layer with doublings the alternative is to form the layer
-    // inside the first doubling step (fuse_el): MOM_RRS_EL_FUSE=1 (default: only above N = 48; below, the separate tile kernel +
-    // the plain first step measured faster, profiles/r05_C5_ab.txt (5)).  MOM_RRS_EL_TILE=0: the element-wise kernel below / the fused form as in r4.
-    static const bool el_tile = !(getenv("MOM_RRS_EL_TILE") && atoi(getenv("MOM_RRS_EL_TILE")) == 0);
-    static const int el_fuse_env = getenv("MOM_RRS_EL_FUSE") ? (atoi(getenv("MOM_RRS_EL_FUSE")) != 0 ? 1 : 0) : -1;
+    // inside the first doubling step (fuse_el): KOPT_EL_FUSE_ON / _OFF (neither: only above N = 48; below, the separate tile kernel +
+    // the plain first step measured faster, profiles/r05_C5_ab.txt (5)).  KOPT_EL_TILE off: the element-wise kernel below / the fused form as in r4.
+    const bool el_tile = (s->kopt & KOPT_EL_TILE) != 0;
+    const int el_fuse_env = (s->kopt & KOPT_EL_FUSE_ON) ? 1 : ((s->kopt & KOPT_EL_FUSE_OFF) ? 0 : -1);
     const bool el_fuse = el_fuse_env >= 0 ? el_fuse_env == 1 : s->N > 48;  // 4 x 4 tiles: the fused form stays ahead (N = 60: 414 vs 420 ms per run)
     if (s->fast && nd >= 1 && (fast_bits() & 1) && (el_fuse || !el_tile)) {  // deferred into the first doubling step (k_dbl_pair, fuse_el)
       s->el_pending = true;
@@ -1996,9 +2007,9 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
       s->el_pending = false;
     }
     // above N = 16: one workgroup per point (mom_rrs_wg.hpp dbl_point_wg: products in strips from LDS copies, Gauss-Jordan inverse
-    // over all waves); MOM_RRS_WG_POINT=0 selects the wave-per-point kernel (operators in scratch, inverse on one wave)
-    static const bool wg_point = !(getenv("MOM_RRS_WG_POINT") && atoi(getenv("MOM_RRS_WG_POINT")) == 0);
-    static const int wg_point_min = getenv("MOM_RRS_WG_POINT_MIN") ? atoi(getenv("MOM_RRS_WG_POINT_MIN")) : 2;  // smallest tile count (experiments)
+    // over all waves); KOPT_WG_POINT off selects the wave-per-point kernel (operators in scratch, inverse on one wave)
+    const bool wg_point = (s->kopt & KOPT_WG_POINT) != 0;
+    static const int wg_point_min = exp_int("MOM_RRS_WG_POINT_MIN", 2);  // smallest tile count
     if (wg_point && wg_nt(s) >= wg_point_min)
       RCHK(momr_big_launch(7, wg_nt(s), 0, 0, (unsigned)std::max(1, std::min(s->S, 256 * 8)), (void *)s->stream, &a, 0));
     else LAUNCH_NT(s, k_dbl_point, 1, grid_points(s), a);
@@ -2009,7 +2020,7 @@ hipError_t doubling(State *s, const Streams &q, int nd) {
       if (MOMR_LDSPF != 0 && s->N <= 16) {
         // work items (n1, chunk of Raman offsets) of dbl_pair_body1: about four items per resident wave, so that
         // the n1-side operands are loaded once per ~nR / nch pairs and the tail of the launch stays short
-        static const int ipw = getenv("MOMR_ITEMS_PER_WAVE") ? atoi(getenv("MOMR_ITEMS_PER_WAVE")) : 4;  // (experiments)
+        static const int ipw = exp_int("MOMR_ITEMS_PER_WAVE", 4);
         const size_t span = (size_t)(s->n1_hi - s->n1_lo), want = (size_t)std::max(ipw, 1) * 3 * 4 * 256;
         const size_t nch = std::max<size_t>(1, std::min<size_t>((size_t)s->nR, (want + span - 1) / std::max<size_t>(span, 1)));
         a.dn_chunk = std::min(64, (int)(((size_t)s->nR + nch - 1) / nch));  // the offsets of a chunk live in the lanes of a wave
@@ -2083,8 +2094,8 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
   if (!with_surface && !a.derive_pm) RCHK(ensure_pm(s, q));
   for (int k = 0; k < 6; ++k) a.x[k] = with_surface ? s->surf[k] : s->added[s->cur][k];
   if (!with_surface) { a.x[R_PM] = s->added[0][R_PM]; a.x[T_MM] = s->added[0][T_MM]; }
-  static const bool wg_point = !(getenv("MOM_RRS_WG_POINT") && atoi(getenv("MOM_RRS_WG_POINT")) == 0);
-  static const int wg_point_min = getenv("MOM_RRS_WG_POINT_MIN") ? atoi(getenv("MOM_RRS_WG_POINT_MIN")) : 2;
+  const bool wg_point = (s->kopt & KOPT_WG_POINT) != 0;
+  static const int wg_point_min = exp_int("MOM_RRS_WG_POINT_MIN", 2);
   if (wg_point && iface == 3 && wg_nt(s) >= wg_point_min)  // one workgroup per point (mom_rrs_wg.hpp int_point_wg)
     RCHK(momr_big_launch(9, wg_nt(s), 0, 0, (unsigned)std::max(1, std::min(s->S, 256 * 8)), (void *)s->stream, &a, 0));
   else LAUNCH_NT(s, k_int_point, 2, grid_points(s), a, iface);
@@ -2097,7 +2108,7 @@ hipError_t interaction(State *s, const Streams &q, int iface, bool with_surface)
     dim3 gr(grid_pairs(s));
     size_t lds1 = lds<1>();
     if (MOMR_LDSPF != 0 && s->N <= 16 && iface == 3) {  // int_pair_body1: (n1, chunk) items, as for the doubling pair kernel
-      static const int ipw = getenv("MOMR_ITEMS_PER_WAVE") ? atoi(getenv("MOMR_ITEMS_PER_WAVE")) : 4;
+      static const int ipw = exp_int("MOMR_ITEMS_PER_WAVE", 4);
       const size_t span = (size_t)(s->n1_hi - s->n1_lo), want = (size_t)std::max(ipw, 1) * 2 * 4 * 256;
       const size_t nch = std::max<size_t>(1, std::min<size_t>((size_t)s->nR, (want + span - 1) / std::max<size_t>(span, 1)));
       a.dn_chunk = std::min(64, (int)(((size_t)s->nR + nch - 1) / nch));

@@ -24,8 +24,13 @@ struct Streams {
 enum { R_PM = 0, R_MP = 1, T_MM = 2, T_PP = 3, J0P = 4, J0M = 5 };        // AddedLayer field order of momcore.h
 enum { C_R_MP = 0, C_R_PM = 1, C_T_PP = 2, C_T_MM = 3, C_J0P = 4, C_J0M = 5 };  // CompositeLayer field order
 
+// kernel-form switches (State::kopt; MOM_OPT_RRS_KERNELS): every form computes the same products in the same order
+enum { KOPT_WG = 1, KOPT_WG2 = 2, KOPT_WG_POINT = 4, KOPT_EL_TILE = 8, KOPT_EL_FUSE_ON = 16, KOPT_EL_FUSE_OFF = 32,
+       KOPT_DEFAULT = KOPT_WG | KOPT_WG2 | KOPT_WG_POINT | KOPT_EL_TILE };
+
 struct State {
   int N = 0, nS = 0, S = 0, nR = 0;
+  int kopt = KOPT_DEFAULT;
   int P = 16;              // row pitch of every device block: 16 (N <= 16) or 32; matrices P x P, vectors P, zero padding --
                            // the tile loads of the kernels are then unmasked, 128-byte aligned and at immediate offsets
   int strict_rrs = 1;      // rrs_strict_reference (DESIGN.md "RRS": D1..D5)

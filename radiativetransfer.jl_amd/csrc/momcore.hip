@@ -397,6 +397,10 @@ struct mom_handle {
   int opt_m0 = 1;
   int opt_w4 = 1;
   int opt_stagger = 1;
+  int opt_rrs_kernels = -1;  // MOM_OPT_RRS_KERNELS (-1: momr::KOPT_DEFAULT)
+  int opt_overlap = 1;       // MOM_OPT_OVERLAP: the m = 0 sub-problem on a second (high-priority) stream of the handle
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_go = nullptr;
   int surf_kind = 0;         // 0 Lambertian scalar, 1 BRDF matrices, 2 Lambertian Legendre (mom_scene_set_surface)
   double *d_Rsurf = nullptr, *d_Rsurf0 = nullptr, *d_albedo_spec = nullptr, *d_hdrJm = nullptr;
   int opt_sweep = 1;       // one launch walks all layers of a unit (LayerArgs::Nz_sweep)
@@ -572,6 +576,14 @@ extern "C" int mom_create(mom_t **out, int device, int N, int nStokes, int S, in
   *out = h;
   HIPCHK(h, hipSetDevice(device));
   HIPCHK(h, hipStreamCreate(&h->stream));
+  {  // the second stream of MOM_OPT_OVERLAP: highest priority, so that its (shorter) launches are dispatched first
+    int lo = 0, hi = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(h, hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, hi));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_go, hipEventDisableTiming));
+  }
   const size_t NN = (size_t)N * N;
   const int Na = N + kPadMax;  // room for the dummy entries of strip_pad
   HIPCHK(h, dmalloc(&h->d_mu, Na));
@@ -637,6 +649,10 @@ extern "C" int mom_destroy(mom_t *h) {
   for (int k = 0; k < 2; ++k) if (h->ev_voigt[k]) (void)hipEventDestroy(h->ev_voigt[k]);
   for (auto e : h->ev_full) (void)hipEventDestroy(e);
   for (auto e : h->ev_red) (void)hipEventDestroy(e);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_go) (void)hipEventDestroy(h->ev_go);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return MOM_OK;
@@ -665,6 +681,13 @@ extern "C" int mom_set_option(mom_t *h, int option, int value) {
   else if (option == MOM_OPT_LAYER_SWEEP) h->opt_sweep = value;
   else if (option == MOM_OPT_STRIP_PAD) { h->opt_pad = value; h->scene_set = false; }
   else if (option == MOM_OPT_LEAN) h->opt_lean = value;
+  else if (option == MOM_OPT_OVERLAP) h->opt_overlap = value;
+  else if (option == MOM_OPT_RRS_KERNELS) {
+    if (value < 0 || value > 63 || ((value & momr::KOPT_EL_FUSE_ON) && (value & momr::KOPT_EL_FUSE_OFF)))
+      return fail(h, MOM_EINVAL, "mom_set_option: MOM_OPT_RRS_KERNELS takes a mask of bits 0..5 (bits 4 and 5 exclude each other)");
+    h->opt_rrs_kernels = value;
+    if (h->rrs) h->rrs->kopt = value;
+  }
   else if (option == MOM_OPT_FORCE_GENERIC) {
     h->opt_force_generic = value;
     h->lds_mode = (h->N <= 64) && !value;
@@ -1399,6 +1422,7 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
   for (int z = za + 2; z < zb && can_sweep; ++z) can_sweep = (h->iface[z] == h->iface[za + 1]);
   if (cont && can_sweep) can_sweep = (h->iface[za] == h->iface[za + 1]);
   for (int z = za; z < zb && can_sweep; ++z) can_sweep = (h->nd[z] <= 127);
+  hipStream_t cur = h->stream;  // the stream launch_layer issues to (MOM_OPT_OVERLAP switches it for the m = 0 sub-problem)
   auto launch_layer = [&](int z, const DevStreams &q, int m_first, int Mcount, const double *Zpp, const double *Zmp,
                           double *const comp[6], double *scratch) -> int {
     LayerArgs a{};
@@ -1443,25 +1467,29 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
         if (lean) {
           const size_t units = S * (size_t)Mcount;
           if (units > h->resume_cap) {  // grow-only
-            if (h->d_resume) { HIPCHK(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_resume); h->d_resume = nullptr; h->resume_cap = 0; }
+            if (h->d_resume) { HIPCHK(h, hipStreamSynchronize(cur)); (void)hipFree(h->d_resume); h->d_resume = nullptr; h->resume_cap = 0; }
             HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_resume), units * sizeof(int)));
             h->resume_cap = units;
           }
           a.resume = h->d_resume;
           const bool six = h->opt_lean >= 2 && (q.N == 40 ? mom6_lean10_lds_bytes(ns_tab) : mom6_lean9_lds_bytes(ns_tab)) > 0;
-          static const int lean_per_cu = getenv("MOM_LEAN_PER_CU") ? atoi(getenv("MOM_LEAN_PER_CU")) : 0;  // (experiments)
+#ifdef MOM_EXPERIMENTS
+          static const int lean_per_cu = getenv("MOM_LEAN_PER_CU") ? atoi(getenv("MOM_LEAN_PER_CU")) : 0;
+#else
+          const int lean_per_cu = 0;
+#endif
           const int per_cu = lean_per_cu > 0 ? lean_per_cu : (six ? 2 : 3);
           const int gridl = (int)std::min<size_t>(units, (size_t)per_cu * h->num_cu);
-          if (six) HIPCHK(h, (q.N == 40 ? mom6_lean10_launch : mom6_lean9_launch)(&a, gridl, h->stream));
-          else HIPCHK(h, (q.N == 40 ? mom_strip10_launch_lean : mom_strip9_launch_lean)(&a, gridl, h->stream));
+          if (six) HIPCHK(h, (q.N == 40 ? mom6_lean10_launch : mom6_lean9_launch)(&a, gridl, cur));
+          else HIPCHK(h, (q.N == 40 ? mom_strip10_launch_lean : mom_strip9_launch_lean)(&a, gridl, cur));
           h->launches++;
         }
         HIPCHK(h, (q.N == 44 ? mom4_strip11_launch_layer : q.N == 40 ? mom_strip10_launch_layer : mom_strip9_launch_layer)(
-                      &a, a.iface, gridp, mom4_strip_lds_bytes(q.N, ns_tab), h->stream));
+                      &a, a.iface, gridp, mom4_strip_lds_bytes(q.N, ns_tab), cur));
         h->launches++;
         return MOM_OK;
       }
-      HIPCHK(h, mom4_launch_layer(&a, a.iface, true, grid4, mom4_lds_bytes(q.N, true), h->stream));
+      HIPCHK(h, mom4_launch_layer(&a, a.iface, true, grid4, mom4_lds_bytes(q.N, true), cur));
       h->launches++;
       return MOM_OK;
     }
@@ -1476,21 +1504,42 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
       }
       const int grid = (int)std::min<size_t>(S * Mcount, (size_t)h->num_cu);
       HIPCHK(h, (q.N == 60 ? mom_strip15_launch_layer : q.N == 56 ? mom_strip14_launch_layer : q.N == 52 ? mom_strip13_launch_layer : mom_strip11_launch_layer)(
-                    &a, a.iface, grid, sm, h->stream));
+                    &a, a.iface, grid, sm, cur));
       h->launches++;
       return MOM_OK;
     }
     const int grid = lds ? (int)((S >= 2048) ? S : S * Mcount) : (int)std::min<size_t>(S * Mcount, (size_t)h->G);
-    HIPCHK(h, mom_gen_launch_layer(&a, a.iface, lds, grid, sm, h->stream));
+    HIPCHK(h, mom_gen_launch_layer(&a, a.iface, lds, grid, sm, cur));
     HIPCHK(h, hipGetLastError());
     h->launches++;
     return MOM_OK;
   };
+  // MOM_OPT_OVERLAP: the two launches of a sweep -- moments 1..M-1 on the full problem, moment 0 on the (I,Q) sub-problem --
+  // are independent, and each ends in a partial round of its persistent workgroups (C2: 20 000 units on 256 workgroups = 78.1
+  // rounds, 10 000 on 768 = 13.02).  The sub-problem (with its surface interaction) goes first, on the handle's second,
+  // high-priority stream; the full problem's workgroups take the CUs as the sub-problem's last round frees them, and the
+  // workgroups that start late are those with the highest indices -- the ones WITHOUT a unit in the full problem's own partial
+  // round.  The images cannot share a CU (149 + 48.5 KB of LDS), so nothing else overlaps.
+  const bool two = red0 && can_sweep && h->opt_overlap && M > 1 && !tg && h->stream2;
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   for (int z = (can_sweep ? -1 : za); z < (can_sweep ? 0 : zb); ++z) {
     int rc;
     const int e = can_sweep ? 0 : z - za;  // event slot
     if (red0) {
+      if (two) {  // the m = 0 sub-problem first, on the high-priority stream: see the comment at `two`
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        cur = h->stream2;
+        // the full problem's launch is released only when the second stream has passed its own wait and stands right before
+        // the sub-problem's launch: otherwise the main stream (no wait packet in front of its kernel) always dispatches first
+        HIPCHK(h, hipEventRecord(h->ev_go, cur));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_go, 0));
+        HIPCHK(h, hipEventRecord(h->ev_red[2 * e], cur));
+        if ((rc = launch_layer(z, h->q0, 0, 1, h->d_Zpp0, h->d_Zmp0, h->comp0, h->d_scratch0))) return rc;
+        HIPCHK(h, hipEventRecord(h->ev_red[2 * e + 1], cur));
+        h->launches_red++;
+        cur = h->stream;
+      }
       if (M > 1) {  // moments 1..M-1 on the full problem
         double *comp1[6];
         for (int k = 0; k < 6; ++k) comp1[k] = compF[k] + ((k < 4) ? (size_t)comp_pitch(Nk) * Nk : (size_t)Nk) * S;
@@ -1499,10 +1548,12 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
         HIPCHK(h, hipEventRecord(h->ev_full[2 * e + 1], h->stream));
         h->launches_full++;
       }
-      HIPCHK(h, hipEventRecord(h->ev_red[2 * e], h->stream));
-      if ((rc = launch_layer(z, h->q0, 0, 1, h->d_Zpp0, h->d_Zmp0, h->comp0, h->d_scratch0))) return rc;
-      HIPCHK(h, hipEventRecord(h->ev_red[2 * e + 1], h->stream));
-      h->launches_red++;
+      if (!two) {
+        HIPCHK(h, hipEventRecord(h->ev_red[2 * e], h->stream));
+        if ((rc = launch_layer(z, h->q0, 0, 1, h->d_Zpp0, h->d_Zmp0, h->comp0, h->d_scratch0))) return rc;
+        HIPCHK(h, hipEventRecord(h->ev_red[2 * e + 1], h->stream));
+        h->launches_red++;
+      }
     } else {
       HIPCHK(h, hipEventRecord(h->ev_full[2 * e], h->stream));
       if ((rc = launch_layer(z, h->qk, 0, M, h->d_Zpp, h->d_Zmp, compF, h->d_scratch))) return rc;
@@ -1528,16 +1579,21 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
     const bool lds = (q.N <= 64) && !h->opt_force_generic;
     const size_t sm = lds_bytes(q.N, lds);
     const int grid = lds ? (int)S : (int)std::min<size_t>(S, (size_t)h->G);
+    const hipStream_t sst = (two && red) ? h->stream2 : h->stream;  // the sub-problem's surface follows its layers
     if (lds && h->opt_w4 && np_for(q.N) <= 48 && 2 * mom4_lds_bytes(q.N, true) + 2048 <= 160 * 1024) {
-      HIPCHK(h, mom4_launch_surface(&a, true, (int)S, mom4_lds_bytes(q.N, true), h->stream));
+      HIPCHK(h, mom4_launch_surface(&a, true, (int)S, mom4_lds_bytes(q.N, true), sst));
     } else if (lds) {
       HIPCHK(h, allow_lds(k_surface<true>, sm));
-      hipLaunchKernelGGL(k_surface<true>, dim3(grid), dim3(kThreads), sm, h->stream, a);
+      hipLaunchKernelGGL(k_surface<true>, dim3(grid), dim3(kThreads), sm, sst, a);
     } else {
       HIPCHK(h, allow_lds(k_surface<false>, sm));
-      hipLaunchKernelGGL(k_surface<false>, dim3(grid), dim3(kThreads), sm, h->stream, a);
+      hipLaunchKernelGGL(k_surface<false>, dim3(grid), dim3(kThreads), sm, sst, a);
     }
     HIPCHK(h, hipGetLastError());
+  }
+  if (two) {  // join: everything below (post-processing, the caller's downloads) is ordered behind both streams
+    HIPCHK(h, hipEventRecord(h->ev_join, h->stream2));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
   }
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
   if (do_post) {
@@ -2495,6 +2551,7 @@ extern "C" int mom_rrs_set(mom_t *h, int nRaman, const int *i_l1l0, const double
     snprintf(buf, sizeof buf, "mom_rrs_set: allocating the RRS layers failed: %s", hipGetErrorString(e));
     return fail(h, MOM_EHIP, buf);
   }
+  if (h->opt_rrs_kernels >= 0) h->rrs->kopt = h->opt_rrs_kernels;
   return MOM_OK;
 }
 

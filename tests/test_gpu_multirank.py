@@ -151,6 +151,35 @@ def test_bench_C3_strong_scaling_two_ranks_gathered_spectra_bitwise(tmp_path):
     assert np.array_equal(a, b)
 
 
+def test_bench_C3_strong_scaling_eight_ranks_full_size_bitwise(tmp_path):
+    """BASELINE configs[2] at FULL size over EIGHT ranks (north_star's node size; all on GPU 0, gloo: RCCL refuses several
+    ranks on one device): 29 944 = 8 x 3 743 points, strong scaling, one all-gather -- every rank's block of the gathered
+    spectra is bitwise the 1-rank run of the same axis."""
+    f1, f8 = tmp_path / "one.npy", tmp_path / "eight.npy"
+    common = ["--workload", "C3", "--steps", "1", "--warmup", "0"]
+    j1 = _bench(common + ["--gpus", "1", "--dump-spectra", str(f1)])
+    j8 = _bench(common + ["--gpus", "8", "--scaling", "strong", "--backend", "gloo", "--share-device", "--dump-spectra", str(f8)], timeout=1800)
+    assert j1["n_gpus"] == 1 and j8["n_gpus"] == 8 and j8["scaling"] == "strong"
+    assert "8 x 3743 points" in j8["config"]["sharding"], j8["config"]["sharding"]
+    a, b = np.load(f1), np.load(f8)
+    assert a.shape == b.shape and a.shape[0] == 2 and a.shape[-1] == 29_944
+    assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
+    assert np.array_equal(a, b)
+
+
+def test_bench_C5_eight_ranks_gathered_spectra_bitwise(tmp_path):
+    """The RRS leg over EIGHT ranks on one GPU (windows with recomputed halos, one all-gather of the packed owned spectra)
+    against the one-rank run of the same 2 400-point axis."""
+    f1, f8 = tmp_path / "one.npy", tmp_path / "eight.npy"
+    _bench(["--workload", "C5", "--points", "2400", "--steps", "1", "--warmup", "0", "--gpus", "1", "--dump-spectra", str(f1)])
+    j8 = _bench(["--workload", "C5", "--points", "300", "--steps", "1", "--warmup", "0", "--gpus", "8", "--backend", "gloo",
+                 "--share-device", "--dump-spectra", str(f8)], timeout=1800)
+    assert j8["n_gpus"] == 8 and "2400 in total" in j8["config"]["workload"]
+    a, b = np.load(f1), np.load(f8)
+    assert a.shape == b.shape and a.shape[-1] == 2400 and np.abs(a[2]).max() > 0
+    assert np.array_equal(a, b)
+
+
 def test_bench_C5_two_ranks_gathered_spectra_bitwise(tmp_path):
     """The RRS leg over two ranks (windows with a recomputed halo; device-side pack of the owned slices,
     mom_get_spectra_rrs_device, then one all-gather) against the one-rank run of the same 1 200-point axis: R, T, ieR, ieT,

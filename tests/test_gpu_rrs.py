@@ -377,28 +377,25 @@ def test_rrs_zero_padding_invariant(rtamd, nS, lt, nv, strict):
 
 @pytest.mark.parametrize("nS,lt,S,Nz", [(4, 9, 12, 2), (3, 21, 10, 2), (4, 21, 8, 2), (3, 33, 8, 2)])   # N = 32, 42, 56, 60: 2, 3, 4, 4 waves per pair
 @pytest.mark.parametrize("strict", [True, False])
-def test_rrs_workgroup_and_wave_kernels_agree(tmp_path, nS, lt, S, Nz, strict):
+def test_rrs_workgroup_and_wave_kernels_agree(rtamd, nS, lt, S, Nz, strict):
     """Above N = 16 the RRS pair kernels run as one WORKGROUP per pair (mom_rrs_wg.hpp: column strips per wave, left factors from
-    LDS); MOM_RRS_WG=0 selects the wave-per-pair bodies they replace.  Both execute the same products in the same order on the
-    same operands, so a scene-level run must agree to rounding of the last place -- asserted at 1e-13 of the elastic intensity,
-    three orders below the parity bound against the restatement (which test_rt_run_rrs_parity holds for the workgroup form)."""
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
-    root = Path(__file__).resolve().parents[1]
+    LDS); MOM_OPT_RRS_KERNELS without bit 0 selects the wave-per-pair bodies they replace.  Both execute the same products in the
+    same order on the same operands, so a scene-level run must agree to rounding of the last place -- asserted at 1e-13 of the
+    elastic intensity, three orders below the parity bound against the restatement (which test_rt_run_rrs_parity holds for the
+    workgroup form).  (r5 needed a process per switch position: the switches were environment variables read once.)"""
+    rt = rtamd.corert
+    m = rtamd.scenes.make_scene(nS, lt, Nz, S, seed=nS + lt + S, aerosol_total=0.1)
+    offs = np.asarray([-4, -1, 2, 7, 3])
+    vp = 0.04 / len(offs) * (1.0 + 0.1 * np.arange(len(offs)))
+    RS = rt.RRS(greek_raman=rt.get_greek_rayleigh(0.2), ϖ_Cabannes=0.96, ϖ_λ1λ0=vp, i_λ1λ0=offs, rrs_strict_reference=bool(strict))
+    # mask bits: 1 workgroup per pair, 2 ... for 16 < N <= 32 too, 4 workgroup per point, 8 tile-form elemental, 16 / 32 the
+    # inelastic elemental layer formed inside the first doubling step always / never.
+    # "point": the point kernels as one wave per point; "fuse": elemental inside the first doubling step; "elementwise": r4's kernel
+    masks = {"0": 2 | 4 | 8, "1": 15, "point": 1 | 2 | 8, "fuse": 15 | 16, "fuse0": 2 | 4 | 8 | 16, "elementwise": 1 | 2 | 4}
     out = {}
-    # "point": the doubling point kernel as one wave per point (default above N = 32: a workgroup per point); "fuse": the inelastic elemental layer
-    # formed inside the first doubling step of a layer (MOM_RRS_EL_FUSE=1) instead of by the separate tile kernel (default)
-    envs = {"0": dict(MOM_RRS_WG="0"), "1": dict(MOM_RRS_WG="1"), "point": dict(MOM_RRS_WG="1", MOM_RRS_WG_POINT="0"),
-            "fuse": dict(MOM_RRS_WG="1", MOM_RRS_EL_FUSE="1"), "fuse0": dict(MOM_RRS_WG="0", MOM_RRS_EL_FUSE="1"),
-            "elementwise": dict(MOM_RRS_WG="1", MOM_RRS_EL_TILE="0")}
-    for wg in envs:
-        f = tmp_path / f"wg{wg}.npz"
-        env = dict(os.environ, **envs[wg])
-        subprocess.run([sys.executable, str(root / "tests" / "rrs_probe.py"), str(nS), str(lt), str(S), str(Nz), str(int(strict)), str(f)],
-                       check=True, env=env, timeout=600)
-        out[wg] = np.load(f)
+    for wg, mask in masks.items():
+        out[wg] = dict(zip(("R", "T", "ieR", "ieT", "hdr", "up", "dw"), rt.rt_run_rrs(RS, m, kernels=mask)))
+        out[wg]["N"] = rtamd.prepare_scene(rt._with_cabannes(RS, m)).N
     assert int(out["0"]["N"]) == {(4, 9): 32, (3, 21): 42, (4, 21): 56, (3, 33): 60}[(nS, lt)]
     scale = np.abs(out["0"]["R"][:, 0:1, :]).max()
     assert np.abs(out["0"]["ieR"]).max() > 0

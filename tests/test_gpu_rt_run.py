@@ -180,19 +180,27 @@ def test_strip_chains_thick_layers_fall_back(rtamd, cref):
 
 
 def test_launch_shape_options_do_not_change_results(rtamd, cref):
-    """MOM_OPT_STAGGER only delays workgroup starts and MOM_OPT_SMALL_WG only picks the workgroup shape: the
-    staggered run is bitwise the default run, the 8-wave run of the m = 0 sub-problem agrees to rounding."""
+    """MOM_OPT_STAGGER only delays workgroup starts, MOM_OPT_OVERLAP only moves the m = 0 sub-problem to the handle's second
+    stream and MOM_OPT_SMALL_WG only picks the workgroup shape: the staggered and the one-stream runs are bitwise the default
+    run (also when repeated on one handle: fork / join ordering), the 8-wave run of the m = 0 sub-problem agrees to rounding."""
     m = rtamd.scenes.make_scene(3, 33, 6, 2400, seed=8)   # N = 60, enough units for the persistent grid to stagger
     sc = rtamd.prepare_scene(m)
     out = {}
     for key, opt, val in (("default", None, None), ("nostagger", rtamd._lib.MOM_OPT_STAGGER, 0),
-                          ("wg8", rtamd._lib.MOM_OPT_SMALL_WG, 0)):
+                          ("onestream", rtamd._lib.MOM_OPT_OVERLAP, 0), ("wg8", rtamd._lib.MOM_OPT_SMALL_WG, 0)):
         with rtamd.corert.make_handle(m) as h:
             if opt is not None:
                 h.set_option(opt, val)
             out[key] = rtamd.corert.run_scene(h, sc)
-    np.testing.assert_array_equal(out["default"][0], out["nostagger"][0])
-    np.testing.assert_array_equal(out["default"][1], out["nostagger"][1])
+            if key == "default":
+                for _ in range(3):          # back-to-back runs without a host sync in between
+                    h.rt_run()
+                again = h.get_RT()
+                np.testing.assert_array_equal(out[key][0], again[0])
+                np.testing.assert_array_equal(out[key][1], again[1])
+    for other in ("nostagger", "onestream"):
+        np.testing.assert_array_equal(out["default"][0], out[other][0])
+        np.testing.assert_array_equal(out["default"][1], out[other][1])
     helpers.assert_stokes_close(out["wg8"][0], out["default"][0], rtol=1e-11, what="8-wave vs 4-wave m = 0")
     pts = np.arange(0, 2400, 300)
     Rr, Tr = _oracle(cref, m, pts=pts)

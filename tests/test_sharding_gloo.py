@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: two processes, gloo backend.  The sharding + all-gather plumbing of
+"""The N > 1 path on CPU: two and EIGHT processes (the node size north_star names), gloo backend.  The sharding + all-gather plumbing of
 radiativetransfer.jl_amd/sharding.py is exercised with the C oracle standing in for the GPU compute
 (tests may use the oracle); the GPU version of the same property is tests/test_gpu_rt_run.py::
 test_sharded_equals_unsharded_bitwise."""
@@ -30,7 +30,7 @@ def _worker(rank, world, port, S, q):
         # oracle on this rank's points only, with the GLOBAL ndoubl / iface of the unsharded scene
         lo, hi = rtamd.sharding.shard_bounds(scene.S, world, rank)
         assert np.array_equal(shard.ndoubl, scene.ndoubl) and shard.S == hi - lo
-        R, T, info = cref.rt_run(p_full, pts=np.arange(lo, hi, dtype=np.int32), nthreads=2)
+        R, T, info = cref.rt_run(p_full, pts=np.arange(lo, hi, dtype=np.int32), nthreads=1)
         assert info == 0
         return R[:, :, lo:hi], T[:, :, lo:hi]
 
@@ -41,8 +41,8 @@ def _worker(rank, world, port, S, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("S", [10, 7])  # even split and a ragged tail
-def test_two_rank_sharded_run_matches_single(S):
+@pytest.mark.parametrize("S,world", [(10, 2), (7, 2), (32, 8), (29, 8), (6, 8)])  # even split, ragged tail, ranks without points
+def test_sharded_run_matches_single(S, world):
     import torch.multiprocessing as mp
     sys.path.insert(0, str(ROOT / "tests"))
     import rtamd
@@ -53,10 +53,10 @@ def test_two_rank_sharded_run_matches_single(S):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, S, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, S, q)) for r in range(world)]
     for p in procs:
         p.start()
-    R, T = q.get(timeout=180)
+    R, T = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -104,7 +104,7 @@ def _gather_worker(rank, world, port, S, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("S,world", [(10, 2), (7, 2), (2, 3)])  # even, ragged, a rank with no points
+@pytest.mark.parametrize("S,world", [(10, 2), (7, 2), (2, 3), (29, 8), (5, 8)])  # even, ragged, ranks with no points, eight ranks
 def test_gather_spectra_over_gloo(S, world):
     """The collective of the sharded RRS run: one all-gather of the seven spectra of the return tuple (any leading shape)."""
     import torch.multiprocessing as mp
@@ -139,3 +139,65 @@ def test_unpack_rrs_spectra_layout():
     got = rtamd.sharding.unpack_rrs_spectra(G, nV, nS, per, S)
     for x, y in zip(got, full):
         assert np.array_equal(x, y[..., :S])
+
+
+def _rrs_worker(rank, world, port, S, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+    import rtamd
+    import helpers
+    from oracle import cref, momref as mr, rrsref as rr
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene, offs, w = _rrs_case(rtamd, helpers, S)
+    lo, hi, wlo, whi = rtamd.sharding.rrs_window(S, world, rank, offs)
+    assert wlo <= lo and hi <= whi
+    nV, nS = len(scene.vza), scene.pol.n
+    if hi > lo:   # the C oracle on this rank's owned window (its elastic part covers the halo, like the GPU's window run)
+        ora = rr.RRSInputs(offs, w, mr.get_greek_rayleigh(0.2), rrs_strict_reference=False, owned=(lo, hi))
+        loc = [x[..., lo:hi] for x in cref.rt_run_rrs(scene, ora, nthreads=1)[:4]]
+    else:
+        loc = [np.zeros((nV, nS, 0))] * 4
+    full = rtamd.sharding.gather_spectra(loc, S, dist)
+    if rank == world - 1:
+        q.put(full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _rrs_case(rtamd, helpers, S):
+    m = rtamd.scenes.make_scene(3, 5, 3, S, seed=31, aerosol_total=0.1, vza=(30.0,), vaz=(20.0,))
+    scene = helpers.oracle_scene(m)
+    scene.varpi_cabannes = 0.96
+    offs = np.array([-5, -2, 3, 6], dtype=np.int64)
+    return scene, offs, 0.02 * (1.0 + 0.1 * np.arange(4))
+
+
+@pytest.mark.parametrize("S,world", [(30, 2), (37, 8)])
+def test_rrs_windows_and_gather_over_gloo(S, world):
+    """rt_run(::RRS) sharded over 2 and 8 processes: sharding.rrs_window (owned slice + halo of max |i_l1l0|), the C oracle's
+    owned-window run standing in for the GPU's, one all-gather of the spectra (sharding.gather_spectra): bitwise the
+    single-process run."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, str(ROOT / "tests"))
+    import rtamd
+    import helpers
+    from oracle import cref, momref as mr, rrsref as rr
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rrs_worker, args=(r, world, port, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    scene, offs, w = _rrs_case(rtamd, helpers, S)
+    ref = cref.rt_run_rrs(scene, rr.RRSInputs(offs, w, mr.get_greek_rayleigh(0.2), rrs_strict_reference=False), nthreads=1)
+    assert np.abs(ref[2]).max() > 0
+    for k in range(4):
+        assert np.array_equal(full[k], ref[k]), k

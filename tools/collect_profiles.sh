@@ -3,7 +3,7 @@
 # (FETCH_SIZE and WRITE_SIZE in separate passes, MFMA-busy in a third: MI355X_MICROARCH.md, rocprofv3 PMC slots; never
 # combined with a trace domain other than --kernel-trace).  Output goes to gpurun_out/<round>_*;
 # tools/summarize_profiles.py turns it into profiles/.
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
@@ -14,7 +14,9 @@ run() {  # tag, bench args...
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${ROUND}_${tag}_write -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/${ROUND}_${tag}_mfma -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1 || true
 }
-run C2 --workload C2
+# C2: --opt 9=0 = MOM_OPT_OVERLAP off: under the kernel trace the two problem sizes run one after the other, so that the
+# per-kernel durations are those of bench.py's roofline block (which takes them from serialized steps as well)
+run C2 --workload C2 --opt 9=0
 run C4 --workload C4 --points 512 --steps 2
 run C1 --workload C1
 run C5 --workload C5
