@@ -295,8 +295,16 @@ def elastic_leg(a, workload, S_loc, steps, warmup, world, rank, dev, dist, with_
                             "counter_frac_of_8TBps": (ctr / launch_s / 1e9 / PEAK_HBM_GBS) if ctr else None}}
         else:
             achieved = flop_dom / (tm["full_layers_ms"] * 1e-3) / 1e12
+            # counter traffic of the committed PMC pass, brought to THIS run's size: the dominant launch moves the composite
+            # state (and, N > 64, the slabs) of its own units, so its bytes are proportional to the spectral points of the
+            # launch (the S = 512 figure was printed next to the duration of an S = 256 launch)
+            traffic, traffic_note = prof.get("hbm_bytes_per_launch"), None
+            if traffic and prof.get("points") and prof["points"] != S_loc:
+                traffic = traffic * S_loc / prof["points"]
+                traffic_note = (f"scaled by {S_loc} / {prof['points']} from the PMC pass at {prof['points']} points "
+                                f"({prof['hbm_bytes_per_launch']:.4g} B per launch there)")
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": prof.get("hbm_bytes_per_launch"),
+                    "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": prof.get("kernel", "full-problem layer kernel"),
                     "avg_launch_ms": tm["full_layers_ms"] / max(tm["full_launches"], 1),
                     "launches_per_step": tm["full_launches"], "moments_per_launch": m_dom,

@@ -425,12 +425,14 @@ int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
  *                         image is padded with up to 4 decoupled dummy stream entries (mu = 1, weight 0, zero
  *                         phase-matrix rows and columns) when that reaches a size with one (36, 40, 44, 52, 56, 60);
  *                         results for the real streams are unchanged; 0 = run the edge as given
- *   MOM_OPT_LEAN          operators of edge 36 / 40 (Float64, layer-sweep mode, ScatteringInterface_11 after the first layer):
- *                         1 (default) = the four-wave LEAN strip image (three operator buffers, 168 registers: three workgroups per
- *                         CU; bitwise the full image's strip path), 2 = the six-wave lean image (doubling chains on half-strips, two
- *                         workgroups per CU, three chain waves on every SIMD: an experiment, measured slower), each followed by one
- *                         launch of the full image that finishes the units the lean one left (series beyond 12 terms) -- TWO launches
- *                         per sweep, both counted in mom_timers' kernel_launches; 0 = the full image only.
+ *   MOM_OPT_LEAN          operators of edge 36 / 40 (Float64, layer-sweep mode, ScatteringInterface_11 after the first layer; the
+ *                         m = 0 (I,Q) sub-problem of a 20-stream IQU scene is one): which image runs them before the full image
+ *                         finishes whatever it left (series beyond 12 terms) -- TWO launches per sweep, both counted in mom_timers'
+ *                         kernel_launches.  3 (default, r6) = the QUAD-BLOCK image: one wavefront per unit, products on
+ *                         v_mfma_f64_4x4x4 (no padding at N = 40, no idle SIMD), four units per CU (csrc/mom_q4.hpp); needs two or
+ *                         more Stokes components per stream, else falls to 1; 1 = the four-wave LEAN strip image (three operator
+ *                         buffers, 168 registers: three workgroups per CU; bitwise the full image's strip path); 2 = the six-wave lean
+ *                         image (doubling chains on half-strips: an experiment, measured slower); 0 = the full image only.
  *   MOM_OPT_OVERLAP       1 (default) = when Fourier moment 0 runs on the (I,Q) sub-problem (MOM_OPT_M0_REDUCTION) in layer-sweep
  *                         mode, its launches and its surface interaction go to a second, high-priority stream of the handle and
  *                         overlap the launch of moments 1..M-1: the partial last round of the persistent workgroups of either

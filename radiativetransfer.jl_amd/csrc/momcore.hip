@@ -307,6 +307,11 @@ hipError_t mom6_lean9_launch(const void *layer_args, int grid, hipStream_t st); 
 hipError_t mom6_lean10_launch(const void *layer_args, int grid, hipStream_t st);
 size_t mom6_lean9_lds_bytes(int ns);
 size_t mom6_lean10_lds_bytes(int ns);
+// the quad-block image (momcore_q4.hip, mom_q4.hpp): one wavefront per unit, v_mfma_f64_4x4x4 products, four units per CU
+hipError_t momq_q4_9_launch(const void *layer_args, int grid, hipStream_t st);
+hipError_t momq_q4_10_launch(const void *layer_args, int grid, hipStream_t st);
+size_t momq_q4_9_lds_bytes(int ns, int K);
+size_t momq_q4_10_lds_bytes(int ns, int K);
 hipError_t mom_strip11_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom4_strip11_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);  // 4-wave build of N = 44
 hipError_t mom_strip13_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
@@ -411,7 +416,8 @@ struct mom_handle {
   double *d_ms_out = nullptr;  // [2][nVza*nS*S*nSensors]
   size_t ms_out_cap = 0;
   int opt_pad = 1;         // scene-level path: pad the operator edge to the next strip-chained kernel size (strip_pad)
-  int opt_lean = 1;        // N = 36, 40: 1 = the four-wave lean strip image (three workgroups per CU), 2 = the six-wave one (half-strip
+  int opt_lean = 3;        // N = 36, 40: 3 = the quad-block image (one wavefront per unit, 4 x 4 x 4 MFMA blocks, four units per CU;
+                           // mom_q4.hpp), 1 = the four-wave lean strip image (three workgroups per CU), 2 = the six-wave one (half-strip
                            // doubling chains, two per CU: measured slower, profiles/r05_mid_ab.txt), each followed by the full image's
                            // resume launch; 0 = the full image only
   int *d_resume = nullptr; // resume[unit] of the lean image (mom_lean.hpp)
@@ -1472,7 +1478,8 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
             h->resume_cap = units;
           }
           a.resume = h->d_resume;
-          const bool six = h->opt_lean >= 2 && (q.N == 40 ? mom6_lean10_lds_bytes(ns_tab) : mom6_lean9_lds_bytes(ns_tab)) > 0;
+          const bool quad = h->opt_lean >= 3 && (q.N == 40 ? momq_q4_10_lds_bytes(ns_tab, h->K) : momq_q4_9_lds_bytes(ns_tab, h->K)) > 0;
+          const bool six = !quad && h->opt_lean == 2 && (q.N == 40 ? mom6_lean10_lds_bytes(ns_tab) : mom6_lean9_lds_bytes(ns_tab)) > 0;
 #ifdef MOM_EXPERIMENTS
           static const int lean_per_cu = getenv("MOM_LEAN_PER_CU") ? atoi(getenv("MOM_LEAN_PER_CU")) : 0;
 #else
@@ -1480,7 +1487,8 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
 #endif
           const int per_cu = lean_per_cu > 0 ? lean_per_cu : (six ? 2 : 3);
           const int gridl = (int)std::min<size_t>(units, (size_t)per_cu * h->num_cu);
-          if (six) HIPCHK(h, (q.N == 40 ? mom6_lean10_launch : mom6_lean9_launch)(&a, gridl, cur));
+          if (quad) HIPCHK(h, (q.N == 40 ? momq_q4_10_launch : momq_q4_9_launch)(&a, (int)std::min<size_t>(units, (size_t)4 * h->num_cu), cur));
+          else if (six) HIPCHK(h, (q.N == 40 ? mom6_lean10_launch : mom6_lean9_launch)(&a, gridl, cur));
           else HIPCHK(h, (q.N == 40 ? mom_strip10_launch_lean : mom_strip9_launch_lean)(&a, gridl, cur));
           h->launches++;
         }

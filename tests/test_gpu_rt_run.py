@@ -150,7 +150,7 @@ def test_lean_strip_image_and_resume(rtamd, cref, nS, lt, N, thick):
     sc = rtamd.prepare_scene(m)
     assert sc.N == N
     out = {}
-    for lean in (2, 1, 0):
+    for lean in (3, 2, 1, 0):
         with rtamd.corert.make_handle(m) as h:
             h.set_option(rtamd._lib.MOM_OPT_LEAN, lean)
             R, T = rtamd.corert.run_scene(h, sc)
@@ -159,13 +159,17 @@ def test_lean_strip_image_and_resume(rtamd, cref, nS, lt, N, thick):
             assert np.array_equal(R, R2) and np.array_equal(T, T2)
     for k in range(5):
         assert np.array_equal(out[1][k], out[0][k]), f"four-wave lean vs full image, output {k}"
-    assert out[1][5] > out[0][5] and out[2][5] > out[0][5]               # the lean launch + the resume launch
+    assert out[1][5] > out[0][5] and out[2][5] > out[0][5] and out[3][5] > out[0][5]   # the lean launch + the resume launch
     Rr, Tr = _oracle(cref, m)
     tol = helpers.stokes_rtol(sc.ndoubl)
-    for lean in (2, 1):   # the six-wave image sums a contraction in two halves: equal to the oracle's tolerance, not bitwise
+    # the six-wave image sums a contraction in two halves, the quad-block image (= 3: one wavefront per unit, 4 x 4 x 4 MFMA
+    # blocks; csrc/mom_q4.hpp) in blocks of four: equal to the oracle's tolerance, not bitwise
+    for lean in (3, 2, 1):
         helpers.assert_stokes_close(out[lean][0], Rr, rtol=tol, what=f"R lean={lean}")
         helpers.assert_stokes_close(out[lean][1], Tr, rtol=tol, what=f"T lean={lean}")
     helpers.assert_stokes_close(out[2][2], out[0][2], rtol=tol, what="hdr six-wave lean vs full")
+    helpers.assert_stokes_close(out[3][2], out[0][2], rtol=tol, what="hdr quad-block vs full")
+    helpers.assert_stokes_close(out[3][0], out[0][0], rtol=min(tol, 1e-10), what="R quad-block vs full")
 
 
 def test_strip_chains_thick_layers_fall_back(rtamd, cref):

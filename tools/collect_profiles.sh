@@ -9,6 +9,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 run() {  # tag, bench args...
   local tag=$1; shift
+  echo "$@" > $O/${ROUND}_${tag}_args.txt   # tools/summarize_profiles.py records --points of the PMC passes in traffic.json
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${ROUND}_${tag}_stats -o p -- python3 $R/bench.py "$@" --no-cpu-baseline --no-voigt --no-extras > $O/${ROUND}_${tag}_bench_under_rocprof.json 2> /dev/null
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/${ROUND}_${tag}_fetch -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${ROUND}_${tag}_write -o p -- python3 $R/bench.py "$@" --steps 1 --warmup 1 --no-cpu-baseline --no-voigt --no-extras > /dev/null 2>&1
@@ -17,7 +18,7 @@ run() {  # tag, bench args...
 # C2: --opt 9=0 = MOM_OPT_OVERLAP off: under the kernel trace the two problem sizes run one after the other, so that the
 # per-kernel durations are those of bench.py's roofline block (which takes them from serialized steps as well)
 run C2 --workload C2 --opt 9=0
-run C4 --workload C4 --points 512 --steps 2
+run C4 --workload C4 --points 256 --steps 2   # the size of the default bench line's C4 leg
 run C1 --workload C1
 run C5 --workload C5
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${ROUND}_voigt_stats -o p -- python3 $R/bench_voigt.py > $O/${ROUND}_bench_voigt.json 2> /dev/null

@@ -13,7 +13,7 @@ import collections, csv, glob, json, os, shutil, subprocess, sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 try:
     commit = subprocess.check_output(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
@@ -83,6 +83,12 @@ for wl in ("C2", "C4", "C1", "C5", "voigt", "rrs_nt"):
         t["note"] = ("the LARGEST launch of the dominant kernel where its launches differ by more than 2 x, else the last one of the "
                      "counter pass (one warm-up + one profiled step; more than 64 launches: their mean); FETCH_SIZE "
                      "doubled per MI355X_MICROARCH.md; layer-sweep mode: ONE launch of the kernel covers all layers of the step")
+        af = ROOT / "gpurun_out" / f"{rnd}_{wl}_args.txt"     # the bench arguments of the counter passes (collect_profiles.sh)
+        if af.exists():
+            args = af.read_text().split()
+            t["bench_args"] = " ".join(args)
+            if "--points" in args:
+                t["points"] = int(args[args.index("--points") + 1])
         traffic[wl] = t
 (out / f"{rnd}_pmc_summary.json").write_text(json.dumps(summ, indent=1))
 (out / "traffic.json").write_text(json.dumps(traffic, indent=1))
