@@ -432,6 +432,14 @@ def c5_leg(a, S, steps, warmup, dev, with_cpu=True, world=1, rank=0, dist=None):
     ms, nl = tk["dbl_pair"]
     avg = ms / max(nl, 1)
     gbs = pairs * bytes_pair / (avg * 1e-3) / 1e9
+    # the interaction pair kernel (interface 11; VERDICT r5: it had no roofline entry): per pair the four composite blocks ieR-+,
+    # ieR+-, ieT++, ieT-- in and out, the added layer's ier-+, iet++ in (ier+-, iet-- are derived from them in the corrected
+    # position, read as well in the strict one), ieJ0+- of the composite in and out and of the added layer in
+    blocks_int = 8 + (4 if RS.rrs_strict_reference else 2)
+    bytes_pair_int = (blocks_int * N * N + 6 * N) * 8
+    ms_i, nl_i = tk["int_pair"]
+    avg_i = ms_i / max(nl_i, 1)
+    gbs_i = pairs * bytes_pair_int / (avg_i * 1e-3) / 1e9 if nl_i else 0.0
     out = None
     if rank == 0:
         prof = {}
@@ -453,6 +461,10 @@ def c5_leg(a, S, steps, warmup, dev, with_cpu=True, world=1, rank=0, dist=None):
                             "pmc_source": ("profiles/traffic.json: " + prof.get("source", prof.get("round", "?"))) if prof else None,
                             "avg_launch_ms": avg, "launches_per_step": nl, "pairs_per_launch": pairs,
                             "algorithmic_bytes_per_pair": bytes_pair, "algorithmic_bytes_per_avg_launch": pairs * bytes_pair},
+               "roofline_int_pair": {"bound": "hbm", "achieved": gbs_i, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs_i / PEAK_HBM_GBS,
+                                     "kernel": "momr::k_int_pair1<...> (one-tile interaction pair kernel, interface 11)",
+                                     "avg_launch_ms": avg_i, "launches_per_step": nl_i, "pairs_per_launch": pairs,
+                                     "algorithmic_bytes_per_pair": bytes_pair_int},
                "stages_ms": {"dbl_pair_ms": tk["dbl_pair"][0], "int_pair_ms": tk["int_pair"][0],
                              "ie_elemental_ms": tk["ie_elemental"][0], "total_ms": tk["total"][0]}}
     h.close()

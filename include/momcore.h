@@ -434,7 +434,8 @@ int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
  *                         buffers, 168 registers: three workgroups per CU; bitwise the full image's strip path); 2 = the six-wave lean
  *                         image (doubling chains on half-strips: an experiment, measured slower); 0 = the full image only.
  *   MOM_OPT_OVERLAP       1 (default) = when Fourier moment 0 runs on the (I,Q) sub-problem (MOM_OPT_M0_REDUCTION) in layer-sweep
- *                         mode, its launches and its surface interaction go to a second, high-priority stream of the handle and
+ *                         mode AND the full problem runs on a one-workgroup-per-CU strip image (operator edge 52, 56, 60: the two
+ *                         kernels then cannot share a CU; where they can, overlapping them measured slower), its launches and its surface interaction go to a second, high-priority stream of the handle and
  *                         overlap the launch of moments 1..M-1: the partial last round of the persistent workgroups of either
  *                         launch is filled by the other; results are unchanged (the launches are independent); mom_timers then
  *                         reports overlapping intervals for the two.  0 = everything on the handle's one stream.

@@ -1528,7 +1528,11 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
   // high-priority stream; the full problem's workgroups take the CUs as the sub-problem's last round frees them, and the
   // workgroups that start late are those with the highest indices -- the ones WITHOUT a unit in the full problem's own partial
   // round.  The images cannot share a CU (149 + 48.5 KB of LDS), so nothing else overlaps.
-  const bool two = red0 && can_sweep && h->opt_overlap && M > 1 && !tg && h->stream2;
+  // ... and only then: where the two kernels CAN share a CU they contend for its matrix pipes and LDS bandwidth and the sweep
+  // takes longer than the two launches in sequence (profiles/r06_C2_ab.txt (b'): N = 36 .. 44 with the m = 0 problem on the
+  // wave-per-point kernel 28 -> 45 ms, C4 -5 %), so the overlap is reserved for the persistent one-per-CU strip images
+  const bool two = red0 && can_sweep && h->opt_overlap && M > 1 && !tg && h->stream2 && !h->opt_force_generic &&
+                   (Nk == 52 || Nk == 56 || Nk == 60);
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   for (int z = (can_sweep ? -1 : za); z < (can_sweep ? 0 : zb); ++z) {
     int rc;
