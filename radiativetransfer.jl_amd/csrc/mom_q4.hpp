@@ -44,7 +44,8 @@ __host__ __device__ inline size_t q4_lds_bytes(int N) { return ((size_t)3 * N * 
 // table space of the elemental layer inside P: E | F1 | F2 (3 Nq^2), the sun-block columns (2 ns N), the layer's scalars (3 + K)
 __host__ __device__ inline bool q4_applies(int N, int ns, int K) {
   const int Nq = N / (ns > 0 ? ns : 1);
-  return kF64 && (N == 36 || N == 40) && ns >= 2 && 3 * Nq * Nq + 2 * ns * N + 3 + K <= N * N && 4 * q4_lds_bytes(N) <= kLdsPerCU;
+  return kF64 && N >= 20 && N <= 40 && N % 4 == 0 && ns >= 2 && N % ns == 0 && 3 * Nq * Nq + 2 * ns * N + 3 + K <= N * N &&
+         4 * q4_lds_bytes(N) <= kLdsPerCU;
 }
 
 // lane coordinates of the D / B layout
@@ -549,8 +550,15 @@ __device__ __forceinline__ bool interaction_q4(Ctx &c, const CompPtrs &g) {
 }
 
 // One launch walks all layers of every unit (sweep mode only), one unit per wavefront.
+// KS >= 9: one wave per SIMD (512 registers: an operator is 54 / 60 of them); smaller edges leave the register budget, and with it
+// the number of units per SIMD, to the compiler (an operator of edge 20 .. 32 is 10 .. 16 registers)
+#if MOM_STRIP_KS >= 9
+#define MOM_Q4_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))
+#else
+#define MOM_Q4_ATTR
+#endif
 template <int KS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_layer_q4(const LayerArgs a) {
+__global__ void __launch_bounds__(64) MOM_Q4_ATTR k_layer_q4(const LayerArgs a) {
   using G = Q4Geom<KS>;
   constexpr int N = G::N;
   const size_t total = (size_t)a.S * a.M;

@@ -308,10 +308,30 @@ hipError_t mom6_lean10_launch(const void *layer_args, int grid, hipStream_t st);
 size_t mom6_lean9_lds_bytes(int ns);
 size_t mom6_lean10_lds_bytes(int ns);
 // the quad-block image (momcore_q4.hip, mom_q4.hpp): one wavefront per unit, v_mfma_f64_4x4x4 products, four units per CU
-hipError_t momq_q4_9_launch(const void *layer_args, int grid, hipStream_t st);
-hipError_t momq_q4_10_launch(const void *layer_args, int grid, hipStream_t st);
-size_t momq_q4_9_lds_bytes(int ns, int K);
-size_t momq_q4_10_lds_bytes(int ns, int K);
+#define MOM_Q4_DECL(KS)                                                                  \
+  hipError_t momq_q4_##KS##_launch(const void *layer_args, int grid, hipStream_t st);     \
+  size_t momq_q4_##KS##_lds_bytes(int ns, int K);                                         \
+  int momq_q4_##KS##_per_cu();
+MOM_Q4_DECL(5) MOM_Q4_DECL(6) MOM_Q4_DECL(7) MOM_Q4_DECL(8) MOM_Q4_DECL(9) MOM_Q4_DECL(10)
+#undef MOM_Q4_DECL
+// the image of operator edge N = 4 KS: LDS bytes (0: does not apply), launch, workgroups per CU
+static size_t q4_image_lds(int N, int ns, int K) {
+  switch (N) {
+    case 20: return momq_q4_5_lds_bytes(ns, K); case 24: return momq_q4_6_lds_bytes(ns, K); case 28: return momq_q4_7_lds_bytes(ns, K);
+    case 32: return momq_q4_8_lds_bytes(ns, K); case 36: return momq_q4_9_lds_bytes(ns, K); case 40: return momq_q4_10_lds_bytes(ns, K);
+    default: return 0;
+  }
+}
+static hipError_t q4_image_launch(int N, const void *args, int num_cu, size_t units, hipStream_t st) {
+  static int per_cu[6] = {0, 0, 0, 0, 0, 0};   // (per process: the occupancy of an image does not depend on the handle)
+  const int k = N / 4 - 5;
+  if (per_cu[k] == 0)
+    per_cu[k] = (N == 20 ? momq_q4_5_per_cu : N == 24 ? momq_q4_6_per_cu : N == 28 ? momq_q4_7_per_cu : N == 32 ? momq_q4_8_per_cu
+                 : N == 36 ? momq_q4_9_per_cu : momq_q4_10_per_cu)();
+  const int grid = (int)std::min<size_t>(units, (size_t)per_cu[k] * num_cu);
+  return (N == 20 ? momq_q4_5_launch : N == 24 ? momq_q4_6_launch : N == 28 ? momq_q4_7_launch : N == 32 ? momq_q4_8_launch
+          : N == 36 ? momq_q4_9_launch : momq_q4_10_launch)(args, grid, st);
+}
 hipError_t mom_strip11_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
 hipError_t mom4_strip11_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);  // 4-wave build of N = 44
 hipError_t mom_strip13_launch_layer(const void *layer_args, int iface, int grid, size_t smem, hipStream_t st);
@@ -686,7 +706,7 @@ extern "C" int mom_set_option(mom_t *h, int option, int value) {
   else if (option == MOM_OPT_SMALL_N) { h->opt_small = value; h->scene_set = false; }  // the padded edge Nk depends on it
   else if (option == MOM_OPT_LAYER_SWEEP) h->opt_sweep = value;
   else if (option == MOM_OPT_STRIP_PAD) { h->opt_pad = value; h->scene_set = false; }
-  else if (option == MOM_OPT_LEAN) h->opt_lean = value;
+  else if (option == MOM_OPT_LEAN) { h->opt_lean = value; h->scene_set = false; }  // the padded edge of the m = 0 sub-problem depends on it
   else if (option == MOM_OPT_OVERLAP) h->opt_overlap = value;
   else if (option == MOM_OPT_RRS_KERNELS) {
     if (value < 0 || value > 63 || ((value & momr::KOPT_EL_FUSE_ON) && (value & momr::KOPT_EL_FUSE_OFF)))
@@ -1202,7 +1222,11 @@ static int scene_common(mom_t *h, int Nz, int K, int M, const double *Zpp, const
     h->red0 = ok;
     if (ok) {
       // N0r real entries; the kernels run on N0 >= N0r (dummy entries of strip_pad at the end: mu = 1, weight 0, Z = 0)
-      const int nS0 = 2, N0r = nS0 * Nq, N0 = h->opt_pad ? strip_pad(N0r) : N0r;
+      const int nS0 = 2, N0r = nS0 * Nq;
+      int N0 = h->opt_pad ? strip_pad(N0r) : N0r;
+      // r6: sub-problems of edge 18 .. 30 that are not a multiple of 4 take ONE dummy stream (two entries) to reach a quad-block
+      // size (20, 24, 28, 32: mom_q4.hpp; IQUV scenes of 9 .. 15 streams)
+      if (h->opt_pad && h->opt_lean >= 3 && N0 == N0r && N0r > 16 && N0r < 32 && (N0r % 4) != 0) N0 = N0r + 2;
       h->N0 = N0; h->nS0 = nS0;
       std::vector<double> mu0v(N0, 1.0), wt0v(N0, 0.0), sg0v(N0, 1.0), zp((size_t)N0 * N0 * K, 0.0), zm((size_t)N0 * N0 * K, 0.0);
       auto full = [&](int i0) { return (i0 / nS0) * nS + (i0 % nS0); };
@@ -1463,6 +1487,24 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
     if (lds && h->opt_w4 && np_for(q.N) <= 48 &&
         2 * (strip4 ? mom4_strip_lds_bytes(q.N, ns_tab) : mom4_lds_bytes(q.N, true)) + 2048 <= 160 * 1024) {
       const int grid4 = (int)((S >= 2048) ? S : S * Mcount);
+      // operator edges 20 .. 32 (multiples of 4) on the quad-block image first (mom_q4.hpp), the general 4-wave image finishes what
+      // it left; the edges 36 / 40 take the same route below, with the strip image as the finisher
+      if (!strip4 && h->opt_lean >= 3 && sweep && !tg && q.inv_mode == 0 && q4_image_lds(q.N, ns_tab, h->K) > 0) {
+        bool quad = true;
+        for (int k = 1; k < nzr && quad; ++k) quad = (a.iface_z[k] == 3);
+        if (quad && !a.first) quad = (a.iface_z[0] == 3);
+        if (quad) {
+          const size_t units = S * (size_t)Mcount;
+          if (units > h->resume_cap) {  // grow-only
+            if (h->d_resume) { HIPCHK(h, hipStreamSynchronize(cur)); (void)hipFree(h->d_resume); h->d_resume = nullptr; h->resume_cap = 0; }
+            HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&h->d_resume), units * sizeof(int)));
+            h->resume_cap = units;
+          }
+          a.resume = h->d_resume;
+          HIPCHK(h, q4_image_launch(q.N, &a, h->num_cu, units, cur));
+          h->launches++;
+        }
+      }
       if (strip4) {  // strip-chained kernels of the 4-wave build (momcore_strip.hip)
         const int gridp = (int)std::min<size_t>(S * Mcount, (size_t)2 * h->num_cu);  // persistent, two per CU
         // N = 36, 40: the lean image first (three workgroups per CU; mom_lean.hpp), then the full image resumes what it left
@@ -1478,7 +1520,7 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
             h->resume_cap = units;
           }
           a.resume = h->d_resume;
-          const bool quad = h->opt_lean >= 3 && (q.N == 40 ? momq_q4_10_lds_bytes(ns_tab, h->K) : momq_q4_9_lds_bytes(ns_tab, h->K)) > 0;
+          const bool quad = h->opt_lean >= 3 && q4_image_lds(q.N, ns_tab, h->K) > 0;
           const bool six = !quad && h->opt_lean == 2 && (q.N == 40 ? mom6_lean10_lds_bytes(ns_tab) : mom6_lean9_lds_bytes(ns_tab)) > 0;
 #ifdef MOM_EXPERIMENTS
           static const int lean_per_cu = getenv("MOM_LEAN_PER_CU") ? atoi(getenv("MOM_LEAN_PER_CU")) : 0;
@@ -1487,7 +1529,7 @@ static int rt_run_core(mom_t *h, int za, int zb, bool allow_red, double *const c
 #endif
           const int per_cu = lean_per_cu > 0 ? lean_per_cu : (six ? 2 : 3);
           const int gridl = (int)std::min<size_t>(units, (size_t)per_cu * h->num_cu);
-          if (quad) HIPCHK(h, (q.N == 40 ? momq_q4_10_launch : momq_q4_9_launch)(&a, (int)std::min<size_t>(units, (size_t)4 * h->num_cu), cur));
+          if (quad) HIPCHK(h, q4_image_launch(q.N, &a, h->num_cu, units, cur));
           else if (six) HIPCHK(h, (q.N == 40 ? mom6_lean10_launch : mom6_lean9_launch)(&a, gridl, cur));
           else HIPCHK(h, (q.N == 40 ? mom_strip10_launch_lean : mom_strip9_launch_lean)(&a, gridl, cur));
           h->launches++;

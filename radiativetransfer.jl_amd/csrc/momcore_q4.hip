@@ -23,6 +23,14 @@ hipError_t MOM_CAT(MOM_CAT(momq_q4_, MOM_STRIP_KS), _launch)(const void *layer_a
   hipLaunchKernelGGL((k_layer_q4<MOM_STRIP_KS>), dim3(grid), dim3(64), smem, st, a);
   return hipGetLastError();
 }
+// workgroups of this image a CU holds: by LDS and by the registers the compiler gave the kernel (occupancy API)
+int MOM_CAT(MOM_CAT(momq_q4_, MOM_STRIP_KS), _per_cu)() {
+  int nb = 0;
+  const size_t smem = q4_lds_bytes(4 * MOM_STRIP_KS);
+  if (mom_allow_lds(reinterpret_cast<const void *>(k_layer_q4<MOM_STRIP_KS>), smem) != hipSuccess) return 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_layer_q4<MOM_STRIP_KS>, 64, smem) != hipSuccess || nb < 1) return 4;
+  return nb;
+}
 // LDS bytes of one (one-wave) workgroup; 0 if the image does not apply to ns Stokes components per stream and K phase-matrix bases
 size_t MOM_CAT(MOM_CAT(momq_q4_, MOM_STRIP_KS), _lds_bytes)(int ns, int K) {
   return q4_applies(4 * MOM_STRIP_KS, ns, K) ? q4_lds_bytes(4 * MOM_STRIP_KS) : 0;

@@ -172,6 +172,36 @@ def test_lean_strip_image_and_resume(rtamd, cref, nS, lt, N, thick):
     helpers.assert_stokes_close(out[3][0], out[0][0], rtol=min(tol, 1e-10), what="R quad-block vs full")
 
 
+@pytest.mark.parametrize("nS,lt,N,small,kw", [
+    (4, 3, 20, 0, {}), (4, 5, 24, 0, {}), (4, 7, 28, 0, dict(aerosol_total=0.8)), (4, 9, 32, 0, {}), (3, 9, 24, 0, {}),   # full problems
+    (4, 17, 48, 1, {}), (4, 21, 56, 1, {}), (4, 23, 60, 1, {}), (4, 19, 52, 1, dict(aerosol_total=2.0, aerosol_p0=600.0, aerosol_σp=200.0)),
+    (3, 23, 45, 1, {})])                                                                                                  # m = 0 sub-problems
+def test_quad_block_image_small_edges(rtamd, cref, nS, lt, N, small, kw):
+    """The quad-block image (csrc/mom_q4.hpp) at the edges 20 .. 32: full problems on the general route (MOM_OPT_SMALL_N = 0; the
+    wave-per-point kernel is the default there) and the m = 0 (I,Q) sub-problems of larger IQUV / IQU scenes (N0 = 24, 28, 30 -> 32
+    by one dummy stream, 26 -> 28; a thick scene whose late steps go to the finishing launch of the general image), against the
+    oracle and against MOM_OPT_LEAN = 1 (no quad-block image)."""
+    m = rtamd.scenes.make_scene(nS, lt, 6, 48, seed=5 * nS + lt, **kw)
+    sc = rtamd.prepare_scene(m)
+    assert sc.N == N
+    Rr, Tr, Hr, upr, dwr, info = cref.rt_run_full(cref.pack_scene(helpers.oracle_scene(m)))
+    assert info == 0
+    out = {}
+    for lean in (3, 1):
+        with rtamd.corert.make_handle(m) as h:
+            h.set_option(rtamd._lib.MOM_OPT_SMALL_N, small)
+            h.set_option(rtamd._lib.MOM_OPT_LEAN, lean)
+            R, T = rtamd.corert.run_scene(h, sc)
+            out[lean] = (R, T) + h.get_hdr() + (h.timers()["layer_launches"],)
+    assert out[3][5] >= out[1][5]                     # the quad-block launch + the finishing launch behind it
+    tol = helpers.stokes_rtol(sc.ndoubl)
+    for lean in (3, 1):
+        helpers.assert_stokes_close(out[lean][0], Rr, rtol=tol, what=f"R lean={lean}")
+        helpers.assert_stokes_close(out[lean][1], Tr, rtol=tol, what=f"T lean={lean}")
+        helpers.assert_stokes_close(out[lean][2], Hr, rtol=tol, what=f"hdr lean={lean}")
+        np.testing.assert_allclose(out[lean][4], dwr, rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
+
+
 def test_strip_chains_thick_layers_fall_back(rtamd, cref):
     """optically thick scattering layers: the series length exceeds the strip chains' limit for part of the
     doubling steps and interactions, which must then take the general path inside the same kernels"""
