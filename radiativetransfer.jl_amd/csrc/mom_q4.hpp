@@ -44,7 +44,8 @@ __host__ __device__ inline size_t q4_lds_bytes(int N) { return ((size_t)3 * N * 
 // table space of the elemental layer inside P: E | F1 | F2 (3 Nq^2), the sun-block columns (2 ns N), the layer's scalars (3 + K)
 __host__ __device__ inline bool q4_applies(int N, int ns, int K) {
   const int Nq = N / (ns > 0 ? ns : 1);
-  return kF64 && N >= 20 && N <= 40 && N % 4 == 0 && ns >= 2 && N % ns == 0 && 3 * Nq * Nq + 2 * ns * N + 3 + K <= N * N &&
+  return kF64 && N >= 20 && N <= 40 && N % 4 == 0 && ns >= 2 && N % ns == 0 && K <= 60 &&   // (3 + K layer scalars: one lane each)
+         3 * Nq * Nq + 2 * ns * N + 3 + K <= N * N &&
          4 * q4_lds_bytes(N) <= kLdsPerCU;
 }
 
