@@ -1130,6 +1130,11 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
   real bp0[8], bm0[8], bp1[8], bm1[8];
   int ii[8], jj[8];
   bool ok[8];
+  // r6 (quad-block image: ONE wave per workgroup, nobody to hide a load behind): the two-term path keeps the coordinates of the
+  // batch it is computing apart from those of the batch it has already requested
+  constexpr bool kPipeZ = (kWaves == 1);
+  int ci[8], cj[8];
+  bool cok[8];
   auto coords = [&](int s0) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1190,7 +1195,7 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
     }
     // Z = sum_k w_k Z_k, accumulated in k order
     if (pre) {
-      if (s0 != 0) issue_z2(s0);
+      if (!kPipeZ && s0 != 0) issue_z2(s0);
       const real wp0 = Zpp.weight(0), wm0 = Zmp.weight(0), wp1 = Zpp.weight(1), wm1 = Zmp.weight(1);
 #pragma unroll
       for (int u = 0; u < 8; ++u)
@@ -1200,6 +1205,11 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
           zp[u] += wp1 * bp1[u];
           zm[u] += wm1 * bm1[u];
         }
+      if constexpr (kPipeZ) {   // one-wave workgroups: the next batch's 32 basis loads travel under this batch's element math
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ci[u] = ii[u]; cj[u] = jj[u]; cok[u] = ok[u]; }
+        if (s0 + 8 < slots) issue_z2(s0 + 8);
+      }
     } else {
       // the (run-time) sum over scatterer types is the OUTER loop: the 16 basis loads of a term are in flight together
       coords(s0);
@@ -1221,8 +1231,9 @@ __device__ __forceinline__ void elemental_build(const Ctx &c, const DevStreams &
       constexpr bool TAB = decltype(tabc)::value;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        if (ok[u]) {
-          const int i = ii[u], j = jj[u];
+        const bool pz = kPipeZ && pre;
+        if (pz ? cok[u] : ok[u]) {
+          const int i = pz ? ci[u] : ii[u], j = pz ? cj[u] : jj[u];
           if (j >= i_start && j < i_end) {
             ZS[i + (j - i_start) * N] = zp[u];
             ZS[i + (n + j - i_start) * N] = zm[u];
