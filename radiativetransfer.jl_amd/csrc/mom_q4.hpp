@@ -229,10 +229,29 @@ __device__ __forceinline__ void q4_mul_z(const real *M, const real (&X)[Q4Geom<K
 // Y = sum_{k < p} (M^T)^k C0 by Horner, Y <- C0 + M^T Y starting from Y = C0: p - 1 products at ONE product site (a second site
 // for alternating registers, i.e. no copy at all, measured slower: 128 KB of code and 105 spilled registers, 60.9 -> 64.5 ms on the
 // C2 m = 0 launch); the initial value is the first k-block's C operand, so a round costs one copy of the running value, not two
+#ifndef Q4_HORNER_SITES
+#define Q4_HORNER_SITES 1
+#endif
 template <int KS>
 __device__ __forceinline__ void q4_horner(const real *M, const real (&C0)[Q4Geom<KS>::NB][Q4Geom<KS>::NJ], int p,
                                           real (&Y)[Q4Geom<KS>::NB][Q4Geom<KS>::NJ]) {
   q4_copy<KS>(Y, C0);
+  MOM_STAMP(82);
+#if Q4_HORNER_SITES == 2
+  // two product sites on alternating registers: one copy per series (odd p - 1) instead of one per round
+  int n = p - 1;
+#pragma nounroll
+  for (; n >= 2; n -= 2) {
+    real Z[Q4Geom<KS>::NB][Q4Geom<KS>::NJ];
+    q4_mul_c<KS>(M, Y, C0, Z);
+    q4_mul_c<KS>(M, Z, C0, Y);
+  }
+  if (n == 1) {
+    real acc[Q4Geom<KS>::NB][Q4Geom<KS>::NJ];
+    q4_mul_c<KS>(M, Y, C0, acc);
+    q4_copy<KS>(Y, acc);
+  }
+#else
 #pragma nounroll
   for (int kk = 1; kk < p; ++kk) {
     real acc[Q4Geom<KS>::NB][Q4Geom<KS>::NJ];
@@ -245,6 +264,7 @@ __device__ __forceinline__ void q4_horner(const real *M, const real (&C0)[Q4Geom
     q4_copy<KS>(Y, acc);
     MOM_STAMP(76);
   }
+#endif
 }
 
 // bit K of the mask: sg[4 K + k] < 0 (this lane's row of block row K)
@@ -348,6 +368,7 @@ __device__ __forceinline__ real doubling_run_q4(Ctx &c, int nd, real expk, bool 
       bail = true;
       return expk;
     }
+    MOM_STAMP(80);
     // riding vectors of the multiplier r for the (A r) product: w1 = j1- + r j0+, w2 = j0+ + r j1- (doubling.jl:51-60), j1 = j0 expk
 #pragma unroll
     for (int J = 0; J < NJ; ++J) {
@@ -358,6 +379,7 @@ __device__ __forceinline__ real doubling_run_q4(Ctx &c, int nd, real expk, bool 
       }
     }
     q4_fence();
+    MOM_STAMP(81);
     real Y[NB][NJ];
     // Y = A^T = (t (I - r r)^-1)^T by Horner: Y <- t^T + (r r)^T Y, p - 1 times starting from t^T (p >= 2 unless r r = 0)
     q4_horner<KS>(P, T0, p, Y);

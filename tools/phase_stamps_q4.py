@@ -27,13 +27,13 @@ names = {43: "loop top: layer scalars", 49: "elem: Z loads done", 57: "elem: ele
          41: "elem: rest", 42: "store first", 70: "dbl: P = r r + store", 71: "dbl: norm, w1/w2, Horner series", 72: "dbl: A r, r + t(Ar), t A, write-back",
          73: "dbl: D signs", 50: "int: R+- -> P", 52: "int: B, W0 products, B store, norm", 54: "int: Horner X", 55: "int: T-- load + Horner T01",
          56: "int: T++ -> P, J0+", 58: "int: chain 1", 59: "int: chain 2",
-         74: "horner: before a product", 75: "horner: the product, first round of a series", 77: "horner: the product, later rounds", 76: "horner: copy of the running value"}
+         74: "horner: before a product", 80: "dbl: norm reduction, series length", 81: "dbl: w1 / w2 to LDS + fence", 82: "horner: initial copy (+ what precedes it in the interaction)", 75: "horner: the product, first round of a series", 77: "horner: the product, later rounds", 76: "horner: copy of the running value"}
 tot = sum(a[k] for k in names)
 print(f"share of momq::k_layer_q4<10>'s time per code section (the middle workgroup, sweep mode, C2 m = 0, S = {S}); 100 MHz ticks total {tot:.0f}")
 for k in sorted(names, key=lambda k: -a[k]):
     if a[k] > 0:
         print(f"{k:3d} {names[k]:44s} {100 * a[k] / tot:6.2f} %")
-grp = {"doubling + interaction (horner parts counted once, in 74..76)": (70, 71, 72, 73, 50, 52, 54, 55, 56, 58, 59, 74, 75, 76, 77), "elemental": (41, 46, 47, 48, 49, 57), "other": (42, 43)}
+grp = {"doubling + interaction (horner parts counted once, in 74..76)": (70, 71, 72, 73, 50, 52, 54, 55, 56, 58, 59, 74, 75, 76, 77, 80, 81, 82), "elemental": (41, 46, 47, 48, 49, 57), "other": (42, 43)}
 for g, ids in grp.items():
     print(f"{g:12s} {100 * sum(a[k] for k in ids) / tot:6.2f} %")
 print(f"ticks per Horner product (s_memtime, ~2.39 GHz): first round of a series {a[75] / max(a[78], 1):.0f} ({a[78]:.0f} products), later rounds {a[77] / max(a[79], 1):.0f} ({a[79]:.0f}); 300 MFMAs x 16 cycles = 4800")
