@@ -202,6 +202,28 @@ def test_quad_block_image_small_edges(rtamd, cref, nS, lt, N, small, kw):
         np.testing.assert_allclose(out[lean][4], dwr, rtol=max(tol, 1e-10), atol=helpers.ATOL_STOKES)
 
 
+@pytest.mark.parametrize("nS,lt,N", [(4, 13, 40), (3, 33, 60), (4, 21, 56)])
+def test_quad_block_image_layers_without_doublings(rtamd, cref, nS, lt, N):
+    """Layers thin enough for ndoubl = 0 (the elemental layer IS the added layer: no doubling step, no D signs from one) and a
+    layer without any scattering at one spectral point (series of one term) through the quad-block image -- as a full problem
+    (N = 40) and as the m = 0 sub-problem (N0 = 40, 28)."""
+    m = rtamd.scenes.make_scene(nS, lt, 6, 32, seed=3 * nS + lt, aerosol_total=0.05)
+    m.τ_rayl[:, :3] *= 1e-6
+    m.τ_abs[:, :3] *= 1e-6
+    m.τ_aer[:, :3] *= 1e-6
+    sc = rtamd.prepare_scene(m)
+    assert sc.N == N and sc.ndoubl[0] == 0 and sc.ndoubl[-1] > 0 and np.all(sc.iface == 3)
+    Rr, Tr, Hr, upr, dwr, info = cref.rt_run_full(cref.pack_scene(helpers.oracle_scene(m)))
+    assert info == 0
+    with rtamd.corert.make_handle(m) as h:
+        R, T = rtamd.corert.run_scene(h, sc)
+        H, up, dw = h.get_hdr()
+    tol = helpers.stokes_rtol(sc.ndoubl)
+    helpers.assert_stokes_close(R, Rr, rtol=tol, what="R")
+    helpers.assert_stokes_close(T, Tr, rtol=tol, what="T")
+    helpers.assert_stokes_close(H, Hr, rtol=tol, what="hdr")
+
+
 def test_strip_chains_thick_layers_fall_back(rtamd, cref):
     """optically thick scattering layers: the series length exceeds the strip chains' limit for part of the
     doubling steps and interactions, which must then take the general path inside the same kernels"""
