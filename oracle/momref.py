@@ -492,10 +492,13 @@ def construct_core_optical_properties(scene: Scene, m: int) -> List[LayerOptics]
     Zb_mp = np.array(Zb_mp)
     K = len(Zb_pp)
     out = []
+    # float64 for every real scene; complex only when oracle/dualref.py pushes a complex-step perturbation through this algebra
+    dt = np.result_type(np.float64, *[np.asarray(x).dtype for x in (scene.tau_rayl, scene.tau_abs, scene.tau_aer, scene.varpi_cabannes)],
+                        *[np.asarray(v).dtype for a in scene.aerosols for v in (a.omega, a.ft)])
     for iz in range(Nz):
-        tau = scene.tau_rayl[:, iz].astype(np.float64).copy()
-        varpi = np.full(S, scene.varpi_cabannes, dtype=np.float64)
-        wts = np.zeros((K, S))
+        tau = scene.tau_rayl[:, iz].astype(dt).copy()
+        varpi = np.full(S, scene.varpi_cabannes, dtype=dt)
+        wts = np.zeros((K, S), dtype=dt)
         wts[0] = 1.0
         only = 0  # index of the single basis in use while Z is still unmixed
         mixed = False
