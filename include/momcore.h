@@ -350,6 +350,31 @@ int mom_scene_set_surface(mom_t *h, int kind, int M, const double *Rsurf, const 
  * surface, post-processing.  Asynchronous on the handle's stream; results stay on the GPU. */
 int mom_rt_run(mom_t *h);
 
+/* ---- rt_run on ForwardDiff.Dual numbers: Jacobians out of the hot path --------------------------------------------
+ * The reference differentiates rt_run by running it on Dual element types: rt_run.jl:89-96 allocates R, T, R_SFI, T_SFI
+ * in the Dual type of the optical properties, every AddedLayer / CompositeLayer array is a Dual array, and the two
+ * batched operators have Dual methods (gpu_batched.jl:100-150).  This is that run for the resident scene: values and P
+ * partials of every layer operator go through elemental! / doubling! / interaction! / create_surface_layer! /
+ * postprocessing_vza! together (csrc/mom_dual.hip: the Dual product rule per product, dX = -X dA X per inverse, the
+ * analytic derivative of every elemental expression; integer decisions -- ndoubl, interface codes -- are the value run's,
+ * as ForwardDiff takes them on the values).
+ *
+ * mom_scene_set_partials   the partials of what mom_scene_set / mom_scene_set_surface uploaded, i.e. of the Dual inputs the
+ *                          reference's host code (model_from_parameters on Dual parameters) hands to rt_run.  Layouts are
+ *                          those of the value arrays with the partial index as the SLOWEST axis; NULL = no dependence:
+ *                            dtau, dvarpi [S, Nz, P];  dzw [K, S, Nz, P];  dZpp, dZmp [N, N, K, M, P] (both or neither);
+ *                            dalbedo [P] (LambertianSurfaceScalar);  dRsurf [N, N, M, P] (surface kind 1);
+ *                            dalbedo_spec [S, P] (kind 2).
+ *                          Call after mom_scene_set (and mom_scene_set_surface); P = 0 clears them (values only).
+ * mom_rt_run_dual          the run; R_SFI / T_SFI are then read with mom_get_RT (they agree with mom_rt_run's to rounding:
+ *                          the same statements in a different association), the partials with mom_get_RT_partials.
+ *                          Operators larger than 128 x 128 return MOM_EUNSUPPORTED; hdr / bhr are not produced.
+ * mom_get_RT_partials      dR_SFI, dT_SFI [nVza, nStokes, nSpec, P] (host). */
+int mom_scene_set_partials(mom_t *h, int P, const double *dtau, const double *dvarpi, const double *dzw, const double *dZpp,
+                           const double *dZmp, const double *dalbedo, const double *dRsurf, const double *dalbedo_spec);
+int mom_rt_run_dual(mom_t *h);
+int mom_get_RT_partials(mom_t *h, double *dR_SFI, double *dT_SFI);
+
 /* rt_run_test_ms(RS_type::noRS, sensor_levels, model, iBand) (src/CoreRT/rt_run_multisensor.jl:14-191) for the resident
  * scene: sensors inside the atmosphere.  sensor_levels[ims] = 0 is the TOA/BOA pair (uwJ = R_SFI, dwJ = T_SFI of
  * mom_rt_run); L in 1..Nz-1 puts the sensor below layer L counted from the top: rt_kernel_multisensor!
@@ -445,11 +470,13 @@ int mom_timers(mom_t *h, double *ms, int n, int *kernel_launches);
  *                         the per-point operands (Gauss-Jordan inverse over all waves), 8 = the inelastic elemental layer as a tile
  *                         kernel, 16 / 32 = form it inside the first doubling step always / never (neither: above N = 48 only).
  *                         (r5 read these from environment variables, once per process.)
+ *   MOM_OPT_DUAL_WORKSPACE_MB   operator workspace of mom_rt_run_dual in MiB (0, default: 60 % of the free HBM when the run
+ *                         starts); a scene that needs more is processed in chunks of spectral points.
  */
 int mom_set_option(mom_t *h, int option, int value);
 enum { MOM_OPT_INVERSE = 0, MOM_OPT_FORCE_GENERIC = 1, MOM_OPT_M0_REDUCTION = 2, MOM_OPT_SMALL_WG = 3, MOM_OPT_STAGGER = 4,
        MOM_OPT_SMALL_N = 5, MOM_OPT_LAYER_SWEEP = 6, MOM_OPT_STRIP_PAD = 7, MOM_OPT_LEAN = 8, MOM_OPT_OVERLAP = 9,
-       MOM_OPT_RRS_KERNELS = 10 };
+       MOM_OPT_RRS_KERNELS = 10, MOM_OPT_DUAL_WORKSPACE_MB = 11 };
 
 /* ---- Voigt line-by-line cross section --------------------------------------------------
  * compute_absorption_cross_section(model::HitranModel, grid, p, T)

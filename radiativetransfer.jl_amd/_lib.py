@@ -37,6 +37,7 @@ MOM_OPT_STRIP_PAD = 7
 MOM_OPT_LEAN = 8
 MOM_OPT_OVERLAP = 9
 MOM_OPT_RRS_KERNELS = 10   # mask: 1 WG pairs, 2 ... for 16 < N <= 32, 4 WG points, 8 tile elemental, 16 / 32 fused elemental always / never
+MOM_OPT_DUAL_WORKSPACE_MB = 11   # operator workspace of mom_rt_run_dual (0: 60 % of the free HBM)
 
 
 class MomError(RuntimeError):
@@ -95,6 +96,9 @@ SIGNATURES = {
     "mom_scene_get_layers": (C.c_int, [c_h, c_ip, c_ip, c_dp, c_dp, c_dp, c_dp]),
     "mom_scene_set_surface": (C.c_int, [c_h, C.c_int, C.c_int, c_dp, c_dp]),
     "mom_rt_run": (C.c_int, [c_h]),
+    "mom_scene_set_partials": (C.c_int, [c_h, C.c_int] + [c_dp] * 8),
+    "mom_rt_run_dual": (C.c_int, [c_h]),
+    "mom_get_RT_partials": (C.c_int, [c_h, c_dp, c_dp]),
     "mom_rt_run_multisensor": (C.c_int, [c_h, C.c_int, c_ip, c_dp, c_dp]),
     "mom_get_RT": (C.c_int, [c_h, c_dp, c_dp]),
     "mom_get_hdr": (C.c_int, [c_h, c_dp, c_dp, c_dp]),
@@ -457,6 +461,26 @@ class Handle:
 
     def rt_run(self):
         self.check(self.lib.mom_rt_run(self._h))
+
+    # -- rt_run on ForwardDiff.Dual numbers (mom_dual.hip) ------------------------------------------
+    def scene_set_partials(self, P, dtau=None, dvarpi=None, dzw=None, dZpp=None, dZmp=None, dalbedo=None, dRsurf=None,
+                           dalbedo_spec=None):
+        """Partials of the scene's inputs, flat buffers in ABI order (partial index slowest); None = no dependence."""
+        bufs = [None if x is None else f64(x).reshape(-1) for x in (dtau, dvarpi, dzw, dZpp, dZmp, dalbedo, dRsurf, dalbedo_spec)]
+        self.dual_P = int(P)
+        self.check(self.lib.mom_scene_set_partials(self._h, int(P), *[None if b is None else dp(b) for b in bufs]))
+
+    def rt_run_dual(self):
+        self.check(self.lib.mom_rt_run_dual(self._h))
+
+    def get_RT_partials(self):
+        """dR_SFI, dT_SFI as numpy [P, nVza, nStokes, S]."""
+        P = self.dual_P
+        n = self.nVza * self.nS * self.S * P
+        dR, dT = np.empty(n), np.empty(n)
+        self.check(self.lib.mom_get_RT_partials(self._h, dp(dR), dp(dT)))
+        shp = (P, self.S, self.nS, self.nVza)
+        return np.transpose(dR.reshape(shp), (0, 3, 2, 1)).copy(), np.transpose(dT.reshape(shp), (0, 3, 2, 1)).copy()
 
     def rt_run_multisensor(self, sensor_levels):
         """uwJ, dwJ as numpy [nSensors, nVza, nStokes, S] (the reference's vector of [nVza, nStokes, nSpec] arrays,

@@ -725,6 +725,58 @@ def run_scene(h: _lib.Handle, sc: SceneInputs):
     return h.get_RT()
 
 
+@dataclass
+class ScenePartial:
+    """Partials of the hot path's inputs with respect to ONE parameter, in the reference's array shapes -- what the Dual
+    numbers of model_from_parameters carry into rt_run (rt_run.jl:89-96).  None = no dependence."""
+    dτ: Optional[np.ndarray] = None             # [nSpec, Nz]
+    dϖ: Optional[np.ndarray] = None             # [nSpec, Nz]
+    dzw: Optional[np.ndarray] = None            # [K, nSpec, Nz] weights of the phase-matrix bases
+    dZpp: Optional[np.ndarray] = None           # [M, K, N, N] partials of the bases themselves (aerosol microphysics)
+    dZmp: Optional[np.ndarray] = None
+    dalbedo: float = 0.0                        # LambertianSurfaceScalar
+    dRsurf: Optional[np.ndarray] = None         # [M, N, N] BRDF surfaces (with the factor 2 of m = 0 like Rsurf)
+    dalbedo_spec: Optional[np.ndarray] = None   # [nSpec] LambertianSurfaceLegendre
+
+
+def scene_set_partials(h: _lib.Handle, sc: SceneInputs, partials: Sequence[ScenePartial]):
+    """Pack the partials into the ABI layout of mom_scene_set_partials (partial index slowest) and upload them."""
+    P = len(partials)
+
+    def pack(get, conv):
+        xs = [get(p) for p in partials]
+        if all(x is None for x in xs):
+            return None
+        ref = next(x for x in xs if x is not None)
+        return np.concatenate([conv(np.zeros_like(ref) if x is None else np.asarray(x, dtype=np.float64)) for x in xs])
+
+    col = lambda a: np.ascontiguousarray(a.T).reshape(-1)
+    h.scene_set_partials(
+        P, dtau=pack(lambda p: p.dτ, col), dvarpi=pack(lambda p: p.dϖ, col),
+        dzw=pack(lambda p: p.dzw, lambda a: np.ascontiguousarray(a.transpose(2, 1, 0)).reshape(-1)),
+        dZpp=pack(lambda p: p.dZpp, _abi_mats), dZmp=pack(lambda p: p.dZmp, _abi_mats),
+        dalbedo=np.array([float(p.dalbedo) for p in partials]) if sc.surf_kind == 0 and P else None,
+        dRsurf=pack(lambda p: p.dRsurf, _abi_mats) if sc.surf_kind == 1 else None,
+        dalbedo_spec=pack(lambda p: p.dalbedo_spec, lambda a: a.reshape(-1)) if sc.surf_kind == 2 else None)
+
+
+def rt_run_dual(model: vSmartMOM_Model, partials: Sequence[ScenePartial], workspace_mb: int = 0):
+    """rt_run on ForwardDiff.Dual inputs (rt_run.jl:41-230 with FT_dual element types): returns
+    (R_SFI, T_SFI [nVza, nStokes, nSpec], dR_SFI, dT_SFI [P, nVza, nStokes, nSpec])."""
+    sc = prepare_scene(model)
+    with make_handle(model) as h:
+        if workspace_mb:
+            h.set_option(_lib.MOM_OPT_DUAL_WORKSPACE_MB, int(workspace_mb))
+        scene_set(h, sc)
+        scene_set_partials(h, sc, partials)
+        h.rt_run_dual()
+        R, T = h.get_RT()
+        if len(partials) == 0:
+            return R, T, np.zeros((0,) + R.shape), np.zeros((0,) + T.shape)
+        dR, dT = h.get_RT_partials()
+    return R, T, dR, dT
+
+
 def run_scene_device_optics(h: _lib.Handle, model: vSmartMOM_Model, upload_tau_abs: bool = True):
     """The same run with the layer optics assembled on the GPU (mom_scene_set_optics): the host hands over the
     INGREDIENTS (τ_rayl, aerosol columns, Z bases) and the gas absorption is the handle's resident τ_abs table --

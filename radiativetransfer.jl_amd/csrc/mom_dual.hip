@@ -1,0 +1,755 @@
+// mom_dual.hip -- ForwardDiff.Dual through the elastic hot path: rt_run on Dual numbers (values + P partials).
+//
+// The reference differentiates rt_run by running it on ForwardDiff.Dual element types (rt_run.jl:89-96 allocates R, T,
+// R_SFI, T_SFI in the Dual type; every layer operator is a Dual array; gpu_batched.jl:100-150 gives the two batched
+// operators their Dual methods: C = A B, dC_i = A dB_i + dA_i B;  X = A^-1, dX_i = -X dA_i X).  Here the same run is the
+// TANGENT-LINEAR sweep of the layer loop, written for the GPU as batched launches over HBM-resident "dual matrices":
+//
+//   DM  [1 + P][U][N x N]   component 0 = the value, component c = the partial c (column-major N x N per unit, no padding)
+//   DV  [1 + P][U][N]       the same for source vectors;   U = units (spectral points) of the current chunk
+//
+// Every statement of rt_kernel!/elemental!/doubling_helper!/interaction_helper! (file:line at each step below) becomes one
+// launch that carries all components: products by k_dgemm (64 x 64 tiles on v_mfma_f64_16x16x4, the Dual product rule
+// applied per component: c = 0: A0 B0, c > 0: Ac B0 + A0 Bc), inverses by k_dinv (pivoted Gauss-Jordan in LDS, value only)
+// followed by two products for the partials (G_c = G0 (dW_c) G0), matrix-vector statements by k_dmatvec, the elemental
+// layer by k_delemental (analytic derivatives of get_elem_rt! / get_elem_rt_SFI!).  A batched product of N = 60 reads
+// and writes 86 KB per 432 kFLOP: the sweep is HBM-bound (about 5 FLOP/B against 9.8 at the ridge), not MFMA-bound --
+// the operators of value AND partials do not fit one CU's LDS (14 x (1 + P) x 29 KB per unit), which is why this path
+// streams them instead of using the fused LDS-resident images of the value run (mom_kernels.hpp, mom_q4.hpp).
+//
+// Units are independent: a scene larger than the workspace budget is processed in chunks of units.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "mom_host.hpp"
+
+namespace momd {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 64, TN = 64, KC = 32, LDA = TM + 2, LDB = KC + 2;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C_c = alpha * prod_c + beta * E_c + eye * (c == 0) I          mode 0: Dual product rule, 1: A0 Bc, 2: Ac B0
+// ---------------------------------------------------------------------------------------------------------------------
+struct GemmArgs {
+  int N, U, c0, mode, tiles_i, tiles_j;
+  const double *A, *B, *E;
+  double *C;
+  double alpha, beta, eye;
+};
+
+__global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
+  __shared__ double As[KC * LDA];  // As[i + k LDA]
+  __shared__ double Bs[TN * LDB];  // Bs[k + j LDB]
+  const int N = a.N;
+  const size_t NN = (size_t)N * N, CS = (size_t)a.U * NN;
+  const int ntile = a.tiles_i * a.tiles_j;
+  const int tile = blockIdx.x % ntile, c = a.c0 + blockIdx.x / ntile;
+  const int i0 = (tile % a.tiles_i) * TM, j0 = (tile / a.tiles_i) * TN;
+  const size_t uo = (size_t)blockIdx.y * NN;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lq = lane >> 4, lr = lane & 15;
+  d4 acc[4];
+#pragma unroll
+  for (int tb = 0; tb < 4; ++tb) acc[tb] = d4{0.0, 0.0, 0.0, 0.0};
+  const double *TA[2], *TB[2];
+  int nterms = 1;
+  const double *A0 = a.A + uo, *B0 = a.B + uo, *Ac = a.A + c * CS + uo, *Bc = a.B + c * CS + uo;
+  if (a.mode == 0) {
+    if (c == 0) { TA[0] = A0; TB[0] = B0; }
+    else { nterms = 2; TA[0] = Ac; TB[0] = B0; TA[1] = A0; TB[1] = Bc; }
+  } else if (a.mode == 1) { TA[0] = A0; TB[0] = Bc; }
+  else { TA[0] = Ac; TB[0] = B0; }
+  for (int t = 0; t < nterms; ++t) {
+    const double *Ag = TA[t], *Bg = TB[t];
+    for (int k0 = 0; k0 < N; k0 += KC) {
+      __syncthreads();
+#pragma unroll
+      for (int e = threadIdx.x; e < TM * KC; e += 256) {
+        const int i = e & (TM - 1), k = e >> 6, gi = i0 + i, gk = k0 + k;
+        As[i + k * LDA] = (gi < N && gk < N) ? Ag[gi + (size_t)gk * N] : 0.0;
+      }
+#pragma unroll
+      for (int e = threadIdx.x; e < TN * KC; e += 256) {
+        const int k = e & (KC - 1), j = e >> 5, gk = k0 + k, gj = j0 + j;
+        Bs[k + j * LDB] = (gk < N && gj < N) ? Bg[gk + (size_t)gj * N] : 0.0;
+      }
+      __syncthreads();
+      const int kmax = min(KC, N - k0);
+      // the product transposed on the matrix core (rows of the MFMA tile = columns j of C, columns = rows i): the 16 lanes of a
+      // quarter-wave then hold 16 consecutive rows of one column of C, so the stores of the epilogue are 128-byte segments
+      for (int kk = 0; kk < kmax; kk += 4) {
+        const double bv = Bs[(kk + lq) + (16 * w + lr) * LDB];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+          const double av = As[(16 * tb + lr) + (kk + lq) * LDA];
+          acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc[tb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  double *C = a.C + c * CS + uo;
+  const double *E = a.E ? a.E + c * CS + uo : nullptr;
+#pragma unroll
+  for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gj = j0 + 16 * w + lq + 4 * r, gi = i0 + 16 * tb + lr;
+      if (gi < N && gj < N) {
+        const size_t o = gi + (size_t)gj * N;
+        double v = a.alpha * acc[tb][r];
+        if (E) v += a.beta * E[o];
+        if (c == 0 && gi == gj) v += a.eye;
+        C[o] = v;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// G0 = inv(eye I + s W0): batch_inv! (gpu_batched.jl:61-82) on the VALUE component, pivoted Gauss-Jordan in LDS, one
+// workgroup per unit.  The partials follow as products (gpu_batched.jl:129-150).
+// ---------------------------------------------------------------------------------------------------------------------
+struct InvArgs {
+  int N, U;
+  const double *W;
+  double *G;
+  double eye, s;
+  int *info;
+};
+
+__global__ void __launch_bounds__(256) k_dinv(InvArgs a) {
+  extern __shared__ double sm[];
+  const int N = a.N, LD = N + 1, t = threadIdx.x;
+  double *A = sm, *rowk = sm + (size_t)N * LD, *colk = rowk + N, *red = colk + N;  // red: 8 doubles
+  int *piv = (int *)(red + 8), *redi = piv + N;                                     // redi: 4 ints
+  const size_t NN = (size_t)N * N, uo = (size_t)blockIdx.x * NN;
+  for (int e = t; e < (int)NN; e += 256) {
+    const int i = e % N, j = e / N;
+    A[i * LD + j] = a.s * a.W[uo + e] + (i == j ? a.eye : 0.0);
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int k = 0; k < N; ++k) {
+    double best = -1.0;
+    int bi = k;
+    for (int i = k + t; i < N; i += 256) {
+      const double v = fabs(A[i * LD + k]);
+      if (v > best) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_down(best, off);
+      const int oi = __shfl_down(bi, off);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if ((t & 63) == 0) { red[t >> 6] = best; redi[t >> 6] = bi; }
+    __syncthreads();
+    best = red[0]; bi = redi[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      if (red[q] > best || (red[q] == best && redi[q] < bi)) { best = red[q]; bi = redi[q]; }
+    if (!(best > 0.0)) bad = true;
+    if (t == 0) piv[k] = bi;
+    if (bi != k)
+      for (int j = t; j < N; j += 256) {
+        const double x = A[k * LD + j];
+        A[k * LD + j] = A[bi * LD + j];
+        A[bi * LD + j] = x;
+      }
+    __syncthreads();
+    const double pinv = 1.0 / A[k * LD + k];
+    __syncthreads();
+    for (int j = t; j < N; j += 256) {
+      rowk[j] = A[k * LD + j] * pinv;
+      colk[j] = A[j * LD + k];
+    }
+    __syncthreads();
+    for (int e = t; e < (int)NN; e += 256) {
+      const int i = e / N, j = e - i * N;
+      double v;
+      if (i == k) v = (j == k) ? pinv : rowk[j];
+      else v = (j == k) ? -colk[i] * pinv : A[i * LD + j] - colk[i] * rowk[j];
+      A[i * LD + j] = v;
+    }
+    __syncthreads();
+  }
+  for (int k = N - 1; k >= 0; --k) {
+    const int p = piv[k];
+    if (p != k)
+      for (int i = t; i < N; i += 256) {
+        const double x = A[i * LD + k];
+        A[i * LD + k] = A[i * LD + p];
+        A[i * LD + p] = x;
+      }
+    __syncthreads();
+  }
+  for (int e = t; e < (int)NN; e += 256) {
+    const int i = e % N, j = e / N;
+    a.G[uo + e] = A[i * LD + j];
+  }
+  if (t == 0 && bad) atomicMax(a.info, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// y_c = add_c + (M x)_c with the Dual product rule, for up to two (x, add, y) sets sharing M
+// ---------------------------------------------------------------------------------------------------------------------
+struct MvArgs {
+  int N, U;
+  const double *M;
+  const double *x[2], *add[2];
+  double *y[2];
+};
+
+__global__ void __launch_bounds__(256) k_dmatvec(MvArgs a) {
+  __shared__ double part[4][64];
+  const int N = a.N, c = blockIdx.x, q = blockIdx.z, t = threadIdx.x, g = t >> 6, il = t & 63;
+  const size_t NN = (size_t)N * N, u = blockIdx.y;
+  const double *M0 = a.M + u * NN, *Mc = a.M + ((size_t)c * a.U + u) * NN;
+  const double *x0 = a.x[q] + u * N, *xc = a.x[q] + ((size_t)c * a.U + u) * N;
+  const double *ad = a.add[q] ? a.add[q] + ((size_t)c * a.U + u) * N : nullptr;
+  double *y = a.y[q] + ((size_t)c * a.U + u) * N;
+  for (int rb = 0; rb < N; rb += 64) {
+    const int i = rb + il;
+    double s = 0.0;
+    if (i < N) {
+      if (c == 0)
+        for (int j = g; j < N; j += 4) s += M0[i + (size_t)j * N] * x0[j];
+      else
+        for (int j = g; j < N; j += 4) s += Mc[i + (size_t)j * N] * x0[j] + M0[i + (size_t)j * N] * xc[j];
+    }
+    part[g][il] = s;
+    __syncthreads();
+    if (g == 0 && i < N) y[i] = (ad ? ad[i] : 0.0) + ((part[0][il] + part[1][il]) + (part[2][il] + part[3][il]));
+    __syncthreads();
+  }
+}
+
+// j1+ = j0+ e, j1- = j0- e (doubling.jl:51-54) on Duals, then expk .= expk.^2 (:62); one block per unit
+struct ScaleArgs {
+  int N, U, P;
+  const double *jp, *jm;
+  double *j1p, *j1m, *e;
+};
+__global__ void k_dscale(ScaleArgs a) {
+  const size_t u = blockIdx.x, US = (size_t)a.U;
+  const double e0 = a.e[u];
+  for (int idx = threadIdx.x; idx < a.N * (a.P + 1); idx += blockDim.x) {
+    const int c = idx / a.N, i = idx - c * a.N;
+    const size_t o = (c * US + u) * a.N + i, o0 = u * a.N + i;
+    if (c == 0) { a.j1p[o] = a.jp[o] * e0; a.j1m[o] = a.jm[o] * e0; }
+    else {
+      const double ec = a.e[c * US + u];
+      a.j1p[o] = a.jp[o] * e0 + a.jp[o0] * ec;
+      a.j1m[o] = a.jm[o] * e0 + a.jm[o0] * ec;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x <= a.P) {
+    const int c = threadIdx.x;
+    a.e[c * US + u] = (c == 0) ? e0 * e0 : 2.0 * e0 * a.e[c * US + u];
+  }
+}
+
+__device__ __forceinline__ int stokes_comp(int i, int n, int strict) { return strict ? ((i + 1) % n) : (i % n) + 1; }
+
+// apply_D! / apply_D_SFI! after the doublings (doubling.jl:93-118): r-+ rows of U, V change sign, r+- = D r-+ D,
+// t-- = D t++ D, j0- rows of U, V change sign -- the same linear map on every component
+struct SignArgs {
+  int N, nS, U, P, strict;
+  double *r_mp, *t_pp, *r_pm, *t_mm, *j0m;
+};
+__global__ void k_dsign(SignArgs a) {
+  const size_t NN = (size_t)a.N * a.N, total = NN * a.U * (a.P + 1);
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int i = (int)(e % a.N), j = (int)((e / a.N) % a.N);
+  if (a.nS == 1) {
+    a.r_pm[e] = a.r_mp[e];
+    a.t_mm[e] = a.t_pp[e];
+    return;
+  }
+  const int ci = stokes_comp(i, a.nS, a.strict), cj = stokes_comp(j, a.nS, a.strict);
+  const double sg = (((ci <= 2) && (cj <= 2)) || ((ci > 2) && (cj > 2))) ? 1.0 : -1.0;
+  double r = a.r_mp[e];
+  if (ci > 2) r = -r;
+  a.r_mp[e] = r;
+  a.r_pm[e] = sg * r;
+  a.t_mm[e] = sg * a.t_pp[e];
+  if (j == 0 && ci > 2) {
+    const size_t o = (e / NN) * a.N + i;
+    a.j0m[o] = -a.j0m[o];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// elemental! (elemental.jl:109-162): get_elem_rt! (:164-207), get_elem_rt_SFI! (:209-253), apply_D_elemental! (:255-274)
+// on Dual tau, varpi, Z: one thread per (unit, i, j) forms the value and, per partial, the exact derivative of the same
+// expression (what a Dual carries through exp, * and /).  Also expk = exp(-dtau/mu0) (rt_kernel.jl:196).
+// ---------------------------------------------------------------------------------------------------------------------
+struct ElArgs {
+  int N, nS, U, P, K, S, Nz, m, iz, nd, strict, imu0;
+  size_t u0;
+  double mu0;
+  const double *mu, *wt;
+  double I0[4], D[4];
+  const double *tau, *varpi, *zw, *tau_sum;       // [S,Nz], [S,Nz], [K,S,Nz], [S,Nz+1]
+  const double *dtau, *dvarpi, *dzw, *dtau_sum;   // the same shapes with P as the slowest axis (nullptr: zero)
+  const double *Zpp, *Zmp, *dZpp, *dZmp;          // moment m: [N,N,K]; partials [N,N,K] at stride dZ_stride per partial
+  size_t dZ_stride;
+  double *r_mp, *t_pp, *r_pm, *t_mm, *j0p, *j0m, *e;
+};
+
+__global__ void __launch_bounds__(256) k_delemental(ElArgs a) {
+  const int N = a.N, n = a.nS, P = a.P, K = a.K;
+  const size_t NN = (size_t)N * N;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NN * a.U) return;
+  const int i = (int)(idx % N), j = (int)((idx / N) % N);
+  const size_t u = idx / NN, s = a.u0 + u, CS = (size_t)a.U * NN, VS = (size_t)a.U * N;
+  const size_t SZ = (size_t)a.S * a.Nz, lz = s + (size_t)a.S * a.iz;
+  const double sc = ldexp(1.0, -a.nd);
+  const double d = a.tau[lz] * sc, w = a.varpi[lz];
+  const double wdiv = (a.m == 0) ? 2.0 : 4.0, wct02 = (a.m == 0) ? 0.5 : 0.25;
+  const double mui = a.mu[i], muj = a.mu[j], wj = a.wt[j] / wdiv, wi = a.wt[i] / wdiv;
+  const size_t zo = i + (size_t)N * j;
+  double Zp = 0.0, Zm = 0.0;
+  for (int k = 0; k < K; ++k) {
+    const double zk = a.zw[k + (size_t)K * lz];
+    Zp += zk * a.Zpp[zo + NN * k];
+    Zm += zk * a.Zmp[zo + NN * k];
+  }
+  // value-side factors: r = w Zm Ar(d), t = w Zp At(d) (off-diagonal) ...
+  const double ei = exp(-d / mui), ej = exp(-d / muj);
+  const bool live = wj > 1.e-8, diag = (i == j), same = (mui == muj);
+  double Ar = 0.0, dAr = 0.0, At = 0.0, dAt = 0.0;
+  if (live) {
+    const double si = (1.0 / mui) + (1.0 / muj), E = exp(-d * si), F1 = muj / (mui + muj);
+    Ar = F1 * wj * (1.0 - E);
+    dAr = F1 * wj * si * E;
+    if (!same) {
+      const double F2 = muj / (mui - muj);
+      At = F2 * wj * (ei - ej);
+      dAt = F2 * wj * (-ei / mui + ej / muj);
+    }
+  }
+  double r0 = 0.0, t0 = 0.0;
+  if (live) {
+    r0 = w * Zm * Ar;
+    if (!same) t0 = w * Zp * At;
+    else if (diag) t0 = ei * (1.0 + w * Zp * (d / mui) * wi);
+  } else if (diag) t0 = ei;
+  const int ci = stokes_comp(i, n, a.strict), cj = stokes_comp(j, n, a.strict);
+  const double sg = (((ci <= 2) && (cj <= 2)) || ((ci > 2) && (cj > 2))) ? 1.0 : -1.0;
+  const double rsign = (a.nd >= 1 && ci > 2) ? -1.0 : 1.0;
+  const size_t o = u * NN + zo;
+  a.r_mp[o] = rsign * r0;
+  a.t_pp[o] = t0;
+  if (a.nd < 1) { a.r_pm[o] = sg * r0; a.t_mm[o] = sg * t0; }
+  for (int p = 0; p < P; ++p) {
+    const double dd = a.dtau ? a.dtau[lz + SZ * p] * sc : 0.0, dw = a.dvarpi ? a.dvarpi[lz + SZ * p] : 0.0;
+    double dZp = 0.0, dZm = 0.0;
+    for (int k = 0; k < K; ++k) {
+      if (a.dzw) {
+        const double dzk = a.dzw[k + (size_t)K * (lz + SZ * p)];
+        dZp += dzk * a.Zpp[zo + NN * k];
+        dZm += dzk * a.Zmp[zo + NN * k];
+      }
+      if (a.dZpp) {
+        const double zk = a.zw[k + (size_t)K * lz];
+        dZp += zk * a.dZpp[zo + NN * k + a.dZ_stride * p];
+        dZm += zk * a.dZmp[zo + NN * k + a.dZ_stride * p];
+      }
+    }
+    double r1 = 0.0, t1 = 0.0;
+    if (live) {
+      r1 = (dw * Zm + w * dZm) * Ar + w * Zm * dAr * dd;
+      if (!same) t1 = (dw * Zp + w * dZp) * At + w * Zp * dAt * dd;
+      else if (diag)
+        t1 = -(dd / mui) * ei * (1.0 + w * Zp * (d / mui) * wi) + ei * (wi / mui) * ((dw * Zp + w * dZp) * d + w * Zp * dd);
+    } else if (diag) t1 = -(dd / mui) * ei;
+    const size_t oc = (size_t)(p + 1) * CS + o;
+    a.r_mp[oc] = rsign * r1;
+    a.t_pp[oc] = t1;
+    if (a.nd < 1) { a.r_pm[oc] = sg * r1; a.t_mm[oc] = sg * t1; }
+  }
+  if (j != 0) return;
+  // source vectors (get_elem_rt_SFI!, elemental.jl:209-253): one thread per (unit, i)
+  const int i_start = n * (a.imu0 - 1), i_end = n * a.imu0;
+  const double mus = a.mu[i_start];
+  const bool insun = (i >= i_start && i < i_end);
+  double gp, dgp, gm, dgm;  // j+ = wct02 w ZpI0 gp(d) att, j- likewise
+  if (insun) {
+    gp = (d / mui) * ei;
+    dgp = (1.0 / mui) * ei * (1.0 - d / mui);
+  } else {
+    const double F = mus / (mui - mus), es = exp(-d / mus);
+    gp = F * (ei - es);
+    dgp = F * (-ei / mui + es / mus);
+  }
+  {
+    const double Fm = mus / (mui + mus), sm_ = (1.0 / mui) + (1.0 / mus), E = exp(-d * sm_);
+    gm = Fm * (1.0 - E);
+    dgm = Fm * sm_ * E;
+  }
+  const size_t ts = s + (size_t)a.S * a.iz, TS = (size_t)a.S * (a.Nz + 1);
+  const double att = exp(-a.tau_sum[ts] / mus);
+  double ZpI = 0.0, ZmI = 0.0;
+  for (int kk = 0; kk < n; ++kk) {
+    double zp = 0.0, zm = 0.0;
+    const size_t zc = i + (size_t)N * (i_start + kk);
+    for (int k = 0; k < K; ++k) {
+      const double zk = a.zw[k + (size_t)K * lz];
+      zp += zk * a.Zpp[zc + NN * k];
+      zm += zk * a.Zmp[zc + NN * k];
+    }
+    ZpI += zp * a.I0[kk];
+    ZmI += zm * a.I0[kk];
+  }
+  const double Dm = (a.nd >= 1) ? a.D[i % n] : 1.0;
+  const size_t ov = u * N + i;
+  a.j0p[ov] = wct02 * w * ZpI * gp * att;
+  a.j0m[ov] = Dm * (wct02 * w * ZmI * gm * att);
+  const double e0 = exp(-d / a.mu0);
+  if (i == 0) a.e[u] = e0;
+  for (int p = 0; p < P; ++p) {
+    const double dd = a.dtau ? a.dtau[lz + SZ * p] * sc : 0.0, dw = a.dvarpi ? a.dvarpi[lz + SZ * p] : 0.0;
+    const double datt = a.dtau_sum ? -(a.dtau_sum[ts + TS * p] / mus) * att : 0.0;
+    double dZpI = 0.0, dZmI = 0.0;
+    for (int kk = 0; kk < n; ++kk) {
+      double zp = 0.0, zm = 0.0;
+      const size_t zc = i + (size_t)N * (i_start + kk);
+      for (int k = 0; k < K; ++k) {
+        if (a.dzw) {
+          const double dzk = a.dzw[k + (size_t)K * (lz + SZ * p)];
+          zp += dzk * a.Zpp[zc + NN * k];
+          zm += dzk * a.Zmp[zc + NN * k];
+        }
+        if (a.dZpp) {
+          const double zk = a.zw[k + (size_t)K * lz];
+          zp += zk * a.dZpp[zc + NN * k + a.dZ_stride * p];
+          zm += zk * a.dZmp[zc + NN * k + a.dZ_stride * p];
+        }
+      }
+      dZpI += zp * a.I0[kk];
+      dZmI += zm * a.I0[kk];
+    }
+    const size_t oc = (size_t)(p + 1) * VS + ov;
+    a.j0p[oc] = wct02 * (((dw * ZpI + w * dZpI) * gp + w * ZpI * dgp * dd) * att + w * ZpI * gp * datt);
+    a.j0m[oc] = Dm * (wct02 * (((dw * ZmI + w * dZmI) * gm + w * ZmI * dgm * dd) * att + w * ZmI * gm * datt));
+    if (i == 0) a.e[(size_t)(p + 1) * a.U + u] = -(dd / a.mu0) * e0;
+  }
+}
+
+// d tau_sum[s, z + 1] = d tau_sum[s, z] + d tau[s, z] (compEffectiveLayerProperties.jl:108 on Duals)
+__global__ void k_dtausum(int S, int Nz, int P, const double *dtau, double *dts) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)S * P) return;
+  const size_t s = idx % S, p = idx / S;
+  double acc = 0.0;
+  dts[s + (size_t)S * (Nz + 1) * p] = 0.0;
+  for (int z = 0; z < Nz; ++z) {
+    acc += dtau[s + (size_t)S * z + (size_t)S * Nz * p];
+    dts[s + (size_t)S * (z + 1) + (size_t)S * (Nz + 1) * p] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// create_surface_layer! on Duals: LambertianSurfaceScalar (lambertian_surface.jl:20-75), BRDF matrices (rpv_surface.jl:
+// 20-66), LambertianSurfaceLegendre (lambertian_surface.jl:77-138) -- written into the added-layer arrays
+// ---------------------------------------------------------------------------------------------------------------------
+struct SurfArgs {
+  int N, nS, U, P, S, Nz, m, kind, imu0;
+  size_t u0;
+  double mu0, albedo;
+  double I0[4];
+  const double *mu, *wt;
+  const double *dalbedo;                 // [P] device (kind 0)
+  const double *Rsurf, *dRsurf;          // moment m: [N,N]; partial p at + dR_stride p (kind 1)
+  size_t dR_stride;
+  const double *alb_spec, *dalb_spec;    // [S], [S,P] (kind 2)
+  const double *tau_sum, *dtau_sum;      // [S,Nz+1](,P)
+  double *r_mp, *t_pp, *r_pm, *t_mm, *j0p, *j0m;
+};
+
+__global__ void __launch_bounds__(256) k_dsurface(SurfArgs a) {
+  const int N = a.N, n = a.nS, P = a.P;
+  const size_t NN = (size_t)N * N;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NN * a.U) return;
+  const int i = (int)(idx % N), j = (int)((idx / N) % N);
+  const size_t u = idx / NN, s = a.u0 + u, CS = (size_t)a.U * NN, VS = (size_t)a.U * N;
+  const size_t ts = s + (size_t)a.S * a.Nz, TS = (size_t)a.S * (a.Nz + 1);
+  const bool lamb0 = (i % n == 0) && (j % n == 0);
+  const bool active = (a.kind == 1) || (a.m == 0);
+  const double eyev = (a.kind == 2 && a.m > 0) ? 0.0 : (i == j ? 1.0 : 0.0);  // Legendre: t = 0 for m > 0 (:131-132)
+  const double mw = a.mu[j] * a.wt[j];
+  const int i_start = n * (a.imu0 - 1);
+  const double att = exp(-a.tau_sum[ts] / a.mu0);
+  for (int c = 0; c <= P; ++c) {
+    const int p = c - 1;
+    // R_surf[i, j] of this component
+    double R = 0.0;
+    if (active) {
+      if (a.kind == 1) R = (c == 0) ? a.Rsurf[i + (size_t)N * j] : (a.dRsurf ? a.dRsurf[i + (size_t)N * j + a.dR_stride * p] : 0.0);
+      else if (a.kind == 0) R = lamb0 ? 2.0 * ((c == 0) ? a.albedo : (a.dalbedo ? a.dalbedo[p] : 0.0)) : 0.0;
+      else R = lamb0 ? 2.0 * ((c == 0) ? a.alb_spec[s] : (a.dalb_spec ? a.dalb_spec[s + (size_t)a.S * p] : 0.0)) : 0.0;
+    }
+    const size_t o = c * CS + idx;
+    a.r_mp[o] = R * mw;
+    a.r_pm[o] = 0.0;
+    a.t_pp[o] = (c == 0) ? eyev : 0.0;
+    a.t_mm[o] = (c == 0) ? eyev : 0.0;
+    if (j == 0) {
+      double RI = 0.0, RI0 = 0.0;  // (R_surf I0N)[i] of this component and of the value
+      double I0i = 0.0;
+      if (active) {
+        for (int kk = 0; kk < n; ++kk) {
+          const int jj = i_start + kk;
+          const bool l0 = (i % n == 0) && (jj % n == 0);
+          double Rv, Rc;
+          if (a.kind == 1) {
+            Rv = a.Rsurf[i + (size_t)N * jj];
+            Rc = (c == 0) ? Rv : (a.dRsurf ? a.dRsurf[i + (size_t)N * jj + a.dR_stride * p] : 0.0);
+          } else if (a.kind == 0) {
+            Rv = l0 ? 2.0 * a.albedo : 0.0;
+            Rc = (c == 0) ? Rv : (l0 && a.dalbedo ? 2.0 * a.dalbedo[p] : 0.0);
+          } else {
+            Rv = l0 ? 2.0 * a.alb_spec[s] : 0.0;
+            Rc = (c == 0) ? Rv : (l0 && a.dalb_spec ? 2.0 * a.dalb_spec[s + (size_t)a.S * p] : 0.0);
+          }
+          RI += Rc * a.I0[kk];
+          RI0 += Rv * a.I0[kk];
+        }
+        if (i >= i_start && i < i_start + n && a.kind != 2) I0i = a.I0[i - i_start];  // Legendre: j0+ = 0 (:112)
+      }
+      const double datt = (c > 0 && a.dtau_sum) ? -(a.dtau_sum[ts + TS * p] / a.mu0) * att : 0.0;
+      const size_t ov = c * VS + u * N + i;
+      if (c == 0) {
+        a.j0p[ov] = I0i * att;
+        a.j0m[ov] = a.mu0 * RI * att;
+      } else {
+        a.j0p[ov] = I0i * datt;
+        a.j0m[ov] = a.mu0 * (RI * att + RI0 * datt);
+      }
+    }
+  }
+}
+
+// postprocessing_vza! (postprocessing_vza.jl:9-60, SFI branch) on Duals: R_SFI += bigCS J0-, T_SFI += bigCS J0+
+struct PostArgs {
+  int N, nS, U, P, S, nVza, m, M;
+  size_t u0;
+  const int *node;
+  const double *cos_mphi, *sin_mphi, *J0p, *J0m;
+  double *R, *T, *dR, *dT;  // [nVza,nS,S], [nVza,nS,S,P]
+};
+__global__ void k_dpost(PostArgs a) {
+  const size_t per = (size_t)a.nVza * a.nS, total = per * a.U * (a.P + 1);
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int v = (int)(idx % a.nVza), k = (int)((idx / a.nVza) % a.nS);
+  const size_t u = (idx / per) % a.U, c = idx / (per * a.U);
+  const double weight = (a.m == 0) ? 0.5 : 1.0;
+  const double cs = weight * ((k < 2) ? a.cos_mphi[v + (size_t)a.nVza * a.m] : a.sin_mphi[v + (size_t)a.nVza * a.m]);
+  const size_t row = (size_t)(a.node[v] - 1) * a.nS + k, o = (c * a.U + u) * a.N + row;
+  const size_t out = v + (size_t)a.nVza * (k + (size_t)a.nS * (a.u0 + u));
+  double *R = (c == 0) ? a.R : a.dR + per * a.S * (c - 1), *T = (c == 0) ? a.T : a.dT + per * a.S * (c - 1);
+  if (a.m == 0) { R[out] = cs * a.J0m[o]; T[out] = cs * a.J0p[o]; }
+  else { R[out] += cs * a.J0m[o]; T[out] += cs * a.J0p[o]; }
+}
+
+}  // namespace momd
+
+// =====================================================================================================================
+// host side
+// =====================================================================================================================
+#define DCHK(x)                                                                                        \
+  do {                                                                                                 \
+    const hipError_t e_ = (x);                                                                         \
+    if (e_ != hipSuccess) {                                                                            \
+      if (err) *err = std::string(#x) + ": " + hipGetErrorString(e_);                                  \
+      return 2;                                                                                        \
+    }                                                                                                  \
+  } while (0)
+
+namespace {
+struct Layer { double *r_mp, *r_pm, *t_pp, *t_mm, *jp, *jm; };   // added layer (DMs / DVs)
+struct Comp { double *R_mp, *R_pm, *T_pp, *T_mm, *Jp, *Jm; };    // composite layer
+}  // namespace
+
+size_t momd_bytes_per_unit(int N, int P) {
+  return ((size_t)14 * N * N + (size_t)14 * N + 1) * (P + 1) * sizeof(double);
+}
+
+int momd_run(const MomDualScene &sc, std::string *err) {
+  using namespace momd;
+  const int N = sc.N, P = sc.P, Nz = sc.Nz;
+  const size_t NN = (size_t)N * N;
+  if (N > 128) {
+    if (err) *err = "mom_rt_run_dual: operator edge N > 128 is not supported (the inverse runs in one CU's LDS)";
+    return 1;
+  }
+  hipStream_t st = sc.stream;
+  // chunk of units that fits the workspace
+  const size_t per_unit = momd_bytes_per_unit(N, P);
+  size_t Uc = std::min<size_t>(std::min<size_t>((size_t)sc.S, 65535), std::max<size_t>(1, sc.work_budget / per_unit));  // grid.y <= 65535
+  const size_t need = Uc * per_unit + 256;
+  if (*sc.work_cap < need) {
+    if (*sc.work) DCHK(hipFree(*sc.work));
+    *sc.work = nullptr;
+    *sc.work_cap = 0;
+    DCHK(hipMalloc(sc.work, need));
+    *sc.work_cap = need;
+  }
+  double *dts = nullptr;  // d tau_sum [S, Nz+1, P]
+  if (P > 0 && sc.dtau) {
+    dts = sc.dtau_sum_buf;
+    const size_t n = (size_t)sc.S * P;
+    hipLaunchKernelGGL(k_dtausum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc.S, Nz, P, sc.dtau, dts);
+  }
+  const size_t inv_lds = ((size_t)N * (N + 1) + 2 * N + 8) * sizeof(double) + (size_t)(N + 4) * sizeof(int);
+  DCHK(mom_allow_lds((const void *)k_dinv, inv_lds));
+
+  for (size_t u0 = 0; u0 < (size_t)sc.S; u0 += Uc) {
+    const int U = (int)std::min<size_t>(Uc, (size_t)sc.S - u0);
+    const size_t MS = (size_t)(P + 1) * U * NN, VS = (size_t)(P + 1) * U * N;
+    double *base = (double *)*sc.work;
+    auto mat = [&]() { double *p = base; base += MS; return p; };
+    auto vec = [&]() { double *p = base; base += VS; return p; };
+    Layer ad{mat(), mat(), mat(), mat(), vec(), vec()};
+    Comp co{mat(), mat(), mat(), mat(), vec(), vec()};
+    double *W = mat(), *G = mat(), *TG = mat(), *X = mat(), *Y = mat(), *t2 = mat();
+    double *j1p = vec(), *j1m = vec(), *va = vec(), *vb = vec(), *vn1 = vec(), *vn2 = vec();
+    double *ek = base;  // [(1+P)][U]
+    base += (size_t)(P + 1) * U;
+
+    const int tiles = (N + TM - 1) / TM;
+    auto gemm = [&](double *C, const double *A, const double *B, int mode, int c0, int nc, double alpha, const double *E,
+                    double beta, double eye) {
+      if (nc <= 0) return;
+      GemmArgs g{N, U, c0, mode, tiles, tiles, A, B, E, C, alpha, beta, eye};
+      hipLaunchKernelGGL(k_dgemm, dim3((unsigned)(tiles * tiles * nc), (unsigned)U), dim3(256), 0, st, g);
+    };
+    auto dual = [&](double *C, const double *A, const double *B) { gemm(C, A, B, 0, 0, P + 1, 1.0, nullptr, 0.0, 0.0); };
+    auto dual_add = [&](double *C, const double *A, const double *B, const double *E) { gemm(C, A, B, 0, 0, P + 1, 1.0, E, 1.0, 0.0); };
+    // G = inv(I - W) on Duals: value by Gauss-Jordan, partials G_c = G0 W_c G0 (d(I - W) = -dW)
+    auto inv_eye_minus = [&](double *Gm, const double *Wm) {
+      InvArgs ia{N, U, Wm, Gm, 1.0, -1.0, sc.info};
+      hipLaunchKernelGGL(k_dinv, dim3((unsigned)U), dim3(256), inv_lds, st, ia);
+      gemm(Y, Gm, Wm, 1, 1, P, 1.0, nullptr, 0.0, 0.0);
+      gemm(Gm, Y, Gm, 2, 1, P, 1.0, nullptr, 0.0, 0.0);
+    };
+    auto matvec = [&](const double *M, int nq, const double *x0, const double *a0, double *y0, const double *x1, const double *a1,
+                      double *y1) {
+      MvArgs mv{N, U, M, {x0, x1}, {a0, a1}, {y0, y1}};
+      hipLaunchKernelGGL(k_dmatvec, dim3((unsigned)(P + 1), (unsigned)U, (unsigned)nq), dim3(256), 0, st, mv);
+    };
+    const unsigned eblocks = (unsigned)((NN * U + 255) / 256);
+
+    // interaction_helper! for the four interfaces (interaction.jl:8-22, 27-43, 49-64, 69-117) on Duals
+    auto interaction = [&](int iface) {
+      if (iface == 0) {
+        matvec(ad.t_pp, 1, co.Jp, ad.jp, vn1, nullptr, nullptr, nullptr);     // J0+ = j0+ + t++ J0+
+        matvec(co.T_mm, 1, ad.jm, co.Jm, vn2, nullptr, nullptr, nullptr);     // J0- = J0- + T-- j0-
+        std::swap(co.Jp, vn1); std::swap(co.Jm, vn2);
+        dual(t2, ad.t_mm, co.T_mm); std::swap(co.T_mm, t2);                   // T-- = t-- T--
+        dual(t2, ad.t_pp, co.T_pp); std::swap(co.T_pp, t2);                   // T++ = t++ T++
+      } else if (iface == 1) {
+        matvec(ad.r_mp, 1, co.Jp, ad.jm, va, nullptr, nullptr, nullptr);      // r-+ J0+ + j0-
+        matvec(co.T_mm, 1, va, co.Jm, vn2, nullptr, nullptr, nullptr);        // J0- += T-- (.)
+        matvec(ad.t_pp, 1, co.Jp, ad.jp, vn1, nullptr, nullptr, nullptr);     // J0+ = j0+ + t++ J0+
+        std::swap(co.Jp, vn1); std::swap(co.Jm, vn2);
+        dual(X, co.T_mm, ad.r_mp); dual(co.R_mp, X, co.T_pp);                 // R-+ = (T-- r-+) T++
+        (void)hipMemcpyAsync(co.R_pm, ad.r_pm, MS * sizeof(double), hipMemcpyDeviceToDevice, st);  // R+- = r+-
+        dual(t2, ad.t_pp, co.T_pp); std::swap(co.T_pp, t2);                   // T++ = t++ T++
+        dual(t2, co.T_mm, ad.t_mm); std::swap(co.T_mm, t2);                   // T-- = T-- t--
+      } else if (iface == 2) {
+        matvec(co.R_pm, 1, ad.jm, co.Jp, va, nullptr, nullptr, nullptr);      // J0+ + R+- j0-
+        matvec(ad.t_pp, 1, va, ad.jp, vn1, nullptr, nullptr, nullptr);        // J0+ = j0+ + t++ (.)
+        matvec(co.T_mm, 1, ad.jm, co.Jm, vn2, nullptr, nullptr, nullptr);     // J0- += T-- j0-
+        std::swap(co.Jp, vn1); std::swap(co.Jm, vn2);
+        dual(X, ad.t_pp, co.R_pm); dual(co.R_pm, X, ad.t_mm);                 // R+- = (t++ R+-) t--
+        dual(t2, ad.t_pp, co.T_pp); std::swap(co.T_pp, t2);
+        dual(t2, co.T_mm, ad.t_mm); std::swap(co.T_mm, t2);
+      } else {
+        dual(W, ad.r_mp, co.R_pm);                                            // r-+ R+-                     (:76-79)
+        inv_eye_minus(G, W);
+        dual(TG, co.T_mm, G);                                                 // T01_inv = T-- (I - r-+ R+-)^-1
+        matvec(ad.r_mp, 1, co.Jp, ad.jm, va, nullptr, nullptr, nullptr);
+        matvec(TG, 1, va, co.Jm, vn2, nullptr, nullptr, nullptr);             // J0- += T01_inv (r-+ J0+ + j0-) (:82)
+        dual(X, TG, ad.r_mp); dual_add(co.R_mp, X, co.T_pp, co.R_mp);         // R-+ += (T01_inv r-+) T++      (:86)
+        dual(co.T_mm, TG, ad.t_mm);                                           // T-- = T01_inv t--             (:89)
+        dual(W, co.R_pm, ad.r_mp);                                            // R+- r-+                       (:93)
+        inv_eye_minus(G, W);
+        dual(TG, ad.t_pp, G);                                                 // T21_inv = t++ (I - R+- r-+)^-1
+        matvec(co.R_pm, 1, ad.jm, co.Jp, va, nullptr, nullptr, nullptr);
+        matvec(TG, 1, va, ad.jp, vn1, nullptr, nullptr, nullptr);             // J0+ = j0+ + T21_inv (J0+ + R+- j0-) (:100)
+        std::swap(co.Jp, vn1); std::swap(co.Jm, vn2);
+        dual(t2, TG, co.T_pp); std::swap(co.T_pp, t2);                        // T++ = T21_inv T++             (:104)
+        dual(X, TG, co.R_pm); dual_add(co.R_pm, X, ad.t_mm, ad.r_pm);         // R+- = r+- + (T21_inv R+-) t-- (:107)
+      }
+    };
+
+    for (int m = 0; m < sc.M; ++m) {
+      const size_t zoff = NN * sc.K * m;
+      for (int iz = 0; iz < Nz; ++iz) {
+        const int nd = sc.nd[iz];
+        ElArgs ea{};
+        ea.N = N; ea.nS = sc.nS; ea.U = U; ea.P = P; ea.K = sc.K; ea.S = sc.S; ea.Nz = Nz; ea.m = m; ea.iz = iz; ea.nd = nd;
+        ea.strict = sc.strict; ea.imu0 = sc.imu0; ea.u0 = u0; ea.mu0 = sc.mu0; ea.mu = sc.mu; ea.wt = sc.wt;
+        for (int k = 0; k < 4; ++k) { ea.I0[k] = sc.I0[k]; ea.D[k] = sc.D[k]; }
+        ea.tau = sc.tau; ea.varpi = sc.varpi; ea.zw = sc.zw; ea.tau_sum = sc.tau_sum;
+        ea.dtau = sc.dtau; ea.dvarpi = sc.dvarpi; ea.dzw = sc.dzw; ea.dtau_sum = dts;
+        ea.Zpp = sc.Zpp + zoff; ea.Zmp = sc.Zmp + zoff;
+        ea.dZpp = sc.dZpp ? sc.dZpp + zoff : nullptr; ea.dZmp = sc.dZmp ? sc.dZmp + zoff : nullptr;
+        ea.dZ_stride = NN * sc.K * sc.M;
+        ea.r_mp = ad.r_mp; ea.t_pp = ad.t_pp; ea.r_pm = ad.r_pm; ea.t_mm = ad.t_mm; ea.j0p = ad.jp; ea.j0m = ad.jm; ea.e = ek;
+        hipLaunchKernelGGL(k_delemental, dim3(eblocks), dim3(256), 0, st, ea);
+        // doubling_helper! (doubling.jl:43-68) on Duals
+        for (int it = 0; it < nd; ++it) {
+          dual(W, ad.r_mp, ad.r_mp);                                          // r-+ r-+                        (:46)
+          inv_eye_minus(G, W);                                                // gp_refl = (I - r-+ r-+)^-1
+          dual(TG, ad.t_pp, G);                                               // tt++_gp_refl                   (:47)
+          ScaleArgs sa{N, U, P, ad.jp, ad.jm, j1p, j1m, ek};
+          hipLaunchKernelGGL(k_dscale, dim3((unsigned)U), dim3(128), 0, st, sa);  // j1+-, expk^2            (:51-54, :62)
+          matvec(ad.r_mp, 2, ad.jp, j1m, va, j1m, ad.jp, vb);                 // j1- + r-+ j0+ ;  j0+ + r-+ j1-
+          matvec(TG, 2, va, ad.jm, vn2, vb, j1p, vn1);                        // j0- += TG (.) ; j0+ = j1+ + TG (.) (:57-60)
+          std::swap(ad.jm, vn2); std::swap(ad.jp, vn1);
+          dual(X, TG, ad.r_mp); dual_add(ad.r_mp, X, ad.t_pp, ad.r_mp);       // r-+ += (TG r-+) t++            (:65)
+          dual(t2, TG, ad.t_pp); std::swap(ad.t_pp, t2);                      // t++ = TG t++                   (:68)
+        }
+        if (nd > 0) {
+          SignArgs sg{N, sc.nS, U, P, sc.strict, ad.r_mp, ad.t_pp, ad.r_pm, ad.t_mm, ad.jm};
+          hipLaunchKernelGGL(k_dsign, dim3((unsigned)((MS + 255) / 256)), dim3(256), 0, st, sg);
+        }
+        if (iz == 0) {  // rt_kernel.jl:213-220: the first layer IS the composite layer
+          std::swap(co.R_mp, ad.r_mp); std::swap(co.R_pm, ad.r_pm); std::swap(co.T_pp, ad.t_pp); std::swap(co.T_mm, ad.t_mm);
+          std::swap(co.Jp, ad.jp); std::swap(co.Jm, ad.jm);
+        } else {
+          interaction(sc.iface[iz]);
+        }
+      }
+      SurfArgs sa{};
+      sa.N = N; sa.nS = sc.nS; sa.U = U; sa.P = P; sa.S = sc.S; sa.Nz = Nz; sa.m = m; sa.kind = sc.surf_kind; sa.imu0 = sc.imu0;
+      sa.u0 = u0; sa.mu0 = sc.mu0; sa.albedo = sc.albedo;
+      for (int k = 0; k < 4; ++k) sa.I0[k] = sc.I0[k];
+      sa.mu = sc.mu; sa.wt = sc.wt; sa.dalbedo = sc.dalbedo;
+      sa.Rsurf = sc.Rsurf ? sc.Rsurf + NN * m : nullptr; sa.dRsurf = sc.dRsurf ? sc.dRsurf + NN * m : nullptr;
+      sa.dR_stride = NN * sc.M;
+      sa.alb_spec = sc.albedo_spec; sa.dalb_spec = sc.dalbedo_spec; sa.tau_sum = sc.tau_sum; sa.dtau_sum = dts;
+      sa.r_mp = ad.r_mp; sa.t_pp = ad.t_pp; sa.r_pm = ad.r_pm; sa.t_mm = ad.t_mm; sa.j0p = ad.jp; sa.j0m = ad.jm;
+      hipLaunchKernelGGL(k_dsurface, dim3(eblocks), dim3(256), 0, st, sa);
+      interaction(sc.iface[Nz - 1]);  // rt_run.jl:198-200: the LAST layer's interface code
+      PostArgs pa{N, sc.nS, U, P, sc.S, sc.nVza, m, sc.M, u0, sc.node, sc.cos_mphi, sc.sin_mphi, co.Jp, co.Jm, sc.R, sc.T, sc.dR, sc.dT};
+      const size_t tot = (size_t)sc.nVza * sc.nS * U * (P + 1);
+      hipLaunchKernelGGL(k_dpost, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, pa);
+    }
+  }
+  DCHK(hipGetLastError());
+  return 0;
+}

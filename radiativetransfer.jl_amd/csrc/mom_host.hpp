@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <string>
 #include <utility>
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is set once per (device, kernel image) and raised only when a
@@ -42,6 +43,31 @@ hipError_t mom_voigt_profile_launch(hipStream_t st, const MomLineTable &tb, int 
 hipError_t mom_line_prefactors_launch(hipStream_t st, const MomLineTable &tb, int nGrid, const double *grid, double p, double T,
                                       double vmr, double wing, double cgd, double *nu, double *gd, double *y, double *S, int *i0,
                                       int *i1, int *unsorted);
+
+// mom_dual.hip: rt_run on ForwardDiff.Dual numbers (values + P partials) for the resident scene.  Device pointers unless noted;
+// partial arrays have the layout of their value arrays with the partial index as the slowest axis, nullptr = zero partials.
+struct MomDualScene {
+  int N, nS, S, Nz, K, M, P, nVza, imu0, strict, surf_kind;
+  double mu0, albedo;
+  double I0[4], D[4];
+  const double *mu, *wt;                                   // [N]
+  const double *tau, *varpi, *zw, *Zpp, *Zmp, *tau_sum;    // [S,Nz], [S,Nz], [K,S,Nz], [N,N,K,M] x2, [S,Nz+1]
+  const double *dtau, *dvarpi, *dzw, *dZpp, *dZmp;         // (.., P)
+  const double *dalbedo;                                   // [P]
+  const double *Rsurf, *dRsurf, *albedo_spec, *dalbedo_spec;  // [N,N,M](,P), [S](,P)
+  const int *nd, *iface;                                   // HOST [Nz]
+  const int *node;                                         // [nVza]
+  const double *cos_mphi, *sin_mphi;                       // [nVza,M]
+  double *R, *T, *dR, *dT;                                 // [nVza,nS,S], [nVza,nS,S,P]
+  double *dtau_sum_buf;                                    // [S,Nz+1,P] scratch
+  int *info;
+  hipStream_t stream;
+  void **work;                                             // workspace owned by the handle (grown on demand)
+  size_t *work_cap;
+  size_t work_budget;                                      // bytes the operator workspace may take (units are chunked to fit)
+};
+size_t momd_bytes_per_unit(int N, int P);
+int momd_run(const MomDualScene &sc, std::string *err);   // 0 ok, 1 unsupported, 2 HIP error (text in *err)
 
 // argument blocks of the single-launch sweep kernels, shared by the launching translation unit (momcore.hip) and the
 // kernels' own (mom_small.hip: momsm::k_sweep; mom_wave.hip: momw::k_wsweep)

@@ -427,6 +427,14 @@ struct mom_handle {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_go = nullptr;
   int surf_kind = 0;         // 0 Lambertian scalar, 1 BRDF matrices, 2 Lambertian Legendre (mom_scene_set_surface)
+  // ForwardDiff.Dual run (mom_dual.hip): partials of the scene's inputs and of the outputs, the operator workspace
+  int dual_P = 0;
+  bool dual_ran = false;
+  double *d_dual_in[8] = {};  // dtau, dvarpi, dzw, dZpp, dZmp, dalbedo, dRsurf, dalbedo_spec
+  double *d_dual_out = nullptr, *d_dual_ts = nullptr;  // dR | dT [nVza,nS,S,P] x 2; d tau_sum [S,Nz+1,P]
+  void *dual_work = nullptr;
+  size_t dual_work_cap = 0;
+  size_t opt_dual_budget = 0;  // MOM_OPT_DUAL_WORKSPACE_MB (0: 60 % of the free HBM at the time of the run)
   double *d_Rsurf = nullptr, *d_Rsurf0 = nullptr, *d_albedo_spec = nullptr, *d_hdrJm = nullptr;
   int opt_sweep = 1;       // one launch walks all layers of a unit (LayerArgs::Nz_sweep)
   double *comp_top[6] = {};  // mom_rt_run_multisensor: composite state of the slab above a sensor
@@ -661,6 +669,8 @@ extern "C" int mom_destroy(mom_t *h) {
   if (h->comm && g_rccl_destroy) g_rccl_destroy(h->comm);
   auto fr = [](void *p) { if (p) (void)hipFree(p); };
   fr(h->d_mu); fr(h->d_wt); fr(h->d_sg);
+  for (int k = 0; k < 8; ++k) fr(h->d_dual_in[k]);
+  fr(h->d_dual_out); fr(h->d_dual_ts); fr(h->dual_work);
   for (int k = 0; k < 6; ++k) { fr(h->added[k]); fr(h->surf[k]); fr(h->comp[k]); fr(h->comp_top[k]); }
   fr(h->d_msJ[0]); fr(h->d_msJ[1]); fr(h->d_ms_out);
   for (auto p : h->ms_comp) fr(p);
@@ -708,6 +718,10 @@ extern "C" int mom_set_option(mom_t *h, int option, int value) {
   else if (option == MOM_OPT_STRIP_PAD) { h->opt_pad = value; h->scene_set = false; }
   else if (option == MOM_OPT_LEAN) { h->opt_lean = value; h->scene_set = false; }  // the padded edge of the m = 0 sub-problem depends on it
   else if (option == MOM_OPT_OVERLAP) h->opt_overlap = value;
+  else if (option == MOM_OPT_DUAL_WORKSPACE_MB) {
+    if (value < 0) return fail(h, MOM_EINVAL, "mom_set_option: MOM_OPT_DUAL_WORKSPACE_MB takes megabytes >= 0 (0 = 60 % of the free HBM)");
+    h->opt_dual_budget = (size_t)value << 20;
+  }
   else if (option == MOM_OPT_RRS_KERNELS) {
     if (value < 0 || value > 63 || ((value & momr::KOPT_EL_FUSE_ON) && (value & momr::KOPT_EL_FUSE_OFF)))
       return fail(h, MOM_EINVAL, "mom_set_option: MOM_OPT_RRS_KERNELS takes a mask of bits 0..5 (bits 4 and 5 exclude each other)");
@@ -1833,6 +1847,106 @@ extern "C" int mom_rt_run_multisensor(mom_t *h, int nSensors, const int *sensor_
   }
   HIPCHK(h, hipMemcpyAsync(uwJ, d_uw, out1 * nSensors * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(dwJ, d_dw, out1 * nSensors * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return check_info(h);
+}
+
+// ---- ForwardDiff.Dual through rt_run (mom_dual.hip) ---------------------------------------------------------------
+// The partials of everything mom_scene_set / mom_scene_set_surface uploaded, in the layout of the value arrays with the
+// partial index as the slowest axis; NULL = that input does not depend on the parameters.
+extern "C" int mom_scene_set_partials(mom_t *h, int P, const double *dtau, const double *dvarpi, const double *dzw,
+                                      const double *dZpp, const double *dZmp, const double *dalbedo, const double *dRsurf,
+                                      const double *dalbedo_spec) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_scene_set_partials");
+  if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_scene_set_partials: call mom_scene_set first");
+  if (P < 0 || P > 64 || ((dZpp == nullptr) != (dZmp == nullptr)))
+    return fail(h, MOM_EINVAL, "mom_scene_set_partials: 0 <= P <= 64; dZpp and dZmp come together");
+  HIPCHK(h, hipSetDevice(h->device));
+  for (int k = 0; k < 8; ++k)
+    if (h->d_dual_in[k]) { (void)hipFree(h->d_dual_in[k]); h->d_dual_in[k] = nullptr; }
+  if (h->d_dual_out) { (void)hipFree(h->d_dual_out); h->d_dual_out = nullptr; }
+  if (h->d_dual_ts) { (void)hipFree(h->d_dual_ts); h->d_dual_ts = nullptr; }
+  h->dual_P = P;
+  h->dual_ran = false;
+  if (P == 0) return MOM_OK;
+  const size_t S = h->S, Nz = h->Nz, K = h->K, M = h->scene_M, N = h->N, Nk = h->Nk;
+  int rc;
+  if (dtau && (rc = upload_new(h, &h->d_dual_in[0], dtau, S * Nz * P))) return rc;
+  if (dvarpi && (rc = upload_new(h, &h->d_dual_in[1], dvarpi, S * Nz * P))) return rc;
+  if (dzw && (rc = upload_new(h, &h->d_dual_in[2], dzw, K * S * Nz * P))) return rc;
+  if (dZpp) {
+    if (Nk == N) {
+      if ((rc = upload_new(h, &h->d_dual_in[3], dZpp, N * N * K * M * P))) return rc;
+      if ((rc = upload_new(h, &h->d_dual_in[4], dZmp, N * N * K * M * P))) return rc;
+    } else {  // the scene's operators carry strip_pad's dummy entries (Z = 0): so do the partials
+      const std::vector<double> zp = pad_blocks(dZpp, (int)N, (int)Nk, K * M * P), zm = pad_blocks(dZmp, (int)N, (int)Nk, K * M * P);
+      if ((rc = upload_new(h, &h->d_dual_in[3], zp.data(), zp.size()))) return rc;
+      if ((rc = upload_new(h, &h->d_dual_in[4], zm.data(), zm.size()))) return rc;
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+  }
+  if (dalbedo && (rc = upload_new(h, &h->d_dual_in[5], dalbedo, (size_t)P))) return rc;
+  if (dRsurf && h->surf_kind == 1) {
+    const std::vector<double> rp = pad_blocks(dRsurf, (int)N, (int)Nk, M * P);
+    if ((rc = upload_new(h, &h->d_dual_in[6], rp.data(), rp.size()))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  if (dalbedo_spec && h->surf_kind == 2 && (rc = upload_new(h, &h->d_dual_in[7], dalbedo_spec, S * P))) return rc;
+  HIPCHK(h, dmalloc(&h->d_dual_out, 2 * (size_t)h->nVza * h->nS * S * P));
+  HIPCHK(h, dmalloc(&h->d_dual_ts, S * (Nz + 1) * P));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return MOM_OK;
+}
+
+// rt_run on Dual numbers for the resident scene: R_SFI / T_SFI (read with mom_get_RT) and their partials
+// (mom_get_RT_partials).  Asynchronous on the handle's stream like mom_rt_run.
+extern "C" int mom_rt_run_dual(mom_t *h) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  F64_ONLY(h, "mom_rt_run_dual");
+  if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_rt_run_dual: call mom_scene_set first");
+  HIPCHK(h, hipSetDevice(h->device));
+  MomDualScene sc{};
+  sc.N = h->Nk; sc.nS = h->nS; sc.S = h->S; sc.Nz = h->Nz; sc.K = h->K; sc.M = h->scene_M; sc.P = h->dual_P; sc.nVza = h->nVza;
+  sc.imu0 = h->q.imu0; sc.strict = h->strict; sc.surf_kind = h->surf_kind; sc.mu0 = h->q.mu0; sc.albedo = h->albedo;
+  for (int k = 0; k < 4; ++k) { sc.I0[k] = h->q.I0[k]; sc.D[k] = h->q.D[k]; }
+  sc.mu = h->d_mu; sc.wt = h->d_wt;
+  sc.tau = h->d_tau; sc.varpi = h->d_varpi; sc.zw = h->d_zw; sc.Zpp = h->d_Zpp; sc.Zmp = h->d_Zmp; sc.tau_sum = h->d_tau_sum;
+  sc.dtau = h->d_dual_in[0]; sc.dvarpi = h->d_dual_in[1]; sc.dzw = h->d_dual_in[2]; sc.dZpp = h->d_dual_in[3];
+  sc.dZmp = h->d_dual_in[4]; sc.dalbedo = h->d_dual_in[5]; sc.dRsurf = h->d_dual_in[6]; sc.dalbedo_spec = h->d_dual_in[7];
+  sc.Rsurf = h->d_Rsurf; sc.albedo_spec = h->d_albedo_spec;
+  sc.nd = h->nd.data(); sc.iface = h->iface.data(); sc.node = h->d_node; sc.cos_mphi = h->d_cos; sc.sin_mphi = h->d_sin;
+  const size_t out = (size_t)h->nVza * h->nS * h->S;
+  sc.R = h->d_R; sc.T = h->d_T; sc.dR = h->d_dual_out; sc.dT = h->d_dual_out ? h->d_dual_out + out * h->dual_P : nullptr;
+  sc.dtau_sum_buf = h->d_dual_ts; sc.info = h->d_info; sc.stream = h->stream;
+  sc.work = &h->dual_work; sc.work_cap = &h->dual_work_cap;
+  size_t budget = h->opt_dual_budget;
+  if (!budget) {
+    size_t fr = 0, tot = 0;
+    HIPCHK(h, hipMemGetInfo(&fr, &tot));
+    budget = (size_t)(0.6 * (double)(fr + h->dual_work_cap));
+  }
+  sc.work_budget = budget;
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  std::string err;
+  const int rc = momd_run(sc, &err);
+  if (rc == 1) return fail(h, MOM_EUNSUPPORTED, err.c_str());
+  if (rc) return fail(h, MOM_EHIP, err.c_str());
+  HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+  HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+  h->dual_ran = true;
+  h->comp_on_chip = true;  // no composite layer of this run is left in the handle's operator-level state
+  return MOM_OK;
+}
+
+extern "C" int mom_get_RT_partials(mom_t *h, double *dR_SFI, double *dT_SFI) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->dual_ran || h->dual_P == 0 || !dR_SFI || !dT_SFI)
+    return fail(h, MOM_ESTATE, "mom_get_RT_partials: no Dual run with P > 0 / null output");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->nVza * h->nS * h->S * h->dual_P * sizeof(double);
+  HIPCHK(h, hipMemcpyAsync(dR_SFI, h->d_dual_out, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dT_SFI, h->d_dual_out + bytes / sizeof(double), bytes, hipMemcpyDeviceToHost, h->stream));
   return check_info(h);
 }
 

@@ -1,0 +1,135 @@
+"""rt_run on ForwardDiff.Dual numbers (mom_scene_set_partials / mom_rt_run_dual / mom_get_RT_partials, csrc/mom_dual.hip)
+against oracle/dualref.py (the same Dual run of the numpy twin) through the C ABI: values to the Stokes bar, partials to the
+same bar relative to the largest partial of the view (tangents are propagated by the same products as the values)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import rtamd  # noqa: E402
+import helpers  # noqa: E402
+from oracle import dualref as dr, momref as mr  # noqa: E402
+from test_oracle_dual import random_partials  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def to_host(p: dr.Partial) -> rtamd.ScenePartial:
+    return rtamd.ScenePartial(dτ=p.dtau, dϖ=p.dvarpi, dzw=p.dzw, dZpp=p.dZpp, dZmp=p.dZmp, dalbedo=p.dalbedo, dRsurf=p.dRsurf,
+                              dalbedo_spec=p.dalbedo_spec)
+
+
+def assert_partial_close(d, dref, rtol, what):
+    """|d - dref| <= rtol * the largest |partial| of the same view (a partial of I crosses zero along the spectrum, so the
+    intensity-relative bar of the values is taken against the view's largest partial instead)."""
+    assert d.shape == dref.shape and np.all(np.isfinite(d)), what
+    scale = np.abs(dref).max(axis=(1, 2), keepdims=True)
+    err = np.abs(d - dref)
+    worst = float((err / np.maximum(scale, 1e-300)).max())
+    helpers._log_parity(what, rtol, worst, err.size)
+    assert np.all(err <= rtol * scale + helpers.ATOL_STOKES), f"{what}: {worst:.3e} of the view's largest partial > {rtol:.1e}"
+
+
+def compare(model, P=2, seed=0, with_Z=True, workspace_mb=0, rtol=None):
+    sc = helpers.oracle_scene(model)
+    L = dr.layer_inputs(sc)
+    ps = random_partials(L, P, seed=seed, with_Z=with_Z, kind=L.surf[0])
+    R, T, dR, dT = rtamd.rt_run_dual(model, [to_host(p) for p in ps], workspace_mb=workspace_mb)
+    Ro, To, dRo, dTo = dr.rt_run_dual(sc, ps, L)
+    rtol = rtol or helpers.stokes_rtol(max(L.ndoubl))
+    helpers.assert_stokes_close(R, Ro, what="dual R", rtol=rtol)
+    helpers.assert_stokes_close(T, To, what="dual T", rtol=rtol)
+    assert np.abs(dRo).max() > 0 and np.abs(dTo).max() > 0
+    for i in range(P):
+        assert_partial_close(dR[i], dRo[i], rtol, f"dR[{i}]")
+        assert_partial_close(dT[i], dTo[i], rtol, f"dT[{i}]")
+    return R, T, dR, dT
+
+
+@pytest.mark.parametrize("nS,ltr,Nz,S", [(1, 3, 3, 9), (3, 5, 4, 7), (4, 5, 3, 5), (3, 13, 3, 6), (1, 40, 2, 3)])
+def test_dual_run_matches_the_dual_oracle(nS, ltr, Nz, S):
+    """Scalar / IQU / IQUV, edges 4 .. 69 (one and two tiles of the product kernel), aerosol + absorption, all three moments."""
+    compare(rtamd.scenes.make_scene(nS, ltr, Nz, S, seed=3 + nS, aerosol_total=0.2), P=2, seed=ltr)
+
+
+def test_dual_values_equal_the_value_run():
+    m = rtamd.scenes.make_scene(3, 9, 5, 12, seed=8)
+    R, T, dR, dT = compare(m, P=1)
+    Rv, Tv = rtamd.rt_run(m)[:2]
+    helpers.assert_stokes_close(R, Rv, what="dual value vs mom_rt_run R")
+    helpers.assert_stokes_close(T, Tv, what="dual value vs mom_rt_run T")
+
+
+def test_dual_no_partials_and_single_partials():
+    """P = 0 is the plain run; a partial that only moves the albedo / only tau uses the NULL (no dependence) inputs."""
+    m = rtamd.scenes.make_scene(3, 5, 3, 6, seed=2, albedo=0.3)
+    R0, T0, dR0, _ = rtamd.rt_run_dual(m, [])
+    Rv, Tv = rtamd.rt_run(m)[:2]
+    assert dR0.shape[0] == 0
+    helpers.assert_stokes_close(R0, Rv, what="P = 0")
+    sc = helpers.oracle_scene(m)
+    L = dr.layer_inputs(sc)
+    for p in (dr.Partial(dalbedo=1.0), dr.Partial(dtau=L.tau.copy()), dr.Partial(dvarpi=-0.1 * L.varpi)):
+        _, _, dR, dT = rtamd.rt_run_dual(m, [to_host(p)])
+        _, _, dRo, dTo = dr.rt_run_dual(sc, [p], L)
+        assert_partial_close(dR[0], dRo[0], helpers.RTOL_STOKES, "single dR")
+        assert_partial_close(dT[0], dTo[0], helpers.RTOL_STOKES, "single dT")
+
+
+def test_dual_interfaces_and_zero_doublings():
+    """Non-scattering layers on top (interfaces 00 / 01), in the middle (10) and layers without doublings."""
+    m = rtamd.scenes.make_scene(3, 5, 6, 5, seed=11, aerosol_total=0.0, absorption=True)
+    m.τ_rayl[:, 0] = 0.0      # 00 then 01
+    m.τ_rayl[:, 3] = 0.0      # 10
+    m.τ_rayl[:, 1] *= 1e-4    # ndoubl = 0
+    sc = helpers.oracle_scene(m)
+    L = dr.layer_inputs(sc)
+    assert 0 in L.iface and 1 in L.iface and 2 in L.iface and 0 in L.ndoubl
+    compare(m, P=2, seed=4, with_Z=False)
+
+
+@pytest.mark.parametrize("surface", ["rpv", "legendre"])
+def test_dual_surface_types(surface):
+    m = rtamd.scenes.make_scene(3, 5, 3, 6, seed=5)
+    if surface == "rpv":
+        m.params.brdf = rtamd.corert.rpvSurfaceScalar(0.1, -0.1, 0.8, 0.05)
+    else:
+        m.params.brdf = rtamd.corert.LambertianSurfaceLegendre((0.3, 0.05, -0.02))
+    compare(m, P=2, seed=6)
+
+
+def test_dual_chunked_workspace_is_bitwise_the_unchunked_run():
+    """MOM_OPT_DUAL_WORKSPACE_MB small enough for several chunks of spectral points: units are independent."""
+    m = rtamd.scenes.make_scene(3, 9, 4, 40, seed=9)
+    sc = helpers.oracle_scene(m)
+    L = dr.layer_inputs(sc)
+    ps = [to_host(p) for p in random_partials(L, 2, seed=1)]
+    a = rtamd.rt_run_dual(m, ps)
+    b = rtamd.rt_run_dual(m, ps, workspace_mb=2)   # 30 x 30 operators, P = 2: 0.3 MB per point -> chunks of 6
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_dual_padded_operator_edge():
+    """A scene whose operators carry strip_pad's dummy entries (N = 58 -> 60): the partials of the bases are padded like the bases."""
+    m = rtamd.scenes.make_scene(1, 110, 2, 3, seed=1, aerosol_total=0.1)
+    assert m.quad_points.qp_μN.size not in (52, 56, 60)
+    compare(m, P=1, seed=2)
+
+
+def test_dual_errors():
+    m = rtamd.scenes.make_scene(1, 3, 2, 4, seed=1)
+    sc = rtamd.prepare_scene(m)
+    with rtamd.corert.make_handle(m) as h:
+        with pytest.raises(rtamd.MomError):
+            h.scene_set_partials(1)              # no scene yet
+        rtamd.corert.scene_set(h, sc)
+        with pytest.raises(rtamd.MomError):
+            h.scene_set_partials(1, dZpp=np.zeros(sc.Zpp.size))   # dZpp without dZmp
+        with pytest.raises(rtamd.MomError):
+            h.get_RT_partials()                  # no Dual run yet
