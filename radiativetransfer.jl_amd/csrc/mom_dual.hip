@@ -11,7 +11,7 @@
 // Every statement of rt_kernel!/elemental!/doubling_helper!/interaction_helper! (file:line at each step below) becomes one
 // launch that carries all components: products by k_dgemm (64 x 64 tiles on v_mfma_f64_16x16x4, the Dual product rule
 // applied per component: c = 0: A0 B0, c > 0: Ac B0 + A0 Bc), inverses by k_dinv (pivoted Gauss-Jordan in LDS, value only)
-// followed by two products for the partials (G_c = G0 (dW_c) G0), matrix-vector statements by k_dmatvec, the elemental
+// followed by two products per partial ((A G)_c = (A_c + (A G)_0 W_c) G0), matrix-vector statements by k_dmatvec, the elemental
 // layer by k_delemental (analytic derivatives of get_elem_rt! / get_elem_rt_SFI!).  A batched product of N = 60 reads
 // and writes 86 KB per 432 kFLOP: the sweep is HBM-bound (about 5 FLOP/B against 9.8 at the ridge), not MFMA-bound --
 // the operators of value AND partials do not fit one CU's LDS (14 x (1 + P) x 29 KB per unit), which is why this path
@@ -38,58 +38,99 @@ constexpr int TM = 64, TN = 64, KC = 32, LDA = TM + 2, LDB = KC + 2;
 // C_c = alpha * prod_c + beta * E_c + eye * (c == 0) I          mode 0: Dual product rule, 1: A0 Bc, 2: Ac B0
 // ---------------------------------------------------------------------------------------------------------------------
 struct GemmArgs {
-  int N, U, c0, mode, tiles_i, tiles_j;
+  int N, U, c0, nc, mode, tiles_i, tiles_j;
   const double *A, *B, *E;
   double *C;
   double alpha, beta, eye;
 };
 
+template <bool VEC2>
 __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
-  __shared__ double As[KC * LDA];  // As[i + k LDA]
-  __shared__ double Bs[TN * LDB];  // Bs[k + j LDB]
+  __shared__ __attribute__((aligned(16))) double As[KC * LDA];  // As[i + k LDA]
+  __shared__ __attribute__((aligned(16))) double Bs[TN * LDB];  // Bs[k + j LDB]
+  typedef double d2 __attribute__((ext_vector_type(2)));
   const int N = a.N;
   const size_t NN = (size_t)N * N, CS = (size_t)a.U * NN;
-  const int ntile = a.tiles_i * a.tiles_j;
-  const int tile = blockIdx.x % ntile, c = a.c0 + blockIdx.x / ntile;
+  const int ntile = a.tiles_i * a.tiles_j, nb = ntile * a.nc;
+  // workgroups b and b + 8 share an XCD (MI355X_MICROARCH.md, dispatch): all tiles and components of one unit go to ONE XCD, next
+  // to each other in time, so the value operands A0 / B0 every component needs are read from HBM once and from that L2 afterwards
+  const int slot = blockIdx.x >> 3, inner = slot % nb, unit = (slot / nb) * 8 + (blockIdx.x & 7);
+  if (unit >= a.U) return;
+  const int tile = inner % ntile, c = a.c0 + inner / ntile;
   const int i0 = (tile % a.tiles_i) * TM, j0 = (tile / a.tiles_i) * TN;
-  const size_t uo = (size_t)blockIdx.y * NN;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, lq = lane >> 4, lr = lane & 15;
+  const size_t uo = (size_t)unit * NN;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6, lq = lane >> 4, lr = lane & 15;
   d4 acc[4];
 #pragma unroll
   for (int tb = 0; tb < 4; ++tb) acc[tb] = d4{0.0, 0.0, 0.0, 0.0};
   const double *TA[2], *TB[2];
   int nterms = 1;
   const double *A0 = a.A + uo, *B0 = a.B + uo, *Ac = a.A + c * CS + uo, *Bc = a.B + c * CS + uo;
+  TA[1] = A0; TB[1] = Bc;
   if (a.mode == 0) {
     if (c == 0) { TA[0] = A0; TB[0] = B0; }
-    else { nterms = 2; TA[0] = Ac; TB[0] = B0; TA[1] = A0; TB[1] = Bc; }
+    else { nterms = 2; TA[0] = Ac; TB[0] = B0; }
   } else if (a.mode == 1) { TA[0] = A0; TB[0] = Bc; }
   else { TA[0] = Ac; TB[0] = B0; }
-  for (int t = 0; t < nterms; ++t) {
-    const double *Ag = TA[t], *Bg = TB[t];
-    for (int k0 = 0; k0 < N; k0 += KC) {
-      __syncthreads();
+  const int nch = (N + KC - 1) / KC, nph = nterms * nch;
+  // the next (term, K chunk) is fetched into registers while the matrix cores work on the current one
+  d2 ra[4], rb[4];
+  double sa[8], sb[8];
+  auto gload = [&](int ph) {
+    const double *Ag = TA[ph / nch], *Bg = TB[ph / nch];
+    const int k0 = (ph % nch) * KC;
+    if (VEC2) {  // N even: pairs along the contiguous axis are 16-byte aligned and never straddle the edge
 #pragma unroll
-      for (int e = threadIdx.x; e < TM * KC; e += 256) {
-        const int i = e & (TM - 1), k = e >> 6, gi = i0 + i, gk = k0 + k;
-        As[i + k * LDA] = (gi < N && gk < N) ? Ag[gi + (size_t)gk * N] : 0.0;
+      for (int q = 0; q < 4; ++q) {
+        const int e = t + 256 * q;
+        { const int i = 2 * (e & 31), k = e >> 5, gi = i0 + i, gk = k0 + k;
+          ra[q] = (gi < N && gk < N) ? *(const d2 *)(Ag + gi + (size_t)gk * N) : d2{0.0, 0.0}; }
+        { const int k = 2 * (e & 15), j = e >> 4, gk = k0 + k, gj = j0 + j;
+          rb[q] = (gk < N && gj < N) ? *(const d2 *)(Bg + gk + (size_t)gj * N) : d2{0.0, 0.0}; }
       }
+    } else {
 #pragma unroll
-      for (int e = threadIdx.x; e < TN * KC; e += 256) {
-        const int k = e & (KC - 1), j = e >> 5, gk = k0 + k, gj = j0 + j;
-        Bs[k + j * LDB] = (gk < N && gj < N) ? Bg[gk + (size_t)gj * N] : 0.0;
+      for (int q = 0; q < 8; ++q) {
+        const int e = t + 256 * q;
+        { const int i = e & (TM - 1), k = e >> 6, gi = i0 + i, gk = k0 + k;
+          sa[q] = (gi < N && gk < N) ? Ag[gi + (size_t)gk * N] : 0.0; }
+        { const int k = e & (KC - 1), j = e >> 5, gk = k0 + k, gj = j0 + j;
+          sb[q] = (gk < N && gj < N) ? Bg[gk + (size_t)gj * N] : 0.0; }
       }
-      __syncthreads();
-      const int kmax = min(KC, N - k0);
-      // the product transposed on the matrix core (rows of the MFMA tile = columns j of C, columns = rows i): the 16 lanes of a
-      // quarter-wave then hold 16 consecutive rows of one column of C, so the stores of the epilogue are 128-byte segments
-      for (int kk = 0; kk < kmax; kk += 4) {
-        const double bv = Bs[(kk + lq) + (16 * w + lr) * LDB];
+    }
+  };
+  auto sstore = [&]() {
+    if (VEC2) {
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb) {
-          const double av = As[(16 * tb + lr) + (kk + lq) * LDA];
-          acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc[tb], 0, 0, 0);
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int e = t + 256 * q;
+        *(d2 *)(As + 2 * (e & 31) + (e >> 5) * LDA) = ra[q];
+        *(d2 *)(Bs + 2 * (e & 15) + (e >> 4) * LDB) = rb[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = t + 256 * q;
+        As[(e & (TM - 1)) + (e >> 6) * LDA] = sa[q];
+        Bs[(e & (KC - 1)) + (e >> 5) * LDB] = sb[q];
+      }
+    }
+  };
+  gload(0);
+  for (int ph = 0; ph < nph; ++ph) {
+    __syncthreads();
+    sstore();
+    __syncthreads();
+    if (ph + 1 < nph) gload(ph + 1);
+    const int kmax = min(KC, N - (ph % nch) * KC);
+    // the product transposed on the matrix core (rows of the MFMA tile = columns j of C, columns = rows i): the 16 lanes of a
+    // quarter-wave then hold 16 consecutive rows of one column of C, so the stores of the epilogue are 128-byte segments
+    for (int kk = 0; kk < kmax; kk += 4) {
+      const double bv = Bs[(kk + lq) + (16 * w + lr) * LDB];
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) {
+        const double av = As[(16 * tb + lr) + (kk + lq) * LDA];
+        acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc[tb], 0, 0, 0);
       }
     }
   }
@@ -122,72 +163,155 @@ struct InvArgs {
   int *info;
 };
 
+// The matrix lives in REGISTERS: thread (tx, ty) owns A[ty + 4 s][tx + 64 jb]; per elimination step only the pivot row, the old
+// row k and column k pass through LDS (the first form kept the matrix in LDS and spent its time on 2 x 29 KB of LDS traffic per
+// step).  Two barriers per step: the owners of column k + 1 collect the next pivot's candidates during the update.
+#define MOMD_ROW_CASES(F)                                                                                          \
+  F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15) F(16) F(17) F(18) F(19) F(20) F(21) \
+  F(22) F(23) F(24) F(25) F(26) F(27) F(28) F(29) F(30) F(31)
+template <int NBK>
 __global__ void __launch_bounds__(256) k_dinv(InvArgs a) {
+  constexpr int RPT = 16 * NBK;
   extern __shared__ double sm[];
-  const int N = a.N, LD = N + 1, t = threadIdx.x;
-  double *A = sm, *rowk = sm + (size_t)N * LD, *colk = rowk + N, *red = colk + N;  // red: 8 doubles
-  int *piv = (int *)(red + 8), *redi = piv + N;                                     // redi: 4 ints
+  const int N = a.N, LD = N | 1, t = threadIdx.x, tx = t & 63;
+  const int ty = __builtin_amdgcn_readfirstlane(t >> 6);   // rows are wave-uniform: scalar tests
+  double *A = sm, *rowk = sm + (size_t)N * LD, *rowx = rowk + 64 * NBK, *colr = rowx + 64 * NBK, *cand = colr + 64 * NBK;
+  int *piv = (int *)(cand + 8), *candi = piv + 64 * NBK, *dst = candi + 4, *src = dst + 64 * NBK;
   const size_t NN = (size_t)N * N, uo = (size_t)blockIdx.x * NN;
-  for (int e = t; e < (int)NN; e += 256) {
-    const int i = e % N, j = e / N;
-    A[i * LD + j] = a.s * a.W[uo + e] + (i == j ? a.eye : 0.0);
+  for (int j = ty; j < N; j += 4)
+    for (int i = tx; i < N; i += 64) A[i * LD + j] = a.s * a.W[uo + i + (size_t)j * N] + (i == j ? a.eye : 0.0);
+  __syncthreads();
+  double R[RPT][NBK];
+#pragma unroll
+  for (int s = 0; s < RPT; ++s)
+#pragma unroll
+    for (int jb = 0; jb < NBK; ++jb) {
+      const int i = ty + 4 * s, j = tx + 64 * jb;
+      R[s][jb] = (i < N && j < N) ? A[i * LD + j] : 0.0;
+    }
+  // the row `srow` of this wave, selected by a scalar switch (the register file is indexed statically)
+  auto with_row = [&](int srow, auto &&f) {
+    switch (srow) {
+#define MOMD_CASE(S) case S: if constexpr (S < RPT) f(R[S < RPT ? S : 0]); break;
+      MOMD_ROW_CASES(MOMD_CASE)
+#undef MOMD_CASE
+      default: break;
+    }
+  };
+  if (tx == 0) {  // candidates of column 0
+    double best = -1.0, val = 0.0;
+    int bi = 0;
+#pragma unroll
+    for (int s = 0; s < RPT; ++s) {
+      const int i = ty + 4 * s;
+      if (i < N && fabs(R[s][0]) > best) { best = fabs(R[s][0]); val = R[s][0]; bi = i; }
+    }
+    cand[2 * ty] = best; cand[2 * ty + 1] = val; candi[ty] = bi;
   }
   __syncthreads();
   bool bad = false;
   for (int k = 0; k < N; ++k) {
-    double best = -1.0;
-    int bi = k;
-    for (int i = k + t; i < N; i += 256) {
-      const double v = fabs(A[i * LD + k]);
-      if (v > best) { best = v; bi = i; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ob = __shfl_down(best, off);
-      const int oi = __shfl_down(bi, off);
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
-    if ((t & 63) == 0) { red[t >> 6] = best; redi[t >> 6] = bi; }
-    __syncthreads();
-    best = red[0]; bi = redi[0];
+    double best = cand[0], val = cand[1];
+    int pv = candi[0];
 #pragma unroll
     for (int q = 1; q < 4; ++q)
-      if (red[q] > best || (red[q] == best && redi[q] < bi)) { best = red[q]; bi = redi[q]; }
+      if (cand[2 * q] > best || (cand[2 * q] == best && candi[q] < pv)) { best = cand[2 * q]; val = cand[2 * q + 1]; pv = candi[q]; }
     if (!(best > 0.0)) bad = true;
-    if (t == 0) piv[k] = bi;
-    if (bi != k)
-      for (int j = t; j < N; j += 256) {
-        const double x = A[k * LD + j];
-        A[k * LD + j] = A[bi * LD + j];
-        A[bi * LD + j] = x;
-      }
-    __syncthreads();
-    const double pinv = 1.0 / A[k * LD + k];
-    __syncthreads();
-    for (int j = t; j < N; j += 256) {
-      rowk[j] = A[k * LD + j] * pinv;
-      colk[j] = A[j * LD + k];
+    const int p = __builtin_amdgcn_readfirstlane(pv);
+    const double pinv = 1.0 / val;
+    if (t == 0) piv[k] = p;
+    const int kb = k >> 6, kx = k & 63;
+    // stage: the scaled pivot row, the old row k, column k (as it stands, before the row exchange).  The owners of column k
+    // then clear it, so that the update below is the same expression in every column (column k: 0 - c_i * pinv).
+    if ((p & 3) == ty)
+      with_row(p >> 2, [&](double (&row)[NBK]) {
+#pragma unroll
+        for (int jb = 0; jb < NBK; ++jb)
+          if (tx + 64 * jb < N) rowk[tx + 64 * jb] = row[jb] * pinv;
+      });
+    if ((k & 3) == ty && p != k)
+      with_row(k >> 2, [&](double (&row)[NBK]) {
+#pragma unroll
+        for (int jb = 0; jb < NBK; ++jb)
+          if (tx + 64 * jb < N) rowx[tx + 64 * jb] = row[jb];
+      });
+    if (tx == kx) {
+#pragma unroll
+      for (int jb = 0; jb < NBK; ++jb)
+        if (jb == kb) {
+#pragma unroll
+          for (int s = 0; s < RPT; ++s) {
+            colr[(ty * RPT) + s] = R[s][jb];   // colr[(i % 4) RPT + i / 4]: each wave's rows are contiguous
+            R[s][jb] = 0.0;
+          }
+        }
     }
     __syncthreads();
-    for (int e = t; e < (int)NN; e += 256) {
-      const int i = e / N, j = e - i * N;
-      double v;
-      if (i == k) v = (j == k) ? pinv : rowk[j];
-      else v = (j == k) ? -colk[i] * pinv : A[i * LD + j] - colk[i] * rowk[j];
-      A[i * LD + j] = v;
+    const int kn = k + 1, nb_ = kn >> 6, nx = kn & 63;
+    double cr[RPT];
+#pragma unroll
+    for (int s = 0; s < RPT; ++s) cr[s] = colr[ty * RPT + s];
+    double rk[NBK];
+#pragma unroll
+    for (int jb = 0; jb < NBK; ++jb) {
+      const int j = tx + 64 * jb;
+      rk[jb] = (j == k) ? pinv : ((j < N) ? rowk[j] : 0.0);
+#pragma unroll
+      for (int s = 0; s < RPT; ++s) R[s][jb] = R[s][jb] - cr[s] * rk[jb];   // every row as a plain row ...
+    }
+    // ... then the two special ones
+    if ((p & 3) == ty && p != k) {   // row p takes the old row k (exchange) and is updated with ITS column-k entry
+      const double ckk = colr[(k & 3) * RPT + (k >> 2)];
+      with_row(p >> 2, [&](double (&row)[NBK]) {
+#pragma unroll
+        for (int jb = 0; jb < NBK; ++jb) {
+          const int j = tx + 64 * jb;
+          const double rx = (j == k) ? 0.0 : ((j < N) ? rowx[j] : 0.0);
+          row[jb] = rx - ckk * rk[jb];
+        }
+      });
+    }
+    if ((k & 3) == ty)               // the pivot row
+      with_row(k >> 2, [&](double (&row)[NBK]) {
+#pragma unroll
+        for (int jb = 0; jb < NBK; ++jb) row[jb] = rk[jb];
+      });
+    if (tx == nx && kn < N) {
+      double best2 = -1.0, val2 = 0.0;
+      int bi2 = kn;
+#pragma unroll
+      for (int jb = 0; jb < NBK; ++jb)
+        if (jb == nb_) {
+#pragma unroll
+          for (int s = 0; s < RPT; ++s) {
+            const int i = ty + 4 * s;
+            const double v = R[s][jb];
+            if (i >= kn && i < N && fabs(v) > best2) { best2 = fabs(v); val2 = v; bi2 = i; }
+          }
+        }
+      cand[2 * ty] = best2; cand[2 * ty + 1] = val2; candi[ty] = bi2;
     }
     __syncthreads();
   }
-  for (int k = N - 1; k >= 0; --k) {
-    const int p = piv[k];
-    if (p != k)
-      for (int i = t; i < N; i += 256) {
-        const double x = A[i * LD + k];
-        A[i * LD + k] = A[i * LD + p];
-        A[i * LD + p] = x;
-      }
-    __syncthreads();
+  // undo the row exchanges as column exchanges in reverse order: dst[j] = final position of the working column j
+  if (t == 0) {
+    for (int j = 0; j < N; ++j) src[j] = j;
+    for (int k = N - 1; k >= 0; --k) {
+      const int p = piv[k], x = src[k];
+      src[k] = src[p];
+      src[p] = x;
+    }
+    for (int j = 0; j < N; ++j) dst[src[j]] = j;
   }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < RPT; ++s)
+#pragma unroll
+    for (int jb = 0; jb < NBK; ++jb) {
+      const int i = ty + 4 * s, j = tx + 64 * jb;
+      if (i < N && j < N) A[i * LD + dst[j]] = R[s][jb];
+    }
+  __syncthreads();
   for (int e = t; e < (int)NN; e += 256) {
     const int i = e % N, j = e / N;
     a.G[uo + e] = A[i * LD + j];
@@ -199,32 +323,43 @@ __global__ void __launch_bounds__(256) k_dinv(InvArgs a) {
 // y_c = add_c + (M x)_c with the Dual product rule, for up to two (x, add, y) sets sharing M
 // ---------------------------------------------------------------------------------------------------------------------
 struct MvArgs {
-  int N, U;
+  int N, U, nq;
   const double *M;
   const double *x[2], *add[2];
   double *y[2];
 };
 
 __global__ void __launch_bounds__(256) k_dmatvec(MvArgs a) {
-  __shared__ double part[4][64];
-  const int N = a.N, c = blockIdx.x, q = blockIdx.z, t = threadIdx.x, g = t >> 6, il = t & 63;
-  const size_t NN = (size_t)N * N, u = blockIdx.y;
+  __shared__ double part[2][4][64];
+  const int N = a.N, c = blockIdx.x, t = threadIdx.x, g = t >> 6, il = t & 63, nq = a.nq;
+  const size_t NN = (size_t)N * N, u = blockIdx.y, vo0 = u * N, voc = ((size_t)c * a.U + u) * N;
   const double *M0 = a.M + u * NN, *Mc = a.M + ((size_t)c * a.U + u) * NN;
-  const double *x0 = a.x[q] + u * N, *xc = a.x[q] + ((size_t)c * a.U + u) * N;
-  const double *ad = a.add[q] ? a.add[q] + ((size_t)c * a.U + u) * N : nullptr;
-  double *y = a.y[q] + ((size_t)c * a.U + u) * N;
   for (int rb = 0; rb < N; rb += 64) {
     const int i = rb + il;
-    double s = 0.0;
+    double s0 = 0.0, s1 = 0.0;
     if (i < N) {
-      if (c == 0)
-        for (int j = g; j < N; j += 4) s += M0[i + (size_t)j * N] * x0[j];
-      else
-        for (int j = g; j < N; j += 4) s += Mc[i + (size_t)j * N] * x0[j] + M0[i + (size_t)j * N] * xc[j];
+      // the matrix is read once for both vector sets
+      if (c == 0) {
+        for (int j = g; j < N; j += 4) {
+          const double m0 = M0[i + (size_t)j * N];
+          s0 += m0 * a.x[0][vo0 + j];
+          if (nq > 1) s1 += m0 * a.x[1][vo0 + j];
+        }
+      } else {
+        for (int j = g; j < N; j += 4) {
+          const double m0 = M0[i + (size_t)j * N], mc = Mc[i + (size_t)j * N];
+          s0 += mc * a.x[0][vo0 + j] + m0 * a.x[0][voc + j];
+          if (nq > 1) s1 += mc * a.x[1][vo0 + j] + m0 * a.x[1][voc + j];
+        }
+      }
     }
-    part[g][il] = s;
+    part[0][g][il] = s0;
+    part[1][g][il] = s1;
     __syncthreads();
-    if (g == 0 && i < N) y[i] = (ad ? ad[i] : 0.0) + ((part[0][il] + part[1][il]) + (part[2][il] + part[3][il]));
+    if (g < nq && i < N) {
+      const double *ad = a.add[g];
+      a.y[g][voc + i] = (ad ? ad[voc + i] : 0.0) + ((part[g][0][il] + part[g][1][il]) + (part[g][2][il] + part[g][3][il]));
+    }
     __syncthreads();
   }
 }
@@ -612,8 +747,10 @@ int momd_run(const MomDualScene &sc, std::string *err) {
     const size_t n = (size_t)sc.S * P;
     hipLaunchKernelGGL(k_dtausum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc.S, Nz, P, sc.dtau, dts);
   }
-  const size_t inv_lds = ((size_t)N * (N + 1) + 2 * N + 8) * sizeof(double) + (size_t)(N + 4) * sizeof(int);
-  DCHK(mom_allow_lds((const void *)k_dinv, inv_lds));
+  const int nbk = (N <= 64) ? 1 : 2;
+  const size_t inv_lds = ((size_t)N * (N | 1) + 3 * 64 * nbk + 8) * sizeof(double) + (size_t)(3 * 64 * nbk + 8) * sizeof(int);
+  DCHK(mom_allow_lds((const void *)k_dinv<1>, inv_lds));
+  DCHK(mom_allow_lds((const void *)k_dinv<2>, inv_lds));
 
   for (size_t u0 = 0; u0 < (size_t)sc.S; u0 += Uc) {
     const int U = (int)std::min<size_t>(Uc, (size_t)sc.S - u0);
@@ -632,22 +769,27 @@ int momd_run(const MomDualScene &sc, std::string *err) {
     auto gemm = [&](double *C, const double *A, const double *B, int mode, int c0, int nc, double alpha, const double *E,
                     double beta, double eye) {
       if (nc <= 0) return;
-      GemmArgs g{N, U, c0, mode, tiles, tiles, A, B, E, C, alpha, beta, eye};
-      hipLaunchKernelGGL(k_dgemm, dim3((unsigned)(tiles * tiles * nc), (unsigned)U), dim3(256), 0, st, g);
+      GemmArgs g{N, U, c0, nc, mode, tiles, tiles, A, B, E, C, alpha, beta, eye};
+      const dim3 grid((unsigned)(8 * tiles * tiles * nc * ((U + 7) / 8)));
+      if (N % 2 == 0) hipLaunchKernelGGL(k_dgemm<true>, grid, dim3(256), 0, st, g);
+      else hipLaunchKernelGGL(k_dgemm<false>, grid, dim3(256), 0, st, g);
     };
     auto dual = [&](double *C, const double *A, const double *B) { gemm(C, A, B, 0, 0, P + 1, 1.0, nullptr, 0.0, 0.0); };
     auto dual_add = [&](double *C, const double *A, const double *B, const double *E) { gemm(C, A, B, 0, 0, P + 1, 1.0, E, 1.0, 0.0); };
-    // G = inv(I - W) on Duals: value by Gauss-Jordan, partials G_c = G0 W_c G0 (d(I - W) = -dW)
-    auto inv_eye_minus = [&](double *Gm, const double *Wm) {
-      InvArgs ia{N, U, Wm, Gm, 1.0, -1.0, sc.info};
-      hipLaunchKernelGGL(k_dinv, dim3((unsigned)U), dim3(256), inv_lds, st, ia);
-      gemm(Y, Gm, Wm, 1, 1, P, 1.0, nullptr, 0.0, 0.0);
-      gemm(Gm, Y, Gm, 2, 1, P, 1.0, nullptr, 0.0, 0.0);
+    // OUT = A (I - W)^-1 on Duals (batch_inv! + batched_mul, gpu_batched.jl:100-150): G0 = (I - W0)^-1 by Gauss-Jordan, OUT0 = A0 G0,
+    // and with dG = G dW G the partials are OUT_c = A_c G0 + A0 G0 W_c G0 = (A_c + OUT0 W_c) G0: two products per partial
+    auto times_inv = [&](double *OUT, const double *A, const double *Wm) {
+      InvArgs ia{N, U, Wm, G, 1.0, -1.0, sc.info};
+      if (nbk == 1) hipLaunchKernelGGL(k_dinv<1>, dim3((unsigned)U), dim3(256), inv_lds, st, ia);
+      else hipLaunchKernelGGL(k_dinv<2>, dim3((unsigned)U), dim3(256), inv_lds, st, ia);
+      gemm(OUT, A, G, 0, 0, 1, 1.0, nullptr, 0.0, 0.0);
+      gemm(Y, OUT, Wm, 1, 1, P, 1.0, A, 1.0, 0.0);
+      gemm(OUT, Y, G, 2, 1, P, 1.0, nullptr, 0.0, 0.0);
     };
     auto matvec = [&](const double *M, int nq, const double *x0, const double *a0, double *y0, const double *x1, const double *a1,
                       double *y1) {
-      MvArgs mv{N, U, M, {x0, x1}, {a0, a1}, {y0, y1}};
-      hipLaunchKernelGGL(k_dmatvec, dim3((unsigned)(P + 1), (unsigned)U, (unsigned)nq), dim3(256), 0, st, mv);
+      MvArgs mv{N, U, nq, M, {x0, x1}, {a0, a1}, {y0, y1}};
+      hipLaunchKernelGGL(k_dmatvec, dim3((unsigned)(P + 1), (unsigned)U), dim3(256), 0, st, mv);
     };
     const unsigned eblocks = (unsigned)((NN * U + 255) / 256);
 
@@ -678,15 +820,13 @@ int momd_run(const MomDualScene &sc, std::string *err) {
         dual(t2, co.T_mm, ad.t_mm); std::swap(co.T_mm, t2);
       } else {
         dual(W, ad.r_mp, co.R_pm);                                            // r-+ R+-                     (:76-79)
-        inv_eye_minus(G, W);
-        dual(TG, co.T_mm, G);                                                 // T01_inv = T-- (I - r-+ R+-)^-1
+        times_inv(TG, co.T_mm, W);                                            // T01_inv = T-- (I - r-+ R+-)^-1
         matvec(ad.r_mp, 1, co.Jp, ad.jm, va, nullptr, nullptr, nullptr);
         matvec(TG, 1, va, co.Jm, vn2, nullptr, nullptr, nullptr);             // J0- += T01_inv (r-+ J0+ + j0-) (:82)
         dual(X, TG, ad.r_mp); dual_add(co.R_mp, X, co.T_pp, co.R_mp);         // R-+ += (T01_inv r-+) T++      (:86)
         dual(co.T_mm, TG, ad.t_mm);                                           // T-- = T01_inv t--             (:89)
         dual(W, co.R_pm, ad.r_mp);                                            // R+- r-+                       (:93)
-        inv_eye_minus(G, W);
-        dual(TG, ad.t_pp, G);                                                 // T21_inv = t++ (I - R+- r-+)^-1
+        times_inv(TG, ad.t_pp, W);                                            // T21_inv = t++ (I - R+- r-+)^-1
         matvec(co.R_pm, 1, ad.jm, co.Jp, va, nullptr, nullptr, nullptr);
         matvec(TG, 1, va, ad.jp, vn1, nullptr, nullptr, nullptr);             // J0+ = j0+ + T21_inv (J0+ + R+- j0-) (:100)
         std::swap(co.Jp, vn1); std::swap(co.Jm, vn2);
@@ -713,8 +853,7 @@ int momd_run(const MomDualScene &sc, std::string *err) {
         // doubling_helper! (doubling.jl:43-68) on Duals
         for (int it = 0; it < nd; ++it) {
           dual(W, ad.r_mp, ad.r_mp);                                          // r-+ r-+                        (:46)
-          inv_eye_minus(G, W);                                                // gp_refl = (I - r-+ r-+)^-1
-          dual(TG, ad.t_pp, G);                                               // tt++_gp_refl                   (:47)
+          times_inv(TG, ad.t_pp, W);                                          // tt++_gp_refl = t++ (I - r-+ r-+)^-1 (:46-47)
           ScaleArgs sa{N, U, P, ad.jp, ad.jm, j1p, j1m, ek};
           hipLaunchKernelGGL(k_dscale, dim3((unsigned)U), dim3(128), 0, st, sa);  // j1+-, expk^2            (:51-54, :62)
           matvec(ad.r_mp, 2, ad.jp, j1m, va, j1m, ad.jp, vb);                 // j1- + r-+ j0+ ;  j0+ + r-+ j1-
