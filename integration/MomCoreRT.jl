@@ -61,7 +61,7 @@ layer optics in the library's native input form (K phase-matrix bases + per-poin
 array of expandOpticalProperties, compEffectiveLayerProperties.jl:124-135), doubling numbers, interface codes,
 surface.  Returns the handle with everything resident in HBM.
 """
-function momcore_scene(RS_type, model::vSmartMOM_Model, iBand, arch::MI355X; strict_reference_indexing::Bool = true)
+function momcore_scene(RS_type, model::vSmartMOM_Model, iBand, arch::MI355X; strict_reference_indexing::Bool = true, split = nothing)
     @unpack qp_μ, qp_μN, wt_μN, iμ₀, μ₀ = model.quad_points
     pol   = model.params.polarization_type
     max_m = model.params.max_m
@@ -77,18 +77,24 @@ function momcore_scene(RS_type, model::vSmartMOM_Model, iBand, arch::MI355X; str
     sinm  = [sind(m * a) for a in model.obs_geom.vaz, m in 0:max_m-1]
     brdf  = model.params.brdf[iBand[1]]
 
+    # Dual models (rt_run_dual below): `split = (val, part)` takes the values for the uploads here and returns the partials
+    val, part = split === nothing ? (identity, A -> nothing) : split
     h = MomHandle(arch, N, pol.n, nSpec, max_m; float_type = model.params.float_type)
     MomCore.mom_set_streams!(h.ptr, qp_μN, wt_μN, N, iμ₀, μ₀, pol.I₀, pol.D, strict_reference_indexing ? 1 : 0)
-    albedo = brdf isa LambertianSurfaceScalar ? Float64(brdf.albedo) : 0.0
-    MomCore.mom_scene_set!(h.ptr, length(nd), size(zw, 1), max_m, τ, ϖ, zw, Zpp, Zmp, nd, iface_code.(ifaces), τ_sum,
-                           albedo, length(node), node, cosm, sinm)
+    albedo = brdf isa LambertianSurfaceScalar ? brdf.albedo : zero(eltype(τ))
+    MomCore.mom_scene_set!(h.ptr, length(nd), size(zw, 1), max_m, val(τ), val(ϖ), val(zw), val(Zpp), val(Zmp), nd,
+                           iface_code.(ifaces), val(τ_sum), Float64(val([albedo])[1]), length(node), node, cosm, sinm)
+    dRsurf = dalb = nothing
     if brdf isa LambertianSurfaceLegendre                       # lambertian_surface.jl:90-96: spectral albedo
-        MomCore.mom_scene_set_surface!(h.ptr, 2, max_m, C_NULL, legendre_albedo(brdf, model, iBand))
+        alb = legendre_albedo(brdf, model, iBand)
+        MomCore.mom_scene_set_surface!(h.ptr, 2, max_m, C_NULL, val(alb));  dalb = part(alb)
     elseif !(brdf isa LambertianSurfaceScalar)                  # rpvSurfaceScalar, RossLiSurfaceScalar: BRDF Fourier moments
         Rsurf = cat([(m == 0 ? 2 : 1) * reflectance(brdf, pol, Array(qp_μ), m) for m in 0:max_m-1]...; dims = 3)
-        MomCore.mom_scene_set_surface!(h.ptr, 1, max_m, Rsurf, C_NULL)
+        MomCore.mom_scene_set_surface!(h.ptr, 1, max_m, val(Rsurf), C_NULL);  dRsurf = part(Rsurf)
     end
-    return h
+    split === nothing && return h
+    return h, (dτ = part(τ), dϖ = part(ϖ), dzw = part(zw), dZpp = part(Zpp), dZmp = part(Zmp), dalbedo = part([albedo]),
+               dRsurf = dRsurf, dalbedo_spec = dalb)
 end
 # <<< scene
 
@@ -108,6 +114,35 @@ function rt_run(RS_type::noRS, model::vSmartMOM_Model, iBand, arch::MI355X)
         close(h)
     end
 end
+
+# >>> rt_run_dual
+"""
+rt_run on a model whose optical properties are ForwardDiff.Dual (the reference's Jacobian route: rt_run.jl:89-96 allocates
+R, T, R_SFI, T_SFI in the Dual type and the whole layer loop runs on Dual arrays, gpu_batched.jl:100-150).  The host
+preparation above runs unchanged on the Dual arrays; values and partials are separated at the boundary
+(`ForwardDiff.value` / `ForwardDiff.partials`), uploaded with mom_scene_set / mom_scene_set_partials, and the results are
+re-assembled into Dual arrays of the caller's tag: every downstream `ForwardDiff.jacobian` sees exactly what the CPU run returns.
+"""
+function rt_run_dual(RS_type::noRS, model::vSmartMOM_Model, iBand, arch::MI355X, ::Type{D}) where {T, V, P, D <: ForwardDiff.Dual{T, V, P}}
+    val(A)     = ForwardDiff.value.(A)
+    part(A)    = cat((ForwardDiff.partials.(A, i) for i in 1:P)...; dims = ndims(A) + 1)   # partial index = slowest axis
+    h, dual_in = momcore_scene(RS_type, model, iBand, arch; split = (val, part))            # τ, ϖ, zw, Z bases, surface as Duals
+    try
+        pol, nV, nSpec = model.params.polarization_type, length(model.obs_geom.vza), h.nSpec
+        nn(x) = x === nothing ? C_NULL : x                            # an input without partials: NULL
+        MomCore.mom_scene_set_partials!(h.ptr, P, dual_in.dτ, dual_in.dϖ, dual_in.dzw, dual_in.dZpp, dual_in.dZmp,
+                                        dual_in.dalbedo, nn(dual_in.dRsurf), nn(dual_in.dalbedo_spec))
+        MomCore.mom_rt_run_dual!(h.ptr)
+        R = zeros(nV, pol.n, nSpec);  Tr = similar(R);  dR = zeros(nV, pol.n, nSpec, P);  dT = similar(dR)
+        MomCore.mom_get_RT!(h.ptr, R, Tr)
+        MomCore.mom_get_RT_partials!(h.ptr, dR, dT)
+        mk(X, dX) = [D(X[i], ForwardDiff.Partials(ntuple(p -> dX[i, p], P))) for i in CartesianIndices(X)]
+        return mk(R, dR), mk(Tr, dT)
+    finally
+        close(h)
+    end
+end
+# <<< rt_run_dual
 
 # The architecture is a FIELD of model.params (vSmartMOM_Parameters), not a type parameter of vSmartMOM_Model
 # (src/CoreRT/types.jl:483), so the two entry points of rt_run.jl:19-21,41-42 gain a run-time branch and the reference's

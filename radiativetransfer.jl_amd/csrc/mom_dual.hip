@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) k_dinv(InvArgs a) {
 // y_c = add_c + (M x)_c with the Dual product rule, for up to two (x, add, y) sets sharing M
 // ---------------------------------------------------------------------------------------------------------------------
 struct MvArgs {
-  int N, U, nq;
+  int N, U, P, nq;
   const double *M;
   const double *x[2], *add[2];
   double *y[2];
@@ -331,8 +331,11 @@ struct MvArgs {
 
 __global__ void __launch_bounds__(256) k_dmatvec(MvArgs a) {
   __shared__ double part[2][4][64];
-  const int N = a.N, c = blockIdx.x, t = threadIdx.x, g = t >> 6, il = t & 63, nq = a.nq;
-  const size_t NN = (size_t)N * N, u = blockIdx.y, vo0 = u * N, voc = ((size_t)c * a.U + u) * N;
+  // all components of a unit on one XCD (see k_dgemm): M0 comes from HBM once
+  const int nb = a.P + 1, slot = blockIdx.x >> 3, c = slot % nb, unit = (slot / nb) * 8 + (blockIdx.x & 7);
+  if (unit >= a.U) return;
+  const int N = a.N, t = threadIdx.x, g = t >> 6, il = t & 63, nq = a.nq;
+  const size_t NN = (size_t)N * N, u = unit, vo0 = u * N, voc = ((size_t)c * a.U + u) * N;
   const double *M0 = a.M + u * NN, *Mc = a.M + ((size_t)c * a.U + u) * NN;
   for (int rb = 0; rb < N; rb += 64) {
     const int i = rb + il;
@@ -788,8 +791,8 @@ int momd_run(const MomDualScene &sc, std::string *err) {
     };
     auto matvec = [&](const double *M, int nq, const double *x0, const double *a0, double *y0, const double *x1, const double *a1,
                       double *y1) {
-      MvArgs mv{N, U, nq, M, {x0, x1}, {a0, a1}, {y0, y1}};
-      hipLaunchKernelGGL(k_dmatvec, dim3((unsigned)(P + 1), (unsigned)U), dim3(256), 0, st, mv);
+      MvArgs mv{N, U, P, nq, M, {x0, x1}, {a0, a1}, {y0, y1}};
+      hipLaunchKernelGGL(k_dmatvec, dim3((unsigned)(8 * (P + 1) * ((U + 7) / 8))), dim3(256), 0, st, mv);
     };
     const unsigned eblocks = (unsigned)((NN * U + 255) / 256);
 

@@ -133,3 +133,10 @@ def test_dual_errors():
             h.scene_set_partials(1, dZpp=np.zeros(sc.Zpp.size))   # dZpp without dZmp
         with pytest.raises(rtamd.MomError):
             h.get_RT_partials()                  # no Dual run yet
+
+
+def test_dual_C2_operator_shape():
+    """The headline's operator shape (IQU, 20 streams, N = 60, three moments, aerosol + absorption) on a short column."""
+    m = rtamd.scenes.make_scene(3, 33, 6, 4, seed=21, aerosol_total=0.3)
+    assert m.quad_points.qp_μN.size == 60
+    compare(m, P=2, seed=7)
