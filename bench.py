@@ -568,6 +568,38 @@ def f32_leg(dev, S=20_000, n_streams=8, nd=5, steps=3):
                          "algorithmic_flop_per_avg_launch": flop}}
 
 
+def dual_leg(dev, S=2000, P=3):
+    """rt_run on ForwardDiff.Dual numbers (mom_rt_run_dual) on the BASELINE scene's shape (C2: IQU, N = 60, 40 layers, M = 3) with P
+    partials, next to the value run of the same scene: whole runs incl. surface and post-processing.  The Dual run streams its
+    operators (values + partials) through HBM in batched MFMA products (csrc/mom_dual.hip); its model is (1 + 2 P) value runs."""
+    import rtamd
+    rt = rtamd.corert
+    m = rtamd.scenes.scene_C2(S=S, architecture=rtamd.MI355X(dev.index))
+    sc = rtamd.prepare_scene(m)
+    L = rt.construct_layer_inputs(m)
+    rng = np.random.default_rng(0)
+    parts = [rtamd.ScenePartial(dτ=L.τ * rng.uniform(-1, 1, L.τ.shape), dϖ=0.1 * L.ϖ * rng.uniform(-1, 1, L.ϖ.shape),
+                                dzw=L.zw * rng.uniform(-1, 1, L.zw.shape), dalbedo=1.0) for _ in range(P)]
+    with rt.make_handle(m) as h:
+        rt.scene_set(h, sc)
+        h.rt_run(); h.sync()
+        t0 = time.perf_counter(); h.rt_run(); h.sync(); tv = time.perf_counter() - t0
+        rt.scene_set_partials(h, sc, parts)
+        h.rt_run_dual(); h.sync()
+        t0 = time.perf_counter(); h.rt_run_dual(); h.sync(); td = time.perf_counter() - t0
+        dR, _ = h.get_RT_partials()
+    N, Nz, M = sc.N, sc.Nz, sc.M
+    nd_sum = int(np.sum(sc.ndoubl))
+    # products of the tangent-linear sweep: 5 value + 10 P per doubling step, 10 value + 20 P per interaction (interface 11)
+    flop = 2.0 * N ** 3 * M * S * (nd_sum * (5 + 10 * P) + Nz * (10 + 20 * P))
+    return {"metric": "rt_run on Dual numbers (values + P partials), C2 operator shape", "value": S / td, "unit": "spectral points/s",
+            "dtype": "f64", "ms_per_run": td * 1e3, "value_run_ms": tv * 1e3, "ratio_to_value_run": td / tv, "ideal_ratio": 1 + 2 * P,
+            "config": {"workload": f"C2 shape: N = {N}, Nz = {Nz}, M = {M}, S = {S}, P = {P} partials (tau, varpi, phase weights, albedo)"},
+            "finite": bool(np.isfinite(dR).all()),
+            "roofline": {"bound": "hbm", "note": "batched products stream values and partials through HBM (no LDS-resident image holds "
+                         "14 x (1 + P) operators); product flops only", "achieved_tflops": flop / td / 1e12}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -651,6 +683,10 @@ def main():
                     extra["f32"] = f32_leg(dev)
                 except Exception as e:
                     extra["f32"] = {"error": repr(e)}
+                try:
+                    extra["dual"] = dual_leg(dev)
+                except Exception as e:
+                    extra["dual"] = {"error": repr(e)}
             if extra:
                 out["extra"] = extra
         print(json.dumps(out), flush=True)
