@@ -163,159 +163,177 @@ struct InvArgs {
   int *info;
 };
 
-// The matrix lives in REGISTERS: thread (tx, ty) owns A[ty + 4 s][tx + 64 jb]; per elimination step only the pivot row, the old
-// row k and column k pass through LDS (the first form kept the matrix in LDS and spent its time on 2 x 29 KB of LDS traffic per
-// step).  Two barriers per step: the owners of column k + 1 collect the next pivot's candidates during the update.
+// The matrix lives in REGISTERS, rows across the lanes: thread (lane l, wave w) owns A[l + 64 ib][w + 4 s].  Per elimination
+// step only the pivot row (16 NBK values per wave) and column k (one value per lane) pass through LDS; everything that is
+// not the rank-one update -- the pivot search of the next column (a wave reduction), its reciprocal, the rewrite of column
+// k -- is done by the ONE wave that owns that column, under a wave-uniform branch, so the other three waves do not issue
+// it.  Lane k gets the coefficient val - 1, which turns the common update R - c * (row k * pinv) into row k * pinv for
+// the pivot row itself.  Rows are exchanged (lanes p and k, through LDS) only when partial pivoting asks for it.
+// Two barriers per step.  (The first forms kept the matrix in LDS, 600 us per launch of 2000 units of N = 60, then in
+// registers with rows across the waves, 300 us: profiles/r06_dual_ab.txt.)
 #define MOMD_ROW_CASES(F)                                                                                          \
   F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15) F(16) F(17) F(18) F(19) F(20) F(21) \
   F(22) F(23) F(24) F(25) F(26) F(27) F(28) F(29) F(30) F(31)
 template <int NBK>
 __global__ void __launch_bounds__(256) k_dinv(InvArgs a) {
-  constexpr int RPT = 16 * NBK;
+  constexpr int RPT = 16 * NBK;   // columns per thread
   extern __shared__ double sm[];
-  const int N = a.N, LD = N | 1, t = threadIdx.x, tx = t & 63;
-  const int ty = __builtin_amdgcn_readfirstlane(t >> 6);   // rows are wave-uniform: scalar tests
-  double *A = sm, *rowk = sm + (size_t)N * LD, *rowx = rowk + 64 * NBK, *colr = rowx + 64 * NBK, *cand = colr + 64 * NBK;
-  int *piv = (int *)(cand + 8), *candi = piv + 64 * NBK, *dst = candi + 4, *src = dst + 64 * NBK;
+  const int N = a.N, LD = N | 1, t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  double *A = sm, *rowk = sm + (size_t)N * LD, *rowx = rowk + 4 * RPT, *colk = rowx + 4 * RPT, *pv = colk + 64 * NBK;  // pv: val, pinv
+  int *piv = (int *)(pv + 2), *pcur = piv + 64 * NBK, *dst = pcur + 2;
   const size_t NN = (size_t)N * N, uo = (size_t)blockIdx.x * NN;
-  for (int j = ty; j < N; j += 4)
-    for (int i = tx; i < N; i += 64) A[i * LD + j] = a.s * a.W[uo + i + (size_t)j * N] + (i == j ? a.eye : 0.0);
+  for (int j = w; j < N; j += 4)
+    for (int i = lane; i < N; i += 64) A[i * LD + j] = a.s * a.W[uo + i + (size_t)j * N] + (i == j ? a.eye : 0.0);
   __syncthreads();
   double R[RPT][NBK];
 #pragma unroll
   for (int s = 0; s < RPT; ++s)
 #pragma unroll
-    for (int jb = 0; jb < NBK; ++jb) {
-      const int i = ty + 4 * s, j = tx + 64 * jb;
-      R[s][jb] = (i < N && j < N) ? A[i * LD + j] : 0.0;
+    for (int ib = 0; ib < NBK; ++ib) {
+      const int i = lane + 64 * ib, j = w + 4 * s;
+      R[s][ib] = (i < N && j < N) ? A[i * LD + j] : 0.0;
     }
-  // the row `srow` of this wave, selected by a scalar switch (the register file is indexed statically)
-  auto with_row = [&](int srow, auto &&f) {
-    switch (srow) {
-#define MOMD_CASE(S) case S: if constexpr (S < RPT) f(R[S < RPT ? S : 0]); break;
-      MOMD_ROW_CASES(MOMD_CASE)
-#undef MOMD_CASE
-      default: break;
-    }
-  };
-  if (tx == 0) {  // candidates of column 0
-    double best = -1.0, val = 0.0;
-    int bi = 0;
+  // column `scol` of this wave: a wave-uniform dynamic index into the register array (s_set_gpr_idx / v_movrel: a 32-way switch
+  // made the kernel 47 KB of code, and the instruction cache its bottleneck)
+  auto with_col = [&](int scol, auto &&f) { f(R[scol]); };
+  // pivot of column kc among rows >= kc: executed by the wave that owns the column; leaves p, val, 1 / val in LDS.  The
+  // maximum goes down the rows of 16 by DPP shifts and across them by readlane (a __shfl ladder is six exposed LDS round
+  // trips on the critical path of all four waves); the row that holds it comes from a ballot.
+  auto search = [&](int kc) {
+    with_col(kc >> 2, [&](double (&col)[NBK]) {
+      double best = -1.0, val = 0.0;
+      int bi = kc;
 #pragma unroll
-    for (int s = 0; s < RPT; ++s) {
-      const int i = ty + 4 * s;
-      if (i < N && fabs(R[s][0]) > best) { best = fabs(R[s][0]); val = R[s][0]; bi = i; }
-    }
-    cand[2 * ty] = best; cand[2 * ty + 1] = val; candi[ty] = bi;
-  }
+      for (int ib = 0; ib < NBK; ++ib) {
+        const int i = lane + 64 * ib;
+        if (i >= kc && i < N && fabs(col[ib]) > best) { best = fabs(col[ib]); val = col[ib]; bi = i; }
+      }
+      double m = best;
+      union { double d; int w2[2]; } ua, ub;
+#define MOMD_DPP_MAX(ctrl)                                                    \
+  ua.d = m;                                                                   \
+  ub.w2[0] = __builtin_amdgcn_update_dpp(ua.w2[0], ua.w2[0], ctrl, 0xf, 0xf, false); \
+  ub.w2[1] = __builtin_amdgcn_update_dpp(ua.w2[1], ua.w2[1], ctrl, 0xf, 0xf, false); \
+  m = fmax(m, ub.d);
+      MOMD_DPP_MAX(0x111) MOMD_DPP_MAX(0x112) MOMD_DPP_MAX(0x114) MOMD_DPP_MAX(0x118)   // row_shr 1, 2, 4, 8: lane 15 of each row
+#undef MOMD_DPP_MAX
+      ua.d = m;
+      double mx = -1.0;
+#pragma unroll
+      for (int row = 0; row < 4; ++row) {
+        union { double d; int w2[2]; } tt;
+        tt.w2[0] = __builtin_amdgcn_readlane(ua.w2[0], 16 * row + 15);
+        tt.w2[1] = __builtin_amdgcn_readlane(ua.w2[1], 16 * row + 15);
+        mx = fmax(mx, tt.d);
+      }
+      const unsigned long long hit = __ballot(best == mx);
+      const int src_lane = __builtin_ctzll(hit);          // the lowest lane holding the maximum (its row index is the smallest)
+      union { double d; int w2[2]; } uv, ur;
+      uv.d = val;
+      ur.w2[0] = __builtin_amdgcn_readlane(uv.w2[0], src_lane);
+      ur.w2[1] = __builtin_amdgcn_readlane(uv.w2[1], src_lane);
+      const int prow = __builtin_amdgcn_readlane(bi, src_lane);
+      if (lane == 0) {
+        double x = __builtin_amdgcn_rcp(ur.d);             // 1 / val to the last bit or two: two Newton steps on v_rcp_f64
+        x = x * (2.0 - ur.d * x);
+        x = x * (2.0 - ur.d * x);
+        pv[0] = ur.d; pv[1] = x; pcur[0] = prow; pcur[1] = (mx > 0.0) ? 0 : 1;
+      }
+    });
+  };
+  if (w == 0) search(0);
   __syncthreads();
   bool bad = false;
   for (int k = 0; k < N; ++k) {
-    double best = cand[0], val = cand[1];
-    int pv = candi[0];
-#pragma unroll
-    for (int q = 1; q < 4; ++q)
-      if (cand[2 * q] > best || (cand[2 * q] == best && candi[q] < pv)) { best = cand[2 * q]; val = cand[2 * q + 1]; pv = candi[q]; }
-    if (!(best > 0.0)) bad = true;
-    const int p = __builtin_amdgcn_readfirstlane(pv);
-    const double pinv = 1.0 / val;
+    const int p = __builtin_amdgcn_readfirstlane(pcur[0]);
+    bad = bad || (pcur[1] != 0);
+    const double val = pv[0], pinv = pv[1];
+    const int kb = k >> 6, kl = k & 63, wk = k & 3, sk = k >> 2;
     if (t == 0) piv[k] = p;
-    const int kb = k >> 6, kx = k & 63;
-    // stage: the scaled pivot row, the old row k, column k (as it stands, before the row exchange).  The owners of column k
-    // then clear it, so that the update below is the same expression in every column (column k: 0 - c_i * pinv).
-    if ((p & 3) == ty)
-      with_row(p >> 2, [&](double (&row)[NBK]) {
+    if (p != k) {  // (block-uniform) exchange rows p and k: every wave hands its 16 NBK entries of both rows through LDS
+      const int pb = p >> 6, pl = p & 63;
 #pragma unroll
-        for (int jb = 0; jb < NBK; ++jb)
-          if (tx + 64 * jb < N) rowk[tx + 64 * jb] = row[jb] * pinv;
-      });
-    if ((k & 3) == ty && p != k)
-      with_row(k >> 2, [&](double (&row)[NBK]) {
+      for (int ib = 0; ib < NBK; ++ib) {
+        if (ib == pb && lane == pl) {
 #pragma unroll
-        for (int jb = 0; jb < NBK; ++jb)
-          if (tx + 64 * jb < N) rowx[tx + 64 * jb] = row[jb];
-      });
-    if (tx == kx) {
-#pragma unroll
-      for (int jb = 0; jb < NBK; ++jb)
-        if (jb == kb) {
-#pragma unroll
-          for (int s = 0; s < RPT; ++s) {
-            colr[(ty * RPT) + s] = R[s][jb];   // colr[(i % 4) RPT + i / 4]: each wave's rows are contiguous
-            R[s][jb] = 0.0;
-          }
+          for (int s = 0; s < RPT; ++s) rowx[w * RPT + s] = R[s][ib];
         }
+        if (ib == kb && lane == kl) {
+#pragma unroll
+          for (int s = 0; s < RPT; ++s) rowk[w * RPT + s] = R[s][ib];
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are complete (same-wave exchange, no barrier needed)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ib = 0; ib < NBK; ++ib) {
+        if (ib == pb && lane == pl) {
+#pragma unroll
+          for (int s = 0; s < RPT; ++s) R[s][ib] = rowk[w * RPT + s];
+        }
+        if (ib == kb && lane == kl) {
+#pragma unroll
+          for (int s = 0; s < RPT; ++s) R[s][ib] = rowx[w * RPT + s];
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
     }
+    // stage the scaled pivot row (each wave its own columns) and column k (its owner wave)
+#pragma unroll
+    for (int ib = 0; ib < NBK; ++ib)
+      if (ib == kb && lane == kl) {
+#pragma unroll
+        for (int s = 0; s < RPT; ++s) rowk[w * RPT + s] = R[s][ib] * pinv;
+      }
+    if (w == wk)
+      with_col(sk, [&](double (&col)[NBK]) {
+#pragma unroll
+        for (int ib = 0; ib < NBK; ++ib) colk[lane + 64 * ib] = col[ib];
+      });
     __syncthreads();
-    const int kn = k + 1, nb_ = kn >> 6, nx = kn & 63;
-    double cr[RPT];
+    double c[NBK], c0[NBK];
 #pragma unroll
-    for (int s = 0; s < RPT; ++s) cr[s] = colr[ty * RPT + s];
-    double rk[NBK];
-#pragma unroll
-    for (int jb = 0; jb < NBK; ++jb) {
-      const int j = tx + 64 * jb;
-      rk[jb] = (j == k) ? pinv : ((j < N) ? rowk[j] : 0.0);
-#pragma unroll
-      for (int s = 0; s < RPT; ++s) R[s][jb] = R[s][jb] - cr[s] * rk[jb];   // every row as a plain row ...
+    for (int ib = 0; ib < NBK; ++ib) {
+      c0[ib] = colk[lane + 64 * ib];
+      c[ib] = (ib == kb && lane == kl) ? val - 1.0 : c0[ib];
     }
-    // ... then the two special ones
-    if ((p & 3) == ty && p != k) {   // row p takes the old row k (exchange) and is updated with ITS column-k entry
-      const double ckk = colr[(k & 3) * RPT + (k >> 2)];
-      with_row(p >> 2, [&](double (&row)[NBK]) {
 #pragma unroll
-        for (int jb = 0; jb < NBK; ++jb) {
-          const int j = tx + 64 * jb;
-          const double rx = (j == k) ? 0.0 : ((j < N) ? rowx[j] : 0.0);
-          row[jb] = rx - ckk * rk[jb];
-        }
+    for (int s = 0; s < RPT; ++s) {
+      const double rk = rowk[w * RPT + s];
+#pragma unroll
+      for (int ib = 0; ib < NBK; ++ib) R[s][ib] = R[s][ib] - c[ib] * rk;
+    }
+    if (w == wk)   // column k of the inverse in progress: pinv on the pivot row, -c_i pinv elsewhere
+      with_col(sk, [&](double (&col)[NBK]) {
+#pragma unroll
+        for (int ib = 0; ib < NBK; ++ib) col[ib] = (ib == kb && lane == kl) ? pinv : -c0[ib] * pinv;
       });
-    }
-    if ((k & 3) == ty)               // the pivot row
-      with_row(k >> 2, [&](double (&row)[NBK]) {
-#pragma unroll
-        for (int jb = 0; jb < NBK; ++jb) row[jb] = rk[jb];
-      });
-    if (tx == nx && kn < N) {
-      double best2 = -1.0, val2 = 0.0;
-      int bi2 = kn;
-#pragma unroll
-      for (int jb = 0; jb < NBK; ++jb)
-        if (jb == nb_) {
-#pragma unroll
-          for (int s = 0; s < RPT; ++s) {
-            const int i = ty + 4 * s;
-            const double v = R[s][jb];
-            if (i >= kn && i < N && fabs(v) > best2) { best2 = fabs(v); val2 = v; bi2 = i; }
-          }
-        }
-      cand[2 * ty] = best2; cand[2 * ty + 1] = val2; candi[ty] = bi2;
-    }
+    if (k + 1 < N && w == ((k + 1) & 3)) search(k + 1);
     __syncthreads();
   }
-  // undo the row exchanges as column exchanges in reverse order: dst[j] = final position of the working column j
-  if (t == 0) {
-    for (int j = 0; j < N; ++j) src[j] = j;
+  // undo the row exchanges as column exchanges in reverse order: dst[j] = final position of the working column j, followed
+  // through the exchanges by one thread per column (the loads of piv[] do not depend on the position: no serial LDS chain)
+  for (int j = t; j < N; j += 256) {
+    int pos = j;
     for (int k = N - 1; k >= 0; --k) {
-      const int p = piv[k], x = src[k];
-      src[k] = src[p];
-      src[p] = x;
+      const int p = piv[k];
+      pos = (pos == k) ? p : ((pos == p) ? k : pos);
     }
-    for (int j = 0; j < N; ++j) dst[src[j]] = j;
+    dst[j] = pos;
   }
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < RPT; ++s)
 #pragma unroll
-    for (int jb = 0; jb < NBK; ++jb) {
-      const int i = ty + 4 * s, j = tx + 64 * jb;
-      if (i < N && j < N) A[i * LD + dst[j]] = R[s][jb];
+    for (int ib = 0; ib < NBK; ++ib) {
+      const int i = lane + 64 * ib, j = w + 4 * s;
+      if (i < N && j < N) A[i * LD + dst[j]] = R[s][ib];
     }
   __syncthreads();
-  for (int e = t; e < (int)NN; e += 256) {
-    const int i = e % N, j = e / N;
-    a.G[uo + e] = A[i * LD + j];
-  }
+  for (int j = w; j < N; j += 4)
+    for (int i = lane; i < N; i += 64) a.G[uo + i + (size_t)j * N] = A[i * LD + j];
   if (t == 0 && bad) atomicMax(a.info, 1);
 }
 
@@ -751,7 +769,7 @@ int momd_run(const MomDualScene &sc, std::string *err) {
     hipLaunchKernelGGL(k_dtausum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc.S, Nz, P, sc.dtau, dts);
   }
   const int nbk = (N <= 64) ? 1 : 2;
-  const size_t inv_lds = ((size_t)N * (N | 1) + 3 * 64 * nbk + 8) * sizeof(double) + (size_t)(3 * 64 * nbk + 8) * sizeof(int);
+  const size_t inv_lds = ((size_t)N * (N | 1) + 3 * 64 * nbk + 2) * sizeof(double) + (size_t)(3 * 64 * nbk + 2) * sizeof(int);
   DCHK(mom_allow_lds((const void *)k_dinv<1>, inv_lds));
   DCHK(mom_allow_lds((const void *)k_dinv<2>, inv_lds));
 
