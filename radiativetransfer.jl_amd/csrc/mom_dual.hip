@@ -42,9 +42,15 @@ struct GemmArgs {
   const double *A, *B, *E;
   double *C;
   double alpha, beta, eye;
+  // riding vectors (mode 0 only): x[q] are columns N + q of the right operand, so y[q] = add[q] + (A x[q]) comes out of the same
+  // product with the same Dual rule -- at N = 60 in columns 60, 61 of the 64-wide tile, which the padding computes anyway.  These
+  // are the matrix-vector statements of doubling.jl:57-60 and interaction.jl:82,100 (the source-vector updates).
+  int nq;
+  const double *x[2], *add[2];
+  double *y[2];
 };
 
-template <bool VEC2>
+template <bool VEC2, bool RIDE>
 __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) double As[KC * LDA];  // As[i + k LDA]
   __shared__ __attribute__((aligned(16))) double Bs[TN * LDB];  // Bs[k + j LDB]
@@ -63,22 +69,27 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
   d4 acc[4];
 #pragma unroll
   for (int tb = 0; tb < 4; ++tb) acc[tb] = d4{0.0, 0.0, 0.0, 0.0};
-  const double *TA[2], *TB[2];
   int nterms = 1;
   const double *A0 = a.A + uo, *B0 = a.B + uo, *Ac = a.A + c * CS + uo, *Bc = a.B + c * CS + uo;
-  TA[1] = A0; TB[1] = Bc;
+  const int nq = RIDE ? a.nq : 0;
+  const size_t vo0 = (size_t)unit * N, voc = ((size_t)c * a.U + unit) * N;
+  // term 0: (TA0, TB0); term 1 (Dual rule, c > 0): (A0, Bc).  Selected by value, not through indexed arrays (those went to scratch).
+  const double *TA0, *TB0;
   if (a.mode == 0) {
-    if (c == 0) { TA[0] = A0; TB[0] = B0; }
-    else { nterms = 2; TA[0] = Ac; TB[0] = B0; }
-  } else if (a.mode == 1) { TA[0] = A0; TB[0] = Bc; }
-  else { TA[0] = Ac; TB[0] = B0; }
+    if (c == 0) { TA0 = A0; TB0 = B0; }
+    else { nterms = 2; TA0 = Ac; TB0 = B0; }
+  } else if (a.mode == 1) { TA0 = A0; TB0 = Bc; }
+  else { TA0 = Ac; TB0 = B0; }
+  const double *x0p = RIDE ? a.x[0] : nullptr, *x1p = (RIDE && nq > 1) ? a.x[1] : nullptr;
   const int nch = (N + KC - 1) / KC, nph = nterms * nch;
   // the next (term, K chunk) is fetched into registers while the matrix cores work on the current one
   d2 ra[4], rb[4];
   double sa[8], sb[8];
   auto gload = [&](int ph) {
-    const double *Ag = TA[ph / nch], *Bg = TB[ph / nch];
-    const int k0 = (ph % nch) * KC;
+    const bool t1 = ph >= nch;
+    const double *Ag = t1 ? A0 : TA0, *Bg = t1 ? Bc : TB0;
+    const size_t xo = t1 ? voc : vo0;   // the riding vectors carry the component of this term's right operand
+    const int k0 = (t1 ? ph - nch : ph) * KC;
     if (VEC2) {  // N even: pairs along the contiguous axis are 16-byte aligned and never straddle the edge
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -86,7 +97,12 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
         { const int i = 2 * (e & 31), k = e >> 5, gi = i0 + i, gk = k0 + k;
           ra[q] = (gi < N && gk < N) ? *(const d2 *)(Ag + gi + (size_t)gk * N) : d2{0.0, 0.0}; }
         { const int k = 2 * (e & 15), j = e >> 4, gk = k0 + k, gj = j0 + j;
-          rb[q] = (gk < N && gj < N) ? *(const d2 *)(Bg + gk + (size_t)gj * N) : d2{0.0, 0.0}; }
+          d2 v = d2{0.0, 0.0};
+          if (gk < N) {
+            if (gj < N) v = *(const d2 *)(Bg + gk + (size_t)gj * N);
+            else if (RIDE && gj - N < nq) v = *(const d2 *)((gj == N ? x0p : x1p) + xo + gk);
+          }
+          rb[q] = v; }
       }
     } else {
 #pragma unroll
@@ -95,7 +111,12 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
         { const int i = e & (TM - 1), k = e >> 6, gi = i0 + i, gk = k0 + k;
           sa[q] = (gi < N && gk < N) ? Ag[gi + (size_t)gk * N] : 0.0; }
         { const int k = e & (KC - 1), j = e >> 5, gk = k0 + k, gj = j0 + j;
-          sb[q] = (gk < N && gj < N) ? Bg[gk + (size_t)gj * N] : 0.0; }
+          double v = 0.0;
+          if (gk < N) {
+            if (gj < N) v = Bg[gk + (size_t)gj * N];
+            else if (RIDE && gj - N < nq) v = (gj == N ? x0p : x1p)[xo + gk];
+          }
+          sb[q] = v; }
       }
     }
   };
@@ -122,7 +143,7 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
     sstore();
     __syncthreads();
     if (ph + 1 < nph) gload(ph + 1);
-    const int kmax = min(KC, N - (ph % nch) * KC);
+    const int kmax = min(KC, N - (ph >= nch ? ph - nch : ph) * KC);
     // the product transposed on the matrix core (rows of the MFMA tile = columns j of C, columns = rows i): the 16 lanes of a
     // quarter-wave then hold 16 consecutive rows of one column of C, so the stores of the epilogue are 128-byte segments
     for (int kk = 0; kk < kmax; kk += 4) {
@@ -147,6 +168,10 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
         if (E) v += a.beta * E[o];
         if (c == 0 && gi == gj) v += a.eye;
         C[o] = v;
+      } else if (RIDE && gi < N && gj - N < nq) {
+        const double *ad = (gj == N) ? a.add[0] : a.add[1];
+        double *y = (gj == N) ? a.y[0] : a.y[1];
+        y[voc + gi] = (ad ? ad[voc + gi] : 0.0) + acc[tb][r];
       }
     }
 }
@@ -787,13 +812,28 @@ int momd_run(const MomDualScene &sc, std::string *err) {
     base += (size_t)(P + 1) * U;
 
     const int tiles = (N + TM - 1) / TM;
-    auto gemm = [&](double *C, const double *A, const double *B, int mode, int c0, int nc, double alpha, const double *E,
-                    double beta, double eye) {
+    struct Ride { int nq; const double *x[2], *add[2]; double *y[2]; };
+    const Ride no_ride{0, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    auto gemm_r = [&](double *C, const double *A, const double *B, int mode, int c0, int nc, double alpha, const double *E,
+                      double beta, double eye, const Ride &rd) {
       if (nc <= 0) return;
-      GemmArgs g{N, U, c0, nc, mode, tiles, tiles, A, B, E, C, alpha, beta, eye};
-      const dim3 grid((unsigned)(8 * tiles * tiles * nc * ((U + 7) / 8)));
-      if (N % 2 == 0) hipLaunchKernelGGL(k_dgemm<true>, grid, dim3(256), 0, st, g);
-      else hipLaunchKernelGGL(k_dgemm<false>, grid, dim3(256), 0, st, g);
+      const int tiles_j = (N + rd.nq + TN - 1) / TN;
+      GemmArgs g{N, U, c0, nc, mode, tiles, tiles_j, A, B, E, C, alpha, beta, eye, rd.nq, {rd.x[0], rd.x[1]}, {rd.add[0], rd.add[1]},
+                 {rd.y[0], rd.y[1]}};
+      const dim3 grid((unsigned)(8 * tiles * tiles_j * nc * ((U + 7) / 8)));
+      if (N % 2 == 0) {
+        if (rd.nq) hipLaunchKernelGGL((k_dgemm<true, true>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_dgemm<true, false>), grid, dim3(256), 0, st, g);
+      } else {
+        if (rd.nq) hipLaunchKernelGGL((k_dgemm<false, true>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_dgemm<false, false>), grid, dim3(256), 0, st, g);
+      }
+    };
+    auto gemm = [&](double *C, const double *A, const double *B, int mode, int c0, int nc, double alpha, const double *E,
+                    double beta, double eye) { gemm_r(C, A, B, mode, c0, nc, alpha, E, beta, eye, no_ride); };
+    // C = A B on Duals with y[q] = add[q] + A x[q] riding along
+    auto dual_ride = [&](double *C, const double *A, const double *B, const double *E, const Ride &rd) {
+      gemm_r(C, A, B, 0, 0, P + 1, 1.0, E, E ? 1.0 : 0.0, 0.0, rd);
     };
     auto dual = [&](double *C, const double *A, const double *B) { gemm(C, A, B, 0, 0, P + 1, 1.0, nullptr, 0.0, 0.0); };
     auto dual_add = [&](double *C, const double *A, const double *B, const double *E) { gemm(C, A, B, 0, 0, P + 1, 1.0, E, 1.0, 0.0); };
@@ -840,18 +880,16 @@ int momd_run(const MomDualScene &sc, std::string *err) {
         dual(t2, ad.t_pp, co.T_pp); std::swap(co.T_pp, t2);
         dual(t2, co.T_mm, ad.t_mm); std::swap(co.T_mm, t2);
       } else {
-        dual(W, ad.r_mp, co.R_pm);                                            // r-+ R+-                     (:76-79)
+        dual_ride(W, ad.r_mp, co.R_pm, nullptr, Ride{1, {co.Jp, nullptr}, {ad.jm, nullptr}, {va, nullptr}});  // r-+ R+- (:76-79); riding: r-+ J0+ + j0-
         times_inv(TG, co.T_mm, W);                                            // T01_inv = T-- (I - r-+ R+-)^-1
-        matvec(ad.r_mp, 1, co.Jp, ad.jm, va, nullptr, nullptr, nullptr);
-        matvec(TG, 1, va, co.Jm, vn2, nullptr, nullptr, nullptr);             // J0- += T01_inv (r-+ J0+ + j0-) (:82)
-        dual(X, TG, ad.r_mp); dual_add(co.R_mp, X, co.T_pp, co.R_mp);         // R-+ += (T01_inv r-+) T++      (:86)
+        dual_ride(X, TG, ad.r_mp, nullptr, Ride{1, {va, nullptr}, {co.Jm, nullptr}, {vn2, nullptr}});       // riding: J0- += T01_inv (.) (:82)
+        dual_add(co.R_mp, X, co.T_pp, co.R_mp);                               // R-+ += (T01_inv r-+) T++      (:86)
         dual(co.T_mm, TG, ad.t_mm);                                           // T-- = T01_inv t--             (:89)
-        dual(W, co.R_pm, ad.r_mp);                                            // R+- r-+                       (:93)
+        dual_ride(W, co.R_pm, ad.r_mp, nullptr, Ride{1, {ad.jm, nullptr}, {co.Jp, nullptr}, {va, nullptr}});  // R+- r-+ (:93); riding: J0+ + R+- j0-
         times_inv(TG, ad.t_pp, W);                                            // T21_inv = t++ (I - R+- r-+)^-1
-        matvec(co.R_pm, 1, ad.jm, co.Jp, va, nullptr, nullptr, nullptr);
-        matvec(TG, 1, va, ad.jp, vn1, nullptr, nullptr, nullptr);             // J0+ = j0+ + T21_inv (J0+ + R+- j0-) (:100)
+        dual_ride(t2, TG, co.T_pp, nullptr, Ride{1, {va, nullptr}, {ad.jp, nullptr}, {vn1, nullptr}});      // T++ = T21_inv T++ (:104); riding: J0+ = j0+ + T21_inv (.) (:100)
+        std::swap(co.T_pp, t2);
         std::swap(co.Jp, vn1); std::swap(co.Jm, vn2);
-        dual(t2, TG, co.T_pp); std::swap(co.T_pp, t2);                        // T++ = T21_inv T++             (:104)
         dual(X, TG, co.R_pm); dual_add(co.R_pm, X, ad.t_mm, ad.r_pm);         // R+- = r+- + (T21_inv R+-) t-- (:107)
       }
     };
@@ -873,14 +911,13 @@ int momd_run(const MomDualScene &sc, std::string *err) {
         hipLaunchKernelGGL(k_delemental, dim3(eblocks), dim3(256), 0, st, ea);
         // doubling_helper! (doubling.jl:43-68) on Duals
         for (int it = 0; it < nd; ++it) {
-          dual(W, ad.r_mp, ad.r_mp);                                          // r-+ r-+                        (:46)
-          times_inv(TG, ad.t_pp, W);                                          // tt++_gp_refl = t++ (I - r-+ r-+)^-1 (:46-47)
           ScaleArgs sa{N, U, P, ad.jp, ad.jm, j1p, j1m, ek};
           hipLaunchKernelGGL(k_dscale, dim3((unsigned)U), dim3(128), 0, st, sa);  // j1+-, expk^2            (:51-54, :62)
-          matvec(ad.r_mp, 2, ad.jp, j1m, va, j1m, ad.jp, vb);                 // j1- + r-+ j0+ ;  j0+ + r-+ j1-
-          matvec(TG, 2, va, ad.jm, vn2, vb, j1p, vn1);                        // j0- += TG (.) ; j0+ = j1+ + TG (.) (:57-60)
+          dual_ride(W, ad.r_mp, ad.r_mp, nullptr, Ride{2, {ad.jp, j1m}, {j1m, ad.jp}, {va, vb}});  // r-+ r-+ (:46); riding: j1- + r-+ j0+, j0+ + r-+ j1-
+          times_inv(TG, ad.t_pp, W);                                          // tt++_gp_refl = t++ (I - r-+ r-+)^-1 (:46-47)
+          dual_ride(X, TG, ad.r_mp, nullptr, Ride{2, {va, vb}, {ad.jm, j1p}, {vn2, vn1}});  // TG r-+; riding: j0- += TG (.), j0+ = j1+ + TG (.) (:57-60)
           std::swap(ad.jm, vn2); std::swap(ad.jp, vn1);
-          dual(X, TG, ad.r_mp); dual_add(ad.r_mp, X, ad.t_pp, ad.r_mp);       // r-+ += (TG r-+) t++            (:65)
+          dual_add(ad.r_mp, X, ad.t_pp, ad.r_mp);                             // r-+ += (TG r-+) t++            (:65)
           dual(t2, TG, ad.t_pp); std::swap(ad.t_pp, t2);                      // t++ = TG t++                   (:68)
         }
         if (nd > 0) {
