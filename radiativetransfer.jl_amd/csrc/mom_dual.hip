@@ -176,6 +176,85 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
     }
 }
 
+// The same product for operators of edge N + nq <= 16 NT (NT = 1, 2): ONE WAVEFRONT per (unit, component), operands read straight
+// from global memory in the layout of the MFMA (a 30 x 30 operator is 7 KB: cache-resident), no LDS, no barrier.  The 64 x 64
+// workgroup tile above costs the same for every edge up to 64 (N = 30: 4.5 x the MFMA work, two staging phases per term).
+template <int NT, bool RIDE>
+__global__ void __launch_bounds__(256) k_dgemm_w(GemmArgs a) {
+  const int N = a.N;
+  const size_t NN = (size_t)N * N, CS = (size_t)a.U * NN;
+  const int lane = threadIdx.x & 63, lq = lane >> 4, lr = lane & 15;
+  const size_t item = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // the four waves of a workgroup: neighbouring components of a unit
+  const size_t unit = item / a.nc;
+  if (unit >= (size_t)a.U) return;
+  const int c = a.c0 + (int)(item % a.nc);
+  const size_t uo = unit * NN;
+  const double *A0 = a.A + uo, *B0 = a.B + uo, *Ac = a.A + c * CS + uo, *Bc = a.B + c * CS + uo;
+  const int nq = RIDE ? a.nq : 0;
+  const size_t vo0 = unit * N, voc = ((size_t)c * a.U + unit) * N;
+  int nterms = 1;
+  const double *TA0, *TB0;
+  if (a.mode == 0) {
+    if (c == 0) { TA0 = A0; TB0 = B0; }
+    else { nterms = 2; TA0 = Ac; TB0 = B0; }
+  } else if (a.mode == 1) { TA0 = A0; TB0 = Bc; }
+  else { TA0 = Ac; TB0 = B0; }
+  d4 acc[NT][NT];
+#pragma unroll
+  for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) acc[tj][ti] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int t = 0; t < nterms; ++t) {
+    const double *Ag = t ? A0 : TA0, *Bg = t ? Bc : TB0;
+    const size_t xo = t ? voc : vo0;
+#pragma unroll 4
+    for (int kk = 0; kk < N; kk += 4) {
+      const int k = kk + lq;
+      double bv[NT], av[NT];
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) {
+        const int col = 16 * tj + lr;
+        double v = 0.0;
+        if (k < N) {
+          if (col < N) v = Bg[k + (size_t)col * N];
+          else if (RIDE && col - N < nq) v = (col == N ? a.x[0] : a.x[1])[xo + k];
+        }
+        bv[tj] = v;
+      }
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti) {
+        const int row = 16 * ti + lr;
+        av[ti] = (k < N && row < N) ? Ag[row + (size_t)k * N] : 0.0;
+      }
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[tj], av[ti], acc[tj][ti], 0, 0, 0);
+    }
+  }
+  double *C = a.C + c * CS + uo;
+  const double *E = a.E ? a.E + c * CS + uo : nullptr;
+#pragma unroll
+  for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gj = 16 * tj + lq + 4 * r, gi = 16 * ti + lr;
+        if (gi < N && gj < N) {
+          const size_t o = gi + (size_t)gj * N;
+          double v = a.alpha * acc[tj][ti][r];
+          if (E) v += a.beta * E[o];
+          if (c == 0 && gi == gj) v += a.eye;
+          C[o] = v;
+        } else if (RIDE && gi < N && gj - N < nq) {
+          const double *ad = (gj == N) ? a.add[0] : a.add[1];
+          double *y = (gj == N) ? a.y[0] : a.y[1];
+          y[voc + gi] = (ad ? ad[voc + gi] : 0.0) + acc[tj][ti][r];
+        }
+      }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // G0 = inv(eye I + s W0): batch_inv! (gpu_batched.jl:61-82) on the VALUE component, pivoted Gauss-Jordan in LDS, one
 // workgroup per unit.  The partials follow as products (gpu_batched.jl:129-150).
@@ -360,6 +439,140 @@ __global__ void __launch_bounds__(256) k_dinv(InvArgs a) {
   for (int j = w; j < N; j += 4)
     for (int i = lane; i < N; i += 64) a.G[uo + i + (size_t)j * N] = A[i * LD + j];
   if (t == 0 && bad) atomicMax(a.info, 1);
+}
+
+// The inverse for N <= NC (16, 32): ONE WAVEFRONT per unit, lane i holds row i in registers.  Pivot search down the lanes (DPP
+// shifts, readlane, ballot), the pivot row broadcast by readlane (scalar operands of the update), no LDS traffic and no barrier in
+// the elimination; rows are exchanged (through LDS) only when the pivot is not on the diagonal.
+template <int NC>
+__global__ void __launch_bounds__(256) k_dinv_w(InvArgs a) {
+  __shared__ double xch[4][2][NC];
+  __shared__ int perm[4][2][NC];   // [wave][piv | dst][.]
+  const int N = a.N, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t unit = (size_t)blockIdx.x * 4 + w;
+  if (unit >= (size_t)a.U) return;
+  const size_t NN = (size_t)N * N, uo = unit * NN;
+  // the row in halves of 16 registers, each its own array: a wave-uniform dynamic index into 16 doubles is a v_movrel, one
+  // 32-element array went to scratch.  `each` runs a body over both halves with static indices.
+  constexpr int NH = NC / 16;
+  double Ra[16], Rb[16];
+  auto each = [&](auto &&f) {
+    f(Ra, 0);
+    if constexpr (NH > 1) f(Rb, 16);
+  };
+  each([&](double (&r)[16], int base) {
+#pragma unroll
+    for (int j2 = 0; j2 < 16; ++j2) {
+      const int j = base + j2;
+      r[j2] = (lane < N && j < N) ? a.s * a.W[uo + lane + (size_t)j * N] + (lane == j ? a.eye : 0.0) : 0.0;
+    }
+  });
+  // column k of every lane's row, k wave-uniform: a scalar switch over statically indexed registers (cases of one move each)
+#define MOMD_C16(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+  auto col_get = [&](int k) {
+    double v = 0.0;
+    switch (k) {
+#define MOMD_G(S) case S: v = Ra[S]; break;
+      MOMD_C16(MOMD_G)
+#undef MOMD_G
+#define MOMD_G(S) case 16 + S: if constexpr (NH > 1) v = Rb[S]; break;
+      MOMD_C16(MOMD_G)
+#undef MOMD_G
+      default: break;
+    }
+    return v;
+  };
+  auto col_set = [&](int k, double v) {
+    switch (k) {
+#define MOMD_G(S) case S: Ra[S] = v; break;
+      MOMD_C16(MOMD_G)
+#undef MOMD_G
+#define MOMD_G(S) case 16 + S: if constexpr (NH > 1) Rb[S] = v; break;
+      MOMD_C16(MOMD_G)
+#undef MOMD_G
+      default: break;
+    }
+  };
+#undef MOMD_C16
+  bool bad = false;
+  union U2 { double d; int w2[2]; };
+  auto lane_get = [&](double v, int src) {
+    U2 u, r;
+    u.d = v;
+    r.w2[0] = __builtin_amdgcn_readlane(u.w2[0], src);
+    r.w2[1] = __builtin_amdgcn_readlane(u.w2[1], src);
+    return r.d;
+  };
+  for (int kv = 0; kv < N; ++kv) {
+    const int k = __builtin_amdgcn_readfirstlane(kv);
+    const double colv = col_get(k);
+    double best = (lane >= k && lane < N) ? fabs(colv) : -1.0;
+    double m = best;
+    U2 ua, ub;
+#define MOMD_DPP_MAX(ctrl)                                                    \
+  ua.d = m;                                                                   \
+  ub.w2[0] = __builtin_amdgcn_update_dpp(ua.w2[0], ua.w2[0], ctrl, 0xf, 0xf, false); \
+  ub.w2[1] = __builtin_amdgcn_update_dpp(ua.w2[1], ua.w2[1], ctrl, 0xf, 0xf, false); \
+  m = fmax(m, ub.d);
+    MOMD_DPP_MAX(0x111) MOMD_DPP_MAX(0x112) MOMD_DPP_MAX(0x114) MOMD_DPP_MAX(0x118)
+#undef MOMD_DPP_MAX
+    double mx = lane_get(m, 15);
+    if (NC > 16) mx = fmax(mx, lane_get(m, 31));
+    const int p = __builtin_ctzll(__ballot(best == mx));
+    if (!(mx > 0.0)) bad = true;
+    if (lane == 0) perm[w][0][k] = p;
+    if (p != k) {   // exchange rows p and k (lanes p and k) through LDS
+      each([&](double (&r)[16], int base) {
+        if (lane == p) {
+#pragma unroll
+          for (int j2 = 0; j2 < 16; ++j2) xch[w][0][base + j2] = r[j2];
+        }
+        if (lane == k) {
+#pragma unroll
+          for (int j2 = 0; j2 < 16; ++j2) xch[w][1][base + j2] = r[j2];
+        }
+      });
+      __builtin_amdgcn_wave_barrier();
+      each([&](double (&r)[16], int base) {
+        if (lane == p) {
+#pragma unroll
+          for (int j2 = 0; j2 < 16; ++j2) r[j2] = xch[w][1][base + j2];
+        }
+        if (lane == k) {
+#pragma unroll
+          for (int j2 = 0; j2 < 16; ++j2) r[j2] = xch[w][0][base + j2];
+        }
+      });
+      __builtin_amdgcn_wave_barrier();
+    }
+    const double c0 = col_get(k);           // column k after the exchange
+    const double val = lane_get(c0, k);
+    double pinv = __builtin_amdgcn_rcp(val);
+    pinv = pinv * (2.0 - val * pinv);
+    pinv = pinv * (2.0 - val * pinv);
+    const double c = (lane == k) ? val - 1.0 : c0;   // lane k: R_k - (val - 1) (R_k pinv) = R_k pinv
+    each([&](double (&r)[16], int base) {
+#pragma unroll
+      for (int j2 = 0; j2 < 16; ++j2)
+        if (base + j2 < N) r[j2] = r[j2] - c * (lane_get(r[j2], k) * pinv);
+    });
+    col_set(k, (lane == k) ? pinv : -c0 * pinv);
+  }
+  // undo the row exchanges as column exchanges in reverse order (one lane per column follows its position)
+  __builtin_amdgcn_wave_barrier();
+  int pos = lane;
+  for (int k = N - 1; k >= 0; --k) {
+    const int p = perm[w][0][k];
+    pos = (pos == k) ? p : ((pos == p) ? k : pos);
+  }
+  if (lane < N) perm[w][1][lane] = pos;
+  __builtin_amdgcn_wave_barrier();
+  each([&](double (&r)[16], int base) {
+#pragma unroll
+    for (int j2 = 0; j2 < 16; ++j2)
+      if (base + j2 < N && lane < N) a.G[uo + lane + (size_t)perm[w][1][base + j2] * N] = r[j2];
+  });
+  if (bad && lane == 0) atomicMax(a.info, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -820,6 +1033,17 @@ int momd_run(const MomDualScene &sc, std::string *err) {
       const int tiles_j = (N + rd.nq + TN - 1) / TN;
       GemmArgs g{N, U, c0, nc, mode, tiles, tiles_j, A, B, E, C, alpha, beta, eye, rd.nq, {rd.x[0], rd.x[1]}, {rd.add[0], rd.add[1]},
                  {rd.y[0], rd.y[1]}};
+      if (N + rd.nq <= 32) {   // one wavefront per (unit, component)
+        const dim3 gw((unsigned)(((size_t)U * nc + 3) / 4));
+        if (N + rd.nq <= 16) {
+          if (rd.nq) hipLaunchKernelGGL((k_dgemm_w<1, true>), gw, dim3(256), 0, st, g);
+          else hipLaunchKernelGGL((k_dgemm_w<1, false>), gw, dim3(256), 0, st, g);
+        } else {
+          if (rd.nq) hipLaunchKernelGGL((k_dgemm_w<2, true>), gw, dim3(256), 0, st, g);
+          else hipLaunchKernelGGL((k_dgemm_w<2, false>), gw, dim3(256), 0, st, g);
+        }
+        return;
+      }
       const dim3 grid((unsigned)(8 * tiles * tiles_j * nc * ((U + 7) / 8)));
       if (N % 2 == 0) {
         if (rd.nq) hipLaunchKernelGGL((k_dgemm<true, true>), grid, dim3(256), 0, st, g);
@@ -841,7 +1065,9 @@ int momd_run(const MomDualScene &sc, std::string *err) {
     // and with dG = G dW G the partials are OUT_c = A_c G0 + A0 G0 W_c G0 = (A_c + OUT0 W_c) G0: two products per partial
     auto times_inv = [&](double *OUT, const double *A, const double *Wm) {
       InvArgs ia{N, U, Wm, G, 1.0, -1.0, sc.info};
-      if (nbk == 1) hipLaunchKernelGGL(k_dinv<1>, dim3((unsigned)U), dim3(256), inv_lds, st, ia);
+      if (N <= 16) hipLaunchKernelGGL(k_dinv_w<16>, dim3((unsigned)((U + 3) / 4)), dim3(256), 0, st, ia);
+      else if (N <= 32) hipLaunchKernelGGL(k_dinv_w<32>, dim3((unsigned)((U + 3) / 4)), dim3(256), 0, st, ia);
+      else if (nbk == 1) hipLaunchKernelGGL(k_dinv<1>, dim3((unsigned)U), dim3(256), inv_lds, st, ia);
       else hipLaunchKernelGGL(k_dinv<2>, dim3((unsigned)U), dim3(256), inv_lds, st, ia);
       gemm(OUT, A, G, 0, 0, 1, 1.0, nullptr, 0.0, 0.0);
       gemm(Y, OUT, Wm, 1, 1, P, 1.0, A, 1.0, 0.0);
