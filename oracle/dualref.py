@@ -127,10 +127,40 @@ def _surface(scene, kind, Rs_m, alb, albedo, added, m, tau_sum):
                 a[:] = 0
 
 
-def _run(scene: mr.Scene, L: LayerInputs, p: Optional[Partial], hook=None):
-    """rt_run.jl:125-215 on momref's operators with x + i H x' inputs (p = None: the plain real run, float64)."""
+def _batch_inv_gj(A: np.ndarray) -> np.ndarray:
+    """Batched Gauss-Jordan with partial pivoting in the array's own precision (numpy.linalg has no extended-precision solver):
+    the inverse for the x87 arbiter run below."""
+    S, N, _ = A.shape
+    M = np.concatenate([A.copy(), np.broadcast_to(np.eye(N, dtype=A.dtype), A.shape).copy()], axis=2)
+    idx = np.arange(S)
+    for k in range(N):
+        p = k + np.argmax(np.abs(M[:, k:, k]), axis=1)
+        rk, rp = M[idx, k].copy(), M[idx, p].copy()
+        M[idx, k], M[idx, p] = rp, rk
+        M[:, k] = M[:, k] / M[:, k, k][:, None]
+        f = M[:, :, k].copy()
+        f[:, k] = 0
+        M -= f[:, :, None] * M[:, k][:, None, :]
+    return M[:, :, N:]
+
+
+def _run(scene: mr.Scene, L: LayerInputs, p: Optional[Partial], hook=None, extended: bool = False):
+    """rt_run.jl:125-215 on momref's operators with x + i H x' inputs (p = None: the plain real run, float64).
+    extended: the same run in x87 extended precision (numpy complex256 / longdouble, 64-bit mantissa) -- the ARBITER of the
+    thick-layer comparisons, where two Float64 runs differ by rounding amplified over the doublings."""
     cplx = p is not None
-    dt = np.complex128 if cplx else np.float64
+    dt = (np.clongdouble if cplx else np.longdouble) if extended else (np.complex128 if cplx else np.float64)
+    if extended:
+        saved = mr.batch_inv
+        mr.batch_inv = _batch_inv_gj
+        try:
+            return _run_dt(scene, L, p, hook, cplx, dt)
+        finally:
+            mr.batch_inv = saved
+    return _run_dt(scene, L, p, hook, cplx, dt)
+
+
+def _run_dt(scene, L, p, hook, cplx, dt):
 
     def pert(x, dx):
         x = np.asarray(x, dtype=dt)
@@ -189,16 +219,18 @@ def _run(scene: mr.Scene, L: LayerInputs, p: Optional[Partial], hook=None):
     return R_SFI, T_SFI
 
 
-def rt_run_dual(scene: mr.Scene, partials: Sequence[Partial], L: Optional[LayerInputs] = None, hook=None):
-    """rt_run on Dual inputs: (R_SFI, T_SFI) [nVza, nStokes, S] and their partials dR, dT [P, nVza, nStokes, S]."""
+def rt_run_dual(scene: mr.Scene, partials: Sequence[Partial], L: Optional[LayerInputs] = None, hook=None, extended: bool = False):
+    """rt_run on Dual inputs: (R_SFI, T_SFI) [nVza, nStokes, S] and their partials dR, dT [P, nVza, nStokes, S].
+    extended = True: the x87 extended-precision run (results rounded to Float64 at the end)."""
     L = layer_inputs(scene) if L is None else L
-    R, T = _run(scene, L, None)
+    R, T = _run(scene, L, None, extended=extended)
+    R, T = np.asarray(R, dtype=np.float64), np.asarray(T, dtype=np.float64)
     dR = np.zeros((len(partials),) + R.shape)
     dT = np.zeros_like(dR)
     for i, p in enumerate(partials):
-        Rc, Tc = _run(scene, L, p, hook=(lambda *a, i=i: hook(i, *a)) if hook else None)
-        dR[i] = Rc.imag / H
-        dT[i] = Tc.imag / H
+        Rc, Tc = _run(scene, L, p, hook=(lambda *a, i=i: hook(i, *a)) if hook else None, extended=extended)
+        dR[i] = np.asarray(Rc.imag / H, dtype=np.float64)
+        dT[i] = np.asarray(Tc.imag / H, dtype=np.float64)
     return R, T, dR, dT
 
 

@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
     }
 }
 
-// The same product for operators of edge N + nq <= 16 NT (NT = 1, 2): ONE WAVEFRONT per (unit, component), operands read straight
+// The same product for operators of edge N + nq <= 16 NT (NT = 1, 2, 3): ONE WAVEFRONT per (unit, component), operands read straight
 // from global memory in the layout of the MFMA (a 30 x 30 operator is 7 KB: cache-resident), no LDS, no barrier.  The 64 x 64
 // workgroup tile above costs the same for every edge up to 64 (N = 30: 4.5 x the MFMA work, two staging phases per term).
 template <int NT, bool RIDE>
@@ -699,6 +699,7 @@ struct ElArgs {
 };
 
 __global__ void __launch_bounds__(256) k_delemental(ElArgs a) {
+#pragma clang fp contract(off)
   const int N = a.N, n = a.nS, P = a.P, K = a.K;
   const size_t NN = (size_t)N * N;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -731,12 +732,16 @@ __global__ void __launch_bounds__(256) k_delemental(ElArgs a) {
       dAt = F2 * wj * (-ei / mui + ej / muj);
     }
   }
+  // the VALUE in the reference's own association (elemental.jl:180-200), no FMA contraction: a one-ulp difference here is amplified
+  // by every later doubling (tests/helpers.py stokes_rtol), so the value follows the text literally like the fused kernels do
   double r0 = 0.0, t0 = 0.0;
-  if (live) {
-    r0 = w * Zm * Ar;
-    if (!same) t0 = w * Zp * At;
-    else if (diag) t0 = ei * (1.0 + w * Zp * (d / mui) * wi);
-  } else if (diag) t0 = ei;
+  {
+    if (live) {
+      r0 = w * Zm * (muj / (mui + muj)) * wj * (1.0 - exp(-d * ((1.0 / mui) + (1.0 / muj))));
+      if (!same) t0 = w * Zp * (muj / (mui - muj)) * wj * (ei - ej);
+      else if (diag) t0 = ei * (1.0 + w * Zp * (d / mui) * wi);
+    } else if (diag) t0 = ei;
+  }
   const int ci = stokes_comp(i, n, a.strict), cj = stokes_comp(j, n, a.strict);
   const double sg = (((ci <= 2) && (cj <= 2)) || ((ci > 2) && (cj > 2))) ? 1.0 : -1.0;
   const double rsign = (a.nd >= 1 && ci > 2) ? -1.0 : 1.0;
@@ -806,8 +811,15 @@ __global__ void __launch_bounds__(256) k_delemental(ElArgs a) {
   }
   const double Dm = (a.nd >= 1) ? a.D[i % n] : 1.0;
   const size_t ov = u * N + i;
-  a.j0p[ov] = wct02 * w * ZpI * gp * att;
-  a.j0m[ov] = Dm * (wct02 * w * ZmI * gm * att);
+  {
+    // elemental.jl:226-246 in the reference's association
+    double jp, jm;
+    if (insun) jp = wct02 * w * ZpI * (d / mui) * exp(-d / mui);
+    else jp = wct02 * w * ZpI * (mus / (mui - mus)) * (exp(-d / mui) - exp(-d / mus));
+    jm = wct02 * w * ZmI * (mus / (mui + mus)) * (1.0 - exp(-d * ((1.0 / mui) + (1.0 / mus))));
+    a.j0p[ov] = jp * att;
+    a.j0m[ov] = Dm * (jm * att);
+  }
   const double e0 = exp(-d / a.mu0);
   if (i == 0) a.e[u] = e0;
   for (int p = 0; p < P; ++p) {
@@ -1033,11 +1045,14 @@ int momd_run(const MomDualScene &sc, std::string *err) {
       const int tiles_j = (N + rd.nq + TN - 1) / TN;
       GemmArgs g{N, U, c0, nc, mode, tiles, tiles_j, A, B, E, C, alpha, beta, eye, rd.nq, {rd.x[0], rd.x[1]}, {rd.add[0], rd.add[1]},
                  {rd.y[0], rd.y[1]}};
-      if (N + rd.nq <= 32) {   // one wavefront per (unit, component)
+      if (N + rd.nq <= 48) {   // one wavefront per (unit, component)
         const dim3 gw((unsigned)(((size_t)U * nc + 3) / 4));
         if (N + rd.nq <= 16) {
           if (rd.nq) hipLaunchKernelGGL((k_dgemm_w<1, true>), gw, dim3(256), 0, st, g);
           else hipLaunchKernelGGL((k_dgemm_w<1, false>), gw, dim3(256), 0, st, g);
+        } else if (N + rd.nq > 32) {
+          if (rd.nq) hipLaunchKernelGGL((k_dgemm_w<3, true>), gw, dim3(256), 0, st, g);
+          else hipLaunchKernelGGL((k_dgemm_w<3, false>), gw, dim3(256), 0, st, g);
         } else {
           if (rd.nq) hipLaunchKernelGGL((k_dgemm_w<2, true>), gw, dim3(256), 0, st, g);
           else hipLaunchKernelGGL((k_dgemm_w<2, false>), gw, dim3(256), 0, st, g);

@@ -1,6 +1,6 @@
 """rt_run on ForwardDiff.Dual numbers (mom_scene_set_partials / mom_rt_run_dual / mom_get_RT_partials, csrc/mom_dual.hip)
-against oracle/dualref.py (the same Dual run of the numpy twin) through the C ABI: values to the Stokes bar, partials to the
-same bar relative to the largest partial of the view (tangents are propagated by the same products as the values)."""
+through the C ABI: values against the C oracle to the Stokes bar, partials against oracle/dualref.py (the Dual run of the numpy
+twin) to the same bar relative to the largest partial of the view (tangents are propagated by the same products as the values)."""
 import sys
 from pathlib import Path
 
@@ -13,7 +13,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 import rtamd  # noqa: E402
 import helpers  # noqa: E402
-from oracle import dualref as dr, momref as mr  # noqa: E402
+from oracle import cref, dualref as dr, momref as mr  # noqa: E402
 from test_oracle_dual import random_partials  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -40,20 +40,39 @@ def compare(model, P=2, seed=0, with_Z=True, workspace_mb=0, rtol=None):
     L = dr.layer_inputs(sc)
     ps = random_partials(L, P, seed=seed, with_Z=with_Z, kind=L.surf[0])
     R, T, dR, dT = rtamd.rt_run_dual(model, [to_host(p) for p in ps], workspace_mb=workspace_mb)
-    Ro, To, dRo, dTo = dr.rt_run_dual(sc, ps, L)
+    _, _, dRo, dTo = dr.rt_run_dual(sc, ps, L)
+    # VALUES against the C oracle, like every other GPU test: on thick layers two Float64 runs with different product kernels
+    # (numpy's dgemm / the C port's / the GPU's) are 1e-10 apart from rounding amplified by the doublings (helpers.stokes_rtol
+    # was measured against the C port); the numpy run that carries the complex step is only the checker of the PARTIALS
+    Ro, To, info = cref.rt_run(cref.pack_scene(sc))
+    assert info == 0
     rtol = rtol or helpers.stokes_rtol(max(L.ndoubl))
     helpers.assert_stokes_close(R, Ro, what="dual R", rtol=rtol)
     helpers.assert_stokes_close(T, To, what="dual T", rtol=rtol)
     assert np.abs(dRo).max() > 0 and np.abs(dTo).max() > 0
-    for i in range(P):
-        assert_partial_close(dR[i], dRo[i], rtol, f"dR[{i}]")
-        assert_partial_close(dT[i], dTo[i], rtol, f"dT[{i}]")
+    if max(L.ndoubl) <= 15:
+        for i in range(P):
+            assert_partial_close(dR[i], dRo[i], helpers.RTOL_STOKES, f"dR[{i}]")
+            assert_partial_close(dT[i], dTo[i], helpers.RTOL_STOKES, f"dT[{i}]")
+        return R, T, dR, dT
+    # thick layers: the Float64 complex-step run is itself 1e-9 .. 1e-8 away from the exact partials of the same equations
+    # (rounding amplified by the doublings, more for a partial than for its value).  Arbiter: the same run in x87 extended
+    # precision; the GPU's error must stay within 4 x the Float64 oracle's own (the rule of tests/test_gpu_precision.py).
+    _, _, dRx, dTx = dr.rt_run_dual(sc, ps, L, extended=True)
+    for name, g, o, x in (("dR", dR, dRo, dRx), ("dT", dT, dTo, dTx)):
+        for i in range(P):
+            scale = np.abs(x[i]).max(axis=(1, 2), keepdims=True)
+            e_gpu = float((np.abs(g[i] - x[i]) / scale).max())
+            e_orc = float((np.abs(o[i] - x[i]) / scale).max())
+            helpers._log_parity(f"{name}[{i}] vs x87 arbiter (oracle's own error {e_orc:.2e})", max(helpers.RTOL_STOKES, 4 * e_orc), e_gpu, g[i].size)
+            assert e_gpu <= max(helpers.RTOL_STOKES, 4 * e_orc), f"{name}[{i}]: GPU {e_gpu:.2e} of the view's largest partial, oracle {e_orc:.2e}"
     return R, T, dR, dT
 
 
-@pytest.mark.parametrize("nS,ltr,Nz,S", [(1, 3, 3, 9), (3, 5, 4, 7), (4, 5, 3, 5), (3, 13, 3, 6), (1, 40, 2, 3)])
+@pytest.mark.parametrize("nS,ltr,Nz,S", [(1, 3, 3, 9), (3, 5, 4, 7), (4, 5, 3, 5), (3, 13, 3, 6), (3, 21, 3, 4), (1, 40, 2, 3), (1, 130, 2, 2)])
 def test_dual_run_matches_the_dual_oracle(nS, ltr, Nz, S):
-    """Scalar / IQU / IQUV, edges 4 .. 69 (one and two tiles of the product kernel), aerosol + absorption, all three moments."""
+    """Scalar / IQU / IQUV, edges 4 .. 68: every kernel form (wavefront per item on 1 x 1, 2 x 2, 3 x 3 tiles up to edge 48, workgroup
+    tiles above; wavefront / workgroup inverse, the two-block inverse above 64), aerosol + absorption, all three moments."""
     compare(rtamd.scenes.make_scene(nS, ltr, Nz, S, seed=3 + nS, aerosol_total=0.2), P=2, seed=ltr)
 
 
@@ -117,7 +136,7 @@ def test_dual_chunked_workspace_is_bitwise_the_unchunked_run():
 
 def test_dual_padded_operator_edge():
     """A scene whose operators carry strip_pad's dummy entries (N = 58 -> 60): the partials of the bases are padded like the bases."""
-    m = rtamd.scenes.make_scene(1, 110, 2, 3, seed=1, aerosol_total=0.1)
+    m = rtamd.scenes.make_scene(1, 110, 2, 2, seed=1, aerosol_total=0.1)
     assert m.quad_points.qp_μN.size not in (52, 56, 60)
     compare(m, P=1, seed=2)
 
@@ -137,6 +156,6 @@ def test_dual_errors():
 
 def test_dual_C2_operator_shape():
     """The headline's operator shape (IQU, 20 streams, N = 60, three moments, aerosol + absorption) on a short column."""
-    m = rtamd.scenes.make_scene(3, 33, 6, 4, seed=21, aerosol_total=0.3)
+    m = rtamd.scenes.make_scene(3, 33, 6, 2, seed=21, aerosol_total=0.3)
     assert m.quad_points.qp_μN.size == 60
-    compare(m, P=2, seed=7)
+    compare(m, P=1, seed=7)

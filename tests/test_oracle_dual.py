@@ -125,3 +125,18 @@ def test_scene_partial_through_the_layer_optics_algebra():
     Rm, Tm = mr.rt_run(move(sc, -eps))
     assert np.abs(dR[0] - (Rp - Rm) / (2 * eps)).max() <= 5e-8 * np.abs(dR).max()
     assert np.abs(dT[0] - (Tp - Tm) / (2 * eps)).max() <= 5e-8 * np.abs(dT).max()
+
+
+def test_extended_precision_arbiter_run():
+    """The x87 extended-precision run of the same statements (numpy complex256, own Gauss-Jordan inverse) -- the arbiter of the
+    thick-layer partials in tests/test_gpu_dual.py: on a thin scene it is the Float64 run to rounding, on a thick one the Float64
+    run is measurably away from it (the reason the arbiter exists)."""
+    sc = _scene(nS=3, aerosol_total=0.2)
+    L = dr.layer_inputs(sc)
+    ps = random_partials(L, 1, seed=1)
+    a = dr.rt_run_dual(sc, ps, L)
+    b = dr.rt_run_dual(sc, ps, L, extended=True)
+    for x, y in zip(a, b):
+        assert np.abs(x - y).max() <= 2e-12 * np.abs(y).max()
+    A = np.random.default_rng(0).uniform(-1, 1, (3, 7, 7)) + 3 * np.eye(7)
+    assert np.allclose(dr._batch_inv_gj(A.astype(np.longdouble)).astype(float), np.linalg.inv(A), rtol=1e-13, atol=1e-15)
