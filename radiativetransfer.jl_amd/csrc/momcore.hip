@@ -430,6 +430,7 @@ struct mom_handle {
   // ForwardDiff.Dual run (mom_dual.hip): partials of the scene's inputs and of the outputs, the operator workspace
   int dual_P = 0;
   bool dual_ran = false;
+  bool dual_last = false;   // the last run of the resident scene was mom_rt_run_dual: hdr / bhr hold nothing of it
   double *d_dual_in[8] = {};  // dtau, dvarpi, dzw, dZpp, dZmp, dalbedo, dRsurf, dalbedo_spec
   double *d_dual_out = nullptr, *d_dual_ts = nullptr;  // dR | dT [nVza,nS,S,P] x 2; d tau_sum [S,Nz+1,P]
   void *dual_work = nullptr;
@@ -1191,6 +1192,10 @@ static int scene_common(mom_t *h, int Nz, int K, int M, const double *Zpp, const
     if (node_1based[v] < 1 || node_1based[v] * h->nS > h->N) return fail(h, MOM_EINVAL, "mom_scene_set: bad view node");
   const size_t S = h->S, NN = (size_t)h->N * h->N;
   int rc;
+  // a new scene: the partials of the previous one (mom_scene_set_partials) do not belong to it
+  for (int k = 0; k < 8; ++k)
+    if (h->d_dual_in[k]) { (void)hipFree(h->d_dual_in[k]); h->d_dual_in[k] = nullptr; }
+  h->dual_P = 0; h->dual_ran = false; h->dual_last = false;
   // (edges up to 32 belong to the wave-per-point kernel, which takes the operators as they are)
   const int Nk = (h->opt_pad && !(h->N <= 32 && h->opt_small)) ? strip_pad(h->N) : h->N;
   h->Nk = Nk;
@@ -1692,6 +1697,7 @@ extern "C" int mom_rt_run(mom_t *h) {
   h->launches = 0; h->launches_full = 0; h->launches_red = 0;
   h->comp_pitched = true;
   h->comp_on_chip = true;
+  h->dual_last = false;
   if (h->N <= 4 && h->opt_small && !h->opt_force_generic && h->nVza <= 4 && h->surf_kind == 0 && h->K <= 4) return rt_run_small(h);
   if (wave_sweep_applies(h)) return rt_run_wave(h);
   h->comp_on_chip = false;
@@ -1935,6 +1941,7 @@ extern "C" int mom_rt_run_dual(mom_t *h) {
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
   HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
   h->dual_ran = true;
+  h->dual_last = true;
   h->comp_on_chip = true;  // no composite layer of this run is left in the handle's operator-level state
   return MOM_OK;
 }
@@ -1967,6 +1974,7 @@ extern "C" int mom_get_RT(mom_t *h, double *R_SFI, double *T_SFI) {
 extern "C" int mom_get_hdr(mom_t *h, double *hdr, double *bhr_uw, double *bhr_dw) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   if (!h->scene_set || !hdr || !bhr_uw || !bhr_dw) return fail(h, MOM_ESTATE, "mom_get_hdr: no scene / null output");
+  if (h->dual_last) return fail(h, MOM_ESTATE, "mom_get_hdr: the last run was mom_rt_run_dual, which does not produce hdr / bhr (run mom_rt_run)");
   HIPCHK(h, hipSetDevice(h->device));
   if (h->f32) {
     const int rc = momf_get_hdr(h->f32, hdr, bhr_uw, bhr_dw);

@@ -152,6 +152,12 @@ def test_dual_errors():
             h.scene_set_partials(1, dZpp=np.zeros(sc.Zpp.size))   # dZpp without dZmp
         with pytest.raises(rtamd.MomError):
             h.get_RT_partials()                  # no Dual run yet
+        h.scene_set_partials(1, dalbedo=np.ones(1))
+        h.rt_run_dual()
+        with pytest.raises(rtamd.MomError):
+            h.get_hdr()                          # the Dual run does not produce hdr / bhr: no stale values handed out
+        h.rt_run()
+        h.get_hdr()
 
 
 def test_dual_C2_operator_shape():
