@@ -1,4 +1,4 @@
-"""Time mom_rt_run_dual on a C2-shaped scene (N = 60, Nz = 40, M = 3) next to the value run: tools/dual_bench.py S P [reps [nStokes l_trunc]]
+"""Time mom_rt_run_dual on a C2-shaped scene (N = 60, Nz = 40, M = 3) next to the value run: tools/dual_bench.py S P [reps [nStokes l_trunc [Nz]]]
 (nStokes, l_trunc: another operator edge, 40 layers)."""
 import sys
 import time
@@ -13,7 +13,7 @@ import rtamd  # noqa: E402
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-m = rtamd.scenes.scene_C2(S=S) if len(sys.argv) <= 5 else rtamd.scenes.make_scene(int(sys.argv[4]), int(sys.argv[5]), 40, S)
+m = rtamd.scenes.scene_C2(S=S) if len(sys.argv) <= 5 else rtamd.scenes.make_scene(int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]) if len(sys.argv) > 6 else 40, S)
 sc = rtamd.prepare_scene(m)
 rng = np.random.default_rng(0)
 L = rtamd.corert.construct_layer_inputs(m)
