@@ -596,8 +596,10 @@ def dual_leg(dev, S=2000, P=3):
             "dtype": "f64", "ms_per_run": td * 1e3, "value_run_ms": tv * 1e3, "ratio_to_value_run": td / tv, "ideal_ratio": 1 + 2 * P,
             "config": {"workload": f"C2 shape: N = {N}, Nz = {Nz}, M = {M}, S = {S}, P = {P} partials (tau, varpi, phase weights, albedo)"},
             "finite": bool(np.isfinite(dR).all()),
-            "roofline": {"bound": "hbm", "note": "batched products stream values and partials through HBM (no LDS-resident image holds "
-                         "14 x (1 + P) operators); product flops only", "achieved_tflops": flop / td / 1e12}}
+            "roofline": {"bound": "mfma", "achieved": flop / td / 1e12, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop / td / 1e12 / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "note": "product flops of the tangent-linear sweep (2 N^3 per term-product) over the whole run; SQ counters: "
+                                 "matrix pipe 43-49 % busy in momd::k_dgemm, HBM 1.5-2.5 TB/s (profiles/r06_dual_ab.txt)"}}
 
 
 def main():

@@ -12,10 +12,10 @@
 // launch that carries all components: products by k_dgemm (64 x 64 tiles on v_mfma_f64_16x16x4, the Dual product rule
 // applied per component: c = 0: A0 B0, c > 0: Ac B0 + A0 Bc), inverses by k_dinv (pivoted Gauss-Jordan in LDS, value only)
 // followed by two products per partial ((A G)_c = (A_c + (A G)_0 W_c) G0), matrix-vector statements by k_dmatvec, the elemental
-// layer by k_delemental (analytic derivatives of get_elem_rt! / get_elem_rt_SFI!).  A batched product of N = 60 reads
-// and writes 86 KB per 432 kFLOP: the sweep is HBM-bound (about 5 FLOP/B against 9.8 at the ridge), not MFMA-bound --
-// the operators of value AND partials do not fit one CU's LDS (14 x (1 + P) x 29 KB per unit), which is why this path
-// streams them instead of using the fused LDS-resident images of the value run (mom_kernels.hpp, mom_q4.hpp).
+// layer by k_delemental (analytic derivatives of get_elem_rt! / get_elem_rt_SFI!).  The operators of value AND partials do not
+// fit one CU's LDS (5 live operators x (1 + P) x 29 KB per unit at N = 60), which is why this path streams them instead of using
+// the fused LDS-resident images of the value run (mom_kernels.hpp, mom_q4.hpp).  Measured (profiles/r06_dual_ab.txt): the
+// sweep is bound by the matrix pipe (43-49 % busy in k_dgemm), not by HBM (1.5-2.5 TB/s per product launch).
 //
 // Units are independent: a scene larger than the workspace budget is processed in chunks of units.
 #include <hip/hip_runtime.h>
