@@ -22,8 +22,9 @@
  *   - `dtype` of mom_create: 0 = Float64 (the reference's default float_type), 1 = Float32 (float_type = Float32,
  *     parameters_from_yaml.jl:160): operators, sources and products in f32 on the GPU.  The ABI keeps Float64 host
  *     arrays for both (inputs are rounded on upload, outputs widened on download).  A Float32 handle supports the
- *     scene-level path -- mom_set_streams, mom_scene_set, mom_scene_set_surface, mom_set_option, mom_rt_run,
- *     mom_get_RT, mom_get_hdr, mom_timers, mom_sync, mom_check: the lane- and wave-per-point kernels (incl. the packed
+ *     scene-level path -- mom_set_streams, mom_scene_set, mom_scene_set_optics with the mom_absorption_* / mom_voigt_tau_abs*
+ *     entry points that feed it (the layer optics are assembled in Float64 on the device and rounded to Float32 there),
+ *     mom_scene_set_surface, mom_set_option, mom_rt_run, mom_get_RT, mom_get_hdr, mom_timers, mom_sync, mom_check: the lane- and wave-per-point kernels (incl. the packed
  *     points at N = 5 ... 8), the strip-chained images (N = 36 ... 60, 4-wave builds: two workgroups per CU), the m = 0
  *     (I,Q) reduction and the padding to the strip sizes --, the operator-level API -- mom_elemental, mom_doubling,
  *     mom_interaction, mom_copy_added_to_composite, mom_surface_lambertian, mom_upload, mom_download (the operator-level

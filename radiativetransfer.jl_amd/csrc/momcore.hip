@@ -350,6 +350,9 @@ int momf_set_streams(momf_scene *s, const double *mu, const double *wt, const do
 int momf_scene_set(momf_scene *s, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
                    const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface, const double *tau_sum,
                    double albedo, int nVza, const int *node, const double *cos_mphi, const double *sin_mphi);
+int momf_scene_set_dev(momf_scene *s, int Nz, int K, int M, const double *d_tau, const double *d_varpi, const double *d_zw,
+                       const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface, const double *d_tau_sum,
+                       double albedo, int nVza, const int *node, const double *cos_mphi, const double *sin_mphi);
 int momf_scene_set_surface(momf_scene *s, int kind, int M, const double *Rsurf, const double *albedo_spec);
 int momf_rt_run(momf_scene *s);
 int momf_get_RT(momf_scene *s, double *R, double *T);
@@ -2249,7 +2252,6 @@ extern "C" int mom_allgather_RT(mom_t *h, double *R_SFI_global, double *T_SFI_gl
 
 extern "C" int mom_absorption_begin(mom_t *h, int Nz, const double *grid) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_absorption_begin");
   if (Nz <= 0) return fail(h, MOM_EINVAL, "mom_absorption_begin: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t S = h->S;
@@ -2267,7 +2269,6 @@ extern "C" int mom_absorption_begin(mom_t *h, int Nz, const double *grid) {
 
 extern "C" int mom_absorption_set(mom_t *h, int Nz, const double *tau_abs) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_absorption_set");
   if (Nz <= 0 || !tau_abs) return fail(h, MOM_EINVAL, "mom_absorption_set: bad argument");
   int rc = mom_absorption_begin(h, Nz, nullptr);
   if (rc) return rc;
@@ -2278,7 +2279,6 @@ extern "C" int mom_absorption_set(mom_t *h, int Nz, const double *tau_abs) {
 
 extern "C" int mom_absorption_get(mom_t *h, double *tau_abs) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_absorption_get");
   if (!h->d_tau_abs || !tau_abs) return fail(h, MOM_ESTATE, "mom_absorption_get: no resident tau_abs table / null output");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpyAsync(tau_abs, h->d_tau_abs, (size_t)h->S * h->abs_Nz * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -2289,7 +2289,6 @@ extern "C" int mom_absorption_get(mom_t *h, double *tau_abs) {
 extern "C" int mom_voigt_tau_abs(mom_t *h, int iz_1based, int nLines, const double *nu, const double *gamma_d, const double *y,
                                  const double *S, const int *ind_start_1based, const int *ind_stop_1based, double factor) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_voigt_tau_abs");
   if (!h->d_tau_abs || !h->d_grid) return fail(h, MOM_ESTATE, "mom_voigt_tau_abs: call mom_absorption_begin with the spectral grid first");
   if (iz_1based < 1 || iz_1based > h->abs_Nz || nLines < 0 ||
       (nLines > 0 && (!nu || !gamma_d || !y || !S || !ind_start_1based || !ind_stop_1based)))
@@ -2336,7 +2335,6 @@ extern "C" int mom_absorption_set_lines(mom_t *h, int nLines, const double *nu0,
                                         const double *delta_air, const double *sqrt_mol_weight, const int *iso_index, int nIso,
                                         int nTmax, const int *nT, const double *tips_T, const double *tips_Q, const double *tips_z) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_absorption_set_lines");
   if (nLines < 0 || nIso < 0 || nTmax < 0 || (nLines > 0 && (!nu0 || !S0 || !gamma_air || !gamma_self || !E_lower || !n_air ||
       !delta_air || !sqrt_mol_weight || !iso_index)) || (nIso > 0 && (nTmax < 2 || !nT || !tips_T || !tips_Q || !tips_z)))
     return fail(h, MOM_EINVAL, "mom_absorption_set_lines: bad argument");
@@ -2380,7 +2378,6 @@ extern "C" int mom_absorption_set_lines(mom_t *h, int nLines, const double *nu0,
 extern "C" int mom_voigt_tau_abs_layer(mom_t *h, int iz_1based, double pressure, double temperature, double vmr,
                                        double wing_cutoff, double factor) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_voigt_tau_abs_layer");
   if (!h->d_tau_abs || !h->d_grid) return fail(h, MOM_ESTATE, "mom_voigt_tau_abs_layer: call mom_absorption_begin with the spectral grid first");
   if (!h->d_lt) return fail(h, MOM_ESTATE, "mom_voigt_tau_abs_layer: call mom_absorption_set_lines first");
   if (iz_1based < 1 || iz_1based > h->abs_Nz || !(temperature > 0.0)) return fail(h, MOM_EINVAL, "mom_voigt_tau_abs_layer: bad argument");
@@ -2426,7 +2423,6 @@ extern "C" int mom_voigt_tau_abs_layer(mom_t *h, int iz_1based, double pressure,
 extern "C" int mom_voigt_tau_abs_profile(mom_t *h, int Nz, const double *pressure, const double *temperature, double vmr,
                                          double wing_cutoff, const double *factor, double *gpu_ms) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_voigt_tau_abs_profile");
   if (!h->d_tau_abs || !h->d_grid) return fail(h, MOM_ESTATE, "mom_voigt_tau_abs_profile: call mom_absorption_begin with the spectral grid first");
   if (!h->d_lt) return fail(h, MOM_ESTATE, "mom_voigt_tau_abs_profile: call mom_absorption_set_lines first");
   if (Nz < 1 || Nz > h->abs_Nz || !pressure || !temperature || !factor) return fail(h, MOM_EINVAL, "mom_voigt_tau_abs_profile: bad argument");
@@ -2581,7 +2577,6 @@ extern "C" int mom_scene_set_optics(mom_t *h, int Nz, int nAer, int M, const dou
                                     const double *Zpp, const double *Zmp, double albedo, int nVza, const int *node_1based,
                                     const double *cos_mphi, const double *sin_mphi) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_scene_set_optics");
   if (!h->streams_set) return fail(h, MOM_ESTATE, "mom_scene_set_optics: call mom_set_streams first");
   if (Nz <= 0 || nAer < 0 || nAer > 7 || M <= 0 || M > h->M || nVza <= 0 || !tau_rayl || !Zpp || !Zmp || !node_1based ||
       !cos_mphi || !sin_mphi || (nAer > 0 && (!tau_aer || !omega_aer || !ft_aer)))
@@ -2650,6 +2645,14 @@ extern "C" int mom_scene_set_optics(mom_t *h, int Nz, int nAer, int M, const dou
     prev = (z == 0) ? (scatter ? 3 : 0) : (prev == 0 ? (scatter ? 1 : 0) : (scatter ? 3 : 2));  // rt_helper_functions.jl:8-27
     h->iface[z] = prev;
   }
+  if (h->f32) {  // Float32 handle: the Float64 assembly above is rounded to Float32 on the device (no host hop of tau_abs either)
+    h->Nz = Nz; h->K = K; h->scene_M = M; h->nVza = nVza; h->albedo = albedo; h->surf_kind = 0;
+    if ((rc = momf_scene_set_dev(h->f32, Nz, K, M, h->d_tau, h->d_varpi, h->d_zw, Zpp, Zmp, h->nd.data(), h->iface.data(), h->d_tau_sum,
+                                 albedo, nVza, node_1based, cos_mphi, sin_mphi)))
+      return fail(h, rc, momf_error(h->f32));
+    h->scene_set = true;
+    return MOM_OK;
+  }
   if ((rc = scene_common(h, Nz, K, M, Zpp, Zmp, albedo, nVza, node_1based, cos_mphi, sin_mphi))) return rc;
   h->scene_set = true;
   return MOM_OK;
@@ -2657,8 +2660,9 @@ extern "C" int mom_scene_set_optics(mom_t *h, int Nz, int nAer, int M, const dou
 
 extern "C" int mom_scene_get_layers(mom_t *h, int *ndoubl, int *iface, double *tau, double *varpi, double *zw, double *tau_sum) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
-  F64_ONLY(h, "mom_scene_get_layers");
   if (!h->scene_set) return fail(h, MOM_ESTATE, "mom_scene_get_layers: no scene");
+  if (h->f32 && (tau || varpi || zw || tau_sum) && !h->d_tau)
+    return fail(h, MOM_ESTATE, "mom_scene_get_layers: a Float32 handle keeps the Float64 layer arrays only after mom_scene_set_optics");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t S = h->S, Nz = h->Nz;
   if (ndoubl) std::copy(h->nd.begin(), h->nd.end(), ndoubl);

@@ -323,20 +323,56 @@ static int upload_f(momf_scene *s, T **dst, const U *src, size_t n) {
   return MOM_OK;
 }
 
+// the layer optics assembled on the device in Float64 (mom_scene_set_optics): rounded to the scene's Float32 there
+__global__ void k_cvt_d2f(const double *src, float *dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+static int convert_f(momf_scene *s, float **dst, const double *d_src, size_t n) {
+  if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+  FCHK(s, dmallocf(dst, n));
+  hipLaunchKernelGGL(k_cvt_d2f, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->stream, d_src, *dst, n);
+  FCHK(s, hipGetLastError());
+  return MOM_OK;
+}
+
 static bool wave_applies_f32(const momf_scene *s);
+
+static int scene_set_impl(momf_scene *s, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
+                          const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface, const double *tau_sum,
+                          double albedo, int nVza, const int *node, const double *cos_mphi, const double *sin_mphi, bool dev_layers);
 
 int momf_scene_set(momf_scene *s, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
                    const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface, const double *tau_sum,
                    double albedo, int nVza, const int *node, const double *cos_mphi, const double *sin_mphi) {
+  return scene_set_impl(s, Nz, K, M, tau, varpi, zw, Zpp, Zmp, ndoubl, iface, tau_sum, albedo, nVza, node, cos_mphi, sin_mphi, false);
+}
+// the same with tau, varpi, zw, tau_sum as DEVICE Float64 arrays (the device-side layer optics of mom_scene_set_optics)
+int momf_scene_set_dev(momf_scene *s, int Nz, int K, int M, const double *d_tau, const double *d_varpi, const double *d_zw,
+                       const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface, const double *d_tau_sum,
+                       double albedo, int nVza, const int *node, const double *cos_mphi, const double *sin_mphi) {
+  return scene_set_impl(s, Nz, K, M, d_tau, d_varpi, d_zw, Zpp, Zmp, ndoubl, iface, d_tau_sum, albedo, nVza, node, cos_mphi, sin_mphi, true);
+}
+
+static int scene_set_impl(momf_scene *s, int Nz, int K, int M, const double *tau, const double *varpi, const double *zw,
+                          const double *Zpp, const double *Zmp, const int *ndoubl, const int *iface, const double *tau_sum,
+                          double albedo, int nVza, const int *node, const double *cos_mphi, const double *sin_mphi, bool dev_layers) {
   FCHK(s, hipSetDevice(s->device));
   int rc;
   if ((rc = apply_streams(s))) return rc;
   const int N = s->N, Nu = s->Nu, nS = s->nS;
   const size_t S = s->S, NN = (size_t)N * N;
-  if ((rc = upload_f(s, &s->d_tau, tau, S * Nz))) return rc;
-  if ((rc = upload_f(s, &s->d_varpi, varpi, S * Nz))) return rc;
-  if ((rc = upload_f(s, &s->d_zw, zw, (size_t)K * S * Nz))) return rc;
-  if ((rc = upload_f(s, &s->d_tau_sum, tau_sum, S * (Nz + 1)))) return rc;
+  if (dev_layers) {
+    if ((rc = convert_f(s, &s->d_tau, tau, S * Nz))) return rc;
+    if ((rc = convert_f(s, &s->d_varpi, varpi, S * Nz))) return rc;
+    if ((rc = convert_f(s, &s->d_zw, zw, (size_t)K * S * Nz))) return rc;
+    if ((rc = convert_f(s, &s->d_tau_sum, tau_sum, S * (Nz + 1)))) return rc;
+  } else {
+    if ((rc = upload_f(s, &s->d_tau, tau, S * Nz))) return rc;
+    if ((rc = upload_f(s, &s->d_varpi, varpi, S * Nz))) return rc;
+    if ((rc = upload_f(s, &s->d_zw, zw, (size_t)K * S * Nz))) return rc;
+    if ((rc = upload_f(s, &s->d_tau_sum, tau_sum, S * (Nz + 1)))) return rc;
+  }
   if (N == Nu) {
     if ((rc = upload_f(s, &s->d_Zpp, Zpp, NN * K * M))) return rc;
     if ((rc = upload_f(s, &s->d_Zmp, Zmp, NN * K * M))) return rc;
@@ -406,8 +442,8 @@ int momf_scene_set(momf_scene *s, int Nz, int K, int M, const double *tau, const
   auto sub_fail = [&](int code) { s->err = u->err; return code; };
   if ((rc = momf_set_streams(u, mu0v.data(), wt0v.data(), sg0v.data(), s->q.imu0, s->hd_mu0, s->hd_I0, one, s->q.regular)))
     return sub_fail(rc);
-  if ((rc = momf_scene_set(u, Nz, K, 1, tau, varpi, zw, zp.data(), zm.data(), ndoubl, iface, tau_sum, albedo, nVza, node, cos_mphi,
-                           sin_mphi)))
+  if ((rc = scene_set_impl(u, Nz, K, 1, tau, varpi, zw, zp.data(), zm.data(), ndoubl, iface, tau_sum, albedo, nVza, node, cos_mphi,
+                           sin_mphi, dev_layers)))
     return sub_fail(rc);
   s->m_first = 1;
   return MOM_OK;

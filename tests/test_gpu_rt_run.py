@@ -615,6 +615,27 @@ def test_device_side_optics_bitwise_equals_host_route(rtamd, cref, nS, lt, aer):
     helpers.assert_stokes_close(R1, Rr, what="device optics R vs oracle")
 
 
+@pytest.mark.parametrize("nS,lt,aer", [(3, 9, 0.2), (1, 5, 0.0), (3, 33, 0.2)])
+def test_device_side_optics_on_a_float32_handle(rtamd, nS, lt, aer):
+    """mom_scene_set_optics on a dtype = 1 handle (r6): the layer optics are assembled on the device in Float64 exactly as for a
+    Float64 handle and rounded to the scene's Float32 there -- the same Float32 inputs the host route uploads (its Float64
+    arrays are bitwise the device's), so the spectra of the two Float32 routes are bitwise equal; tau_abs never visits the host."""
+    m = rtamd.scenes.make_scene(nS, lt, 6, 40, seed=3 + nS, aerosol_total=aer)
+    if aer == 0.0:
+        m.τ_rayl[:, 1] = 0.0
+    sc = rtamd.prepare_scene(m)
+    with rtamd.corert.make_handle(m, float_type="Float32") as h:
+        R0, T0 = rtamd.corert.run_scene(h, sc)
+    with rtamd.corert.make_handle(m, float_type="Float32") as h:
+        R1, T1 = rtamd.corert.run_scene_device_optics(h, m)
+        nd, iface, tau, varpi, zw, tau_sum = h.scene_get_layers(sc.Nz, sc.K)
+    assert np.array_equal(nd, sc.ndoubl) and np.array_equal(iface, sc.iface) and np.array_equal(tau, sc.tau)
+    assert np.abs(R0).max() > 0 and np.array_equal(R1, R0) and np.array_equal(T1, T0)
+    R64 = rtamd.rt_run(m)[0]
+    assert np.isfinite(R1).all() and np.abs(R1 - R64).max() > 0    # a Float32 run of this scene, not the Float64 one (its accuracy
+    #                                                                    against the Float32 oracle: test_float32_scene_level_path)
+
+
 def test_voigt_to_spectrum_without_host_tau(rtamd):
     """Line list -> tau_abs (mom_voigt_tau_abs) -> layer optics (mom_scene_set_optics) -> spectrum, with tau_abs
     resident on the GPU throughout; equals the route that downloads tau_abs and feeds it through the host algebra."""
