@@ -369,12 +369,16 @@ int mom_rt_run(mom_t *h);
  *                          Call after mom_scene_set (and mom_scene_set_surface); P = 0 clears them (values only).
  * mom_rt_run_dual          the run; R_SFI / T_SFI are then read with mom_get_RT (they agree with mom_rt_run's to rounding:
  *                          the same statements in a different association), the partials with mom_get_RT_partials.
- *                          Operators larger than 128 x 128 return MOM_EUNSUPPORTED; hdr / bhr are not produced.
- * mom_get_RT_partials      dR_SFI, dT_SFI [nVza, nStokes, nSpec, P] (host). */
+ *                          hdr / bhr_uw / bhr_dw (interaction_hdrf!, postprocessing_vza_hdrf!) come out as well: values through
+ *                          mom_get_hdr, partials through mom_get_hdr_partials.  Operators larger than 128 x 128 return
+ *                          MOM_EUNSUPPORTED.
+ * mom_get_RT_partials      dR_SFI, dT_SFI [nVza, nStokes, nSpec, P] (host).
+ * mom_get_hdr_partials     dhdr [nVza, nStokes, nSpec, P], dbhr_uw, dbhr_dw [nStokes, nSpec, P] (host). */
 int mom_scene_set_partials(mom_t *h, int P, const double *dtau, const double *dvarpi, const double *dzw, const double *dZpp,
                            const double *dZmp, const double *dalbedo, const double *dRsurf, const double *dalbedo_spec);
 int mom_rt_run_dual(mom_t *h);
 int mom_get_RT_partials(mom_t *h, double *dR_SFI, double *dT_SFI);
+int mom_get_hdr_partials(mom_t *h, double *dhdr, double *dbhr_uw, double *dbhr_dw);
 
 /* rt_run_test_ms(RS_type::noRS, sensor_levels, model, iBand) (src/CoreRT/rt_run_multisensor.jl:14-191) for the resident
  * scene: sensors inside the atmosphere.  sensor_levels[ims] = 0 is the TOA/BOA pair (uwJ = R_SFI, dwJ = T_SFI of

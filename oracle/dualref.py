@@ -144,7 +144,7 @@ def _batch_inv_gj(A: np.ndarray) -> np.ndarray:
     return M[:, :, N:]
 
 
-def _run(scene: mr.Scene, L: LayerInputs, p: Optional[Partial], hook=None, extended: bool = False):
+def _run(scene: mr.Scene, L: LayerInputs, p: Optional[Partial], hook=None, extended: bool = False, full: bool = False):
     """rt_run.jl:125-215 on momref's operators with x + i H x' inputs (p = None: the plain real run, float64).
     extended: the same run in x87 extended precision (numpy complex256 / longdouble, 64-bit mantissa) -- the ARBITER of the
     thick-layer comparisons, where two Float64 runs differ by rounding amplified over the doublings."""
@@ -154,13 +154,13 @@ def _run(scene: mr.Scene, L: LayerInputs, p: Optional[Partial], hook=None, exten
         saved = mr.batch_inv
         mr.batch_inv = _batch_inv_gj
         try:
-            return _run_dt(scene, L, p, hook, cplx, dt)
+            return _run_dt(scene, L, p, hook, cplx, dt, full)
         finally:
             mr.batch_inv = saved
-    return _run_dt(scene, L, p, hook, cplx, dt)
+    return _run_dt(scene, L, p, hook, cplx, dt, full)
 
 
-def _run_dt(scene, L, p, hook, cplx, dt):
+def _run_dt(scene, L, p, hook, cplx, dt, full=False):
 
     def pert(x, dx):
         x = np.asarray(x, dtype=dt)
@@ -183,6 +183,9 @@ def _run_dt(scene, L, p, hook, cplx, dt):
     nV = len(scene.vza)
     R_SFI = np.zeros((nV, pol.n, S), dtype=dt)
     T_SFI = np.zeros((nV, pol.n, S), dtype=dt)
+    hdr = np.zeros((nV, pol.n, S), dtype=dt)
+    bhr_uw = np.zeros((pol.n, S), dtype=dt)
+    bhr_dw = np.zeros((pol.n, S), dtype=dt)
 
     def layer(cls):
         z = lambda: np.zeros((S, N, N), dtype=dt)
@@ -216,6 +219,12 @@ def _run_dt(scene, L, p, hook, cplx, dt):
         _surface(scene, kind, Rs[m] if kind == 1 else None, alb, albedo, surf, m, tau_sum[:, -1])
         mr.interaction(L.iface[-1], comp, surf)
         mr.postprocessing_vza(pol, comp, scene.vza, quad.qp_mu, m, scene.vaz, weight, R_SFI, T_SFI)
+        # the RAMI extras (momref.rt_run_full: interaction_hdrf!, postprocessing_vza_hdrf!)
+        hdr_J0m = mr.interaction_hdrf(surf, comp, m, pol, quad, bhr_uw, bhr_dw)
+        dummy = mr.CompositeLayer(None, None, None, None, np.zeros_like(hdr_J0m), hdr_J0m)
+        mr.postprocessing_vza(pol, dummy, scene.vza, quad.qp_mu, m, scene.vaz, weight, hdr, np.zeros_like(hdr))
+    if full:
+        return R_SFI, T_SFI, hdr, bhr_uw, bhr_dw
     return R_SFI, T_SFI
 
 
@@ -232,6 +241,17 @@ def rt_run_dual(scene: mr.Scene, partials: Sequence[Partial], L: Optional[LayerI
         dR[i] = np.asarray(Rc.imag / H, dtype=np.float64)
         dT[i] = np.asarray(Tc.imag / H, dtype=np.float64)
     return R, T, dR, dT
+
+
+def rt_run_dual_full(scene: mr.Scene, partials: Sequence[Partial], L: Optional[LayerInputs] = None):
+    """The reference's whole return tuple on Duals: values (R, T, hdr, bhr_uw, bhr_dw) and their partials (leading axis P)."""
+    L = layer_inputs(scene) if L is None else L
+    vals = [np.asarray(x, dtype=np.float64) for x in _run(scene, L, None, full=True)]
+    ders = [np.zeros((len(partials),) + v.shape) for v in vals]
+    for i, p in enumerate(partials):
+        for d, x in zip(ders, _run(scene, L, p, full=True)):
+            d[i] = x.imag / H
+    return vals, ders
 
 
 def rt_run_values(scene: mr.Scene, L: LayerInputs):

@@ -99,6 +99,7 @@ SIGNATURES = {
     "mom_scene_set_partials": (C.c_int, [c_h, C.c_int] + [c_dp] * 8),
     "mom_rt_run_dual": (C.c_int, [c_h]),
     "mom_get_RT_partials": (C.c_int, [c_h, c_dp, c_dp]),
+    "mom_get_hdr_partials": (C.c_int, [c_h, c_dp, c_dp, c_dp]),
     "mom_rt_run_multisensor": (C.c_int, [c_h, C.c_int, c_ip, c_dp, c_dp]),
     "mom_get_RT": (C.c_int, [c_h, c_dp, c_dp]),
     "mom_get_hdr": (C.c_int, [c_h, c_dp, c_dp, c_dp]),
@@ -481,6 +482,15 @@ class Handle:
         self.check(self.lib.mom_get_RT_partials(self._h, dp(dR), dp(dT)))
         shp = (P, self.S, self.nS, self.nVza)
         return np.transpose(dR.reshape(shp), (0, 3, 2, 1)).copy(), np.transpose(dT.reshape(shp), (0, 3, 2, 1)).copy()
+
+    def get_hdr_partials(self):
+        """dhdr [P, nVza, nStokes, S], dbhr_uw, dbhr_dw [P, nStokes, S]."""
+        P = self.dual_P
+        n, f = self.nVza * self.nS * self.S * P, self.nS * self.S * P
+        dH, up, dw = np.empty(n), np.empty(f), np.empty(f)
+        self.check(self.lib.mom_get_hdr_partials(self._h, dp(dH), dp(up), dp(dw)))
+        tr = lambda x: np.transpose(x.reshape(P, self.S, self.nS), (0, 2, 1)).copy()
+        return np.transpose(dH.reshape(P, self.S, self.nS, self.nVza), (0, 3, 2, 1)).copy(), tr(up), tr(dw)
 
     def rt_run_multisensor(self, sensor_levels):
         """uwJ, dwJ as numpy [nSensors, nVza, nStokes, S] (the reference's vector of [nVza, nStokes, nSpec] arrays,

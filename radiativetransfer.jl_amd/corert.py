@@ -760,9 +760,10 @@ def scene_set_partials(h: _lib.Handle, sc: SceneInputs, partials: Sequence[Scene
         dalbedo_spec=pack(lambda p: p.dalbedo_spec, lambda a: a.reshape(-1)) if sc.surf_kind == 2 else None)
 
 
-def rt_run_dual(model: vSmartMOM_Model, partials: Sequence[ScenePartial], workspace_mb: int = 0):
+def rt_run_dual(model: vSmartMOM_Model, partials: Sequence[ScenePartial], workspace_mb: int = 0, full: bool = False):
     """rt_run on ForwardDiff.Dual inputs (rt_run.jl:41-230 with FT_dual element types): returns
-    (R_SFI, T_SFI [nVza, nStokes, nSpec], dR_SFI, dT_SFI [P, nVza, nStokes, nSpec])."""
+    (R_SFI, T_SFI [nVza, nStokes, nSpec], dR_SFI, dT_SFI [P, nVza, nStokes, nSpec]); full = True: the rest of the reference's
+    tuple as well -- ((R, T, hdr, bhr_uw, bhr_dw), (dR, dT, dhdr, dbhr_uw, dbhr_dw)), bhr_* [nStokes, nSpec]."""
     sc = prepare_scene(model)
     with make_handle(model) as h:
         if workspace_mb:
@@ -774,6 +775,10 @@ def rt_run_dual(model: vSmartMOM_Model, partials: Sequence[ScenePartial], worksp
         if len(partials) == 0:
             return R, T, np.zeros((0,) + R.shape), np.zeros((0,) + T.shape)
         dR, dT = h.get_RT_partials()
+        if full:
+            hdr, up, dw = h.get_hdr()
+            dhdr, dup, ddw = h.get_hdr_partials()
+            return (R, T, hdr, up, dw), (dR, dT, dhdr, dup, ddw)
     return R, T, dR, dT
 
 

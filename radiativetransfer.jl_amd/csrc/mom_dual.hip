@@ -951,8 +951,9 @@ struct PostArgs {
   int N, nS, U, P, S, nVza, m, M;
   size_t u0;
   const int *node;
-  const double *cos_mphi, *sin_mphi, *J0p, *J0m;
+  const double *cos_mphi, *sin_mphi, *J0p, *J0m, *hdrJ;   // hdrJ: r-+_surf J0+ + j0-_surf (interaction_hdrf!, interaction_hdrf.jl:9-45)
   double *R, *T, *dR, *dT;  // [nVza,nS,S], [nVza,nS,S,P]
+  double *hdr, *dhdr;       // postprocessing_vza_hdrf! (postprocessing_vza.jl:63-93)
 };
 __global__ void k_dpost(PostArgs a) {
   const size_t per = (size_t)a.nVza * a.nS, total = per * a.U * (a.P + 1);
@@ -965,8 +966,36 @@ __global__ void k_dpost(PostArgs a) {
   const size_t row = (size_t)(a.node[v] - 1) * a.nS + k, o = (c * a.U + u) * a.N + row;
   const size_t out = v + (size_t)a.nVza * (k + (size_t)a.nS * (a.u0 + u));
   double *R = (c == 0) ? a.R : a.dR + per * a.S * (c - 1), *T = (c == 0) ? a.T : a.dT + per * a.S * (c - 1);
-  if (a.m == 0) { R[out] = cs * a.J0m[o]; T[out] = cs * a.J0p[o]; }
-  else { R[out] += cs * a.J0m[o]; T[out] += cs * a.J0p[o]; }
+  double *H = (c == 0) ? a.hdr : a.dhdr + per * a.S * (c - 1);
+  if (a.m == 0) { R[out] = cs * a.J0m[o]; T[out] = cs * a.J0p[o]; H[out] = cs * a.hdrJ[o]; }
+  else { R[out] += cs * a.J0m[o]; T[out] += cs * a.J0p[o]; H[out] += cs * a.hdrJ[o]; }
+}
+
+// the up- and down-welling flux sums of the BHR (interaction_hdrf.jl:27-41, m = 0) on Duals: one thread per (unit, component, Stokes i)
+struct BhrArgs {
+  int N, nS, U, P, S, imu0;
+  size_t u0;
+  const double *mu, *wt, *hdrJ, *J0p, *surf_j0p;
+  double *uw, *dw, *duw, *ddw;   // [nS,S], [nS,S,P]
+};
+__global__ void k_dbhr(BhrArgs a) {
+  const size_t total = (size_t)a.nS * a.U * (a.P + 1);
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int i = (int)(idx % a.nS);
+  const size_t u = (idx / a.nS) % a.U, c = idx / ((size_t)a.nS * a.U);
+  const size_t o = (c * a.U + u) * a.N;
+  double up = 0.0, dn = 0.0;
+  for (int r = i; r < a.N; r += a.nS) {
+    const double wq = a.wt[r] * a.mu[r];
+    up += a.hdrJ[o + r] * wq;
+    dn += a.J0p[o + r] * wq;
+  }
+  const int i0 = a.nS * (a.imu0 - 1);
+  dn += a.surf_j0p[o + i0] * a.mu[i0];   // the direct beam: component 0 of the sun block for every i, as written (:38-40)
+  const size_t out = i + (size_t)a.nS * (a.u0 + u);
+  if (c == 0) { a.uw[out] = up; a.dw[out] = dn; }
+  else { a.duw[out + (size_t)a.nS * a.S * (c - 1)] = up; a.ddw[out + (size_t)a.nS * a.S * (c - 1)] = dn; }
 }
 
 }  // namespace momd
@@ -1183,7 +1212,14 @@ int momd_run(const MomDualScene &sc, std::string *err) {
       sa.r_mp = ad.r_mp; sa.t_pp = ad.t_pp; sa.r_pm = ad.r_pm; sa.t_mm = ad.t_mm; sa.j0p = ad.jp; sa.j0m = ad.jm;
       hipLaunchKernelGGL(k_dsurface, dim3(eblocks), dim3(256), 0, st, sa);
       interaction(sc.iface[Nz - 1]);  // rt_run.jl:198-200: the LAST layer's interface code
-      PostArgs pa{N, sc.nS, U, P, sc.S, sc.nVza, m, sc.M, u0, sc.node, sc.cos_mphi, sc.sin_mphi, co.Jp, co.Jm, sc.R, sc.T, sc.dR, sc.dT};
+      matvec(ad.r_mp, 1, co.Jp, ad.jm, va, nullptr, nullptr, nullptr);   // hdr_J0- = r-+_surf J0+ + j0-_surf (interaction_hdrf.jl:20-24)
+      if (m == 0) {
+        BhrArgs ba{N, sc.nS, U, P, sc.S, sc.imu0, u0, sc.mu, sc.wt, va, co.Jp, ad.jp, sc.bhr_uw, sc.bhr_dw, sc.dbhr_uw, sc.dbhr_dw};
+        const size_t nb_ = (size_t)sc.nS * U * (P + 1);
+        hipLaunchKernelGGL(k_dbhr, dim3((unsigned)((nb_ + 255) / 256)), dim3(256), 0, st, ba);
+      }
+      PostArgs pa{N, sc.nS, U, P, sc.S, sc.nVza, m, sc.M, u0, sc.node, sc.cos_mphi, sc.sin_mphi, co.Jp, co.Jm, va, sc.R, sc.T, sc.dR, sc.dT,
+                  sc.hdr, sc.dhdr};
       const size_t tot = (size_t)sc.nVza * sc.nS * U * (P + 1);
       hipLaunchKernelGGL(k_dpost, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, pa);
     }

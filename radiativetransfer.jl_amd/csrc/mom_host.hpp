@@ -59,6 +59,7 @@ struct MomDualScene {
   const int *node;                                         // [nVza]
   const double *cos_mphi, *sin_mphi;                       // [nVza,M]
   double *R, *T, *dR, *dT;                                 // [nVza,nS,S], [nVza,nS,S,P]
+  double *hdr, *dhdr, *bhr_uw, *bhr_dw, *dbhr_uw, *dbhr_dw; // [nVza,nS,S](,P); [nS,S](,P)
   double *dtau_sum_buf;                                    // [S,Nz+1,P] scratch
   int *info;
   hipStream_t stream;

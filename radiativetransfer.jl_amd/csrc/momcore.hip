@@ -1901,7 +1901,7 @@ extern "C" int mom_scene_set_partials(mom_t *h, int P, const double *dtau, const
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
   if (dalbedo_spec && h->surf_kind == 2 && (rc = upload_new(h, &h->d_dual_in[7], dalbedo_spec, S * P))) return rc;
-  HIPCHK(h, dmalloc(&h->d_dual_out, 2 * (size_t)h->nVza * h->nS * S * P));
+  HIPCHK(h, dmalloc(&h->d_dual_out, (3 * (size_t)h->nVza + 2) * h->nS * S * P));   // dR | dT | dhdr | dbhr_uw | dbhr_dw
   HIPCHK(h, dmalloc(&h->d_dual_ts, S * (Nz + 1) * P));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return MOM_OK;
@@ -1926,6 +1926,10 @@ extern "C" int mom_rt_run_dual(mom_t *h) {
   sc.nd = h->nd.data(); sc.iface = h->iface.data(); sc.node = h->d_node; sc.cos_mphi = h->d_cos; sc.sin_mphi = h->d_sin;
   const size_t out = (size_t)h->nVza * h->nS * h->S;
   sc.R = h->d_R; sc.T = h->d_T; sc.dR = h->d_dual_out; sc.dT = h->d_dual_out ? h->d_dual_out + out * h->dual_P : nullptr;
+  sc.hdr = h->d_hdr; sc.bhr_uw = h->d_bhr_uw; sc.bhr_dw = h->d_bhr_dw;
+  sc.dhdr = h->d_dual_out ? h->d_dual_out + 2 * out * h->dual_P : nullptr;
+  sc.dbhr_uw = h->d_dual_out ? h->d_dual_out + 3 * out * h->dual_P : nullptr;
+  sc.dbhr_dw = sc.dbhr_uw ? sc.dbhr_uw + (size_t)h->nS * h->S * h->dual_P : nullptr;
   sc.dtau_sum_buf = h->d_dual_ts; sc.info = h->d_info; sc.stream = h->stream;
   sc.work = &h->dual_work; sc.work_cap = &h->dual_work_cap;
   size_t budget = h->opt_dual_budget;
@@ -1960,6 +1964,18 @@ extern "C" int mom_get_RT_partials(mom_t *h, double *dR_SFI, double *dT_SFI) {
   return check_info(h);
 }
 
+extern "C" int mom_get_hdr_partials(mom_t *h, double *dhdr, double *dbhr_uw, double *dbhr_dw) {
+  if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
+  if (!h->dual_ran || h->dual_P == 0 || !dhdr || !dbhr_uw || !dbhr_dw)
+    return fail(h, MOM_ESTATE, "mom_get_hdr_partials: no Dual run with P > 0 / null output");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t out = (size_t)h->nVza * h->nS * h->S * h->dual_P, fl = (size_t)h->nS * h->S * h->dual_P;
+  HIPCHK(h, hipMemcpyAsync(dhdr, h->d_dual_out + 2 * out, out * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dbhr_uw, h->d_dual_out + 3 * out, fl * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(dbhr_dw, h->d_dual_out + 3 * out + fl, fl * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return check_info(h);
+}
+
 extern "C" int mom_get_RT(mom_t *h, double *R_SFI, double *T_SFI) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   if (!h->scene_set || !R_SFI || !T_SFI) return fail(h, MOM_ESTATE, "mom_get_RT: no scene / null output");
@@ -1977,7 +1993,6 @@ extern "C" int mom_get_RT(mom_t *h, double *R_SFI, double *T_SFI) {
 extern "C" int mom_get_hdr(mom_t *h, double *hdr, double *bhr_uw, double *bhr_dw) {
   if (!h) return fail(nullptr, MOM_EINVAL, "null handle");
   if (!h->scene_set || !hdr || !bhr_uw || !bhr_dw) return fail(h, MOM_ESTATE, "mom_get_hdr: no scene / null output");
-  if (h->dual_last) return fail(h, MOM_ESTATE, "mom_get_hdr: the last run was mom_rt_run_dual, which does not produce hdr / bhr (run mom_rt_run)");
   HIPCHK(h, hipSetDevice(h->device));
   if (h->f32) {
     const int rc = momf_get_hdr(h->f32, hdr, bhr_uw, bhr_dw);

@@ -152,12 +152,10 @@ def test_dual_errors():
             h.scene_set_partials(1, dZpp=np.zeros(sc.Zpp.size))   # dZpp without dZmp
         with pytest.raises(rtamd.MomError):
             h.get_RT_partials()                  # no Dual run yet
-        h.scene_set_partials(1, dalbedo=np.ones(1))
+        h.scene_set_partials(0)
         h.rt_run_dual()
         with pytest.raises(rtamd.MomError):
-            h.get_hdr()                          # the Dual run does not produce hdr / bhr: no stale values handed out
-        h.rt_run()
-        h.get_hdr()
+            h.get_hdr_partials()                 # a run without partials
 
 
 def test_dual_C2_operator_shape():
@@ -165,3 +163,29 @@ def test_dual_C2_operator_shape():
     m = rtamd.scenes.make_scene(3, 33, 6, 2, seed=21, aerosol_total=0.3)
     assert m.quad_points.qp_μN.size == 60
     compare(m, P=1, seed=7)
+
+
+@pytest.mark.parametrize("surface", [None, "rpv", "legendre"])
+def test_dual_hdr_and_bhr(surface):
+    """The rest of the reference's return tuple on Duals: hdr (postprocessing_vza_hdrf!) and the BHR flux sums (interaction_hdrf!)."""
+    m = rtamd.scenes.make_scene(3, 5, 3, 6, seed=5, albedo=0.3)
+    if surface == "rpv":
+        m.params.brdf = rtamd.corert.rpvSurfaceScalar(0.1, -0.1, 0.8, 0.05)
+    elif surface == "legendre":
+        m.params.brdf = rtamd.corert.LambertianSurfaceLegendre((0.3, 0.05, -0.02))
+    sc = helpers.oracle_scene(m)
+    L = dr.layer_inputs(sc)
+    ps = random_partials(L, 2, seed=3, kind=L.surf[0])
+    vals, ders = rtamd.rt_run_dual(m, [to_host(p) for p in ps], full=True)
+    vo, do = dr.rt_run_dual_full(sc, ps, L)
+    hdr_v = rtamd.rt_run(m)[4]
+    helpers.assert_stokes_close(vals[2], hdr_v, what="dual hdr vs mom_rt_run")
+    for k, name in enumerate(("R", "T", "hdr")):
+        helpers.assert_stokes_close(vals[k], vo[k], what="dual " + name)
+        for i in range(2):
+            assert_partial_close(ders[k][i], do[k][i], helpers.RTOL_STOKES, f"d{name}[{i}]")
+    for k, name in ((3, "bhr_uw"), (4, "bhr_dw")):
+        assert np.abs(vo[k]).max() > 0
+        assert np.abs(vals[k] - vo[k]).max() <= 1e-10 * np.abs(vo[k]).max(), name
+        for i in range(2):
+            assert np.abs(ders[k][i] - do[k][i]).max() <= 1e-10 * np.abs(do[k][i]).max(), name
