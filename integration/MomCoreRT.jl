@@ -136,8 +136,13 @@ function rt_run_dual(RS_type::noRS, model::vSmartMOM_Model, iBand, arch::MI355X,
         R = zeros(nV, pol.n, nSpec);  Tr = similar(R);  dR = zeros(nV, pol.n, nSpec, P);  dT = similar(dR)
         MomCore.mom_get_RT!(h.ptr, R, Tr)
         MomCore.mom_get_RT_partials!(h.ptr, dR, dT)
+        hdr = similar(R);  uw = zeros(pol.n, nSpec);  dw = similar(uw)                     # the RAMI extras of rt_run.jl:91-94
+        dhdr = similar(dR);  duw = zeros(pol.n, nSpec, P);  ddw = similar(duw)
+        MomCore.mom_get_hdr!(h.ptr, hdr, uw, dw)
+        MomCore.mom_get_hdr_partials!(h.ptr, dhdr, duw, ddw)
         mk(X, dX) = [D(X[i], ForwardDiff.Partials(ntuple(p -> dX[i, p], P))) for i in CartesianIndices(X)]
-        return mk(R, dR), mk(Tr, dT)
+        Rd, Td = mk(R, dR), mk(Tr, dT)
+        return Rd, Td, zero(Rd), zero(Rd), mk(hdr, dhdr), mk(uw, duw)[1, :], mk(dw, ddw)[1, :]   # the 7-tuple of rt_run.jl:226
     finally
         close(h)
     end
