@@ -568,7 +568,25 @@ def f32_leg(dev, S=20_000, n_streams=8, nd=5, steps=3):
                          "algorithmic_flop_per_avg_launch": flop}}
 
 
-def dual_leg(dev, S=2000, P=3):
+def dual_cpu_baseline(P, budget_s=20.0):
+    """The Dual run of the numpy oracle (oracle/dualref.py: complex-step run of the restatement, one run per partial) on a
+    bounded sample of the same shape: 2 spectral points, the value run + ONE partial timed, scaled to P partials."""
+    import rtamd
+    sys.path.insert(0, str(ROOT / "tests"))
+    import helpers
+    from oracle import dualref as dr
+    m = rtamd.scenes.scene_C2(S=2)
+    sc = helpers.oracle_scene(m)
+    L = dr.layer_inputs(sc)
+    p = dr.Partial(dtau=L.tau.copy(), dvarpi=0.1 * L.varpi, dzw=L.zw.copy(), dalbedo=1.0)
+    t0 = time.perf_counter(); dr._run(sc, L, None); tv = time.perf_counter() - t0
+    t0 = time.perf_counter(); dr._run(sc, L, p); tp = time.perf_counter() - t0
+    return {"value": 2.0 / (tv + P * tp), "unit": "spectral points/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"2 spectral points of the same scene: value run {tv:.2f} s + one complex-step partial {tp:.2f} s on numpy (threaded BLAS), "
+                      f"scaled to {P} partials"}
+
+
+def dual_leg(dev, S=2000, P=3, with_cpu=True):
     """rt_run on ForwardDiff.Dual numbers (mom_rt_run_dual) on the BASELINE scene's shape (C2: IQU, N = 60, 40 layers, M = 3) with P
     partials, next to the value run of the same scene: whole runs incl. surface and post-processing.  The Dual run streams its
     operators (values + partials) through HBM in batched MFMA products (csrc/mom_dual.hip); its model is (1 + 2 P) value runs."""
@@ -595,7 +613,7 @@ def dual_leg(dev, S=2000, P=3):
     return {"metric": "rt_run on Dual numbers (values + P partials), C2 operator shape", "value": S / td, "unit": "spectral points/s",
             "dtype": "f64", "ms_per_run": td * 1e3, "value_run_ms": tv * 1e3, "ratio_to_value_run": td / tv, "ideal_ratio": 1 + 2 * P,
             "config": {"workload": f"C2 shape: N = {N}, Nz = {Nz}, M = {M}, S = {S}, P = {P} partials (tau, varpi, phase weights, albedo)"},
-            "finite": bool(np.isfinite(dR).all()),
+            "finite": bool(np.isfinite(dR).all()), "cpu_baseline": dual_cpu_baseline(P) if with_cpu else None,
             "roofline": {"bound": "mfma", "achieved": flop / td / 1e12, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": flop / td / 1e12 / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
                          "note": "product flops of the tangent-linear sweep (2 N^3 per term-product) over the whole run; SQ counters: "
@@ -686,7 +704,7 @@ def main():
                 except Exception as e:
                     extra["f32"] = {"error": repr(e)}
                 try:
-                    extra["dual"] = dual_leg(dev)
+                    extra["dual"] = dual_leg(dev, with_cpu=not a.no_cpu_baseline)
                 except Exception as e:
                     extra["dual"] = {"error": repr(e)}
             if extra:

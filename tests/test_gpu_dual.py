@@ -189,3 +189,22 @@ def test_dual_hdr_and_bhr(surface):
         assert np.abs(vals[k] - vo[k]).max() <= 1e-10 * np.abs(vo[k]).max(), name
         for i in range(2):
             assert np.abs(ders[k][i] - do[k][i]).max() <= 1e-10 * np.abs(do[k][i]).max(), name
+
+
+def test_dual_on_a_device_optics_scene():
+    """The partials attach to a scene whose layer optics were assembled on the device (mom_scene_set_optics): its tau / varpi / zw
+    are bitwise the host route's, so the Dual run is bitwise the one on the host-prepared scene."""
+    m = rtamd.scenes.make_scene(3, 5, 4, 8, seed=3, aerosol_total=0.2)
+    sc = rtamd.prepare_scene(m)
+    L = dr.layer_inputs(helpers.oracle_scene(m))
+    ps = [to_host(p) for p in random_partials(L, 2, seed=5)]
+    R0, T0, dR0, dT0 = rtamd.rt_run_dual(m, ps)
+    with rtamd.corert.make_handle(m) as h:
+        rtamd.corert.run_scene_device_optics(h, m)
+        rtamd.corert.scene_set_partials(h, sc, ps)
+        h.rt_run_dual()
+        R1, T1 = h.get_RT()
+        dR1, dT1 = h.get_RT_partials()
+    assert np.abs(dR0).max() > 0
+    for x, y in ((R0, R1), (T0, T1), (dR0, dR1), (dT0, dT1)):
+        assert np.array_equal(x, y)
