@@ -101,3 +101,26 @@ def rt_run_sharded(scene, run_local: Callable, dist, device=None):
     out = out.cpu().numpy().reshape((world,) + tuple(buf.shape))  # [world, 2, per, nS, nV]
     full = out.transpose(1, 0, 2, 3, 4).reshape(2, world * per, nS, nV)[:, : scene.S]
     return full[0].transpose(2, 1, 0).copy(), full[1].transpose(2, 1, 0).copy()
+
+
+def slice_partials(partials, lo: int, hi: int):
+    """The spectral slice [lo, hi) of a list of corert.ScenePartial (per-point arrays cut along the spectral axis; the partials of
+    the phase-matrix bases, of the scalar albedo and of the BRDF matrices are the same for every point)."""
+    from dataclasses import replace
+    cut = lambda a, ax: None if a is None else np.ascontiguousarray(np.take(np.asarray(a), range(lo, hi), axis=ax))
+    return [replace(p, dτ=cut(p.dτ, 0), dϖ=cut(p.dϖ, 0), dzw=cut(p.dzw, 1), dalbedo_spec=cut(p.dalbedo_spec, 0)) for p in partials]
+
+
+def rt_run_dual_sharded(scene, partials, run_local: Callable, dist, device=None):
+    """rt_run on Dual numbers over the ranks of a node: every spectral point and each of its partials is independent, so rank r
+    runs `run_local(shard, partials_of_the_shard) -> (R, T, dR, dT)` on its slice ([nVza, nStokes, S_loc] and [P, nVza, nStokes,
+    S_loc]; ndoubl / interface codes stay the global ones of `scene`) and ONE all-gather (gather_spectra) assembles the four
+    arrays on every rank."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_bounds(scene.S, world, rank)
+    nV, nS, P = len(scene.node), scene.nStokes, len(partials)
+    if hi > lo:
+        loc = list(run_local(scene.spectral_slice(lo, hi), slice_partials(partials, lo, hi)))
+    else:
+        loc = [np.zeros((nV, nS, 0)), np.zeros((nV, nS, 0)), np.zeros((P, nV, nS, 0)), np.zeros((P, nV, nS, 0))]
+    return tuple(gather_spectra(loc, scene.S, dist, device))

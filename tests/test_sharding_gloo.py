@@ -201,3 +201,73 @@ def test_rrs_windows_and_gather_over_gloo(S, world):
     assert np.abs(ref[2]).max() > 0
     for k in range(4):
         assert np.array_equal(full[k], ref[k]), k
+
+
+def _dual_worker(rank, world, port, S, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+    import rtamd
+    import helpers
+    from oracle import dualref as dr
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model, sc, parts, host = _dual_case(rtamd, helpers, dr, S)
+    scene = rtamd.prepare_scene(model)
+    L_full = dr.layer_inputs(sc)
+
+    def run_local(shard, shard_parts):
+        # the Dual oracle on this rank's points, with the GLOBAL ndoubl / interface codes of the unsharded scene
+        lo, hi = rtamd.sharding.shard_bounds(scene.S, world, rank)
+        assert np.array_equal(shard.ndoubl, scene.ndoubl) and shard.S == hi - lo and shard_parts[0].dτ.shape[0] == hi - lo
+        from dataclasses import replace
+        Ls = replace(L_full, tau=L_full.tau[lo:hi], varpi=L_full.varpi[lo:hi], zw=L_full.zw[:, lo:hi])
+        scs = replace(sc, tau_rayl=sc.tau_rayl[lo:hi], tau_abs=sc.tau_abs[lo:hi])
+        ps = [dr.Partial(dtau=p.dτ, dvarpi=p.dϖ, dzw=p.dzw, dalbedo=p.dalbedo) for p in shard_parts]
+        return dr.rt_run_dual(scs, ps, Ls)
+
+    out = rtamd.sharding.rt_run_dual_sharded(scene, host, run_local, dist)
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _dual_case(rtamd, helpers, dr, S):
+    model = rtamd.scenes.make_scene(3, 5, 3, S, seed=17, aerosol_total=0.1)
+    sc = helpers.oracle_scene(model)
+    L = dr.layer_inputs(sc)
+    rng = np.random.default_rng(4)
+    parts = [dr.Partial(dtau=L.tau * rng.uniform(-1, 1, L.tau.shape), dvarpi=0.1 * L.varpi, dzw=L.zw * rng.uniform(-1, 1, L.zw.shape),
+                        dalbedo=float(i + 1)) for i in range(2)]
+    host = [rtamd.ScenePartial(dτ=p.dtau, dϖ=p.dvarpi, dzw=p.dzw, dalbedo=p.dalbedo) for p in parts]
+    return model, sc, parts, host
+
+
+@pytest.mark.parametrize("S,world", [(9, 2), (13, 8)])
+def test_dual_run_sharded_over_gloo(S, world):
+    """rt_run on Dual numbers sharded over 2 and 8 processes (sharding.rt_run_dual_sharded: values and partials of a spectral point
+    are independent of every other point; one all-gather of the four arrays), the Dual oracle standing in for the GPU: bitwise
+    the single-process run."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, str(ROOT / "tests"))
+    import rtamd
+    import helpers
+    from oracle import dualref as dr
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dual_worker, args=(r, world, port, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model, sc, parts, host = _dual_case(rtamd, helpers, dr, S)
+    ref = dr.rt_run_dual(sc, parts)
+    assert np.abs(ref[2]).max() > 0
+    for a, b in zip(out, ref):
+        assert np.array_equal(a, b)
