@@ -50,8 +50,33 @@ struct GemmArgs {
   double *y[2];
 };
 
+#ifdef MOMD_STAMPS
+// diagnostic build only (tools/dgemm_stamps.py; never part of the shipped library): s_memtime deltas of the sections of a (term, K chunk)
+// phase, wave 0 of one workgroup in the middle of every launch
+__device__ unsigned long long momd_stamp_acc[8];
+#define MOMD_STAMP(id)                                                          \
+  do {                                                                          \
+    if (stamp_on) {                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                        \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();             \
+      if (threadIdx.x == 0) atomicAdd(&momd_stamp_acc[id], now_ - stamp_last);  \
+      stamp_last = now_;                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                        \
+    }                                                                           \
+  } while (0)
+extern "C" void momd_stamps_read(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(momd_stamp_acc), sizeof(momd_stamp_acc));
+  if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(momd_stamp_acc), z, sizeof(z)); }
+}
+#else
+#define MOMD_STAMP(id)
+#endif
 template <bool VEC2, bool RIDE>
 __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
+#ifdef MOMD_STAMPS
+  const bool stamp_on = (blockIdx.x == gridDim.x / 2) && (threadIdx.x < 64);
+  unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
   __shared__ __attribute__((aligned(16))) double As[KC * LDA];  // As[i + k LDA]
   __shared__ __attribute__((aligned(16))) double Bs[TN * LDB];  // Bs[k + j LDB]
   typedef double d2 __attribute__((ext_vector_type(2)));
@@ -138,11 +163,16 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
     }
   };
   gload(0);
+  MOMD_STAMP(0);   // start-up: argument loads, index arithmetic, the first loads going out
   for (int ph = 0; ph < nph; ++ph) {
     __syncthreads();
+    MOMD_STAMP(1); // barrier at the top of a phase
     sstore();
+    MOMD_STAMP(2); // wait for this phase's global loads + the LDS stores
     __syncthreads();
+    MOMD_STAMP(3); // barrier after the stores
     if (ph + 1 < nph) gload(ph + 1);
+    MOMD_STAMP(4); // issue of the next phase's loads
     const int kmax = min(KC, N - (ph >= nch ? ph - nch : ph) * KC);
     // the product transposed on the matrix core (rows of the MFMA tile = columns j of C, columns = rows i): the 16 lanes of a
     // quarter-wave then hold 16 consecutive rows of one column of C, so the stores of the epilogue are 128-byte segments
@@ -154,7 +184,9 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
         acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc[tb], 0, 0, 0);
       }
     }
+    MOMD_STAMP(5); // the chunk's k-steps: LDS operand reads + MFMAs
   }
+  MOMD_STAMP(6);   // drain
   double *C = a.C + c * CS + uo;
   const double *E = a.E ? a.E + c * CS + uo : nullptr;
 #pragma unroll
