@@ -77,8 +77,8 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
   const bool stamp_on = (blockIdx.x == gridDim.x / 2) && (threadIdx.x < 64);
   unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
-  __shared__ __attribute__((aligned(16))) double As[KC * LDA];  // As[i + k LDA]
-  __shared__ __attribute__((aligned(16))) double Bs[TN * LDB];  // Bs[k + j LDB]
+  __shared__ __attribute__((aligned(16))) double smem[KC * LDA + TN * LDB];
+  double *As = smem, *Bs = smem + KC * LDA;   // As[i + k LDA], Bs[k + j LDB]; the epilogue reuses the space as Ct[i + j LDA]
   typedef double d2 __attribute__((ext_vector_type(2)));
   const int N = a.N;
   const size_t NN = (size_t)N * N, CS = (size_t)a.U * NN;
@@ -187,25 +187,55 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
     MOMD_STAMP(5); // the chunk's k-steps: LDS operand reads + MFMAs
   }
   MOMD_STAMP(6);   // drain
-  double *C = a.C + c * CS + uo;
-  const double *E = a.E ? a.E + c * CS + uo : nullptr;
+  // Epilogue through LDS: the accumulators hold 16-row runs of scattered columns (128-byte pieces that straddle the 128-byte lines of a
+  // 60-row column); written from there, the stores were the largest single cost of the kernel (the run without this kernel's MFMAs
+  // is 9 % shorter, without its global loads 17 %; profiles/r06_dual_ab.txt).  Staged as the tile Ct[i + j LDA], the result leaves in
+  // 16-byte pieces along the contiguous axis -- whole lines -- and the E operand is read the same way.
+  __syncthreads();
+  double *Ct = smem;
 #pragma unroll
   for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int gj = j0 + 16 * w + lq + 4 * r, gi = i0 + 16 * tb + lr;
+    for (int r = 0; r < 4; ++r) Ct[(16 * tb + lr) + (16 * w + lq + 4 * r) * LDA] = acc[tb][r];
+  __syncthreads();
+  double *C = a.C + c * CS + uo;
+  const double *E = a.E ? a.E + c * CS + uo : nullptr;
+  if (VEC2) {
+    const int i = 2 * (t & 31), gi = i0 + i;
+    for (int j = t >> 5; j < TN; j += 8) {
+      const int gj = j0 + j;
       if (gi < N && gj < N) {
         const size_t o = gi + (size_t)gj * N;
-        double v = a.alpha * acc[tb][r];
+        d2 v = *(const d2 *)(Ct + i + j * LDA);
+        v = v * a.alpha;
+        if (E) v += a.beta * *(const d2 *)(E + o);
+        if (c == 0) { if (gi == gj) v[0] += a.eye; if (gi + 1 == gj) v[1] += a.eye; }
+        *(d2 *)(C + o) = v;
+      } else if (RIDE && gi < N && gj >= N && gj - N < nq) {
+        const double *ad = (gj == N) ? a.add[0] : a.add[1];
+        double *y = (gj == N) ? a.y[0] : a.y[1];
+        d2 v = *(const d2 *)(Ct + i + j * LDA);
+        if (ad) v += *(const d2 *)(ad + voc + gi);
+        *(d2 *)(y + voc + gi) = v;
+      }
+    }
+  } else {
+    const int i = t & 63, gi = i0 + i;
+    for (int j = t >> 6; j < TN; j += 4) {
+      const int gj = j0 + j;
+      if (gi < N && gj < N) {
+        const size_t o = gi + (size_t)gj * N;
+        double v = a.alpha * Ct[i + j * LDA];
         if (E) v += a.beta * E[o];
         if (c == 0 && gi == gj) v += a.eye;
         C[o] = v;
-      } else if (RIDE && gi < N && gj - N < nq) {
+      } else if (RIDE && gi < N && gj >= N && gj - N < nq) {
         const double *ad = (gj == N) ? a.add[0] : a.add[1];
         double *y = (gj == N) ? a.y[0] : a.y[1];
-        y[voc + gi] = (ad ? ad[voc + gi] : 0.0) + acc[tb][r];
+        y[voc + gi] = (ad ? ad[voc + gi] : 0.0) + Ct[i + j * LDA];
       }
     }
+  }
 }
 
 // The same product for operators of edge N + nq <= 16 NT (NT = 1, 2, 3): ONE WAVEFRONT per (unit, component), operands read straight
