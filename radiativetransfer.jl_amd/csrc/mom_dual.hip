@@ -32,7 +32,8 @@ namespace momd {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int TM = 64, TN = 64, KC = 32, LDA = TM + 2, LDB = KC + 2;
+constexpr int TM = 64, TN = 64, KC = 16, LDA = TM + 2, LDB = KC + 2;   // K chunks of 16: 17.7 KB of LDS per workgroup
+constexpr int NQA = TM * KC / 512;   // 16-byte pieces of a staged tile per thread (A and B alike: TM = TN)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // C_c = alpha * prod_c + beta * E_c + eye * (c == 0) I          mode 0: Dual product rule, 1: A0 Bc, 2: Ac B0
@@ -108,8 +109,8 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
   const double *x0p = RIDE ? a.x[0] : nullptr, *x1p = (RIDE && nq > 1) ? a.x[1] : nullptr;
   const int nch = (N + KC - 1) / KC, nph = nterms * nch;
   // the next (term, K chunk) is fetched into registers while the matrix cores work on the current one
-  d2 ra[4], rb[4];
-  double sa[8], sb[8];
+  d2 ra[NQA], rb[NQA];
+  double sa[2 * NQA], sb[2 * NQA];
   auto gload = [&](int ph) {
     const bool t1 = ph >= nch;
     const double *Ag = t1 ? A0 : TA0, *Bg = t1 ? Bc : TB0;
@@ -117,11 +118,11 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
     const int k0 = (t1 ? ph - nch : ph) * KC;
     if (VEC2) {  // N even: pairs along the contiguous axis are 16-byte aligned and never straddle the edge
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NQA; ++q) {
         const int e = t + 256 * q;
         { const int i = 2 * (e & 31), k = e >> 5, gi = i0 + i, gk = k0 + k;
           ra[q] = (gi < N && gk < N) ? *(const d2 *)(Ag + gi + (size_t)gk * N) : d2{0.0, 0.0}; }
-        { const int k = 2 * (e & 15), j = e >> 4, gk = k0 + k, gj = j0 + j;
+        { const int k = 2 * (e % (KC / 2)), j = e / (KC / 2), gk = k0 + k, gj = j0 + j;
           d2 v = d2{0.0, 0.0};
           if (gk < N) {
             if (gj < N) v = *(const d2 *)(Bg + gk + (size_t)gj * N);
@@ -131,11 +132,11 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < 2 * NQA; ++q) {
         const int e = t + 256 * q;
         { const int i = e & (TM - 1), k = e >> 6, gi = i0 + i, gk = k0 + k;
           sa[q] = (gi < N && gk < N) ? Ag[gi + (size_t)gk * N] : 0.0; }
-        { const int k = e & (KC - 1), j = e >> 5, gk = k0 + k, gj = j0 + j;
+        { const int k = e % KC, j = e / KC, gk = k0 + k, gj = j0 + j;
           double v = 0.0;
           if (gk < N) {
             if (gj < N) v = Bg[gk + (size_t)gj * N];
@@ -148,17 +149,17 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
   auto sstore = [&]() {
     if (VEC2) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < NQA; ++q) {
         const int e = t + 256 * q;
         *(d2 *)(As + 2 * (e & 31) + (e >> 5) * LDA) = ra[q];
-        *(d2 *)(Bs + 2 * (e & 15) + (e >> 4) * LDB) = rb[q];
+        *(d2 *)(Bs + 2 * (e % (KC / 2)) + (e / (KC / 2)) * LDB) = rb[q];
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < 2 * NQA; ++q) {
         const int e = t + 256 * q;
         As[(e & (TM - 1)) + (e >> 6) * LDA] = sa[q];
-        Bs[(e & (KC - 1)) + (e >> 5) * LDB] = sb[q];
+        Bs[(e % KC) + (e / KC) * LDB] = sb[q];
       }
     }
   };
@@ -191,48 +192,53 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
   // 60-row column); written from there, the stores were the largest single cost of the kernel (the run without this kernel's MFMAs
   // is 9 % shorter, without its global loads 17 %; profiles/r06_dual_ab.txt).  Staged as the tile Ct[i + j LDA], the result leaves in
   // 16-byte pieces along the contiguous axis -- whole lines -- and the E operand is read the same way.
-  __syncthreads();
-  double *Ct = smem;
-#pragma unroll
-  for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Ct[(16 * tb + lr) + (16 * w + lq + 4 * r) * LDA] = acc[tb][r];
-  __syncthreads();
+  double *Ct = smem;   // half a tile at a time: 32 columns x 66 = 2112 doubles fit the staging space (KC LDA + TN LDB = 2208)
+  static_assert(32 * LDA <= KC * LDA + TN * LDB, "epilogue half-tile does not fit the staging space");
   double *C = a.C + c * CS + uo;
   const double *E = a.E ? a.E + c * CS + uo : nullptr;
-  if (VEC2) {
-    const int i = 2 * (t & 31), gi = i0 + i;
-    for (int j = t >> 5; j < TN; j += 8) {
-      const int gj = j0 + j;
-      if (gi < N && gj < N) {
-        const size_t o = gi + (size_t)gj * N;
-        d2 v = *(const d2 *)(Ct + i + j * LDA);
-        v = v * a.alpha;
-        if (E) v += a.beta * *(const d2 *)(E + o);
-        if (c == 0) { if (gi == gj) v[0] += a.eye; if (gi + 1 == gj) v[1] += a.eye; }
-        *(d2 *)(C + o) = v;
-      } else if (RIDE && gi < N && gj >= N && gj - N < nq) {
-        const double *ad = (gj == N) ? a.add[0] : a.add[1];
-        double *y = (gj == N) ? a.y[0] : a.y[1];
-        d2 v = *(const d2 *)(Ct + i + j * LDA);
-        if (ad) v += *(const d2 *)(ad + voc + gi);
-        *(d2 *)(y + voc + gi) = v;
-      }
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if ((w >> 1) == half) {
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ct[(16 * tb + lr) + (16 * (w & 1) + lq + 4 * r) * LDA] = acc[tb][r];
     }
-  } else {
-    const int i = t & 63, gi = i0 + i;
-    for (int j = t >> 6; j < TN; j += 4) {
-      const int gj = j0 + j;
-      if (gi < N && gj < N) {
-        const size_t o = gi + (size_t)gj * N;
-        double v = a.alpha * Ct[i + j * LDA];
-        if (E) v += a.beta * E[o];
-        if (c == 0 && gi == gj) v += a.eye;
-        C[o] = v;
-      } else if (RIDE && gi < N && gj >= N && gj - N < nq) {
-        const double *ad = (gj == N) ? a.add[0] : a.add[1];
-        double *y = (gj == N) ? a.y[0] : a.y[1];
-        y[voc + gi] = (ad ? ad[voc + gi] : 0.0) + Ct[i + j * LDA];
+    __syncthreads();
+    if (VEC2) {
+      const int i = 2 * (t & 31), gi = i0 + i;
+      for (int jl = t >> 5; jl < 32; jl += 8) {
+        const int gj = j0 + 32 * half + jl;
+        if (gi < N && gj < N) {
+          const size_t o = gi + (size_t)gj * N;
+          d2 v = *(const d2 *)(Ct + i + jl * LDA);
+          v = v * a.alpha;
+          if (E) v += a.beta * *(const d2 *)(E + o);
+          if (c == 0) { if (gi == gj) v[0] += a.eye; if (gi + 1 == gj) v[1] += a.eye; }
+          *(d2 *)(C + o) = v;
+        } else if (RIDE && gi < N && gj >= N && gj - N < nq) {
+          const double *ad = (gj == N) ? a.add[0] : a.add[1];
+          double *y = (gj == N) ? a.y[0] : a.y[1];
+          d2 v = *(const d2 *)(Ct + i + jl * LDA);
+          if (ad) v += *(const d2 *)(ad + voc + gi);
+          *(d2 *)(y + voc + gi) = v;
+        }
+      }
+    } else {
+      const int i = t & 63, gi = i0 + i;
+      for (int jl = t >> 6; jl < 32; jl += 4) {
+        const int gj = j0 + 32 * half + jl;
+        if (gi < N && gj < N) {
+          const size_t o = gi + (size_t)gj * N;
+          double v = a.alpha * Ct[i + jl * LDA];
+          if (E) v += a.beta * E[o];
+          if (c == 0 && gi == gj) v += a.eye;
+          C[o] = v;
+        } else if (RIDE && gi < N && gj >= N && gj - N < nq) {
+          const double *ad = (gj == N) ? a.add[0] : a.add[1];
+          double *y = (gj == N) ? a.y[0] : a.y[1];
+          y[voc + gi] = (ad ? ad[voc + gi] : 0.0) + Ct[i + jl * LDA];
+        }
       }
     }
   }
