@@ -14,8 +14,9 @@
 // followed by two products per partial ((A G)_c = (A_c + (A G)_0 W_c) G0), matrix-vector statements by k_dmatvec, the elemental
 // layer by k_delemental (analytic derivatives of get_elem_rt! / get_elem_rt_SFI!).  The operators of value AND partials do not
 // fit one CU's LDS (5 live operators x (1 + P) x 29 KB per unit at N = 60), which is why this path streams them instead of using
-// the fused LDS-resident images of the value run (mom_kernels.hpp, mom_q4.hpp).  Measured (profiles/r06_dual_ab.txt): the
-// sweep is bound by the matrix pipe (43-49 % busy in k_dgemm), not by HBM (1.5-2.5 TB/s per product launch).
+// the fused LDS-resident images of the value run (mom_kernels.hpp, mom_q4.hpp).  Measured (profiles/r06_dual_ab.txt): neither
+// HBM (1.5-2.5 TB/s per product launch) nor the matrix pipe (0.4-0.56 busy) is at its roof; half of k_dgemm's time at N = 60 is
+// the fixed cost of an item (start-up, first loads, epilogue), which is why the kernel is small (17.7 KB, five per CU).
 //
 // Units are independent: a scene larger than the workspace budget is processed in chunks of units.
 #include <hip/hip_runtime.h>
