@@ -351,21 +351,20 @@ template <int NBK>
 __global__ void __launch_bounds__(256) k_dinv(InvArgs a) {
   constexpr int RPT = 16 * NBK;   // columns per thread
   extern __shared__ double sm[];
-  const int N = a.N, LD = N | 1, t = threadIdx.x, lane = t & 63;
+  const int N = a.N, t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  double *A = sm, *rowk = sm + (size_t)N * LD, *rowx = rowk + 4 * RPT, *colk = rowx + 4 * RPT, *pv = colk + 64 * NBK;  // pv: val, pinv
+  // no staging matrix: with rows across the lanes, column j of the operator is 64 consecutive lanes = one coalesced access, both
+  // ways; the 2 KB of LDS left (pivot row, column k, bookkeeping) let the register count, not the LDS, set the workgroups per CU
+  double *rowk = sm, *rowx = rowk + 4 * RPT, *colk = rowx + 4 * RPT, *pv = colk + 64 * NBK;  // pv: val, pinv
   int *piv = (int *)(pv + 2), *pcur = piv + 64 * NBK, *dst = pcur + 2;
   const size_t NN = (size_t)N * N, uo = (size_t)blockIdx.x * NN;
-  for (int j = w; j < N; j += 4)
-    for (int i = lane; i < N; i += 64) A[i * LD + j] = a.s * a.W[uo + i + (size_t)j * N] + (i == j ? a.eye : 0.0);
-  __syncthreads();
   double R[RPT][NBK];
 #pragma unroll
   for (int s = 0; s < RPT; ++s)
 #pragma unroll
     for (int ib = 0; ib < NBK; ++ib) {
       const int i = lane + 64 * ib, j = w + 4 * s;
-      R[s][ib] = (i < N && j < N) ? A[i * LD + j] : 0.0;
+      R[s][ib] = (i < N && j < N) ? a.s * a.W[uo + i + (size_t)j * N] + (i == j ? a.eye : 0.0) : 0.0;
     }
   // column `scol` of this wave: a wave-uniform dynamic index into the register array (s_set_gpr_idx / v_movrel: a 32-way switch
   // made the kernel 47 KB of code, and the instruction cache its bottleneck)
@@ -502,11 +501,8 @@ __global__ void __launch_bounds__(256) k_dinv(InvArgs a) {
 #pragma unroll
     for (int ib = 0; ib < NBK; ++ib) {
       const int i = lane + 64 * ib, j = w + 4 * s;
-      if (i < N && j < N) A[i * LD + dst[j]] = R[s][ib];
+      if (i < N && j < N) a.G[uo + i + (size_t)dst[j] * N] = R[s][ib];
     }
-  __syncthreads();
-  for (int j = w; j < N; j += 4)
-    for (int i = lane; i < N; i += 64) a.G[uo + i + (size_t)j * N] = A[i * LD + j];
   if (t == 0 && bad) atomicMax(a.info, 1);
 }
 
@@ -1117,7 +1113,7 @@ int momd_run(const MomDualScene &sc, std::string *err) {
     hipLaunchKernelGGL(k_dtausum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, sc.S, Nz, P, sc.dtau, dts);
   }
   const int nbk = (N <= 64) ? 1 : 2;
-  const size_t inv_lds = ((size_t)N * (N | 1) + 3 * 64 * nbk + 2) * sizeof(double) + (size_t)(3 * 64 * nbk + 2) * sizeof(int);
+  const size_t inv_lds = ((size_t)3 * 64 * nbk + 2) * sizeof(double) + (size_t)(3 * 64 * nbk + 2) * sizeof(int);
   DCHK(mom_allow_lds((const void *)k_dinv<1>, inv_lds));
   DCHK(mom_allow_lds((const void *)k_dinv<2>, inv_lds));
 
