@@ -271,3 +271,15 @@ def test_dual_run_sharded_over_gloo(S, world):
     assert np.abs(ref[2]).max() > 0
     for a, b in zip(out, ref):
         assert np.array_equal(a, b)
+
+
+def test_slice_partials():
+    """Per-point partial arrays are cut with the points; per-scene ones (bases, scalar albedo, BRDF matrices) are shared."""
+    import rtamd
+    rng = np.random.default_rng(0)
+    S, Nz, K = 7, 3, 2
+    p = rtamd.ScenePartial(dτ=rng.standard_normal((S, Nz)), dϖ=None, dzw=rng.standard_normal((K, S, Nz)), dZpp=np.ones((1, K, 4, 4)),
+                           dZmp=np.ones((1, K, 4, 4)), dalbedo=0.5, dalbedo_spec=rng.standard_normal(S))
+    q, = rtamd.sharding.slice_partials([p], 2, 5)
+    assert np.array_equal(q.dτ, p.dτ[2:5]) and q.dϖ is None and np.array_equal(q.dzw, p.dzw[:, 2:5])
+    assert q.dZpp is p.dZpp and q.dalbedo == 0.5 and np.array_equal(q.dalbedo_spec, p.dalbedo_spec[2:5])
