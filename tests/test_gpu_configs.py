@@ -224,6 +224,51 @@ def test_config_C2_full_size_stratified(rtamd, cref):
     helpers.assert_stokes_close(T, Tr, what="C2 all points T")
 
 
+def test_config_C2_dual_full_size(rtamd):
+    """rt_run on Dual numbers at the headline size (N = 60, 40 layers, S = 10 000, three partials) through size-independent
+    properties on ALL points: the values are mom_rt_run's, the partials are linear in the direction (the third direction is
+    2 x the first - 0.5 x the second), and the partial along the first direction is the central difference quotient of two
+    VALUE runs of the fused kernels on scenes moved by +-eps along it (an independent code path: elemental -> doubling ->
+    interaction in LDS-resident images against the streamed tangent-linear sweep)."""
+    rt = rtamd.corert
+    m = rtamd.scenes.scene_C2()
+    sc = rtamd.prepare_scene(m)
+    L = rt.construct_layer_inputs(m)
+    rng = np.random.default_rng(2)
+    p1 = rtamd.ScenePartial(dτ=L.τ * rng.uniform(0.0, 1.0, L.τ.shape), dϖ=-0.05 * L.ϖ * rng.uniform(0, 1, L.ϖ.shape), dalbedo=0.3)
+    p2 = rtamd.ScenePartial(dτ=L.τ * rng.uniform(-1, 1, L.τ.shape), dzw=L.zw * rng.uniform(-1, 1, L.zw.shape), dalbedo=-1.0)
+    comb = rtamd.ScenePartial(dτ=2.0 * p1.dτ - 0.5 * p2.dτ, dϖ=2.0 * p1.dϖ, dzw=-0.5 * p2.dzw, dalbedo=2.0 * 0.3 + 0.5)
+    with rt.make_handle(m) as h:
+        Rv, Tv = rt.run_scene(h, sc)
+        rt.scene_set_partials(h, sc, [p1, p2, comb])
+        h.rt_run_dual()
+        R, T = h.get_RT()
+        dR, dT = h.get_RT_partials()
+        # two value runs of the fused kernels on the scene moved along p1 (tau, varpi and the albedo only: same ndoubl / interfaces)
+        eps, fd = 1e-4, []
+        for sgn in (1.0, -1.0):
+            tau = L.τ + sgn * eps * p1.dτ
+            varpi = L.ϖ + sgn * eps * p1.dϖ
+            tau_sum = np.concatenate([np.zeros((tau.shape[0], 1)), np.cumsum(tau, axis=1)], axis=1)
+            col = lambda a: np.ascontiguousarray(a.T).reshape(-1)
+            h.scene_set(sc.Nz, sc.K, sc.M, col(tau), col(varpi), sc.zw, sc.Zpp, sc.Zmp, sc.ndoubl, sc.iface, col(tau_sum),
+                        sc.albedo + sgn * eps * 0.3, sc.node, sc.cos_mphi, sc.sin_mphi)
+            h.rt_run()
+            fd.append(h.get_RT())
+    assert np.all(np.isfinite(dR)) and np.all(np.isfinite(dT)) and np.abs(dR).max() > 0
+    helpers.assert_stokes_close(R, Rv, what="C2 dual values vs mom_rt_run R")
+    helpers.assert_stokes_close(T, Tv, what="C2 dual values vs mom_rt_run T")
+    for d in (dR, dT):
+        scale = np.abs(d[:2]).max(axis=(0, 2, 3), keepdims=True)[0]          # the view's largest partial
+        assert np.abs(d[2] - (2.0 * d[0] - 0.5 * d[1])).max() <= 1e-10 * scale.max()
+    for d, k in ((dR[0], 0), (dT[0], 1)):
+        q = (fd[0][k] - fd[1][k]) / (2 * eps)
+        scale = np.abs(d).max(axis=(1, 2), keepdims=True)
+        # the quotient's own noise: each value run is within stokes_rtol(nd = 16) = 2.2e-10 of I of the exact result of the equations,
+        # so the quotient carries up to 2.2e-10 I / eps = 2e-6 of I (measured 7.6e-7 of the largest partial); truncation is eps^2
+        assert np.abs(d - q).max() <= 3e-6 * scale.max(), float(np.abs(d - q).max() / scale.max())
+
+
 def test_config_C3_three_bands(rtamd, cref):
     """configs[2] on one GPU: 13 672 + 6 402 + 9 870 = 29 944 points on one spectral axis, same kernels as C2;
     3 072 points stratified over absorption depth against the oracle, and the 8-way spectral split of the multi-GPU run (global ndoubl)
