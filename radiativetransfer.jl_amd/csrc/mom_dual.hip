@@ -358,28 +358,66 @@ __global__ void __launch_bounds__(256) k_dinv(InvArgs a) {
   double *rowk = sm, *rowx = rowk + 4 * RPT, *colk = rowx + 4 * RPT, *pv = colk + 64 * NBK;  // pv: val, pinv
   int *piv = (int *)(pv + 2), *pcur = piv + 64 * NBK, *dst = pcur + 2;
   const size_t NN = (size_t)N * N, uo = (size_t)blockIdx.x * NN;
-  double R[RPT][NBK];
-#pragma unroll
-  for (int s = 0; s < RPT; ++s)
-#pragma unroll
-    for (int ib = 0; ib < NBK; ++ib) {
-      const int i = lane + 64 * ib, j = w + 4 * s;
-      R[s][ib] = (i < N && j < N) ? a.s * a.W[uo + i + (size_t)j * N] + (i == j ? a.eye : 0.0) : 0.0;
+  // thread (lane, w) owns A[lane + 64 ib][w + 4 s], s < 16 NBK, ib < NBK.  The registers are FOUR arrays of 16 doubles -- [s < 16 | s >= 16]
+  // x [ib 0 | ib 1] -- because a wave-uniform dynamic index into 16 doubles is a v_movrel while one 64-double array went to scratch
+  // (N = 80: 3.8 ms per launch of 1000 units, 65 % of the Dual run).  `each` runs a body over the halves with static indices.
+  double A0[16], A1[16], B0[16], B1[16];
+  auto each = [&](auto &&f) {
+    f(A0, A1, 0);
+    if constexpr (NBK > 1) f(B0, B1, 16);
+  };
+  // column `scol` of this wave, scol wave-uniform: f(entry of row block 0, entry of row block 1).  One register array of 16 doubles takes a
+  // dynamic index as a v_movrel (NBK = 1); with four of them the compiler keeps them in scratch, so there the entries are fetched and
+  // put back through a scalar switch over statically indexed registers (cases of two moves)
+#define MOMD_C16(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+  auto with_col = [&](int scol, bool writeback, auto &&f) {
+    if constexpr (NBK == 1) {
+      f(A0[scol & 15], A1[0]);
+    } else {
+      double e0 = 0.0, e1 = 0.0;
+      switch (scol) {
+#define MOMD_G(S) case S: e0 = A0[S]; e1 = A1[S]; break;
+        MOMD_C16(MOMD_G)
+#undef MOMD_G
+#define MOMD_G(S) case 16 + S: e0 = B0[S]; e1 = B1[S]; break;
+        MOMD_C16(MOMD_G)
+#undef MOMD_G
+        default: break;
+      }
+      f(e0, e1);
+      if (writeback) {
+        switch (scol) {
+#define MOMD_G(S) case S: A0[S] = e0; A1[S] = e1; break;
+          MOMD_C16(MOMD_G)
+#undef MOMD_G
+#define MOMD_G(S) case 16 + S: B0[S] = e0; B1[S] = e1; break;
+          MOMD_C16(MOMD_G)
+#undef MOMD_G
+          default: break;
+        }
+      }
     }
-  // column `scol` of this wave: a wave-uniform dynamic index into the register array (s_set_gpr_idx / v_movrel: a 32-way switch
-  // made the kernel 47 KB of code, and the instruction cache its bottleneck)
-  auto with_col = [&](int scol, auto &&f) { f(R[scol]); };
+  };
+#undef MOMD_C16
+  each([&](double (&r0)[16], double (&r1)[16], int sbase) {
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int j = w + 4 * (sbase + s2);
+      r0[s2] = (lane < N && j < N) ? a.s * a.W[uo + lane + (size_t)j * N] + (lane == j ? a.eye : 0.0) : 0.0;
+      if constexpr (NBK > 1) r1[s2] = (lane + 64 < N && j < N) ? a.s * a.W[uo + lane + 64 + (size_t)j * N] + (lane + 64 == j ? a.eye : 0.0) : 0.0;
+    }
+  });
   // pivot of column kc among rows >= kc: executed by the wave that owns the column; leaves p, val, 1 / val in LDS.  The
   // maximum goes down the rows of 16 by DPP shifts and across them by readlane (a __shfl ladder is six exposed LDS round
   // trips on the critical path of all four waves); the row that holds it comes from a ballot.
   auto search = [&](int kc) {
-    with_col(kc >> 2, [&](double (&col)[NBK]) {
+    with_col(kc >> 2, false, [&](double &e0, double &e1) {
       double best = -1.0, val = 0.0;
       int bi = kc;
-#pragma unroll
-      for (int ib = 0; ib < NBK; ++ib) {
-        const int i = lane + 64 * ib;
-        if (i >= kc && i < N && fabs(col[ib]) > best) { best = fabs(col[ib]); val = col[ib]; bi = i; }
+      if (lane >= kc && lane < N) { best = fabs(e0); val = e0; bi = lane; }
+      if constexpr (NBK > 1) {
+        const int i = lane + 64;
+        if (i >= kc && i < N && fabs(e1) > best) { best = fabs(e1); val = e1; bi = i; }
       }
       double m = best;
       union { double d; int w2[2]; } ua, ub;
@@ -400,7 +438,7 @@ __global__ void __launch_bounds__(256) k_dinv(InvArgs a) {
         mx = fmax(mx, tt.d);
       }
       const unsigned long long hit = __ballot(best == mx);
-      const int src_lane = __builtin_ctzll(hit);          // the lowest lane holding the maximum (its row index is the smallest)
+      const int src_lane = __builtin_ctzll(hit);          // the lowest lane holding the maximum
       union { double d; int w2[2]; } uv, ur;
       uv.d = val;
       ur.w2[0] = __builtin_amdgcn_readlane(uv.w2[0], src_lane);
@@ -425,62 +463,55 @@ __global__ void __launch_bounds__(256) k_dinv(InvArgs a) {
     if (t == 0) piv[k] = p;
     if (p != k) {  // (block-uniform) exchange rows p and k: every wave hands its 16 NBK entries of both rows through LDS
       const int pb = p >> 6, pl = p & 63;
+      each([&](double (&r0)[16], double (&r1)[16], int sbase) {
 #pragma unroll
-      for (int ib = 0; ib < NBK; ++ib) {
-        if (ib == pb && lane == pl) {
-#pragma unroll
-          for (int s = 0; s < RPT; ++s) rowx[w * RPT + s] = R[s][ib];
+        for (int s2 = 0; s2 < 16; ++s2) {
+          if (lane == pl) rowx[w * RPT + sbase + s2] = (NBK > 1 && pb == 1) ? r1[s2] : r0[s2];
+          if (lane == kl) rowk[w * RPT + sbase + s2] = (NBK > 1 && kb == 1) ? r1[s2] : r0[s2];
         }
-        if (ib == kb && lane == kl) {
-#pragma unroll
-          for (int s = 0; s < RPT; ++s) rowk[w * RPT + s] = R[s][ib];
-        }
-      }
+      });
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes are complete (same-wave exchange, no barrier needed)
       __builtin_amdgcn_wave_barrier();
+      each([&](double (&r0)[16], double (&r1)[16], int sbase) {
 #pragma unroll
-      for (int ib = 0; ib < NBK; ++ib) {
-        if (ib == pb && lane == pl) {
-#pragma unroll
-          for (int s = 0; s < RPT; ++s) R[s][ib] = rowk[w * RPT + s];
+        for (int s2 = 0; s2 < 16; ++s2) {
+          if (lane == pl) { const double v = rowk[w * RPT + sbase + s2]; if (NBK > 1 && pb == 1) r1[s2] = v; else r0[s2] = v; }
+          if (lane == kl) { const double v = rowx[w * RPT + sbase + s2]; if (NBK > 1 && kb == 1) r1[s2] = v; else r0[s2] = v; }
         }
-        if (ib == kb && lane == kl) {
-#pragma unroll
-          for (int s = 0; s < RPT; ++s) R[s][ib] = rowx[w * RPT + s];
-        }
-      }
+      });
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
     }
     // stage the scaled pivot row (each wave its own columns) and column k (its owner wave)
+    if (lane == kl)
+      each([&](double (&r0)[16], double (&r1)[16], int sbase) {
 #pragma unroll
-    for (int ib = 0; ib < NBK; ++ib)
-      if (ib == kb && lane == kl) {
-#pragma unroll
-        for (int s = 0; s < RPT; ++s) rowk[w * RPT + s] = R[s][ib] * pinv;
-      }
+        for (int s2 = 0; s2 < 16; ++s2) rowk[w * RPT + sbase + s2] = ((NBK > 1 && kb == 1) ? r1[s2] : r0[s2]) * pinv;
+      });
     if (w == wk)
-      with_col(sk, [&](double (&col)[NBK]) {
-#pragma unroll
-        for (int ib = 0; ib < NBK; ++ib) colk[lane + 64 * ib] = col[ib];
+      with_col(sk, false, [&](double &e0, double &e1) {
+        colk[lane] = e0;
+        if constexpr (NBK > 1) colk[lane + 64] = e1;
       });
     __syncthreads();
-    double c[NBK], c0[NBK];
+    double c[2], c0[2];
 #pragma unroll
     for (int ib = 0; ib < NBK; ++ib) {
       c0[ib] = colk[lane + 64 * ib];
       c[ib] = (ib == kb && lane == kl) ? val - 1.0 : c0[ib];
     }
+    each([&](double (&r0)[16], double (&r1)[16], int sbase) {
 #pragma unroll
-    for (int s = 0; s < RPT; ++s) {
-      const double rk = rowk[w * RPT + s];
-#pragma unroll
-      for (int ib = 0; ib < NBK; ++ib) R[s][ib] = R[s][ib] - c[ib] * rk;
-    }
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const double rk = rowk[w * RPT + sbase + s2];
+        r0[s2] = r0[s2] - c[0] * rk;
+        if constexpr (NBK > 1) r1[s2] = r1[s2] - c[1] * rk;
+      }
+    });
     if (w == wk)   // column k of the inverse in progress: pinv on the pivot row, -c_i pinv elsewhere
-      with_col(sk, [&](double (&col)[NBK]) {
-#pragma unroll
-        for (int ib = 0; ib < NBK; ++ib) col[ib] = (ib == kb && lane == kl) ? pinv : -c0[ib] * pinv;
+      with_col(sk, true, [&](double &e0, double &e1) {
+        e0 = (kb == 0 && lane == kl) ? pinv : -c0[0] * pinv;
+        if constexpr (NBK > 1) e1 = (kb == 1 && lane == kl) ? pinv : -c0[1] * pinv;
       });
     if (k + 1 < N && w == ((k + 1) & 3)) search(k + 1);
     __syncthreads();
@@ -496,13 +527,16 @@ __global__ void __launch_bounds__(256) k_dinv(InvArgs a) {
     dst[j] = pos;
   }
   __syncthreads();
+  each([&](double (&r0)[16], double (&r1)[16], int sbase) {
 #pragma unroll
-  for (int s = 0; s < RPT; ++s)
-#pragma unroll
-    for (int ib = 0; ib < NBK; ++ib) {
-      const int i = lane + 64 * ib, j = w + 4 * s;
-      if (i < N && j < N) a.G[uo + i + (size_t)dst[j] * N] = R[s][ib];
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int j = w + 4 * (sbase + s2);
+      if (j < N) {
+        if (lane < N) a.G[uo + lane + (size_t)dst[j] * N] = r0[s2];
+        if (NBK > 1 && lane + 64 < N) a.G[uo + lane + 64 + (size_t)dst[j] * N] = r1[s2];
+      }
     }
+  });
   if (t == 0 && bad) atomicMax(a.info, 1);
 }
 
