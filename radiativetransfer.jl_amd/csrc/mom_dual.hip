@@ -33,8 +33,7 @@ namespace momd {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int TM = 64, TN = 64, KC = 16, LDA = TM + 2, LDB = KC + 2;   // K chunks of 16: 17.7 KB of LDS per workgroup
-constexpr int NQA = TM * KC / 512;   // 16-byte pieces of a staged tile per thread (A and B alike: TM = TN)
+constexpr int TM = 64, TN = 64, KC = 16, LDB = KC + 2;   // the 64 x 64 tile, K chunks of 16: 17.7 KB of LDS per workgroup
 
 // ---------------------------------------------------------------------------------------------------------------------
 // C_c = alpha * prod_c + beta * E_c + eye * (c == 0) I          mode 0: Dual product rule, 1: A0 Bc, 2: Ac B0
@@ -73,14 +72,19 @@ extern "C" void momd_stamps_read(unsigned long long *out, int reset) {
 #else
 #define MOMD_STAMP(id)
 #endif
-template <bool VEC2, bool RIDE>
-__global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
+// NW wavefronts per workgroup = a tile of 16 NW x 16 NW (NW = 4: the 64 x 64 tile; 5, 6: ONE tile for operator edges up to 80 / 96, where
+// 2 x 2 tiles of 64 would spend three quarters of their work on padding).  Wave w owns columns 16 w .. 16 w + 15 and NW row blocks.
+template <bool VEC2, bool RIDE, int NW>
+__global__ void __launch_bounds__(64 * NW) k_dgemm(GemmArgs a) {
+  constexpr int TMw = 16 * NW, TNw = 16 * NW, LDAw = TMw + 2, NTH = 64 * NW;
+  static_assert((TMw / 2) * KC % NTH == 0 && TNw * (KC / 2) % NTH == 0, "staging pieces per thread");
+  constexpr int NQw = (TMw / 2) * KC / NTH;   // 16-byte pieces of a staged tile per thread (A and B alike)
 #ifdef MOMD_STAMPS
   const bool stamp_on = (blockIdx.x == gridDim.x / 2) && (threadIdx.x < 64);
   unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
-  __shared__ __attribute__((aligned(16))) double smem[KC * LDA + TN * LDB];
-  double *As = smem, *Bs = smem + KC * LDA;   // As[i + k LDA], Bs[k + j LDB]; the epilogue reuses the space as Ct[i + j LDA]
+  __shared__ __attribute__((aligned(16))) double smem[KC * LDAw + TNw * LDB];
+  double *As = smem, *Bs = smem + KC * LDAw;   // As[i + k LDA], Bs[k + j LDB]; the epilogue reuses the space as Ct[i + j LDA]
   typedef double d2 __attribute__((ext_vector_type(2)));
   const int N = a.N;
   const size_t NN = (size_t)N * N, CS = (size_t)a.U * NN;
@@ -90,12 +94,12 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
   const int slot = blockIdx.x >> 3, inner = slot % nb, unit = (slot / nb) * 8 + (blockIdx.x & 7);
   if (unit >= a.U) return;
   const int tile = inner % ntile, c = a.c0 + inner / ntile;
-  const int i0 = (tile % a.tiles_i) * TM, j0 = (tile / a.tiles_i) * TN;
+  const int i0 = (tile % a.tiles_i) * TMw, j0 = (tile / a.tiles_i) * TNw;
   const size_t uo = (size_t)unit * NN;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, lq = lane >> 4, lr = lane & 15;
-  d4 acc[4];
+  d4 acc[NW];
 #pragma unroll
-  for (int tb = 0; tb < 4; ++tb) acc[tb] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int tb = 0; tb < NW; ++tb) acc[tb] = d4{0.0, 0.0, 0.0, 0.0};
   int nterms = 1;
   const double *A0 = a.A + uo, *B0 = a.B + uo, *Ac = a.A + c * CS + uo, *Bc = a.B + c * CS + uo;
   const int nq = RIDE ? a.nq : 0;
@@ -110,8 +114,8 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
   const double *x0p = RIDE ? a.x[0] : nullptr, *x1p = (RIDE && nq > 1) ? a.x[1] : nullptr;
   const int nch = (N + KC - 1) / KC, nph = nterms * nch;
   // the next (term, K chunk) is fetched into registers while the matrix cores work on the current one
-  d2 ra[NQA], rb[NQA];
-  double sa[2 * NQA], sb[2 * NQA];
+  d2 ra[NQw], rb[NQw];
+  double sa[2 * NQw], sb[2 * NQw];
   auto gload = [&](int ph) {
     const bool t1 = ph >= nch;
     const double *Ag = t1 ? A0 : TA0, *Bg = t1 ? Bc : TB0;
@@ -119,9 +123,9 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
     const int k0 = (t1 ? ph - nch : ph) * KC;
     if (VEC2) {  // N even: pairs along the contiguous axis are 16-byte aligned and never straddle the edge
 #pragma unroll
-      for (int q = 0; q < NQA; ++q) {
-        const int e = t + 256 * q;
-        { const int i = 2 * (e & 31), k = e >> 5, gi = i0 + i, gk = k0 + k;
+      for (int q = 0; q < NQw; ++q) {
+        const int e = t + NTH * q;
+        { const int i = 2 * (e % (TMw / 2)), k = e / (TMw / 2), gi = i0 + i, gk = k0 + k;
           ra[q] = (gi < N && gk < N) ? *(const d2 *)(Ag + gi + (size_t)gk * N) : d2{0.0, 0.0}; }
         { const int k = 2 * (e % (KC / 2)), j = e / (KC / 2), gk = k0 + k, gj = j0 + j;
           d2 v = d2{0.0, 0.0};
@@ -133,9 +137,9 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 2 * NQA; ++q) {
-        const int e = t + 256 * q;
-        { const int i = e & (TM - 1), k = e >> 6, gi = i0 + i, gk = k0 + k;
+      for (int q = 0; q < 2 * NQw; ++q) {
+        const int e = t + NTH * q;
+        { const int i = e % TMw, k = e / TMw, gi = i0 + i, gk = k0 + k;
           sa[q] = (gi < N && gk < N) ? Ag[gi + (size_t)gk * N] : 0.0; }
         { const int k = e % KC, j = e / KC, gk = k0 + k, gj = j0 + j;
           double v = 0.0;
@@ -150,16 +154,16 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
   auto sstore = [&]() {
     if (VEC2) {
 #pragma unroll
-      for (int q = 0; q < NQA; ++q) {
-        const int e = t + 256 * q;
-        *(d2 *)(As + 2 * (e & 31) + (e >> 5) * LDA) = ra[q];
+      for (int q = 0; q < NQw; ++q) {
+        const int e = t + NTH * q;
+        *(d2 *)(As + 2 * (e % (TMw / 2)) + (e / (TMw / 2)) * LDAw) = ra[q];
         *(d2 *)(Bs + 2 * (e % (KC / 2)) + (e / (KC / 2)) * LDB) = rb[q];
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 2 * NQA; ++q) {
-        const int e = t + 256 * q;
-        As[(e & (TM - 1)) + (e >> 6) * LDA] = sa[q];
+      for (int q = 0; q < 2 * NQw; ++q) {
+        const int e = t + NTH * q;
+        As[(e % TMw) + (e / TMw) * LDAw] = sa[q];
         Bs[(e % KC) + (e / KC) * LDB] = sb[q];
       }
     }
@@ -181,8 +185,8 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
     for (int kk = 0; kk < kmax; kk += 4) {
       const double bv = Bs[(kk + lq) + (16 * w + lr) * LDB];
 #pragma unroll
-      for (int tb = 0; tb < 4; ++tb) {
-        const double av = As[(16 * tb + lr) + (kk + lq) * LDA];
+      for (int tb = 0; tb < NW; ++tb) {
+        const double av = As[(16 * tb + lr) + (kk + lq) * LDAw];
         acc[tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc[tb], 0, 0, 0);
       }
     }
@@ -193,26 +197,27 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
   // 60-row column); written from there, the stores were the largest single cost of the kernel (the run without this kernel's MFMAs
   // is 9 % shorter, without its global loads 17 %; profiles/r06_dual_ab.txt).  Staged as the tile Ct[i + j LDA], the result leaves in
   // 16-byte pieces along the contiguous axis -- whole lines -- and the E operand is read the same way.
-  double *Ct = smem;   // half a tile at a time: 32 columns x 66 = 2112 doubles fit the staging space (KC LDA + TN LDB = 2208)
-  static_assert(32 * LDA <= KC * LDA + TN * LDB, "epilogue half-tile does not fit the staging space");
+  double *Ct = smem;   // 32 columns at a time: 32 x LDAw doubles fit the staging space (NW = 4: 2112 of 2208)
+  static_assert(32 * LDAw <= KC * LDAw + TNw * LDB, "epilogue pass does not fit the staging space");
+  constexpr int NPASS = (TNw + 31) / 32;
   double *C = a.C + c * CS + uo;
   const double *E = a.E ? a.E + c * CS + uo : nullptr;
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < NPASS; ++half) {
     __syncthreads();
     if ((w >> 1) == half) {
 #pragma unroll
-      for (int tb = 0; tb < 4; ++tb)
+      for (int tb = 0; tb < NW; ++tb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ct[(16 * tb + lr) + (16 * (w & 1) + lq + 4 * r) * LDA] = acc[tb][r];
+        for (int r = 0; r < 4; ++r) Ct[(16 * tb + lr) + (16 * (w & 1) + lq + 4 * r) * LDAw] = acc[tb][r];
     }
     __syncthreads();
     if (VEC2) {
-      const int i = 2 * (t & 31), gi = i0 + i;
-      for (int jl = t >> 5; jl < 32; jl += 8) {
+      const int i = 2 * (t % (TMw / 2)), gi = i0 + i;
+      for (int jl = t / (TMw / 2); jl < 32; jl += NTH / (TMw / 2)) {
         const int gj = j0 + 32 * half + jl;
         if (gi < N && gj < N) {
           const size_t o = gi + (size_t)gj * N;
-          d2 v = *(const d2 *)(Ct + i + jl * LDA);
+          d2 v = *(const d2 *)(Ct + i + jl * LDAw);
           v = v * a.alpha;
           if (E) v += a.beta * *(const d2 *)(E + o);
           if (c == 0) { if (gi == gj) v[0] += a.eye; if (gi + 1 == gj) v[1] += a.eye; }
@@ -220,25 +225,25 @@ __global__ void __launch_bounds__(256) k_dgemm(GemmArgs a) {
         } else if (RIDE && gi < N && gj >= N && gj - N < nq) {
           const double *ad = (gj == N) ? a.add[0] : a.add[1];
           double *y = (gj == N) ? a.y[0] : a.y[1];
-          d2 v = *(const d2 *)(Ct + i + jl * LDA);
+          d2 v = *(const d2 *)(Ct + i + jl * LDAw);
           if (ad) v += *(const d2 *)(ad + voc + gi);
           *(d2 *)(y + voc + gi) = v;
         }
       }
     } else {
-      const int i = t & 63, gi = i0 + i;
-      for (int jl = t >> 6; jl < 32; jl += 4) {
+      const int i = t % TMw, gi = i0 + i;
+      for (int jl = t / TMw; jl < 32; jl += NTH / TMw) {
         const int gj = j0 + 32 * half + jl;
         if (gi < N && gj < N) {
           const size_t o = gi + (size_t)gj * N;
-          double v = a.alpha * Ct[i + jl * LDA];
+          double v = a.alpha * Ct[i + jl * LDAw];
           if (E) v += a.beta * E[o];
           if (c == 0 && gi == gj) v += a.eye;
           C[o] = v;
         } else if (RIDE && gi < N && gj >= N && gj - N < nq) {
           const double *ad = (gj == N) ? a.add[0] : a.add[1];
           double *y = (gj == N) ? a.y[0] : a.y[1];
-          y[voc + gi] = (ad ? ad[voc + gi] : 0.0) + Ct[i + jl * LDA];
+          y[voc + gi] = (ad ? ad[voc + gi] : 0.0) + Ct[i + jl * LDAw];
         }
       }
     }
@@ -1187,13 +1192,24 @@ int momd_run(const MomDualScene &sc, std::string *err) {
         }
         return;
       }
+      if (N + rd.nq > 64 && N + rd.nq <= 96) {   // ONE tile of 80 x 80 / 96 x 96 (five / six wavefronts) instead of 2 x 2 tiles of 64 x 64
+        const bool w5 = N + rd.nq <= 80;
+        g.tiles_i = 1; g.tiles_j = 1;
+        const dim3 grid1((unsigned)(8 * nc * ((U + 7) / 8)));
+#define MOMD_GO(V2, RD) do { if (w5) hipLaunchKernelGGL((k_dgemm<V2, RD, 5>), grid1, dim3(320), 0, st, g); \
+                             else hipLaunchKernelGGL((k_dgemm<V2, RD, 6>), grid1, dim3(384), 0, st, g); } while (0)
+        if (N % 2 == 0) { if (rd.nq) MOMD_GO(true, true); else MOMD_GO(true, false); }
+        else { if (rd.nq) MOMD_GO(false, true); else MOMD_GO(false, false); }
+#undef MOMD_GO
+        return;
+      }
       const dim3 grid((unsigned)(8 * tiles * tiles_j * nc * ((U + 7) / 8)));
       if (N % 2 == 0) {
-        if (rd.nq) hipLaunchKernelGGL((k_dgemm<true, true>), grid, dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((k_dgemm<true, false>), grid, dim3(256), 0, st, g);
+        if (rd.nq) hipLaunchKernelGGL((k_dgemm<true, true, 4>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_dgemm<true, false, 4>), grid, dim3(256), 0, st, g);
       } else {
-        if (rd.nq) hipLaunchKernelGGL((k_dgemm<false, true>), grid, dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((k_dgemm<false, false>), grid, dim3(256), 0, st, g);
+        if (rd.nq) hipLaunchKernelGGL((k_dgemm<false, true, 4>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_dgemm<false, false, 4>), grid, dim3(256), 0, st, g);
       }
     };
     auto gemm = [&](double *C, const double *A, const double *B, int mode, int c0, int nc, double alpha, const double *E,

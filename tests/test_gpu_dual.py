@@ -208,3 +208,10 @@ def test_dual_on_a_device_optics_scene():
     assert np.abs(dR0).max() > 0
     for x, y in ((R0, R1), (T0, T1), (dR0, dR1), (dT0, dT1)):
         assert np.array_equal(x, y)
+
+
+def test_dual_six_wave_tile():
+    """IQUV with 24 streams, N = 96: the one-tile 96 x 96 form of the product kernel (six wavefronts) and the two-block inverse."""
+    m = rtamd.scenes.make_scene(4, 41, 2, 2, seed=2, aerosol_total=0.1, absorption=False)
+    assert m.quad_points.qp_μN.size == 96
+    compare(m, P=1, seed=3)
