@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(64 * NW) k_dgemm(GemmArgs a) {
   }
 }
 
-// The same product for operators of edge N + nq <= 16 NT (NT = 1, 2, 3): ONE WAVEFRONT per (unit, component), operands read straight
+// The same product for operators of edge N + nq <= 16 NT (shipped: NT = 1): ONE WAVEFRONT per (unit, component), operands read straight
 // from global memory in the layout of the MFMA (a 30 x 30 operator is 7 KB: cache-resident), no LDS, no barrier.  The 64 x 64
 // workgroup tile above costs the same for every edge up to 64 (N = 30: 4.5 x the MFMA work, two staging phases per term).
 template <int NT, bool RIDE>
@@ -1178,26 +1178,29 @@ int momd_run(const MomDualScene &sc, std::string *err) {
       const int tiles_j = (N + rd.nq + TN - 1) / TN;
       GemmArgs g{N, U, c0, nc, mode, tiles, tiles_j, A, B, E, C, alpha, beta, eye, rd.nq, {rd.x[0], rd.x[1]}, {rd.add[0], rd.add[1]},
                  {rd.y[0], rd.y[1]}};
-      if (N + rd.nq <= 48) {   // one wavefront per (unit, component)
+      if (N + rd.nq <= 16) {   // one wavefront per (unit, component), operands straight from global memory (k_dgemm_w)
+        g.tiles_i = 1; g.tiles_j = 1;
         const dim3 gw((unsigned)(((size_t)U * nc + 3) / 4));
-        if (N + rd.nq <= 16) {
-          if (rd.nq) hipLaunchKernelGGL((k_dgemm_w<1, true>), gw, dim3(256), 0, st, g);
-          else hipLaunchKernelGGL((k_dgemm_w<1, false>), gw, dim3(256), 0, st, g);
-        } else if (N + rd.nq > 32) {
-          if (rd.nq) hipLaunchKernelGGL((k_dgemm_w<3, true>), gw, dim3(256), 0, st, g);
-          else hipLaunchKernelGGL((k_dgemm_w<3, false>), gw, dim3(256), 0, st, g);
-        } else {
-          if (rd.nq) hipLaunchKernelGGL((k_dgemm_w<2, true>), gw, dim3(256), 0, st, g);
-          else hipLaunchKernelGGL((k_dgemm_w<2, false>), gw, dim3(256), 0, st, g);
-        }
+        if (rd.nq) hipLaunchKernelGGL((k_dgemm_w<1, true>), gw, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((k_dgemm_w<1, false>), gw, dim3(256), 0, st, g);
         return;
       }
-      if (N + rd.nq > 64 && N + rd.nq <= 96) {   // ONE tile of 80 x 80 / 96 x 96 (five / six wavefronts) instead of 2 x 2 tiles of 64 x 64
-        const bool w5 = N + rd.nq <= 80;
+      if (N + rd.nq <= 96) {
+        // ONE workgroup tile of 16 nw x 16 nw, nw wavefronts: 32 / 48 (faster than wavefront tiles of that size: N = 30 / 42: 461 / 953 ->
+        // 351 / 673 ms), 64, and 80 / 96 instead of 2 x 2 tiles of 64 (N = 72 / 80 / 96: 500 / 579 / 684 -> 362 / 452 / 656 ms)
+        const int nw = (N + rd.nq + 15) / 16;
         g.tiles_i = 1; g.tiles_j = 1;
         const dim3 grid1((unsigned)(8 * nc * ((U + 7) / 8)));
-#define MOMD_GO(V2, RD) do { if (w5) hipLaunchKernelGGL((k_dgemm<V2, RD, 5>), grid1, dim3(320), 0, st, g); \
-                             else hipLaunchKernelGGL((k_dgemm<V2, RD, 6>), grid1, dim3(384), 0, st, g); } while (0)
+#define MOMD_GO(V2, RD)                                                                                      \
+  do {                                                                                                       \
+    switch (nw) {                                                                                            \
+      case 2: hipLaunchKernelGGL((k_dgemm<V2, RD, 2>), grid1, dim3(128), 0, st, g); break;                   \
+      case 3: hipLaunchKernelGGL((k_dgemm<V2, RD, 3>), grid1, dim3(192), 0, st, g); break;                   \
+      case 4: hipLaunchKernelGGL((k_dgemm<V2, RD, 4>), grid1, dim3(256), 0, st, g); break;                   \
+      case 5: hipLaunchKernelGGL((k_dgemm<V2, RD, 5>), grid1, dim3(320), 0, st, g); break;                   \
+      default: hipLaunchKernelGGL((k_dgemm<V2, RD, 6>), grid1, dim3(384), 0, st, g); break;                  \
+    }                                                                                                        \
+  } while (0)
         if (N % 2 == 0) { if (rd.nq) MOMD_GO(true, true); else MOMD_GO(true, false); }
         else { if (rd.nq) MOMD_GO(false, true); else MOMD_GO(false, false); }
 #undef MOMD_GO
