@@ -69,10 +69,11 @@ def compare(model, P=2, seed=0, with_Z=True, workspace_mb=0, rtol=None):
     return R, T, dR, dT
 
 
-@pytest.mark.parametrize("nS,ltr,Nz,S", [(1, 3, 3, 9), (3, 5, 4, 7), (4, 5, 3, 5), (3, 13, 3, 6), (3, 21, 3, 4), (1, 40, 2, 3), (1, 130, 2, 2)])
+@pytest.mark.parametrize("nS,ltr,Nz,S", [(1, 3, 3, 9), (3, 5, 4, 7), (4, 5, 3, 5), (3, 13, 3, 6), (3, 21, 3, 4), (1, 40, 2, 3), (1, 75, 2, 3), (1, 130, 2, 2)])
 def test_dual_run_matches_the_dual_oracle(nS, ltr, Nz, S):
-    """Scalar / IQU / IQUV, edges 4 .. 68: every kernel form (wavefront per item on 1 x 1, 2 x 2, 3 x 3 tiles up to edge 48, workgroup
-    tiles above; wavefront / workgroup inverse, the two-block inverse above 64), aerosol + absorption, all three moments."""
+    """Scalar / IQU / IQUV, edges 5 .. 68: every kernel form (wavefront per item up to edge 16; workgroup tiles of 32, 48, 64, 80 -- 96 in
+    test_dual_six_wave_tile --, even and odd edges = 16-byte and 8-byte staging; wavefront / workgroup / two-block inverse), aerosol +
+    absorption, all three moments."""
     compare(rtamd.scenes.make_scene(nS, ltr, Nz, S, seed=3 + nS, aerosol_total=0.2), P=2, seed=ltr)
 
 
